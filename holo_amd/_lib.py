@@ -1,0 +1,79 @@
+"""ctypes binding of libholo_spf_hip.so (include/holo_spf_hip.h).
+
+Fails loudly: there is no Python / CPU fallback for the SPF engine.  If the shared library is
+missing or a symbol is absent, importing callers get an exception, not a slow path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libholo_spf_hip.so")
+
+u8p = ctypes.POINTER(ctypes.c_uint8)
+u16p = ctypes.POINTER(ctypes.c_uint16)
+u32p = ctypes.POINTER(ctypes.c_uint32)
+u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class HspfCsr(ctypes.Structure):
+    _fields_ = [("n_vertices", ctypes.c_uint32), ("n_edges", ctypes.c_uint32),
+                ("row_ptr", u32p), ("col", u32p), ("metric", u32p), ("vflags", u8p),
+                ("max_path_metric", ctypes.c_uint32)]
+
+
+class HspfResult(ctypes.Structure):
+    _fields_ = [("dist", ctypes.c_void_p), ("hops", ctypes.c_void_p), ("vflags_out", ctypes.c_void_p),
+                ("first_hop_mask", ctypes.c_void_p), ("n_mask_words", ctypes.c_uint32),
+                ("pop_rank", ctypes.c_void_p)]
+
+
+class HspfStats(ctypes.Structure):
+    _fields_ = [("n_roots", ctypes.c_uint32), ("n_batches", ctypes.c_uint32),
+                ("n_relax_launches", ctypes.c_uint32), ("n_dag_launches", ctypes.c_uint32),
+                ("n_exact_roots", ctypes.c_uint32), ("n_mask_words", ctypes.c_uint32),
+                ("ms_total", ctypes.c_float), ("ms_relax", ctypes.c_float), ("ms_dag", ctypes.c_float),
+                ("ms_finish", ctypes.c_float), ("ms_d2h", ctypes.c_float)]
+
+
+# every symbol include/holo_spf_hip.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("hspf_abi_version", ctypes.c_uint32, []),
+    ("hspf_device_count", ctypes.c_int, []),
+    ("hspf_init", ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    ("hspf_shutdown", None, [ctypes.c_void_p]),
+    ("hspf_strerror", ctypes.c_char_p, [ctypes.c_int]),
+    ("hspf_last_error", ctypes.c_char_p, [ctypes.c_void_p]),
+    ("hspf_set_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("hspf_get_stream", ctypes.c_void_p, [ctypes.c_void_p]),
+    ("hspf_graph_upload", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(HspfCsr), ctypes.POINTER(ctypes.c_void_p)]),
+    ("hspf_graph_free", None, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("hspf_graph_n_vertices", ctypes.c_uint32, [ctypes.c_void_p]),
+    ("hspf_graph_n_edges_kept", ctypes.c_uint32, [ctypes.c_void_p]),
+    ("hspf_mask_words", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, u32p]),
+    ("hspf_slot_table", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, u32p]),
+    ("hspf_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(HspfResult)]),
+    ("hspf_run_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(HspfResult)]),
+    ("hspf_get_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(HspfStats)]),
+]
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m holo_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the SPF engine.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib

@@ -1,0 +1,618 @@
+// spf_capi.hip — host side of libholo_spf_hip.so: the C ABI of include/holo_spf_hip.h.
+//
+// Replaces, at function granularity, the SPT loops of
+//   holo-ospf/src/spf.rs:587-729 (run_area) and holo-isis/src/spf.rs:527-709 (compute_spt);
+// the batched caller is holo-isis/src/flooding/manet.rs:47-69.  No CPU fallback lives here: if
+// there is no HIP device, hspf_init fails and the caller keeps its own loop.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared spf_capi.hip -o libholo_spf_hip.so
+#include "../../include/holo_spf_hip.h"
+#include "spf_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace hspf;
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct hspf_graph {
+  uint32_t n = 0, e = 0, e_kept = 0;
+  uint32_t max_path_metric = 0;
+  // host copies (slot tables, validation)
+  std::vector<uint32_t> row_ptr, col;
+  std::vector<uint8_t> twoway;     // per original link
+  std::vector<uint8_t> vflags;
+  // device
+  uint32_t *d_in_ptr = nullptr, *d_in_src = nullptr, *d_in_w = nullptr, *d_in_fpos = nullptr;
+  uint32_t *d_out_ptr = nullptr, *d_out_dst = nullptr, *d_out_w = nullptr, *d_out_fpos = nullptr;
+  uint8_t *d_vflags = nullptr;
+  GraphDev dev() const {
+    GraphDev g;
+    g.n = n; g.e_in = e_kept;
+    g.in_ptr = d_in_ptr; g.in_src = d_in_src; g.in_w = d_in_w; g.in_fpos = d_in_fpos;
+    g.vflags = d_vflags;
+    g.out_ptr = d_out_ptr; g.out_dst = d_out_dst; g.out_w = d_out_w; g.out_fpos = d_out_fpos;
+    return g;
+  }
+};
+
+struct hspf_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  std::string last_error;
+  hipEvent_t ev[6] = {};
+  // scratch (grown on demand, reused across runs)
+  DevBuf dist, hv, mask, roots, lane_flags, changed, tab_ptr, tab_vtx, tab_base;
+  DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
+  DevBuf ex_list, ex_heap, ex_pos;
+  int *h_changed = nullptr;        // pinned
+  uint32_t *h_lane_flags = nullptr; // pinned
+  size_t h_lane_cap = 0;
+  uint32_t est_relax = 12, est_dag = 12;   // launch-ahead estimates (adapted run to run)
+  hspf_stats stats = {};
+};
+
+namespace {
+
+constexpr uint32_t CHANGED_CAP = 1u << 20;   // max launches per phase
+
+#define HIPCHK(ctx, call)                                                          \
+  do {                                                                             \
+    hipError_t _e = (call);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(_e);       \
+      return _e == hipErrorOutOfMemory ? HSPF_E_NOMEM : HSPF_E_HIP;                \
+    }                                                                              \
+  } while (0)
+
+int ensure(hspf_ctx *ctx, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return HSPF_OK;
+  if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+  size_t want = bytes + bytes / 8;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    want = bytes;
+    e = hipMalloc(&b.p, want);
+  }
+  if (e != hipSuccess) {
+    ctx->last_error = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+    b.p = nullptr; b.cap = 0;
+    return HSPF_E_NOMEM;
+  }
+  b.cap = want;
+  return HSPF_OK;
+}
+
+void release(DevBuf &b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+// Slot table of one root (include/holo_spf_hip.h): H = [root] ++ BFS over network vertices
+// reachable through network vertices only, links in row order, two-way links only.
+void build_slot_table(const hspf_graph *g, uint32_t root, std::vector<uint32_t> &hv,
+                      std::vector<uint32_t> &hb, uint32_t &total, std::vector<uint32_t> &mark,
+                      uint32_t stamp) {
+  hv.clear(); hb.clear();
+  hv.push_back(root); hb.push_back(0);
+  total = g->row_ptr[root + 1] - g->row_ptr[root];
+  mark[root] = stamp;
+  for (size_t qi = 0; qi < hv.size(); ++qi) {
+    const uint32_t p = hv[qi];
+    for (uint32_t k = g->row_ptr[p]; k < g->row_ptr[p + 1]; ++k) {
+      const uint32_t t = g->col[k];
+      if (!g->twoway[k] || !(g->vflags[t] & HSPF_VF_NETWORK) || mark[t] == stamp) continue;
+      mark[t] = stamp;
+      hv.push_back(t); hb.push_back(total);
+      total += g->row_ptr[t + 1] - g->row_ptr[t];
+    }
+  }
+}
+
+uint32_t round_words(uint32_t w) {   // template instantiations of k_dag / k_emit
+  if (w <= 1) return 1;
+  if (w <= 2) return 2;
+  if (w <= 4) return 4;
+  if (w <= 8) return 8;
+  return 16;
+}
+
+template <int W>
+void launch_dag(dim3 grid, hipStream_t s, GraphDev g, const uint32_t *dist, uint32_t *hv, uint64_t *mask,
+                const uint32_t *roots, SlotTabs tabs, uint32_t nn, uint32_t io, int *changed, int sweep,
+                uint32_t epoch, uint32_t *lf) {
+  hipLaunchKernelGGL((k_dag<W>), grid, dim3(256), 0, s, g, dist, hv, mask, roots, tabs, nn, io, changed,
+                     sweep, epoch, lf);
+}
+template <int W>
+void launch_emit(dim3 grid, hipStream_t s, uint32_t n, uint32_t nr, const uint32_t *dist, const uint32_t *hv,
+                 const uint64_t *mask, OutDev o) {
+  hipLaunchKernelGGL((k_emit<W>), grid, dim3(256), 0, s, n, nr, dist, hv, mask, o);
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t hspf_abi_version(void) { return HSPF_ABI_VERSION; }
+
+int hspf_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return e == hipErrorNoDevice ? 0 : HSPF_E_HIP;
+  return n;
+}
+
+const char *hspf_strerror(int code) {
+  switch (code) {
+    case HSPF_OK: return "ok";
+    case HSPF_E_INVAL: return "invalid argument";
+    case HSPF_E_NODEV: return "no usable HIP device";
+    case HSPF_E_HIP: return "HIP runtime error";
+    case HSPF_E_NOMEM: return "out of memory";
+    case HSPF_E_TOO_MANY_SLOTS: return "too many first-hop slots for n_mask_words";
+    case HSPF_E_INTERNAL: return "internal invariant violated";
+    default: return "unknown error";
+  }
+}
+
+const char *hspf_last_error(const hspf_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int hspf_init(int device_ordinal, hspf_ctx **out) {
+  if (!out) return HSPF_E_INVAL;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return HSPF_E_NODEV;
+  if (device_ordinal < 0 || device_ordinal >= n) return HSPF_E_NODEV;
+  hspf_ctx *ctx = new (std::nothrow) hspf_ctx();
+  if (!ctx) return HSPF_E_NOMEM;
+  ctx->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return HSPF_E_NODEV; }
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
+  for (auto &e : ctx->ev)
+    if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
+  if (hipHostMalloc((void **)&ctx->h_changed, sizeof(int) * 4, hipHostMallocDefault) != hipSuccess) { delete ctx; return HSPF_E_NOMEM; }
+  *out = ctx;
+  return HSPF_OK;
+}
+
+void hspf_shutdown(hspf_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->roots, &ctx->lane_flags, &ctx->changed,
+                    &ctx->tab_ptr, &ctx->tab_vtx, &ctx->tab_base, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos})
+    release(*b);
+  if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
+  if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
+  for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int hspf_set_stream(hspf_ctx *ctx, void *hip_stream) {
+  if (!ctx) return HSPF_E_INVAL;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+  ctx->stream = (hipStream_t)hip_stream;
+  ctx->own_stream = false;
+  return HSPF_OK;
+}
+
+void *hspf_get_stream(const hspf_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---- graph ------------------------------------------------------------------------------------
+
+int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
+  if (!ctx || !csr || !out) return HSPF_E_INVAL;
+  *out = nullptr;
+  const uint32_t n = csr->n_vertices, e = csr->n_edges;
+  if (n == 0 || n >= 0x7FFFFFFFu || !csr->row_ptr || !csr->vflags || (e && (!csr->col || !csr->metric))) {
+    ctx->last_error = "hspf_graph_upload: malformed hspf_csr";
+    return HSPF_E_INVAL;
+  }
+  if (csr->row_ptr[0] != 0 || csr->row_ptr[n] != e) { ctx->last_error = "row_ptr[0]!=0 or row_ptr[n]!=n_edges"; return HSPF_E_INVAL; }
+  for (uint32_t u = 0; u < n; ++u)
+    if (csr->row_ptr[u + 1] < csr->row_ptr[u]) { ctx->last_error = "row_ptr not monotone"; return HSPF_E_INVAL; }
+  for (uint32_t k = 0; k < e; ++k)
+    if (csr->col[k] >= n) { ctx->last_error = "col out of range"; return HSPF_E_INVAL; }
+  (void)hipSetDevice(ctx->device);
+
+  hspf_graph *g = new (std::nothrow) hspf_graph();
+  if (!g) return HSPF_E_NOMEM;
+  g->n = n; g->e = e; g->max_path_metric = csr->max_path_metric;
+  try {
+    g->row_ptr.assign(csr->row_ptr, csr->row_ptr + n + 1);
+    g->col.assign(csr->col, csr->col + e);
+    g->vflags.assign(csr->vflags, csr->vflags + n);
+    g->twoway.assign(e, 0);
+    // Two-way connectivity check, once per LSDB generation instead of once per link visit
+    // (holo-ospf/src/spf.rs:654-664, holo-isis/src/spf.rs:616-627): link u->t is usable iff row t
+    // lists u (cost not compared).  Sort-free: mark the targets of row t, probe with row t's
+    // sources.  O(E * avg-degree) worst case is avoided by marking per target row.
+    {
+      // For each t, mark[col[k']] = t for k' in row t; then u->t two-way iff mark'[u]==t.  We
+      // need the reverse view: iterate rows t, stamp their targets; link (u->t) asks "does row t
+      // contain u".  Process links grouped by target using a counting sort of link ids by target.
+      std::vector<uint32_t> cnt(n + 1, 0);
+      for (uint32_t k = 0; k < e; ++k) cnt[csr->col[k] + 1]++;
+      for (uint32_t i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
+      std::vector<uint32_t> by_t(e), src_of(e);
+      {
+        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+        for (uint32_t u = 0; u < n; ++u)
+          for (uint32_t k = csr->row_ptr[u]; k < csr->row_ptr[u + 1]; ++k) { src_of[k] = u; by_t[cur[csr->col[k]]++] = k; }
+      }
+      std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
+      for (uint32_t t = 0; t < n; ++t) {
+        if (cnt[t] == cnt[t + 1]) continue;
+        for (uint32_t k2 = csr->row_ptr[t]; k2 < csr->row_ptr[t + 1]; ++k2) stamp[csr->col[k2]] = t;
+        for (uint32_t i = cnt[t]; i < cnt[t + 1]; ++i) { const uint32_t k = by_t[i]; g->twoway[k] = stamp[src_of[k]] == t; }
+      }
+      // Kept links: two-way AND the source can ever be expanded.  Transposed (in-link) CSR by a
+      // counting sort that keeps source order -> deterministic layout.
+      std::vector<uint32_t> in_ptr(n + 1, 0), out_ptr(n + 1, 0);
+      uint32_t kept = 0;
+      for (uint32_t k = 0; k < e; ++k) {
+        const bool keep = g->twoway[k] && !(csr->vflags[src_of[k]] & HSPF_VF_NO_EXPAND);
+        if (keep) { in_ptr[csr->col[k] + 1]++; out_ptr[src_of[k] + 1]++; ++kept; }
+      }
+      for (uint32_t i = 0; i < n; ++i) { in_ptr[i + 1] += in_ptr[i]; out_ptr[i + 1] += out_ptr[i]; }
+      g->e_kept = kept;
+      std::vector<uint32_t> in_src(kept), in_w(kept), in_fpos(kept), out_dst(kept), out_w(kept), out_fpos(kept);
+      std::vector<uint32_t> cur(in_ptr.begin(), in_ptr.end() - 1);
+      uint32_t oi = 0;
+      for (uint32_t u = 0; u < n; ++u) {
+        const bool nt = csr->vflags[u] & HSPF_VF_NO_TRANSIT;
+        const bool ne = csr->vflags[u] & HSPF_VF_NO_EXPAND;
+        for (uint32_t k = csr->row_ptr[u]; k < csr->row_ptr[u + 1]; ++k) {
+          if (!g->twoway[k] || ne) continue;
+          const uint32_t t = csr->col[k], i = cur[t]++;
+          in_src[i] = u | (nt ? SRC_NO_TRANSIT : 0u);
+          in_w[i] = csr->metric[k];
+          in_fpos[i] = k - csr->row_ptr[u];
+          out_dst[oi] = t; out_w[oi] = csr->metric[k]; out_fpos[oi] = k - csr->row_ptr[u]; ++oi;
+        }
+      }
+      auto up = [&](uint32_t **d, const std::vector<uint32_t> &h) -> hipError_t {
+        const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(uint32_t);
+        hipError_t er = hipMalloc((void **)d, bytes);
+        if (er != hipSuccess) return er;
+        if (!h.empty()) er = hipMemcpy(*d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        return er;
+      };
+      hipError_t er = hipSuccess;
+      if (er == hipSuccess) er = up(&g->d_in_ptr, in_ptr);
+      if (er == hipSuccess) er = up(&g->d_in_src, in_src);
+      if (er == hipSuccess) er = up(&g->d_in_w, in_w);
+      if (er == hipSuccess) er = up(&g->d_in_fpos, in_fpos);
+      if (er == hipSuccess) er = up(&g->d_out_ptr, out_ptr);
+      if (er == hipSuccess) er = up(&g->d_out_dst, out_dst);
+      if (er == hipSuccess) er = up(&g->d_out_w, out_w);
+      if (er == hipSuccess) er = up(&g->d_out_fpos, out_fpos);
+      if (er == hipSuccess) er = hipMalloc((void **)&g->d_vflags, n);
+      if (er == hipSuccess) er = hipMemcpy(g->d_vflags, csr->vflags, n, hipMemcpyHostToDevice);
+      if (er != hipSuccess) {
+        ctx->last_error = std::string("graph upload: ") + hipGetErrorString(er);
+        hspf_graph_free(ctx, g);
+        return er == hipErrorOutOfMemory ? HSPF_E_NOMEM : HSPF_E_HIP;
+      }
+    }
+  } catch (const std::bad_alloc &) {
+    hspf_graph_free(ctx, g);
+    return HSPF_E_NOMEM;
+  }
+  *out = g;
+  return HSPF_OK;
+}
+
+void hspf_graph_free(hspf_ctx *ctx, hspf_graph *g) {
+  if (!g) return;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  for (uint32_t *p : {g->d_in_ptr, g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_ptr, g->d_out_dst, g->d_out_w, g->d_out_fpos})
+    if (p) (void)hipFree(p);
+  if (g->d_vflags) (void)hipFree(g->d_vflags);
+  delete g;
+}
+
+uint32_t hspf_graph_n_vertices(const hspf_graph *g) { return g ? g->n : 0; }
+uint32_t hspf_graph_n_edges_kept(const hspf_graph *g) { return g ? g->e_kept : 0; }
+
+// ---- slots ------------------------------------------------------------------------------------
+
+int hspf_mask_words(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t *out_words) {
+  if (!ctx || !g || !roots || !out_words) return HSPF_E_INVAL;
+  std::vector<uint32_t> hv, hb, mark(g->n, 0xFFFFFFFFu);
+  uint32_t w = 1;
+  for (uint32_t r = 0; r < n_roots; ++r) {
+    if (roots[r] == HSPF_NO_ROOT) continue;
+    if (roots[r] >= g->n) return HSPF_E_INVAL;
+    uint32_t total = 0;
+    build_slot_table(g, roots[r], hv, hb, total, mark, r);
+    w = std::max(w, (total + 63) / 64);
+  }
+  *out_words = w;
+  return HSPF_OK;
+}
+
+int hspf_slot_table(hspf_ctx *ctx, const hspf_graph *g, uint32_t root, uint32_t *h_vertex, uint32_t *h_base,
+                    uint32_t cap, uint32_t *out_total_slots) {
+  if (!ctx || !g || root >= g->n) return HSPF_E_INVAL;
+  std::vector<uint32_t> hv, hb, mark(g->n, 0xFFFFFFFFu);
+  uint32_t total = 0;
+  build_slot_table(g, root, hv, hb, total, mark, 0);
+  for (uint32_t i = 0; i < hv.size() && i < cap; ++i) {
+    if (h_vertex) h_vertex[i] = hv[i];
+    if (h_base) h_base[i] = hb[i];
+  }
+  if (out_total_slots) *out_total_slots = total;
+  return (int)hv.size();
+}
+
+// ---- run --------------------------------------------------------------------------------------
+
+static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                    hspf_result *out, bool host_out) {
+  if (!ctx || !g || !roots || !out || n_roots == 0 || !out->dist) return HSPF_E_INVAL;
+  (void)hipSetDevice(ctx->device);
+  const uint32_t n = g->n;
+  for (uint32_t r = 0; r < n_roots; ++r)
+    if (roots[r] != HSPF_NO_ROOT && roots[r] >= n) { ctx->last_error = "root out of range"; return HSPF_E_INVAL; }
+  if ((run_flags & HSPF_RUN_POP_RANK) && !out->pop_rank) { ctx->last_error = "HSPF_RUN_POP_RANK without pop_rank buffer"; return HSPF_E_INVAL; }
+  const uint32_t B = (n_roots + 63) / 64, L = B * 64;
+  hipStream_t s = ctx->stream;
+  hspf_stats &st = ctx->stats;
+  st = hspf_stats{};
+  st.n_roots = n_roots; st.n_batches = B;
+
+  // ---- slot tables (host, O(deg) per root) and mask width
+  std::vector<uint32_t> tab_ptr(L + 1, 0), tab_vtx, tab_base;
+  uint32_t need_words = 1;
+  {
+    std::vector<uint32_t> hv, hb, mark(n, 0xFFFFFFFFu);
+    for (uint32_t r = 0; r < L; ++r) {
+      if (r < n_roots && roots[r] != HSPF_NO_ROOT) {
+        uint32_t total = 0;
+        build_slot_table(g, roots[r], hv, hb, total, mark, r);
+        need_words = std::max(need_words, (total + 63) / 64);
+        // entry 0 (the root itself, base 0) is implicit on device
+        tab_vtx.insert(tab_vtx.end(), hv.begin() + 1, hv.end());
+        tab_base.insert(tab_base.end(), hb.begin() + 1, hb.end());
+      }
+      tab_ptr[r + 1] = (uint32_t)tab_vtx.size();
+    }
+  }
+  const bool want_mask = out->first_hop_mask != nullptr;
+  if (want_mask && out->n_mask_words < need_words) {
+    ctx->last_error = "n_mask_words too small: need " + std::to_string(need_words);
+    return HSPF_E_TOO_MANY_SLOTS;
+  }
+  if (need_words > 16) { ctx->last_error = "more than 1024 first-hop slots"; return HSPF_E_TOO_MANY_SLOTS; }
+  const uint32_t W = round_words(need_words);
+  const uint32_t out_words = want_mask ? out->n_mask_words : W;
+  st.n_mask_words = need_words;
+
+  // ---- scratch
+  int rc;
+  const size_t rows = (size_t)B * n * 64;
+  if ((rc = ensure(ctx, ctx->dist, rows * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->hv, rows * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->mask, rows * 8 * W))) return rc;
+  if ((rc = ensure(ctx, ctx->roots, (size_t)L * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->lane_flags, (size_t)L * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->changed, (size_t)CHANGED_CAP * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->tab_ptr, (size_t)(L + 1) * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->tab_vtx, std::max<size_t>(tab_vtx.size(), 1) * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->tab_base, std::max<size_t>(tab_base.size(), 1) * 4))) return rc;
+  if (ctx->h_lane_cap < L) {
+    if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
+    ctx->h_lane_flags = nullptr; ctx->h_lane_cap = 0;
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lane_flags, (size_t)L * 4, hipHostMallocDefault));
+    ctx->h_lane_cap = L;
+  }
+  // row-major output targets (device): the caller's device buffers, or staging for host output
+  OutDev od{};
+  const size_t rn = (size_t)n_roots * n;
+  uint32_t *d_rank = nullptr;
+  if (host_out) {
+    if ((rc = ensure(ctx, ctx->o_dist, rn * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->o_hops, rn * 2))) return rc;
+    if ((rc = ensure(ctx, ctx->o_flags, rn * 2))) return rc;
+    if ((rc = ensure(ctx, ctx->o_mask, rn * 8 * out_words))) return rc;
+    od.dist = (uint32_t *)ctx->o_dist.p; od.hops = (uint16_t *)ctx->o_hops.p; od.flags = (uint16_t *)ctx->o_flags.p;
+    od.mask = (uint64_t *)ctx->o_mask.p; od.out_words = out_words;
+    if (run_flags & HSPF_RUN_POP_RANK) { if ((rc = ensure(ctx, ctx->o_rank, rn * 4))) return rc; d_rank = (uint32_t *)ctx->o_rank.p; }
+  } else {
+    od.dist = out->dist; od.hops = out->hops; od.flags = out->vflags_out; od.mask = out->first_hop_mask; od.out_words = out_words;
+    if (run_flags & HSPF_RUN_POP_RANK) d_rank = out->pop_rank;
+  }
+
+  uint32_t *d_dist = (uint32_t *)ctx->dist.p, *d_hv = (uint32_t *)ctx->hv.p, *d_roots = (uint32_t *)ctx->roots.p;
+  uint64_t *d_mask = (uint64_t *)ctx->mask.p;
+  uint32_t *d_lf = (uint32_t *)ctx->lane_flags.p;
+  int *d_changed = (int *)ctx->changed.p;
+  const GraphDev gd = g->dev();
+  const SlotTabs tabs{(const uint32_t *)ctx->tab_ptr.p, (const uint32_t *)ctx->tab_vtx.p, (const uint32_t *)ctx->tab_base.p};
+  const uint32_t ignore_ovl = (run_flags & HSPF_RUN_IGNORE_OVERLOAD) ? 1u : 0u;
+  const uint32_t net_nh = (run_flags & HSPF_RUN_NET_NEXTHOPS) ? 1u : 0u;
+
+  // ---- upload roots / slot tables, init state
+  {
+    std::vector<uint32_t> rl(L, HSPF_NO_ROOT);
+    std::copy(roots, roots + n_roots, rl.begin());
+    HIPCHK(ctx, hipMemcpyAsync(d_roots, rl.data(), (size_t)L * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->tab_ptr.p, tab_ptr.data(), (size_t)(L + 1) * 4, hipMemcpyHostToDevice, s));
+    if (!tab_vtx.empty()) {
+      HIPCHK(ctx, hipMemcpyAsync(ctx->tab_vtx.p, tab_vtx.data(), tab_vtx.size() * 4, hipMemcpyHostToDevice, s));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->tab_base.p, tab_base.data(), tab_base.size() * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(s));   // rl / tab_* are stack vectors
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
+  HIPCHK(ctx, hipMemsetAsync(d_dist, 0xFF, rows * 4, s));
+  HIPCHK(ctx, hipMemsetAsync(d_hv, 0, rows * 4, s));
+  HIPCHK(ctx, hipMemsetAsync(d_lf, 0, (size_t)L * 4, s));
+  hipLaunchKernelGGL(k_init_roots, dim3((L + 255) / 256), dim3(256), 0, s, n, d_dist, d_roots, L);
+
+  const uint32_t vblocks = (n + VPB - 1) / VPB;
+  const dim3 grid(((vblocks + 7) / 8) * 8, B);
+
+  // ---- phase 1: distances.  Launch ahead `est` sweeps (each launch exits at once when the
+  // previous one changed nothing), then read ONE flag back; repeat in small chunks if needed.
+  auto run_phase = [&](uint32_t est, auto &&launch, uint32_t &n_launch) -> int {
+    hipError_t er = hipMemsetAsync(d_changed, 0, (size_t)std::min<uint32_t>(CHANGED_CAP, est + 4096) * 4, s);
+    if (er != hipSuccess) { ctx->last_error = hipGetErrorString(er); return HSPF_E_HIP; }
+    uint32_t zeroed = std::min<uint32_t>(CHANGED_CAP, est + 4096);
+    uint32_t sweep = 0, chunk = std::max(2u, est);
+    for (;;) {
+      if (sweep + chunk > zeroed) {
+        if (sweep + chunk > CHANGED_CAP) { ctx->last_error = "phase did not converge within launch cap"; return HSPF_E_INTERNAL; }
+        const uint32_t upto = std::min<uint32_t>(CHANGED_CAP, sweep + chunk + 4096);
+        er = hipMemsetAsync(d_changed + zeroed, 0, (size_t)(upto - zeroed) * 4, s);
+        if (er != hipSuccess) { ctx->last_error = hipGetErrorString(er); return HSPF_E_HIP; }
+        zeroed = upto;
+      }
+      for (uint32_t i = 0; i < chunk; ++i) launch(sweep + i);
+      sweep += chunk;
+      er = hipMemcpyAsync(ctx->h_changed, d_changed + (sweep - 1), sizeof(int), hipMemcpyDeviceToHost, s);
+      if (er == hipSuccess) er = hipStreamSynchronize(s);
+      if (er != hipSuccess) { ctx->last_error = std::string("phase: ") + hipGetErrorString(er); return HSPF_E_HIP; }
+      if (ctx->h_changed[0] == 0) break;
+      chunk = 4;
+    }
+    // count the launches that did work (for stats and the next estimate)
+    std::vector<int> ch(sweep);
+    er = hipMemcpy(ch.data(), d_changed, (size_t)sweep * 4, hipMemcpyDeviceToHost);
+    if (er != hipSuccess) { ctx->last_error = hipGetErrorString(er); return HSPF_E_HIP; }
+    uint32_t active = 0;
+    while (active < sweep && ch[active]) ++active;
+    n_launch = active + 1;   // the launch that found the fixed point did a full pass too
+    return HSPF_OK;
+  };
+
+  HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
+  uint32_t n_relax = 0;
+  rc = run_phase(ctx->est_relax, [&](uint32_t sweep) {
+    hipLaunchKernelGGL(k_relax, grid, dim3(256), 0, s, gd, d_dist, d_roots, g->max_path_metric, ignore_ovl, d_changed, (int)sweep, d_lf);
+  }, n_relax);
+  if (rc) return rc;
+  ctx->est_relax = n_relax + 1;
+  st.n_relax_launches = n_relax;
+  HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
+
+  // ---- phase 2: hops + first-hop masks over the tight-edge DAG
+  HIPCHK(ctx, hipMemsetAsync(d_mask, 0, rows * 8 * W, s));
+  uint32_t n_dag = 0;
+  uint32_t epoch = 1;
+  rc = run_phase(ctx->est_dag, [&](uint32_t sweep) {
+    if (epoch >= HV_EPOCH_MAX) {
+      hipLaunchKernelGGL(k_rebase, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_hv, rows);
+      epoch = 2;
+    }
+    switch (W) {
+      case 1: launch_dag<1>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
+      case 2: launch_dag<2>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
+      case 4: launch_dag<4>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
+      case 8: launch_dag<8>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
+      default: launch_dag<16>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
+    }
+    ++epoch;
+  }, n_dag);
+  if (rc) return rc;
+  ctx->est_dag = n_dag + 1;
+  st.n_dag_launches = n_dag;
+  HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
+
+  // ---- emit row-major results
+  {
+    const dim3 egrid((n + 63) / 64, B);
+    switch (W) {
+      case 1: launch_emit<1>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
+      case 2: launch_emit<2>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
+      case 4: launch_emit<4>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
+      case 8: launch_emit<8>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
+      default: launch_emit<16>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
+    }
+  }
+
+  // ---- roots whose pop order is dynamic (or forced): sequential exact kernel
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  std::vector<uint32_t> ex;
+  for (uint32_t r = 0; r < n_roots; ++r) {
+    const bool forced = (run_flags & (HSPF_RUN_FORCE_EXACT | HSPF_RUN_POP_RANK)) != 0;
+    if (roots[r] != HSPF_NO_ROOT && (forced || (ctx->h_lane_flags[r] & LF_NEED_EXACT))) ex.push_back(r);
+  }
+  st.n_exact_roots = (uint32_t)ex.size();
+  if (!ex.empty()) {
+    // k_exact needs all four result arrays; use staging for the ones the caller skipped.
+    ExactArgs a{};
+    a.g = gd; a.roots = d_roots; a.n_exact = (uint32_t)ex.size();
+    a.maxpath = g->max_path_metric; a.net_nexthops = net_nh; a.ignore_ovl = ignore_ovl; a.tabs = tabs;
+    a.dist = od.dist; a.hops = od.hops; a.flags = od.flags; a.mask = od.mask; a.words = out_words; a.pop_rank = d_rank;
+    if (!a.hops) { if ((rc = ensure(ctx, ctx->o_hops, rn * 2))) return rc; a.hops = (uint16_t *)ctx->o_hops.p; }
+    if (!a.flags) { if ((rc = ensure(ctx, ctx->o_flags, rn * 2))) return rc; a.flags = (uint16_t *)ctx->o_flags.p; }
+    if (!a.mask) { if ((rc = ensure(ctx, ctx->o_mask, rn * 8 * out_words))) return rc; a.mask = (uint64_t *)ctx->o_mask.p; }
+    if ((rc = ensure(ctx, ctx->ex_list, ex.size() * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->ex_heap, ex.size() * (size_t)n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->ex_pos, ex.size() * (size_t)n * 4))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ex_list.p, ex.data(), ex.size() * 4, hipMemcpyHostToDevice, s));
+    a.root_list = (const uint32_t *)ctx->ex_list.p;
+    a.heap = (uint32_t *)ctx->ex_heap.p; a.pos = (uint32_t *)ctx->ex_pos.p;
+    hipLaunchKernelGGL(k_exact, dim3((a.n_exact + 63) / 64), dim3(64), 0, s, a);
+  }
+  if ((run_flags & HSPF_RUN_POP_RANK) && d_rank) {
+    // pop_rank of padding roots
+    for (uint32_t r = 0; r < n_roots; ++r)
+      if (roots[r] == HSPF_NO_ROOT) HIPCHK(ctx, hipMemsetAsync(d_rank + (size_t)r * n, 0xFF, (size_t)n * 4, s));
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
+
+  // ---- results to the caller
+  if (host_out) {
+    HIPCHK(ctx, hipMemcpyAsync(out->dist, od.dist, rn * 4, hipMemcpyDeviceToHost, s));
+    if (out->hops) HIPCHK(ctx, hipMemcpyAsync(out->hops, od.hops, rn * 2, hipMemcpyDeviceToHost, s));
+    if (out->vflags_out) HIPCHK(ctx, hipMemcpyAsync(out->vflags_out, od.flags, rn * 2, hipMemcpyDeviceToHost, s));
+    if (out->first_hop_mask) HIPCHK(ctx, hipMemcpyAsync(out->first_hop_mask, od.mask, rn * 8 * out_words, hipMemcpyDeviceToHost, s));
+    if ((run_flags & HSPF_RUN_POP_RANK) && out->pop_rank) HIPCHK(ctx, hipMemcpyAsync(out->pop_rank, d_rank, rn * 4, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  {
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { ctx->last_error = std::string("kernel launch: ") + hipGetErrorString(le); return HSPF_E_HIP; }
+  }
+  (void)hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[4]);
+  (void)hipEventElapsedTime(&st.ms_relax, ctx->ev[1], ctx->ev[2]);
+  (void)hipEventElapsedTime(&st.ms_dag, ctx->ev[2], ctx->ev[3]);
+  (void)hipEventElapsedTime(&st.ms_finish, ctx->ev[3], ctx->ev[4]);
+  (void)hipEventElapsedTime(&st.ms_d2h, ctx->ev[4], ctx->ev[5]);
+  return HSPF_OK;
+}
+
+int hspf_run(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags, hspf_result *out) {
+  return run_impl(ctx, g, roots, n_roots, run_flags, out, true);
+}
+
+int hspf_run_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags, hspf_result *out_device) {
+  return run_impl(ctx, g, roots, n_roots, run_flags, out_device, false);
+}
+
+int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out) {
+  if (!ctx || !out) return HSPF_E_INVAL;
+  *out = ctx->stats;
+  return HSPF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,417 @@
+// spf_kernels.hip.h — gfx950 (CDNA4) kernels of the batched SPF engine.
+//
+// Layout ("lane = root"): one wavefront carries 64 SPF roots of the same graph.  All per-run
+// state is [batch][vertex][64 lanes], so the 64 roots' values of one vertex are one 256-byte row:
+// every access to a neighbour's state is a single fully coalesced wave load, the link record
+// (source, cost) is wave-uniform and comes through the scalar cache, and no atomics are needed
+// because the wave that owns vertex v is the only writer of row v (pull / in-edge formulation).
+// No MFMA: this is an irregular integer path bound by cache / HBM bandwidth.
+//
+// Semantics restated on device (see include/holo_spf_hip.h for the reference file:line map):
+//   k_relax   label-correcting fixed point of   dist[v] = min over in-links (u,w) of dist[u] (+) w
+//             under the reference's gates (holo-isis/src/spf.rs:557-604, 637-647).
+//   k_dag     hops (first-discoverer rule, holo-ospf/src/spf.rs:700-703 / holo-isis :674-676) and
+//             the ECMP first-hop set (holo-ospf/src/spf.rs:733-767, holo-isis/src/spf.rs:680-704)
+//             over the tight-edge DAG, valid when the reference's pop order equals the static
+//             (distance, vertex) order; every root for which that is not provable is flagged and
+//             re-done by k_exact.
+//   k_exact   one lane = one root, literal sequential restatement of the reference loop with a
+//             binary heap in HBM (slow; only for roots with zero-cost plateaus that make the pop
+//             order dynamic, or u32 saturation).
+//   k_emit    LDS-tiled transpose of the lane-major state into the row-major [root][vertex]
+//             result arrays of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hspf {
+
+constexpr uint32_t INF = 0xFFFFFFFFu;
+constexpr uint32_t SRC_NO_TRANSIT = 0x80000000u;   // bit31 of in_src: source has the overload bit
+constexpr uint32_t SRC_MASK = 0x7FFFFFFFu;
+
+// hv word: [15:0] hops, [31:16] epoch.  epoch == 0: not final yet; epoch == e: became final in the
+// DAG launch with epoch e.  A reader in launch E only trusts rows with 0 < epoch < E, i.e. rows
+// finalised by an EARLIER launch: the row's mask words were written by that launch too and are
+// visible after the kernel boundary, so no in-kernel release/acquire is needed between the two
+// stores (MI355X_MICROARCH.md: per-XCD L2s are not coherent inside a launch).
+constexpr uint32_t HV_EPOCH_SHIFT = 16;
+constexpr uint32_t HV_EPOCH_MAX = 0xFFFFu;
+
+// per-root (lane) status bits
+constexpr uint32_t LF_NEED_EXACT = 1u;   // static pop order not provable / saturation: use k_exact
+
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int VPW = 4;                    // vertices per wave per block
+constexpr int VPB = WAVES_PER_BLOCK * VPW;
+
+struct GraphDev {
+  uint32_t n;            // vertices
+  uint32_t e_in;         // kept in-links
+  const uint32_t *in_ptr;   // [n+1]  transposed CSR of the links that survive the two-way check
+  const uint32_t *in_src;   // [e_in] source vertex | SRC_NO_TRANSIT
+  const uint32_t *in_w;     // [e_in] cost
+  const uint32_t *in_fpos;  // [e_in] position of the link inside its source row (for slots)
+  const uint8_t *vflags;    // [n]
+  // forward CSR (kept links only) for k_exact
+  const uint32_t *out_ptr;  // [n+1]
+  const uint32_t *out_dst;  // [e_in]
+  const uint32_t *out_w;    // [e_in]
+  const uint32_t *out_fpos; // [e_in]
+};
+
+struct SlotTabs {           // per root: H vertices and their slot bases (include/holo_spf_hip.h)
+  const uint32_t *ptr;      // [n_root_slots+1]
+  const uint32_t *vtx;
+  const uint32_t *base;
+};
+
+// The dispatcher places consecutive workgroups round-robin on the 8 XCDs (block b -> XCD b%8,
+// MI355X_MICROARCH.md "Workgroup dispatch").  Give every XCD one contiguous eighth of the vertex
+// range so that the rows a wave touches (its neighbours in a spatially numbered LSDB) stay in
+// that XCD's private 4 MiB L2.  Speed only: any placement gives the same result.
+__device__ __forceinline__ uint32_t xcd_chunk(uint32_t bx, uint32_t gx /* multiple of 8 */) {
+  return (bx & 7u) * (gx >> 3) + (bx >> 3);
+}
+
+__device__ __forceinline__ uint32_t slot_base_of(const SlotTabs &t, uint32_t root_slot, uint32_t u) {
+  const uint32_t a = t.ptr[root_slot], b = t.ptr[root_slot + 1];
+  for (uint32_t i = a; i < b; ++i)
+    if (t.vtx[i] == u) return t.base[i];
+  return 0xFFFFFFFFu;
+}
+
+// ---------------------------------------------------------------------------------------------
+// init: dist = INF except dist[root] = 0; hv = 0; mask = 0 are memsets; this sets the roots.
+__global__ void k_init_roots(uint32_t n, uint32_t *dist, const uint32_t *roots, uint32_t n_lanes) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_lanes) return;
+  const uint32_t r = roots[i];
+  if (r == INF) return;
+  const uint32_t batch = i >> 6, lane = i & 63;
+  dist[((size_t)batch * n + r) * 64 + lane] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Distance relaxation sweep.  grid = (ceil8(ceil(n / VPB)), n_batches), block = 256.
+__global__ __launch_bounds__(256) void k_relax(GraphDev g, uint32_t *__restrict__ dist,
+                                               const uint32_t *__restrict__ roots,
+                                               uint32_t maxpath, uint32_t ignore_ovl,
+                                               int *changed, int sweep,
+                                               uint32_t *lane_flags) {
+  if (sweep > 0 && changed[sweep - 1] == 0) return;      // converged in an earlier launch
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t batch = blockIdx.y;
+  const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const uint32_t vbeg = chunk * VPB + wave * VPW;
+  if (vbeg >= g.n) return;
+  const uint32_t my_root = roots[batch * 64 + lane];
+  uint32_t *D = dist + (size_t)batch * g.n * 64;
+  bool any = false, sat = false;
+#pragma unroll 1
+  for (int i = 0; i < VPW; ++i) {
+    const uint32_t v = vbeg + i;
+    if (v >= g.n) break;
+    const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
+    const uint32_t d_old = D[(size_t)v * 64 + lane];
+    uint32_t best = d_old;
+#pragma unroll 4
+    for (uint32_t e = e0; e < e1; ++e) {
+      const uint32_t sw = g.in_src[e];
+      const uint32_t w = g.in_w[e];
+      const uint32_t u = sw & SRC_MASK;
+      const uint32_t du = D[(size_t)u * 64 + lane];
+      const bool gate = !(sw & SRC_NO_TRANSIT) || ignore_ovl || u == my_root;
+      const uint64_t c = (uint64_t)du + w;
+      if (du != INF && gate) {
+        if (c >= INF) sat = true;                // u32 saturation: not representable here
+        else if (c <= maxpath && (uint32_t)c < best) best = (uint32_t)c;
+      }
+    }
+    if (best < d_old) {
+      D[(size_t)v * 64 + lane] = best;
+      any = true;
+    }
+  }
+  if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
+  if (sat && maxpath == INF) atomicOr(&lane_flags[batch * 64 + lane], LF_NEED_EXACT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// SPT-DAG sweep: hops + first-hop mask.  Same grid as k_relax.  W = mask words (template).
+template <int W>
+__global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restrict__ dist,
+                                             uint32_t *__restrict__ hv, uint64_t *__restrict__ mask,
+                                             const uint32_t *__restrict__ roots, SlotTabs tabs,
+                                             uint32_t net_nexthops, uint32_t ignore_ovl,
+                                             int *changed, int sweep, uint32_t epoch,
+                                             uint32_t *lane_flags) {
+  if (sweep > 0 && changed[sweep - 1] == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t batch = blockIdx.y;
+  const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const uint32_t vbeg = chunk * VPB + wave * VPW;
+  if (vbeg >= g.n) return;
+  const uint32_t root_slot = batch * 64 + lane;
+  const uint32_t my_root = roots[root_slot];
+  const uint32_t *D = dist + (size_t)batch * g.n * 64;
+  uint32_t *H = hv + (size_t)batch * g.n * 64;
+  uint64_t *M = mask + (size_t)batch * g.n * 64 * W;
+  bool any = false;
+#pragma unroll 1
+  for (int i = 0; i < VPW; ++i) {
+    const uint32_t v = vbeg + i;
+    if (v >= g.n) break;
+    const uint32_t cur = H[(size_t)v * 64 + lane];
+    const bool need0 = (cur >> HV_EPOCH_SHIFT) == 0;
+    if (__ballot(need0) == 0ull) continue;               // whole row already final
+    const uint32_t dv = D[(size_t)v * 64 + lane];
+    uint32_t out_hv = 0;
+    bool done = false;
+    if (need0 && (dv == INF || v == my_root)) done = true;   // not in SPT, or the root (hops 0)
+    const bool need = need0 && !done;
+    uint64_t m[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) m[k] = 0;
+    if (__ballot(need) != 0ull) {
+      const bool v_router = !(g.vflags[v] & 1u);
+      bool pending = false, anyp = false;
+      uint32_t bk_d = INF, bk_u = INF, p0h = 0;
+      const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
+      for (uint32_t e = e0; e < e1; ++e) {
+        const uint32_t sw = g.in_src[e];
+        const uint32_t w = g.in_w[e];
+        const uint32_t u = sw & SRC_MASK;
+        const uint32_t du = D[(size_t)u * 64 + lane];
+        const bool gate = !(sw & SRC_NO_TRANSIT) || ignore_ovl || u == my_root;
+        // tight parent that pops before v in the static (distance, vertex) order
+        const bool tight = need && gate && du != INF && ((uint64_t)du + w == (uint64_t)dv) &&
+                           (du < dv || u < v);
+        if (__ballot(tight) == 0ull) continue;
+        const uint32_t hu = H[(size_t)u * 64 + lane];
+        const uint32_t hh = hu & 0xFFFFu;
+        const uint32_t eu = hu >> HV_EPOCH_SHIFT;
+        const bool ready = tight && eu != 0 && eu < epoch;   // final since an earlier launch
+        if (tight) { anyp = true; if (!ready) pending = true; }
+        if (ready && (du < bk_d || (du == bk_d && u < bk_u))) { bk_d = du; bk_u = u; p0h = hh; }
+        const bool direct = ready && hh == 0;            // parent is the root or a hops-0 network
+        const bool inherit = ready && hh != 0;
+        if (__ballot(direct) != 0ull) {
+          if (direct && (v_router || net_nexthops)) {
+            uint32_t base = (u == my_root) ? 0u : slot_base_of(tabs, root_slot, u);
+            const uint32_t s = base + g.in_fpos[e];
+#pragma unroll
+            for (int k = 0; k < W; ++k)
+              if ((s >> 6) == (uint32_t)k) m[k] |= 1ull << (s & 63u);
+          }
+        }
+        if (__ballot(inherit) != 0ull) {
+#pragma unroll
+          for (int k = 0; k < W; ++k) {
+            const uint64_t mu = M[((size_t)u * W + k) * 64 + lane];
+            if (inherit) m[k] |= mu;
+          }
+        }
+      }
+      if (need && !anyp) {
+        // In the SPT but no parent precedes it in static order: the reference's pop order is
+        // dynamic here (zero-cost plateau).  Hand the whole root to k_exact.
+        atomicOr(&lane_flags[root_slot], LF_NEED_EXACT);
+        out_hv = 0; done = true;
+#pragma unroll
+        for (int k = 0; k < W; ++k) m[k] = 0;
+      } else if (need && !pending) {
+        uint32_t hops = p0h + (v_router ? 1u : 0u);
+        if (hops > 0xFFFFu) hops = 0xFFFFu;              // u16 saturating_add
+        out_hv = hops; done = true;
+      }
+    }
+    if (done) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) M[((size_t)v * W + k) * 64 + lane] = m[k];
+      H[(size_t)v * 64 + lane] = out_hv | (epoch << HV_EPOCH_SHIFT);
+      any = true;
+    }
+  }
+  if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
+}
+
+// Epoch rebase (only when a DAG phase needs more than 65534 launches): every final row -> epoch 1.
+__global__ void k_rebase(uint32_t *hv, size_t count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t x = hv[i];
+  if (x >> HV_EPOCH_SHIFT) hv[i] = (x & 0xFFFFu) | (1u << HV_EPOCH_SHIFT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Emit: lane-major state -> row-major results.  One block = 64 vertices x 64 roots of one batch.
+// grid = (ceil(n/64), n_batches), block = 256.
+struct OutDev {
+  uint32_t *dist; uint16_t *hops; uint16_t *flags; uint64_t *mask; uint32_t out_words;
+};
+
+template <int W>
+__global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t n_roots,
+                                              const uint32_t *__restrict__ dist,
+                                              const uint32_t *__restrict__ hv,
+                                              const uint64_t *__restrict__ mask, OutDev o) {
+  __shared__ uint32_t t32[64][65];
+  __shared__ uint64_t t64[64][65];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t batch = blockIdx.y, v0 = blockIdx.x * 64;
+  const uint32_t nv = min(64u, n - v0);
+  const uint32_t r0 = batch * 64;
+  const uint32_t nr = min(64u, n_roots - r0);
+  const uint32_t *D = dist + ((size_t)batch * n + v0) * 64;
+  const uint32_t *H = hv + ((size_t)batch * n + v0) * 64;
+  const uint64_t *M = mask + ((size_t)batch * n + v0) * 64 * W;
+  // dist (+ flags: in SPT <=> dist != INF on this path; saturated roots go through k_exact)
+  for (uint32_t j = wave; j < nv; j += 4) t32[j][lane] = D[(size_t)j * 64 + lane];
+  __syncthreads();
+  for (uint32_t r = wave; r < nr; r += 4)
+    if (lane < nv) {
+      const uint32_t x = t32[lane][r];
+      const size_t idx = (size_t)(r0 + r) * n + v0 + lane;
+      o.dist[idx] = x;
+      if (o.flags) o.flags[idx] = (x != INF) ? 1 : 0;
+    }
+  __syncthreads();
+  // hops + flags
+  if (o.hops) {
+    for (uint32_t j = wave; j < nv; j += 4) t32[j][lane] = H[(size_t)j * 64 + lane];
+    __syncthreads();
+    for (uint32_t r = wave; r < nr; r += 4)
+      if (lane < nv) {
+        o.hops[(size_t)(r0 + r) * n + v0 + lane] = (uint16_t)(t32[lane][r] & 0xFFFFu);
+      }
+    __syncthreads();
+  }
+  if (o.mask) {
+    for (int k = 0; k < W; ++k) {
+      for (uint32_t j = wave; j < nv; j += 4) t64[j][lane] = M[((size_t)j * W + k) * 64 + lane];
+      __syncthreads();
+      for (uint32_t r = wave; r < nr; r += 4)
+        if (lane < nv)
+          o.mask[((size_t)(r0 + r) * n + v0 + lane) * o.out_words + k] = t64[lane][r];
+      __syncthreads();
+    }
+    // words beyond W (caller capacity larger than needed) are zero
+    for (uint32_t k = W; k < o.out_words; ++k)
+      for (uint32_t r = wave; r < nr; r += 4)
+        if (lane < nv) o.mask[((size_t)(r0 + r) * n + v0 + lane) * o.out_words + k] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact sequential kernel: one lane = one root.  Literal restatement of the reference loop
+//  with a binary heap keyed (distance, vertex) with decrease-key, which
+// pops in exactly the ordered-map order.  State lives in the row-major OUTPUT arrays of that root
+// (dist / hops / flags / mask) plus two u32 scratch rows (heap, pos) per root.
+struct ExactArgs {
+  GraphDev g;
+  const uint32_t *root_list;   // [n_exact] indices into roots[]
+  const uint32_t *roots;       // [n_roots]
+  uint32_t n_exact;
+  uint32_t maxpath, net_nexthops, ignore_ovl;
+  SlotTabs tabs;
+  uint32_t *dist; uint16_t *hops; uint16_t *flags; uint64_t *mask; uint32_t words;
+  uint32_t *pop_rank;          // may be null
+  uint32_t *heap; uint32_t *pos;   // [n_exact][n]
+};
+
+__device__ __forceinline__ bool ex_less(const uint32_t *dist, uint32_t a, uint32_t b) {
+  const uint32_t da = dist[a], db = dist[b];
+  return da < db || (da == db && a < b);
+}
+
+__global__ void k_exact(ExactArgs a) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.n_exact) return;
+  const uint32_t ri = a.root_list[t];
+  const uint32_t root = a.roots[ri];
+  const uint32_t n = a.g.n;
+  uint32_t *dist = a.dist + (size_t)ri * n;
+  uint16_t *hops = a.hops + (size_t)ri * n;
+  uint16_t *flags = a.flags + (size_t)ri * n;
+  uint64_t *mask = a.mask + (size_t)ri * n * a.words;
+  uint32_t *rank = a.pop_rank ? a.pop_rank + (size_t)ri * n : nullptr;
+  uint32_t *heap = a.heap + (size_t)t * n;
+  uint32_t *pos = a.pos + (size_t)t * n;
+  const uint32_t W = a.words;
+  for (uint32_t i = 0; i < n; ++i) {
+    dist[i] = INF; hops[i] = 0; flags[i] = 0; pos[i] = INF;
+    if (rank) rank[i] = INF;
+    for (uint32_t k = 0; k < W; ++k) mask[(size_t)i * W + k] = 0;
+  }
+  if (root == INF) return;
+  uint32_t hn = 0, popped = 0;
+  dist[root] = 0; heap[0] = root; pos[root] = 0; hn = 1;
+  while (hn) {
+    const uint32_t v = heap[0];
+    // pop
+    --hn;
+    if (hn) {
+      uint32_t x = heap[hn], i = 0;
+      for (;;) {
+        uint32_t c = 2 * i + 1;
+        if (c >= hn) break;
+        if (c + 1 < hn && ex_less(dist, heap[c + 1], heap[c])) ++c;
+        if (!ex_less(dist, heap[c], x)) break;
+        heap[i] = heap[c]; pos[heap[i]] = i; i = c;
+      }
+      heap[i] = x; pos[x] = i;
+    }
+    pos[v] = INF;
+    flags[v] = 1 | 2;                                  // HSPF_RF_IN_SPT | HSPF_RF_EXACT
+    if (rank) rank[v] = popped;
+    ++popped;
+    const uint32_t vf = a.g.vflags[v];
+    const uint32_t vhops = hops[v];
+    // NO_EXPAND sources have no kept out-links at all (dropped at upload)
+    if (vhops != 0 && !(vf & 1u) && !a.ignore_ovl && (vf & 2u)) continue;
+    const uint32_t dvv = dist[v];
+    uint32_t vbase = 0xFFFFFFFFu;
+    for (uint32_t k = a.g.out_ptr[v]; k < a.g.out_ptr[v + 1]; ++k) {
+      const uint32_t tv = a.g.out_dst[k];
+      if (flags[tv] & 1) continue;                      // already on the SPT
+      const uint64_t c64 = (uint64_t)dvv + a.g.out_w[k];
+      const uint32_t d = c64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c64;
+      if (d > a.maxpath) continue;
+      const bool on_cand = pos[tv] != INF;
+      if (on_cand && d > dist[tv]) continue;
+      const bool t_router = !(a.g.vflags[tv] & 1u);
+      if (!on_cand || d < dist[tv]) {
+        dist[tv] = d;
+        uint32_t h = vhops + (t_router ? 1u : 0u);
+        hops[tv] = (uint16_t)(h > 0xFFFFu ? 0xFFFFu : h);
+        for (uint32_t q = 0; q < W; ++q) mask[(size_t)tv * W + q] = 0;
+        uint32_t i;
+        if (!on_cand) { i = hn++; } else { i = pos[tv]; }
+        // sift up
+        while (i > 0) {
+          uint32_t p = (i - 1) / 2;
+          const uint32_t hp = heap[p];
+          // compare (d,tv) with heap[p]
+          const uint32_t dp = dist[hp];
+          if (!(d < dp || (d == dp && tv < hp))) break;
+          heap[i] = hp; pos[hp] = i; i = p;
+        }
+        heap[i] = tv; pos[tv] = i;
+      }
+      if (vhops == 0) {
+        if (t_router || a.net_nexthops) {
+          if (vbase == 0xFFFFFFFFu) vbase = (v == root) ? 0u : slot_base_of(a.tabs, ri, v);
+          const uint32_t s = vbase + a.g.out_fpos[k];
+          mask[(size_t)tv * W + (s >> 6)] |= 1ull << (s & 63u);
+        }
+      } else {
+        for (uint32_t q = 0; q < W; ++q) mask[(size_t)tv * W + q] |= mask[(size_t)v * W + q];
+      }
+    }
+  }
+}
+
+}  // namespace hspf

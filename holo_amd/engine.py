@@ -1,0 +1,192 @@
+"""Thin Python wrapper over the C ABI of libholo_spf_hip.so (include/holo_spf_hip.h).
+
+This is the host-side handle layer a caller (the Python mirrors of holo-ospf `run_area` /
+holo-isis `compute_spt` in holo_amd.isis / holo_amd.ospf, bench.py, tests) uses.  All compute is
+in the HIP library; there is no Python or CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+# run flags (mirror of HSPF_RUN_*)
+RUN_NET_NEXTHOPS = 0x01
+RUN_IGNORE_OVERLOAD = 0x02
+RUN_FORCE_EXACT = 0x04
+RUN_POP_RANK = 0x08
+
+RF_IN_SPT = 0x0001
+RF_EXACT = 0x0002
+DIST_INF = 0xFFFFFFFF
+NO_ROOT = 0xFFFFFFFF
+
+
+class HspfError(RuntimeError):
+    def __init__(self, code: int, what: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{what}: {code} ({L.load().hspf_strerror(code).decode()})"
+                         + (f": {detail}" if detail else ""))
+
+
+@dataclass
+class SpfResult:
+    """Row-major per-root results on the host (numpy)."""
+    dist: np.ndarray                 # [R, N] u32, DIST_INF when not in SPT
+    hops: np.ndarray                 # [R, N] u16
+    flags: np.ndarray                # [R, N] u16 (RF_*)
+    first_hop_mask: np.ndarray       # [R, N, W] u64
+    pop_rank: Optional[np.ndarray]   # [R, N] u32 or None
+    stats: dict
+
+
+def _u32(a):
+    return a.ctypes.data_as(L.u32p)
+
+
+class SpfGraph:
+    """Device-resident graph of one LSDB generation (hspf_graph)."""
+
+    def __init__(self, ctx: "SpfContext", row_ptr, col, metric, vflags, max_path_metric: int):
+        self.ctx = ctx
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+        self.col = np.ascontiguousarray(col, dtype=np.uint32)
+        self.metric = np.ascontiguousarray(metric, dtype=np.uint32)
+        self.vflags = np.ascontiguousarray(vflags, dtype=np.uint8)
+        self.n = len(self.row_ptr) - 1
+        csr = L.HspfCsr(self.n, len(self.col), _u32(self.row_ptr), _u32(self.col), _u32(self.metric),
+                        self.vflags.ctypes.data_as(L.u8p), ctypes.c_uint32(max_path_metric))
+        h = ctypes.c_void_p()
+        rc = ctx.lib.hspf_graph_upload(ctx.handle, ctypes.byref(csr), ctypes.byref(h))
+        if rc != 0:
+            raise HspfError(rc, "hspf_graph_upload", ctx.last_error())
+        self.handle = h
+
+    @property
+    def n_edges_kept(self) -> int:
+        return int(self.ctx.lib.hspf_graph_n_edges_kept(self.handle))
+
+    def mask_words(self, roots) -> int:
+        roots = np.ascontiguousarray(roots, dtype=np.uint32)
+        w = ctypes.c_uint32()
+        rc = self.ctx.lib.hspf_mask_words(self.ctx.handle, self.handle, _u32(roots), len(roots), ctypes.byref(w))
+        if rc != 0:
+            raise HspfError(rc, "hspf_mask_words", self.ctx.last_error())
+        return int(w.value)
+
+    def slot_table(self, root: int):
+        """(H vertices, slot bases, total slots) of one root — see include/holo_spf_hip.h."""
+        total = ctypes.c_uint32()
+        cnt = self.ctx.lib.hspf_slot_table(self.ctx.handle, self.handle, root, None, None, 0, ctypes.byref(total))
+        if cnt < 0:
+            raise HspfError(cnt, "hspf_slot_table", self.ctx.last_error())
+        hv = np.empty(cnt, np.uint32)
+        hb = np.empty(cnt, np.uint32)
+        self.ctx.lib.hspf_slot_table(self.ctx.handle, self.handle, root, _u32(hv), _u32(hb), cnt, ctypes.byref(total))
+        return hv, hb, int(total.value)
+
+    def slot_to_link(self, root: int, slot: int):
+        """Map a first-hop slot of `root` back to (parent vertex, link position in its row,
+        global link index)."""
+        hv, hb, total = self.slot_table(root)
+        if slot >= total:
+            raise IndexError(slot)
+        i = int(np.searchsorted(hb, slot, side="right")) - 1
+        p = int(hv[i])
+        j = slot - int(hb[i])
+        return p, j, int(self.row_ptr[p]) + j
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.hspf_graph_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+                self.free()
+        except Exception:
+            pass
+
+
+class SpfContext:
+    """One engine context: device, HIP stream, scratch (hspf_ctx).  One thread at a time."""
+
+    def __init__(self, device: int = 0):
+        self.lib = L.load()
+        h = ctypes.c_void_p()
+        rc = self.lib.hspf_init(device, ctypes.byref(h))
+        if rc != 0:
+            raise HspfError(rc, "hspf_init")
+        self.handle = h
+        self.device = device
+
+    def last_error(self) -> str:
+        return self.lib.hspf_last_error(self.handle).decode()
+
+    def set_stream(self, hip_stream_ptr: int):
+        rc = self.lib.hspf_set_stream(self.handle, ctypes.c_void_p(hip_stream_ptr))
+        if rc != 0:
+            raise HspfError(rc, "hspf_set_stream")
+
+    def upload(self, row_ptr, col, metric, vflags, max_path_metric: int) -> SpfGraph:
+        return SpfGraph(self, row_ptr, col, metric, vflags, max_path_metric)
+
+    def stats(self) -> dict:
+        s = L.HspfStats()
+        self.lib.hspf_get_stats(self.handle, ctypes.byref(s))
+        return {name: getattr(s, name) for name, _ in L.HspfStats._fields_}
+
+    def run(self, graph: SpfGraph, roots: Sequence[int], run_flags: int = 0, *, want_mask: bool = True,
+            mask_words: Optional[int] = None) -> SpfResult:
+        """hspf_run(): results land in host numpy arrays."""
+        roots = np.ascontiguousarray(roots, dtype=np.uint32)
+        R, n = len(roots), graph.n
+        W = mask_words or graph.mask_words(roots)
+        dist = np.empty((R, n), np.uint32)
+        hops = np.empty((R, n), np.uint16)
+        flags = np.empty((R, n), np.uint16)
+        mask = np.empty((R, n, W), np.uint64) if want_mask else None
+        rank = np.empty((R, n), np.uint32) if (run_flags & RUN_POP_RANK) else None
+        res = L.HspfResult(dist.ctypes.data, hops.ctypes.data, flags.ctypes.data,
+                           mask.ctypes.data if want_mask else None, W,
+                           rank.ctypes.data if rank is not None else None)
+        rc = self.lib.hspf_run(self.handle, graph.handle, _u32(roots), R, run_flags, ctypes.byref(res))
+        if rc != 0:
+            raise HspfError(rc, "hspf_run", self.last_error())
+        return SpfResult(dist, hops, flags, mask, rank, self.stats())
+
+    def run_device(self, graph: SpfGraph, roots: Sequence[int], run_flags: int, *, dist_ptr: int,
+                   hops_ptr: int = 0, flags_ptr: int = 0, mask_ptr: int = 0, mask_words: int = 1,
+                   pop_rank_ptr: int = 0) -> dict:
+        """hspf_run_device(): results stay in HBM at the given device pointers (e.g. torch
+        tensors' data_ptr()); returns the stats of the run."""
+        roots = np.ascontiguousarray(roots, dtype=np.uint32)
+        res = L.HspfResult(dist_ptr or None, hops_ptr or None, flags_ptr or None, mask_ptr or None,
+                           mask_words, pop_rank_ptr or None)
+        rc = self.lib.hspf_run_device(self.handle, graph.handle, _u32(roots), len(roots), run_flags,
+                                      ctypes.byref(res))
+        if rc != 0:
+            raise HspfError(rc, "hspf_run_device", self.last_error())
+        return self.stats()
+
+    def close(self):
+        if self.handle:
+            self.lib.hspf_shutdown(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,191 @@
+/*
+ * holo_spf_hip.h — C ABI of libholo_spf_hip.so, the MI355X (gfx950) SPF engine.
+ *
+ * This is the drop-in boundary for the link-state SPF hot path of holo-routing/holo.
+ * The reference has no FFI for this path; the boundary is drawn at
+ * the two functions that do all shortest-path-tree work:
+ *
+ *   holo-ospf/src/spf.rs:587-729   run_area<V>()     one SPT per area, root = self
+ *   holo-isis/src/spf.rs:527-709   compute_spt()     one SPT per (level, MT, arbitrary root)
+ *   holo-isis/src/flooding/manet.rs:47-69            the batched-roots caller (one SPT per adjacency)
+ *
+ * What crosses the boundary is the *graph* those loops walk (CSR restatement of
+ * `vertex_lsa_links` holo-ospf/src/ospfv2/spf.rs:389-460, ospfv3/spf.rs:348-419 and
+ * `vertex_edges` holo-isis/src/spf.rs:1013-1128) and, per root, the per-vertex result the
+ * loops produce (`Vertex{distance,hops,nexthops}` holo-ospf/src/spf.rs:38-46,
+ * holo-isis/src/spf.rs:78-88).  Everything that needs Interface / Adjacency / LSA objects
+ * (next-hop address resolution, prefix attachment) stays with the caller and consumes
+ * dist / hops / first_hop_mask.  See INTEGRATION.md for the Rust-side binding.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes, no C++ or torch types;
+ *   - every entry point returns 0 (HSPF_OK) or a negative HSPF_E* code; nothing aborts or
+ *     throws across the boundary (mirrors `Error::SpfRootNotFound(..).log(); return;`
+ *     holo-ospf/src/spf.rs:605-610 — the caller logs and keeps its own loop as fallback);
+ *   - a ctx is used by one thread at a time; distinct ctxs may run concurrently (one HIP
+ *     stream each), matching the one-OS-thread-per-instance contract of
+ *     holo-protocol/src/lib.rs:427-430;
+ *   - there is NO CPU fallback inside the library: without a HIP device hspf_init fails.
+ */
+#ifndef HOLO_SPF_HIP_H
+#define HOLO_SPF_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSPF_ABI_VERSION 1u
+
+/* ---- error codes ------------------------------------------------------------------- */
+#define HSPF_OK                 0
+#define HSPF_E_INVAL           -1   /* bad argument (NULL, out-of-range root, malformed CSR)   */
+#define HSPF_E_NODEV           -2   /* no usable HIP device / device ordinal out of range     */
+#define HSPF_E_HIP             -3   /* a HIP runtime call failed; see hspf_last_error(ctx)     */
+#define HSPF_E_NOMEM           -4   /* host or device allocation failed                        */
+#define HSPF_E_TOO_MANY_SLOTS  -5   /* a root has more first-hop slots than n_mask_words*64    */
+#define HSPF_E_INTERNAL        -6   /* invariant violated (never expected)                     */
+
+/* ---- vertex flags (hspf_csr.vflags) -------------------------------------------------- */
+/* bit0: vertex is an OSPF network vertex / IS-IS pseudonode.  Reaching it does not
+ *       increment `hops` (holo-ospf/src/spf.rs:675-678, holo-isis/src/spf.rs:650-653).      */
+#define HSPF_VF_NETWORK    0x01u
+/* bit1: IS-IS overload bit set for the topology of this run: the vertex stays in the SPT
+ *       but its links are skipped unless it is the root (holo-isis/src/spf.rs:568-574).      */
+#define HSPF_VF_NO_TRANSIT 0x02u
+/* bit2: never expanded, root included: zeroth LSP missing / seqno 0 / lifetime 0
+ *       (holo-isis/src/spf.rs:558-561) or protocols-supported gate (:582-604).               */
+#define HSPF_VF_NO_EXPAND  0x04u
+
+/* ---- run flags (hspf_run*.run_flags) -------------------------------------------------- */
+/* OSPF semantics for first hops: a network reached from a hops==0 parent gets its own
+ * first-hop slot (holo-ospf/src/ospfv2/spf.rs:296-302).  Without it (IS-IS) a pseudonode
+ * reached from a hops==0 parent gets no next hop (holo-isis/src/spf.rs:680-701).            */
+#define HSPF_RUN_NET_NEXTHOPS     0x01u
+/* IS-IS flooding-topology run (mt_id == None): overload bit is not applied
+ * (holo-isis/src/spf.rs:566-574).                                                           */
+#define HSPF_RUN_IGNORE_OVERLOAD  0x02u
+/* Force the sequential exact kernel for every root (test hook).                             */
+#define HSPF_RUN_FORCE_EXACT      0x04u
+/* Also produce hspf_result.pop_rank.                                                        */
+#define HSPF_RUN_POP_RANK         0x08u
+
+/* ---- per-(root,vertex) result flags (hspf_result.vflags_out) --------------------------- */
+#define HSPF_RF_IN_SPT   0x0001u    /* vertex was popped into the SPT                         */
+#define HSPF_RF_EXACT    0x0002u    /* produced by the sequential exact kernel (diagnostic)   */
+
+#define HSPF_DIST_INF    0xFFFFFFFFu /* dist of a vertex that is not in the SPT               */
+#define HSPF_NO_ROOT     0xFFFFFFFFu /* padding entry in a roots[] array: produces an empty SPT */
+
+typedef struct hspf_ctx   hspf_ctx;    /* one per protocol-instance thread: device, stream, scratch */
+typedef struct hspf_graph hspf_graph;  /* device-resident graph of one LSDB generation              */
+
+/*
+ * The LSDB graph of one area (OSPF) or one level x topology (IS-IS), as forward CSR.
+ *   - vertex index == rank in the reference's VertexId order, so that integer compare is
+ *     the candidate-list tie-break (holo-ospf/src/ospfv2/spf.rs:41-45: networks before
+ *     routers, then numeric; holo-isis/src/spf.rs:96-100: pseudonodes first, then the
+ *     7-byte LAN id);
+ *   - row u lists the links of u in LSA / LSP order exactly as the reference iterates them
+ *     (incl. parallel links and the TLV2+TLV22 duplicates of metric-type "both"); links whose
+ *     target LSA/LSP is absent are simply not listed;
+ *   - the two-way connectivity check (holo-ospf/src/spf.rs:654-664,
+ *     holo-isis/src/spf.rs:616-627) is applied by the library, not the caller;
+ *   - arrays are caller-owned host memory, borrowed for the duration of the call only.
+ */
+typedef struct {
+  uint32_t        n_vertices;       /* < 2^31                                                 */
+  uint32_t        n_edges;
+  const uint32_t *row_ptr;          /* [n_vertices+1], row_ptr[0]==0, non-decreasing          */
+  const uint32_t *col;              /* [n_edges] target vertex index                          */
+  const uint32_t *metric;           /* [n_edges] link cost (OSPF u16, IS-IS u8/u24, widened)  */
+  const uint8_t  *vflags;           /* [n_vertices] HSPF_VF_*                                 */
+  uint32_t        max_path_metric;  /* relaxations with dist > this are dropped: 0xFFFFFFFF
+                                       for OSPF (saturating add, holo-ospf/src/spf.rs:672),
+                                       1023 / 0xFE000000 for IS-IS (holo-isis/src/spf.rs:44-49,
+                                       637-647)                                               */
+} hspf_csr;
+
+/*
+ * Per-root results, row-major [n_roots][n_vertices].  With hspf_run() the pointers are
+ * caller-owned HOST memory; with hspf_run_device() they are DEVICE (HBM) pointers and the
+ * results never leave the GPU (for device-side consumers and the RCCL all-gather).
+ * Any pointer may be NULL to skip that output (dist must not be NULL).
+ *
+ * first_hop_mask: bit k of word k/64 == first-hop slot k of that root is one of the vertex's
+ * next hops.  Slots are numbered per root over the out-links of the vertices that can have
+ * hops == 0:  H = [root] ++ (network vertices reachable from the root through network
+ * vertices only, breadth-first, links in row order, each vertex once);
+ * slot(p, j) = sum(deg(H[i]) for H[i] before p) + j   for the j-th link of row p
+ * (positions count ALL links of the row as passed in hspf_csr).  hspf_slot_table() returns
+ * H and the bases so the caller can map a slot back to (parent vertex, link) and call its
+ * own `calc_nexthops` / `resolve_nexthop` on it.
+ */
+typedef struct {
+  uint32_t *dist;            /* HSPF_DIST_INF when not in SPT                                 */
+  uint16_t *hops;            /* holo `Vertex.hops` (first-discoverer rule)                    */
+  uint16_t *vflags_out;      /* HSPF_RF_*                                                     */
+  uint64_t *first_hop_mask;  /* [n_roots][n_vertices][n_mask_words]                           */
+  uint32_t  n_mask_words;    /* capacity in u64 words per (root,vertex); >= hspf_mask_words() */
+  uint32_t *pop_rank;        /* position in the reference's pop order (needs HSPF_RUN_POP_RANK),
+                                0xFFFFFFFF when not in SPT                                     */
+} hspf_result;
+
+/* Timing / work counters of the last hspf_run*() on a ctx (HIP-event timed, on the ctx stream). */
+typedef struct {
+  uint32_t n_roots;
+  uint32_t n_batches;          /* 64-root wavefront batches                                   */
+  uint32_t n_relax_launches;   /* launches of the distance relaxation kernel                  */
+  uint32_t n_dag_launches;     /* launches of the SPT-DAG (hops / first-hop) kernel           */
+  uint32_t n_exact_roots;      /* roots that needed the sequential exact kernel               */
+  uint32_t n_mask_words;
+  float    ms_total;           /* first launch -> results in place (device time)              */
+  float    ms_relax;
+  float    ms_dag;
+  float    ms_finish;          /* transpose to row-major outputs (+ exact kernel)             */
+  float    ms_d2h;             /* only for hspf_run(): device->host copies                    */
+} hspf_stats;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+uint32_t    hspf_abi_version(void);
+int         hspf_device_count(void);                       /* >=0, or HSPF_E_*                 */
+int         hspf_init(int device_ordinal, hspf_ctx **out);
+void        hspf_shutdown(hspf_ctx *ctx);
+const char *hspf_strerror(int code);
+const char *hspf_last_error(const hspf_ctx *ctx);          /* detail of the last failure       */
+/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the ctx's own. */
+int         hspf_set_stream(hspf_ctx *ctx, void *hip_stream);
+void       *hspf_get_stream(const hspf_ctx *ctx);
+
+/* ---- graph ------------------------------------------------------------------------------ */
+int      hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out);
+void     hspf_graph_free(hspf_ctx *ctx, hspf_graph *g);
+uint32_t hspf_graph_n_vertices(const hspf_graph *g);
+uint32_t hspf_graph_n_edges_kept(const hspf_graph *g);     /* links surviving the two-way check */
+
+/* ---- first-hop slots -------------------------------------------------------------------- */
+/* Number of u64 mask words needed for these roots on this graph (>= 1). */
+int hspf_mask_words(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots,
+                    uint32_t *out_words);
+/* Slot table of one root: writes up to `cap` entries of H (vertex index) and its slot base;
+ * returns the number of entries of H (may exceed cap), or HSPF_E_*. */
+int hspf_slot_table(hspf_ctx *ctx, const hspf_graph *g, uint32_t root,
+                    uint32_t *h_vertex, uint32_t *h_base, uint32_t cap, uint32_t *out_total_slots);
+
+/* ---- run -------------------------------------------------------------------------------- */
+/* Synchronous: on return the results are in the caller's host buffers. */
+int hspf_run(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots,
+             uint32_t run_flags, hspf_result *out);
+/* Results are written to device buffers; returns after the work has been *enqueued and
+ * completed* on the ctx stream (the call synchronises the stream once at the end so that
+ * error flags can be read).  roots is a host array. */
+int hspf_run_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots,
+                    uint32_t run_flags, hspf_result *out_device);
+int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOLO_SPF_HIP_H */

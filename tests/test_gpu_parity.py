@@ -1,0 +1,157 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle, bit for bit.
+
+Integer path: every comparison is exact (dist u32, hops u16, in-SPT flag, first-hop mask).
+"""
+import numpy as np
+import pytest
+
+from holo_amd import synth
+from holo_amd import engine as E
+from oracle import graph_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def check(ctx, g, roots, run_flags=0, oracle_variant=go.MAP, expect_exact=None):
+    roots = np.asarray(roots, np.uint32)
+    G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        res = ctx.run(G, roots, run_flags)
+    finally:
+        G.free()
+    oflags = run_flags & (E.RUN_NET_NEXTHOPS | E.RUN_IGNORE_OVERLOAD)
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, oflags, oracle_variant,
+                 mask_words_=res.first_hop_mask.shape[2])
+    assert np.array_equal(res.dist, ref.dist), "dist"
+    assert np.array_equal(res.flags & 1, ref.flags), "in-SPT flag"
+    assert np.array_equal(res.hops, ref.hops), "hops"
+    assert np.array_equal(res.first_hop_mask, ref.mask), "first-hop mask"
+    if res.pop_rank is not None:
+        assert np.array_equal(res.pop_rank, ref.pop_rank), "pop rank"
+    if expect_exact is not None:
+        assert (res.stats["n_exact_roots"] > 0) == expect_exact
+    return res, ref
+
+
+@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("run_flags", [0, E.RUN_NET_NEXTHOPS, E.RUN_IGNORE_OVERLOAD])
+def test_random_lsdb_normal_metrics(spf_ctx, seed, run_flags):
+    """Routers + LANs, parallel / one-way links, overload and no-expand vertices, tie-heavy
+    metrics >= 1: the static-order fast path must cover these (no exact-kernel roots)."""
+    g = synth.random_lsdb(60, 8, 3.0, seed, metric_hi=6)
+    roots = np.arange(8, 8 + 40, dtype=np.uint32)
+    check(spf_ctx, g, roots, run_flags, expect_exact=False)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_lsdb_all_roots_ragged(spf_ctx, seed):
+    """Ragged root counts (not multiples of 64), incl. network vertices as roots and padding."""
+    g = synth.random_lsdb(90, 10, 2.5, 100 + seed, metric_hi=4)
+    roots = np.arange(g.n, dtype=np.uint32)             # 100 roots -> 2 batches, second ragged
+    roots[5] = E.NO_ROOT
+    check(spf_ctx, g, roots, 0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_zero_cost_router_links_exact_path(spf_ctx, seed):
+    """Zero-cost router links make the reference's pop order dynamic: flagged roots go through
+    the sequential exact kernel and must still match bit for bit."""
+    g = synth.random_lsdb(50, 6, 3.0, 200 + seed, metric_hi=3, zero_cost_router_links=True)
+    roots = np.arange(6, 6 + 30, dtype=np.uint32)
+    check(spf_ctx, g, roots, 0)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hopcount_mode(spf_ctx, seed):
+    """MetricMode::HopCount (holo-isis/src/flooding/manet.rs:59-69): cost 0 to pseudonodes, 1 to
+    routers, overload ignored, local = false."""
+    g = synth.random_lsdb(50, 8, 2.5, 300 + seed, hopcount=True)
+    roots = np.arange(8, 8 + 20, dtype=np.uint32)
+    check(spf_ctx, g, roots, E.RUN_IGNORE_OVERLOAD)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_forced_exact_and_pop_rank(spf_ctx, seed):
+    g = synth.random_lsdb(40, 5, 3.0, 400 + seed, metric_hi=5)
+    roots = np.arange(5, 5 + 10, dtype=np.uint32)
+    res, ref = check(spf_ctx, g, roots, E.RUN_POP_RANK)
+    assert res.stats["n_exact_roots"] == 10
+
+
+def test_standard_metric_max_path_prune(spf_ctx):
+    """MAX_PATH_METRIC_STANDARD = 1023 (holo-isis/src/spf.rs:45, 637-647): a long chain is cut."""
+    n = 40
+    src = np.arange(n - 1); dst = src + 1
+    s = np.concatenate([src, dst]); d = np.concatenate([dst, src])
+    m = np.full(2 * (n - 1), 63)
+    row_ptr, col, metric = synth._csr_from_links(n, s, d, m)
+    g = synth.CsrGraph(row_ptr, col, metric, np.zeros(n, np.uint8), synth.MAX_PATH_METRIC_STANDARD)
+    res, ref = check(spf_ctx, g, [0, n - 1, n // 2])
+    assert (res.dist[0] != E.DIST_INF).sum() == 1023 // 63 + 1
+
+
+def test_ospf_saturation_goes_exact(spf_ctx):
+    """u32 saturating add (holo-ospf/src/spf.rs:672) is only representable on the exact path."""
+    n = 4
+    s = np.array([0, 1, 1, 2, 2, 3]); d = np.array([1, 0, 2, 1, 3, 2])
+    m = np.array([0xFFFFFFF0, 1, 0x20, 1, 5, 1])
+    row_ptr, col, metric = synth._csr_from_links(n, s, d, m)
+    g = synth.CsrGraph(row_ptr, col, metric, np.zeros(n, np.uint8), synth.MAX_PATH_METRIC_OSPF)
+    res, ref = check(spf_ctx, g, [0, 3], E.RUN_NET_NEXTHOPS)
+    assert res.dist[0, 2] == 0xFFFFFFFF and (res.flags[0, 2] & 1)
+
+
+def test_config_ospf_500_and_10k(spf_ctx):
+    for g in (synth.ospf_500(), synth.ospf_10k()):
+        check(spf_ctx, g, g.meta["roots"], E.RUN_NET_NEXTHOPS, expect_exact=False)
+
+
+def test_config_isis_100k_sample_roots(spf_ctx):
+    """Headline graph, 64 roots on the GPU; the oracle (heap variant) checks a sample of 6."""
+    g = synth.isis_100k()
+    roots = np.asarray(g.meta["roots"], np.uint32)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    res = spf_ctx.run(G, roots, 0)
+    G.free()
+    assert res.stats["n_exact_roots"] == 0
+    sample = [0, 1, 17, 31, 40, 63]
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots[sample], 0, go.HEAP,
+                 mask_words_=res.first_hop_mask.shape[2])
+    assert np.array_equal(res.dist[sample], ref.dist)
+    assert np.array_equal(res.hops[sample], ref.hops)
+    assert np.array_equal(res.flags[sample] & 1, ref.flags)
+    assert np.array_equal(res.first_hop_mask[sample], ref.mask)
+    # size-independent properties over all 64 roots
+    N = g.n
+    assert (res.dist[np.arange(64), roots] == 0).all()
+    assert ((res.flags & 1) == 1).all()                       # connected graph: everything reached
+    # triangle inequality on every kept link: dist[t] <= dist[u] + w   (fixed point of relaxation)
+    u = np.repeat(np.arange(N), np.diff(g.row_ptr).astype(np.int64))
+    for r in range(0, 64, 9):
+        assert (res.dist[r][g.col].astype(np.int64) <= res.dist[r][u].astype(np.int64) + g.metric).all()
+    # symmetry-free check: first-hop mask non-empty exactly for non-root vertices
+    nz = res.first_hop_mask.any(axis=2)
+    assert (nz.sum(axis=1) == N - 1).all()
+
+
+def test_determinism(spf_ctx):
+    """Replay (holo-tools/holo-replay) needs bit-identical reruns."""
+    g = synth.ospf_10k()
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    roots = np.arange(0, 10000, 157, dtype=np.uint32)
+    a = spf_ctx.run(G, roots, E.RUN_NET_NEXTHOPS)
+    b = spf_ctx.run(G, roots, E.RUN_NET_NEXTHOPS)
+    G.free()
+    for f in ("dist", "hops", "flags", "first_hop_mask"):
+        assert np.array_equal(getattr(a, f), getattr(b, f))
+
+
+def test_errors_are_codes_not_crashes(spf_ctx):
+    g = synth.ospf_500()
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    with pytest.raises(E.HspfError) as ei:
+        spf_ctx.run(G, [g.n + 5])
+    assert ei.value.code == -1
+    with pytest.raises(E.HspfError):
+        spf_ctx.upload(g.row_ptr, g.col + 100000, g.metric, g.vflags, g.max_path_metric)
+    G.free()
