@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -62,6 +63,7 @@ struct hspf_ctx {
   uint32_t *h_lane_flags = nullptr; // pinned
   size_t h_lane_cap = 0;
   uint32_t est_relax = 12, est_dag = 12;   // launch-ahead estimates (adapted run to run)
+  uint32_t variant = 0;                    // HSPF_VARIANT env: kernel A/B switches (tuning only)
   hspf_stats stats = {};
 };
 
@@ -127,11 +129,11 @@ uint32_t round_words(uint32_t w) {   // template instantiations of k_dag / k_emi
   return 16;
 }
 
-template <int W>
+template <int W, bool GS = false>
 void launch_dag(dim3 grid, hipStream_t s, GraphDev g, const uint32_t *dist, uint32_t *hv, uint64_t *mask,
                 const uint32_t *roots, SlotTabs tabs, uint32_t nn, uint32_t io, int *changed, int sweep,
                 uint32_t epoch, uint32_t *lf) {
-  hipLaunchKernelGGL((k_dag<W>), grid, dim3(256), 0, s, g, dist, hv, mask, roots, tabs, nn, io, changed,
+  hipLaunchKernelGGL((k_dag<W, GS>), grid, dim3(256), 0, s, g, dist, hv, mask, roots, tabs, nn, io, changed,
                      sweep, epoch, lf);
 }
 template <int W>
@@ -177,6 +179,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   hspf_ctx *ctx = new (std::nothrow) hspf_ctx();
   if (!ctx) return HSPF_E_NOMEM;
   ctx->device = device_ordinal;
+  if (const char *v = getenv("HSPF_VARIANT")) ctx->variant = (uint32_t)strtoul(v, nullptr, 0);
   if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return HSPF_E_NODEV; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
   for (auto &e : ctx->ev)
@@ -218,15 +221,17 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
   if (!ctx || !csr || !out) return HSPF_E_INVAL;
   *out = nullptr;
   const uint32_t n = csr->n_vertices, e = csr->n_edges;
-  if (n == 0 || n >= 0x7FFFFFFFu || !csr->row_ptr || !csr->vflags || (e && (!csr->col || !csr->metric))) {
+  if (n == 0 || n > (1u << 24) || !csr->row_ptr || !csr->vflags || (e && (!csr->col || !csr->metric))) {
     ctx->last_error = "hspf_graph_upload: malformed hspf_csr";
     return HSPF_E_INVAL;
   }
   if (csr->row_ptr[0] != 0 || csr->row_ptr[n] != e) { ctx->last_error = "row_ptr[0]!=0 or row_ptr[n]!=n_edges"; return HSPF_E_INVAL; }
   for (uint32_t u = 0; u < n; ++u)
     if (csr->row_ptr[u + 1] < csr->row_ptr[u]) { ctx->last_error = "row_ptr not monotone"; return HSPF_E_INVAL; }
-  for (uint32_t k = 0; k < e; ++k)
+  for (uint32_t k = 0; k < e; ++k) {
     if (csr->col[k] >= n) { ctx->last_error = "col out of range"; return HSPF_E_INVAL; }
+    if (csr->metric[k] == 0xFFFFFFFFu) { ctx->last_error = "metric 0xFFFFFFFF is reserved"; return HSPF_E_INVAL; }
+  }
   (void)hipSetDevice(ctx->device);
 
   hspf_graph *g = new (std::nothrow) hspf_graph();
@@ -504,7 +509,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
   uint32_t n_relax = 0;
   rc = run_phase(ctx->est_relax, [&](uint32_t sweep) {
-    hipLaunchKernelGGL(k_relax, grid, dim3(256), 0, s, gd, d_dist, d_roots, g->max_path_metric, ignore_ovl, d_changed, (int)sweep, d_lf);
+    if (g->max_path_metric == HSPF_DIST_INF)
+      hipLaunchKernelGGL((k_relax<true>), grid, dim3(256), 0, s, gd, d_dist, d_roots, g->max_path_metric, ignore_ovl, d_changed, (int)sweep, d_lf);
+    else
+      hipLaunchKernelGGL((k_relax<false>), grid, dim3(256), 0, s, gd, d_dist, d_roots, g->max_path_metric, ignore_ovl, d_changed, (int)sweep, d_lf);
   }, n_relax);
   if (rc) return rc;
   ctx->est_relax = n_relax + 1;
@@ -521,7 +529,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       epoch = 2;
     }
     switch (W) {
-      case 1: launch_dag<1>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
+      case 1: launch_dag<1, true>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
       case 2: launch_dag<2>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
       case 4: launch_dag<4>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
       case 8: launch_dag<8>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;

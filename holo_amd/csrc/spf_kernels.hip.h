@@ -93,7 +93,36 @@ __global__ void k_init_roots(uint32_t n, uint32_t *dist, const uint32_t *roots, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Inner-loop design (measured, profiles/r01_pmc_notes.md): a CU has ONE scalar ALU for its four
+// SIMDs, and a first version that kept the wave-uniform link data (source, cost, addresses,
+// bounds) on the scalar side was issue-bound on it (1350 SALU + 1010 VALU instructions per wave,
+// memory wait only 22 % of wave cycles).  So per link the kernels do exactly:
+//     v_readlane (source)  v_readlane (cost)  v_lshl_add (row offset)  global_load (saddr form)
+//     v_add_u32 clamp      v_min / v_cmp
+// with COMPILE-TIME lane numbers (fully unrolled groups of 4 links), a 32-bit VGPR byte offset on
+// top of an SGPR base (needs n * 256 <= 2^32), and everything rare (overload gating, padding,
+// zero-cost ordering) folded beforehand into the per-lane link vectors instead of per-link tests.
+// One coalesced vector load brings up to 64 links of the row (lane j = link j).
+
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ __forceinline__ uint32_t add_sat(uint32_t a, uint32_t b) {   // v_add_u32 ... clamp
+  return __builtin_elementwise_add_sat(a, b);
+}
+__device__ __forceinline__ uint32_t ld_row(const uint32_t *base, uint32_t byte_off) {
+  return *(const uint32_t *)((const char *)base + byte_off);           // saddr + 32-bit voffset
+}
+__device__ __forceinline__ uint64_t ld_row64(const uint64_t *base, size_t byte_off) {
+  return *(const uint64_t *)((const char *)base + byte_off);
+}
+
+constexpr int GRP = 4;            // links per unrolled group
+constexpr int NGRP = 64 / GRP;
+
 // Distance relaxation sweep.  grid = (ceil8(ceil(n / VPB)), n_batches), block = 256.
+// MAXINF: max_path_metric == 0xFFFFFFFF (OSPF): u32 saturation must be detected.
+template <bool MAXINF>
 __global__ __launch_bounds__(256) void k_relax(GraphDev g, uint32_t *__restrict__ dist,
                                                const uint32_t *__restrict__ roots,
                                                uint32_t maxpath, uint32_t ignore_ovl,
@@ -105,42 +134,74 @@ __global__ __launch_bounds__(256) void k_relax(GraphDev g, uint32_t *__restrict_
   const uint32_t batch = blockIdx.y;
   const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
   const uint32_t vbeg = chunk * VPB + wave * VPW;
-  if (vbeg >= g.n) return;
+  const uint32_t n = g.n;
+  if (vbeg >= n) return;
+  const uint32_t *__restrict__ in_ptr = g.in_ptr;
+  const uint32_t *__restrict__ in_src = g.in_src;
+  const uint32_t *__restrict__ in_w = g.in_w;
   const uint32_t my_root = roots[batch * 64 + lane];
-  uint32_t *D = dist + (size_t)batch * g.n * 64;
+  uint32_t *D = dist + (size_t)batch * n * 64;
+  const uint32_t lane4 = lane * 4u;
+  // row bounds of the VPW vertices of this wave: one vector load, lanes 0..VPW
+  const uint32_t pv = in_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
   bool any = false, sat = false;
-#pragma unroll 1
+#pragma unroll
   for (int i = 0; i < VPW; ++i) {
     const uint32_t v = vbeg + i;
-    if (v >= g.n) break;
-    const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
-    const uint32_t d_old = D[(size_t)v * 64 + lane];
+    if (v >= n) break;
+    const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
+    const uint32_t d_old = ld_row(D, v * 256u + lane4);
     uint32_t best = d_old;
-#pragma unroll 4
-    for (uint32_t e = e0; e < e1; ++e) {
-      const uint32_t sw = g.in_src[e];
-      const uint32_t w = g.in_w[e];
-      const uint32_t u = sw & SRC_MASK;
-      const uint32_t du = D[(size_t)u * 64 + lane];
-      const bool gate = !(sw & SRC_NO_TRANSIT) || ignore_ovl || u == my_root;
-      const uint64_t c = (uint64_t)du + w;
-      if (du != INF && gate) {
-        if (c >= INF) sat = true;                // u32 saturation: not representable here
-        else if (c <= maxpath && (uint32_t)c < best) best = (uint32_t)c;
+    for (uint32_t eb = e0; eb < e1; eb += 64) {
+      const uint32_t cnt = min(64u, e1 - eb);
+      // padding lanes: (own row, cost INF) -> saturates to INF, never improves anything
+      uint32_t sv = lane < cnt ? in_src[eb + lane] : v;
+      const uint32_t wv = lane < cnt ? in_w[eb + lane] : INF;
+      // overload gating is rare: only rows that list an overloaded source take the slow path
+      const bool has_nt = !ignore_ovl && __ballot((sv & SRC_NO_TRANSIT) != 0) != 0ull;
+      if (!has_nt) sv &= SRC_MASK;
+#pragma unroll
+      for (int gi = 0; gi < NGRP; ++gi) {
+        if (cnt <= (uint32_t)(gi * GRP)) break;
+        uint32_t du[GRP];
+#pragma unroll
+        for (int k = 0; k < GRP; ++k) {
+          const uint32_t u = rdlane(sv, gi * GRP + k) & SRC_MASK;
+          du[k] = ld_row(D, u * 256u + lane4);
+        }
+#pragma unroll
+        for (int k = 0; k < GRP; ++k) {
+          const uint32_t w = rdlane(wv, gi * GRP + k);
+          uint32_t d = du[k];
+          if (has_nt) {                                           // uniform
+            const uint32_t sw = rdlane(sv, gi * GRP + k);
+            if ((sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;
+          }
+          const uint32_t c = add_sat(d, w);                       // INF stays INF
+          if (MAXINF && c == INF && d != INF && w != INF) sat = true;   // genuine u32 saturation
+          best = min(best, c);        // candidates above max_path_metric are rejected at the end
+        }
       }
     }
-    if (best < d_old) {
+    // min over all candidates: if the smallest exceeds max_path_metric, every one does
+    if (best < d_old && best <= maxpath) {
       D[(size_t)v * 64 + lane] = best;
       any = true;
     }
   }
   if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
-  if (sat && maxpath == INF) atomicOr(&lane_flags[batch * 64 + lane], LF_NEED_EXACT);
+  if (MAXINF && sat) atomicOr(&lane_flags[batch * 64 + lane], LF_NEED_EXACT);
 }
 
 // ---------------------------------------------------------------------------------------------
 // SPT-DAG sweep: hops + first-hop mask.  Same grid as k_relax.  W = mask words (template).
-template <int W>
+// GS (only W == 1): accept parents finalised in THIS launch too.  Safe without fences because a
+// final row with hops != 0 always has a non-zero mask word (every non-first-hop vertex inherits
+// at least one slot), the mask array starts at 0 and is written exactly once: a reader that sees
+// a stale or not-yet-written mask sees 0 and simply treats the parent as pending.
+// In-links of a row are stored in ascending source order (upload keeps it), so the first link
+// with the minimal parent distance IS the earliest-popped tight parent (first discoverer).
+template <int W, bool GS>
 __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restrict__ dist,
                                              uint32_t *__restrict__ hv, uint64_t *__restrict__ mask,
                                              const uint32_t *__restrict__ roots, SlotTabs tabs,
@@ -153,24 +214,29 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
   const uint32_t batch = blockIdx.y;
   const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
   const uint32_t vbeg = chunk * VPB + wave * VPW;
-  if (vbeg >= g.n) return;
+  const uint32_t n = g.n;
+  if (vbeg >= n) return;
+  const uint32_t *__restrict__ in_ptr = g.in_ptr;
+  const uint32_t *__restrict__ in_src = g.in_src;
+  const uint32_t *__restrict__ in_w = g.in_w;
   const uint32_t root_slot = batch * 64 + lane;
   const uint32_t my_root = roots[root_slot];
-  const uint32_t *D = dist + (size_t)batch * g.n * 64;
-  uint32_t *H = hv + (size_t)batch * g.n * 64;
-  uint64_t *M = mask + (size_t)batch * g.n * 64 * W;
+  const uint32_t *D = dist + (size_t)batch * n * 64;
+  uint32_t *H = hv + (size_t)batch * n * 64;
+  uint64_t *M = mask + (size_t)batch * n * 64 * W;
+  const uint32_t lane4 = lane * 4u, lane8 = lane * 8u;
+  const uint32_t pv = in_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
   bool any = false;
 #pragma unroll 1
   for (int i = 0; i < VPW; ++i) {
     const uint32_t v = vbeg + i;
-    if (v >= g.n) break;
-    const uint32_t cur = H[(size_t)v * 64 + lane];
+    if (v >= n) break;
+    const uint32_t cur = ld_row(H, v * 256u + lane4);
     const bool need0 = (cur >> HV_EPOCH_SHIFT) == 0;
     if (__ballot(need0) == 0ull) continue;               // whole row already final
-    const uint32_t dv = D[(size_t)v * 64 + lane];
+    const uint32_t dv = ld_row(D, v * 256u + lane4);
     uint32_t out_hv = 0;
-    bool done = false;
-    if (need0 && (dv == INF || v == my_root)) done = true;   // not in SPT, or the root (hops 0)
+    bool done = need0 && (dv == INF || v == my_root);    // not in SPT, or the root (hops 0)
     const bool need = need0 && !done;
     uint64_t m[W];
 #pragma unroll
@@ -178,40 +244,81 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
     if (__ballot(need) != 0ull) {
       const bool v_router = !(g.vflags[v] & 1u);
       bool pending = false, anyp = false;
-      uint32_t bk_d = INF, bk_u = INF, p0h = 0;
-      const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
-      for (uint32_t e = e0; e < e1; ++e) {
-        const uint32_t sw = g.in_src[e];
-        const uint32_t w = g.in_w[e];
-        const uint32_t u = sw & SRC_MASK;
-        const uint32_t du = D[(size_t)u * 64 + lane];
-        const bool gate = !(sw & SRC_NO_TRANSIT) || ignore_ovl || u == my_root;
-        // tight parent that pops before v in the static (distance, vertex) order
-        const bool tight = need && gate && du != INF && ((uint64_t)du + w == (uint64_t)dv) &&
-                           (du < dv || u < v);
-        if (__ballot(tight) == 0ull) continue;
-        const uint32_t hu = H[(size_t)u * 64 + lane];
-        const uint32_t hh = hu & 0xFFFFu;
-        const uint32_t eu = hu >> HV_EPOCH_SHIFT;
-        const bool ready = tight && eu != 0 && eu < epoch;   // final since an earlier launch
-        if (tight) { anyp = true; if (!ready) pending = true; }
-        if (ready && (du < bk_d || (du == bk_d && u < bk_u))) { bk_d = du; bk_u = u; p0h = hh; }
-        const bool direct = ready && hh == 0;            // parent is the root or a hops-0 network
-        const bool inherit = ready && hh != 0;
-        if (__ballot(direct) != 0ull) {
-          if (direct && (v_router || net_nexthops)) {
-            uint32_t base = (u == my_root) ? 0u : slot_base_of(tabs, root_slot, u);
-            const uint32_t s = base + g.in_fpos[e];
+      uint32_t bk_d = INF, p0h = 0;
+      const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
+      for (uint32_t eb = e0; eb < e1; eb += 64) {
+        const uint32_t cnt = min(64u, e1 - eb);
+        uint32_t sv = lane < cnt ? in_src[eb + lane] : v;
+        uint32_t wv = lane < cnt ? in_w[eb + lane] : 1u;
+        const bool has_nt = !ignore_ovl && __ballot((sv & SRC_NO_TRANSIT) != 0) != 0ull;
+        if (!has_nt) sv &= SRC_MASK;
+        // A zero-cost link from a HIGHER-numbered source is never a static-order parent; padding
+        // lanes likewise: rewrite both as (own row, cost 1), which can never be tight.
+        if (lane >= cnt || (wv == 0u && (sv & SRC_MASK) >= v)) { sv = v; wv = 1u; }
 #pragma unroll
-            for (int k = 0; k < W; ++k)
-              if ((s >> 6) == (uint32_t)k) m[k] |= 1ull << (s & 63u);
+        for (int gi = 0; gi < NGRP; ++gi) {
+          if (cnt <= (uint32_t)(gi * GRP)) break;
+          uint32_t du[GRP];
+          bool tight[GRP];
+#pragma unroll
+          for (int k = 0; k < GRP; ++k) {
+            const uint32_t u = rdlane(sv, gi * GRP + k) & SRC_MASK;
+            du[k] = ld_row(D, u * 256u + lane4);
           }
-        }
-        if (__ballot(inherit) != 0ull) {
+          bool anyt = false;
 #pragma unroll
-          for (int k = 0; k < W; ++k) {
-            const uint64_t mu = M[((size_t)u * W + k) * 64 + lane];
-            if (inherit) m[k] |= mu;
+          for (int k = 0; k < GRP; ++k) {
+            const uint32_t w = rdlane(wv, gi * GRP + k);
+            uint32_t d = du[k];
+            if (has_nt) {
+              const uint32_t sw = rdlane(sv, gi * GRP + k);
+              if ((sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;
+            }
+            // tight parent (d + w == dv without saturation; dv != INF for `need` lanes)
+            tight[k] = need && d != INF && add_sat(d, w) == dv;
+            anyt = anyt || tight[k];
+          }
+          if (__ballot(anyt) == 0ull) continue;
+          uint32_t hu[GRP];
+          uint64_t mu[GRP][W];
+#pragma unroll
+          for (int k = 0; k < GRP; ++k) {
+            const uint32_t u = rdlane(sv, gi * GRP + k) & SRC_MASK;
+            hu[k] = ld_row(H, u * 256u + lane4);
+#pragma unroll
+            for (int q = 0; q < W; ++q) mu[k][q] = ld_row64(M, ((size_t)u * W + q) * 512u + lane8);
+          }
+#pragma unroll
+          for (int k = 0; k < GRP; ++k) {
+            const uint32_t hh = hu[k] & 0xFFFFu;
+            const uint32_t eu = hu[k] >> HV_EPOCH_SHIFT;
+            bool ready;
+            if (GS) {
+              bool mz = true;
+#pragma unroll
+              for (int q = 0; q < W; ++q) mz = mz && (mu[k][q] == 0);
+              ready = tight[k] && eu != 0 && (hh == 0 || !mz);
+            } else {
+              ready = tight[k] && eu != 0 && eu < epoch;         // final since an earlier launch
+            }
+            anyp = anyp || tight[k];
+            pending = pending || (tight[k] && !ready);
+            if (ready && du[k] < bk_d) { bk_d = du[k]; p0h = hh; }
+            const bool direct = ready && hh == 0;                // parent: root or hops-0 network
+            if (__ballot(direct) != 0ull) {
+              const uint32_t u = rdlane(sv, gi * GRP + k) & SRC_MASK;
+              const uint32_t fpos = g.in_fpos[eb + gi * GRP + k];
+              if (direct && (v_router || net_nexthops)) {
+                const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(tabs, root_slot, u);
+                const uint32_t sidx = base_s + fpos;
+#pragma unroll
+                for (int q = 0; q < W; ++q)
+                  if ((sidx >> 6) == (uint32_t)q) m[q] |= 1ull << (sidx & 63u);
+              }
+            }
+            const bool inherit = ready && hh != 0;
+#pragma unroll
+            for (int q = 0; q < W; ++q) m[q] |= inherit ? mu[k][q] : 0ull;
           }
         }
       }

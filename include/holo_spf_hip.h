@@ -96,7 +96,7 @@ typedef struct hspf_graph hspf_graph;  /* device-resident graph of one LSDB gene
  *   - arrays are caller-owned host memory, borrowed for the duration of the call only.
  */
 typedef struct {
-  uint32_t        n_vertices;       /* < 2^31                                                 */
+  uint32_t        n_vertices;       /* <= 2^24                                                */
   uint32_t        n_edges;
   const uint32_t *row_ptr;          /* [n_vertices+1], row_ptr[0]==0, non-decreasing          */
   const uint32_t *col;              /* [n_edges] target vertex index                          */

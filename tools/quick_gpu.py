@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from holo_amd import synth, engine as E
 ctx = E.SpfContext(0)
 g = synth.isis_100k()
