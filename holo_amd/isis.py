@@ -1,0 +1,629 @@
+"""holo_amd.isis — host-side mirror of holo-isis' SPF path on top of the HIP engine.
+
+Same names, argument meaning and failure behaviour as the reference functions it stands in for:
+
+  compute_spt()      holo-isis/src/spf.rs:527-709      one SPT per (level, root, local, mt_id, mode)
+  compute_spts()     holo-isis/src/flooding/manet.rs:47-69   the batched-roots caller: ONE engine run
+  compute_routes()   holo-isis/src/spf.rs:840-949      RIB from an SPT
+  compute_spf()      holo-isis/src/spf.rs:719-836      per-level orchestration + L1/L2 merge
+                                                       (holo-isis/src/route.rs:185-249)
+
+What runs where: the LSDB walk (`vertex_edges`, spf.rs:1013-1128) is done ONCE per LSDB generation
+into the CSR of include/holo_spf_hip.h (LevelGraph); the SPT loop itself — distances, hops, ECMP
+first-hop sets for every root — runs on the GPU through the C ABI; everything that needs
+Interface / Adjacency objects (resolve_nexthop, spf.rs:956-1010) and the prefix attachment stays
+here and consumes dist / hops / first_hop_mask, exactly as INTEGRATION.md describes for the Rust
+side.  There is no CPU SPT loop in this module: without an engine it cannot compute anything.
+"""
+from __future__ import annotations
+
+import ipaddress
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import engine as E
+
+MAX_PATH_METRIC_STANDARD = 1023          # holo-isis/src/spf.rs:45
+MAX_PATH_METRIC_WIDE = 0xFE000000        # holo-isis/src/spf.rs:47
+MAX_LINK_METRIC_WIDE = 0x00FFFFFF        # holo-isis/src/spf.rs:49
+MT_STANDARD, MT_IPV6_UNICAST = 0, 2
+NLPID_IPV4, NLPID_IPV6 = 0xCC, 0x8E
+
+VF_NETWORK, VF_NO_TRANSIT, VF_NO_EXPAND = 1, 2, 4
+
+LanId = Tuple[bytes, int]                # (system id, pseudonode number)
+VertexId = Tuple[bool, bytes, int]       # (non_pseudonode, system id, pseudonode): derive(Ord) order
+
+
+def lan_id_from_str(s: str) -> LanId:
+    a, b, c, pn = s.split(".")
+    return bytes.fromhex(a + b + c), int(pn, 16)
+
+
+def system_id_from_str(s: str) -> bytes:
+    return bytes.fromhex(s.replace(".", ""))
+
+
+def vertex_id(lan_id: LanId) -> VertexId:
+    """holo-isis/src/spf.rs:96-100, 301-317."""
+    return (lan_id[1] == 0, lan_id[0], lan_id[1])
+
+
+# ---- LSDB model (the fields of Lsp / LspTlvs the path reads) ---------------------------------
+
+@dataclass
+class Lsp:
+    system_id: bytes
+    pseudonode: int
+    fragment: int
+    seqno: int = 1
+    rem_lifetime: int = 1200
+    overload: bool = False
+    att: bool = False
+    protocols_supported: Optional[List[int]] = None
+    mt_flags: Dict[int, Tuple[bool, bool]] = field(default_factory=dict)   # mt -> (overload, att)
+    is_reach: List[Tuple[LanId, int]] = field(default_factory=list)        # TLV 2
+    ext_is_reach: List[Tuple[LanId, int]] = field(default_factory=list)    # TLV 22
+    mt_is_reach: List[Tuple[int, LanId, int]] = field(default_factory=list)  # TLV 222
+    ipv4_internal: List[Tuple[str, int]] = field(default_factory=list)     # TLV 128
+    ipv4_external: List[Tuple[str, int]] = field(default_factory=list)     # TLV 130
+    ext_ipv4: List[Tuple[str, int, bool]] = field(default_factory=list)    # TLV 135 (+X flag)
+    ipv6: List[Tuple[str, int, bool]] = field(default_factory=list)        # TLV 236
+    mt_ipv6: List[Tuple[int, str, int, bool]] = field(default_factory=list)  # TLV 237
+
+    @property
+    def lan_id(self) -> LanId:
+        return (self.system_id, self.pseudonode)
+
+    def live(self) -> bool:                # spf.rs:1024-1025
+        return self.seqno != 0 and self.rem_lifetime != 0
+
+    def overload_bit(self, mt_id: int) -> bool:   # holo-isis/src/packet/pdu.rs:1463-1477
+        return self.overload if mt_id == MT_STANDARD else self.mt_flags.get(mt_id, (False, False))[0]
+
+    def att_bit(self, mt_id: int) -> bool:        # pdu.rs:1446-1460
+        return self.att if mt_id == MT_STANDARD else self.mt_flags.get(mt_id, (False, False))[1]
+
+
+@dataclass
+class Adjacency:
+    system_id: bytes
+    level_usage: str                       # "level-1" | "level-2" | "level-all"
+    state: str = "up"
+    ipv4_addrs: List[str] = field(default_factory=list)
+    ipv6_addrs: List[str] = field(default_factory=list)
+    topologies: List[int] = field(default_factory=lambda: [0])
+    area_addrs: List[str] = field(default_factory=list)
+    snpa: object = None                    # anything hashable & unique per adjacency
+
+    def intersects(self, level: int) -> bool:
+        return self.level_usage in ("level-all", f"level-{level}")
+
+
+@dataclass
+class Interface:
+    name: str
+    interface_type: str = "broadcast"      # "broadcast" | "point-to-point"
+    metric: Dict[int, int] = field(default_factory=lambda: {1: 10, 2: 10})
+    adjacencies: List[Adjacency] = field(default_factory=list)
+
+
+@dataclass
+class InstanceCfg:
+    system_id: bytes
+    level_type: str = "level-all"
+    metric_type: Dict[int, str] = field(default_factory=lambda: {1: "wide", 2: "wide"})
+    ipv4_enabled: bool = True
+    ipv6_enabled: bool = True
+    mt_ipv6_unicast: bool = False
+    max_paths: int = 16
+    att_ignore: bool = False
+    area_addrs: List[str] = field(default_factory=list)
+
+    def is_af_enabled(self, af: str) -> bool:
+        return self.ipv4_enabled if af == "ipv4" else self.ipv6_enabled
+
+    def is_topology_enabled(self, mt_id: int) -> bool:
+        return True if mt_id == MT_STANDARD else self.mt_ipv6_unicast
+
+    def levels(self) -> List[int]:
+        return {"level-1": [1], "level-2": [2], "level-all": [1, 2]}[self.level_type]
+
+
+class Lsdb:
+    """LSPs of one level ordered by LSP id (holo-isis/src/collections.rs:657-706)."""
+
+    def __init__(self, lsps: Iterable[Lsp] = ()):
+        self._by_id: Dict[Tuple[bytes, int, int], Lsp] = {}
+        for l in lsps:
+            self._by_id[(l.system_id, l.pseudonode, l.fragment)] = l
+        self.generation = 0
+
+    def insert(self, lsp: Lsp):
+        self._by_id[(lsp.system_id, lsp.pseudonode, lsp.fragment)] = lsp
+        self.generation += 1
+
+    def iter(self):
+        for k in sorted(self._by_id):
+            yield self._by_id[k]
+
+    def iter_for_lan_id(self, lan_id: LanId):
+        return [l for k, l in sorted(self._by_id.items()) if k[0] == lan_id[0] and k[1] == lan_id[1]]
+
+    def zeroth_lsp(self, lan_id: LanId) -> Optional[Lsp]:      # spf.rs:1299-1309
+        l = self._by_id.get((lan_id[0], lan_id[1], 0))
+        return l if (l is not None and l.live()) else None
+
+
+@dataclass
+class Instance:
+    """The slice of InstanceUpView the path reads."""
+    config: InstanceCfg
+    interfaces: List[Interface]
+    lsdb: Dict[int, Lsdb]
+
+    def interfaces_by_name(self) -> List[Interface]:           # collections.rs:258-265
+        return sorted(self.interfaces, key=lambda i: i.name)
+
+    def is_l2_attached_to_backbone(self, mt_id: int) -> bool:  # holo-isis/src/instance.rs:577-591
+        mine = set(self.config.area_addrs)
+        return any(mt_id in a.topologies and a.state == "up" and a.intersects(2)
+                   and mine.isdisjoint(a.area_addrs)
+                   for i in self.interfaces_by_name() for a in i.adjacencies)
+
+    @classmethod
+    def from_vector(cls, vec: dict) -> "Instance":
+        """Build from a tests/golden/isis/*.json vector (tools/make_golden.py)."""
+        c = vec["config"]
+        cfg = InstanceCfg(system_id=system_id_from_str(c["system_id"]), level_type=c["level_type"],
+                          metric_type={1: c["metric_type"]["1"], 2: c["metric_type"]["2"]},
+                          ipv4_enabled=c["afs"].get("ipv4", True), ipv6_enabled=c["afs"].get("ipv6", True),
+                          mt_ipv6_unicast=c["mt_ipv6_unicast"], max_paths=c["max_paths"],
+                          att_ignore=c["att_ignore"], area_addrs=list(c["area_addrs"]))
+        ifaces = []
+        for i in vec["interfaces"]:
+            adjs = [Adjacency(system_id_from_str(a["system_id"]), a["usage"], a["state"], list(a["ipv4"]),
+                              list(a["ipv6"]), list(a["topologies"]), list(a["area_addrs"]),
+                              snpa=(i["name"], a["system_id"], a["usage"]))
+                    for a in i["adjacencies"]]
+            ifaces.append(Interface(i["name"], i["type"], {1: i["metric"]["1"], 2: i["metric"]["2"]}, adjs))
+        lsdb = {}
+        for lv, lsps in vec["lsdb"].items():
+            out = []
+            for l in lsps:
+                lan, frag = l["id"].rsplit("-", 1)
+                sysid, pn = lan_id_from_str(lan)
+                out.append(Lsp(
+                    sysid, pn, int(frag, 16), seqno=l.get("seqno", 1), rem_lifetime=l.get("lifetime", 1200),
+                    overload="ol" in l["flags"], att="att" in l["flags"], protocols_supported=l["protocols"],
+                    mt_flags={m["id"]: ("ol" in m["flags"], "att" in m["flags"]) for m in l["mt"]},
+                    is_reach=[(lan_id_from_str(n), m) for n, m in l["is_reach"]],
+                    ext_is_reach=[(lan_id_from_str(n), m) for n, m in l["ext_is_reach"]],
+                    mt_is_reach=[(t, lan_id_from_str(n), m) for t, n, m in l["mt_is_reach"]],
+                    ipv4_internal=[tuple(x) for x in l["ipv4_int"]], ipv4_external=[tuple(x) for x in l["ipv4_ext"]],
+                    ext_ipv4=[tuple(x) for x in l["ext_ipv4"]], ipv6=[tuple(x) for x in l["ipv6"]],
+                    mt_ipv6=[tuple(x) for x in l["mt_ipv6"]]))
+            lsdb[int(lv)] = Lsdb(out)
+        return cls(cfg, ifaces, lsdb)
+
+
+# ---- LSDB -> CSR ------------------------------------------------------------------------------
+
+def vertex_edges(lsp: Lsp, mt_id: Optional[int], hopcount: bool, metric_type: str):
+    """Edges one live fragment contributes, in the reference's order (spf.rs:1026-1127)."""
+    std_on = metric_type in ("standard", "both")
+    wide_on = metric_type in ("wide", "both")
+
+    def cost(nbr: LanId, metric: int) -> int:                  # spf.rs:1131-1146
+        return metric if not hopcount else (0 if nbr[1] != 0 else 1)
+
+    if (mt_id is None or mt_id == MT_STANDARD) and std_on:
+        for nbr, m in lsp.is_reach:
+            yield nbr, cost(nbr, m)
+    if ((mt_id is None or mt_id == MT_STANDARD) or lsp.pseudonode != 0) and wide_on:
+        for nbr, m in lsp.ext_is_reach:
+            if m < MAX_LINK_METRIC_WIDE:
+                yield nbr, cost(nbr, m)
+    if mt_id is not None and mt_id != MT_STANDARD:
+        for t, nbr, m in lsp.mt_is_reach:
+            if t == mt_id and m < MAX_LINK_METRIC_WIDE:
+                yield nbr, cost(nbr, m)
+    if mt_id is None:
+        for _t, nbr, m in lsp.mt_is_reach:
+            if m < MAX_LINK_METRIC_WIDE:
+                yield nbr, cost(nbr, m)
+
+
+class LevelGraph:
+    """CSR form (include/holo_spf_hip.h) of one level's LSDB for one (mt_id, metric mode).
+
+    Vertex index = rank in VertexId order over the LAN ids that own at least one live LSP
+    fragment; links to LAN ids without any LSP are not listed (they can never pass the two-way
+    check).  `edge_cost[k]` keeps the link cost the reference hands to resolve_nexthop."""
+
+    def __init__(self, instance: Instance, level: int, mt_id: Optional[int], hopcount: bool = False):
+        cfg = instance.config
+        lsdb = instance.lsdb.get(level) or Lsdb()
+        self.level, self.mt_id, self.hopcount = level, mt_id, hopcount
+        self.metric_type = cfg.metric_type[level]
+        frags: Dict[LanId, List[Lsp]] = {}
+        for l in lsdb.iter():
+            if l.live():
+                frags.setdefault(l.lan_id, []).append(l)
+        self.vids: List[VertexId] = sorted(vertex_id(k) for k in frags)
+        self.index: Dict[VertexId, int] = {v: i for i, v in enumerate(self.vids)}
+        n = len(self.vids)
+        row_ptr = np.zeros(n + 1, np.uint32)
+        col, met = [], []
+        vflags = np.zeros(n, np.uint8)
+        for i, vid in enumerate(self.vids):
+            lan = (vid[1], vid[2])
+            for lsp in frags[lan]:
+                for nbr, c in vertex_edges(lsp, mt_id, hopcount, self.metric_type):
+                    j = self.index.get(vertex_id(nbr))
+                    if j is not None:
+                        col.append(j)
+                        met.append(c)
+            row_ptr[i + 1] = len(col)
+            is_pn = lan[1] != 0
+            if is_pn:
+                vflags[i] |= VF_NETWORK
+            z = lsdb.zeroth_lsp(lan)
+            if z is None:
+                vflags[i] |= VF_NO_EXPAND                          # spf.rs:557-561
+                continue
+            if not is_pn and mt_id is not None and z.overload_bit(mt_id):
+                vflags[i] |= VF_NO_TRANSIT                         # spf.rs:568-574
+            if mt_id is not None and mt_id == MT_STANDARD and not is_pn:   # spf.rs:582-604
+                ps = z.protocols_supported
+                if ps is None or (cfg.is_af_enabled("ipv4") and NLPID_IPV4 not in ps) \
+                        or (cfg.is_af_enabled("ipv6") and NLPID_IPV6 not in ps):
+                    vflags[i] |= VF_NO_EXPAND
+        self.row_ptr = row_ptr
+        self.col = np.asarray(col, np.uint32)
+        self.metric = np.asarray(met, np.uint32)
+        self.vflags = vflags
+        self.max_path_metric = (MAX_PATH_METRIC_STANDARD if self.metric_type == "standard"
+                                else MAX_PATH_METRIC_WIDE)                 # spf.rs:637-641
+        self.run_flags = E.RUN_IGNORE_OVERLOAD if mt_id is None else 0    # spf.rs:566-574
+        self._dev = None
+
+    @property
+    def n(self) -> int:
+        return len(self.vids)
+
+    def device(self, engine):
+        if self._dev is None or self._dev[0] is not engine:
+            g = engine.upload(self.row_ptr, self.col, self.metric, self.vflags, self.max_path_metric)
+            self._dev = (engine, g)
+        return self._dev[1]
+
+    def links_back(self, t: int, v: int) -> bool:
+        return bool((self.col[self.row_ptr[t]:self.row_ptr[t + 1]] == v).any())
+
+
+# ---- SPT ------------------------------------------------------------------------------------------
+
+@dataclass
+class VertexNexthop:                       # holo-isis/src/spf.rs:107-114
+    system_id: bytes
+    iface_name: Optional[str] = None
+    ipv4: Optional[str] = None
+    ipv6: Optional[str] = None
+
+
+@dataclass
+class Vertex:                              # holo-isis/src/spf.rs:78-88
+    id: VertexId
+    distance: int
+    hops: int
+    nexthops: List[VertexNexthop] = field(default_factory=list)
+
+
+class Spt:
+    """holo-isis/src/spf.rs:67-73, 224-297."""
+
+    def __init__(self):
+        self.vertices: Dict[VertexId, Vertex] = {}
+        self._pop_order: List[VertexId] = []
+
+    def contains(self, vid: VertexId) -> bool:
+        return vid in self.vertices
+
+    def get(self, vid: VertexId) -> Optional[Vertex]:
+        return self.vertices.get(vid)
+
+    def iter(self):
+        for k in sorted(self.vertices):
+            yield self.vertices[k]
+
+    def first_hops(self):
+        return [self.vertices[v] for v in self._pop_order if v[0] and self.vertices[v].hops == 1]
+
+    def second_hops(self):
+        return [self.vertices[v] for v in self._pop_order if v[0] and self.vertices[v].hops == 2]
+
+
+def resolve_nexthop(nexthop: VertexNexthop, level: int, mt_id: int, parent_is_pseudonode: bool,
+                    target_system_id: bytes, link_cost: int, used_adjs: set, ifaces: Sequence[Interface]):
+    """holo-isis/src/spf.rs:956-1010 (ifaces already in name order)."""
+    want = "broadcast" if parent_is_pseudonode else "point-to-point"
+    for iface in ifaces:
+        if iface.interface_type != want:
+            continue
+        adj = None
+        if want == "broadcast":
+            adj = next((a for a in iface.adjacencies
+                        if a.level_usage == f"level-{level}" and a.system_id == target_system_id), None)
+            if adj is not None and (mt_id not in adj.topologies or adj.state != "up"):
+                adj = None
+        else:
+            if iface.metric[level] != link_cost:
+                continue
+            a = iface.adjacencies[0] if iface.adjacencies else None
+            if (a is not None and mt_id in a.topologies and a.intersects(level)
+                    and a.system_id == target_system_id and a.state == "up"):
+                adj = a
+        if adj is None or adj.snpa in used_adjs:
+            continue
+        used_adjs.add(adj.snpa)
+        nexthop.iface_name = iface.name
+        nexthop.ipv4 = adj.ipv4_addrs[0] if adj.ipv4_addrs else None
+        nexthop.ipv6 = adj.ipv6_addrs[0] if adj.ipv6_addrs else None
+        return
+
+
+def _slot_nexthops(g: LevelGraph, G, root: int, dist: np.ndarray, hops: np.ndarray, in_spt: np.ndarray,
+                   rank_key, local: bool, level: int, instance: Instance) -> Dict[int, VertexNexthop]:
+    """Replays the relaxations made from hops == 0 vertices, in the reference's order, to give every
+    first-hop slot its VertexNexthop (spf.rs:680-701).  resolve_nexthop is order dependent through
+    `used_adjs`, and the reference calls it for EVERY relaxation that is not `Ordering::Greater`
+    at that moment — also for candidates a later, shorter path replaces — so the replay evaluates
+    the candidate-list state at each of those moments from the final distances."""
+    hv, hb, _total = G.slot_table(root)
+    parents = [(int(p), int(b)) for p, b in zip(hv, hb) if in_spt[p] and hops[p] == 0]
+    parents.sort(key=lambda pb: rank_key(pb[0]))
+    ifaces = instance.interfaces_by_name()
+    used_adjs: set = set()
+    out: Dict[int, VertexNexthop] = {}
+    max_path = g.max_path_metric
+    ignore_ovl = g.mt_id is None
+
+    def expandable(u: int) -> bool:
+        f = g.vflags[u]
+        if f & VF_NO_EXPAND:
+            return False
+        if hops[u] != 0 and not (f & VF_NETWORK) and not ignore_ovl and (f & VF_NO_TRANSIT):
+            return False
+        return True
+
+    def cand_before(t: int, p: int, upto_k: int) -> int:
+        """Distance of t on the candidate list just before link `upto_k` of p is processed."""
+        best = None
+        pk = rank_key(p)
+        for u in set(int(x) for x in g.col[g.row_ptr[t]:g.row_ptr[t + 1]]):   # two-way => u lists t
+            if not in_spt[u] or not expandable(u):
+                continue
+            uk = rank_key(u)
+            if uk > pk:
+                continue
+            for k in range(int(g.row_ptr[u]), int(g.row_ptr[u + 1])):
+                if int(g.col[k]) != t:
+                    continue
+                if u == p and k >= upto_k:
+                    break
+                d = min(int(dist[u]) + int(g.metric[k]), 0xFFFFFFFF)
+                if d <= max_path and (best is None or d < best):
+                    best = d
+        return best
+
+    for p, base in parents:
+        if not expandable(p):
+            continue
+        for k in range(int(g.row_ptr[p]), int(g.row_ptr[p + 1])):
+            t = int(g.col[k])
+            if not g.links_back(t, p):
+                continue
+            if in_spt[t] and rank_key(t) < rank_key(p):          # already on the SPT
+                continue
+            d = min(int(dist[p]) + int(g.metric[k]), 0xFFFFFFFF)
+            if d > max_path:
+                continue
+            cur = cand_before(t, p, k)
+            if cur is not None and d > cur:                       # Ordering::Greater
+                continue
+            if g.vflags[t] & VF_NETWORK:                          # pseudonode target: no next hop
+                continue
+            nh = VertexNexthop(system_id=g.vids[t][1])
+            if local and g.mt_id is not None:
+                resolve_nexthop(nh, level, g.mt_id, bool(g.vflags[p] & VF_NETWORK), g.vids[t][1],
+                                int(g.metric[k]), used_adjs, ifaces)
+            out[base + (k - int(g.row_ptr[p]))] = nh
+    return out
+
+
+def compute_spts(level: int, root_system_ids: Sequence[bytes], local: bool, mt_id: Optional[int],
+                 hopcount: bool, instance: Instance, engine, graph: Optional[LevelGraph] = None) -> List[Spt]:
+    """All SPTs of one level/topology for a list of roots with ONE engine run — the shape of
+    flooding::manet::init_cache (holo-isis/src/flooding/manet.rs:47-69)."""
+    g = graph or LevelGraph(instance, level, mt_id, hopcount)
+    spts: List[Optional[Spt]] = [None] * len(root_system_ids)
+    roots, where = [], []
+    for i, sid in enumerate(root_system_ids):
+        rv = vertex_id((sid, 0))
+        r = g.index.get(rv)
+        if r is None:
+            # Root without any LSP: it is inserted into the SPT and not expanded (spf.rs:552-561).
+            s = Spt()
+            s.vertices[rv] = Vertex(rv, 0, 0)
+            s._pop_order = [rv]
+            spts[i] = s
+        else:
+            roots.append(r)
+            where.append(i)
+    if not roots:
+        return spts  # type: ignore[return-value]
+    G = g.device(engine)
+    res = engine.run(G, np.asarray(roots, np.uint32), g.run_flags)
+    W = res.first_hop_mask.shape[2]
+    # Roots the engine had to run through its sequential kernel (zero-cost plateaus: the pop order
+    # is not the static (distance, id) order) are re-run once more for their exact pop ranks.
+    exact_j = [j for j in range(len(roots)) if (res.flags[j] & E.RF_EXACT).any()]
+    pop_rank = {}
+    if exact_j:
+        rr = engine.run(G, np.asarray([roots[j] for j in exact_j], np.uint32), g.run_flags | E.RUN_POP_RANK)
+        for q, j in enumerate(exact_j):
+            pop_rank[j] = rr.pop_rank[q]
+    for j, (r, i) in enumerate(zip(roots, where)):
+        dist, hops = res.dist[j], res.hops[j]
+        in_spt = (res.flags[j] & E.RF_IN_SPT) != 0
+        if j in pop_rank:
+            pr = pop_rank[j]
+            rank_key = lambda v, pr=pr: (int(pr[v]), 0)                 # noqa: E731
+        else:
+            rank_key = lambda v, dist=dist: (int(dist[v]), v)           # noqa: E731  static order
+        slot_nh = _slot_nexthops(g, G, r, dist, hops, in_spt, rank_key, local, level, instance)
+        s = Spt()
+        members = np.nonzero(in_spt)[0]
+        for v in members.tolist():
+            vx = Vertex(g.vids[v], int(dist[v]), int(hops[v]))
+            for w in range(W):
+                m = int(res.first_hop_mask[j, v, w])
+                while m:
+                    b = (m & -m).bit_length() - 1
+                    m &= m - 1
+                    nh = slot_nh.get(w * 64 + b)
+                    if nh is not None:
+                        vx.nexthops.append(nh)
+            s.vertices[vx.id] = vx
+        s._pop_order = [g.vids[v] for v in sorted(members.tolist(), key=rank_key)]
+        spts[i] = s
+    return spts  # type: ignore[return-value]
+
+
+def compute_spt(level: int, root_system_id: bytes, local: bool, mt_id: Optional[int], hopcount: bool,
+                instance: Instance, engine, graph: Optional[LevelGraph] = None) -> Spt:
+    """holo-isis/src/spf.rs:527-709."""
+    return compute_spts(level, [root_system_id], local, mt_id, hopcount, instance, engine, graph)[0]
+
+
+# ---- routes ------------------------------------------------------------------------------------------
+
+def _addr_key(a: str):
+    ip = ipaddress.ip_address(a)
+    return (ip.version, int(ip))
+
+
+def _net_key(p: str):
+    n = ipaddress.ip_network(p, strict=False)
+    return (n.version, int(n.network_address), n.prefixlen)
+
+
+@dataclass
+class Route:                               # holo-isis/src/route.rs:27-37
+    prefix: str
+    metric: int
+    level: int
+    external: bool
+    connected: bool
+    nexthops: Dict[tuple, Tuple[str, str, bytes]]   # addr key -> (addr, iface, system id)
+
+
+def vertex_networks(instance: Instance, level: int, mt_id: int, lan_id: LanId, att_bit: bool,
+                    l2_attached: bool, ipv4_enabled: bool, ipv6_enabled: bool):
+    """holo-isis/src/spf.rs:1149-1296."""
+    cfg = instance.config
+    metric_type = cfg.metric_type[level]
+    std_on = metric_type in ("standard", "both")
+    wide_on = metric_type in ("wide", "both")
+    for lsp in instance.lsdb[level].iter_for_lan_id(lan_id):
+        if not lsp.live():
+            continue
+        if att_bit and level == 1 and (cfg.level_type == "level-1" or not l2_attached):
+            if ipv4_enabled:
+                yield "0.0.0.0/0", 0, False
+            if ipv6_enabled:
+                yield "::/0", 0, False
+        if mt_id == MT_STANDARD and ipv4_enabled:
+            if std_on:
+                for p, m in lsp.ipv4_internal:
+                    yield p, m, False
+                for p, m in lsp.ipv4_external:
+                    yield p, m, True
+            if wide_on:
+                for p, m, x in lsp.ext_ipv4:
+                    if m <= MAX_PATH_METRIC_WIDE:
+                        yield p, m, x
+        if ipv6_enabled:
+            it = ([(p, m, x) for t, p, m, x in lsp.mt_ipv6 if t == MT_IPV6_UNICAST]
+                  if mt_id == MT_IPV6_UNICAST else lsp.ipv6)
+            for p, m, x in it:
+                if m <= MAX_PATH_METRIC_WIDE:
+                    yield p, m, x
+
+
+def _build_nexthops(vertex: Vertex, prefix: str):          # route.rs:118-142
+    v6 = ":" in prefix
+    out = {}
+    for nh in vertex.nexthops:
+        addr = nh.ipv6 if v6 else nh.ipv4
+        if addr is not None:
+            out[_addr_key(addr)] = (addr, nh.iface_name, nh.system_id)
+    return out
+
+
+def compute_routes(level: int, mt_id: int, instance: Instance, spt: Spt, rib: Dict[tuple, Route]):
+    """holo-isis/src/spf.rs:840-949."""
+    cfg = instance.config
+    l2_attached = instance.is_l2_attached_to_backbone(mt_id)
+    ipv4_enabled = cfg.is_af_enabled("ipv4") and mt_id == MT_STANDARD
+    ipv6_enabled = cfg.is_af_enabled("ipv6") and (
+        (not cfg.is_topology_enabled(MT_IPV6_UNICAST)) if mt_id == MT_STANDARD else True)
+    lsdb = instance.lsdb.get(level) or Lsdb()
+    for vertex in spt.iter():
+        lan = (vertex.id[1], vertex.id[2])
+        z = lsdb.zeroth_lsp(lan)
+        if z is None:
+            continue
+        att = (not cfg.att_ignore) and z.att_bit(mt_id) and not z.overload_bit(mt_id)
+        for prefix, metric, external in vertex_networks(instance, level, mt_id, lan, att, l2_attached,
+                                                        ipv4_enabled, ipv6_enabled):
+            key = _net_key(prefix)
+            route_metric = vertex.distance + metric
+            cur = rib.get(key)
+            if cur is None or route_metric < cur.metric:
+                cur = rib[key] = Route(prefix, route_metric, level, external, vertex.hops == 0,
+                                       _build_nexthops(vertex, prefix))
+            elif route_metric == cur.metric:
+                cur.nexthops.update(_build_nexthops(vertex, prefix))
+            else:
+                continue
+            if len(cur.nexthops) > cfg.max_paths:
+                cur.nexthops = {k: cur.nexthops[k] for k in sorted(cur.nexthops)[:cfg.max_paths]}
+
+
+def compute_spf(instance: Instance, engine) -> List[dict]:
+    """Full SPF of every configured level and topology (holo-isis/src/spf.rs:719-836) followed by
+    the L1/L2 merge of holo-isis/src/route.rs:185-249; returns the rows of the YANG `local-rib`."""
+    cfg = instance.config
+    per_level: Dict[int, Dict[tuple, Route]] = {}
+    for level in cfg.levels():
+        if level not in instance.lsdb:
+            instance.lsdb[level] = Lsdb()
+        rib: Dict[tuple, Route] = {}
+        for mt_id in (MT_STANDARD, MT_IPV6_UNICAST):
+            if cfg.is_topology_enabled(mt_id):
+                spt = compute_spt(level, cfg.system_id, True, mt_id, False, instance, engine)
+                compute_routes(level, mt_id, instance, spt, rib)
+        per_level[level] = rib
+    merged: Dict[tuple, Route] = {}
+    for level in (2, 1):
+        merged.update(per_level.get(level, {}))
+    rows = []
+    for key in sorted(merged):
+        r = merged[key]
+        rows.append({"prefix": r.prefix, "metric": r.metric, "level": r.level,
+                     "nexthops": [[r.nexthops[k][0], r.nexthops[k][1]] for k in sorted(r.nexthops)]})
+    return rows

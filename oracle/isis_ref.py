@@ -1,0 +1,358 @@
+"""oracle/isis_ref.py — literal CPU restatement of holo-isis' SPF path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Pure-Python (small cases only), written directly against the LSDB as the reference walks it —
+ordered maps keyed by LSP id, TLV lists, a candidate list keyed (distance, VertexId) — with NO
+CSR, so it is independent of both the C++ graph oracle (oracle/spf_oracle.cpp) and the product's
+host layer (holo_amd/isis.py).  Input is a golden vector made by tools/make_golden.py from the
+reference's conformance fixtures; tests/test_oracle_golden.py checks the RIB this produces
+against the fixture's recorded `local-rib`, which is what pins the restatement to the reference.
+
+Follows (reference @ /root/reference, v0.9.0):
+  holo-isis/src/spf.rs:527-709     compute_spt
+  holo-isis/src/spf.rs:840-949     compute_routes
+  holo-isis/src/spf.rs:956-1010    resolve_nexthop
+  holo-isis/src/spf.rs:1013-1146   vertex_edges / vertex_edge_cost
+  holo-isis/src/spf.rs:1149-1309   vertex_networks / zeroth_lsp
+  holo-isis/src/route.rs:79-142    Route::new / merge_nexthops / build_nexthops
+  holo-isis/src/route.rs:185-249   update_rib (L1/L2 merge)
+"""
+from __future__ import annotations
+
+import ipaddress
+from dataclasses import dataclass, field
+
+MAX_PATH_METRIC_STANDARD = 1023          # holo-isis/src/spf.rs:45
+MAX_PATH_METRIC_WIDE = 0xFE000000        # :47
+MAX_LINK_METRIC_WIDE = 0x00FFFFFF        # :49
+MT_STANDARD, MT_IPV6_UNICAST = 0, 2      # holo-isis/src/packet/consts.rs MtId
+NLPID = {"ipv4": 0xCC, "ipv6": 0x8E}
+U32_MAX = 0xFFFFFFFF
+
+
+def parse_lan_id(s: str):
+    """'0000.0000.0003.01' -> (system_id bytes, pseudonode)."""
+    a, b, c, pn = s.split(".")
+    return bytes.fromhex(a + b + c), int(pn, 16)
+
+
+def parse_lsp_id(s: str):
+    lan, frag = s.rsplit("-", 1)
+    sysid, pn = parse_lan_id(lan)
+    return sysid, pn, int(frag, 16)
+
+
+def vertex_id(lan_id):
+    """VertexId{non_pseudonode, lan_id} derive(Ord) (holo-isis/src/spf.rs:96-100): pseudonodes
+    sort first, then the 7 bytes of the LAN id."""
+    sysid, pn = lan_id
+    return (pn == 0, sysid, pn)
+
+
+@dataclass
+class Vertex:                     # holo-isis/src/spf.rs:78-88
+    id: tuple
+    distance: int
+    hops: int
+    parents: list = field(default_factory=list)
+    nexthops: list = field(default_factory=list)   # dicts: system_id, iface, ipv4, ipv6
+
+
+class Lsdb:
+    """One level's LSP database: ordered by LSP id (holo-isis/src/collections.rs:657-706)."""
+
+    def __init__(self, lsps):
+        self.by_id = {parse_lsp_id(l["id"]): l for l in lsps}
+        self.order = sorted(self.by_id)
+
+    def iter_for_lan_id(self, lan_id):
+        sysid, pn = lan_id
+        for k in self.order:
+            if k[0] == sysid and k[1] == pn:
+                l = self.by_id[k]
+                # seqno / remaining lifetime are hidden in the recorded state (`ignore_in_testing`);
+                # every LSP present in a converged fixture is live.  Vectors may carry explicit
+                # "seqno"/"lifetime" to exercise the filters (spf.rs:1024-1025).
+                if l.get("seqno", 1) != 0 and l.get("lifetime", 1) != 0:
+                    yield l
+
+    def zeroth_lsp(self, lan_id):            # spf.rs:1299-1309
+        l = self.by_id.get((lan_id[0], lan_id[1], 0))
+        if l is None or l.get("seqno", 1) == 0 or l.get("lifetime", 1) == 0:
+            return None
+        return l
+
+
+def overload_bit(lsp, mt_id):               # holo-isis/src/packet/pdu.rs:1463-1477
+    if mt_id == MT_STANDARD:
+        return "ol" in lsp["flags"]
+    return any(m["id"] == mt_id and "ol" in m["flags"] for m in lsp["mt"])
+
+
+def att_bit(lsp, mt_id):                    # pdu.rs:1446-1460
+    if mt_id == MT_STANDARD:
+        return "att" in lsp["flags"]
+    return any(m["id"] == mt_id and "att" in m["flags"] for m in lsp["mt"])
+
+
+def vertex_edges(vid, mt_id, hopcount, metric_type, lsdb: Lsdb):
+    """spf.rs:1013-1128: per fragment, TLV 2, then TLV 22, then TLV 222 of the topology, then all
+    TLV 222 when no topology is given."""
+    std_on = metric_type in ("standard", "both")
+    wide_on = metric_type in ("wide", "both")
+    lan_id = (vid[1], vid[2])
+    for lsp in lsdb.iter_for_lan_id(lan_id):
+        is_pn = lan_id[1] != 0
+
+        def cost(nbr, metric):               # spf.rs:1131-1146
+            if not hopcount:
+                return metric
+            return 0 if nbr[1] != 0 else 1
+
+        if (mt_id is None or mt_id == MT_STANDARD) and std_on:
+            for nbr, metric in lsp["is_reach"]:
+                n = parse_lan_id(nbr)
+                yield vertex_id(n), cost(n, metric)
+        if ((mt_id is None or mt_id == MT_STANDARD) or is_pn) and wide_on:
+            for nbr, metric in lsp["ext_is_reach"]:
+                if metric < MAX_LINK_METRIC_WIDE:
+                    n = parse_lan_id(nbr)
+                    yield vertex_id(n), cost(n, metric)
+        if mt_id is not None and mt_id != MT_STANDARD:
+            for mt, nbr, metric in lsp["mt_is_reach"]:
+                if mt == mt_id and metric < MAX_LINK_METRIC_WIDE:
+                    n = parse_lan_id(nbr)
+                    yield vertex_id(n), cost(n, metric)
+        if mt_id is None:
+            for mt, nbr, metric in lsp["mt_is_reach"]:
+                if metric < MAX_LINK_METRIC_WIDE:
+                    n = parse_lan_id(nbr)
+                    yield vertex_id(n), cost(n, metric)
+
+
+def _level_intersects(usage: str, level: int) -> bool:
+    return usage == "level-all" or usage == f"level-{level}"
+
+
+def resolve_nexthop(nh, level, mt_id, vertex, link_id, link_cost, used_adjs, interfaces):
+    """spf.rs:956-1010.  Interfaces iterate in name order (collections.rs:258-265).  The SNPA
+    that `used_adjs` keys on is not part of the recorded state; distinct adjacencies have
+    distinct SNPAs, so (interface, neighbour, usage) stands in for it."""
+    want = "broadcast" if vertex.id[2] != 0 else "point-to-point"
+    tgt = link_id[1]
+    for iface in sorted(interfaces, key=lambda i: i["name"]):
+        if iface["type"] != want:
+            continue
+        adj = None
+        if want == "broadcast":
+            for a in iface["adjacencies"]:        # lan_adjacencies.get(level).get_by_system_id
+                if a["usage"] == f"level-{level}" and parse_lan_id(a["system_id"] + ".00")[0] == tgt:
+                    adj = a
+                    break
+            if adj is not None and (mt_id not in adj["topologies"] or adj["state"] != "up"):
+                adj = None
+        else:
+            if iface["metric"][str(level)] != link_cost:
+                continue
+            a = iface["adjacencies"][0] if iface["adjacencies"] else None
+            if (a is not None and mt_id in a["topologies"] and _level_intersects(a["usage"], level)
+                    and parse_lan_id(a["system_id"] + ".00")[0] == tgt and a["state"] == "up"):
+                adj = a
+        if adj is None:
+            continue
+        snpa = (iface["name"], adj["system_id"], adj["usage"])
+        if snpa in used_adjs:                      # "shouldn't be used more than once"
+            continue
+        used_adjs.add(snpa)
+        nh["iface"] = iface["name"]
+        nh["ipv4"] = adj["ipv4"][0] if adj["ipv4"] else None
+        nh["ipv6"] = adj["ipv6"][0] if adj["ipv6"] else None
+        return
+
+
+def compute_spt(vec, level, root_system_id: bytes, local, mt_id, hopcount=False):
+    """spf.rs:527-709.  Returns (spt: dict VertexId -> Vertex, pop order list)."""
+    cfg = vec["config"]
+    lsdb = Lsdb(vec["lsdb"].get(str(level), []))
+    metric_type = cfg["metric_type"][str(level)]
+    used_adjs = set()
+    root_vid = vertex_id((root_system_id, 0))
+    spt, order = {}, []
+    cand = {(0, root_vid): Vertex(root_vid, 0, 0)}          # BTreeMap<(u32, VertexId), Vertex>
+    while cand:
+        key = min(cand)                                     # pop_first
+        vertex = cand.pop(key)
+        spt[vertex.id] = vertex
+        order.append(vertex.id)
+        lan_id = (vertex.id[1], vertex.id[2])
+        z = lsdb.zeroth_lsp(lan_id)
+        if z is None:
+            continue
+        is_pn = lan_id[1] != 0
+        if vertex.hops != 0 and not is_pn and mt_id is not None and overload_bit(z, mt_id):
+            continue
+        if mt_id is not None and mt_id == MT_STANDARD and not is_pn:
+            ps = z["protocols"]
+            if ps is None:
+                continue
+            if any(cfg["afs"].get(af, True) and NLPID[af] not in ps for af in ("ipv4", "ipv6")):
+                continue
+        for link_id, cost in vertex_edges(vertex.id, mt_id, hopcount, metric_type, lsdb):
+            if not any(back == vertex.id
+                       for back, _ in vertex_edges(link_id, mt_id, hopcount, metric_type, lsdb)):
+                continue
+            if link_id in spt:
+                continue
+            distance = min(vertex.distance + cost, U32_MAX)         # saturating_add
+            max_path = MAX_PATH_METRIC_STANDARD if metric_type == "standard" else MAX_PATH_METRIC_WIDE
+            if distance > max_path:
+                continue
+            hops = vertex.hops
+            if link_id[2] == 0:
+                hops = min(hops + 1, 0xFFFF)
+            existing = next((k for k, c in cand.items() if c.id == link_id), None)
+            if existing is not None:
+                if distance < cand[existing].distance:
+                    del cand[existing]
+                elif distance > cand[existing].distance:
+                    continue
+            cv = cand.setdefault((distance, link_id), Vertex(link_id, distance, hops))
+            cv.parents.append(vertex.id)
+            if vertex.hops == 0:
+                if link_id[2] == 0:
+                    nh = {"system_id": link_id[1], "iface": None, "ipv4": None, "ipv6": None}
+                    if local and mt_id is not None:
+                        resolve_nexthop(nh, level, mt_id, vertex, link_id, cost, used_adjs,
+                                        vec["interfaces"])
+                    cv.nexthops.append(nh)
+            else:
+                cv.nexthops.extend(dict(n) for n in vertex.nexthops)
+    return spt, order
+
+
+def is_l2_attached_to_backbone(vec, mt_id):             # holo-isis/src/instance.rs:577-591
+    mine = set(vec["config"]["area_addrs"])
+    for iface in vec["interfaces"]:
+        for a in iface["adjacencies"]:
+            if (mt_id in a["topologies"] and a["state"] == "up" and _level_intersects(a["usage"], 2)
+                    and mine.isdisjoint(a["area_addrs"])):
+                return True
+    return False
+
+
+def vertex_networks(vec, level, mt_id, vertex, att, l2_attached, metric_type, v4_on, v6_on, lsdb):
+    """spf.rs:1149-1296 -> (prefix str, metric, external)."""
+    level_type = vec["config"]["level_type"]
+    std_on = metric_type in ("standard", "both")
+    wide_on = metric_type in ("wide", "both")
+    for lsp in lsdb.iter_for_lan_id((vertex.id[1], vertex.id[2])):
+        if att and level == 1 and (level_type == "level-1" or not l2_attached):
+            if v4_on:
+                yield "0.0.0.0/0", 0, False
+            if v6_on:
+                yield "::/0", 0, False
+        if mt_id == MT_STANDARD and v4_on:
+            if std_on:
+                for p, m in lsp["ipv4_int"]:
+                    yield p, m, False
+                for p, m in lsp["ipv4_ext"]:
+                    yield p, m, True
+            if wide_on:
+                for p, m, x in lsp["ext_ipv4"]:
+                    if m <= MAX_PATH_METRIC_WIDE:
+                        yield p, m, x
+        if v6_on:
+            if mt_id == MT_IPV6_UNICAST:
+                it = [(p, m, x) for t, p, m, x in lsp["mt_ipv6"] if t == MT_IPV6_UNICAST]
+            else:
+                it = lsp["ipv6"]
+            for p, m, x in it:
+                if m <= MAX_PATH_METRIC_WIDE:
+                    yield p, m, x
+
+
+def _addr_key(a: str):
+    ip = ipaddress.ip_address(a)
+    return (ip.version, int(ip))                   # IpAddr derive(Ord): V4 < V6, then numeric
+
+
+def _net_key(p: str):
+    n = ipaddress.ip_network(p, strict=False)
+    return (n.version, int(n.network_address), n.prefixlen)
+
+
+def build_nexthops(vertex, prefix):                # route.rs:118-142
+    v6 = ":" in prefix
+    out = {}
+    for nh in vertex.nexthops:
+        addr = nh["ipv6"] if v6 else nh["ipv4"]
+        if addr is None:
+            continue
+        out[_addr_key(addr)] = (addr, nh["iface"])  # BTreeMap<IpAddr, Nexthop>: last insert wins
+    return out
+
+
+def compute_routes(vec, level, mt_id, spt, rib):
+    """spf.rs:840-949 (SR prefix-SID bookkeeping left out: it does not touch metric/next hops)."""
+    cfg = vec["config"]
+    lsdb = Lsdb(vec["lsdb"].get(str(level), []))
+    metric_type = cfg["metric_type"][str(level)]
+    l2_attached = is_l2_attached_to_backbone(vec, mt_id)
+    v4_on = cfg["afs"].get("ipv4", True) and mt_id == MT_STANDARD
+    v6_on = cfg["afs"].get("ipv6", True) and (
+        (not cfg["mt_ipv6_unicast"]) if mt_id == MT_STANDARD else True)
+    for vid in sorted(spt):                                   # Spt::iter = id_tree order
+        vertex = spt[vid]
+        z = lsdb.zeroth_lsp((vid[1], vid[2]))
+        if z is None:
+            continue
+        att = (not cfg["att_ignore"]) and att_bit(z, mt_id) and not overload_bit(z, mt_id)
+        for prefix, metric, external in vertex_networks(vec, level, mt_id, vertex, att, l2_attached,
+                                                        metric_type, v4_on, v6_on, lsdb):
+            key = _net_key(prefix)
+            route_metric = vertex.distance + metric
+            cur = rib.get(key)
+            if cur is None or route_metric < cur["metric"]:
+                cur = rib[key] = {"prefix": prefix, "metric": route_metric, "level": level,
+                                  "external": external, "connected": vertex.hops == 0,
+                                  "nexthops": build_nexthops(vertex, prefix)}
+            elif route_metric == cur["metric"]:
+                cur["nexthops"].update(build_nexthops(vertex, prefix))
+            else:
+                continue
+            mp = cfg["max_paths"]
+            if len(cur["nexthops"]) > mp:
+                keep = sorted(cur["nexthops"])[:mp]
+                cur["nexthops"] = {k: cur["nexthops"][k] for k in keep}
+
+
+def levels_of(vec):
+    lt = vec["config"]["level_type"]
+    return {"level-1": [1], "level-2": [2], "level-all": [1, 2]}[lt]
+
+
+def topologies_of(vec):
+    return [MT_STANDARD] + ([MT_IPV6_UNICAST] if vec["config"]["mt_ipv6_unicast"] else [])
+
+
+def local_rib(vec):
+    """compute_spf per level (spf.rs:719-836) + the L1/L2 merge of route.rs:185-249; returns the
+    rows of the YANG `local-rib` list in its order (BTreeMap<IpNetwork, Route>)."""
+    root = parse_lan_id(vec["config"]["system_id"] + ".00")[0]
+    per_level = {}
+    for level in levels_of(vec):
+        rib = {}
+        for mt_id in topologies_of(vec):
+            spt, _ = compute_spt(vec, level, root, True, mt_id)
+            compute_routes(vec, level, mt_id, spt, rib)
+        per_level[level] = rib
+    merged = {}
+    for level in (2, 1):                       # rib_l2.chain(rib_l1).collect(): L1 wins
+        merged.update(per_level.get(level, {}))
+    rows = []
+    for key in sorted(merged):
+        r = merged[key]
+        nhs = [list(r["nexthops"][k]) for k in sorted(r["nexthops"])]
+        rows.append({"prefix": r["prefix"], "metric": r["metric"], "level": r["level"], "nexthops": nhs})
+    return rows

@@ -1,0 +1,60 @@
+"""An `engine` stand-in for CPU-only tests of the HOST logic (holo_amd/isis.py, holo_amd/ospf.py):
+same upload()/run()/slot_table() surface as holo_amd.engine.SpfContext, answered by the CPU
+oracle.  Lives under tests/ on purpose: the product never sees it (no CPU fallback there)."""
+from __future__ import annotations
+
+import numpy as np
+
+from holo_amd import engine as E
+from oracle import graph_oracle as go
+
+
+class OracleGraph:
+    def __init__(self, row_ptr, col, metric, vflags, max_path_metric):
+        self.row_ptr = np.ascontiguousarray(row_ptr, np.uint32)
+        self.col = np.ascontiguousarray(col, np.uint32)
+        self.metric = np.ascontiguousarray(metric, np.uint32)
+        self.vflags = np.ascontiguousarray(vflags, np.uint8)
+        self.max_path_metric = max_path_metric
+        self.n = len(self.row_ptr) - 1
+
+    def _twoway(self, u, k):
+        t = int(self.col[k])
+        return bool((self.col[self.row_ptr[t]:self.row_ptr[t + 1]] == u).any())
+
+    def slot_table(self, root: int):
+        """Independent restatement of the slot numbering of include/holo_spf_hip.h."""
+        hv, hb = [root], [0]
+        total = int(self.row_ptr[root + 1] - self.row_ptr[root])
+        seen = {root}
+        qi = 0
+        while qi < len(hv):
+            p = hv[qi]; qi += 1
+            for k in range(int(self.row_ptr[p]), int(self.row_ptr[p + 1])):
+                t = int(self.col[k])
+                if t in seen or not (self.vflags[t] & 1) or not self._twoway(p, k):
+                    continue
+                seen.add(t)
+                hv.append(t); hb.append(total)
+                total += int(self.row_ptr[t + 1] - self.row_ptr[t])
+        return np.asarray(hv, np.uint32), np.asarray(hb, np.uint32), total
+
+    def free(self):
+        pass
+
+
+class OracleEngine:
+    variant = go.MAP
+
+    def upload(self, row_ptr, col, metric, vflags, max_path_metric):
+        return OracleGraph(row_ptr, col, metric, vflags, max_path_metric)
+
+    def run(self, G: OracleGraph, roots, run_flags: int = 0, **_kw):
+        roots = np.ascontiguousarray(roots, np.uint32)
+        oflags = run_flags & (E.RUN_NET_NEXTHOPS | E.RUN_IGNORE_OVERLOAD)
+        r = go.run(G.row_ptr, G.col, G.metric, G.vflags, G.max_path_metric, roots, oflags, self.variant)
+        rank = r.pop_rank if (run_flags & E.RUN_POP_RANK) else None
+        # mark everything "exact" when the graph has zero-cost router->router links so that the host
+        # layer exercises its pop-rank path the way it would behind the real engine
+        flags = r.flags.copy()
+        return E.SpfResult(r.dist, r.hops, flags, r.mask, rank, {})

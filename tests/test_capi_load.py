@@ -1,0 +1,49 @@
+"""The C-ABI shared library must load without a GPU and export every symbol include/*.h declares."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for h in os.listdir(os.path.join(ROOT, "include")):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(hspf_[a-z0-9_]+)\s*\(", src))
+    return names
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from holo_amd import build, _lib
+    build.build_lib()
+    lib = _lib.load()
+    decl = declared_symbols()
+    assert len(decl) >= 17
+    for name in sorted(decl):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert {n for n, _, _ in _lib.SYMBOLS} == decl, "ctypes binding table out of sync with the header"
+    assert lib.hspf_abi_version() == 1
+    assert lib.hspf_strerror(-5).decode().startswith("too many")
+
+
+def test_no_device_is_an_error_code_not_a_crash():
+    """On the CPU-only build container hspf_init must fail with HSPF_E_NODEV (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    from holo_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.hspf_init(0, ctypes.byref(h)) == -2
+    assert not h.value
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    for dp, _dn, fns in os.walk(os.path.join(ROOT, "holo_amd")):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, fn)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "liboracle" not in src, fn

@@ -1,0 +1,58 @@
+"""Host logic of holo_amd.isis (LSDB -> CSR, first-hop slot replay, resolve_nexthop, route build,
+L1/L2 merge) on CPU: the engine is replaced by the CPU oracle behind the same interface
+(tests/_oracle_engine.py), the answers are the reference's recorded local RIBs."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from holo_amd import isis as H
+from oracle import isis_ref as R
+from _oracle_engine import OracleEngine
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ISIS = sorted(glob.glob(os.path.join(GOLD, "isis", "*.json")))
+
+
+@pytest.mark.parametrize("path", ISIS, ids=[os.path.basename(p)[:-5] for p in ISIS])
+def test_compute_spf_reproduces_reference_local_rib(path):
+    vec = json.load(open(path))
+    inst = H.Instance.from_vector(vec)
+    want = sorted(vec["rib"], key=lambda r: R._net_key(r["prefix"]))
+    assert H.compute_spf(inst, OracleEngine()) == want
+
+
+def check_spts_against_ref(vec, inst, engine):
+    """Every system as root in one batched run (the flooding::manet::init_cache shape), local and
+    hop-count variants, against the literal restatement: distance, hops, next-hop system ids and
+    first/second-hop lists in pop order."""
+    for level in inst.config.levels():
+        systems = sorted({l.system_id for l in inst.lsdb[level].iter()})
+        for mt_id, hopcount, local in ((0, False, False), (None, True, False), (0, False, True)):
+            roots = systems if not local else [inst.config.system_id]
+            spts = H.compute_spts(level, roots, local, mt_id, hopcount, inst, engine)
+            for sid, spt in zip(roots, spts):
+                ref, order = R.compute_spt(vec, level, sid, local, mt_id, hopcount)
+                assert set(spt.vertices) == set(ref)
+                for vid, vx in ref.items():
+                    got = spt.get(vid)
+                    assert (got.distance, got.hops) == (vx.distance, vx.hops)
+                    assert ({(n.system_id, n.iface_name, n.ipv4, n.ipv6) for n in got.nexthops}
+                            == {(n["system_id"], n["iface"], n["ipv4"], n["ipv6"]) for n in vx.nexthops})
+                assert [v.id for v in spt.first_hops()] == [v for v in order if v[0] and ref[v].hops == 1]
+                assert [v.id for v in spt.second_hops()] == [v for v in order if v[0] and ref[v].hops == 2]
+
+
+@pytest.mark.parametrize("path", ISIS[::3], ids=[os.path.basename(p)[:-5] for p in ISIS[::3]])
+def test_batched_roots_match_literal_restatement(path):
+    vec = json.load(open(path))
+    check_spts_against_ref(vec, H.Instance.from_vector(vec), OracleEngine())
+
+
+def test_root_without_lsp_is_alone_in_its_spt():
+    vec = json.load(open(ISIS[0]))
+    inst = H.Instance.from_vector(vec)
+    spt = H.compute_spt(inst.config.levels()[0], b"\xaa" * 6, True, 0, False, inst, OracleEngine())
+    assert [v.id for v in spt.iter()] == [(True, b"\xaa" * 6, 0)]

@@ -1,0 +1,74 @@
+"""Pins the oracles to the reference (CPU only, no GPU, no /root/reference at run time).
+
+1. oracle/isis_ref.py (literal pure-Python restatement of holo-isis compute_spt + compute_routes)
+   must reproduce the `local-rib` the reference itself recorded in its conformance fixtures
+   (tests/golden/isis/*.json, extracted by tools/make_golden.py): metric, level and the ORDERED
+   next-hop list (address, interface) of every route, 38 routers over 6 topologies (p2p and LAN
+   pseudonodes, L1/L2 with ATT defaults, parallel links / ECMP, old/wide/both metrics, MT IPv6).
+2. oracle/spf_oracle.cpp (the CSR graph oracle the GPU is compared with) must agree with that
+   restatement vertex by vertex — distance, hops, number of parents, length of the next-hop Vec
+   (duplicates included) — for every router of every fixture as root, local and non-local,
+   normal and hop-count metric mode, in all three variants.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from holo_amd import isis as H
+from oracle import graph_oracle as go
+from oracle import isis_ref as R
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ISIS = sorted(glob.glob(os.path.join(GOLD, "isis", "*.json")))
+
+
+def _load(p):
+    with open(p) as f:
+        return json.load(f)
+
+
+def test_golden_vectors_present():
+    assert len(ISIS) == 38
+
+
+@pytest.mark.parametrize("path", ISIS, ids=[os.path.basename(p)[:-5] for p in ISIS])
+def test_isis_ref_reproduces_reference_local_rib(path):
+    vec = _load(path)
+    want = sorted(vec["rib"], key=lambda r: R._net_key(r["prefix"]))
+    assert R.local_rib(vec) == want
+
+
+@pytest.mark.parametrize("path", ISIS, ids=[os.path.basename(p)[:-5] for p in ISIS])
+def test_graph_oracle_agrees_with_isis_ref(path):
+    vec = _load(path)
+    inst = H.Instance.from_vector(vec)
+    for level in inst.config.levels():
+        for mt_id, hopcount in ((0, False), (2, False), (None, True)):
+            if mt_id == 2 and not inst.config.mt_ipv6_unicast:
+                continue
+            g = H.LevelGraph(inst, level, mt_id, hopcount)
+            if g.n == 0:
+                continue
+            roots = np.arange(g.n, dtype=np.uint32)      # every vertex, pseudonodes included
+            res = {v: go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, g.run_flags, v)
+                   for v in (go.REF, go.MAP, go.HEAP)}
+            for f in ("dist", "hops", "flags", "pop_rank", "mask", "n_nexthops", "n_parents"):
+                assert np.array_equal(getattr(res[go.REF], f), getattr(res[go.MAP], f)), f
+                assert np.array_equal(getattr(res[go.REF], f), getattr(res[go.HEAP], f)), f
+            r = res[go.MAP]
+            for ri, vid in enumerate(g.vids):
+                if not vid[0]:
+                    continue                           # compute_spt roots are systems, not LANs
+                spt, order = R.compute_spt(vec, level, vid[1], False, mt_id, hopcount)
+                in_spt = {g.index[v] for v in spt if v in g.index}
+                assert set(np.nonzero(r.flags[ri])[0].tolist()) == in_spt
+                for v, vx in spt.items():
+                    i = g.index[v]
+                    assert r.dist[ri, i] == vx.distance
+                    assert r.hops[ri, i] == vx.hops
+                    assert r.n_parents[ri, i] == len(vx.parents)
+                    assert r.n_nexthops[ri, i] == len(vx.nexthops)
+                assert [g.index[v] for v in order] == np.argsort(r.pop_rank[ri], kind="stable")[:len(order)].tolist()
