@@ -1,0 +1,312 @@
+"""holo_amd.ospf — host-side mirror of holo-ospf's OSPFv2 SPF path on top of the HIP engine.
+
+  run_area()               holo-ospf/src/spf.rs:587-729        one SPT per area, root = self
+  calc_nexthops()          holo-ospf/src/spf.rs:733-767 + holo-ospf/src/ospfv2/spf.rs:172-353
+  intra_area_networks()    holo-ospf/src/ospfv2/spf.rs:462-538
+  update_rib_intra_area()  holo-ospf/src/route.rs:343-448 (+ route_update :918-965)
+
+The LSA walk (`vertex_lsa_find` / `vertex_lsa_links`, ospfv2/spf.rs:355-460) is done once per LSDB
+generation into the CSR of include/holo_spf_hip.h (AreaGraph); the SPT loop runs on the GPU
+(HSPF_RUN_NET_NEXTHOPS semantics: a network reached from a hops == 0 parent owns a first-hop
+slot); `calc_nexthops`, which needs Interface / Neighbor objects, is evaluated here once per
+first-hop slot and OR-ed through the per-vertex slot masks.  No CPU SPT loop lives here.
+"""
+from __future__ import annotations
+
+import ipaddress
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import engine as E
+
+NET, RTR = 0, 1                       # enum VertexId { Network, Router } derive(Ord), ospfv2/spf.rs:41-45
+VF_NETWORK = 1
+MAX_PATH_METRIC_OSPF = 0xFFFFFFFF     # u32 saturating add, holo-ospf/src/spf.rs:672
+
+VertexId = Tuple[int, int]
+
+
+def ip(s: str) -> int:
+    return int(ipaddress.IPv4Address(s))
+
+
+@dataclass
+class RouterLink:                     # LsaRouterLink
+    link_type: str                    # point-to-point-link | transit-network-link | stub-network-link | virtual-link
+    link_id: str
+    link_data: str
+    metric: int
+
+
+@dataclass
+class RouterLsa:
+    adv_rtr: str
+    links: List[RouterLink]
+    bits: List[str] = field(default_factory=list)
+    maxage: bool = False
+
+
+@dataclass
+class NetworkLsa:
+    lsa_id: str
+    adv_rtr: str
+    mask: str
+    attached: List[str]
+    maxage: bool = False
+
+
+@dataclass
+class Neighbor:
+    router_id: str
+    src: str
+
+
+@dataclass
+class Interface:
+    name: str
+    if_type: str = "broadcast"        # point-to-point | broadcast | point-to-multipoint | virtual-link
+    index: int = 0                    # arena slot: first component of NexthopKey (route.rs:92-98)
+    neighbors: List[Neighbor] = field(default_factory=list)
+    addrs: List[str] = field(default_factory=list)
+
+
+@dataclass
+class Area:
+    area_id: str
+    routers: List[RouterLsa]
+    networks: List[NetworkLsa]
+    interfaces: List[Interface]
+
+    @classmethod
+    def from_vector(cls, a: dict) -> "Area":
+        return cls(a["area_id"],
+                   [RouterLsa(r["adv_rtr"], [RouterLink(k["type"], k["id"], k["data"], k["metric"]) for k in r["links"]],
+                              r.get("bits", [])) for r in a["routers"]],
+                   [NetworkLsa(n["lsa_id"], n["adv_rtr"], n["mask"], n["attached"]) for n in a["networks"]],
+                   [Interface(i["name"], i["type"], i["index"], [Neighbor(n["router_id"], n["src"]) for n in i["neighbors"]],
+                              i.get("addrs", [])) for i in a["interfaces"]])
+
+
+@dataclass
+class Vertex:                          # holo-ospf/src/spf.rs:38-46
+    id: VertexId
+    lsa: object
+    distance: int
+    hops: int
+    nexthops: Dict[tuple, tuple] = field(default_factory=dict)   # (iface idx, addr|-1) -> (iface name, addr|None)
+
+
+class AreaGraph:
+    """CSR of one area's Router-/Network-LSAs.  Vertex index = rank in VertexId order (all networks,
+    then all routers, numeric).  link_pos / link_ref keep, per CSR entry, what Ospfv2::calc_nexthops
+    needs from `SpfLink.parent` (the position among the non-stub links BEFORE the existence filter,
+    ospfv2/spf.rs:439-456, and the link itself)."""
+
+    def __init__(self, area: Area):
+        self.area = area
+        self.routers: Dict[int, RouterLsa] = {ip(l.adv_rtr): l for l in area.routers if not l.maxage}
+        nets: Dict[int, NetworkLsa] = {}
+        # vertex_lsa_find for a network: FIRST Network-LSA in (adv_rtr, lsa_id) order whose LS-ID
+        # matches, then dropped if MaxAge (ospfv2/spf.rs:362-373)
+        for l in sorted(area.networks, key=lambda l: (ip(l.adv_rtr), ip(l.lsa_id))):
+            nets.setdefault(ip(l.lsa_id), l)
+        self.networks = {k: l for k, l in nets.items() if not l.maxage}
+        self.vids: List[VertexId] = sorted([(NET, k) for k in self.networks] + [(RTR, k) for k in self.routers])
+        self.index = {v: i for i, v in enumerate(self.vids)}
+        n = len(self.vids)
+        row_ptr = np.zeros(n + 1, np.uint32)
+        col, met, self.link_pos, self.link_ref = [], [], [], []
+        for i, vid in enumerate(self.vids):
+            if vid[0] == NET:
+                for r in sorted(ip(a) for a in self.networks[vid[1]].attached):
+                    j = self.index.get((RTR, r))
+                    if j is not None:
+                        col.append(j); met.append(0); self.link_pos.append(-1); self.link_ref.append(None)
+            else:
+                pos = -1
+                for link in self.routers[vid[1]].links:
+                    if link.link_type in ("point-to-point-link", "virtual-link"):
+                        tid = (RTR, ip(link.link_id))
+                    elif link.link_type == "transit-network-link":
+                        tid = (NET, ip(link.link_id))
+                    else:
+                        continue
+                    pos += 1
+                    j = self.index.get(tid)
+                    if j is not None:
+                        col.append(j); met.append(link.metric); self.link_pos.append(pos); self.link_ref.append(link)
+            row_ptr[i + 1] = len(col)
+        self.row_ptr = row_ptr
+        self.col = np.asarray(col, np.uint32)
+        self.metric = np.asarray(met, np.uint32)
+        self.vflags = np.asarray([VF_NETWORK if v[0] == NET else 0 for v in self.vids], np.uint8)
+        self._dev = None
+
+    def lsa_of(self, v: int):
+        vid = self.vids[v]
+        return self.networks[vid[1]] if vid[0] == NET else self.routers[vid[1]]
+
+    def device(self, engine):
+        if self._dev is None or self._dev[0] is not engine:
+            self._dev = (engine, engine.upload(self.row_ptr, self.col, self.metric, self.vflags, MAX_PATH_METRIC_OSPF))
+        return self._dev[1]
+
+
+def calc_nexthops(g: AreaGraph, parent: Vertex, k: int, dest: VertexId, dest_lsa) -> Optional[dict]:
+    """Ospfv2::calc_nexthops for a hops == 0 parent and CSR entry k (ospfv2/spf.rs:172-353).
+    None = Err(SpfNexthopCalcError), which the reference logs and skips (spf.rs:717-718)."""
+    out: Dict[tuple, tuple] = {}
+    if parent.id[0] == RTR:
+        pos = g.link_pos[k]
+        cands = [i for i in sorted(g.area.interfaces, key=lambda i: i.name) if len(i.neighbors) > 0]
+        if pos >= len(cands):
+            return None
+        iface = cands[pos]
+        if iface.if_type == "virtual-link":
+            return out
+        if dest[0] == RTR:
+            if iface.if_type in ("point-to-point", "virtual-link"):
+                nbr = next((n for n in iface.neighbors if ip(n.router_id) == dest[1]), None)
+                if nbr is None:
+                    return None
+                out[(iface.index, ip(nbr.src))] = (iface.name, nbr.src)
+            elif iface.if_type == "point-to-multipoint":
+                for link in dest_lsa.links:
+                    if any(ipaddress.IPv4Address(link.link_data) in ipaddress.ip_network(a, strict=False)
+                           for a in iface.addrs):
+                        out[(iface.index, ip(link.link_data))] = (iface.name, link.link_data)
+            if not out:
+                return None
+        else:
+            out[(iface.index, -1)] = (iface.name, None)
+        return out
+    try:
+        net = ipaddress.ip_network((parent.lsa.lsa_id, parent.lsa.mask), strict=False)
+    except ValueError:
+        return None
+    link = next((l for l in dest_lsa.links if ipaddress.IPv4Address(l.link_data) in net), None)
+    if link is None or not parent.nexthops:
+        return None
+    first_key = min(parent.nexthops)
+    out[(first_key[0], ip(link.link_data))] = (parent.nexthops[first_key][0], link.link_data)
+    return out
+
+
+def run_area(router_id: str, area: Area, engine, graph: Optional[AreaGraph] = None):
+    """holo-ospf/src/spf.rs:587-729 -> dict VertexId -> Vertex (the area's SPT), or None when the
+    root's Router-LSA is missing (Error::SpfRootNotFound is logged and the run returns, :605-610)."""
+    g = graph or AreaGraph(area)
+    root_vid = (RTR, ip(router_id))
+    root = g.index.get(root_vid)
+    if root is None:
+        return None
+    G = g.device(engine)
+    res = engine.run(G, np.asarray([root], np.uint32), E.RUN_NET_NEXTHOPS)
+    dist, hops = res.dist[0], res.hops[0]
+    in_spt = (res.flags[0] & E.RF_IN_SPT) != 0
+    mask = res.first_hop_mask[0]
+    hv, hb, _tot = G.slot_table(root)
+    hv, hb = [int(x) for x in hv], [int(x) for x in hb]
+    spt: Dict[VertexId, Vertex] = {}
+    slot_cache: Dict[int, Optional[dict]] = {}
+
+    def slots_of(v: int):
+        for w in range(mask.shape[1]):
+            m = int(mask[v, w])
+            while m:
+                b = (m & -m).bit_length() - 1
+                m &= m - 1
+                yield w * 64 + b
+
+    def vertex(v: int) -> Vertex:
+        vid = g.vids[v]
+        vx = spt.get(vid)
+        if vx is not None:
+            return vx
+        vx = Vertex(vid, g.lsa_of(v), int(dist[v]), int(hops[v]))
+        for s in slots_of(v):
+            nh = resolve_slot(s)
+            if nh:
+                vx.nexthops.update(nh)
+        spt[vid] = vx
+        return vx
+
+    def resolve_slot(s: int) -> Optional[dict]:
+        if s in slot_cache:
+            return slot_cache[s]
+        i = int(np.searchsorted(hb, s, side="right")) - 1
+        p, k = hv[i], int(g.row_ptr[hv[i]]) + (s - hb[i])
+        t = int(g.col[k])
+        slot_cache[s] = calc_nexthops(g, vertex(p), k, g.vids[t], g.lsa_of(t))
+        return slot_cache[s]
+
+    # distance order guarantees parents (hops == 0 networks) are materialised before children
+    for v in sorted(np.nonzero(in_spt)[0].tolist(), key=lambda v: (int(dist[v]), v)):
+        vertex(v)
+    return spt
+
+
+def intra_area_networks(spt: Dict[VertexId, Vertex]):          # ospfv2/spf.rs:462-538
+    for vid in sorted(spt):
+        v = spt[vid]
+        if vid[0] == NET:
+            try:
+                n = ipaddress.ip_network((v.lsa.lsa_id, v.lsa.mask), strict=False)
+            except ValueError:
+                continue
+            yield v, str(n), 0, ip(v.lsa.lsa_id)
+        else:
+            for link in v.lsa.links:
+                if link.link_type != "stub-network-link":
+                    continue
+                try:
+                    n = ipaddress.ip_network((link.link_id, link.link_data), strict=False)
+                except ValueError:
+                    continue
+                yield v, str(n), link.metric, ip(v.lsa.adv_rtr)
+
+
+def _net_key(p: str):
+    n = ipaddress.ip_network(p, strict=False)
+    return (int(n.network_address), n.prefixlen)
+
+
+def update_rib_intra_area(rib: dict, spt: Dict[VertexId, Vertex], max_paths: int):   # route.rs:343-448
+    for v, prefix, smetric, origin_id in intra_area_networks(spt):
+        key = _net_key(prefix)
+        metric = min(v.distance + smetric, 0xFFFFFFFF)
+        cur = rib.get(key)
+        if cur is not None and metric > cur["metric"]:
+            continue
+        if v.id[0] == NET and cur is not None:
+            if metric < cur["metric"] or (metric == cur["metric"] and origin_id > cur["origin"]):
+                del rib[key]
+            else:
+                continue
+        new = {"prefix": prefix, "metric": metric, "origin": origin_id, "connected": v.hops == 0,
+               "nexthops": dict(v.nexthops)}
+        cur = rib.get(key)                                        # route_update, route.rs:918-965
+        if cur is None or new["metric"] < cur["metric"]:
+            cur = rib[key] = new
+        elif new["metric"] == cur["metric"]:
+            cur["nexthops"].update(new["nexthops"])
+        if len(cur["nexthops"]) > max_paths:
+            cur["nexthops"] = {k: cur["nexthops"][k] for k in sorted(cur["nexthops"])[:max_paths]}
+
+
+def compute_spf_intra_area(router_id: str, areas: List[Area], max_paths: int, engine) -> List[dict]:
+    """The SPT + intra-area part of compute_spf (holo-ospf/src/spf.rs:489-584, route.rs:146-160):
+    areas in area-id order, one run_area each; rows like the YANG `local-rib` list."""
+    rib: dict = {}
+    for area in sorted(areas, key=lambda a: ip(a.area_id)):
+        spt = run_area(router_id, area, engine)
+        if spt is not None:
+            update_rib_intra_area(rib, spt, max_paths)
+    rows = []
+    for key in sorted(rib):
+        r = rib[key]
+        rows.append({"prefix": r["prefix"], "metric": r["metric"], "type": "intra-area",
+                     "nexthops": [[r["nexthops"][k][1], r["nexthops"][k][0]] for k in sorted(r["nexthops"])]})
+    return rows

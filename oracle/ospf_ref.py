@@ -1,0 +1,220 @@
+"""oracle/ospf_ref.py — literal CPU restatement of holo-ospf's OSPFv2 SPF path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Pure Python on the LSDB as the reference walks it (no CSR).  Input: a tests/golden/ospfv2 vector
+(tools/make_golden_ospf.py).  tests/test_oracle_golden.py checks the intra-area routes this
+produces against the `local-rib` the reference recorded, which pins the restatement.
+
+Follows (reference @ /root/reference, v0.9.0):
+  holo-ospf/src/spf.rs:587-729          run_area
+  holo-ospf/src/spf.rs:733-767          calc_nexthops (generic)
+  holo-ospf/src/ospfv2/spf.rs:41-45     VertexId order (networks before routers)
+  holo-ospf/src/ospfv2/spf.rs:172-353   Ospfv2::calc_nexthops
+  holo-ospf/src/ospfv2/spf.rs:355-460   vertex_lsa_find / vertex_lsa_links
+  holo-ospf/src/ospfv2/spf.rs:462-538   intra_area_networks
+  holo-ospf/src/route.rs:343-448        update_rib_intra_area
+  holo-ospf/src/route.rs:918-994        route_update / route_compare
+"""
+from __future__ import annotations
+
+import ipaddress
+from dataclasses import dataclass, field
+
+U32_MAX = 0xFFFFFFFF
+NET, RTR = 0, 1                 # enum VertexId { Network, Router } derive(Ord)
+
+
+def ip(s: str) -> int:
+    return int(ipaddress.IPv4Address(s))
+
+
+@dataclass
+class Vertex:                   # holo-ospf/src/spf.rs:38-46
+    id: tuple                   # (NET|RTR, u32 address)
+    lsa: dict
+    distance: int
+    hops: int
+    nexthops: dict = field(default_factory=dict)     # NexthopKey (iface index, addr|None) -> nexthop
+
+
+class AreaDb:
+    def __init__(self, area: dict):
+        self.area = area
+        self.routers = {ip(l["adv_rtr"]): l for l in area["routers"]}
+        # iter_by_type: LsaKey{type, adv_rtr, lsa_id} order (holo-ospf/src/packet/lsa.rs:44-56)
+        self.networks = sorted(area["networks"], key=lambda l: (ip(l["adv_rtr"]), ip(l["lsa_id"])))
+
+    def vertex_lsa_find(self, vid):                   # ospfv2/spf.rs:355-387
+        kind, addr = vid
+        if kind == NET:
+            return next((l for l in self.networks if ip(l["lsa_id"]) == addr), None)
+        return self.routers.get(addr)
+
+    def vertex_lsa_links(self, vid, lsa):             # ospfv2/spf.rs:389-460
+        """-> (parent_link (pos, link) | None, link vertex id, link lsa, cost)"""
+        if vid[0] == NET:
+            for r in sorted(ip(a) for a in lsa["attached"]):      # BTreeSet<Ipv4Addr>
+                l = self.vertex_lsa_find((RTR, r))
+                if l is not None:
+                    yield None, (RTR, r), l, 0
+            return
+        pos = -1
+        for link in lsa["links"]:
+            if link["type"] in ("point-to-point-link", "virtual-link"):
+                tid = (RTR, ip(link["id"]))
+            elif link["type"] == "transit-network-link":
+                tid = (NET, ip(link["id"]))
+            else:
+                continue                                # stub links: no position consumed
+            pos += 1
+            l = self.vertex_lsa_find(tid)
+            if l is not None:
+                yield (pos, link), tid, l, link["metric"]
+
+
+def calc_nexthops_v2(db: AreaDb, parent: Vertex, parent_link, dest_id, dest_lsa):
+    """ospfv2/spf.rs:172-353.  Returns dict or None (= Err, logged by the caller)."""
+    out = {}
+    if parent.id[0] == RTR:
+        pos, _ = parent_link
+        cands = [i for i in sorted(db.area["interfaces"], key=lambda i: i["name"]) if len(i["neighbors"]) > 0]
+        if pos >= len(cands):
+            return None
+        iface = cands[pos]
+        if iface["type"] == "virtual-link":
+            return out
+        if dest_id[0] == RTR:
+            if iface["type"] in ("point-to-point", "virtual-link"):
+                nbr = next((n for n in iface["neighbors"] if ip(n["router_id"]) == dest_id[1]), None)
+                if nbr is None:
+                    return None
+                out[(iface["index"], ip(nbr["src"]))] = (iface["name"], nbr["src"])
+            elif iface["type"] == "point-to-multipoint":
+                for link in dest_lsa["links"]:
+                    if any(ipaddress.IPv4Address(link["data"]) in ipaddress.ip_network(a, strict=False)
+                           for a in iface.get("addrs", [])):
+                        out[(iface["index"], ip(link["data"]))] = (iface["name"], link["data"])
+            if not out:
+                return None
+        else:
+            out[(iface["index"], -1)] = (iface["name"], None)       # None < Some(addr)
+        return out
+    # parent is a network directly connecting the root to the destination router
+    try:
+        net = ipaddress.ip_network((parent.lsa["lsa_id"], parent.lsa["mask"]), strict=False)
+    except ValueError:
+        return None
+    link = next((k for k in dest_lsa["links"] if ipaddress.IPv4Address(k["data"]) in net), None)
+    if link is None or not parent.nexthops:
+        return None
+    first = parent.nexthops[min(parent.nexthops)]
+    idx = min(parent.nexthops)[0]
+    out[(idx, ip(link["data"]))] = (first[0], link["data"])
+    return out
+
+
+def run_area(vec: dict, area: dict):
+    """holo-ospf/src/spf.rs:587-729 -> (spt dict VertexId -> Vertex, pop order) or None."""
+    db = AreaDb(area)
+    root_id = (RTR, ip(vec["router_id"]))
+    root_lsa = db.vertex_lsa_find(root_id)
+    if root_lsa is None:
+        return None                                               # Error::SpfRootNotFound
+    spt, order = {}, []
+    cand = {(0, root_id): Vertex(root_id, root_lsa, 0, 0)}
+    while cand:
+        key = min(cand)
+        vertex = cand.pop(key)
+        spt[vertex.id] = vertex
+        order.append(vertex.id)
+        for parent_link, lid, llsa, cost in db.vertex_lsa_links(vertex.id, vertex.lsa):
+            if not any(b == vertex.id for _, b, _, _ in db.vertex_lsa_links(lid, llsa)):
+                continue
+            if lid in spt:
+                continue
+            distance = min(vertex.distance + cost, U32_MAX)
+            hops = vertex.hops + (1 if lid[0] == RTR else 0)
+            hops = min(hops, 0xFFFF)
+            ex = next((k for k, c in cand.items() if c.id == lid), None)
+            if ex is not None:
+                if distance < cand[ex].distance:
+                    del cand[ex]
+                elif distance > cand[ex].distance:
+                    continue
+            cv = cand.setdefault((distance, lid), Vertex(lid, llsa, distance, hops))
+            if vertex.hops == 0:
+                nh = calc_nexthops_v2(db, vertex, parent_link, lid, cv.lsa)
+            else:
+                nh = dict(vertex.nexthops)
+            if nh is not None:
+                cv.nexthops.update(nh)
+    return spt, order
+
+
+def intra_area_networks(spt):                                      # ospfv2/spf.rs:462-538
+    for vid in sorted(spt):
+        v = spt[vid]
+        if vid[0] == NET:
+            try:
+                n = ipaddress.ip_network((v.lsa["lsa_id"], v.lsa["mask"]), strict=False)
+            except ValueError:
+                continue
+            yield v, str(n), 0
+        else:
+            for link in v.lsa["links"]:
+                if link["type"] != "stub-network-link":
+                    continue
+                try:
+                    n = ipaddress.ip_network((link["id"], link["data"]), strict=False)
+                except ValueError:
+                    continue
+                yield v, str(n), link["metric"]
+
+
+def _net_key(p: str):
+    n = ipaddress.ip_network(p, strict=False)
+    return (int(n.network_address), n.prefixlen)
+
+
+def update_rib_intra_area(rib: dict, spt, max_paths: int):          # route.rs:343-448
+    for v, prefix, smetric in intra_area_networks(spt):
+        key = _net_key(prefix)
+        metric = min(v.distance + smetric, U32_MAX)
+        cur = rib.get(key)
+        if cur is not None and metric > cur["metric"]:
+            continue
+        origin_id = ip(v.lsa["lsa_id"])
+        if v.id[0] == NET and cur is not None:
+            if metric < cur["metric"] or (metric == cur["metric"] and origin_id > cur["origin"]):
+                del rib[key]
+            else:
+                continue
+        new = {"prefix": prefix, "metric": metric, "origin": origin_id, "connected": v.hops == 0,
+               "nexthops": dict(v.nexthops)}
+        # route_update (route.rs:918-965); all routes here are IntraArea so compare = metric
+        cur = rib.get(key)
+        if cur is None:
+            cur = rib[key] = new
+        elif new["metric"] < cur["metric"]:
+            cur = rib[key] = new
+        elif new["metric"] == cur["metric"]:
+            cur["nexthops"].update(new["nexthops"])
+        if len(cur["nexthops"]) > max_paths:
+            cur["nexthops"] = {k: cur["nexthops"][k] for k in sorted(cur["nexthops"])[:max_paths]}
+
+
+def intra_area_rib(vec: dict):
+    """All areas in area-id order (update_rib_full, route.rs:146-160) -> rows like the YANG local-rib."""
+    rib = {}
+    for area in sorted(vec["areas"], key=lambda a: ip(a["area_id"])):
+        r = run_area(vec, area)
+        if r is None:
+            continue
+        update_rib_intra_area(rib, r[0], vec["max_paths"])
+    rows = []
+    for key in sorted(rib):
+        r = rib[key]
+        nhs = [[r["nexthops"][k][1], r["nexthops"][k][0]] for k in sorted(r["nexthops"])]
+        rows.append({"prefix": r["prefix"], "metric": r["metric"], "type": "intra-area", "nexthops": nhs})
+    return rows

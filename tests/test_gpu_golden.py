@@ -29,3 +29,12 @@ def test_isis_compute_spf_on_gpu_reproduces_reference_local_rib(spf_ctx, path):
 def test_isis_batched_roots_on_gpu_match_literal_restatement(spf_ctx, path):
     vec = json.load(open(path))
     check_spts_against_ref(vec, H.Instance.from_vector(vec), spf_ctx)
+
+
+# ---- OSPFv2 -----------------------------------------------------------------------------------------
+from test_host_ospf import OSPF, check_ospf_vector      # noqa: E402
+
+
+@pytest.mark.parametrize("path", OSPF, ids=[os.path.basename(p)[:-5] for p in OSPF])
+def test_ospfv2_run_area_on_gpu_reproduces_reference_intra_area_rib(spf_ctx, path):
+    check_ospf_vector(json.load(open(path)), spf_ctx)

@@ -1,0 +1,41 @@
+"""Host logic of holo_amd.ospf (LSA walk -> CSR, per-slot calc_nexthops, intra-area route build)
+on CPU, engine replaced by the CPU oracle behind the same interface; answers = the reference's
+recorded intra-area routes (ordered next hops included)."""
+import glob
+import json
+import os
+
+import pytest
+
+from holo_amd import ospf as HO
+from oracle import ospf_ref as RO
+from _oracle_engine import OracleEngine
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+OSPF = sorted(glob.glob(os.path.join(GOLD, "ospfv2", "*.json")))
+
+
+def check_ospf_vector(vec, engine):
+    areas = [HO.Area.from_vector(a) for a in vec["areas"]]
+    got = HO.compute_spf_intra_area(vec["router_id"], areas, vec["max_paths"], engine)
+    # 1. against the literal restatement (every vector, virtual links included)
+    assert got == RO.intra_area_rib(vec)
+    for a, area in zip(vec["areas"], areas):
+        ref = RO.run_area(vec, a)
+        spt = HO.run_area(vec["router_id"], area, engine)
+        if ref is None:
+            assert spt is None
+            continue
+        assert set(spt) == set(ref[0])
+        for vid, vx in ref[0].items():
+            assert (spt[vid].distance, spt[vid].hops) == (vx.distance, vx.hops)
+            assert spt[vid].nexthops == vx.nexthops
+    # 2. against the reference's own recorded answer
+    if not vec["has_vlinks"]:
+        want = sorted([r for r in vec["rib"] if r["type"] == "intra-area"], key=lambda r: RO._net_key(r["prefix"]))
+        assert got == want
+
+
+@pytest.mark.parametrize("path", OSPF, ids=[os.path.basename(p)[:-5] for p in OSPF])
+def test_run_area_and_intra_area_rib(path):
+    check_ospf_vector(json.load(open(path)), OracleEngine())

@@ -72,3 +72,51 @@ def test_graph_oracle_agrees_with_isis_ref(path):
                     assert r.n_parents[ri, i] == len(vx.parents)
                     assert r.n_nexthops[ri, i] == len(vx.nexthops)
                 assert [g.index[v] for v in order] == np.argsort(r.pop_rank[ri], kind="stable")[:len(order)].tolist()
+
+
+# ---- OSPFv2 -----------------------------------------------------------------------------------------
+from holo_amd import ospf as HO          # noqa: E402
+from oracle import ospf_ref as RO        # noqa: E402
+
+OSPF = sorted(glob.glob(os.path.join(GOLD, "ospfv2", "*.json")))
+OSPF_IDS = [os.path.basename(p)[:-5] for p in OSPF]
+
+
+def test_ospf_golden_vectors_present():
+    assert len(OSPF) == 63
+
+
+def _intra(vec):
+    return sorted([r for r in vec["rib"] if r["type"] == "intra-area"], key=lambda r: RO._net_key(r["prefix"]))
+
+
+@pytest.mark.parametrize("path", OSPF, ids=OSPF_IDS)
+def test_ospf_ref_reproduces_reference_intra_area_rib(path):
+    """57 routers (p2p, broadcast/DR, multi-area ABRs, stub areas, unnumbered, ECMP); the 6
+    virtual-link endpoints are out: their backbone next hops are filled in later by
+    area::update_virtual_links (holo-ospf/src/area.rs:207), which is not on the SPF path."""
+    vec = _load(path)
+    if vec["has_vlinks"]:
+        pytest.skip("virtual-link endpoint: next hops completed outside run_area")
+    assert RO.intra_area_rib(vec) == _intra(vec)
+
+
+@pytest.mark.parametrize("path", OSPF, ids=OSPF_IDS)
+def test_graph_oracle_agrees_with_ospf_ref(path):
+    vec = _load(path)
+    for a in vec["areas"]:
+        r = RO.run_area(vec, a)
+        g = HO.AreaGraph(HO.Area.from_vector(a))
+        root = g.index.get((HO.RTR, HO.ip(vec["router_id"])))
+        if r is None:
+            assert root is None
+            continue
+        spt, order = r
+        for variant in (go.REF, go.MAP, go.HEAP):
+            o = go.run(g.row_ptr, g.col, g.metric, g.vflags, HO.MAX_PATH_METRIC_OSPF, [root],
+                       go.RUN_NET_NEXTHOPS, variant)
+            assert {g.vids[i] for i in np.nonzero(o.flags[0])[0].tolist()} == set(spt)
+            for vid, vx in spt.items():
+                i = g.index[vid]
+                assert (o.dist[0, i], o.hops[0, i]) == (vx.distance, vx.hops)
+            assert [g.index[v] for v in order] == np.argsort(o.pop_rank[0], kind="stable")[:len(order)].tolist()
