@@ -172,7 +172,10 @@ def main():
         K = args.steps
         relax_avg = phase["relax_ms"] / max(phase["n_relax"], 1) * 1e-3
         dag_avg = phase["dag_ms"] / max(phase["n_dag"], 1) * 1e-3
-        dominant = "k_dag" if phase["dag_ms"] >= phase["relax_ms"] else "k_relax"
+        if phase["n_dag"] == 0:
+            dominant = "k_fused"          # fused fast path: one kernel does distances + hops + masks
+        else:
+            dominant = "k_dag" if phase["dag_ms"] >= phase["relax_ms"] else "k_relax"
         avg = dag_avg if dominant == "k_dag" else relax_avg
         launches_per_step = (phase["n_relax"] + phase["n_dag"]) / K
         bytes_per_launch = R * ba / launches_per_step          # §8d figure x units per launch

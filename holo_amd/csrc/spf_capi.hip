@@ -56,13 +56,13 @@ struct hspf_ctx {
   std::string last_error;
   hipEvent_t ev[6] = {};
   // scratch (grown on demand, reused across runs)
-  DevBuf dist, hv, mask, roots, lane_flags, changed, tab_ptr, tab_vtx, tab_base;
+  DevBuf dist, hv, mask, roots, lane_flags, changed, tab_ptr, tab_vtx, tab_base, st64, stamp;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   int *h_changed = nullptr;        // pinned
   uint32_t *h_lane_flags = nullptr; // pinned
   size_t h_lane_cap = 0;
-  uint32_t est_relax = 12, est_dag = 12;   // launch-ahead estimates (adapted run to run)
+  uint32_t est_relax = 12, est_dag = 12, est_fused = 12;   // launch-ahead estimates (adapted run to run)
   uint32_t variant = 0;                    // HSPF_VARIANT env: kernel A/B switches (tuning only)
   hspf_stats stats = {};
 };
@@ -194,7 +194,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->roots, &ctx->lane_flags, &ctx->changed,
-                    &ctx->tab_ptr, &ctx->tab_vtx, &ctx->tab_base, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
+                    &ctx->tab_ptr, &ctx->tab_vtx, &ctx->tab_base, &ctx->st64, &ctx->stamp, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
                     &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
@@ -383,13 +383,14 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 
   // ---- slot tables (host, O(deg) per root) and mask width
   std::vector<uint32_t> tab_ptr(L + 1, 0), tab_vtx, tab_base;
-  uint32_t need_words = 1;
+  uint32_t need_words = 1, max_slots = 0;
   {
     std::vector<uint32_t> hv, hb, mark(n, 0xFFFFFFFFu);
     for (uint32_t r = 0; r < L; ++r) {
       if (r < n_roots && roots[r] != HSPF_NO_ROOT) {
         uint32_t total = 0;
         build_slot_table(g, roots[r], hv, hb, total, mark, r);
+        max_slots = std::max(max_slots, total);
         need_words = std::max(need_words, (total + 63) / 64);
         // entry 0 (the root itself, base 0) is implicit on device
         tab_vtx.insert(tab_vtx.end(), hv.begin() + 1, hv.end());
@@ -408,12 +409,21 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   const uint32_t out_words = want_mask ? out->n_mask_words : W;
   st.n_mask_words = need_words;
 
+  // Fast path: every root has <= 16 first-hop slots -> one fused fixed point over a packed 8-byte
+  // state (k_fused); otherwise distances first, then the SPT-DAG phase with W mask words.
+  // HSPF_VARIANT bit0 forces the two-phase path (A/B measurements).
+  const bool fused = max_slots <= 16 && n < (1u << 23) && !(ctx->variant & 1u);
   // ---- scratch
   int rc;
   const size_t rows = (size_t)B * n * 64;
-  if ((rc = ensure(ctx, ctx->dist, rows * 4))) return rc;
-  if ((rc = ensure(ctx, ctx->hv, rows * 4))) return rc;
-  if ((rc = ensure(ctx, ctx->mask, rows * 8 * W))) return rc;
+  if (fused) {
+    if ((rc = ensure(ctx, ctx->st64, rows * 8))) return rc;
+    if ((rc = ensure(ctx, ctx->stamp, (size_t)B * n * 4))) return rc;
+  } else {
+    if ((rc = ensure(ctx, ctx->dist, rows * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->hv, rows * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->mask, rows * 8 * W))) return rc;
+  }
   if ((rc = ensure(ctx, ctx->roots, (size_t)L * 4))) return rc;
   if ((rc = ensure(ctx, ctx->lane_flags, (size_t)L * 4))) return rc;
   if ((rc = ensure(ctx, ctx->changed, (size_t)CHANGED_CAP * 4))) return rc;
@@ -464,11 +474,19 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     }
     HIPCHK(ctx, hipStreamSynchronize(s));   // rl / tab_* are stack vectors
   }
+  uint64_t *d_st = (uint64_t *)ctx->st64.p;
+  uint32_t *d_stamp = (uint32_t *)ctx->stamp.p;
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
-  HIPCHK(ctx, hipMemsetAsync(d_dist, 0xFF, rows * 4, s));
-  HIPCHK(ctx, hipMemsetAsync(d_hv, 0, rows * 4, s));
   HIPCHK(ctx, hipMemsetAsync(d_lf, 0, (size_t)L * 4, s));
-  hipLaunchKernelGGL(k_init_roots, dim3((L + 255) / 256), dim3(256), 0, s, n, d_dist, d_roots, L);
+  if (fused) {
+    HIPCHK(ctx, hipMemsetAsync(d_st, 0xFF, rows * 8, s));
+    HIPCHK(ctx, hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s));
+    hipLaunchKernelGGL(k_init_fused, dim3((L + 255) / 256), dim3(256), 0, s, n, d_st, d_stamp, d_roots, L);
+  } else {
+    HIPCHK(ctx, hipMemsetAsync(d_dist, 0xFF, rows * 4, s));
+    HIPCHK(ctx, hipMemsetAsync(d_hv, 0, rows * 4, s));
+    hipLaunchKernelGGL(k_init_roots, dim3((L + 255) / 256), dim3(256), 0, s, n, d_dist, d_roots, L);
+  }
 
   const uint32_t vblocks = (n + VPB - 1) / VPB;
   const dim3 grid(((vblocks + 7) / 8) * 8, B);
@@ -507,6 +525,21 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   };
 
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
+  if (fused) {
+    uint32_t n_f = 0;
+    rc = run_phase(ctx->est_fused, [&](uint32_t sweep) {
+      if (g->max_path_metric == HSPF_DIST_INF)
+        hipLaunchKernelGGL((k_fused<true>), grid, dim3(256), 0, s, gd, d_st, d_stamp, d_roots, tabs, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+      else
+        hipLaunchKernelGGL((k_fused<false>), grid, dim3(256), 0, s, gd, d_st, d_stamp, d_roots, tabs, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+    }, n_f);
+    if (rc) return rc;
+    ctx->est_fused = n_f + 1;
+    st.n_relax_launches = n_f;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
+    hipLaunchKernelGGL(k_emit_fused, dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, d_st, od);
+  } else {
   uint32_t n_relax = 0;
   rc = run_phase(ctx->est_relax, [&](uint32_t sweep) {
     if (g->max_path_metric == HSPF_DIST_INF)
@@ -552,6 +585,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       case 8: launch_emit<8>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
       default: launch_emit<16>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
     }
+  }
+
   }
 
   // ---- roots whose pop order is dynamic (or forced): sequential exact kernel

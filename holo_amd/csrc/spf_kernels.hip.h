@@ -60,6 +60,10 @@ struct GraphDev {
   const uint32_t *out_fpos; // [e_in]
 };
 
+struct OutDev {
+  uint32_t *dist; uint16_t *hops; uint16_t *flags; uint64_t *mask; uint32_t out_words;
+};
+
 struct SlotTabs {           // per root: H vertices and their slot bases (include/holo_spf_hip.h)
   const uint32_t *ptr;      // [n_root_slots+1]
   const uint32_t *vtx;
@@ -116,6 +120,11 @@ __device__ __forceinline__ uint32_t ld_row(const uint32_t *base, uint32_t byte_o
 __device__ __forceinline__ uint64_t ld_row64(const uint64_t *base, size_t byte_off) {
   return *(const uint64_t *)((const char *)base + byte_off);
 }
+__device__ __forceinline__ uint64_t ld_row64s(const uint64_t *base, uint32_t byte_off) {
+  return *(const uint64_t *)((const char *)base + byte_off);           // saddr + 32-bit voffset
+}
+
+__device__ __forceinline__ uint32_t in_fpos_of(const GraphDev &g, uint32_t e) { return g.in_fpos[e]; }
 
 constexpr int GRP = 4;            // links per unrolled group
 constexpr int NGRP = 64 / GRP;
@@ -345,6 +354,177 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
   if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused sweep (the fast path when every root of the run has <= 16 first-hop slots): ONE
+// label-correcting fixed point over the packed per-(vertex, root) state
+//     [63:32] dist   [31:16] hops   [15:0] first-hop mask        (all ones = not reached)
+// instead of a distance phase followed by a DAG phase.  Every recomputation of a lane is a pure
+// function of its in-neighbours' states:
+//     dist  = min over in-links of dist[u] (+) w           (gates as in k_relax)
+//     mask  = OR over the links attaining the min of (hops[u] == 0 ? slot bit : mask[u])
+//     hops  = hops[p0] + is_router(v),  p0 = first link (ascending source) with the smallest dist[u]
+// so the unique fixed point is the reference's result whenever its pop order is the static
+// (dist, index) order (same proof obligation as k_dag; lanes that violate it are flagged for
+// k_exact).  An 8-byte state is read and written by single dwordx2 accesses, so a reader can never
+// see a distance with somebody else's mask.  Stale reads inside a launch are harmless: memory is
+// monotone across launches and the run ends only after a launch in which nothing changed.
+//
+// Row skipping: stamp[v] = number (sweep + 2) of the last sweep that changed row v (0 = never,
+// roots start at 1).  A row is recomputed in sweep s only if some in-neighbour changed in sweep
+// s-1 (or already in s); measured on isis-100k this visits 21 of 34 row-sweeps.
+constexpr uint64_t ST_INF = ~0ull;
+
+template <bool MAXINF>
+__global__ __launch_bounds__(256) void k_fused(GraphDev g, uint64_t *__restrict__ st,
+                                               uint32_t *__restrict__ stamp,
+                                               const uint32_t *__restrict__ roots, SlotTabs tabs,
+                                               uint32_t maxpath, uint32_t net_nexthops,
+                                               uint32_t ignore_ovl, int *changed, int sweep,
+                                               uint32_t *lane_flags) {
+  if (sweep > 0 && changed[sweep - 1] == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t batch = blockIdx.y;
+  const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const uint32_t vbeg = chunk * VPB + wave * VPW;
+  const uint32_t n = g.n;
+  if (vbeg >= n) return;
+  const uint32_t *__restrict__ in_ptr = g.in_ptr;
+  const uint32_t *__restrict__ in_src = g.in_src;
+  const uint32_t *__restrict__ in_w = g.in_w;
+  const uint32_t root_slot = batch * 64 + lane;
+  const uint32_t my_root = roots[root_slot];
+  uint64_t *S = st + (size_t)batch * n * 64;
+  uint32_t *T = stamp + (size_t)batch * n;
+  const uint32_t cur = (uint32_t)sweep + 2u;
+  const uint32_t lane8 = lane * 8u;
+  const uint32_t pv = in_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
+  bool any = false, sat = false, need_exact = false;
+#pragma unroll 1
+  for (int i = 0; i < VPW; ++i) {
+    const uint32_t v = vbeg + i;
+    if (v >= n) break;
+    const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
+    // ---- did any in-neighbour change since this row was last brought up to date?
+    bool act = false;
+    for (uint32_t eb = e0; eb < e1; eb += 64) {
+      const uint32_t cnt = min(64u, e1 - eb);
+      if (lane < cnt) act = act || (T[in_src[eb + lane] & SRC_MASK] + 1u >= cur);
+    }
+    if (__ballot(act) == 0ull) continue;
+    const uint64_t old = ld_row64s(S, v * 512u + lane8);
+    const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
+    uint32_t bd = INF, bm = 0, bpd = INF, bh = 0, bd_all = INF;
+    for (uint32_t eb = e0; eb < e1; eb += 64) {
+      const uint32_t cnt = min(64u, e1 - eb);
+      // padding lanes: (own row, cost INF) -> candidate INF, ignored
+      uint32_t sv = lane < cnt ? in_src[eb + lane] : v;
+      const uint32_t wv = lane < cnt ? in_w[eb + lane] : INF;
+      const bool has_nt = !ignore_ovl && __ballot((sv & SRC_NO_TRANSIT) != 0) != 0ull;
+      if (!has_nt) sv &= SRC_MASK;
+      // zero-cost links from a higher-numbered source are never static-order parents
+      const uint32_t zv = (lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
+      const bool has_z = __ballot(zv != 0u) != 0ull;
+#pragma unroll
+      for (int gi = 0; gi < NGRP; ++gi) {
+        if (cnt <= (uint32_t)(gi * GRP)) break;
+        uint64_t su[GRP];
+#pragma unroll
+        for (int k = 0; k < GRP; ++k) {
+          const uint32_t u = rdlane(sv, gi * GRP + k) & SRC_MASK;
+          su[k] = ld_row64s(S, u * 512u + lane8);
+        }
+#pragma unroll
+        for (int k = 0; k < GRP; ++k) {
+          const uint32_t w = rdlane(wv, gi * GRP + k);
+          uint32_t d = (uint32_t)(su[k] >> 32);
+          const uint32_t hm = (uint32_t)su[k];
+          if (has_nt) {                                           // uniform, rare
+            const uint32_t sw = rdlane(sv, gi * GRP + k);
+            if ((sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;
+          }
+          const uint32_t c = add_sat(d, w);                       // INF stays INF
+          if (MAXINF && c == INF && d != INF && w != INF) sat = true;
+          if (has_z) {                                            // uniform, rare
+            if (rdlane(zv, gi * GRP + k)) { bd_all = min(bd_all, c); continue; }
+          }
+          const bool lt = c < bd;
+          const bool eq = (c == bd) && (c != INF);
+          const uint32_t hh = hm >> 16;
+          uint32_t contrib = hm & 0xFFFFu;
+          const bool direct = (lt || eq) && hh == 0u;             // parent: root or hops-0 network
+          if (__ballot(direct) != 0ull) {                         // rare
+            const uint32_t u = rdlane(sv, gi * GRP + k) & SRC_MASK;
+            const uint32_t fpos = in_fpos_of(g, eb + gi * GRP + k);
+            if (direct) {
+              const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(tabs, root_slot, u);
+              const uint32_t sidx = base_s + fpos;
+              contrib = ((v_router || net_nexthops) && sidx < 16u) ? (1u << sidx) : 0u;
+            }
+          }
+          if (lt) { bd = c; bm = contrib; bpd = d; bh = hh; }
+          else if (eq) { bm |= contrib; if (d < bpd) { bpd = d; bh = hh; } }
+        }
+      }
+    }
+    uint64_t nw;
+    if (v == my_root) nw = 0ull;                                  // dist 0, hops 0, no next hops
+    else if (bd == INF || bd > maxpath) nw = ST_INF;
+    else {
+      uint32_t hops = bh + v_router;
+      if (hops > 0xFFFFu) hops = 0xFFFFu;                         // u16 saturating_add
+      nw = ((uint64_t)bd << 32) | ((uint64_t)hops << 16) | (uint64_t)(bm & 0xFFFFu);
+    }
+    // a shorter (or the only) way in through a zero-cost link from a higher-numbered source: the
+    // reference's pop order is dynamic there -> whole root goes to k_exact
+    if (v != my_root && bd_all <= maxpath && bd_all < bd) need_exact = true;
+    const bool ch = nw != old;
+    if (ch) { *(uint64_t *)((char *)S + (v * 512u + lane8)) = nw; any = true; }
+    if (__ballot(ch) != 0ull && lane == 0) T[v] = cur;
+  }
+  if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
+  if ((MAXINF && sat) || need_exact) atomicOr(&lane_flags[root_slot], LF_NEED_EXACT);
+}
+
+// init for the fused path: roots' own lanes = (0, 0, 0) and their rows stamped "changed".
+__global__ void k_init_fused(uint32_t n, uint64_t *st, uint32_t *stamp, const uint32_t *roots, uint32_t n_lanes) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_lanes) return;
+  const uint32_t r = roots[i];
+  if (r == INF) return;
+  const uint32_t batch = i >> 6, lane = i & 63;
+  st[((size_t)batch * n + r) * 64 + lane] = 0ull;
+  stamp[(size_t)batch * n + r] = 1u;
+}
+
+// Emit for the fused path: packed lane-major state -> row-major results.
+__global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots,
+                                                    const uint64_t *__restrict__ st, OutDev o) {
+  __shared__ uint64_t t64[64][65];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t batch = blockIdx.y, v0 = blockIdx.x * 64;
+  const uint32_t nv = min(64u, n - v0);
+  const uint32_t r0 = batch * 64;
+  const uint32_t nr = min(64u, n_roots - r0);
+  const uint64_t *S = st + ((size_t)batch * n + v0) * 64;
+  for (uint32_t j = wave; j < nv; j += 4) t64[j][lane] = S[(size_t)j * 64 + lane];
+  __syncthreads();
+  for (uint32_t r = wave; r < nr; r += 4)
+    if (lane < nv) {
+      const uint64_t x = t64[lane][r];
+      const size_t idx = (size_t)(r0 + r) * n + v0 + lane;
+      const uint32_t d = (uint32_t)(x >> 32);
+      const bool in = d != INF;
+      o.dist[idx] = d;
+      if (o.hops) o.hops[idx] = in ? (uint16_t)((uint32_t)x >> 16) : (uint16_t)0;
+      if (o.flags) o.flags[idx] = in ? 1 : 0;
+      if (o.mask) {
+        o.mask[idx * o.out_words] = in ? (uint64_t)((uint32_t)x & 0xFFFFu) : 0ull;
+        for (uint32_t k = 1; k < o.out_words; ++k) o.mask[idx * o.out_words + k] = 0;
+      }
+    }
+}
+
 // Epoch rebase (only when a DAG phase needs more than 65534 launches): every final row -> epoch 1.
 __global__ void k_rebase(uint32_t *hv, size_t count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -356,9 +536,6 @@ __global__ void k_rebase(uint32_t *hv, size_t count) {
 // ---------------------------------------------------------------------------------------------
 // Emit: lane-major state -> row-major results.  One block = 64 vertices x 64 roots of one batch.
 // grid = (ceil(n/64), n_batches), block = 256.
-struct OutDev {
-  uint32_t *dist; uint16_t *hops; uint16_t *flags; uint64_t *mask; uint32_t out_words;
-};
 
 template <int W>
 __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t n_roots,
