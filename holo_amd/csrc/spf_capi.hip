@@ -56,7 +56,7 @@ struct hspf_ctx {
   std::string last_error;
   hipEvent_t ev[6] = {};
   // scratch (grown on demand, reused across runs)
-  DevBuf dist, hv, mask, roots, lane_flags, changed, tab_ptr, tab_vtx, tab_base, st64, stamp;
+  DevBuf dist, hv, mask, roots, lane_flags, changed, tab_ptr, tab_vtx, tab_base, st64, stamp, hnb;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   int *h_changed = nullptr;        // pinned
@@ -194,7 +194,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->roots, &ctx->lane_flags, &ctx->changed,
-                    &ctx->tab_ptr, &ctx->tab_vtx, &ctx->tab_base, &ctx->st64, &ctx->stamp, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
+                    &ctx->tab_ptr, &ctx->tab_vtx, &ctx->tab_base, &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
                     &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
@@ -419,6 +419,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if (fused) {
     if ((rc = ensure(ctx, ctx->st64, rows * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stamp, (size_t)B * n * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->hnb, (size_t)B * n))) return rc;
   } else {
     if ((rc = ensure(ctx, ctx->dist, rows * 4))) return rc;
     if ((rc = ensure(ctx, ctx->hv, rows * 4))) return rc;
@@ -481,7 +482,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if (fused) {
     HIPCHK(ctx, hipMemsetAsync(d_st, 0xFF, rows * 8, s));
     HIPCHK(ctx, hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s));
-    hipLaunchKernelGGL(k_init_fused, dim3((L + 255) / 256), dim3(256), 0, s, n, d_st, d_stamp, d_roots, L);
+    HIPCHK(ctx, hipMemsetAsync(ctx->hnb.p, 0, (size_t)B * n, s));
+    hipLaunchKernelGGL(k_init_fused, dim3((L + 255) / 256), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
   } else {
     HIPCHK(ctx, hipMemsetAsync(d_dist, 0xFF, rows * 4, s));
     HIPCHK(ctx, hipMemsetAsync(d_hv, 0, rows * 4, s));
@@ -529,9 +531,9 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     uint32_t n_f = 0;
     rc = run_phase(ctx->est_fused, [&](uint32_t sweep) {
       if (g->max_path_metric == HSPF_DIST_INF)
-        hipLaunchKernelGGL((k_fused<true>), grid, dim3(256), 0, s, gd, d_st, d_stamp, d_roots, tabs, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+        hipLaunchKernelGGL((k_fused<true>), grid, dim3(256), 0, s, gd, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, tabs, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
       else
-        hipLaunchKernelGGL((k_fused<false>), grid, dim3(256), 0, s, gd, d_st, d_stamp, d_roots, tabs, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+        hipLaunchKernelGGL((k_fused<false>), grid, dim3(256), 0, s, gd, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, tabs, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
     }, n_f);
     if (rc) return rc;
     ctx->est_fused = n_f + 1;

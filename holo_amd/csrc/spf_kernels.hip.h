@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace hspf {
 
@@ -369,14 +370,130 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
 // see a distance with somebody else's mask.  Stale reads inside a launch are harmless: memory is
 // monotone across launches and the run ends only after a launch in which nothing changed.
 //
-// Row skipping: stamp[v] = number (sweep + 2) of the last sweep that changed row v (0 = never,
-// roots start at 1).  A row is recomputed in sweep s only if some in-neighbour changed in sweep
-// s-1 (or already in s); measured on isis-100k this visits 21 of 34 row-sweeps.
+// Row skipping by PUSH activation: act[v] = id of the latest sweep in which row v has to be
+// recomputed.  A wave that changes row u in sweep c stamps c+1 on u's out-neighbours (<= deg
+// scattered 4-byte stores), so the next sweep's "is there anything to do here" test is ONE load
+// per wave instead of a gather over the in-neighbours, and a sweep with nothing to do costs a few
+// microseconds.  A stale or racing stamp can only cause an extra recomputation, never a missed
+// one: every change made in sweep c is seen (kernel boundary) by all its dependents in sweep c+1.
+// Measured on isis-100k the run visits ~21 of 34 row-sweeps.
+//
+// Memory-level parallelism (profiles/r01b_*: the first version was latency bound, 64 % of wave
+// cycles in s_waitcnt with 4 row loads in flight per wave): the link vectors of all VPW vertices
+// are fetched up front, and the neighbour rows of a vertex are requested 8 at a time with the
+// exact count (computed goto-free by a fall-through switch), 512 B per request per wave.
 constexpr uint64_t ST_INF = ~0ull;
+constexpr int FG = 4;             // neighbour rows requested per group
+constexpr int NFG = 64 / FG;
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// One packed row element through a raw buffer load: address = rsrc.base + voff (lane * 8, VGPR) +
+// soff (row byte offset, SGPR straight out of v_readlane) -> no vector ALU work per link for
+// addressing (profiles/r01b_pmc_fused_v1.json: the first fused kernel was issue bound, 24 M scalar
+// + 33 M vector instructions per sweep, not memory bound).
+__device__ __forceinline__ uint64_t ld_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return ((uint64_t)x.y << 32) | x.x;
+}
+
+struct RowOut { uint64_t nw; bool sat, need_exact; };
+
+// Recompute one row (64 roots of vertex v).  SLOW = false: no overloaded source, no zero-cost link
+// from a higher-numbered source, no in-neighbour that can have hops == 0, at most 64 links:
+// straight-line groups of FG links, no per-link scalar control flow.  SLOW = true: everything.
+template <bool MAXINF, bool SLOW>
+__device__ __forceinline__ RowOut fused_row(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v,
+                                            uint32_t e0, uint32_t e1, uint32_t sv0, uint32_t wv0,
+                                            uint32_t lane, uint32_t lane8, uint32_t my_root,
+                                            uint32_t root_slot, const SlotTabs &tabs, uint32_t maxpath,
+                                            uint32_t net_nexthops, uint32_t ignore_ovl) {
+  const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
+  uint32_t bd = INF, bm = 0, bpd = INF, bh = 0, bd_all = INF;
+  bool sat = false;
+  for (uint32_t eb = e0; eb < e1; eb += 64) {
+    const uint32_t cnt = min(64u, e1 - eb);
+    uint32_t sv = sv0, wv = wv0;                                  // padding lanes: cost INF
+    if (SLOW && eb != e0) {
+      sv = lane < cnt ? g.in_src[eb + lane] : v;
+      wv = lane < cnt ? g.in_w[eb + lane] : INF;
+    }
+    const bool has_nt = SLOW && !ignore_ovl && __ballot((sv & SRC_NO_TRANSIT) != 0) != 0ull;
+    const uint32_t zv = (SLOW && lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
+    const bool has_z = SLOW && __ballot(zv != 0u) != 0ull;
+    const uint32_t so = (sv & SRC_MASK) << 9;                     // row byte offsets, lane j = link j
+#pragma unroll
+    for (int gi = 0; gi < NFG; ++gi) {
+      if (cnt <= (uint32_t)(gi * FG)) break;                      // one scalar branch per FG links
+      uint64_t su[FG];
+#pragma unroll
+      for (int k = 0; k < FG; ++k) su[k] = ST_INF;
+#define HSPF_LD(K) su[K] = ld_st(rs, lane8, rdlane(so, gi * FG + K))
+      switch (min(cnt - (uint32_t)(gi * FG), (uint32_t)FG)) {     // exactly that many requests
+        case 4: HSPF_LD(3); [[fallthrough]];
+        case 3: HSPF_LD(2); [[fallthrough]];
+        case 2: HSPF_LD(1); [[fallthrough]];
+        default: HSPF_LD(0);
+      }
+#undef HSPF_LD
+#pragma unroll
+      for (int k = 0; k < FG; ++k) {
+        const uint32_t w = rdlane(wv, gi * FG + k);               // INF on padding lanes
+        uint32_t d = (uint32_t)(su[k] >> 32);
+        const uint32_t hm = (uint32_t)su[k];
+        if (has_nt) {                                             // uniform, rare
+          const uint32_t sw = rdlane(sv, gi * FG + k);
+          if ((sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;
+        }
+        const uint32_t c = add_sat(d, w);                         // INF stays INF
+        if (MAXINF && c == INF && d != INF && w != INF) sat = true;
+        if (has_z) {                                              // uniform, rare
+          if (rdlane(zv, gi * FG + k)) { bd_all = min(bd_all, c); continue; }
+        }
+        const bool lt = c < bd;
+        const bool eq = c == bd;          // c == bd == INF also lands here: harmless, row ends as ST_INF
+        const uint32_t hh = hm >> 16;
+        uint32_t contrib = hm & 0xFFFFu;
+        if (SLOW) {
+          const bool direct = (lt || eq) && hh == 0u && c != INF;  // parent: root or hops-0 network
+          if (__ballot(direct) != 0ull) {
+            const uint32_t u = rdlane(sv, gi * FG + k) & SRC_MASK;
+            const uint32_t fpos = g.in_fpos[eb + gi * FG + k];
+            if (direct) {
+              const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(tabs, root_slot, u);
+              const uint32_t sidx = base_s + fpos;
+              contrib = ((v_router || net_nexthops) && sidx < 16u) ? (1u << sidx) : 0u;
+            }
+          }
+        }
+        const uint32_t m_or = bm | contrib;
+        bm = lt ? contrib : (eq ? m_or : bm);
+        const bool newp = lt || (eq && d < bpd);                  // first discoverer: smallest parent dist
+        bpd = newp ? d : bpd;
+        bh = newp ? hh : bh;
+        bd = min(bd, c);
+      }
+    }
+  }
+  RowOut o;
+  o.sat = sat;
+  if (v == my_root) o.nw = 0ull;                                  // dist 0, hops 0, no next hops
+  else if (bd == INF || bd > maxpath) o.nw = ST_INF;
+  else {
+    uint32_t hops = bh + v_router;
+    if (hops > 0xFFFFu) hops = 0xFFFFu;                           // u16 saturating_add
+    o.nw = ((uint64_t)bd << 32) | ((uint64_t)hops << 16) | (uint64_t)(bm & 0xFFFFu);
+  }
+  // a shorter (or the only) way in through a zero-cost link from a higher-numbered source: the
+  // reference's pop order is dynamic there -> whole root goes to k_exact
+  o.need_exact = SLOW && v != my_root && bd_all <= maxpath && bd_all < bd;
+  return o;
+}
 
 template <bool MAXINF>
 __global__ __launch_bounds__(256) void k_fused(GraphDev g, uint64_t *__restrict__ st,
-                                               uint32_t *__restrict__ stamp,
+                                               uint32_t *__restrict__ act,
+                                               const uint8_t *__restrict__ hnb,
                                                const uint32_t *__restrict__ roots, SlotTabs tabs,
                                                uint32_t maxpath, uint32_t net_nexthops,
                                                uint32_t ignore_ovl, int *changed, int sweep,
@@ -389,112 +506,84 @@ __global__ __launch_bounds__(256) void k_fused(GraphDev g, uint64_t *__restrict_
   const uint32_t vbeg = chunk * VPB + wave * VPW;
   const uint32_t n = g.n;
   if (vbeg >= n) return;
+  uint32_t *A = act + (size_t)batch * n;
+  const uint32_t cur = (uint32_t)sweep + 2u;
+  // one load: activation stamps of the wave's vertices (lanes 0..VPW-1)
+  const uint32_t vl = min(vbeg + min(lane, (uint32_t)(VPW - 1)), n - 1);
+  const uint32_t av = A[vl];
+  if (__ballot(lane < (uint32_t)VPW && vbeg + lane < n && av >= cur) == 0ull) return;
+  const uint32_t hb = hnb[(size_t)batch * n + vl];
   const uint32_t *__restrict__ in_ptr = g.in_ptr;
   const uint32_t *__restrict__ in_src = g.in_src;
   const uint32_t *__restrict__ in_w = g.in_w;
   const uint32_t root_slot = batch * 64 + lane;
   const uint32_t my_root = roots[root_slot];
   uint64_t *S = st + (size_t)batch * n * 64;
-  uint32_t *T = stamp + (size_t)batch * n;
-  const uint32_t cur = (uint32_t)sweep + 2u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)S, (short)0, (int)(n * 512u), 0x00020000);
   const uint32_t lane8 = lane * 8u;
   const uint32_t pv = in_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
-  bool any = false, sat = false, need_exact = false;
-#pragma unroll 1
+  const uint32_t po = g.out_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
+  // link vectors (first 64 links) of all active vertices, requested back to back
+  uint32_t svv[VPW], wvv[VPW];
+#pragma unroll
   for (int i = 0; i < VPW; ++i) {
     const uint32_t v = vbeg + i;
-    if (v >= n) break;
     const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
-    // ---- did any in-neighbour change since this row was last brought up to date?
-    bool act = false;
-    for (uint32_t eb = e0; eb < e1; eb += 64) {
-      const uint32_t cnt = min(64u, e1 - eb);
-      if (lane < cnt) act = act || (T[in_src[eb + lane] & SRC_MASK] + 1u >= cur);
-    }
-    if (__ballot(act) == 0ull) continue;
-    const uint64_t old = ld_row64s(S, v * 512u + lane8);
-    const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
-    uint32_t bd = INF, bm = 0, bpd = INF, bh = 0, bd_all = INF;
-    for (uint32_t eb = e0; eb < e1; eb += 64) {
-      const uint32_t cnt = min(64u, e1 - eb);
-      // padding lanes: (own row, cost INF) -> candidate INF, ignored
-      uint32_t sv = lane < cnt ? in_src[eb + lane] : v;
-      const uint32_t wv = lane < cnt ? in_w[eb + lane] : INF;
-      const bool has_nt = !ignore_ovl && __ballot((sv & SRC_NO_TRANSIT) != 0) != 0ull;
-      if (!has_nt) sv &= SRC_MASK;
-      // zero-cost links from a higher-numbered source are never static-order parents
-      const uint32_t zv = (lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
-      const bool has_z = __ballot(zv != 0u) != 0ull;
-#pragma unroll
-      for (int gi = 0; gi < NGRP; ++gi) {
-        if (cnt <= (uint32_t)(gi * GRP)) break;
-        uint64_t su[GRP];
-#pragma unroll
-        for (int k = 0; k < GRP; ++k) {
-          const uint32_t u = rdlane(sv, gi * GRP + k) & SRC_MASK;
-          su[k] = ld_row64s(S, u * 512u + lane8);
-        }
-#pragma unroll
-        for (int k = 0; k < GRP; ++k) {
-          const uint32_t w = rdlane(wv, gi * GRP + k);
-          uint32_t d = (uint32_t)(su[k] >> 32);
-          const uint32_t hm = (uint32_t)su[k];
-          if (has_nt) {                                           // uniform, rare
-            const uint32_t sw = rdlane(sv, gi * GRP + k);
-            if ((sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;
-          }
-          const uint32_t c = add_sat(d, w);                       // INF stays INF
-          if (MAXINF && c == INF && d != INF && w != INF) sat = true;
-          if (has_z) {                                            // uniform, rare
-            if (rdlane(zv, gi * GRP + k)) { bd_all = min(bd_all, c); continue; }
-          }
-          const bool lt = c < bd;
-          const bool eq = (c == bd) && (c != INF);
-          const uint32_t hh = hm >> 16;
-          uint32_t contrib = hm & 0xFFFFu;
-          const bool direct = (lt || eq) && hh == 0u;             // parent: root or hops-0 network
-          if (__ballot(direct) != 0ull) {                         // rare
-            const uint32_t u = rdlane(sv, gi * GRP + k) & SRC_MASK;
-            const uint32_t fpos = in_fpos_of(g, eb + gi * GRP + k);
-            if (direct) {
-              const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(tabs, root_slot, u);
-              const uint32_t sidx = base_s + fpos;
-              contrib = ((v_router || net_nexthops) && sidx < 16u) ? (1u << sidx) : 0u;
-            }
-          }
-          if (lt) { bd = c; bm = contrib; bpd = d; bh = hh; }
-          else if (eq) { bm |= contrib; if (d < bpd) { bpd = d; bh = hh; } }
-        }
-      }
-    }
-    uint64_t nw;
-    if (v == my_root) nw = 0ull;                                  // dist 0, hops 0, no next hops
-    else if (bd == INF || bd > maxpath) nw = ST_INF;
-    else {
-      uint32_t hops = bh + v_router;
-      if (hops > 0xFFFFu) hops = 0xFFFFu;                         // u16 saturating_add
-      nw = ((uint64_t)bd << 32) | ((uint64_t)hops << 16) | (uint64_t)(bm & 0xFFFFu);
-    }
-    // a shorter (or the only) way in through a zero-cost link from a higher-numbered source: the
-    // reference's pop order is dynamic there -> whole root goes to k_exact
-    if (v != my_root && bd_all <= maxpath && bd_all < bd) need_exact = true;
-    const bool ch = nw != old;
-    if (ch) { *(uint64_t *)((char *)S + (v * 512u + lane8)) = nw; any = true; }
-    if (__ballot(ch) != 0ull && lane == 0) T[v] = cur;
+    const bool on = v < n && rdlane(av, i) >= cur && lane < min(64u, e1 - e0);
+    svv[i] = on ? in_src[e0 + lane] : min(v, n - 1);
+    wvv[i] = on ? in_w[e0 + lane] : INF;
   }
+  bool any = false, sat = false, need_exact = false;
+  auto row = [&](auto I) {                                        // explicit 4x instantiation: compile-time lane numbers
+    constexpr int i = decltype(I)::value;
+    const uint32_t v = vbeg + i;
+    if (v >= n) return;
+    if (rdlane(av, i) < cur) return;                              // nothing changed around this row
+    const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
+    const uint64_t old = ld_st(rs, lane8, v << 9);
+    const uint32_t cnt0 = min(64u, e1 - e0);
+    const bool slow = (e1 - e0) > 64u || rdlane(hb, i) != 0u ||
+                      (!ignore_ovl && __ballot((svv[i] & SRC_NO_TRANSIT) != 0) != 0ull) ||
+                      __ballot(lane < cnt0 && wvv[i] == 0u && (svv[i] & SRC_MASK) >= v) != 0ull;
+    RowOut r;
+    if (!slow) r = fused_row<MAXINF, false>(g, rs, v, e0, e1, svv[i], wvv[i], lane, lane8, my_root, root_slot, tabs, maxpath, net_nexthops, ignore_ovl);
+    else       r = fused_row<MAXINF, true>(g, rs, v, e0, e1, svv[i], wvv[i], lane, lane8, my_root, root_slot, tabs, maxpath, net_nexthops, ignore_ovl);
+    sat = sat || r.sat;
+    need_exact = need_exact || r.need_exact;
+    const bool ch = r.nw != old;
+    if (ch) { *(uint64_t *)((char *)S + (v * 512u + lane8)) = r.nw; any = true; }
+    if (__ballot(ch) != 0ull) {                                   // wake the out-neighbours up
+      const uint32_t o0 = rdlane(po, i), o1 = rdlane(po, i + 1);
+      for (uint32_t ob = o0 + lane; ob < o1; ob += 64) A[g.out_dst[ob]] = cur + 1u;
+    }
+  };
+  static_assert(VPW == 4, "row() is instantiated four times");
+  row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{});
+  row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
   if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
   if ((MAXINF && sat) || need_exact) atomicOr(&lane_flags[root_slot], LF_NEED_EXACT);
 }
 
-// init for the fused path: roots' own lanes = (0, 0, 0) and their rows stamped "changed".
-__global__ void k_init_fused(uint32_t n, uint64_t *st, uint32_t *stamp, const uint32_t *roots, uint32_t n_lanes) {
+// init for the fused path: roots' own lanes = (0, 0, 0); their out-neighbours are due in the
+// first sweep (id 2); out-neighbours of every vertex that can have hops == 0 for some root of the
+// batch (the root and its slot-table networks) are marked for the general row routine.
+__global__ void k_init_fused(GraphDev g, uint64_t *st, uint32_t *act, uint8_t *hnb, const uint32_t *roots,
+                             SlotTabs tabs, uint32_t n_lanes) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_lanes) return;
   const uint32_t r = roots[i];
   if (r == INF) return;
+  const uint32_t n = g.n;
   const uint32_t batch = i >> 6, lane = i & 63;
   st[((size_t)batch * n + r) * 64 + lane] = 0ull;
-  stamp[(size_t)batch * n + r] = 1u;
+  for (uint32_t k = g.out_ptr[r]; k < g.out_ptr[r + 1]; ++k) {
+    act[(size_t)batch * n + g.out_dst[k]] = 2u;
+    hnb[(size_t)batch * n + g.out_dst[k]] = 1;
+  }
+  for (uint32_t j = tabs.ptr[i]; j < tabs.ptr[i + 1]; ++j) {
+    const uint32_t h = tabs.vtx[j];
+    for (uint32_t k = g.out_ptr[h]; k < g.out_ptr[h + 1]; ++k) hnb[(size_t)batch * n + g.out_dst[k]] = 1;
+  }
 }
 
 // Emit for the fused path: packed lane-major state -> row-major results.
