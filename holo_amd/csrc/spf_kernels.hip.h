@@ -397,13 +397,23 @@ __device__ __forceinline__ uint64_t ld_st(__amdgpu_buffer_rsrc_t r, uint32_t vof
   return ((uint64_t)x.y << 32) | x.x;
 }
 
+// Buffer resource of one batch's state slab, built from values forced into SGPRs: a descriptor
+// that the compiler keeps in VGPRs (e.g. a function argument) turns every load into a waterfall loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const uint64_t *S, uint32_t n) {
+  const uint64_t a = (uint64_t)S;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0,
+                                           (int)__builtin_amdgcn_readfirstlane(n * 512u), 0x00020000);
+}
+
 struct RowOut { uint64_t nw; bool sat, need_exact; };
 
 // Recompute one row (64 roots of vertex v).  SLOW = false: no overloaded source, no zero-cost link
 // from a higher-numbered source, no in-neighbour that can have hops == 0, at most 64 links:
 // straight-line groups of FG links, no per-link scalar control flow.  SLOW = true: everything.
 template <bool MAXINF, bool SLOW>
-__device__ __forceinline__ RowOut fused_row(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v,
+__device__ __attribute__((always_inline)) inline RowOut fused_row(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v,
                                             uint32_t e0, uint32_t e1, uint32_t sv0, uint32_t wv0,
                                             uint32_t lane, uint32_t lane8, uint32_t my_root,
                                             uint32_t root_slot, const SlotTabs &tabs, uint32_t maxpath,
@@ -421,21 +431,18 @@ __device__ __forceinline__ RowOut fused_row(const GraphDev &g, __amdgpu_buffer_r
     const bool has_nt = SLOW && !ignore_ovl && __ballot((sv & SRC_NO_TRANSIT) != 0) != 0ull;
     const uint32_t zv = (SLOW && lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
     const bool has_z = SLOW && __ballot(zv != 0u) != 0ull;
-    const uint32_t so = (sv & SRC_MASK) << 9;                     // row byte offsets, lane j = link j
-#pragma unroll
+    // row byte offsets, lane j = link j; padding lanes point at the row itself (an L1 hit whose
+    // candidate is INF because the padding cost is INF) so that a group is FG unconditional
+    // requests with no scalar control flow and no waits in between
+    const uint32_t so = (lane < cnt ? (sv & SRC_MASK) : v) << 9;
+    // fast path: fully unrolled, compile-time lane numbers; general path: rolled (rare, keeps the
+    // kernel small: both are inlined because a real call would need a stack, i.e. scratch memory)
+#pragma unroll(SLOW ? 1 : NFG)
     for (int gi = 0; gi < NFG; ++gi) {
       if (cnt <= (uint32_t)(gi * FG)) break;                      // one scalar branch per FG links
       uint64_t su[FG];
 #pragma unroll
-      for (int k = 0; k < FG; ++k) su[k] = ST_INF;
-#define HSPF_LD(K) su[K] = ld_st(rs, lane8, rdlane(so, gi * FG + K))
-      switch (min(cnt - (uint32_t)(gi * FG), (uint32_t)FG)) {     // exactly that many requests
-        case 4: HSPF_LD(3); [[fallthrough]];
-        case 3: HSPF_LD(2); [[fallthrough]];
-        case 2: HSPF_LD(1); [[fallthrough]];
-        default: HSPF_LD(0);
-      }
-#undef HSPF_LD
+      for (int k = 0; k < FG; ++k) su[k] = ld_st(rs, lane8, rdlane(so, gi * FG + k));
 #pragma unroll
       for (int k = 0; k < FG; ++k) {
         const uint32_t w = rdlane(wv, gi * FG + k);               // INF on padding lanes
@@ -490,6 +497,75 @@ __device__ __forceinline__ RowOut fused_row(const GraphDev &g, __amdgpu_buffer_r
   return o;
 }
 
+// Fast row routine for rows with at most 16 links (and none of the rare conditions): ALL neighbour
+// rows are requested before the first one is consumed.  The first fused kernels asked for 4 rows,
+// waited, computed, asked for the next 4: three dependent memory round trips per vertex, twelve per
+// wave, and the sweep time was exactly (waves / resident waves) x 12 x loaded latency
+// (tools/ubench/rowload.hip shows the memory system delivers random 512-byte rows 2x faster than
+// that).  Nested uniform branches instead of a counted loop so that no value needs a phi (a phi on a
+// loaded register makes the compiler wait for the load).
+struct RowAcc { uint32_t bd, bm, bpd, bh; bool sat; };
+
+template <bool MAXINF>
+__device__ __forceinline__ void acc_link(RowAcc &a, uint64_t su, uint32_t w) {
+  const uint32_t d = (uint32_t)(su >> 32), hm = (uint32_t)su;
+  const uint32_t c = add_sat(d, w);                               // INF stays INF; padding cost is INF
+  if (MAXINF && c == INF && d != INF && w != INF) a.sat = true;
+  const bool lt = c < a.bd, eq = c == a.bd;                       // c == bd == INF: harmless
+  const uint32_t hh = hm >> 16, contrib = hm & 0xFFFFu;
+  const uint32_t m_or = a.bm | contrib;
+  a.bm = lt ? contrib : (eq ? m_or : a.bm);
+  const bool newp = lt || (eq && d < a.bpd);                      // first discoverer: smallest parent dist
+  a.bpd = newp ? d : a.bpd;
+  a.bh = newp ? hh : a.bh;
+  a.bd = min(a.bd, c);
+}
+
+#define HSPF_LD4(G) const uint64_t q##G##0 = ld_st(rs, lane8, rdlane(so, 4 * G + 0)), q##G##1 = ld_st(rs, lane8, rdlane(so, 4 * G + 1)), \
+                                   q##G##2 = ld_st(rs, lane8, rdlane(so, 4 * G + 2)), q##G##3 = ld_st(rs, lane8, rdlane(so, 4 * G + 3))
+#define HSPF_AC4(G) acc_link<MAXINF>(a, q##G##0, rdlane(wv, 4 * G + 0)); acc_link<MAXINF>(a, q##G##1, rdlane(wv, 4 * G + 1)); \
+                    acc_link<MAXINF>(a, q##G##2, rdlane(wv, 4 * G + 2)); acc_link<MAXINF>(a, q##G##3, rdlane(wv, 4 * G + 3))
+
+template <bool MAXINF>
+__device__ __forceinline__ RowOut fused_row16(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v, uint32_t cnt,
+                                              uint32_t sv, uint32_t wv, uint32_t lane, uint32_t lane8,
+                                              uint32_t my_root, uint32_t maxpath) {
+  const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
+  // padding lanes point at the row itself (L1 hit) and carry cost INF
+  const uint32_t so = (lane < cnt ? (sv & SRC_MASK) : v) << 9;
+  RowAcc a{INF, 0u, INF, 0u, false};
+  HSPF_LD4(0);
+  if (cnt > 4u) {
+    HSPF_LD4(1);
+    if (cnt > 8u) {
+      HSPF_LD4(2);
+      if (cnt > 12u) {
+        HSPF_LD4(3);
+        HSPF_AC4(0); HSPF_AC4(1); HSPF_AC4(2); HSPF_AC4(3);
+      } else {
+        HSPF_AC4(0); HSPF_AC4(1); HSPF_AC4(2);
+      }
+    } else {
+      HSPF_AC4(0); HSPF_AC4(1);
+    }
+  } else {
+    HSPF_AC4(0);
+  }
+  RowOut o;
+  o.sat = a.sat;
+  o.need_exact = false;
+  if (v == my_root) o.nw = 0ull;
+  else if (a.bd == INF || a.bd > maxpath) o.nw = ST_INF;
+  else {
+    uint32_t hops = a.bh + v_router;
+    if (hops > 0xFFFFu) hops = 0xFFFFu;
+    o.nw = ((uint64_t)a.bd << 32) | ((uint64_t)hops << 16) | (uint64_t)(a.bm & 0xFFFFu);
+  }
+  return o;
+}
+#undef HSPF_LD4
+#undef HSPF_AC4
+
 template <bool MAXINF>
 __global__ __launch_bounds__(256) void k_fused(GraphDev g, uint64_t *__restrict__ st,
                                                uint32_t *__restrict__ act,
@@ -519,7 +595,7 @@ __global__ __launch_bounds__(256) void k_fused(GraphDev g, uint64_t *__restrict_
   const uint32_t root_slot = batch * 64 + lane;
   const uint32_t my_root = roots[root_slot];
   uint64_t *S = st + (size_t)batch * n * 64;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)S, (short)0, (int)(n * 512u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, n);
   const uint32_t lane8 = lane * 8u;
   const uint32_t pv = in_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
   const uint32_t po = g.out_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
@@ -542,11 +618,11 @@ __global__ __launch_bounds__(256) void k_fused(GraphDev g, uint64_t *__restrict_
     const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
     const uint64_t old = ld_st(rs, lane8, v << 9);
     const uint32_t cnt0 = min(64u, e1 - e0);
-    const bool slow = (e1 - e0) > 64u || rdlane(hb, i) != 0u ||
+    const bool slow = (e1 - e0) > 16u || rdlane(hb, i) != 0u ||
                       (!ignore_ovl && __ballot((svv[i] & SRC_NO_TRANSIT) != 0) != 0ull) ||
                       __ballot(lane < cnt0 && wvv[i] == 0u && (svv[i] & SRC_MASK) >= v) != 0ull;
     RowOut r;
-    if (!slow) r = fused_row<MAXINF, false>(g, rs, v, e0, e1, svv[i], wvv[i], lane, lane8, my_root, root_slot, tabs, maxpath, net_nexthops, ignore_ovl);
+    if (!slow) r = fused_row16<MAXINF>(g, rs, v, cnt0, svv[i], wvv[i], lane, lane8, my_root, maxpath);
     else       r = fused_row<MAXINF, true>(g, rs, v, e0, e1, svv[i], wvv[i], lane, lane8, my_root, root_slot, tabs, maxpath, net_nexthops, ignore_ovl);
     sat = sat || r.sat;
     need_exact = need_exact || r.need_exact;
