@@ -119,7 +119,7 @@ def main():
 
     pending = [None]
     phase = {"relax_ms": 0.0, "dag_ms": 0.0, "finish_ms": 0.0, "total_ms": 0.0, "n_relax": 0, "n_dag": 0,
-             "n_exact": 0}
+             "n_exact": 0, "state_bytes": 0, "narrow_overflow": 0}
 
     def step(i: int, record: bool):
         b = bufs[i & 1]
@@ -134,6 +134,7 @@ def main():
             phase["finish_ms"] += st["ms_finish"]; phase["total_ms"] += st["ms_total"]
             phase["n_relax"] += st["n_relax_launches"]; phase["n_dag"] += st["n_dag_launches"]
             phase["n_exact"] += st["n_exact_roots"]
+            phase["state_bytes"] = st["state_bytes"]; phase["narrow_overflow"] += st["narrow_overflow"]
 
     def fence():
         if pending[0] is not None:
@@ -207,7 +208,8 @@ def main():
                          "whole_run_frac": round(value / world * ba / HBM_PEAK, 5)},
             "phases_ms_per_step": {"relax": round(phase["relax_ms"] / K, 4), "dag": round(phase["dag_ms"] / K, 4),
                                    "finish": round(phase["finish_ms"] / K, 4), "device_total": round(phase["total_ms"] / K, 4),
-                                   "relax_launches": phase["n_relax"] / K, "dag_launches": phase["n_dag"] / K},
+                                   "relax_launches": phase["n_relax"] / K, "dag_launches": phase["n_dag"] / K,
+                                   "fused_state_bytes": phase["state_bytes"], "narrow_overflows": phase["narrow_overflow"]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, roots)

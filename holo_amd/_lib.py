@@ -34,7 +34,8 @@ class HspfStats(ctypes.Structure):
                 ("n_relax_launches", ctypes.c_uint32), ("n_dag_launches", ctypes.c_uint32),
                 ("n_exact_roots", ctypes.c_uint32), ("n_mask_words", ctypes.c_uint32),
                 ("ms_total", ctypes.c_float), ("ms_relax", ctypes.c_float), ("ms_dag", ctypes.c_float),
-                ("ms_finish", ctypes.c_float), ("ms_d2h", ctypes.c_float)]
+                ("ms_finish", ctypes.c_float), ("ms_d2h", ctypes.c_float),
+                ("state_bytes", ctypes.c_uint32), ("narrow_overflow", ctypes.c_uint32)]
 
 
 # every symbol include/holo_spf_hip.h declares: (name, restype, argtypes)

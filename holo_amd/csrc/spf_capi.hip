@@ -31,6 +31,8 @@ struct DevBuf {
 struct hspf_graph {
   uint32_t n = 0, e = 0, e_kept = 0;
   uint32_t max_path_metric = 0;
+  uint32_t wmax = 0;                 // largest cost among the kept links
+  mutable bool narrow_bad = false;   // a run overflowed the 4-byte fused state: use the 8-byte one
   // host copies (slot tables, validation)
   std::vector<uint32_t> row_ptr, col;
   std::vector<uint8_t> twoway;     // per original link
@@ -286,8 +288,28 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
           const uint32_t t = csr->col[k], i = cur[t]++;
           in_src[i] = u | (nt ? SRC_NO_TRANSIT : 0u);
           in_w[i] = csr->metric[k];
+          g->wmax = std::max(g->wmax, csr->metric[k]);
           in_fpos[i] = k - csr->row_ptr[u];
           out_dst[oi] = t; out_w[oi] = csr->metric[k]; out_fpos[oi] = k - csr->row_ptr[u]; ++oi;
+        }
+      }
+      // In-links of a row by (cost descending, source ascending): among tight links, i.e. equal
+      // dist[u] + cost, the first in row order has the smallest dist[u] and then the smallest u =
+      // the reference's first discoverer (earliest popped tight parent).  k_fused relies on it;
+      // k_dag / k_exact do not care.
+      {
+        std::vector<uint32_t> perm;
+        for (uint32_t t = 0; t < n; ++t) {
+          const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
+          if (b - a < 2) continue;
+          perm.resize(b - a);
+          for (uint32_t i = 0; i < b - a; ++i) perm[i] = a + i;
+          std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return in_w[x] > in_w[y]; });
+          std::vector<uint32_t> s1(b - a), s2(b - a), s3(b - a);
+          for (uint32_t i = 0; i < b - a; ++i) { s1[i] = in_src[perm[i]]; s2[i] = in_w[perm[i]]; s3[i] = in_fpos[perm[i]]; }
+          std::copy(s1.begin(), s1.end(), in_src.begin() + a);
+          std::copy(s2.begin(), s2.end(), in_w.begin() + a);
+          std::copy(s3.begin(), s3.end(), in_fpos.begin() + a);
         }
       }
       auto up = [&](uint32_t **d, const std::vector<uint32_t> &h) -> hipError_t {
@@ -409,10 +431,30 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   const uint32_t out_words = want_mask ? out->n_mask_words : W;
   st.n_mask_words = need_words;
 
-  // Fast path: every root has <= 16 first-hop slots -> one fused fixed point over a packed 8-byte
-  // state (k_fused); otherwise distances first, then the SPT-DAG phase with W mask words.
-  // HSPF_VARIANT bit0 forces the two-phase path (A/B measurements).
+  // Fast path: every root has <= 16 first-hop slots -> one fused fixed point over a packed state
+  // (k_fused), 4 bytes per (vertex, root) when the slots, hop counts and distances fit (checked on
+  // device, LF_OVERFLOW -> the run is redone with the 8-byte state and the graph remembers), else 8;
+  // otherwise distances first, then the SPT-DAG phase with W mask words.
+  // HSPF_VARIANT bit0 forces the two-phase path, bit1 forbids the narrow state (A/B measurements).
   const bool fused = max_slots <= 16 && n < (1u << 23) && !(ctx->variant & 1u);
+  FusedParams fp_wide{0u, 16u, 0xFFFFu, 0xFFFFFFFFu, g->max_path_metric, 0xFFFFFFFFu};
+  FusedParams fp_narrow = fp_wide;
+  bool narrow = false;
+  if (fused && !g->narrow_bad && !(ctx->variant & 2u)) {
+    // field split of the 4-byte state: M mask bits = slots of this run, 7 hop bits (6 when that
+    // leaves fewer than 13 distance bits), the rest distance; used when a link cost is at most
+    // 1/8 of the distance range and there are at least 12 distance bits
+    const uint32_t M = std::max(max_slots, 1u);
+    const uint32_t H = (32u - M - 7u >= 13u) ? 7u : 6u;
+    const uint32_t sh = M + H, D = 32u - sh;
+    const uint32_t dmax = (1u << D) - 1u;
+    if (D >= 12u && g->wmax < (1u << (D - 3))) {
+      narrow = true;
+      fp_narrow = FusedParams{sh, M, (1u << H) - 1u, dmax << sh,
+                              g->max_path_metric >= dmax ? 0xFFFFFFFFu : (g->max_path_metric << sh),
+                              (dmax - g->wmax) << sh};
+    }
+  }
   // ---- scratch
   int rc;
   const size_t rows = (size_t)B * n * 64;
@@ -480,10 +522,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
   HIPCHK(ctx, hipMemsetAsync(d_lf, 0, (size_t)L * 4, s));
   if (fused) {
-    HIPCHK(ctx, hipMemsetAsync(d_st, 0xFF, rows * 8, s));
-    HIPCHK(ctx, hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s));
-    HIPCHK(ctx, hipMemsetAsync(ctx->hnb.p, 0, (size_t)B * n, s));
-    hipLaunchKernelGGL(k_init_fused, dim3((L + 255) / 256), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
+    // state / stamps are initialised by fused_run (it may run twice: narrow, then wide)
   } else {
     HIPCHK(ctx, hipMemsetAsync(d_dist, 0xFF, rows * 4, s));
     HIPCHK(ctx, hipMemsetAsync(d_hv, 0, rows * 4, s));
@@ -528,19 +567,43 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
   if (fused) {
-    uint32_t n_f = 0;
-    rc = run_phase(ctx->est_fused, [&](uint32_t sweep) {
-      if (g->max_path_metric == HSPF_DIST_INF)
-        hipLaunchKernelGGL((k_fused<true>), grid, dim3(256), 0, s, gd, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, tabs, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
-      else
-        hipLaunchKernelGGL((k_fused<false>), grid, dim3(256), 0, s, gd, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, tabs, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
-    }, n_f);
-    if (rc) return rc;
-    ctx->est_fused = n_f + 1;
-    st.n_relax_launches = n_f;
+    auto fused_run = [&](bool nar) -> int {
+      const FusedParams P = nar ? fp_narrow : fp_wide;
+      const size_t esz = nar ? 4 : 8;
+      hipError_t er = hipMemsetAsync(d_lf, 0, (size_t)L * 4, s);
+      if (er == hipSuccess) er = hipMemsetAsync(d_st, 0xFF, rows * esz, s);
+      if (er == hipSuccess) er = hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s);
+      if (er == hipSuccess) er = hipMemsetAsync(ctx->hnb.p, 0, (size_t)B * n, s);
+      if (er != hipSuccess) { ctx->last_error = std::string("fused init: ") + hipGetErrorString(er); return HSPF_E_HIP; }
+      if (nar) hipLaunchKernelGGL((k_init_fused<uint32_t>), dim3((L + 255) / 256), dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
+      else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 255) / 256), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
+      uint32_t n_f = 0;
+      const bool maxinf = g->max_path_metric == HSPF_DIST_INF;
+      int r2 = run_phase(ctx->est_fused, [&](uint32_t sweep) {
+        if (nar)         hipLaunchKernelGGL((k_fused<uint32_t, false>), grid, dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, tabs, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+        else if (maxinf) hipLaunchKernelGGL((k_fused<uint64_t, true>), grid, dim3(256), 0, s, gd, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, tabs, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+        else             hipLaunchKernelGGL((k_fused<uint64_t, false>), grid, dim3(256), 0, s, gd, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, tabs, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+      }, n_f);
+      if (r2) return r2;
+      ctx->est_fused = n_f + 1;
+      st.n_relax_launches += n_f;
+      return HSPF_OK;
+    };
+    if (narrow) {
+      if ((rc = fused_run(true))) return rc;
+      // did any lane leave the 4-byte fields?  (run_phase has synchronised the stream)
+      HIPCHK(ctx, hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(ctx, hipStreamSynchronize(s));
+      bool ovf = false;
+      for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);
+      if (ovf) { g->narrow_bad = true; narrow = false; st.narrow_overflow = 1; }
+    }
+    if (!narrow && (rc = fused_run(false))) return rc;
+    st.state_bytes = narrow ? 4 : 8;
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
-    hipLaunchKernelGGL(k_emit_fused, dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, d_st, od);
+    if (narrow) hipLaunchKernelGGL((k_emit_fused<uint32_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint32_t *)d_st, fp_narrow, od);
+    else        hipLaunchKernelGGL((k_emit_fused<uint64_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint64_t *)d_st, fp_wide, od);
   } else {
   uint32_t n_relax = 0;
   rc = run_phase(ctx->est_relax, [&](uint32_t sweep) {

@@ -41,6 +41,7 @@ constexpr uint32_t HV_EPOCH_MAX = 0xFFFFu;
 
 // per-root (lane) status bits
 constexpr uint32_t LF_NEED_EXACT = 1u;   // static pop order not provable / saturation: use k_exact
+constexpr uint32_t LF_OVERFLOW = 2u;     // narrow fused state could not hold a value: redo the run wide
 
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int VPW = 4;                    // vertices per wave per block
@@ -357,162 +358,99 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
 
 // ---------------------------------------------------------------------------------------------
 // Fused sweep (the fast path when every root of the run has <= 16 first-hop slots): ONE
-// label-correcting fixed point over the packed per-(vertex, root) state
-//     [63:32] dist   [31:16] hops   [15:0] first-hop mask        (all ones = not reached)
-// instead of a distance phase followed by a DAG phase.  Every recomputation of a lane is a pure
-// function of its in-neighbours' states:
+// label-correcting fixed point over a packed per-(vertex, root) state instead of a distance phase
+// followed by a DAG phase.  Two state widths, same code (template parameter ST):
+//   wide   (uint64_t)  [63:32] dist   [31:16] hops   [15:0] first-hop mask
+//   narrow (uint32_t)  [31:sh] dist   [sh-1:M] hops  [M-1:0] mask      (M = slots of the run,
+//          H = sh-M hop bits; chosen by the host when the graph's costs fit; a lane that gets
+//          within one link cost of the field limit, or too many hops, raises LF_OVERFLOW and the
+//          whole run is redone wide -> results never depend on the width)
+// all ones = not reached.  Every recomputation of a lane is a pure function of its in-neighbours':
 //     dist  = min over in-links of dist[u] (+) w           (gates as in k_relax)
 //     mask  = OR over the links attaining the min of (hops[u] == 0 ? slot bit : mask[u])
 //     hops  = hops[p0] + is_router(v),  p0 = first link (ascending source) with the smallest dist[u]
 // so the unique fixed point is the reference's result whenever its pop order is the static
 // (dist, index) order (same proof obligation as k_dag; lanes that violate it are flagged for
-// k_exact).  An 8-byte state is read and written by single dwordx2 accesses, so a reader can never
-// see a distance with somebody else's mask.  Stale reads inside a launch are harmless: memory is
+// k_exact).  A state is read and written by ONE access per lane, so a reader can never see a
+// distance with somebody else's mask.  Stale reads inside a launch are harmless: memory is
 // monotone across launches and the run ends only after a launch in which nothing changed.
+//
+// Arithmetic is done in "key space": dkey = the distance field left in place (low bits zero),
+// wkey = cost << sh, candidate = v_add_u32 clamp: a sum that leaves the field saturates to all
+// ones, which is >= inf_t, i.e. "not reached"; comparisons are plain u32 compares.
 //
 // Row skipping by PUSH activation: act[v] = id of the latest sweep in which row v has to be
 // recomputed.  A wave that changes row u in sweep c stamps c+1 on u's out-neighbours (<= deg
 // scattered 4-byte stores), so the next sweep's "is there anything to do here" test is ONE load
-// per wave instead of a gather over the in-neighbours, and a sweep with nothing to do costs a few
-// microseconds.  A stale or racing stamp can only cause an extra recomputation, never a missed
-// one: every change made in sweep c is seen (kernel boundary) by all its dependents in sweep c+1.
-// Measured on isis-100k the run visits ~21 of 34 row-sweeps.
+// per wave, and a sweep with nothing to do costs a few microseconds.  A stale or racing stamp can
+// only cause an extra recomputation, never a missed one: every change made in sweep c is seen
+// (kernel boundary) by all its dependents in sweep c+1.  isis-100k: ~21 of 34 row-sweeps visited.
 //
-// Memory-level parallelism (profiles/r01b_*: the first version was latency bound, 64 % of wave
-// cycles in s_waitcnt with 4 row loads in flight per wave): the link vectors of all VPW vertices
-// are fetched up front, and the neighbour rows of a vertex are requested 8 at a time with the
-// exact count (computed goto-free by a fall-through switch), 512 B per request per wave.
-constexpr uint64_t ST_INF = ~0ull;
-constexpr int FG = 4;             // neighbour rows requested per group
-constexpr int NFG = 64 / FG;
+// Memory-level parallelism: the link vectors of all VPW vertices are fetched up front and ALL
+// neighbour rows of a row are requested before the first one is consumed (profiles/r01b notes:
+// the first versions, 4 rows per round trip, ran at exactly waves/resident x 12 x loaded latency).
+struct FusedParams {
+  uint32_t sh;        // bit position of the dist field (narrow) / 0 (wide: dist is the high word)
+  uint32_t mbits;     // mask field width
+  uint32_t hmax;      // largest representable hops value
+  uint32_t inf_t;     // dkey >= inf_t  <=> not reached
+  uint32_t maxkey;    // dkey >  maxkey <=> beyond max_path_metric
+  uint32_t ovf_t;     // narrow: dkey >= ovf_t (and reached) -> a later sum could leave the field
+};
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-// One packed row element through a raw buffer load: address = rsrc.base + voff (lane * 8, VGPR) +
-// soff (row byte offset, SGPR straight out of v_readlane) -> no vector ALU work per link for
-// addressing (profiles/r01b_pmc_fused_v1.json: the first fused kernel was issue bound, 24 M scalar
-// + 33 M vector instructions per sweep, not memory bound).
-__device__ __forceinline__ uint64_t ld_st(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
-  const u32x2 x = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-  return ((uint64_t)x.y << 32) | x.x;
-}
-
 // Buffer resource of one batch's state slab, built from values forced into SGPRs: a descriptor
-// that the compiler keeps in VGPRs (e.g. a function argument) turns every load into a waterfall loop.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const uint64_t *S, uint32_t n) {
+// that the compiler keeps in VGPRs turns every load into a waterfall loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void *S, uint32_t bytes) {
   const uint64_t a = (uint64_t)S;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
   const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
   return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), (short)0,
-                                           (int)__builtin_amdgcn_readfirstlane(n * 512u), 0x00020000);
+                                           (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-struct RowOut { uint64_t nw; bool sat, need_exact; };
-
-// Recompute one row (64 roots of vertex v).  SLOW = false: no overloaded source, no zero-cost link
-// from a higher-numbered source, no in-neighbour that can have hops == 0, at most 64 links:
-// straight-line groups of FG links, no per-link scalar control flow.  SLOW = true: everything.
-template <bool MAXINF, bool SLOW>
-__device__ __attribute__((always_inline)) inline RowOut fused_row(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v,
-                                            uint32_t e0, uint32_t e1, uint32_t sv0, uint32_t wv0,
-                                            uint32_t lane, uint32_t lane8, uint32_t my_root,
-                                            uint32_t root_slot, const SlotTabs &tabs, uint32_t maxpath,
-                                            uint32_t net_nexthops, uint32_t ignore_ovl) {
-  const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
-  uint32_t bd = INF, bm = 0, bpd = INF, bh = 0, bd_all = INF;
-  bool sat = false;
-  for (uint32_t eb = e0; eb < e1; eb += 64) {
-    const uint32_t cnt = min(64u, e1 - eb);
-    uint32_t sv = sv0, wv = wv0;                                  // padding lanes: cost INF
-    if (SLOW && eb != e0) {
-      sv = lane < cnt ? g.in_src[eb + lane] : v;
-      wv = lane < cnt ? g.in_w[eb + lane] : INF;
-    }
-    const bool has_nt = SLOW && !ignore_ovl && __ballot((sv & SRC_NO_TRANSIT) != 0) != 0ull;
-    const uint32_t zv = (SLOW && lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
-    const bool has_z = SLOW && __ballot(zv != 0u) != 0ull;
-    // row byte offsets, lane j = link j; padding lanes point at the row itself (an L1 hit whose
-    // candidate is INF because the padding cost is INF) so that a group is FG unconditional
-    // requests with no scalar control flow and no waits in between
-    const uint32_t so = (lane < cnt ? (sv & SRC_MASK) : v) << 9;
-    // fast path: fully unrolled, compile-time lane numbers; general path: rolled (rare, keeps the
-    // kernel small: both are inlined because a real call would need a stack, i.e. scratch memory)
-#pragma unroll(SLOW ? 1 : NFG)
-    for (int gi = 0; gi < NFG; ++gi) {
-      if (cnt <= (uint32_t)(gi * FG)) break;                      // one scalar branch per FG links
-      uint64_t su[FG];
-#pragma unroll
-      for (int k = 0; k < FG; ++k) su[k] = ld_st(rs, lane8, rdlane(so, gi * FG + k));
-#pragma unroll
-      for (int k = 0; k < FG; ++k) {
-        const uint32_t w = rdlane(wv, gi * FG + k);               // INF on padding lanes
-        uint32_t d = (uint32_t)(su[k] >> 32);
-        const uint32_t hm = (uint32_t)su[k];
-        if (has_nt) {                                             // uniform, rare
-          const uint32_t sw = rdlane(sv, gi * FG + k);
-          if ((sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;
-        }
-        const uint32_t c = add_sat(d, w);                         // INF stays INF
-        if (MAXINF && c == INF && d != INF && w != INF) sat = true;
-        if (has_z) {                                              // uniform, rare
-          if (rdlane(zv, gi * FG + k)) { bd_all = min(bd_all, c); continue; }
-        }
-        const bool lt = c < bd;
-        const bool eq = c == bd;          // c == bd == INF also lands here: harmless, row ends as ST_INF
-        const uint32_t hh = hm >> 16;
-        uint32_t contrib = hm & 0xFFFFu;
-        if (SLOW) {
-          const bool direct = (lt || eq) && hh == 0u && c != INF;  // parent: root or hops-0 network
-          if (__ballot(direct) != 0ull) {
-            const uint32_t u = rdlane(sv, gi * FG + k) & SRC_MASK;
-            const uint32_t fpos = g.in_fpos[eb + gi * FG + k];
-            if (direct) {
-              const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(tabs, root_slot, u);
-              const uint32_t sidx = base_s + fpos;
-              contrib = ((v_router || net_nexthops) && sidx < 16u) ? (1u << sidx) : 0u;
-            }
-          }
-        }
-        const uint32_t m_or = bm | contrib;
-        bm = lt ? contrib : (eq ? m_or : bm);
-        const bool newp = lt || (eq && d < bpd);                  // first discoverer: smallest parent dist
-        bpd = newp ? d : bpd;
-        bh = newp ? hh : bh;
-        bd = min(bd, c);
-      }
-    }
+// One row element through a raw buffer load: address = rsrc.base + voff (lane * sizeof(ST), VGPR)
+// + soff (row byte offset, SGPR straight out of v_readlane): no vector ALU work per link for
+// addressing.  Split into (dkey, pay): pay = hops << mbits | mask.
+template <typename ST> struct StIO;
+template <> struct StIO<uint64_t> {
+  static constexpr uint32_t ROW_SHIFT = 9;
+  struct Raw { u32x2 x; };
+  static __device__ __forceinline__ Raw ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return Raw{__builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0)};
   }
-  RowOut o;
-  o.sat = sat;
-  if (v == my_root) o.nw = 0ull;                                  // dist 0, hops 0, no next hops
-  else if (bd == INF || bd > maxpath) o.nw = ST_INF;
-  else {
-    uint32_t hops = bh + v_router;
-    if (hops > 0xFFFFu) hops = 0xFFFFu;                           // u16 saturating_add
-    o.nw = ((uint64_t)bd << 32) | ((uint64_t)hops << 16) | (uint64_t)(bm & 0xFFFFu);
+  static __device__ __forceinline__ uint32_t dkey(const Raw &q, const FusedParams &) { return q.x.y; }
+  static __device__ __forceinline__ uint32_t pay(const Raw &q, const FusedParams &) { return q.x.x; }
+  static __device__ __forceinline__ uint64_t join(uint32_t dk, uint32_t hops, uint32_t mask, const FusedParams &) {
+    return ((uint64_t)dk << 32) | ((uint64_t)hops << 16) | mask;
   }
-  // a shorter (or the only) way in through a zero-cost link from a higher-numbered source: the
-  // reference's pop order is dynamic there -> whole root goes to k_exact
-  o.need_exact = SLOW && v != my_root && bd_all <= maxpath && bd_all < bd;
-  return o;
-}
+  static __device__ __forceinline__ uint64_t bits(const Raw &q) { return ((uint64_t)q.x.y << 32) | q.x.x; }
+};
+template <> struct StIO<uint32_t> {
+  static constexpr uint32_t ROW_SHIFT = 8;
+  struct Raw { uint32_t x; };
+  static __device__ __forceinline__ Raw ld(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return Raw{__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0)};
+  }
+  static __device__ __forceinline__ uint32_t dkey(const Raw &q, const FusedParams &P) { return q.x & ~((1u << P.sh) - 1u); }
+  static __device__ __forceinline__ uint32_t pay(const Raw &q, const FusedParams &P) { return q.x & ((1u << P.sh) - 1u); }
+  static __device__ __forceinline__ uint32_t join(uint32_t dk, uint32_t hops, uint32_t mask, const FusedParams &P) {
+    return dk | (hops << P.mbits) | mask;
+  }
+  static __device__ __forceinline__ uint32_t bits(const Raw &q) { return q.x; }
+};
 
-// Fast row routine for rows with at most 16 links (and none of the rare conditions): ALL neighbour
-// rows are requested before the first one is consumed.  The first fused kernels asked for 4 rows,
-// waited, computed, asked for the next 4: three dependent memory round trips per vertex, twelve per
-// wave, and the sweep time was exactly (waves / resident waves) x 12 x loaded latency
-// (tools/ubench/rowload.hip shows the memory system delivers random 512-byte rows 2x faster than
-// that).  Nested uniform branches instead of a counted loop so that no value needs a phi (a phi on a
-// loaded register makes the compiler wait for the load).
 struct RowAcc { uint32_t bd, bm, bpd, bh; bool sat; };
+template <typename ST> struct RowOut { ST nw; bool sat, need_exact, ovf; };
 
-template <bool MAXINF>
-__device__ __forceinline__ void acc_link(RowAcc &a, uint64_t su, uint32_t w) {
-  const uint32_t d = (uint32_t)(su >> 32), hm = (uint32_t)su;
-  const uint32_t c = add_sat(d, w);                               // INF stays INF; padding cost is INF
-  if (MAXINF && c == INF && d != INF && w != INF) a.sat = true;
-  const bool lt = c < a.bd, eq = c == a.bd;                       // c == bd == INF: harmless
-  const uint32_t hh = hm >> 16, contrib = hm & 0xFFFFu;
+template <typename ST, bool MAXINF>
+__device__ __forceinline__ void acc_link(RowAcc &a, const typename StIO<ST>::Raw &q, uint32_t wkey, const FusedParams &P) {
+  const uint32_t d = StIO<ST>::dkey(q, P), pay = StIO<ST>::pay(q, P);
+  const uint32_t c = add_sat(d, wkey);                            // leaves the field -> all ones
+  if (MAXINF && sizeof(ST) == 8 && c == INF && d != INF && wkey != INF) a.sat = true;
+  const bool lt = c < a.bd, eq = c == a.bd;                       // c == bd == "not reached": harmless
+  const uint32_t hh = pay >> P.mbits, contrib = pay & ((1u << P.mbits) - 1u);
   const uint32_t m_or = a.bm | contrib;
   a.bm = lt ? contrib : (eq ? m_or : a.bm);
   const bool newp = lt || (eq && d < a.bpd);                      // first discoverer: smallest parent dist
@@ -521,19 +459,68 @@ __device__ __forceinline__ void acc_link(RowAcc &a, uint64_t su, uint32_t w) {
   a.bd = min(a.bd, c);
 }
 
-#define HSPF_LD4(G) const uint64_t q##G##0 = ld_st(rs, lane8, rdlane(so, 4 * G + 0)), q##G##1 = ld_st(rs, lane8, rdlane(so, 4 * G + 1)), \
-                                   q##G##2 = ld_st(rs, lane8, rdlane(so, 4 * G + 2)), q##G##3 = ld_st(rs, lane8, rdlane(so, 4 * G + 3))
-#define HSPF_AC4(G) acc_link<MAXINF>(a, q##G##0, rdlane(wv, 4 * G + 0)); acc_link<MAXINF>(a, q##G##1, rdlane(wv, 4 * G + 1)); \
-                    acc_link<MAXINF>(a, q##G##2, rdlane(wv, 4 * G + 2)); acc_link<MAXINF>(a, q##G##3, rdlane(wv, 4 * G + 3))
+template <typename ST>
+__device__ __forceinline__ RowOut<ST> finish_row(const RowAcc &a, uint32_t v, uint32_t my_root, uint32_t v_router,
+                                                 uint32_t bd_all, const FusedParams &P) {
+  RowOut<ST> o;
+  o.sat = a.sat;
+  o.ovf = false;
+  if (v == my_root) o.nw = (ST)0;                                 // dist 0, hops 0, no next hops
+  else if (a.bd >= P.inf_t || a.bd > P.maxkey) o.nw = (ST)~(ST)0;
+  else {
+    uint32_t hops = a.bh + v_router;
+    if (hops > P.hmax) { hops = P.hmax; o.ovf = sizeof(ST) == 4; }   // wide: u16 saturating_add
+    o.ovf = o.ovf || a.bd >= P.ovf_t;
+    o.nw = StIO<ST>::join(a.bd, hops, a.bm & ((1u << P.mbits) - 1u), P);
+  }
+  // a shorter (or the only) way in through a zero-cost link from a higher-numbered source: the
+  // reference's pop order is dynamic there -> whole root goes to k_exact
+  o.need_exact = v != my_root && bd_all < P.inf_t && bd_all <= P.maxkey && bd_all < a.bd;
+  return o;
+}
 
-template <bool MAXINF>
-__device__ __forceinline__ RowOut fused_row16(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v, uint32_t cnt,
-                                              uint32_t sv, uint32_t wv, uint32_t lane, uint32_t lane8,
-                                              uint32_t my_root, uint32_t maxpath) {
+// Fast row routine: at most 16 links and none of the rare conditions.  The kernel is bound by
+// vector-ALU issue, not by bytes (a wave64 integer op occupies its SIMD for 4 cycles; the 4-byte and
+// the 8-byte state run at the same speed), so the routine is written for instruction count:
+//   pass 1   c_j = dkey_j (+) wkey_j ;  bd = min(c_j)            (v_add_u32 clamp, v_min3_u32)
+//   pass 2   t_j = (c_j == bd) ;  macc |= t_j ? pay_j : 0 ;  bpay = t_j ? pay_j : bpay   (LAST link first)
+// = 5 vector instructions per link plus two v_readlane.  The in-links of a row are stored by
+// (cost descending, source ascending) — see hspf_graph_upload — so among the tight links (equal
+// c_j) the FIRST one in row order is the one with the smallest parent distance and, on ties, the
+// smallest parent index: the reference's first discoverer.  Walking pass 2 backwards makes a plain
+// overwrite end on it.  Nested uniform branches instead of a counted loop so that no loaded value
+// needs a phi (a phi on a loaded register makes the compiler wait for the load).
+template <typename ST> struct PayBits;
+template <> struct PayBits<uint64_t> { static __device__ __forceinline__ uint32_t of(const StIO<uint64_t>::Raw &q) { return q.x.x; } };
+template <> struct PayBits<uint32_t> { static __device__ __forceinline__ uint32_t of(const StIO<uint32_t>::Raw &q) { return q.x; } };
+
+#define HSPF_LD4(G) const typename StIO<ST>::Raw q##G##0 = StIO<ST>::ld(rs, lvo, rdlane(so, 4 * G + 0)), q##G##1 = StIO<ST>::ld(rs, lvo, rdlane(so, 4 * G + 1)), \
+                                                 q##G##2 = StIO<ST>::ld(rs, lvo, rdlane(so, 4 * G + 2)), q##G##3 = StIO<ST>::ld(rs, lvo, rdlane(so, 4 * G + 3))
+#define HSPF_C1(G, K) const uint32_t c##G##K = cand<ST, MAXINF>(q##G##K, rdlane(wk, 4 * G + K), P, sat)
+#define HSPF_C4(G) HSPF_C1(G, 0); HSPF_C1(G, 1); HSPF_C1(G, 2); HSPF_C1(G, 3); \
+                   bd = min(min(bd, min(c##G##0, c##G##1)), min(c##G##2, c##G##3))
+#define HSPF_T1(G, K) { const bool t = c##G##K == bd; const uint32_t pb = PayBits<ST>::of(q##G##K); \
+                        macc |= t ? pb : 0u; bpay = t ? pb : bpay; }
+#define HSPF_T4(G) HSPF_T1(G, 3) HSPF_T1(G, 2) HSPF_T1(G, 1) HSPF_T1(G, 0)
+
+template <typename ST, bool MAXINF>
+__device__ __forceinline__ uint32_t cand(const typename StIO<ST>::Raw &q, uint32_t wkey, const FusedParams &P, bool &sat) {
+  const uint32_t d = StIO<ST>::dkey(q, P);
+  const uint32_t c = add_sat(d, wkey);                            // leaves the field -> all ones
+  if (MAXINF && sizeof(ST) == 8 && c == INF && d != INF && wkey != INF) sat = true;
+  return c;
+}
+
+template <typename ST, bool MAXINF>
+__device__ __forceinline__ RowOut<ST> fused_row16(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v, uint32_t cnt,
+                                                  uint32_t sv, uint32_t wv, uint32_t lane, uint32_t lvo,
+                                                  uint32_t my_root, const FusedParams &P) {
   const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
-  // padding lanes point at the row itself (L1 hit) and carry cost INF
-  const uint32_t so = (lane < cnt ? (sv & SRC_MASK) : v) << 9;
-  RowAcc a{INF, 0u, INF, 0u, false};
+  // padding lanes point at the row itself (L1 hit) and carry cost "infinite"
+  const uint32_t so = (lane < cnt ? (sv & SRC_MASK) : v) << StIO<ST>::ROW_SHIFT;
+  const uint32_t wk = lane < cnt ? (wv << P.sh) : INF;            // host guarantees wv << sh fits
+  uint32_t bd = INF, macc = 0u, bpay = 0u;
+  bool sat = false;
   HSPF_LD4(0);
   if (cnt > 4u) {
     HSPF_LD4(1);
@@ -541,39 +528,102 @@ __device__ __forceinline__ RowOut fused_row16(const GraphDev &g, __amdgpu_buffer
       HSPF_LD4(2);
       if (cnt > 12u) {
         HSPF_LD4(3);
-        HSPF_AC4(0); HSPF_AC4(1); HSPF_AC4(2); HSPF_AC4(3);
+        HSPF_C4(0); HSPF_C4(1); HSPF_C4(2); HSPF_C4(3);
+        HSPF_T4(3) HSPF_T4(2) HSPF_T4(1) HSPF_T4(0)
       } else {
-        HSPF_AC4(0); HSPF_AC4(1); HSPF_AC4(2);
+        HSPF_C4(0); HSPF_C4(1); HSPF_C4(2);
+        HSPF_T4(2) HSPF_T4(1) HSPF_T4(0)
       }
     } else {
-      HSPF_AC4(0); HSPF_AC4(1);
+      HSPF_C4(0); HSPF_C4(1);
+      HSPF_T4(1) HSPF_T4(0)
     }
   } else {
-    HSPF_AC4(0);
+    HSPF_C4(0);
+    HSPF_T4(0)
   }
-  RowOut o;
-  o.sat = a.sat;
-  o.need_exact = false;
-  if (v == my_root) o.nw = 0ull;
-  else if (a.bd == INF || a.bd > maxpath) o.nw = ST_INF;
-  else {
-    uint32_t hops = a.bh + v_router;
-    if (hops > 0xFFFFu) hops = 0xFFFFu;
-    o.nw = ((uint64_t)a.bd << 32) | ((uint64_t)hops << 16) | (uint64_t)(a.bm & 0xFFFFu);
-  }
-  return o;
+  // pay bits of the winner / of the union: wide = the low word, narrow = the whole word (distance
+  // bits are dropped by the masks below)
+  RowAcc a;
+  a.bd = bd; a.sat = sat; a.bpd = 0u;
+  a.bm = macc & ((1u << P.mbits) - 1u);
+  a.bh = (bpay >> P.mbits) & P.hmax;
+  if (sizeof(ST) == 8) a.bh = (bpay >> 16);
+  return finish_row<ST>(a, v, my_root, v_router, INF, P);
 }
 #undef HSPF_LD4
-#undef HSPF_AC4
+#undef HSPF_C1
+#undef HSPF_C4
+#undef HSPF_T1
+#undef HSPF_T4
 
-template <bool MAXINF>
-__global__ __launch_bounds__(256) void k_fused(GraphDev g, uint64_t *__restrict__ st,
-                                               uint32_t *__restrict__ act,
+// General row routine (rare: rows next to a vertex that can have hops == 0, overloaded sources,
+// zero-cost links from higher-numbered sources, more than 16 links): one link at a time, rolled
+// loops.  Inlined all the same: a real call would need a stack, i.e. scratch memory.
+template <typename ST, bool MAXINF>
+__device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v,
+                                                    uint32_t e0, uint32_t e1, uint32_t sv0, uint32_t wv0,
+                                                    uint32_t lane, uint32_t lvo, uint32_t my_root,
+                                                    uint32_t root_slot, const SlotTabs &tabs,
+                                                    uint32_t net_nexthops, uint32_t ignore_ovl,
+                                                    const FusedParams &P) {
+  const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
+  RowAcc a{INF, 0u, INF, 0u, false};
+  uint32_t bd_all = INF;
+  for (uint32_t eb = e0; eb < e1; eb += 64) {
+    const uint32_t cnt = min(64u, e1 - eb);
+    uint32_t sv = sv0, wv = wv0;
+    if (eb != e0) {
+      sv = lane < cnt ? g.in_src[eb + lane] : v;
+      wv = lane < cnt ? g.in_w[eb + lane] : INF;
+    }
+    const bool has_nt = !ignore_ovl && __ballot(lane < cnt && (sv & SRC_NO_TRANSIT) != 0) != 0ull;
+    const uint32_t zv = (lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
+    const bool has_z = __ballot(zv != 0u) != 0ull;
+    const uint32_t so = (lane < cnt ? (sv & SRC_MASK) : v) << StIO<ST>::ROW_SHIFT;
+    const uint32_t wk = lane < cnt ? (wv << P.sh) : INF;
+#pragma unroll 1
+    for (uint32_t j = 0; j < cnt; ++j) {
+      const typename StIO<ST>::Raw q0 = StIO<ST>::ld(rs, lvo, rdlane(so, j));
+      typename StIO<ST>::Raw q = q0;
+      const uint32_t w = rdlane(wk, j);
+      const uint32_t sw = rdlane(sv, j);
+      uint32_t d = StIO<ST>::dkey(q, P);
+      uint32_t pay = StIO<ST>::pay(q, P);
+      if (has_nt && (sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;   // overloaded source
+      const uint32_t c = add_sat(d, w);
+      if (MAXINF && sizeof(ST) == 8 && c == INF && d != INF && w != INF) a.sat = true;
+      if (has_z && rdlane(zv, j)) { bd_all = min(bd_all, c); continue; }
+      const bool lt = c < a.bd, eq = c == a.bd;
+      const uint32_t hh = pay >> P.mbits;
+      uint32_t contrib = pay & ((1u << P.mbits) - 1u);
+      const bool direct = (lt || eq) && hh == 0u && c < P.inf_t;  // parent: root or hops-0 network
+      if (__ballot(direct) != 0ull) {
+        const uint32_t u = sw & SRC_MASK;
+        const uint32_t fpos = g.in_fpos[eb + j];
+        if (direct) {
+          const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(tabs, root_slot, u);
+          const uint32_t sidx = base_s + fpos;
+          contrib = ((v_router || net_nexthops) && sidx < P.mbits) ? (1u << sidx) : 0u;
+        }
+      }
+      const uint32_t m_or = a.bm | contrib;
+      a.bm = lt ? contrib : (eq ? m_or : a.bm);
+      const bool newp = lt || (eq && d < a.bpd);
+      a.bpd = newp ? d : a.bpd;
+      a.bh = newp ? hh : a.bh;
+      a.bd = min(a.bd, c);
+    }
+  }
+  return finish_row<ST>(a, v, my_root, v_router, bd_all, P);
+}
+
+template <typename ST, bool MAXINF>
+__global__ __launch_bounds__(256) void k_fused(GraphDev g, ST *__restrict__ st, uint32_t *__restrict__ act,
                                                const uint8_t *__restrict__ hnb,
                                                const uint32_t *__restrict__ roots, SlotTabs tabs,
-                                               uint32_t maxpath, uint32_t net_nexthops,
-                                               uint32_t ignore_ovl, int *changed, int sweep,
-                                               uint32_t *lane_flags) {
+                                               FusedParams P, uint32_t net_nexthops, uint32_t ignore_ovl,
+                                               int *changed, int sweep, uint32_t *lane_flags) {
   if (sweep > 0 && changed[sweep - 1] == 0) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -594,9 +644,9 @@ __global__ __launch_bounds__(256) void k_fused(GraphDev g, uint64_t *__restrict_
   const uint32_t *__restrict__ in_w = g.in_w;
   const uint32_t root_slot = batch * 64 + lane;
   const uint32_t my_root = roots[root_slot];
-  uint64_t *S = st + (size_t)batch * n * 64;
-  const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, n);
-  const uint32_t lane8 = lane * 8u;
+  ST *S = st + (size_t)batch * n * 64;
+  const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, n << StIO<ST>::ROW_SHIFT);
+  const uint32_t lvo = lane * (uint32_t)sizeof(ST);
   const uint32_t pv = in_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
   const uint32_t po = g.out_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
   // link vectors (first 64 links) of all active vertices, requested back to back
@@ -609,25 +659,26 @@ __global__ __launch_bounds__(256) void k_fused(GraphDev g, uint64_t *__restrict_
     svv[i] = on ? in_src[e0 + lane] : min(v, n - 1);
     wvv[i] = on ? in_w[e0 + lane] : INF;
   }
-  bool any = false, sat = false, need_exact = false;
+  bool any = false, sat = false, need_exact = false, ovf = false;
   auto row = [&](auto I) {                                        // explicit 4x instantiation: compile-time lane numbers
     constexpr int i = decltype(I)::value;
     const uint32_t v = vbeg + i;
     if (v >= n) return;
     if (rdlane(av, i) < cur) return;                              // nothing changed around this row
     const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
-    const uint64_t old = ld_st(rs, lane8, v << 9);
+    const typename StIO<ST>::Raw oldq = StIO<ST>::ld(rs, lvo, v << StIO<ST>::ROW_SHIFT);
     const uint32_t cnt0 = min(64u, e1 - e0);
     const bool slow = (e1 - e0) > 16u || rdlane(hb, i) != 0u ||
-                      (!ignore_ovl && __ballot((svv[i] & SRC_NO_TRANSIT) != 0) != 0ull) ||
+                      (!ignore_ovl && __ballot(lane < cnt0 && (svv[i] & SRC_NO_TRANSIT) != 0) != 0ull) ||
                       __ballot(lane < cnt0 && wvv[i] == 0u && (svv[i] & SRC_MASK) >= v) != 0ull;
-    RowOut r;
-    if (!slow) r = fused_row16<MAXINF>(g, rs, v, cnt0, svv[i], wvv[i], lane, lane8, my_root, maxpath);
-    else       r = fused_row<MAXINF, true>(g, rs, v, e0, e1, svv[i], wvv[i], lane, lane8, my_root, root_slot, tabs, maxpath, net_nexthops, ignore_ovl);
+    RowOut<ST> r;
+    if (!slow) r = fused_row16<ST, MAXINF>(g, rs, v, cnt0, svv[i], wvv[i], lane, lvo, my_root, P);
+    else       r = fused_row_any<ST, MAXINF>(g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, tabs, net_nexthops, ignore_ovl, P);
     sat = sat || r.sat;
     need_exact = need_exact || r.need_exact;
-    const bool ch = r.nw != old;
-    if (ch) { *(uint64_t *)((char *)S + (v * 512u + lane8)) = r.nw; any = true; }
+    ovf = ovf || r.ovf;
+    const bool ch = r.nw != StIO<ST>::bits(oldq);
+    if (ch) { S[(size_t)v * 64 + lane] = r.nw; any = true; }
     if (__ballot(ch) != 0ull) {                                   // wake the out-neighbours up
       const uint32_t o0 = rdlane(po, i), o1 = rdlane(po, i + 1);
       for (uint32_t ob = o0 + lane; ob < o1; ob += 64) A[g.out_dst[ob]] = cur + 1u;
@@ -637,13 +688,17 @@ __global__ __launch_bounds__(256) void k_fused(GraphDev g, uint64_t *__restrict_
   row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{});
   row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
   if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
-  if ((MAXINF && sat) || need_exact) atomicOr(&lane_flags[root_slot], LF_NEED_EXACT);
+  uint32_t lf = 0;
+  if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
+  if (ovf) lf |= LF_OVERFLOW;
+  if (lf) atomicOr(&lane_flags[root_slot], lf);
 }
 
 // init for the fused path: roots' own lanes = (0, 0, 0); their out-neighbours are due in the
 // first sweep (id 2); out-neighbours of every vertex that can have hops == 0 for some root of the
 // batch (the root and its slot-table networks) are marked for the general row routine.
-__global__ void k_init_fused(GraphDev g, uint64_t *st, uint32_t *act, uint8_t *hnb, const uint32_t *roots,
+template <typename ST>
+__global__ void k_init_fused(GraphDev g, ST *st, uint32_t *act, uint8_t *hnb, const uint32_t *roots,
                              SlotTabs tabs, uint32_t n_lanes) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_lanes) return;
@@ -651,7 +706,7 @@ __global__ void k_init_fused(GraphDev g, uint64_t *st, uint32_t *act, uint8_t *h
   if (r == INF) return;
   const uint32_t n = g.n;
   const uint32_t batch = i >> 6, lane = i & 63;
-  st[((size_t)batch * n + r) * 64 + lane] = 0ull;
+  st[((size_t)batch * n + r) * 64 + lane] = (ST)0;
   for (uint32_t k = g.out_ptr[r]; k < g.out_ptr[r + 1]; ++k) {
     act[(size_t)batch * n + g.out_dst[k]] = 2u;
     hnb[(size_t)batch * n + g.out_dst[k]] = 1;
@@ -663,28 +718,31 @@ __global__ void k_init_fused(GraphDev g, uint64_t *st, uint32_t *act, uint8_t *h
 }
 
 // Emit for the fused path: packed lane-major state -> row-major results.
-__global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots,
-                                                    const uint64_t *__restrict__ st, OutDev o) {
-  __shared__ uint64_t t64[64][65];
+template <typename ST>
+__global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots, const ST *__restrict__ st,
+                                                    FusedParams P, OutDev o) {
+  __shared__ ST tt[64][65];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t batch = blockIdx.y, v0 = blockIdx.x * 64;
   const uint32_t nv = min(64u, n - v0);
   const uint32_t r0 = batch * 64;
   const uint32_t nr = min(64u, n_roots - r0);
-  const uint64_t *S = st + ((size_t)batch * n + v0) * 64;
-  for (uint32_t j = wave; j < nv; j += 4) t64[j][lane] = S[(size_t)j * 64 + lane];
+  const ST *S = st + ((size_t)batch * n + v0) * 64;
+  for (uint32_t j = wave; j < nv; j += 4) tt[j][lane] = S[(size_t)j * 64 + lane];
   __syncthreads();
   for (uint32_t r = wave; r < nr; r += 4)
     if (lane < nv) {
-      const uint64_t x = t64[lane][r];
+      const ST x = tt[lane][r];
       const size_t idx = (size_t)(r0 + r) * n + v0 + lane;
-      const uint32_t d = (uint32_t)(x >> 32);
-      const bool in = d != INF;
-      o.dist[idx] = d;
-      if (o.hops) o.hops[idx] = in ? (uint16_t)((uint32_t)x >> 16) : (uint16_t)0;
+      uint32_t d, pay;
+      if (sizeof(ST) == 8) { d = (uint32_t)((uint64_t)x >> 32); pay = (uint32_t)x; }
+      else { d = (uint32_t)x >> P.sh; pay = (uint32_t)x & ((1u << P.sh) - 1u); }
+      const bool in = x != (ST)~(ST)0;
+      o.dist[idx] = in ? d : INF;
+      if (o.hops) o.hops[idx] = in ? (uint16_t)(pay >> P.mbits) : (uint16_t)0;
       if (o.flags) o.flags[idx] = in ? 1 : 0;
       if (o.mask) {
-        o.mask[idx * o.out_words] = in ? (uint64_t)((uint32_t)x & 0xFFFFu) : 0ull;
+        o.mask[idx * o.out_words] = in ? (uint64_t)(pay & ((1u << P.mbits) - 1u)) : 0ull;
         for (uint32_t k = 1; k < o.out_words; ++k) o.mask[idx * o.out_words + k] = 0;
       }
     }

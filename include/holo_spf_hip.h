@@ -137,7 +137,7 @@ typedef struct {
 typedef struct {
   uint32_t n_roots;
   uint32_t n_batches;          /* 64-root wavefront batches                                   */
-  uint32_t n_relax_launches;   /* launches of the distance relaxation kernel                  */
+  uint32_t n_relax_launches;   /* launches of the fused sweep / distance relaxation kernel    */
   uint32_t n_dag_launches;     /* launches of the SPT-DAG (hops / first-hop) kernel           */
   uint32_t n_exact_roots;      /* roots that needed the sequential exact kernel               */
   uint32_t n_mask_words;
@@ -146,6 +146,8 @@ typedef struct {
   float    ms_dag;
   float    ms_finish;          /* transpose to row-major outputs (+ exact kernel)             */
   float    ms_d2h;             /* only for hspf_run(): device->host copies                    */
+  uint32_t state_bytes;        /* per-(vertex,root) state of the fused path: 4 or 8; 0 = two-phase path */
+  uint32_t narrow_overflow;    /* 1: the 4-byte state overflowed and the run was redone with 8 bytes   */
 } hspf_stats;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */

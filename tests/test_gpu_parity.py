@@ -155,3 +155,29 @@ def test_errors_are_codes_not_crashes(spf_ctx):
     with pytest.raises(E.HspfError):
         spf_ctx.upload(g.row_ptr, g.col + 100000, g.metric, g.vflags, g.max_path_metric)
     G.free()
+
+
+def _chain(n, metric, max_path=synth.MAX_PATH_METRIC_WIDE):
+    src = np.arange(n - 1); dst = src + 1
+    s = np.concatenate([src, dst]); d = np.concatenate([dst, src])
+    row_ptr, col, met = synth._csr_from_links(n, s, d, np.full(2 * (n - 1), metric))
+    return synth.CsrGraph(row_ptr, col, met, np.zeros(n, np.uint8), max_path)
+
+
+def test_narrow_state_hops_overflow_falls_back_to_wide(spf_ctx):
+    """The 4-byte fused state has 7 hop bits: a 300-router chain leaves the field, the run must be
+    redone with the 8-byte state and still be exact."""
+    g = _chain(300, 1)
+    res, ref = check(spf_ctx, g, [0, 150, 299], expect_exact=False)
+    assert res.hops.max() == 299
+
+
+def test_narrow_state_distance_overflow_falls_back_to_wide(spf_ctx):
+    g = _chain(120, 1 << 20)            # 2 first-hop slots -> 23 distance bits; 119 * 2^20 does not fit
+    res, ref = check(spf_ctx, g, [0, 60], expect_exact=False)
+    assert int(res.dist[0].max()) == 119 << 20
+
+
+def test_costs_too_large_for_narrow_state_use_wide_directly(spf_ctx):
+    g = _chain(50, 0x00FFFFFE)          # MAX_LINK_METRIC_WIDE - 1 (holo-isis/src/spf.rs:49)
+    check(spf_ctx, g, [0, 49], expect_exact=False)
