@@ -40,12 +40,12 @@ struct hspf_graph {
   // device
   uint32_t *d_in_ptr = nullptr, *d_in_src = nullptr, *d_in_w = nullptr, *d_in_fpos = nullptr;
   uint32_t *d_out_ptr = nullptr, *d_out_dst = nullptr, *d_out_w = nullptr, *d_out_fpos = nullptr;
-  uint8_t *d_vflags = nullptr;
+  uint8_t *d_vflags = nullptr, *d_rowflags = nullptr;
   GraphDev dev() const {
     GraphDev g;
     g.n = n; g.e_in = e_kept;
     g.in_ptr = d_in_ptr; g.in_src = d_in_src; g.in_w = d_in_w; g.in_fpos = d_in_fpos;
-    g.vflags = d_vflags;
+    g.vflags = d_vflags; g.rowflags = d_rowflags;
     g.out_ptr = d_out_ptr; g.out_dst = d_out_dst; g.out_w = d_out_w; g.out_fpos = d_out_fpos;
     return g;
   }
@@ -58,7 +58,7 @@ struct hspf_ctx {
   std::string last_error;
   hipEvent_t ev[6] = {};
   // scratch (grown on demand, reused across runs)
-  DevBuf dist, hv, mask, roots, lane_flags, changed, tab_ptr, tab_vtx, tab_base, st64, stamp, hnb;
+  DevBuf dist, hv, mask, roots, lane_flags, changed, tab_ptr, tab_vtx, tab_base, st64, stamp, hnb, fgraph;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   int *h_changed = nullptr;        // pinned
@@ -196,7 +196,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->roots, &ctx->lane_flags, &ctx->changed,
-                    &ctx->tab_ptr, &ctx->tab_vtx, &ctx->tab_base, &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
+                    &ctx->tab_ptr, &ctx->tab_vtx, &ctx->tab_base, &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->fgraph, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
                     &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
@@ -312,11 +312,25 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
           std::copy(s3.begin(), s3.end(), in_fpos.begin() + a);
         }
       }
+      // static reasons for the general fused row routine
+      std::vector<uint8_t> rowflags(n, 0);
+      for (uint32_t t = 0; t < n; ++t) {
+        uint8_t f = 0;
+        if (in_ptr[t + 1] - in_ptr[t] > 16) f |= RF_MANY;
+        for (uint32_t i = in_ptr[t]; i < in_ptr[t + 1]; ++i) {
+          if (in_src[i] & SRC_NO_TRANSIT) f |= RF_NT;
+          if (in_w[i] == 0 && (in_src[i] & SRC_MASK) >= t) f |= RF_ZERO;
+        }
+        rowflags[t] = f;
+      }
+      // every device array is padded by 16 zero entries: the kernels fetch link records and row
+      // bounds in fixed-size scalar loads that may run past a row's (or the array's) end
       auto up = [&](uint32_t **d, const std::vector<uint32_t> &h) -> hipError_t {
-        const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(uint32_t);
+        const size_t bytes = (h.size() + 16) * sizeof(uint32_t);
         hipError_t er = hipMalloc((void **)d, bytes);
         if (er != hipSuccess) return er;
-        if (!h.empty()) er = hipMemcpy(*d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        er = hipMemset(*d, 0, bytes);
+        if (er == hipSuccess && !h.empty()) er = hipMemcpy(*d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         return er;
       };
       hipError_t er = hipSuccess;
@@ -330,6 +344,8 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
       if (er == hipSuccess) er = up(&g->d_out_fpos, out_fpos);
       if (er == hipSuccess) er = hipMalloc((void **)&g->d_vflags, n);
       if (er == hipSuccess) er = hipMemcpy(g->d_vflags, csr->vflags, n, hipMemcpyHostToDevice);
+      if (er == hipSuccess) er = hipMalloc((void **)&g->d_rowflags, n);
+      if (er == hipSuccess) er = hipMemcpy(g->d_rowflags, rowflags.data(), n, hipMemcpyHostToDevice);
       if (er != hipSuccess) {
         ctx->last_error = std::string("graph upload: ") + hipGetErrorString(er);
         hspf_graph_free(ctx, g);
@@ -350,6 +366,7 @@ void hspf_graph_free(hspf_ctx *ctx, hspf_graph *g) {
   for (uint32_t *p : {g->d_in_ptr, g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_ptr, g->d_out_dst, g->d_out_w, g->d_out_fpos})
     if (p) (void)hipFree(p);
   if (g->d_vflags) (void)hipFree(g->d_vflags);
+  if (g->d_rowflags) (void)hipFree(g->d_rowflags);
   delete g;
 }
 
@@ -462,6 +479,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     if ((rc = ensure(ctx, ctx->st64, rows * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stamp, (size_t)B * n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->hnb, (size_t)B * n))) return rc;
+    if ((rc = ensure(ctx, ctx->fgraph, sizeof(FusedGraph)))) return rc;
   } else {
     if ((rc = ensure(ctx, ctx->dist, rows * 4))) return rc;
     if ((rc = ensure(ctx, ctx->hv, rows * 4))) return rc;
@@ -567,22 +585,28 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
   if (fused) {
+    {
+      const FusedGraph fg{gd, tabs};
+      HIPCHK(ctx, hipMemcpyAsync(ctx->fgraph.p, &fg, sizeof(fg), hipMemcpyHostToDevice, s));
+      HIPCHK(ctx, hipStreamSynchronize(s));     // fg is a stack object
+    }
+    const FusedGraph *d_fg = (const FusedGraph *)ctx->fgraph.p;
     auto fused_run = [&](bool nar) -> int {
       const FusedParams P = nar ? fp_narrow : fp_wide;
       const size_t esz = nar ? 4 : 8;
       hipError_t er = hipMemsetAsync(d_lf, 0, (size_t)L * 4, s);
       if (er == hipSuccess) er = hipMemsetAsync(d_st, 0xFF, rows * esz, s);
       if (er == hipSuccess) er = hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s);
-      if (er == hipSuccess) er = hipMemsetAsync(ctx->hnb.p, 0, (size_t)B * n, s);
       if (er != hipSuccess) { ctx->last_error = std::string("fused init: ") + hipGetErrorString(er); return HSPF_E_HIP; }
+      hipLaunchKernelGGL(k_fill_rowflags, dim3((unsigned)(((size_t)B * n + 255) / 256)), dim3(256), 0, s, n, B, g->d_rowflags, (uint8_t *)ctx->hnb.p);
       if (nar) hipLaunchKernelGGL((k_init_fused<uint32_t>), dim3((L + 255) / 256), dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
       else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 255) / 256), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
       uint32_t n_f = 0;
       const bool maxinf = g->max_path_metric == HSPF_DIST_INF;
       int r2 = run_phase(ctx->est_fused, [&](uint32_t sweep) {
-        if (nar)         hipLaunchKernelGGL((k_fused<uint32_t, false>), grid, dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, tabs, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
-        else if (maxinf) hipLaunchKernelGGL((k_fused<uint64_t, true>), grid, dim3(256), 0, s, gd, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, tabs, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
-        else             hipLaunchKernelGGL((k_fused<uint64_t, false>), grid, dim3(256), 0, s, gd, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, tabs, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+        if (nar)         hipLaunchKernelGGL((k_fused<uint32_t, false>), grid, dim3(256), 0, s, d_fg, (uint32_t *)d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+        else if (maxinf) hipLaunchKernelGGL((k_fused<uint64_t, true>), grid, dim3(256), 0, s, d_fg, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+        else             hipLaunchKernelGGL((k_fused<uint64_t, false>), grid, dim3(256), 0, s, d_fg, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
       }, n_f);
       if (r2) return r2;
       ctx->est_fused = n_f + 1;

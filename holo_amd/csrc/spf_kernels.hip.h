@@ -55,6 +55,7 @@ struct GraphDev {
   const uint32_t *in_w;     // [e_in] cost
   const uint32_t *in_fpos;  // [e_in] position of the link inside its source row (for slots)
   const uint8_t *vflags;    // [n]
+  const uint8_t *rowflags;  // [n] RF_* : static reasons why a row needs the general fused routine
   // forward CSR (kept links only) for k_exact
   const uint32_t *out_ptr;  // [n+1]
   const uint32_t *out_dst;  // [e_in]
@@ -65,6 +66,12 @@ struct GraphDev {
 struct OutDev {
   uint32_t *dist; uint16_t *hops; uint16_t *flags; uint64_t *mask; uint32_t out_words;
 };
+
+// rowflags bits (set at upload); RF_HNB is added per batch by k_init_fused
+constexpr uint32_t RF_MANY = 1u;      // more than 16 kept in-links
+constexpr uint32_t RF_NT = 2u;        // an in-link from an overloaded (no-transit) source
+constexpr uint32_t RF_ZERO = 4u;      // a zero-cost in-link from a higher- or equal-numbered source
+constexpr uint32_t RF_HNB = 8u;       // an in-neighbour that can have hops == 0 for some root of the batch
 
 struct SlotTabs {           // per root: H vertices and their slot bases (include/holo_spf_hip.h)
   const uint32_t *ptr;      // [n_root_slots+1]
@@ -389,6 +396,8 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
 // Memory-level parallelism: the link vectors of all VPW vertices are fetched up front and ALL
 // neighbour rows of a row are requested before the first one is consumed (profiles/r01b notes:
 // the first versions, 4 rows per round trip, ran at exactly waves/resident x 12 x loaded latency).
+struct FusedGraph { GraphDev g; SlotTabs tabs; };   // device-resident descriptor of one run
+
 struct FusedParams {
   uint32_t sh;        // bit position of the dist field (narrow) / 0 (wide: dist is the high word)
   uint32_t mbits;     // mask field width
@@ -480,82 +489,89 @@ __device__ __forceinline__ RowOut<ST> finish_row(const RowAcc &a, uint32_t v, ui
 }
 
 // Fast row routine: at most 16 links and none of the rare conditions.  The kernel is bound by
-// vector-ALU issue, not by bytes (a wave64 integer op occupies its SIMD for 4 cycles; the 4-byte and
-// the 8-byte state run at the same speed), so the routine is written for instruction count:
-//   pass 1   c_j = dkey_j (+) wkey_j ;  bd = min(c_j)            (v_add_u32 clamp, v_min3_u32)
-//   pass 2   t_j = (c_j == bd) ;  macc |= t_j ? pay_j : 0 ;  bpay = t_j ? pay_j : bpay   (LAST link first)
-// = 5 vector instructions per link plus two v_readlane.  The in-links of a row are stored by
-// (cost descending, source ascending) — see hspf_graph_upload — so among the tight links (equal
-// c_j) the FIRST one in row order is the one with the smallest parent distance and, on ties, the
-// smallest parent index: the reference's first discoverer.  Walking pass 2 backwards makes a plain
-// overwrite end on it.  Nested uniform branches instead of a counted loop so that no loaded value
-// needs a phi (a phi on a loaded register makes the compiler wait for the load).
+// vector-ALU issue, not by bytes (a wave64 integer op occupies its SIMD for 4 cycles), so the
+// routine is written for vector instruction count:
+//   * the link records (source, cost) of a row are one coalesced vector load each (lane j = link
+//     j), broadcast by v_readlane; the neighbour rows come through raw buffer loads whose row
+//     offset is that SGPR: no vector instruction is spent on addressing.  (Fetching the records
+//     through the scalar cache instead saves the two v_readlane per link but costs 32 SGPRs per row
+//     and a dependent scalar round trip per row: measured slower, 52 vs 45 us per sweep.);
+//   * pass 1   c_j = dkey_j (+) wkey_j ;  bd = min(c_j)           (v_add_u32 clamp, v_min3_u32)
+//     pass 2   t_j = (c_j == bd) ;  macc |= t_j ? pay_j : 0 ;  bpay = t_j ? pay_j : bpay  (LAST link first)
+//   * exactly deg(v) links are processed: the routine is a compile-time recursion over the link
+//     index with one uniform branch per link (no padding work), and every neighbour row is
+//     requested before the first one is consumed.  Values are only ever defined in a block that
+//     dominates their uses, so no loaded value needs a phi (a phi makes the compiler wait).
+// The in-links of a row are stored by (cost descending, source ascending) — hspf_graph_upload —
+// so among the tight links (equal c_j) the FIRST one in row order has the smallest parent distance
+// and, on ties, the smallest parent index: the reference's first discoverer.  Walking pass 2
+// backwards makes a plain overwrite end on it.
+typedef uint32_t u32x16a __attribute__((ext_vector_type(16), aligned(4)));
+typedef uint32_t u32x8a __attribute__((ext_vector_type(8), aligned(4)));
+
 template <typename ST> struct PayBits;
 template <> struct PayBits<uint64_t> { static __device__ __forceinline__ uint32_t of(const StIO<uint64_t>::Raw &q) { return q.x.x; } };
 template <> struct PayBits<uint32_t> { static __device__ __forceinline__ uint32_t of(const StIO<uint32_t>::Raw &q) { return q.x; } };
 
-#define HSPF_LD4(G) const typename StIO<ST>::Raw q##G##0 = StIO<ST>::ld(rs, lvo, rdlane(so, 4 * G + 0)), q##G##1 = StIO<ST>::ld(rs, lvo, rdlane(so, 4 * G + 1)), \
-                                                 q##G##2 = StIO<ST>::ld(rs, lvo, rdlane(so, 4 * G + 2)), q##G##3 = StIO<ST>::ld(rs, lvo, rdlane(so, 4 * G + 3))
-#define HSPF_C1(G, K) const uint32_t c##G##K = cand<ST, MAXINF>(q##G##K, rdlane(wk, 4 * G + K), P, sat)
-#define HSPF_C4(G) HSPF_C1(G, 0); HSPF_C1(G, 1); HSPF_C1(G, 2); HSPF_C1(G, 3); \
-                   bd = min(min(bd, min(c##G##0, c##G##1)), min(c##G##2, c##G##3))
-#define HSPF_T1(G, K) { const bool t = c##G##K == bd; const uint32_t pb = PayBits<ST>::of(q##G##K); \
-                        macc |= t ? pb : 0u; bpay = t ? pb : bpay; }
-#define HSPF_T4(G) HSPF_T1(G, 3) HSPF_T1(G, 2) HSPF_T1(G, 1) HSPF_T1(G, 0)
+template <typename ST> struct Row16 {
+  __amdgpu_buffer_rsrc_t rs;
+  uint32_t lvo, cnt;
+  uint32_t so, wk;                 // lane j = link j: row byte offset of the source / shifted cost
+  FusedParams P;
+  typename StIO<ST>::Raw q[16];
+  uint32_t c[16];
+  uint32_t bd, macc, bpay;
+  bool sat;
+};
 
-template <typename ST, bool MAXINF>
-__device__ __forceinline__ uint32_t cand(const typename StIO<ST>::Raw &q, uint32_t wkey, const FusedParams &P, bool &sat) {
-  const uint32_t d = StIO<ST>::dkey(q, P);
-  const uint32_t c = add_sat(d, wkey);                            // leaves the field -> all ones
-  if (MAXINF && sizeof(ST) == 8 && c == INF && d != INF && wkey != INF) sat = true;
-  return c;
+template <typename ST, bool MAXINF, int L>
+__device__ __forceinline__ void row16_compute(Row16<ST> &r) {
+  uint32_t bd = INF;
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    const uint32_t d = StIO<ST>::dkey(r.q[j], r.P);
+    r.c[j] = add_sat(d, rdlane(r.wk, j));                         // leaves the field -> all ones
+    if (MAXINF && sizeof(ST) == 8 && r.c[j] == INF && d != INF) r.sat = true;
+    bd = min(bd, r.c[j]);
+  }
+  uint32_t macc = 0u, bpay = 0u;
+#pragma unroll
+  for (int j = L - 1; j >= 0; --j) {
+    const bool t = r.c[j] == bd;
+    const uint32_t pb = PayBits<ST>::of(r.q[j]);
+    macc |= t ? pb : 0u;
+    bpay = t ? pb : bpay;
+  }
+  r.bd = bd; r.macc = macc; r.bpay = bpay;
+}
+
+template <typename ST, bool MAXINF, int J>
+__device__ __forceinline__ void row16_step(Row16<ST> &r) {
+  r.q[J] = StIO<ST>::ld(r.rs, r.lvo, rdlane(r.so, J));
+  if constexpr (J + 1 < 16) {
+    if (r.cnt > (uint32_t)(J + 1)) { row16_step<ST, MAXINF, J + 1>(r); return; }
+  }
+  row16_compute<ST, MAXINF, J + 1>(r);
 }
 
 template <typename ST, bool MAXINF>
-__device__ __forceinline__ RowOut<ST> fused_row16(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v, uint32_t cnt,
-                                                  uint32_t sv, uint32_t wv, uint32_t lane, uint32_t lvo,
-                                                  uint32_t my_root, const FusedParams &P) {
-  const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
-  // padding lanes point at the row itself (L1 hit) and carry cost "infinite"
-  const uint32_t so = (lane < cnt ? (sv & SRC_MASK) : v) << StIO<ST>::ROW_SHIFT;
-  const uint32_t wk = lane < cnt ? (wv << P.sh) : INF;            // host guarantees wv << sh fits
-  uint32_t bd = INF, macc = 0u, bpay = 0u;
-  bool sat = false;
-  HSPF_LD4(0);
-  if (cnt > 4u) {
-    HSPF_LD4(1);
-    if (cnt > 8u) {
-      HSPF_LD4(2);
-      if (cnt > 12u) {
-        HSPF_LD4(3);
-        HSPF_C4(0); HSPF_C4(1); HSPF_C4(2); HSPF_C4(3);
-        HSPF_T4(3) HSPF_T4(2) HSPF_T4(1) HSPF_T4(0)
-      } else {
-        HSPF_C4(0); HSPF_C4(1); HSPF_C4(2);
-        HSPF_T4(2) HSPF_T4(1) HSPF_T4(0)
-      }
-    } else {
-      HSPF_C4(0); HSPF_C4(1);
-      HSPF_T4(1) HSPF_T4(0)
-    }
-  } else {
-    HSPF_C4(0);
-    HSPF_T4(0)
-  }
+__device__ __forceinline__ RowOut<ST> fused_row16(__amdgpu_buffer_rsrc_t rs, uint32_t v, uint32_t cnt, uint32_t sv,
+                                                  uint32_t wv, uint32_t lvo, uint32_t my_root, uint32_t v_router,
+                                                  const FusedParams &P) {
+  Row16<ST> r;
+  r.rs = rs; r.lvo = lvo; r.cnt = cnt; r.P = P; r.sat = false;
+  r.bd = INF; r.macc = 0u; r.bpay = 0u;
+  r.so = (sv & SRC_MASK) << StIO<ST>::ROW_SHIFT;
+  r.wk = wv << P.sh;                                              // host guarantees wv << sh fits
+  if (cnt != 0u) row16_step<ST, MAXINF, 0>(r);
   // pay bits of the winner / of the union: wide = the low word, narrow = the whole word (distance
   // bits are dropped by the masks below)
   RowAcc a;
-  a.bd = bd; a.sat = sat; a.bpd = 0u;
-  a.bm = macc & ((1u << P.mbits) - 1u);
-  a.bh = (bpay >> P.mbits) & P.hmax;
-  if (sizeof(ST) == 8) a.bh = (bpay >> 16);
+  a.bd = r.bd; a.sat = r.sat; a.bpd = 0u;
+  a.bm = r.macc & ((1u << P.mbits) - 1u);
+  a.bh = sizeof(ST) == 8 ? (r.bpay >> 16) : ((r.bpay >> P.mbits) & P.hmax);
   return finish_row<ST>(a, v, my_root, v_router, INF, P);
 }
-#undef HSPF_LD4
-#undef HSPF_C1
-#undef HSPF_C4
-#undef HSPF_T1
-#undef HSPF_T4
 
 // General row routine (rare: rows next to a vertex that can have hops == 0, overloaded sources,
 // zero-cost links from higher-numbered sources, more than 16 links): one link at a time, rolled
@@ -618,70 +634,95 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
   return finish_row<ST>(a, v, my_root, v_router, bd_all, P);
 }
 
+// Wave schedule (what the sweep time is made of: SIMD utilisation = resident waves x compute /
+// (compute + dependent memory round trips), measured 42 % for the first versions whose chain was 12
+// round trips per wave): ONE round trip for everything that only depends on the wave's vertex
+// range (stamps, row bounds, flags), ONE for the link vectors, old states and out-link vectors of
+// all its active rows, then one per row for the neighbour rows; state stores and wake-up stamps
+// are fire-and-forget (the out-link vector was fetched up front, speculatively).
 template <typename ST, bool MAXINF>
-__global__ __launch_bounds__(256) void k_fused(GraphDev g, ST *__restrict__ st, uint32_t *__restrict__ act,
-                                               const uint8_t *__restrict__ hnb,
-                                               const uint32_t *__restrict__ roots, SlotTabs tabs,
-                                               FusedParams P, uint32_t net_nexthops, uint32_t ignore_ovl,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fused(const FusedGraph *__restrict__ gp, ST *__restrict__ st,
+                                               uint32_t *__restrict__ act, const uint8_t *__restrict__ hnb,
+                                               const uint32_t *__restrict__ roots, FusedParams P,
+                                               uint32_t net_nexthops, uint32_t ignore_ovl,
                                                int *changed, int sweep, uint32_t *lane_flags) {
+  // The graph / slot-table descriptors live in device memory and are fetched (scalar loads) where
+  // they are used: as by-value kernel arguments they pinned ~40 SGPRs for the whole kernel, and
+  // above 96 SGPRs a CU only admits 6 of these workgroups instead of 8 (MI355X_MICROARCH.md).
   if (sweep > 0 && changed[sweep - 1] == 0) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t batch = blockIdx.y;
   const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
   const uint32_t vbeg = chunk * VPB + wave * VPW;
-  const uint32_t n = g.n;
+  const uint32_t n = gp->g.n;
   if (vbeg >= n) return;
   uint32_t *A = act + (size_t)batch * n;
   const uint32_t cur = (uint32_t)sweep + 2u;
-  // one load: activation stamps of the wave's vertices (lanes 0..VPW-1)
-  const uint32_t vl = min(vbeg + min(lane, (uint32_t)(VPW - 1)), n - 1);
-  const uint32_t av = A[vl];
+  // ---- round trip 1: stamps, row bounds, flags of the wave's VPW vertices (lanes 0..VPW)
+  const uint32_t vl = min(vbeg + min(lane, (uint32_t)VPW), n);    // in_ptr / out_ptr have n+1 (+16) entries
+  const uint32_t vlc = min(vl, n - 1);
+  const uint32_t av = A[vlc];
+  const uint32_t pv = gp->g.in_ptr[vl];
+  const uint32_t po = gp->g.out_ptr[vl];
+  const uint32_t hb = hnb[(size_t)batch * n + vlc] & (ignore_ovl ? ~RF_NT : ~0u);
+  const uint32_t vf = gp->g.vflags[vlc];
   if (__ballot(lane < (uint32_t)VPW && vbeg + lane < n && av >= cur) == 0ull) return;
-  const uint32_t hb = hnb[(size_t)batch * n + vl];
-  const uint32_t *__restrict__ in_ptr = g.in_ptr;
-  const uint32_t *__restrict__ in_src = g.in_src;
-  const uint32_t *__restrict__ in_w = g.in_w;
   const uint32_t root_slot = batch * 64 + lane;
   const uint32_t my_root = roots[root_slot];
   ST *S = st + (size_t)batch * n * 64;
   const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, n << StIO<ST>::ROW_SHIFT);
+  const __amdgpu_buffer_rsrc_t ra = st_rsrc(A, n * 4u);
+  const uint32_t ebytes = (gp->g.e_in + 16u) * 4u;
+  const __amdgpu_buffer_rsrc_t rsrc_src = st_rsrc(gp->g.in_src, ebytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = st_rsrc(gp->g.in_w, ebytes);
+  const __amdgpu_buffer_rsrc_t rsrc_od = st_rsrc(gp->g.out_dst, ebytes);
   const uint32_t lvo = lane * (uint32_t)sizeof(ST);
-  const uint32_t pv = in_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
-  const uint32_t po = g.out_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
-  // link vectors (first 64 links) of all active vertices, requested back to back
-  uint32_t svv[VPW], wvv[VPW];
+  const uint32_t lane4 = lane * 4u;
+  // ---- round trip 2: link vectors (first 64 links), old state, out-link vector of every active row
+  uint32_t svv[VPW], wvv[VPW], odv[VPW];
+  typename StIO<ST>::Raw oldq[VPW];
 #pragma unroll
   for (int i = 0; i < VPW; ++i) {
     const uint32_t v = vbeg + i;
-    const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
-    const bool on = v < n && rdlane(av, i) >= cur && lane < min(64u, e1 - e0);
-    svv[i] = on ? in_src[e0 + lane] : min(v, n - 1);
-    wvv[i] = on ? in_w[e0 + lane] : INF;
+    const bool on = v < n && rdlane(av, i) >= cur;                // uniform
+    svv[i] = min(v, n - 1); wvv[i] = INF; odv[i] = 0u;
+    if (on) {
+      const uint32_t e0 = rdlane(pv, i), cnt = min(64u, rdlane(pv, i + 1) - e0);
+      const uint32_t o0 = rdlane(po, i), ocnt = min(64u, rdlane(po, i + 1) - o0);
+      // reads past a row's end stay inside the (padded) arrays; masked afterwards
+      const uint32_t a = __builtin_amdgcn_raw_buffer_load_b32(rsrc_src, lane4, e0 * 4u, 0);
+      const uint32_t b = __builtin_amdgcn_raw_buffer_load_b32(rsrc_w, lane4, e0 * 4u, 0);
+      const uint32_t c = __builtin_amdgcn_raw_buffer_load_b32(rsrc_od, lane4, o0 * 4u, 0);
+      oldq[i] = StIO<ST>::ld(rs, lvo, v << StIO<ST>::ROW_SHIFT);
+      svv[i] = lane < cnt ? a : v;
+      wvv[i] = lane < cnt ? b : INF;
+      odv[i] = lane < ocnt ? c * 4u : 0xFFFFFFFFu;                // byte offset into A; out of range = dropped
+    }
   }
   bool any = false, sat = false, need_exact = false, ovf = false;
-  auto row = [&](auto I) {                                        // explicit 4x instantiation: compile-time lane numbers
+  auto row = [&](auto I) {                                        // explicit 4x instantiation
     constexpr int i = decltype(I)::value;
     const uint32_t v = vbeg + i;
     if (v >= n) return;
     if (rdlane(av, i) < cur) return;                              // nothing changed around this row
     const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
-    const typename StIO<ST>::Raw oldq = StIO<ST>::ld(rs, lvo, v << StIO<ST>::ROW_SHIFT);
-    const uint32_t cnt0 = min(64u, e1 - e0);
-    const bool slow = (e1 - e0) > 16u || rdlane(hb, i) != 0u ||
-                      (!ignore_ovl && __ballot(lane < cnt0 && (svv[i] & SRC_NO_TRANSIT) != 0) != 0ull) ||
-                      __ballot(lane < cnt0 && wvv[i] == 0u && (svv[i] & SRC_MASK) >= v) != 0ull;
+    const uint32_t v_router = (rdlane(vf, i) & 1u) ? 0u : 1u;
     RowOut<ST> r;
-    if (!slow) r = fused_row16<ST, MAXINF>(g, rs, v, cnt0, svv[i], wvv[i], lane, lvo, my_root, P);
-    else       r = fused_row_any<ST, MAXINF>(g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, tabs, net_nexthops, ignore_ovl, P);
+    if (rdlane(hb, i) == 0u)
+      r = fused_row16<ST, MAXINF>(rs, v, e1 - e0, svv[i], wvv[i], lvo, my_root, v_router, P);
+    else
+      r = fused_row_any<ST, MAXINF>(gp->g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
     sat = sat || r.sat;
     need_exact = need_exact || r.need_exact;
     ovf = ovf || r.ovf;
-    const bool ch = r.nw != StIO<ST>::bits(oldq);
+    const bool ch = r.nw != StIO<ST>::bits(oldq[i]);
     if (ch) { S[(size_t)v * 64 + lane] = r.nw; any = true; }
     if (__ballot(ch) != 0ull) {                                   // wake the out-neighbours up
+      __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, odv[i], 0, 0);
       const uint32_t o0 = rdlane(po, i), o1 = rdlane(po, i + 1);
-      for (uint32_t ob = o0 + lane; ob < o1; ob += 64) A[g.out_dst[ob]] = cur + 1u;
+      for (uint32_t ob = o0 + 64u + lane; ob < o1; ob += 64)      // rows with more than 64 out-links
+        __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, gp->g.out_dst[ob] * 4u, 0, 0);
     }
   };
   static_assert(VPW == 4, "row() is instantiated four times");
@@ -692,6 +733,13 @@ __global__ __launch_bounds__(256) void k_fused(GraphDev g, ST *__restrict__ st, 
   if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
   if (ovf) lf |= LF_OVERFLOW;
   if (lf) atomicOr(&lane_flags[root_slot], lf);
+}
+
+// Per-batch row flags = the graph's static ones (k_init_fused then adds RF_HNB).
+__global__ void k_fill_rowflags(uint32_t n, uint32_t n_batches, const uint8_t *__restrict__ rowflags, uint8_t *__restrict__ hnb) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)n * n_batches) return;
+  hnb[i] = rowflags[i % n];
 }
 
 // init for the fused path: roots' own lanes = (0, 0, 0); their out-neighbours are due in the
@@ -709,11 +757,12 @@ __global__ void k_init_fused(GraphDev g, ST *st, uint32_t *act, uint8_t *hnb, co
   st[((size_t)batch * n + r) * 64 + lane] = (ST)0;
   for (uint32_t k = g.out_ptr[r]; k < g.out_ptr[r + 1]; ++k) {
     act[(size_t)batch * n + g.out_dst[k]] = 2u;
-    hnb[(size_t)batch * n + g.out_dst[k]] = 1;
+    hnb[(size_t)batch * n + g.out_dst[k]] = (uint8_t)(g.rowflags[g.out_dst[k]] | RF_HNB);
   }
   for (uint32_t j = tabs.ptr[i]; j < tabs.ptr[i + 1]; ++j) {
     const uint32_t h = tabs.vtx[j];
-    for (uint32_t k = g.out_ptr[h]; k < g.out_ptr[h + 1]; ++k) hnb[(size_t)batch * n + g.out_dst[k]] = 1;
+    for (uint32_t k = g.out_ptr[h]; k < g.out_ptr[h + 1]; ++k)
+      hnb[(size_t)batch * n + g.out_dst[k]] = (uint8_t)(g.rowflags[g.out_dst[k]] | RF_HNB);
   }
 }
 
