@@ -545,13 +545,11 @@ __device__ __forceinline__ void row16_compute(Row16<ST> &r) {
   r.bd = bd; r.macc = macc; r.bpay = bpay;
 }
 
-template <typename ST, bool MAXINF, int J>
-__device__ __forceinline__ void row16_step(Row16<ST> &r) {
-  r.q[J] = StIO<ST>::ld(r.rs, r.lvo, rdlane(r.so, J));
-  if constexpr (J + 1 < 16) {
-    if (r.cnt > (uint32_t)(J + 1)) { row16_step<ST, MAXINF, J + 1>(r); return; }
-  }
-  row16_compute<ST, MAXINF, J + 1>(r);
+template <typename ST, bool MAXINF, int L>
+__device__ __forceinline__ void row16_case(Row16<ST> &r) {       // exactly L links: L requests, then compute
+#pragma unroll
+  for (int j = 0; j < L; ++j) r.q[j] = StIO<ST>::ld(r.rs, r.lvo, rdlane(r.so, j));
+  row16_compute<ST, MAXINF, L>(r);
 }
 
 template <typename ST, bool MAXINF>
@@ -563,7 +561,17 @@ __device__ __forceinline__ RowOut<ST> fused_row16(__amdgpu_buffer_rsrc_t rs, uin
   r.bd = INF; r.macc = 0u; r.bpay = 0u;
   r.so = (sv & SRC_MASK) << StIO<ST>::ROW_SHIFT;
   r.wk = wv << P.sh;                                              // host guarantees wv << sh fits
-  if (cnt != 0u) row16_step<ST, MAXINF, 0>(r);
+  switch (cnt) {                                                  // uniform; one straight-line block per degree
+    case 0: break;
+    case 1: row16_case<ST, MAXINF, 1>(r); break;   case 2: row16_case<ST, MAXINF, 2>(r); break;
+    case 3: row16_case<ST, MAXINF, 3>(r); break;   case 4: row16_case<ST, MAXINF, 4>(r); break;
+    case 5: row16_case<ST, MAXINF, 5>(r); break;   case 6: row16_case<ST, MAXINF, 6>(r); break;
+    case 7: row16_case<ST, MAXINF, 7>(r); break;   case 8: row16_case<ST, MAXINF, 8>(r); break;
+    case 9: row16_case<ST, MAXINF, 9>(r); break;   case 10: row16_case<ST, MAXINF, 10>(r); break;
+    case 11: row16_case<ST, MAXINF, 11>(r); break; case 12: row16_case<ST, MAXINF, 12>(r); break;
+    case 13: row16_case<ST, MAXINF, 13>(r); break; case 14: row16_case<ST, MAXINF, 14>(r); break;
+    case 15: row16_case<ST, MAXINF, 15>(r); break; default: row16_case<ST, MAXINF, 16>(r); break;
+  }
   // pay bits of the winner / of the union: wide = the low word, narrow = the whole word (distance
   // bits are dropped by the masks below)
   RowAcc a;
@@ -682,22 +690,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
   // ---- round trip 2: link vectors (first 64 links), old state, out-link vector of every active row
   uint32_t svv[VPW], wvv[VPW], odv[VPW];
   typename StIO<ST>::Raw oldq[VPW];
+  {
+    // unconditional (rows that are not due simply are not used): 16 requests in flight, no control
+    // flow; reads past a row's end stay inside the padded arrays and are masked afterwards
+    uint32_t ta[VPW], tb[VPW], tc[VPW];
 #pragma unroll
-  for (int i = 0; i < VPW; ++i) {
-    const uint32_t v = vbeg + i;
-    const bool on = v < n && rdlane(av, i) >= cur;                // uniform
-    svv[i] = min(v, n - 1); wvv[i] = INF; odv[i] = 0u;
-    if (on) {
-      const uint32_t e0 = rdlane(pv, i), cnt = min(64u, rdlane(pv, i + 1) - e0);
-      const uint32_t o0 = rdlane(po, i), ocnt = min(64u, rdlane(po, i + 1) - o0);
-      // reads past a row's end stay inside the (padded) arrays; masked afterwards
-      const uint32_t a = __builtin_amdgcn_raw_buffer_load_b32(rsrc_src, lane4, e0 * 4u, 0);
-      const uint32_t b = __builtin_amdgcn_raw_buffer_load_b32(rsrc_w, lane4, e0 * 4u, 0);
-      const uint32_t c = __builtin_amdgcn_raw_buffer_load_b32(rsrc_od, lane4, o0 * 4u, 0);
-      oldq[i] = StIO<ST>::ld(rs, lvo, v << StIO<ST>::ROW_SHIFT);
-      svv[i] = lane < cnt ? a : v;
-      wvv[i] = lane < cnt ? b : INF;
-      odv[i] = lane < ocnt ? c * 4u : 0xFFFFFFFFu;                // byte offset into A; out of range = dropped
+    for (int i = 0; i < VPW; ++i) {
+      const uint32_t e0 = rdlane(pv, i), o0 = rdlane(po, i);
+      ta[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_src, lane4, e0 * 4u, 0);
+      tb[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_w, lane4, e0 * 4u, 0);
+      tc[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_od, lane4, o0 * 4u, 0);
+      oldq[i] = StIO<ST>::ld(rs, lvo, min(vbeg + i, n - 1) << StIO<ST>::ROW_SHIFT);
+    }
+#pragma unroll
+    for (int i = 0; i < VPW; ++i) {
+      const uint32_t cnt = min(64u, rdlane(pv, i + 1) - rdlane(pv, i));
+      const uint32_t ocnt = min(64u, rdlane(po, i + 1) - rdlane(po, i));
+      svv[i] = lane < cnt ? ta[i] : min(vbeg + i, n - 1);
+      wvv[i] = lane < cnt ? tb[i] : INF;
+      odv[i] = lane < ocnt ? tc[i] * 4u : 0xFFFFFFFFu;            // byte offset into A; out of range = dropped
     }
   }
   bool any = false, sat = false, need_exact = false, ovf = false;
