@@ -649,7 +649,7 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
 // all its active rows, then one per row for the neighbour rows; state stores and wake-up stamps
 // are fire-and-forget (the out-link vector was fetched up front, speculatively).
 template <typename ST, bool MAXINF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fused(const FusedGraph *__restrict__ gp, ST *__restrict__ st,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fused(const FusedGraph *__restrict__ gp, ST *__restrict__ st,
                                                uint32_t *__restrict__ act, const uint8_t *__restrict__ hnb,
                                                const uint32_t *__restrict__ roots, FusedParams P,
                                                uint32_t net_nexthops, uint32_t ignore_ovl,
