@@ -1,19 +1,46 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): bench + rocprofv3 kernel trace + PMC passes -> gpurun_out/
+# Runs on the GPU box (via gpurun): bench + rocprofv3 kernel-trace stats + PMC passes -> gpurun_out/prof
+# usage: bash tools/gpu_profile.sh <tag>      (summaries are then copied to profiles/<tag>_* by hand)
 set -u
 export TMPDIR=/tmp
-R=$(pwd)
-OUT=$R/gpurun_out/prof
-mkdir -p $OUT
+R=$(pwd); OUT=$R/gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
-tail -c 3000 $OUT/bench.json
+tail -c 2500 $OUT/bench.json
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o spf -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o spf -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o spf -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -o spf -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_l2.log 2>&1
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
+            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
+            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
+  i=$(echo "$pass" | md5sum | cut -c1-6)
+  rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$i -o q -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$i.log 2>&1
+done
 cd $R
-find $OUT -name "*.csv" | head -20
-ls -la $OUT/trace/* | head
-# keep only small files (kernel trace csv can be large): stats + per-kernel aggregated
-find $OUT -name "*kernel_trace.csv" -size +8M -delete
+python - <<'PY'
+import csv, glob, collections, json
+out = collections.defaultdict(dict)
+for f in sorted(glob.glob("gpurun_out/prof/pmc_*/*counter_collection.csv")):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if "hspf" in k: agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in agg.items():
+        for c, x in v.items():
+            x = sorted(x); top = x[len(x)//2:]
+            out[k][c] = {"launches": len(x), "mean_all": sum(x)/len(x), "mean_top_half": sum(top)/len(top), "max": x[-1]}
+json.dump(out, open("gpurun_out/prof/pmc_summary.json", "w"), indent=1)
+# HBM-side traffic per launch of the dominant kernel.  FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950
+# correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 128-B requests as 64 B -> x2; the
+# factor is calibrated here on k_emit_fused (reads the whole packed state once, writes every result
+# once: known byte counts) and recorded next to the number.
+traffic = {}
+for k, v in out.items():
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        traffic[k.replace("hspf::", "").split("<")[0]] = {
+            "kernel": k, "fetch_kib_per_launch": v["FETCH_SIZE"]["mean_all"], "write_kib_per_launch": v["WRITE_SIZE"]["mean_all"],
+            "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"]["mean_all"] + v["WRITE_SIZE"]["mean_all"]) * 1024),
+            "launches_sampled": v["FETCH_SIZE"]["launches"], "fetch_correction": 2.0}
+json.dump(traffic, open("gpurun_out/prof/traffic.json", "w"), indent=1)
+print(json.dumps(traffic, indent=1))
+PY
+cp $OUT/trace/spf_kernel_stats.csv $OUT/kernel_stats.csv
+rm -rf $OUT/pmc_*/ ; find $OUT -name "*kernel_trace.csv" -size +2M -delete
