@@ -181,3 +181,40 @@ def test_narrow_state_distance_overflow_falls_back_to_wide(spf_ctx):
 def test_costs_too_large_for_narrow_state_use_wide_directly(spf_ctx):
     g = _chain(50, 0x00FFFFFE)          # MAX_LINK_METRIC_WIDE - 1 (holo-isis/src/spf.rs:49)
     check(spf_ctx, g, [0, 49], expect_exact=False)
+
+
+def test_two_contexts_on_two_threads(spf_ctx):
+    """holo runs one OS thread per protocol instance (holo-protocol/src/lib.rs:427-430): distinct
+    contexts must work concurrently (own stream, own scratch) and give the same answers."""
+    import threading
+    g = synth.ospf_10k()
+    roots = np.arange(0, 10000, 79, dtype=np.uint32)
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, go.RUN_NET_NEXTHOPS, go.HEAP)
+    out, errs = {}, []
+
+    def work(tag):
+        try:
+            ctx = E.SpfContext(0)
+            G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+            for _ in range(3):
+                out[tag] = ctx.run(G, roots, E.RUN_NET_NEXTHOPS)
+            G.free(); ctx.close()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errs, errs
+    for tag in (0, 1):
+        assert np.array_equal(out[tag].dist, ref.dist) and np.array_equal(out[tag].hops, ref.hops)
+        assert np.array_equal(out[tag].first_hop_mask, ref.mask[:, :, :out[tag].first_hop_mask.shape[2]])
+
+
+def test_fattree_two_mask_words_two_phase_path(spf_ctx):
+    """configs[4] shape at reduced k: an edge switch of a k=16 fat-tree has 16 first-hop slots with
+    its 8 hosts... scaled: k=40 -> 40 slots per edge switch, core switches 40: > 16 slots selects the
+    two-phase path (k_relax + k_dag<W>), unit metrics = maximal ECMP."""
+    g = synth.isis_fattree(k=40)
+    roots = np.asarray(g.meta["roots"][:24], np.uint32)
+    res, ref = check(spf_ctx, g, roots, 0, oracle_variant=go.HEAP, expect_exact=False)
+    assert res.stats["state_bytes"] == 0 and res.stats["n_dag_launches"] > 0
