@@ -194,14 +194,11 @@ def calc_nexthops(g: AreaGraph, parent: Vertex, k: int, dest: VertexId, dest_lsa
     return out
 
 
-def run_area(router_id: str, area: Area, engine, graph: Optional[AreaGraph] = None):
-    """holo-ospf/src/spf.rs:587-729 -> dict VertexId -> Vertex (the area's SPT), or None when the
-    root's Router-LSA is missing (Error::SpfRootNotFound is logged and the run returns, :605-610)."""
-    g = graph or AreaGraph(area)
-    root_vid = (RTR, ip(router_id))
-    root = g.index.get(root_vid)
-    if root is None:
-        return None
+def spt_from_engine(g, root: int, engine, calc) -> Dict[tuple, Vertex]:
+    """Version-generic back half of run_area: one engine run (HSPF_RUN_NET_NEXTHOPS), then every
+    first-hop slot is expanded ONCE through the version's `calc(g, parent_vertex, k, dest_vid,
+    dest_lsa)` (= V::calc_nexthops for a hops == 0 parent, holo-ospf/src/spf.rs:747-760) and the
+    per-slot sets are OR-ed through the per-vertex masks (= the inheritance of :761-766)."""
     G = g.device(engine)
     res = engine.run(G, np.asarray([root], np.uint32), E.RUN_NET_NEXTHOPS)
     dist, hops = res.dist[0], res.hops[0]
@@ -209,7 +206,7 @@ def run_area(router_id: str, area: Area, engine, graph: Optional[AreaGraph] = No
     mask = res.first_hop_mask[0]
     hv, hb, _tot = G.slot_table(root)
     hv, hb = [int(x) for x in hv], [int(x) for x in hb]
-    spt: Dict[VertexId, Vertex] = {}
+    spt: Dict[tuple, Vertex] = {}
     slot_cache: Dict[int, Optional[dict]] = {}
 
     def slots_of(v: int):
@@ -239,13 +236,23 @@ def run_area(router_id: str, area: Area, engine, graph: Optional[AreaGraph] = No
         i = int(np.searchsorted(hb, s, side="right")) - 1
         p, k = hv[i], int(g.row_ptr[hv[i]]) + (s - hb[i])
         t = int(g.col[k])
-        slot_cache[s] = calc_nexthops(g, vertex(p), k, g.vids[t], g.lsa_of(t))
+        slot_cache[s] = calc(g, vertex(p), k, g.vids[t], g.lsa_of(t))
         return slot_cache[s]
 
     # distance order guarantees parents (hops == 0 networks) are materialised before children
     for v in sorted(np.nonzero(in_spt)[0].tolist(), key=lambda v: (int(dist[v]), v)):
         vertex(v)
     return spt
+
+
+def run_area(router_id: str, area: Area, engine, graph: Optional[AreaGraph] = None):
+    """holo-ospf/src/spf.rs:587-729 -> dict VertexId -> Vertex (the area's SPT), or None when the
+    root's Router-LSA is missing (Error::SpfRootNotFound is logged and the run returns, :605-610)."""
+    g = graph or AreaGraph(area)
+    root = g.index.get((RTR, ip(router_id)))
+    if root is None:
+        return None
+    return spt_from_engine(g, root, engine, calc_nexthops)
 
 
 def intra_area_networks(spt: Dict[VertexId, Vertex]):          # ospfv2/spf.rs:462-538

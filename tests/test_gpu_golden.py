@@ -38,3 +38,12 @@ from test_host_ospf import OSPF, check_ospf_vector      # noqa: E402
 @pytest.mark.parametrize("path", OSPF, ids=[os.path.basename(p)[:-5] for p in OSPF])
 def test_ospfv2_run_area_on_gpu_reproduces_reference_intra_area_rib(spf_ctx, path):
     check_ospf_vector(json.load(open(path)), spf_ctx)
+
+
+# ---- OSPFv3 -----------------------------------------------------------------------------------------
+from test_host_ospf import OSPF3, check_ospfv3_vector      # noqa: E402
+
+
+@pytest.mark.parametrize("path", OSPF3, ids=[os.path.basename(p)[:-5] for p in OSPF3])
+def test_ospfv3_run_area_on_gpu_reproduces_reference_intra_area_rib(spf_ctx, path):
+    check_ospfv3_vector(json.load(open(path)), spf_ctx)

@@ -39,3 +39,34 @@ def check_ospf_vector(vec, engine):
 @pytest.mark.parametrize("path", OSPF, ids=[os.path.basename(p)[:-5] for p in OSPF])
 def test_run_area_and_intra_area_rib(path):
     check_ospf_vector(json.load(open(path)), OracleEngine())
+
+
+# ---- OSPFv3 -----------------------------------------------------------------------------------------
+from holo_amd import ospfv3 as H3        # noqa: E402
+from oracle import ospfv3_ref as R3      # noqa: E402
+
+OSPF3 = sorted(glob.glob(os.path.join(GOLD, "ospfv3", "*.json")))
+
+
+def check_ospfv3_vector(vec, engine):
+    areas = [H3.Area3.from_vector(a) for a in vec["areas"]]
+    got = H3.compute_spf_intra_area(vec["router_id"], areas, vec["max_paths"], engine, vec["af"])
+    assert got == R3.intra_area_rib(vec)
+    for a, area in zip(vec["areas"], areas):
+        ref = R3.run_area(vec, a)
+        spt = H3.run_area(vec["router_id"], area, engine, vec["af"])
+        if ref is None:
+            assert spt is None
+            continue
+        assert set(spt) == set(ref[0])
+        for vid, vx in ref[0].items():
+            assert (spt[vid].distance, spt[vid].hops) == (vx.distance, vx.hops)
+            assert spt[vid].nexthops == vx.nexthops
+    if not vec["has_vlinks"]:
+        want = sorted([r for r in vec["rib"] if r["type"] == "intra-area"], key=lambda r: R3._net_key(r["prefix"]))
+        assert got == want
+
+
+@pytest.mark.parametrize("path", OSPF3, ids=[os.path.basename(p)[:-5] for p in OSPF3])
+def test_ospfv3_run_area_and_intra_area_rib(path):
+    check_ospfv3_vector(json.load(open(path)), OracleEngine())

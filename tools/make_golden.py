@@ -183,7 +183,8 @@ if __name__ == "__main__":
         sys.exit("needs /root/reference (build container only)")
     make_isis()
     try:
-        from make_golden_ospf import make_ospfv2   # noqa
+        from make_golden_ospf import make_ospfv2, make_ospfv3   # noqa
         make_ospfv2()
+        make_ospfv3()
     except ImportError:
         pass

@@ -112,3 +112,109 @@ def make_ospfv2():
 
 if __name__ == "__main__":
     make_ospfv2()
+
+
+# --------------------------------------------------------------------------------------------
+# OSPFv3  (fixtures exist although `mod ospfv3` is commented out upstream,
+#          holo-ospf/tests/conformance/mod.rs:7-8)
+# --------------------------------------------------------------------------------------------
+
+def _iface_order(cfg, st):
+    """Same arena-slot recovery as for OSPFv2 (see ospfv2_vector)."""
+    names = sorted({i["name"] for a in cfg.get("areas", {}).get("area", [])
+                    for i in a.get("interfaces", {}).get("interface", [])})
+    before = set()
+    for r in st.get("local-rib", {}).get("route", []):
+        seq = []
+        for n in r.get("next-hops", {}).get("next-hop", []):
+            if n.get("outgoing-interface") and (not seq or seq[-1] != n["outgoing-interface"]):
+                seq.append(n["outgoing-interface"])
+        before |= {(x, y) for x, y in zip(seq, seq[1:])}
+    placed = []
+    while len(placed) < len(names):
+        nxt = next(n for n in names if n not in placed
+                   and not any((m, n) in before for m in names if m not in placed and m != n))
+        placed.append(nxt)
+    return {n: k for k, n in enumerate(placed)}
+
+
+def ospfv3_vector(rt_dir: str) -> dict:
+    cfg_doc = json.load(open(os.path.join(rt_dir, "config.json")))
+    st_doc = json.load(open(os.path.join(rt_dir, "output", "northbound-state.json")))
+    cfg = _proto(cfg_doc, "ietf-ospf:ospf")
+    st = _proto(st_doc, "ietf-ospf:ospf")
+    order = _iface_order(cfg, st)
+    iftype, has_vlinks = {}, False
+    for a in cfg.get("areas", {}).get("area", []):
+        for i in a.get("interfaces", {}).get("interface", []):
+            iftype[i["name"]] = i.get("interface-type", "broadcast")
+        if a.get("virtual-links", {}).get("virtual-link"):
+            has_vlinks = True
+    areas = []
+    for a in st.get("areas", {}).get("area", []):
+        routers, networks, iaps = [], [], []
+        for t in a.get("database", {}).get("area-scope-lsa-type", []):
+            for l in t["area-scope-lsas"]["area-scope-lsa"]:
+                body, hdr = l["ospfv3"]["body"], l["ospfv3"]["header"]
+                if "router" in body:
+                    b = body["router"]
+                    routers.append({"adv_rtr": hdr["adv-router"], "lsa_id": int(hdr["lsa-id"]),
+                                    "options": [_strip(o) for o in b.get("lsa-options", {}).get("lsa-options", [])],
+                                    "bits": [_strip(x) for x in b.get("router-bits", {}).get("rtr-lsa-bits", [])],
+                                    "links": [{"type": _strip(k["type"]), "iface_id": int(k["interface-id"]),
+                                               "nbr_iface_id": int(k["neighbor-interface-id"]),
+                                               "nbr_router_id": k["neighbor-router-id"], "metric": int(k["metric"])}
+                                              for k in b.get("links", {}).get("link", [])]})
+                elif "network" in body:
+                    networks.append({"adv_rtr": hdr["adv-router"], "lsa_id": int(hdr["lsa-id"]),
+                                     "attached": body["network"]["attached-routers"]["attached-router"]})
+                elif "intra-area-prefix" in body:
+                    b = body["intra-area-prefix"]
+                    iaps.append({"adv_rtr": hdr["adv-router"], "lsa_id": int(hdr["lsa-id"]),
+                                 "ref_type": _strip(b["referenced-ls-type"]), "ref_lsa_id": int(b["referenced-link-state-id"]),
+                                 "ref_adv_rtr": b["referenced-adv-router"],
+                                 "prefixes": [{"prefix": p["prefix"], "metric": int(p.get("metric", 0)),
+                                               "options": [_strip(o) for o in p.get("prefix-options", {}).get("prefix-options", [])]}
+                                              for p in b.get("prefixes", {}).get("prefix", [])]})
+        ifaces = []
+        for i in a.get("interfaces", {}).get("interface", []):
+            links = []
+            for t in i.get("database", {}).get("link-scope-lsa-type", []):
+                for l in t["link-scope-lsas"]["link-scope-lsa"]:
+                    b = l["ospfv3"]["body"]
+                    if "link" in b:
+                        links.append({"adv_rtr": l["ospfv3"]["header"]["adv-router"], "lsa_id": int(l["ospfv3"]["header"]["lsa-id"]),
+                                      "lladdr": b["link"]["link-local-interface-address"]})
+            ifaces.append({"name": i["name"], "type": iftype.get(i["name"], "broadcast"),
+                           "index": order.get(i["name"], 1000 + len(ifaces)), "iface_id": int(i.get("interface-id", 0)),
+                           "neighbors": [{"router_id": n["neighbor-router-id"], "src": n["address"]}
+                                         for n in i.get("neighbors", {}).get("neighbor", [])],
+                           "link_lsas": links})
+        if a.get("virtual-links", {}).get("virtual-link"):
+            has_vlinks = True
+        areas.append({"area_id": a["area-id"], "routers": routers, "networks": networks, "iaps": iaps, "interfaces": ifaces})
+    rib = []
+    for r in st.get("local-rib", {}).get("route", []):
+        nhs = [[n.get("next-hop"), n.get("outgoing-interface")] for n in r.get("next-hops", {}).get("next-hop", [])]
+        rib.append({"prefix": r["prefix"], "metric": int(r["metric"]), "type": r["route-type"], "nexthops": nhs})
+    af = "ipv4" if any("." in r["prefix"].split("/")[0] and ":" not in r["prefix"] for r in rib) else "ipv6"
+    return {"source": os.path.relpath(rt_dir, REF), "proto": "ospfv3", "router_id": st["router-id"], "af": af,
+            "max_paths": int(cfg.get("spf-control", {}).get("paths", 16)), "has_vlinks": has_vlinks,
+            "areas": areas, "rib": rib}
+
+
+def make_ospfv3():
+    base = os.path.join(REF, "holo-ospf/tests/conformance/ospfv3/topologies")
+    out = os.path.join(OUT, "ospfv3")
+    os.makedirs(out, exist_ok=True)
+    n = 0
+    for rt in sorted(glob.glob(os.path.join(base, "topo*", "rt*"))):
+        try:
+            v = ospfv3_vector(rt)
+        except Exception as e:      # noqa: BLE001
+            print("skip", rt, repr(e)[:100])
+            continue
+        name = f"{os.path.basename(os.path.dirname(rt))}_{os.path.basename(rt)}.json"
+        json.dump(v, open(os.path.join(out, name), "w"), separators=(",", ":"), sort_keys=True)
+        n += 1
+    print(f"ospfv3: {n} vectors -> {out}")
