@@ -328,6 +328,8 @@ class Spt:
     def __init__(self):
         self.vertices: Dict[VertexId, Vertex] = {}
         self._pop_order: List[VertexId] = []
+        self._parents: Optional[Dict[VertexId, List[VertexId]]] = None
+        self._parent_src = None            # (graph, dist row, hops row, in-SPT row, rank_key) for the lazy rebuild
 
     def contains(self, vid: VertexId) -> bool:
         return vid in self.vertices
@@ -344,6 +346,46 @@ class Spt:
 
     def second_hops(self):
         return [self.vertices[v] for v in self._pop_order if v[0] and self.vertices[v].hops == 2]
+
+    def parents(self, vid: VertexId) -> List[VertexId]:
+        """`Vertex.parents` (spf.rs:85, 677): every relaxation that reached the vertex at its final
+        distance, in the order they happened (parents in pop order, their links in LSP order,
+        parallel links repeated).  Rebuilt on first use from the tight links of the graph."""
+        if self._parents is None:
+            self._parents = {}
+            if self._parent_src is not None:
+                g, dist, hops, in_spt, rank_key = self._parent_src
+                ignore_ovl = g.mt_id is None
+                members = sorted(np.nonzero(in_spt)[0].tolist(), key=rank_key)
+                for u in members:
+                    f = g.vflags[u]
+                    if f & VF_NO_EXPAND:
+                        continue
+                    if hops[u] != 0 and not (f & VF_NETWORK) and not ignore_ovl and (f & VF_NO_TRANSIT):
+                        continue
+                    for k in range(int(g.row_ptr[u]), int(g.row_ptr[u + 1])):
+                        t = int(g.col[k])
+                        if not in_spt[t] or rank_key(t) <= rank_key(u) or not g.links_back(t, u):
+                            continue
+                        if min(int(dist[u]) + int(g.metric[k]), 0xFFFFFFFF) == int(dist[t]):
+                            self._parents.setdefault(g.vids[t], []).append(g.vids[u])
+        return self._parents.get(vid, [])
+
+    def is_on_path(self, ancestor: bytes, descendant: bytes) -> bool:
+        """spf.rs:261-286: does `ancestor` appear on ANY shortest path from `descendant` to the root."""
+        a, d = vertex_id((ancestor, 0)), vertex_id((descendant, 0))
+        if a not in self.vertices or d not in self.vertices:
+            return False
+        stack, seen = [d], set()
+        while stack:
+            cur = stack.pop()
+            if cur == a:
+                return True
+            if cur in seen:
+                continue
+            seen.add(cur)
+            stack.extend(self.parents(cur))
+        return False
 
 
 def resolve_nexthop(nexthop: VertexNexthop, level: int, mt_id: int, parent_is_pseudonode: bool,
@@ -499,6 +541,7 @@ def compute_spts(level: int, root_system_ids: Sequence[bytes], local: bool, mt_i
                         vx.nexthops.append(nh)
             s.vertices[vx.id] = vx
         s._pop_order = [g.vids[v] for v in sorted(members.tolist(), key=rank_key)]
+        s._parent_src = (g, dist, hops, in_spt, rank_key)
         spts[i] = s
     return spts  # type: ignore[return-value]
 
@@ -507,6 +550,30 @@ def compute_spt(level: int, root_system_id: bytes, local: bool, mt_id: Optional[
                 instance: Instance, engine, graph: Optional[LevelGraph] = None) -> Spt:
     """holo-isis/src/spf.rs:527-709."""
     return compute_spts(level, [root_system_id], local, mt_id, hopcount, instance, engine, graph)[0]
+
+
+@dataclass
+class NeighborCache:                       # holo-isis/src/flooding/manet.rs:30-35
+    spt_hopcount: Spt
+    remote_nbr_list: Dict[bytes, str]
+
+
+def manet_init_cache(level: int, instance: Instance, engine, flooding_algo_of=None) -> Dict[bytes, NeighborCache]:
+    """flooding::manet::init_cache (holo-isis/src/flooding/manet.rs:39-97): one hop-count SPT per Up
+    adjacency — here ONE batched engine run instead of a sequential loop — and, per neighbour, its
+    remote neighbour list (the first hops of that SPT with the flooding algorithm each advertises;
+    `flooding_algo_of(system_id)` supplies the sub-TLV value, default zero-pruner as in :84)."""
+    nbrs: List[bytes] = []
+    for iface in instance.interfaces_by_name():
+        for adj in iface.adjacencies:
+            if adj.state == "up" and adj.system_id not in nbrs:
+                nbrs.append(adj.system_id)
+    spts = compute_spts(level, nbrs, False, None, True, instance, engine)
+    out = {}
+    for sid, spt in zip(nbrs, spts):
+        rnl = {v.id[1]: (flooding_algo_of(v.id[1]) if flooding_algo_of else "zero-pruner") for v in spt.first_hops()}
+        out[sid] = NeighborCache(spt, dict(sorted(rnl.items())))
+    return out
 
 
 # ---- routes ------------------------------------------------------------------------------------------

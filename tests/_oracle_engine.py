@@ -54,7 +54,13 @@ class OracleEngine:
         oflags = run_flags & (E.RUN_NET_NEXTHOPS | E.RUN_IGNORE_OVERLOAD)
         r = go.run(G.row_ptr, G.col, G.metric, G.vflags, G.max_path_metric, roots, oflags, self.variant)
         rank = r.pop_rank if (run_flags & E.RUN_POP_RANK) else None
-        # mark everything "exact" when the graph has zero-cost router->router links so that the host
-        # layer exercises its pop-rank path the way it would behind the real engine
+        # like the real engine, tell the caller which roots did NOT pop in the static (distance,
+        # index) order (zero-cost plateaus): RF_EXACT makes the host layer ask for pop ranks
         flags = r.flags.copy()
+        for j in range(len(roots)):
+            members = np.nonzero(r.flags[j])[0]
+            static = members[np.lexsort((members, r.dist[j][members]))]
+            popped = members[np.argsort(r.pop_rank[j][members], kind="stable")]
+            if not np.array_equal(static, popped):
+                flags[j][members] |= E.RF_EXACT
         return E.SpfResult(r.dist, r.hops, flags, r.mask, rank, {})

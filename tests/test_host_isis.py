@@ -41,8 +41,24 @@ def check_spts_against_ref(vec, inst, engine):
                     assert (got.distance, got.hops) == (vx.distance, vx.hops)
                     assert ({(n.system_id, n.iface_name, n.ipv4, n.ipv6) for n in got.nexthops}
                             == {(n["system_id"], n["iface"], n["ipv4"], n["ipv6"]) for n in vx.nexthops})
+                    assert spt.parents(vid) == vx.parents
                 assert [v.id for v in spt.first_hops()] == [v for v in order if v[0] and ref[v].hops == 1]
                 assert [v.id for v in spt.second_hops()] == [v for v in order if v[0] and ref[v].hops == 2]
+                # Spt::is_on_path (holo-isis/src/spf.rs:261-286), every pair of systems
+                def ref_on_path(a, d):
+                    stack, seen = [d], set()
+                    while stack:
+                        c = stack.pop()
+                        if c == a:
+                            return True
+                        if c in seen:
+                            continue
+                        seen.add(c); stack.extend(ref[c].parents)
+                    return False
+                routers = [v for v in ref if v[0]]
+                for a in routers:
+                    for d in routers:
+                        assert spt.is_on_path(a[1], d[1]) == ref_on_path(a, d)
 
 
 @pytest.mark.parametrize("path", ISIS[::3], ids=[os.path.basename(p)[:-5] for p in ISIS[::3]])
@@ -56,3 +72,22 @@ def test_root_without_lsp_is_alone_in_its_spt():
     inst = H.Instance.from_vector(vec)
     spt = H.compute_spt(inst.config.levels()[0], b"\xaa" * 6, True, 0, False, inst, OracleEngine())
     assert [v.id for v in spt.iter()] == [(True, b"\xaa" * 6, 0)]
+
+
+def test_manet_init_cache_is_one_batched_run():
+    vec = json.load(open(ISIS[8]))
+    inst = H.Instance.from_vector(vec)
+
+    class Counting(OracleEngine):
+        runs = 0
+
+        def run(self, *a, **k):
+            Counting.runs += 1
+            return super().run(*a, **k)
+    level = inst.config.levels()[0]
+    cache = H.manet_init_cache(level, inst, Counting())
+    nbrs = {a.system_id for i in inst.interfaces for a in i.adjacencies if a.state == "up"}
+    assert set(cache) == nbrs and Counting.runs == 1
+    for sid, c in cache.items():
+        ref, order = R.compute_spt(vec, level, sid, False, None, True)
+        assert list(c.remote_nbr_list) == sorted(v[1] for v in order if v[0] and ref[v].hops == 1)
