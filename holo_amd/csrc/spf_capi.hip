@@ -549,6 +549,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 
   const uint32_t vblocks = (n + VPB - 1) / VPB;
   const dim3 grid(((vblocks + 7) / 8) * 8, B);
+  const uint32_t fblocks = (n + FVPB - 1) / FVPB;
+  const dim3 fgrid(((fblocks + 7) / 8) * 8, B);          // the fused kernel's blocks cover FQ x more vertices
 
   // ---- phase 1: distances.  Launch ahead `est` sweeps (each launch exits at once when the
   // previous one changed nothing), then read ONE flag back; repeat in small chunks if needed.
@@ -604,9 +606,9 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       uint32_t n_f = 0;
       const bool maxinf = g->max_path_metric == HSPF_DIST_INF;
       int r2 = run_phase(ctx->est_fused, [&](uint32_t sweep) {
-        if (nar)         hipLaunchKernelGGL((k_fused<uint32_t, false>), grid, dim3(256), 0, s, d_fg, (uint32_t *)d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
-        else if (maxinf) hipLaunchKernelGGL((k_fused<uint64_t, true>), grid, dim3(256), 0, s, d_fg, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
-        else             hipLaunchKernelGGL((k_fused<uint64_t, false>), grid, dim3(256), 0, s, d_fg, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+        if (nar)         hipLaunchKernelGGL((k_fused<uint32_t, false>), fgrid, dim3(256), 0, s, d_fg, (uint32_t *)d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+        else if (maxinf) hipLaunchKernelGGL((k_fused<uint64_t, true>), fgrid, dim3(256), 0, s, d_fg, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+        else             hipLaunchKernelGGL((k_fused<uint64_t, false>), fgrid, dim3(256), 0, s, d_fg, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
       }, n_f);
       if (r2) return r2;
       ctx->est_fused = n_f + 1;

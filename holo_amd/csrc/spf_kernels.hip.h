@@ -648,12 +648,19 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
 // range (stamps, row bounds, flags), ONE for the link vectors, old states and out-link vectors of
 // all its active rows, then one per row for the neighbour rows; state stores and wake-up stamps
 // are fire-and-forget (the out-link vector was fetched up front, speculatively).
+// A wave owns FQ quads of VPW consecutive vertices (a block = 4 waves x FQ x VPW vertices): the
+// wave-level set-up (ids, descriptors, activation stamps of all its vertices in ONE load) is paid
+// once per FQ x VPW rows and a sweep launches FQ x fewer waves — the floor of a sweep with little
+// to do is the cost of launching and retiring its waves (profiles/r01_notes.md).
+constexpr int FQ = 1;          // measured: FQ = 4 makes sparse sweeps cheaper (tail 6 vs 10 us) but dense ones slower (50 vs 39.5 us: 4x fewer waves to hide latency)
+constexpr int FVPW = FQ * VPW;                    // vertices per wave (<= 63: one lane per vertex + 1)
+constexpr int FVPB = WAVES_PER_BLOCK * FVPW;      // vertices per block of the fused kernel
+
 template <typename ST, bool MAXINF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fused(const FusedGraph *__restrict__ gp, ST *__restrict__ st,
-                                               uint32_t *__restrict__ act, const uint8_t *__restrict__ hnb,
-                                               const uint32_t *__restrict__ roots, FusedParams P,
-                                               uint32_t net_nexthops, uint32_t ignore_ovl,
-                                               int *changed, int sweep, uint32_t *lane_flags) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fused(
+    const FusedGraph *__restrict__ gp, ST *__restrict__ st, uint32_t *__restrict__ act,
+    const uint8_t *__restrict__ hnb, const uint32_t *__restrict__ roots, FusedParams P,
+    uint32_t net_nexthops, uint32_t ignore_ovl, int *changed, int sweep, uint32_t *lane_flags) {
   // The graph / slot-table descriptors live in device memory and are fetched (scalar loads) where
   // they are used: as by-value kernel arguments they pinned ~40 SGPRs for the whole kernel, and
   // above 96 SGPRs a CU only admits 6 of these workgroups instead of 8 (MI355X_MICROARCH.md).
@@ -662,20 +669,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t batch = blockIdx.y;
   const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
-  const uint32_t vbeg = chunk * VPB + wave * VPW;
+  const uint32_t wbeg = chunk * FVPB + wave * FVPW;
   const uint32_t n = gp->g.n;
-  if (vbeg >= n) return;
+  if (wbeg >= n) return;
   uint32_t *A = act + (size_t)batch * n;
   const uint32_t cur = (uint32_t)sweep + 2u;
-  // ---- round trip 1: stamps, row bounds, flags of the wave's VPW vertices (lanes 0..VPW)
-  const uint32_t vl = min(vbeg + min(lane, (uint32_t)VPW), n);    // in_ptr / out_ptr have n+1 (+16) entries
+  // ---- round trip 1: stamps, row bounds, flags of ALL the wave's vertices (lanes 0..FVPW)
+  const uint32_t vl = min(wbeg + min(lane, (uint32_t)FVPW), n);   // in_ptr / out_ptr have n+1 (+16) entries
   const uint32_t vlc = min(vl, n - 1);
   const uint32_t av = A[vlc];
   const uint32_t pv = gp->g.in_ptr[vl];
   const uint32_t po = gp->g.out_ptr[vl];
   const uint32_t hb = hnb[(size_t)batch * n + vlc] & (ignore_ovl ? ~RF_NT : ~0u);
   const uint32_t vf = gp->g.vflags[vlc];
-  if (__ballot(lane < (uint32_t)VPW && vbeg + lane < n && av >= cur) == 0ull) return;
+  const uint64_t due = __ballot(lane < (uint32_t)FVPW && wbeg + lane < n && av >= cur);
+  if (due == 0ull) return;
   const uint32_t root_slot = batch * 64 + lane;
   const uint32_t my_root = roots[root_slot];
   ST *S = st + (size_t)batch * n * 64;
@@ -687,58 +695,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   const __amdgpu_buffer_rsrc_t rsrc_od = st_rsrc(gp->g.out_dst, ebytes);
   const uint32_t lvo = lane * (uint32_t)sizeof(ST);
   const uint32_t lane4 = lane * 4u;
-  // ---- round trip 2: link vectors (first 64 links), old state, out-link vector of every active row
-  uint32_t svv[VPW], wvv[VPW], odv[VPW];
-  typename StIO<ST>::Raw oldq[VPW];
-  {
-    // unconditional (rows that are not due simply are not used): 16 requests in flight, no control
-    // flow; reads past a row's end stay inside the padded arrays and are masked afterwards
-    uint32_t ta[VPW], tb[VPW], tc[VPW];
-#pragma unroll
-    for (int i = 0; i < VPW; ++i) {
-      const uint32_t e0 = rdlane(pv, i), o0 = rdlane(po, i);
-      ta[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_src, lane4, e0 * 4u, 0);
-      tb[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_w, lane4, e0 * 4u, 0);
-      tc[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_od, lane4, o0 * 4u, 0);
-      oldq[i] = StIO<ST>::ld(rs, lvo, min(vbeg + i, n - 1) << StIO<ST>::ROW_SHIFT);
-    }
-#pragma unroll
-    for (int i = 0; i < VPW; ++i) {
-      const uint32_t cnt = min(64u, rdlane(pv, i + 1) - rdlane(pv, i));
-      const uint32_t ocnt = min(64u, rdlane(po, i + 1) - rdlane(po, i));
-      svv[i] = lane < cnt ? ta[i] : min(vbeg + i, n - 1);
-      wvv[i] = lane < cnt ? tb[i] : INF;
-      odv[i] = lane < ocnt ? tc[i] * 4u : 0xFFFFFFFFu;            // byte offset into A; out of range = dropped
-    }
-  }
   bool any = false, sat = false, need_exact = false, ovf = false;
-  auto row = [&](auto I) {                                        // explicit 4x instantiation
-    constexpr int i = decltype(I)::value;
-    const uint32_t v = vbeg + i;
-    if (v >= n) return;
-    if (rdlane(av, i) < cur) return;                              // nothing changed around this row
-    const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
-    const uint32_t v_router = (rdlane(vf, i) & 1u) ? 0u : 1u;
-    RowOut<ST> r;
-    if (rdlane(hb, i) == 0u)
-      r = fused_row16<ST, MAXINF>(rs, v, e1 - e0, svv[i], wvv[i], lvo, my_root, v_router, P);
-    else
-      r = fused_row_any<ST, MAXINF>(gp->g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
-    sat = sat || r.sat;
-    need_exact = need_exact || r.need_exact;
-    ovf = ovf || r.ovf;
-    const bool ch = r.nw != StIO<ST>::bits(oldq[i]);
-    if (ch) { S[(size_t)v * 64 + lane] = r.nw; any = true; }
-    if (__ballot(ch) != 0ull) {                                   // wake the out-neighbours up
-      __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, odv[i], 0, 0);
-      const uint32_t o0 = rdlane(po, i), o1 = rdlane(po, i + 1);
-      for (uint32_t ob = o0 + 64u + lane; ob < o1; ob += 64)      // rows with more than 64 out-links
-        __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, gp->g.out_dst[ob] * 4u, 0, 0);
+#pragma unroll 1
+  for (uint32_t q = 0; q < (uint32_t)FQ; ++q) {
+    if (((due >> (q * VPW)) & ((1ull << VPW) - 1ull)) == 0ull) continue;   // nothing due in this quad
+    const uint32_t vbeg = wbeg + q * VPW;
+    const uint32_t lb = q * VPW;                                  // lane of the quad's first vertex
+    // ---- round trip 2: link vectors (first 64 links), old state, out-link vector of the quad's
+    // rows: unconditional (rows that are not due simply are not used): 16 requests in flight, no
+    // control flow; reads past a row's end stay inside the padded arrays and are masked afterwards
+    uint32_t svv[VPW], wvv[VPW], odv[VPW];
+    typename StIO<ST>::Raw oldq[VPW];
+    {
+      uint32_t ta[VPW], tb[VPW], tc[VPW];
+#pragma unroll
+      for (int i = 0; i < VPW; ++i) {
+        const uint32_t e0 = rdlane(pv, lb + i), o0 = rdlane(po, lb + i);
+        ta[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_src, lane4, e0 * 4u, 0);
+        tb[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_w, lane4, e0 * 4u, 0);
+        tc[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_od, lane4, o0 * 4u, 0);
+        oldq[i] = StIO<ST>::ld(rs, lvo, min(vbeg + i, n - 1) << StIO<ST>::ROW_SHIFT);
+      }
+#pragma unroll
+      for (int i = 0; i < VPW; ++i) {
+        const uint32_t cnt = min(64u, rdlane(pv, lb + i + 1) - rdlane(pv, lb + i));
+        const uint32_t ocnt = min(64u, rdlane(po, lb + i + 1) - rdlane(po, lb + i));
+        svv[i] = lane < cnt ? ta[i] : min(vbeg + i, n - 1);
+        wvv[i] = lane < cnt ? tb[i] : INF;
+        odv[i] = lane < ocnt ? tc[i] * 4u : 0xFFFFFFFFu;          // byte offset into A; out of range = dropped
+      }
     }
-  };
-  static_assert(VPW == 4, "row() is instantiated four times");
-  row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{});
-  row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
+    auto row = [&](auto I) {                                      // explicit 4x instantiation
+      constexpr int i = decltype(I)::value;
+      const uint32_t v = vbeg + i;
+      if (v >= n) return;
+      if (rdlane(av, lb + i) < cur) return;                       // nothing changed around this row
+      const uint32_t e0 = rdlane(pv, lb + i), e1 = rdlane(pv, lb + i + 1);
+      const uint32_t v_router = (rdlane(vf, lb + i) & 1u) ? 0u : 1u;
+      RowOut<ST> r;
+      if (rdlane(hb, lb + i) == 0u)
+        r = fused_row16<ST, MAXINF>(rs, v, e1 - e0, svv[i], wvv[i], lvo, my_root, v_router, P);
+      else
+        r = fused_row_any<ST, MAXINF>(gp->g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
+      sat = sat || r.sat;
+      need_exact = need_exact || r.need_exact;
+      ovf = ovf || r.ovf;
+      const bool ch = r.nw != StIO<ST>::bits(oldq[i]);
+      if (ch) { S[(size_t)v * 64 + lane] = r.nw; any = true; }
+      if (__ballot(ch) != 0ull) {                                 // wake the out-neighbours up
+        __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, odv[i], 0, 0);
+        const uint32_t o0 = rdlane(po, lb + i), o1 = rdlane(po, lb + i + 1);
+        for (uint32_t ob = o0 + 64u + lane; ob < o1; ob += 64)    // rows with more than 64 out-links
+          __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, gp->g.out_dst[ob] * 4u, 0, 0);
+      }
+    };
+    static_assert(VPW == 4, "row() is instantiated four times");
+    row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{});
+    row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
+  }
   if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
   uint32_t lf = 0;
   if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
