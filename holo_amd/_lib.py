@@ -38,6 +38,15 @@ class HspfStats(ctypes.Structure):
                 ("state_bytes", ctypes.c_uint32), ("narrow_overflow", ctypes.c_uint32)]
 
 
+class HspfPrefixTable(ctypes.Structure):
+    _fields_ = [("n_prefixes", ctypes.c_uint32), ("n_entries", ctypes.c_uint32),
+                ("pfx_ptr", u32p), ("pfx_vertex", u32p), ("pfx_metric", u32p)]
+
+
+class HspfRoutes(ctypes.Structure):
+    _fields_ = [("best_metric", ctypes.c_void_p), ("best_entry", ctypes.c_void_p), ("nexthop_mask", ctypes.c_void_p)]
+
+
 # every symbol include/holo_spf_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("hspf_abi_version", ctypes.c_uint32, []),
@@ -57,6 +66,9 @@ SYMBOLS = [
     ("hspf_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(HspfResult)]),
     ("hspf_run_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(HspfResult)]),
     ("hspf_get_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(HspfStats)]),
+    ("hspf_routes_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.POINTER(HspfPrefixTable), ctypes.POINTER(HspfRoutes)]),
 ]
 
 _lib = None
@@ -71,6 +83,13 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m holo_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the SPF engine.")
+    # PyTorch-ROCm wheels ship their own libamdhip64; if it is loaded AFTER this library has pulled
+    # in /opt/rocm's copy, torch finds "no HIP GPUs".  Whoever wants torch device buffers next to
+    # the engine (bench.py, holo_amd.routes) gets one HIP runtime per process this way.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # noqa: BLE001  (torch is optional for the engine itself)
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported

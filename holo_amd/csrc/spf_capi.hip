@@ -61,6 +61,7 @@ struct hspf_ctx {
   DevBuf dist, hv, mask, roots, lane_flags, changed, tab_ptr, tab_vtx, tab_base, st64, stamp, hnb, fgraph;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
+  DevBuf pf_ptr, pf_vtx, pf_met;                    // prefix table of hspf_routes_device
   int *h_changed = nullptr;        // pinned
   uint32_t *h_lane_flags = nullptr; // pinned
   size_t h_lane_cap = 0;
@@ -197,7 +198,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->roots, &ctx->lane_flags, &ctx->changed,
                     &ctx->tab_ptr, &ctx->tab_vtx, &ctx->tab_base, &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->fgraph, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
@@ -746,6 +747,39 @@ int hspf_run_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out) {
   if (!ctx || !out) return HSPF_E_INVAL;
   *out = ctx->stats;
+  return HSPF_OK;
+}
+
+int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uint32_t n_mask_words,
+                       const uint32_t *dist_dev, const uint16_t *flags_dev, const uint64_t *mask_dev,
+                       const hspf_prefix_table *t, hspf_routes *out) {
+  if (!ctx || !t || !out || !dist_dev || !flags_dev || !mask_dev || !out->best_metric || !out->best_entry ||
+      !out->nexthop_mask || n_roots == 0 || n_mask_words == 0 || !t->pfx_ptr || (t->n_entries && (!t->pfx_vertex || !t->pfx_metric)))
+    return HSPF_E_INVAL;
+  if (t->pfx_ptr[0] != 0 || t->pfx_ptr[t->n_prefixes] != t->n_entries) { ctx->last_error = "pfx_ptr malformed"; return HSPF_E_INVAL; }
+  for (uint32_t p = 0; p < t->n_prefixes; ++p)
+    if (t->pfx_ptr[p + 1] < t->pfx_ptr[p]) { ctx->last_error = "pfx_ptr not monotone"; return HSPF_E_INVAL; }
+  for (uint32_t e = 0; e < t->n_entries; ++e)
+    if (t->pfx_vertex[e] >= n_vertices) { ctx->last_error = "pfx_vertex out of range"; return HSPF_E_INVAL; }
+  if (t->n_prefixes == 0) return HSPF_OK;
+  (void)hipSetDevice(ctx->device);
+  int rc;
+  if ((rc = ensure(ctx, ctx->pf_ptr, (size_t)(t->n_prefixes + 1) * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->pf_vtx, std::max<size_t>(t->n_entries, 1) * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->pf_met, std::max<size_t>(t->n_entries, 1) * 4))) return rc;
+  hipStream_t s = ctx->stream;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pf_ptr.p, t->pfx_ptr, (size_t)(t->n_prefixes + 1) * 4, hipMemcpyHostToDevice, s));
+  if (t->n_entries) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pf_vtx.p, t->pfx_vertex, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pf_met.p, t->pfx_metric, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
+  }
+  hipLaunchKernelGGL(k_routes, dim3((t->n_prefixes + 255) / 256, n_roots), dim3(256), 0, s, n_vertices, n_roots, n_mask_words,
+                     t->n_prefixes, (const uint32_t *)ctx->pf_ptr.p, (const uint32_t *)ctx->pf_vtx.p,
+                     (const uint32_t *)ctx->pf_met.p, dist_dev, flags_dev, mask_dev, out->best_metric, out->best_entry,
+                     out->nexthop_mask);
+  HIPCHK(ctx, hipStreamSynchronize(s));       // the table was read from caller-owned host memory
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { ctx->last_error = std::string("k_routes: ") + hipGetErrorString(le); return HSPF_E_HIP; }
   return HSPF_OK;
 }
 

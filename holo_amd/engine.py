@@ -174,6 +174,21 @@ class SpfContext:
             raise HspfError(rc, "hspf_run_device", self.last_error())
         return self.stats()
 
+    def routes_device(self, n_vertices: int, n_roots: int, mask_words: int, dist_ptr: int, flags_ptr: int,
+                      mask_ptr: int, pfx_ptr, pfx_vertex, pfx_metric, *, best_metric_ptr: int,
+                      best_entry_ptr: int, nexthop_mask_ptr: int) -> None:
+        """hspf_routes_device(): prefix attachment for every root of a previous run_device(); all
+        `*_ptr` arguments are device pointers, the prefix table is host numpy."""
+        pfx_ptr = np.ascontiguousarray(pfx_ptr, np.uint32)
+        pfx_vertex = np.ascontiguousarray(pfx_vertex, np.uint32)
+        pfx_metric = np.ascontiguousarray(pfx_metric, np.uint32)
+        t = L.HspfPrefixTable(len(pfx_ptr) - 1, len(pfx_vertex), _u32(pfx_ptr), _u32(pfx_vertex), _u32(pfx_metric))
+        o = L.HspfRoutes(best_metric_ptr, best_entry_ptr, nexthop_mask_ptr)
+        rc = self.lib.hspf_routes_device(self.handle, n_vertices, n_roots, mask_words, dist_ptr, flags_ptr, mask_ptr,
+                                         ctypes.byref(t), ctypes.byref(o))
+        if rc != 0:
+            raise HspfError(rc, "hspf_routes_device", self.last_error())
+
     def close(self):
         if self.handle:
             self.lib.hspf_shutdown(self.handle)

@@ -187,6 +187,41 @@ int hspf_run_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
                     uint32_t run_flags, hspf_result *out_device);
 int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out);
 
+/* ---- route derivation on device (the step right after the SPT) ------------------- */
+/*
+ * Prefix attachment of holo-isis compute_routes (holo-isis/src/spf.rs:864-918) for every root of a
+ * previous hspf_run_device(): for each IP prefix, over the vertices that advertise it (iterated in
+ * VertexId order, i.e. ascending vertex index), route metric = dist[v] + prefix metric; the smallest
+ * wins (`Ordering::Less` replaces the route, :902-905), equal metrics merge their next hops
+ * (`merge_nexthops`, :906-909).  What needs addresses — building Nexthop objects, the max-paths
+ * truncation by address order (:920-929) — stays with the caller and consumes best_metric /
+ * best_entry / nexthop_mask.
+ *
+ * The prefix table is CSR by prefix: entries pfx_ptr[p] .. pfx_ptr[p+1] are the (vertex, metric)
+ * advertisements of prefix p, sorted by vertex index.  All result / input table pointers are DEVICE
+ * pointers; pfx_* are caller-owned HOST arrays (uploaded per call).
+ */
+typedef struct {
+  uint32_t        n_prefixes;
+  uint32_t        n_entries;
+  const uint32_t *pfx_ptr;      /* [n_prefixes+1]                                                */
+  const uint32_t *pfx_vertex;   /* [n_entries] advertising vertex                                */
+  const uint32_t *pfx_metric;   /* [n_entries] advertised metric                                 */
+} hspf_prefix_table;
+
+typedef struct {
+  uint32_t *best_metric;        /* [n_roots][n_prefixes]  HSPF_DIST_INF: no advertising vertex in the SPT */
+  uint32_t *best_entry;         /* [n_roots][n_prefixes]  index of the FIRST entry attaining it (route
+                                   attributes — level, external flag, CONNECTED — come from that vertex,
+                                   holo-isis/src/route.rs:79-107); 0xFFFFFFFF when unreachable    */
+  uint64_t *nexthop_mask;       /* [n_roots][n_prefixes][n_mask_words] union of the first-hop masks of
+                                   every entry attaining it                                        */
+} hspf_routes;
+
+int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uint32_t n_mask_words,
+                       const uint32_t *dist_dev, const uint16_t *flags_dev, const uint64_t *mask_dev,
+                       const hspf_prefix_table *table, hspf_routes *out_dev);
+
 #ifdef __cplusplus
 }
 #endif
