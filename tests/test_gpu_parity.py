@@ -218,3 +218,36 @@ def test_fattree_two_mask_words_two_phase_path(spf_ctx):
     roots = np.asarray(g.meta["roots"][:24], np.uint32)
     res, ref = check(spf_ctx, g, roots, 0, oracle_variant=go.HEAP, expect_exact=False)
     assert res.stats["state_bytes"] == 0 and res.stats["n_dag_launches"] > 0
+
+
+def test_single_vertex_and_isolated_root(spf_ctx):
+    g = synth.CsrGraph(np.zeros(2, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(1, np.uint8),
+                       synth.MAX_PATH_METRIC_WIDE)
+    res, ref = check(spf_ctx, g, [0])
+    assert res.dist[0, 0] == 0 and res.hops[0, 0] == 0
+    # three vertices, one of them with no links at all
+    row_ptr, col, met = synth._csr_from_links(3, np.array([0, 1]), np.array([1, 0]), np.array([5, 7]))
+    g = synth.CsrGraph(row_ptr, col, met, np.zeros(3, np.uint8), synth.MAX_PATH_METRIC_WIDE)
+    res, ref = check(spf_ctx, g, [0, 1, 2])
+    assert res.dist[2, 0] == E.DIST_INF and (res.flags[2] & 1).sum() == 1
+
+
+@pytest.mark.parametrize("fanout", [70, 200])
+def test_star_rows_with_more_than_64_links(spf_ctx, fanout):
+    """The hub row has `fanout` in- and out-links: multi-chunk general row routine and the
+    more-than-64 wake-up path of the fused kernel; leaf roots keep the run on the fused path (1 slot),
+    the hub as a root needs ceil(fanout/64) mask words (two-phase path)."""
+    hub = 0
+    leaves = np.arange(1, fanout + 1)
+    chain = np.arange(fanout + 1, fanout + 30)                 # a tail behind leaf 1 so that hops grow
+    s = np.concatenate([np.full(fanout, hub), leaves, [1], [chain[0]], chain[:-1], chain[1:]])
+    d = np.concatenate([leaves, np.full(fanout, hub), [chain[0]], [1], chain[1:], chain[:-1]])
+    rng = np.random.default_rng(fanout)
+    m = rng.integers(1, 4, len(s))
+    n = fanout + 30
+    row_ptr, col, met = synth._csr_from_links(n, s, d, m)
+    g = synth.CsrGraph(row_ptr, col, met, np.zeros(n, np.uint8), synth.MAX_PATH_METRIC_WIDE)
+    res, ref = check(spf_ctx, g, [1, 2, int(chain[-1]), 5], expect_exact=False)
+    assert res.stats["state_bytes"] in (4, 8)
+    res, ref = check(spf_ctx, g, [hub, 3], expect_exact=False)
+    assert res.first_hop_mask.shape[2] == (fanout + 63) // 64
