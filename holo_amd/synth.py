@@ -190,6 +190,22 @@ def isis_fattree(k: int = 100, seed: int = SEED) -> CsrGraph:
     return g
 
 
+def ospf_multi_area(n_areas: int = 10, per_area: int = 5000, seed: int = SEED) -> list:
+    """configs[3]: multi-area OSPF, `n_areas` areas of `per_area` routers, each a 50x100 8-neighbour
+    grid (19 502 links) padded with random chords to exactly 20 000 links -> 40 000 entries, metrics
+    U[1,100]; every area is its own graph (run_area is per area), roots = every 5th router of the
+    area (1 000 per area, ~10 k in total).  The 50-router backbone of the survey's description only
+    joins the areas at the route level and carries no per-prefix SPT work; it is left out."""
+    out = []
+    for a in range(n_areas):
+        links = _add_chords(per_area, _grid8_links(50, per_area // 50), 20000, seed + 1000 * (a + 1))
+        g = _routers_only(per_area, links, seed + 77 * (a + 1), 1, 100, MAX_PATH_METRIC_OSPF, f"ospf-ma-area{a}",
+                          {"proto": "ospf", "area": a})
+        g.meta["roots"] = list(range(0, per_area, 5))
+        out.append(g)
+    return out
+
+
 # ---- adversarial random graphs for parity tests -------------------------------------------------
 
 def random_lsdb(n_routers: int, n_networks: int, avg_deg: float, seed: int, *,

@@ -251,3 +251,53 @@ def test_star_rows_with_more_than_64_links(spf_ctx, fanout):
     assert res.stats["state_bytes"] in (4, 8)
     res, ref = check(spf_ctx, g, [hub, 3], expect_exact=False)
     assert res.first_hop_mask.shape[2] == (fanout + 63) // 64
+
+
+def _properties(g, roots, res, sample, variant=go.HEAP, run_flags=0):
+    """Full-size check: a sample of roots bit for bit against the oracle, all roots through
+    size-independent properties (root at distance 0, fixed point of relaxation on every kept link,
+    hops 0 only at the root, first-hop mask non-empty exactly for reached non-root vertices)."""
+    roots = np.asarray(roots, np.uint32)
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots[sample], run_flags, variant,
+                 mask_words_=res.first_hop_mask.shape[2])
+    assert np.array_equal(res.dist[sample], ref.dist)
+    assert np.array_equal(res.hops[sample], ref.hops)
+    assert np.array_equal(res.flags[sample] & 1, ref.flags)
+    assert np.array_equal(res.first_hop_mask[sample], ref.mask)
+    R = len(roots)
+    assert (res.dist[np.arange(R), roots] == 0).all()
+    u = np.repeat(np.arange(g.n), np.diff(g.row_ptr).astype(np.int64))
+    for r in range(0, R, max(1, R // 8)):
+        d = res.dist[r].astype(np.int64)
+        assert (d[g.col] <= d[u] + g.metric).all()
+        reached = (res.flags[r] & 1) == 1
+        assert (res.first_hop_mask[r].any(axis=1) == (reached & (np.arange(g.n) != roots[r]))).all()
+        assert ((res.hops[r] == 0) & reached).sum() == 1
+
+
+def test_config_fattree_262k_two_mask_words(spf_ctx):
+    """BASELINE configs[4] at full size: k=100 fat-tree, 262 500 vertices / 1 500 000 entries, unit
+    metrics (maximal ECMP), self = an edge switch with 100 first-hop slots (2 mask words) + its 100
+    neighbours as roots."""
+    g = synth.isis_fattree(100)
+    roots = np.asarray(g.meta["roots"], np.uint32)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    res = spf_ctx.run(G, roots, 0)
+    G.free()
+    assert res.first_hop_mask.shape[2] == 2 and res.stats["n_exact_roots"] == 0
+    _properties(g, roots, res, [0, 1, 57, 100])
+
+
+def test_config_multi_area_10k_roots(spf_ctx):
+    """BASELINE configs[3] shape: 10 areas x 5 000 routers, 1 000 roots per area (16 wavefront
+    batches per run, fused path), OSPF semantics."""
+    total = 0
+    for g in synth.ospf_multi_area()[:3]:
+        roots = np.asarray(g.meta["roots"], np.uint32)
+        G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        res = spf_ctx.run(G, roots, E.RUN_NET_NEXTHOPS)
+        G.free()
+        assert res.stats["n_exact_roots"] == 0 and res.stats["state_bytes"] in (4, 8)
+        _properties(g, roots, res, [0, 333, 999], run_flags=go.RUN_NET_NEXTHOPS)
+        total += len(roots)
+    assert total == 3000
