@@ -14,7 +14,7 @@ from test_host_isis import check_spts_against_ref
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-ISIS = sorted(glob.glob(os.path.join(GOLD, "isis", "*.json")))
+ISIS = sorted(glob.glob(os.path.join(GOLD, "isis", "*.json"))) + sorted(glob.glob(os.path.join(GOLD, "isis_steps", "*.json")))
 
 
 @pytest.mark.parametrize("path", ISIS, ids=[os.path.basename(p)[:-5] for p in ISIS])

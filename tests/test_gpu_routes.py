@@ -16,7 +16,7 @@ from oracle import isis_ref as R
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-ISIS = sorted(glob.glob(os.path.join(GOLD, "isis", "*.json")))
+ISIS = sorted(glob.glob(os.path.join(GOLD, "isis", "*.json"))) + sorted(glob.glob(os.path.join(GOLD, "isis_steps", "*.json")))
 
 
 @pytest.mark.parametrize("path", ISIS, ids=[os.path.basename(p)[:-5] for p in ISIS])

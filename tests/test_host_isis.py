@@ -14,9 +14,10 @@ from _oracle_engine import OracleEngine
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 ISIS = sorted(glob.glob(os.path.join(GOLD, "isis", "*.json")))
+ISIS_STEPS = sorted(glob.glob(os.path.join(GOLD, "isis_steps", "*.json")))
 
 
-@pytest.mark.parametrize("path", ISIS, ids=[os.path.basename(p)[:-5] for p in ISIS])
+@pytest.mark.parametrize("path", ISIS + ISIS_STEPS, ids=[os.path.basename(p)[:-5] for p in ISIS + ISIS_STEPS])
 def test_compute_spf_reproduces_reference_local_rib(path):
     vec = json.load(open(path))
     inst = H.Instance.from_vector(vec)

@@ -23,6 +23,9 @@ from oracle import isis_ref as R
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 ISIS = sorted(glob.glob(os.path.join(GOLD, "isis", "*.json")))
+# step tests of the reference whose last step re-ran SPF (overload bit, ATT bit, att-ignore, max-paths
+# 16 -> 1, interface metric, passive interface, address families, LSP expiry, adjacency loss ...)
+ISIS_STEPS = sorted(glob.glob(os.path.join(GOLD, "isis_steps", "*.json")))
 
 
 def _load(p):
@@ -34,7 +37,14 @@ def test_golden_vectors_present():
     assert len(ISIS) == 38
 
 
-@pytest.mark.parametrize("path", ISIS, ids=[os.path.basename(p)[:-5] for p in ISIS])
+def test_isis_step_vectors_present():
+    assert len(ISIS_STEPS) == 19
+    names = {os.path.basename(p)[:-5] for p in ISIS_STEPS}
+    assert {"pdu-lsp-overload1", "pdu-lsp-att-bit1", "nb-config-spf-paths1", "nb-config-att-ignore1",
+            "nb-config-iface-metric1", "pdu-lsp-expiration1"} <= names
+
+
+@pytest.mark.parametrize("path", ISIS + ISIS_STEPS, ids=[os.path.basename(p)[:-5] for p in ISIS + ISIS_STEPS])
 def test_isis_ref_reproduces_reference_local_rib(path):
     vec = _load(path)
     want = sorted(vec["rib"], key=lambda r: R._net_key(r["prefix"]))

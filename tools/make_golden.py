@@ -73,7 +73,7 @@ def isis_vector(rt_dir: str) -> dict:
         "afs": afs,
         "mt_ipv6_unicast": mt_ipv6,
         "max_paths": int(cfg.get("spf-control", {}).get("paths", 16)),
-        "att_ignore": bool(cfg.get("attached-bit", {}).get("ignore-reception", False)),
+        "att_ignore": bool((cfg.get("attached-bit") or cfg.get("holo-isis:attached-bit") or {}).get("ignore-reception", False)),
         "area_addrs": cfg.get("area-address", []),
     }
 
@@ -139,7 +139,11 @@ def isis_vector(rt_dir: str) -> dict:
                     out.append(e)
                 return out
 
+            extra = {}
+            if l.get("remaining-lifetime", 1) == 0:       # expired / purged, still in the LSDB (spf.rs:1025)
+                extra["lifetime"] = 0
             lsps.append({
+                **extra,
                 "id": l["lsp-id"],
                 "flags": flags,
                 "protocols": l.get("protocol-supported"),
@@ -178,13 +182,80 @@ def make_isis():
     print(f"isis: {n} vectors -> {out}")
 
 
+# --------------------------------------------------------------------------------------------
+# IS-IS step tests (holo-isis/tests/conformance/<name>/NN-{input,output}-*): a topology snapshot,
+# then inputs (PDUs, config changes, interface events).  The LAST recorded state is again LSDB +
+# adjacencies + local-rib, i.e. a known-answer vector — the ones whose last step ran SPF pin the
+# overload / ATT / max-paths / metric gates with the reference's own answers.
+# --------------------------------------------------------------------------------------------
+
+def _merge_cfg(base, patch):
+    for k, v in patch.items():
+        if k.startswith("@"):
+            continue
+        kk = k.split(":", 1)[1] if (":" in k and k not in base and k.split(":", 1)[1] in base) else k
+        if isinstance(v, dict):
+            base[kk] = _merge_cfg(base.get(kk, {}) if isinstance(base.get(kk), dict) else {}, v)
+        elif isinstance(v, list) and v and isinstance(v[0], dict) and "name" in v[0]:
+            cur = {e["name"]: e for e in base.get(kk, [])}
+            for e in v:
+                cur[e["name"]] = _merge_cfg(cur.get(e["name"], {}), e)
+            base[kk] = list(cur.values())
+        else:
+            base[kk] = v
+    return base
+
+
+def make_isis_steps():
+    import re
+    import tempfile
+    import shutil
+    base = os.path.join(REF, "holo-isis/tests/conformance")
+    src = open(os.path.join(base, "mod.rs")).read()
+    out = os.path.join(OUT, "isis_steps")
+    os.makedirs(out, exist_ok=True)
+    n = 0
+    for name, topo, rt in re.findall(r'run_test::<Instance>\(\s*"([^"]+)",\s*"([^"]+)",\s*"([^"]+)"', src):
+        d = os.path.join(base, name)
+        states = sorted(glob.glob(os.path.join(d, "*-output-northbound-state.json")))
+        if not states:
+            continue
+        # Only steps after which the reference demonstrably re-ran SPF: the same step also recorded
+        # route (re)installations on the ibus.  (Other final states still show the RIB of the
+        # previous SPF run: the delay timer had not fired yet when the step was recorded.)
+        ibus = states[-1].replace("-output-northbound-state.json", "-output-ibus.jsonl")
+        if not os.path.exists(ibus) or "RouteIp" not in open(ibus).read():
+            continue
+        cfg = json.load(open(os.path.join(base, "topologies", topo, rt, "config.json")))
+        for ch in sorted(glob.glob(os.path.join(d, "*-input-northbound-config-change.json"))):
+            _merge_cfg(cfg, json.load(open(ch)))
+        tmp = tempfile.mkdtemp()
+        try:
+            os.makedirs(os.path.join(tmp, "output"))
+            json.dump(cfg, open(os.path.join(tmp, "config.json"), "w"))
+            shutil.copy(states[-1], os.path.join(tmp, "output", "northbound-state.json"))
+            try:
+                v = isis_vector(tmp)
+            except Exception as e:      # noqa: BLE001
+                print("skip", name, repr(e)[:80])
+                continue
+        finally:
+            shutil.rmtree(tmp)
+        v["source"] = f"holo-isis/tests/conformance/{name} (snapshot {topo}/{rt}, state {os.path.basename(states[-1])})"
+        json.dump(v, open(os.path.join(out, f"{name}.json"), "w"), separators=(",", ":"), sort_keys=True)
+        n += 1
+    print(f"isis step tests: {n} vectors -> {out}")
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("needs /root/reference (build container only)")
     make_isis()
+    make_isis_steps()
     try:
         from make_golden_ospf import make_ospfv2, make_ospfv3   # noqa
         make_ospfv2()
         make_ospfv3()
     except ImportError:
         pass
+
