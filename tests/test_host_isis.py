@@ -30,6 +30,8 @@ def check_spts_against_ref(vec, inst, engine):
     hop-count variants, against the literal restatement: distance, hops, next-hop system ids and
     first/second-hop lists in pop order."""
     for level in inst.config.levels():
+        if level not in inst.lsdb:
+            continue                          # instance disabled: empty LSDB, nothing to compute
         systems = sorted({l.system_id for l in inst.lsdb[level].iter()})
         for mt_id, hopcount, local in ((0, False, False), (None, True, False), (0, False, True)):
             roots = systems if not local else [inst.config.system_id]
