@@ -83,8 +83,8 @@ class Area:
     def from_vector(cls, a: dict) -> "Area":
         return cls(a["area_id"],
                    [RouterLsa(r["adv_rtr"], [RouterLink(k["type"], k["id"], k["data"], k["metric"]) for k in r["links"]],
-                              r.get("bits", [])) for r in a["routers"]],
-                   [NetworkLsa(n["lsa_id"], n["adv_rtr"], n["mask"], n["attached"]) for n in a["networks"]],
+                              r.get("bits", []), bool(r.get("maxage"))) for r in a["routers"]],
+                   [NetworkLsa(n["lsa_id"], n["adv_rtr"], n["mask"], n["attached"], bool(n.get("maxage"))) for n in a["networks"]],
                    [Interface(i["name"], i["type"], i["index"], [Neighbor(n["router_id"], n["src"]) for n in i["neighbors"]],
                               i.get("addrs", [])) for i in a["interfaces"]])
 

@@ -41,14 +41,15 @@ class Vertex:                   # holo-ospf/src/spf.rs:38-46
 class AreaDb:
     def __init__(self, area: dict):
         self.area = area
-        self.routers = {ip(l["adv_rtr"]): l for l in area["routers"]}
+        self.routers = {ip(l["adv_rtr"]): l for l in area["routers"] if not l.get("maxage")}   # is_maxage filter, :383
         # iter_by_type: LsaKey{type, adv_rtr, lsa_id} order (holo-ospf/src/packet/lsa.rs:44-56)
         self.networks = sorted(area["networks"], key=lambda l: (ip(l["adv_rtr"]), ip(l["lsa_id"])))
 
     def vertex_lsa_find(self, vid):                   # ospfv2/spf.rs:355-387
         kind, addr = vid
         if kind == NET:
-            return next((l for l in self.networks if ip(l["lsa_id"]) == addr), None)
+            l = next((l for l in self.networks if ip(l["lsa_id"]) == addr), None)     # find, THEN the MaxAge filter
+            return None if (l is None or l.get("maxage")) else l
         return self.routers.get(addr)
 
     def vertex_lsa_links(self, vid, lsa):             # ospfv2/spf.rs:389-460

@@ -12,7 +12,7 @@ from oracle import ospf_ref as RO
 from _oracle_engine import OracleEngine
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-OSPF = sorted(glob.glob(os.path.join(GOLD, "ospfv2", "*.json")))
+OSPF = sorted(glob.glob(os.path.join(GOLD, "ospfv2", "*.json"))) + sorted(glob.glob(os.path.join(GOLD, "ospfv2_steps", "*.json")))
 
 
 def check_ospf_vector(vec, engine):

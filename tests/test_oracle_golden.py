@@ -88,12 +88,12 @@ def test_graph_oracle_agrees_with_isis_ref(path):
 from holo_amd import ospf as HO          # noqa: E402
 from oracle import ospf_ref as RO        # noqa: E402
 
-OSPF = sorted(glob.glob(os.path.join(GOLD, "ospfv2", "*.json")))
+OSPF = sorted(glob.glob(os.path.join(GOLD, "ospfv2", "*.json"))) + sorted(glob.glob(os.path.join(GOLD, "ospfv2_steps", "*.json")))
 OSPF_IDS = [os.path.basename(p)[:-5] for p in OSPF]
 
 
 def test_ospf_golden_vectors_present():
-    assert len(OSPF) == 63
+    assert len(OSPF) == 63 + 11          # topologies + step tests whose last step re-ran SPF (incl. lsa-expiry1/2: MaxAge)
 
 
 def _intra(vec):

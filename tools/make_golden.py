@@ -253,8 +253,9 @@ if __name__ == "__main__":
     make_isis()
     make_isis_steps()
     try:
-        from make_golden_ospf import make_ospfv2, make_ospfv3   # noqa
+        from make_golden_ospf import make_ospfv2, make_ospfv2_steps, make_ospfv3   # noqa
         make_ospfv2()
+        make_ospfv2_steps()
         make_ospfv3()
     except ImportError:
         pass

@@ -73,11 +73,12 @@ def ospfv2_vector(rt_dir: str) -> dict:
                                       "metric": int(k["topologies"]["topology"][0]["metric"])})
                     bits = [_strip(b) for b in body["router"].get("router-bits", {}).get("rtr-lsa-bits", [])]
                     routers.append({"adv_rtr": hdr["adv-router"], "lsa_id": hdr["lsa-id"], "bits": bits,
-                                    "links": links})
+                                    "links": links, "maxage": "holo-ospf-dev:maxage" in hdr})
                 elif "network" in body:
                     networks.append({"lsa_id": hdr["lsa-id"], "adv_rtr": hdr["adv-router"],
                                      "mask": body["network"]["network-mask"],
-                                     "attached": body["network"]["attached-routers"]["attached-router"]})
+                                     "attached": body["network"]["attached-routers"]["attached-router"],
+                                     "maxage": "holo-ospf-dev:maxage" in hdr})
         ifaces = []
         for i in a.get("interfaces", {}).get("interface", []):
             ifaces.append({"name": i["name"], "type": iftype.get(i["name"], "broadcast"),
@@ -218,3 +219,43 @@ def make_ospfv3():
         json.dump(v, open(os.path.join(out, name), "w"), separators=(",", ":"), sort_keys=True)
         n += 1
     print(f"ospfv3: {n} vectors -> {out}")
+
+
+def make_ospfv2_steps():
+    """OSPFv2 step tests (holo-ospf/tests/conformance/ospfv2/<name>/): like the IS-IS ones, only the
+    steps after which the reference demonstrably re-ran SPF (route (re)installations on the ibus in
+    the same step as the last recorded state)."""
+    import re
+    import shutil
+    import tempfile
+    base = os.path.join(REF, "holo-ospf/tests/conformance/ospfv2")
+    src = open(os.path.join(base, "mod.rs")).read()
+    out = os.path.join(OUT, "ospfv2_steps")
+    os.makedirs(out, exist_ok=True)
+    n = 0
+    for name, topo, rt in re.findall(r'run_test::<Instance<Ospfv2>>\(\s*"([^"]+)",\s*"([^"]+)",\s*"([^"]+)"', src):
+        d = os.path.join(base, name)
+        states = sorted(glob.glob(os.path.join(d, "*-output-northbound-state.json")))
+        if not states:
+            continue
+        ibus = states[-1].replace("-output-northbound-state.json", "-output-ibus.jsonl")
+        if not os.path.exists(ibus) or "RouteIp" not in open(ibus).read():
+            continue
+        if glob.glob(os.path.join(d, "*-input-northbound-config-change.json")):
+            continue          # config edits (interface types, areas ...) are not replayed here
+        tmp = tempfile.mkdtemp()
+        try:
+            os.makedirs(os.path.join(tmp, "output"))
+            shutil.copy(os.path.join(base, "topologies", topo, rt, "config.json"), os.path.join(tmp, "config.json"))
+            shutil.copy(states[-1], os.path.join(tmp, "output", "northbound-state.json"))
+            try:
+                v = ospfv2_vector(tmp)
+            except Exception as e:      # noqa: BLE001
+                print("skip", name, repr(e)[:80])
+                continue
+        finally:
+            shutil.rmtree(tmp)
+        v["source"] = f"holo-ospf/tests/conformance/ospfv2/{name} (snapshot {topo}/{rt}, state {os.path.basename(states[-1])})"
+        json.dump(v, open(os.path.join(out, f"{name}.json"), "w"), separators=(",", ":"), sort_keys=True)
+        n += 1
+    print(f"ospfv2 step tests: {n} vectors -> {out}")
