@@ -299,18 +299,18 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
       // the reference's first discoverer (earliest popped tight parent).  k_fused relies on it;
       // k_dag / k_exact do not care.
       {
-        std::vector<uint32_t> perm;
+        // rows are short: a stable insertion sort in place on the three parallel arrays (no allocation)
         for (uint32_t t = 0; t < n; ++t) {
           const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
-          if (b - a < 2) continue;
-          perm.resize(b - a);
-          for (uint32_t i = 0; i < b - a; ++i) perm[i] = a + i;
-          std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return in_w[x] > in_w[y]; });
-          std::vector<uint32_t> s1(b - a), s2(b - a), s3(b - a);
-          for (uint32_t i = 0; i < b - a; ++i) { s1[i] = in_src[perm[i]]; s2[i] = in_w[perm[i]]; s3[i] = in_fpos[perm[i]]; }
-          std::copy(s1.begin(), s1.end(), in_src.begin() + a);
-          std::copy(s2.begin(), s2.end(), in_w.begin() + a);
-          std::copy(s3.begin(), s3.end(), in_fpos.begin() + a);
+          for (uint32_t i = a + 1; i < b; ++i) {
+            const uint32_t ks = in_src[i], kw = in_w[i], kf = in_fpos[i];
+            uint32_t j = i;
+            while (j > a && in_w[j - 1] < kw) {
+              in_src[j] = in_src[j - 1]; in_w[j] = in_w[j - 1]; in_fpos[j] = in_fpos[j - 1];
+              --j;
+            }
+            in_src[j] = ks; in_w[j] = kw; in_fpos[j] = kf;
+          }
         }
       }
       // static reasons for the general fused row routine
