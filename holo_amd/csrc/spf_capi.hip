@@ -412,6 +412,38 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if (!ctx || !g || !roots || !out || n_roots == 0 || !out->dist) return HSPF_E_INVAL;
   (void)hipSetDevice(ctx->device);
   const uint32_t n = g->n;
+  // Bound the scratch (state, stamps, staging) of one pass: the batch axis is processed in groups of
+  // at most ~2^26 (vertex, root) pairs (>= 1 batch of 64 roots), each group a complete run of its own,
+  // so that "every router as a root" on a large LSDB does not need state for all roots at once.
+  {
+    const uint64_t max_pairs = 1ull << 26;
+    uint32_t group = (uint32_t)std::max<uint64_t>(64, (max_pairs / std::max<uint32_t>(n, 1)) / 64 * 64);
+    if (n_roots > group) {
+      hspf_stats acc{};
+      if (out->first_hop_mask && out->n_mask_words == 0) return HSPF_E_INVAL;
+      for (uint32_t off = 0; off < n_roots; off += group) {
+        const uint32_t nr = std::min(group, n_roots - off);
+        hspf_result part = *out;
+        const size_t o = (size_t)off * n;
+        part.dist = out->dist + o;
+        if (out->hops) part.hops = out->hops + o;
+        if (out->vflags_out) part.vflags_out = out->vflags_out + o;
+        if (out->first_hop_mask) part.first_hop_mask = out->first_hop_mask + o * out->n_mask_words;
+        if (out->pop_rank) part.pop_rank = out->pop_rank + o;
+        const int rc = run_impl(ctx, g, roots + off, nr, run_flags, &part, host_out);
+        if (rc) return rc;
+        const hspf_stats &p = ctx->stats;
+        acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
+        acc.n_dag_launches += p.n_dag_launches; acc.n_exact_roots += p.n_exact_roots;
+        acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
+        acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
+        acc.ms_d2h += p.ms_d2h; acc.state_bytes = std::max(acc.state_bytes, p.state_bytes);
+        acc.narrow_overflow += p.narrow_overflow;
+      }
+      ctx->stats = acc;
+      return HSPF_OK;
+    }
+  }
   for (uint32_t r = 0; r < n_roots; ++r)
     if (roots[r] != HSPF_NO_ROOT && roots[r] >= n) { ctx->last_error = "root out of range"; return HSPF_E_INVAL; }
   if ((run_flags & HSPF_RUN_POP_RANK) && !out->pop_rank) { ctx->last_error = "HSPF_RUN_POP_RANK without pop_rank buffer"; return HSPF_E_INVAL; }

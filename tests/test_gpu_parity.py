@@ -301,3 +301,17 @@ def test_config_multi_area_10k_roots(spf_ctx):
         _properties(g, roots, res, [0, 333, 999], run_flags=go.RUN_NET_NEXTHOPS)
         total += len(roots)
     assert total == 3000
+
+
+def test_root_groups_bound_the_scratch(spf_ctx):
+    """More (vertex, root) pairs than one pass may hold (2^26): the batch axis is split into groups;
+    the caller sees one result.  80 000 x 1 100 roots = 88 M pairs -> 2 groups."""
+    n = 80000
+    links = synth._grid8_links(200, 400)
+    g = synth._routers_only(n, links, 12345, 1, 9, synth.MAX_PATH_METRIC_WIDE, "grid-80k", {})
+    roots = (np.arange(1100, dtype=np.uint32) * 71) % n
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    res = spf_ctx.run(G, roots, 0, want_mask=True)
+    G.free()
+    assert res.stats["n_roots"] == 1100 and res.stats["n_batches"] == 18
+    _properties(g, roots, res, [0, 831, 832, 1099])
