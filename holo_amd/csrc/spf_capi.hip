@@ -33,6 +33,7 @@ struct hspf_graph {
   uint32_t max_path_metric = 0;
   uint32_t wmax = 0;                 // largest cost among the kept links
   mutable bool narrow_bad = false;   // a run overflowed the 4-byte fused state: use the 8-byte one
+  bool hopcount_like = false;        // every kept link into a network costs 0 (from a router), into a router 1
   // host copies (slot tables, validation)
   std::vector<uint32_t> row_ptr, col;
   std::vector<uint8_t> twoway;     // per original link
@@ -135,9 +136,9 @@ uint32_t round_words(uint32_t w) {   // template instantiations of k_dag / k_emi
 template <int W, bool GS = false>
 void launch_dag(dim3 grid, hipStream_t s, GraphDev g, const uint32_t *dist, uint32_t *hv, uint64_t *mask,
                 const uint32_t *roots, SlotTabs tabs, uint32_t nn, uint32_t io, int *changed, int sweep,
-                uint32_t epoch, uint32_t *lf) {
+                uint32_t epoch, uint32_t *lf, uint32_t hc) {
   hipLaunchKernelGGL((k_dag<W, GS>), grid, dim3(256), 0, s, g, dist, hv, mask, roots, tabs, nn, io, changed,
-                     sweep, epoch, lf);
+                     sweep, epoch, lf, hc);
 }
 template <int W>
 void launch_emit(dim3 grid, hipStream_t s, uint32_t n, uint32_t nr, const uint32_t *dist, const uint32_t *hv,
@@ -313,6 +314,21 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
           }
         }
       }
+      // hop-count-like (MetricMode::HopCount graphs): lets the fused path resolve the router -> network
+      // zero-cost plateaus itself instead of sending every root to the sequential kernel
+      {
+        bool hc = false, ok = true;
+        for (uint32_t t = 0; t < n && ok; ++t) {
+          const bool net = csr->vflags[t] & HSPF_VF_NETWORK;
+          for (uint32_t i = in_ptr[t]; i < in_ptr[t + 1] && ok; ++i) {
+            const uint32_t u = in_src[i] & SRC_MASK;
+            const bool unet = csr->vflags[u] & HSPF_VF_NETWORK;
+            if (net) { ok = in_w[i] == 0 && !unet && u > t; hc = true; }
+            else ok = in_w[i] == 1;
+          }
+        }
+        g->hopcount_like = ok && hc;
+      }
       // static reasons for the general fused row routine
       std::vector<uint8_t> rowflags(n, 0);
       for (uint32_t t = 0; t < n; ++t) {
@@ -487,7 +503,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // otherwise distances first, then the SPT-DAG phase with W mask words.
   // HSPF_VARIANT bit0 forces the two-phase path, bit1 forbids the narrow state (A/B measurements).
   const bool fused = max_slots <= 16 && n < (1u << 23) && !(ctx->variant & 1u);
-  FusedParams fp_wide{0u, 16u, 0xFFFFu, 0xFFFFFFFFu, g->max_path_metric, 0xFFFFFFFFu};
+  FusedParams fp_wide{0u, 16u, 0xFFFFu, 0xFFFFFFFFu, g->max_path_metric, 0xFFFFFFFFu, g->hopcount_like ? 1u : 0u};
   FusedParams fp_narrow = fp_wide;
   bool narrow = false;
   if (fused && !g->narrow_bad && !(ctx->variant & 2u)) {
@@ -502,7 +518,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       narrow = true;
       fp_narrow = FusedParams{sh, M, (1u << H) - 1u, dmax << sh,
                               g->max_path_metric >= dmax ? 0xFFFFFFFFu : (g->max_path_metric << sh),
-                              (dmax - g->wmax) << sh};
+                              (dmax - g->wmax) << sh, g->hopcount_like ? 1u : 0u};
     }
   }
   // ---- scratch
@@ -686,11 +702,11 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       epoch = 2;
     }
     switch (W) {
-      case 1: launch_dag<1, true>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
-      case 2: launch_dag<2>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
-      case 4: launch_dag<4>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
-      case 8: launch_dag<8>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
-      default: launch_dag<16>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf); break;
+      case 1: launch_dag<1, true>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u); break;
+      case 2: launch_dag<2>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u); break;
+      case 4: launch_dag<4>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u); break;
+      case 8: launch_dag<8>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u); break;
+      default: launch_dag<16>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u); break;
     }
     ++epoch;
   }, n_dag);

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
                                              const uint32_t *__restrict__ roots, SlotTabs tabs,
                                              uint32_t net_nexthops, uint32_t ignore_ovl,
                                              int *changed, int sweep, uint32_t epoch,
-                                             uint32_t *lane_flags) {
+                                             uint32_t *lane_flags, uint32_t hc) {
   if (sweep > 0 && changed[sweep - 1] == 0) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
     if (__ballot(need) != 0ull) {
       const bool v_router = !(g.vflags[v] & 1u);
       bool pending = false, anyp = false;
+      bool zdone = false;                 // hop-count-like graphs: the one zero-cost parent has been met
       uint32_t bk_d = INF, p0h = 0;
       const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
       for (uint32_t eb = e0; eb < e1; eb += 64) {
@@ -271,8 +272,12 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
         const bool has_nt = !ignore_ovl && __ballot((sv & SRC_NO_TRANSIT) != 0) != 0ull;
         if (!has_nt) sv &= SRC_MASK;
         // A zero-cost link from a HIGHER-numbered source is never a static-order parent; padding
-        // lanes likewise: rewrite both as (own row, cost 1), which can never be tight.
-        if (lane >= cnt || (wv == 0u && (sv & SRC_MASK) >= v)) { sv = v; wv = 1u; }
+        // lanes likewise: rewrite both as (own row, cost 1), which can never be tight.  Exception:
+        // hop-count-like graphs (see fused_row_any): there the FIRST tight one of them, in row order
+        // = lowest source, is the vertex' only parent.
+        const uint32_t zvec = (lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
+        const bool has_zl = hc != 0u && __ballot(zvec != 0u) != 0ull;
+        if (lane >= cnt || (zvec && !hc)) { sv = v; wv = 1u; }
 #pragma unroll
         for (int gi = 0; gi < NGRP; ++gi) {
           if (cnt <= (uint32_t)(gi * GRP)) break;
@@ -294,6 +299,10 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
             }
             // tight parent (d + w == dv without saturation; dv != INF for `need` lanes)
             tight[k] = need && d != INF && add_sat(d, w) == dv;
+            if (has_zl && rdlane(zvec, gi * GRP + k) != 0u) {    // uniform, hop-count-like graphs only
+              tight[k] = tight[k] && !zdone;
+              zdone = zdone || tight[k];
+            }
             anyt = anyt || tight[k];
           }
           if (__ballot(anyt) == 0ull) continue;
@@ -405,6 +414,7 @@ struct FusedParams {
   uint32_t inf_t;     // dkey >= inf_t  <=> not reached
   uint32_t maxkey;    // dkey >  maxkey <=> beyond max_path_metric
   uint32_t ovf_t;     // narrow: dkey >= ovf_t (and reached) -> a later sum could leave the field
+  uint32_t hc;        // 1: hop-count-like graph (every link into a network costs 0, into a router 1)
 };
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -594,6 +604,7 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
   const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
   RowAcc a{INF, 0u, INF, 0u, false};
   uint32_t bd_all = INF;
+  uint32_t zb = INF, zm = 0u, zh = 0u;      // hop-count-like graphs: best zero-cost link from a higher-numbered source
   for (uint32_t eb = e0; eb < e1; eb += 64) {
     const uint32_t cnt = min(64u, e1 - eb);
     uint32_t sv = sv0, wv = wv0;
@@ -617,8 +628,9 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
       if (has_nt && (sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;   // overloaded source
       const uint32_t c = add_sat(d, w);
       if (MAXINF && sizeof(ST) == 8 && c == INF && d != INF && w != INF) a.sat = true;
-      if (has_z && rdlane(zv, j)) { bd_all = min(bd_all, c); continue; }
-      const bool lt = c < a.bd, eq = c == a.bd;
+      const bool zlink = has_z && rdlane(zv, j) != 0u;            // uniform
+      if (zlink && !P.hc) { bd_all = min(bd_all, c); continue; }
+      const bool lt = zlink ? (c < zb) : (c < a.bd), eq = !zlink && c == a.bd;
       const uint32_t hh = pay >> P.mbits;
       uint32_t contrib = pay & ((1u << P.mbits) - 1u);
       const bool direct = (lt || eq) && hh == 0u && c < P.inf_t;  // parent: root or hops-0 network
@@ -631,6 +643,15 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
           contrib = ((v_router || net_nexthops) && sidx < P.mbits) ? (1u << sidx) : 0u;
         }
       }
+      if (zlink) {
+        // Hop-count-like graph (holo-isis MetricMode::HopCount, spf.rs:1138-1145): a network whose
+        // only way in is a zero-cost link from routers of the same distance is put on the candidate
+        // list by the FIRST of them to be popped — the lowest-numbered one, rows list equal-cost links
+        // by ascending source — and, its own index being lower than any router's, is popped next:
+        // the later routers find it on the SPT already (spf.rs:630-632).  One parent, no union.
+        if (lt) { zb = c; zm = contrib; zh = hh; }
+        continue;
+      }
       const uint32_t m_or = a.bm | contrib;
       a.bm = lt ? contrib : (eq ? m_or : a.bm);
       const bool newp = lt || (eq && d < a.bpd);
@@ -638,6 +659,12 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
       a.bh = newp ? hh : a.bh;
       a.bd = min(a.bd, c);
     }
+  }
+  if (P.hc) {                               // late vertex: strictly better through the zero-cost links
+    const bool late = zb < a.bd;
+    a.bm = late ? zm : a.bm;
+    a.bh = late ? zh : a.bh;
+    a.bd = late ? zb : a.bd;
   }
   return finish_row<ST>(a, v, my_root, v_router, bd_all, P);
 }

@@ -523,9 +523,25 @@ def compute_spts(level: int, root_system_ids: Sequence[bytes], local: bool, mt_i
         in_spt = (res.flags[j] & E.RF_IN_SPT) != 0
         if j in pop_rank:
             pr = pop_rank[j]
-            rank_key = lambda v, pr=pr: (int(pr[v]), 0)                 # noqa: E731
+            rank_key = lambda v, pr=pr: (int(pr[v]), 0, 0, 0)           # noqa: E731
+        elif g.hopcount:
+            # Hop-count graphs (spf.rs:1138-1145): links into pseudonodes cost 0, so a pseudonode is
+            # put on the candidate list by the lowest-numbered router of its own distance that lists
+            # it and, sorting before every router, is popped right after that router.
+            def rank_key(v, dist=dist, in_spt=in_spt, g=g, cache={}):   # noqa: B006
+                k = cache.get(v)
+                if k is None:
+                    k = (int(dist[v]), v, 0, 0)
+                    if g.vflags[v] & VF_NETWORK:
+                        acts = [int(u) for u in g.col[g.row_ptr[v]:g.row_ptr[v + 1]]
+                                if in_spt[u] and dist[u] == dist[v] and not (g.vflags[u] & VF_NO_EXPAND)
+                                and g.links_back(int(u), v)]
+                        if acts:
+                            k = (int(dist[v]), min(acts), 1, v)
+                    cache[v] = k
+                return k
         else:
-            rank_key = lambda v, dist=dist: (int(dist[v]), v)           # noqa: E731  static order
+            rank_key = lambda v, dist=dist: (int(dist[v]), v, 0, 0)     # noqa: E731  static order
         slot_nh = _slot_nexthops(g, G, r, dist, hops, in_spt, rank_key, local, level, instance)
         s = Spt()
         members = np.nonzero(in_spt)[0]

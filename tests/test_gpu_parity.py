@@ -315,3 +315,33 @@ def test_root_groups_bound_the_scratch(spf_ctx):
     G.free()
     assert res.stats["n_roots"] == 1100 and res.stats["n_batches"] == 18
     _properties(g, roots, res, [0, 831, 832, 1099])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hopcount_lan_graphs_stay_on_the_parallel_path(spf_ctx, seed):
+    """MetricMode::HopCount on an LSDB with LAN pseudonodes (flooding::manet::init_cache,
+    holo-isis/src/flooding/manet.rs:47-69): links into pseudonodes cost 0 and come from
+    higher-numbered routers, i.e. the reference's pop order is NOT the static one — the fused kernel
+    resolves that plateau shape itself (one parent: the lowest-numbered router of the same distance),
+    no root may fall back to the sequential kernel."""
+    g = synth.random_lsdb(300, 40, 2.5, 700 + seed, hopcount=True, p_overload=0.0, p_noexpand=0.02)
+    roots = np.arange(40, 40 + 70, dtype=np.uint32)
+    check(spf_ctx, g, roots, E.RUN_IGNORE_OVERLOAD, expect_exact=False)            # > 16 slots: two-phase path
+    few = [int(r) for r in roots if G_slots(g, int(r)) <= 16][:40]
+    if few:
+        res, _ = check(spf_ctx, g, few, E.RUN_IGNORE_OVERLOAD, expect_exact=False)  # fused path
+        assert res.stats["state_bytes"] in (4, 8)
+
+
+def G_slots(g, root):
+    """first-hop slots of a root (include/holo_spf_hip.h): its links + the links of the network vertices
+    reachable from it through networks only."""
+    tot, seen, q = int(g.row_ptr[root + 1] - g.row_ptr[root]), {root}, [root]
+    while q:
+        p = q.pop()
+        for k in range(int(g.row_ptr[p]), int(g.row_ptr[p + 1])):
+            t = int(g.col[k])
+            back = (g.col[g.row_ptr[t]:g.row_ptr[t + 1]] == p).any()
+            if t not in seen and (g.vflags[t] & 1) and back:
+                seen.add(t); q.append(t); tot += int(g.row_ptr[t + 1] - g.row_ptr[t])
+    return tot
