@@ -1,0 +1,112 @@
+// holo_spf_hip.hpp — C++17 RAII convenience layer over the C ABI of include/holo_spf_hip.h.
+//
+// Header only, no dependency beyond the C header and the HIP runtime the caller already links for its
+// device buffers.  It is the compiled-language twin of the safe Rust wrapper sketched in
+// INTEGRATION.md §3 (Engine: Send, not Sync; Graph freed on drop; errors as codes, never exceptions
+// across the boundary — this layer turns a non-zero code into hspf::Error for C++ callers).
+#ifndef HOLO_SPF_HIP_HPP
+#define HOLO_SPF_HIP_HPP
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "holo_spf_hip.h"
+
+namespace hspf {
+
+struct Error : std::runtime_error {
+  int code;
+  Error(int c, const std::string &what) : std::runtime_error(what + ": " + hspf_strerror(c)), code(c) {}
+};
+
+struct Tables {                       // row-major [root][vertex] host results of one run
+  uint32_t n_roots = 0, n_vertices = 0, mask_words = 1;
+  std::vector<uint32_t> dist, pop_rank;
+  std::vector<uint16_t> hops, flags;
+  std::vector<uint64_t> mask;
+  hspf_stats stats{};
+};
+
+class Engine;
+
+class Graph {
+ public:
+  Graph(Graph &&o) noexcept : ctx_(o.ctx_), g_(o.g_) { o.g_ = nullptr; }
+  Graph(const Graph &) = delete;
+  Graph &operator=(const Graph &) = delete;
+  ~Graph() { if (g_) hspf_graph_free(ctx_, g_); }
+  uint32_t n_vertices() const { return hspf_graph_n_vertices(g_); }
+  uint32_t n_links_kept() const { return hspf_graph_n_edges_kept(g_); }
+  hspf_graph *raw() const { return g_; }
+
+ private:
+  friend class Engine;
+  Graph(hspf_ctx *c, hspf_graph *g) : ctx_(c), g_(g) {}
+  hspf_ctx *ctx_;
+  hspf_graph *g_;
+};
+
+class Engine {
+ public:
+  explicit Engine(int device = 0) {
+    const int rc = hspf_init(device, &ctx_);
+    if (rc != HSPF_OK) throw Error(rc, "hspf_init");
+  }
+  Engine(const Engine &) = delete;
+  Engine &operator=(const Engine &) = delete;
+  ~Engine() { if (ctx_) hspf_shutdown(ctx_); }
+  hspf_ctx *raw() const { return ctx_; }
+
+  Graph upload(const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col,
+               const std::vector<uint32_t> &metric, const std::vector<uint8_t> &vflags, uint32_t max_path_metric) {
+    hspf_csr csr{(uint32_t)vflags.size(), (uint32_t)col.size(), row_ptr.data(), col.data(), metric.data(), vflags.data(),
+                 max_path_metric};
+    hspf_graph *g = nullptr;
+    const int rc = hspf_graph_upload(ctx_, &csr, &g);
+    if (rc != HSPF_OK) throw Error(rc, std::string("hspf_graph_upload (") + hspf_last_error(ctx_) + ")");
+    return Graph(ctx_, g);
+  }
+
+  uint32_t mask_words(const Graph &g, const std::vector<uint32_t> &roots) {
+    uint32_t w = 1;
+    const int rc = hspf_mask_words(ctx_, g.raw(), roots.data(), (uint32_t)roots.size(), &w);
+    if (rc != HSPF_OK) throw Error(rc, "hspf_mask_words");
+    return w;
+  }
+
+  // (H vertices, slot bases, total slots) of one root — see the header comment of hspf_result.
+  std::pair<std::vector<uint32_t>, std::vector<uint32_t>> slot_table(const Graph &g, uint32_t root, uint32_t *total = nullptr) {
+    uint32_t tot = 0;
+    const int cnt = hspf_slot_table(ctx_, g.raw(), root, nullptr, nullptr, 0, &tot);
+    if (cnt < 0) throw Error(cnt, "hspf_slot_table");
+    std::vector<uint32_t> hv(cnt), hb(cnt);
+    hspf_slot_table(ctx_, g.raw(), root, hv.data(), hb.data(), (uint32_t)cnt, &tot);
+    if (total) *total = tot;
+    return {hv, hb};
+  }
+
+  Tables run(const Graph &g, const std::vector<uint32_t> &roots, uint32_t run_flags = 0) {
+    Tables t;
+    t.n_roots = (uint32_t)roots.size();
+    t.n_vertices = g.n_vertices();
+    t.mask_words = mask_words(g, roots);
+    const size_t rn = (size_t)t.n_roots * t.n_vertices;
+    t.dist.resize(rn); t.hops.resize(rn); t.flags.resize(rn); t.mask.resize(rn * t.mask_words);
+    if (run_flags & HSPF_RUN_POP_RANK) t.pop_rank.resize(rn);
+    hspf_result out{t.dist.data(), t.hops.data(), t.flags.data(), t.mask.data(), t.mask_words,
+                    t.pop_rank.empty() ? nullptr : t.pop_rank.data()};
+    const int rc = hspf_run(ctx_, g.raw(), roots.data(), t.n_roots, run_flags, &out);
+    if (rc != HSPF_OK) throw Error(rc, std::string("hspf_run (") + hspf_last_error(ctx_) + ")");
+    hspf_get_stats(ctx_, &t.stats);
+    return t;
+  }
+
+ private:
+  hspf_ctx *ctx_ = nullptr;
+};
+
+}  // namespace hspf
+#endif

@@ -1,0 +1,153 @@
+// tests/cpp/capi_parity.cpp — the C ABI driven from compiled code (no Python, no torch): seeded random
+// LSDB-shaped graphs through include/holo_spf_hip.hpp, compared bit for bit with the CPU oracle
+// (oracle/liboracle_spf.so, loaded with dlopen: TEST INFRASTRUCTURE, see oracle/spf_oracle.cpp), plus the
+// error-code contract and the device-resident path (hspf_run_device + hspf_routes_device on hipMalloc'ed
+// buffers).  Exit codes: 0 all checks passed, 77 no HIP device (the CPU-only build container), 1 mismatch.
+//
+// Build (done by __graft_entry__.build()):
+//   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude tests/cpp/capi_parity.cpp -Lholo_amd -lholo_spf_hip
+//         -Wl,-rpath,$ORIGIN/../../holo_amd -ldl -o tests/cpp/capi_parity
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "holo_spf_hip.hpp"
+
+using u32 = uint32_t;
+typedef int (*oracle_run_t)(u32, u32, const u32 *, const u32 *, const u32 *, const uint8_t *, u32, const u32 *, u32, u32, int,
+                            u32 *, uint16_t *, uint16_t *, u32 *, uint64_t *, u32, u32 *, u32 *, uint64_t *);
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static u32 rnd(u32 m) { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (u32)((rng_state >> 11) % m); }
+
+struct Lsdb { std::vector<u32> row_ptr, col, metric; std::vector<uint8_t> vflags; u32 n; };
+
+// networks [0, n_net) then routers: router-router p2p links (some one-way, some parallel), LANs with
+// zero-cost network->router links, overloaded and non-expandable vertices.
+static Lsdb make(u32 n_rtr, u32 n_net, u32 seed) {
+  rng_state = 0x9E3779B97F4A7C15ull ^ (seed * 0x100000001B3ull);
+  const u32 n = n_rtr + n_net;
+  std::vector<std::vector<std::pair<u32, u32>>> rows(n);
+  for (u32 i = 0; i < n_rtr * 3 / 2; ++i) {
+    const u32 u = n_net + rnd(n_rtr), v = n_net + rnd(n_rtr);
+    if (u == v) continue;
+    rows[u].push_back({v, 1 + rnd(6)});
+    if (rnd(100) >= 3) rows[v].push_back({u, 1 + rnd(6)});
+    if (rnd(100) < 5) { rows[u].push_back({v, 1 + rnd(6)}); rows[v].push_back({u, 1 + rnd(6)}); }
+  }
+  for (u32 net = 0; net < n_net; ++net)
+    for (u32 k = 0; k < 4; ++k) {
+      const u32 r = n_net + rnd(n_rtr);
+      rows[r].push_back({net, 1 + rnd(6)});
+      rows[net].push_back({r, 0});
+    }
+  Lsdb g; g.n = n; g.row_ptr.assign(n + 1, 0); g.vflags.assign(n, 0);
+  for (u32 u = 0; u < n; ++u) {
+    for (auto &e : rows[u]) { g.col.push_back(e.first); g.metric.push_back(e.second); }
+    g.row_ptr[u + 1] = (u32)g.col.size();
+    if (u < n_net) g.vflags[u] |= HSPF_VF_NETWORK;
+    else if (rnd(100) < 3) g.vflags[u] |= HSPF_VF_NO_TRANSIT;
+    if (rnd(100) < 2) g.vflags[u] |= HSPF_VF_NO_EXPAND;
+  }
+  return g;
+}
+
+#define CHECK(c, msg) do { if (!(c)) { std::fprintf(stderr, "FAIL %s:%d %s\n", __FILE__, __LINE__, msg); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+  if (hspf_device_count() <= 0) {
+    hspf_ctx *c = nullptr;
+    const int rc = hspf_init(0, &c);
+    std::printf("no HIP device: hspf_init -> %d (%s)\n", rc, hspf_strerror(rc));
+    return (rc == HSPF_E_NODEV && c == nullptr) ? 77 : 1;
+  }
+  const std::string here = argc > 1 ? argv[1] : ".";
+  void *so = dlopen((here + "/oracle/liboracle_spf.so").c_str(), RTLD_NOW);
+  CHECK(so, "dlopen oracle/liboracle_spf.so (run `make -C oracle`)");
+  auto oracle = (oracle_run_t)dlsym(so, "oracle_spf_run");
+  CHECK(oracle, "oracle_spf_run");
+
+  hspf::Engine eng(0);
+  int checked = 0;
+  for (u32 seed = 0; seed < 6; ++seed)
+    for (u32 flags : {0u, (u32)HSPF_RUN_NET_NEXTHOPS, (u32)HSPF_RUN_IGNORE_OVERLOAD}) {
+      Lsdb g = make(120 + 37 * seed, 10 + seed, seed);
+      hspf::Graph G = eng.upload(g.row_ptr, g.col, g.metric, g.vflags, 0xFE000000u);
+      std::vector<u32> roots;
+      for (u32 r = 10 + seed; r < 10 + seed + 90 && r < g.n; ++r) roots.push_back(r);
+      roots[3] = HSPF_NO_ROOT;                                   // padding entry: empty SPT
+      hspf::Tables t = eng.run(G, roots, flags);
+      const size_t rn = (size_t)roots.size() * g.n;
+      std::vector<u32> d(rn), pr(rn), nn(rn), np(rn); std::vector<uint16_t> h(rn), f(rn); std::vector<uint64_t> m(rn * t.mask_words), wk(roots.size());
+      const int rc = oracle(g.n, (u32)g.col.size(), g.row_ptr.data(), g.col.data(), g.metric.data(), g.vflags.data(), 0xFE000000u,
+                            roots.data(), (u32)roots.size(), flags, /*variant MAP*/ 1, d.data(), h.data(), f.data(), pr.data(), m.data(),
+                            t.mask_words, nn.data(), np.data(), wk.data());
+      CHECK(rc == 0, "oracle failed");
+      CHECK(d == t.dist, "dist");
+      CHECK(h == t.hops, "hops");
+      for (size_t i = 0; i < rn; ++i) CHECK((t.flags[i] & 1) == f[i], "in-SPT flag");
+      CHECK(m == t.mask, "first-hop mask");
+      ++checked;
+    }
+
+  // error contract: codes, not crashes
+  {
+    Lsdb g = make(50, 4, 99);
+    hspf::Graph G = eng.upload(g.row_ptr, g.col, g.metric, g.vflags, 0xFE000000u);
+    u32 bad = g.n + 7, dist = 0;
+    hspf_result out{&dist, nullptr, nullptr, nullptr, 1, nullptr};
+    CHECK(hspf_run(eng.raw(), G.raw(), &bad, 1, 0, &out) == HSPF_E_INVAL, "root out of range must be HSPF_E_INVAL");
+    CHECK(hspf_run(eng.raw(), G.raw(), nullptr, 1, 0, &out) == HSPF_E_INVAL, "NULL roots");
+    std::vector<u32> col2 = g.col; col2[0] = g.n + 1;
+    hspf_csr csr{g.n, (u32)col2.size(), g.row_ptr.data(), col2.data(), g.metric.data(), g.vflags.data(), 0xFE000000u};
+    hspf_graph *gg = nullptr;
+    CHECK(hspf_graph_upload(eng.raw(), &csr, &gg) == HSPF_E_INVAL && gg == nullptr, "col out of range");
+  }
+
+  // device-resident path: hspf_run_device + hspf_routes_device on plain hipMalloc buffers
+  {
+    Lsdb g = make(200, 12, 5);
+    hspf::Graph G = eng.upload(g.row_ptr, g.col, g.metric, g.vflags, 0xFE000000u);
+    std::vector<u32> roots; for (u32 r = 12; r < 12 + 70; ++r) roots.push_back(r);
+    const u32 W = eng.mask_words(G, roots), R = (u32)roots.size(), n = g.n;
+    hspf::Tables t = eng.run(G, roots, 0);
+    u32 *dd; uint16_t *dh, *df; uint64_t *dm;
+    hipMalloc(&dd, (size_t)R * n * 4); hipMalloc(&dh, (size_t)R * n * 2); hipMalloc(&df, (size_t)R * n * 2); hipMalloc(&dm, (size_t)R * n * 8 * W);
+    hspf_result od{dd, dh, df, dm, W, nullptr};
+    CHECK(hspf_run_device(eng.raw(), G.raw(), roots.data(), R, 0, &od) == HSPF_OK, "hspf_run_device");
+    // prefix table: prefix p advertised by vertices p and (7p+3) mod n with metrics 1 and 2
+    const u32 P = n;
+    std::vector<u32> pptr(P + 1), pv, pm;
+    for (u32 p = 0; p < P; ++p) { u32 a = p, b = (7 * p + 3) % n; if (a > b) std::swap(a, b); pv.push_back(a); pm.push_back(a == p ? 1 : 2); if (b != a) { pv.push_back(b); pm.push_back(b == p ? 1 : 2); } pptr[p + 1] = (u32)pv.size(); }
+    u32 *bm, *be; uint64_t *nm;
+    hipMalloc(&bm, (size_t)R * P * 4); hipMalloc(&be, (size_t)R * P * 4); hipMalloc(&nm, (size_t)R * P * 8 * W);
+    hspf_prefix_table tab{P, (u32)pv.size(), pptr.data(), pv.data(), pm.data()};
+    hspf_routes ro{bm, be, nm};
+    CHECK(hspf_routes_device(eng.raw(), n, R, W, dd, df, dm, &tab, &ro) == HSPF_OK, "hspf_routes_device");
+    std::vector<u32> hbm((size_t)R * P), hbe((size_t)R * P); std::vector<uint64_t> hnm((size_t)R * P * W);
+    hipMemcpy(hbm.data(), bm, hbm.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(hbe.data(), be, hbe.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(hnm.data(), nm, hnm.size() * 8, hipMemcpyDeviceToHost);
+    for (u32 r = 0; r < R; ++r)
+      for (u32 p = 0; p < P; ++p) {
+        u32 best = 0xFFFFFFFFu, ent = 0xFFFFFFFFu; std::vector<uint64_t> acc(W, 0);
+        for (u32 e = pptr[p]; e < pptr[p + 1]; ++e) {
+          const size_t i = (size_t)r * n + pv[e];
+          if (!(t.flags[i] & 1)) continue;
+          const u32 mm = t.dist[i] + pm[e];
+          if (mm < best) { best = mm; ent = e; for (u32 w = 0; w < W; ++w) acc[w] = t.mask[i * W + w]; }
+          else if (mm == best) for (u32 w = 0; w < W; ++w) acc[w] |= t.mask[i * W + w];
+        }
+        const size_t o = (size_t)r * P + p;
+        CHECK(hbm[o] == best && hbe[o] == ent, "route metric / entry");
+        for (u32 w = 0; w < W; ++w) CHECK(hnm[o * W + w] == acc[w], "route next-hop mask");
+      }
+    hipFree(dd); hipFree(dh); hipFree(df); hipFree(dm); hipFree(bm); hipFree(be); hipFree(nm);
+  }
+  std::printf("capi_parity: %d graph runs bit-exact, error contract ok, device route derivation ok\n", checked);
+  return 0;
+}
