@@ -10,6 +10,7 @@
 #include "spf_kernels.hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -238,6 +239,14 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
   }
   (void)hipSetDevice(ctx->device);
 
+  const bool tdbg = getenv("HSPF_UPLOAD_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!tdbg) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[hspf upload] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   hspf_graph *g = new (std::nothrow) hspf_graph();
   if (!g) return HSPF_E_NOMEM;
   g->n = n; g->e = e; g->max_path_metric = csr->max_path_metric;
@@ -254,6 +263,7 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
       // For each t, mark[col[k']] = t for k' in row t; then u->t two-way iff mark'[u]==t.  We
       // need the reverse view: iterate rows t, stamp their targets; link (u->t) asks "does row t
       // contain u".  Process links grouped by target using a counting sort of link ids by target.
+      lap("host copies");
       std::vector<uint32_t> cnt(n + 1, 0);
       for (uint32_t k = 0; k < e; ++k) cnt[csr->col[k] + 1]++;
       for (uint32_t i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
@@ -269,6 +279,7 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
         for (uint32_t k2 = csr->row_ptr[t]; k2 < csr->row_ptr[t + 1]; ++k2) stamp[csr->col[k2]] = t;
         for (uint32_t i = cnt[t]; i < cnt[t + 1]; ++i) { const uint32_t k = by_t[i]; g->twoway[k] = stamp[src_of[k]] == t; }
       }
+      lap("two-way check");
       // Kept links: two-way AND the source can ever be expanded.  Transposed (in-link) CSR by a
       // counting sort that keeps source order -> deterministic layout.
       std::vector<uint32_t> in_ptr(n + 1, 0), out_ptr(n + 1, 0);
@@ -279,41 +290,43 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
       }
       for (uint32_t i = 0; i < n; ++i) { in_ptr[i + 1] += in_ptr[i]; out_ptr[i + 1] += out_ptr[i]; }
       g->e_kept = kept;
-      std::vector<uint32_t> in_src(kept), in_w(kept), in_fpos(kept), out_dst(kept), out_w(kept), out_fpos(kept);
+      // Transpose into an array of (cost, source, position) records — one scattered write per link —
+      // sort each in-row in place, then split into the structure-of-arrays the kernels read.
+      struct InRec { uint32_t w, src, fpos; };
+      std::vector<InRec> rec(kept);
+      std::vector<uint32_t> out_dst(kept), out_w(kept), out_fpos(kept);
       std::vector<uint32_t> cur(in_ptr.begin(), in_ptr.end() - 1);
       uint32_t oi = 0;
       for (uint32_t u = 0; u < n; ++u) {
         const bool nt = csr->vflags[u] & HSPF_VF_NO_TRANSIT;
         const bool ne = csr->vflags[u] & HSPF_VF_NO_EXPAND;
-        for (uint32_t k = csr->row_ptr[u]; k < csr->row_ptr[u + 1]; ++k) {
+        const uint32_t r0 = csr->row_ptr[u];
+        for (uint32_t k = r0; k < csr->row_ptr[u + 1]; ++k) {
           if (!g->twoway[k] || ne) continue;
-          const uint32_t t = csr->col[k], i = cur[t]++;
-          in_src[i] = u | (nt ? SRC_NO_TRANSIT : 0u);
-          in_w[i] = csr->metric[k];
-          g->wmax = std::max(g->wmax, csr->metric[k]);
-          in_fpos[i] = k - csr->row_ptr[u];
-          out_dst[oi] = t; out_w[oi] = csr->metric[k]; out_fpos[oi] = k - csr->row_ptr[u]; ++oi;
+          const uint32_t t = csr->col[k], w = csr->metric[k];
+          rec[cur[t]++] = InRec{w, u | (nt ? SRC_NO_TRANSIT : 0u), k - r0};
+          g->wmax = std::max(g->wmax, w);
+          out_dst[oi] = t; out_w[oi] = w; out_fpos[oi] = k - r0; ++oi;
         }
       }
+      lap("transpose");
       // In-links of a row by (cost descending, source ascending): among tight links, i.e. equal
       // dist[u] + cost, the first in row order has the smallest dist[u] and then the smallest u =
       // the reference's first discoverer (earliest popped tight parent).  k_fused relies on it;
-      // k_dag / k_exact do not care.
-      {
-        // rows are short: a stable insertion sort in place on the three parallel arrays (no allocation)
-        for (uint32_t t = 0; t < n; ++t) {
-          const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
-          for (uint32_t i = a + 1; i < b; ++i) {
-            const uint32_t ks = in_src[i], kw = in_w[i], kf = in_fpos[i];
-            uint32_t j = i;
-            while (j > a && in_w[j - 1] < kw) {
-              in_src[j] = in_src[j - 1]; in_w[j] = in_w[j - 1]; in_fpos[j] = in_fpos[j - 1];
-              --j;
-            }
-            in_src[j] = ks; in_w[j] = kw; in_fpos[j] = kf;
-          }
+      // k_dag / k_exact do not care.  Rows arrive in ascending source order (the scatter above walks
+      // the sources in order) and are short: stable insertion sort by cost.
+      for (uint32_t t = 0; t < n; ++t) {
+        const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
+        for (uint32_t i = a + 1; i < b; ++i) {
+          const InRec key = rec[i];
+          uint32_t j = i;
+          while (j > a && rec[j - 1].w < key.w) { rec[j] = rec[j - 1]; --j; }
+          rec[j] = key;
         }
       }
+      std::vector<uint32_t> in_src(kept), in_w(kept), in_fpos(kept);
+      for (uint32_t i = 0; i < kept; ++i) { in_src[i] = rec[i].src; in_w[i] = rec[i].w; in_fpos[i] = rec[i].fpos; }
+      lap("row sort");
       // hop-count-like (MetricMode::HopCount graphs): lets the fused path resolve the router -> network
       // zero-cost plateaus itself instead of sending every root to the sequential kernel
       {
@@ -350,6 +363,7 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
         if (er == hipSuccess && !h.empty()) er = hipMemcpy(*d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
         return er;
       };
+      lap("flags");
       hipError_t er = hipSuccess;
       if (er == hipSuccess) er = up(&g->d_in_ptr, in_ptr);
       if (er == hipSuccess) er = up(&g->d_in_src, in_src);
@@ -373,6 +387,7 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
     hspf_graph_free(ctx, g);
     return HSPF_E_NOMEM;
   }
+  lap("device alloc + H2D");
   *out = g;
   return HSPF_OK;
 }
