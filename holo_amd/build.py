@@ -32,7 +32,7 @@ def needs_build() -> bool:
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fopenmp",
            "-Wall", "-Wno-unused-function"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     cmd += ["-o", LIB + ".tmp"]

@@ -315,6 +315,7 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
       // the reference's first discoverer (earliest popped tight parent).  k_fused relies on it;
       // k_dag / k_exact do not care.  Rows arrive in ascending source order (the scatter above walks
       // the sources in order) and are short: stable insertion sort by cost.
+#pragma omp parallel for schedule(static) num_threads(8)
       for (uint32_t t = 0; t < n; ++t) {
         const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
         for (uint32_t i = a + 1; i < b; ++i) {
@@ -325,6 +326,7 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
         }
       }
       std::vector<uint32_t> in_src(kept), in_w(kept), in_fpos(kept);
+#pragma omp parallel for schedule(static) num_threads(8)
       for (uint32_t i = 0; i < kept; ++i) { in_src[i] = rec[i].src; in_w[i] = rec[i].w; in_fpos[i] = rec[i].fpos; }
       lap("row sort");
       // hop-count-like (MetricMode::HopCount graphs): lets the fused path resolve the router -> network
@@ -344,6 +346,7 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
       }
       // static reasons for the general fused row routine
       std::vector<uint8_t> rowflags(n, 0);
+#pragma omp parallel for schedule(static) num_threads(8)
       for (uint32_t t = 0; t < n; ++t) {
         uint8_t f = 0;
         if (in_ptr[t + 1] - in_ptr[t] > 16) f |= RF_MANY;
