@@ -594,7 +594,7 @@ __device__ __forceinline__ RowOut<ST> fused_row16(__amdgpu_buffer_rsrc_t rs, uin
 // General row routine (rare: rows next to a vertex that can have hops == 0, overloaded sources,
 // zero-cost links from higher-numbered sources, more than 16 links): one link at a time, rolled
 // loops.  Inlined all the same: a real call would need a stack, i.e. scratch memory.
-template <typename ST, bool MAXINF>
+template <typename ST, bool MAXINF, bool HC>
 __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v,
                                                     uint32_t e0, uint32_t e1, uint32_t sv0, uint32_t wv0,
                                                     uint32_t lane, uint32_t lvo, uint32_t my_root,
@@ -629,8 +629,8 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
       const uint32_t c = add_sat(d, w);
       if (MAXINF && sizeof(ST) == 8 && c == INF && d != INF && w != INF) a.sat = true;
       const bool zlink = has_z && rdlane(zv, j) != 0u;            // uniform
-      if (zlink && !P.hc) { bd_all = min(bd_all, c); continue; }
-      const bool lt = zlink ? (c < zb) : (c < a.bd), eq = !zlink && c == a.bd;
+      if (zlink && !HC) { bd_all = min(bd_all, c); continue; }
+      const bool lt = (HC && zlink) ? (c < zb) : (c < a.bd), eq = !(HC && zlink) && c == a.bd;
       const uint32_t hh = pay >> P.mbits;
       uint32_t contrib = pay & ((1u << P.mbits) - 1u);
       const bool direct = (lt || eq) && hh == 0u && c < P.inf_t;  // parent: root or hops-0 network
@@ -643,7 +643,7 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
           contrib = ((v_router || net_nexthops) && sidx < P.mbits) ? (1u << sidx) : 0u;
         }
       }
-      if (zlink) {
+      if (HC && zlink) {
         // Hop-count-like graph (holo-isis MetricMode::HopCount, spf.rs:1138-1145): a network whose
         // only way in is a zero-cost link from routers of the same distance is put on the candidate
         // list by the FIRST of them to be popped — the lowest-numbered one, rows list equal-cost links
@@ -660,7 +660,7 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
       a.bd = min(a.bd, c);
     }
   }
-  if (P.hc) {                               // late vertex: strictly better through the zero-cost links
+  if (HC) {                                 // late vertex: strictly better through the zero-cost links
     const bool late = zb < a.bd;
     a.bm = late ? zm : a.bm;
     a.bh = late ? zh : a.bh;
@@ -762,8 +762,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
       RowOut<ST> r;
       if (rdlane(hb, lb + i) == 0u)
         r = fused_row16<ST, MAXINF>(rs, v, e1 - e0, svv[i], wvv[i], lvo, my_root, v_router, P);
+      else if (P.hc)       // hop-count-like graphs only (MANET): its own instantiation keeps the usual one lean
+        r = fused_row_any<ST, MAXINF, true>(gp->g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
       else
-        r = fused_row_any<ST, MAXINF>(gp->g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
+        r = fused_row_any<ST, MAXINF, false>(gp->g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
       sat = sat || r.sat;
       need_exact = need_exact || r.need_exact;
       ovf = ovf || r.ovf;
