@@ -84,6 +84,9 @@ struct SlotTabs {           // per root: H vertices and their slot bases (includ
 // range so that the rows a wave touches (its neighbours in a spatially numbered LSDB) stay in
 // that XCD's private 4 MiB L2.  Speed only: any placement gives the same result.
 __device__ __forceinline__ uint32_t xcd_chunk(uint32_t bx, uint32_t gx /* multiple of 8 */) {
+#ifdef HSPF_NO_XCD
+  return bx;
+#endif
   return (bx & 7u) * (gx >> 3) + (bx >> 3);
 }
 
