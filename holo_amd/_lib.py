@@ -43,6 +43,11 @@ class HspfPrefixTable(ctypes.Structure):
                 ("pfx_ptr", u32p), ("pfx_vertex", u32p), ("pfx_metric", u32p)]
 
 
+class HspfRows(ctypes.Structure):
+    _fields_ = [("n_changed", ctypes.c_uint32), ("vertex", u32p), ("row_ptr", u32p), ("col", u32p),
+                ("metric", u32p), ("vflags", u8p)]
+
+
 class HspfRoutes(ctypes.Structure):
     _fields_ = [("best_metric", ctypes.c_void_p), ("best_entry", ctypes.c_void_p), ("nexthop_mask", ctypes.c_void_p)]
 
@@ -60,7 +65,11 @@ SYMBOLS = [
     ("hspf_graph_upload", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(HspfCsr), ctypes.POINTER(ctypes.c_void_p)]),
     ("hspf_graph_free", None, [ctypes.c_void_p, ctypes.c_void_p]),
     ("hspf_graph_n_vertices", ctypes.c_uint32, [ctypes.c_void_p]),
+    ("hspf_graph_n_edges", ctypes.c_uint32, [ctypes.c_void_p]),
     ("hspf_graph_n_edges_kept", ctypes.c_uint32, [ctypes.c_void_p]),
+    ("hspf_graph_patch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(HspfRows)]),
+    ("hspf_graph_export", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                                         ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
     ("hspf_mask_words", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, u32p]),
     ("hspf_slot_table", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, u32p, u32p, ctypes.c_uint32, u32p]),
     ("hspf_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(HspfResult)]),

@@ -1,0 +1,284 @@
+// graph_build.hip.h — gfx950 kernels that turn the caller's CSR (one row per LSA / LSP vertex, links in
+// LSA order) into the layout the SPF kernels read, entirely in HBM.
+//
+// This is the step immediately before the path: the reference re-derives the graph from
+// TLVs / LSAs on every link visit and repeats the two-way check per visit
+// (holo-ospf/src/spf.rs:654-664, holo-isis/src/spf.rs:616-627); here it is done once per LSDB generation
+// (hspf_graph_upload) or once per changed set of rows (hspf_graph_patch), by streaming passes over the links:
+//
+//   kb_links     one thread per link: owning row (binary search in row_ptr), range checks, two-way check
+//                (row of the target lists the source), kept = two-way and the source can be expanded;
+//                in-degree histogram.
+//   scan         exclusive prefix sums: kept links -> positions of the forward (out) arrays and out_ptr;
+//                in-degrees -> in_ptr.
+//   kb_scatter   kept links into the forward arrays (stable: global link order) and, through a per-row
+//                atomic cursor, into unsorted in-rows.
+//   kb_rank      each in-link counts the in-links of its row that precede it in
+//                (cost descending, source ascending, position ascending) — a total order, so the final
+//                layout does not depend on the order the atomics happened to resolve in.
+//   kb_rowflags  per-row static flags for the fused sweep; hop-count shape of the graph; pads.
+//   kb_splice    (patch) new raw CSR = old rows, except the replaced ones taken from the delta.
+//
+// Everything is integer streaming work bound by HBM / L2 bandwidth; no MFMA, no LDS tiling beyond the scans.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "spf_kernels.hip.h"
+
+namespace hspf {
+
+constexpr uint32_t GB_ERR_COL = 1u;      // a link targets a vertex >= n_vertices
+constexpr uint32_t GB_ERR_METRIC = 2u;   // a link carries the reserved cost 0xFFFFFFFF
+
+struct BuildInfo {       // device-resident summary of one build, copied back once
+  uint32_t err;          // GB_ERR_*
+  uint32_t kept;         // links that survive (two-way, source expandable)
+  uint32_t wmax;         // largest kept cost
+  uint32_t hc_bad;       // some kept link breaks the hop-count shape
+  uint32_t hc_net;       // some network row has a kept in-link
+  uint32_t pad[3];
+};
+
+constexpr int GB_BLOCK = 256;
+constexpr int GB_ITEMS = 8;                       // scan: items per thread
+constexpr int GB_TILE = GB_BLOCK * GB_ITEMS;      // scan: items per block
+
+// Row that owns link k: the largest u < n with row_ptr[u] <= k (empty rows are skipped naturally).
+__device__ __forceinline__ uint32_t gb_row_of(const uint32_t *__restrict__ row_ptr, uint32_t n, uint32_t k) {
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (row_ptr[mid] <= k) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_links(uint32_t n, uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
+         const uint32_t *__restrict__ metric, const uint8_t *__restrict__ vflags, uint32_t *__restrict__ src_of,
+         uint8_t *__restrict__ twoway, uint8_t *__restrict__ keep, uint32_t *__restrict__ in_cnt,
+         BuildInfo *__restrict__ info) {
+  const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (k >= e) return;
+  const uint32_t u = gb_row_of(row_ptr, n, k);
+  const uint32_t t = col[k];
+  src_of[k] = u;
+  uint32_t bad = 0;
+  if (t >= n) bad |= GB_ERR_COL;
+  if (metric[k] == INF) bad |= GB_ERR_METRIC;
+  if (bad) {
+    atomicOr(&info->err, bad);
+    twoway[k] = 0; keep[k] = 0;
+    return;
+  }
+  // two-way connectivity: the target's row lists the source, cost not compared
+  bool two = false;
+  const uint32_t b = row_ptr[t + 1];
+  for (uint32_t k2 = row_ptr[t]; k2 < b; ++k2)
+    if (col[k2] == u) { two = true; break; }
+  const bool kp = two && !(vflags[u] & HSPF_VF_NO_EXPAND);
+  twoway[k] = two ? 1 : 0;
+  keep[k] = kp ? 1 : 0;
+  if (kp) atomicAdd(&in_cnt[t], 1u);
+}
+
+// ---- exclusive scan of m items (u8 or u32) into out[0..m], out[m] = total ----------------------------
+
+__device__ __forceinline__ uint32_t gb_block_exclusive(uint32_t v, uint32_t *sh, uint32_t &total) {
+  const int tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (int d = 1; d < GB_BLOCK; d <<= 1) {
+    const uint32_t add = tid >= d ? sh[tid - d] : 0u;
+    __syncthreads();
+    sh[tid] += add;
+    __syncthreads();
+  }
+  total = sh[GB_BLOCK - 1];
+  return sh[tid] - v;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_scan_sums(const T *__restrict__ in, uint32_t m, uint32_t *__restrict__ sums) {
+  __shared__ uint32_t sh[GB_BLOCK];
+  const uint32_t base = blockIdx.x * GB_TILE + threadIdx.x * GB_ITEMS;
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < GB_ITEMS; ++i)
+    if (base + i < m) s += (uint32_t)in[base + i];
+  uint32_t total;
+  (void)gb_block_exclusive(s, sh, total);
+  if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// one block: sums[0..nb) -> exclusive prefix in place, grand total -> *total (and info->kept when asked)
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_scan_mid(uint32_t *__restrict__ sums, uint32_t nb, uint32_t *__restrict__ total_out) {
+  __shared__ uint32_t sh[GB_BLOCK];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < nb; base += GB_BLOCK) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nb ? sums[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = gb_block_exclusive(v, sh, total);
+    if (i < nb) sums[i] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_scan_apply(const T *__restrict__ in, uint32_t m, const uint32_t *__restrict__ sums, uint32_t *__restrict__ out) {
+  __shared__ uint32_t sh[GB_BLOCK];
+  const uint32_t base = blockIdx.x * GB_TILE + threadIdx.x * GB_ITEMS;
+  uint32_t v[GB_ITEMS];
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < GB_ITEMS; ++i) {
+    v[i] = base + i < m ? (uint32_t)in[base + i] : 0u;
+    s += v[i];
+  }
+  uint32_t total;
+  uint32_t run = sums[blockIdx.x] + gb_block_exclusive(s, sh, total);
+#pragma unroll
+  for (int i = 0; i < GB_ITEMS; ++i) {
+    if (base + i <= m) out[base + i] = run;      // position m receives the grand total
+    run += v[i];
+  }
+}
+
+// out_ptr[u] = number of kept links before row u
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_out_ptr(uint32_t n, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ kpre,
+           uint32_t *__restrict__ out_ptr, BuildInfo *__restrict__ info, uint32_t e) {
+  const uint32_t u = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (u <= n) out_ptr[u] = kpre[row_ptr[u]];
+  if (u == 0) info->kept = kpre[e];
+}
+
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_scatter(uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
+           const uint32_t *__restrict__ metric, const uint8_t *__restrict__ vflags,
+           const uint32_t *__restrict__ src_of, const uint8_t *__restrict__ keep, const uint32_t *__restrict__ kpre,
+           const uint32_t *__restrict__ in_ptr, uint32_t *__restrict__ in_cnt,
+           uint32_t *__restrict__ out_dst, uint32_t *__restrict__ out_w, uint32_t *__restrict__ out_fpos,
+           uint32_t *__restrict__ tmp_w, uint32_t *__restrict__ tmp_src, uint32_t *__restrict__ tmp_fpos,
+           uint32_t *__restrict__ tmp_t, BuildInfo *__restrict__ info) {
+  __shared__ uint32_t bmax;
+  if (threadIdx.x == 0) bmax = 0;
+  __syncthreads();
+  const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (k < e && keep[k]) {
+    const uint32_t u = src_of[k], t = col[k], w = metric[k];
+    const uint32_t fpos = k - row_ptr[u];
+    const uint32_t o = kpre[k];
+    out_dst[o] = t; out_w[o] = w; out_fpos[o] = fpos;
+    const uint32_t slot = atomicSub(&in_cnt[t], 1u) - 1u;      // any order: kb_rank fixes the final one
+    const uint32_t i = in_ptr[t] + slot;
+    tmp_w[i] = w;
+    tmp_src[i] = u | ((vflags[u] & HSPF_VF_NO_TRANSIT) ? SRC_NO_TRANSIT : 0u);
+    tmp_fpos[i] = fpos;
+    tmp_t[i] = t;
+    atomicMax(&bmax, w);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && bmax) atomicMax(&info->wmax, bmax);
+}
+
+// In-links of a row by (cost descending, source ascending, position ascending): among tight links, i.e. equal
+// dist[u] + cost, the first in row order has the smallest dist[u] and then the smallest u = the reference's
+// first discoverer (earliest popped tight parent).  k_fused relies on it; k_dag / k_exact do not care.
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_rank(uint32_t e, const BuildInfo *__restrict__ info, const uint32_t *__restrict__ in_ptr,
+        const uint32_t *__restrict__ tmp_w, const uint32_t *__restrict__ tmp_src,
+        const uint32_t *__restrict__ tmp_fpos, const uint32_t *__restrict__ tmp_t,
+        uint32_t *__restrict__ in_src, uint32_t *__restrict__ in_w, uint32_t *__restrict__ in_fpos) {
+  const uint32_t i = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (i >= e || i >= info->kept) return;
+  const uint32_t t = tmp_t[i];
+  const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
+  const uint32_t w = tmp_w[i], sraw = tmp_src[i], s = sraw & SRC_MASK, f = tmp_fpos[i];
+  uint32_t rank = 0;
+  for (uint32_t j = a; j < b; ++j) {
+    const uint32_t wj = tmp_w[j], sj = tmp_src[j] & SRC_MASK, fj = tmp_fpos[j];
+    const bool before = wj > w || (wj == w && (sj < s || (sj == s && fj < f)));
+    rank += before ? 1u : 0u;
+  }
+  in_w[a + rank] = w;
+  in_src[a + rank] = sraw;
+  in_fpos[a + rank] = f;
+}
+
+// Static reasons why a row needs the general fused routine (RF_*), the hop-count shape of the graph
+// (MetricMode::HopCount graphs, holo-isis/src/spf.rs:1131-1146: cost 0 into a pseudonode, 1 into a router), and the
+// 16 zero entries behind every array that the kernels' fixed-size fetches may touch.
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ in_src,
+            const uint32_t *__restrict__ in_w, const uint8_t *__restrict__ vflags, uint8_t *__restrict__ rowflags,
+            BuildInfo *__restrict__ info) {
+  const uint32_t t = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
+  const bool net = vflags[t] & HSPF_VF_NETWORK;
+  uint32_t f = b - a > 16u ? RF_MANY : 0u;
+  bool bad = false;
+  for (uint32_t i = a; i < b; ++i) {
+    const uint32_t sraw = in_src[i], u = sraw & SRC_MASK, w = in_w[i];
+    if (sraw & SRC_NO_TRANSIT) f |= RF_NT;
+    if (w == 0u && u >= t) f |= RF_ZERO;
+    if (net) bad |= !(w == 0u && !(vflags[u] & HSPF_VF_NETWORK) && u > t);
+    else bad |= w != 1u;
+  }
+  rowflags[t] = (uint8_t)f;
+  if (bad) info->hc_bad = 1u;                 // plain stores: every writer stores the same value
+  if (net && b > a) info->hc_net = 1u;
+}
+
+__global__ void kb_pads(uint32_t n, const BuildInfo *__restrict__ info, uint32_t *in_ptr, uint32_t *out_ptr,
+                        uint32_t *a0, uint32_t *a1, uint32_t *a2, uint32_t *a3, uint32_t *a4, uint32_t *a5) {
+  const uint32_t i = threadIdx.x;
+  if (i >= 16) return;
+  const uint32_t kept = info->kept;
+  in_ptr[n + 1 + i] = 0; out_ptr[n + 1 + i] = 0;
+  a0[kept + i] = 0; a1[kept + i] = 0; a2[kept + i] = 0; a3[kept + i] = 0; a4[kept + i] = 0; a5[kept + i] = 0;
+}
+
+// ---- patch: replace whole rows of the raw CSR ----------------------------------------------------------
+
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_splice(uint32_t n, uint32_t e_new, const uint32_t *__restrict__ new_row_ptr,
+          const uint32_t *__restrict__ old_row_ptr, const uint32_t *__restrict__ old_col,
+          const uint32_t *__restrict__ old_metric, uint32_t n_changed, const uint32_t *__restrict__ changed,
+          const uint32_t *__restrict__ delta_ptr, const uint32_t *__restrict__ delta_col,
+          const uint32_t *__restrict__ delta_metric, uint32_t *__restrict__ new_col, uint32_t *__restrict__ new_metric) {
+  const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (k >= e_new) return;
+  const uint32_t u = gb_row_of(new_row_ptr, n, k);
+  const uint32_t off = k - new_row_ptr[u];
+  // is u one of the replaced rows?  (changed[] is strictly ascending)
+  uint32_t lo = 0, hi = n_changed;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (changed[mid] < u) lo = mid + 1; else hi = mid;
+  }
+  if (lo < n_changed && changed[lo] == u) {
+    new_col[k] = delta_col[delta_ptr[lo] + off];
+    new_metric[k] = delta_metric[delta_ptr[lo] + off];
+  } else {
+    new_col[k] = old_col[old_row_ptr[u] + off];
+    new_metric[k] = old_metric[old_row_ptr[u] + off];
+  }
+}
+
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_set_vflags(uint32_t n_changed, const uint32_t *__restrict__ changed, const uint8_t *__restrict__ nf,
+              uint8_t *__restrict__ vflags) {
+  const uint32_t i = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (i < n_changed) vflags[changed[i]] = nf[i];
+}
+
+}  // namespace hspf

@@ -8,6 +8,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared spf_capi.hip -o libholo_spf_hip.so
 #include "../../include/holo_spf_hip.h"
 #include "spf_kernels.hip.h"
+#include "graph_build.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -31,18 +32,37 @@ struct DevBuf {
 
 struct hspf_graph {
   uint32_t n = 0, e = 0, e_kept = 0;
+  uint32_t cap_e = 0;                // link capacity of the device arrays (>= e; patches grow into it)
   uint32_t max_path_metric = 0;
   uint32_t wmax = 0;                 // largest cost among the kept links
   mutable bool narrow_bad = false;   // a run overflowed the 4-byte fused state: use the 8-byte one
   bool hopcount_like = false;        // every kept link into a network costs 0 (from a router), into a router 1
-  // host copies (slot tables, validation)
+  // host mirrors: slot tables walk the root's neighbourhood on the host
   std::vector<uint32_t> row_ptr, col;
-  std::vector<uint8_t> twoway;     // per original link
+  std::vector<uint8_t> twoway;     // per original link (computed on device, copied back)
   std::vector<uint8_t> vflags;
-  // device
+  // device: one allocation, carved by layout()
+  char *arena = nullptr;
+  size_t arena_bytes = 0;
+  int cur = 0;                                                    // which raw set is live
+  uint32_t *d_row_ptr[2] = {}, *d_col[2] = {}, *d_metric[2] = {};  // caller's CSR (ping-pong for patches)
   uint32_t *d_in_ptr = nullptr, *d_in_src = nullptr, *d_in_w = nullptr, *d_in_fpos = nullptr;
   uint32_t *d_out_ptr = nullptr, *d_out_dst = nullptr, *d_out_w = nullptr, *d_out_fpos = nullptr;
   uint8_t *d_vflags = nullptr, *d_rowflags = nullptr;
+  // Carves the arrays out of `base` for n vertices / cap links; returns the bytes needed.
+  size_t layout(char *base, uint32_t nv, uint32_t cap) {
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { char *p = base ? base + off : nullptr; off = (off + bytes + 255) & ~size_t(255); return p; };
+    const size_t vb = (size_t(nv) + 17) * 4, lb = (size_t(cap) + 16) * 4;
+    for (int i = 0; i < 2; ++i) {
+      d_row_ptr[i] = (uint32_t *)carve(vb); d_col[i] = (uint32_t *)carve(lb); d_metric[i] = (uint32_t *)carve(lb);
+    }
+    d_in_ptr = (uint32_t *)carve(vb); d_out_ptr = (uint32_t *)carve(vb);
+    d_in_src = (uint32_t *)carve(lb); d_in_w = (uint32_t *)carve(lb); d_in_fpos = (uint32_t *)carve(lb);
+    d_out_dst = (uint32_t *)carve(lb); d_out_w = (uint32_t *)carve(lb); d_out_fpos = (uint32_t *)carve(lb);
+    d_vflags = (uint8_t *)carve(nv); d_rowflags = (uint8_t *)carve(nv);
+    return off;
+  }
   GraphDev dev() const {
     GraphDev g;
     g.n = n; g.e_in = e_kept;
@@ -64,6 +84,8 @@ struct hspf_ctx {
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met;                    // prefix table of hspf_routes_device
+  DevBuf gb, gb_delta;                              // graph build scratch, patch delta
+  BuildInfo *h_info = nullptr;     // pinned
   int *h_changed = nullptr;        // pinned
   uint32_t *h_lane_flags = nullptr; // pinned
   size_t h_lane_cap = 0;
@@ -147,6 +169,95 @@ void launch_emit(dim3 grid, hipStream_t s, uint32_t n, uint32_t nr, const uint32
   hipLaunchKernelGGL((k_emit<W>), grid, dim3(256), 0, s, n, nr, dist, hv, mask, o);
 }
 
+// Exclusive prefix sums of in[0..m) into out[0..m], out[m] = total (graph_build.hip.h).
+template <typename T>
+void gb_scan(hipStream_t s, const T *in, uint32_t m, uint32_t *out, uint32_t *sums) {
+  const uint32_t nb = (uint32_t)(((uint64_t)m + 1 + GB_TILE - 1) / GB_TILE);
+  hipLaunchKernelGGL((kb_scan_sums<T>), dim3(nb), dim3(GB_BLOCK), 0, s, in, m, sums);
+  hipLaunchKernelGGL(kb_scan_mid, dim3(1), dim3(GB_BLOCK), 0, s, sums, nb, (uint32_t *)nullptr);
+  hipLaunchKernelGGL((kb_scan_apply<T>), dim3(nb), dim3(GB_BLOCK), 0, s, in, m, (const uint32_t *)sums, out);
+}
+
+// Builds everything the SPF kernels read from the live raw CSR of g (d_row_ptr/d_col/d_metric[g->cur],
+// d_vflags), on the ctx stream, and refreshes the host-side summary (e_kept, wmax, hop-count shape, two-way
+// flags for the slot tables).  Synchronises the stream once at the end.
+int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
+  const uint32_t n = g->n, e = g->e;
+  hipStream_t s = ctx->stream;
+  const size_t le = (size_t)e + 16;
+  const size_t nsums = (size_t)std::max(e, n) / GB_TILE + 4;
+  // scratch: src_of, kpre, tmp_w, tmp_src, tmp_fpos, tmp_t (u32 x le each) | in_cnt (n+1) | sums | info | keep, twoway (u8)
+  const size_t words = 6 * le + (size_t)n + 17 + nsums + 16;
+  const size_t bytes = words * 4 + 2 * le + 64;
+  int rc = ensure(ctx, ctx->gb, bytes);
+  if (rc != HSPF_OK) return rc;
+  uint32_t *w = (uint32_t *)ctx->gb.p;
+  uint32_t *src_of = w; w += le;
+  uint32_t *kpre = w; w += le;
+  uint32_t *tmp_w = w; w += le;
+  uint32_t *tmp_src = w; w += le;
+  uint32_t *tmp_fpos = w; w += le;
+  uint32_t *tmp_t = w; w += le;
+  uint32_t *in_cnt = w; w += (size_t)n + 17;
+  uint32_t *sums = w; w += nsums;
+  BuildInfo *info = (BuildInfo *)w; w += 16;
+  uint8_t *keep = (uint8_t *)w;
+  uint8_t *twoway = keep + le;
+  const uint32_t *row_ptr = g->d_row_ptr[g->cur], *col = g->d_col[g->cur], *metric = g->d_metric[g->cur];
+
+  HIPCHK(ctx, hipMemsetAsync(in_cnt, 0, ((size_t)n + 1) * 4, s));
+  HIPCHK(ctx, hipMemsetAsync(info, 0, sizeof(BuildInfo), s));
+  const dim3 ge((e + GB_BLOCK - 1) / GB_BLOCK), gn((n + 1 + GB_BLOCK - 1) / GB_BLOCK);
+  if (e)
+    hipLaunchKernelGGL(kb_links, ge, dim3(GB_BLOCK), 0, s, n, e, row_ptr, col, metric, (const uint8_t *)g->d_vflags,
+                       src_of, twoway, keep, in_cnt, info);
+  gb_scan<uint8_t>(s, keep, e, kpre, sums);
+  hipLaunchKernelGGL(kb_out_ptr, gn, dim3(GB_BLOCK), 0, s, n, row_ptr, (const uint32_t *)kpre, g->d_out_ptr, info, e);
+  gb_scan<uint32_t>(s, in_cnt, n, g->d_in_ptr, sums);
+  if (e) {
+    hipLaunchKernelGGL(kb_scatter, ge, dim3(GB_BLOCK), 0, s, e, row_ptr, col, metric, (const uint8_t *)g->d_vflags,
+                       (const uint32_t *)src_of, (const uint8_t *)keep, (const uint32_t *)kpre,
+                       (const uint32_t *)g->d_in_ptr, in_cnt, g->d_out_dst, g->d_out_w, g->d_out_fpos,
+                       tmp_w, tmp_src, tmp_fpos, tmp_t, info);
+    hipLaunchKernelGGL(kb_rank, ge, dim3(GB_BLOCK), 0, s, e, (const BuildInfo *)info, (const uint32_t *)g->d_in_ptr,
+                       (const uint32_t *)tmp_w, (const uint32_t *)tmp_src, (const uint32_t *)tmp_fpos,
+                       (const uint32_t *)tmp_t, g->d_in_src, g->d_in_w, g->d_in_fpos);
+  }
+  hipLaunchKernelGGL(kb_rowflags, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
+                     (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info);
+  hipLaunchKernelGGL(kb_pads, dim3(1), dim3(64), 0, s, n, (const BuildInfo *)info, g->d_in_ptr, g->d_out_ptr,
+                     g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_info, info, sizeof(BuildInfo), hipMemcpyDeviceToHost, s));
+  g->twoway.resize(e);
+  if (e) HIPCHK(ctx, hipMemcpyAsync(g->twoway.data(), twoway, e, hipMemcpyDeviceToHost, s));
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  const BuildInfo bi = *ctx->h_info;
+  if (bi.err) {
+    ctx->last_error = (bi.err & GB_ERR_COL) ? "col out of range" : "metric 0xFFFFFFFF is reserved";
+    return HSPF_E_INVAL;
+  }
+  g->e_kept = bi.kept;
+  g->wmax = bi.wmax;
+  g->hopcount_like = !bi.hc_bad && bi.hc_net;
+  g->narrow_bad = false;
+  return HSPF_OK;
+}
+
+int alloc_arena(hspf_ctx *ctx, hspf_graph *g, uint32_t n, uint32_t cap) {
+  const size_t bytes = g->layout(nullptr, n, cap);
+  char *base = nullptr;
+  hipError_t er = hipMalloc((void **)&base, bytes);
+  if (er != hipSuccess) {
+    ctx->last_error = std::string("graph arena hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(er);
+    g->layout(nullptr, n, cap);
+    return er == hipErrorOutOfMemory ? HSPF_E_NOMEM : HSPF_E_HIP;
+  }
+  g->arena = base; g->arena_bytes = bytes; g->cap_e = cap;
+  g->layout(base, n, cap);
+  return HSPF_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -190,6 +301,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   for (auto &e : ctx->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
   if (hipHostMalloc((void **)&ctx->h_changed, sizeof(int) * 4, hipHostMallocDefault) != hipSuccess) { delete ctx; return HSPF_E_NOMEM; }
+  if (hipHostMalloc((void **)&ctx->h_info, sizeof(BuildInfo), hipHostMallocDefault) != hipSuccess) { hspf_shutdown(ctx); return HSPF_E_NOMEM; }
   *out = ctx;
   return HSPF_OK;
 }
@@ -200,10 +312,11 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->roots, &ctx->lane_flags, &ctx->changed,
                     &ctx->tab_ptr, &ctx->tab_vtx, &ctx->tab_base, &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->fgraph, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->gb, &ctx->gb_delta})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
+  if (ctx->h_info) (void)hipHostFree(ctx->h_info);
   for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -226,17 +339,13 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
   if (!ctx || !csr || !out) return HSPF_E_INVAL;
   *out = nullptr;
   const uint32_t n = csr->n_vertices, e = csr->n_edges;
-  if (n == 0 || n > (1u << 24) || !csr->row_ptr || !csr->vflags || (e && (!csr->col || !csr->metric))) {
+  if (n == 0 || n > (1u << 24) || e > 0x7FFFFFF0u || !csr->row_ptr || !csr->vflags || (e && (!csr->col || !csr->metric))) {
     ctx->last_error = "hspf_graph_upload: malformed hspf_csr";
     return HSPF_E_INVAL;
   }
   if (csr->row_ptr[0] != 0 || csr->row_ptr[n] != e) { ctx->last_error = "row_ptr[0]!=0 or row_ptr[n]!=n_edges"; return HSPF_E_INVAL; }
   for (uint32_t u = 0; u < n; ++u)
     if (csr->row_ptr[u + 1] < csr->row_ptr[u]) { ctx->last_error = "row_ptr not monotone"; return HSPF_E_INVAL; }
-  for (uint32_t k = 0; k < e; ++k) {
-    if (csr->col[k] >= n) { ctx->last_error = "col out of range"; return HSPF_E_INVAL; }
-    if (csr->metric[k] == 0xFFFFFFFFu) { ctx->last_error = "metric 0xFFFFFFFF is reserved"; return HSPF_E_INVAL; }
-  }
   (void)hipSetDevice(ctx->device);
 
   const bool tdbg = getenv("HSPF_UPLOAD_TIMING") != nullptr;
@@ -250,163 +359,191 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
   hspf_graph *g = new (std::nothrow) hspf_graph();
   if (!g) return HSPF_E_NOMEM;
   g->n = n; g->e = e; g->max_path_metric = csr->max_path_metric;
+  int rc = alloc_arena(ctx, g, n, e + std::max(e / 8, 1024u));
+  if (rc != HSPF_OK) { delete g; return rc; }
+  lap("device alloc");
+  auto fail = [&](int code) { hspf_graph_free(ctx, g); return code; };
+  hipStream_t s = ctx->stream;
+  hipError_t er = hipMemcpyAsync(g->d_row_ptr[0], csr->row_ptr, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s);
+  if (er == hipSuccess && e) er = hipMemcpyAsync(g->d_col[0], csr->col, (size_t)e * 4, hipMemcpyHostToDevice, s);
+  if (er == hipSuccess && e) er = hipMemcpyAsync(g->d_metric[0], csr->metric, (size_t)e * 4, hipMemcpyHostToDevice, s);
+  if (er == hipSuccess) er = hipMemcpyAsync(g->d_vflags, csr->vflags, n, hipMemcpyHostToDevice, s);
+  if (er != hipSuccess) { ctx->last_error = std::string("graph upload H2D: ") + hipGetErrorString(er); return fail(HSPF_E_HIP); }
+  lap("H2D");
   try {
+    // host mirrors for the slot tables (hspf_slot_table walks the root's neighbourhood on the host)
     g->row_ptr.assign(csr->row_ptr, csr->row_ptr + n + 1);
     g->col.assign(csr->col, csr->col + e);
     g->vflags.assign(csr->vflags, csr->vflags + n);
-    g->twoway.assign(e, 0);
-    // Two-way connectivity check, once per LSDB generation instead of once per link visit
-    // (holo-ospf/src/spf.rs:654-664, holo-isis/src/spf.rs:616-627): link u->t is usable iff row t
-    // lists u (cost not compared).  Sort-free: mark the targets of row t, probe with row t's
-    // sources.  O(E * avg-degree) worst case is avoided by marking per target row.
-    {
-      // For each t, mark[col[k']] = t for k' in row t; then u->t two-way iff mark'[u]==t.  We
-      // need the reverse view: iterate rows t, stamp their targets; link (u->t) asks "does row t
-      // contain u".  Process links grouped by target using a counting sort of link ids by target.
-      lap("host copies");
-      std::vector<uint32_t> cnt(n + 1, 0);
-      for (uint32_t k = 0; k < e; ++k) cnt[csr->col[k] + 1]++;
-      for (uint32_t i = 0; i < n; ++i) cnt[i + 1] += cnt[i];
-      std::vector<uint32_t> by_t(e), src_of(e);
-      {
-        std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
-        for (uint32_t u = 0; u < n; ++u)
-          for (uint32_t k = csr->row_ptr[u]; k < csr->row_ptr[u + 1]; ++k) { src_of[k] = u; by_t[cur[csr->col[k]]++] = k; }
-      }
-      std::vector<uint32_t> stamp(n, 0xFFFFFFFFu);
-      for (uint32_t t = 0; t < n; ++t) {
-        if (cnt[t] == cnt[t + 1]) continue;
-        for (uint32_t k2 = csr->row_ptr[t]; k2 < csr->row_ptr[t + 1]; ++k2) stamp[csr->col[k2]] = t;
-        for (uint32_t i = cnt[t]; i < cnt[t + 1]; ++i) { const uint32_t k = by_t[i]; g->twoway[k] = stamp[src_of[k]] == t; }
-      }
-      lap("two-way check");
-      // Kept links: two-way AND the source can ever be expanded.  Transposed (in-link) CSR by a
-      // counting sort that keeps source order -> deterministic layout.
-      std::vector<uint32_t> in_ptr(n + 1, 0), out_ptr(n + 1, 0);
-      uint32_t kept = 0;
-      for (uint32_t k = 0; k < e; ++k) {
-        const bool keep = g->twoway[k] && !(csr->vflags[src_of[k]] & HSPF_VF_NO_EXPAND);
-        if (keep) { in_ptr[csr->col[k] + 1]++; out_ptr[src_of[k] + 1]++; ++kept; }
-      }
-      for (uint32_t i = 0; i < n; ++i) { in_ptr[i + 1] += in_ptr[i]; out_ptr[i + 1] += out_ptr[i]; }
-      g->e_kept = kept;
-      // Transpose into an array of (cost, source, position) records — one scattered write per link —
-      // sort each in-row in place, then split into the structure-of-arrays the kernels read.
-      struct InRec { uint32_t w, src, fpos; };
-      std::vector<InRec> rec(kept);
-      std::vector<uint32_t> out_dst(kept), out_w(kept), out_fpos(kept);
-      std::vector<uint32_t> cur(in_ptr.begin(), in_ptr.end() - 1);
-      uint32_t oi = 0;
-      for (uint32_t u = 0; u < n; ++u) {
-        const bool nt = csr->vflags[u] & HSPF_VF_NO_TRANSIT;
-        const bool ne = csr->vflags[u] & HSPF_VF_NO_EXPAND;
-        const uint32_t r0 = csr->row_ptr[u];
-        for (uint32_t k = r0; k < csr->row_ptr[u + 1]; ++k) {
-          if (!g->twoway[k] || ne) continue;
-          const uint32_t t = csr->col[k], w = csr->metric[k];
-          rec[cur[t]++] = InRec{w, u | (nt ? SRC_NO_TRANSIT : 0u), k - r0};
-          g->wmax = std::max(g->wmax, w);
-          out_dst[oi] = t; out_w[oi] = w; out_fpos[oi] = k - r0; ++oi;
-        }
-      }
-      lap("transpose");
-      // In-links of a row by (cost descending, source ascending): among tight links, i.e. equal
-      // dist[u] + cost, the first in row order has the smallest dist[u] and then the smallest u =
-      // the reference's first discoverer (earliest popped tight parent).  k_fused relies on it;
-      // k_dag / k_exact do not care.  Rows arrive in ascending source order (the scatter above walks
-      // the sources in order) and are short: stable insertion sort by cost.
-#pragma omp parallel for schedule(static) num_threads(8)
-      for (uint32_t t = 0; t < n; ++t) {
-        const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
-        for (uint32_t i = a + 1; i < b; ++i) {
-          const InRec key = rec[i];
-          uint32_t j = i;
-          while (j > a && rec[j - 1].w < key.w) { rec[j] = rec[j - 1]; --j; }
-          rec[j] = key;
-        }
-      }
-      std::vector<uint32_t> in_src(kept), in_w(kept), in_fpos(kept);
-#pragma omp parallel for schedule(static) num_threads(8)
-      for (uint32_t i = 0; i < kept; ++i) { in_src[i] = rec[i].src; in_w[i] = rec[i].w; in_fpos[i] = rec[i].fpos; }
-      lap("row sort");
-      // hop-count-like (MetricMode::HopCount graphs): lets the fused path resolve the router -> network
-      // zero-cost plateaus itself instead of sending every root to the sequential kernel
-      {
-        bool hc = false, ok = true;
-        for (uint32_t t = 0; t < n && ok; ++t) {
-          const bool net = csr->vflags[t] & HSPF_VF_NETWORK;
-          for (uint32_t i = in_ptr[t]; i < in_ptr[t + 1] && ok; ++i) {
-            const uint32_t u = in_src[i] & SRC_MASK;
-            const bool unet = csr->vflags[u] & HSPF_VF_NETWORK;
-            if (net) { ok = in_w[i] == 0 && !unet && u > t; hc = true; }
-            else ok = in_w[i] == 1;
-          }
-        }
-        g->hopcount_like = ok && hc;
-      }
-      // static reasons for the general fused row routine
-      std::vector<uint8_t> rowflags(n, 0);
-#pragma omp parallel for schedule(static) num_threads(8)
-      for (uint32_t t = 0; t < n; ++t) {
-        uint8_t f = 0;
-        if (in_ptr[t + 1] - in_ptr[t] > 16) f |= RF_MANY;
-        for (uint32_t i = in_ptr[t]; i < in_ptr[t + 1]; ++i) {
-          if (in_src[i] & SRC_NO_TRANSIT) f |= RF_NT;
-          if (in_w[i] == 0 && (in_src[i] & SRC_MASK) >= t) f |= RF_ZERO;
-        }
-        rowflags[t] = f;
-      }
-      // every device array is padded by 16 zero entries: the kernels fetch link records and row
-      // bounds in fixed-size scalar loads that may run past a row's (or the array's) end
-      auto up = [&](uint32_t **d, const std::vector<uint32_t> &h) -> hipError_t {
-        const size_t bytes = (h.size() + 16) * sizeof(uint32_t);
-        hipError_t er = hipMalloc((void **)d, bytes);
-        if (er != hipSuccess) return er;
-        er = hipMemset(*d, 0, bytes);
-        if (er == hipSuccess && !h.empty()) er = hipMemcpy(*d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        return er;
-      };
-      lap("flags");
-      hipError_t er = hipSuccess;
-      if (er == hipSuccess) er = up(&g->d_in_ptr, in_ptr);
-      if (er == hipSuccess) er = up(&g->d_in_src, in_src);
-      if (er == hipSuccess) er = up(&g->d_in_w, in_w);
-      if (er == hipSuccess) er = up(&g->d_in_fpos, in_fpos);
-      if (er == hipSuccess) er = up(&g->d_out_ptr, out_ptr);
-      if (er == hipSuccess) er = up(&g->d_out_dst, out_dst);
-      if (er == hipSuccess) er = up(&g->d_out_w, out_w);
-      if (er == hipSuccess) er = up(&g->d_out_fpos, out_fpos);
-      if (er == hipSuccess) er = hipMalloc((void **)&g->d_vflags, n);
-      if (er == hipSuccess) er = hipMemcpy(g->d_vflags, csr->vflags, n, hipMemcpyHostToDevice);
-      if (er == hipSuccess) er = hipMalloc((void **)&g->d_rowflags, n);
-      if (er == hipSuccess) er = hipMemcpy(g->d_rowflags, rowflags.data(), n, hipMemcpyHostToDevice);
-      if (er != hipSuccess) {
-        ctx->last_error = std::string("graph upload: ") + hipGetErrorString(er);
-        hspf_graph_free(ctx, g);
-        return er == hipErrorOutOfMemory ? HSPF_E_NOMEM : HSPF_E_HIP;
+    g->twoway.resize(e);
+  } catch (const std::bad_alloc &) {
+    (void)hipStreamSynchronize(s);
+    return fail(HSPF_E_NOMEM);
+  }
+  lap("host mirrors");
+  rc = build_on_device(ctx, g);
+  lap("device build + sync");
+  if (rc != HSPF_OK) return fail(rc);
+  *out = g;
+  return HSPF_OK;
+}
+
+int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
+  if (!ctx || !g || !rows) return HSPF_E_INVAL;
+  const uint32_t m = rows->n_changed, n = g->n;
+  if (m == 0) return HSPF_OK;
+  if (!rows->vertex || !rows->row_ptr || !rows->vflags) { ctx->last_error = "hspf_graph_patch: NULL array"; return HSPF_E_INVAL; }
+  if (rows->row_ptr[0] != 0) { ctx->last_error = "hspf_graph_patch: row_ptr[0] != 0"; return HSPF_E_INVAL; }
+  for (uint32_t j = 0; j < m; ++j) {
+    if (rows->vertex[j] >= n || (j && rows->vertex[j] <= rows->vertex[j - 1])) {
+      ctx->last_error = "hspf_graph_patch: vertex list must be strictly ascending and < n_vertices";
+      return HSPF_E_INVAL;
+    }
+    if (rows->row_ptr[j + 1] < rows->row_ptr[j]) { ctx->last_error = "hspf_graph_patch: row_ptr not monotone"; return HSPF_E_INVAL; }
+  }
+  const uint32_t de = rows->row_ptr[m];
+  if (de && (!rows->col || !rows->metric)) { ctx->last_error = "hspf_graph_patch: NULL col/metric"; return HSPF_E_INVAL; }
+  for (uint32_t k = 0; k < de; ++k) {
+    if (rows->col[k] >= n) { ctx->last_error = "col out of range"; return HSPF_E_INVAL; }
+    if (rows->metric[k] == 0xFFFFFFFFu) { ctx->last_error = "metric 0xFFFFFFFF is reserved"; return HSPF_E_INVAL; }
+  }
+  (void)hipSetDevice(ctx->device);
+  hipStream_t s = ctx->stream;
+  // New row bounds and the spliced host mirror of col: the rows between two replaced ones keep their
+  // contents and stay contiguous, so each such run is one memcpy.
+  std::vector<uint32_t> nrp, ncol;
+  uint64_t e_new64 = g->e;
+  for (uint32_t j = 0; j < m; ++j) {
+    const uint32_t v = rows->vertex[j];
+    e_new64 += (uint64_t)(rows->row_ptr[j + 1] - rows->row_ptr[j]);
+    e_new64 -= (uint64_t)(g->row_ptr[v + 1] - g->row_ptr[v]);
+  }
+  if (e_new64 > 0x7FFFFFF0ull) { ctx->last_error = "hspf_graph_patch: too many links"; return HSPF_E_INVAL; }
+  const uint32_t e_new = (uint32_t)e_new64;
+  try {
+    nrp.resize((size_t)n + 1);
+    ncol.resize(e_new);
+    uint32_t j = 0, pos = 0;
+    for (uint32_t u = 0; u < n;) {
+      if (j < m && rows->vertex[j] == u) {
+        const uint32_t len = rows->row_ptr[j + 1] - rows->row_ptr[j];
+        nrp[u] = pos;
+        if (len) memcpy(&ncol[pos], rows->col + rows->row_ptr[j], (size_t)len * 4);
+        pos += len; ++j; ++u;
+      } else {
+        const uint32_t u_end = j < m ? rows->vertex[j] : n;          // unchanged rows [u, u_end)
+        const uint32_t a = g->row_ptr[u], b = g->row_ptr[u_end];
+        if (b > a) memcpy(&ncol[pos], &g->col[a], (size_t)(b - a) * 4);
+        for (uint32_t x = u; x < u_end; ++x) nrp[x] = pos + (g->row_ptr[x] - a);
+        pos += b - a; u = u_end;
       }
     }
+    nrp[n] = pos;
   } catch (const std::bad_alloc &) {
-    hspf_graph_free(ctx, g);
     return HSPF_E_NOMEM;
   }
-  lap("device alloc + H2D");
-  *out = g;
+  // grow the arena when the patched graph does not fit (raw CSR and flags move device-to-device)
+  if (e_new > g->cap_e) {
+    char *old_arena = g->arena;
+    const size_t old_bytes = g->arena_bytes;
+    const uint32_t old_cap = g->cap_e;
+    const uint32_t *o_rp = g->d_row_ptr[g->cur], *o_col = g->d_col[g->cur], *o_met = g->d_metric[g->cur];
+    const uint8_t *o_vf = g->d_vflags;
+    const uint32_t cap = e_new + std::max(e_new / 4, 1024u);
+    int rc = alloc_arena(ctx, g, n, cap);
+    if (rc != HSPF_OK) {
+      g->arena = old_arena; g->arena_bytes = old_bytes; g->cap_e = old_cap; g->layout(old_arena, n, old_cap);
+      return rc;
+    }
+    g->cur = 0;
+    hipError_t er = hipMemcpyAsync(g->d_row_ptr[0], o_rp, ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, s);
+    if (er == hipSuccess && g->e) er = hipMemcpyAsync(g->d_col[0], o_col, (size_t)g->e * 4, hipMemcpyDeviceToDevice, s);
+    if (er == hipSuccess && g->e) er = hipMemcpyAsync(g->d_metric[0], o_met, (size_t)g->e * 4, hipMemcpyDeviceToDevice, s);
+    if (er == hipSuccess) er = hipMemcpyAsync(g->d_vflags, o_vf, n, hipMemcpyDeviceToDevice, s);
+    if (er == hipSuccess) er = hipStreamSynchronize(s);
+    (void)hipFree(old_arena);
+    if (er != hipSuccess) { ctx->last_error = std::string("hspf_graph_patch: grow: ") + hipGetErrorString(er); return HSPF_E_HIP; }
+  }
+  // delta to the device: changed[m] | delta_ptr[m+1] | delta_col[de] | delta_metric[de] | flags[m]
+  const size_t dwords = (size_t)m + (m + 1) + 2 * (size_t)de;
+  int rc = ensure(ctx, ctx->gb_delta, dwords * 4 + m + 64);
+  if (rc != HSPF_OK) return rc;
+  uint32_t *d_changed = (uint32_t *)ctx->gb_delta.p;
+  uint32_t *d_dptr = d_changed + m, *d_dcol = d_dptr + m + 1, *d_dmet = d_dcol + de;
+  uint8_t *d_nf = (uint8_t *)(d_dmet + de);
+  const int nxt = g->cur ^ 1;
+  HIPCHK(ctx, hipMemcpyAsync(d_changed, rows->vertex, (size_t)m * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(d_dptr, rows->row_ptr, ((size_t)m + 1) * 4, hipMemcpyHostToDevice, s));
+  if (de) {
+    HIPCHK(ctx, hipMemcpyAsync(d_dcol, rows->col, (size_t)de * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(d_dmet, rows->metric, (size_t)de * 4, hipMemcpyHostToDevice, s));
+  }
+  HIPCHK(ctx, hipMemcpyAsync(d_nf, rows->vflags, m, hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(g->d_row_ptr[nxt], nrp.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+  if (e_new)
+    hipLaunchKernelGGL(kb_splice, dim3((e_new + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, e_new,
+                       (const uint32_t *)g->d_row_ptr[nxt], (const uint32_t *)g->d_row_ptr[g->cur],
+                       (const uint32_t *)g->d_col[g->cur], (const uint32_t *)g->d_metric[g->cur], m,
+                       (const uint32_t *)d_changed, (const uint32_t *)d_dptr, (const uint32_t *)d_dcol,
+                       (const uint32_t *)d_dmet, g->d_col[nxt], g->d_metric[nxt]);
+  hipLaunchKernelGGL(kb_set_vflags, dim3((m + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, m,
+                     (const uint32_t *)d_changed, (const uint8_t *)d_nf, g->d_vflags);
+  // the pageable host buffers above must be consumed before nrp goes out of scope: build_on_device
+  // synchronises the stream before returning
+  g->cur = nxt;
+  g->e = e_new;
+  for (uint32_t j = 0; j < m; ++j) g->vflags[rows->vertex[j]] = rows->vflags[j];
+  g->row_ptr.swap(nrp);
+  g->col.swap(ncol);
+  rc = build_on_device(ctx, g);
+  if (rc != HSPF_OK) (void)hipStreamSynchronize(s);
+  return rc;
+}
+
+int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *dst, size_t cap_bytes, size_t *out_bytes) {
+  if (!ctx || !g) return HSPF_E_INVAL;
+  const void *src = nullptr;
+  size_t bytes = 0;
+  const size_t nb = ((size_t)g->n + 1) * 4, eb = (size_t)g->e * 4, kb = (size_t)g->e_kept * 4;
+  switch (which) {
+    case HSPF_GX_ROW_PTR: src = g->d_row_ptr[g->cur]; bytes = nb; break;
+    case HSPF_GX_COL: src = g->d_col[g->cur]; bytes = eb; break;
+    case HSPF_GX_METRIC: src = g->d_metric[g->cur]; bytes = eb; break;
+    case HSPF_GX_VFLAGS: src = g->d_vflags; bytes = g->n; break;
+    case HSPF_GX_IN_PTR: src = g->d_in_ptr; bytes = nb; break;
+    case HSPF_GX_IN_SRC: src = g->d_in_src; bytes = kb; break;
+    case HSPF_GX_IN_COST: src = g->d_in_w; bytes = kb; break;
+    case HSPF_GX_IN_POS: src = g->d_in_fpos; bytes = kb; break;
+    case HSPF_GX_OUT_PTR: src = g->d_out_ptr; bytes = nb; break;
+    case HSPF_GX_OUT_DST: src = g->d_out_dst; bytes = kb; break;
+    case HSPF_GX_OUT_COST: src = g->d_out_w; bytes = kb; break;
+    case HSPF_GX_OUT_POS: src = g->d_out_fpos; bytes = kb; break;
+    case HSPF_GX_ROWFLAGS: src = g->d_rowflags; bytes = g->n; break;
+    case HSPF_GX_TWOWAY: bytes = g->e; break;                       // host mirror
+    default: ctx->last_error = "hspf_graph_export: unknown array"; return HSPF_E_INVAL;
+  }
+  if (out_bytes) *out_bytes = bytes;
+  if (!dst) return HSPF_OK;
+  if (cap_bytes < bytes) { ctx->last_error = "hspf_graph_export: buffer too small"; return HSPF_E_INVAL; }
+  if (which == HSPF_GX_TWOWAY) { if (bytes) memcpy(dst, g->twoway.data(), bytes); return HSPF_OK; }
+  (void)hipSetDevice(ctx->device);
+  if (bytes) {
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return HSPF_OK;
 }
 
 void hspf_graph_free(hspf_ctx *ctx, hspf_graph *g) {
   if (!g) return;
-  if (ctx) (void)hipSetDevice(ctx->device);
-  for (uint32_t *p : {g->d_in_ptr, g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_ptr, g->d_out_dst, g->d_out_w, g->d_out_fpos})
-    if (p) (void)hipFree(p);
-  if (g->d_vflags) (void)hipFree(g->d_vflags);
-  if (g->d_rowflags) (void)hipFree(g->d_rowflags);
+  if (ctx) { (void)hipSetDevice(ctx->device); if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); }
+  if (g->arena) (void)hipFree(g->arena);
   delete g;
 }
 
 uint32_t hspf_graph_n_vertices(const hspf_graph *g) { return g ? g->n : 0; }
 uint32_t hspf_graph_n_edges_kept(const hspf_graph *g) { return g ? g->e_kept : 0; }
+uint32_t hspf_graph_n_edges(const hspf_graph *g) { return g ? g->e : 0; }
 
 // ---- slots ------------------------------------------------------------------------------------
 

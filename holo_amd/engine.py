@@ -48,6 +48,31 @@ def _u32(a):
     return a.ctypes.data_as(L.u32p)
 
 
+def splice_rows(row_ptr, col, metric, vflags, vertices, cols, mets, new_flags):
+    """CSR with the rows of `vertices` (ascending) replaced — the host-side twin of hspf_graph_patch."""
+    n = len(row_ptr) - 1
+    lens = np.diff(row_ptr.astype(np.int64))
+    for v, c in zip(vertices, cols):
+        lens[int(v)] = len(c)
+    nrp = np.zeros(n + 1, np.int64)
+    nrp[1:] = np.cumsum(lens)
+    ncol = np.empty(int(nrp[-1]), np.uint32)
+    nmet = np.empty(int(nrp[-1]), np.uint32)
+    prev = 0
+    for v, c, m in list(zip(vertices, cols, mets)) + [(n, None, None)]:
+        v = int(v)
+        a, b = int(row_ptr[prev]), int(row_ptr[v])                  # unchanged rows [prev, v)
+        ncol[nrp[prev]:nrp[prev] + (b - a)] = col[a:b]
+        nmet[nrp[prev]:nrp[prev] + (b - a)] = metric[a:b]
+        if c is not None:
+            ncol[nrp[v]:nrp[v + 1]] = c
+            nmet[nrp[v]:nrp[v + 1]] = m
+        prev = v + 1
+    nvf = vflags.copy()
+    nvf[np.asarray(vertices, dtype=np.int64)] = new_flags
+    return nrp.astype(np.uint32), ncol, nmet, nvf
+
+
 class SpfGraph:
     """Device-resident graph of one LSDB generation (hspf_graph)."""
 
@@ -69,6 +94,47 @@ class SpfGraph:
     @property
     def n_edges_kept(self) -> int:
         return int(self.ctx.lib.hspf_graph_n_edges_kept(self.handle))
+
+    # arrays of the device-resident graph (HSPF_GX_*)
+    GX = {"row_ptr": (0, np.uint32), "col": (1, np.uint32), "metric": (2, np.uint32), "vflags": (3, np.uint8),
+          "in_ptr": (4, np.uint32), "in_src": (5, np.uint32), "in_cost": (6, np.uint32), "in_pos": (7, np.uint32),
+          "out_ptr": (8, np.uint32), "out_dst": (9, np.uint32), "out_cost": (10, np.uint32),
+          "out_pos": (11, np.uint32), "rowflags": (12, np.uint8), "twoway": (13, np.uint8)}
+
+    def export(self, name: str) -> np.ndarray:
+        """One array of the graph as it sits on the device (hspf_graph_export)."""
+        which, dt = self.GX[name]
+        nbytes = ctypes.c_size_t()
+        rc = self.ctx.lib.hspf_graph_export(self.ctx.handle, self.handle, which, None, 0, ctypes.byref(nbytes))
+        if rc != 0:
+            raise HspfError(rc, "hspf_graph_export", self.ctx.last_error())
+        out = np.empty(nbytes.value // np.dtype(dt).itemsize, dt)
+        rc = self.ctx.lib.hspf_graph_export(self.ctx.handle, self.handle, which, out.ctypes.data_as(ctypes.c_void_p),
+                                            out.nbytes, ctypes.byref(nbytes))
+        if rc != 0:
+            raise HspfError(rc, "hspf_graph_export", self.ctx.last_error())
+        return out
+
+    def patch(self, vertices, rows, vflags) -> None:
+        """Replace whole rows (hspf_graph_patch): `rows[i]` = (col array, metric array) of `vertices[i]`,
+        `vflags[i]` its new flags.  The numpy mirrors of the CSR are spliced the same way."""
+        order = np.argsort(np.asarray(vertices, dtype=np.int64), kind="stable")
+        vs = np.ascontiguousarray(np.asarray(vertices, dtype=np.uint32)[order])
+        cols = [np.asarray(rows[i][0], dtype=np.uint32) for i in order]
+        mets = [np.asarray(rows[i][1], dtype=np.uint32) for i in order]
+        nf = np.ascontiguousarray(np.asarray(vflags, dtype=np.uint8)[order])
+        rp = np.zeros(len(vs) + 1, np.uint32)
+        rp[1:] = np.cumsum([len(c) for c in cols], dtype=np.uint64)
+        dcol = np.ascontiguousarray(np.concatenate(cols)) if cols else np.zeros(0, np.uint32)
+        dmet = np.ascontiguousarray(np.concatenate(mets)) if mets else np.zeros(0, np.uint32)
+        if len(dcol) == 0:
+            dcol = np.zeros(1, np.uint32); dmet = np.zeros(1, np.uint32)     # non-NULL pointers
+        r = L.HspfRows(len(vs), _u32(vs), _u32(rp), _u32(dcol), _u32(dmet), nf.ctypes.data_as(L.u8p))
+        rc = self.ctx.lib.hspf_graph_patch(self.ctx.handle, self.handle, ctypes.byref(r))
+        if rc != 0:
+            raise HspfError(rc, "hspf_graph_patch", self.ctx.last_error())
+        self.row_ptr, self.col, self.metric, self.vflags = splice_rows(
+            self.row_ptr, self.col, self.metric, self.vflags, vs, cols, mets, nf)
 
     def mask_words(self, roots) -> int:
         roots = np.ascontiguousarray(roots, dtype=np.uint32)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HSPF_ABI_VERSION 1u
+#define HSPF_ABI_VERSION 2u
 
 /* ---- error codes ------------------------------------------------------------------- */
 #define HSPF_OK                 0
@@ -165,7 +165,50 @@ void       *hspf_get_stream(const hspf_ctx *ctx);
 int      hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out);
 void     hspf_graph_free(hspf_ctx *ctx, hspf_graph *g);
 uint32_t hspf_graph_n_vertices(const hspf_graph *g);
+uint32_t hspf_graph_n_edges(const hspf_graph *g);          /* links of the caller's CSR (after patches) */
 uint32_t hspf_graph_n_edges_kept(const hspf_graph *g);     /* links surviving the two-way check */
+
+/*
+ * Incremental update.  An LSP / LSA that is re-originated, purged or aged out changes
+ * exactly the links OUT OF its own vertex and that vertex's gates — holo-isis keys a partial run by the
+ * changed LSPs (`trigger_lsps`, holo-isis/src/spf.rs:144,735), holo-ospf by the changed LSAs
+ * (`SpfTriggerLsa`, holo-ospf/src/spf.rs:120-139) — so the unit of change is "replace whole rows":
+ * for each listed vertex the new row (links in LSA order, as in hspf_csr) and its new flags.  The vertex set
+ * is fixed; a new or vanished vertex needs a fresh hspf_graph_upload.  After the call the graph is
+ * indistinguishable from one uploaded from the patched CSR (two-way check, kept links and the whole device
+ * layout are rebuilt on the device from the resident CSR; only the replaced rows cross the bus).
+ * On HSPF_E_INVAL nothing has changed; after HSPF_E_HIP / HSPF_E_NOMEM the graph must be freed.
+ */
+typedef struct {
+  uint32_t        n_changed;
+  const uint32_t *vertex;     /* [n_changed]   strictly ascending vertex indices                   */
+  const uint32_t *row_ptr;    /* [n_changed+1] bounds of the replacement rows inside col / metric  */
+  const uint32_t *col;        /* [row_ptr[n_changed]]                                              */
+  const uint32_t *metric;     /* [row_ptr[n_changed]]                                              */
+  const uint8_t  *vflags;     /* [n_changed]   HSPF_VF_* of those vertices after the change        */
+} hspf_rows;
+int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows);
+
+/* Copies one array of the device-resident graph back to the host (inspection, tests, debugging).
+ * dst == NULL: only *out_bytes is set.  The layout: kept links = two-way and source expandable; in-rows
+ * (links INTO a vertex) ordered by (cost descending, source ascending, position in the source row
+ * ascending), IN_SRC carries the source's HSPF_VF_NO_TRANSIT in bit 31; out-rows in the caller's order. */
+#define HSPF_GX_ROW_PTR   0u   /* u32 [n+1]    caller's CSR as resident on the device             */
+#define HSPF_GX_COL       1u   /* u32 [e]                                                         */
+#define HSPF_GX_METRIC    2u   /* u32 [e]                                                         */
+#define HSPF_GX_VFLAGS    3u   /* u8  [n]                                                         */
+#define HSPF_GX_IN_PTR    4u   /* u32 [n+1]                                                       */
+#define HSPF_GX_IN_SRC    5u   /* u32 [kept]                                                      */
+#define HSPF_GX_IN_COST   6u   /* u32 [kept]                                                      */
+#define HSPF_GX_IN_POS    7u   /* u32 [kept]   position of the link inside its source row         */
+#define HSPF_GX_OUT_PTR   8u   /* u32 [n+1]                                                       */
+#define HSPF_GX_OUT_DST   9u   /* u32 [kept]                                                      */
+#define HSPF_GX_OUT_COST 10u   /* u32 [kept]                                                      */
+#define HSPF_GX_OUT_POS  11u   /* u32 [kept]                                                      */
+#define HSPF_GX_ROWFLAGS 12u   /* u8  [n]      internal per-row flags of the fused sweep          */
+#define HSPF_GX_TWOWAY   13u   /* u8  [e]      1 = the target's row lists the source              */
+int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *dst, size_t cap_bytes,
+                      size_t *out_bytes);
 
 /* ---- first-hop slots -------------------------------------------------------------------- */
 /* Number of u64 mask words needed for these roots on this graph (>= 1). */

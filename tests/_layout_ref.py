@@ -1,0 +1,52 @@
+"""CPU restatement (numpy + plain loops) of the device graph layout that hspf_graph_upload / hspf_graph_patch
+build with the kernels of holo_amd/csrc/graph_build.hip.h.  TEST INFRASTRUCTURE ONLY.
+
+Semantics restated (include/holo_spf_hip.h, hspf_graph_export):
+  two-way check   link u->t usable iff row t lists u, cost not compared
+                  (holo-ospf/src/spf.rs:654-664, holo-isis/src/spf.rs:616-627)
+  kept            two-way and the source may be expanded (not HSPF_VF_NO_EXPAND, holo-isis/src/spf.rs:557-604)
+  out-rows        kept links in the caller's order
+  in-rows         kept links into a vertex by (cost descending, source ascending, position ascending);
+                  bit 31 of the source = HSPF_VF_NO_TRANSIT of the source
+"""
+import numpy as np
+
+VF_NETWORK, VF_NO_TRANSIT, VF_NO_EXPAND = 1, 2, 4
+RF_MANY, RF_NT, RF_ZERO = 1, 2, 4
+
+
+def layout(row_ptr, col, metric, vflags):
+    n = len(row_ptr) - 1
+    rp = row_ptr.astype(np.int64)
+    src = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+    pos = np.arange(len(col), dtype=np.int64) - rp[src]
+    rows = [set(col[rp[u]:rp[u + 1]].tolist()) for u in range(n)]
+    twoway = np.array([int(src[k]) in rows[int(col[k])] for k in range(len(col))], dtype=np.uint8)
+    keep = (twoway == 1) & ((vflags[src] & VF_NO_EXPAND) == 0) if len(col) else np.zeros(0, bool)
+    ks, kt, kw, kp = src[keep], col[keep].astype(np.int64), metric[keep].astype(np.int64), pos[keep]
+    out_ptr = np.zeros(n + 1, np.int64)
+    np.add.at(out_ptr, ks + 1, 1)
+    out_ptr = np.cumsum(out_ptr)
+    order = np.lexsort((kp, ks, -kw, kt))                 # target, cost desc, source, position
+    in_ptr = np.zeros(n + 1, np.int64)
+    np.add.at(in_ptr, kt + 1, 1)
+    in_ptr = np.cumsum(in_ptr)
+    nt = (vflags[ks[order]] & VF_NO_TRANSIT) != 0
+    in_src = (ks[order] | (nt.astype(np.int64) << 31)).astype(np.uint32)
+    rowflags = np.zeros(n, np.uint8)
+    t_o, w_o, s_o = kt[order], kw[order], ks[order]
+    for t in range(n):
+        a, b = in_ptr[t], in_ptr[t + 1]
+        f = RF_MANY if b - a > 16 else 0
+        if nt[a:b].any():
+            f |= RF_NT
+        if ((w_o[a:b] == 0) & (s_o[a:b] >= t)).any():
+            f |= RF_ZERO
+        rowflags[t] = f
+    return {
+        "twoway": twoway,
+        "in_ptr": in_ptr.astype(np.uint32), "in_src": in_src, "in_cost": w_o.astype(np.uint32),
+        "in_pos": kp[order].astype(np.uint32),
+        "out_ptr": out_ptr.astype(np.uint32), "out_dst": kt.astype(np.uint32), "out_cost": kw.astype(np.uint32),
+        "out_pos": kp.astype(np.uint32), "rowflags": rowflags,
+    }

@@ -1,0 +1,218 @@
+"""Graph construction on the device (hspf_graph_upload) and incremental row replacement
+(hspf_graph_patch): the exported device layout against the CPU restatement in
+tests/_layout_ref.py, a patched graph against a fresh upload of the patched CSR array by array, and SPF on
+the patched graph against the oracle."""
+import numpy as np
+import pytest
+
+from holo_amd import synth
+from holo_amd import engine as E
+from oracle import graph_oracle as go
+from _layout_ref import layout
+
+pytestmark = pytest.mark.gpu
+
+BUILT = ("twoway", "in_ptr", "in_src", "in_cost", "in_pos", "out_ptr", "out_dst", "out_cost", "out_pos", "rowflags")
+RAW = ("row_ptr", "col", "metric", "vflags")
+
+
+def assert_layout(G, g):
+    want = layout(g.row_ptr, g.col, g.metric, g.vflags)
+    for name in BUILT:
+        got = G.export(name)
+        assert np.array_equal(got, want[name]), name
+    for name in RAW:
+        assert np.array_equal(G.export(name), getattr(g, name)), name
+    assert G.n_edges_kept == len(want["in_src"])
+
+
+def graphs():
+    yield synth.random_lsdb(60, 8, 3.0, 1, metric_hi=6)
+    yield synth.random_lsdb(90, 10, 2.5, 2, metric_hi=3, p_oneway=0.3, p_parallel=0.4, p_noexpand=0.2, p_overload=0.3)
+    yield synth.random_lsdb(50, 8, 2.5, 3, hopcount=True)
+    yield synth.random_lsdb(40, 1, 3.0, 4, lan_size=40)                 # one LAN with 40 members: rows > 16 links
+    yield synth.random_lsdb(3000, 100, 4.0, 5, metric_hi=2, zero_cost_router_links=True)   # several scan tiles
+    yield synth.ospf_500()
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_device_layout_matches_restatement(spf_ctx, i):
+    g = list(graphs())[i]
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        assert_layout(G, g)
+    finally:
+        G.free()
+
+
+def test_graph_without_links_and_single_vertex(spf_ctx):
+    for n in (1, 5):
+        g = synth.CsrGraph(np.zeros(n + 1, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(n, np.uint8))
+        G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        assert_layout(G, g)
+        res = spf_ctx.run(G, [0])
+        assert res.dist[0, 0] == 0 and (res.dist[0, 1:] == E.DIST_INF).all()
+        G.free()
+
+
+def test_upload_rejects_bad_links_with_a_code(spf_ctx):
+    g = synth.ospf_500()
+    col = g.col.copy(); col[123] = g.n
+    with pytest.raises(E.HspfError) as ei:
+        spf_ctx.upload(g.row_ptr, col, g.metric, g.vflags, g.max_path_metric)
+    assert ei.value.code == -1 and "col out of range" in str(ei.value)
+    met = g.metric.copy(); met[7] = 0xFFFFFFFF
+    with pytest.raises(E.HspfError) as ei:
+        spf_ctx.upload(g.row_ptr, g.col, met, g.vflags, g.max_path_metric)
+    assert ei.value.code == -1 and "reserved" in str(ei.value)
+
+
+def random_rows(g, rng, k, grow=0):
+    """k replacement rows: links dropped, re-costed, re-ordered, added (also one-way ones), flags flipped."""
+    n = g.n
+    vs = np.sort(rng.choice(n, size=min(k, n), replace=False))
+    rows, flags = [], []
+    nn = g.meta.get("n_networks", 0)
+    for v in vs.tolist():
+        c = g.col[g.row_ptr[v]:g.row_ptr[v + 1]].copy()
+        m = g.metric[g.row_ptr[v]:g.row_ptr[v + 1]].copy()
+        keep = rng.random(len(c)) > 0.3
+        c, m = c[keep], m[keep]
+        if len(m) and v >= nn:
+            m = np.where(rng.random(len(m)) < 0.5, rng.integers(1, 7, len(m)), m).astype(np.uint32)
+        extra = rng.integers(0, 4) + grow
+        if v >= nn and extra:
+            ec = rng.integers(nn, n, extra).astype(np.uint32)          # router -> router, mostly one-way
+            c = np.concatenate([c, ec]); m = np.concatenate([m, rng.integers(1, 7, extra).astype(np.uint32)])
+        p = rng.permutation(len(c))
+        rows.append((c[p], m[p]))
+        f = int(g.vflags[v])
+        if v >= nn and rng.random() < 0.3:
+            f ^= synth.VF_NO_TRANSIT
+        if rng.random() < 0.2:
+            f ^= synth.VF_NO_EXPAND
+        flags.append(f)
+    return vs, rows, np.array(flags, np.uint8)
+
+
+def check_spf(ctx, G, g, roots, run_flags=0):
+    res = ctx.run(G, roots, run_flags)
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, np.asarray(roots, np.uint32), run_flags & 3,
+                 go.MAP, mask_words_=res.first_hop_mask.shape[2])
+    assert np.array_equal(res.dist, ref.dist)
+    assert np.array_equal(res.hops, ref.hops)
+    assert np.array_equal(res.flags & 1, ref.flags)
+    assert np.array_equal(res.first_hop_mask, ref.mask)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_patch_equals_fresh_upload(spf_ctx, seed):
+    rng = np.random.default_rng(seed)
+    g = synth.random_lsdb(70, 9, 3.0, 700 + seed, metric_hi=6)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    roots = np.arange(9, 9 + 40, dtype=np.uint32)
+    try:
+        for rnd in range(4):
+            vs, rows, flags = random_rows(g, rng, [1, 3, 10, 79][rnd])
+            G.patch(vs, rows, flags)
+            g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
+            F = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+            try:
+                for name in BUILT + RAW:
+                    assert np.array_equal(G.export(name), F.export(name)), (rnd, name)
+                assert G.n_edges_kept == F.n_edges_kept
+            finally:
+                F.free()
+            assert_layout(G, g)
+            check_spf(spf_ctx, G, g, roots, E.RUN_NET_NEXTHOPS)
+    finally:
+        G.free()
+
+
+def test_patch_grows_past_the_spare_capacity(spf_ctx):
+    rng = np.random.default_rng(11)
+    g = synth.random_lsdb(200, 10, 3.0, 811, metric_hi=5)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        for _ in range(3):                                   # +~4000 links per round, spare capacity is 1024
+            vs, rows, flags = random_rows(g, rng, 40, grow=100)
+            G.patch(vs, rows, flags)
+            g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
+            assert_layout(G, g)
+        check_spf(spf_ctx, G, g, np.arange(10, 74, dtype=np.uint32))
+    finally:
+        G.free()
+
+
+def test_patch_hopcount_shape_follows_the_links(spf_ctx):
+    """A hop-count graph (every root on the fused path) stops being one when a row gets real metrics, and is one
+    again when the row is restored; results match the oracle in all three states."""
+    g0 = synth.random_lsdb(50, 8, 2.5, 301, hopcount=True)
+    G = spf_ctx.upload(g0.row_ptr, g0.col, g0.metric, g0.vflags, g0.max_path_metric)
+    roots = np.arange(8, 8 + 20, dtype=np.uint32)
+    try:
+        check_spf(spf_ctx, G, g0, roots, E.RUN_IGNORE_OVERLOAD)
+        exact0 = spf_ctx.stats()["n_exact_roots"]
+        v = 20
+        c = g0.col[g0.row_ptr[v]:g0.row_ptr[v + 1]]; m = g0.metric[g0.row_ptr[v]:g0.row_ptr[v + 1]]
+        G.patch([v], [(c, m + 3)], [g0.vflags[v]])
+        g1 = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g0.max_path_metric)
+        check_spf(spf_ctx, G, g1, roots, E.RUN_IGNORE_OVERLOAD)
+        G.patch([v], [(c, m)], [g0.vflags[v]])
+        assert np.array_equal(G.col, g0.col) and np.array_equal(G.metric, g0.metric)
+        check_spf(spf_ctx, G, g0, roots, E.RUN_IGNORE_OVERLOAD)
+        assert spf_ctx.stats()["n_exact_roots"] == exact0
+    finally:
+        G.free()
+
+
+def test_invalid_patch_changes_nothing(spf_ctx):
+    g = synth.random_lsdb(60, 8, 3.0, 5, metric_hi=6)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        before = {name: G.export(name) for name in BUILT + RAW}
+        bad = [
+            ([10, 10], [([9], [1]), ([9], [1])], [0, 0]),            # not strictly ascending
+            ([g.n], [([9], [1])], [0]),                              # vertex out of range
+            ([10], [([g.n], [1])], [0]),                             # target out of range
+            ([10], [([9], [0xFFFFFFFF])], [0]),                      # reserved cost
+        ]
+        for vs, rows, fl in bad:
+            with pytest.raises(E.HspfError) as ei:
+                G.patch(vs, rows, fl)
+            assert ei.value.code == -1
+        for name in BUILT + RAW:
+            assert np.array_equal(G.export(name), before[name]), name
+        assert np.array_equal(G.col, g.col)
+    finally:
+        G.free()
+
+
+def test_patch_full_size_router_purge_and_return(spf_ctx):
+    """isis-100k: one router's LSP is purged (its row becomes empty: every link to it now fails the two-way check on
+    the unchanged rows of its neighbours) and re-originated; the patched graph gives the results of a fresh upload,
+    and the return restores the original results bit for bit."""
+    g = synth.isis_100k()
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    roots = (np.arange(64, dtype=np.uint64) * g.n // 64).astype(np.uint32)
+    try:
+        base = spf_ctx.run(G, roots)
+        u = 5000
+        a, b = int(g.row_ptr[u]), int(g.row_ptr[u + 1])
+        row_u = (g.col[a:b].copy(), g.metric[a:b].copy())
+        kept0 = G.n_edges_kept
+        G.patch([u], [(np.zeros(0, np.uint32), np.zeros(0, np.uint32))], [g.vflags[u]])
+        assert G.n_edges_kept == kept0 - 2 * (b - a)
+        F = spf_ctx.upload(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
+        r1, r2 = spf_ctx.run(G, roots), spf_ctx.run(F, roots)
+        F.free()
+        for f in ("dist", "hops", "flags", "first_hop_mask"):
+            assert np.array_equal(getattr(r1, f), getattr(r2, f)), f
+        assert (r1.dist[:, u] == E.DIST_INF).all() and (base.dist[:, u] != E.DIST_INF).all()
+        G.patch([u], [row_u], [g.vflags[u]])
+        assert G.n_edges_kept == kept0
+        r3 = spf_ctx.run(G, roots)
+        for f in ("dist", "hops", "flags", "first_hop_mask"):
+            assert np.array_equal(getattr(r3, f), getattr(base, f)), f
+    finally:
+        G.free()
