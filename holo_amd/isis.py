@@ -248,10 +248,8 @@ class LevelGraph:
         lsdb = instance.lsdb.get(level) or Lsdb()
         self.level, self.mt_id, self.hopcount = level, mt_id, hopcount
         self.metric_type = cfg.metric_type[level]
-        frags: Dict[LanId, List[Lsp]] = {}
-        for l in lsdb.iter():
-            if l.live():
-                frags.setdefault(l.lan_id, []).append(l)
+        self.cfg_key = self._cfg_key(cfg, level)
+        frags = self._live_fragments(lsdb)
         self.vids: List[VertexId] = sorted(vertex_id(k) for k in frags)
         self.index: Dict[VertexId, int] = {v: i for i, v in enumerate(self.vids)}
         n = len(self.vids)
@@ -259,28 +257,11 @@ class LevelGraph:
         col, met = [], []
         vflags = np.zeros(n, np.uint8)
         for i, vid in enumerate(self.vids):
-            lan = (vid[1], vid[2])
-            for lsp in frags[lan]:
-                for nbr, c in vertex_edges(lsp, mt_id, hopcount, self.metric_type):
-                    j = self.index.get(vertex_id(nbr))
-                    if j is not None:
-                        col.append(j)
-                        met.append(c)
+            c, m, f = self._row((vid[1], vid[2]), frags, lsdb, cfg)
+            col += c
+            met += m
+            vflags[i] = f
             row_ptr[i + 1] = len(col)
-            is_pn = lan[1] != 0
-            if is_pn:
-                vflags[i] |= VF_NETWORK
-            z = lsdb.zeroth_lsp(lan)
-            if z is None:
-                vflags[i] |= VF_NO_EXPAND                          # spf.rs:557-561
-                continue
-            if not is_pn and mt_id is not None and z.overload_bit(mt_id):
-                vflags[i] |= VF_NO_TRANSIT                         # spf.rs:568-574
-            if mt_id is not None and mt_id == MT_STANDARD and not is_pn:   # spf.rs:582-604
-                ps = z.protocols_supported
-                if ps is None or (cfg.is_af_enabled("ipv4") and NLPID_IPV4 not in ps) \
-                        or (cfg.is_af_enabled("ipv6") and NLPID_IPV6 not in ps):
-                    vflags[i] |= VF_NO_EXPAND
         self.row_ptr = row_ptr
         self.col = np.asarray(col, np.uint32)
         self.metric = np.asarray(met, np.uint32)
@@ -289,6 +270,71 @@ class LevelGraph:
                                 else MAX_PATH_METRIC_WIDE)                 # spf.rs:637-641
         self.run_flags = E.RUN_IGNORE_OVERLOAD if mt_id is None else 0    # spf.rs:566-574
         self._dev = None
+
+    @staticmethod
+    def _cfg_key(cfg: InstanceCfg, level: int):
+        """Everything outside the LSDB that a row depends on (vertex_edges' TLV choice, the gates)."""
+        return (cfg.metric_type[level], cfg.is_af_enabled("ipv4"), cfg.is_af_enabled("ipv6"))
+
+    @staticmethod
+    def _live_fragments(lsdb: Lsdb) -> Dict[LanId, List[Lsp]]:
+        frags: Dict[LanId, List[Lsp]] = {}
+        for l in lsdb.iter():
+            if l.live():
+                frags.setdefault(l.lan_id, []).append(l)
+        return frags
+
+    def _row(self, lan: LanId, frags, lsdb: Lsdb, cfg: InstanceCfg):
+        """Links (in fragment, then TLV order: spf.rs:1013-1128) and gate flags (spf.rs:557-604) of one vertex."""
+        col, met = [], []
+        for lsp in frags[lan]:
+            for nbr, c in vertex_edges(lsp, self.mt_id, self.hopcount, self.metric_type):
+                j = self.index.get(vertex_id(nbr))
+                if j is not None:
+                    col.append(j)
+                    met.append(c)
+        is_pn = lan[1] != 0
+        f = VF_NETWORK if is_pn else 0
+        z = lsdb.zeroth_lsp(lan)
+        if z is None:
+            return col, met, f | VF_NO_EXPAND                           # spf.rs:557-561
+        if not is_pn and self.mt_id is not None and z.overload_bit(self.mt_id):
+            f |= VF_NO_TRANSIT                                          # spf.rs:568-574
+        if self.mt_id is not None and self.mt_id == MT_STANDARD and not is_pn:   # spf.rs:582-604
+            ps = z.protocols_supported
+            if ps is None or (cfg.is_af_enabled("ipv4") and NLPID_IPV4 not in ps) \
+                    or (cfg.is_af_enabled("ipv6") and NLPID_IPV6 not in ps):
+                f |= VF_NO_EXPAND
+        return col, met, f
+
+    def refresh(self, instance: Instance, changed: Iterable[LanId]) -> bool:
+        """Incremental re-derivation after the LSPs of `changed` LAN ids were re-originated, purged or aged out
+        (the reference's `trigger_lsps`, holo-isis/src/spf.rs:144,735): only their rows are rebuilt and — when the
+        graph is on the device — replaced there by hspf_graph_patch.  Returns False, leaving everything untouched,
+        when the change cannot be expressed as row replacements (a vertex appeared or vanished, or the
+        configuration the rows depend on changed): the caller builds a new LevelGraph."""
+        cfg = instance.config
+        lsdb = instance.lsdb.get(self.level) or Lsdb()
+        if self._cfg_key(cfg, self.level) != self.cfg_key:
+            return False
+        frags = self._live_fragments(lsdb)
+        if len(frags) != len(self.vids) or any(vertex_id(k) not in self.index for k in frags):
+            return False
+        vs = sorted({self.index[vertex_id(lan)] for lan in changed if vertex_id(lan) in self.index})
+        if not vs:
+            return True
+        rows, flags = [], []
+        for i in vs:
+            vid = self.vids[i]
+            c, m, f = self._row((vid[1], vid[2]), frags, lsdb, cfg)
+            rows.append((np.asarray(c, np.uint32), np.asarray(m, np.uint32)))
+            flags.append(f)
+        if self._dev is not None:
+            self._dev[1].patch(vs, rows, flags)
+        self.row_ptr, self.col, self.metric, self.vflags = E.splice_rows(
+            self.row_ptr, self.col, self.metric, self.vflags, vs, [r[0] for r in rows], [r[1] for r in rows],
+            np.asarray(flags, np.uint8))
+        return True
 
     @property
     def n(self) -> int:
@@ -687,9 +733,45 @@ def compute_routes(level: int, mt_id: int, instance: Instance, spt: Spt, rib: Di
                 cur.nexthops = {k: cur.nexthops[k] for k in sorted(cur.nexthops)[:cfg.max_paths]}
 
 
-def compute_spf(instance: Instance, engine) -> List[dict]:
+class GraphCache:
+    """Device graphs kept across SPF runs, one per (level, topology, metric mode), brought up to date from the
+    changed LSPs instead of being re-derived from the whole LSDB."""
+
+    def __init__(self):
+        self.graphs: Dict[tuple, LevelGraph] = {}
+        self.rebuilt = 0
+        self.patched = 0
+
+    def get(self, instance: Instance, level: int, mt_id: Optional[int], hopcount: bool = False,
+            trigger_lsps: Optional[Iterable[LanId]] = None) -> LevelGraph:
+        """`trigger_lsps` = LAN ids whose LSPs changed since the previous call for this instance (None: unknown,
+        rebuild)."""
+        key = (level, mt_id, hopcount)
+        g = self.graphs.get(key)
+        if g is not None and trigger_lsps is not None and g.refresh(instance, trigger_lsps):
+            self.patched += 1
+            return g
+        if g is not None and g._dev is not None:
+            g._dev[1].free()
+        g = self.graphs[key] = LevelGraph(instance, level, mt_id, hopcount)
+        self.rebuilt += 1
+        return g
+
+
+def changed_lan_ids(old: Lsdb, new: Lsdb) -> List[LanId]:
+    """LAN ids with an LSP fragment that differs between two LSDB snapshots (what the reference accumulates in
+    `trigger_lsps` as LSPs are installed, holo-isis/src/lsdb.rs)."""
+    a = {(l.system_id, l.pseudonode, l.fragment): l for l in old.iter()}
+    b = {(l.system_id, l.pseudonode, l.fragment): l for l in new.iter()}
+    return sorted({(k[0], k[1]) for k in set(a) | set(b) if a.get(k) != b.get(k)})
+
+
+def compute_spf(instance: Instance, engine, cache: Optional[GraphCache] = None,
+                trigger_lsps: Optional[Dict[int, Iterable[LanId]]] = None) -> List[dict]:
     """Full SPF of every configured level and topology (holo-isis/src/spf.rs:719-836) followed by
-    the L1/L2 merge of holo-isis/src/route.rs:185-249; returns the rows of the YANG `local-rib`."""
+    the L1/L2 merge of holo-isis/src/route.rs:185-249; returns the rows of the YANG `local-rib`.
+    With a GraphCache the level graphs persist on the device between calls and `trigger_lsps[level]` (changed LAN
+    ids) turns the LSDB -> CSR step into row patches."""
     cfg = instance.config
     per_level: Dict[int, Dict[tuple, Route]] = {}
     for level in cfg.levels():
@@ -698,7 +780,11 @@ def compute_spf(instance: Instance, engine) -> List[dict]:
         rib: Dict[tuple, Route] = {}
         for mt_id in (MT_STANDARD, MT_IPV6_UNICAST):
             if cfg.is_topology_enabled(mt_id):
-                spt = compute_spt(level, cfg.system_id, True, mt_id, False, instance, engine)
+                graph = None
+                if cache is not None:
+                    graph = cache.get(instance, level, mt_id, False,
+                                      None if trigger_lsps is None else trigger_lsps.get(level, ()))
+                spt = compute_spt(level, cfg.system_id, True, mt_id, False, instance, engine, graph)
                 compute_routes(level, mt_id, instance, spt, rib)
         per_level[level] = rib
     merged: Dict[tuple, Route] = {}

@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import ipaddress
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Tuple
+from typing import Iterable, Dict, List, Optional, Tuple
 
 import numpy as np
 
@@ -106,43 +106,88 @@ class AreaGraph:
 
     def __init__(self, area: Area):
         self.area = area
-        self.routers: Dict[int, RouterLsa] = {ip(l.adv_rtr): l for l in area.routers if not l.maxage}
-        nets: Dict[int, NetworkLsa] = {}
-        # vertex_lsa_find for a network: FIRST Network-LSA in (adv_rtr, lsa_id) order whose LS-ID
-        # matches, then dropped if MaxAge (ospfv2/spf.rs:362-373)
-        for l in sorted(area.networks, key=lambda l: (ip(l.adv_rtr), ip(l.lsa_id))):
-            nets.setdefault(ip(l.lsa_id), l)
-        self.networks = {k: l for k, l in nets.items() if not l.maxage}
+        self.routers, self.networks = self._live_lsas(area)
         self.vids: List[VertexId] = sorted([(NET, k) for k in self.networks] + [(RTR, k) for k in self.routers])
         self.index = {v: i for i, v in enumerate(self.vids)}
         n = len(self.vids)
         row_ptr = np.zeros(n + 1, np.uint32)
         col, met, self.link_pos, self.link_ref = [], [], [], []
         for i, vid in enumerate(self.vids):
-            if vid[0] == NET:
-                for r in sorted(ip(a) for a in self.networks[vid[1]].attached):
-                    j = self.index.get((RTR, r))
-                    if j is not None:
-                        col.append(j); met.append(0); self.link_pos.append(-1); self.link_ref.append(None)
-            else:
-                pos = -1
-                for link in self.routers[vid[1]].links:
-                    if link.link_type in ("point-to-point-link", "virtual-link"):
-                        tid = (RTR, ip(link.link_id))
-                    elif link.link_type == "transit-network-link":
-                        tid = (NET, ip(link.link_id))
-                    else:
-                        continue
-                    pos += 1
-                    j = self.index.get(tid)
-                    if j is not None:
-                        col.append(j); met.append(link.metric); self.link_pos.append(pos); self.link_ref.append(link)
+            c, m, pos, ref = self._row(vid)
+            col += c; met += m; self.link_pos += pos; self.link_ref += ref
             row_ptr[i + 1] = len(col)
         self.row_ptr = row_ptr
         self.col = np.asarray(col, np.uint32)
         self.metric = np.asarray(met, np.uint32)
         self.vflags = np.asarray([VF_NETWORK if v[0] == NET else 0 for v in self.vids], np.uint8)
         self._dev = None
+
+    @staticmethod
+    def _live_lsas(area: Area):
+        routers: Dict[int, RouterLsa] = {ip(l.adv_rtr): l for l in area.routers if not l.maxage}
+        nets: Dict[int, NetworkLsa] = {}
+        # vertex_lsa_find for a network: FIRST Network-LSA in (adv_rtr, lsa_id) order whose LS-ID
+        # matches, then dropped if MaxAge (ospfv2/spf.rs:362-373)
+        for l in sorted(area.networks, key=lambda l: (ip(l.adv_rtr), ip(l.lsa_id))):
+            nets.setdefault(ip(l.lsa_id), l)
+        return routers, {k: l for k, l in nets.items() if not l.maxage}
+
+    def _row(self, vid: VertexId):
+        """vertex_lsa_links (ospfv2/spf.rs:389-460) of one vertex against the current vertex set."""
+        col, met, lpos, ref = [], [], [], []
+        if vid[0] == NET:
+            for r in sorted(ip(a) for a in self.networks[vid[1]].attached):
+                j = self.index.get((RTR, r))
+                if j is not None:
+                    col.append(j); met.append(0); lpos.append(-1); ref.append(None)
+            return col, met, lpos, ref
+        pos = -1
+        for link in self.routers[vid[1]].links:
+            if link.link_type in ("point-to-point-link", "virtual-link"):
+                tid = (RTR, ip(link.link_id))
+            elif link.link_type == "transit-network-link":
+                tid = (NET, ip(link.link_id))
+            else:
+                continue
+            pos += 1
+            j = self.index.get(tid)
+            if j is not None:
+                col.append(j); met.append(link.metric); lpos.append(pos); ref.append(link)
+        return col, met, lpos, ref
+
+    def refresh(self, area: Area, changed: Iterable[VertexId]) -> bool:
+        """Bring the graph forward to `area` (a later state of the same area's LSDB) when only the LSAs of the
+        `changed` vertices were re-originated (the reference's SpfTriggerLsa list, holo-ospf/src/spf.rs:120-139):
+        their rows are rebuilt and replaced on the device with hspf_graph_patch.  False (nothing touched) when a
+        vertex appeared or vanished (new LSA, MaxAge): the caller builds a new AreaGraph."""
+        routers, networks = self._live_lsas(area)
+        if set(routers) != set(self.routers) or set(networks) != set(self.networks):
+            return False
+        self.area, self.routers, self.networks = area, routers, networks
+        vs = sorted({self.index[v] for v in changed if v in self.index})
+        if not vs:
+            return True
+        rows, aux = [], {}
+        for i in vs:
+            c, m, lpos, ref = self._row(self.vids[i])
+            rows.append((np.asarray(c, np.uint32), np.asarray(m, np.uint32)))
+            aux[i] = (lpos, ref)
+        # per-entry side tables of calc_nexthops, spliced like the CSR
+        npos, nref = [], []
+        for u in range(len(self.vids)):
+            if u in aux:
+                npos += aux[u][0]; nref += aux[u][1]
+            else:
+                a, b = int(self.row_ptr[u]), int(self.row_ptr[u + 1])
+                npos += self.link_pos[a:b]; nref += self.link_ref[a:b]
+        flags = [int(self.vflags[i]) for i in vs]
+        if self._dev is not None:
+            self._dev[1].patch(vs, rows, flags)
+        self.row_ptr, self.col, self.metric, self.vflags = E.splice_rows(
+            self.row_ptr, self.col, self.metric, self.vflags, vs, [r[0] for r in rows], [r[1] for r in rows],
+            np.asarray(flags, np.uint8))
+        self.link_pos, self.link_ref = npos, nref
+        return True
 
     def lsa_of(self, v: int):
         vid = self.vids[v]
@@ -303,12 +348,48 @@ def update_rib_intra_area(rib: dict, spt: Dict[VertexId, Vertex], max_paths: int
             cur["nexthops"] = {k: cur["nexthops"][k] for k in sorted(cur["nexthops"])[:max_paths]}
 
 
-def compute_spf_intra_area(router_id: str, areas: List[Area], max_paths: int, engine) -> List[dict]:
+def changed_vertex_ids(old: Area, new: Area) -> List[VertexId]:
+    """Vertices whose Router-/Network-LSA differs between two states of an area (the SpfTriggerLsa list the
+    reference accumulates as LSAs are installed, holo-ospf/src/spf.rs:120-139)."""
+    ra, rb = ({ip(l.adv_rtr): l for l in a.routers} for a in (old, new))
+    na, nb = ({(ip(l.adv_rtr), ip(l.lsa_id)): l for l in a.networks} for a in (old, new))
+    out = {(RTR, k) for k in set(ra) | set(rb) if ra.get(k) != rb.get(k)}
+    out |= {(NET, k[1]) for k in set(na) | set(nb) if na.get(k) != nb.get(k)}
+    return sorted(out)
+
+
+class GraphCache:
+    """Area graphs kept on the device across SPF runs and patched from the changed LSAs."""
+
+    def __init__(self):
+        self.graphs: Dict[str, AreaGraph] = {}
+        self.rebuilt = 0
+        self.patched = 0
+
+    def get(self, area: Area, trigger: Optional[Iterable[VertexId]] = None) -> AreaGraph:
+        g = self.graphs.get(area.area_id)
+        if g is not None and trigger is not None and g.refresh(area, trigger):
+            self.patched += 1
+            return g
+        if g is not None and g._dev is not None:
+            g._dev[1].free()
+        g = self.graphs[area.area_id] = AreaGraph(area)
+        self.rebuilt += 1
+        return g
+
+
+def compute_spf_intra_area(router_id: str, areas: List[Area], max_paths: int, engine,
+                           cache: Optional[GraphCache] = None,
+                           trigger: Optional[Dict[str, Iterable[VertexId]]] = None) -> List[dict]:
     """The SPT + intra-area part of compute_spf (holo-ospf/src/spf.rs:489-584, route.rs:146-160):
-    areas in area-id order, one run_area each; rows like the YANG `local-rib` list."""
+    areas in area-id order, one run_area each; rows like the YANG `local-rib` list.  With a GraphCache the area
+    graphs persist on the device and `trigger[area_id]` (changed vertices) turns LSDB -> CSR into row patches."""
     rib: dict = {}
     for area in sorted(areas, key=lambda a: ip(a.area_id)):
-        spt = run_area(router_id, area, engine)
+        graph = None
+        if cache is not None:
+            graph = cache.get(area, None if trigger is None else trigger.get(area.area_id, ()))
+        spt = run_area(router_id, area, engine, graph)
         if spt is not None:
             update_rib_intra_area(rib, spt, max_paths)
     rows = []

@@ -11,6 +11,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "holo_spf_hip.h"
@@ -39,8 +40,34 @@ class Graph {
   Graph &operator=(const Graph &) = delete;
   ~Graph() { if (g_) hspf_graph_free(ctx_, g_); }
   uint32_t n_vertices() const { return hspf_graph_n_vertices(g_); }
+  uint32_t n_links() const { return hspf_graph_n_edges(g_); }
   uint32_t n_links_kept() const { return hspf_graph_n_edges_kept(g_); }
   hspf_graph *raw() const { return g_; }
+
+  // One re-originated / purged LSP or LSA = one replaced row (hspf_graph_patch).
+  struct Row {
+    uint32_t vertex;
+    std::vector<uint32_t> col, metric;
+    uint8_t vflags;
+  };
+  // Rows in any order; duplicates of a vertex are an error (HSPF_E_INVAL from the library).
+  void patch(std::vector<Row> rows) {
+    std::sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return a.vertex < b.vertex; });
+    std::vector<uint32_t> vertex, row_ptr{0}, col, metric;
+    std::vector<uint8_t> vflags;
+    for (const Row &r : rows) {
+      if (r.col.size() != r.metric.size()) throw Error(HSPF_E_INVAL, "Graph::patch: col/metric length mismatch");
+      vertex.push_back(r.vertex);
+      col.insert(col.end(), r.col.begin(), r.col.end());
+      metric.insert(metric.end(), r.metric.begin(), r.metric.end());
+      row_ptr.push_back((uint32_t)col.size());
+      vflags.push_back(r.vflags);
+    }
+    if (col.empty()) { col.push_back(0); metric.push_back(0); }      // non-NULL pointers for an all-empty delta
+    hspf_rows d{(uint32_t)vertex.size(), vertex.data(), row_ptr.data(), col.data(), metric.data(), vflags.data()};
+    const int rc = hspf_graph_patch(ctx_, g_, &d);
+    if (rc != HSPF_OK) throw Error(rc, std::string("hspf_graph_patch (") + hspf_last_error(ctx_) + ")");
+  }
 
  private:
   friend class Engine;

@@ -39,6 +39,16 @@ class OracleGraph:
                 total += int(self.row_ptr[t + 1] - self.row_ptr[t])
         return np.asarray(hv, np.uint32), np.asarray(hb, np.uint32), total
 
+    def patch(self, vertices, rows, vflags):
+        """Row replacement with the semantics of hspf_graph_patch (holo_amd.engine.SpfGraph.patch)."""
+        order = np.argsort(np.asarray(vertices, dtype=np.int64), kind="stable")
+        vs = np.asarray(vertices, np.uint32)[order]
+        assert len(set(vs.tolist())) == len(vs) and (vs < self.n).all()
+        cols = [np.asarray(rows[i][0], np.uint32) for i in order]
+        mets = [np.asarray(rows[i][1], np.uint32) for i in order]
+        self.row_ptr, self.col, self.metric, self.vflags = E.splice_rows(
+            self.row_ptr, self.col, self.metric, self.vflags, vs, cols, mets, np.asarray(vflags, np.uint8)[order])
+
     def free(self):
         pass
 

@@ -148,6 +148,51 @@ int main(int argc, char **argv) {
       }
     hipFree(dd); hipFree(dh); hipFree(df); hipFree(dm); hipFree(bm); hipFree(be); hipFree(nm);
   }
-  std::printf("capi_parity: %d graph runs bit-exact, error contract ok, device route derivation ok\n", checked);
+  // incremental update: rows replaced through hspf::Graph::patch, results against the oracle on the patched CSR
+  int patched = 0;
+  {
+    Lsdb g = make(150, 10, 21);
+    hspf::Graph G = eng.upload(g.row_ptr, g.col, g.metric, g.vflags, 0xFE000000u);
+    std::vector<u32> roots; for (u32 r = 10; r < 10 + 64; ++r) roots.push_back(r);
+    for (u32 round = 0; round < 5; ++round) {
+      // rewrite up to 1 + 3*round router rows: drop a third of the links, re-cost the rest, add one link
+      std::vector<hspf::Graph::Row> rows;
+      std::vector<std::vector<std::pair<u32, u32>>> all(g.n);
+      for (u32 u = 0; u < g.n; ++u)
+        for (u32 k = g.row_ptr[u]; k < g.row_ptr[u + 1]; ++k) all[u].push_back({g.col[k], g.metric[k]});
+      for (u32 j = 0; j < 1 + 3 * round; ++j) {
+        const u32 u = 10 + rnd(150);
+        bool dup = false; for (auto &r : rows) dup |= r.vertex == u;
+        if (dup) continue;
+        std::vector<std::pair<u32, u32>> nr;
+        for (auto &e : all[u]) if (rnd(3)) nr.push_back({e.first, e.first < 10 ? e.second : 1 + rnd(6)});
+        nr.push_back({10 + rnd(150), 1 + rnd(6)});
+        all[u] = nr;
+        g.vflags[u] ^= (rnd(4) == 0) ? HSPF_VF_NO_TRANSIT : 0;
+        hspf::Graph::Row row{u, {}, {}, g.vflags[u]};
+        for (auto &e : nr) { row.col.push_back(e.first); row.metric.push_back(e.second); }
+        rows.push_back(row);
+      }
+      G.patch(rows);
+      g.col.clear(); g.metric.clear();
+      for (u32 u = 0; u < g.n; ++u) {
+        for (auto &e : all[u]) { g.col.push_back(e.first); g.metric.push_back(e.second); }
+        g.row_ptr[u + 1] = (u32)g.col.size();
+      }
+      CHECK(G.n_links() == g.col.size(), "patched link count");
+      hspf::Tables t = eng.run(G, roots, HSPF_RUN_NET_NEXTHOPS);
+      const size_t rn = (size_t)roots.size() * g.n;
+      std::vector<u32> d(rn), pr(rn), nn(rn), np(rn); std::vector<uint16_t> h(rn), f(rn); std::vector<uint64_t> m(rn * t.mask_words), wk(roots.size());
+      const int rc = oracle(g.n, (u32)g.col.size(), g.row_ptr.data(), g.col.data(), g.metric.data(), g.vflags.data(), 0xFE000000u,
+                            roots.data(), (u32)roots.size(), HSPF_RUN_NET_NEXTHOPS, 1, d.data(), h.data(), f.data(), pr.data(), m.data(),
+                            t.mask_words, nn.data(), np.data(), wk.data());
+      CHECK(rc == 0, "oracle failed");
+      CHECK(d == t.dist && h == t.hops && m == t.mask, "patched graph differs from the oracle on the patched CSR");
+      ++patched;
+    }
+    hspf_rows bad{1, nullptr, nullptr, nullptr, nullptr, nullptr};
+    CHECK(hspf_graph_patch(eng.raw(), G.raw(), &bad) == HSPF_E_INVAL, "NULL arrays in a patch must be HSPF_E_INVAL");
+  }
+  std::printf("capi_parity: %d graph runs bit-exact, %d patched generations bit-exact, error contract ok, device route derivation ok\n", checked, patched);
   return 0;
 }

@@ -47,3 +47,18 @@ from test_host_ospf import OSPF3, check_ospfv3_vector      # noqa: E402
 @pytest.mark.parametrize("path", OSPF3, ids=[os.path.basename(p)[:-5] for p in OSPF3])
 def test_ospfv3_run_area_on_gpu_reproduces_reference_intra_area_rib(spf_ctx, path):
     check_ospfv3_vector(json.load(open(path)), spf_ctx)
+
+
+# ---- incremental LSDB -> CSR: step tests replayed through device-resident, patched graphs ---------
+from test_host_isis_incremental import STEPS as ISIS_STEP_FILES, replay_isis_step      # noqa: E402
+from test_host_ospf_incremental import STEPS as OSPF_STEP_FILES, replay_ospf_step      # noqa: E402
+
+
+@pytest.mark.parametrize("path", ISIS_STEP_FILES, ids=[os.path.basename(p)[:-5] for p in ISIS_STEP_FILES])
+def test_isis_step_on_gpu_through_patched_graphs(spf_ctx, path):
+    replay_isis_step(json.load(open(path)), spf_ctx)
+
+
+@pytest.mark.parametrize("path", OSPF_STEP_FILES, ids=[os.path.basename(p)[:-5] for p in OSPF_STEP_FILES])
+def test_ospfv2_step_on_gpu_through_patched_graphs(spf_ctx, path):
+    replay_ospf_step(json.load(open(path)), spf_ctx)
