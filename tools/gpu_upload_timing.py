@@ -23,7 +23,7 @@ def med(f, reps):
 
 def main():
     ctx = E.SpfContext(0)
-    for name, g in (("ospf-10k", synth.ospf_10k()), ("isis-100k", synth.isis_100k()), ("isis-fattree-250k", synth.isis_fattree())):
+    for name, g in (("ospf-500", synth.ospf_500()), ("ospf-10k", synth.ospf_10k()), ("isis-100k", synth.isis_100k()), ("isis-fattree-250k", synth.isis_fattree())):
         graphs = []
 
         def up():
