@@ -40,7 +40,7 @@ class HspfStats(ctypes.Structure):
 
 class HspfPrefixTable(ctypes.Structure):
     _fields_ = [("n_prefixes", ctypes.c_uint32), ("n_entries", ctypes.c_uint32),
-                ("pfx_ptr", u32p), ("pfx_vertex", u32p), ("pfx_metric", u32p)]
+                ("pfx_ptr", u32p), ("pfx_vertex", u32p), ("pfx_metric", u32p), ("flags", ctypes.c_uint32)]
 
 
 class HspfRows(ctypes.Structure):

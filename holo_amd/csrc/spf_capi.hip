@@ -959,6 +959,7 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
   if (!ctx || !t || !out || !dist_dev || !flags_dev || !mask_dev || !out->best_metric || !out->best_entry ||
       !out->nexthop_mask || n_roots == 0 || n_mask_words == 0 || !t->pfx_ptr || (t->n_entries && (!t->pfx_vertex || !t->pfx_metric)))
     return HSPF_E_INVAL;
+  if (t->flags & ~(HSPF_PFX_SATURATING | HSPF_PFX_LAST_MIN)) { ctx->last_error = "hspf_prefix_table: unknown flags"; return HSPF_E_INVAL; }
   if (t->pfx_ptr[0] != 0 || t->pfx_ptr[t->n_prefixes] != t->n_entries) { ctx->last_error = "pfx_ptr malformed"; return HSPF_E_INVAL; }
   for (uint32_t p = 0; p < t->n_prefixes; ++p)
     if (t->pfx_ptr[p + 1] < t->pfx_ptr[p]) { ctx->last_error = "pfx_ptr not monotone"; return HSPF_E_INVAL; }
@@ -979,7 +980,7 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
   hipLaunchKernelGGL(k_routes, dim3((t->n_prefixes + 255) / 256, n_roots), dim3(256), 0, s, n_vertices, n_roots, n_mask_words,
                      t->n_prefixes, (const uint32_t *)ctx->pf_ptr.p, (const uint32_t *)ctx->pf_vtx.p,
                      (const uint32_t *)ctx->pf_met.p, dist_dev, flags_dev, mask_dev, out->best_metric, out->best_entry,
-                     out->nexthop_mask);
+                     out->nexthop_mask, t->flags);
   HIPCHK(ctx, hipStreamSynchronize(s));       // the table was read from caller-owned host memory
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { ctx->last_error = std::string("k_routes: ") + hipGetErrorString(le); return HSPF_E_HIP; }

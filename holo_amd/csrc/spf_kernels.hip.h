@@ -1041,7 +1041,8 @@ __global__ __launch_bounds__(256) void k_routes(uint32_t n, uint32_t n_roots, ui
                                                 const uint64_t *__restrict__ mask,
                                                 uint32_t *__restrict__ best_metric,
                                                 uint32_t *__restrict__ best_entry,
-                                                uint64_t *__restrict__ nh_mask) {
+                                                uint64_t *__restrict__ nh_mask, uint32_t mode) {
+  const bool sat = mode & HSPF_PFX_SATURATING, lastmin = mode & HSPF_PFX_LAST_MIN;
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t r = blockIdx.y;
   if (p >= n_pfx) return;
@@ -1053,18 +1054,23 @@ __global__ __launch_bounds__(256) void k_routes(uint32_t n, uint32_t n_roots, ui
   for (uint32_t e = a; e < b; ++e) {                     // entries are in ascending vertex order
     const uint32_t v = pfx_vertex[e];
     if (!(F[v] & 1u)) continue;                          // vertex not in this root's SPT
-    const uint32_t m = D[v] + pfx_metric[e];             // `vertex.distance + network.metric`, plain add
-    if (m < bm) { bm = m; be = e; }
+    uint32_t m = D[v] + pfx_metric[e];                   // `vertex.distance + network.metric`, plain add
+    if (sat && m < D[v]) m = INF;                        // holo-ospf: saturating_add (route.rs:362-366)
+    if (be == INF || m < bm || (lastmin && m == bm)) { bm = m; be = e; }
   }
   const size_t o = (size_t)r * n_pfx + p;
   best_metric[o] = bm;
   best_entry[o] = be;
   for (uint32_t w = 0; w < W; ++w) {
     uint64_t acc = 0;
-    if (be != INF)
+    if (be != INF && lastmin) acc = M[(size_t)pfx_vertex[be] * W + w];     // the later entry replaced the route
+    else if (be != INF)
       for (uint32_t e = be; e < b; ++e) {                // entries before `be` have a larger metric
         const uint32_t v = pfx_vertex[e];
-        if ((F[v] & 1u) && D[v] + pfx_metric[e] == bm) acc |= M[(size_t)v * W + w];
+        if (!(F[v] & 1u)) continue;
+        uint32_t m = D[v] + pfx_metric[e];
+        if (sat && m < D[v]) m = INF;
+        if (m == bm) acc |= M[(size_t)v * W + w];
       }
     nh_mask[o * W + w] = acc;
   }

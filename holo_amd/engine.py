@@ -20,6 +20,9 @@ RUN_IGNORE_OVERLOAD = 0x02
 RUN_FORCE_EXACT = 0x04
 RUN_POP_RANK = 0x08
 
+PFX_SATURATING = 0x1
+PFX_LAST_MIN = 0x2
+
 RF_IN_SPT = 0x0001
 RF_EXACT = 0x0002
 DIST_INF = 0xFFFFFFFF
@@ -242,13 +245,13 @@ class SpfContext:
 
     def routes_device(self, n_vertices: int, n_roots: int, mask_words: int, dist_ptr: int, flags_ptr: int,
                       mask_ptr: int, pfx_ptr, pfx_vertex, pfx_metric, *, best_metric_ptr: int,
-                      best_entry_ptr: int, nexthop_mask_ptr: int) -> None:
+                      best_entry_ptr: int, nexthop_mask_ptr: int, flags: int = 0) -> None:
         """hspf_routes_device(): prefix attachment for every root of a previous run_device(); all
         `*_ptr` arguments are device pointers, the prefix table is host numpy."""
         pfx_ptr = np.ascontiguousarray(pfx_ptr, np.uint32)
         pfx_vertex = np.ascontiguousarray(pfx_vertex, np.uint32)
         pfx_metric = np.ascontiguousarray(pfx_metric, np.uint32)
-        t = L.HspfPrefixTable(len(pfx_ptr) - 1, len(pfx_vertex), _u32(pfx_ptr), _u32(pfx_vertex), _u32(pfx_metric))
+        t = L.HspfPrefixTable(len(pfx_ptr) - 1, len(pfx_vertex), _u32(pfx_ptr), _u32(pfx_vertex), _u32(pfx_metric), flags)
         o = L.HspfRoutes(best_metric_ptr, best_entry_ptr, nexthop_mask_ptr)
         rc = self.lib.hspf_routes_device(self.handle, n_vertices, n_roots, mask_words, dist_ptr, flags_ptr, mask_ptr,
                                          ctypes.byref(t), ctypes.byref(o))

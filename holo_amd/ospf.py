@@ -239,13 +239,14 @@ def calc_nexthops(g: AreaGraph, parent: Vertex, k: int, dest: VertexId, dest_lsa
     return out
 
 
-def spt_from_engine(g, root: int, engine, calc) -> Dict[tuple, Vertex]:
+def spt_from_engine(g, root: int, engine, calc, res=None, slots_out: Optional[dict] = None) -> Dict[tuple, Vertex]:
     """Version-generic back half of run_area: one engine run (HSPF_RUN_NET_NEXTHOPS), then every
     first-hop slot is expanded ONCE through the version's `calc(g, parent_vertex, k, dest_vid,
     dest_lsa)` (= V::calc_nexthops for a hops == 0 parent, holo-ospf/src/spf.rs:747-760) and the
     per-slot sets are OR-ed through the per-vertex masks (= the inheritance of :761-766)."""
     G = g.device(engine)
-    res = engine.run(G, np.asarray([root], np.uint32), E.RUN_NET_NEXTHOPS)
+    if res is None:                       # `res`: tables of a run the caller already made (device-resident path)
+        res = engine.run(G, np.asarray([root], np.uint32), E.RUN_NET_NEXTHOPS)
     dist, hops = res.dist[0], res.hops[0]
     in_spt = (res.flags[0] & E.RF_IN_SPT) != 0
     mask = res.first_hop_mask[0]
@@ -287,6 +288,8 @@ def spt_from_engine(g, root: int, engine, calc) -> Dict[tuple, Vertex]:
     # distance order guarantees parents (hops == 0 networks) are materialised before children
     for v in sorted(np.nonzero(in_spt)[0].tolist(), key=lambda v: (int(dist[v]), v)):
         vertex(v)
+    if slots_out is not None:             # slot -> next hops, for consumers of masks that are not vertices
+        slots_out.update(slot_cache)
     return spt
 
 

@@ -18,6 +18,7 @@ import numpy as np
 
 from . import engine as E
 from . import isis as I
+from . import ospf as O
 
 
 @dataclass
@@ -163,3 +164,139 @@ def compute_spf_device_routes(instance: I.Instance, engine, device="cuda:0") -> 
     return [{"prefix": merged[k]["prefix"], "metric": merged[k]["metric"], "level": merged[k]["level"],
              "nexthops": [[merged[k]["nexthops"][a][0], merged[k]["nexthops"][a][1]] for a in sorted(merged[k]["nexthops"])]}
             for k in sorted(merged)]
+
+
+# ---- OSPFv2: update_rib_intra_area with the prefix attachment on the GPU ---------------------------------------------
+
+@dataclass
+class OspfPrefixTables:
+    """CSR-by-prefix tables of one area (root independent): `net` = the prefixes of Network-LSA vertices (metric 0),
+    `stub` = the stub links of Router-LSA vertices, in the order intra_area_networks() yields them
+    (holo-ospf/src/ospfv2/spf.rs:462-538).  Two tables because the two vertex kinds follow different tie rules
+    (include/holo_spf_hip.h, HSPF_PFX_LAST_MIN) and all networks precede all routers in VertexId order."""
+    prefixes: List[str]
+    net: tuple                        # (pfx_ptr, pfx_vertex, pfx_metric)
+    stub: tuple
+
+    @classmethod
+    def build(cls, g: "O.AreaGraph") -> "OspfPrefixTables":
+        import ipaddress
+        rows = {"net": [], "stub": []}
+        for v, vid in enumerate(g.vids):
+            lsa = g.lsa_of(v)
+            if vid[0] == O.NET:
+                try:
+                    rows["net"].append((str(ipaddress.ip_network((lsa.lsa_id, lsa.mask), strict=False)), v, 0))
+                except ValueError:
+                    continue
+            else:
+                for link in lsa.links:
+                    if link.link_type != "stub-network-link":
+                        continue
+                    try:
+                        rows["stub"].append((str(ipaddress.ip_network((link.link_id, link.link_data), strict=False)), v, link.metric))
+                    except ValueError:
+                        continue
+        keys = sorted({O._net_key(p): p for kind in rows.values() for p, _, _ in kind}.items())
+        pid = {k: i for i, (k, _) in enumerate(keys)}
+
+        def table(rs):
+            order = sorted(range(len(rs)), key=lambda i: (pid[O._net_key(rs[i][0])], rs[i][1], i))
+            ptr = np.zeros(len(keys) + 1, np.uint64)
+            for p, _, _ in rs:
+                ptr[pid[O._net_key(p)] + 1] += 1
+            return (np.cumsum(ptr).astype(np.uint32), np.asarray([rs[i][1] for i in order], np.uint32),
+                    np.asarray([rs[i][2] for i in order], np.uint32))
+        return cls([p for _, p in keys], table(rows["net"]), table(rows["stub"]))
+
+
+def ospf_area_device_routes(engine, g: "O.AreaGraph", root: int, tables: OspfPrefixTables, rib: dict, max_paths: int,
+                            device="cuda:0") -> None:
+    """run_area + update_rib_intra_area of one area with the SPT and both prefix reductions on the device; folds the
+    per-prefix results into `rib` (shared by the areas, holo-ospf/src/route.rs:146-160) with the reference's compare
+    rules.  Only the tables needed to turn first-hop slots into next hops come back to the host."""
+    import torch
+    G = g.device(engine)
+    roots = np.asarray([root], np.uint32)
+    n, W = g.n if hasattr(g, "n") else len(g.vids), G.mask_words(roots)
+    dev = torch.device(device)
+    dist = torch.empty((1, n), dtype=torch.int32, device=dev)
+    hops = torch.empty((1, n), dtype=torch.int16, device=dev)
+    flags = torch.empty((1, n), dtype=torch.int16, device=dev)
+    mask = torch.empty((1, n, W), dtype=torch.int64, device=dev)
+    stats = engine.run_device(G, roots, E.RUN_NET_NEXTHOPS, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(),
+                              flags_ptr=flags.data_ptr(), mask_ptr=mask.data_ptr(), mask_words=W)
+    P = len(tables.prefixes)
+    out = {}
+    for kind, tab, fl in (("net", tables.net, E.PFX_SATURATING | E.PFX_LAST_MIN), ("stub", tables.stub, E.PFX_SATURATING)):
+        bm = torch.empty((1, P), dtype=torch.int32, device=dev)
+        be = torch.empty((1, P), dtype=torch.int32, device=dev)
+        nm = torch.empty((1, P, W), dtype=torch.int64, device=dev)
+        if P:
+            engine.routes_device(n, 1, W, dist.data_ptr(), flags.data_ptr(), mask.data_ptr(), tab[0], tab[1], tab[2],
+                                 best_metric_ptr=bm.data_ptr(), best_entry_ptr=be.data_ptr(),
+                                 nexthop_mask_ptr=nm.data_ptr(), flags=fl)
+        torch.cuda.synchronize(dev)
+        out[kind] = (bm.cpu().numpy().view(np.uint32)[0], be.cpu().numpy().view(np.uint32)[0],
+                     nm.cpu().numpy().view(np.uint64)[0])
+    res = E.SpfResult(dist.cpu().numpy().view(np.uint32), hops.cpu().numpy().view(np.uint16),
+                      flags.cpu().numpy().view(np.uint16), mask.cpu().numpy().view(np.uint64), None, stats)
+    slot_nh: dict = {}
+    O.spt_from_engine(g, root, engine, O.calc_nexthops, res=res, slots_out=slot_nh)
+
+    def expand(mrow) -> dict:
+        nhs = {}
+        for w in range(len(mrow)):
+            m = int(mrow[w])
+            while m:
+                b = (m & -m).bit_length() - 1
+                m &= m - 1
+                nh = slot_nh.get(w * 64 + b)
+                if nh:
+                    nhs.update(nh)
+        return nhs
+
+    for p, prefix in enumerate(tables.prefixes):
+        key = O._net_key(prefix)
+        for kind, tab in (("net", tables.net), ("stub", tables.stub)):      # networks before routers: VertexId order
+            bm, be, nm = out[kind]
+            if be[p] == 0xFFFFFFFF:
+                continue
+            v = int(tab[1][be[p]])
+            lsa = g.lsa_of(v)
+            metric = int(bm[p])
+            origin = O.ip(lsa.lsa_id) if kind == "net" else O.ip(lsa.adv_rtr)
+            cur = rib.get(key)
+            if cur is not None and metric > cur["metric"]:
+                continue
+            if kind == "net" and cur is not None:                            # route.rs:388-400
+                if metric < cur["metric"] or (metric == cur["metric"] and origin > cur["origin"]):
+                    del rib[key]
+                else:
+                    continue
+            new = {"prefix": prefix, "metric": metric, "origin": origin, "connected": int(res.hops[0][v]) == 0,
+                   "nexthops": expand(nm[p])}
+            cur = rib.get(key)                                               # route_update, route.rs:918-965
+            if cur is None or new["metric"] < cur["metric"]:
+                cur = rib[key] = new
+            elif new["metric"] == cur["metric"]:
+                cur["nexthops"].update(new["nexthops"])
+            if len(cur["nexthops"]) > max_paths:
+                cur["nexthops"] = {k: cur["nexthops"][k] for k in sorted(cur["nexthops"])[:max_paths]}
+
+
+def ospf_intra_area_device_routes(router_id: str, areas: Sequence["O.Area"], max_paths: int, engine,
+                                  device="cuda:0") -> List[dict]:
+    """holo_amd.ospf.compute_spf_intra_area with SPT and prefix attachment on the GPU; same rows."""
+    rib: dict = {}
+    for area in sorted(areas, key=lambda a: O.ip(a.area_id)):
+        g = O.AreaGraph(area)
+        root = g.index.get((O.RTR, O.ip(router_id)))
+        if root is None:
+            continue
+        ospf_area_device_routes(engine, g, root, OspfPrefixTables.build(g), rib, max_paths, device)
+        if g._dev is not None:
+            g._dev[1].free()
+    return [{"prefix": rib[k]["prefix"], "metric": rib[k]["metric"], "type": "intra-area",
+             "nexthops": [[rib[k]["nexthops"][a][1], rib[k]["nexthops"][a][0]] for a in sorted(rib[k]["nexthops"])]}
+            for k in sorted(rib)]

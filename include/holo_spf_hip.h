@@ -243,13 +243,28 @@ int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out);
  * The prefix table is CSR by prefix: entries pfx_ptr[p] .. pfx_ptr[p+1] are the (vertex, metric)
  * advertisements of prefix p, sorted by vertex index.  All result / input table pointers are DEVICE
  * pointers; pfx_* are caller-owned HOST arrays (uploaded per call).
+ *
+ * holo-ospf's update_rib_intra_area (holo-ospf/src/route.rs:343-448) is the same reduction with two twists,
+ * selected by `flags`:
+ *   HSPF_PFX_SATURATING   route metric = dist[v].saturating_add(metric)  (route.rs:362-366); the reached / not
+ *                         reached distinction is then carried by best_entry alone (0xFFFFFFFF = no route).
+ *   HSPF_PFX_LAST_MIN     the transit-network rule (route.rs:388-400): among equal metrics the LATER entry —
+ *                         the larger LS-ID, entries being in ascending vertex = LS-ID order — REPLACES the
+ *                         route instead of merging into it: best_entry = last entry attaining the minimum,
+ *                         nexthop_mask = that entry's mask only.
+ * An OSPF caller evaluates one table of Network-LSA prefixes with both flags and one table of Router-LSA stub
+ * prefixes with HSPF_PFX_SATURATING, and folds the two per-prefix results in that order (networks sort before
+ * routers in VertexId order): holo_amd/routes.py ospf_intra_area_device_routes.
  */
+#define HSPF_PFX_SATURATING 0x1u
+#define HSPF_PFX_LAST_MIN   0x2u
 typedef struct {
   uint32_t        n_prefixes;
   uint32_t        n_entries;
   const uint32_t *pfx_ptr;      /* [n_prefixes+1]                                                */
   const uint32_t *pfx_vertex;   /* [n_entries] advertising vertex                                */
   const uint32_t *pfx_metric;   /* [n_entries] advertised metric                                 */
+  uint32_t        flags;        /* HSPF_PFX_*; 0 = the IS-IS rule                                */
 } hspf_prefix_table;
 
 typedef struct {

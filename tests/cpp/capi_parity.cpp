@@ -126,7 +126,7 @@ int main(int argc, char **argv) {
     for (u32 p = 0; p < P; ++p) { u32 a = p, b = (7 * p + 3) % n; if (a > b) std::swap(a, b); pv.push_back(a); pm.push_back(a == p ? 1 : 2); if (b != a) { pv.push_back(b); pm.push_back(b == p ? 1 : 2); } pptr[p + 1] = (u32)pv.size(); }
     u32 *bm, *be; uint64_t *nm;
     hipMalloc(&bm, (size_t)R * P * 4); hipMalloc(&be, (size_t)R * P * 4); hipMalloc(&nm, (size_t)R * P * 8 * W);
-    hspf_prefix_table tab{P, (u32)pv.size(), pptr.data(), pv.data(), pm.data()};
+    hspf_prefix_table tab{P, (u32)pv.size(), pptr.data(), pv.data(), pm.data(), 0};
     hspf_routes ro{bm, be, nm};
     CHECK(hspf_routes_device(eng.raw(), n, R, W, dd, df, dm, &tab, &ro) == HSPF_OK, "hspf_routes_device");
     std::vector<u32> hbm((size_t)R * P), hbe((size_t)R * P); std::vector<uint64_t> hnm((size_t)R * P * W);
