@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstdint>
 #include <vector>
+template <typename T> __device__ inline uint32_t first_word(const T& v) { return (uint32_t)v; }
+template <> __device__ inline uint32_t first_word<uint4>(const uint4& v) { return v.x; }
 template <typename T, int K>
 __global__ __launch_bounds__(256) void k(const T* __restrict__ buf, const uint32_t* __restrict__ idx, uint32_t nidx, uint32_t iters, uint32_t* out) {
   const uint32_t lane = threadIdx.x & 63, wave = (blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -22,7 +24,7 @@ __global__ __launch_bounds__(256) void k(const T* __restrict__ buf, const uint32
         v[j] = buf[(size_t)r * 64 + lane];
       }
 #pragma unroll
-      for (int j = 0; j < K; ++j) { const uint32_t* w = (const uint32_t*)&v[j]; acc += w[0]; }
+      for (int j = 0; j < K; ++j) acc += first_word(v[j]);
     }
   }
   if (acc == 0x12345678) out[0] = acc;
@@ -44,8 +46,9 @@ template <typename T, int K> double run(size_t mb, int bpc, int iters) {
   return bytes / ms / 1e9;   // TB/s... bytes/ms/1e9 = TB/s
 }
 int main(int argc, char** argv) {
-  for (size_t mb : {2, 16, 51, 200}) for (int bpc : {4, 8}) {
-    printf("buf %4zu MB  blocks/CU %d :  4B/lane K4 %6.2f  K8 %6.2f | 8B/lane K4 %6.2f K8 %6.2f | 16B/lane K4 %6.2f K8 %6.2f  TB/s\n", mb, bpc,
-      run<uint32_t,4>(mb,bpc,40), run<uint32_t,8>(mb,bpc,40), run<uint64_t,4>(mb,bpc,40), run<uint64_t,8>(mb,bpc,40), run<uint4,4>(mb,bpc,20), run<uint4,8>(mb,bpc,20));
+  for (size_t mb : {2, 13, 26, 51, 200}) for (int bpc : {4, 8}) {
+    printf("buf %4zu MB  blocks/CU %d :  2B/lane K8 %6.2f K16 %6.2f | 4B/lane K4 %6.2f  K8 %6.2f K16 %6.2f | 8B/lane K4 %6.2f K8 %6.2f | 16B/lane K4 %6.2f K8 %6.2f  TB/s\n", mb, bpc,
+      run<uint16_t,8>(mb,bpc,40), run<uint16_t,16>(mb,bpc,40),
+      run<uint32_t,4>(mb,bpc,40), run<uint32_t,8>(mb,bpc,40), run<uint32_t,16>(mb,bpc,40), run<uint64_t,4>(mb,bpc,40), run<uint64_t,8>(mb,bpc,40), run<uint4,4>(mb,bpc,20), run<uint4,8>(mb,bpc,20));
   }
 }
