@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes (counters only) on a short bench run; aggregates per kernel (full sweeps only = top 50% by value)
+# PMC passes (counters only; every pass under its own `timeout`: a counter set the hardware cannot collect makes
+# rocprofv3 abort and then hang in its finaliser) on a short bench run; aggregates per kernel (full sweeps only = top 50% by value)
 export TMPDIR=/tmp
 R=$(pwd); OUT=$R/gpurun_out/pmc; rm -rf $OUT; mkdir -p $OUT
 cd /tmp
@@ -7,14 +8,15 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  rocprofv3 --pmc $line --output-format csv -d $OUT/p$i -o q -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/p$i.log 2>&1
+  timeout -k 5 45 rocprofv3 --pmc $line --output-format csv -d $OUT/p$i -o q -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/p$i.log 2>&1
 done <<'PASSES'
-FETCH_SIZE
-WRITE_SIZE
-TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
-SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM
-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE
-TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum
+GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum
+TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
+TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_GATE_EN1_sum
+TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_CACHE_ACCESSES_sum
+TCC_TAG_STALL_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_CYCLE_sum
+TCC_EA0_RDREQ_LEVEL_sum TCC_LATENCY_FIFO_FULL_sum TCC_SRC_FIFO_FULL_sum
+SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_INST_CYCLES_VMEM_RD SQ_BUSY_CYCLES
 PASSES
 cd $R
 python - <<'PY'

@@ -7,12 +7,12 @@ R=$(pwd); OUT=$R/gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 2500 $OUT/bench.json
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o spf -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o spf -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
             "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
             "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
   i=$(echo "$pass" | md5sum | cut -c1-6)
-  rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$i -o q -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$i.log 2>&1
+  timeout -k 5 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$i -o q -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$i.log 2>&1
 done
 cd $R
 python - <<'PY'

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 R=$(pwd); OUT=$R/gpurun_out/trace; rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o spf -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/run.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o spf -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/run.log 2>&1
 cd $R
 python - <<'PY'
 import csv, glob
