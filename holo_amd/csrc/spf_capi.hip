@@ -82,6 +82,7 @@ struct hspf_ctx {
   // scratch (grown on demand, reused across runs)
   DevBuf dist, hv, mask, roots, lane_flags, changed, tab_ptr, tab_vtx, tab_base, st64, stamp, hnb, fgraph;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
+  DevBuf p_dist, p_hops, p_flags, p_mask, p_rank, p_dest;   // regrouped runs: outputs in class order before the row permute
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met;                    // prefix table of hspf_routes_device
   DevBuf gb, gb_delta;                              // graph build scratch, patch delta
@@ -312,7 +313,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->roots, &ctx->lane_flags, &ctx->changed,
                     &ctx->tab_ptr, &ctx->tab_vtx, &ctx->tab_base, &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->fgraph, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->gb, &ctx->gb_delta})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->p_dist, &ctx->p_hops, &ctx->p_flags, &ctx->p_mask, &ctx->p_rank, &ctx->p_dest, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->gb, &ctx->gb_delta})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
@@ -939,12 +940,127 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   return HSPF_OK;
 }
 
+// A run takes the state its most demanding root needs: one root with more than 16 first-hop slots sends every root of
+// the call down the two-phase path, one with 15-16 slots makes the packed state 8 bytes wide for all.  With many roots
+// ("every router of the area") that is the common case, so the roots are regrouped by what
+// they need — narrow fused / wide fused / two-phase —, each class runs on its own, and the rows are put back in the
+// caller's order by one streaming pass.  Small calls are left alone: an extra run costs a whole fixed point.
+static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                       hspf_result *out, bool host_out) {
+  if (!ctx || !g || !roots || !out || n_roots < 128 || !out->dist || (run_flags & (HSPF_RUN_FORCE_EXACT | HSPF_RUN_POP_RANK)))
+    return run_impl(ctx, g, roots, n_roots, run_flags, out, host_out);
+  const uint32_t n = g->n;
+  // widest mask field the 4-byte state can take on this graph (same rule as run_impl)
+  uint32_t m_narrow = 0;
+  if (!g->narrow_bad && !(ctx->variant & 2u))
+    for (uint32_t M = 16; M >= 1; --M) {
+      const uint32_t H = (32u - M - 7u >= 13u) ? 7u : 6u, D = 32u - M - H;
+      if (D >= 12u && g->wmax < (1u << (D - 3))) { m_narrow = M; break; }
+    }
+  std::vector<uint8_t> cls(n_roots, 0);
+  uint32_t cnt[3] = {0, 0, 0};
+  {
+    std::vector<uint32_t> hv, hb, mark(n, 0xFFFFFFFFu);
+    for (uint32_t r = 0; r < n_roots; ++r) {
+      uint32_t total = 0;
+      if (roots[r] != HSPF_NO_ROOT) {
+        if (roots[r] >= n) { ctx->last_error = "root out of range"; return HSPF_E_INVAL; }
+        build_slot_table(g, roots[r], hv, hb, total, mark, r);
+      }
+      cls[r] = total > 16 ? 2 : (total > m_narrow ? 1 : 0);
+      cnt[cls[r]]++;
+    }
+  }
+  const bool fused_ok = n < (1u << 23) && !(ctx->variant & 1u);
+  const bool split2 = fused_ok && cnt[2] > 0 && cnt[0] + cnt[1] >= 64;          // keep the others off the two-phase path
+  const bool split1 = fused_ok && m_narrow > 0 && cnt[1] > 0 && cnt[0] >= 256;  // keep the narrow ones narrow
+  if ((cnt[2] > 0 && !split2) || (!split1 && !split2))        // one run as before (two-phase for all / fused for all)
+    return run_impl(ctx, g, roots, n_roots, run_flags, out, host_out);
+  if (!split1) for (auto &c : cls) if (c == 1) c = 0;           // classes 0 and 1 share one fused run
+  // class order, stable inside a class
+  std::vector<uint32_t> proots(n_roots), dest(n_roots);
+  uint32_t start[4] = {0, 0, 0, 0};
+  { uint32_t c0 = 0, c1 = 0, c2 = 0; for (auto c : cls) (c == 0 ? c0 : c == 1 ? c1 : c2)++; start[1] = c0; start[2] = c0 + c1; start[3] = n_roots; }
+  { uint32_t pos[3] = {start[0], start[1], start[2]};
+    for (uint32_t r = 0; r < n_roots; ++r) { const uint32_t i = pos[cls[r]]++; proots[i] = roots[r]; dest[i] = r; } }
+  const size_t rn = (size_t)n_roots * n;
+  const bool want_mask = out->first_hop_mask != nullptr, want_rank = (run_flags & HSPF_RUN_POP_RANK) && out->pop_rank;
+  if (want_mask && out->n_mask_words == 0) return HSPF_E_INVAL;
+  const uint32_t W = want_mask ? out->n_mask_words : 0;
+  int rc;
+  if ((rc = ensure(ctx, ctx->p_dist, rn * 4))) return rc;
+  if (out->hops && (rc = ensure(ctx, ctx->p_hops, rn * 2))) return rc;
+  if (out->vflags_out && (rc = ensure(ctx, ctx->p_flags, rn * 2))) return rc;
+  if (want_mask && (rc = ensure(ctx, ctx->p_mask, rn * 8 * W))) return rc;
+  if (want_rank && (rc = ensure(ctx, ctx->p_rank, rn * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->p_dest, (size_t)n_roots * 4))) return rc;
+  hspf_result T{(uint32_t *)ctx->p_dist.p, out->hops ? (uint16_t *)ctx->p_hops.p : nullptr,
+                out->vflags_out ? (uint16_t *)ctx->p_flags.p : nullptr, want_mask ? (uint64_t *)ctx->p_mask.p : nullptr, W,
+                want_rank ? (uint32_t *)ctx->p_rank.p : nullptr};
+  hspf_stats acc{};
+  for (int c = 0; c < 3; ++c) {
+    const uint32_t off = start[c], nr = start[c + 1] - start[c];
+    if (nr == 0) continue;
+    hspf_result part = T;
+    const size_t o = (size_t)off * n;
+    part.dist = T.dist + o;
+    if (T.hops) part.hops = T.hops + o;
+    if (T.vflags_out) part.vflags_out = T.vflags_out + o;
+    if (T.first_hop_mask) part.first_hop_mask = T.first_hop_mask + o * W;
+    if (T.pop_rank) part.pop_rank = T.pop_rank + o;
+    rc = run_impl(ctx, g, proots.data() + off, nr, run_flags, &part, false);
+    if (rc) return rc;
+    const hspf_stats &p = ctx->stats;
+    acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
+    acc.n_dag_launches += p.n_dag_launches; acc.n_exact_roots += p.n_exact_roots;
+    acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
+    acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
+    acc.state_bytes = std::max(acc.state_bytes, p.state_bytes); acc.narrow_overflow += p.narrow_overflow;
+  }
+  // rows back into the caller's order: straight into its device buffers, or into the staging that is copied out
+  hipStream_t s = ctx->stream;
+  hspf_result U = *out;
+  if (host_out) {
+    if ((rc = ensure(ctx, ctx->o_dist, rn * 4))) return rc;
+    U.dist = (uint32_t *)ctx->o_dist.p;
+    if (out->hops) { if ((rc = ensure(ctx, ctx->o_hops, rn * 2))) return rc; U.hops = (uint16_t *)ctx->o_hops.p; }
+    if (out->vflags_out) { if ((rc = ensure(ctx, ctx->o_flags, rn * 2))) return rc; U.vflags_out = (uint16_t *)ctx->o_flags.p; }
+    if (want_mask) { if ((rc = ensure(ctx, ctx->o_mask, rn * 8 * W))) return rc; U.first_hop_mask = (uint64_t *)ctx->o_mask.p; }
+    if (want_rank) { if ((rc = ensure(ctx, ctx->o_rank, rn * 4))) return rc; U.pop_rank = (uint32_t *)ctx->o_rank.p; }
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->p_dest.p, dest.data(), (size_t)n_roots * 4, hipMemcpyHostToDevice, s));
+  const uint32_t *d_dest = (const uint32_t *)ctx->p_dest.p;
+  for (uint32_t row0 = 0; row0 < n_roots; row0 += 32768) {
+    const uint32_t ny = std::min(32768u, n_roots - row0);
+    const dim3 g1((unsigned)(((size_t)n + 255) / 256), ny), gm((unsigned)(((size_t)n * std::max(W, 1u) + 255) / 256), ny);
+    hipLaunchKernelGGL((k_permute_rows<uint32_t>), g1, dim3(256), 0, s, (size_t)n, d_dest, row0, (const uint32_t *)T.dist, U.dist);
+    if (T.hops) hipLaunchKernelGGL((k_permute_rows<uint16_t>), g1, dim3(256), 0, s, (size_t)n, d_dest, row0, (const uint16_t *)T.hops, U.hops);
+    if (T.vflags_out) hipLaunchKernelGGL((k_permute_rows<uint16_t>), g1, dim3(256), 0, s, (size_t)n, d_dest, row0, (const uint16_t *)T.vflags_out, U.vflags_out);
+    if (T.first_hop_mask) hipLaunchKernelGGL((k_permute_rows<uint64_t>), gm, dim3(256), 0, s, (size_t)n * W, d_dest, row0, (const uint64_t *)T.first_hop_mask, U.first_hop_mask);
+    if (T.pop_rank) hipLaunchKernelGGL((k_permute_rows<uint32_t>), g1, dim3(256), 0, s, (size_t)n, d_dest, row0, (const uint32_t *)T.pop_rank, U.pop_rank);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  if (host_out) {
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
+    HIPCHK(ctx, hipMemcpyAsync(out->dist, U.dist, rn * 4, hipMemcpyDeviceToHost, s));
+    if (out->hops) HIPCHK(ctx, hipMemcpyAsync(out->hops, U.hops, rn * 2, hipMemcpyDeviceToHost, s));
+    if (out->vflags_out) HIPCHK(ctx, hipMemcpyAsync(out->vflags_out, U.vflags_out, rn * 2, hipMemcpyDeviceToHost, s));
+    if (want_mask) HIPCHK(ctx, hipMemcpyAsync(out->first_hop_mask, U.first_hop_mask, rn * 8 * W, hipMemcpyDeviceToHost, s));
+    if (want_rank) HIPCHK(ctx, hipMemcpyAsync(out->pop_rank, U.pop_rank, rn * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(s));       // dest / proots are stack vectors; results are in place on return
+  if (host_out) { float ms = 0; if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) acc.ms_d2h = ms; }
+  ctx->stats = acc;
+  return HSPF_OK;
+}
+
 int hspf_run(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags, hspf_result *out) {
-  return run_impl(ctx, g, roots, n_roots, run_flags, out, true);
+  return run_classes(ctx, g, roots, n_roots, run_flags, out, true);
 }
 
 int hspf_run_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags, hspf_result *out_device) {
-  return run_impl(ctx, g, roots, n_roots, run_flags, out_device, false);
+  return run_classes(ctx, g, roots, n_roots, run_flags, out_device, false);
 }
 
 int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out) {

@@ -854,6 +854,16 @@ __global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots
     }
 }
 
+// Rows of a row-major [root][len] table to their final places: out[dest[i]] = in[i] (runs whose roots were regrouped
+// by the state they need, spf_capi.hip run_classes).
+template <typename T>
+__global__ __launch_bounds__(256) void k_permute_rows(size_t len, const uint32_t *__restrict__ dest, uint32_t row0,
+                                                      const T *__restrict__ in, T *__restrict__ out) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t i = row0 + blockIdx.y;
+  if (j < len) out[(size_t)dest[i] * len + j] = in[(size_t)i * len + j];
+}
+
 // Epoch rebase (only when a DAG phase needs more than 65534 launches): every final row -> epoch 1.
 __global__ void k_rebase(uint32_t *hv, size_t count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -345,3 +345,44 @@ def G_slots(g, root):
             if t not in seen and (g.vflags[t] & 1) and back:
                 seen.add(t); q.append(t); tot += int(g.row_ptr[t + 1] - g.row_ptr[t])
     return tot
+
+
+@pytest.mark.parametrize("run_flags", [0, E.RUN_NET_NEXTHOPS])
+def test_many_roots_regrouped_by_state_class(spf_ctx, run_flags):
+    """Every router as a root on a graph where a few roots need wide masks (members of a 40-router LAN: 40+ first-hop
+    slots -> two-phase path) and most need few: the call regroups the roots by the state they need, runs each class on
+    its own and puts the rows back in the caller's order — results identical to the oracle's, row by row."""
+    g = synth.random_lsdb(420, 2, 3.0, 4242, metric_hi=5, lan_size=40)
+    roots = np.arange(2, g.n, dtype=np.uint32)
+    rng = np.random.default_rng(1)
+    rng.shuffle(roots)                                   # classes interleaved in the caller's order
+    roots[17] = E.NO_ROOT
+    res, ref = check(spf_ctx, g, roots, run_flags)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    tot = np.array([G.slot_table(int(r))[2] if r != E.NO_ROOT else 0 for r in roots])
+    G.free()
+    assert (tot > 16).sum() >= 20 and (tot <= 16).sum() >= 256        # the mixture this test is about
+    assert res.stats["n_dag_launches"] > 0 and res.stats["state_bytes"] in (4, 8)   # both paths ran in one call
+    assert res.stats["n_roots"] == len(roots)
+
+
+def test_many_roots_regrouped_device_outputs(spf_ctx):
+    """Same regrouping through hspf_run_device (rows permuted straight into the caller's device buffers)."""
+    import torch
+    g = synth.random_lsdb(420, 2, 3.0, 777, metric_hi=5, lan_size=40)
+    roots = np.arange(2, g.n, dtype=np.uint32)[::-1].copy()
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    W = G.mask_words(roots)
+    R, n = len(roots), g.n
+    dev = torch.device("cuda:0")
+    dist = torch.empty((R, n), dtype=torch.int32, device=dev); hops = torch.empty((R, n), dtype=torch.int16, device=dev)
+    flags = torch.empty((R, n), dtype=torch.int16, device=dev); mask = torch.empty((R, n, W), dtype=torch.int64, device=dev)
+    spf_ctx.run_device(G, roots, 0, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(), flags_ptr=flags.data_ptr(),
+                       mask_ptr=mask.data_ptr(), mask_words=W)
+    torch.cuda.synchronize()
+    G.free()
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 0, go.MAP, mask_words_=W)
+    assert np.array_equal(dist.cpu().numpy().view(np.uint32), ref.dist)
+    assert np.array_equal(hops.cpu().numpy().view(np.uint16), ref.hops)
+    assert np.array_equal(flags.cpu().numpy().view(np.uint16) & 1, ref.flags)
+    assert np.array_equal(mask.cpu().numpy().view(np.uint64), ref.mask)
