@@ -638,6 +638,54 @@ def manet_init_cache(level: int, instance: Instance, engine, flooding_algo_of=No
     return out
 
 
+def flood_reduction_hash(lsp_id: Tuple[bytes, int, int]) -> int:
+    """flood_reduction_hash (holo-isis/src/flooding/manet.rs:190-194): Fletcher-16 of the 8-byte LSP id with
+    the fragment number shifted right by 3 (`fletcher` crate, calc_fletcher16: two running sums mod 255 over
+    the bytes, result = sum2 << 8 | sum1).  Pinned by the reference's unit test vectors
+    (manet.rs:205-232, from draft-ietf-lsr-distoptflood-12 section 1.2.3) in tests/test_host_manet.py."""
+    system_id, pseudonode, fragment = lsp_id
+    s1 = s2 = 0
+    for b in bytes(system_id) + bytes([pseudonode & 0xFF, (fragment & 0xFF) >> 3]):
+        s1 = (s1 + b) % 255
+        s2 = (s2 + s1) % 255
+    return (s2 << 8) | s1
+
+
+def reflood_list(cache: Dict[bytes, NeighborCache], local_system_id: bytes, tn: bytes,
+                 lsp_id: Tuple[bytes, int, int]) -> List[bytes]:
+    """flooding::manet::reflood_list (holo-isis/src/flooding/manet.rs:99-173): the neighbours of transmitting
+    neighbour `tn` that this router has to re-flood LSP `lsp_id` to.  Every query is answered from the
+    hop-count SPT of the batched run in manet_init_cache: second hops in pop order, is_on_path over the tight
+    parent links.  Returns the BTreeSet order (ascending system id)."""
+    c = cache.get(tn)
+    if c is None or not c.remote_nbr_list:
+        return []
+    spt = c.spt_hopcount
+    originator = lsp_id[0]
+    thl = sorted({v.id[1] for v in spt.second_hops()                        # :120-132
+                  if v.id[1] != originator and not spt.is_on_path(v.id[1], originator)})
+    rnl = list(c.remote_nbr_list.items())                                    # BTreeMap order
+    rnum = len(rnl)
+    n0 = flood_reduction_hash(lsp_id) % rnum                                 # :135-139
+    out: List[bytes] = []
+    for k in range(rnum):                                                    # circular from index N, :143-170
+        if not thl:
+            break
+        sid, algo = rnl[(n0 + k) % rnum]
+        if sid == local_system_id:
+            out = [t for t in thl if spt.is_on_path(sid, t)]
+            break
+        if algo != "modified-manet":
+            continue
+        thl = [t for t in thl if not spt.is_on_path(sid, t)]
+    return sorted(out)
+
+
+def should_flood(iface: Interface, reflood: Sequence[bytes]) -> bool:      # manet.rs:176-186
+    rs = set(reflood)
+    return any(a.state == "up" and a.system_id in rs for a in iface.adjacencies)
+
+
 # ---- routes ------------------------------------------------------------------------------------------
 
 def _addr_key(a: str):

@@ -356,3 +356,58 @@ def local_rib(vec):
         nhs = [list(r["nexthops"][k]) for k in sorted(r["nexthops"])]
         rows.append({"prefix": r["prefix"], "metric": r["metric"], "level": r["level"], "nexthops": nhs})
     return rows
+
+
+# ---- flooding::manet (holo-isis/src/flooding/manet.rs) ---------------------------------------------------------------
+
+def flood_reduction_hash(lsp_id):
+    """manet.rs:190-194 over the 8 bytes [system id (6), pseudonode, fragment >> 3]; Fletcher-16 as the `fletcher`
+    crate (0.3) computes it: sum1 = (sum1 + byte) mod 255, sum2 = (sum2 + sum1) mod 255, result sum2 << 8 | sum1."""
+    sid, pn, frag = lsp_id
+    data = bytes(sid) + bytes([pn & 0xFF, (frag & 0xFF) >> 3])
+    s1 = s2 = 0
+    for b in data:
+        s1 = (s1 + b) % 255
+        s2 = (s2 + s1) % 255
+    return (s2 << 8) | s1
+
+
+def _is_on_path(spt, ancestor, descendant):                                 # spf.rs:261-286, DFS over every parent
+    a, d = (True, ancestor, 0), (True, descendant, 0)
+    if a not in spt or d not in spt:
+        return False
+    stack, seen = [d], set()
+    while stack:
+        cur = stack.pop()
+        if cur == a:
+            return True
+        if cur in seen:
+            continue
+        seen.add(cur)
+        stack.extend(spt[cur].parents)
+    return False
+
+
+def reflood_list(vec, level, local_system_id, tn, lsp_id, algo_of=None):
+    """manet.rs:47-97 (the cache entry of neighbour `tn`, rebuilt here from scratch) + :99-173, literally."""
+    spt, order = compute_spt(vec, level, tn, False, None, True)
+    first = [v for v in order if v[0] and spt[v].hops == 1]
+    second = [v for v in order if v[0] and spt[v].hops == 2]
+    rnl = sorted((v[1], (algo_of(v[1]) if algo_of else "zero-pruner")) for v in first)
+    if not rnl:
+        return []
+    originator = lsp_id[0]
+    thl = sorted({v[1] for v in second if v[1] != originator and not _is_on_path(spt, v[1], originator)})
+    n0 = flood_reduction_hash(lsp_id) % len(rnl)
+    out = []
+    for k in range(len(rnl)):
+        if not thl:
+            break
+        sid, algo = rnl[(n0 + k) % len(rnl)]
+        if sid == local_system_id:
+            out = [t for t in thl if _is_on_path(spt, sid, t)]
+            break
+        if algo != "modified-manet":
+            continue
+        thl = [t for t in thl if not _is_on_path(spt, sid, t)]
+    return sorted(out)

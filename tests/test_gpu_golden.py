@@ -62,3 +62,14 @@ def test_isis_step_on_gpu_through_patched_graphs(spf_ctx, path):
 @pytest.mark.parametrize("path", OSPF_STEP_FILES, ids=[os.path.basename(p)[:-5] for p in OSPF_STEP_FILES])
 def test_ospfv2_step_on_gpu_through_patched_graphs(spf_ctx, path):
     replay_ospf_step(json.load(open(path)), spf_ctx)
+
+
+# ---- flooding::manet: one batched hop-count run per level, reflood lists answered from it ----------------------------
+from test_host_manet import check_reflood_lists      # noqa: E402
+
+MANET_FILES = sorted(glob.glob(os.path.join(GOLD, "isis", "*.json")))[::2]
+
+
+@pytest.mark.parametrize("path", MANET_FILES, ids=[os.path.basename(p)[:-5] for p in MANET_FILES])
+def test_manet_reflood_lists_on_gpu_match_literal_restatement(spf_ctx, path):
+    assert check_reflood_lists(json.load(open(path)), spf_ctx) > 0
