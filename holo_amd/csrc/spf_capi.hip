@@ -87,7 +87,12 @@ struct hspf_ctx {
   DevBuf pf_ptr, pf_vtx, pf_met;                    // prefix table of hspf_routes_device
   DevBuf gb, gb_delta;                              // graph build scratch, patch delta
   BuildInfo *h_info = nullptr;     // pinned
-  int *h_changed = nullptr;        // pinned
+  int *h_changed = nullptr;        // pinned, h_changed_cap ints: per-sweep "something changed" flags of a phase
+  size_t h_changed_cap = 0;
+  // host copies of what a run uploads: owned by the ctx so that the asynchronous H2D copies need no stream
+  // synchronisation of their own (they are consumed long before the next run overwrites them)
+  std::vector<uint32_t> hb_roots, hb_tab_ptr, hb_tab_vtx, hb_tab_base;
+  FusedGraph hb_fg;
   uint32_t *h_lane_flags = nullptr; // pinned
   size_t h_lane_cap = 0;
   uint32_t est_relax = 12, est_dag = 12, est_fused = 12;   // launch-ahead estimates (adapted run to run)
@@ -301,7 +306,8 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
   for (auto &e : ctx->ev)
     if (hipEventCreate(&e) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
-  if (hipHostMalloc((void **)&ctx->h_changed, sizeof(int) * 4, hipHostMallocDefault) != hipSuccess) { delete ctx; return HSPF_E_NOMEM; }
+  if (hipHostMalloc((void **)&ctx->h_changed, sizeof(int) * 256, hipHostMallocDefault) != hipSuccess) { delete ctx; return HSPF_E_NOMEM; }
+  ctx->h_changed_cap = 256;
   if (hipHostMalloc((void **)&ctx->h_info, sizeof(BuildInfo), hipHostMallocDefault) != hipSuccess) { hspf_shutdown(ctx); return HSPF_E_NOMEM; }
   *out = ctx;
   return HSPF_OK;
@@ -626,7 +632,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   st.n_roots = n_roots; st.n_batches = B;
 
   // ---- slot tables (host, O(deg) per root) and mask width
-  std::vector<uint32_t> tab_ptr(L + 1, 0), tab_vtx, tab_base;
+  std::vector<uint32_t> &tab_ptr = ctx->hb_tab_ptr, &tab_vtx = ctx->hb_tab_vtx, &tab_base = ctx->hb_tab_base;
+  tab_ptr.assign(L + 1, 0); tab_vtx.clear(); tab_base.clear();
   uint32_t need_words = 1, max_slots = 0;
   {
     std::vector<uint32_t> hv, hb, mark(n, 0xFFFFFFFFu);
@@ -730,7 +737,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 
   // ---- upload roots / slot tables, init state
   {
-    std::vector<uint32_t> rl(L, HSPF_NO_ROOT);
+    std::vector<uint32_t> &rl = ctx->hb_roots;
+    rl.assign(L, HSPF_NO_ROOT);
     std::copy(roots, roots + n_roots, rl.begin());
     HIPCHK(ctx, hipMemcpyAsync(d_roots, rl.data(), (size_t)L * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(ctx->tab_ptr.p, tab_ptr.data(), (size_t)(L + 1) * 4, hipMemcpyHostToDevice, s));
@@ -738,7 +746,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       HIPCHK(ctx, hipMemcpyAsync(ctx->tab_vtx.p, tab_vtx.data(), tab_vtx.size() * 4, hipMemcpyHostToDevice, s));
       HIPCHK(ctx, hipMemcpyAsync(ctx->tab_base.p, tab_base.data(), tab_base.size() * 4, hipMemcpyHostToDevice, s));
     }
-    HIPCHK(ctx, hipStreamSynchronize(s));   // rl / tab_* are stack vectors
+    // rl / tab_* live in the ctx: no synchronisation needed before they go out of scope
   }
   uint64_t *d_st = (uint64_t *)ctx->st64.p;
   uint32_t *d_stamp = (uint32_t *)ctx->stamp.p;
@@ -774,18 +782,25 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       }
       for (uint32_t i = 0; i < chunk; ++i) launch(sweep + i);
       sweep += chunk;
-      er = hipMemcpyAsync(ctx->h_changed, d_changed + (sweep - 1), sizeof(int), hipMemcpyDeviceToHost, s);
+      // ONE read-back per chunk: the flags of every sweep launched so far and the per-root status bits
+      if (ctx->h_changed_cap < sweep) {
+        (void)hipStreamSynchronize(s);
+        (void)hipHostFree(ctx->h_changed);
+        ctx->h_changed = nullptr; ctx->h_changed_cap = 0;
+        const size_t cap = (size_t)sweep * 2;
+        if (hipHostMalloc((void **)&ctx->h_changed, cap * sizeof(int), hipHostMallocDefault) != hipSuccess) { ctx->last_error = "pinned flag buffer"; return HSPF_E_NOMEM; }
+        ctx->h_changed_cap = cap;
+      }
+      er = hipMemcpyAsync(ctx->h_changed, d_changed, (size_t)sweep * sizeof(int), hipMemcpyDeviceToHost, s);
+      if (er == hipSuccess) er = hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s);
       if (er == hipSuccess) er = hipStreamSynchronize(s);
       if (er != hipSuccess) { ctx->last_error = std::string("phase: ") + hipGetErrorString(er); return HSPF_E_HIP; }
-      if (ctx->h_changed[0] == 0) break;
+      if (ctx->h_changed[sweep - 1] == 0) break;
       chunk = 4;
     }
     // count the launches that did work (for stats and the next estimate)
-    std::vector<int> ch(sweep);
-    er = hipMemcpy(ch.data(), d_changed, (size_t)sweep * 4, hipMemcpyDeviceToHost);
-    if (er != hipSuccess) { ctx->last_error = hipGetErrorString(er); return HSPF_E_HIP; }
     uint32_t active = 0;
-    while (active < sweep && ch[active]) ++active;
+    while (active < sweep && ctx->h_changed[active]) ++active;
     n_launch = active + 1;   // the launch that found the fixed point did a full pass too
     return HSPF_OK;
   };
@@ -793,9 +808,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
   if (fused) {
     {
-      const FusedGraph fg{gd, tabs};
-      HIPCHK(ctx, hipMemcpyAsync(ctx->fgraph.p, &fg, sizeof(fg), hipMemcpyHostToDevice, s));
-      HIPCHK(ctx, hipStreamSynchronize(s));     // fg is a stack object
+      ctx->hb_fg = FusedGraph{gd, tabs};
+      HIPCHK(ctx, hipMemcpyAsync(ctx->fgraph.p, &ctx->hb_fg, sizeof(FusedGraph), hipMemcpyHostToDevice, s));
     }
     const FusedGraph *d_fg = (const FusedGraph *)ctx->fgraph.p;
     auto fused_run = [&](bool nar) -> int {
@@ -822,9 +836,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     };
     if (narrow) {
       if ((rc = fused_run(true))) return rc;
-      // did any lane leave the 4-byte fields?  (run_phase has synchronised the stream)
-      HIPCHK(ctx, hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s));
-      HIPCHK(ctx, hipStreamSynchronize(s));
+      // did any lane leave the 4-byte fields?  (run_phase has brought the per-root status bits back)
       bool ovf = false;
       for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);
       if (ovf) { g->narrow_bad = true; narrow = false; st.narrow_overflow = 1; }
@@ -885,9 +897,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 
   }
 
-  // ---- roots whose pop order is dynamic (or forced): sequential exact kernel
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(ctx, hipStreamSynchronize(s));
+  // ---- roots whose pop order is dynamic (or forced): sequential exact kernel (status bits: last run_phase)
   std::vector<uint32_t> ex;
   for (uint32_t r = 0; r < n_roots; ++r) {
     const bool forced = (run_flags & (HSPF_RUN_FORCE_EXACT | HSPF_RUN_POP_RANK)) != 0;
