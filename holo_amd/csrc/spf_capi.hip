@@ -80,7 +80,7 @@ struct hspf_ctx {
   std::string last_error;
   hipEvent_t ev[6] = {};
   // scratch (grown on demand, reused across runs)
-  DevBuf dist, hv, mask, roots, lane_flags, changed, tab_ptr, tab_vtx, tab_base, st64, stamp, hnb, fgraph;
+  DevBuf dist, hv, mask, lane_flags, changed, st64, stamp, hnb;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf p_dist, p_hops, p_flags, p_mask, p_rank, p_dest;   // regrouped runs: outputs in class order before the row permute
   DevBuf ex_list, ex_heap, ex_pos;
@@ -91,8 +91,14 @@ struct hspf_ctx {
   size_t h_changed_cap = 0;
   // host copies of what a run uploads: owned by the ctx so that the asynchronous H2D copies need no stream
   // synchronisation of their own (they are consumed long before the next run overwrites them)
-  std::vector<uint32_t> hb_roots, hb_tab_ptr, hb_tab_vtx, hb_tab_base;
-  FusedGraph hb_fg;
+  std::vector<uint32_t> hb_tab_ptr, hb_tab_vtx, hb_tab_base;
+  // everything a run uploads (roots, slot tables, the fused kernel's descriptor) goes through ONE pinned staging
+  // buffer and ONE asynchronous H2D copy
+  DevBuf up;
+  uint32_t *h_up = nullptr;        // pinned
+  size_t h_up_cap = 0;             // bytes
+  std::vector<uint32_t> mark;      // visited stamps of build_slot_table, kept across calls (no O(n) fill per run)
+  uint32_t mark_epoch = 0;
   uint32_t *h_lane_flags = nullptr; // pinned
   size_t h_lane_cap = 0;
   uint32_t est_relax = 12, est_dag = 12, est_fused = 12;   // launch-ahead estimates (adapted run to run)
@@ -152,6 +158,12 @@ void build_slot_table(const hspf_graph *g, uint32_t root, std::vector<uint32_t> 
       total += g->row_ptr[t + 1] - g->row_ptr[t];
     }
   }
+}
+
+// A fresh stamp for build_slot_table's visited marks (ctx->mark has at least n entries, none equal to the stamp).
+uint32_t next_mark(hspf_ctx *ctx, uint32_t n) {
+  if (ctx->mark.size() < n || ctx->mark_epoch >= 0xFFFFFFF0u) { ctx->mark.assign(std::max<size_t>(n, ctx->mark.size()), 0u); ctx->mark_epoch = 0; }
+  return ++ctx->mark_epoch;
 }
 
 uint32_t round_words(uint32_t w) {   // template instantiations of k_dag / k_emit
@@ -317,12 +329,14 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->roots, &ctx->lane_flags, &ctx->changed,
-                    &ctx->tab_ptr, &ctx->tab_vtx, &ctx->tab_base, &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->fgraph, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
+  for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
+                    &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
                     &ctx->o_mask, &ctx->o_rank, &ctx->p_dist, &ctx->p_hops, &ctx->p_flags, &ctx->p_mask, &ctx->p_rank, &ctx->p_dest, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->gb, &ctx->gb_delta})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
+  if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+  release(ctx->up);
   if (ctx->h_info) (void)hipHostFree(ctx->h_info);
   for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -556,13 +570,13 @@ uint32_t hspf_graph_n_edges(const hspf_graph *g) { return g ? g->e : 0; }
 
 int hspf_mask_words(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t *out_words) {
   if (!ctx || !g || !roots || !out_words) return HSPF_E_INVAL;
-  std::vector<uint32_t> hv, hb, mark(g->n, 0xFFFFFFFFu);
+  std::vector<uint32_t> hv, hb;
   uint32_t w = 1;
   for (uint32_t r = 0; r < n_roots; ++r) {
     if (roots[r] == HSPF_NO_ROOT) continue;
     if (roots[r] >= g->n) return HSPF_E_INVAL;
     uint32_t total = 0;
-    build_slot_table(g, roots[r], hv, hb, total, mark, r);
+    build_slot_table(g, roots[r], hv, hb, total, ctx->mark, next_mark(ctx, g->n));
     w = std::max(w, (total + 63) / 64);
   }
   *out_words = w;
@@ -572,9 +586,9 @@ int hspf_mask_words(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 int hspf_slot_table(hspf_ctx *ctx, const hspf_graph *g, uint32_t root, uint32_t *h_vertex, uint32_t *h_base,
                     uint32_t cap, uint32_t *out_total_slots) {
   if (!ctx || !g || root >= g->n) return HSPF_E_INVAL;
-  std::vector<uint32_t> hv, hb, mark(g->n, 0xFFFFFFFFu);
+  std::vector<uint32_t> hv, hb;
   uint32_t total = 0;
-  build_slot_table(g, root, hv, hb, total, mark, 0);
+  build_slot_table(g, root, hv, hb, total, ctx->mark, next_mark(ctx, g->n));
   for (uint32_t i = 0; i < hv.size() && i < cap; ++i) {
     if (h_vertex) h_vertex[i] = hv[i];
     if (h_base) h_base[i] = hb[i];
@@ -636,11 +650,11 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   tab_ptr.assign(L + 1, 0); tab_vtx.clear(); tab_base.clear();
   uint32_t need_words = 1, max_slots = 0;
   {
-    std::vector<uint32_t> hv, hb, mark(n, 0xFFFFFFFFu);
+    std::vector<uint32_t> hv, hb;
     for (uint32_t r = 0; r < L; ++r) {
       if (r < n_roots && roots[r] != HSPF_NO_ROOT) {
         uint32_t total = 0;
-        build_slot_table(g, roots[r], hv, hb, total, mark, r);
+        build_slot_table(g, roots[r], hv, hb, total, ctx->mark, next_mark(ctx, n));
         max_slots = std::max(max_slots, total);
         need_words = std::max(need_words, (total + 63) / 64);
         // entry 0 (the root itself, base 0) is implicit on device
@@ -691,18 +705,26 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     if ((rc = ensure(ctx, ctx->st64, rows * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stamp, (size_t)B * n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->hnb, (size_t)B * n))) return rc;
-    if ((rc = ensure(ctx, ctx->fgraph, sizeof(FusedGraph)))) return rc;
   } else {
     if ((rc = ensure(ctx, ctx->dist, rows * 4))) return rc;
     if ((rc = ensure(ctx, ctx->hv, rows * 4))) return rc;
     if ((rc = ensure(ctx, ctx->mask, rows * 8 * W))) return rc;
   }
-  if ((rc = ensure(ctx, ctx->roots, (size_t)L * 4))) return rc;
   if ((rc = ensure(ctx, ctx->lane_flags, (size_t)L * 4))) return rc;
   if ((rc = ensure(ctx, ctx->changed, (size_t)CHANGED_CAP * 4))) return rc;
-  if ((rc = ensure(ctx, ctx->tab_ptr, (size_t)(L + 1) * 4))) return rc;
-  if ((rc = ensure(ctx, ctx->tab_vtx, std::max<size_t>(tab_vtx.size(), 1) * 4))) return rc;
-  if ((rc = ensure(ctx, ctx->tab_base, std::max<size_t>(tab_base.size(), 1) * 4))) return rc;
+  // upload block (u32 words): roots[L] | tab_ptr[L+1] | tab_vtx[nv] | tab_base[nv] | pad to 16 B | FusedGraph
+  const size_t nv = tab_vtx.size();
+  const size_t w_roots = 0, w_ptr = L, w_vtx = w_ptr + L + 1, w_base = w_vtx + std::max<size_t>(nv, 1);
+  const size_t w_fg = (w_base + std::max<size_t>(nv, 1) + 3) & ~size_t(3);
+  const size_t up_bytes = w_fg * 4 + sizeof(FusedGraph);
+  if ((rc = ensure(ctx, ctx->up, up_bytes))) return rc;
+  if (ctx->h_up_cap < up_bytes) {
+    (void)hipStreamSynchronize(s);
+    if (ctx->h_up) (void)hipHostFree(ctx->h_up);
+    ctx->h_up = nullptr; ctx->h_up_cap = 0;
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_up, up_bytes * 2, hipHostMallocDefault));
+    ctx->h_up_cap = up_bytes * 2;
+  }
   if (ctx->h_lane_cap < L) {
     if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
     ctx->h_lane_flags = nullptr; ctx->h_lane_cap = 0;
@@ -726,27 +748,28 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     if (run_flags & HSPF_RUN_POP_RANK) d_rank = out->pop_rank;
   }
 
-  uint32_t *d_dist = (uint32_t *)ctx->dist.p, *d_hv = (uint32_t *)ctx->hv.p, *d_roots = (uint32_t *)ctx->roots.p;
+  uint32_t *d_up = (uint32_t *)ctx->up.p;
+  uint32_t *d_dist = (uint32_t *)ctx->dist.p, *d_hv = (uint32_t *)ctx->hv.p, *d_roots = d_up + w_roots;
   uint64_t *d_mask = (uint64_t *)ctx->mask.p;
   uint32_t *d_lf = (uint32_t *)ctx->lane_flags.p;
   int *d_changed = (int *)ctx->changed.p;
   const GraphDev gd = g->dev();
-  const SlotTabs tabs{(const uint32_t *)ctx->tab_ptr.p, (const uint32_t *)ctx->tab_vtx.p, (const uint32_t *)ctx->tab_base.p};
+  const SlotTabs tabs{d_up + w_ptr, d_up + w_vtx, d_up + w_base};
   const uint32_t ignore_ovl = (run_flags & HSPF_RUN_IGNORE_OVERLOAD) ? 1u : 0u;
   const uint32_t net_nh = (run_flags & HSPF_RUN_NET_NEXTHOPS) ? 1u : 0u;
 
-  // ---- upload roots / slot tables, init state
+  // ---- upload roots / slot tables / descriptor (one pinned block, one copy), init state
   {
-    std::vector<uint32_t> &rl = ctx->hb_roots;
-    rl.assign(L, HSPF_NO_ROOT);
-    std::copy(roots, roots + n_roots, rl.begin());
-    HIPCHK(ctx, hipMemcpyAsync(d_roots, rl.data(), (size_t)L * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->tab_ptr.p, tab_ptr.data(), (size_t)(L + 1) * 4, hipMemcpyHostToDevice, s));
-    if (!tab_vtx.empty()) {
-      HIPCHK(ctx, hipMemcpyAsync(ctx->tab_vtx.p, tab_vtx.data(), tab_vtx.size() * 4, hipMemcpyHostToDevice, s));
-      HIPCHK(ctx, hipMemcpyAsync(ctx->tab_base.p, tab_base.data(), tab_base.size() * 4, hipMemcpyHostToDevice, s));
-    }
-    // rl / tab_* live in the ctx: no synchronisation needed before they go out of scope
+    uint32_t *h = ctx->h_up;
+    std::fill(h + w_roots, h + w_roots + L, HSPF_NO_ROOT);
+    std::copy(roots, roots + n_roots, h + w_roots);
+    std::copy(tab_ptr.begin(), tab_ptr.end(), h + w_ptr);
+    std::copy(tab_vtx.begin(), tab_vtx.end(), h + w_vtx);
+    std::copy(tab_base.begin(), tab_base.end(), h + w_base);
+    const FusedGraph fg{gd, tabs};
+    memcpy(h + w_fg, &fg, sizeof(FusedGraph));
+    HIPCHK(ctx, hipMemcpyAsync(d_up, h, up_bytes, hipMemcpyHostToDevice, s));
+    // the pinned block belongs to the ctx and is rewritten by the next run only, after this one has synchronised
   }
   uint64_t *d_st = (uint64_t *)ctx->st64.p;
   uint32_t *d_stamp = (uint32_t *)ctx->stamp.p;
@@ -767,7 +790,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 
   // ---- phase 1: distances.  Launch ahead `est` sweeps (each launch exits at once when the
   // previous one changed nothing), then read ONE flag back; repeat in small chunks if needed.
-  auto run_phase = [&](uint32_t est, auto &&launch, uint32_t &n_launch) -> int {
+  // `post` is enqueued behind every chunk of sweeps, BEFORE the host knows whether the chunk reached the fixed point:
+  // work that is only needed once (the emit of the fused path) then starts without waiting for the host's round
+  // trip; after a chunk that did not converge it is simply enqueued again behind the next one.
+  auto run_phase = [&](uint32_t est, auto &&launch, uint32_t &n_launch, auto &&post) -> int {
     hipError_t er = hipMemsetAsync(d_changed, 0, (size_t)std::min<uint32_t>(CHANGED_CAP, est + 4096) * 4, s);
     if (er != hipSuccess) { ctx->last_error = hipGetErrorString(er); return HSPF_E_HIP; }
     uint32_t zeroed = std::min<uint32_t>(CHANGED_CAP, est + 4096);
@@ -782,6 +808,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       }
       for (uint32_t i = 0; i < chunk; ++i) launch(sweep + i);
       sweep += chunk;
+      post();
       // ONE read-back per chunk: the flags of every sweep launched so far and the per-root status bits
       if (ctx->h_changed_cap < sweep) {
         (void)hipStreamSynchronize(s);
@@ -807,11 +834,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 
   HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
   if (fused) {
-    {
-      ctx->hb_fg = FusedGraph{gd, tabs};
-      HIPCHK(ctx, hipMemcpyAsync(ctx->fgraph.p, &ctx->hb_fg, sizeof(FusedGraph), hipMemcpyHostToDevice, s));
-    }
-    const FusedGraph *d_fg = (const FusedGraph *)ctx->fgraph.p;
+    const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
     auto fused_run = [&](bool nar) -> int {
       const FusedParams P = nar ? fp_narrow : fp_wide;
       const size_t esz = nar ? 4 : 8;
@@ -828,7 +851,14 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         if (nar)         hipLaunchKernelGGL((k_fused<uint32_t, false>), fgrid, dim3(256), 0, s, d_fg, (uint32_t *)d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
         else if (maxinf) hipLaunchKernelGGL((k_fused<uint64_t, true>), fgrid, dim3(256), 0, s, d_fg, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
         else             hipLaunchKernelGGL((k_fused<uint64_t, false>), fgrid, dim3(256), 0, s, d_fg, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
-      }, n_f);
+      }, n_f, [&]() {
+        // results out of the packed state (speculative: valid when this chunk reached the fixed point and, for the
+        // 4-byte state, no lane overflowed; otherwise redone behind the next chunk / the wide run)
+        (void)hipEventRecord(ctx->ev[2], s);
+        (void)hipEventRecord(ctx->ev[3], s);
+        if (nar) hipLaunchKernelGGL((k_emit_fused<uint32_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint32_t *)d_st, P, od);
+        else     hipLaunchKernelGGL((k_emit_fused<uint64_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint64_t *)d_st, P, od);
+      });
       if (r2) return r2;
       ctx->est_fused = n_f + 1;
       st.n_relax_launches += n_f;
@@ -843,10 +873,6 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     }
     if (!narrow && (rc = fused_run(false))) return rc;
     st.state_bytes = narrow ? 4 : 8;
-    HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
-    HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
-    if (narrow) hipLaunchKernelGGL((k_emit_fused<uint32_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint32_t *)d_st, fp_narrow, od);
-    else        hipLaunchKernelGGL((k_emit_fused<uint64_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint64_t *)d_st, fp_wide, od);
   } else {
   uint32_t n_relax = 0;
   rc = run_phase(ctx->est_relax, [&](uint32_t sweep) {
@@ -854,7 +880,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       hipLaunchKernelGGL((k_relax<true>), grid, dim3(256), 0, s, gd, d_dist, d_roots, g->max_path_metric, ignore_ovl, d_changed, (int)sweep, d_lf);
     else
       hipLaunchKernelGGL((k_relax<false>), grid, dim3(256), 0, s, gd, d_dist, d_roots, g->max_path_metric, ignore_ovl, d_changed, (int)sweep, d_lf);
-  }, n_relax);
+  }, n_relax, []() {});
   if (rc) return rc;
   ctx->est_relax = n_relax + 1;
   st.n_relax_launches = n_relax;
@@ -877,7 +903,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       default: launch_dag<16>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u); break;
     }
     ++epoch;
-  }, n_dag);
+  }, n_dag, []() {});
   if (rc) return rc;
   ctx->est_dag = n_dag + 1;
   st.n_dag_launches = n_dag;
@@ -970,12 +996,12 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
   std::vector<uint8_t> cls(n_roots, 0);
   uint32_t cnt[3] = {0, 0, 0};
   {
-    std::vector<uint32_t> hv, hb, mark(n, 0xFFFFFFFFu);
+    std::vector<uint32_t> hv, hb;
     for (uint32_t r = 0; r < n_roots; ++r) {
       uint32_t total = 0;
       if (roots[r] != HSPF_NO_ROOT) {
         if (roots[r] >= n) { ctx->last_error = "root out of range"; return HSPF_E_INVAL; }
-        build_slot_table(g, roots[r], hv, hb, total, mark, r);
+        build_slot_table(g, roots[r], hv, hb, total, ctx->mark, next_mark(ctx, n));
       }
       cls[r] = total > 16 ? 2 : (total > m_narrow ? 1 : 0);
       cnt[cls[r]]++;
