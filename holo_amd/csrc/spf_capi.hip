@@ -980,10 +980,11 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 // the call down the two-phase path, one with 15-16 slots makes the packed state 8 bytes wide for all.  With many roots
 // ("every router of the area") that is the common case, so the roots are regrouped by what
 // they need — narrow fused / wide fused / two-phase —, each class runs on its own, and the rows are put back in the
-// caller's order by one streaming pass.  Small calls are left alone: an extra run costs a whole fixed point.
+// caller's order by one streaming pass.  A class is only split off when that saves work: an extra run costs a whole
+// fixed point.
 static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
                        hspf_result *out, bool host_out) {
-  if (!ctx || !g || !roots || !out || n_roots < 128 || !out->dist || (run_flags & (HSPF_RUN_FORCE_EXACT | HSPF_RUN_POP_RANK)))
+  if (!ctx || !g || !roots || !out || n_roots <= 64 || !out->dist || (run_flags & (HSPF_RUN_FORCE_EXACT | HSPF_RUN_POP_RANK)))
     return run_impl(ctx, g, roots, n_roots, run_flags, out, host_out);
   const uint32_t n = g->n;
   // widest mask field the 4-byte state can take on this graph (same rule as run_impl)
@@ -1008,7 +1009,9 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     }
   }
   const bool fused_ok = n < (1u << 23) && !(ctx->variant & 1u);
-  const bool split2 = fused_ok && cnt[2] > 0 && cnt[0] + cnt[1] >= 64;          // keep the others off the two-phase path
+  // off the two-phase path with everybody who does not need it, when that saves at least one 64-root batch there (a
+  // two-phase batch moves 8W-byte mask rows and costs several fused ones)
+  const bool split2 = fused_ok && cnt[2] > 0 && cnt[0] + cnt[1] > 0 && (cnt[2] + 63) / 64 < (n_roots + 63) / 64;
   const bool split1 = fused_ok && m_narrow > 0 && cnt[1] > 0 && cnt[0] >= 256;  // keep the narrow ones narrow
   if ((cnt[2] > 0 && !split2) || (!split1 && !split2))        // one run as before (two-phase for all / fused for all)
     return run_impl(ctx, g, roots, n_roots, run_flags, out, host_out);
