@@ -37,7 +37,8 @@ struct BuildInfo {       // device-resident summary of one build, copied back on
   uint32_t wmax;         // largest kept cost
   uint32_t hc_bad;       // some kept link breaks the hop-count shape
   uint32_t hc_net;       // some network row has a kept in-link
-  uint32_t pad[3];
+  uint32_t xcd_start[9]; // GraphDev::xcd_start: work-balanced chunk ranges of the 8 XCDs
+  uint32_t pad[2];
 };
 
 constexpr int GB_BLOCK = 256;
@@ -236,6 +237,23 @@ kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__r
   rowflags[t] = (uint8_t)f;
   if (bad) info->hc_bad = 1u;                 // plain stores: every writer stores the same value
   if (net && b > a) info->hc_net = 1u;
+}
+
+// Work-balanced XCD ranges (GraphDev::xcd_start): cost of a 16-vertex chunk prefix k = in-links of the first 16k
+// vertices + 8 per vertex (a row costs about 8 links' worth of fixed work); XCD x starts at the first chunk whose
+// prefix reaches x/8 of the total.  Seven binary searches, one thread each.
+__global__ void kb_xcd(uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *__restrict__ info) {
+  const uint32_t x = threadIdx.x;
+  if (x > 8u) return;
+  const uint32_t nb = (n + 15u) / 16u;
+  auto cost = [&](uint32_t k) -> uint64_t { const uint32_t v = min(k * 16u, n); return (uint64_t)in_ptr[v] + 8ull * v; };
+  const uint64_t total = cost(nb), want = total * x / 8ull;
+  uint32_t lo = 0, hi = nb;                       // smallest k with cost(k) >= want
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (cost(mid) >= want) hi = mid; else lo = mid + 1;
+  }
+  info->xcd_start[x] = x == 8u ? nb : lo;
 }
 
 __global__ void kb_pads(uint32_t n, const BuildInfo *__restrict__ info, uint32_t *in_ptr, uint32_t *out_ptr,

@@ -37,6 +37,8 @@ struct hspf_graph {
   uint32_t wmax = 0;                 // largest cost among the kept links
   mutable bool narrow_bad = false;   // a run overflowed the 4-byte fused state: use the 8-byte one
   bool hopcount_like = false;        // every kept link into a network costs 0 (from a router), into a router 1
+  uint32_t xcd_start[9] = {};        // work-balanced chunk ranges of the 8 XCDs (GraphDev::xcd_start)
+  uint32_t xcd_blocks() const { uint32_t m = 0; for (int x = 0; x < 8; ++x) m = std::max(m, xcd_start[x + 1] - xcd_start[x]); return 8u * std::max(m, 1u); }
   // host mirrors: slot tables walk the root's neighbourhood on the host
   std::vector<uint32_t> row_ptr, col;
   std::vector<uint8_t> twoway;     // per original link (computed on device, copied back)
@@ -69,6 +71,7 @@ struct hspf_graph {
     g.in_ptr = d_in_ptr; g.in_src = d_in_src; g.in_w = d_in_w; g.in_fpos = d_in_fpos;
     g.vflags = d_vflags; g.rowflags = d_rowflags;
     g.out_ptr = d_out_ptr; g.out_dst = d_out_dst; g.out_w = d_out_w; g.out_fpos = d_out_fpos;
+    for (int x = 0; x < 9; ++x) g.xcd_start[x] = xcd_start[x];
     return g;
   }
 };
@@ -177,9 +180,9 @@ uint32_t round_words(uint32_t w) {   // template instantiations of k_dag / k_emi
 template <int W, bool GS = false>
 void launch_dag(dim3 grid, hipStream_t s, GraphDev g, const uint32_t *dist, uint32_t *hv, uint64_t *mask,
                 const uint32_t *roots, SlotTabs tabs, uint32_t nn, uint32_t io, int *changed, int sweep,
-                uint32_t epoch, uint32_t *lf, uint32_t hc) {
+                uint32_t epoch, uint32_t *lf, uint32_t hc, uint32_t *act) {
   hipLaunchKernelGGL((k_dag<W, GS>), grid, dim3(256), 0, s, g, dist, hv, mask, roots, tabs, nn, io, changed,
-                     sweep, epoch, lf, hc);
+                     sweep, epoch, lf, hc, act);
 }
 template <int W>
 void launch_emit(dim3 grid, hipStream_t s, uint32_t n, uint32_t nr, const uint32_t *dist, const uint32_t *hv,
@@ -243,6 +246,7 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   }
   hipLaunchKernelGGL(kb_rowflags, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
                      (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info);
+  hipLaunchKernelGGL(kb_xcd, dim3(1), dim3(64), 0, s, n, (const uint32_t *)g->d_in_ptr, info);
   hipLaunchKernelGGL(kb_pads, dim3(1), dim3(64), 0, s, n, (const BuildInfo *)info, g->d_in_ptr, g->d_out_ptr,
                      g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos);
   HIPCHK(ctx, hipGetLastError());
@@ -258,6 +262,7 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   g->e_kept = bi.kept;
   g->wmax = bi.wmax;
   g->hopcount_like = !bi.hc_bad && bi.hc_net;
+  for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
   g->narrow_bad = false;
   return HSPF_OK;
 }
@@ -709,6 +714,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     if ((rc = ensure(ctx, ctx->dist, rows * 4))) return rc;
     if ((rc = ensure(ctx, ctx->hv, rows * 4))) return rc;
     if ((rc = ensure(ctx, ctx->mask, rows * 8 * W))) return rc;
+    if ((rc = ensure(ctx, ctx->stamp, (size_t)B * n * 4))) return rc;
   }
   if ((rc = ensure(ctx, ctx->lane_flags, (size_t)L * 4))) return rc;
   if ((rc = ensure(ctx, ctx->changed, (size_t)CHANGED_CAP * 4))) return rc;
@@ -784,9 +790,12 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   }
 
   const uint32_t vblocks = (n + VPB - 1) / VPB;
-  const dim3 grid(((vblocks + 7) / 8) * 8, B);
+  (void)vblocks;
+  const dim3 grid(g->xcd_blocks(), B);                     // 8 x the longest XCD range; shorter ranges leave idle blocks
   const uint32_t fblocks = (n + FVPB - 1) / FVPB;
-  const dim3 fgrid(((fblocks + 7) / 8) * 8, B);          // the fused kernel's blocks cover FQ x more vertices
+  (void)fblocks;
+  static_assert(FVPB == VPB && VPB == 16, "xcd_start is in 16-vertex chunks for every kernel");
+  const dim3 fgrid(g->xcd_blocks(), B);
 
   // ---- phase 1: distances.  Launch ahead `est` sweeps (each launch exits at once when the
   // previous one changed nothing), then read ONE flag back; repeat in small chunks if needed.
@@ -888,6 +897,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 
   // ---- phase 2: hops + first-hop masks over the tight-edge DAG
   HIPCHK(ctx, hipMemsetAsync(d_mask, 0, rows * 8 * W, s));
+  HIPCHK(ctx, hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s));       // activation stamps: every row due in sweep 0
   uint32_t n_dag = 0;
   uint32_t epoch = 1;
   rc = run_phase(ctx->est_dag, [&](uint32_t sweep) {
@@ -896,11 +906,11 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       epoch = 2;
     }
     switch (W) {
-      case 1: launch_dag<1, true>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u); break;
-      case 2: launch_dag<2>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u); break;
-      case 4: launch_dag<4>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u); break;
-      case 8: launch_dag<8>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u); break;
-      default: launch_dag<16>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u); break;
+      case 1: launch_dag<1, true>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u, d_stamp); break;
+      case 2: launch_dag<2>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u, d_stamp); break;
+      case 4: launch_dag<4>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u, d_stamp); break;
+      case 8: launch_dag<8>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u, d_stamp); break;
+      default: launch_dag<16>(grid, s, gd, d_dist, d_hv, d_mask, d_roots, tabs, net_nh, ignore_ovl, d_changed, (int)sweep, epoch, d_lf, g->hopcount_like ? 1u : 0u, d_stamp); break;
     }
     ++epoch;
   }, n_dag, []() {});

@@ -61,6 +61,11 @@ struct GraphDev {
   const uint32_t *out_dst;  // [e_in]
   const uint32_t *out_w;    // [e_in]
   const uint32_t *out_fpos; // [e_in]
+  // XCD x (blocks with blockIdx.x % 8 == x, MI355X_MICROARCH.md) owns the 16-vertex chunks xcd_start[x] ..
+  // xcd_start[x+1]: contiguous, so that the rows a wave touches stay in that XCD's L2, and cut at equal WORK
+  // (in-links + a per-row constant), not equal vertex counts: in a fat-tree all 12 500 hundred-link switch rows come
+  // first in VertexId order and would otherwise all land on XCD 0.
+  uint32_t xcd_start[9];
 };
 
 struct OutDev {
@@ -83,11 +88,12 @@ struct SlotTabs {           // per root: H vertices and their slot bases (includ
 // MI355X_MICROARCH.md "Workgroup dispatch").  Give every XCD one contiguous eighth of the vertex
 // range so that the rows a wave touches (its neighbours in a spatially numbered LSDB) stay in
 // that XCD's private 4 MiB L2.  Speed only: any placement gives the same result.
-__device__ __forceinline__ uint32_t xcd_chunk(uint32_t bx, uint32_t gx /* multiple of 8 */) {
-#ifdef HSPF_NO_XCD
-  return bx;
-#endif
-  return (bx & 7u) * (gx >> 3) + (bx >> 3);
+// Returns the chunk of block bx, or 0xFFFFFFFF when this XCD's range is shorter than the grid's share (the grid is
+// 8 x the longest range).
+__device__ __forceinline__ uint32_t xcd_chunk(const uint32_t *xcd_start, uint32_t bx) {
+  const uint32_t x = bx & 7u, j = bx >> 3;
+  const uint32_t s0 = xcd_start[x], s1 = xcd_start[x + 1];
+  return j < s1 - s0 ? s0 + j : 0xFFFFFFFFu;
 }
 
 __device__ __forceinline__ uint32_t slot_base_of(const SlotTabs &t, uint32_t root_slot, uint32_t u) {
@@ -153,7 +159,8 @@ __global__ __launch_bounds__(256) void k_relax(GraphDev g, uint32_t *__restrict_
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t batch = blockIdx.y;
-  const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const uint32_t chunk = xcd_chunk(g.xcd_start, blockIdx.x);
+  if (chunk == 0xFFFFFFFFu) return;
   const uint32_t vbeg = chunk * VPB + wave * VPW;
   const uint32_t n = g.n;
   if (vbeg >= n) return;
@@ -228,12 +235,17 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
                                              const uint32_t *__restrict__ roots, SlotTabs tabs,
                                              uint32_t net_nexthops, uint32_t ignore_ovl,
                                              int *changed, int sweep, uint32_t epoch,
-                                             uint32_t *lane_flags, uint32_t hc) {
+                                             uint32_t *lane_flags, uint32_t hc, uint32_t *__restrict__ act) {
+  // links per group = neighbour rows requested together: more for narrow masks (a 100-link row of a fat-tree switch is
+  // 2 dependent round trips per group), fewer for wide ones (2 * DG * W mask registers)
+  constexpr int DG = W <= 2 ? 8 : (W <= 4 ? 4 : 2);
+  constexpr int NDG = 64 / DG;
   if (sweep > 0 && changed[sweep - 1] == 0) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t batch = blockIdx.y;
-  const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const uint32_t chunk = xcd_chunk(g.xcd_start, blockIdx.x);
+  if (chunk == 0xFFFFFFFFu) return;
   const uint32_t vbeg = chunk * VPB + wave * VPW;
   const uint32_t n = g.n;
   if (vbeg >= n) return;
@@ -247,11 +259,18 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
   uint64_t *M = mask + (size_t)batch * n * 64 * W;
   const uint32_t lane4 = lane * 4u, lane8 = lane * 8u;
   const uint32_t pv = in_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
+  // Push activation, as in k_fused: a row can only make progress after one of its in-neighbours became final for
+  // some root, and a row that does so in sweep s stamps s + 1 on its out-neighbours; every row is due in sweep 0
+  // (stamps start at 0).  Without it every pending row re-walks all its links in every sweep.
+  uint32_t *A = act + (size_t)batch * n;
+  const uint32_t av = A[min(vbeg + min(lane, (uint32_t)VPW - 1u), n - 1)];
+  const uint32_t po = g.out_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
   bool any = false;
 #pragma unroll 1
   for (int i = 0; i < VPW; ++i) {
     const uint32_t v = vbeg + i;
     if (v >= n) break;
+    if (rdlane(av, i) < (uint32_t)sweep) continue;       // none of its in-neighbours changed in the last sweep
     const uint32_t cur = ld_row(H, v * 256u + lane4);
     const bool need0 = (cur >> HV_EPOCH_SHIFT) == 0;
     if (__ballot(need0) == 0ull) continue;               // whole row already final
@@ -282,44 +301,45 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
         const bool has_zl = hc != 0u && __ballot(zvec != 0u) != 0ull;
         if (lane >= cnt || (zvec && !hc)) { sv = v; wv = 1u; }
 #pragma unroll
-        for (int gi = 0; gi < NGRP; ++gi) {
-          if (cnt <= (uint32_t)(gi * GRP)) break;
-          uint32_t du[GRP];
-          bool tight[GRP];
+        for (int gi = 0; gi < NDG; ++gi) {
+          if (cnt <= (uint32_t)(gi * DG)) break;
+          uint32_t du[DG];
+          bool tight[DG];
 #pragma unroll
-          for (int k = 0; k < GRP; ++k) {
-            const uint32_t u = rdlane(sv, gi * GRP + k) & SRC_MASK;
-            du[k] = ld_row(D, u * 256u + lane4);
+          for (int k = 0; k < DG; ++k) {                          // no requests for the padding of a short row
+            const uint32_t u = rdlane(sv, gi * DG + k) & SRC_MASK;
+            du[k] = (uint32_t)(gi * DG + k) < cnt ? ld_row(D, u * 256u + lane4) : INF;
           }
           bool anyt = false;
 #pragma unroll
-          for (int k = 0; k < GRP; ++k) {
-            const uint32_t w = rdlane(wv, gi * GRP + k);
+          for (int k = 0; k < DG; ++k) {
+            const uint32_t w = rdlane(wv, gi * DG + k);
             uint32_t d = du[k];
             if (has_nt) {
-              const uint32_t sw = rdlane(sv, gi * GRP + k);
+              const uint32_t sw = rdlane(sv, gi * DG + k);
               if ((sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;
             }
             // tight parent (d + w == dv without saturation; dv != INF for `need` lanes)
             tight[k] = need && d != INF && add_sat(d, w) == dv;
-            if (has_zl && rdlane(zvec, gi * GRP + k) != 0u) {    // uniform, hop-count-like graphs only
+            if (has_zl && rdlane(zvec, gi * DG + k) != 0u) {    // uniform, hop-count-like graphs only
               tight[k] = tight[k] && !zdone;
               zdone = zdone || tight[k];
             }
             anyt = anyt || tight[k];
           }
           if (__ballot(anyt) == 0ull) continue;
-          uint32_t hu[GRP];
-          uint64_t mu[GRP][W];
+          uint32_t hu[DG];
+          uint64_t mu[DG][W];
 #pragma unroll
-          for (int k = 0; k < GRP; ++k) {
-            const uint32_t u = rdlane(sv, gi * GRP + k) & SRC_MASK;
-            hu[k] = ld_row(H, u * 256u + lane4);
+          for (int k = 0; k < DG; ++k) {                          // hops / masks only of links tight for some root
+            const uint32_t u = rdlane(sv, gi * DG + k) & SRC_MASK;
+            const bool tk = __ballot(tight[k]) != 0ull;
+            hu[k] = tk ? ld_row(H, u * 256u + lane4) : 0u;
 #pragma unroll
-            for (int q = 0; q < W; ++q) mu[k][q] = ld_row64(M, ((size_t)u * W + q) * 512u + lane8);
+            for (int q = 0; q < W; ++q) mu[k][q] = tk ? ld_row64(M, ((size_t)u * W + q) * 512u + lane8) : 0ull;
           }
 #pragma unroll
-          for (int k = 0; k < GRP; ++k) {
+          for (int k = 0; k < DG; ++k) {
             const uint32_t hh = hu[k] & 0xFFFFu;
             const uint32_t eu = hu[k] >> HV_EPOCH_SHIFT;
             bool ready;
@@ -336,8 +356,8 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
             if (ready && du[k] < bk_d) { bk_d = du[k]; p0h = hh; }
             const bool direct = ready && hh == 0;                // parent: root or hops-0 network
             if (__ballot(direct) != 0ull) {
-              const uint32_t u = rdlane(sv, gi * GRP + k) & SRC_MASK;
-              const uint32_t fpos = g.in_fpos[eb + gi * GRP + k];
+              const uint32_t u = rdlane(sv, gi * DG + k) & SRC_MASK;
+              const uint32_t fpos = g.in_fpos[eb + gi * DG + k];
               if (direct && (v_router || net_nexthops)) {
                 const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(tabs, root_slot, u);
                 const uint32_t sidx = base_s + fpos;
@@ -370,6 +390,10 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
       for (int k = 0; k < W; ++k) M[((size_t)v * W + k) * 64 + lane] = m[k];
       H[(size_t)v * 64 + lane] = out_hv | (epoch << HV_EPOCH_SHIFT);
       any = true;
+    }
+    if (__ballot(done) != 0ull) {                        // wake the out-neighbours up for the next sweep
+      const uint32_t o0 = rdlane(po, i), o1 = rdlane(po, i + 1);
+      for (uint32_t ob = o0 + lane; ob < o1; ob += 64) A[g.out_dst[ob]] = (uint32_t)sweep + 1u;
     }
   }
   if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
@@ -595,8 +619,7 @@ __device__ __forceinline__ RowOut<ST> fused_row16(__amdgpu_buffer_rsrc_t rs, uin
 }
 
 // General row routine (rare: rows next to a vertex that can have hops == 0, overloaded sources,
-// zero-cost links from higher-numbered sources, more than 16 links): one link at a time, rolled
-// loops.  Inlined all the same: a real call would need a stack, i.e. scratch memory.
+// zero-cost links from higher-numbered sources, more than 16 links): rolled loops, four neighbour rows in flight.  Inlined all the same: a real call would need a stack, i.e. scratch memory.
 template <typename ST, bool MAXINF, bool HC>
 __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v,
                                                     uint32_t e0, uint32_t e1, uint32_t sv0, uint32_t wv0,
@@ -620,10 +643,19 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
     const bool has_z = __ballot(zv != 0u) != 0ull;
     const uint32_t so = (lane < cnt ? (sv & SRC_MASK) : v) << StIO<ST>::ROW_SHIFT;
     const uint32_t wk = lane < cnt ? (wv << P.sh) : INF;
+    // PF neighbour rows are requested before the first of them is consumed: a row with 100 links (a fat-tree switch, a
+    // big LAN) otherwise pays 100 dependent round trips.  Lanes >= cnt of `so` point at the own row: harmless loads.
+    constexpr uint32_t PF = 4;
 #pragma unroll 1
-    for (uint32_t j = 0; j < cnt; ++j) {
-      const typename StIO<ST>::Raw q0 = StIO<ST>::ld(rs, lvo, rdlane(so, j));
-      typename StIO<ST>::Raw q = q0;
+    for (uint32_t j0 = 0; j0 < cnt; j0 += PF) {
+      typename StIO<ST>::Raw qq[PF];
+#pragma unroll
+      for (uint32_t k = 0; k < PF; ++k) qq[k] = StIO<ST>::ld(rs, lvo, rdlane(so, min(j0 + k, 63u)));
+#pragma unroll
+      for (uint32_t k = 0; k < PF; ++k) {
+      const uint32_t j = j0 + k;
+      if (j >= cnt) break;
+      typename StIO<ST>::Raw q = qq[k];
       const uint32_t w = rdlane(wk, j);
       const uint32_t sw = rdlane(sv, j);
       uint32_t d = StIO<ST>::dkey(q, P);
@@ -661,6 +693,7 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
       a.bpd = newp ? d : a.bpd;
       a.bh = newp ? hh : a.bh;
       a.bd = min(a.bd, c);
+      }
     }
   }
   if (HC) {                                 // late vertex: strictly better through the zero-cost links
@@ -698,7 +731,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t batch = blockIdx.y;
-  const uint32_t chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const uint32_t chunk = xcd_chunk(gp->g.xcd_start, blockIdx.x);
+  if (chunk == 0xFFFFFFFFu) return;
   const uint32_t wbeg = chunk * FVPB + wave * FVPW;
   const uint32_t n = gp->g.n;
   if (wbeg >= n) return;
