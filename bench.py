@@ -83,11 +83,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # the host driver only supports dmabuf IPC (RCCL / cross-process device memory); harmless when already set
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand with --gpus N: become the launcher (one rank per GPU over RCCL, rendezvous on 127.0.0.1)
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29517"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch
     import torch.distributed as dist
