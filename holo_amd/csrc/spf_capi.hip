@@ -85,7 +85,6 @@ struct hspf_ctx {
   // scratch (grown on demand, reused across runs)
   DevBuf dist, hv, mask, lane_flags, changed, st64, stamp, hnb;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
-  DevBuf p_dist, p_hops, p_flags, p_mask, p_rank, p_dest;   // regrouped runs: outputs in class order before the row permute
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met;                    // prefix table of hspf_routes_device
   DevBuf gb, gb_delta;                              // graph build scratch, patch delta
@@ -336,7 +335,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->p_dist, &ctx->p_hops, &ctx->p_flags, &ctx->p_mask, &ctx->p_rank, &ctx->p_dest, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->gb, &ctx->gb_delta})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->gb, &ctx->gb_delta})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
@@ -604,9 +603,12 @@ int hspf_slot_table(hspf_ctx *ctx, const hspf_graph *g, uint32_t root, uint32_t 
 
 // ---- run --------------------------------------------------------------------------------------
 
+// row_map (host array, may be null): output row of roots[r] inside `out` (device buffers of total_rows rows; only with
+// host_out == false) — used by run_classes to let every class write straight into the caller's row order.
 static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
-                    hspf_result *out, bool host_out) {
-  if (!ctx || !g || !roots || !out || n_roots == 0 || !out->dist) return HSPF_E_INVAL;
+                    hspf_result *out, bool host_out, const uint32_t *row_map = nullptr, uint32_t total_rows = 0) {
+  if (!ctx || !g || !roots || !out || n_roots == 0 || !out->dist || (row_map && host_out)) return HSPF_E_INVAL;
+  if (!row_map) total_rows = n_roots;
   (void)hipSetDevice(ctx->device);
   const uint32_t n = g->n;
   // Bound the scratch (state, stamps, staging) of one pass: the batch axis is processed in groups of
@@ -621,13 +623,13 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       for (uint32_t off = 0; off < n_roots; off += group) {
         const uint32_t nr = std::min(group, n_roots - off);
         hspf_result part = *out;
-        const size_t o = (size_t)off * n;
+        const size_t o = row_map ? 0 : (size_t)off * n;          // mapped rows are addressed through the map
         part.dist = out->dist + o;
         if (out->hops) part.hops = out->hops + o;
         if (out->vflags_out) part.vflags_out = out->vflags_out + o;
         if (out->first_hop_mask) part.first_hop_mask = out->first_hop_mask + o * out->n_mask_words;
         if (out->pop_rank) part.pop_rank = out->pop_rank + o;
-        const int rc = run_impl(ctx, g, roots + off, nr, run_flags, &part, host_out);
+        const int rc = run_impl(ctx, g, roots + off, nr, run_flags, &part, host_out, row_map ? row_map + off : nullptr, total_rows);
         if (rc) return rc;
         const hspf_stats &p = ctx->stats;
         acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
@@ -718,10 +720,11 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   }
   if ((rc = ensure(ctx, ctx->lane_flags, (size_t)L * 4))) return rc;
   if ((rc = ensure(ctx, ctx->changed, (size_t)CHANGED_CAP * 4))) return rc;
-  // upload block (u32 words): roots[L] | tab_ptr[L+1] | tab_vtx[nv] | tab_base[nv] | pad to 16 B | FusedGraph
+  // upload block (u32 words): roots[L] | tab_ptr[L+1] | tab_vtx[nv] | tab_base[nv] | row_map[L] | pad to 16 B | FusedGraph
   const size_t nv = tab_vtx.size();
   const size_t w_roots = 0, w_ptr = L, w_vtx = w_ptr + L + 1, w_base = w_vtx + std::max<size_t>(nv, 1);
-  const size_t w_fg = (w_base + std::max<size_t>(nv, 1) + 3) & ~size_t(3);
+  const size_t w_map = w_base + std::max<size_t>(nv, 1);
+  const size_t w_fg = (w_map + L + 3) & ~size_t(3);
   const size_t up_bytes = w_fg * 4 + sizeof(FusedGraph);
   if ((rc = ensure(ctx, ctx->up, up_bytes))) return rc;
   if (ctx->h_up_cap < up_bytes) {
@@ -739,7 +742,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   }
   // row-major output targets (device): the caller's device buffers, or staging for host output
   OutDev od{};
-  const size_t rn = (size_t)n_roots * n;
+  const size_t rn = (size_t)total_rows * n;               // rows of the output arrays (== n_roots unless mapped)
   uint32_t *d_rank = nullptr;
   if (host_out) {
     if ((rc = ensure(ctx, ctx->o_dist, rn * 4))) return rc;
@@ -753,6 +756,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     od.dist = out->dist; od.hops = out->hops; od.flags = out->vflags_out; od.mask = out->first_hop_mask; od.out_words = out_words;
     if (run_flags & HSPF_RUN_POP_RANK) d_rank = out->pop_rank;
   }
+  od.row_map = nullptr;                                    // set below, once the upload block's address is known
 
   uint32_t *d_up = (uint32_t *)ctx->up.p;
   uint32_t *d_dist = (uint32_t *)ctx->dist.p, *d_hv = (uint32_t *)ctx->hv.p, *d_roots = d_up + w_roots;
@@ -761,6 +765,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   int *d_changed = (int *)ctx->changed.p;
   const GraphDev gd = g->dev();
   const SlotTabs tabs{d_up + w_ptr, d_up + w_vtx, d_up + w_base};
+  if (row_map) od.row_map = d_up + w_map;
   const uint32_t ignore_ovl = (run_flags & HSPF_RUN_IGNORE_OVERLOAD) ? 1u : 0u;
   const uint32_t net_nh = (run_flags & HSPF_RUN_NET_NEXTHOPS) ? 1u : 0u;
 
@@ -772,6 +777,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     std::copy(tab_ptr.begin(), tab_ptr.end(), h + w_ptr);
     std::copy(tab_vtx.begin(), tab_vtx.end(), h + w_vtx);
     std::copy(tab_base.begin(), tab_base.end(), h + w_base);
+    for (uint32_t r = 0; r < L; ++r) h[w_map + r] = (row_map && r < n_roots) ? row_map[r] : r;
     const FusedGraph fg{gd, tabs};
     memcpy(h + w_fg, &fg, sizeof(FusedGraph));
     HIPCHK(ctx, hipMemcpyAsync(d_up, h, up_bytes, hipMemcpyHostToDevice, s));
@@ -946,6 +952,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     a.g = gd; a.roots = d_roots; a.n_exact = (uint32_t)ex.size();
     a.maxpath = g->max_path_metric; a.net_nexthops = net_nh; a.ignore_ovl = ignore_ovl; a.tabs = tabs;
     a.dist = od.dist; a.hops = od.hops; a.flags = od.flags; a.mask = od.mask; a.words = out_words; a.pop_rank = d_rank;
+    a.row_map = od.row_map;
     if (!a.hops) { if ((rc = ensure(ctx, ctx->o_hops, rn * 2))) return rc; a.hops = (uint16_t *)ctx->o_hops.p; }
     if (!a.flags) { if ((rc = ensure(ctx, ctx->o_flags, rn * 2))) return rc; a.flags = (uint16_t *)ctx->o_flags.p; }
     if (!a.mask) { if ((rc = ensure(ctx, ctx->o_mask, rn * 8 * out_words))) return rc; a.mask = (uint64_t *)ctx->o_mask.p; }
@@ -960,7 +967,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if ((run_flags & HSPF_RUN_POP_RANK) && d_rank) {
     // pop_rank of padding roots
     for (uint32_t r = 0; r < n_roots; ++r)
-      if (roots[r] == HSPF_NO_ROOT) HIPCHK(ctx, hipMemsetAsync(d_rank + (size_t)r * n, 0xFF, (size_t)n * 4, s));
+      if (roots[r] == HSPF_NO_ROOT) HIPCHK(ctx, hipMemsetAsync(d_rank + (size_t)(row_map ? row_map[r] : r) * n, 0xFF, (size_t)n * 4, s));
   }
   HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
 
@@ -989,8 +996,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 // A run takes the state its most demanding root needs: one root with more than 16 first-hop slots sends every root of
 // the call down the two-phase path, one with 15-16 slots makes the packed state 8 bytes wide for all.  With many roots
 // ("every router of the area") that is the common case, so the roots are regrouped by what
-// they need — narrow fused / wide fused / two-phase —, each class runs on its own, and the rows are put back in the
-// caller's order by one streaming pass.  A class is only split off when that saves work: an extra run costs a whole
+// they need — narrow fused / wide fused / two-phase —, each class runs on its own and writes its rows straight to
+// their places in the caller's order (row map).  A class is only split off when that saves work: an extra run costs a whole
 // fixed point.
 static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
                        hspf_result *out, bool host_out) {
@@ -1037,36 +1044,8 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
   if (want_mask && out->n_mask_words == 0) return HSPF_E_INVAL;
   const uint32_t W = want_mask ? out->n_mask_words : 0;
   int rc;
-  if ((rc = ensure(ctx, ctx->p_dist, rn * 4))) return rc;
-  if (out->hops && (rc = ensure(ctx, ctx->p_hops, rn * 2))) return rc;
-  if (out->vflags_out && (rc = ensure(ctx, ctx->p_flags, rn * 2))) return rc;
-  if (want_mask && (rc = ensure(ctx, ctx->p_mask, rn * 8 * W))) return rc;
-  if (want_rank && (rc = ensure(ctx, ctx->p_rank, rn * 4))) return rc;
-  if ((rc = ensure(ctx, ctx->p_dest, (size_t)n_roots * 4))) return rc;
-  hspf_result T{(uint32_t *)ctx->p_dist.p, out->hops ? (uint16_t *)ctx->p_hops.p : nullptr,
-                out->vflags_out ? (uint16_t *)ctx->p_flags.p : nullptr, want_mask ? (uint64_t *)ctx->p_mask.p : nullptr, W,
-                want_rank ? (uint32_t *)ctx->p_rank.p : nullptr};
-  hspf_stats acc{};
-  for (int c = 0; c < 3; ++c) {
-    const uint32_t off = start[c], nr = start[c + 1] - start[c];
-    if (nr == 0) continue;
-    hspf_result part = T;
-    const size_t o = (size_t)off * n;
-    part.dist = T.dist + o;
-    if (T.hops) part.hops = T.hops + o;
-    if (T.vflags_out) part.vflags_out = T.vflags_out + o;
-    if (T.first_hop_mask) part.first_hop_mask = T.first_hop_mask + o * W;
-    if (T.pop_rank) part.pop_rank = T.pop_rank + o;
-    rc = run_impl(ctx, g, proots.data() + off, nr, run_flags, &part, false);
-    if (rc) return rc;
-    const hspf_stats &p = ctx->stats;
-    acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
-    acc.n_dag_launches += p.n_dag_launches; acc.n_exact_roots += p.n_exact_roots;
-    acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
-    acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
-    acc.state_bytes = std::max(acc.state_bytes, p.state_bytes); acc.narrow_overflow += p.narrow_overflow;
-  }
-  // rows back into the caller's order: straight into its device buffers, or into the staging that is copied out
+  // Every class writes its rows straight to their final places (row map): into the caller's device buffers, or into
+  // the staging that is copied out once at the end.
   hipStream_t s = ctx->stream;
   hspf_result U = *out;
   if (host_out) {
@@ -1077,18 +1056,19 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     if (want_mask) { if ((rc = ensure(ctx, ctx->o_mask, rn * 8 * W))) return rc; U.first_hop_mask = (uint64_t *)ctx->o_mask.p; }
     if (want_rank) { if ((rc = ensure(ctx, ctx->o_rank, rn * 4))) return rc; U.pop_rank = (uint32_t *)ctx->o_rank.p; }
   }
-  HIPCHK(ctx, hipMemcpyAsync(ctx->p_dest.p, dest.data(), (size_t)n_roots * 4, hipMemcpyHostToDevice, s));
-  const uint32_t *d_dest = (const uint32_t *)ctx->p_dest.p;
-  for (uint32_t row0 = 0; row0 < n_roots; row0 += 32768) {
-    const uint32_t ny = std::min(32768u, n_roots - row0);
-    const dim3 g1((unsigned)(((size_t)n + 255) / 256), ny), gm((unsigned)(((size_t)n * std::max(W, 1u) + 255) / 256), ny);
-    hipLaunchKernelGGL((k_permute_rows<uint32_t>), g1, dim3(256), 0, s, (size_t)n, d_dest, row0, (const uint32_t *)T.dist, U.dist);
-    if (T.hops) hipLaunchKernelGGL((k_permute_rows<uint16_t>), g1, dim3(256), 0, s, (size_t)n, d_dest, row0, (const uint16_t *)T.hops, U.hops);
-    if (T.vflags_out) hipLaunchKernelGGL((k_permute_rows<uint16_t>), g1, dim3(256), 0, s, (size_t)n, d_dest, row0, (const uint16_t *)T.vflags_out, U.vflags_out);
-    if (T.first_hop_mask) hipLaunchKernelGGL((k_permute_rows<uint64_t>), gm, dim3(256), 0, s, (size_t)n * W, d_dest, row0, (const uint64_t *)T.first_hop_mask, U.first_hop_mask);
-    if (T.pop_rank) hipLaunchKernelGGL((k_permute_rows<uint32_t>), g1, dim3(256), 0, s, (size_t)n, d_dest, row0, (const uint32_t *)T.pop_rank, U.pop_rank);
+  hspf_stats acc{};
+  for (int c = 0; c < 3; ++c) {
+    const uint32_t off = start[c], nr = start[c + 1] - start[c];
+    if (nr == 0) continue;
+    rc = run_impl(ctx, g, proots.data() + off, nr, run_flags, &U, false, dest.data() + off, n_roots);
+    if (rc) return rc;
+    const hspf_stats &p = ctx->stats;
+    acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
+    acc.n_dag_launches += p.n_dag_launches; acc.n_exact_roots += p.n_exact_roots;
+    acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
+    acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
+    acc.state_bytes = std::max(acc.state_bytes, p.state_bytes); acc.narrow_overflow += p.narrow_overflow;
   }
-  HIPCHK(ctx, hipGetLastError());
   if (host_out) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
     HIPCHK(ctx, hipMemcpyAsync(out->dist, U.dist, rn * 4, hipMemcpyDeviceToHost, s));
@@ -1097,9 +1077,10 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     if (want_mask) HIPCHK(ctx, hipMemcpyAsync(out->first_hop_mask, U.first_hop_mask, rn * 8 * W, hipMemcpyDeviceToHost, s));
     if (want_rank) HIPCHK(ctx, hipMemcpyAsync(out->pop_rank, U.pop_rank, rn * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) acc.ms_d2h = ms;
   }
-  HIPCHK(ctx, hipStreamSynchronize(s));       // dest / proots are stack vectors; results are in place on return
-  if (host_out) { float ms = 0; if (hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]) == hipSuccess) acc.ms_d2h = ms; }
   ctx->stats = acc;
   return HSPF_OK;
 }

@@ -70,6 +70,8 @@ struct GraphDev {
 
 struct OutDev {
   uint32_t *dist; uint16_t *hops; uint16_t *flags; uint64_t *mask; uint32_t out_words;
+  const uint32_t *row_map;   // output row of the run's root r (null: r itself) — runs regrouped by state class
+  __device__ __forceinline__ size_t row(uint32_t r) const { return row_map ? row_map[r] : r; }
 };
 
 // rowflags bits (set at upload); RF_HNB is added per batch by k_init_fused
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots
   for (uint32_t r = wave; r < nr; r += 4)
     if (lane < nv) {
       const ST x = tt[lane][r];
-      const size_t idx = (size_t)(r0 + r) * n + v0 + lane;
+      const size_t idx = o.row(r0 + r) * n + v0 + lane;
       uint32_t d, pay;
       if (sizeof(ST) == 8) { d = (uint32_t)((uint64_t)x >> 32); pay = (uint32_t)x; }
       else { d = (uint32_t)x >> P.sh; pay = (uint32_t)x & ((1u << P.sh) - 1u); }
@@ -886,16 +888,6 @@ __global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots
         for (uint32_t k = 1; k < o.out_words; ++k) o.mask[idx * o.out_words + k] = 0;
       }
     }
-}
-
-// Rows of a row-major [root][len] table to their final places: out[dest[i]] = in[i] (runs whose roots were regrouped
-// by the state they need, spf_capi.hip run_classes).
-template <typename T>
-__global__ __launch_bounds__(256) void k_permute_rows(size_t len, const uint32_t *__restrict__ dest, uint32_t row0,
-                                                      const T *__restrict__ in, T *__restrict__ out) {
-  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const uint32_t i = row0 + blockIdx.y;
-  if (j < len) out[(size_t)dest[i] * len + j] = in[(size_t)i * len + j];
 }
 
 // Epoch rebase (only when a DAG phase needs more than 65534 launches): every final row -> epoch 1.
@@ -931,7 +923,7 @@ __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t n_roots,
   for (uint32_t r = wave; r < nr; r += 4)
     if (lane < nv) {
       const uint32_t x = t32[lane][r];
-      const size_t idx = (size_t)(r0 + r) * n + v0 + lane;
+      const size_t idx = o.row(r0 + r) * n + v0 + lane;
       o.dist[idx] = x;
       if (o.flags) o.flags[idx] = (x != INF) ? 1 : 0;
     }
@@ -942,7 +934,7 @@ __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t n_roots,
     __syncthreads();
     for (uint32_t r = wave; r < nr; r += 4)
       if (lane < nv) {
-        o.hops[(size_t)(r0 + r) * n + v0 + lane] = (uint16_t)(t32[lane][r] & 0xFFFFu);
+        o.hops[o.row(r0 + r) * n + v0 + lane] = (uint16_t)(t32[lane][r] & 0xFFFFu);
       }
     __syncthreads();
   }
@@ -952,13 +944,13 @@ __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t n_roots,
       __syncthreads();
       for (uint32_t r = wave; r < nr; r += 4)
         if (lane < nv)
-          o.mask[((size_t)(r0 + r) * n + v0 + lane) * o.out_words + k] = t64[lane][r];
+          o.mask[(o.row(r0 + r) * n + v0 + lane) * o.out_words + k] = t64[lane][r];
       __syncthreads();
     }
     // words beyond W (caller capacity larger than needed) are zero
     for (uint32_t k = W; k < o.out_words; ++k)
       for (uint32_t r = wave; r < nr; r += 4)
-        if (lane < nv) o.mask[((size_t)(r0 + r) * n + v0 + lane) * o.out_words + k] = 0;
+        if (lane < nv) o.mask[(o.row(r0 + r) * n + v0 + lane) * o.out_words + k] = 0;
   }
 }
 
@@ -976,6 +968,7 @@ struct ExactArgs {
   SlotTabs tabs;
   uint32_t *dist; uint16_t *hops; uint16_t *flags; uint64_t *mask; uint32_t words;
   uint32_t *pop_rank;          // may be null
+  const uint32_t *row_map;     // output row of root index ri (null: ri itself)
   uint32_t *heap; uint32_t *pos;   // [n_exact][n]
 };
 
@@ -990,11 +983,12 @@ __global__ void k_exact(ExactArgs a) {
   const uint32_t ri = a.root_list[t];
   const uint32_t root = a.roots[ri];
   const uint32_t n = a.g.n;
-  uint32_t *dist = a.dist + (size_t)ri * n;
-  uint16_t *hops = a.hops + (size_t)ri * n;
-  uint16_t *flags = a.flags + (size_t)ri * n;
-  uint64_t *mask = a.mask + (size_t)ri * n * a.words;
-  uint32_t *rank = a.pop_rank ? a.pop_rank + (size_t)ri * n : nullptr;
+  const size_t orow = a.row_map ? a.row_map[ri] : ri;
+  uint32_t *dist = a.dist + orow * n;
+  uint16_t *hops = a.hops + orow * n;
+  uint16_t *flags = a.flags + orow * n;
+  uint64_t *mask = a.mask + orow * n * a.words;
+  uint32_t *rank = a.pop_rank ? a.pop_rank + orow * n : nullptr;
   uint32_t *heap = a.heap + (size_t)t * n;
   uint32_t *pos = a.pos + (size_t)t * n;
   const uint32_t W = a.words;
