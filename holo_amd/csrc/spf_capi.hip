@@ -36,6 +36,7 @@ struct hspf_graph {
   uint32_t max_path_metric = 0;
   uint32_t wmax = 0;                 // largest cost among the kept links
   mutable bool narrow_bad = false;   // a run overflowed the 4-byte fused state: use the 8-byte one
+  mutable bool wide24_bad = false;   // a run overflowed the hop field of the 8-byte state with > 16 mask bits
   bool hopcount_like = false;        // every kept link into a network costs 0 (from a router), into a router 1
   uint32_t xcd_start[9] = {};        // work-balanced chunk ranges of the 8 XCDs (GraphDev::xcd_start)
   uint32_t xcd_blocks() const { uint32_t m = 0; for (int x = 0; x < 8; ++x) m = std::max(m, xcd_start[x + 1] - xcd_start[x]); return 8u * std::max(m, 1u); }
@@ -263,6 +264,7 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   g->hopcount_like = !bi.hc_bad && bi.hc_net;
   for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
   g->narrow_bad = false;
+  g->wide24_bad = false;
   return HSPF_OK;
 }
 
@@ -606,7 +608,8 @@ int hspf_slot_table(hspf_ctx *ctx, const hspf_graph *g, uint32_t root, uint32_t 
 // row_map (host array, may be null): output row of roots[r] inside `out` (device buffers of total_rows rows; only with
 // host_out == false) — used by run_classes to let every class write straight into the caller's row order.
 static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
-                    hspf_result *out, bool host_out, const uint32_t *row_map = nullptr, uint32_t total_rows = 0) {
+                    hspf_result *out, bool host_out, const uint32_t *row_map = nullptr, uint32_t total_rows = 0,
+                    bool no_fused = false) {
   if (!ctx || !g || !roots || !out || n_roots == 0 || !out->dist || (row_map && host_out)) return HSPF_E_INVAL;
   if (!row_map) total_rows = n_roots;
   (void)hipSetDevice(ctx->device);
@@ -629,7 +632,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         if (out->vflags_out) part.vflags_out = out->vflags_out + o;
         if (out->first_hop_mask) part.first_hop_mask = out->first_hop_mask + o * out->n_mask_words;
         if (out->pop_rank) part.pop_rank = out->pop_rank + o;
-        const int rc = run_impl(ctx, g, roots + off, nr, run_flags, &part, host_out, row_map ? row_map + off : nullptr, total_rows);
+        const int rc = run_impl(ctx, g, roots + off, nr, run_flags, &part, host_out, row_map ? row_map + off : nullptr, total_rows, no_fused);
         if (rc) return rc;
         const hspf_stats &p = ctx->stats;
         acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
@@ -686,8 +689,13 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // device, LF_OVERFLOW -> the run is redone with the 8-byte state and the graph remembers), else 8;
   // otherwise distances first, then the SPT-DAG phase with W mask words.
   // HSPF_VARIANT bit0 forces the two-phase path, bit1 forbids the narrow state (A/B measurements).
-  const bool fused = max_slots <= 16 && n < (1u << 23) && !(ctx->variant & 1u);
-  FusedParams fp_wide{0u, 16u, 0xFFFFu, 0xFFFFFFFFu, g->max_path_metric, 0xFFFFFFFFu, g->hopcount_like ? 1u : 0u};
+  // 17-24 slots: the 8-byte state with a wider mask field and correspondingly fewer hop bits (32 - M); a root farther
+  // than that many router hops from something raises LF_OVERFLOW and the run is redone on the two-phase path.
+  const uint32_t fused_max_slots = g->wide24_bad ? 16u : 24u;
+  const bool fused = !no_fused && max_slots <= fused_max_slots && n < (1u << 23) && !(ctx->variant & 1u);
+  const uint32_t Mw = std::max(16u, max_slots);
+  FusedParams fp_wide{0u, Mw, Mw == 16u ? 0xFFFFu : (1u << (32u - Mw)) - 1u, 0xFFFFFFFFu, g->max_path_metric, 0xFFFFFFFFu,
+                      g->hopcount_like ? 1u : 0u};
   FusedParams fp_narrow = fp_wide;
   bool narrow = false;
   if (fused && !g->narrow_bad && !(ctx->variant & 2u)) {
@@ -887,6 +895,14 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       if (ovf) { g->narrow_bad = true; narrow = false; st.narrow_overflow = 1; }
     }
     if (!narrow && (rc = fused_run(false))) return rc;
+    if (!narrow && fp_wide.hmax < 0xFFFFu) {                       // more than 16 mask bits: did the hop field hold?
+      bool ovf = false;
+      for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);
+      if (ovf) {
+        g->wide24_bad = true;
+        return run_impl(ctx, g, roots, n_roots, run_flags, out, host_out, row_map, total_rows, true);
+      }
+    }
     st.state_bytes = narrow ? 4 : 8;
   } else {
   uint32_t n_relax = 0;
@@ -1021,7 +1037,7 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
         if (roots[r] >= n) { ctx->last_error = "root out of range"; return HSPF_E_INVAL; }
         build_slot_table(g, roots[r], hv, hb, total, ctx->mark, next_mark(ctx, n));
       }
-      cls[r] = total > 16 ? 2 : (total > m_narrow ? 1 : 0);
+      cls[r] = total > (g->wide24_bad ? 16u : 24u) ? 2 : (total > m_narrow ? 1 : 0);
       cnt[cls[r]]++;
     }
   }

@@ -405,7 +405,8 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
 // Fused sweep (the fast path when every root of the run has <= 16 first-hop slots): ONE
 // label-correcting fixed point over a packed per-(vertex, root) state instead of a distance phase
 // followed by a DAG phase.  Two state widths, same code (template parameter ST):
-//   wide   (uint64_t)  [63:32] dist   [31:16] hops   [15:0] first-hop mask
+//   wide   (uint64_t)  [63:32] dist   [31:M] hops   [M-1:0] first-hop mask   (M = 16, or up to 24 for runs whose
+//          roots have 17-24 slots: 8-15 hop bits, LF_OVERFLOW -> redone on the two-phase path)
 //   narrow (uint32_t)  [31:sh] dist   [sh-1:M] hops  [M-1:0] mask      (M = slots of the run,
 //          H = sh-M hop bits; chosen by the host when the graph's costs fit; a lane that gets
 //          within one link cost of the field limit, or too many hops, raises LF_OVERFLOW and the
@@ -470,8 +471,8 @@ template <> struct StIO<uint64_t> {
   }
   static __device__ __forceinline__ uint32_t dkey(const Raw &q, const FusedParams &) { return q.x.y; }
   static __device__ __forceinline__ uint32_t pay(const Raw &q, const FusedParams &) { return q.x.x; }
-  static __device__ __forceinline__ uint64_t join(uint32_t dk, uint32_t hops, uint32_t mask, const FusedParams &) {
-    return ((uint64_t)dk << 32) | ((uint64_t)hops << 16) | mask;
+  static __device__ __forceinline__ uint64_t join(uint32_t dk, uint32_t hops, uint32_t mask, const FusedParams &P) {
+    return ((uint64_t)dk << 32) | ((uint64_t)hops << P.mbits) | mask;   // low word = [hops | mask], mbits = 16..24
   }
   static __device__ __forceinline__ uint64_t bits(const Raw &q) { return ((uint64_t)q.x.y << 32) | q.x.x; }
 };
@@ -517,7 +518,9 @@ __device__ __forceinline__ RowOut<ST> finish_row(const RowAcc &a, uint32_t v, ui
   else if (a.bd >= P.inf_t || a.bd > P.maxkey) o.nw = (ST)~(ST)0;
   else {
     uint32_t hops = a.bh + v_router;
-    if (hops > P.hmax) { hops = P.hmax; o.ovf = sizeof(ST) == 4; }   // wide: u16 saturating_add
+    // 16 hop bits: the reference's u16 saturating_add; fewer (4-byte state, or the 8-byte one with more than 16 mask
+    // bits): the run is redone with the next wider representation
+    if (hops > P.hmax) { hops = P.hmax; o.ovf = P.hmax < 0xFFFFu; }
     o.ovf = o.ovf || a.bd >= P.ovf_t;
     o.nw = StIO<ST>::join(a.bd, hops, a.bm & ((1u << P.mbits) - 1u), P);
   }
@@ -616,7 +619,7 @@ __device__ __forceinline__ RowOut<ST> fused_row16(__amdgpu_buffer_rsrc_t rs, uin
   RowAcc a;
   a.bd = r.bd; a.sat = r.sat; a.bpd = 0u;
   a.bm = r.macc & ((1u << P.mbits) - 1u);
-  a.bh = sizeof(ST) == 8 ? (r.bpay >> 16) : ((r.bpay >> P.mbits) & P.hmax);
+  a.bh = sizeof(ST) == 8 ? (r.bpay >> P.mbits) : ((r.bpay >> P.mbits) & P.hmax);
   return finish_row<ST>(a, v, my_root, v_router, INF, P);
 }
 

@@ -386,3 +386,42 @@ def test_many_roots_regrouped_device_outputs(spf_ctx):
     assert np.array_equal(hops.cpu().numpy().view(np.uint16), ref.hops)
     assert np.array_equal(flags.cpu().numpy().view(np.uint16) & 1, ref.flags)
     assert np.array_equal(mask.cpu().numpy().view(np.uint64), ref.mask)
+
+
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("run_flags", [0, E.RUN_NET_NEXTHOPS])
+def test_roots_with_17_to_24_slots_stay_on_the_fused_path(spf_ctx, seed, run_flags):
+    """Routers on a 14-member LAN: their own links + the LAN's members give 17-24 first-hop slots — the 8-byte packed
+    state with a 17..24-bit mask field (fewer hop bits) instead of the two-phase path."""
+    g = synth.random_lsdb(120, 3, 2.0, 1700 + seed, metric_hi=5, lan_size=14, p_parallel=0.0)
+    roots = [r for r in range(3, g.n) if 16 < G_slots(g, r) <= 24][:40]
+    assert len(roots) >= 8
+    res, _ = check(spf_ctx, g, roots, run_flags, expect_exact=False)
+    assert res.stats["state_bytes"] == 8 and res.stats["n_dag_launches"] == 0
+
+
+def test_wide_mask_hop_field_overflow_falls_back_to_two_phase(spf_ctx):
+    """A hub with 24 neighbours (24 slots -> 8 hop bits) and a 300-router tail: hop counts beyond 255 raise the
+    overflow flag, the run is redone on the two-phase path (u16 hops) and the graph remembers."""
+    fan, tail = 24, 300
+    hub = 0
+    leaves = np.arange(1, fan + 1)
+    chain = np.arange(fan + 1, fan + 1 + tail)
+    s = np.concatenate([np.full(fan, hub), leaves, [1], [chain[0]], chain[:-1], chain[1:]])
+    d = np.concatenate([leaves, np.full(fan, hub), [chain[0]], [1], chain[1:], chain[:-1]])
+    m = np.ones(len(s), np.int64)
+    n = fan + 1 + tail
+    row_ptr, col, met = synth._csr_from_links(n, s, d, m)
+    g = synth.CsrGraph(row_ptr, col, met, np.zeros(n, np.uint8), synth.MAX_PATH_METRIC_WIDE)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        for attempt in range(2):
+            res = spf_ctx.run(G, np.array([hub, 5], np.uint32), 0)
+            ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, np.array([hub, 5], np.uint32), 0, go.MAP,
+                         mask_words_=res.first_hop_mask.shape[2])
+            assert np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops)
+            assert np.array_equal(res.first_hop_mask, ref.mask) and np.array_equal(res.flags & 1, ref.flags)
+            assert int(res.hops.max()) > 255
+            assert res.stats["state_bytes"] == 0 and res.stats["n_dag_launches"] > 0       # ended on the two-phase path
+    finally:
+        G.free()
