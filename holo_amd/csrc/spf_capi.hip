@@ -684,7 +684,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   const uint32_t out_words = want_mask ? out->n_mask_words : W;
   st.n_mask_words = need_words;
 
-  // Fast path: every root has <= 16 first-hop slots -> one fused fixed point over a packed state
+  // Fast path: every root has <= 24 first-hop slots -> one fused fixed point over a packed state
   // (k_fused), 4 bytes per (vertex, root) when the slots, hop counts and distances fit (checked on
   // device, LF_OVERFLOW -> the run is redone with the 8-byte state and the graph remembers), else 8;
   // otherwise distances first, then the SPT-DAG phase with W mask words.
@@ -1009,8 +1009,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   return HSPF_OK;
 }
 
-// A run takes the state its most demanding root needs: one root with more than 16 first-hop slots sends every root of
-// the call down the two-phase path, one with 15-16 slots makes the packed state 8 bytes wide for all.  With many roots
+// A run takes the state its most demanding root needs: one root with more than 24 first-hop slots sends every root of
+// the call down the two-phase path, one with 15-24 slots makes the packed state 8 bytes wide for all.  With many roots
 // ("every router of the area") that is the common case, so the roots are regrouped by what
 // they need — narrow fused / wide fused / two-phase —, each class runs on its own and writes its rows straight to
 // their places in the caller's order (row map).  A class is only split off when that saves work: an extra run costs a whole

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused sweep (the fast path when every root of the run has <= 16 first-hop slots): ONE
+// Fused sweep (the fast path when every root of the run has <= 24 first-hop slots): ONE
 // label-correcting fixed point over a packed per-(vertex, root) state instead of a distance phase
 // followed by a DAG phase.  Two state widths, same code (template parameter ST):
 //   wide   (uint64_t)  [63:32] dist   [31:M] hops   [M-1:0] first-hop mask   (M = 16, or up to 24 for runs whose
@@ -624,7 +624,8 @@ __device__ __forceinline__ RowOut<ST> fused_row16(__amdgpu_buffer_rsrc_t rs, uin
 }
 
 // General row routine (rare: rows next to a vertex that can have hops == 0, overloaded sources,
-// zero-cost links from higher-numbered sources, more than 16 links): rolled loops, four neighbour rows in flight.  Inlined all the same: a real call would need a stack, i.e. scratch memory.
+// zero-cost links from higher-numbered sources, more than 16 links): rolled loops, four neighbour rows in flight.
+// Inlined all the same: a real call would need a stack, i.e. scratch memory.
 template <typename ST, bool MAXINF, bool HC>
 __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v,
                                                     uint32_t e0, uint32_t e1, uint32_t sv0, uint32_t wv0,
