@@ -943,7 +943,9 @@ __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t n_roots,
     __syncthreads();
   }
   if (o.mask) {
-    for (int k = 0; k < W; ++k) {
+    // W is the run's word count rounded up to 1/2/4/8/16; the caller's rows have out_words >= the words really needed
+    // (maybe fewer than W, e.g. 3): the surplus internal words are zero and must not be written past a row's end
+    for (int k = 0; k < W && (uint32_t)k < o.out_words; ++k) {
       for (uint32_t j = wave; j < nv; j += 4) t64[j][lane] = M[((size_t)j * W + k) * 64 + lane];
       __syncthreads();
       for (uint32_t r = wave; r < nr; r += 4)

@@ -232,7 +232,7 @@ def test_single_vertex_and_isolated_root(spf_ctx):
     assert res.dist[2, 0] == E.DIST_INF and (res.flags[2] & 1).sum() == 1
 
 
-@pytest.mark.parametrize("fanout", [70, 200])
+@pytest.mark.parametrize("fanout", [70, 150, 200, 330])       # 2, 3, 4 and 6 mask words (3 and 6: not a power of two)
 def test_star_rows_with_more_than_64_links(spf_ctx, fanout):
     """The hub row has `fanout` in- and out-links: multi-chunk general row routine and the
     more-than-64 wake-up path of the fused kernel; leaf roots keep the run on the fused path (1 slot),

@@ -1,0 +1,85 @@
+"""Randomised differential run on the GPU box: many small adversarial LSDBs (LANs of every size, one-way / parallel /
+zero-cost links, overloaded and non-expandable vertices, hop-count mode, tight max-path metrics, ragged root lists with
+padding entries, network vertices as roots), every run flag combination, optional row patches in between — the HIP
+engine against the CPU oracle, bit for bit.  Not part of the pytest suite (minutes, not seconds):
+
+    python tools/gpu_fuzz.py [first_seed] [n_graphs]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from holo_amd import _lib                      # noqa: E402
+if os.environ.get("HSPF_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["HSPF_LIB"])
+from holo_amd import synth                     # noqa: E402
+from holo_amd import engine as E               # noqa: E402
+from oracle import graph_oracle as go          # noqa: E402
+
+
+def compare(ctx, G, g, roots, flags, tag):
+    res = ctx.run(G, roots, flags)
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, flags & 3, go.MAP,
+                 mask_words_=res.first_hop_mask.shape[2])
+    bad = []
+    if not np.array_equal(res.dist, ref.dist): bad.append("dist")
+    if not np.array_equal(res.hops, ref.hops): bad.append("hops")
+    if not np.array_equal(res.flags & 1, ref.flags): bad.append("flags")
+    if not np.array_equal(res.first_hop_mask, ref.mask): bad.append("mask")
+    if res.pop_rank is not None and not np.array_equal(res.pop_rank, ref.pop_rank): bad.append("pop_rank")
+    if bad:
+        print("MISMATCH", tag, bad, "stats", res.stats, flush=True)
+    return not bad
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    ctx = E.SpfContext(0)
+    ok = runs = 0
+    t0 = time.time()
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(10_000 + seed)
+        nr = int(rng.integers(5, 220)); nn = int(rng.integers(0, 14))
+        hop = rng.random() < 0.2
+        g = synth.random_lsdb(nr, nn, float(rng.uniform(1.2, 4.5)), 50_000 + seed,
+                              metric_lo=1, metric_hi=int(rng.integers(1, 40)),
+                              max_path=(1023 if rng.random() < 0.15 else (0xFFFFFFFF if rng.random() < 0.3 else synth.MAX_PATH_METRIC_WIDE)),
+                              p_oneway=float(rng.choice([0.0, 0.03, 0.3])), p_parallel=float(rng.choice([0.0, 0.05, 0.4])),
+                              p_overload=float(rng.choice([0.0, 0.03, 0.3])), p_noexpand=float(rng.choice([0.0, 0.02, 0.2])),
+                              zero_cost_router_links=bool(rng.random() < 0.15), lan_size=int(rng.integers(2, 31)), hopcount=hop)
+        G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        for rep in range(3):
+            k = int(rng.integers(1, min(g.n, 150) + 1))
+            roots = rng.choice(g.n, size=k, replace=rng.random() < 0.2).astype(np.uint32)
+            if k > 3 and rng.random() < 0.3:
+                roots[int(rng.integers(0, k))] = E.NO_ROOT
+            flags = int(rng.choice([0, E.RUN_NET_NEXTHOPS, E.RUN_IGNORE_OVERLOAD, E.RUN_NET_NEXTHOPS | E.RUN_IGNORE_OVERLOAD]))
+            if hop:
+                flags |= E.RUN_IGNORE_OVERLOAD
+            if rng.random() < 0.08:
+                flags |= E.RUN_POP_RANK
+            runs += 1
+            ok += compare(ctx, G, g, roots, flags, (seed, rep, flags, k))
+            if rep < 2 and rng.random() < 0.5:                      # re-originate a few rows in between
+                vs = np.sort(rng.choice(g.n, size=int(rng.integers(1, 6)), replace=False))
+                rows, fl = [], []
+                for v in vs.tolist():
+                    c = g.col[g.row_ptr[v]:g.row_ptr[v + 1]]; m = g.metric[g.row_ptr[v]:g.row_ptr[v + 1]]
+                    keep = rng.random(len(c)) > 0.25
+                    c, m = c[keep], m[keep].copy()
+                    if len(m) and v >= nn and not hop:
+                        m[rng.random(len(m)) < 0.5] = int(rng.integers(1, 9))
+                    rows.append((c, m)); fl.append(int(g.vflags[v]) ^ (synth.VF_NO_TRANSIT if (v >= nn and rng.random() < 0.3) else 0))
+                G.patch(vs, rows, fl)
+                g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
+        G.free()
+    print(f"fuzz: {ok}/{runs} runs bit-exact over {count} graphs in {time.time() - t0:.1f} s", flush=True)
+    sys.exit(0 if ok == runs else 1)
+
+
+if __name__ == "__main__":
+    main()
