@@ -1,0 +1,17 @@
+"""A slice of the randomised differential run of tools/gpu_fuzz.py inside the GPU suite: 150 adversarial LSDBs x 3 runs
+(LANs up to 140 members = up to 3 mask words, every flag combination, ragged root lists up to 200 roots so that the
+regrouping by state class kicks in, row patches in between) — the HIP engine against the CPU oracle, bit for bit."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("first", [0, 5000, 9000])
+def test_random_lsdbs_runs_and_patches_against_the_oracle(spf_ctx, first):
+    import gpu_fuzz
+    ok, runs = gpu_fuzz.fuzz(spf_ctx, first, 50, verbose=False)
+    assert ok == runs and runs == 150

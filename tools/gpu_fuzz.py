@@ -21,7 +21,12 @@ from oracle import graph_oracle as go          # noqa: E402
 
 
 def compare(ctx, G, g, roots, flags, tag):
-    res = ctx.run(G, roots, flags)
+    try:
+        res = ctx.run(G, roots, flags)
+    except E.HspfError as e:
+        if e.code == -5:                       # documented limit: more than 1024 first-hop slots (16 mask words)
+            return True
+        raise
     ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, flags & 3, go.MAP,
                  mask_words_=res.first_hop_mask.shape[2])
     bad = []
@@ -35,25 +40,22 @@ def compare(ctx, G, g, roots, flags, tag):
     return not bad
 
 
-def main():
-    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-    ctx = E.SpfContext(0)
+def fuzz(ctx, first, count, verbose=True):
     ok = runs = 0
     t0 = time.time()
     for seed in range(first, first + count):
         rng = np.random.default_rng(10_000 + seed)
-        nr = int(rng.integers(5, 220)); nn = int(rng.integers(0, 14))
+        nr = int(rng.integers(5, 260)); nn = int(rng.integers(0, 14))
         hop = rng.random() < 0.2
         g = synth.random_lsdb(nr, nn, float(rng.uniform(1.2, 4.5)), 50_000 + seed,
                               metric_lo=1, metric_hi=int(rng.integers(1, 40)),
                               max_path=(1023 if rng.random() < 0.15 else (0xFFFFFFFF if rng.random() < 0.3 else synth.MAX_PATH_METRIC_WIDE)),
                               p_oneway=float(rng.choice([0.0, 0.03, 0.3])), p_parallel=float(rng.choice([0.0, 0.05, 0.4])),
                               p_overload=float(rng.choice([0.0, 0.03, 0.3])), p_noexpand=float(rng.choice([0.0, 0.02, 0.2])),
-                              zero_cost_router_links=bool(rng.random() < 0.15), lan_size=int(rng.integers(2, 31)), hopcount=hop)
+                              zero_cost_router_links=bool(rng.random() < 0.15), lan_size=int(rng.choice([2, 3, 5, 8, 14, 20, 30, 45, 70, 140])), hopcount=hop)
         G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
         for rep in range(3):
-            k = int(rng.integers(1, min(g.n, 150) + 1))
+            k = int(rng.integers(1, min(g.n, 200) + 1))
             roots = rng.choice(g.n, size=k, replace=rng.random() < 0.2).astype(np.uint32)
             if k > 3 and rng.random() < 0.3:
                 roots[int(rng.integers(0, k))] = E.NO_ROOT
@@ -77,7 +79,15 @@ def main():
                 G.patch(vs, rows, fl)
                 g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
         G.free()
-    print(f"fuzz: {ok}/{runs} runs bit-exact over {count} graphs in {time.time() - t0:.1f} s", flush=True)
+    if verbose:
+        print(f"fuzz: {ok}/{runs} runs bit-exact over {count} graphs in {time.time() - t0:.1f} s", flush=True)
+    return ok, runs
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    ok, runs = fuzz(E.SpfContext(0), first, count)
     sys.exit(0 if ok == runs else 1)
 
 
