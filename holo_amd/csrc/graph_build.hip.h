@@ -181,7 +181,10 @@ kb_scatter(uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__r
     const uint32_t slot = atomicSub(&in_cnt[t], 1u) - 1u;      // any order: kb_rank fixes the final one
     const uint32_t i = in_ptr[t] + slot;
     tmp_w[i] = w;
-    tmp_src[i] = u | ((vflags[u] & HSPF_VF_NO_TRANSIT) ? SRC_NO_TRANSIT : 0u);
+    // the overload gate only exists for routers (holo-isis/src/spf.rs:568-574: `!vertex.id.is_pseudonode()`): the bit on
+    // a network vertex is ignored, as k_exact and the oracle do
+    const uint32_t uf = vflags[u];
+    tmp_src[i] = u | (((uf & HSPF_VF_NO_TRANSIT) && !(uf & HSPF_VF_NETWORK)) ? SRC_NO_TRANSIT : 0u);
     tmp_fpos[i] = fpos;
     tmp_t[i] = t;
     atomicMax(&bmax, w);

@@ -53,7 +53,9 @@ extern "C" {
  *       increment `hops` (holo-ospf/src/spf.rs:675-678, holo-isis/src/spf.rs:650-653).      */
 #define HSPF_VF_NETWORK    0x01u
 /* bit1: IS-IS overload bit set for the topology of this run: the vertex stays in the SPT
- *       but its links are skipped unless it is the root (holo-isis/src/spf.rs:568-574).      */
+ *       but its links are skipped unless it is the root (holo-isis/src/spf.rs:568-574).
+ *       Routers only, as in the reference (`!vertex.id.is_pseudonode()`): ignored on a vertex
+ *       that also has HSPF_VF_NETWORK.                                                          */
 #define HSPF_VF_NO_TRANSIT 0x02u
 /* bit2: never expanded, root included: zeroth LSP missing / seqno 0 / lifetime 0
  *       (holo-isis/src/spf.rs:558-561) or protocols-supported gate (:582-604).               */

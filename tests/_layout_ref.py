@@ -7,7 +7,7 @@ Semantics restated (include/holo_spf_hip.h, hspf_graph_export):
   kept            two-way and the source may be expanded (not HSPF_VF_NO_EXPAND, holo-isis/src/spf.rs:557-604)
   out-rows        kept links in the caller's order
   in-rows         kept links into a vertex by (cost descending, source ascending, position ascending);
-                  bit 31 of the source = HSPF_VF_NO_TRANSIT of the source
+                  bit 31 of the source = HSPF_VF_NO_TRANSIT of the source (routers only: ignored on network vertices)
 """
 import numpy as np
 
@@ -31,7 +31,7 @@ def layout(row_ptr, col, metric, vflags):
     in_ptr = np.zeros(n + 1, np.int64)
     np.add.at(in_ptr, kt + 1, 1)
     in_ptr = np.cumsum(in_ptr)
-    nt = (vflags[ks[order]] & VF_NO_TRANSIT) != 0
+    nt = ((vflags[ks[order]] & VF_NO_TRANSIT) != 0) & ((vflags[ks[order]] & VF_NETWORK) == 0)   # routers only
     in_src = (ks[order] | (nt.astype(np.int64) << 31)).astype(np.uint32)
     rowflags = np.zeros(n, np.uint8)
     t_o, w_o, s_o = kt[order], kw[order], ks[order]

@@ -15,3 +15,11 @@ def test_random_lsdbs_runs_and_patches_against_the_oracle(spf_ctx, first):
     import gpu_fuzz
     ok, runs = gpu_fuzz.fuzz(spf_ctx, first, 50, verbose=False)
     assert ok == runs and runs == 150
+
+
+def test_random_layouts_and_arbitrary_row_patches_against_the_restatement(spf_ctx):
+    import gpu_fuzz
+    # spf=True: after every round of arbitrary row replacements (links between any two vertices, any flags) an SPF
+    # run on whatever graph that made, against the oracle
+    ok, runs = gpu_fuzz.fuzz_layout(spf_ctx, 0, 40, verbose=False, spf=True)
+    assert ok == runs and runs == 240

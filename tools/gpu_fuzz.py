@@ -84,11 +84,57 @@ def fuzz(ctx, first, count, verbose=True):
     return ok, runs
 
 
+def fuzz_layout(ctx, first, count, verbose=True, spf=False):
+    """Device graph construction and row patches: every exported array against the numpy restatement
+    (tests/_layout_ref.py), and a patched graph against a fresh upload of the patched CSR."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from _layout_ref import layout
+    built = ("twoway", "in_ptr", "in_src", "in_cost", "in_pos", "out_ptr", "out_dst", "out_cost", "out_pos", "rowflags")
+    ok = runs = 0
+    t0 = time.time()
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(70_000 + seed)
+        g = synth.random_lsdb(int(rng.integers(3, 150)), int(rng.integers(0, 10)), float(rng.uniform(1.0, 5.0)), 90_000 + seed,
+                              metric_hi=int(rng.integers(1, 10)), p_oneway=float(rng.choice([0.0, 0.1, 0.5])),
+                              p_parallel=float(rng.choice([0.0, 0.2, 0.6])), p_overload=float(rng.choice([0.0, 0.3])),
+                              p_noexpand=float(rng.choice([0.0, 0.3])), zero_cost_router_links=bool(rng.random() < 0.3),
+                              lan_size=int(rng.choice([2, 6, 20, 50])), hopcount=bool(rng.random() < 0.2))
+        G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        for rep in range(3):
+            want = layout(G.row_ptr, G.col, G.metric, G.vflags)
+            good = all(np.array_equal(G.export(k), want[k]) for k in built) and G.n_edges_kept == len(want["in_src"])
+            good = good and all(np.array_equal(G.export(k), getattr(G, k)) for k in ("row_ptr", "col", "metric", "vflags"))
+            runs += 1
+            ok += good
+            if not good:
+                print("LAYOUT MISMATCH", seed, rep, flush=True)
+            n = G.n
+            vs = np.sort(rng.choice(n, size=int(rng.integers(1, min(n, 12) + 1)), replace=False))
+            rows, fl = [], []
+            for v in vs.tolist():
+                deg = int(rng.integers(0, 9))
+                rows.append((rng.integers(0, n, deg).astype(np.uint32), rng.integers(0, 6, deg).astype(np.uint32)))
+                fl.append(int(rng.integers(0, 8)))
+            G.patch(vs, rows, fl)
+            if spf:                                            # SPF on whatever graph the arbitrary rows made
+                gg = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
+                roots = rng.choice(n, size=int(rng.integers(1, min(n, 70) + 1)), replace=False).astype(np.uint32)
+                flags = int(rng.choice([0, E.RUN_NET_NEXTHOPS, E.RUN_IGNORE_OVERLOAD, 3]))
+                runs += 1
+                ok += compare(ctx, G, gg, roots, flags, ("arbitrary", seed, rep, flags))
+        G.free()
+    if verbose:
+        print(f"fuzz_layout: {ok}/{runs} layouts identical over {count} graphs in {time.time() - t0:.1f} s", flush=True)
+    return ok, runs
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-    ok, runs = fuzz(E.SpfContext(0), first, count)
-    sys.exit(0 if ok == runs else 1)
+    ctx = E.SpfContext(0)
+    ok, runs = fuzz(ctx, first, count)
+    ok2, runs2 = fuzz_layout(ctx, first, max(count // 4, 20), spf=bool(os.environ.get("FUZZ_ARBITRARY")))
+    sys.exit(0 if (ok == runs and ok2 == runs2) else 1)
 
 
 if __name__ == "__main__":
