@@ -23,3 +23,9 @@ def test_random_layouts_and_arbitrary_row_patches_against_the_restatement(spf_ct
     # run on whatever graph that made, against the oracle
     ok, runs = gpu_fuzz.fuzz_layout(spf_ctx, 0, 40, verbose=False, spf=True)
     assert ok == runs and runs == 240
+
+
+def test_random_prefix_tables_on_device_against_the_restatement(spf_ctx):
+    import gpu_fuzz
+    ok, runs = gpu_fuzz.fuzz_routes(spf_ctx, 0, 12, verbose=False)
+    assert ok == runs and runs == 48

@@ -45,7 +45,8 @@ def fuzz(ctx, first, count, verbose=True):
     t0 = time.time()
     for seed in range(first, first + count):
         rng = np.random.default_rng(10_000 + seed)
-        nr = int(rng.integers(5, 260)); nn = int(rng.integers(0, 14))
+        nr = int(rng.integers(5, 260)) if rng.random() > 0.04 else int(rng.integers(800, 3000))
+        nn = int(rng.integers(0, 14))
         hop = rng.random() < 0.2
         g = synth.random_lsdb(nr, nn, float(rng.uniform(1.2, 4.5)), 50_000 + seed,
                               metric_lo=1, metric_hi=int(rng.integers(1, 40)),
@@ -53,9 +54,11 @@ def fuzz(ctx, first, count, verbose=True):
                               p_oneway=float(rng.choice([0.0, 0.03, 0.3])), p_parallel=float(rng.choice([0.0, 0.05, 0.4])),
                               p_overload=float(rng.choice([0.0, 0.03, 0.3])), p_noexpand=float(rng.choice([0.0, 0.02, 0.2])),
                               zero_cost_router_links=bool(rng.random() < 0.15), lan_size=int(rng.choice([2, 3, 5, 8, 14, 20, 30, 45, 70, 140])), hopcount=hop)
+        if rng.random() < 0.15 and not hop:                       # large costs: 8-byte state, max-path pruning, u32 saturation
+            g.metric = (g.metric.astype(np.uint64) << int(rng.integers(8, 25))).clip(0, 0xFFFFFFFE).astype(np.uint32)
         G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
         for rep in range(3):
-            k = int(rng.integers(1, min(g.n, 200) + 1))
+            k = int(rng.integers(1, min(g.n, 200 if g.n < 800 else 700) + 1))
             roots = rng.choice(g.n, size=k, replace=rng.random() < 0.2).astype(np.uint32)
             if k > 3 and rng.random() < 0.3:
                 roots[int(rng.integers(0, k))] = E.NO_ROOT
@@ -128,13 +131,76 @@ def fuzz_layout(ctx, first, count, verbose=True, spf=False):
     return ok, runs
 
 
+def fuzz_routes(ctx, first, count, verbose=True):
+    """hspf_routes_device (IS-IS rule, OSPF saturating add, OSPF last-min-replaces) on random prefix tables against a
+    per-prefix restatement over the oracle's SPT tables."""
+    import torch
+    dev = torch.device("cuda:0")
+    ok = runs = 0
+    t0 = time.time()
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(130_000 + seed)
+        g = synth.random_lsdb(int(rng.integers(5, 120)), int(rng.integers(0, 8)), float(rng.uniform(1.5, 4.0)), 140_000 + seed,
+                              metric_hi=int(rng.integers(1, 8)), lan_size=int(rng.choice([2, 5, 12])), max_path=0xFFFFFFFF)
+        n = g.n
+        R = int(rng.integers(1, min(n, 70) + 1))
+        roots = rng.choice(n, size=R, replace=False).astype(np.uint32)
+        rflags = int(rng.choice([0, E.RUN_NET_NEXTHOPS]))
+        ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, rflags, go.MAP)
+        W = ref.mask.shape[2]
+        G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        dist = torch.empty((R, n), dtype=torch.int32, device=dev); hops = torch.empty((R, n), dtype=torch.int16, device=dev)
+        fl = torch.empty((R, n), dtype=torch.int16, device=dev); mask = torch.empty((R, n, W), dtype=torch.int64, device=dev)
+        ctx.run_device(G, roots, rflags, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(), flags_ptr=fl.data_ptr(),
+                       mask_ptr=mask.data_ptr(), mask_words=W)
+        G.free()
+        P = int(rng.integers(1, 60)); ne = int(rng.integers(0, 200))
+        pfx = np.sort(rng.integers(0, P, ne)); vtx = rng.integers(0, n, ne)
+        order = np.lexsort((vtx, pfx)); pfx, vtx = pfx[order], vtx[order].astype(np.uint32)
+        met = rng.integers(0, 4, ne).astype(np.uint32)
+        big = rng.random(ne) < 0.08
+        met[big] = (0xFFFFFFFF - rng.integers(0, 6, int(big.sum()))).astype(np.uint32)
+        ptr = np.zeros(P + 1, np.uint32); np.add.at(ptr, pfx + 1, 1); ptr = np.cumsum(ptr, dtype=np.uint64).astype(np.uint32)
+        for mode in (0, E.PFX_SATURATING, E.PFX_LAST_MIN, E.PFX_SATURATING | E.PFX_LAST_MIN):
+            bm = torch.empty((R, P), dtype=torch.int32, device=dev); be = torch.empty((R, P), dtype=torch.int32, device=dev)
+            nm = torch.empty((R, P, W), dtype=torch.int64, device=dev)
+            ctx.routes_device(n, R, W, dist.data_ptr(), fl.data_ptr(), mask.data_ptr(), ptr, vtx, met, best_metric_ptr=bm.data_ptr(),
+                              best_entry_ptr=be.data_ptr(), nexthop_mask_ptr=nm.data_ptr(), flags=mode)
+            torch.cuda.synchronize()
+            hbm = bm.cpu().numpy().view(np.uint32); hbe = be.cpu().numpy().view(np.uint32); hnm = nm.cpu().numpy().view(np.uint64)
+            sat, last = bool(mode & E.PFX_SATURATING), bool(mode & E.PFX_LAST_MIN)
+            good = True
+            for r in range(R):
+                for p in range(P):
+                    best, ent, acc = 0xFFFFFFFF, 0xFFFFFFFF, np.zeros(W, np.uint64)
+                    for e in range(int(ptr[p]), int(ptr[p + 1])):
+                        v = int(vtx[e])
+                        if not ref.flags[r, v]:
+                            continue
+                        m = int(ref.dist[r, v]) + int(met[e])
+                        m = min(m, 0xFFFFFFFF) if sat else m & 0xFFFFFFFF
+                        if ent == 0xFFFFFFFF or m < best or (last and m == best):
+                            best, ent, acc = m, e, ref.mask[r, v].copy()
+                        elif m == best:
+                            acc |= ref.mask[r, v]
+                    good = good and hbm[r, p] == best and hbe[r, p] == ent and np.array_equal(hnm[r, p], acc)
+            runs += 1
+            ok += good
+            if not good:
+                print("ROUTES MISMATCH", seed, mode, flush=True)
+    if verbose:
+        print(f"fuzz_routes: {ok}/{runs} tables identical over {count} graphs in {time.time() - t0:.1f} s", flush=True)
+    return ok, runs
+
+
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     ctx = E.SpfContext(0)
     ok, runs = fuzz(ctx, first, count)
     ok2, runs2 = fuzz_layout(ctx, first, max(count // 4, 20), spf=bool(os.environ.get("FUZZ_ARBITRARY")))
-    sys.exit(0 if (ok == runs and ok2 == runs2) else 1)
+    ok3, runs3 = fuzz_routes(ctx, first, max(count // 20, 5))
+    sys.exit(0 if (ok == runs and ok2 == runs2 and ok3 == runs3) else 1)
 
 
 if __name__ == "__main__":
