@@ -1,0 +1,105 @@
+"""Random IS-IS instances in the schema of tests/golden/isis/*.json (tools/make_golden.py), for differential tests of the
+host twin (holo_amd/isis.py: LSDB -> CSR, slot replay through resolve_nexthop, route build) against the literal
+restatement (oracle/isis_ref.py).  TEST INFRASTRUCTURE ONLY.
+
+What is varied: router count, p2p links (also parallel ones between the same pair, with equal or different metrics),
+LANs with a pseudonode LSP, metric type (standard / wide / both), overload and attached bits, missing or partial
+protocols-supported TLVs, expired LSPs, one-way adjacencies in the LSDB, fragments, shared prefixes (ECMP across
+advertisers), the local router's interfaces in name order (p2p metric must equal the link cost, holo-isis/src/spf.rs:988-990)."""
+import numpy as np
+
+
+def sid(i):
+    return f"0000.0000.{i:04x}"
+
+
+def make(seed: int) -> dict:
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(3, 13))
+    mtype = str(rng.choice(["standard", "wide", "both"]))
+    maxm = 60 if mtype != "wide" else 5000
+    local = int(rng.integers(1, n + 1))
+    # topology
+    p2p = []                                     # (a, b, metric a->b, metric b->a)
+    for a in range(1, n + 1):
+        for b in range(a + 1, n + 1):
+            if rng.random() < min(1.0, 2.2 / n):
+                reps = 2 if rng.random() < 0.25 else 1
+                m = int(rng.integers(1, maxm))
+                for _ in range(reps):
+                    same = rng.random() < 0.6
+                    p2p.append((a, b, m, m if rng.random() < 0.7 else int(rng.integers(1, maxm))))
+                    if not same:
+                        m = int(rng.integers(1, maxm))
+    for a in range(1, n):                        # keep it mostly connected
+        if not any(x[:2] in ((a, a + 1),) for x in p2p) and rng.random() < 0.8:
+            m = int(rng.integers(1, maxm)); p2p.append((a, a + 1, m, m))
+    lans = []                                    # (dis, pn id, members, metric per member)
+    for k in range(int(rng.integers(0, 3))):
+        size = int(rng.integers(2, min(n, 6) + 1))
+        members = sorted(rng.choice(np.arange(1, n + 1), size=size, replace=False).tolist())
+        dis = int(rng.choice(members))
+        lans.append((dis, k + 1, members, {m: int(rng.integers(1, maxm)) for m in members}))
+    # LSPs
+    lsps = []
+    std_on, wide_on = mtype in ("standard", "both"), mtype in ("wide", "both")
+    for r in range(1, n + 1):
+        nbrs = []
+        for a, b, mab, mba in p2p:
+            if a == r and rng.random() > 0.04: nbrs.append((f"{sid(b)}.00", mab))
+            if b == r and rng.random() > 0.04: nbrs.append((f"{sid(a)}.00", mba))     # 4 %: one-way in the LSDB
+        for dis, pn, members, met in lans:
+            if r in members: nbrs.append((f"{sid(dis)}.{pn:02x}", met[r]))
+        order = rng.permutation(len(nbrs)).tolist()
+        nbrs = [nbrs[i] for i in order]
+        flags = (["ol"] if rng.random() < 0.12 else []) + (["att"] if rng.random() < 0.1 else [])
+        protos = [204, 142] if rng.random() > 0.1 else ([204] if rng.random() < 0.5 else None)
+        pf4 = [[f"{r}.{r}.{r}.{r}/32", int(rng.integers(0, 20))]]
+        if rng.random() < 0.6: pf4.append([f"10.{int(rng.integers(0, 4))}.0.0/24", int(rng.integers(0, 20))])     # shared
+        pf6 = [[f"2001:db8::{r:x}/128", int(rng.integers(0, 20)), False]]
+        if rng.random() < 0.4: pf6.append([f"fc00:{int(rng.integers(0, 3))}::/64", int(rng.integers(0, 20)), bool(rng.random() < 0.2)])
+        split = len(nbrs) // 2 if (len(nbrs) > 2 and rng.random() < 0.3) else len(nbrs)      # second fragment
+        for frag, part in ((0, nbrs[:split]), (1, nbrs[split:])):
+            if frag == 1 and not part:
+                continue
+            l = {"id": f"{sid(r)}.00-{frag:02x}", "flags": flags if frag == 0 else [], "protocols": protos if frag == 0 else None,
+                 "is_reach": [[x, min(m, 63)] for x, m in part] if std_on else [],
+                 "ext_is_reach": [[x, m] for x, m in part] if wide_on else [],
+                 "mt": [], "mt_is_reach": [], "mt_ipv6": [],
+                 "ipv4_int": pf4 if (frag == 0 and std_on) else [], "ipv4_ext": [],
+                 "ext_ipv4": [[p, m, False] for p, m in pf4] if (frag == 0 and wide_on) else [],
+                 "ipv6": pf6 if frag == 0 else []}
+            if rng.random() < 0.04:
+                l["lifetime"] = 0                                                               # expired fragment
+            lsps.append(l)
+    for dis, pn, members, met in lans:
+        if rng.random() < 0.93:                                                                 # 7 %: DIS LSP missing
+            ms = [m for m in members if rng.random() > 0.05]
+            lsps.append({"id": f"{sid(dis)}.{pn:02x}-00", "flags": [], "protocols": None,
+                         "is_reach": [[f"{sid(m)}.00", 0] for m in ms] if std_on else [],
+                         "ext_is_reach": [[f"{sid(m)}.00", 0] for m in ms] if wide_on else [],
+                         "mt": [], "mt_is_reach": [], "mt_ipv6": [], "ipv4_int": [], "ipv4_ext": [], "ext_ipv4": [], "ipv6": []})
+    # the local router's interfaces
+    ifaces, k = [], 0
+    for a, b, mab, mba in p2p:
+        if local in (a, b):
+            other, m = (b, mab) if a == local else (a, mba)
+            k += 1
+            ifaces.append({"name": f"eth{int(rng.integers(0, 50)):02d}-{k}", "type": "point-to-point",
+                           "metric": {"1": min(m, 63) if mtype == "standard" else m, "2": min(m, 63) if mtype == "standard" else m},
+                           "adjacencies": [{"system_id": sid(other), "usage": "level-2", "state": "up" if rng.random() > 0.05 else "down",
+                                            "ipv4": [f"10.{local}.{k}.{other}"], "ipv6": [f"fe80::{local:x}:{k:x}:{other:x}"],
+                                            "topologies": [0], "area_addrs": ["49.0000"]}]})
+    for dis, pn, members, met in lans:
+        if local in members:
+            k += 1
+            ifaces.append({"name": f"lan{int(rng.integers(0, 50)):02d}-{k}", "type": "broadcast", "metric": {"1": met[local], "2": met[local]},
+                           "adjacencies": [{"system_id": sid(m), "usage": "level-2", "state": "up",
+                                            "ipv4": [f"172.16.{pn}.{m}"], "ipv6": [f"fe80::aa:{pn:x}:{m:x}"],
+                                            "topologies": [0], "area_addrs": ["49.0000"]} for m in members if m != local]})
+    ifaces.append({"name": "lo", "type": "broadcast", "metric": {"1": 10, "2": 10}, "adjacencies": []})
+    return {"proto": "isis", "source": f"random instance {seed}",
+            "config": {"system_id": sid(local), "level_type": "level-2", "metric_type": {"1": mtype, "2": mtype},
+                       "afs": {"ipv4": bool(rng.random() > 0.1), "ipv6": bool(rng.random() > 0.2)}, "mt_ipv6_unicast": False,
+                       "max_paths": int(rng.choice([1, 2, 16])), "att_ignore": bool(rng.random() < 0.2), "area_addrs": ["49.0000"]},
+            "interfaces": ifaces, "lsdb": {"2": lsps}, "rib": []}

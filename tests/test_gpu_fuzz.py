@@ -29,3 +29,21 @@ def test_random_prefix_tables_on_device_against_the_restatement(spf_ctx):
     import gpu_fuzz
     ok, runs = gpu_fuzz.fuzz_routes(spf_ctx, 0, 12, verbose=False)
     assert ok == runs and runs == 48
+
+
+def test_random_isis_instances_and_ospf_areas_through_the_engine(spf_ctx):
+    """The host twins on random protocol-level inputs (tests/_random_isis.py, tests/_random_ospf.py) with the HIP engine
+    behind them, against the literal restatements: RIBs, and whole SPTs for a sample."""
+    from holo_amd import isis as H
+    from oracle import isis_ref as R
+    from _random_isis import make as make_isis
+    from _random_ospf import make as make_ospf
+    from test_host_isis import check_spts_against_ref
+    from test_host_ospf_random import check as check_ospf
+    for seed in range(1000, 1060):
+        vec = make_isis(seed)
+        assert H.compute_spf(H.Instance.from_vector(vec), spf_ctx) == R.local_rib(vec), seed
+        if seed % 6 == 0:
+            check_spts_against_ref(vec, H.Instance.from_vector(vec), spf_ctx)
+    for seed in range(1000, 1060):
+        check_ospf(make_ospf(seed), spf_ctx)
