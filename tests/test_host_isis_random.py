@@ -20,3 +20,57 @@ def test_random_instances_local_rib_and_all_roots(block):
         assert H.compute_spf(inst, eng) == R.local_rib(vec), seed
         if seed % 5 == 0:
             check_spts_against_ref(vec, H.Instance.from_vector(vec), eng)
+
+
+def mutate(vec, rng):
+    """A few LSP-level changes of the kind the protocol produces: overload bit flips, metric changes, a neighbour
+    dropped, a fragment purged (lifetime 0)."""
+    import copy
+    v = copy.deepcopy(vec)
+    lsps = v["lsdb"]["2"]
+    for _ in range(int(rng.integers(1, 4))):
+        l = lsps[int(rng.integers(0, len(lsps)))]
+        what = int(rng.integers(0, 4))
+        if what == 0:
+            l["flags"] = [f for f in l["flags"] if f != "ol"] if "ol" in l["flags"] else l["flags"] + ["ol"]
+        elif what == 1:
+            for key in ("is_reach", "ext_is_reach"):
+                if l[key]:
+                    i = int(rng.integers(0, len(l[key])))
+                    l[key][i] = [l[key][i][0], int(rng.integers(1, 60))]
+        elif what == 2:
+            for key in ("is_reach", "ext_is_reach"):
+                if l[key]:
+                    l[key].pop(int(rng.integers(0, len(l[key]))))
+        else:
+            l["lifetime"] = 0
+    return v
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_lsp_changes_through_the_graph_cache(block):
+    """LSDB -> CSR kept current from the changed LSPs (GraphCache / LevelGraph.refresh): after random LSP changes the
+    cached graph equals one derived from scratch and the RIB equals the literal restatement's."""
+    import numpy as np
+    eng = OracleEngine()
+    patched = 0
+    for seed in range(500 + block * 30, 500 + block * 30 + 30):
+        rng = np.random.default_rng(seed)
+        vec = make(seed)
+        cache = H.GraphCache()
+        inst = H.Instance.from_vector(vec)
+        assert H.compute_spf(inst, eng, cache) == R.local_rib(vec)
+        for step in range(3):
+            vec2 = mutate(vec, rng)
+            inst2 = H.Instance.from_vector(vec2)
+            trig = {2: H.changed_lan_ids(inst.lsdb.get(2) or H.Lsdb(), inst2.lsdb.get(2) or H.Lsdb())}
+            before = cache.patched
+            assert H.compute_spf(inst2, eng, cache, trig) == R.local_rib(vec2), (seed, step)
+            patched += cache.patched - before
+            for (level, mt_id, hc), g in cache.graphs.items():
+                fresh = H.LevelGraph(inst2, level, mt_id, hc)
+                assert g.vids == fresh.vids
+                for name in ("row_ptr", "col", "metric", "vflags"):
+                    assert np.array_equal(getattr(g, name), getattr(fresh, name)), (seed, step, name)
+            vec, inst = vec2, inst2
+    assert patched > 20           # most changes keep the vertex set: they must go through refresh(), not a rebuild
