@@ -72,3 +72,12 @@ def test_reflood_list_without_cache_entry_is_empty():
     inst = H.Instance.from_vector(vec)
     cache = H.manet_init_cache(inst.config.levels()[0], inst, OracleEngine())
     assert H.reflood_list(cache, inst.config.system_id, b"\xee" * 6, (b"\x01" * 6, 0, 0)) == []
+
+
+@pytest.mark.parametrize("block", range(3))
+def test_reflood_lists_on_random_instances(block):
+    from _random_isis import make
+    total = 0
+    for seed in range(2000 + block * 20, 2000 + block * 20 + 20):
+        total += check_reflood_lists(make(seed), OracleEngine())
+    assert total > 100
