@@ -1,0 +1,149 @@
+// holo_spf_host.hpp — what the C++ host-side twins (holo_spf_isis.hpp, holo_spf_ospf.hpp) share: the three engine calls
+// they need, the product implementation of those calls on the C ABI, and IP prefix / address keys in the order of the
+// reference's BTreeMap<IpNetwork, _> / BTreeMap<IpAddr, _>.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "holo_spf_hip.h"
+
+namespace hspf {
+namespace host {
+
+// ---- engine seen from the host side ------------------------------------------------------------------------------
+struct Tables {                       // row-major [root][vertex] results of one run
+  uint32_t n_roots = 0, n_vertices = 0, mask_words = 1;
+  std::vector<uint32_t> dist, pop_rank;
+  std::vector<uint16_t> hops, flags;
+  std::vector<uint64_t> mask;
+};
+struct SlotTable { std::vector<uint32_t> vertex, base; uint32_t total = 0; };
+
+class Graph {                         // one uploaded graph (device resident for the product engine)
+ public:
+  virtual ~Graph() = default;
+};
+class Engine {
+ public:
+  virtual ~Engine() = default;
+  virtual std::unique_ptr<Graph> upload(const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col,
+                                        const std::vector<uint32_t> &metric, const std::vector<uint8_t> &vflags,
+                                        uint32_t max_path_metric) = 0;
+  virtual Tables run(Graph &g, const std::vector<uint32_t> &roots, uint32_t run_flags) = 0;
+  virtual SlotTable slot_table(Graph &g, uint32_t root) = 0;
+};
+
+// ---- addresses and prefixes (BTreeMap<IpNetwork, _> / BTreeMap<IpAddr, _> order) -----------------------------------
+struct IpKey {                        // (version, 128-bit address, prefix length)
+  int version = 4;
+  std::array<uint8_t, 16> addr{};
+  int len = 0;
+  bool operator<(const IpKey &o) const { return std::tie(version, addr, len) < std::tie(o.version, o.addr, o.len); }
+  bool operator==(const IpKey &o) const { return version == o.version && addr == o.addr && len == o.len; }
+};
+inline IpKey parse_ip(const std::string &text) {             // "a.b.c.d[/len]" or IPv6 text form (with "::")
+  IpKey k;
+  std::string a = text;
+  const size_t slash = a.find('/');
+  int len = -1;
+  if (slash != std::string::npos) { len = std::stoi(a.substr(slash + 1)); a = a.substr(0, slash); }
+  if (a.find(':') == std::string::npos) {
+    k.version = 4;
+    size_t pos = 0;
+    for (int i = 0; i < 4; ++i) {
+      const size_t dot = a.find('.', pos);
+      k.addr[12 + i] = (uint8_t)std::stoi(a.substr(pos, dot == std::string::npos ? std::string::npos : dot - pos));
+      pos = dot == std::string::npos ? a.size() : dot + 1;
+    }
+    k.len = len < 0 ? 32 : len;
+    if (k.len < 32) {                                        // network address: host bits cleared (strict = false)
+      uint32_t v = ((uint32_t)k.addr[12] << 24) | ((uint32_t)k.addr[13] << 16) | ((uint32_t)k.addr[14] << 8) | k.addr[15];
+      v = k.len == 0 ? 0 : (v & (0xFFFFFFFFu << (32 - k.len)));
+      k.addr[12] = v >> 24; k.addr[13] = v >> 16; k.addr[14] = v >> 8; k.addr[15] = v;
+    }
+    return k;
+  }
+  k.version = 6;
+  std::vector<uint16_t> head, tail;
+  bool in_tail = false;
+  size_t pos = 0;
+  if (a.rfind("::", 0) == 0) { in_tail = true; pos = 2; }
+  while (pos < a.size()) {
+    size_t c = a.find(':', pos);
+    std::string grp = a.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+    if (grp.empty()) { in_tail = true; pos = c + 1; continue; }
+    (in_tail ? tail : head).push_back((uint16_t)std::stoul(grp, nullptr, 16));
+    if (c == std::string::npos) break;
+    if (c + 1 < a.size() && a[c + 1] == ':') { in_tail = true; pos = c + 2; } else pos = c + 1;
+  }
+  std::vector<uint16_t> g(8, 0);
+  for (size_t i = 0; i < head.size() && i < 8; ++i) g[i] = head[i];
+  for (size_t i = 0; i < tail.size() && i < 8; ++i) g[8 - tail.size() + i] = tail[i];
+  for (int i = 0; i < 8; ++i) { k.addr[2 * i] = g[i] >> 8; k.addr[2 * i + 1] = g[i] & 0xFF; }
+  k.len = len < 0 ? 128 : len;
+  for (int bit = k.len; bit < 128; ++bit) k.addr[bit / 8] &= ~(uint8_t)(0x80u >> (bit % 8));
+  return k;
+}
+
+
+// ---- the product engine: libholo_spf_hip.so through the C ABI ---------------------------------------------------------
+class HipGraph : public Graph {
+ public:
+  HipGraph(hspf_ctx *c, hspf_graph *g) : ctx(c), g(g) {}
+  ~HipGraph() override { if (g) hspf_graph_free(ctx, g); }
+  hspf_ctx *ctx;
+  hspf_graph *g;
+};
+class HipEngine : public Engine {
+ public:
+  explicit HipEngine(int device = 0) {
+    const int rc = hspf_init(device, &ctx_);
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_init: ") + hspf_strerror(rc));   // no CPU fallback
+  }
+  ~HipEngine() override { if (ctx_) hspf_shutdown(ctx_); }
+  std::unique_ptr<Graph> upload(const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col,
+                                const std::vector<uint32_t> &metric, const std::vector<uint8_t> &vflags,
+                                uint32_t max_path_metric) override {
+    hspf_csr csr{(uint32_t)vflags.size(), (uint32_t)col.size(), row_ptr.data(), col.data(), metric.data(), vflags.data(), max_path_metric};
+    hspf_graph *g = nullptr;
+    const int rc = hspf_graph_upload(ctx_, &csr, &g);
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_graph_upload: ") + hspf_last_error(ctx_));
+    return std::make_unique<HipGraph>(ctx_, g);
+  }
+  Tables run(Graph &gr, const std::vector<uint32_t> &roots, uint32_t run_flags) override {
+    hspf_graph *g = static_cast<HipGraph &>(gr).g;
+    Tables t;
+    t.n_roots = (uint32_t)roots.size();
+    t.n_vertices = hspf_graph_n_vertices(g);
+    int rc = hspf_mask_words(ctx_, g, roots.data(), t.n_roots, &t.mask_words);
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_mask_words: ") + hspf_last_error(ctx_));
+    const size_t rn = (size_t)t.n_roots * t.n_vertices;
+    t.dist.resize(rn); t.hops.resize(rn); t.flags.resize(rn); t.mask.resize(rn * t.mask_words);
+    if (run_flags & HSPF_RUN_POP_RANK) t.pop_rank.resize(rn);
+    hspf_result out{t.dist.data(), t.hops.data(), t.flags.data(), t.mask.data(), t.mask_words,
+                    (run_flags & HSPF_RUN_POP_RANK) ? t.pop_rank.data() : nullptr};
+    rc = hspf_run(ctx_, g, roots.data(), t.n_roots, run_flags, &out);
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_run: ") + hspf_last_error(ctx_));
+    return t;
+  }
+  SlotTable slot_table(Graph &gr, uint32_t root) override {
+    hspf_graph *g = static_cast<HipGraph &>(gr).g;
+    SlotTable st;
+    const int cnt = hspf_slot_table(ctx_, g, root, nullptr, nullptr, 0, &st.total);
+    if (cnt < 0) throw std::runtime_error(std::string("hspf_slot_table: ") + hspf_last_error(ctx_));
+    st.vertex.resize(cnt); st.base.resize(cnt);
+    hspf_slot_table(ctx_, g, root, st.vertex.data(), st.base.data(), (uint32_t)cnt, &st.total);
+    return st;
+  }
+ private:
+  hspf_ctx *ctx_ = nullptr;
+};
+
+}  // namespace host
+}  // namespace hspf

@@ -1,0 +1,622 @@
+// holo_spf_isis.hpp — C++17 host side of the IS-IS SPF path on top of the C ABI (include/holo_spf_hip.h).
+//
+// The compiled-code twin of what a maintainer's Rust patch does around the engine, function for
+// function, with the reference's names, argument meaning and failure behaviour:
+//
+//   vertex_edges()       holo-isis/src/spf.rs:1013-1146   edges of one LSP fragment, TLV order, metric mode
+//   LevelGraph           (new)                            LSDB of one level/topology -> hspf_csr, once per generation
+//   resolve_nexthop()    holo-isis/src/spf.rs:956-1010    unchanged: first matching interface in name order, used_adjs
+//   compute_spt(s)()     holo-isis/src/spf.rs:527-709     SPT loop on the device; first-hop slots replayed in reference
+//                        flooding/manet.rs:47-69          order through resolve_nexthop; batched roots = one run
+//   vertex_networks()    holo-isis/src/spf.rs:1149-1296   prefixes of one SPT vertex
+//   compute_routes()     holo-isis/src/spf.rs:840-949     prefix attachment, ECMP merge, max-paths truncation
+//   compute_spf()        holo-isis/src/spf.rs:719-836     per level / topology + L1/L2 merge (route.rs:185-249)
+//
+// The engine is reached through hspf::host::Engine (three calls: upload, run, slot_table); the product implementation
+// is hspf::host::HipEngine (holo_spf_host.hpp, the C ABI).  There is no CPU SPT loop in this file.  Python twin with the same structure:
+// holo_amd/isis.py.  Tests: tests/cpp/host_parity.cpp (recorded RIBs of the reference's conformance fixtures).
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <optional>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "holo_spf_host.hpp"
+
+namespace hspf {
+namespace host {
+namespace isis {
+
+constexpr uint32_t MAX_PATH_METRIC_STANDARD = 1023;          // holo-isis/src/spf.rs:45
+constexpr uint32_t MAX_PATH_METRIC_WIDE = 0xFE000000u;       // holo-isis/src/spf.rs:47
+constexpr uint32_t MAX_LINK_METRIC_WIDE = 0x00FFFFFFu;       // holo-isis/src/spf.rs:49
+constexpr int MT_STANDARD = 0, MT_IPV6_UNICAST = 2;
+constexpr int NLPID_IPV4 = 0xCC, NLPID_IPV6 = 0x8E;
+
+using SystemId = std::array<uint8_t, 6>;
+struct LanId {
+  SystemId system_id{};
+  uint8_t pseudonode = 0;
+  bool operator<(const LanId &o) const { return std::tie(system_id, pseudonode) < std::tie(o.system_id, o.pseudonode); }
+  bool operator==(const LanId &o) const { return system_id == o.system_id && pseudonode == o.pseudonode; }
+};
+struct VertexId {                     // holo-isis/src/spf.rs:96-100: derive(Ord) => pseudonodes first
+  bool non_pseudonode = true;
+  LanId lan_id;
+  bool operator<(const VertexId &o) const { return std::tie(non_pseudonode, lan_id) < std::tie(o.non_pseudonode, o.lan_id); }
+  bool operator==(const VertexId &o) const { return non_pseudonode == o.non_pseudonode && lan_id == o.lan_id; }
+};
+inline VertexId vertex_id(const LanId &l) { return VertexId{l.pseudonode == 0, l}; }
+
+// ---- the fields of Lsp / LspTlvs / Interface / Adjacency the path reads -----------------------------------------
+struct Lsp {
+  SystemId system_id{};
+  uint8_t pseudonode = 0, fragment = 0;
+  uint32_t seqno = 1;
+  uint16_t rem_lifetime = 1200;
+  bool overload = false, att = false;
+  std::optional<std::vector<int>> protocols_supported;
+  std::map<int, std::pair<bool, bool>> mt_flags;                               // mt -> (overload, att)
+  std::vector<std::pair<LanId, uint32_t>> is_reach, ext_is_reach;              // TLV 2, TLV 22
+  std::vector<std::tuple<int, LanId, uint32_t>> mt_is_reach;                   // TLV 222
+  std::vector<std::pair<std::string, uint32_t>> ipv4_internal, ipv4_external;  // TLV 128, 130
+  std::vector<std::tuple<std::string, uint32_t, bool>> ext_ipv4, ipv6;         // TLV 135 (+X), 236
+  std::vector<std::tuple<int, std::string, uint32_t, bool>> mt_ipv6;           // TLV 237
+  LanId lan_id() const { return LanId{system_id, pseudonode}; }
+  bool live() const { return seqno != 0 && rem_lifetime != 0; }               // spf.rs:1024-1025
+  bool overload_bit(int mt) const { auto it = mt_flags.find(mt); return mt == MT_STANDARD ? overload : (it != mt_flags.end() && it->second.first); }
+  bool att_bit(int mt) const { auto it = mt_flags.find(mt); return mt == MT_STANDARD ? att : (it != mt_flags.end() && it->second.second); }
+};
+struct Adjacency {
+  SystemId system_id{};
+  std::string level_usage;             // "level-1" | "level-2" | "level-all"
+  std::string state = "up";
+  std::vector<std::string> ipv4_addrs, ipv6_addrs, area_addrs;
+  std::vector<int> topologies{0};
+  std::string snpa;                    // anything unique per adjacency
+  bool intersects(int level) const { return level_usage == "level-all" || level_usage == "level-" + std::to_string(level); }
+  bool in_topology(int mt) const { return std::find(topologies.begin(), topologies.end(), mt) != topologies.end(); }
+};
+struct Interface {
+  std::string name, interface_type = "broadcast";     // "broadcast" | "point-to-point"
+  std::map<int, uint32_t> metric{{1, 10}, {2, 10}};
+  std::vector<Adjacency> adjacencies;
+};
+struct InstanceCfg {
+  SystemId system_id{};
+  std::string level_type = "level-all";
+  std::map<int, std::string> metric_type{{1, "wide"}, {2, "wide"}};
+  bool ipv4_enabled = true, ipv6_enabled = true, mt_ipv6_unicast = false, att_ignore = false;
+  uint32_t max_paths = 16;
+  std::vector<std::string> area_addrs;
+  bool is_af_enabled(bool v6) const { return v6 ? ipv6_enabled : ipv4_enabled; }
+  bool is_topology_enabled(int mt) const { return mt == MT_STANDARD ? true : mt_ipv6_unicast; }
+  std::vector<int> levels() const {
+    if (level_type == "level-1") return {1};
+    if (level_type == "level-2") return {2};
+    return {1, 2};
+  }
+};
+class Lsdb {                           // LSPs of one level ordered by LSP id (holo-isis/src/collections.rs:657-706)
+ public:
+  using Key = std::tuple<SystemId, uint8_t, uint8_t>;
+  void insert(Lsp l) { Key k{l.system_id, l.pseudonode, l.fragment}; by_id_[k] = std::move(l); }
+  const std::map<Key, Lsp> &all() const { return by_id_; }
+  std::vector<const Lsp *> iter_for_lan_id(const LanId &lan) const {
+    std::vector<const Lsp *> out;
+    for (auto it = by_id_.lower_bound(Key{lan.system_id, lan.pseudonode, 0}); it != by_id_.end(); ++it) {
+      if (!(std::get<0>(it->first) == lan.system_id) || std::get<1>(it->first) != lan.pseudonode) break;
+      out.push_back(&it->second);
+    }
+    return out;
+  }
+  const Lsp *zeroth_lsp(const LanId &lan) const {                              // spf.rs:1299-1309
+    auto it = by_id_.find(Key{lan.system_id, lan.pseudonode, 0});
+    return (it != by_id_.end() && it->second.live()) ? &it->second : nullptr;
+  }
+ private:
+  std::map<Key, Lsp> by_id_;
+};
+struct Instance {                      // the slice of InstanceUpView the path reads
+  InstanceCfg config;
+  std::vector<Interface> interfaces;
+  std::map<int, Lsdb> lsdb;
+  std::vector<const Interface *> interfaces_by_name() const {                  // collections.rs:258-265
+    std::vector<const Interface *> v;
+    for (auto &i : interfaces) v.push_back(&i);
+    std::sort(v.begin(), v.end(), [](const Interface *a, const Interface *b) { return a->name < b->name; });
+    return v;
+  }
+  bool is_l2_attached_to_backbone(int mt) const {                              // holo-isis/src/instance.rs:577-591
+    for (const Interface *i : interfaces_by_name())
+      for (const Adjacency &a : i->adjacencies) {
+        if (!a.in_topology(mt) || a.state != "up" || !a.intersects(2)) continue;
+        bool disjoint = true;
+        for (auto &x : a.area_addrs)
+          if (std::find(config.area_addrs.begin(), config.area_addrs.end(), x) != config.area_addrs.end()) disjoint = false;
+        if (disjoint) return true;
+      }
+    return false;
+  }
+};
+
+// ---- LSDB -> CSR -------------------------------------------------------------------------------------------------
+// Edges one live fragment contributes, in the reference's order (spf.rs:1026-1127); HopCount mode: cost 0 to a
+// pseudonode, 1 to a router (:1131-1146).
+inline std::vector<std::pair<LanId, uint32_t>> vertex_edges(const Lsp &lsp, std::optional<int> mt_id, bool hopcount,
+                                                            const std::string &metric_type) {
+  const bool std_on = metric_type == "standard" || metric_type == "both";
+  const bool wide_on = metric_type == "wide" || metric_type == "both";
+  std::vector<std::pair<LanId, uint32_t>> out;
+  auto cost = [&](const LanId &nbr, uint32_t m) { return !hopcount ? m : (nbr.pseudonode != 0 ? 0u : 1u); };
+  const bool none_or_std = !mt_id || *mt_id == MT_STANDARD;
+  if (none_or_std && std_on)
+    for (auto &e : lsp.is_reach) out.push_back({e.first, cost(e.first, e.second)});
+  if ((none_or_std || lsp.pseudonode != 0) && wide_on)
+    for (auto &e : lsp.ext_is_reach)
+      if (e.second < MAX_LINK_METRIC_WIDE) out.push_back({e.first, cost(e.first, e.second)});
+  if (mt_id && *mt_id != MT_STANDARD)
+    for (auto &e : lsp.mt_is_reach)
+      if (std::get<0>(e) == *mt_id && std::get<2>(e) < MAX_LINK_METRIC_WIDE) out.push_back({std::get<1>(e), cost(std::get<1>(e), std::get<2>(e))});
+  if (!mt_id)
+    for (auto &e : lsp.mt_is_reach)
+      if (std::get<2>(e) < MAX_LINK_METRIC_WIDE) out.push_back({std::get<1>(e), cost(std::get<1>(e), std::get<2>(e))});
+  return out;
+}
+
+// CSR form (include/holo_spf_hip.h) of one level's LSDB for one (mt_id, metric mode).  Vertex index = rank in VertexId
+// order over the LAN ids that own at least one live fragment; links to LAN ids without any LSP are not listed (they
+// can never pass the two-way check).
+class LevelGraph {
+ public:
+  int level;
+  std::optional<int> mt_id;
+  bool hopcount;
+  std::string metric_type;
+  std::vector<VertexId> vids;
+  std::map<VertexId, uint32_t> index;
+  std::vector<uint32_t> row_ptr, col, metric;
+  std::vector<uint8_t> vflags;
+  uint32_t max_path_metric, run_flags;
+
+  LevelGraph(const Instance &inst, int level_, std::optional<int> mt, bool hop = false)
+      : level(level_), mt_id(mt), hopcount(hop) {
+    const InstanceCfg &cfg = inst.config;
+    static const Lsdb empty;
+    auto li = inst.lsdb.find(level);
+    const Lsdb &lsdb = li == inst.lsdb.end() ? empty : li->second;
+    metric_type = cfg.metric_type.at(level);
+    std::map<LanId, std::vector<const Lsp *>> frags;
+    for (auto &kv : lsdb.all())
+      if (kv.second.live()) frags[kv.second.lan_id()].push_back(&kv.second);
+    for (auto &kv : frags) vids.push_back(vertex_id(kv.first));
+    std::sort(vids.begin(), vids.end());
+    for (uint32_t i = 0; i < vids.size(); ++i) index[vids[i]] = i;
+    row_ptr.assign(vids.size() + 1, 0);
+    vflags.assign(vids.size(), 0);
+    for (uint32_t i = 0; i < vids.size(); ++i) {
+      const LanId lan = vids[i].lan_id;
+      for (const Lsp *lsp : frags[lan])
+        for (auto &e : vertex_edges(*lsp, mt_id, hopcount, metric_type)) {
+          auto it = index.find(vertex_id(e.first));
+          if (it != index.end()) { col.push_back(it->second); metric.push_back(e.second); }
+        }
+      row_ptr[i + 1] = (uint32_t)col.size();
+      const bool is_pn = lan.pseudonode != 0;
+      uint8_t f = is_pn ? HSPF_VF_NETWORK : 0;
+      const Lsp *z = lsdb.zeroth_lsp(lan);
+      if (!z) { vflags[i] = f | HSPF_VF_NO_EXPAND; continue; }                 // spf.rs:557-561
+      if (!is_pn && mt_id && z->overload_bit(*mt_id)) f |= HSPF_VF_NO_TRANSIT; // spf.rs:568-574
+      if (mt_id && *mt_id == MT_STANDARD && !is_pn) {                          // spf.rs:582-604
+        auto has = [&](int p) { return z->protocols_supported && std::find(z->protocols_supported->begin(), z->protocols_supported->end(), p) != z->protocols_supported->end(); };
+        if (!z->protocols_supported || (cfg.ipv4_enabled && !has(NLPID_IPV4)) || (cfg.ipv6_enabled && !has(NLPID_IPV6)))
+          f |= HSPF_VF_NO_EXPAND;
+      }
+      vflags[i] = f;
+    }
+    max_path_metric = metric_type == "standard" ? MAX_PATH_METRIC_STANDARD : MAX_PATH_METRIC_WIDE;   // spf.rs:637-641
+    run_flags = mt_id ? 0u : (uint32_t)HSPF_RUN_IGNORE_OVERLOAD;                                     // spf.rs:566-574
+  }
+  uint32_t n() const { return (uint32_t)vids.size(); }
+  Graph &device(Engine &e) {
+    if (!dev_ || dev_engine_ != &e) { dev_ = e.upload(row_ptr, col, metric, vflags, max_path_metric); dev_engine_ = &e; }
+    return *dev_;
+  }
+  bool links_back(uint32_t t, uint32_t v) const {
+    for (uint32_t k = row_ptr[t]; k < row_ptr[t + 1]; ++k)
+      if (col[k] == v) return true;
+    return false;
+  }
+ private:
+  std::unique_ptr<Graph> dev_;
+  Engine *dev_engine_ = nullptr;
+};
+
+// ---- SPT ---------------------------------------------------------------------------------------------------------
+struct VertexNexthop {                 // holo-isis/src/spf.rs:107-114
+  SystemId system_id{};
+  std::optional<std::string> iface_name, ipv4, ipv6;
+};
+struct Vertex {                        // holo-isis/src/spf.rs:78-88
+  VertexId id;
+  uint32_t distance = 0;
+  uint16_t hops = 0;
+  std::vector<std::shared_ptr<VertexNexthop>> nexthops;
+};
+using RankKey = std::array<uint64_t, 4>;
+
+class Spt {                            // holo-isis/src/spf.rs:67-73, 224-297
+ public:
+  std::map<VertexId, Vertex> vertices;
+  std::vector<VertexId> pop_order;
+  const Vertex *get(const VertexId &v) const { auto it = vertices.find(v); return it == vertices.end() ? nullptr : &it->second; }
+  std::vector<const Vertex *> hops_eq(uint16_t h) const {
+    std::vector<const Vertex *> out;
+    for (auto &v : pop_order) { const Vertex &x = vertices.at(v); if (v.non_pseudonode && x.hops == h) out.push_back(&x); }
+    return out;
+  }
+  std::vector<const Vertex *> first_hops() const { return hops_eq(1); }
+  std::vector<const Vertex *> second_hops() const { return hops_eq(2); }
+  // `Vertex.parents` (spf.rs:85, 677), rebuilt on first use from the tight links of the graph
+  const std::vector<VertexId> &parents(const VertexId &vid) {
+    static const std::vector<VertexId> none;
+    if (!parents_built_) { parents_built_ = true; if (rebuild_) rebuild_(parents_); }
+    auto it = parents_.find(vid);
+    return it == parents_.end() ? none : it->second;
+  }
+  bool is_on_path(const SystemId &ancestor, const SystemId &descendant) {     // spf.rs:261-286
+    const VertexId a = vertex_id(LanId{ancestor, 0}), d = vertex_id(LanId{descendant, 0});
+    if (!vertices.count(a) || !vertices.count(d)) return false;
+    std::vector<VertexId> stack{d};
+    std::set<VertexId> seen;
+    while (!stack.empty()) {
+      VertexId cur = stack.back(); stack.pop_back();
+      if (cur == a) return true;
+      if (!seen.insert(cur).second) continue;
+      for (auto &p : parents(cur)) stack.push_back(p);
+    }
+    return false;
+  }
+  std::function<void(std::map<VertexId, std::vector<VertexId>> &)> rebuild_;
+ private:
+  bool parents_built_ = false;
+  std::map<VertexId, std::vector<VertexId>> parents_;
+};
+
+// holo-isis/src/spf.rs:956-1010 (ifaces already in name order)
+inline void resolve_nexthop(VertexNexthop &nh, int level, int mt_id, bool parent_is_pseudonode, const SystemId &target,
+                            uint32_t link_cost, std::set<std::string> &used_adjs, const std::vector<const Interface *> &ifaces) {
+  const std::string want = parent_is_pseudonode ? "broadcast" : "point-to-point";
+  for (const Interface *iface : ifaces) {
+    if (iface->interface_type != want) continue;
+    const Adjacency *adj = nullptr;
+    if (parent_is_pseudonode) {
+      for (auto &a : iface->adjacencies)
+        if (a.level_usage == "level-" + std::to_string(level) && a.system_id == target) { adj = &a; break; }
+      if (adj && (!adj->in_topology(mt_id) || adj->state != "up")) adj = nullptr;
+    } else {
+      auto mi = iface->metric.find(level);
+      if (mi == iface->metric.end() || mi->second != link_cost) continue;
+      const Adjacency *a = iface->adjacencies.empty() ? nullptr : &iface->adjacencies[0];
+      if (a && a->in_topology(mt_id) && a->intersects(level) && a->system_id == target && a->state == "up") adj = a;
+    }
+    if (!adj || used_adjs.count(adj->snpa)) continue;
+    used_adjs.insert(adj->snpa);
+    nh.iface_name = iface->name;
+    nh.ipv4 = adj->ipv4_addrs.empty() ? std::optional<std::string>() : adj->ipv4_addrs[0];
+    nh.ipv6 = adj->ipv6_addrs.empty() ? std::optional<std::string>() : adj->ipv6_addrs[0];
+    return;
+  }
+}
+
+namespace detail {
+inline uint32_t sat_add(uint32_t a, uint32_t b) { const uint64_t s = (uint64_t)a + b; return s > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)s; }
+struct RunView {                       // one root's rows of a Tables
+  const uint32_t *dist; const uint16_t *hops; const uint16_t *flags; const uint64_t *mask; uint32_t words;
+  bool in_spt(uint32_t v) const { return flags[v] & HSPF_RF_IN_SPT; }
+};
+
+// Replays the relaxations made from hops == 0 vertices, in the reference's order, to give every first-hop slot its
+// VertexNexthop (spf.rs:680-701).  resolve_nexthop is order dependent through `used_adjs`, and the reference calls it
+// for EVERY relaxation that is not Ordering::Greater at that moment — also for candidates a later, shorter path
+// replaces — so the replay evaluates the candidate-list state at each of those moments from the final distances.
+inline std::map<uint32_t, std::shared_ptr<VertexNexthop>>
+slot_nexthops(const LevelGraph &g, const SlotTable &st, const RunView &r, const std::function<RankKey(uint32_t)> &rank,
+              bool local, int level, const Instance &inst) {
+  std::vector<std::pair<uint32_t, uint32_t>> parents;
+  for (size_t i = 0; i < st.vertex.size(); ++i)
+    if (r.in_spt(st.vertex[i]) && r.hops[st.vertex[i]] == 0) parents.push_back({st.vertex[i], st.base[i]});
+  std::stable_sort(parents.begin(), parents.end(), [&](auto &a, auto &b) { return rank(a.first) < rank(b.first); });
+  const auto ifaces = inst.interfaces_by_name();
+  std::set<std::string> used_adjs;
+  std::map<uint32_t, std::shared_ptr<VertexNexthop>> out;
+  const uint32_t max_path = g.max_path_metric;
+  const bool ignore_ovl = !g.mt_id;
+  auto expandable = [&](uint32_t u) {
+    const uint8_t f = g.vflags[u];
+    if (f & HSPF_VF_NO_EXPAND) return false;
+    if (r.hops[u] != 0 && !(f & HSPF_VF_NETWORK) && !ignore_ovl && (f & HSPF_VF_NO_TRANSIT)) return false;
+    return true;
+  };
+  // distance of t on the candidate list just before link `upto_k` of p is processed
+  auto cand_before = [&](uint32_t t, uint32_t p, uint32_t upto_k) -> std::optional<uint32_t> {
+    std::optional<uint32_t> best;
+    const RankKey pk = rank(p);
+    std::set<uint32_t> srcs(g.col.begin() + g.row_ptr[t], g.col.begin() + g.row_ptr[t + 1]);   // two-way => u lists t
+    for (uint32_t u : srcs) {
+      if (!r.in_spt(u) || !expandable(u)) continue;
+      if (rank(u) > pk) continue;
+      for (uint32_t k = g.row_ptr[u]; k < g.row_ptr[u + 1]; ++k) {
+        if (g.col[k] != t) continue;
+        if (u == p && k >= upto_k) break;
+        const uint32_t d = sat_add(r.dist[u], g.metric[k]);
+        if (d <= max_path && (!best || d < *best)) best = d;
+      }
+    }
+    return best;
+  };
+  for (auto &pb : parents) {
+    const uint32_t p = pb.first, base = pb.second;
+    if (!expandable(p)) continue;
+    for (uint32_t k = g.row_ptr[p]; k < g.row_ptr[p + 1]; ++k) {
+      const uint32_t t = g.col[k];
+      if (!g.links_back(t, p)) continue;
+      if (r.in_spt(t) && rank(t) < rank(p)) continue;                 // already on the SPT
+      const uint32_t d = sat_add(r.dist[p], g.metric[k]);
+      if (d > max_path) continue;
+      const auto cur = cand_before(t, p, k);
+      if (cur && d > *cur) continue;                                   // Ordering::Greater
+      if (g.vflags[t] & HSPF_VF_NETWORK) continue;                     // pseudonode target: no next hop
+      auto nh = std::make_shared<VertexNexthop>();
+      nh->system_id = g.vids[t].lan_id.system_id;
+      if (local && g.mt_id)
+        resolve_nexthop(*nh, level, *g.mt_id, g.vflags[p] & HSPF_VF_NETWORK, nh->system_id, g.metric[k], used_adjs, ifaces);
+      out[base + (k - g.row_ptr[p])] = nh;
+    }
+  }
+  return out;
+}
+}  // namespace detail
+
+// All SPTs of one level/topology for a list of roots with ONE engine run — the shape of flooding::manet::init_cache
+// (holo-isis/src/flooding/manet.rs:47-69).
+inline std::vector<Spt> compute_spts(int level, const std::vector<SystemId> &root_system_ids, bool local,
+                                     std::optional<int> mt_id, bool hopcount, const Instance &inst, Engine &engine,
+                                     LevelGraph *graph = nullptr) {
+  // the SPTs keep the graph alive for their lazily rebuilt parent lists; a graph passed in must outlive them
+  std::shared_ptr<LevelGraph> keep = graph ? std::shared_ptr<LevelGraph>(graph, [](LevelGraph *) {})
+                                           : std::make_shared<LevelGraph>(inst, level, mt_id, hopcount);
+  const LevelGraph &G = *keep;
+  std::vector<Spt> spts(root_system_ids.size());
+  std::vector<uint32_t> roots, where;
+  for (size_t i = 0; i < root_system_ids.size(); ++i) {
+    const VertexId rv = vertex_id(LanId{root_system_ids[i], 0});
+    auto it = G.index.find(rv);
+    if (it == G.index.end()) {           // root without any LSP: inserted into the SPT and not expanded (spf.rs:552-561)
+      spts[i].vertices[rv] = Vertex{rv, 0, 0, {}};
+      spts[i].pop_order = {rv};
+    } else { roots.push_back(it->second); where.push_back((uint32_t)i); }
+  }
+  if (roots.empty()) return spts;
+  Graph &dev = keep->device(engine);
+  auto res = std::make_shared<Tables>(engine.run(dev, roots, G.run_flags));
+  const uint32_t n = G.n(), W = res->mask_words;
+  // roots the engine ran through its sequential kernel (zero-cost plateaus: the pop order is not the static
+  // (distance, id) order) are re-run once more for their exact pop ranks
+  std::vector<uint32_t> exact_j;
+  for (uint32_t j = 0; j < roots.size(); ++j)
+    for (uint32_t v = 0; v < n; ++v)
+      if (res->flags[(size_t)j * n + v] & HSPF_RF_EXACT) { exact_j.push_back(j); break; }
+  std::shared_ptr<Tables> rr;
+  std::map<uint32_t, uint32_t> exact_row;
+  if (!exact_j.empty()) {
+    std::vector<uint32_t> er;
+    for (uint32_t j : exact_j) { exact_row[j] = (uint32_t)er.size(); er.push_back(roots[j]); }
+    rr = std::make_shared<Tables>(engine.run(dev, er, G.run_flags | HSPF_RUN_POP_RANK));
+  }
+  for (uint32_t j = 0; j < roots.size(); ++j) {
+    detail::RunView r{&res->dist[(size_t)j * n], &res->hops[(size_t)j * n], &res->flags[(size_t)j * n], &res->mask[(size_t)j * n * W], W};
+    std::function<RankKey(uint32_t)> rank;
+    if (exact_row.count(j)) {
+      const uint32_t *pr = &rr->pop_rank[(size_t)exact_row[j] * n];
+      auto hold = rr;
+      rank = [pr, hold](uint32_t v) { return RankKey{pr[v], 0, 0, 0}; };
+    } else if (G.hopcount) {
+      // Hop-count graphs (spf.rs:1138-1145): links into pseudonodes cost 0, so a pseudonode is put on the candidate
+      // list by the lowest-numbered router of its own distance that lists it and, sorting before every router, is
+      // popped right after that router.
+      auto cache = std::make_shared<std::map<uint32_t, RankKey>>();
+      rank = [keep, res, r, cache](uint32_t v) {
+        auto it = cache->find(v);
+        if (it != cache->end()) return it->second;
+        const LevelGraph &g = *keep;
+        RankKey k{r.dist[v], v, 0, 0};
+        if (g.vflags[v] & HSPF_VF_NETWORK) {
+          std::optional<uint32_t> act;
+          for (uint32_t e = g.row_ptr[v]; e < g.row_ptr[v + 1]; ++e) {
+            const uint32_t u = g.col[e];
+            if (r.in_spt(u) && r.dist[u] == r.dist[v] && !(g.vflags[u] & HSPF_VF_NO_EXPAND) && g.links_back(u, v))
+              if (!act || u < *act) act = u;
+          }
+          if (act) k = RankKey{r.dist[v], *act, 1, v};
+        }
+        (*cache)[v] = k;
+        return k;
+      };
+    } else {
+      auto hold = res;
+      rank = [r, hold](uint32_t v) { return RankKey{r.dist[v], v, 0, 0}; };   // static order
+    }
+    const SlotTable st = engine.slot_table(dev, roots[j]);
+    auto slot_nh = detail::slot_nexthops(G, st, r, rank, local, level, inst);
+    Spt &s = spts[where[j]];
+    std::vector<uint32_t> members;
+    for (uint32_t v = 0; v < n; ++v)
+      if (r.in_spt(v)) members.push_back(v);
+    for (uint32_t v : members) {
+      Vertex vx{G.vids[v], r.dist[v], r.hops[v], {}};
+      for (uint32_t w = 0; w < W; ++w) {
+        uint64_t m = r.mask[(size_t)v * W + w];
+        while (m) {
+          const int b = __builtin_ctzll(m);
+          m &= m - 1;
+          auto it = slot_nh.find(w * 64 + b);
+          if (it != slot_nh.end()) vx.nexthops.push_back(it->second);
+        }
+      }
+      s.vertices[vx.id] = std::move(vx);
+    }
+    std::stable_sort(members.begin(), members.end(), [&](uint32_t a, uint32_t b) { return rank(a) < rank(b); });
+    for (uint32_t v : members) s.pop_order.push_back(G.vids[v]);
+    s.rebuild_ = [keep, res, r, rank, members](std::map<VertexId, std::vector<VertexId>> &out) {
+      const LevelGraph &g = *keep;
+      const bool ignore_ovl = !g.mt_id;
+      for (uint32_t u : members) {
+        const uint8_t f = g.vflags[u];
+        if (f & HSPF_VF_NO_EXPAND) continue;
+        if (r.hops[u] != 0 && !(f & HSPF_VF_NETWORK) && !ignore_ovl && (f & HSPF_VF_NO_TRANSIT)) continue;
+        for (uint32_t k = g.row_ptr[u]; k < g.row_ptr[u + 1]; ++k) {
+          const uint32_t t = g.col[k];
+          if (!r.in_spt(t) || !(rank(u) < rank(t)) || !g.links_back(t, u)) continue;
+          if (detail::sat_add(r.dist[u], g.metric[k]) == r.dist[t]) out[g.vids[t]].push_back(g.vids[u]);
+        }
+      }
+    };
+  }
+  return spts;
+}
+
+// holo-isis/src/spf.rs:527-709
+inline Spt compute_spt(int level, const SystemId &root, bool local, std::optional<int> mt_id, bool hopcount,
+                       const Instance &inst, Engine &engine, LevelGraph *graph = nullptr) {
+  return std::move(compute_spts(level, {root}, local, mt_id, hopcount, inst, engine, graph)[0]);
+}
+
+// ---- routes --------------------------------------------------------------------------------------------------------
+struct Nexthop { std::string addr, iface_name; SystemId system_id{}; };
+struct Route {                         // holo-isis/src/route.rs:27-37
+  std::string prefix;
+  uint32_t metric = 0;
+  int level = 0;
+  bool external = false, connected = false;
+  std::map<IpKey, Nexthop> nexthops;   // BTreeMap<IpAddr, Nexthop>: ECMP order = ascending address
+};
+struct Network { std::string prefix; uint32_t metric; bool external; };
+
+// holo-isis/src/spf.rs:1149-1296
+inline std::vector<Network> vertex_networks(const Instance &inst, int level, int mt_id, const LanId &lan, bool att_bit,
+                                            bool l2_attached, bool ipv4_enabled, bool ipv6_enabled) {
+  const InstanceCfg &cfg = inst.config;
+  const std::string &mt = cfg.metric_type.at(level);
+  const bool std_on = mt == "standard" || mt == "both", wide_on = mt == "wide" || mt == "both";
+  std::vector<Network> out;
+  auto li = inst.lsdb.find(level);
+  if (li == inst.lsdb.end()) return out;
+  for (const Lsp *lsp : li->second.iter_for_lan_id(lan)) {
+    if (!lsp->live()) continue;
+    if (att_bit && level == 1 && (cfg.level_type == "level-1" || !l2_attached)) {
+      if (ipv4_enabled) out.push_back({"0.0.0.0/0", 0, false});
+      if (ipv6_enabled) out.push_back({"::/0", 0, false});
+    }
+    if (mt_id == MT_STANDARD && ipv4_enabled) {
+      if (std_on) {
+        for (auto &p : lsp->ipv4_internal) out.push_back({p.first, p.second, false});
+        for (auto &p : lsp->ipv4_external) out.push_back({p.first, p.second, true});
+      }
+      if (wide_on)
+        for (auto &p : lsp->ext_ipv4)
+          if (std::get<1>(p) <= MAX_PATH_METRIC_WIDE) out.push_back({std::get<0>(p), std::get<1>(p), std::get<2>(p)});
+    }
+    if (ipv6_enabled) {
+      if (mt_id == MT_IPV6_UNICAST) {
+        for (auto &p : lsp->mt_ipv6)
+          if (std::get<0>(p) == MT_IPV6_UNICAST && std::get<2>(p) <= MAX_PATH_METRIC_WIDE) out.push_back({std::get<1>(p), std::get<2>(p), std::get<3>(p)});
+      } else {
+        for (auto &p : lsp->ipv6)
+          if (std::get<1>(p) <= MAX_PATH_METRIC_WIDE) out.push_back({std::get<0>(p), std::get<1>(p), std::get<2>(p)});
+      }
+    }
+  }
+  return out;
+}
+
+inline std::map<IpKey, Nexthop> build_nexthops(const Vertex &v, const std::string &prefix) {     // route.rs:118-142
+  const bool v6 = prefix.find(':') != std::string::npos;
+  std::map<IpKey, Nexthop> out;
+  for (auto &nh : v.nexthops) {
+    const auto &addr = v6 ? nh->ipv6 : nh->ipv4;
+    if (addr) out[parse_ip(*addr)] = Nexthop{*addr, nh->iface_name.value_or(""), nh->system_id};
+  }
+  return out;
+}
+
+// holo-isis/src/spf.rs:840-949
+inline void compute_routes(int level, int mt_id, const Instance &inst, const Spt &spt, std::map<IpKey, Route> &rib) {
+  const InstanceCfg &cfg = inst.config;
+  const bool l2_attached = inst.is_l2_attached_to_backbone(mt_id);
+  const bool ipv4_enabled = cfg.ipv4_enabled && mt_id == MT_STANDARD;
+  const bool ipv6_enabled = cfg.ipv6_enabled && (mt_id == MT_STANDARD ? !cfg.is_topology_enabled(MT_IPV6_UNICAST) : true);
+  auto li = inst.lsdb.find(level);
+  if (li == inst.lsdb.end()) return;
+  for (auto &kv : spt.vertices) {                                       // Spt::iter: VertexId order
+    const Vertex &vertex = kv.second;
+    const Lsp *z = li->second.zeroth_lsp(vertex.id.lan_id);
+    if (!z) continue;
+    const bool att = !cfg.att_ignore && z->att_bit(mt_id) && !z->overload_bit(mt_id);
+    for (auto &net : vertex_networks(inst, level, mt_id, vertex.id.lan_id, att, l2_attached, ipv4_enabled, ipv6_enabled)) {
+      const IpKey key = parse_ip(net.prefix);
+      const uint32_t route_metric = vertex.distance + net.metric;      // route.rs:97, plain `+`
+      auto it = rib.find(key);
+      Route *cur;
+      if (it == rib.end() || route_metric < it->second.metric) {
+        rib[key] = Route{net.prefix, route_metric, level, net.external, vertex.hops == 0, build_nexthops(vertex, net.prefix)};
+        cur = &rib[key];
+      } else if (route_metric == it->second.metric) {
+        cur = &it->second;
+        for (auto &n : build_nexthops(vertex, net.prefix)) cur->nexthops[n.first] = n.second;
+      } else continue;
+      while (cur->nexthops.size() > cfg.max_paths) cur->nexthops.erase(std::prev(cur->nexthops.end()));   // first k by key
+    }
+  }
+}
+
+struct RibRow { std::string prefix; uint32_t metric; int level; std::vector<std::pair<std::string, std::string>> nexthops; };
+
+// Full SPF of every configured level and topology (holo-isis/src/spf.rs:719-836) followed by the L1/L2 merge of
+// holo-isis/src/route.rs:185-249; rows like the YANG `local-rib`.
+inline std::vector<RibRow> compute_spf(const Instance &inst, Engine &engine) {
+  const InstanceCfg &cfg = inst.config;
+  std::map<int, std::map<IpKey, Route>> per_level;
+  for (int level : cfg.levels()) {
+    std::map<IpKey, Route> rib;
+    for (int mt_id : {MT_STANDARD, MT_IPV6_UNICAST}) {
+      if (!cfg.is_topology_enabled(mt_id)) continue;
+      Spt spt = compute_spt(level, cfg.system_id, true, mt_id, false, inst, engine);
+      compute_routes(level, mt_id, inst, spt, rib);
+    }
+    per_level[level] = std::move(rib);
+  }
+  std::map<IpKey, Route> merged;
+  for (int level : {2, 1})
+    for (auto &kv : per_level[level]) merged[kv.first] = kv.second;
+  std::vector<RibRow> rows;
+  for (auto &kv : merged) {
+    RibRow r{kv.second.prefix, kv.second.metric, kv.second.level, {}};
+    for (auto &n : kv.second.nexthops) r.nexthops.push_back({n.second.addr, n.second.iface_name});
+    rows.push_back(std::move(r));
+  }
+  return rows;
+}
+
+}  // namespace isis
+}  // namespace host
+}  // namespace hspf

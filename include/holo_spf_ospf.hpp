@@ -1,0 +1,316 @@
+// holo_spf_ospf.hpp — C++17 host side of the OSPFv2 SPF path on top of the C ABI (include/holo_spf_hip.h).
+//
+// The compiled-code twin of what a maintainer's Rust patch does around the engine, function for
+// function, with the reference's names, argument meaning and failure behaviour:
+//
+//   AreaGraph (vertex_lsa_find / vertex_lsa_links)   holo-ospf/src/ospfv2/spf.rs:355-460   Router-/Network-LSAs -> hspf_csr
+//   calc_nexthops()                                   holo-ospf/src/ospfv2/spf.rs:172-353   unchanged, per first-hop slot
+//   run_area()                                        holo-ospf/src/spf.rs:587-729          SPT loop on the device
+//   intra_area_networks() / update_rib_intra_area()   ospfv2/spf.rs:462-538, route.rs:343-448, 918-965
+//   compute_spf_intra_area()                          holo-ospf/src/spf.rs:489-584 (SPT + intra-area part), route.rs:146-160
+//
+// Engine: hspf::host::Engine (holo_spf_host.hpp).  No CPU SPT loop here.  Python twin: holo_amd/ospf.py.
+// Tests: tests/cpp/host_parity.cpp (recorded intra-area RIBs of the reference's conformance fixtures).
+#pragma once
+#include <functional>
+#include <map>
+#include <optional>
+#include <set>
+#include <utility>
+
+#include "holo_spf_host.hpp"
+
+namespace hspf {
+namespace host {
+namespace ospf {
+
+constexpr uint32_t MAX_PATH_METRIC_OSPF = 0xFFFFFFFFu;      // u32 saturating add, holo-ospf/src/spf.rs:672
+enum Kind { NET = 0, RTR = 1 };                             // enum VertexId { Network, Router } derive(Ord), ospfv2/spf.rs:41-45
+using VertexId = std::pair<int, uint32_t>;                  // (kind, IPv4 address as integer)
+
+inline uint32_t ip4(const std::string &s) {
+  const IpKey k = parse_ip(s);
+  return ((uint32_t)k.addr[12] << 24) | ((uint32_t)k.addr[13] << 16) | ((uint32_t)k.addr[14] << 8) | k.addr[15];
+}
+inline std::string ip4_str(uint32_t a) {
+  return std::to_string(a >> 24) + "." + std::to_string((a >> 16) & 255) + "." + std::to_string((a >> 8) & 255) + "." + std::to_string(a & 255);
+}
+inline int mask_len(uint32_t mask, bool &valid) {           // contiguous netmask -> prefix length
+  int len = 0;
+  while (len < 32 && (mask & (0x80000000u >> len))) ++len;
+  valid = len == 32 || (mask & (0xFFFFFFFFu >> len)) == 0;
+  return len;
+}
+
+struct RouterLink { std::string link_type, link_id, link_data; uint32_t metric = 0; };   // LsaRouterLink
+struct RouterLsa { std::string adv_rtr; std::vector<RouterLink> links; bool maxage = false; };
+struct NetworkLsa { std::string lsa_id, adv_rtr, mask; std::vector<std::string> attached; bool maxage = false; };
+struct Neighbor { std::string router_id, src; };
+struct Interface {
+  std::string name, if_type = "broadcast";   // point-to-point | broadcast | point-to-multipoint | virtual-link
+  int64_t index = 0;                         // arena slot: first component of NexthopKey (route.rs:92-98)
+  std::vector<Neighbor> neighbors;
+  std::vector<std::string> addrs;
+};
+struct Area {
+  std::string area_id;
+  std::vector<RouterLsa> routers;
+  std::vector<NetworkLsa> networks;
+  std::vector<Interface> interfaces;
+};
+
+using NexthopKey = std::pair<int64_t, int64_t>;               // (iface arena index, address or -1 for None): None < Some
+struct NexthopVal { std::string iface_name; std::optional<std::string> addr; };
+using Nexthops = std::map<NexthopKey, NexthopVal>;
+struct Vertex {                                               // holo-ospf/src/spf.rs:38-46
+  VertexId id;
+  const RouterLsa *rlsa = nullptr;
+  const NetworkLsa *nlsa = nullptr;
+  uint32_t distance = 0;
+  uint16_t hops = 0;
+  Nexthops nexthops;
+};
+
+// CSR of one area's Router-/Network-LSAs.  Vertex index = rank in VertexId order (all networks, then all routers,
+// numeric).  link_pos / link_ref keep, per CSR entry, what Ospfv2::calc_nexthops needs from `SpfLink.parent` (the
+// position among the non-stub links BEFORE the existence filter, ospfv2/spf.rs:439-456, and the link itself).
+class AreaGraph {
+ public:
+  const Area &area;
+  std::map<uint32_t, const RouterLsa *> routers;
+  std::map<uint32_t, const NetworkLsa *> networks;
+  std::vector<VertexId> vids;
+  std::map<VertexId, uint32_t> index;
+  std::vector<uint32_t> row_ptr, col, metric;
+  std::vector<int> link_pos;
+  std::vector<const RouterLink *> link_ref;
+  std::vector<uint8_t> vflags;
+
+  explicit AreaGraph(const Area &a) : area(a) {
+    for (auto &l : a.routers) if (!l.maxage) routers[ip4(l.adv_rtr)] = &l;
+    // vertex_lsa_find for a network: FIRST Network-LSA in (adv_rtr, lsa_id) order whose LS-ID matches, then dropped
+    // if MaxAge (ospfv2/spf.rs:362-373)
+    std::vector<const NetworkLsa *> sorted;
+    for (auto &l : a.networks) sorted.push_back(&l);
+    std::stable_sort(sorted.begin(), sorted.end(), [](const NetworkLsa *x, const NetworkLsa *y) {
+      return std::make_pair(ip4(x->adv_rtr), ip4(x->lsa_id)) < std::make_pair(ip4(y->adv_rtr), ip4(y->lsa_id)); });
+    std::map<uint32_t, const NetworkLsa *> first;
+    for (auto *l : sorted) first.emplace(ip4(l->lsa_id), l);
+    for (auto &kv : first) if (!kv.second->maxage) networks[kv.first] = kv.second;
+    for (auto &kv : networks) vids.push_back({NET, kv.first});
+    for (auto &kv : routers) vids.push_back({RTR, kv.first});
+    std::sort(vids.begin(), vids.end());
+    for (uint32_t i = 0; i < vids.size(); ++i) index[vids[i]] = i;
+    row_ptr.assign(vids.size() + 1, 0);
+    for (uint32_t i = 0; i < vids.size(); ++i) {
+      const VertexId vid = vids[i];
+      if (vid.first == NET) {
+        std::vector<uint32_t> att;
+        for (auto &r : networks[vid.second]->attached) att.push_back(ip4(r));
+        std::sort(att.begin(), att.end());                        // BTreeSet<Ipv4Addr>
+        att.erase(std::unique(att.begin(), att.end()), att.end());
+        for (uint32_t r : att) {
+          auto it = index.find({RTR, r});
+          if (it != index.end()) { col.push_back(it->second); metric.push_back(0); link_pos.push_back(-1); link_ref.push_back(nullptr); }
+        }
+      } else {
+        int pos = -1;
+        for (auto &link : routers[vid.second]->links) {
+          VertexId tid;
+          if (link.link_type == "point-to-point-link" || link.link_type == "virtual-link") tid = {RTR, ip4(link.link_id)};
+          else if (link.link_type == "transit-network-link") tid = {NET, ip4(link.link_id)};
+          else continue;                                          // stub links: no position consumed
+          ++pos;
+          auto it = index.find(tid);
+          if (it != index.end()) { col.push_back(it->second); metric.push_back(link.metric); link_pos.push_back(pos); link_ref.push_back(&link); }
+        }
+      }
+      row_ptr[i + 1] = (uint32_t)col.size();
+    }
+    for (auto &v : vids) vflags.push_back(v.first == NET ? HSPF_VF_NETWORK : 0);
+  }
+  Graph &device(Engine &e) {
+    if (!dev_ || dev_engine_ != &e) { dev_ = e.upload(row_ptr, col, metric, vflags, MAX_PATH_METRIC_OSPF); dev_engine_ = &e; }
+    return *dev_;
+  }
+ private:
+  std::unique_ptr<Graph> dev_;
+  Engine *dev_engine_ = nullptr;
+};
+
+inline bool in_net(uint32_t addr, uint32_t net, int len) { return len == 0 || ((addr ^ net) >> (32 - len)) == 0; }
+
+// Ospfv2::calc_nexthops for a hops == 0 parent and CSR entry k (ospfv2/spf.rs:172-353).  nullopt =
+// Err(SpfNexthopCalcError), which the reference logs and skips (spf.rs:717-718).
+inline std::optional<Nexthops> calc_nexthops(const AreaGraph &g, const Vertex &parent, uint32_t k, const VertexId &dest,
+                                             const RouterLsa *dest_rlsa) {
+  Nexthops out;
+  if (parent.id.first == RTR) {
+    const int pos = g.link_pos[k];
+    std::vector<const Interface *> cands;
+    for (auto &i : g.area.interfaces) if (!i.neighbors.empty()) cands.push_back(&i);
+    std::stable_sort(cands.begin(), cands.end(), [](const Interface *a, const Interface *b) { return a->name < b->name; });
+    if (pos < 0 || (size_t)pos >= cands.size()) return std::nullopt;
+    const Interface *iface = cands[pos];
+    if (iface->if_type == "virtual-link") return out;
+    if (dest.first == RTR) {
+      if (iface->if_type == "point-to-point" || iface->if_type == "virtual-link") {
+        const Neighbor *nbr = nullptr;
+        for (auto &n : iface->neighbors) if (ip4(n.router_id) == dest.second) { nbr = &n; break; }
+        if (!nbr) return std::nullopt;
+        out[{iface->index, (int64_t)ip4(nbr->src)}] = NexthopVal{iface->name, nbr->src};
+      } else if (iface->if_type == "point-to-multipoint" && dest_rlsa) {
+        for (auto &link : dest_rlsa->links)
+          for (auto &a : iface->addrs) {
+            const IpKey net = parse_ip(a);
+            const uint32_t base = ((uint32_t)net.addr[12] << 24) | ((uint32_t)net.addr[13] << 16) | ((uint32_t)net.addr[14] << 8) | net.addr[15];
+            if (in_net(ip4(link.link_data), base, net.len)) { out[{iface->index, (int64_t)ip4(link.link_data)}] = NexthopVal{iface->name, link.link_data}; break; }
+          }
+      }
+      if (out.empty()) return std::nullopt;
+    } else {
+      out[{iface->index, -1}] = NexthopVal{iface->name, std::nullopt};          // None < Some(addr)
+    }
+    return out;
+  }
+  // parent is a network directly connecting the root to the destination router
+  bool valid = true;
+  const int len = mask_len(ip4(parent.nlsa->mask), valid);
+  if (!valid || !dest_rlsa) return std::nullopt;
+  const uint32_t net = len == 0 ? 0 : (ip4(parent.nlsa->lsa_id) & (0xFFFFFFFFu << (32 - len)));
+  const RouterLink *link = nullptr;
+  for (auto &l : dest_rlsa->links) if (in_net(ip4(l.link_data), net, len)) { link = &l; break; }
+  if (!link || parent.nexthops.empty()) return std::nullopt;
+  const auto first = parent.nexthops.begin();
+  out[{first->first.first, (int64_t)ip4(link->link_data)}] = NexthopVal{first->second.iface_name, link->link_data};
+  return out;
+}
+
+using SptMap = std::map<VertexId, Vertex>;
+
+// holo-ospf/src/spf.rs:587-729 -> the area's SPT, or nullopt when the root's Router-LSA is missing
+// (Error::SpfRootNotFound is logged and the run returns, :605-610).  One engine run (HSPF_RUN_NET_NEXTHOPS), then every
+// first-hop slot is expanded ONCE through calc_nexthops and the per-slot sets are OR-ed through the per-vertex masks
+// (= the inheritance of spf.rs:761-766).
+inline std::optional<SptMap> run_area(const std::string &router_id, AreaGraph &g, Engine &engine) {
+  auto ri = g.index.find({RTR, ip4(router_id)});
+  if (ri == g.index.end()) return std::nullopt;
+  const uint32_t root = ri->second, n = (uint32_t)g.vids.size();
+  Graph &dev = g.device(engine);
+  const Tables res = engine.run(dev, {root}, HSPF_RUN_NET_NEXTHOPS);
+  const SlotTable st = engine.slot_table(dev, root);
+  const uint32_t W = res.mask_words;
+  SptMap spt;
+  std::map<uint32_t, std::optional<Nexthops>> slot_cache;
+  std::function<Vertex &(uint32_t)> vertex;
+  auto resolve_slot = [&](uint32_t s) -> const std::optional<Nexthops> & {
+    auto it = slot_cache.find(s);
+    if (it != slot_cache.end()) return it->second;
+    size_t i = std::upper_bound(st.base.begin(), st.base.end(), s) - st.base.begin() - 1;
+    const uint32_t p = st.vertex[i], k = g.row_ptr[p] + (s - st.base[i]);
+    const uint32_t t = g.col[k];
+    const VertexId tv = g.vids[t];
+    const RouterLsa *dl = tv.first == RTR ? g.routers.at(tv.second) : nullptr;
+    auto r = calc_nexthops(g, vertex(p), k, tv, dl);
+    return slot_cache[s] = std::move(r);
+  };
+  vertex = [&](uint32_t v) -> Vertex & {
+    const VertexId vid = g.vids[v];
+    auto it = spt.find(vid);
+    if (it != spt.end()) return it->second;
+    Vertex vx;
+    vx.id = vid;
+    if (vid.first == RTR) vx.rlsa = g.routers.at(vid.second); else vx.nlsa = g.networks.at(vid.second);
+    vx.distance = res.dist[v]; vx.hops = res.hops[v];
+    Vertex &ref = spt[vid] = std::move(vx);
+    for (uint32_t w = 0; w < W; ++w) {
+      uint64_t m = res.mask[(size_t)v * W + w];
+      while (m) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        const auto &nh = resolve_slot(w * 64 + b);
+        if (nh) for (auto &kv : *nh) ref.nexthops[kv.first] = kv.second;
+      }
+    }
+    return ref;
+  };
+  // distance order guarantees parents (hops == 0 networks) are materialised before children
+  std::vector<uint32_t> members;
+  for (uint32_t v = 0; v < n; ++v) if (res.flags[v] & HSPF_RF_IN_SPT) members.push_back(v);
+  std::stable_sort(members.begin(), members.end(), [&](uint32_t a, uint32_t b) { return std::make_pair(res.dist[a], a) < std::make_pair(res.dist[b], b); });
+  for (uint32_t v : members) vertex(v);
+  return spt;
+}
+
+struct RouteNet { std::string prefix; uint32_t metric = 0, origin = 0; bool connected = false; Nexthops nexthops; };
+
+// update_rib_intra_area (route.rs:343-448) over intra_area_networks (ospfv2/spf.rs:462-538) with route_update
+// (route.rs:918-965); the RIB is shared by the areas.
+inline void update_rib_intra_area(std::map<IpKey, RouteNet> &rib, const SptMap &spt, uint32_t max_paths) {
+  auto offer = [&](const Vertex &v, uint32_t net, int len, uint32_t smetric, uint32_t origin) {
+    IpKey key; key.version = 4; key.len = len;
+    key.addr[12] = net >> 24; key.addr[13] = net >> 16; key.addr[14] = net >> 8; key.addr[15] = net;
+    const uint64_t sum = (uint64_t)v.distance + smetric;
+    const uint32_t metric = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum;
+    auto it = rib.find(key);
+    if (it != rib.end() && metric > it->second.metric) return;
+    if (v.id.first == NET && it != rib.end()) {                              // route.rs:388-400
+      if (metric < it->second.metric || (metric == it->second.metric && origin > it->second.origin)) { rib.erase(it); it = rib.end(); }
+      else return;
+    }
+    RouteNet *cur;
+    if (it == rib.end() || metric < it->second.metric) {
+      cur = &(rib[key] = RouteNet{ip4_str(net) + "/" + std::to_string(len), metric, origin, v.hops == 0, v.nexthops});
+    } else {                                                                 // equal: merge next hops
+      cur = &it->second;
+      for (auto &kv : v.nexthops) cur->nexthops[kv.first] = kv.second;
+    }
+    while (cur->nexthops.size() > max_paths) cur->nexthops.erase(std::prev(cur->nexthops.end()));
+  };
+  for (auto &kv : spt) {                                                     // VertexId order
+    const Vertex &v = kv.second;
+    if (v.id.first == NET) {
+      bool valid = true;
+      const int len = mask_len(ip4(v.nlsa->mask), valid);
+      if (!valid) continue;
+      const uint32_t id = ip4(v.nlsa->lsa_id);
+      offer(v, len == 0 ? 0 : (id & (0xFFFFFFFFu << (32 - len))), len, 0, id);
+    } else {
+      for (auto &link : v.rlsa->links) {
+        if (link.link_type != "stub-network-link") continue;
+        bool valid = true;
+        const int len = mask_len(ip4(link.link_data), valid);
+        if (!valid) continue;
+        const uint32_t id = ip4(link.link_id);
+        offer(v, len == 0 ? 0 : (id & (0xFFFFFFFFu << (32 - len))), len, link.metric, ip4(v.rlsa->adv_rtr));
+      }
+    }
+  }
+}
+
+struct RibRow { std::string prefix; uint32_t metric; std::vector<std::pair<std::optional<std::string>, std::string>> nexthops; };
+
+// The SPT + intra-area part of compute_spf (holo-ospf/src/spf.rs:489-584, route.rs:146-160): areas in area-id order,
+// one run_area each; rows like the YANG `local-rib` list (type intra-area).
+inline std::vector<RibRow> compute_spf_intra_area(const std::string &router_id, const std::vector<Area> &areas, uint32_t max_paths, Engine &engine) {
+  std::vector<const Area *> order;
+  for (auto &a : areas) order.push_back(&a);
+  std::stable_sort(order.begin(), order.end(), [](const Area *a, const Area *b) { return ip4(a->area_id) < ip4(b->area_id); });
+  std::map<IpKey, RouteNet> rib;
+  for (const Area *a : order) {
+    AreaGraph g(*a);
+    auto spt = run_area(router_id, g, engine);
+    if (spt) update_rib_intra_area(rib, *spt, max_paths);
+  }
+  std::vector<RibRow> rows;
+  for (auto &kv : rib) {
+    RibRow r{kv.second.prefix, kv.second.metric, {}};
+    for (auto &n : kv.second.nexthops) r.nexthops.push_back({n.second.addr, n.second.iface_name});
+    rows.push_back(std::move(r));
+  }
+  return rows;
+}
+
+}  // namespace ospf
+}  // namespace host
+}  // namespace hspf

@@ -1,0 +1,266 @@
+// tests/cpp/host_parity.cpp — the C++ host side (include/holo_spf_isis.hpp) against the RIBs the reference recorded
+// in its conformance fixtures (tests/golden/{isis,isis_steps,ospfv2,ospfv2_steps}/*.json): vector -> Instance / areas ->
+// compute_spf -> rows of `local-rib` (include/holo_spf_isis.hpp, include/holo_spf_ospf.hpp).
+//
+//   host_parity --engine hip    <files...>     the product path: libholo_spf_hip.so through the C ABI (needs an MI355X)
+//   host_parity --engine oracle <files...>     CPU stand-in for the ENGINE ONLY (oracle/liboracle_spf.so, dlopen'ed;
+//                                              TEST INFRASTRUCTURE): checks the host logic where there is no GPU
+// Exit codes: 0 every vector reproduced, 1 mismatch / error, 77 --engine hip without a HIP device.
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "holo_spf_isis.hpp"
+#include "holo_spf_ospf.hpp"
+#include "mini_json.hpp"
+
+using namespace hspf::host;
+namespace I = hspf::host::isis;
+namespace O = hspf::host::ospf;
+
+// ---- CPU stand-in for the engine (tests only) ----------------------------------------------------------------------
+typedef int (*oracle_run_t)(uint32_t, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, const uint8_t *, uint32_t,
+                            const uint32_t *, uint32_t, uint32_t, int, uint32_t *, uint16_t *, uint16_t *, uint32_t *, uint64_t *,
+                            uint32_t, uint32_t *, uint32_t *, uint64_t *);
+struct OracleGraph : Graph {
+  std::vector<uint32_t> row_ptr, col, metric;
+  std::vector<uint8_t> vflags;
+  uint32_t max_path;
+};
+class OracleEngine : public Engine {
+ public:
+  explicit OracleEngine(const std::string &so) {
+    void *h = dlopen(so.c_str(), RTLD_NOW);
+    if (!h) throw std::runtime_error("dlopen " + so + " (run `make -C oracle`)");
+    run_ = (oracle_run_t)dlsym(h, "oracle_spf_run");
+    if (!run_) throw std::runtime_error("oracle_spf_run");
+  }
+  std::unique_ptr<Graph> upload(const std::vector<uint32_t> &rp, const std::vector<uint32_t> &c, const std::vector<uint32_t> &m,
+                                const std::vector<uint8_t> &vf, uint32_t mp) override {
+    auto g = std::make_unique<OracleGraph>();
+    g->row_ptr = rp; g->col = c; g->metric = m; g->vflags = vf; g->max_path = mp;
+    return g;
+  }
+  SlotTable slot_table(Graph &gr, uint32_t root) override {          // restatement of include/holo_spf_hip.h "first-hop slots"
+    auto &g = static_cast<OracleGraph &>(gr);
+    SlotTable st;
+    st.vertex = {root}; st.base = {0};
+    st.total = g.row_ptr[root + 1] - g.row_ptr[root];
+    std::vector<char> seen(g.vflags.size(), 0);
+    seen[root] = 1;
+    for (size_t qi = 0; qi < st.vertex.size(); ++qi) {
+      const uint32_t p = st.vertex[qi];
+      for (uint32_t k = g.row_ptr[p]; k < g.row_ptr[p + 1]; ++k) {
+        const uint32_t t = g.col[k];
+        bool back = false;
+        for (uint32_t k2 = g.row_ptr[t]; k2 < g.row_ptr[t + 1]; ++k2) back |= g.col[k2] == p;
+        if (seen[t] || !(g.vflags[t] & HSPF_VF_NETWORK) || !back) continue;
+        seen[t] = 1;
+        st.vertex.push_back(t); st.base.push_back(st.total);
+        st.total += g.row_ptr[t + 1] - g.row_ptr[t];
+      }
+    }
+    return st;
+  }
+  Tables run(Graph &gr, const std::vector<uint32_t> &roots, uint32_t run_flags) override {
+    auto &g = static_cast<OracleGraph &>(gr);
+    Tables t;
+    t.n_roots = (uint32_t)roots.size(); t.n_vertices = (uint32_t)g.vflags.size();
+    uint32_t words = 1;
+    for (uint32_t r : roots) words = std::max(words, (slot_table(gr, r).total + 63) / 64);
+    t.mask_words = words;
+    const size_t rn = (size_t)t.n_roots * t.n_vertices;
+    t.dist.resize(rn); t.hops.resize(rn); t.flags.resize(rn); t.pop_rank.resize(rn); t.mask.resize(rn * words);
+    const int rc = run_(t.n_vertices, (uint32_t)g.col.size(), g.row_ptr.data(), g.col.data(), g.metric.data(), g.vflags.data(), g.max_path,
+                        roots.data(), t.n_roots, run_flags & 3u, /*MAP*/ 1, t.dist.data(), t.hops.data(), t.flags.data(), t.pop_rank.data(),
+                        t.mask.data(), words, nullptr, nullptr, nullptr);
+    if (rc != 0) throw std::runtime_error("oracle_spf_run failed");
+    // like the real engine: tell the caller which roots did not pop in the static (distance, index) order
+    const uint32_t n = t.n_vertices;
+    for (uint32_t j = 0; j < t.n_roots; ++j) {
+      std::vector<uint32_t> mem;
+      for (uint32_t v = 0; v < n; ++v) if (t.flags[(size_t)j * n + v] & 1) mem.push_back(v);
+      auto a = mem, b = mem;
+      std::stable_sort(a.begin(), a.end(), [&](uint32_t x, uint32_t y) { return std::make_pair(t.dist[(size_t)j * n + x], x) < std::make_pair(t.dist[(size_t)j * n + y], y); });
+      std::stable_sort(b.begin(), b.end(), [&](uint32_t x, uint32_t y) { return t.pop_rank[(size_t)j * n + x] < t.pop_rank[(size_t)j * n + y]; });
+      if (a != b) for (uint32_t v : mem) t.flags[(size_t)j * n + v] |= HSPF_RF_EXACT;
+    }
+    if (!(run_flags & HSPF_RUN_POP_RANK)) t.pop_rank.clear();
+    return t;
+  }
+ private:
+  oracle_run_t run_;
+};
+
+// ---- vector -> Instance (schema of tools/make_golden.py) -----------------------------------------------------------
+static I::SystemId sysid(const std::string &s) {                    // "0000.0000.0001"
+  std::string hex;
+  for (char c : s) if (c != '.') hex += c;
+  I::SystemId out{};
+  for (int i = 0; i < 6; ++i) out[i] = (uint8_t)std::stoi(hex.substr(2 * i, 2), nullptr, 16);
+  return out;
+}
+static I::LanId lanid(const std::string &s) {                        // "0000.0000.0001.02"
+  return I::LanId{sysid(s.substr(0, 14)), (uint8_t)std::stoi(s.substr(15, 2), nullptr, 16)};
+}
+static bool has_flag(const J &arr, const char *f) { for (auto &x : arr.arr) if (x.s == f) return true; return false; }
+
+static I::Instance instance_from_vector(const J &vec) {
+  I::Instance inst;
+  const J &c = vec["config"];
+  inst.config.system_id = sysid(c["system_id"].s);
+  inst.config.level_type = c["level_type"].s;
+  inst.config.metric_type = {{1, c["metric_type"]["1"].s}, {2, c["metric_type"]["2"].s}};
+  inst.config.ipv4_enabled = !c["afs"].has("ipv4") || c["afs"]["ipv4"].b;
+  inst.config.ipv6_enabled = !c["afs"].has("ipv6") || c["afs"]["ipv6"].b;
+  inst.config.mt_ipv6_unicast = c["mt_ipv6_unicast"].b;
+  inst.config.max_paths = (uint32_t)c["max_paths"].i();
+  inst.config.att_ignore = c["att_ignore"].b;
+  for (auto &a : c["area_addrs"].arr) inst.config.area_addrs.push_back(a.s);
+  for (auto &i : vec["interfaces"].arr) {
+    I::Interface f;
+    f.name = i["name"].s; f.interface_type = i["type"].s;
+    f.metric = {{1, (uint32_t)i["metric"]["1"].i()}, {2, (uint32_t)i["metric"]["2"].i()}};
+    for (auto &a : i["adjacencies"].arr) {
+      I::Adjacency d;
+      d.system_id = sysid(a["system_id"].s); d.level_usage = a["usage"].s; d.state = a["state"].s;
+      for (auto &x : a["ipv4"].arr) d.ipv4_addrs.push_back(x.s);
+      for (auto &x : a["ipv6"].arr) d.ipv6_addrs.push_back(x.s);
+      d.topologies.clear();
+      for (auto &x : a["topologies"].arr) d.topologies.push_back((int)x.i());
+      for (auto &x : a["area_addrs"].arr) d.area_addrs.push_back(x.s);
+      d.snpa = f.name + "|" + a["system_id"].s + "|" + a["usage"].s;
+      f.adjacencies.push_back(d);
+    }
+    inst.interfaces.push_back(f);
+  }
+  for (auto &lv : vec["lsdb"].obj) {
+    I::Lsdb db;
+    for (auto &l : lv.second.arr) {
+      I::Lsp p;
+      const std::string id = l["id"].s;                              // "0000.0000.0001.00-00"
+      const I::LanId lan = lanid(id.substr(0, 17));
+      p.system_id = lan.system_id; p.pseudonode = lan.pseudonode;
+      p.fragment = (uint8_t)std::stoi(id.substr(18), nullptr, 16);
+      if (l.has("seqno")) p.seqno = (uint32_t)l["seqno"].i();
+      if (l.has("lifetime")) p.rem_lifetime = (uint16_t)l["lifetime"].i();
+      p.overload = has_flag(l["flags"], "ol"); p.att = has_flag(l["flags"], "att");
+      if (!l["protocols"].is_null()) { p.protocols_supported = std::vector<int>(); for (auto &x : l["protocols"].arr) p.protocols_supported->push_back((int)x.i()); }
+      for (auto &m : l["mt"].arr) p.mt_flags[(int)m["id"].i()] = {has_flag(m["flags"], "ol"), has_flag(m["flags"], "att")};
+      for (auto &x : l["is_reach"].arr) p.is_reach.push_back({lanid(x[0].s), (uint32_t)x[1].i()});
+      for (auto &x : l["ext_is_reach"].arr) p.ext_is_reach.push_back({lanid(x[0].s), (uint32_t)x[1].i()});
+      for (auto &x : l["mt_is_reach"].arr) p.mt_is_reach.push_back({(int)x[0].i(), lanid(x[1].s), (uint32_t)x[2].i()});
+      for (auto &x : l["ipv4_int"].arr) p.ipv4_internal.push_back({x[0].s, (uint32_t)x[1].i()});
+      for (auto &x : l["ipv4_ext"].arr) p.ipv4_external.push_back({x[0].s, (uint32_t)x[1].i()});
+      for (auto &x : l["ext_ipv4"].arr) p.ext_ipv4.push_back({x[0].s, (uint32_t)x[1].i(), x[2].b});
+      for (auto &x : l["ipv6"].arr) p.ipv6.push_back({x[0].s, (uint32_t)x[1].i(), x[2].b});
+      for (auto &x : l["mt_ipv6"].arr) p.mt_ipv6.push_back({(int)x[0].i(), x[1].s, (uint32_t)x[2].i(), x[3].b});
+      db.insert(std::move(p));
+    }
+    inst.lsdb[std::stoi(lv.first)] = std::move(db);
+  }
+  return inst;
+}
+
+static std::vector<O::Area> areas_from_vector(const J &vec) {        // schema of tools/make_golden_ospf.py
+  std::vector<O::Area> out;
+  for (auto &a : vec["areas"].arr) {
+    O::Area ar;
+    ar.area_id = a["area_id"].s;
+    for (auto &r : a["routers"].arr) {
+      O::RouterLsa l;
+      l.adv_rtr = r["adv_rtr"].s; l.maxage = r.has("maxage") && r["maxage"].b;
+      for (auto &k : r["links"].arr) l.links.push_back(O::RouterLink{k["type"].s, k["id"].s, k["data"].s, (uint32_t)k["metric"].i()});
+      ar.routers.push_back(std::move(l));
+    }
+    for (auto &nw : a["networks"].arr) {
+      O::NetworkLsa l;
+      l.lsa_id = nw["lsa_id"].s; l.adv_rtr = nw["adv_rtr"].s; l.mask = nw["mask"].s; l.maxage = nw.has("maxage") && nw["maxage"].b;
+      for (auto &x : nw["attached"].arr) l.attached.push_back(x.s);
+      ar.networks.push_back(std::move(l));
+    }
+    for (auto &i : a["interfaces"].arr) {
+      O::Interface f;
+      f.name = i["name"].s; f.if_type = i["type"].s; f.index = i["index"].i();
+      for (auto &nb : i["neighbors"].arr) f.neighbors.push_back(O::Neighbor{nb["router_id"].s, nb["src"].s});
+      if (i.has("addrs")) for (auto &x : i["addrs"].arr) f.addrs.push_back(x.s);
+      ar.interfaces.push_back(std::move(f));
+    }
+    out.push_back(std::move(ar));
+  }
+  return out;
+}
+
+// OSPFv2 vector: intra-area rows of the recorded local RIB (virtual-link endpoints are completed after the path by
+// area::update_virtual_links and are left to the Python suite's literal restatement)
+static int check_ospf(const J &vec, Engine &eng, const std::string &path) {
+  if (vec["has_vlinks"].b) return -1;
+  const auto areas = areas_from_vector(vec);
+  const auto rows = O::compute_spf_intra_area(vec["router_id"].s, areas, (uint32_t)vec["max_paths"].i(), eng);
+  std::vector<const J *> want;
+  for (auto &r : vec["rib"].arr) if (r["type"].s == "intra-area") want.push_back(&r);
+  std::stable_sort(want.begin(), want.end(), [](const J *a, const J *b) { return parse_ip((*a)["prefix"].s) < parse_ip((*b)["prefix"].s); });
+  bool same = want.size() == rows.size();
+  for (size_t i = 0; same && i < rows.size(); ++i) {
+    const J &w = *want[i];
+    same = w["prefix"].s == rows[i].prefix && (uint32_t)w["metric"].i() == rows[i].metric && w["nexthops"].arr.size() == rows[i].nexthops.size();
+    for (size_t k = 0; same && k < rows[i].nexthops.size(); ++k) {
+      const J &a = w["nexthops"][k][0];
+      same = (a.is_null() ? !rows[i].nexthops[k].first : (rows[i].nexthops[k].first && a.s == *rows[i].nexthops[k].first)) &&
+             w["nexthops"][k][1].s == rows[i].nexthops[k].second;
+    }
+    if (!same) std::fprintf(stderr, "MISMATCH %s row %zu: %s metric %u (%zu next hops)\n", path.c_str(), i, rows[i].prefix.c_str(), rows[i].metric, rows[i].nexthops.size());
+  }
+  if (want.size() != rows.size()) std::fprintf(stderr, "MISMATCH %s: %zu rows, recorded %zu\n", path.c_str(), rows.size(), want.size());
+  return same ? 1 : 0;
+}
+
+int main(int argc, char **argv) {
+  std::string engine = "hip", oracle_so = "oracle/liboracle_spf.so";
+  std::vector<std::string> files;
+  for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--engine") && i + 1 < argc) engine = argv[++i];
+    else if (!strcmp(argv[i], "--oracle-so") && i + 1 < argc) oracle_so = argv[++i];
+    else files.push_back(argv[i]);
+  }
+  std::unique_ptr<Engine> eng;
+  try {
+    if (engine == "hip") {
+      if (hspf_device_count() <= 0) { std::printf("no HIP device: the product engine cannot run here\n"); return 77; }
+      eng = std::make_unique<HipEngine>(0);
+    } else eng = std::make_unique<OracleEngine>(oracle_so);
+  } catch (const std::exception &e) { std::fprintf(stderr, "engine: %s\n", e.what()); return 1; }
+  int ok = 0, bad = 0, skipped = 0;
+  for (auto &path : files) {
+    try {
+      const J vec = load_json(path);
+      if (vec["proto"].s == "ospfv2") {
+        const int r = check_ospf(vec, *eng, path);
+        if (r > 0) ++ok; else if (r == 0) ++bad; else ++skipped;
+        continue;
+      }
+      if (vec["proto"].s != "isis") continue;
+      const I::Instance inst = instance_from_vector(vec);
+      const auto rows = I::compute_spf(inst, *eng);
+      // recorded rows in BTreeMap<IpNetwork, _> order
+      std::vector<const J *> want;
+      for (auto &r : vec["rib"].arr) want.push_back(&r);
+      std::stable_sort(want.begin(), want.end(), [](const J *a, const J *b) { return parse_ip((*a)["prefix"].s) < parse_ip((*b)["prefix"].s); });
+      bool same = want.size() == rows.size();
+      for (size_t i = 0; same && i < rows.size(); ++i) {
+        const J &w = *want[i];
+        same = w["prefix"].s == rows[i].prefix && (uint32_t)w["metric"].i() == rows[i].metric && (int)w["level"].i() == rows[i].level &&
+               w["nexthops"].arr.size() == rows[i].nexthops.size();
+        for (size_t k = 0; same && k < rows[i].nexthops.size(); ++k)
+          same = w["nexthops"][k][0].s == rows[i].nexthops[k].first && w["nexthops"][k][1].s == rows[i].nexthops[k].second;
+        if (!same) std::fprintf(stderr, "MISMATCH %s row %zu: %s metric %u level %d (%zu next hops)\n", path.c_str(), i, rows[i].prefix.c_str(),
+                                rows[i].metric, rows[i].level, rows[i].nexthops.size());
+      }
+      if (same) ++ok; else { ++bad; if (want.size() != rows.size()) std::fprintf(stderr, "MISMATCH %s: %zu rows, recorded %zu\n", path.c_str(), rows.size(), want.size()); }
+    } catch (const std::exception &e) { ++bad; std::fprintf(stderr, "ERROR %s: %s\n", path.c_str(), e.what()); }
+  }
+  std::printf("host_parity (%s engine): %d vectors reproduce the recorded local RIB, %d do not, %d skipped (virtual links)\n", engine.c_str(), ok, bad, skipped);
+  return bad ? 1 : 0;
+}

@@ -36,3 +36,52 @@ def test_cpp_driver_parity_on_gpu():
     r = subprocess.run([EXE, ROOT], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bit-exact" in r.stdout
+
+
+# ---- the C++ host side (include/holo_spf_isis.hpp, include/holo_spf_ospf.hpp) ---------------------------------------
+import glob      # noqa: E402
+
+HOST = os.path.join(ROOT, "tests", "cpp", "host_parity")
+VECTORS = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "isis", "*.json")) +
+                 glob.glob(os.path.join(ROOT, "tests", "golden", "isis_steps", "*.json")) +
+                 glob.glob(os.path.join(ROOT, "tests", "golden", "ospfv2", "*.json")) +
+                 glob.glob(os.path.join(ROOT, "tests", "golden", "ospfv2_steps", "*.json")))
+
+
+def _build_host():
+    deps = [HOST + ".cpp", os.path.join(ROOT, "tests", "cpp", "mini_json.hpp")] + glob.glob(os.path.join(ROOT, "include", "*.h*"))
+    if not os.path.exists(HOST) or os.path.getmtime(HOST) < max(os.path.getmtime(d) for d in deps):
+        from holo_amd import build as hb
+        hb.build_lib()
+        subprocess.check_call([hb.hipcc_path(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"),
+                               HOST + ".cpp", "-L" + os.path.join(ROOT, "holo_amd"), "-lholo_spf_hip",
+                               "-Wl,-rpath,$ORIGIN/../../holo_amd", "-ldl", "-o", HOST])
+
+
+def test_cpp_host_side_reproduces_recorded_ribs_with_the_oracle_as_engine():
+    """CPU: the compiled host side (LSDB -> CSR, slot replay through resolve_nexthop / calc_nexthops, route build) with
+    the CPU oracle standing in for the ENGINE only; answers = the reference's recorded local RIBs (IS-IS 38 + 19 step
+    vectors, OSPFv2 57 + 11; the 6 virtual-link endpoints are skipped)."""
+    from oracle import graph_oracle
+    graph_oracle.build()
+    _build_host()
+    r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so")] + VECTORS,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "125 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
+
+
+def test_cpp_host_side_without_a_device_reports_it():
+    import torch
+    _build_host()
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    assert subprocess.run([HOST, "--engine", "hip"] + VECTORS[:1]).returncode == 77      # no CPU fallback
+
+
+@pytest.mark.gpu
+def test_cpp_host_side_reproduces_recorded_ribs_on_gpu():
+    _build_host()
+    r = subprocess.run([HOST, "--engine", "hip"] + VECTORS, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "125 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
