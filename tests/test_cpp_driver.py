@@ -85,3 +85,26 @@ def test_cpp_host_side_reproduces_recorded_ribs_on_gpu():
     r = subprocess.run([HOST, "--engine", "hip"] + VECTORS, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "125 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
+
+
+def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_path):
+    """The compiled host side on random protocol-level inputs (tests/_random_isis.py, tests/_random_ospf.py): expected
+    rows = the literal restatements' RIBs (oracle/isis_ref.py, oracle/ospf_ref.py), engine = the CPU oracle."""
+    import json
+    from oracle import graph_oracle, isis_ref, ospf_ref
+    from _random_isis import make as make_isis
+    from _random_ospf import make as make_ospf
+    graph_oracle.build()
+    _build_host()
+    files = []
+    for seed in range(3000, 3150):
+        v = make_isis(seed)
+        v["rib"] = isis_ref.local_rib(v)
+        p = tmp_path / f"isis_{seed}.json"; p.write_text(json.dumps(v)); files.append(str(p))
+        w = make_ospf(seed)
+        w["rib"] = ospf_ref.intra_area_rib(w)
+        p = tmp_path / f"ospf_{seed}.json"; p.write_text(json.dumps(w)); files.append(str(p))
+    r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so")] + files,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    assert "300 vectors reproduce" in r.stdout
