@@ -11,6 +11,7 @@
 //   vertex_networks()    holo-isis/src/spf.rs:1149-1296   prefixes of one SPT vertex
 //   compute_routes()     holo-isis/src/spf.rs:840-949     prefix attachment, ECMP merge, max-paths truncation
 //   compute_spf()        holo-isis/src/spf.rs:719-836     per level / topology + L1/L2 merge (route.rs:185-249)
+//   flooding::init_cache / reflood_list / flood_reduction_hash   holo-isis/src/flooding/manet.rs:39-194
 //
 // The engine is reached through hspf::host::Engine (three calls: upload, run, slot_table); the product implementation
 // is hspf::host::HipEngine (holo_spf_host.hpp, the C ABI).  There is no CPU SPT loop in this file.  Python twin with the same structure:
@@ -616,6 +617,84 @@ inline std::vector<RibRow> compute_spf(const Instance &inst, Engine &engine) {
   }
   return rows;
 }
+
+// ---- flooding::manet (holo-isis/src/flooding/manet.rs) ---------------------------------------------------------------
+namespace flooding {
+
+struct NeighborCache {                 // manet.rs:30-35
+  Spt spt_hopcount;
+  std::map<SystemId, std::string> remote_nbr_list;     // BTreeMap<SystemId, FloodingAlgo>
+};
+
+// init_cache (manet.rs:39-97): one hop-count SPT per Up adjacency — ONE batched engine run instead of a sequential
+// loop — and, per neighbour, its remote neighbour list (the first hops of that SPT with the flooding algorithm each
+// advertises; `flooding_algo_of(system id)` supplies the sub-TLV value, default zero-pruner as in :84).
+inline std::map<SystemId, NeighborCache> init_cache(int level, const Instance &inst, Engine &engine,
+                                                    const std::function<std::string(const SystemId &)> &flooding_algo_of = {}) {
+  std::vector<SystemId> nbrs;
+  for (const Interface *iface : inst.interfaces_by_name())
+    for (auto &adj : iface->adjacencies)
+      if (adj.state == "up" && std::find(nbrs.begin(), nbrs.end(), adj.system_id) == nbrs.end()) nbrs.push_back(adj.system_id);
+  std::map<SystemId, NeighborCache> out;
+  if (nbrs.empty()) return out;
+  std::vector<Spt> spts = compute_spts(level, nbrs, false, std::nullopt, true, inst, engine);
+  for (size_t i = 0; i < nbrs.size(); ++i) {
+    NeighborCache c;
+    c.spt_hopcount = std::move(spts[i]);
+    for (const Vertex *v : c.spt_hopcount.first_hops())
+      c.remote_nbr_list[v->id.lan_id.system_id] = flooding_algo_of ? flooding_algo_of(v->id.lan_id.system_id) : std::string("zero-pruner");
+    out[nbrs[i]] = std::move(c);
+  }
+  return out;
+}
+
+// flood_reduction_hash (manet.rs:190-194): Fletcher-16 (`fletcher` crate: two running sums mod 255, sum2 << 8 | sum1) of
+// the 8-byte LSP id with the fragment number shifted right by 3.  Vectors: manet.rs:205-232.
+inline uint16_t flood_reduction_hash(const SystemId &system_id, uint8_t pseudonode, uint8_t fragment) {
+  uint32_t s1 = 0, s2 = 0;
+  auto feed = [&](uint8_t b) { s1 = (s1 + b) % 255; s2 = (s2 + s1) % 255; };
+  for (uint8_t b : system_id) feed(b);
+  feed(pseudonode);
+  feed(fragment >> 3);
+  return (uint16_t)((s2 << 8) | s1);
+}
+
+// reflood_list (manet.rs:99-173): the neighbours of transmitting neighbour `tn` this router has to re-flood the LSP to;
+// every query is answered from the hop-count SPT of the batched run.  BTreeSet order.
+inline std::vector<SystemId> reflood_list(std::map<SystemId, NeighborCache> &cache, const SystemId &local_system_id, const SystemId &tn,
+                                          const SystemId &lsp_system_id, uint8_t lsp_pseudonode, uint8_t lsp_fragment) {
+  auto ci = cache.find(tn);
+  if (ci == cache.end() || ci->second.remote_nbr_list.empty()) return {};
+  NeighborCache &c = ci->second;
+  Spt &spt = c.spt_hopcount;
+  std::set<SystemId> thl;                                                             // :120-132
+  for (const Vertex *v : spt.second_hops()) {
+    const SystemId &s = v->id.lan_id.system_id;
+    if (s != lsp_system_id && !spt.is_on_path(s, lsp_system_id)) thl.insert(s);
+  }
+  std::vector<std::pair<SystemId, std::string>> rnl(c.remote_nbr_list.begin(), c.remote_nbr_list.end());
+  const size_t rnum = rnl.size(), n0 = flood_reduction_hash(lsp_system_id, lsp_pseudonode, lsp_fragment) % rnum;     // :135-139
+  std::vector<SystemId> out;
+  for (size_t k = 0; k < rnum; ++k) {                                                   // circular from index N, :143-170
+    if (thl.empty()) break;
+    const auto &e = rnl[(n0 + k) % rnum];
+    if (e.first == local_system_id) {
+      for (auto &t : thl) if (spt.is_on_path(e.first, t)) out.push_back(t);
+      break;
+    }
+    if (e.second != "modified-manet") continue;
+    for (auto it = thl.begin(); it != thl.end();) it = spt.is_on_path(e.first, *it) ? thl.erase(it) : std::next(it);
+  }
+  return out;
+}
+
+inline bool should_flood(const Interface &iface, const std::vector<SystemId> &reflood) {     // manet.rs:176-186
+  for (auto &a : iface.adjacencies)
+    if (a.state == "up" && std::find(reflood.begin(), reflood.end(), a.system_id) != reflood.end()) return true;
+  return false;
+}
+
+}  // namespace flooding
 
 }  // namespace isis
 }  // namespace host

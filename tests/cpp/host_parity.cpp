@@ -217,6 +217,39 @@ static int check_ospf(const J &vec, Engine &eng, const std::string &path) {
   return same ? 1 : 0;
 }
 
+// flooding::manet: (1) the reference's own hash vectors (manet.rs:205-232); (2) per vector, optional "manet" cases written by
+// the Python suite from the literal restatement: {"level", "algo": zero-pruner|modified-manet|mixed, "tn", "lsp": [sys, pn, frag], "want": [sys...]}
+static bool check_hash_kat() {
+  struct K { uint8_t b[8]; uint16_t h; } kat[] = {{{1, 2, 3, 4, 5, 6, 0, 0x00}, 0x6215}, {{1, 2, 3, 4, 5, 6, 0, 0x07}, 0x6215},
+                                                 {{1, 2, 3, 4, 5, 6, 0, 0x0F}, 0x6316}, {{0, 1, 2, 3, 4, 5, 0, 0x01}, 0x410F}};
+  for (auto &k : kat) {
+    I::SystemId s{}; for (int i = 0; i < 6; ++i) s[i] = k.b[i];
+    if (I::flooding::flood_reduction_hash(s, k.b[6], k.b[7]) != k.h) return false;
+  }
+  return true;
+}
+static int check_manet(const J &vec, const I::Instance &inst, Engine &eng, const std::string &path) {
+  int bad = 0;
+  std::map<std::pair<int, std::string>, std::map<I::SystemId, I::flooding::NeighborCache>> caches;
+  for (auto &c : vec["manet"].arr) {
+    const int level = (int)c["level"].i();
+    const std::string algo = c["algo"].s;
+    auto key = std::make_pair(level, algo);
+    if (!caches.count(key)) {
+      std::function<std::string(const I::SystemId &)> f;
+      if (algo == "modified-manet") f = [](const I::SystemId &) { return std::string("modified-manet"); };
+      else if (algo == "mixed") f = [](const I::SystemId &s) { return std::string((s[5] & 1) ? "modified-manet" : "zero-pruner"); };
+      caches[key] = I::flooding::init_cache(level, inst, eng, f);
+    }
+    const auto got = I::flooding::reflood_list(caches[key], inst.config.system_id, sysid(c["tn"].s), sysid(c["lsp"][0].s),
+                                               (uint8_t)c["lsp"][1].i(), (uint8_t)c["lsp"][2].i());
+    std::vector<I::SystemId> want;
+    for (auto &w : c["want"].arr) want.push_back(sysid(w.s));
+    if (got != want) { ++bad; std::fprintf(stderr, "MANET MISMATCH %s tn %s\n", path.c_str(), c["tn"].s.c_str()); }
+  }
+  return bad;
+}
+
 int main(int argc, char **argv) {
   std::string engine = "hip", oracle_so = "oracle/liboracle_spf.so";
   std::vector<std::string> files;
@@ -232,7 +265,8 @@ int main(int argc, char **argv) {
       eng = std::make_unique<HipEngine>(0);
     } else eng = std::make_unique<OracleEngine>(oracle_so);
   } catch (const std::exception &e) { std::fprintf(stderr, "engine: %s\n", e.what()); return 1; }
-  int ok = 0, bad = 0, skipped = 0;
+  int ok = 0, bad = 0, skipped = 0, manet_cases = 0, manet_bad = 0;
+  if (!check_hash_kat()) { std::fprintf(stderr, "flood_reduction_hash: reference vectors not reproduced\n"); return 1; }
   for (auto &path : files) {
     try {
       const J vec = load_json(path);
@@ -243,6 +277,7 @@ int main(int argc, char **argv) {
       }
       if (vec["proto"].s != "isis") continue;
       const I::Instance inst = instance_from_vector(vec);
+      if (vec.has("manet")) { const int mb = check_manet(vec, inst, *eng, path); manet_cases += (int)vec["manet"].size(); manet_bad += mb; }
       const auto rows = I::compute_spf(inst, *eng);
       // recorded rows in BTreeMap<IpNetwork, _> order
       std::vector<const J *> want;
@@ -262,5 +297,6 @@ int main(int argc, char **argv) {
     } catch (const std::exception &e) { ++bad; std::fprintf(stderr, "ERROR %s: %s\n", path.c_str(), e.what()); }
   }
   std::printf("host_parity (%s engine): %d vectors reproduce the recorded local RIB, %d do not, %d skipped (virtual links)\n", engine.c_str(), ok, bad, skipped);
-  return bad ? 1 : 0;
+  if (manet_cases) std::printf("host_parity: %d reflood lists checked, %d differ\n", manet_cases, manet_bad);
+  return (bad || manet_bad) ? 1 : 0;
 }

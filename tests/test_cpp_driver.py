@@ -108,3 +108,41 @@ def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr[-3000:]
     assert "300 vectors reproduce" in r.stdout
+
+
+def test_cpp_flooding_manet_reflood_lists_against_the_literal_restatement(tmp_path):
+    """flooding::manet in the compiled host side (init_cache = one batched hop-count run, reflood_list, the hash pinned by
+    the reference's unit-test vectors inside the driver): expected lists = oracle/isis_ref.py on recorded topologies and on
+    random instances; engine = the CPU oracle."""
+    import json
+    from oracle import graph_oracle, isis_ref
+    from _random_isis import make as make_isis
+    graph_oracle.build()
+    _build_host()
+    algos = {"zero-pruner": None, "modified-manet": lambda s: "modified-manet",
+             "mixed": lambda s: "modified-manet" if s[-1] & 1 else "zero-pruner"}
+    vecs = [json.load(open(p)) for p in VECTORS if os.sep + "isis" + os.sep in p][::3] + [make_isis(s) for s in range(4000, 4040)]
+    files, n_cases = [], 0
+    for i, v in enumerate(vecs):
+        local = bytes.fromhex(v["config"]["system_id"].replace(".", ""))
+        cases = []
+        for level_s, lsps in v["lsdb"].items():
+            level = int(level_s)
+            systems = sorted({l["id"][:14] for l in lsps})
+            nbrs = sorted({a["system_id"] for f in v["interfaces"] for a in f["adjacencies"] if a["state"] == "up"})
+            for algo, fn in algos.items():
+                for tn in nbrs:
+                    for sysid in systems[:6]:
+                        lsp = (bytes.fromhex(sysid.replace(".", "")), 0, 9)
+                        want = isis_ref.reflood_list(v, level, local, bytes.fromhex(tn.replace(".", "")), lsp, fn)
+                        fmt = lambda b: f"{b[:2].hex()}.{b[2:4].hex()}.{b[4:].hex()}"      # noqa: E731
+                        cases.append({"level": level, "algo": algo, "tn": tn, "lsp": [sysid, 0, 9], "want": [fmt(w) for w in want]})
+        v = dict(v); v["manet"] = cases
+        if "rib" not in v or not v["rib"]:
+            v["rib"] = isis_ref.local_rib(v)
+        n_cases += len(cases)
+        p = tmp_path / f"m{i}.json"; p.write_text(json.dumps(v)); files.append(str(p))
+    r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so")] + files,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    assert f"{n_cases} reflood lists checked, 0 differ" in r.stdout and n_cases > 500
