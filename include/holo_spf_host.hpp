@@ -9,6 +9,7 @@
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "holo_spf_hip.h"
@@ -37,7 +38,35 @@ class Engine {
                                         uint32_t max_path_metric) = 0;
   virtual Tables run(Graph &g, const std::vector<uint32_t> &roots, uint32_t run_flags) = 0;
   virtual SlotTable slot_table(Graph &g, uint32_t root) = 0;
+  // whole rows replaced (hspf_graph_patch): vertices strictly ascending, rows[i] = (col, metric) of vertices[i]
+  virtual void patch(Graph &g, const std::vector<uint32_t> &vertices,
+                     const std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> &rows,
+                     const std::vector<uint8_t> &vflags) = 0;
 };
+
+// CSR with the rows of `vertices` (strictly ascending) replaced — the host-side twin of hspf_graph_patch.
+inline void splice_rows(std::vector<uint32_t> &row_ptr, std::vector<uint32_t> &col, std::vector<uint32_t> &metric,
+                        std::vector<uint8_t> &vflags, const std::vector<uint32_t> &vertices,
+                        const std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> &rows,
+                        const std::vector<uint8_t> &new_flags) {
+  const uint32_t n = (uint32_t)row_ptr.size() - 1;
+  std::vector<uint32_t> nrp(n + 1, 0), ncol, nmet;
+  size_t j = 0;
+  for (uint32_t u = 0; u < n; ++u) {
+    nrp[u] = (uint32_t)ncol.size();
+    if (j < vertices.size() && vertices[j] == u) {
+      ncol.insert(ncol.end(), rows[j].first.begin(), rows[j].first.end());
+      nmet.insert(nmet.end(), rows[j].second.begin(), rows[j].second.end());
+      vflags[u] = new_flags[j];
+      ++j;
+    } else {
+      ncol.insert(ncol.end(), col.begin() + row_ptr[u], col.begin() + row_ptr[u + 1]);
+      nmet.insert(nmet.end(), metric.begin() + row_ptr[u], metric.begin() + row_ptr[u + 1]);
+    }
+  }
+  nrp[n] = (uint32_t)ncol.size();
+  row_ptr.swap(nrp); col.swap(ncol); metric.swap(nmet);
+}
 
 // ---- addresses and prefixes (BTreeMap<IpNetwork, _> / BTreeMap<IpAddr, _> order) -----------------------------------
 struct IpKey {                        // (version, 128-bit address, prefix length)
@@ -140,6 +169,15 @@ class HipEngine : public Engine {
     st.vertex.resize(cnt); st.base.resize(cnt);
     hspf_slot_table(ctx_, g, root, st.vertex.data(), st.base.data(), (uint32_t)cnt, &st.total);
     return st;
+  }
+  void patch(Graph &gr, const std::vector<uint32_t> &vertices,
+             const std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> &rows, const std::vector<uint8_t> &vflags) override {
+    std::vector<uint32_t> rp{0}, c, m;
+    for (auto &r : rows) { c.insert(c.end(), r.first.begin(), r.first.end()); m.insert(m.end(), r.second.begin(), r.second.end()); rp.push_back((uint32_t)c.size()); }
+    if (c.empty()) { c.push_back(0); m.push_back(0); }              // non-NULL pointers for an all-empty delta
+    hspf_rows d{(uint32_t)vertices.size(), vertices.data(), rp.data(), c.data(), m.data(), vflags.data()};
+    const int rc = hspf_graph_patch(ctx_, static_cast<HipGraph &>(gr).g, &d);
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_graph_patch: ") + hspf_last_error(ctx_));
   }
  private:
   hspf_ctx *ctx_ = nullptr;

@@ -76,6 +76,12 @@ struct Lsp {
   bool live() const { return seqno != 0 && rem_lifetime != 0; }               // spf.rs:1024-1025
   bool overload_bit(int mt) const { auto it = mt_flags.find(mt); return mt == MT_STANDARD ? overload : (it != mt_flags.end() && it->second.first); }
   bool att_bit(int mt) const { auto it = mt_flags.find(mt); return mt == MT_STANDARD ? att : (it != mt_flags.end() && it->second.second); }
+  bool operator==(const Lsp &o) const {
+    return system_id == o.system_id && pseudonode == o.pseudonode && fragment == o.fragment && seqno == o.seqno &&
+           rem_lifetime == o.rem_lifetime && overload == o.overload && att == o.att && protocols_supported == o.protocols_supported &&
+           mt_flags == o.mt_flags && is_reach == o.is_reach && ext_is_reach == o.ext_is_reach && mt_is_reach == o.mt_is_reach &&
+           ipv4_internal == o.ipv4_internal && ipv4_external == o.ipv4_external && ext_ipv4 == o.ext_ipv4 && ipv6 == o.ipv6 && mt_ipv6 == o.mt_ipv6;
+  }
 };
 struct Adjacency {
   SystemId system_id{};
@@ -192,40 +198,46 @@ class LevelGraph {
   LevelGraph(const Instance &inst, int level_, std::optional<int> mt, bool hop = false)
       : level(level_), mt_id(mt), hopcount(hop) {
     const InstanceCfg &cfg = inst.config;
-    static const Lsdb empty;
-    auto li = inst.lsdb.find(level);
-    const Lsdb &lsdb = li == inst.lsdb.end() ? empty : li->second;
+    const Lsdb &lsdb = lsdb_of(inst);
     metric_type = cfg.metric_type.at(level);
-    std::map<LanId, std::vector<const Lsp *>> frags;
-    for (auto &kv : lsdb.all())
-      if (kv.second.live()) frags[kv.second.lan_id()].push_back(&kv.second);
+    cfg_key_ = cfg_key(cfg);
+    auto frags = live_fragments(lsdb);
     for (auto &kv : frags) vids.push_back(vertex_id(kv.first));
     std::sort(vids.begin(), vids.end());
     for (uint32_t i = 0; i < vids.size(); ++i) index[vids[i]] = i;
     row_ptr.assign(vids.size() + 1, 0);
     vflags.assign(vids.size(), 0);
     for (uint32_t i = 0; i < vids.size(); ++i) {
-      const LanId lan = vids[i].lan_id;
-      for (const Lsp *lsp : frags[lan])
-        for (auto &e : vertex_edges(*lsp, mt_id, hopcount, metric_type)) {
-          auto it = index.find(vertex_id(e.first));
-          if (it != index.end()) { col.push_back(it->second); metric.push_back(e.second); }
-        }
+      auto r = row(vids[i].lan_id, frags, lsdb, cfg);
+      col.insert(col.end(), r.col.begin(), r.col.end());
+      metric.insert(metric.end(), r.metric.begin(), r.metric.end());
+      vflags[i] = r.flags;
       row_ptr[i + 1] = (uint32_t)col.size();
-      const bool is_pn = lan.pseudonode != 0;
-      uint8_t f = is_pn ? HSPF_VF_NETWORK : 0;
-      const Lsp *z = lsdb.zeroth_lsp(lan);
-      if (!z) { vflags[i] = f | HSPF_VF_NO_EXPAND; continue; }                 // spf.rs:557-561
-      if (!is_pn && mt_id && z->overload_bit(*mt_id)) f |= HSPF_VF_NO_TRANSIT; // spf.rs:568-574
-      if (mt_id && *mt_id == MT_STANDARD && !is_pn) {                          // spf.rs:582-604
-        auto has = [&](int p) { return z->protocols_supported && std::find(z->protocols_supported->begin(), z->protocols_supported->end(), p) != z->protocols_supported->end(); };
-        if (!z->protocols_supported || (cfg.ipv4_enabled && !has(NLPID_IPV4)) || (cfg.ipv6_enabled && !has(NLPID_IPV6)))
-          f |= HSPF_VF_NO_EXPAND;
-      }
-      vflags[i] = f;
     }
     max_path_metric = metric_type == "standard" ? MAX_PATH_METRIC_STANDARD : MAX_PATH_METRIC_WIDE;   // spf.rs:637-641
     run_flags = mt_id ? 0u : (uint32_t)HSPF_RUN_IGNORE_OVERLOAD;                                     // spf.rs:566-574
+  }
+  // Incremental re-derivation after the LSPs of `changed` LAN ids were re-originated, purged or aged out (the reference's
+  // `trigger_lsps`, holo-isis/src/spf.rs:144,735): only their rows are rebuilt and — when the graph is on the device —
+  // replaced there with hspf_graph_patch.  false (nothing touched) when the change is not a set of row replacements (a
+  // vertex appeared or vanished, or the configuration the rows depend on changed): the caller builds a new LevelGraph.
+  bool refresh(const Instance &inst, const std::vector<LanId> &changed) {
+    const InstanceCfg &cfg = inst.config;
+    const Lsdb &lsdb = lsdb_of(inst);
+    if (cfg_key(cfg) != cfg_key_) return false;
+    auto frags = live_fragments(lsdb);
+    if (frags.size() != vids.size()) return false;
+    for (auto &kv : frags) if (!index.count(vertex_id(kv.first))) return false;
+    std::set<uint32_t> vs;
+    for (auto &lan : changed) { auto it = index.find(vertex_id(lan)); if (it != index.end()) vs.insert(it->second); }
+    if (vs.empty()) return true;
+    std::vector<uint32_t> vv(vs.begin(), vs.end());
+    std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> rows;
+    std::vector<uint8_t> fl;
+    for (uint32_t i : vv) { auto r = row(vids[i].lan_id, frags, lsdb, cfg); rows.push_back({r.col, r.metric}); fl.push_back(r.flags); }
+    if (dev_) dev_engine_->patch(*dev_, vv, rows, fl);
+    splice_rows(row_ptr, col, metric, vflags, vv, rows, fl);
+    return true;
   }
   uint32_t n() const { return (uint32_t)vids.size(); }
   Graph &device(Engine &e) {
@@ -238,6 +250,42 @@ class LevelGraph {
     return false;
   }
  private:
+  struct Row { std::vector<uint32_t> col, metric; uint8_t flags; };
+  using CfgKey = std::tuple<std::string, bool, bool>;       // everything outside the LSDB a row depends on
+  CfgKey cfg_key(const InstanceCfg &cfg) const { return {cfg.metric_type.at(level), cfg.ipv4_enabled, cfg.ipv6_enabled}; }
+  const Lsdb &lsdb_of(const Instance &inst) const {
+    static const Lsdb empty;
+    auto li = inst.lsdb.find(level);
+    return li == inst.lsdb.end() ? empty : li->second;
+  }
+  static std::map<LanId, std::vector<const Lsp *>> live_fragments(const Lsdb &lsdb) {
+    std::map<LanId, std::vector<const Lsp *>> frags;
+    for (auto &kv : lsdb.all())
+      if (kv.second.live()) frags[kv.second.lan_id()].push_back(&kv.second);
+    return frags;
+  }
+  // links (fragment, then TLV order: spf.rs:1013-1128) and gate flags (spf.rs:557-604) of one vertex
+  Row row(const LanId &lan, std::map<LanId, std::vector<const Lsp *>> &frags, const Lsdb &lsdb, const InstanceCfg &cfg) const {
+    Row r;
+    for (const Lsp *lsp : frags[lan])
+      for (auto &e : vertex_edges(*lsp, mt_id, hopcount, metric_type)) {
+        auto it = index.find(vertex_id(e.first));
+        if (it != index.end()) { r.col.push_back(it->second); r.metric.push_back(e.second); }
+      }
+    const bool is_pn = lan.pseudonode != 0;
+    uint8_t f = is_pn ? HSPF_VF_NETWORK : 0;
+    const Lsp *z = lsdb.zeroth_lsp(lan);
+    if (!z) { r.flags = f | HSPF_VF_NO_EXPAND; return r; }                   // spf.rs:557-561
+    if (!is_pn && mt_id && z->overload_bit(*mt_id)) f |= HSPF_VF_NO_TRANSIT; // spf.rs:568-574
+    if (mt_id && *mt_id == MT_STANDARD && !is_pn) {                          // spf.rs:582-604
+      auto has = [&](int p) { return z->protocols_supported && std::find(z->protocols_supported->begin(), z->protocols_supported->end(), p) != z->protocols_supported->end(); };
+      if (!z->protocols_supported || (cfg.ipv4_enabled && !has(NLPID_IPV4)) || (cfg.ipv6_enabled && !has(NLPID_IPV6)))
+        f |= HSPF_VF_NO_EXPAND;
+    }
+    r.flags = f;
+    return r;
+  }
+  CfgKey cfg_key_;
   std::unique_ptr<Graph> dev_;
   Engine *dev_engine_ = nullptr;
 };
@@ -592,16 +640,47 @@ inline void compute_routes(int level, int mt_id, const Instance &inst, const Spt
 
 struct RibRow { std::string prefix; uint32_t metric; int level; std::vector<std::pair<std::string, std::string>> nexthops; };
 
+// LAN ids with an LSP fragment that differs between two LSDB snapshots (what the reference accumulates in `trigger_lsps`)
+inline std::vector<LanId> changed_lan_ids(const Lsdb &old_db, const Lsdb &new_db) {
+  std::set<LanId> out;
+  for (auto &kv : old_db.all()) { auto it = new_db.all().find(kv.first); if (it == new_db.all().end() || !(it->second == kv.second)) out.insert(kv.second.lan_id()); }
+  for (auto &kv : new_db.all()) if (!old_db.all().count(kv.first)) out.insert(kv.second.lan_id());
+  return std::vector<LanId>(out.begin(), out.end());
+}
+
+// Level graphs kept on the device across SPF runs, brought up to date from the changed LSPs.
+class GraphCache {
+ public:
+  int rebuilt = 0, patched = 0;
+  std::map<std::tuple<int, int, bool>, std::unique_ptr<LevelGraph>> graphs;       // (level, mt_id or -1, hop count)
+  LevelGraph &get(const Instance &inst, int level, std::optional<int> mt_id, bool hopcount, const std::vector<LanId> *trigger_lsps) {
+    auto key = std::make_tuple(level, mt_id ? *mt_id : -1, hopcount);
+    auto it = graphs.find(key);
+    if (it != graphs.end() && trigger_lsps && it->second->refresh(inst, *trigger_lsps)) { ++patched; return *it->second; }
+    graphs[key] = std::make_unique<LevelGraph>(inst, level, mt_id, hopcount);
+    ++rebuilt;
+    return *graphs[key];
+  }
+};
+
 // Full SPF of every configured level and topology (holo-isis/src/spf.rs:719-836) followed by the L1/L2 merge of
 // holo-isis/src/route.rs:185-249; rows like the YANG `local-rib`.
-inline std::vector<RibRow> compute_spf(const Instance &inst, Engine &engine) {
+inline std::vector<RibRow> compute_spf(const Instance &inst, Engine &engine, GraphCache *cache = nullptr,
+                                       const std::map<int, std::vector<LanId>> *trigger_lsps = nullptr) {
   const InstanceCfg &cfg = inst.config;
   std::map<int, std::map<IpKey, Route>> per_level;
   for (int level : cfg.levels()) {
     std::map<IpKey, Route> rib;
     for (int mt_id : {MT_STANDARD, MT_IPV6_UNICAST}) {
       if (!cfg.is_topology_enabled(mt_id)) continue;
-      Spt spt = compute_spt(level, cfg.system_id, true, mt_id, false, inst, engine);
+      LevelGraph *graph = nullptr;
+      if (cache) {
+        static const std::vector<LanId> none;
+        const std::vector<LanId> *trig = nullptr;
+        if (trigger_lsps) { auto ti = trigger_lsps->find(level); trig = ti == trigger_lsps->end() ? &none : &ti->second; }
+        graph = &cache->get(inst, level, mt_id, false, trig);
+      }
+      Spt spt = compute_spt(level, cfg.system_id, true, mt_id, false, inst, engine, graph);
       compute_routes(level, mt_id, inst, spt, rib);
     }
     per_level[level] = std::move(rib);

@@ -76,7 +76,7 @@ struct Vertex {                                               // holo-ospf/src/s
 // position among the non-stub links BEFORE the existence filter, ospfv2/spf.rs:439-456, and the link itself).
 class AreaGraph {
  public:
-  const Area &area;
+  const Area *area;
   std::map<uint32_t, const RouterLsa *> routers;
   std::map<uint32_t, const NetworkLsa *> networks;
   std::vector<VertexId> vids;
@@ -86,7 +86,61 @@ class AreaGraph {
   std::vector<const RouterLink *> link_ref;
   std::vector<uint8_t> vflags;
 
-  explicit AreaGraph(const Area &a) : area(a) {
+  explicit AreaGraph(const Area &a) : area(&a) {
+    live_lsas(a, routers, networks);
+    for (auto &kv : networks) vids.push_back({NET, kv.first});
+    for (auto &kv : routers) vids.push_back({RTR, kv.first});
+    std::sort(vids.begin(), vids.end());
+    for (uint32_t i = 0; i < vids.size(); ++i) index[vids[i]] = i;
+    row_ptr.assign(vids.size() + 1, 0);
+    for (uint32_t i = 0; i < vids.size(); ++i) {
+      Row r = row(vids[i]);
+      col.insert(col.end(), r.col.begin(), r.col.end());
+      metric.insert(metric.end(), r.metric.begin(), r.metric.end());
+      link_pos.insert(link_pos.end(), r.pos.begin(), r.pos.end());
+      link_ref.insert(link_ref.end(), r.ref.begin(), r.ref.end());
+      row_ptr[i + 1] = (uint32_t)col.size();
+    }
+    for (auto &v : vids) vflags.push_back(v.first == NET ? HSPF_VF_NETWORK : 0);
+  }
+  // Bring the graph forward to `a` (a later state of the same area's LSDB) when only the LSAs of the `changed` vertices
+  // were re-originated (the reference's SpfTriggerLsa list, holo-ospf/src/spf.rs:120-139): their rows are rebuilt and
+  // replaced on the device with hspf_graph_patch.  false (nothing touched) when a vertex appeared or vanished.
+  bool refresh(const Area &a, const std::vector<VertexId> &changed) {
+    std::map<uint32_t, const RouterLsa *> r2;
+    std::map<uint32_t, const NetworkLsa *> n2;
+    live_lsas(a, r2, n2);
+    auto same_keys = [](auto &x, auto &y) { if (x.size() != y.size()) return false; auto i = x.begin(); auto j = y.begin(); for (; i != x.end(); ++i, ++j) if (i->first != j->first) return false; return true; };
+    if (!same_keys(r2, routers) || !same_keys(n2, networks)) return false;
+    area = &a; routers.swap(r2); networks.swap(n2);
+    std::set<uint32_t> vs;
+    for (auto &v : changed) { auto it = index.find(v); if (it != index.end()) vs.insert(it->second); }
+    // every per-entry link reference points into the new area's LSAs
+    std::vector<int> npos;
+    std::vector<const RouterLink *> nref;
+    std::vector<uint32_t> vv(vs.begin(), vs.end());
+    std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> rows;
+    std::vector<uint8_t> fl;
+    for (uint32_t u = 0; u < vids.size(); ++u) {
+      Row r = row(vids[u]);                       // cheap; also re-anchors link_ref of unchanged rows in the new LSAs
+      if (vs.count(u)) { rows.push_back({r.col, r.metric}); fl.push_back(vflags[u]); }
+      npos.insert(npos.end(), r.pos.begin(), r.pos.end());
+      nref.insert(nref.end(), r.ref.begin(), r.ref.end());
+    }
+    if (!vv.empty()) {
+      if (dev_) dev_engine_->patch(*dev_, vv, rows, fl);
+      splice_rows(row_ptr, col, metric, vflags, vv, rows, fl);
+    }
+    link_pos.swap(npos); link_ref.swap(nref);
+    return true;
+  }
+  Graph &device(Engine &e) {
+    if (!dev_ || dev_engine_ != &e) { dev_ = e.upload(row_ptr, col, metric, vflags, MAX_PATH_METRIC_OSPF); dev_engine_ = &e; }
+    return *dev_;
+  }
+ private:
+  struct Row { std::vector<uint32_t> col, metric; std::vector<int> pos; std::vector<const RouterLink *> ref; };
+  static void live_lsas(const Area &a, std::map<uint32_t, const RouterLsa *> &routers, std::map<uint32_t, const NetworkLsa *> &networks) {
     for (auto &l : a.routers) if (!l.maxage) routers[ip4(l.adv_rtr)] = &l;
     // vertex_lsa_find for a network: FIRST Network-LSA in (adv_rtr, lsa_id) order whose LS-ID matches, then dropped
     // if MaxAge (ospfv2/spf.rs:362-373)
@@ -97,43 +151,33 @@ class AreaGraph {
     std::map<uint32_t, const NetworkLsa *> first;
     for (auto *l : sorted) first.emplace(ip4(l->lsa_id), l);
     for (auto &kv : first) if (!kv.second->maxage) networks[kv.first] = kv.second;
-    for (auto &kv : networks) vids.push_back({NET, kv.first});
-    for (auto &kv : routers) vids.push_back({RTR, kv.first});
-    std::sort(vids.begin(), vids.end());
-    for (uint32_t i = 0; i < vids.size(); ++i) index[vids[i]] = i;
-    row_ptr.assign(vids.size() + 1, 0);
-    for (uint32_t i = 0; i < vids.size(); ++i) {
-      const VertexId vid = vids[i];
-      if (vid.first == NET) {
-        std::vector<uint32_t> att;
-        for (auto &r : networks[vid.second]->attached) att.push_back(ip4(r));
-        std::sort(att.begin(), att.end());                        // BTreeSet<Ipv4Addr>
-        att.erase(std::unique(att.begin(), att.end()), att.end());
-        for (uint32_t r : att) {
-          auto it = index.find({RTR, r});
-          if (it != index.end()) { col.push_back(it->second); metric.push_back(0); link_pos.push_back(-1); link_ref.push_back(nullptr); }
-        }
-      } else {
-        int pos = -1;
-        for (auto &link : routers[vid.second]->links) {
-          VertexId tid;
-          if (link.link_type == "point-to-point-link" || link.link_type == "virtual-link") tid = {RTR, ip4(link.link_id)};
-          else if (link.link_type == "transit-network-link") tid = {NET, ip4(link.link_id)};
-          else continue;                                          // stub links: no position consumed
-          ++pos;
-          auto it = index.find(tid);
-          if (it != index.end()) { col.push_back(it->second); metric.push_back(link.metric); link_pos.push_back(pos); link_ref.push_back(&link); }
-        }
+  }
+  // vertex_lsa_links (ospfv2/spf.rs:389-460) of one vertex against the current vertex set
+  Row row(const VertexId &vid) const {
+    Row r;
+    if (vid.first == NET) {
+      std::vector<uint32_t> att;
+      for (auto &x : networks.at(vid.second)->attached) att.push_back(ip4(x));
+      std::sort(att.begin(), att.end());                        // BTreeSet<Ipv4Addr>
+      att.erase(std::unique(att.begin(), att.end()), att.end());
+      for (uint32_t x : att) {
+        auto it = index.find({RTR, x});
+        if (it != index.end()) { r.col.push_back(it->second); r.metric.push_back(0); r.pos.push_back(-1); r.ref.push_back(nullptr); }
       }
-      row_ptr[i + 1] = (uint32_t)col.size();
+      return r;
     }
-    for (auto &v : vids) vflags.push_back(v.first == NET ? HSPF_VF_NETWORK : 0);
+    int pos = -1;
+    for (auto &link : routers.at(vid.second)->links) {
+      VertexId tid;
+      if (link.link_type == "point-to-point-link" || link.link_type == "virtual-link") tid = {RTR, ip4(link.link_id)};
+      else if (link.link_type == "transit-network-link") tid = {NET, ip4(link.link_id)};
+      else continue;                                          // stub links: no position consumed
+      ++pos;
+      auto it = index.find(tid);
+      if (it != index.end()) { r.col.push_back(it->second); r.metric.push_back(link.metric); r.pos.push_back(pos); r.ref.push_back(&link); }
+    }
+    return r;
   }
-  Graph &device(Engine &e) {
-    if (!dev_ || dev_engine_ != &e) { dev_ = e.upload(row_ptr, col, metric, vflags, MAX_PATH_METRIC_OSPF); dev_engine_ = &e; }
-    return *dev_;
-  }
- private:
   std::unique_ptr<Graph> dev_;
   Engine *dev_engine_ = nullptr;
 };
@@ -148,7 +192,7 @@ inline std::optional<Nexthops> calc_nexthops(const AreaGraph &g, const Vertex &p
   if (parent.id.first == RTR) {
     const int pos = g.link_pos[k];
     std::vector<const Interface *> cands;
-    for (auto &i : g.area.interfaces) if (!i.neighbors.empty()) cands.push_back(&i);
+    for (auto &i : g.area->interfaces) if (!i.neighbors.empty()) cands.push_back(&i);
     std::stable_sort(cands.begin(), cands.end(), [](const Interface *a, const Interface *b) { return a->name < b->name; });
     if (pos < 0 || (size_t)pos >= cands.size()) return std::nullopt;
     const Interface *iface = cands[pos];
@@ -290,15 +334,59 @@ inline void update_rib_intra_area(std::map<IpKey, RouteNet> &rib, const SptMap &
 
 struct RibRow { std::string prefix; uint32_t metric; std::vector<std::pair<std::optional<std::string>, std::string>> nexthops; };
 
+inline bool operator==(const RouterLink &a, const RouterLink &b) { return a.link_type == b.link_type && a.link_id == b.link_id && a.link_data == b.link_data && a.metric == b.metric; }
+inline bool operator==(const RouterLsa &a, const RouterLsa &b) { return a.adv_rtr == b.adv_rtr && a.links == b.links && a.maxage == b.maxage; }
+inline bool operator==(const NetworkLsa &a, const NetworkLsa &b) { return a.lsa_id == b.lsa_id && a.adv_rtr == b.adv_rtr && a.mask == b.mask && a.attached == b.attached && a.maxage == b.maxage; }
+
+// vertices whose Router-/Network-LSA differs between two states of an area (the SpfTriggerLsa list, spf.rs:120-139)
+inline std::vector<VertexId> changed_vertex_ids(const Area &old_a, const Area &new_a) {
+  std::set<VertexId> out;
+  auto rkey = [](const RouterLsa &l) { return ip4(l.adv_rtr); };
+  std::map<uint32_t, const RouterLsa *> ra, rb;
+  for (auto &l : old_a.routers) ra[rkey(l)] = &l;
+  for (auto &l : new_a.routers) rb[rkey(l)] = &l;
+  for (auto &kv : ra) { auto it = rb.find(kv.first); if (it == rb.end() || !(*it->second == *kv.second)) out.insert({RTR, kv.first}); }
+  for (auto &kv : rb) if (!ra.count(kv.first)) out.insert({RTR, kv.first});
+  std::map<std::pair<uint32_t, uint32_t>, const NetworkLsa *> na, nb;
+  for (auto &l : old_a.networks) na[{ip4(l.adv_rtr), ip4(l.lsa_id)}] = &l;
+  for (auto &l : new_a.networks) nb[{ip4(l.adv_rtr), ip4(l.lsa_id)}] = &l;
+  for (auto &kv : na) { auto it = nb.find(kv.first); if (it == nb.end() || !(*it->second == *kv.second)) out.insert({NET, kv.first.second}); }
+  for (auto &kv : nb) if (!na.count(kv.first)) out.insert({NET, kv.first.second});
+  return std::vector<VertexId>(out.begin(), out.end());
+}
+
+// Area graphs kept on the device across SPF runs and patched from the changed LSAs.
+class GraphCache {
+ public:
+  int rebuilt = 0, patched = 0;
+  std::map<std::string, std::unique_ptr<AreaGraph>> graphs;
+  AreaGraph &get(const Area &a, const std::vector<VertexId> *trigger) {
+    auto it = graphs.find(a.area_id);
+    if (it != graphs.end() && trigger && it->second->refresh(a, *trigger)) { ++patched; return *it->second; }
+    graphs[a.area_id] = std::make_unique<AreaGraph>(a);
+    ++rebuilt;
+    return *graphs[a.area_id];
+  }
+};
+
 // The SPT + intra-area part of compute_spf (holo-ospf/src/spf.rs:489-584, route.rs:146-160): areas in area-id order,
 // one run_area each; rows like the YANG `local-rib` list (type intra-area).
-inline std::vector<RibRow> compute_spf_intra_area(const std::string &router_id, const std::vector<Area> &areas, uint32_t max_paths, Engine &engine) {
+inline std::vector<RibRow> compute_spf_intra_area(const std::string &router_id, const std::vector<Area> &areas, uint32_t max_paths, Engine &engine,
+                                                  GraphCache *cache = nullptr, const std::map<std::string, std::vector<VertexId>> *trigger = nullptr) {
   std::vector<const Area *> order;
   for (auto &a : areas) order.push_back(&a);
   std::stable_sort(order.begin(), order.end(), [](const Area *a, const Area *b) { return ip4(a->area_id) < ip4(b->area_id); });
   std::map<IpKey, RouteNet> rib;
   for (const Area *a : order) {
-    AreaGraph g(*a);
+    std::unique_ptr<AreaGraph> own;
+    AreaGraph *gp;
+    if (cache) {
+      static const std::vector<VertexId> none;
+      const std::vector<VertexId> *trig = nullptr;
+      if (trigger) { auto ti = trigger->find(a->area_id); trig = ti == trigger->end() ? &none : &ti->second; }
+      gp = &cache->get(*a, trig);
+    } else { own = std::make_unique<AreaGraph>(*a); gp = own.get(); }
+    AreaGraph &g = *gp;
     auto spt = run_area(router_id, g, engine);
     if (spt) update_rib_intra_area(rib, *spt, max_paths);
   }

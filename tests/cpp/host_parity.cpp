@@ -64,6 +64,13 @@ class OracleEngine : public Engine {
     }
     return st;
   }
+  void patch(Graph &gr, const std::vector<uint32_t> &vertices,
+             const std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> &rows, const std::vector<uint8_t> &vflags) override {
+    auto &g = static_cast<OracleGraph &>(gr);
+    splice_rows(g.row_ptr, g.col, g.metric, g.vflags, vertices, rows, vflags);
+    ++patches;
+  }
+  int patches = 0;
   Tables run(Graph &gr, const std::vector<uint32_t> &roots, uint32_t run_flags) override {
     auto &g = static_cast<OracleGraph &>(gr);
     Tables t;
@@ -250,12 +257,101 @@ static int check_manet(const J &vec, const I::Instance &inst, Engine &eng, const
   return bad;
 }
 
+static bool rows_equal(const std::vector<I::RibRow> &rows, const J &rib) {
+  std::vector<const J *> want;
+  for (auto &r : rib.arr) want.push_back(&r);
+  std::stable_sort(want.begin(), want.end(), [](const J *a, const J *b) { return parse_ip((*a)["prefix"].s) < parse_ip((*b)["prefix"].s); });
+  if (want.size() != rows.size()) return false;
+  for (size_t i = 0; i < rows.size(); ++i) {
+    const J &w = *want[i];
+    if (w["prefix"].s != rows[i].prefix || (uint32_t)w["metric"].i() != rows[i].metric || (int)w["level"].i() != rows[i].level ||
+        w["nexthops"].arr.size() != rows[i].nexthops.size()) return false;
+    for (size_t k = 0; k < rows[i].nexthops.size(); ++k)
+      if (w["nexthops"][k][0].s != rows[i].nexthops[k].first || w["nexthops"][k][1].s != rows[i].nexthops[k].second) return false;
+  }
+  return true;
+}
+
+// A reference step test replayed as "topology snapshot, then the LSDB after the step": the level graphs built for the
+// snapshot are brought forward with row patches (LevelGraph::refresh -> Engine::patch) or rebuilt, must equal graphs
+// derived from scratch, and the SPF on them must give the RIB the reference recorded after the step.
+static int replay_isis_step(const J &step, const std::string &golden_dir, Engine &eng, int &patched) {
+  const std::string src = step["source"].s;                       // "... (snapshot topo2-1/rt6, state ...)"
+  const size_t a = src.find("snapshot ");
+  if (a == std::string::npos) return -1;
+  const size_t sl = src.find('/', a), co = src.find(',', a);
+  const std::string topo = src.substr(a + 9, sl - a - 9), rt = src.substr(sl + 1, co - sl - 1);
+  const J base = load_json(golden_dir + "/isis/" + topo + "_" + rt + ".json");
+  const I::Instance inst0 = instance_from_vector(base), inst1 = instance_from_vector(step);
+  I::GraphCache cache;
+  if (!rows_equal(I::compute_spf(inst0, eng, &cache), base["rib"])) return 0;
+  std::map<int, std::vector<I::LanId>> trig;
+  static const I::Lsdb empty;
+  for (int level : {1, 2}) {
+    auto i0 = inst0.lsdb.find(level), i1 = inst1.lsdb.find(level);
+    trig[level] = I::changed_lan_ids(i0 == inst0.lsdb.end() ? empty : i0->second, i1 == inst1.lsdb.end() ? empty : i1->second);
+  }
+  const int before = cache.patched;
+  if (!rows_equal(I::compute_spf(inst1, eng, &cache, &trig), step["rib"])) return 0;
+  patched += cache.patched - before;
+  for (auto &kv : cache.graphs) {
+    const int level = std::get<0>(kv.first), mt = std::get<1>(kv.first);
+    const auto levels = inst1.config.levels();
+    if (std::find(levels.begin(), levels.end(), level) == levels.end() || !inst1.config.is_topology_enabled(mt)) continue;
+    I::LevelGraph fresh(inst1, level, mt < 0 ? std::optional<int>() : std::optional<int>(mt), std::get<2>(kv.first));
+    const I::LevelGraph &g = *kv.second;
+    if (!(g.vids == fresh.vids) || g.row_ptr != fresh.row_ptr || g.col != fresh.col || g.metric != fresh.metric || g.vflags != fresh.vflags) return 0;
+  }
+  return 1;
+}
+
+static bool ospf_rows_equal(const std::vector<O::RibRow> &rows, const J &rib) {
+  std::vector<const J *> want;
+  for (auto &r : rib.arr) if (r["type"].s == "intra-area") want.push_back(&r);
+  std::stable_sort(want.begin(), want.end(), [](const J *a, const J *b) { return parse_ip((*a)["prefix"].s) < parse_ip((*b)["prefix"].s); });
+  if (want.size() != rows.size()) return false;
+  for (size_t i = 0; i < rows.size(); ++i) {
+    const J &w = *want[i];
+    if (w["prefix"].s != rows[i].prefix || (uint32_t)w["metric"].i() != rows[i].metric || w["nexthops"].arr.size() != rows[i].nexthops.size()) return false;
+    for (size_t k = 0; k < rows[i].nexthops.size(); ++k) {
+      const J &a = w["nexthops"][k][0];
+      if (!(a.is_null() ? !rows[i].nexthops[k].first : (rows[i].nexthops[k].first && a.s == *rows[i].nexthops[k].first)) ||
+          w["nexthops"][k][1].s != rows[i].nexthops[k].second) return false;
+    }
+  }
+  return true;
+}
+static int replay_ospf_step(const J &step, const std::string &golden_dir, Engine &eng, int &patched) {
+  if (step["has_vlinks"].b) return -1;
+  const std::string src = step["source"].s;
+  const size_t a = src.find("snapshot ");
+  if (a == std::string::npos) return -1;
+  const size_t sl = src.find('/', a), co = src.find(',', a);
+  const J base = load_json(golden_dir + "/ospfv2/" + src.substr(a + 9, sl - a - 9) + "_" + src.substr(sl + 1, co - sl - 1) + ".json");
+  if (base["has_vlinks"].b) return -1;
+  const auto areas0 = areas_from_vector(base), areas1 = areas_from_vector(step);
+  O::GraphCache cache;
+  if (!ospf_rows_equal(O::compute_spf_intra_area(base["router_id"].s, areas0, (uint32_t)base["max_paths"].i(), eng, &cache), base["rib"])) return 0;
+  std::map<std::string, std::vector<O::VertexId>> trig;
+  for (auto &n : areas1) for (auto &o : areas0) if (o.area_id == n.area_id) trig[n.area_id] = O::changed_vertex_ids(o, n);
+  const int before = cache.patched;
+  if (!ospf_rows_equal(O::compute_spf_intra_area(step["router_id"].s, areas1, (uint32_t)step["max_paths"].i(), eng, &cache, &trig), step["rib"])) return 0;
+  patched += cache.patched - before;
+  for (auto &n : areas1) {
+    O::AreaGraph fresh(n);
+    const O::AreaGraph &g = *cache.graphs.at(n.area_id);
+    if (g.vids != fresh.vids || g.row_ptr != fresh.row_ptr || g.col != fresh.col || g.metric != fresh.metric || g.link_pos != fresh.link_pos) return 0;
+  }
+  return 1;
+}
+
 int main(int argc, char **argv) {
-  std::string engine = "hip", oracle_so = "oracle/liboracle_spf.so";
+  std::string engine = "hip", oracle_so = "oracle/liboracle_spf.so", golden_dir;
   std::vector<std::string> files;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--engine") && i + 1 < argc) engine = argv[++i];
     else if (!strcmp(argv[i], "--oracle-so") && i + 1 < argc) oracle_so = argv[++i];
+    else if (!strcmp(argv[i], "--replay-steps") && i + 1 < argc) golden_dir = argv[++i];
     else files.push_back(argv[i]);
   }
   std::unique_ptr<Engine> eng;
@@ -265,17 +361,25 @@ int main(int argc, char **argv) {
       eng = std::make_unique<HipEngine>(0);
     } else eng = std::make_unique<OracleEngine>(oracle_so);
   } catch (const std::exception &e) { std::fprintf(stderr, "engine: %s\n", e.what()); return 1; }
-  int ok = 0, bad = 0, skipped = 0, manet_cases = 0, manet_bad = 0;
+  int ok = 0, bad = 0, skipped = 0, manet_cases = 0, manet_bad = 0, steps_ok = 0, steps_bad = 0, steps_patched = 0;
   if (!check_hash_kat()) { std::fprintf(stderr, "flood_reduction_hash: reference vectors not reproduced\n"); return 1; }
   for (auto &path : files) {
     try {
       const J vec = load_json(path);
       if (vec["proto"].s == "ospfv2") {
+        if (!golden_dir.empty() && vec["source"].s.find("snapshot ") != std::string::npos) {
+          const int sr = replay_ospf_step(vec, golden_dir, *eng, steps_patched);
+          if (sr > 0) ++steps_ok; else if (sr == 0) { ++steps_bad; std::fprintf(stderr, "STEP REPLAY MISMATCH %s\n", path.c_str()); }
+        }
         const int r = check_ospf(vec, *eng, path);
         if (r > 0) ++ok; else if (r == 0) ++bad; else ++skipped;
         continue;
       }
       if (vec["proto"].s != "isis") continue;
+      if (!golden_dir.empty() && vec["source"].s.find("snapshot ") != std::string::npos) {
+        const int r = replay_isis_step(vec, golden_dir, *eng, steps_patched);
+        if (r > 0) ++steps_ok; else if (r == 0) { ++steps_bad; std::fprintf(stderr, "STEP REPLAY MISMATCH %s\n", path.c_str()); }
+      }
       const I::Instance inst = instance_from_vector(vec);
       if (vec.has("manet")) { const int mb = check_manet(vec, inst, *eng, path); manet_cases += (int)vec["manet"].size(); manet_bad += mb; }
       const auto rows = I::compute_spf(inst, *eng);
@@ -298,5 +402,6 @@ int main(int argc, char **argv) {
   }
   std::printf("host_parity (%s engine): %d vectors reproduce the recorded local RIB, %d do not, %d skipped (virtual links)\n", engine.c_str(), ok, bad, skipped);
   if (manet_cases) std::printf("host_parity: %d reflood lists checked, %d differ\n", manet_cases, manet_bad);
-  return (bad || manet_bad) ? 1 : 0;
+  if (steps_ok + steps_bad) std::printf("host_parity: %d step tests replayed through patched graphs (%d row-patch refreshes), %d differ\n", steps_ok + steps_bad, steps_patched, steps_bad);
+  return (bad || manet_bad || steps_bad) ? 1 : 0;
 }

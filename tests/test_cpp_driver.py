@@ -65,10 +65,12 @@ def test_cpp_host_side_reproduces_recorded_ribs_with_the_oracle_as_engine():
     from oracle import graph_oracle
     graph_oracle.build()
     _build_host()
-    r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so")] + VECTORS,
-                       capture_output=True, text=True, timeout=600)
+    r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so"),
+                        "--replay-steps", os.path.join(ROOT, "tests", "golden")] + VECTORS, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "125 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
+    # the reference's step tests replayed as snapshot + row patches (LevelGraph / AreaGraph refresh, GraphCache)
+    assert "30 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout
 
 
 def test_cpp_host_side_without_a_device_reports_it():
@@ -82,9 +84,11 @@ def test_cpp_host_side_without_a_device_reports_it():
 @pytest.mark.gpu
 def test_cpp_host_side_reproduces_recorded_ribs_on_gpu():
     _build_host()
-    r = subprocess.run([HOST, "--engine", "hip"] + VECTORS, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([HOST, "--engine", "hip", "--replay-steps", os.path.join(ROOT, "tests", "golden")] + VECTORS,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "125 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
+    assert "30 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout      # hspf_graph_patch
 
 
 def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_path):
