@@ -16,6 +16,7 @@
 #include <map>
 #include <optional>
 #include <set>
+#include <tuple>
 #include <utility>
 
 #include "holo_spf_host.hpp"
@@ -398,6 +399,240 @@ inline std::vector<RibRow> compute_spf_intra_area(const std::string &router_id, 
   }
   return rows;
 }
+
+// ---- OSPFv3 (holo-ospf/src/ospfv3/spf.rs) ----------------------------------------------------------------------------
+// Version-specific parts: VertexId { Network{router_id, iface_id}, Router{router_id} } (:38-42), vertex_lsa_find /
+// vertex_lsa_links over Router-LSA fragments with the R bit (and V6 bit for the IPv6 address family) (:286-419),
+// calc_nexthops through the neighbour's Link-LSA link-local address (:165-284, 593-612), intra_area_networks over
+// Intra-Area-Prefix LSAs (:421-478).  Python twin: holo_amd/ospfv3.py.
+namespace v3 {
+
+using VertexId = std::tuple<int, uint32_t, uint32_t>;          // (kind, router id, interface id — 0 for routers)
+struct RouterLink { std::string link_type; uint32_t iface_id = 0, nbr_iface_id = 0; std::string nbr_router_id; uint32_t metric = 0; };
+struct RouterLsa { std::string adv_rtr; uint32_t lsa_id = 0; std::vector<std::string> options; std::vector<RouterLink> links; bool maxage = false; };
+struct NetworkLsa { std::string adv_rtr; uint32_t lsa_id = 0; std::vector<std::string> attached; bool maxage = false; };
+struct Prefix { std::string prefix; uint32_t metric = 0; std::vector<std::string> options; };
+struct IntraAreaPrefixLsa { std::string adv_rtr; uint32_t lsa_id = 0; std::string ref_type; uint32_t ref_lsa_id = 0; std::string ref_adv_rtr; std::vector<Prefix> prefixes; bool maxage = false; };
+struct LinkLsa { std::string adv_rtr; uint32_t lsa_id = 0; std::string lladdr; };
+struct Interface { std::string name, if_type; int64_t index = 0; uint32_t iface_id = 0; std::vector<LinkLsa> link_lsas; };
+struct Area { std::string area_id; std::vector<RouterLsa> routers; std::vector<NetworkLsa> networks; std::vector<IntraAreaPrefixLsa> iaps; std::vector<Interface> interfaces; };
+
+using NexthopKey = std::tuple<int64_t, int, IpKey>;             // (iface arena index, 0 = None | 1 = Some, address)
+struct NexthopVal { std::string iface_name; std::optional<std::string> addr; };
+using Nexthops = std::map<NexthopKey, NexthopVal>;
+struct Vertex {
+  VertexId id;
+  std::vector<const RouterLsa *> rlsa;       // all fragments of a router vertex
+  const NetworkLsa *nlsa = nullptr;
+  uint32_t distance = 0;
+  uint16_t hops = 0;
+  Nexthops nexthops;
+};
+inline bool has_opt(const std::vector<std::string> &o, const char *x) { return std::find(o.begin(), o.end(), x) != o.end(); }
+
+class AreaGraph {
+ public:
+  const Area *area;
+  std::map<uint32_t, std::vector<const RouterLsa *>> routers;            // fragments in ascending LS-ID
+  std::map<std::pair<uint32_t, uint32_t>, const NetworkLsa *> networks;
+  std::vector<VertexId> vids;
+  std::map<VertexId, uint32_t> index;
+  std::vector<uint32_t> row_ptr, col, metric;
+  std::vector<const RouterLink *> link_ref;
+  std::vector<uint8_t> vflags;
+  AreaGraph(const Area &a, const std::string &af) : area(&a) {
+    std::vector<const RouterLsa *> sorted;
+    for (auto &l : a.routers) sorted.push_back(&l);
+    std::stable_sort(sorted.begin(), sorted.end(), [](const RouterLsa *x, const RouterLsa *y) { return std::make_pair(ip4(x->adv_rtr), x->lsa_id) < std::make_pair(ip4(y->adv_rtr), y->lsa_id); });
+    for (auto *l : sorted)
+      if (!l->maxage && has_opt(l->options, "r-bit") && (af != "ipv6" || has_opt(l->options, "v6-bit"))) routers[ip4(l->adv_rtr)].push_back(l);
+    for (auto &l : a.networks) if (!l.maxage) networks[{ip4(l.adv_rtr), l.lsa_id}] = &l;
+    for (auto &kv : networks) vids.push_back({NET, kv.first.first, kv.first.second});
+    for (auto &kv : routers) vids.push_back({RTR, kv.first, 0});
+    std::sort(vids.begin(), vids.end());
+    for (uint32_t i = 0; i < vids.size(); ++i) index[vids[i]] = i;
+    row_ptr.assign(vids.size() + 1, 0);
+    for (uint32_t i = 0; i < vids.size(); ++i) {
+      const VertexId vid = vids[i];
+      if (std::get<0>(vid) == NET) {
+        std::vector<uint32_t> att;
+        for (auto &x : networks[{std::get<1>(vid), std::get<2>(vid)}]->attached) att.push_back(ip4(x));
+        std::sort(att.begin(), att.end());
+        att.erase(std::unique(att.begin(), att.end()), att.end());
+        for (uint32_t r : att) { auto it = index.find({RTR, r, 0}); if (it != index.end()) { col.push_back(it->second); metric.push_back(0); link_ref.push_back(nullptr); } }
+      } else {
+        for (auto *frag : routers[std::get<1>(vid)])
+          for (auto &link : frag->links) {
+            const VertexId tid = (link.link_type == "point-to-point-link" || link.link_type == "virtual-link")
+                                     ? VertexId{RTR, ip4(link.nbr_router_id), 0} : VertexId{NET, ip4(link.nbr_router_id), link.nbr_iface_id};
+            auto it = index.find(tid);
+            if (it != index.end()) { col.push_back(it->second); metric.push_back(link.metric); link_ref.push_back(&link); }
+          }
+      }
+      row_ptr[i + 1] = (uint32_t)col.size();
+    }
+    for (auto &v : vids) vflags.push_back(std::get<0>(v) == NET ? HSPF_VF_NETWORK : 0);
+  }
+  Graph &device(Engine &e) {
+    if (!dev_ || dev_engine_ != &e) { dev_ = e.upload(row_ptr, col, metric, vflags, MAX_PATH_METRIC_OSPF); dev_engine_ = &e; }
+    return *dev_;
+  }
+ private:
+  std::unique_ptr<Graph> dev_;
+  Engine *dev_engine_ = nullptr;
+};
+
+inline std::optional<std::string> lladdr(const Interface &iface, uint32_t nbr_router_id, uint32_t nbr_iface_id) {   // ospfv3/spf.rs:593-612
+  for (auto &l : iface.link_lsas) if (ip4(l.adv_rtr) == nbr_router_id && l.lsa_id == nbr_iface_id) return l.lladdr;
+  return std::nullopt;
+}
+
+// Ospfv3::calc_nexthops for a hops == 0 parent and CSR entry k (ospfv3/spf.rs:165-284)
+inline std::optional<Nexthops> calc_nexthops(const AreaGraph &g, const Vertex &parent, uint32_t k, const VertexId &dest,
+                                             const std::vector<const RouterLsa *> *dest_rlsa) {
+  Nexthops out;
+  if (std::get<0>(parent.id) == RTR) {
+    const RouterLink *plink = g.link_ref[k];
+    const Interface *iface = nullptr;
+    for (auto &i : g.area->interfaces) if (i.iface_id == plink->iface_id) { iface = &i; break; }      // get_by_ifindex
+    if (!iface) return std::nullopt;
+    if (iface->if_type == "virtual-link") return out;
+    if (std::get<0>(dest) == RTR) {
+      auto addr = lladdr(*iface, ip4(plink->nbr_router_id), plink->nbr_iface_id);
+      if (!addr) return std::nullopt;
+      out[{iface->index, 1, parse_ip(*addr)}] = NexthopVal{iface->name, *addr};
+    } else {
+      out[{iface->index, 0, IpKey{}}] = NexthopVal{iface->name, std::nullopt};
+    }
+    return out;
+  }
+  // parent = network directly connecting the root to the destination router
+  const NetworkLsa *plsa = parent.nlsa;
+  const RouterLink *link = nullptr;
+  if (dest_rlsa)
+    for (auto *frag : *dest_rlsa) {
+      for (auto &l : frag->links) if (ip4(l.nbr_router_id) == ip4(plsa->adv_rtr) && l.nbr_iface_id == plsa->lsa_id) { link = &l; break; }
+      if (link) break;
+    }
+  if (!link || parent.nexthops.empty()) return std::nullopt;
+  const auto first = parent.nexthops.begin();
+  const int64_t idx = std::get<0>(first->first);
+  const Interface *iface = nullptr;
+  for (auto &i : g.area->interfaces) if (i.index == idx) { iface = &i; break; }
+  if (!iface) return std::nullopt;
+  auto addr = lladdr(*iface, std::get<1>(dest), link->iface_id);
+  if (!addr) return std::nullopt;
+  out[{idx, 1, parse_ip(*addr)}] = NexthopVal{iface->name, *addr};
+  return out;
+}
+
+using SptMap = std::map<VertexId, Vertex>;
+
+// holo-ospf/src/spf.rs:587-729 for V = Ospfv3
+inline std::optional<SptMap> run_area(const std::string &router_id, AreaGraph &g, Engine &engine) {
+  auto ri = g.index.find({RTR, ip4(router_id), 0});
+  if (ri == g.index.end()) return std::nullopt;
+  const uint32_t root = ri->second, n = (uint32_t)g.vids.size();
+  Graph &dev = g.device(engine);
+  const Tables res = engine.run(dev, {root}, HSPF_RUN_NET_NEXTHOPS);
+  const SlotTable st = engine.slot_table(dev, root);
+  const uint32_t W = res.mask_words;
+  SptMap spt;
+  std::map<uint32_t, std::optional<Nexthops>> slot_cache;
+  std::function<Vertex &(uint32_t)> vertex;
+  auto resolve_slot = [&](uint32_t s) -> const std::optional<Nexthops> & {
+    auto it = slot_cache.find(s);
+    if (it != slot_cache.end()) return it->second;
+    const size_t i = std::upper_bound(st.base.begin(), st.base.end(), s) - st.base.begin() - 1;
+    const uint32_t p = st.vertex[i], k = g.row_ptr[p] + (s - st.base[i]);
+    const VertexId tv = g.vids[g.col[k]];
+    const std::vector<const RouterLsa *> *dl = std::get<0>(tv) == RTR ? &g.routers.at(std::get<1>(tv)) : nullptr;
+    auto r = calc_nexthops(g, vertex(p), k, tv, dl);
+    return slot_cache[s] = std::move(r);
+  };
+  vertex = [&](uint32_t v) -> Vertex & {
+    const VertexId vid = g.vids[v];
+    auto it = spt.find(vid);
+    if (it != spt.end()) return it->second;
+    Vertex vx;
+    vx.id = vid;
+    if (std::get<0>(vid) == RTR) vx.rlsa = g.routers.at(std::get<1>(vid)); else vx.nlsa = g.networks.at({std::get<1>(vid), std::get<2>(vid)});
+    vx.distance = res.dist[v]; vx.hops = res.hops[v];
+    Vertex &ref = spt[vid] = std::move(vx);
+    for (uint32_t w = 0; w < W; ++w) {
+      uint64_t m = res.mask[(size_t)v * W + w];
+      while (m) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        const auto &nh = resolve_slot(w * 64 + b);
+        if (nh) for (auto &kv : *nh) ref.nexthops[kv.first] = kv.second;
+      }
+    }
+    return ref;
+  };
+  std::vector<uint32_t> members;
+  for (uint32_t v = 0; v < n; ++v) if (res.flags[v] & HSPF_RF_IN_SPT) members.push_back(v);
+  std::stable_sort(members.begin(), members.end(), [&](uint32_t a, uint32_t b) { return std::make_pair(res.dist[a], a) < std::make_pair(res.dist[b], b); });
+  for (uint32_t v : members) vertex(v);
+  return spt;
+}
+
+struct RouteNet { std::string prefix; uint32_t metric = 0, origin = 0; Nexthops nexthops; };
+
+// intra_area_networks (ospfv3/spf.rs:421-478) + update_rib_intra_area (route.rs:343-448)
+inline void update_rib_intra_area(std::map<IpKey, RouteNet> &rib, const Area &area, const SptMap &spt, uint32_t max_paths) {
+  std::vector<const IntraAreaPrefixLsa *> iaps;
+  for (auto &l : area.iaps) iaps.push_back(&l);
+  std::stable_sort(iaps.begin(), iaps.end(), [](auto *x, auto *y) { return std::make_pair(ip4(x->adv_rtr), x->lsa_id) < std::make_pair(ip4(y->adv_rtr), y->lsa_id); });
+  for (auto *lsa : iaps) {
+    if (lsa->maxage) continue;
+    SptMap::const_iterator vi = spt.end();
+    if (lsa->ref_type == "ospfv3-router-lsa") { if (lsa->ref_lsa_id == 0) vi = spt.find({RTR, ip4(lsa->ref_adv_rtr), 0}); }
+    else if (lsa->ref_type == "ospfv3-network-lsa") vi = spt.find({NET, ip4(lsa->ref_adv_rtr), lsa->ref_lsa_id});
+    if (vi == spt.end()) continue;
+    const Vertex &v = vi->second;
+    const bool is_net = std::get<0>(v.id) == NET;
+    const uint32_t origin = is_net ? v.nlsa->lsa_id : v.rlsa[0]->lsa_id;
+    for (auto &p : lsa->prefixes) {
+      if (has_opt(p.options, "nu-bit")) continue;
+      const IpKey key = parse_ip(p.prefix);
+      const uint64_t sum = (uint64_t)v.distance + p.metric;
+      const uint32_t metric = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum;
+      auto it = rib.find(key);
+      if (it != rib.end() && metric > it->second.metric) continue;
+      if (is_net && it != rib.end()) {
+        if (metric < it->second.metric || (metric == it->second.metric && origin > it->second.origin)) { rib.erase(it); it = rib.end(); }
+        else continue;
+      }
+      RouteNet *cur;
+      if (it == rib.end() || metric < it->second.metric) cur = &(rib[key] = RouteNet{p.prefix, metric, origin, v.nexthops});
+      else { cur = &it->second; for (auto &kv : v.nexthops) cur->nexthops[kv.first] = kv.second; }
+      while (cur->nexthops.size() > max_paths) cur->nexthops.erase(std::prev(cur->nexthops.end()));
+    }
+  }
+}
+
+inline std::vector<RibRow> compute_spf_intra_area(const std::string &router_id, const std::vector<Area> &areas, uint32_t max_paths,
+                                                  Engine &engine, const std::string &af = "ipv6") {
+  std::vector<const Area *> order;
+  for (auto &a : areas) order.push_back(&a);
+  std::stable_sort(order.begin(), order.end(), [](const Area *a, const Area *b) { return ip4(a->area_id) < ip4(b->area_id); });
+  std::map<IpKey, RouteNet> rib;
+  for (const Area *a : order) {
+    AreaGraph g(*a, af);
+    auto spt = run_area(router_id, g, engine);
+    if (spt) update_rib_intra_area(rib, *a, *spt, max_paths);
+  }
+  std::vector<RibRow> rows;
+  for (auto &kv : rib) {
+    RibRow r{kv.second.prefix, kv.second.metric, {}};
+    for (auto &n : kv.second.nexthops) r.nexthops.push_back({n.second.addr, n.second.iface_name});
+    rows.push_back(std::move(r));
+  }
+  return rows;
+}
+
+}  // namespace v3
 
 }  // namespace ospf
 }  // namespace host

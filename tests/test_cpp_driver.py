@@ -45,7 +45,8 @@ HOST = os.path.join(ROOT, "tests", "cpp", "host_parity")
 VECTORS = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "isis", "*.json")) +
                  glob.glob(os.path.join(ROOT, "tests", "golden", "isis_steps", "*.json")) +
                  glob.glob(os.path.join(ROOT, "tests", "golden", "ospfv2", "*.json")) +
-                 glob.glob(os.path.join(ROOT, "tests", "golden", "ospfv2_steps", "*.json")))
+                 glob.glob(os.path.join(ROOT, "tests", "golden", "ospfv2_steps", "*.json")) +
+                 glob.glob(os.path.join(ROOT, "tests", "golden", "ospfv3", "*.json")))
 
 
 def _build_host():
@@ -61,14 +62,14 @@ def _build_host():
 def test_cpp_host_side_reproduces_recorded_ribs_with_the_oracle_as_engine():
     """CPU: the compiled host side (LSDB -> CSR, slot replay through resolve_nexthop / calc_nexthops, route build) with
     the CPU oracle standing in for the ENGINE only; answers = the reference's recorded local RIBs (IS-IS 38 + 19 step
-    vectors, OSPFv2 57 + 11; the 6 virtual-link endpoints are skipped)."""
+    vectors, OSPFv2 57 + 11, OSPFv3 38; the 6 + 6 virtual-link endpoints are skipped)."""
     from oracle import graph_oracle
     graph_oracle.build()
     _build_host()
     r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so"),
                         "--replay-steps", os.path.join(ROOT, "tests", "golden")] + VECTORS, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "125 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
+    assert "163 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
     # the reference's step tests replayed as snapshot + row patches (LevelGraph / AreaGraph refresh, GraphCache)
     assert "30 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout
 
@@ -87,7 +88,7 @@ def test_cpp_host_side_reproduces_recorded_ribs_on_gpu():
     r = subprocess.run([HOST, "--engine", "hip", "--replay-steps", os.path.join(ROOT, "tests", "golden")] + VECTORS,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "125 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
+    assert "163 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
     assert "30 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout      # hspf_graph_patch
 
 
@@ -95,9 +96,10 @@ def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_
     """The compiled host side on random protocol-level inputs (tests/_random_isis.py, tests/_random_ospf.py): expected
     rows = the literal restatements' RIBs (oracle/isis_ref.py, oracle/ospf_ref.py), engine = the CPU oracle."""
     import json
-    from oracle import graph_oracle, isis_ref, ospf_ref
+    from oracle import graph_oracle, isis_ref, ospf_ref, ospfv3_ref
     from _random_isis import make as make_isis
     from _random_ospf import make as make_ospf
+    from _random_ospfv3 import make as make_ospfv3
     graph_oracle.build()
     _build_host()
     files = []
@@ -108,10 +110,13 @@ def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_
         w = make_ospf(seed)
         w["rib"] = ospf_ref.intra_area_rib(w)
         p = tmp_path / f"ospf_{seed}.json"; p.write_text(json.dumps(w)); files.append(str(p))
+        x = make_ospfv3(seed)
+        x["rib"] = ospfv3_ref.intra_area_rib(x)
+        p = tmp_path / f"ospfv3_{seed}.json"; p.write_text(json.dumps(x)); files.append(str(p))
     r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so")] + files,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr[-3000:]
-    assert "300 vectors reproduce" in r.stdout
+    assert "450 vectors reproduce" in r.stdout
 
 
 def test_cpp_flooding_manet_reflood_lists_against_the_literal_restatement(tmp_path):
