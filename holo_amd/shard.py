@@ -9,7 +9,7 @@ on GPUs, `gloo` in the CPU tests.
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Sequence, Tuple
 
 import numpy as np
 
