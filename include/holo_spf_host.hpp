@@ -12,6 +12,8 @@
 #include <utility>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "holo_spf_hip.h"
 
 namespace hspf {
@@ -30,6 +32,17 @@ class Graph {                         // one uploaded graph (device resident for
  public:
   virtual ~Graph() = default;
 };
+// Results of one run left where the engine produced them (HBM for the product engine): input of routes().
+class DeviceRun {
+ public:
+  virtual ~DeviceRun() = default;
+  virtual Tables host_tables() = 0;   // the copy the host side still needs for next-hop resolution
+  uint32_t n_roots = 0, n_vertices = 0, mask_words = 1;
+};
+struct RoutesOut {                    // per (root, prefix), row-major: see hspf_routes in holo_spf_hip.h
+  std::vector<uint32_t> best_metric, best_entry;
+  std::vector<uint64_t> nexthop_mask;
+};
 class Engine {
  public:
   virtual ~Engine() = default;
@@ -42,6 +55,11 @@ class Engine {
   virtual void patch(Graph &g, const std::vector<uint32_t> &vertices,
                      const std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> &rows,
                      const std::vector<uint8_t> &vflags) = 0;
+  // device-resident variant (hspf_run_device) + prefix attachment on the device (hspf_routes_device; table CSR by
+  // prefix, flags = HSPF_PFX_*)
+  virtual std::unique_ptr<DeviceRun> run_device(Graph &g, const std::vector<uint32_t> &roots, uint32_t run_flags) = 0;
+  virtual RoutesOut routes(DeviceRun &run, const std::vector<uint32_t> &pfx_ptr, const std::vector<uint32_t> &pfx_vertex,
+                           const std::vector<uint32_t> &pfx_metric, uint32_t flags) = 0;
 };
 
 // CSR with the rows of `vertices` (strictly ascending) replaced — the host-side twin of hspf_graph_patch.
@@ -129,6 +147,22 @@ class HipGraph : public Graph {
   hspf_ctx *ctx;
   hspf_graph *g;
 };
+class HipDeviceRun : public DeviceRun {             // dist / hops / flags / masks of one run in plain hipMalloc buffers
+ public:
+  ~HipDeviceRun() override { for (void *p : {(void *)dist, (void *)hops, (void *)flags, (void *)mask}) if (p) (void)hipFree(p); }
+  Tables host_tables() override {
+    Tables t;
+    t.n_roots = n_roots; t.n_vertices = n_vertices; t.mask_words = mask_words;
+    const size_t rn = (size_t)n_roots * n_vertices;
+    t.dist.resize(rn); t.hops.resize(rn); t.flags.resize(rn); t.mask.resize(rn * mask_words);
+    if (hipMemcpy(t.dist.data(), dist, rn * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(t.hops.data(), hops, rn * 2, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(t.flags.data(), flags, rn * 2, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(t.mask.data(), mask, rn * 8 * mask_words, hipMemcpyDeviceToHost) != hipSuccess)
+      throw std::runtime_error("hipMemcpy of the run tables failed");
+    return t;
+  }
+  uint32_t *dist = nullptr; uint16_t *hops = nullptr, *flags = nullptr; uint64_t *mask = nullptr;
+};
 class HipEngine : public Engine {
  public:
   explicit HipEngine(int device = 0) {
@@ -178,6 +212,44 @@ class HipEngine : public Engine {
     hspf_rows d{(uint32_t)vertices.size(), vertices.data(), rp.data(), c.data(), m.data(), vflags.data()};
     const int rc = hspf_graph_patch(ctx_, static_cast<HipGraph &>(gr).g, &d);
     if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_graph_patch: ") + hspf_last_error(ctx_));
+  }
+  std::unique_ptr<DeviceRun> run_device(Graph &gr, const std::vector<uint32_t> &roots, uint32_t run_flags) override {
+    hspf_graph *g = static_cast<HipGraph &>(gr).g;
+    auto r = std::make_unique<HipDeviceRun>();
+    r->n_roots = (uint32_t)roots.size(); r->n_vertices = hspf_graph_n_vertices(g);
+    int rc = hspf_mask_words(ctx_, g, roots.data(), r->n_roots, &r->mask_words);
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_mask_words: ") + hspf_last_error(ctx_));
+    const size_t rn = (size_t)r->n_roots * r->n_vertices;
+    if (hipMalloc((void **)&r->dist, rn * 4) != hipSuccess || hipMalloc((void **)&r->hops, rn * 2) != hipSuccess ||
+        hipMalloc((void **)&r->flags, rn * 2) != hipSuccess || hipMalloc((void **)&r->mask, rn * 8 * r->mask_words) != hipSuccess)
+      throw std::runtime_error("hipMalloc of the run tables failed");
+    hspf_result out{r->dist, r->hops, r->flags, r->mask, r->mask_words, nullptr};
+    rc = hspf_run_device(ctx_, g, roots.data(), r->n_roots, run_flags, &out);
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_run_device: ") + hspf_last_error(ctx_));
+    return r;
+  }
+  RoutesOut routes(DeviceRun &run, const std::vector<uint32_t> &pfx_ptr, const std::vector<uint32_t> &pfx_vertex,
+                   const std::vector<uint32_t> &pfx_metric, uint32_t flags) override {
+    auto &r = static_cast<HipDeviceRun &>(run);
+    const uint32_t P = (uint32_t)pfx_ptr.size() - 1;
+    RoutesOut o;
+    const size_t rp = (size_t)r.n_roots * P;
+    o.best_metric.assign(rp, 0xFFFFFFFFu); o.best_entry.assign(rp, 0xFFFFFFFFu); o.nexthop_mask.assign(rp * r.mask_words, 0);
+    if (P == 0) return o;
+    uint32_t *bm = nullptr, *be = nullptr; uint64_t *nm = nullptr;
+    if (hipMalloc((void **)&bm, rp * 4) != hipSuccess || hipMalloc((void **)&be, rp * 4) != hipSuccess || hipMalloc((void **)&nm, rp * 8 * r.mask_words) != hipSuccess)
+      throw std::runtime_error("hipMalloc of the route tables failed");
+    static const uint32_t zero = 0;
+    hspf_prefix_table tab{P, (uint32_t)pfx_vertex.size(), pfx_ptr.data(), pfx_vertex.empty() ? &zero : pfx_vertex.data(),
+                          pfx_metric.empty() ? &zero : pfx_metric.data(), flags};
+    hspf_routes ro{bm, be, nm};
+    const int rc = hspf_routes_device(ctx_, r.n_vertices, r.n_roots, r.mask_words, r.dist, r.flags, r.mask, &tab, &ro);
+    bool ok = rc == HSPF_OK && hipMemcpy(o.best_metric.data(), bm, rp * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+              hipMemcpy(o.best_entry.data(), be, rp * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+              hipMemcpy(o.nexthop_mask.data(), nm, rp * 8 * r.mask_words, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(bm); (void)hipFree(be); (void)hipFree(nm);
+    if (!ok) throw std::runtime_error(std::string("hspf_routes_device: ") + hspf_last_error(ctx_));
+    return o;
   }
  private:
   hspf_ctx *ctx_ = nullptr;

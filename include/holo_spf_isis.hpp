@@ -697,6 +697,113 @@ inline std::vector<RibRow> compute_spf(const Instance &inst, Engine &engine, Gra
   return rows;
 }
 
+// ---- route derivation with the prefix attachment on the device -------------------------------------
+// Every (vertex, prefix, metric) the unchanged vertex_networks() yields, vertices in VertexId order, as a CSR-by-prefix
+// table (root independent, built once per LSDB generation); hspf_routes_device reduces it for every root of a run.
+struct PrefixTable {
+  std::vector<std::string> prefixes;           // BTreeMap<IpNetwork, _> order
+  std::vector<uint32_t> pfx_ptr, pfx_vertex, pfx_metric;
+  std::vector<uint8_t> external;
+  static PrefixTable build(const Instance &inst, int level, int mt_id, const LevelGraph &g) {
+    const InstanceCfg &cfg = inst.config;
+    const bool l2_attached = inst.is_l2_attached_to_backbone(mt_id);
+    const bool v4 = cfg.ipv4_enabled && mt_id == MT_STANDARD;
+    const bool v6 = cfg.ipv6_enabled && (mt_id == MT_STANDARD ? !cfg.is_topology_enabled(MT_IPV6_UNICAST) : true);
+    struct Row { IpKey key; std::string prefix; uint32_t v, metric; bool ext; size_t seq; };
+    std::vector<Row> rows;
+    auto li = inst.lsdb.find(level);
+    if (li != inst.lsdb.end())
+      for (uint32_t v = 0; v < g.n(); ++v) {
+        const LanId lan = g.vids[v].lan_id;
+        const Lsp *z = li->second.zeroth_lsp(lan);
+        if (!z) continue;                                                        // spf.rs:866-869
+        const bool att = !cfg.att_ignore && z->att_bit(mt_id) && !z->overload_bit(mt_id);
+        for (auto &net : vertex_networks(inst, level, mt_id, lan, att, l2_attached, v4, v6))
+          rows.push_back({parse_ip(net.prefix), net.prefix, v, net.metric, net.external, rows.size()});
+      }
+    std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return std::tie(a.key, a.v, a.seq) < std::tie(b.key, b.v, b.seq); });
+    PrefixTable t;
+    t.pfx_ptr.push_back(0);
+    for (size_t i = 0; i < rows.size(); ++i) {
+      if (i == 0 || !(rows[i].key == rows[i - 1].key)) { if (i) t.pfx_ptr.push_back((uint32_t)i); t.prefixes.push_back(rows[i].prefix); }
+      t.pfx_vertex.push_back(rows[i].v); t.pfx_metric.push_back(rows[i].metric); t.external.push_back(rows[i].ext);
+    }
+    if (!rows.empty()) t.pfx_ptr.push_back((uint32_t)rows.size());
+    return t;
+  }
+};
+
+// compute_spf (spf.rs:719-836) with BOTH the SPT and the prefix attachment on the device; same rows as compute_spf.
+inline std::vector<RibRow> compute_spf_device_routes(const Instance &inst, Engine &engine) {
+  const InstanceCfg &cfg = inst.config;
+  std::map<int, std::map<IpKey, Route>> per_level;
+  for (int level : cfg.levels()) {
+    std::map<IpKey, Route> rib;
+    for (int mt_id : {MT_STANDARD, MT_IPV6_UNICAST}) {
+      if (!cfg.is_topology_enabled(mt_id)) continue;
+      auto g = std::make_shared<LevelGraph>(inst, level, mt_id, false);
+      auto ri = g->index.find(vertex_id(LanId{cfg.system_id, 0}));
+      if (ri == g->index.end()) continue;          // root without LSP: SPT = {root}, zeroth LSP missing -> no routes
+      const PrefixTable table = PrefixTable::build(inst, level, mt_id, *g);
+      if (table.prefixes.empty()) continue;
+      Graph &dev = g->device(engine);
+      const uint32_t root = ri->second, n = g->n();
+      auto run = engine.run_device(dev, {root}, g->run_flags);
+      const RoutesOut ro = engine.routes(*run, table.pfx_ptr, table.pfx_vertex, table.pfx_metric, 0);
+      auto res = std::make_shared<Tables>(run->host_tables());
+      const uint32_t W = res->mask_words;
+      detail::RunView r{res->dist.data(), res->hops.data(), res->flags.data(), res->mask.data(), W};
+      std::function<RankKey(uint32_t)> rank;
+      bool exact = false;
+      for (uint32_t v = 0; v < n; ++v) exact |= (res->flags[v] & HSPF_RF_EXACT) != 0;
+      std::shared_ptr<Tables> rr;
+      if (exact) {
+        rr = std::make_shared<Tables>(engine.run(dev, {root}, g->run_flags | HSPF_RUN_POP_RANK));
+        rank = [rr](uint32_t v) { return RankKey{rr->pop_rank[v], 0, 0, 0}; };
+      } else rank = [r](uint32_t v) { return RankKey{r.dist[v], v, 0, 0}; };
+      const auto slot_nh = detail::slot_nexthops(*g, engine.slot_table(dev, root), r, rank, true, level, inst);
+      for (size_t p = 0; p < table.prefixes.size(); ++p) {
+        if (ro.best_entry[p] == 0xFFFFFFFFu) continue;
+        const std::string &prefix = table.prefixes[p];
+        const uint32_t metric = ro.best_metric[p];
+        const bool is6 = prefix.find(':') != std::string::npos;
+        std::map<IpKey, Nexthop> nhs;
+        for (uint32_t w = 0; w < W; ++w) {
+          uint64_t m = ro.nexthop_mask[p * W + w];
+          while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            auto it = slot_nh.find(w * 64 + b);
+            if (it == slot_nh.end()) continue;
+            const auto &addr = is6 ? it->second->ipv6 : it->second->ipv4;
+            if (addr) nhs[parse_ip(*addr)] = Nexthop{*addr, it->second->iface_name.value_or(""), it->second->system_id};
+          }
+        }
+        const IpKey key = parse_ip(prefix);
+        auto it = rib.find(key);
+        Route *cur;
+        if (it == rib.end() || metric < it->second.metric) {
+          const uint32_t v = table.pfx_vertex[ro.best_entry[p]];
+          cur = &(rib[key] = Route{prefix, metric, level, (bool)table.external[ro.best_entry[p]], r.hops[v] == 0, nhs});
+        } else if (metric == it->second.metric) { cur = &it->second; for (auto &kv : nhs) cur->nexthops[kv.first] = kv.second; }
+        else continue;
+        while (cur->nexthops.size() > cfg.max_paths) cur->nexthops.erase(std::prev(cur->nexthops.end()));
+      }
+    }
+    per_level[level] = std::move(rib);
+  }
+  std::map<IpKey, Route> merged;
+  for (int level : {2, 1})
+    for (auto &kv : per_level[level]) merged[kv.first] = kv.second;
+  std::vector<RibRow> rows;
+  for (auto &kv : merged) {
+    RibRow row{kv.second.prefix, kv.second.metric, kv.second.level, {}};
+    for (auto &nh : kv.second.nexthops) row.nexthops.push_back({nh.second.addr, nh.second.iface_name});
+    rows.push_back(std::move(row));
+  }
+  return rows;
+}
+
 // ---- flooding::manet (holo-isis/src/flooding/manet.rs) ---------------------------------------------------------------
 namespace flooding {
 

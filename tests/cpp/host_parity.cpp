@@ -71,6 +71,38 @@ class OracleEngine : public Engine {
     ++patches;
   }
   int patches = 0;
+  struct OracleRun : DeviceRun { Tables t; Tables host_tables() override { return t; } };
+  std::unique_ptr<DeviceRun> run_device(Graph &gr, const std::vector<uint32_t> &roots, uint32_t run_flags) override {
+    auto r = std::make_unique<OracleRun>();
+    r->t = run(gr, roots, run_flags);
+    r->n_roots = r->t.n_roots; r->n_vertices = r->t.n_vertices; r->mask_words = r->t.mask_words;
+    return r;
+  }
+  // restatement of the per-prefix reduction of hspf_routes_device (include/holo_spf_hip.h)
+  RoutesOut routes(DeviceRun &run, const std::vector<uint32_t> &ptr, const std::vector<uint32_t> &vtx, const std::vector<uint32_t> &met, uint32_t flags) override {
+    const Tables &t = static_cast<OracleRun &>(run).t;
+    const uint32_t P = (uint32_t)ptr.size() - 1, W = t.mask_words, n = t.n_vertices;
+    RoutesOut o;
+    o.best_metric.assign((size_t)t.n_roots * P, 0xFFFFFFFFu); o.best_entry.assign((size_t)t.n_roots * P, 0xFFFFFFFFu); o.nexthop_mask.assign((size_t)t.n_roots * P * W, 0);
+    const bool sat = flags & HSPF_PFX_SATURATING, last = flags & HSPF_PFX_LAST_MIN;
+    for (uint32_t r = 0; r < t.n_roots; ++r)
+      for (uint32_t p = 0; p < P; ++p) {
+        uint32_t best = 0xFFFFFFFFu, ent = 0xFFFFFFFFu;
+        std::vector<uint64_t> acc(W, 0);
+        for (uint32_t e = ptr[p]; e < ptr[p + 1]; ++e) {
+          const size_t i = (size_t)r * n + vtx[e];
+          if (!(t.flags[i] & 1)) continue;
+          uint32_t m = t.dist[i] + met[e];
+          if (sat && m < t.dist[i]) m = 0xFFFFFFFFu;
+          if (ent == 0xFFFFFFFFu || m < best || (last && m == best)) { best = m; ent = e; for (uint32_t w = 0; w < W; ++w) acc[w] = t.mask[i * W + w]; }
+          else if (m == best) for (uint32_t w = 0; w < W; ++w) acc[w] |= t.mask[i * W + w];
+        }
+        const size_t oi = (size_t)r * P + p;
+        o.best_metric[oi] = best; o.best_entry[oi] = ent;
+        for (uint32_t w = 0; w < W; ++w) o.nexthop_mask[oi * W + w] = acc[w];
+      }
+    return o;
+  }
   Tables run(Graph &gr, const std::vector<uint32_t> &roots, uint32_t run_flags) override {
     auto &g = static_cast<OracleGraph &>(gr);
     Tables t;
@@ -395,7 +427,7 @@ int main(int argc, char **argv) {
       eng = std::make_unique<HipEngine>(0);
     } else eng = std::make_unique<OracleEngine>(oracle_so);
   } catch (const std::exception &e) { std::fprintf(stderr, "engine: %s\n", e.what()); return 1; }
-  int ok = 0, bad = 0, skipped = 0, manet_cases = 0, manet_bad = 0, steps_ok = 0, steps_bad = 0, steps_patched = 0;
+  int ok = 0, bad = 0, skipped = 0, manet_cases = 0, manet_bad = 0, steps_ok = 0, steps_bad = 0, steps_patched = 0, dev_ok = 0, dev_bad = 0;
   if (!check_hash_kat()) { std::fprintf(stderr, "flood_reduction_hash: reference vectors not reproduced\n"); return 1; }
   for (auto &path : files) {
     try {
@@ -423,6 +455,8 @@ int main(int argc, char **argv) {
       const I::Instance inst = instance_from_vector(vec);
       if (vec.has("manet")) { const int mb = check_manet(vec, inst, *eng, path); manet_cases += (int)vec["manet"].size(); manet_bad += mb; }
       const auto rows = I::compute_spf(inst, *eng);
+      // the same RIB with the prefix attachment done by the engine (hspf_run_device + hspf_routes_device)
+      if (rows_equal(I::compute_spf_device_routes(inst, *eng), vec["rib"])) ++dev_ok; else { ++dev_bad; std::fprintf(stderr, "DEVICE ROUTES MISMATCH %s\n", path.c_str()); }
       // recorded rows in BTreeMap<IpNetwork, _> order
       std::vector<const J *> want;
       for (auto &r : vec["rib"].arr) want.push_back(&r);
@@ -443,5 +477,6 @@ int main(int argc, char **argv) {
   std::printf("host_parity (%s engine): %d vectors reproduce the recorded local RIB, %d do not, %d skipped (virtual links)\n", engine.c_str(), ok, bad, skipped);
   if (manet_cases) std::printf("host_parity: %d reflood lists checked, %d differ\n", manet_cases, manet_bad);
   if (steps_ok + steps_bad) std::printf("host_parity: %d step tests replayed through patched graphs (%d row-patch refreshes), %d differ\n", steps_ok + steps_bad, steps_patched, steps_bad);
-  return (bad || manet_bad || steps_bad) ? 1 : 0;
+  if (dev_ok + dev_bad) std::printf("host_parity: %d IS-IS RIBs also derived with the prefix attachment on the engine, %d differ\n", dev_ok + dev_bad, dev_bad);
+  return (bad || manet_bad || steps_bad || dev_bad) ? 1 : 0;
 }

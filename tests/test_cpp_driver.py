@@ -72,6 +72,7 @@ def test_cpp_host_side_reproduces_recorded_ribs_with_the_oracle_as_engine():
     assert "163 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
     # the reference's step tests replayed as snapshot + row patches (LevelGraph / AreaGraph refresh, GraphCache)
     assert "30 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout
+    assert "57 IS-IS RIBs also derived with the prefix attachment on the engine, 0 differ" in r.stdout
 
 
 def test_cpp_host_side_without_a_device_reports_it():
@@ -90,6 +91,7 @@ def test_cpp_host_side_reproduces_recorded_ribs_on_gpu():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "163 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
     assert "30 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout      # hspf_graph_patch
+    assert "57 IS-IS RIBs also derived with the prefix attachment on the engine, 0 differ" in r.stdout     # hspf_routes_device
 
 
 def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_path):
