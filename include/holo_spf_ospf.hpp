@@ -400,6 +400,143 @@ inline std::vector<RibRow> compute_spf_intra_area(const std::string &router_id, 
   return rows;
 }
 
+// ---- update_rib_intra_area with the prefix attachment on the device ------------------------------------
+// Two CSR-by-prefix tables per area (root independent): `net` = the prefixes of Network-LSA vertices (metric 0), `stub`
+// = the stub links of Router-LSA vertices in the order intra_area_networks() yields them.  Two tables because the two
+// vertex kinds follow different tie rules (HSPF_PFX_LAST_MIN, include/holo_spf_hip.h) and all networks precede all
+// routers in VertexId order; their per-prefix results are folded into the RIB in that order with the unchanged compare.
+struct PrefixTables {
+  std::vector<IpKey> keys;
+  std::vector<std::string> prefixes;
+  struct Tab { std::vector<uint32_t> ptr, vertex, metric; } net, stub;
+  static PrefixTables build(const AreaGraph &g) {
+    struct Row { IpKey key; std::string prefix; uint32_t v, metric; size_t seq; };
+    std::vector<Row> rn, rs;
+    auto mk = [](uint32_t id, uint32_t mask, IpKey &key, std::string &text) {
+      bool valid = true;
+      const int len = mask_len(mask, valid);
+      if (!valid) return false;
+      const uint32_t net = len == 0 ? 0 : (id & (0xFFFFFFFFu << (32 - len)));
+      key = IpKey{}; key.version = 4; key.len = len;
+      key.addr[12] = net >> 24; key.addr[13] = net >> 16; key.addr[14] = net >> 8; key.addr[15] = net;
+      text = ip4_str(net) + "/" + std::to_string(len);
+      return true;
+    };
+    for (uint32_t v = 0; v < g.vids.size(); ++v) {
+      IpKey key; std::string text;
+      if (g.vids[v].first == NET) {
+        const NetworkLsa *l = g.networks.at(g.vids[v].second);
+        if (mk(ip4(l->lsa_id), ip4(l->mask), key, text)) rn.push_back({key, text, v, 0, rn.size()});
+      } else {
+        for (auto &link : g.routers.at(g.vids[v].second)->links)
+          if (link.link_type == "stub-network-link" && mk(ip4(link.link_id), ip4(link.link_data), key, text)) rs.push_back({key, text, v, link.metric, rs.size()});
+      }
+    }
+    PrefixTables t;
+    std::map<IpKey, std::string> all;
+    for (auto &r : rn) all.emplace(r.key, r.prefix);
+    for (auto &r : rs) all.emplace(r.key, r.prefix);
+    std::map<IpKey, uint32_t> pid;
+    for (auto &kv : all) { pid[kv.first] = (uint32_t)t.keys.size(); t.keys.push_back(kv.first); t.prefixes.push_back(kv.second); }
+    auto fill = [&](std::vector<Row> &rows, Tab &tab) {
+      std::stable_sort(rows.begin(), rows.end(), [&](const Row &a, const Row &b) { return std::make_tuple(pid[a.key], a.v, a.seq) < std::make_tuple(pid[b.key], b.v, b.seq); });
+      tab.ptr.assign(t.keys.size() + 1, 0);
+      for (auto &r : rows) tab.ptr[pid[r.key] + 1]++;
+      for (size_t i = 0; i < t.keys.size(); ++i) tab.ptr[i + 1] += tab.ptr[i];
+      for (auto &r : rows) { tab.vertex.push_back(r.v); tab.metric.push_back(r.metric); }
+    };
+    fill(rn, t.net); fill(rs, t.stub);
+    return t;
+  }
+};
+
+// run_area + update_rib_intra_area of one area with the SPT and both prefix reductions on the engine; folds the
+// per-prefix results into `rib` (shared by the areas, route.rs:146-160).
+inline void area_device_routes(const std::string &router_id, AreaGraph &g, Engine &engine, std::map<IpKey, RouteNet> &rib, uint32_t max_paths) {
+  auto ri = g.index.find({RTR, ip4(router_id)});
+  if (ri == g.index.end()) return;
+  const uint32_t root = ri->second;
+  const PrefixTables tables = PrefixTables::build(g);
+  Graph &dev = g.device(engine);
+  auto run = engine.run_device(dev, {root}, HSPF_RUN_NET_NEXTHOPS);
+  const RoutesOut rn = engine.routes(*run, tables.net.ptr, tables.net.vertex, tables.net.metric, HSPF_PFX_SATURATING | HSPF_PFX_LAST_MIN);
+  const RoutesOut rs = engine.routes(*run, tables.stub.ptr, tables.stub.vertex, tables.stub.metric, HSPF_PFX_SATURATING);
+  const Tables res = run->host_tables();
+  const uint32_t W = res.mask_words;
+  const SlotTable st = engine.slot_table(dev, root);
+  // slot -> next hops: the hops == 0 parents are materialised in distance order, as in run_area
+  std::map<uint32_t, Vertex> verts;
+  std::map<uint32_t, std::optional<Nexthops>> slot_cache;
+  std::function<Vertex &(uint32_t)> vertex;
+  std::function<const std::optional<Nexthops> &(uint32_t)> resolve_slot = [&](uint32_t s) -> const std::optional<Nexthops> & {
+    auto it = slot_cache.find(s);
+    if (it != slot_cache.end()) return it->second;
+    const size_t i = std::upper_bound(st.base.begin(), st.base.end(), s) - st.base.begin() - 1;
+    const uint32_t p = st.vertex[i], k = g.row_ptr[p] + (s - st.base[i]);
+    const VertexId tv = g.vids[g.col[k]];
+    auto r = calc_nexthops(g, vertex(p), k, tv, tv.first == RTR ? g.routers.at(tv.second) : nullptr);
+    return slot_cache[s] = std::move(r);
+  };
+  vertex = [&](uint32_t v) -> Vertex & {
+    auto it = verts.find(v);
+    if (it != verts.end()) return it->second;
+    Vertex vx;
+    vx.id = g.vids[v];
+    if (vx.id.first == RTR) vx.rlsa = g.routers.at(vx.id.second); else vx.nlsa = g.networks.at(vx.id.second);
+    vx.distance = res.dist[v]; vx.hops = res.hops[v];
+    Vertex &ref = verts[v] = std::move(vx);
+    for (uint32_t w = 0; w < W; ++w) {
+      uint64_t m = res.mask[(size_t)v * W + w];
+      while (m) { const int b = __builtin_ctzll(m); m &= m - 1; const auto &nh = resolve_slot(w * 64 + b); if (nh) for (auto &kv : *nh) ref.nexthops[kv.first] = kv.second; }
+    }
+    return ref;
+  };
+  auto expand = [&](const uint64_t *mrow) {
+    Nexthops out;
+    for (uint32_t w = 0; w < W; ++w) {
+      uint64_t m = mrow[w];
+      while (m) { const int b = __builtin_ctzll(m); m &= m - 1; const auto &nh = resolve_slot(w * 64 + b); if (nh) for (auto &kv : *nh) out[kv.first] = kv.second; }
+    }
+    return out;
+  };
+  for (size_t p = 0; p < tables.keys.size(); ++p) {
+    const IpKey &key = tables.keys[p];
+    for (int kind = 0; kind < 2; ++kind) {                       // networks before routers: VertexId order
+      const RoutesOut &ro = kind == 0 ? rn : rs;
+      const PrefixTables::Tab &tab = kind == 0 ? tables.net : tables.stub;
+      if (ro.best_entry[p] == 0xFFFFFFFFu) continue;
+      const uint32_t v = tab.vertex[ro.best_entry[p]], metric = ro.best_metric[p];
+      const uint32_t origin = kind == 0 ? ip4(g.networks.at(g.vids[v].second)->lsa_id) : ip4(g.routers.at(g.vids[v].second)->adv_rtr);
+      auto it = rib.find(key);
+      if (it != rib.end() && metric > it->second.metric) continue;
+      if (kind == 0 && it != rib.end()) {                        // route.rs:388-400
+        if (metric < it->second.metric || (metric == it->second.metric && origin > it->second.origin)) { rib.erase(it); it = rib.end(); }
+        else continue;
+      }
+      Nexthops nhs = expand(&ro.nexthop_mask[p * W]);
+      RouteNet *cur;
+      if (it == rib.end() || metric < it->second.metric) cur = &(rib[key] = RouteNet{tables.prefixes[p], metric, origin, res.hops[v] == 0, nhs});
+      else { cur = &it->second; for (auto &kv : nhs) cur->nexthops[kv.first] = kv.second; }
+      while (cur->nexthops.size() > max_paths) cur->nexthops.erase(std::prev(cur->nexthops.end()));
+    }
+  }
+}
+
+inline std::vector<RibRow> intra_area_device_routes(const std::string &router_id, const std::vector<Area> &areas, uint32_t max_paths, Engine &engine) {
+  std::vector<const Area *> order;
+  for (auto &a : areas) order.push_back(&a);
+  std::stable_sort(order.begin(), order.end(), [](const Area *a, const Area *b) { return ip4(a->area_id) < ip4(b->area_id); });
+  std::map<IpKey, RouteNet> rib;
+  for (const Area *a : order) { AreaGraph g(*a); area_device_routes(router_id, g, engine, rib, max_paths); }
+  std::vector<RibRow> rows;
+  for (auto &kv : rib) {
+    RibRow r{kv.second.prefix, kv.second.metric, {}};
+    for (auto &n : kv.second.nexthops) r.nexthops.push_back({n.second.addr, n.second.iface_name});
+    rows.push_back(std::move(r));
+  }
+  return rows;
+}
+
 // ---- OSPFv3 (holo-ospf/src/ospfv3/spf.rs) ----------------------------------------------------------------------------
 // Version-specific parts: VertexId { Network{router_id, iface_id}, Router{router_id} } (:38-42), vertex_lsa_find /
 // vertex_lsa_links over Router-LSA fragments with the R bit (and V6 bit for the IPv6 address family) (:286-419),

@@ -234,6 +234,7 @@ static std::vector<O::Area> areas_from_vector(const J &vec) {        // schema o
 
 // OSPFv2 vector: intra-area rows of the recorded local RIB (virtual-link endpoints are completed after the path by
 // area::update_virtual_links and are left to the Python suite's literal restatement)
+static bool ospf_rows_equal(const std::vector<O::RibRow> &rows, const J &rib);
 static int check_ospf(const J &vec, Engine &eng, const std::string &path) {
   if (vec["has_vlinks"].b) return -1;
   const auto areas = areas_from_vector(vec);
@@ -253,6 +254,11 @@ static int check_ospf(const J &vec, Engine &eng, const std::string &path) {
     if (!same) std::fprintf(stderr, "MISMATCH %s row %zu: %s metric %u (%zu next hops)\n", path.c_str(), i, rows[i].prefix.c_str(), rows[i].metric, rows[i].nexthops.size());
   }
   if (want.size() != rows.size()) std::fprintf(stderr, "MISMATCH %s: %zu rows, recorded %zu\n", path.c_str(), rows.size(), want.size());
+  // the same RIB with both prefix reductions done by the engine (hspf_routes_device, OSPF rule flags)
+  if (same && !ospf_rows_equal(O::intra_area_device_routes(vec["router_id"].s, areas, (uint32_t)vec["max_paths"].i(), eng), vec["rib"])) {
+    std::fprintf(stderr, "DEVICE ROUTES MISMATCH %s\n", path.c_str());
+    return 0;
+  }
   return same ? 1 : 0;
 }
 
