@@ -121,15 +121,11 @@ def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_
     assert "450 vectors reproduce" in r.stdout
 
 
-def test_cpp_flooding_manet_reflood_lists_against_the_literal_restatement(tmp_path):
-    """flooding::manet in the compiled host side (init_cache = one batched hop-count run, reflood_list, the hash pinned by
-    the reference's unit-test vectors inside the driver): expected lists = oracle/isis_ref.py on recorded topologies and on
-    random instances; engine = the CPU oracle."""
+def _manet_case_files(tmp_path):
+    """Vectors with "manet" cases (expected reflood lists from oracle/isis_ref.py) for the C++ driver."""
     import json
-    from oracle import graph_oracle, isis_ref
+    from oracle import isis_ref
     from _random_isis import make as make_isis
-    graph_oracle.build()
-    _build_host()
     algos = {"zero-pruner": None, "modified-manet": lambda s: "modified-manet",
              "mixed": lambda s: "modified-manet" if s[-1] & 1 else "zero-pruner"}
     vecs = [json.load(open(p)) for p in VECTORS if os.sep + "isis" + os.sep in p][::3] + [make_isis(s) for s in range(4000, 4040)]
@@ -153,7 +149,28 @@ def test_cpp_flooding_manet_reflood_lists_against_the_literal_restatement(tmp_pa
             v["rib"] = isis_ref.local_rib(v)
         n_cases += len(cases)
         p = tmp_path / f"m{i}.json"; p.write_text(json.dumps(v)); files.append(str(p))
+    return files, n_cases
+
+
+def test_cpp_flooding_manet_reflood_lists_against_the_literal_restatement(tmp_path):
+    """flooding::manet in the compiled host side (init_cache = one batched hop-count run, reflood_list, the hash pinned by
+    the reference's unit-test vectors inside the driver): expected lists = oracle/isis_ref.py on recorded topologies and on
+    random instances; engine = the CPU oracle."""
+    from oracle import graph_oracle
+    graph_oracle.build()
+    _build_host()
+    files, n_cases = _manet_case_files(tmp_path)
     r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so")] + files,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr[-3000:]
     assert f"{n_cases} reflood lists checked, 0 differ" in r.stdout and n_cases > 500
+
+
+@pytest.mark.gpu
+def test_cpp_flooding_manet_reflood_lists_on_gpu(tmp_path):
+    """The same reflood lists with the hop-count SPTs of every neighbour computed by ONE batched run of the product engine."""
+    _build_host()
+    files, n_cases = _manet_case_files(tmp_path)
+    r = subprocess.run([HOST, "--engine", "hip"] + files, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    assert f"{n_cases} reflood lists checked, 0 differ" in r.stdout
