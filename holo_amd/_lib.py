@@ -35,7 +35,8 @@ class HspfStats(ctypes.Structure):
                 ("n_exact_roots", ctypes.c_uint32), ("n_mask_words", ctypes.c_uint32),
                 ("ms_total", ctypes.c_float), ("ms_relax", ctypes.c_float), ("ms_dag", ctypes.c_float),
                 ("ms_finish", ctypes.c_float), ("ms_d2h", ctypes.c_float),
-                ("state_bytes", ctypes.c_uint32), ("narrow_overflow", ctypes.c_uint32)]
+                ("state_bytes", ctypes.c_uint32), ("narrow_overflow", ctypes.c_uint32),
+                ("rows_recomputed", ctypes.c_uint64)]
 
 
 class HspfPrefixTable(ctypes.Structure):

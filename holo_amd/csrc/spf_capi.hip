@@ -84,7 +84,7 @@ struct hspf_ctx {
   std::string last_error;
   hipEvent_t ev[6] = {};
   // scratch (grown on demand, reused across runs)
-  DevBuf dist, hv, mask, lane_flags, changed, st64, stamp, hnb;
+  DevBuf dist, hv, mask, lane_flags, changed, st64, stamp, hnb, kcnt;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met;                    // prefix table of hspf_routes_device
@@ -102,7 +102,7 @@ struct hspf_ctx {
   size_t h_up_cap = 0;             // bytes
   std::vector<uint32_t> mark;      // visited stamps of build_slot_table, kept across calls (no O(n) fill per run)
   uint32_t mark_epoch = 0;
-  uint32_t *h_lane_flags = nullptr; // pinned
+  uint32_t *h_lane_flags = nullptr; // pinned: per-root status bits, then the 256 rows_done words of the fused kernel
   size_t h_lane_cap = 0;
   uint32_t est_relax = 12, est_dag = 12, est_fused = 12;   // launch-ahead estimates (adapted run to run)
   uint32_t variant = 0;                    // HSPF_VARIANT env: kernel A/B switches (tuning only)
@@ -337,7 +337,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->gb, &ctx->gb_delta})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->gb, &ctx->gb_delta, &ctx->kcnt})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
@@ -640,7 +640,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
         acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
         acc.ms_d2h += p.ms_d2h; acc.state_bytes = std::max(acc.state_bytes, p.state_bytes);
-        acc.narrow_overflow += p.narrow_overflow;
+        acc.narrow_overflow += p.narrow_overflow; acc.rows_recomputed += p.rows_recomputed;
       }
       ctx->stats = acc;
       return HSPF_OK;
@@ -745,9 +745,13 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if (ctx->h_lane_cap < L) {
     if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
     ctx->h_lane_flags = nullptr; ctx->h_lane_cap = 0;
-    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lane_flags, (size_t)L * 4, hipHostMallocDefault));
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lane_flags, ((size_t)L + 256) * 4, hipHostMallocDefault));
     ctx->h_lane_cap = L;
   }
+  // work counter of the fused kernel (HSPF_RUN_COUNT_ROWS): [256] rows recomputed
+  if ((rc = ensure(ctx, ctx->kcnt, 256 * 4))) return rc;
+  uint32_t *d_kcnt = (uint32_t *)ctx->kcnt.p;
+  const bool count_rows = (run_flags & HSPF_RUN_COUNT_ROWS) != 0;
   // row-major output targets (device): the caller's device buffers, or staging for host output
   OutDev od{};
   const size_t rn = (size_t)total_rows * n;               // rows of the output arrays (== n_roots unless mapped)
@@ -786,7 +790,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     std::copy(tab_vtx.begin(), tab_vtx.end(), h + w_vtx);
     std::copy(tab_base.begin(), tab_base.end(), h + w_base);
     for (uint32_t r = 0; r < L; ++r) h[w_map + r] = (row_map && r < n_roots) ? row_map[r] : r;
-    const FusedGraph fg{gd, tabs};
+    const FusedGraph fg{gd, tabs, d_kcnt, {0u, 0u}};
     memcpy(h + w_fg, &fg, sizeof(FusedGraph));
     HIPCHK(ctx, hipMemcpyAsync(d_up, h, up_bytes, hipMemcpyHostToDevice, s));
     // the pinned block belongs to the ctx and is rewritten by the next run only, after this one has synchronised
@@ -843,6 +847,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       }
       er = hipMemcpyAsync(ctx->h_changed, d_changed, (size_t)sweep * sizeof(int), hipMemcpyDeviceToHost, s);
       if (er == hipSuccess) er = hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s);
+      if (er == hipSuccess && fused && count_rows) er = hipMemcpyAsync(ctx->h_lane_flags + L, d_kcnt, 256 * 4, hipMemcpyDeviceToHost, s);
       if (er == hipSuccess) er = hipStreamSynchronize(s);
       if (er != hipSuccess) { ctx->last_error = std::string("phase: ") + hipGetErrorString(er); return HSPF_E_HIP; }
       if (ctx->h_changed[sweep - 1] == 0) break;
@@ -864,6 +869,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       hipError_t er = hipMemsetAsync(d_lf, 0, (size_t)L * 4, s);
       if (er == hipSuccess) er = hipMemsetAsync(d_st, 0xFF, rows * esz, s);
       if (er == hipSuccess) er = hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s);
+      if (er == hipSuccess && count_rows) er = hipMemsetAsync(d_kcnt, 0, 256 * 4, s);
       if (er != hipSuccess) { ctx->last_error = std::string("fused init: ") + hipGetErrorString(er); return HSPF_E_HIP; }
       hipLaunchKernelGGL(k_fill_rowflags, dim3((unsigned)(((size_t)B * n + 255) / 256)), dim3(256), 0, s, n, B, g->d_rowflags, (uint8_t *)ctx->hnb.p);
       if (nar) hipLaunchKernelGGL((k_init_fused<uint32_t>), dim3((L + 255) / 256), dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
@@ -871,9 +877,17 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       uint32_t n_f = 0;
       const bool maxinf = g->max_path_metric == HSPF_DIST_INF;
       int r2 = run_phase(ctx->est_fused, [&](uint32_t sweep) {
-        if (nar)         hipLaunchKernelGGL((k_fused<uint32_t, false>), fgrid, dim3(256), 0, s, d_fg, (uint32_t *)d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
-        else if (maxinf) hipLaunchKernelGGL((k_fused<uint64_t, true>), fgrid, dim3(256), 0, s, d_fg, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
-        else             hipLaunchKernelGGL((k_fused<uint64_t, false>), fgrid, dim3(256), 0, s, d_fg, d_st, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf);
+#define HSPF_LAUNCH_FUSED(ST_, MI_, CN_, stp_) hipLaunchKernelGGL((k_fused<ST_, MI_, CN_>), fgrid, dim3(256), 0, s, d_fg, stp_, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf)
+        if (count_rows) {
+          if (nar)         HSPF_LAUNCH_FUSED(uint32_t, false, true, (uint32_t *)d_st);
+          else if (maxinf) HSPF_LAUNCH_FUSED(uint64_t, true, true, d_st);
+          else             HSPF_LAUNCH_FUSED(uint64_t, false, true, d_st);
+        } else {
+          if (nar)         HSPF_LAUNCH_FUSED(uint32_t, false, false, (uint32_t *)d_st);
+          else if (maxinf) HSPF_LAUNCH_FUSED(uint64_t, true, false, d_st);
+          else             HSPF_LAUNCH_FUSED(uint64_t, false, false, d_st);
+        }
+#undef HSPF_LAUNCH_FUSED
       }, n_f, [&]() {
         // results out of the packed state (speculative: valid when this chunk reached the fixed point and, for the
         // 4-byte state, no lane overflowed; otherwise redone behind the next chunk / the wide run)
@@ -885,6 +899,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       if (r2) return r2;
       ctx->est_fused = n_f + 1;
       st.n_relax_launches += n_f;
+      if (count_rows) for (uint32_t i = 0; i < 256; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
       return HSPF_OK;
     };
     if (narrow) {
@@ -1084,6 +1099,7 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
     acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
     acc.state_bytes = std::max(acc.state_bytes, p.state_bytes); acc.narrow_overflow += p.narrow_overflow;
+    acc.rows_recomputed += p.rows_recomputed;
   }
   if (host_out) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));

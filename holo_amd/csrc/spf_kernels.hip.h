@@ -435,7 +435,11 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
 // Memory-level parallelism: the link vectors of all VPW vertices are fetched up front and ALL
 // neighbour rows of a row are requested before the first one is consumed (profiles/r01b notes:
 // the first versions, 4 rows per round trip, ran at exactly waves/resident x 12 x loaded latency).
-struct FusedGraph { GraphDev g; SlotTabs tabs; };   // device-resident descriptor of one run
+// rows_done: [256] work counter of a run launched with HSPF_RUN_COUNT_ROWS (the COUNT instantiation of k_fused): rows
+// evaluated, spread over 256 words and summed by the host (hspf_stats.rows_recomputed).  Not touched otherwise: even
+// one fire-and-forget atomic per wave behind a scalar pointer load measurably lengthens the ~10 us life of a wave
+// (profiles/r02_notes.md: 0.93 vs 0.85 ms per batch).
+struct FusedGraph { GraphDev g; SlotTabs tabs; uint32_t *rows_done; uint32_t pad_[2]; };   // device-resident descriptor of one run
 
 struct FusedParams {
   uint32_t sh;        // bit position of the dist field (narrow) / 0 (wide: dist is the high word)
@@ -725,7 +729,7 @@ constexpr int FQ = 1;          // measured: FQ = 4 makes sparse sweeps cheaper (
 constexpr int FVPW = FQ * VPW;                    // vertices per wave (<= 63: one lane per vertex + 1)
 constexpr int FVPB = WAVES_PER_BLOCK * FVPW;      // vertices per block of the fused kernel
 
-template <typename ST, bool MAXINF>
+template <typename ST, bool MAXINF, bool COUNT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fused(
     const FusedGraph *__restrict__ gp, ST *__restrict__ st, uint32_t *__restrict__ act,
     const uint8_t *__restrict__ hnb, const uint32_t *__restrict__ roots, FusedParams P,
@@ -766,6 +770,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   const uint32_t lvo = lane * (uint32_t)sizeof(ST);
   const uint32_t lane4 = lane * 4u;
   bool any = false, sat = false, need_exact = false, ovf = false;
+  uint32_t n_done = 0;                                            // COUNT only: rows this wave evaluated
 #pragma unroll 1
   for (uint32_t q = 0; q < (uint32_t)FQ; ++q) {
     if (((due >> (q * VPW)) & ((1ull << VPW) - 1ull)) == 0ull) continue;   // nothing due in this quad
@@ -814,6 +819,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
       ovf = ovf || r.ovf;
       const bool ch = r.nw != StIO<ST>::bits(oldq[i]);
       if (ch) { S[(size_t)v * 64 + lane] = r.nw; any = true; }
+      if (COUNT) ++n_done;
       if (__ballot(ch) != 0ull) {                                 // wake the out-neighbours up
         __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, odv[i], 0, 0);
         const uint32_t o0 = rdlane(po, lb + i), o1 = rdlane(po, lb + i + 1);
@@ -826,6 +832,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
     row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
   }
   if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
+  if (COUNT && lane == 0) atomicAdd(&gp->rows_done[(blockIdx.x + wave) & 255u], n_done);
   uint32_t lf = 0;
   if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
   if (ovf) lf |= LF_OVERFLOW;

@@ -19,6 +19,7 @@ RUN_NET_NEXTHOPS = 0x01
 RUN_IGNORE_OVERLOAD = 0x02
 RUN_FORCE_EXACT = 0x04
 RUN_POP_RANK = 0x08
+RUN_COUNT_ROWS = 0x10
 
 PFX_SATURATING = 0x1
 PFX_LAST_MIN = 0x2

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HSPF_ABI_VERSION 2u
+#define HSPF_ABI_VERSION 3u
 
 /* ---- error codes ------------------------------------------------------------------- */
 #define HSPF_OK                 0
@@ -73,6 +73,9 @@ extern "C" {
 #define HSPF_RUN_FORCE_EXACT      0x04u
 /* Also produce hspf_result.pop_rank.                                                        */
 #define HSPF_RUN_POP_RANK         0x08u
+/* Count the rows the fused fixed point evaluates (hspf_stats.rows_recomputed).  A diagnostic: the counting
+ * instantiation of the kernel is a few per cent slower, the results are the same.                           */
+#define HSPF_RUN_COUNT_ROWS       0x10u
 
 /* ---- per-(root,vertex) result flags (hspf_result.vflags_out) --------------------------- */
 #define HSPF_RF_IN_SPT   0x0001u    /* vertex was popped into the SPT                         */
@@ -150,6 +153,9 @@ typedef struct {
   float    ms_d2h;             /* only for hspf_run(): device->host copies                    */
   uint32_t state_bytes;        /* per-(vertex,root) state of the fused path: 4 or 8; 0 = two-phase path */
   uint32_t narrow_overflow;    /* 1: the 4-byte state overflowed and the run was redone with 8 bytes   */
+  uint64_t rows_recomputed;    /* HSPF_RUN_COUNT_ROWS: (vertex, 64-root batch) rows the fused fixed point evaluated, summed
+                                  over its launches (0 without the flag); the reference settles each vertex once per root
+                                  (holo-isis/src/spf.rs:552-556), i.e. n_batches * n_vertices rows would be 1x */
 } hspf_stats;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
