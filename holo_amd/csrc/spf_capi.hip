@@ -106,6 +106,8 @@ struct hspf_ctx {
   size_t h_lane_cap = 0;
   uint32_t est_relax = 12, est_dag = 12, est_fused = 12;   // launch-ahead estimates (adapted run to run)
   uint32_t variant = 0;                    // HSPF_VARIANT env: kernel A/B switches (tuning only)
+  bool single_attr = false;                // k_single's dynamic-LDS attribute has been set
+  uint32_t single_max_n = 4096;            // HSPF_SINGLE_MAX_N env: largest graph that takes the one-workgroup-per-root kernel
   hspf_stats stats = {};
 };
 
@@ -320,6 +322,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   if (!ctx) return HSPF_E_NOMEM;
   ctx->device = device_ordinal;
   if (const char *v = getenv("HSPF_VARIANT")) ctx->variant = (uint32_t)strtoul(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_SINGLE_MAX_N")) ctx->single_max_n = (uint32_t)strtoul(v, nullptr, 0);
   if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return HSPF_E_NODEV; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
   for (auto &e : ctx->ev)
@@ -902,14 +905,46 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       if (count_rows) for (uint32_t i = 0; i < 256; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
       return HSPF_OK;
     };
-    if (narrow) {
+    // Small graphs: one workgroup per root, the whole state in LDS, ONE launch (k_single) instead of a launch per sweep.
+    // Chosen by size alone: up to ctx->single_max_n vertices (HSPF_SINGLE_MAX_N, default 4096; 0 switches it off) a run
+    // of the in-LDS fixed point is shorter than the ~50 kernel boundaries of the sweep engine whatever the number of roots.
+    const bool single = n <= std::min(ctx->single_max_n, SINGLE_MAX_N) && g->e_kept <= SINGLE_MAX_E;
+    if (single) {
+      hipError_t er = hipMemsetAsync(d_lf, 0, (size_t)L * 4, s);
+      if (er == hipSuccess && count_rows) er = hipMemsetAsync(d_kcnt, 0, 256 * 4, s);
+      if (er != hipSuccess) { ctx->last_error = std::string("single init: ") + hipGetErrorString(er); return HSPF_E_HIP; }
+      // the link records are staged in LDS when they fit next to the state; with many roots only while two workgroups
+      // still fit a CU (the staging itself is a pass over the links per root)
+      const size_t lds_full = single_lds_bytes(n, g->e_kept, true);
+      const bool lds_links = lds_full <= (n_roots > 256 ? SINGLE_LDS_MAX / 2 : SINGLE_LDS_MAX);
+      const size_t lds = single_lds_bytes(n, g->e_kept, lds_links);
+      const uint32_t thr = std::min<uint32_t>(SINGLE_THREADS, std::max<uint32_t>(64u, (n + 63u) / 64u * 64u));
+      SingleArgs sa{d_fg, d_roots, fp_wide, net_nh, ignore_ovl, n_roots, count_rows ? 1u : 0u, lds_links ? 1u : 0u, d_lf, od};
+      if (!ctx->single_attr) {      // more than 64 KB of dynamic LDS has to be allowed per kernel, once
+        (void)hipFuncSetAttribute((const void *)k_single<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SINGLE_LDS_MAX);
+        (void)hipFuncSetAttribute((const void *)k_single<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SINGLE_LDS_MAX);
+        ctx->single_attr = true;
+      }
+      if (g->max_path_metric == HSPF_DIST_INF) hipLaunchKernelGGL((k_single<true>), dim3(n_roots), dim3(thr), lds, s, sa);
+      else                                     hipLaunchKernelGGL((k_single<false>), dim3(n_roots), dim3(thr), lds, s, sa);
+      (void)hipEventRecord(ctx->ev[2], s);
+      (void)hipEventRecord(ctx->ev[3], s);
+      er = hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s);
+      if (er == hipSuccess && count_rows) er = hipMemcpyAsync(ctx->h_lane_flags + L, d_kcnt, 256 * 4, hipMemcpyDeviceToHost, s);
+      if (er == hipSuccess) er = hipStreamSynchronize(s);
+      if (er == hipSuccess) er = hipGetLastError();
+      if (er != hipSuccess) { ctx->last_error = std::string("k_single: ") + hipGetErrorString(er); return HSPF_E_HIP; }
+      st.n_relax_launches = 1; st.single_wg = 1;
+      if (count_rows) for (uint32_t i = 0; i < 256; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
+      narrow = false;
+    } else if (narrow) {
       if ((rc = fused_run(true))) return rc;
       // did any lane leave the 4-byte fields?  (run_phase has brought the per-root status bits back)
       bool ovf = false;
       for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);
       if (ovf) { g->narrow_bad = true; narrow = false; st.narrow_overflow = 1; }
     }
-    if (!narrow && (rc = fused_run(false))) return rc;
+    if (!single && !narrow && (rc = fused_run(false))) return rc;
     if (!narrow && fp_wide.hmax < 0xFFFFu) {                       // more than 16 mask bits: did the hop field hold?
       bool ovf = false;
       for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);

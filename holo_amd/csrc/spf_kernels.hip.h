@@ -839,6 +839,166 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   if (lf) atomicOr(&lane_flags[root_slot], lf);
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_single — small graphs: ONE workgroup per root, lane = vertex, the whole packed state of the run in LDS.
+//
+// run_area / compute_spt are called with one root per area / level (holo-ospf/src/spf.rs:540-542,
+// holo-isis/src/spf.rs:527), mostly on LSDBs of tens to a few thousand routers — the reference's own benchmark is a
+// 500-router area.  There the batched sweep engine is bound by kernel boundaries (51 launches x ~6 us on ospf-500,
+// slower than one CPU core) and 63 of its 64 lanes idle.  This kernel runs the SAME fixed point — the row routine
+// below is fused_row_any / finish_row with the row walked by one lane instead of one wave — inside one launch: thread
+// t owns vertices t, t + 1024, ...; the state word of every vertex ([dist32 | hops | mask], the 8-byte form of the
+// fused path, <= 24 first-hop slots) lives in LDS; a sweep recomputes every vertex from its in-links and ends at a
+// workgroup barrier; the run ends after a sweep that changed nothing.  Reads of a neighbour's word race with its
+// owner's write inside a sweep: one 8-byte LDS access per word, so a (distance, hops, mask) triple is never torn,
+// and a stale triple is a triple the neighbour had earlier in the run — the same "memory is monotone" argument as
+// k_fused.  Results go straight to the row-major output arrays (no transpose pass).  Many roots = many workgroups,
+// each with its own LDS: a batch on a small graph uses this kernel too.
+// Link records come from global memory every sweep: for the graphs this kernel is chosen for they stay in L1 / L2.
+constexpr int SINGLE_THREADS = 1024;
+constexpr uint32_t SINGLE_MAX_N = 8192;          // 64 KB of LDS state
+constexpr uint32_t SINGLE_MAX_E = 65536;
+constexpr size_t SINGLE_LDS_MAX = 160 * 1024 - 64;   // dynamic LDS a workgroup may ask for (one workgroup per CU then)
+
+struct SingleArgs {
+  const FusedGraph *gp;
+  const uint32_t *roots;
+  FusedParams P;               // the 8-byte state's parameters (sh = 0)
+  uint32_t net_nexthops, ignore_ovl, n_roots, count_rows, lds_links;
+  uint32_t *lane_flags;
+  OutDev o;
+};
+
+// LDS layout (dynamic): state words [n] | when lds_links: in_ptr [n+1] (u32) | link records [e] (u32x2: source|NT, cost).
+// The link records do not change during a run; staged once, a sweep touches global memory only for the rare
+// first-hop-slot lookups.
+__host__ __device__ inline size_t single_lds_bytes(uint32_t n, uint32_t e, bool lds_links) {
+  return (size_t)n * 8 + (lds_links ? (((size_t)n + 2) / 2 * 2 * 4 + (size_t)e * 8) : 0);
+}
+
+template <bool MAXINF>
+__global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
+  extern __shared__ uint64_t s_st[];
+  __shared__ int s_changed[2];
+  const GraphDev &g = a.gp->g;
+  const uint32_t n = g.n;
+  const uint32_t root_slot = blockIdx.x;
+  const uint32_t my_root = a.roots[root_slot];
+  const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+  const FusedParams P = a.P;
+  const uint32_t mmask = (1u << P.mbits) - 1u;
+  const size_t orow = a.o.row(root_slot) * (size_t)n;
+  if (my_root == INF) {                            // padding root: empty SPT
+    for (uint32_t v = tid; v < n; v += nthr) {
+      a.o.dist[orow + v] = INF;
+      if (a.o.hops) a.o.hops[orow + v] = 0;
+      if (a.o.flags) a.o.flags[orow + v] = 0;
+      if (a.o.mask) for (uint32_t k = 0; k < a.o.out_words; ++k) a.o.mask[(orow + v) * a.o.out_words + k] = 0;
+    }
+    return;
+  }
+  const uint32_t e_in = g.e_in;
+  uint32_t *const s_ptr = (uint32_t *)(s_st + n);
+  u32x2 *const s_rec = (u32x2 *)(s_ptr + ((size_t)n + 2) / 2 * 2);
+  const bool ll = a.lds_links != 0u;
+  for (uint32_t v = tid; v < n; v += nthr) s_st[v] = (v == my_root) ? 0ull : ~0ull;
+  if (ll) {
+    for (uint32_t v = tid; v <= n; v += nthr)       // bit 31: the vertex is a network (in_ptr values stay below 2^31)
+      s_ptr[v] = g.in_ptr[v] | ((v < n && (g.vflags[v] & 1u)) ? 0x80000000u : 0u);
+    for (uint32_t e = tid; e < e_in; e += nthr) s_rec[e] = u32x2{g.in_src[e], g.in_w[e]};
+  }
+  if (tid < 2) s_changed[tid] = 0;
+  __syncthreads();
+  bool sat = false, need_exact = false, ovf = false;
+  const uint32_t max_sweeps = 4u * n + 64u;        // far beyond any run; a run that gets there is handed to k_exact
+  uint32_t sweep = 0;
+  for (;; ++sweep) {
+    bool any = false;
+    for (uint32_t v = tid; v < n; v += nthr) {
+      if (v == my_root) continue;
+      const uint32_t p0 = ll ? s_ptr[v] : g.in_ptr[v];
+      const uint32_t e0 = p0 & 0x7FFFFFFFu, e1 = (ll ? s_ptr[v + 1] : g.in_ptr[v + 1]) & 0x7FFFFFFFu;
+      const uint32_t v_router = ll ? ((p0 >> 31) ^ 1u) : ((g.vflags[v] & 1u) ? 0u : 1u);
+      RowAcc r{INF, 0u, INF, 0u, false};
+      uint32_t bd_all = INF, zb = INF, zm = 0u, zh = 0u;
+      constexpr uint32_t PF = 4;                    // link records, then their sources' states, of 4 links in flight
+      for (uint32_t eb = e0; eb < e1; eb += PF) {
+        u32x2 rec[PF];
+        uint64_t qs[PF];
+#pragma unroll
+        for (uint32_t k = 0; k < PF; ++k) {
+          const uint32_t e = min(eb + k, e1 - 1u);
+          rec[k] = ll ? s_rec[e] : u32x2{g.in_src[e], g.in_w[e]};
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PF; ++k) qs[k] = s_st[rec[k].x & SRC_MASK];
+#pragma unroll
+        for (uint32_t k = 0; k < PF; ++k) {
+          const uint32_t e = eb + k;
+          if (e >= e1) break;
+          const uint32_t sw = rec[k].x, w = rec[k].y;
+          const uint32_t u = sw & SRC_MASK;
+          const uint64_t q = qs[k];
+          uint32_t d = (uint32_t)(q >> 32);
+          const uint32_t pay = (uint32_t)q;
+          if (!a.ignore_ovl && (sw & SRC_NO_TRANSIT) && u != my_root) d = INF;        // overloaded source
+          const uint32_t c = add_sat(d, w);
+          if (MAXINF && c == INF && d != INF) r.sat = true;
+          const bool zlink = w == 0u && u >= v;
+          if (zlink && !P.hc) { bd_all = min(bd_all, c); continue; }
+          const bool lt = (P.hc && zlink) ? (c < zb) : (c < r.bd), eq = !(P.hc && zlink) && c == r.bd;
+          const uint32_t hh = pay >> P.mbits;
+          uint32_t contrib = pay & mmask;
+          if ((lt || eq) && hh == 0u && c < P.inf_t) {                               // parent: root or hops-0 network
+            const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(a.gp->tabs, root_slot, u);
+            const uint32_t sidx = base_s + g.in_fpos[e];
+            contrib = ((v_router || a.net_nexthops) && sidx < P.mbits) ? (1u << sidx) : 0u;
+          }
+          if (P.hc && zlink) { if (lt) { zb = c; zm = contrib; zh = hh; } continue; }   // see fused_row_any
+          const uint32_t m_or = r.bm | contrib;
+          r.bm = lt ? contrib : (eq ? m_or : r.bm);
+          const bool newp = lt || (eq && d < r.bpd);
+          r.bpd = newp ? d : r.bpd;
+          r.bh = newp ? hh : r.bh;
+          r.bd = min(r.bd, c);
+        }
+      }
+      if (P.hc) {
+        const bool late = zb < r.bd;
+        r.bm = late ? zm : r.bm; r.bh = late ? zh : r.bh; r.bd = late ? zb : r.bd;
+      }
+      const RowOut<uint64_t> o = finish_row<uint64_t>(r, v, my_root, v_router, bd_all, P);
+      sat = sat || o.sat; need_exact = need_exact || o.need_exact; ovf = ovf || o.ovf;
+      if (o.nw != s_st[v]) { s_st[v] = o.nw; any = true; }
+    }
+    if (any) s_changed[sweep & 1u] = 1;
+    __syncthreads();
+    const bool go_on = s_changed[sweep & 1u] != 0;
+    if (tid == 0) s_changed[(sweep + 1u) & 1u] = 0;
+    if (!go_on) break;
+    if (sweep >= max_sweeps) { need_exact = true; break; }
+    __syncthreads();                               // the flag of the next sweep is clear before anyone sets it
+  }
+  // results: one row of the row-major outputs per root, consecutive threads = consecutive vertices
+  for (uint32_t v = tid; v < n; v += nthr) {
+    const uint64_t x = s_st[v];
+    const bool in = x != ~0ull;
+    const uint32_t pay = (uint32_t)x;
+    a.o.dist[orow + v] = in ? (uint32_t)(x >> 32) : INF;
+    if (a.o.hops) a.o.hops[orow + v] = in ? (uint16_t)(pay >> P.mbits) : (uint16_t)0;
+    if (a.o.flags) a.o.flags[orow + v] = in ? 1 : 0;
+    if (a.o.mask) {
+      a.o.mask[(orow + v) * a.o.out_words] = in ? (uint64_t)(pay & mmask) : 0ull;
+      for (uint32_t k = 1; k < a.o.out_words; ++k) a.o.mask[(orow + v) * a.o.out_words + k] = 0;
+    }
+  }
+  uint32_t lf = 0;
+  if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
+  if (ovf) lf |= LF_OVERFLOW;
+  if (lf) atomicOr(&a.lane_flags[root_slot], lf);
+  if (a.count_rows && tid == 0) atomicAdd(&a.gp->rows_done[root_slot & 255u], (sweep + 1u) * n);   // HSPF_RUN_COUNT_ROWS
+}
+
 // Per-batch row flags = the graph's static ones (k_init_fused then adds RF_HNB).
 __global__ void k_fill_rowflags(uint32_t n, uint32_t n_batches, const uint8_t *__restrict__ rowflags, uint8_t *__restrict__ hnb) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -156,6 +156,8 @@ typedef struct {
   uint64_t rows_recomputed;    /* HSPF_RUN_COUNT_ROWS: (vertex, 64-root batch) rows the fused fixed point evaluated, summed
                                   over its launches (0 without the flag); the reference settles each vertex once per root
                                   (holo-isis/src/spf.rs:552-556), i.e. n_batches * n_vertices rows would be 1x */
+  uint32_t single_wg;          /* 1: small graph, the run took the one-workgroup-per-root kernel (one launch)     */
+  uint32_t reserved_;
 } hspf_stats;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */

@@ -34,6 +34,7 @@ def _lib():
         _LIB = ctypes.CDLL(build())
         u32p = ctypes.POINTER(ctypes.c_uint32)
         _LIB.oracle_spf_run.restype = ctypes.c_int
+        _LIB.oracle_spf_run_mt.restype = ctypes.c_int
         _LIB.oracle_mask_words.restype = ctypes.c_uint32
     return _LIB
 
@@ -70,8 +71,8 @@ def mask_words(row_ptr, col, metric, vflags, roots) -> int:
 
 
 def run(row_ptr, col, metric, vflags, max_path_metric, roots, run_flags=0, variant=MAP,
-        mask_words_=None) -> OracleResult:
-    """Run the oracle for every root (sequentially, one thread)."""
+        mask_words_=None, threads: int = 1) -> OracleResult:
+    """Run the oracle for every root: sequentially (threads = 1) or with the roots dealt to `threads` workers."""
     lib = _lib()
     row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
     col = np.ascontiguousarray(col, dtype=np.uint32)
@@ -90,13 +91,45 @@ def run(row_ptr, col, metric, vflags, max_path_metric, roots, run_flags=0, varia
     nnh = np.empty((R, n), np.uint32)
     npar = np.empty((R, n), np.uint32)
     work = np.zeros((R,), np.uint64)
-    rc = lib.oracle_spf_run(
+    rc = lib.oracle_spf_run_mt(
         ctypes.c_uint32(n), ctypes.c_uint32(e), _p(row_ptr, ctypes.c_uint32), _p(col, ctypes.c_uint32),
         _p(metric, ctypes.c_uint32), _p(vflags, ctypes.c_uint8), ctypes.c_uint32(max_path_metric),
         _p(roots, ctypes.c_uint32), ctypes.c_uint32(R), ctypes.c_uint32(run_flags), ctypes.c_int(variant),
         _p(dist, ctypes.c_uint32), _p(hops, ctypes.c_uint16), _p(flags, ctypes.c_uint16),
         _p(rank, ctypes.c_uint32), _p(mask, ctypes.c_uint64), ctypes.c_uint32(W),
-        _p(nnh, ctypes.c_uint32), _p(npar, ctypes.c_uint32), _p(work, ctypes.c_uint64))
+        _p(nnh, ctypes.c_uint32), _p(npar, ctypes.c_uint32), _p(work, ctypes.c_uint64), ctypes.c_uint32(max(1, int(threads))))
     if rc != 0:
         raise RuntimeError(f"oracle_spf_run failed: {rc}")
     return OracleResult(dist, hops, flags, rank, mask, nnh, npar, work)
+
+
+class Runner:
+    """Repeated runs into preallocated dist / hops / mask arrays (the diagnostic outputs are skipped): what bench.py's
+    all-cores CPU baseline times, so that the baseline is the SPF loop and not the page faults of fresh result arrays."""
+
+    def __init__(self, row_ptr, col, metric, vflags, max_path_metric, max_roots: int, mask_words_: int = 1):
+        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+        self.col = np.ascontiguousarray(col, dtype=np.uint32)
+        self.metric = np.ascontiguousarray(metric, dtype=np.uint32)
+        self.vflags = np.ascontiguousarray(vflags, dtype=np.uint8)
+        self.maxp = int(max_path_metric)
+        self.n = len(self.row_ptr) - 1
+        self.W = mask_words_
+        self.dist = np.zeros((max_roots, self.n), np.uint32)
+        self.hops = np.zeros((max_roots, self.n), np.uint16)
+        self.mask = np.zeros((max_roots, self.n, self.W), np.uint64)
+
+    def run(self, roots, run_flags=0, variant=HEAP, threads: int = 1):
+        lib = _lib()
+        roots = np.ascontiguousarray(roots, dtype=np.uint32)
+        R = len(roots)
+        assert R <= self.dist.shape[0]
+        rc = lib.oracle_spf_run_mt(
+            ctypes.c_uint32(self.n), ctypes.c_uint32(len(self.col)), _p(self.row_ptr, ctypes.c_uint32), _p(self.col, ctypes.c_uint32),
+            _p(self.metric, ctypes.c_uint32), _p(self.vflags, ctypes.c_uint8), ctypes.c_uint32(self.maxp),
+            _p(roots, ctypes.c_uint32), ctypes.c_uint32(R), ctypes.c_uint32(run_flags), ctypes.c_int(variant),
+            _p(self.dist, ctypes.c_uint32), _p(self.hops, ctypes.c_uint16), None, None, _p(self.mask, ctypes.c_uint64),
+            ctypes.c_uint32(self.W), None, None, None, ctypes.c_uint32(max(1, int(threads))))
+        if rc != 0:
+            raise RuntimeError(f"oracle_spf_run_mt failed: {rc}")
+        return self.dist[:R], self.hops[:R], self.mask[:R]

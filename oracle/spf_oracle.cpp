@@ -32,6 +32,8 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include <algorithm>
 #include <utility>
@@ -320,15 +322,15 @@ uint32_t oracle_mask_words(uint32_t n, uint32_t e, const uint32_t *row_ptr, cons
   return w ? w : 1;
 }
 
-// Runs `n_roots` SPFs one after the other (single thread).  Outputs are row-major
-// [n_roots][n]; any of hops/flags/pop_rank/mask/n_nexthops/n_parents/work may be NULL.
+// Runs `n_roots` SPFs, one after the other (oracle_spf_run, n_threads = 1) or dealt to n_threads workers.  Outputs are
+// row-major [n_roots][n]; any of hops/flags/pop_rank/mask/n_nexthops/n_parents/work may be NULL.
 // Returns 0, or -1 on bad input, -5 if mask_words is too small.
-int oracle_spf_run(uint32_t n, uint32_t e, const uint32_t *row_ptr, const uint32_t *col,
-                   const uint32_t *metric, const uint8_t *vflags, uint32_t max_path_metric,
-                   const uint32_t *roots, uint32_t n_roots, uint32_t run_flags, int variant,
-                   uint32_t *dist, uint16_t *hops, uint16_t *flags, uint32_t *pop_rank,
-                   uint64_t *mask, uint32_t mask_words, uint32_t *n_nexthops,
-                   uint32_t *n_parents, uint64_t *work) {
+int oracle_spf_run_mt(uint32_t n, uint32_t e, const uint32_t *row_ptr, const uint32_t *col,
+                      const uint32_t *metric, const uint8_t *vflags, uint32_t max_path_metric,
+                      const uint32_t *roots, uint32_t n_roots, uint32_t run_flags, int variant,
+                      uint32_t *dist, uint16_t *hops, uint16_t *flags, uint32_t *pop_rank,
+                      uint64_t *mask, uint32_t mask_words, uint32_t *n_nexthops,
+                      uint32_t *n_parents, uint64_t *work, uint32_t n_threads) {
   if (!row_ptr || !dist || (e && (!col || !metric)) || !vflags) return -1;
   Graph g{n, e, row_ptr, col, metric, vflags, max_path_metric};
   std::vector<uint8_t> twoway(e);
@@ -337,7 +339,11 @@ int oracle_spf_run(uint32_t n, uint32_t e, const uint32_t *row_ptr, const uint32
       if (col[k] >= n) return -1;
       twoway[k] = links_back(g, col[k], u);
     }
-  for (uint32_t r = 0; r < n_roots; ++r) {
+  // n_threads > 1: the roots are independent runs over the read-only graph; worker t takes roots t, t + T, t + 2T, ...
+  // (the all-cores CPU baseline of bench.py and a faster checker for the full-size parity tests; one run is still the
+  // same sequential loop)
+  std::atomic<int> first_err{0};
+  auto one = [&](uint32_t r) -> int {
     const size_t off = (size_t)r * n;
     Out o{dist + off, hops ? hops + off : nullptr, flags ? flags + off : nullptr,
           pop_rank ? pop_rank + off : nullptr, mask ? mask + off * mask_words : nullptr, mask_words,
@@ -347,17 +353,41 @@ int oracle_spf_run(uint32_t n, uint32_t e, const uint32_t *row_ptr, const uint32
       for (uint32_t i = 0; i < n; ++i) {
         o.dist[i] = INF; if (o.hops) o.hops[i] = 0; if (o.flags) o.flags[i] = 0;
         if (o.pop_rank) o.pop_rank[i] = INF;
-        if (o.n_nexthops) o.n_nexthops[i] = 0; if (o.n_parents) o.n_parents[i] = 0;
+        if (o.n_nexthops) o.n_nexthops[i] = 0;
+        if (o.n_parents) o.n_parents[i] = 0;
       }
       if (o.mask) std::memset(o.mask, 0, sizeof(uint64_t) * (size_t)n * mask_words);
-      continue;
+      return 0;
     }
     if (roots[r] >= n) return -1;
-    int rc = variant == 2 ? run_heap(g, roots[r], run_flags, o, twoway)
-                          : run_map(g, roots[r], run_flags, variant == 0, o, twoway);
-    if (rc) return rc;
+    return variant == 2 ? run_heap(g, roots[r], run_flags, o, twoway)
+                        : run_map(g, roots[r], run_flags, variant == 0, o, twoway);
+  };
+  const uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(n_threads, n_roots));
+  if (T == 1) {
+    for (uint32_t r = 0; r < n_roots; ++r) { const int rc = one(r); if (rc) return rc; }
+    return 0;
   }
-  return 0;
+  std::vector<std::thread> pool;
+  for (uint32_t t = 0; t < T; ++t)
+    pool.emplace_back([&, t]() {
+      for (uint32_t r = t; r < n_roots && first_err.load() == 0; r += T) {
+        const int rc = one(r);
+        if (rc) { int z = 0; first_err.compare_exchange_strong(z, rc); }
+      }
+    });
+  for (auto &th : pool) th.join();
+  return first_err.load();
+}
+
+int oracle_spf_run(uint32_t n, uint32_t e, const uint32_t *row_ptr, const uint32_t *col,
+                   const uint32_t *metric, const uint8_t *vflags, uint32_t max_path_metric,
+                   const uint32_t *roots, uint32_t n_roots, uint32_t run_flags, int variant,
+                   uint32_t *dist, uint16_t *hops, uint16_t *flags, uint32_t *pop_rank,
+                   uint64_t *mask, uint32_t mask_words, uint32_t *n_nexthops,
+                   uint32_t *n_parents, uint64_t *work) {
+  return oracle_spf_run_mt(n, e, row_ptr, col, metric, vflags, max_path_metric, roots, n_roots, run_flags, variant, dist, hops,
+                           flags, pop_rank, mask, mask_words, n_nexthops, n_parents, work, 1);
 }
 
 }  // extern "C"

@@ -1,0 +1,5 @@
+"""Which engine configuration a GPU test runs with (see the spf_ctx fixture in conftest.py)."""
+import pytest
+
+both_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps"], indirect=True)
+sweeps_engine = pytest.mark.parametrize("spf_ctx", ["sweeps"], indirect=True)

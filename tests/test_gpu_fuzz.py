@@ -7,7 +7,9 @@ import sys
 import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-pytestmark = pytest.mark.gpu
+from _engines import both_engines  # noqa: E402
+
+pytestmark = [pytest.mark.gpu, both_engines]
 
 
 @pytest.mark.parametrize("first", [0, 5000, 9000])

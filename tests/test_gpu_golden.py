@@ -11,7 +11,9 @@ from holo_amd import isis as H
 from oracle import isis_ref as R
 from test_host_isis import check_spts_against_ref
 
-pytestmark = pytest.mark.gpu
+from _engines import both_engines  # noqa: E402
+
+pytestmark = [pytest.mark.gpu, both_engines]
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 ISIS = sorted(glob.glob(os.path.join(GOLD, "isis", "*.json"))) + sorted(glob.glob(os.path.join(GOLD, "isis_steps", "*.json")))

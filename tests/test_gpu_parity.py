@@ -9,7 +9,12 @@ from holo_amd import synth
 from holo_amd import engine as E
 from oracle import graph_oracle as go
 
+from _engines import both_engines, sweeps_engine  # noqa: E402
+
 pytestmark = pytest.mark.gpu
+
+import os
+ORACLE_THREADS = min(64, os.cpu_count() or 1)      # the oracle deals whole roots to host threads (exhaustive full-size checks)
 
 
 def check(ctx, g, roots, run_flags=0, oracle_variant=go.MAP, expect_exact=None):
@@ -33,6 +38,7 @@ def check(ctx, g, roots, run_flags=0, oracle_variant=go.MAP, expect_exact=None):
     return res, ref
 
 
+@both_engines
 @pytest.mark.parametrize("seed", range(12))
 @pytest.mark.parametrize("run_flags", [0, E.RUN_NET_NEXTHOPS, E.RUN_IGNORE_OVERLOAD])
 def test_random_lsdb_normal_metrics(spf_ctx, seed, run_flags):
@@ -43,6 +49,7 @@ def test_random_lsdb_normal_metrics(spf_ctx, seed, run_flags):
     check(spf_ctx, g, roots, run_flags, expect_exact=False)
 
 
+@both_engines
 @pytest.mark.parametrize("seed", range(6))
 def test_random_lsdb_all_roots_ragged(spf_ctx, seed):
     """Ragged root counts (not multiples of 64), incl. network vertices as roots and padding."""
@@ -52,6 +59,7 @@ def test_random_lsdb_all_roots_ragged(spf_ctx, seed):
     check(spf_ctx, g, roots, 0)
 
 
+@both_engines
 @pytest.mark.parametrize("seed", range(6))
 def test_zero_cost_router_links_exact_path(spf_ctx, seed):
     """Zero-cost router links make the reference's pop order dynamic: flagged roots go through
@@ -61,6 +69,7 @@ def test_zero_cost_router_links_exact_path(spf_ctx, seed):
     check(spf_ctx, g, roots, 0)
 
 
+@both_engines
 @pytest.mark.parametrize("seed", range(4))
 def test_hopcount_mode(spf_ctx, seed):
     """MetricMode::HopCount (holo-isis/src/flooding/manet.rs:59-69): cost 0 to pseudonodes, 1 to
@@ -70,6 +79,7 @@ def test_hopcount_mode(spf_ctx, seed):
     check(spf_ctx, g, roots, E.RUN_IGNORE_OVERLOAD)
 
 
+@both_engines
 @pytest.mark.parametrize("seed", range(4))
 def test_forced_exact_and_pop_rank(spf_ctx, seed):
     g = synth.random_lsdb(40, 5, 3.0, 400 + seed, metric_hi=5)
@@ -78,6 +88,7 @@ def test_forced_exact_and_pop_rank(spf_ctx, seed):
     assert res.stats["n_exact_roots"] == 10
 
 
+@both_engines
 def test_standard_metric_max_path_prune(spf_ctx):
     """MAX_PATH_METRIC_STANDARD = 1023 (holo-isis/src/spf.rs:45, 637-647): a long chain is cut."""
     n = 40
@@ -90,6 +101,7 @@ def test_standard_metric_max_path_prune(spf_ctx):
     assert (res.dist[0] != E.DIST_INF).sum() == 1023 // 63 + 1
 
 
+@both_engines
 def test_ospf_saturation_goes_exact(spf_ctx):
     """u32 saturating add (holo-ospf/src/spf.rs:672) is only representable on the exact path."""
     n = 4
@@ -106,21 +118,21 @@ def test_config_ospf_500_and_10k(spf_ctx):
         check(spf_ctx, g, g.meta["roots"], E.RUN_NET_NEXTHOPS, expect_exact=False)
 
 
-def test_config_isis_100k_sample_roots(spf_ctx):
-    """Headline graph, 64 roots on the GPU; the oracle (heap variant) checks a sample of 6."""
+def test_config_isis_100k_all_roots(spf_ctx):
+    """Headline graph, 64 roots on the GPU; ALL 64 bit for bit against the oracle (heap variant, roots dealt to the
+    host's cores)."""
     g = synth.isis_100k()
     roots = np.asarray(g.meta["roots"], np.uint32)
     G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
     res = spf_ctx.run(G, roots, 0)
     G.free()
     assert res.stats["n_exact_roots"] == 0
-    sample = [0, 1, 17, 31, 40, 63]
-    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots[sample], 0, go.HEAP,
-                 mask_words_=res.first_hop_mask.shape[2])
-    assert np.array_equal(res.dist[sample], ref.dist)
-    assert np.array_equal(res.hops[sample], ref.hops)
-    assert np.array_equal(res.flags[sample] & 1, ref.flags)
-    assert np.array_equal(res.first_hop_mask[sample], ref.mask)
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 0, go.HEAP,
+                 mask_words_=res.first_hop_mask.shape[2], threads=ORACLE_THREADS)
+    assert np.array_equal(res.dist, ref.dist)
+    assert np.array_equal(res.hops, ref.hops)
+    assert np.array_equal(res.flags & 1, ref.flags)
+    assert np.array_equal(res.first_hop_mask, ref.mask)
     # size-independent properties over all 64 roots
     N = g.n
     assert (res.dist[np.arange(64), roots] == 0).all()
@@ -134,6 +146,7 @@ def test_config_isis_100k_sample_roots(spf_ctx):
     assert (nz.sum(axis=1) == N - 1).all()
 
 
+@both_engines
 def test_determinism(spf_ctx):
     """Replay (holo-tools/holo-replay) needs bit-identical reruns."""
     g = synth.ospf_10k()
@@ -164,6 +177,7 @@ def _chain(n, metric, max_path=synth.MAX_PATH_METRIC_WIDE):
     return synth.CsrGraph(row_ptr, col, met, np.zeros(n, np.uint8), max_path)
 
 
+@sweeps_engine
 def test_narrow_state_hops_overflow_falls_back_to_wide(spf_ctx):
     """The 4-byte fused state has 7 hop bits: a 300-router chain leaves the field, the run must be
     redone with the 8-byte state and still be exact."""
@@ -172,12 +186,14 @@ def test_narrow_state_hops_overflow_falls_back_to_wide(spf_ctx):
     assert res.hops.max() == 299
 
 
+@sweeps_engine
 def test_narrow_state_distance_overflow_falls_back_to_wide(spf_ctx):
     g = _chain(120, 1 << 20)            # 2 first-hop slots -> 23 distance bits; 119 * 2^20 does not fit
     res, ref = check(spf_ctx, g, [0, 60], expect_exact=False)
     assert int(res.dist[0].max()) == 119 << 20
 
 
+@sweeps_engine
 def test_costs_too_large_for_narrow_state_use_wide_directly(spf_ctx):
     g = _chain(50, 0x00FFFFFE)          # MAX_LINK_METRIC_WIDE - 1 (holo-isis/src/spf.rs:49)
     check(spf_ctx, g, [0, 49], expect_exact=False)
@@ -220,6 +236,7 @@ def test_fattree_two_mask_words_two_phase_path(spf_ctx):
     assert res.stats["state_bytes"] == 0 and res.stats["n_dag_launches"] > 0
 
 
+@both_engines
 def test_single_vertex_and_isolated_root(spf_ctx):
     g = synth.CsrGraph(np.zeros(2, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(1, np.uint8),
                        synth.MAX_PATH_METRIC_WIDE)
@@ -254,12 +271,14 @@ def test_star_rows_with_more_than_64_links(spf_ctx, fanout):
 
 
 def _properties(g, roots, res, sample, variant=go.HEAP, run_flags=0):
-    """Full-size check: a sample of roots bit for bit against the oracle, all roots through
+    """Full-size check: the roots in `sample` (None: ALL of them) bit for bit against the oracle, all roots through
     size-independent properties (root at distance 0, fixed point of relaxation on every kept link,
     hops 0 only at the root, first-hop mask non-empty exactly for reached non-root vertices)."""
     roots = np.asarray(roots, np.uint32)
+    if sample is None:
+        sample = np.arange(len(roots))
     ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots[sample], run_flags, variant,
-                 mask_words_=res.first_hop_mask.shape[2])
+                 mask_words_=res.first_hop_mask.shape[2], threads=ORACLE_THREADS)
     assert np.array_equal(res.dist[sample], ref.dist)
     assert np.array_equal(res.hops[sample], ref.hops)
     assert np.array_equal(res.flags[sample] & 1, ref.flags)
@@ -285,22 +304,22 @@ def test_config_fattree_262k_two_mask_words(spf_ctx):
     res = spf_ctx.run(G, roots, 0)
     G.free()
     assert res.first_hop_mask.shape[2] == 2 and res.stats["n_exact_roots"] == 0
-    _properties(g, roots, res, [0, 1, 57, 100])
+    _properties(g, roots, res, None)                           # all 101 roots against the oracle
 
 
 def test_config_multi_area_10k_roots(spf_ctx):
     """BASELINE configs[3] shape: 10 areas x 5 000 routers, 1 000 roots per area (16 wavefront
     batches per run, fused path), OSPF semantics."""
     total = 0
-    for g in synth.ospf_multi_area()[:3]:
+    for g in synth.ospf_multi_area():                          # all 10 areas, every root against the oracle
         roots = np.asarray(g.meta["roots"], np.uint32)
         G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
         res = spf_ctx.run(G, roots, E.RUN_NET_NEXTHOPS)
         G.free()
         assert res.stats["n_exact_roots"] == 0 and res.stats["state_bytes"] in (4, 8)
-        _properties(g, roots, res, [0, 333, 999], run_flags=go.RUN_NET_NEXTHOPS)
+        _properties(g, roots, res, None, run_flags=go.RUN_NET_NEXTHOPS)
         total += len(roots)
-    assert total == 3000
+    assert total == 10000
 
 
 def test_root_groups_bound_the_scratch(spf_ctx):
@@ -317,6 +336,7 @@ def test_root_groups_bound_the_scratch(spf_ctx):
     _properties(g, roots, res, [0, 831, 832, 1099])
 
 
+@both_engines
 @pytest.mark.parametrize("seed", range(4))
 def test_hopcount_lan_graphs_stay_on_the_parallel_path(spf_ctx, seed):
     """MetricMode::HopCount on an LSDB with LAN pseudonodes (flooding::manet::init_cache,
@@ -347,6 +367,7 @@ def G_slots(g, root):
     return tot
 
 
+@sweeps_engine
 @pytest.mark.parametrize("run_flags", [0, E.RUN_NET_NEXTHOPS])
 def test_many_roots_regrouped_by_state_class(spf_ctx, run_flags):
     """Every router as a root on a graph where a few roots need wide masks (members of a 40-router LAN: 40+ first-hop
@@ -366,6 +387,7 @@ def test_many_roots_regrouped_by_state_class(spf_ctx, run_flags):
     assert res.stats["n_roots"] == len(roots)
 
 
+@sweeps_engine
 def test_many_roots_regrouped_device_outputs(spf_ctx):
     """Same regrouping through hspf_run_device (rows permuted straight into the caller's device buffers)."""
     import torch
@@ -388,6 +410,7 @@ def test_many_roots_regrouped_device_outputs(spf_ctx):
     assert np.array_equal(mask.cpu().numpy().view(np.uint64), ref.mask)
 
 
+@both_engines
 @pytest.mark.parametrize("seed", range(4))
 @pytest.mark.parametrize("run_flags", [0, E.RUN_NET_NEXTHOPS])
 def test_roots_with_17_to_24_slots_stay_on_the_fused_path(spf_ctx, seed, run_flags):
