@@ -7,10 +7,12 @@ IS-reachability entries, metrics U[1,100]) through the C ABI (hspf_run_device): 
 (first-discoverer rule) and ECMP first-hop masks for every (root, vertex), written row-major
 into HBM.  The graph is uploaded (resident in HBM) before the timed region; results stay in HBM.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): roots are independent units
-over a replicated read-only graph, so every rank runs its own 64 roots per step (weak scaling)
-and the per-root distance tables are exchanged with ONE RCCL all-gather per step, issued
-asynchronously so that it overlaps the next step's kernels.
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): roots are independent units over a replicated
+read-only graph, so every rank runs its own 64 roots per step (weak scaling).  The sharding and the exchange are the C
+ABI's (hspf_multi_run): whole 64-root batches per rank, ONE RCCL all-gather of the per-root distance tables per step
+(librccl.so loaded by the library; the communicator id travels over torch.distributed), issued asynchronously on a
+communication stream so that it overlaps the next step's kernels.  At N = 1 the same entry point runs
+a one-rank job.
 
 Prints ONE JSON line on rank 0.
 """
@@ -155,7 +157,7 @@ def main():
     import torch
     import torch.distributed as dist
     from holo_amd import synth
-    from holo_amd.engine import SpfContext
+    from holo_amd import engine as E
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
@@ -168,43 +170,72 @@ def main():
 
     g = synth.isis_100k()
     n, e = g.n, g.e
-    ctx = SpfContext(local_rank)
-    # Run the engine on a torch-owned side stream: the RCCL all-gather (NCCL stream) then orders
-    # itself against the engine's kernels on device, and the HIP events the library records for
-    # the roofline figures are on this same stream.
-    side = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(side)
-    ctx.set_stream(side.cuda_stream)
-    G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
-    roots = roots_for_rank(n, rank, world)
-    R = len(roots)
-    W = G.mask_words(roots)
+    # The sharded run goes through the C ABI's multi-GPU entry points (hspf_multi_*): one rank = one engine context on
+    # this process's GPU; at N > 1 the communicator id of the library's own RCCL all-gather is created on rank 0 and
+    # carried to the other processes by torch.distributed (plumbing: holo would use its ibus).
+    gather_via = "none"
+    m = None
+    if world > 1 and args.gather == "dist":
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.tensor(list(E.multi_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            m = E.MultiEngine([local_rank], world=world, first_rank=rank, unique_id=bytes(idt.cpu().numpy().tobytes()))
+            gather_via = "hspf_multi_run: RCCL all-gather inside the C ABI (librccl.so), asynchronous"
+        except Exception as ex:  # noqa: BLE001   (plumbing failure: keep the job alive, say so in the JSON line)
+            sys.stderr.write(f"[rank {rank}] hspf_multi RCCL communicator failed ({ex}); gathering through torch.distributed\n")
+            m = None
+        ok = torch.tensor([1 if m is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and m is not None:
+            m.close(); m = None
+        if m is None:
+            gather_via = "torch.distributed all_gather_into_tensor (RCCL) after hspf_multi_run without exchange"
+    sharded_in_lib = m is not None
+    if m is None:
+        m = E.MultiEngine([local_rank])                           # a one-rank job: no exchange inside the library
+    mg = m.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    R = 64                                                         # roots per GPU per step (weak scaling)
+    all_roots = ((np.arange(R * world, dtype=np.int64) * n) // (R * world)).astype(np.uint32)
+    lo, hi = E.shard_bounds(len(all_roots), world, rank)
+    roots = all_roots[lo:hi]
+    assert hi - lo == R
+    W = m.mask_words(mg, all_roots)
+    run_roots = all_roots if sharded_in_lib else roots             # the library shards; or this rank's slice, one-rank job
+    RA = len(all_roots) if (sharded_in_lib or (world > 1 and args.gather == "dist")) else R
+    row0 = lo if RA == len(all_roots) else 0                       # where this rank's rows sit in its tables
 
-    # double-buffered device results (row-major [root][vertex])
+    # double-buffered device results (row-major [root][vertex]); the distance table holds ALL roots when gathered
     bufs = []
     for _ in range(2):
         bufs.append(dict(
-            dist=torch.empty((R, n), dtype=torch.int32, device=dev),
-            hops=torch.empty((R, n), dtype=torch.int16, device=dev),
-            flags=torch.empty((R, n), dtype=torch.int16, device=dev),
-            mask=torch.empty((R, n, W), dtype=torch.int64, device=dev)))
-    gathered = None
-    if world > 1 and args.gather == "dist":
-        gathered = [torch.empty((world * R, n), dtype=torch.int32, device=dev) for _ in range(2)]
+            dist=torch.empty((RA, n), dtype=torch.int32, device=dev),
+            hops=torch.empty((RA if sharded_in_lib else R, n), dtype=torch.int16, device=dev),
+            flags=torch.empty((RA if sharded_in_lib else R, n), dtype=torch.int16, device=dev),
+            mask=torch.empty((RA if sharded_in_lib else R, n, W), dtype=torch.int64, device=dev)))
 
     pending = [None]
     phase = {"relax_ms": 0.0, "dag_ms": 0.0, "finish_ms": 0.0, "total_ms": 0.0, "n_relax": 0, "n_dag": 0,
              "n_exact": 0, "state_bytes": 0, "narrow_overflow": 0}
 
+    def ptrs(b, own_rows_only: bool):
+        off = row0 * n if own_rows_only else 0
+        return dict(dist=b["dist"].data_ptr() + off * 4, hops=b["hops"].data_ptr(), flags=b["flags"].data_ptr(),
+                    mask=b["mask"].data_ptr(), mask_words=W)
+
     def step(i: int, record: bool):
         b = bufs[i & 1]
-        st = ctx.run_device(G, roots, 0, dist_ptr=b["dist"].data_ptr(), hops_ptr=b["hops"].data_ptr(),
-                            flags_ptr=b["flags"].data_ptr(), mask_ptr=b["mask"].data_ptr(), mask_words=W)
-        if gathered is not None:
-            if pending[0] is not None:
-                pending[0].wait()
-            pending[0] = dist.all_gather_into_tensor(gathered[i & 1], b["dist"], async_op=True)
+        if sharded_in_lib:
+            m.run(mg, run_roots, 0, [ptrs(b, False)], E.GATHER_DIST | E.GATHER_ASYNC)
+        else:
+            m.run(mg, run_roots, 0, [ptrs(b, True)], 0)
+            if world > 1 and args.gather == "dist":
+                if pending[0] is not None:
+                    pending[0].wait()
+                pending[0] = dist.all_gather_into_tensor(b["dist"], b["dist"][row0:row0 + R], async_op=True)
         if record:
+            st = m.stats(0)
             phase["relax_ms"] += st["ms_relax"]; phase["dag_ms"] += st["ms_dag"]
             phase["finish_ms"] += st["ms_finish"]; phase["total_ms"] += st["ms_total"]
             phase["n_relax"] += st["n_relax_launches"]; phase["n_dag"] += st["n_dag_launches"]
@@ -215,6 +246,7 @@ def main():
         if pending[0] is not None:
             pending[0].wait()
             pending[0] = None
+        m.wait()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -245,31 +277,31 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # sanity inside the bench: the roots' own distances are 0 and everything was reached
     last = bufs[(timed_steps - 1) & 1]
-    d_last = last["dist"]
-    assert int((d_last[torch.arange(R, device=dev), torch.from_numpy(roots.astype(np.int64)).to(dev)] != 0).sum()) == 0
-    assert int((d_last == -1).sum()) == 0, "isis-100k is connected: every vertex must be in every SPT"
+    own = slice(row0, row0 + R)
+    hrow = own if sharded_in_lib else slice(0, R)
     assert phase["n_exact"] == 0, "headline workload must stay on the wavefront-parallel path"
 
     # what was timed is what is checked: the last timed step's results of this rank's 64 roots, every (root, vertex),
-    # bit for bit against the CPU oracle (outside the timed region; the oracle deals the roots to the host's cores)
-    verified = 0
+    # bit for bit against the CPU oracle (outside the timed region; the oracle deals the roots to the host's cores); at
+    # N > 1 rank 0 also checks the GATHERED distance table of all N x 64 roots
+    verified = verified_gathered = 0
     if rank == 0:
         from oracle import graph_oracle as go
-        ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 0, go.HEAP, mask_words_=W,
+        chk = all_roots if RA == len(all_roots) else roots
+        ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, chk, 0, go.HEAP, mask_words_=W,
                      threads=min(64, os.cpu_count() or 1))
         assert np.array_equal(last["dist"].cpu().numpy().view(np.uint32), ref.dist), "bench: distances differ from the oracle"
-        assert np.array_equal(last["hops"].cpu().numpy().view(np.uint16), ref.hops), "bench: hops differ from the oracle"
-        assert np.array_equal(last["flags"].cpu().numpy().view(np.uint16) & 1, ref.flags), "bench: in-SPT flags differ from the oracle"
-        assert np.array_equal(last["mask"].cpu().numpy().view(np.uint64), ref.mask), "bench: first-hop masks differ from the oracle"
+        o = slice(row0, row0 + R) if RA == len(all_roots) else slice(0, R)
+        assert np.array_equal(last["hops"][hrow].cpu().numpy().view(np.uint16), ref.hops[o]), "bench: hops differ from the oracle"
+        assert np.array_equal(last["flags"][hrow].cpu().numpy().view(np.uint16) & 1, ref.flags[o]), "bench: in-SPT flags differ from the oracle"
+        assert np.array_equal(last["mask"][hrow].cpu().numpy().view(np.uint64), ref.mask[o]), "bench: first-hop masks differ from the oracle"
         verified = R
+        verified_gathered = len(chk) if world > 1 else 0
         del ref
     # one extra, untimed run with the row counter on (the counting kernel instantiation is slower)
-    from holo_amd import engine as _E
-    stc = ctx.run_device(G, roots, _E.RUN_COUNT_ROWS, dist_ptr=last["dist"].data_ptr(), hops_ptr=last["hops"].data_ptr(),
-                         flags_ptr=last["flags"].data_ptr(), mask_ptr=last["mask"].data_ptr(), mask_words=W)
-    rows_recomputed = int(stc["rows_recomputed"])
+    m.run(mg, run_roots, E.RUN_COUNT_ROWS, [ptrs(last, not sharded_in_lib)], 0)
+    rows_recomputed = int(m.stats(0)["rows_recomputed"])
 
     if rank == 0:
         runs = timed_steps * R * world
@@ -300,14 +332,15 @@ def main():
             "value": round(value, 2), "unit": "spf_runs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / timed_steps * 1e3, 4),
             "timed_steps": timed_steps, "timed_ms": round(dt * 1e3, 2), "verified_roots": verified,
+            "verified_gathered_dist_roots": verified_gathered,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": "isis-100k: IS-IS L2 100000 routers / 1000000 directed entries, metrics U[1,100], "
                                    "64 concurrent SPF roots per GPU per step (BASELINE.json configs[2])",
                        "n_vertices": n, "n_entries": e, "roots_per_step_per_gpu": R, "mask_words": W,
                        "outputs": "dist u32 + hops u16 + flags u16 + first-hop mask u64 per (root,vertex), in HBM",
-                       "parallelism": f"roots sharded over {world} GPU(s), graph replicated"
-                                      + (", 1 RCCL all-gather of dist tables per step" if gathered is not None else "")},
+                       "parallelism": f"roots sharded over {world} GPU(s) by hspf_multi_run (C ABI), graph replicated",
+                       "gather": gather_via},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 3),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5),
                          "traffic": traffic,
@@ -322,11 +355,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, roots)
-            out["latency_1root"] = latency_1root(ctx, dev)
+            out["latency_1root"] = latency_1root(E.SpfContext(local_rank), dev)
         print(json.dumps(out), flush=True)
 
-    G.free()
-    ctx.close()
+    m.free_graph(mg)
+    m.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -36,7 +36,8 @@ class HspfStats(ctypes.Structure):
                 ("ms_total", ctypes.c_float), ("ms_relax", ctypes.c_float), ("ms_dag", ctypes.c_float),
                 ("ms_finish", ctypes.c_float), ("ms_d2h", ctypes.c_float),
                 ("state_bytes", ctypes.c_uint32), ("narrow_overflow", ctypes.c_uint32),
-                ("rows_recomputed", ctypes.c_uint64), ("single_wg", ctypes.c_uint32), ("reserved_", ctypes.c_uint32)]
+                ("rows_recomputed", ctypes.c_uint64), ("single_wg", ctypes.c_uint32), ("reserved_", ctypes.c_uint32),
+                ("dbg", ctypes.c_uint32 * 4)]
 
 
 class HspfPrefixTable(ctypes.Structure):
@@ -52,6 +53,17 @@ class HspfRows(ctypes.Structure):
 class HspfRoutes(ctypes.Structure):
     _fields_ = [("best_metric", ctypes.c_void_p), ("best_entry", ctypes.c_void_p), ("nexthop_mask", ctypes.c_void_p)]
 
+
+class HspfMultiConfig(ctypes.Structure):
+    _fields_ = [("n_local", ctypes.c_uint32), ("device_ordinals", ctypes.POINTER(ctypes.c_int)),
+                ("world", ctypes.c_uint32), ("first_rank", ctypes.c_uint32), ("unique_id", u8p)]
+
+
+class HspfAreaSlice(ctypes.Structure):
+    _fields_ = [("rank", ctypes.c_uint32), ("area", ctypes.c_uint32), ("root_begin", ctypes.c_uint32), ("root_end", ctypes.c_uint32)]
+
+
+COMM_ID_BYTES = 128
 
 # every symbol include/holo_spf_hip.h declares: (name, restype, argtypes)
 SYMBOLS = [
@@ -79,6 +91,25 @@ SYMBOLS = [
     ("hspf_routes_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.POINTER(HspfPrefixTable), ctypes.POINTER(HspfRoutes)]),
+    # several GPUs
+    ("hspf_multi_unique_id", ctypes.c_int, [u8p]),
+    ("hspf_multi_init", ctypes.c_int, [ctypes.POINTER(HspfMultiConfig), ctypes.POINTER(ctypes.c_void_p)]),
+    ("hspf_multi_shutdown", None, [ctypes.c_void_p]),
+    ("hspf_multi_last_error", ctypes.c_char_p, [ctypes.c_void_p]),
+    ("hspf_multi_ctx", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_uint32]),
+    ("hspf_multi_n_local", ctypes.c_uint32, [ctypes.c_void_p]),
+    ("hspf_multi_graph_upload", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(HspfCsr), ctypes.POINTER(ctypes.c_void_p)]),
+    ("hspf_multi_graph_patch", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(HspfRows)]),
+    ("hspf_multi_graph_free", None, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("hspf_multi_graph_local", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_uint32]),
+    ("hspf_shard_bounds", None, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, u32p, u32p]),
+    ("hspf_plan_areas", ctypes.c_uint32, [ctypes.c_uint32, u32p, ctypes.c_uint32, ctypes.POINTER(HspfAreaSlice), ctypes.c_uint32]),
+    ("hspf_multi_mask_words", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, u32p]),
+    ("hspf_multi_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,
+                                      ctypes.POINTER(HspfResult), ctypes.c_uint32]),
+    ("hspf_multi_wait", ctypes.c_int, [ctypes.c_void_p]),
+    ("hspf_multi_allgather_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint32]),
+    ("hspf_multi_get_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(HspfStats)]),
 ]
 
 _lib = None

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libholo_spf_hip.so")
 SOURCES = ["spf_capi.hip"]
-DEPS = ["spf_capi.hip", "spf_kernels.hip.h", "graph_build.hip.h", os.path.join("..", "..", "include", "holo_spf_hip.h")]
+DEPS = ["spf_capi.hip", "spf_kernels.hip.h", "graph_build.hip.h", "spf_multi.hip.h", os.path.join("..", "..", "include", "holo_spf_hip.h")]
 
 
 def hipcc_path() -> str:
@@ -35,7 +35,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB + ".tmp"]
+    cmd += ["-ldl", "-pthread", "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

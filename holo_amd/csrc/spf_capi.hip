@@ -106,14 +106,15 @@ struct hspf_ctx {
   size_t h_lane_cap = 0;
   uint32_t est_relax = 12, est_dag = 12, est_fused = 12;   // launch-ahead estimates (adapted run to run)
   uint32_t variant = 0;                    // HSPF_VARIANT env: kernel A/B switches (tuning only)
-  bool single_attr = false;                // k_single's dynamic-LDS attribute has been set
-  uint32_t single_max_n = 4096;            // HSPF_SINGLE_MAX_N env: largest graph that takes the one-workgroup-per-root kernel
+  uint32_t single_attr = 0;                // per k_single instantiation: its dynamic-LDS attribute has been set
+  uint32_t single_max_n = 1024;            // HSPF_SINGLE_MAX_N env: largest graph that takes the one-workgroup-per-root kernel
   hspf_stats stats = {};
 };
 
 namespace {
 
 constexpr uint32_t CHANGED_CAP = 1u << 20;   // max launches per phase
+constexpr uint32_t HSPF_MAX_LINKS = (1u << 30) - 16u;
 
 #define HIPCHK(ctx, call)                                                          \
   do {                                                                             \
@@ -123,6 +124,21 @@ constexpr uint32_t CHANGED_CAP = 1u << 20;   // max launches per phase
       return _e == hipErrorOutOfMemory ? HSPF_E_NOMEM : HSPF_E_HIP;                \
     }                                                                              \
   } while (0)
+
+// Nothing may unwind through the C boundary (the caller is Rust / ctypes): every entry point that can allocate host
+// memory runs its body through this.
+template <typename F>
+int guarded(hspf_ctx *ctx, F &&body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    if (ctx) { try { ctx->last_error = "host allocation failed"; } catch (...) {} }
+    return HSPF_E_NOMEM;
+  } catch (...) {
+    if (ctx) { try { ctx->last_error = "unexpected C++ exception"; } catch (...) {} }
+    return HSPF_E_INTERNAL;
+  }
+}
 
 int ensure(hspf_ctx *ctx, DevBuf &b, size_t bytes) {
   if (bytes <= b.cap) return HSPF_OK;
@@ -369,7 +385,8 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
   if (!ctx || !csr || !out) return HSPF_E_INVAL;
   *out = nullptr;
   const uint32_t n = csr->n_vertices, e = csr->n_edges;
-  if (n == 0 || n > (1u << 24) || e > 0x7FFFFFF0u || !csr->row_ptr || !csr->vflags || (e && (!csr->col || !csr->metric))) {
+  // link arrays are addressed through 32-bit byte offsets (buffer resources of k_fused): at most 2^30 - 16 links
+  if (n == 0 || n > (1u << 24) || e > HSPF_MAX_LINKS || !csr->row_ptr || !csr->vflags || (e && (!csr->col || !csr->metric))) {
     ctx->last_error = "hspf_graph_upload: malformed hspf_csr";
     return HSPF_E_INVAL;
   }
@@ -448,7 +465,7 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
     e_new64 += (uint64_t)(rows->row_ptr[j + 1] - rows->row_ptr[j]);
     e_new64 -= (uint64_t)(g->row_ptr[v + 1] - g->row_ptr[v]);
   }
-  if (e_new64 > 0x7FFFFFF0ull) { ctx->last_error = "hspf_graph_patch: too many links"; return HSPF_E_INVAL; }
+  if (e_new64 > HSPF_MAX_LINKS) { ctx->last_error = "hspf_graph_patch: too many links"; return HSPF_E_INVAL; }
   const uint32_t e_new = (uint32_t)e_new64;
   try {
     nrp.resize((size_t)n + 1);
@@ -578,6 +595,7 @@ uint32_t hspf_graph_n_edges(const hspf_graph *g) { return g ? g->e : 0; }
 // ---- slots ------------------------------------------------------------------------------------
 
 int hspf_mask_words(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t *out_words) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx || !g || !roots || !out_words) return HSPF_E_INVAL;
   std::vector<uint32_t> hv, hb;
   uint32_t w = 1;
@@ -590,10 +608,12 @@ int hspf_mask_words(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   }
   *out_words = w;
   return HSPF_OK;
+  });
 }
 
 int hspf_slot_table(hspf_ctx *ctx, const hspf_graph *g, uint32_t root, uint32_t *h_vertex, uint32_t *h_base,
                     uint32_t cap, uint32_t *out_total_slots) {
+  return guarded(ctx, [&]() -> int {
   if (!ctx || !g || root >= g->n) return HSPF_E_INVAL;
   std::vector<uint32_t> hv, hb;
   uint32_t total = 0;
@@ -604,6 +624,7 @@ int hspf_slot_table(hspf_ctx *ctx, const hspf_graph *g, uint32_t root, uint32_t 
   }
   if (out_total_slots) *out_total_slots = total;
   return (int)hv.size();
+  });
 }
 
 // ---- run --------------------------------------------------------------------------------------
@@ -906,9 +927,14 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       return HSPF_OK;
     };
     // Small graphs: one workgroup per root, the whole state in LDS, ONE launch (k_single) instead of a launch per sweep.
-    // Chosen by size alone: up to ctx->single_max_n vertices (HSPF_SINGLE_MAX_N, default 4096; 0 switches it off) a run
-    // of the in-LDS fixed point is shorter than the ~50 kernel boundaries of the sweep engine whatever the number of roots.
-    const bool single = n <= std::min(ctx->single_max_n, SINGLE_MAX_N) && g->e_kept <= SINGLE_MAX_E;
+    // Measured (profiles/r02e_single_threshold.jsonl, 4-neighbour grids, device time): 500 vertices 2.0-2.8x faster than
+    // the sweep engine for 1 / 64 / 1024 roots, 1024 vertices 1.7x / 2.0x / 1.0x, 2048 vertices 1.2x / 1.3x / 0.4x,
+    // 4096 vertices 0.4x: a sweep of the one-workgroup kernel is one long dependent chain at two waves per SIMD (~3 700
+    // cycles), so it wins only while the sweep engine is bound by its ~50 kernel boundaries.  Hence: up to
+    // ctx->single_max_n vertices (HSPF_SINGLE_MAX_N, default 1024; 0 switches the kernel off), twice that for at most
+    // one batch of roots.
+    const uint32_t smax = std::min(n_roots <= 64 ? ctx->single_max_n * 2u : ctx->single_max_n, SINGLE_MAX_N);
+    const bool single = n <= smax && g->e_kept <= SINGLE_MAX_E;
     if (single) {
       hipError_t er = hipMemsetAsync(d_lf, 0, (size_t)L * 4, s);
       if (er == hipSuccess && count_rows) er = hipMemsetAsync(d_kcnt, 0, 256 * 4, s);
@@ -919,14 +945,19 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       const bool lds_links = lds_full <= (n_roots > 256 ? SINGLE_LDS_MAX / 2 : SINGLE_LDS_MAX);
       const size_t lds = single_lds_bytes(n, g->e_kept, lds_links);
       const uint32_t thr = std::min<uint32_t>(SINGLE_THREADS, std::max<uint32_t>(64u, (n + 63u) / 64u * 64u));
+      const uint32_t need_vpt = (n + thr - 1) / thr;                  // 1 .. 8
       SingleArgs sa{d_fg, d_roots, fp_wide, net_nh, ignore_ovl, n_roots, count_rows ? 1u : 0u, lds_links ? 1u : 0u, d_lf, od};
-      if (!ctx->single_attr) {      // more than 64 KB of dynamic LDS has to be allowed per kernel, once
-        (void)hipFuncSetAttribute((const void *)k_single<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SINGLE_LDS_MAX);
-        (void)hipFuncSetAttribute((const void *)k_single<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SINGLE_LDS_MAX);
-        ctx->single_attr = true;
+      const bool mi = g->max_path_metric == HSPF_DIST_INF;
+      void (*kern)(SingleArgs) = nullptr;
+#define HSPF_PICK(V_) (lds_links ? (mi ? k_single<true, V_, true> : k_single<false, V_, true>) : (mi ? k_single<true, V_, false> : k_single<false, V_, false>))
+      kern = need_vpt <= 1 ? HSPF_PICK(1) : need_vpt <= 2 ? HSPF_PICK(2) : need_vpt <= 4 ? HSPF_PICK(4) : HSPF_PICK(8);
+#undef HSPF_PICK
+      const int slot = ((need_vpt <= 1 ? 0 : need_vpt <= 2 ? 1 : need_vpt <= 4 ? 2 : 3) * 2 + (mi ? 1 : 0)) * 2 + (lds_links ? 1 : 0);
+      if (!(ctx->single_attr & (1u << slot))) {      // more than 64 KB of dynamic LDS has to be allowed per kernel, once
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SINGLE_LDS_MAX);
+        ctx->single_attr |= 1u << slot;
       }
-      if (g->max_path_metric == HSPF_DIST_INF) hipLaunchKernelGGL((k_single<true>), dim3(n_roots), dim3(thr), lds, s, sa);
-      else                                     hipLaunchKernelGGL((k_single<false>), dim3(n_roots), dim3(thr), lds, s, sa);
+      hipLaunchKernelGGL(kern, dim3(n_roots), dim3(thr), lds, s, sa);
       (void)hipEventRecord(ctx->ev[2], s);
       (void)hipEventRecord(ctx->ev[3], s);
       er = hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s);
@@ -935,7 +966,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       if (er == hipSuccess) er = hipGetLastError();
       if (er != hipSuccess) { ctx->last_error = std::string("k_single: ") + hipGetErrorString(er); return HSPF_E_HIP; }
       st.n_relax_launches = 1; st.single_wg = 1;
-      if (count_rows) for (uint32_t i = 0; i < 256; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
+      if (count_rows) {
+        for (uint32_t i = 0; i < 128; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
+        for (uint32_t i = 0; i < 3; ++i) st.dbg[i] = ctx->h_lane_flags[L + 128 + i];   // sweeps, shader cycles, 100 MHz ticks of workgroup 0
+      }
       narrow = false;
     } else if (narrow) {
       if ((rc = fused_run(true))) return rc;
@@ -1153,11 +1187,11 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
 }
 
 int hspf_run(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags, hspf_result *out) {
-  return run_classes(ctx, g, roots, n_roots, run_flags, out, true);
+  return guarded(ctx, [&]() { return run_classes(ctx, g, roots, n_roots, run_flags, out, true); });
 }
 
 int hspf_run_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags, hspf_result *out_device) {
-  return run_classes(ctx, g, roots, n_roots, run_flags, out_device, false);
+  return guarded(ctx, [&]() { return run_classes(ctx, g, roots, n_roots, run_flags, out_device, false); });
 }
 
 int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out) {
@@ -1190,10 +1224,15 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
     HIPCHK(ctx, hipMemcpyAsync(ctx->pf_vtx.p, t->pfx_vertex, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(ctx->pf_met.p, t->pfx_metric, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
   }
-  hipLaunchKernelGGL(k_routes, dim3((t->n_prefixes + 255) / 256, n_roots), dim3(256), 0, s, n_vertices, n_roots, n_mask_words,
-                     t->n_prefixes, (const uint32_t *)ctx->pf_ptr.p, (const uint32_t *)ctx->pf_vtx.p,
-                     (const uint32_t *)ctx->pf_met.p, dist_dev, flags_dev, mask_dev, out->best_metric, out->best_entry,
-                     out->nexthop_mask, t->flags);
+  // gridDim.y is capped at 65535: "every router as a root" on a large LSDB goes in slabs of roots
+  for (uint32_t r0 = 0; r0 < n_roots; r0 += 65535u) {
+    const uint32_t nr = std::min(65535u, n_roots - r0);
+    const size_t ov = (size_t)r0 * n_vertices, op = (size_t)r0 * t->n_prefixes;
+    hipLaunchKernelGGL(k_routes, dim3((t->n_prefixes + 255) / 256, nr), dim3(256), 0, s, n_vertices, nr, n_mask_words,
+                       t->n_prefixes, (const uint32_t *)ctx->pf_ptr.p, (const uint32_t *)ctx->pf_vtx.p,
+                       (const uint32_t *)ctx->pf_met.p, dist_dev + ov, flags_dev + ov, mask_dev + ov * n_mask_words,
+                       out->best_metric + op, out->best_entry + op, out->nexthop_mask + op * n_mask_words, t->flags);
+  }
   HIPCHK(ctx, hipStreamSynchronize(s));       // the table was read from caller-owned host memory
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { ctx->last_error = std::string("k_routes: ") + hipGetErrorString(le); return HSPF_E_HIP; }
@@ -1201,3 +1240,5 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
 }
 
 }  // extern "C"
+
+#include "spf_multi.hip.h"

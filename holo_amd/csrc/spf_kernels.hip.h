@@ -229,8 +229,9 @@ __global__ __launch_bounds__(256) void k_relax(GraphDev g, uint32_t *__restrict_
 // final row with hops != 0 always has a non-zero mask word (every non-first-hop vertex inherits
 // at least one slot), the mask array starts at 0 and is written exactly once: a reader that sees
 // a stale or not-yet-written mask sees 0 and simply treats the parent as pending.
-// In-links of a row are stored in ascending source order (upload keeps it), so the first link
-// with the minimal parent distance IS the earliest-popped tight parent (first discoverer).
+// In-links of a row are stored by (cost descending, source ascending) — graph_build.hip.h, kb_rank —, so among the
+// tight links the first one in row order has the smallest parent distance and, on ties, the smallest parent index:
+// the earliest-popped tight parent (first discoverer).
 template <int W, bool GS>
 __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restrict__ dist,
                                              uint32_t *__restrict__ hv, uint64_t *__restrict__ mask,
@@ -869,17 +870,58 @@ struct SingleArgs {
   OutDev o;
 };
 
-// LDS layout (dynamic): state words [n] | when lds_links: in_ptr [n+1] (u32) | link records [e] (u32x2: source|NT, cost).
-// The link records do not change during a run; staged once, a sweep touches global memory only for the rare
-// first-hop-slot lookups.
+// LDS layout (dynamic): state words [n] | when the links are staged, per link: source|NT, cost, position in the source's
+// row (3 x u32 arrays).  The link records do not change during a run; staged once, a sweep touches global memory only
+// for the slot base of a hops-0 NETWORK parent (the root's own base is 0).  Row bounds, vertex kind and "needs the
+// general routine" of a thread's own vertices stay in registers for the whole run.
 __host__ __device__ inline size_t single_lds_bytes(uint32_t n, uint32_t e, bool lds_links) {
-  return (size_t)n * 8 + (lds_links ? (((size_t)n + 2) / 2 * 2 * 4 + (size_t)e * 8) : 0);
+  return (size_t)n * 8 + (lds_links ? (size_t)e * 12 : 0);
 }
 
-template <bool MAXINF>
+constexpr uint32_t SINGLE_VPT_MAX = SINGLE_MAX_N / SINGLE_THREADS;     // vertices per thread at most (8)
+
+// One link into the row accumulator: the per-lane form of fused_row_any's loop body.  RARE = the row has an
+// overloaded source, a zero-cost link from a higher-numbered source, or the graph is hop-count-like.
+template <bool MAXINF, bool RARE>
+__device__ __forceinline__ void single_link(RowAcc &r, uint32_t &bd_all, uint32_t &zb, uint32_t &zm, uint32_t &zh,
+                                            uint32_t sw, uint32_t w, uint32_t fpos, uint64_t q, uint32_t v, uint32_t v_router,
+                                            uint32_t my_root, uint32_t root_slot, const SingleArgs &a, const FusedParams &P,
+                                            uint32_t mmask) {
+  const uint32_t u = sw & SRC_MASK;
+  uint32_t d = (uint32_t)(q >> 32);
+  const uint32_t pay = (uint32_t)q;
+  if (RARE && !a.ignore_ovl && (sw & SRC_NO_TRANSIT) && u != my_root) d = INF;        // overloaded source
+  const uint32_t c = add_sat(d, w);
+  if (MAXINF && c == INF && d != INF) r.sat = true;
+  const bool zlink = RARE && w == 0u && u >= v;
+  if (RARE && zlink && !P.hc) { bd_all = min(bd_all, c); return; }
+  const bool hz = RARE && P.hc && zlink;
+  const bool lt = hz ? (c < zb) : (c < r.bd), eq = !hz && c == r.bd;
+  const uint32_t hh = pay >> P.mbits;
+  uint32_t contrib = pay & mmask;
+  if ((lt || eq) && hh == 0u && c < P.inf_t) {                               // parent: root or hops-0 network
+    const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(a.gp->tabs, root_slot, u);
+    const uint32_t sidx = base_s + fpos;
+    contrib = ((v_router || a.net_nexthops) && sidx < P.mbits) ? (1u << sidx) : 0u;
+  }
+  if (hz) { if (lt) { zb = c; zm = contrib; zh = hh; } return; }             // see fused_row_any
+  const uint32_t m_or = r.bm | contrib;
+  r.bm = lt ? contrib : (eq ? m_or : r.bm);
+  const bool newp = lt || (eq && d < r.bpd);
+  r.bpd = newp ? d : r.bpd;
+  r.bh = newp ? hh : r.bh;
+  r.bd = min(r.bd, c);
+}
+
+// VPT = vertices per thread (1, 2, 4 or 8: the host picks the smallest that covers n with the block size it launches).
+// LL = the link records are staged in LDS: a template parameter, not a run-time select, so that the loads are
+// ds_read — a pointer that may be LDS or global compiles to FLAT loads, whose latency is that of a global load
+// (measured: 3 700 cycles per sweep on ospf-500 with the select, profiles/r02_notes.md).
+template <bool MAXINF, int VPT, bool LL>
 __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
+  constexpr uint32_t SINGLE_VPT = (uint32_t)VPT;
   extern __shared__ uint64_t s_st[];
-  __shared__ int s_changed[2];
+  __shared__ int s_changed[4];
   const GraphDev &g = a.gp->g;
   const uint32_t n = g.n;
   const uint32_t root_slot = blockIdx.x;
@@ -897,87 +939,86 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
     }
     return;
   }
+  const uint64_t t_clk0 = clock64(), t_wall0 = wall_clock64();
   const uint32_t e_in = g.e_in;
-  uint32_t *const s_ptr = (uint32_t *)(s_st + n);
-  u32x2 *const s_rec = (u32x2 *)(s_ptr + ((size_t)n + 2) / 2 * 2);
-  const bool ll = a.lds_links != 0u;
+  uint32_t *const s_src = (uint32_t *)(s_st + n);
+  uint32_t *const s_w = s_src + e_in;
+  uint32_t *const s_fp = s_w + e_in;
+  const uint32_t *const g_src = g.in_src, *const g_w = g.in_w, *const g_fp = g.in_fpos;
   for (uint32_t v = tid; v < n; v += nthr) s_st[v] = (v == my_root) ? 0ull : ~0ull;
-  if (ll) {
-    for (uint32_t v = tid; v <= n; v += nthr)       // bit 31: the vertex is a network (in_ptr values stay below 2^31)
-      s_ptr[v] = g.in_ptr[v] | ((v < n && (g.vflags[v] & 1u)) ? 0x80000000u : 0u);
-    for (uint32_t e = tid; e < e_in; e += nthr) s_rec[e] = u32x2{g.in_src[e], g.in_w[e]};
+  if (LL) {
+    for (uint32_t e = tid; e < e_in; e += nthr) { s_src[e] = g_src[e]; s_w[e] = g_w[e]; s_fp[e] = g_fp[e]; }
   }
-  if (tid < 2) s_changed[tid] = 0;
+  if (tid < 4) s_changed[tid] = 0;
+  // this thread's vertices: row bounds, kind and "needs the general routine" in registers for the whole run
+  uint32_t ce0[SINGLE_VPT], ce1[SINGLE_VPT];       // ce1 bit 31: network, bit 30: rare row
+  uint64_t cur[SINGLE_VPT];
+#pragma unroll
+  for (uint32_t i = 0; i < SINGLE_VPT; ++i) {
+    const uint32_t v = tid + i * nthr;
+    ce0[i] = 0u; ce1[i] = 0u; cur[i] = ~0ull;
+    if (v < n) {
+      const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
+      bool rare = P.hc != 0u;
+      for (uint32_t e = e0; e < e1; ++e) {
+        const uint32_t sw = g.in_src[e];
+        rare = rare || (!a.ignore_ovl && (sw & SRC_NO_TRANSIT)) || (g.in_w[e] == 0u && (sw & SRC_MASK) >= v);
+      }
+      ce0[i] = e0;
+      ce1[i] = e1 | ((g.vflags[v] & 1u) ? 0x80000000u : 0u) | (rare ? 0x40000000u : 0u);
+      cur[i] = (v == my_root) ? 0ull : ~0ull;
+    }
+  }
   __syncthreads();
   bool sat = false, need_exact = false, ovf = false;
   const uint32_t max_sweeps = 4u * n + 64u;        // far beyond any run; a run that gets there is handed to k_exact
   uint32_t sweep = 0;
   for (;; ++sweep) {
     bool any = false;
-    for (uint32_t v = tid; v < n; v += nthr) {
-      if (v == my_root) continue;
-      const uint32_t p0 = ll ? s_ptr[v] : g.in_ptr[v];
-      const uint32_t e0 = p0 & 0x7FFFFFFFu, e1 = (ll ? s_ptr[v + 1] : g.in_ptr[v + 1]) & 0x7FFFFFFFu;
-      const uint32_t v_router = ll ? ((p0 >> 31) ^ 1u) : ((g.vflags[v] & 1u) ? 0u : 1u);
+#pragma unroll
+    for (uint32_t i = 0; i < SINGLE_VPT; ++i) {
+      const uint32_t v = tid + i * nthr;
+      if (v >= n || v == my_root) continue;
+      const uint32_t e0 = ce0[i], e1 = ce1[i] & 0x3FFFFFFFu;
+      const uint32_t v_router = (ce1[i] >> 31) ^ 1u;
+      const bool rare = (ce1[i] & 0x40000000u) != 0u;
       RowAcc r{INF, 0u, INF, 0u, false};
       uint32_t bd_all = INF, zb = INF, zm = 0u, zh = 0u;
       constexpr uint32_t PF = 4;                    // link records, then their sources' states, of 4 links in flight
       for (uint32_t eb = e0; eb < e1; eb += PF) {
-        u32x2 rec[PF];
+        uint32_t rs[PF], rw[PF], rf[PF];
         uint64_t qs[PF];
 #pragma unroll
         for (uint32_t k = 0; k < PF; ++k) {
           const uint32_t e = min(eb + k, e1 - 1u);
-          rec[k] = ll ? s_rec[e] : u32x2{g.in_src[e], g.in_w[e]};
+          if (LL) { rs[k] = s_src[e]; rw[k] = s_w[e]; rf[k] = s_fp[e]; }
+          else    { rs[k] = g_src[e]; rw[k] = g_w[e]; rf[k] = g_fp[e]; }
         }
 #pragma unroll
-        for (uint32_t k = 0; k < PF; ++k) qs[k] = s_st[rec[k].x & SRC_MASK];
+        for (uint32_t k = 0; k < PF; ++k) qs[k] = s_st[rs[k] & SRC_MASK];
 #pragma unroll
         for (uint32_t k = 0; k < PF; ++k) {
-          const uint32_t e = eb + k;
-          if (e >= e1) break;
-          const uint32_t sw = rec[k].x, w = rec[k].y;
-          const uint32_t u = sw & SRC_MASK;
-          const uint64_t q = qs[k];
-          uint32_t d = (uint32_t)(q >> 32);
-          const uint32_t pay = (uint32_t)q;
-          if (!a.ignore_ovl && (sw & SRC_NO_TRANSIT) && u != my_root) d = INF;        // overloaded source
-          const uint32_t c = add_sat(d, w);
-          if (MAXINF && c == INF && d != INF) r.sat = true;
-          const bool zlink = w == 0u && u >= v;
-          if (zlink && !P.hc) { bd_all = min(bd_all, c); continue; }
-          const bool lt = (P.hc && zlink) ? (c < zb) : (c < r.bd), eq = !(P.hc && zlink) && c == r.bd;
-          const uint32_t hh = pay >> P.mbits;
-          uint32_t contrib = pay & mmask;
-          if ((lt || eq) && hh == 0u && c < P.inf_t) {                               // parent: root or hops-0 network
-            const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(a.gp->tabs, root_slot, u);
-            const uint32_t sidx = base_s + g.in_fpos[e];
-            contrib = ((v_router || a.net_nexthops) && sidx < P.mbits) ? (1u << sidx) : 0u;
-          }
-          if (P.hc && zlink) { if (lt) { zb = c; zm = contrib; zh = hh; } continue; }   // see fused_row_any
-          const uint32_t m_or = r.bm | contrib;
-          r.bm = lt ? contrib : (eq ? m_or : r.bm);
-          const bool newp = lt || (eq && d < r.bpd);
-          r.bpd = newp ? d : r.bpd;
-          r.bh = newp ? hh : r.bh;
-          r.bd = min(r.bd, c);
+          if (eb + k >= e1) break;
+          if (rare) single_link<MAXINF, true>(r, bd_all, zb, zm, zh, rs[k], rw[k], rf[k], qs[k], v, v_router, my_root, root_slot, a, P, mmask);
+          else      single_link<MAXINF, false>(r, bd_all, zb, zm, zh, rs[k], rw[k], rf[k], qs[k], v, v_router, my_root, root_slot, a, P, mmask);
         }
       }
-      if (P.hc) {
+      if (rare && P.hc) {
         const bool late = zb < r.bd;
         r.bm = late ? zm : r.bm; r.bh = late ? zh : r.bh; r.bd = late ? zb : r.bd;
       }
       const RowOut<uint64_t> o = finish_row<uint64_t>(r, v, my_root, v_router, bd_all, P);
       sat = sat || o.sat; need_exact = need_exact || o.need_exact; ovf = ovf || o.ovf;
-      if (o.nw != s_st[v]) { s_st[v] = o.nw; any = true; }
+      if (o.nw != cur[i]) { cur[i] = o.nw; s_st[v] = o.nw; any = true; }
     }
-    if (any) s_changed[sweep & 1u] = 1;
+    // ONE barrier per sweep: flag slot sweep & 3 is set during sweep `sweep`, read after its barrier, and cleared by
+    // thread 0 during sweep + 2 — after every thread has passed the barrier of sweep + 1 and therefore finished reading
+    // it, and two barriers before sweep + 4 sets it again.
+    if (any) s_changed[sweep & 3u] = 1;
+    if (tid == 0) s_changed[(sweep + 2u) & 3u] = 0;
     __syncthreads();
-    const bool go_on = s_changed[sweep & 1u] != 0;
-    if (tid == 0) s_changed[(sweep + 1u) & 1u] = 0;
-    if (!go_on) break;
+    if (s_changed[sweep & 3u] == 0) break;
     if (sweep >= max_sweeps) { need_exact = true; break; }
-    __syncthreads();                               // the flag of the next sweep is clear before anyone sets it
   }
   // results: one row of the row-major outputs per root, consecutive threads = consecutive vertices
   for (uint32_t v = tid; v < n; v += nthr) {
@@ -996,7 +1037,14 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
   if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
   if (ovf) lf |= LF_OVERFLOW;
   if (lf) atomicOr(&a.lane_flags[root_slot], lf);
-  if (a.count_rows && tid == 0) atomicAdd(&a.gp->rows_done[root_slot & 255u], (sweep + 1u) * n);   // HSPF_RUN_COUNT_ROWS
+  if (a.count_rows && tid == 0) {                  // HSPF_RUN_COUNT_ROWS: rows evaluated; workgroup 0 also leaves its sweep
+    atomicAdd(&a.gp->rows_done[root_slot & 127u], (sweep + 1u) * n);   // count, shader cycles and 100 MHz wall ticks
+    if (root_slot == 0) {
+      a.gp->rows_done[128] = sweep + 1u;
+      a.gp->rows_done[129] = (uint32_t)(clock64() - t_clk0);
+      a.gp->rows_done[130] = (uint32_t)(wall_clock64() - t_wall0);
+    }
+  }
 }
 
 // Per-batch row flags = the graph's static ones (k_init_fused then adds RF_HNB).

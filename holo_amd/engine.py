@@ -209,7 +209,9 @@ class SpfContext:
     def stats(self) -> dict:
         s = L.HspfStats()
         self.lib.hspf_get_stats(self.handle, ctypes.byref(s))
-        return {name: getattr(s, name) for name, _ in L.HspfStats._fields_}
+        out = {name: getattr(s, name) for name, _ in L.HspfStats._fields_}
+        out["dbg"] = list(out["dbg"])
+        return out
 
     def run(self, graph: SpfGraph, roots: Sequence[int], run_flags: int = 0, *, want_mask: bool = True,
             mask_words: Optional[int] = None) -> SpfResult:
@@ -274,4 +276,127 @@ class SpfContext:
         try:
             self.close()
         except Exception:
+            pass
+
+
+# ---- several GPUs: hspf_multi_* (include/holo_spf_hip.h "several GPUs") -------------------------------------------------
+
+GATHER_DIST, GATHER_HOPS, GATHER_FLAGS, GATHER_MASK = 1, 2, 4, 8
+GATHER_ASYNC = 0x100
+
+
+def shard_bounds(n_roots: int, world: int, rank: int):
+    """hspf_shard_bounds: [begin, end) of `rank` — whole 64-root batches (pure host arithmetic, no GPU needed)."""
+    lib = L.load()
+    b, e = ctypes.c_uint32(), ctypes.c_uint32()
+    lib.hspf_shard_bounds(n_roots, world, rank, ctypes.byref(b), ctypes.byref(e))
+    return int(b.value), int(e.value)
+
+
+def plan_areas(roots_per_area: Sequence[int], world: int):
+    """hspf_plan_areas: areas first, then roots — list of (rank, area, root_begin, root_end)."""
+    lib = L.load()
+    rpa = np.ascontiguousarray(roots_per_area, np.uint32)
+    n = lib.hspf_plan_areas(len(rpa), _u32(rpa), world, None, 0)
+    buf = (L.HspfAreaSlice * max(n, 1))()
+    lib.hspf_plan_areas(len(rpa), _u32(rpa), world, buf, n)
+    return [(int(s.rank), int(s.area), int(s.root_begin), int(s.root_end)) for s in buf[:n]]
+
+
+def multi_unique_id() -> bytes:
+    lib = L.load()
+    buf = (ctypes.c_uint8 * L.COMM_ID_BYTES)()
+    rc = lib.hspf_multi_unique_id(buf)
+    if rc != 0:
+        raise HspfError(rc, "hspf_multi_unique_id")
+    return bytes(buf)
+
+
+class MultiEngine:
+    """hspf_multi: one engine context per rank.  `devices` = the ordinals this process drives (an ordinal may repeat:
+    several contexts on one GPU); single process when unique_id is None (world = len(devices)), else one member of a
+    job of `world` ranks whose RCCL communicator is created from `unique_id`."""
+
+    def __init__(self, devices: Sequence[int], world: Optional[int] = None, first_rank: int = 0, unique_id: Optional[bytes] = None):
+        self.lib = L.load()
+        self.devices = list(devices)
+        self.world = world if world is not None else len(self.devices)
+        self.first_rank = first_rank
+        ords = (ctypes.c_int * len(self.devices))(*self.devices)
+        idbuf = (ctypes.c_uint8 * L.COMM_ID_BYTES)(*unique_id) if unique_id is not None else None
+        cfg = L.HspfMultiConfig(len(self.devices), ords, self.world, first_rank, idbuf)
+        h = ctypes.c_void_p()
+        rc = self.lib.hspf_multi_init(ctypes.byref(cfg), ctypes.byref(h))
+        if rc != 0:
+            raise HspfError(rc, "hspf_multi_init")
+        self.handle = h
+        self.graph = None
+
+    def last_error(self) -> str:
+        return (self.lib.hspf_multi_last_error(self.handle) or b"").decode()
+
+    def ctx_handle(self, i: int):
+        return self.lib.hspf_multi_ctx(self.handle, i)
+
+    def upload(self, row_ptr, col, metric, vflags, max_path_metric: int):
+        row_ptr = np.ascontiguousarray(row_ptr, np.uint32); col = np.ascontiguousarray(col, np.uint32)
+        metric = np.ascontiguousarray(metric, np.uint32); vflags = np.ascontiguousarray(vflags, np.uint8)
+        csr = L.HspfCsr(len(row_ptr) - 1, len(col), _u32(row_ptr), _u32(col), _u32(metric),
+                        vflags.ctypes.data_as(L.u8p), max_path_metric)
+        g = ctypes.c_void_p()
+        rc = self.lib.hspf_multi_graph_upload(self.handle, ctypes.byref(csr), ctypes.byref(g))
+        if rc != 0:
+            raise HspfError(rc, "hspf_multi_graph_upload", self.last_error())
+        return g
+
+    def free_graph(self, g):
+        self.lib.hspf_multi_graph_free(self.handle, g)
+
+    def mask_words(self, g, roots) -> int:
+        roots = np.ascontiguousarray(roots, np.uint32)
+        w = ctypes.c_uint32()
+        rc = self.lib.hspf_multi_mask_words(self.handle, g, _u32(roots), len(roots), ctypes.byref(w))
+        if rc != 0:
+            raise HspfError(rc, "hspf_multi_mask_words", self.last_error())
+        return int(w.value)
+
+    def run(self, g, roots, run_flags: int, results: Sequence[dict], gather: int) -> None:
+        """hspf_multi_run: results[i] = dict(dist=ptr, hops=ptr, flags=ptr, mask=ptr, mask_words=W) of device pointers on
+        local device i, each table sized for ALL roots."""
+        roots = np.ascontiguousarray(roots, np.uint32)
+        arr = (L.HspfResult * len(results))()
+        for i, r in enumerate(results):
+            arr[i] = L.HspfResult(r["dist"], r.get("hops") or None, r.get("flags") or None, r.get("mask") or None,
+                                  r.get("mask_words", 1), None)
+        rc = self.lib.hspf_multi_run(self.handle, g, _u32(roots), len(roots), run_flags, arr, gather)
+        if rc != 0:
+            raise HspfError(rc, "hspf_multi_run", self.last_error())
+
+    def wait(self) -> None:
+        rc = self.lib.hspf_multi_wait(self.handle)
+        if rc != 0:
+            raise HspfError(rc, "hspf_multi_wait", self.last_error())
+
+    def allgather_rows(self, table_ptrs: Sequence[int], row_bytes: int, n_roots: int) -> None:
+        arr = (ctypes.c_void_p * len(table_ptrs))(*table_ptrs)
+        rc = self.lib.hspf_multi_allgather_rows(self.handle, arr, row_bytes, n_roots)
+        if rc != 0:
+            raise HspfError(rc, "hspf_multi_allgather_rows", self.last_error())
+
+    def stats(self, i: int = 0) -> dict:
+        s = L.HspfStats()
+        self.lib.hspf_multi_get_stats(self.handle, i, ctypes.byref(s))
+        out = {name: getattr(s, name) for name, _ in L.HspfStats._fields_}
+        out["dbg"] = list(out["dbg"])
+        return out
+
+    def close(self):
+        if self.handle:
+            self.lib.hspf_multi_shutdown(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
             pass

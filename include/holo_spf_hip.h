@@ -158,6 +158,8 @@ typedef struct {
                                   (holo-isis/src/spf.rs:552-556), i.e. n_batches * n_vertices rows would be 1x */
   uint32_t single_wg;          /* 1: small graph, the run took the one-workgroup-per-root kernel (one launch)     */
   uint32_t reserved_;
+  uint32_t dbg[4];             /* HSPF_RUN_COUNT_ROWS on the one-workgroup path: sweeps, shader cycles and 100 MHz wall
+                                  ticks of the first root's workgroup                                             */
 } hspf_stats;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -289,6 +291,87 @@ typedef struct {
 int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uint32_t n_mask_words,
                        const uint32_t *dist_dev, const uint16_t *flags_dev, const uint64_t *mask_dev,
                        const hspf_prefix_table *table, hspf_routes *out_dev);
+
+/* ---- several GPUs --------------------------------------------------------------------------
+ * SPF roots are independent units over a read-only graph: the graph is replicated on every GPU, whole 64-root
+ * wavefront batches are dealt to the ranks (hspf_shard_bounds), every rank runs its slice, and ONE all-gather per
+ * table gives every rank the rows of all roots.  The reference has no analogue — its only multi-root caller is the
+ * sequential loop of holo-isis/src/flooding/manet.rs:47-69; what this replaces on the holo side is that loop and the
+ * per-area fan-out of holo-ospf/src/spf.rs:540-542.
+ *
+ * A rank is one engine context on one device.  Two job shapes:
+ *   single process  hspf_multi_config.unique_id == NULL, world == n_local: the process drives every device (one host
+ *                   thread per device inside hspf_multi_run); the gather is direct device-to-device copies over
+ *                   xGMI (every device pushes its slice to every other one: the all-to-all pattern a fully
+ *                   connected xGMI mesh is built for).  device_ordinals may repeat an ordinal — several contexts and
+ *                   streams on one GPU — which is how the path is tested on a one-GPU box.
+ *   one process per GPU  (n_local = 1, world = number of processes): rank 0 creates a communicator id with
+ *                   hspf_multi_unique_id, the HOST transports its 128 bytes to the other processes (holo would use its
+ *                   ibus; bench.py uses torch.distributed), every process calls hspf_multi_init with it; the gather is
+ *                   ncclAllGather / ncclBroadcast of RCCL (librccl.so, loaded at run time) on the contexts' streams.
+ * Every call is collective over the ranks of the job and synchronous. */
+typedef struct hspf_multi hspf_multi;
+typedef struct hspf_multi_graph hspf_multi_graph;
+#define HSPF_COMM_ID_BYTES 128
+typedef struct {
+  uint32_t       n_local;          /* devices driven by this process                                              */
+  const int     *device_ordinals;  /* [n_local]                                                                   */
+  uint32_t       world;            /* ranks of the job                                                            */
+  uint32_t       first_rank;       /* rank of local device 0 (local device i is rank first_rank + i)              */
+  const uint8_t *unique_id;        /* NULL, or HSPF_COMM_ID_BYTES bytes from hspf_multi_unique_id                 */
+} hspf_multi_config;
+
+int         hspf_multi_unique_id(uint8_t id[HSPF_COMM_ID_BYTES]);      /* needs librccl.so                        */
+int         hspf_multi_init(const hspf_multi_config *cfg, hspf_multi **out);
+void        hspf_multi_shutdown(hspf_multi *m);
+const char *hspf_multi_last_error(const hspf_multi *m);
+hspf_ctx   *hspf_multi_ctx(hspf_multi *m, uint32_t local_index);      /* the rank's context, for the one-device calls */
+uint32_t    hspf_multi_n_local(const hspf_multi *m);
+
+int  hspf_multi_graph_upload(hspf_multi *m, const hspf_csr *csr, hspf_multi_graph **out);   /* a replica per local device */
+int  hspf_multi_graph_patch(hspf_multi *m, hspf_multi_graph *g, const hspf_rows *rows);
+void hspf_multi_graph_free(hspf_multi *m, hspf_multi_graph *g);
+hspf_graph *hspf_multi_graph_local(hspf_multi_graph *g, uint32_t local_index);
+
+/* [begin, end) of rank `rank` in a list of n_roots roots: whole 64-root batches dealt as evenly as possible, the
+ * first n_batches % world ranks take one more, the ragged tail goes to the last rank that has work. */
+void hspf_shard_bounds(uint32_t n_roots, uint32_t world, uint32_t rank, uint32_t *begin, uint32_t *end);
+
+/* Areas first, then roots (BASELINE configs[3]): every area is its own graph with its own root list;
+ * the (area, 64-root batch) units, in area order, are cut into `world` contiguous runs of equal batch counts, so a
+ * rank touches as few areas as possible (it uploads only those) and no batch is split.  Writes one slice per (rank,
+ * area) pair that has work, rank-major; returns the number of slices (may exceed cap; nothing beyond cap is written). */
+typedef struct { uint32_t rank, area, root_begin, root_end; } hspf_area_slice;
+uint32_t hspf_plan_areas(uint32_t n_areas, const uint32_t *roots_per_area, uint32_t world,
+                         hspf_area_slice *out, uint32_t cap);
+
+/* Number of mask words the roots of the whole job need (every rank passes the same list). */
+int hspf_multi_mask_words(hspf_multi *m, const hspf_multi_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t *out_words);
+
+/* Sharded run.  `all[i]` (i < n_local) are DEVICE buffers on local device i sized for ALL n_roots roots, laid out as
+ * for hspf_run_device ([n_roots][n_vertices] ...).  Rank r computes rows [begin_r, end_r) straight into its own
+ * buffers; the tables selected in `gather` (present in `all`) are then all-gathered in place, so that on return every
+ * local device holds those tables for every root.  gather = 0: no exchange (each device holds its own rows only). */
+#define HSPF_GATHER_DIST   0x1u
+#define HSPF_GATHER_HOPS   0x2u
+#define HSPF_GATHER_FLAGS  0x4u
+#define HSPF_GATHER_MASK   0x8u
+/* The exchange is enqueued on the ranks' communication streams and the call returns when the ranks' OWN rows are
+ * complete: the gather then overlaps whatever the caller does next — typically the next hspf_multi_run into a second
+ * set of tables.  A later hspf_multi_run into the SAME tables first waits for their pending gather; hspf_multi_wait
+ * waits for all of them (call it before reading gathered rows). */
+#define HSPF_GATHER_ASYNC  0x100u
+int hspf_multi_wait(hspf_multi *m);
+int hspf_multi_run(hspf_multi *m, const hspf_multi_graph *g, const uint32_t *roots, uint32_t n_roots,
+                   uint32_t run_flags, hspf_result *all, uint32_t gather);
+
+/* The collective on its own, for any per-root table (route tables after hspf_routes_device: "a single all-gather of
+ * per-root route tables", BASELINE north_star): tables[i] is a device buffer on local device i of n_roots rows of
+ * row_bytes bytes whose rows [begin_r, end_r) are filled; on return all rows are, on every device. */
+int hspf_multi_allgather_rows(hspf_multi *m, void *const *tables, size_t row_bytes, uint32_t n_roots);
+
+/* Statistics of the last hspf_multi_run on local device i (as hspf_get_stats). */
+int hspf_multi_get_stats(const hspf_multi *m, uint32_t local_index, hspf_stats *out);
 
 #ifdef __cplusplus
 }

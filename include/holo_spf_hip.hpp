@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <utility>
 #include <algorithm>
@@ -33,9 +34,20 @@ struct Tables {                       // row-major [root][vertex] host results o
 
 class Engine;
 
+// The engine context, shared by the Engine and every Graph made from it: a Graph that outlives its Engine (members
+// declared in the wrong order, a Graph moved out of the Engine's scope) keeps the context alive until it has freed its
+// device arrays, instead of handing hspf_graph_free a dangling ctx.
+struct CtxHolder {
+  hspf_ctx *ctx = nullptr;
+  CtxHolder() = default;
+  CtxHolder(const CtxHolder &) = delete;
+  CtxHolder &operator=(const CtxHolder &) = delete;
+  ~CtxHolder() { if (ctx) hspf_shutdown(ctx); }
+};
+
 class Graph {
  public:
-  Graph(Graph &&o) noexcept : ctx_(o.ctx_), g_(o.g_) { o.g_ = nullptr; }
+  Graph(Graph &&o) noexcept : holder_(std::move(o.holder_)), ctx_(o.ctx_), g_(o.g_) { o.g_ = nullptr; }
   Graph(const Graph &) = delete;
   Graph &operator=(const Graph &) = delete;
   ~Graph() { if (g_) hspf_graph_free(ctx_, g_); }
@@ -71,20 +83,22 @@ class Graph {
 
  private:
   friend class Engine;
-  Graph(hspf_ctx *c, hspf_graph *g) : ctx_(c), g_(g) {}
+  Graph(std::shared_ptr<CtxHolder> h, hspf_graph *g) : holder_(std::move(h)), ctx_(holder_->ctx), g_(g) {}
+  std::shared_ptr<CtxHolder> holder_;
   hspf_ctx *ctx_;
   hspf_graph *g_;
 };
 
 class Engine {
  public:
-  explicit Engine(int device = 0) {
-    const int rc = hspf_init(device, &ctx_);
+  explicit Engine(int device = 0) : holder_(std::make_shared<CtxHolder>()) {
+    const int rc = hspf_init(device, &holder_->ctx);
     if (rc != HSPF_OK) throw Error(rc, "hspf_init");
+    ctx_ = holder_->ctx;
   }
   Engine(const Engine &) = delete;
   Engine &operator=(const Engine &) = delete;
-  ~Engine() { if (ctx_) hspf_shutdown(ctx_); }
+  ~Engine() = default;                               // the context goes with the last holder (this, or a surviving Graph)
   hspf_ctx *raw() const { return ctx_; }
 
   Graph upload(const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col,
@@ -94,7 +108,7 @@ class Engine {
     hspf_graph *g = nullptr;
     const int rc = hspf_graph_upload(ctx_, &csr, &g);
     if (rc != HSPF_OK) throw Error(rc, std::string("hspf_graph_upload (") + hspf_last_error(ctx_) + ")");
-    return Graph(ctx_, g);
+    return Graph(holder_, g);
   }
 
   uint32_t mask_words(const Graph &g, const std::vector<uint32_t> &roots) {
@@ -132,6 +146,7 @@ class Engine {
   }
 
  private:
+  std::shared_ptr<CtxHolder> holder_;
   hspf_ctx *ctx_ = nullptr;
 };
 

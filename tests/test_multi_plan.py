@@ -1,0 +1,56 @@
+"""Host arithmetic of the multi-GPU entry points of the C ABI (hspf_shard_bounds, hspf_plan_areas): no GPU needed.
+The Python twin holo_amd.shard.shard_bounds (used by the gloo test) must agree with the C function."""
+import numpy as np
+import pytest
+
+from holo_amd import engine as E
+from holo_amd import shard
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_shard_bounds_matches_python_twin_and_covers_all_roots(world):
+    for n_roots in [0, 1, 63, 64, 65, 127, 128, 129, 511, 512, 513, 1000, 10007]:
+        py = shard.shard_bounds(n_roots, world)
+        c = [E.shard_bounds(n_roots, world, r) for r in range(world)]
+        assert c == py
+        # contiguous cover, whole batches except the ragged tail, sizes differ by at most one batch
+        assert c[0][0] == 0 and c[-1][1] == n_roots
+        for (a0, a1), (b0, b1) in zip(c, c[1:]):
+            assert a1 == b0
+        for lo, hi in c:
+            assert lo == hi or (lo % 64 == 0 and (hi % 64 == 0 or hi == n_roots))
+        sizes = [(hi - lo + 63) // 64 for lo, hi in c]
+        assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 16])
+def test_plan_areas_partitions_area_batches_contiguously(world):
+    rng = np.random.default_rng(world)
+    for trial in range(20):
+        n_areas = int(rng.integers(1, 12))
+        rpa = rng.integers(0, 3000, n_areas).astype(np.uint32)
+        plan = E.plan_areas(rpa, world)
+        # every root of every area exactly once, in order
+        seen = {a: 0 for a in range(n_areas)}
+        last = (-1, -1, -1)
+        load = [0] * world
+        for rank, area, b, e in plan:
+            assert 0 <= rank < world and b < e <= rpa[area]
+            assert b == seen[area] and b % 64 == 0 and (e % 64 == 0 or e == rpa[area])
+            seen[area] = e
+            assert (rank, area, b) > last
+            last = (rank, area, b)
+            load[rank] += (e - b + 63) // 64
+        assert all(seen[a] == rpa[a] for a in range(n_areas))
+        total = sum(int(r + 63) // 64 for r in rpa)
+        assert sum(load) == total and max(load) - min(load) <= 1
+
+
+def test_plan_areas_multi_area_config_keeps_areas_whole_when_it_can():
+    """BASELINE configs[3]: 10 areas x 1000 roots on 8 GPUs = 160 batches, 20 per rank: an area (16 batches) is cut at
+    most once and a rank touches at most 3 areas."""
+    plan = E.plan_areas([1000] * 10, 8)
+    per_rank = {}
+    for rank, area, b, e in plan:
+        per_rank.setdefault(rank, []).append(area)
+    assert len(per_rank) == 8 and all(len(v) <= 3 for v in per_rank.values())
