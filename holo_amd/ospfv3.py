@@ -188,8 +188,9 @@ def _net_key(p: str):
     return (n.version, int(n.network_address), n.prefixlen)
 
 
-def update_rib_intra_area(rib: dict, area: Area3, spt: Dict[tuple, Vertex], max_paths: int):
-    """intra_area_networks (ospfv3/spf.rs:421-478) + update_rib_intra_area (route.rs:343-448)."""
+def update_rib_intra_area(rib: dict, area: Area3, spt: Dict[tuple, Vertex], max_paths: int, filter=None):
+    """intra_area_networks (ospfv3/spf.rs:421-478) + update_rib_intra_area (route.rs:343-448); `filter` = the prefix
+    keys of a partial run (route.rs:356-362)."""
     for lsa in sorted(area.iaps, key=lambda l: (ip(l.adv_rtr), l.lsa_id)):
         if lsa.maxage:
             continue
@@ -206,6 +207,8 @@ def update_rib_intra_area(rib: dict, area: Area3, spt: Dict[tuple, Vertex], max_
             if "nu-bit" in p["options"]:
                 continue
             key = _net_key(p["prefix"])
+            if filter is not None and key not in filter:
+                continue
             metric = min(v.distance + p["metric"], 0xFFFFFFFF)
             cur = rib.get(key)
             if cur is not None and metric > cur["metric"]:
@@ -234,3 +237,69 @@ def compute_spf_intra_area(router_id: str, areas: List[Area3], max_paths: int, e
     return [{"prefix": rib[k]["prefix"], "metric": rib[k]["metric"], "type": "intra-area",
              "nexthops": [[rib[k]["nexthops"][n][1], rib[k]["nexthops"][n][0]] for n in sorted(rib[k]["nexthops"])]}
             for k in sorted(rib)]
+
+
+# ---- SpfComputation::{Full, Partial} (holo-ospf/src/spf.rs:48-60, 489-584) ----------------------------------------------
+
+FULL_FUNCTIONS_V3 = ("router", "network", "link", "router-info")                     # ospfv3/spf.rs:106-118
+FULL_FUNCTIONS_V2 = ("router", "network", "opaque-area-router-info", "opaque-area-ext-prefix", "opaque-area-ext-link",
+                     "opaque-as-ext-prefix")                                         # ospfv2/spf.rs:104-119
+
+
+def spf_computation_type(trigger_lsas, version: int = 3):
+    """`V::spf_computation_type`: which changed LSAs need the SPT again.  trigger_lsas: [{"new": {"function": ...,
+    "prefixes": [...]}, "old": ... or None}].  Returns ("full", None) or ("partial", {"intra": set of prefix keys}):
+    a partial run does NOT touch the SPT — the engine is not called — and, for OSPFv3, re-attaches the prefixes of the
+    changed Intra-Area-Prefix-LSAs (old and new version) to the stored SPTs; in OSPFv2 the intra-area information lives
+    in Router- / Network-LSAs, so `intra` is always empty there (ospfv2/spf.rs:121-123).  The inter-area / external
+    members of SpfPartialComputation belong to route calculations outside this path."""
+    full = FULL_FUNCTIONS_V3 if version == 3 else FULL_FUNCTIONS_V2
+    if any(t["new"]["function"] in full for t in trigger_lsas):
+        return "full", None
+    intra = set()
+    if version == 3:
+        for t in trigger_lsas:
+            for lsa in (t["new"], t.get("old")):
+                if lsa is not None and lsa["function"] == "intra-area-prefix":
+                    intra.update(_net_key(p["prefix"]) for p in lsa["prefixes"])
+    return "partial", {"intra": intra}
+
+
+class SpfState:
+    """What compute_spf keeps between runs (holo-ospf/src/spf.rs:489-584): the per-area SPTs of the last FULL run
+    (`area.state.spt`) and the intra-area RIB.  `run` dispatches like the reference: a Full computation runs every area
+    on the engine and rebuilds the RIB (route::update_rib_full); a Partial one (route::update_rib_partial, route.rs:
+    200-237) removes the affected prefixes, re-attaches them from the STORED SPTs over all areas and never calls the
+    engine."""
+
+    def __init__(self, router_id: str, max_paths: int, engine, af: str = "ipv6"):
+        self.router_id, self.max_paths, self.engine, self.af = router_id, max_paths, engine, af
+        self.spts: Dict[str, Optional[Dict[tuple, Vertex]]] = {}
+        self.rib: dict = {}
+        self.engine_runs = 0
+
+    def run(self, areas: List[Area3], trigger_lsas=None) -> List[dict]:
+        kind, partial = ("full", None) if trigger_lsas is None else spf_computation_type(trigger_lsas, 3)
+        ordered = sorted(areas, key=lambda a: ip(a.area_id))
+        if kind == "full":
+            self.rib = {}
+            for area in ordered:
+                spt = run_area(self.router_id, area, self.engine, self.af)
+                self.engine_runs += 1
+                self.spts[area.area_id] = spt
+                if spt is not None:
+                    update_rib_intra_area(self.rib, area, spt, self.max_paths)
+        elif partial["intra"]:
+            intra = partial["intra"]
+            rib = {k: r for k, r in self.rib.items() if k not in intra}
+            part: dict = {}
+            for area in ordered:
+                spt = self.spts.get(area.area_id)
+                if spt is not None:
+                    update_rib_intra_area(part, area, spt, self.max_paths, intra)
+            rib.update(part)
+            self.rib = rib
+        rib = self.rib
+        return [{"prefix": rib[k]["prefix"], "metric": rib[k]["metric"], "type": "intra-area",
+                 "nexthops": [[rib[k]["nexthops"][n][1], rib[k]["nexthops"][n][0]] for n in sorted(rib[k]["nexthops"])]}
+                for k in sorted(rib)]

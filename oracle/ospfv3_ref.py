@@ -159,9 +159,11 @@ def _origin(v: Vertex):
     return v.lsa["lsa_id"] if v.id[0] == NET else v.lsa[0]["lsa_id"]
 
 
-def update_rib_intra_area(rib: dict, area: dict, spt, max_paths: int):   # holo-ospf/src/route.rs:343-448
+def update_rib_intra_area(rib: dict, area: dict, spt, max_paths: int, filter=None):   # holo-ospf/src/route.rs:343-448
     for v, prefix, smetric in intra_area_networks(area, spt):
         key = _net_key(prefix)
+        if filter is not None and key not in filter:                     # route.rs:356-362 (partial SPF)
+            continue
         metric = min(v.distance + smetric, U32_MAX)
         cur = rib.get(key)
         if cur is not None and metric > cur["metric"]:
@@ -187,6 +189,41 @@ def intra_area_rib(vec: dict):
         r = run_area(vec, area)
         if r is not None:
             update_rib_intra_area(rib, area, r[0], vec["max_paths"])
+    return [{"prefix": rib[k]["prefix"], "metric": rib[k]["metric"], "type": "intra-area",
+             "nexthops": [[rib[k]["nexthops"][n][1], rib[k]["nexthops"][n][0]] for n in sorted(rib[k]["nexthops"])]}
+            for k in sorted(rib)]
+
+
+# ---- SpfComputation::{Full, Partial} (holo-ospf/src/spf.rs:48-60, 489-584) ----------------------------------------------
+
+def spf_computation_type(trigger_lsas):                                  # ospfv3/spf.rs:97-163
+    """trigger_lsas: [{"new": lsa, "old": lsa or None}], lsa = {"function": ..., ...}.  ("full", None), or ("partial",
+    {"intra": set of prefix keys}) — the inter-area / external members of SpfPartialComputation are outside this path."""
+    if any(t["new"]["function"] in ("router", "network", "link", "router-info") for t in trigger_lsas):
+        return "full", None
+    intra = set()
+    for t in trigger_lsas:
+        for lsa in (t["new"], t.get("old")):
+            if lsa is not None and lsa["function"] == "intra-area-prefix":
+                intra.update(_net_key(p["prefix"]) for p in lsa["prefixes"])
+    return "partial", {"intra": intra}
+
+
+def update_rib_partial_intra(rib: dict, intra: set, areas_spts, max_paths: int) -> dict:   # route.rs:200-237, 335-337
+    """`rib`: prefix key -> route of the last run; `areas_spts`: [(area, stored SPT)] in area-id order, the SPTs being
+    those of the last FULL run (area.state.spt is not touched by a partial run).  Returns the new RIB."""
+    partial_rib: dict = {}
+    if intra:
+        rib = {k: r for k, r in rib.items() if k not in intra}          # extract_if: affected intra-area routes leave the RIB
+        for area, spt in areas_spts:                                     # all areas: correct ECMP across areas
+            if spt is not None:
+                update_rib_intra_area(partial_rib, area, spt, max_paths, intra)
+    rib = dict(rib)
+    rib.update(partial_rib)                                              # rib.extend(partial_rib)
+    return rib
+
+
+def rows_of(rib: dict):
     return [{"prefix": rib[k]["prefix"], "metric": rib[k]["metric"], "type": "intra-area",
              "nexthops": [[rib[k]["nexthops"][n][1], rib[k]["nexthops"][n][0]] for n in sorted(rib[k]["nexthops"])]}
             for k in sorted(rib)]

@@ -1,0 +1,85 @@
+"""SpfComputation::{Full, Partial} dispatch of compute_spf (holo-ospf/src/spf.rs:48-60, 489-584, route.rs:200-237) on random
+OSPFv3 areas, CPU only: after a FULL run, Intra-Area-Prefix-LSAs are changed (metrics, prefixes added / removed, NU bit,
+LSAs withdrawn); the twin's PARTIAL run — stored SPTs, no engine call — must give (a) what the literal restatement of
+update_rib_partial gives and (b) what a full run on the new LSDB gives (the topology did not change)."""
+import copy
+import random
+
+import pytest
+
+from holo_amd import ospfv3 as H3
+from oracle import ospfv3_ref as R3
+from oracle.ospf_ref import ip
+from _oracle_engine import OracleEngine
+from _random_ospfv3 import make
+
+
+def mutate_iaps(vec, rng):
+    """Changes some Intra-Area-Prefix-LSAs of a vector; returns the trigger list [{"new":..., "old":...}]."""
+    trig = []
+    for area in vec["areas"]:
+        for lsa in list(area["iaps"]):
+            if rng.random() < 0.5:
+                continue
+            old = copy.deepcopy(lsa)
+            what = rng.choice(["metric", "drop-prefix", "add-prefix", "nu", "withdraw"])
+            if what == "metric" and lsa["prefixes"]:
+                rng.choice(lsa["prefixes"])["metric"] = rng.randint(0, 40)
+            elif what == "drop-prefix" and lsa["prefixes"]:
+                lsa["prefixes"].pop(rng.randrange(len(lsa["prefixes"])))
+            elif what == "add-prefix":
+                lsa["prefixes"].append({"prefix": f"2001:db8:{rng.randint(1, 40):x}::/64", "metric": rng.randint(0, 30), "options": []})
+            elif what == "nu" and lsa["prefixes"]:
+                p = rng.choice(lsa["prefixes"])
+                p["options"] = [] if "nu-bit" in p["options"] else ["nu-bit"]
+            elif what == "withdraw":
+                area["iaps"].remove(lsa)
+                new = dict(old, prefixes=[])                 # the MaxAge copy that triggers the run carries no prefixes to add
+                trig.append({"new": {"function": "intra-area-prefix", "prefixes": new["prefixes"]},
+                             "old": {"function": "intra-area-prefix", "prefixes": old["prefixes"]}})
+                continue
+            trig.append({"new": {"function": "intra-area-prefix", "prefixes": lsa["prefixes"]},
+                         "old": {"function": "intra-area-prefix", "prefixes": old["prefixes"]}})
+    return trig
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_partial_run_equals_restatement_and_full_run(block):
+    eng = OracleEngine()
+    for seed in range(block * 30, block * 30 + 30):
+        vec = make(seed)
+        rng = random.Random(seed)
+        st = H3.SpfState(vec["router_id"], vec["max_paths"], eng, vec["af"])
+        areas = [H3.Area3.from_vector(a) for a in vec["areas"]]
+        rows0 = st.run(areas)
+        assert rows0 == R3.intra_area_rib(vec)
+        runs = st.engine_runs
+        # the restatement's state after the full run
+        ordered = sorted(vec["areas"], key=lambda a: ip(a["area_id"]))
+        spts = [(R3.run_area(vec, a) or (None,))[0] for a in ordered]
+        rib = {}
+        for a, spt in zip(ordered, spts):
+            if spt is not None:
+                R3.update_rib_intra_area(rib, a, spt, vec["max_paths"])
+        for step in range(3):
+            trig = mutate_iaps(vec, rng)
+            kind, partial = R3.spf_computation_type(trig)
+            assert (kind, partial) == H3.spf_computation_type(trig, 3) and kind == "partial"
+            ordered = sorted(vec["areas"], key=lambda a: ip(a["area_id"]))
+            rib = R3.update_rib_partial_intra(rib, partial["intra"], list(zip(ordered, spts)), vec["max_paths"])
+            rows = st.run([H3.Area3.from_vector(a) for a in vec["areas"]], trig)
+            assert st.engine_runs == runs, "a partial run must not call the engine"
+            assert rows == R3.rows_of(rib)
+            assert rows == R3.intra_area_rib(vec), "partial run == full run on the new LSDB (topology unchanged)"
+
+
+def test_classification_full_vs_partial():
+    iap = {"function": "intra-area-prefix", "prefixes": [{"prefix": "2001:db8:1::/64", "metric": 1, "options": []}]}
+    for fn in ("router", "network", "link", "router-info"):
+        assert H3.spf_computation_type([{"new": iap, "old": None}, {"new": {"function": fn}, "old": None}], 3) == ("full", None)
+    kind, partial = H3.spf_computation_type([{"new": {"function": "inter-area-prefix"}, "old": None}], 3)
+    assert kind == "partial" and partial["intra"] == set()
+    # OSPFv2: Router-/Network-LSAs and the SR opaque LSAs are full runs; summaries / externals are partial with no intra part
+    for fn in H3.FULL_FUNCTIONS_V2:
+        assert H3.spf_computation_type([{"new": {"function": fn}, "old": None}], 2) == ("full", None)
+    assert H3.spf_computation_type([{"new": {"function": "summary-network"}, "old": None}], 2) == ("partial", {"intra": set()})
