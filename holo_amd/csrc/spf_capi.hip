@@ -38,6 +38,7 @@ struct hspf_graph {
   mutable bool narrow_bad = false;   // a run overflowed the 4-byte fused state: use the 8-byte one
   mutable bool wide24_bad = false;   // a run overflowed the hop field of the 8-byte state with > 16 mask bits
   bool hopcount_like = false;        // every kept link into a network costs 0 (from a router), into a router 1
+  bool heavy_rows = false;           // a quarter or more of the links sit in rows of more than 32 (fat-tree switches, big LANs)
   uint32_t xcd_start[9] = {};        // work-balanced chunk ranges of the 8 XCDs (GraphDev::xcd_start)
   uint32_t xcd_blocks() const { uint32_t m = 0; for (int x = 0; x < 8; ++x) m = std::max(m, xcd_start[x + 1] - xcd_start[x]); return 8u * std::max(m, 1u); }
   // host mirrors: slot tables walk the root's neighbourhood on the host
@@ -104,7 +105,7 @@ struct hspf_ctx {
   uint32_t mark_epoch = 0;
   uint32_t *h_lane_flags = nullptr; // pinned: per-root status bits, then the 256 rows_done words of the fused kernel
   size_t h_lane_cap = 0;
-  uint32_t est_relax = 12, est_dag = 12, est_fused = 12;   // launch-ahead estimates (adapted run to run)
+  uint32_t est_relax = 12, est_dag = 12, est_fused = 12, est_fw = 12;   // launch-ahead estimates (adapted run to run)
   uint32_t variant = 0;                    // HSPF_VARIANT env: kernel A/B switches (tuning only)
   uint32_t single_attr = 0;                // per k_single instantiation: its dynamic-LDS attribute has been set
   uint32_t single_max_n = 1024;            // HSPF_SINGLE_MAX_N env: largest graph that takes the one-workgroup-per-root kernel
@@ -280,6 +281,11 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   g->e_kept = bi.kept;
   g->wmax = bi.wmax;
   g->hopcount_like = !bi.hc_bad && bi.hc_net;
+  {
+    uint64_t heavy = 0;                                   // from the host mirror of the caller's rows (out-degrees)
+    for (uint32_t v = 0; v < n; ++v) { const uint32_t d = g->row_ptr[v + 1] - g->row_ptr[v]; if (d > 32u) heavy += d; }
+    g->heavy_rows = heavy * 4u >= (uint64_t)std::max<uint32_t>(e, 1u);
+  }
   for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
   g->narrow_bad = false;
   g->wide24_bad = false;
@@ -989,6 +995,43 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     }
     st.state_bytes = narrow ? 4 : 8;
   } else {
+  // More than 24 first-hop slots: two ways.  k_fw = ONE fused fixed point over (distance, hops, W mask words): half the
+  // launches, but a label-correcting sweep re-reads the masks of ALL in-links of a row every time the row is revisited.
+  // k_relax + k_dag = distances first (4 bytes per lane and link), then every row's masks ONCE, when its tight parents are
+  // final.  Measured (profiles/r02g_wide_mask*.jsonl): isis-100k with its roots on a 48-router LAN (one mask word): 2.51
+  // vs 2.47 ms, a tie; fat-tree k = 100 (100-link switch rows, two mask words): 5.04 vs 4.38 ms — the two-phase path
+  // wins where most links sit in heavy rows.  So: k_fw for graphs up to 65 536 vertices (launch-bound: 24 instead of 48
+  // launches) and for large graphs without heavy rows; the two-phase path for large graphs with them, for hop-count-like
+  // graphs with more than 4 mask words (the plateau rule doubles k_fw's mask registers), and when HSPF_VARIANT bit6 asks.
+  const bool use_fw = !(ctx->variant & 64u) && (!g->hopcount_like || W <= 4) && (n <= 65536u || !g->heavy_rows);
+  if (use_fw) {
+    const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
+    HIPCHK(ctx, hipMemsetAsync(d_mask, 0, rows * 8 * W, s));
+    HIPCHK(ctx, hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s));
+    hipLaunchKernelGGL(k_init_fw, dim3((L + 255) / 256), dim3(256), 0, s, gd, d_dist, d_stamp, d_roots, L);
+    const bool mi = g->max_path_metric == HSPF_DIST_INF, hcl = g->hopcount_like;
+    uint32_t n_fw = 0;
+    rc = run_phase(ctx->est_fw, [&](uint32_t sweep) {
+#define HSPF_FW(W_) do { \
+      if (hcl) { if (mi) hipLaunchKernelGGL((k_fw<(W_ <= 4 ? W_ : 1), true, true>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); \
+                 else    hipLaunchKernelGGL((k_fw<(W_ <= 4 ? W_ : 1), false, true>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); } \
+      else     { if (mi) hipLaunchKernelGGL((k_fw<W_, true, false>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); \
+                 else    hipLaunchKernelGGL((k_fw<W_, false, false>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); } } while (0)
+      switch (W) {
+        case 1: HSPF_FW(1); break;
+        case 2: HSPF_FW(2); break;
+        case 4: HSPF_FW(4); break;
+        case 8: HSPF_FW(8); break;
+        default: HSPF_FW(16); break;
+      }
+#undef HSPF_FW
+    }, n_fw, []() {});
+    if (rc) return rc;
+    ctx->est_fw = n_fw + 1;
+    st.n_relax_launches = n_fw;
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
+  } else {
   uint32_t n_relax = 0;
   rc = run_phase(ctx->est_relax, [&](uint32_t sweep) {
     if (g->max_path_metric == HSPF_DIST_INF)
@@ -1025,6 +1068,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   st.n_dag_launches = n_dag;
   HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
 
+  }
   // ---- emit row-major results
   {
     const dim3 egrid((n + 63) / 64, B);

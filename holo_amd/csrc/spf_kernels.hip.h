@@ -1176,6 +1176,204 @@ __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t n_roots,
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_fw<W> — the fused fixed point for runs whose roots have MORE first-hop slots than a packed state word holds
+// (> 24: routers on a big LAN, fat-tree switches): distances, hops and W mask words in ONE label-correcting sweep
+// instead of a distance phase followed by the epoch-driven DAG phase (k_relax + k_dag: every row is walked in both
+// phases, and a DAG sweep only accepts parents finalised by an EARLIER launch).  The reference merges next hops
+// without any width limit (holo-isis/src/spf.rs:702-704); this is the same merge with the set as a W x 64 bit mask.
+//
+// State = the three lane-major arrays of the two-phase path (dist u32, hv u32 = hops, mask u64 x W), so k_init_roots
+// and k_emit<W> serve both.  A (distance, hops, mask) triple is therefore NOT one memory access and a reader can see a
+// neighbour's new distance with its old mask.  That is harmless for the result: every recomputation of a row is a pure
+// function of what it read; a row that changes stamps its out-neighbours for the NEXT launch, so every row is
+// recomputed at least once after the last change of any in-neighbour, in a later launch, where it reads that
+// neighbour's final triple whole; and the run ends only after a launch that changed nothing.  The tight links that
+// feed masks always come from a vertex that precedes the row in (distance, index) order (zero-cost links from
+// higher-numbered sources are excluded, exactly as in fused_row_any), so the final masks are determined by induction
+// over that order, whatever transient values were seen on the way.
+//
+// Activation: act[v] >= sweep + 1 <=> row v is due in this sweep; k_init_fw stamps the roots' out-neighbours with 1,
+// a row that changes in sweep s stamps s + 2 on its out-neighbours (due next sweep — and in this one if not yet
+// visited).  Row routine: the per-lane accumulator of fused_row_any with W-word masks; hops and masks of a neighbour
+// are only requested when its candidate is <= the running minimum for some lane.
+template <int W, bool MAXINF, bool HC>
+__global__ __launch_bounds__(256) void k_fw(const FusedGraph *__restrict__ gp, uint32_t *__restrict__ dist,
+                                            uint32_t *__restrict__ hv, uint64_t *__restrict__ mask,
+                                            uint32_t *__restrict__ act, const uint32_t *__restrict__ roots,
+                                            uint32_t maxpath, uint32_t net_nexthops, uint32_t ignore_ovl,
+                                            int *changed, int sweep, uint32_t *lane_flags) {
+  // Neighbour rows requested together: the whole triple (distance, hops, W mask words) of DG links in ONE round trip.
+  // The sweep is bound by dependent round trips, not bytes (a fat-tree switch row has 100 links): asking for the hops
+  // and masks only after the distances have shown which links are tight — what k_dag does — doubles the chain.
+  constexpr int DG = W <= 2 ? 8 : (W <= 4 ? 4 : (W <= 8 ? 2 : 1));
+  if (sweep > 0 && changed[sweep - 1] == 0) return;
+  const GraphDev &g = gp->g;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t batch = blockIdx.y;
+  const uint32_t chunk = xcd_chunk(g.xcd_start, blockIdx.x);
+  if (chunk == 0xFFFFFFFFu) return;
+  const uint32_t vbeg = chunk * VPB + wave * VPW;
+  const uint32_t n = g.n;
+  if (vbeg >= n) return;
+  uint32_t *A = act + (size_t)batch * n;
+  const uint32_t av = A[min(vbeg + min(lane, (uint32_t)VPW - 1u), n - 1)];
+  const uint64_t due = __ballot(lane < (uint32_t)VPW && vbeg + lane < n && av >= (uint32_t)sweep + 1u);
+  if (due == 0ull) return;
+  const uint32_t *__restrict__ in_src = g.in_src;
+  const uint32_t *__restrict__ in_w = g.in_w;
+  const uint32_t root_slot = batch * 64 + lane;
+  const uint32_t my_root = roots[root_slot];
+  uint32_t *D = dist + (size_t)batch * n * 64;
+  uint32_t *H = hv + (size_t)batch * n * 64;
+  uint64_t *M = mask + (size_t)batch * n * 64 * W;
+  const uint32_t lane4 = lane * 4u, lane8 = lane * 8u;
+  const uint32_t pv = g.in_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
+  const uint32_t po = g.out_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
+  bool any = false, sat = false, need_exact = false;
+#pragma unroll 1
+  for (int i = 0; i < VPW; ++i) {
+    const uint32_t v = vbeg + i;
+    if (v >= n) break;
+    if (!((due >> i) & 1ull)) continue;
+    const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
+    const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
+    // the row's own triple (to see whether anything changes)
+    const uint32_t od = ld_row(D, v * 256u + lane4), oh = ld_row(H, v * 256u + lane4);
+    uint64_t om[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) om[q] = ld_row64(M, ((size_t)v * W + q) * 512u + lane8);
+    uint32_t bd = INF, bpd = INF, bh = 0u, bd_all = INF;
+    uint64_t am[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) am[q] = 0ull;
+    uint32_t zb = INF, zh = 0u;            // HC: best zero-cost link from a higher-numbered source (see fused_row_any)
+    uint64_t zm[HC ? W : 1];
+#pragma unroll
+    for (int q = 0; q < (HC ? W : 1); ++q) zm[q] = 0ull;
+    for (uint32_t eb = e0; eb < e1; eb += 64) {
+      const uint32_t cnt = min(64u, e1 - eb);
+      const uint32_t sv = lane < cnt ? in_src[eb + lane] : v;
+      const uint32_t wv = lane < cnt ? in_w[eb + lane] : INF;
+      const bool has_nt = !ignore_ovl && __ballot(lane < cnt && (sv & SRC_NO_TRANSIT) != 0) != 0ull;
+      const uint32_t zv = (lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
+      const bool has_z = __ballot(zv != 0u) != 0ull;
+#pragma unroll 1
+      for (uint32_t j0 = 0; j0 < cnt; j0 += DG) {
+        uint32_t du[DG], hu[DG];
+        uint64_t mu[DG][W];
+#pragma unroll
+        for (int k = 0; k < DG; ++k) {
+          const uint32_t u = rdlane(sv, min(j0 + (uint32_t)k, 63u)) & SRC_MASK;
+          const bool in = (j0 + k) < cnt;                                // uniform: no requests for a short row's padding
+          du[k] = in ? ld_row(D, u * 256u + lane4) : INF;
+          hu[k] = in ? ld_row(H, u * 256u + lane4) : 0u;
+#pragma unroll
+          for (int q = 0; q < W; ++q) mu[k][q] = in ? ld_row64(M, ((size_t)u * W + q) * 512u + lane8) : 0ull;
+        }
+        uint32_t cc[DG];
+#pragma unroll
+        for (int k = 0; k < DG; ++k) {
+          const uint32_t j = min(j0 + (uint32_t)k, 63u);
+          const uint32_t w = rdlane(wv, j);
+          uint32_t d = du[k];
+          if (has_nt) {
+            const uint32_t sw = rdlane(sv, j);
+            if ((sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;     // overloaded source
+          }
+          du[k] = d;
+          cc[k] = (j0 + k) < cnt ? add_sat(d, w) : INF;
+          if (MAXINF && cc[k] == INF && d != INF && w != INF) sat = true;
+        }
+#pragma unroll
+        for (int k = 0; k < DG; ++k) {
+          const uint32_t j = j0 + k;
+          if (j >= cnt) break;
+          const uint32_t c = cc[k], d = du[k];
+          const bool zlink = has_z && rdlane(zv, j) != 0u;              // uniform
+          if (zlink && !HC) { bd_all = min(bd_all, c); continue; }
+          const bool hz = HC && zlink;
+          const bool lt = hz ? (c < zb) : (c < bd), eq = !hz && c == bd && c != INF;
+          const uint32_t hh = hu[k] & 0xFFFFu;
+          uint64_t contrib[W];
+#pragma unroll
+          for (int q = 0; q < W; ++q) contrib[q] = mu[k][q];
+          const bool direct = (lt || eq) && hh == 0u && c != INF;      // parent: root or hops-0 network
+          if (__ballot(direct) != 0ull) {
+            const uint32_t u = rdlane(sv, j) & SRC_MASK;
+            const uint32_t fpos = g.in_fpos[eb + j];
+            if (direct) {
+              const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(gp->tabs, root_slot, u);
+              const uint32_t sidx = base_s + fpos;
+              const bool on = (v_router || net_nexthops) && sidx < (uint32_t)W * 64u;
+#pragma unroll
+              for (int q = 0; q < W; ++q) contrib[q] = (on && (sidx >> 6) == (uint32_t)q) ? (1ull << (sidx & 63u)) : 0ull;
+            }
+          }
+          if (hz) {
+            if (lt) {
+              zb = c; zh = hh;
+#pragma unroll
+              for (int q = 0; q < (HC ? W : 1); ++q) zm[q] = contrib[HC ? q : 0];
+            }
+            continue;
+          }
+#pragma unroll
+          for (int q = 0; q < W; ++q) am[q] = lt ? contrib[q] : (eq ? (am[q] | contrib[q]) : am[q]);
+          const bool newp = lt || (eq && d < bpd);
+          bpd = newp ? d : bpd;
+          bh = newp ? hh : bh;
+          bd = min(bd, c);
+        }
+      }
+    }
+    if (HC) {
+      const bool late = zb < bd;
+#pragma unroll
+      for (int q = 0; q < (HC ? W : 1); ++q) am[HC ? q : 0] = late ? zm[q] : am[HC ? q : 0];
+      bh = late ? zh : bh;
+      bd = late ? zb : bd;
+    }
+    // finish (finish_row of the packed path, on a triple)
+    uint32_t nd, nh;
+    if (v == my_root) { nd = 0u; nh = 0u; }
+    else if (bd == INF || bd > maxpath) { nd = INF; nh = 0u; }
+    else { nd = bd; nh = min(bh + v_router, 0xFFFFu); }                 // u16 saturating_add
+    const bool live = v != my_root && nd != INF;
+    need_exact = need_exact || (v != my_root && bd_all != INF && bd_all <= maxpath && bd_all < bd);
+    bool ch = nd != od || nh != (oh & 0xFFFFu);
+#pragma unroll
+    for (int q = 0; q < W; ++q) { am[q] = live ? am[q] : 0ull; ch = ch || am[q] != om[q]; }
+    if (ch) {
+#pragma unroll
+      for (int q = 0; q < W; ++q) M[((size_t)v * W + q) * 64 + lane] = am[q];
+      H[(size_t)v * 64 + lane] = nh;
+      D[(size_t)v * 64 + lane] = nd;
+      any = true;
+    }
+    if (__ballot(ch) != 0ull) {                        // wake the out-neighbours up
+      const uint32_t o0 = rdlane(po, i), o1 = rdlane(po, i + 1);
+      for (uint32_t ob = o0 + lane; ob < o1; ob += 64) A[g.out_dst[ob]] = (uint32_t)sweep + 2u;
+    }
+  }
+  if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
+  uint32_t lf = 0;
+  if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
+  if (lf) atomicOr(&lane_flags[root_slot], lf);
+}
+
+// init for k_fw: the roots' own distance (dist = 0; hv / mask are zero already) and the first activation stamps.
+__global__ void k_init_fw(GraphDev g, uint32_t *dist, uint32_t *act, const uint32_t *roots, uint32_t n_lanes) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_lanes) return;
+  const uint32_t r = roots[i];
+  if (r == INF) return;
+  const uint32_t n = g.n, batch = i >> 6, lane = i & 63;
+  dist[((size_t)batch * n + r) * 64 + lane] = 0;
+  for (uint32_t k = g.out_ptr[r]; k < g.out_ptr[r + 1]; ++k) act[(size_t)batch * n + g.out_dst[k]] = 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Exact sequential kernel: one lane = one root.  Literal restatement of the reference loop
 //  with a binary heap keyed (distance, vertex) with decrease-key, which
 // pops in exactly the ordered-map order.  State lives in the row-major OUTPUT arrays of that root

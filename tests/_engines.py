@@ -3,3 +3,4 @@ import pytest
 
 both_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps"], indirect=True)
 sweeps_engine = pytest.mark.parametrize("spf_ctx", ["sweeps"], indirect=True)
+all_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps", "twophase"], indirect=True)

@@ -24,20 +24,21 @@ def _ctx_pool():
 def spf_ctx(request, _ctx_pool):
     """Engine contexts shared by the GPU tests of a session.  "default" is the product configuration (small graphs
     take the one-workgroup-per-root kernel, k_single); "sweeps" has that kernel switched off (HSPF_SINGLE_MAX_N=0), so
-    that the batched sweep engine keeps its coverage on the small adversarial graphs of the suite.  Tests choose with
-    tests/_engines.py: `both_engines` / `sweeps_engine` (indirect parametrisation); unmarked tests get "default"."""
+    that the batched sweep engine keeps its coverage on the small adversarial graphs of the suite; "twophase" additionally
+    sends runs with more than 24 first-hop slots down the older k_relax + k_dag path instead of k_fw (HSPF_VARIANT bit6).
+    Tests choose with tests/_engines.py (indirect parametrisation); unmarked tests get "default"."""
     mode = getattr(request, "param", "default")
     if mode not in _ctx_pool:
         from holo_amd.engine import SpfContext
-        old = os.environ.get("HSPF_SINGLE_MAX_N")
-        if mode == "sweeps":
-            os.environ["HSPF_SINGLE_MAX_N"] = "0"
+        env = {"sweeps": {"HSPF_SINGLE_MAX_N": "0"}, "twophase": {"HSPF_SINGLE_MAX_N": "0", "HSPF_VARIANT": "64"}}.get(mode, {})
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
         try:
-            _ctx_pool[mode] = SpfContext(0)          # the switch is read once, at hspf_init
+            _ctx_pool[mode] = SpfContext(0)          # the switches are read once, at hspf_init
         finally:
-            if mode == "sweeps":
-                if old is None:
-                    del os.environ["HSPF_SINGLE_MAX_N"]
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
                 else:
-                    os.environ["HSPF_SINGLE_MAX_N"] = old
+                    os.environ[k] = v
     return _ctx_pool[mode]

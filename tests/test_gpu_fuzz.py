@@ -7,9 +7,9 @@ import sys
 import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-from _engines import both_engines  # noqa: E402
+from _engines import all_engines  # noqa: E402
 
-pytestmark = [pytest.mark.gpu, both_engines]
+pytestmark = [pytest.mark.gpu, all_engines]
 
 
 @pytest.mark.parametrize("first", [0, 5000, 9000])
