@@ -174,3 +174,33 @@ def test_cpp_flooding_manet_reflood_lists_on_gpu(tmp_path):
     r = subprocess.run([HOST, "--engine", "hip"] + files, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr[-3000:]
     assert f"{n_cases} reflood lists checked, 0 differ" in r.stdout
+
+
+def test_cpp_host_side_under_asan_ubsan():
+    """the compiled host side (include/holo_spf_{host,isis,ospf}.hpp through tests/cpp/host_parity.cpp) built
+    with g++ -fsanitize=address,undefined (-fno-sanitize-recover: any report aborts) and run over every recorded fixture
+    with the oracle standing in for the engine.  Leak detection is off: the HIP runtime the C ABI library pulls in keeps
+    process-lifetime allocations."""
+    import shutil
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    from oracle import graph_oracle
+    from holo_amd import build as hb
+    graph_oracle.build()
+    hb.build_lib()
+    exe = HOST + "_asan"
+    deps = [HOST + ".cpp", os.path.join(ROOT, "tests", "cpp", "mini_json.hpp")] + glob.glob(os.path.join(ROOT, "include", "*.h*"))
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                            "-D__HIP_PLATFORM_AMD__", "-w", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+                            HOST + ".cpp", "-L" + os.path.join(ROOT, "holo_amd"), "-lholo_spf_hip", "-Wl,-rpath,$ORIGIN/../../holo_amd",
+                            "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib", "-ldl", "-o", exe], capture_output=True, text=True)
+        if r.returncode != 0 and "sanitizer" in (r.stderr or "").lower() and "cannot find" in r.stderr:
+            pytest.skip("libasan / libubsan not installed")
+        assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so"),
+                        "--replay-steps", os.path.join(ROOT, "tests", "golden")] + VECTORS, capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "163 vectors reproduce" in r.stdout and " 0 do not" in r.stdout and ", 0 differ" in r.stdout
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr

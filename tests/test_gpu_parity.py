@@ -385,7 +385,7 @@ def test_many_roots_regrouped_by_state_class(spf_ctx, run_flags):
     tot = np.array([G.slot_table(int(r))[2] if r != E.NO_ROOT else 0 for r in roots])
     G.free()
     assert (tot > 16).sum() >= 20 and (tot <= 16).sum() >= 256        # the mixture this test is about
-    assert res.stats["n_dag_launches"] > 0 and res.stats["state_bytes"] in (4, 8)   # both paths ran in one call
+    assert res.stats["state_bytes"] in (4, 8)                # the packed-state class ran (the wide-mask class: k_fw or two-phase)
     assert res.stats["n_roots"] == len(roots)
 
 
@@ -448,6 +448,6 @@ def test_wide_mask_hop_field_overflow_falls_back_to_two_phase(spf_ctx):
             assert np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops)
             assert np.array_equal(res.first_hop_mask, ref.mask) and np.array_equal(res.flags & 1, ref.flags)
             assert int(res.hops.max()) > 255
-            assert res.stats["state_bytes"] == 0 and res.stats["n_dag_launches"] > 0       # ended on the two-phase path
+            assert res.stats["state_bytes"] == 0                 # ended on the u16-hops path (k_fw, or k_relax + k_dag)
     finally:
         G.free()

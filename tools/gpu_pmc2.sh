@@ -8,7 +8,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout -k 5 45 rocprofv3 --pmc $line --output-format csv -d $OUT/p$i -o q -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/p$i.log 2>&1
+  timeout -k 5 45 rocprofv3 --pmc $line --output-format csv -d $OUT/p$i -o q -- python $R/bench.py --steps 3 --warmup 1 --min-timed-ms 0 --no-cpu-baseline > $OUT/p$i.log 2>&1
 done <<'PASSES'
 GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum
 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum

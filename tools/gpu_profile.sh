@@ -7,12 +7,12 @@ R=$(pwd); OUT=$R/gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
 python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 tail -c 2500 $OUT/bench.json
 cd /tmp
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o spf -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o spf -- python $R/bench.py --steps 10 --warmup 2 --min-timed-ms 0 --no-cpu-baseline > $OUT/trace.log 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
             "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
             "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
   i=$(echo "$pass" | md5sum | cut -c1-6)
-  timeout -k 5 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$i -o q -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$i.log 2>&1
+  timeout -k 5 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$i -o q -- python $R/bench.py --steps 3 --warmup 1 --min-timed-ms 0 --no-cpu-baseline > $OUT/pmc_$i.log 2>&1
 done
 cd $R
 python - <<'PY'
@@ -35,10 +35,13 @@ json.dump(out, open("gpurun_out/prof/pmc_summary.json", "w"), indent=1)
 traffic = {}
 for k, v in out.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-        traffic[k.replace("hspf::", "").split("<")[0]] = {
+        key = k.replace("hspf::", "").split("<")[0]
+        rec = {
             "kernel": k, "fetch_kib_per_launch": v["FETCH_SIZE"]["mean_all"], "write_kib_per_launch": v["WRITE_SIZE"]["mean_all"],
             "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"]["mean_all"] + v["WRITE_SIZE"]["mean_all"]) * 1024),
             "launches_sampled": v["FETCH_SIZE"]["launches"], "fetch_correction": 2.0}
+        if key not in traffic or rec["launches_sampled"] > traffic[key]["launches_sampled"]:    # several instantiations: the one that ran most
+            traffic[key] = rec
 json.dump(traffic, open("gpurun_out/prof/traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 PY
