@@ -91,6 +91,9 @@ SYMBOLS = [
     ("hspf_routes_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.POINTER(HspfPrefixTable), ctypes.POINTER(HspfRoutes)]),
+    ("hspf_ancestors_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     # several GPUs
     ("hspf_multi_unique_id", ctypes.c_int, [u8p]),
     ("hspf_multi_init", ctypes.c_int, [ctypes.POINTER(HspfMultiConfig), ctypes.POINTER(ctypes.c_void_p)]),

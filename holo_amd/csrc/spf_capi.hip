@@ -1283,6 +1283,70 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
   return HSPF_OK;
 }
 
+int hspf_ancestors_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                          const uint32_t *dist_dev, const uint16_t *hops_dev, const uint16_t *flags_dev,
+                          uint32_t level, uint32_t n_words, uint32_t *level_rank_dev, uint32_t *level_count_dev,
+                          uint64_t *anc_dev) {
+  if (!ctx || !g || !roots || !dist_dev || !hops_dev || !flags_dev || !level_count_dev || !anc_dev || n_roots == 0 ||
+      n_words == 0 || level == 0 || level > 0xFFFFu)
+    return HSPF_E_INVAL;
+  return guarded(ctx, [&]() -> int {
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    const uint32_t n = g->n, nb = (n + 255) / 256;
+    for (uint32_t r = 0; r < n_roots; ++r)
+      if (roots[r] != HSPF_NO_ROOT && roots[r] >= n) { ctx->last_error = "root out of range"; return HSPF_E_INVAL; }
+    int rc;
+    // scratch: roots [n_roots] | per-block counts / offsets [n_roots][nb]
+    if ((rc = ensure(ctx, ctx->gb_delta, ((size_t)n_roots + (size_t)n_roots * nb) * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->changed, (size_t)CHANGED_CAP * 4))) return rc;
+    uint32_t *d_roots = (uint32_t *)ctx->gb_delta.p, *d_blk = d_roots + n_roots;
+    int *d_changed = (int *)ctx->changed.p;
+    HIPCHK(ctx, hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 4, hipMemcpyHostToDevice, s));
+    const GraphDev gd = g->dev();
+    for (uint32_t r0 = 0; r0 < n_roots; r0 += 65535u) {            // gridDim.y
+      const uint32_t nr = std::min(65535u, n_roots - r0);
+      const size_t o = (size_t)r0 * n;
+      hipLaunchKernelGGL(k_anc_count, dim3(nb, nr), dim3(256), 0, s, gd, d_roots + r0, hops_dev + o, flags_dev + o, level, d_blk + (size_t)r0 * nb);
+    }
+    hipLaunchKernelGGL(k_anc_scan, dim3((n_roots + 63) / 64), dim3(64), 0, s, n_roots, nb, d_roots, flags_dev, n, d_blk, level_count_dev);
+    std::vector<uint32_t> cnt(n_roots);
+    HIPCHK(ctx, hipMemcpyAsync(cnt.data(), level_count_dev, (size_t)n_roots * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    for (uint32_t r = 0; r < n_roots; ++r)
+      if (cnt[r] != 0xFFFFFFFFu && cnt[r] > 64u * n_words) { ctx->last_error = "hspf_ancestors_device: need " + std::to_string((cnt[r] + 63) / 64) + " words"; return HSPF_E_TOO_MANY_SLOTS; }
+    for (uint32_t r0 = 0; r0 < n_roots; r0 += 65535u) {
+      const uint32_t nr = std::min(65535u, n_roots - r0);
+      const size_t o = (size_t)r0 * n;
+      hipLaunchKernelGGL(k_anc_init, dim3(nb, nr), dim3(256), 0, s, gd, d_roots + r0, hops_dev + o, flags_dev + o, level, n_words,
+                         d_blk + (size_t)r0 * nb, level_rank_dev ? level_rank_dev + o : nullptr, anc_dev + o * n_words);
+    }
+    const uint32_t ignore_ovl = (run_flags & HSPF_RUN_IGNORE_OVERLOAD) ? 1u : 0u, hc = g->hopcount_like ? 1u : 0u;
+    // the fixed point of a monotone OR: chunks of sweeps launched ahead, one flag read-back per chunk
+    uint32_t sweep = 0;
+    for (;;) {
+      const uint32_t chunk = 8;
+      if (sweep + chunk > CHANGED_CAP) { ctx->last_error = "ancestor sweeps did not converge"; return HSPF_E_INTERNAL; }
+      HIPCHK(ctx, hipMemsetAsync(d_changed + sweep, 0, (size_t)chunk * 4, s));
+      for (uint32_t i = 0; i < chunk; ++i)
+        for (uint32_t r0 = 0; r0 < n_roots; r0 += 65535u) {
+          const uint32_t nr = std::min(65535u, n_roots - r0);
+          const size_t o = (size_t)r0 * n;
+          hipLaunchKernelGGL(k_anc_sweep, dim3(nb, nr), dim3(256), 0, s, gd, d_roots + r0, dist_dev + o, hops_dev + o, flags_dev + o,
+                             level, n_words, ignore_ovl, hc, anc_dev + o * n_words, d_changed, (int)(sweep + i));
+        }
+      sweep += chunk;
+      int last = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&last, d_changed + sweep - 1, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(ctx, hipStreamSynchronize(s));
+      if (!last) break;
+    }
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { ctx->last_error = std::string("k_anc: ") + hipGetErrorString(le); return HSPF_E_HIP; }
+    return HSPF_OK;
+  });
+}
+
 }  // extern "C"
 
 #include "spf_multi.hip.h"

@@ -1533,4 +1533,108 @@ __global__ __launch_bounds__(256) void k_routes(uint32_t n, uint32_t n_roots, ui
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Ancestor sets over the SPT's parent DAG: what holo-isis answers with a stack DFS over
+// `Vertex.parents` (Spt::is_on_path, holo-isis/src/spf.rs:261-286) for flooding::manet::reflood_list
+// (flooding/manet.rs:99-173: "second hops that are not on a shortest path to the LSP originator", "two-hop nodes behind
+// this remote neighbour").  For every root of a finished run and a level L: the root's level-L routers (router
+// vertices of its SPT with hops == L: L = 1 the first hops / remote-neighbour list, L = 2 the second hops) are
+// numbered in ascending vertex index, and anc[root][v] = bit set of the level-L routers that are ancestors of v in the
+// parent DAG, or v itself.  is_on_path(a, d) for a level-L router a is then one bit test in anc[root][d].
+//
+// A link u -> v is a parent link (spf.rs:637-706: every relaxation that reached v at its final distance while v was
+// still a candidate) iff both are in the SPT, dist[u] (+) w == dist[v], u may be expanded (the in-CSR holds only links
+// of expandable sources; an overloaded source other than the root is excluded unless the run ignores the overload bit)
+// and u was popped before v: the static (distance, index) order, i.e. w > 0 or u < v.  Hop-count-like graphs: a network
+// whose way in is a zero-cost link from higher-numbered routers has exactly ONE parent, the first tight one in row order
+// (= lowest-numbered router; see fused_row_any).  Roots that needed the sequential kernel (dynamic pop order) are not
+// handled here: their level count is reported as 0xFFFFFFFF and the caller keeps its own walk.
+// Row-major [root][vertex] like the run's outputs; one thread per (root, vertex), sweeps to the fixed point of a
+// monotone OR (depth of the SPT below level L).
+__device__ __forceinline__ bool anc_is_level(const uint16_t *F, const uint16_t *H, const uint8_t *vflags, uint32_t v, uint32_t level) {
+  return (F[v] & 1u) && !(vflags[v] & 1u) && H[v] == level;
+}
+
+__global__ __launch_bounds__(256) void k_anc_count(GraphDev g, const uint32_t *__restrict__ roots, const uint16_t *__restrict__ hops,
+                                                   const uint16_t *__restrict__ flags, uint32_t level, uint32_t *__restrict__ blockcnt) {
+  __shared__ uint32_t s_cnt;
+  const uint32_t r = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const bool is = v < g.n && roots[r] != INF && anc_is_level(flags + (size_t)r * g.n, hops + (size_t)r * g.n, g.vflags, v, level);
+  const uint64_t b = __ballot(is);
+  if ((threadIdx.x & 63u) == 0 && b) atomicAdd(&s_cnt, (uint32_t)__popcll(b));
+  __syncthreads();
+  if (threadIdx.x == 0) blockcnt[(size_t)r * gridDim.x + blockIdx.x] = s_cnt;
+}
+
+__global__ void k_anc_scan(uint32_t n_roots, uint32_t n_blocks, const uint32_t *__restrict__ roots, const uint16_t *__restrict__ flags,
+                           uint32_t n, uint32_t *__restrict__ blockcnt, uint32_t *__restrict__ level_count) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_roots) return;
+  uint32_t acc = 0;
+  for (uint32_t b = 0; b < n_blocks; ++b) { const uint32_t c = blockcnt[(size_t)r * n_blocks + b]; blockcnt[(size_t)r * n_blocks + b] = acc; acc += c; }
+  const uint32_t root = roots[r];
+  const bool exact = root != INF && (flags[(size_t)r * n + root] & 2u);       // HSPF_RF_EXACT: dynamic pop order
+  level_count[r] = exact ? INF : acc;
+}
+
+__global__ __launch_bounds__(256) void k_anc_init(GraphDev g, const uint32_t *__restrict__ roots, const uint16_t *__restrict__ hops,
+                                                  const uint16_t *__restrict__ flags, uint32_t level, uint32_t W,
+                                                  const uint32_t *__restrict__ blockoff, uint32_t *__restrict__ level_rank,
+                                                  uint64_t *__restrict__ anc) {
+  __shared__ uint32_t s_w[4];
+  const uint32_t r = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t n = g.n;
+  const bool is = v < n && roots[r] != INF && anc_is_level(flags + (size_t)r * n, hops + (size_t)r * n, g.vflags, v, level);
+  const uint64_t b = __ballot(is);
+  if (lane == 0) s_w[wave] = (uint32_t)__popcll(b);
+  __syncthreads();
+  uint32_t base = blockoff[(size_t)r * gridDim.x + blockIdx.x];
+  for (uint32_t w = 0; w < wave; ++w) base += s_w[w];
+  const uint32_t rank = base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+  if (v >= n) return;
+  const size_t o = (size_t)r * n + v;
+  if (level_rank) level_rank[o] = is ? rank : INF;
+  for (uint32_t q = 0; q < W; ++q) anc[o * W + q] = (is && (rank >> 6) == q) ? (1ull << (rank & 63u)) : 0ull;
+}
+
+__global__ __launch_bounds__(256) void k_anc_sweep(GraphDev g, const uint32_t *__restrict__ roots, const uint32_t *__restrict__ dist,
+                                                   const uint16_t *__restrict__ hops, const uint16_t *__restrict__ flags,
+                                                   uint32_t level, uint32_t W, uint32_t ignore_ovl, uint32_t hc,
+                                                   uint64_t *__restrict__ anc, int *changed, int sweep) {
+  if (sweep > 0 && changed[sweep - 1] == 0) return;
+  const uint32_t r = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t n = g.n;
+  const uint32_t root = roots[r];
+  if (v >= n || root == INF) return;
+  const uint32_t *D = dist + (size_t)r * n;
+  const uint16_t *H = hops + (size_t)r * n, *F = flags + (size_t)r * n;
+  if (!(F[v] & 1u) || v == root || H[v] < level) return;
+  if (F[root] & 2u) return;                                         // exact-kernel root: not handled (level_count says so)
+  uint64_t *A = anc + (size_t)r * n * W;
+  const uint32_t dv = D[v];
+  const bool v_net = (g.vflags[v] & 1u) != 0;
+  bool zdone = false, any = false;
+  for (uint32_t e = g.in_ptr[v]; e < g.in_ptr[v + 1]; ++e) {
+    const uint32_t sw = g.in_src[e], u = sw & SRC_MASK, w = g.in_w[e];
+    if (!(F[u] & 1u)) continue;
+    if (!ignore_ovl && (sw & SRC_NO_TRANSIT) && u != root) continue;
+    const uint32_t du = D[u];
+    const uint64_t c = (uint64_t)du + w;
+    if ((c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c) != dv) continue;       // not tight
+    if (w == 0u && u >= v) {                                                    // zero-cost link from a higher-numbered source
+      if (!(hc && v_net) || zdone) continue;                                    // static order: never a parent; hop-count-like: the first one only
+      zdone = true;
+    }
+    if (H[u] < level) continue;                                                 // nothing to inherit above the level
+    for (uint32_t q = 0; q < W; ++q) {
+      const uint64_t pu = A[(size_t)u * W + q], pv = A[(size_t)v * W + q];
+      if (pu & ~pv) { A[(size_t)v * W + q] = pv | pu; any = true; }
+    }
+  }
+  if (any) changed[sweep] = 1;
+}
+
 }  // namespace hspf

@@ -20,6 +20,7 @@ RUN_IGNORE_OVERLOAD = 0x02
 RUN_FORCE_EXACT = 0x04
 RUN_POP_RANK = 0x08
 RUN_COUNT_ROWS = 0x10
+E_TOO_MANY_SLOTS = -5
 
 PFX_SATURATING = 0x1
 PFX_LAST_MIN = 0x2
@@ -245,6 +246,18 @@ class SpfContext:
         if rc != 0:
             raise HspfError(rc, "hspf_run_device", self.last_error())
         return self.stats()
+
+    def ancestors_device(self, graph: SpfGraph, roots: Sequence[int], run_flags: int, *, dist_ptr: int, hops_ptr: int,
+                         flags_ptr: int, level: int, n_words: int, level_rank_ptr: int, level_count_ptr: int, anc_ptr: int) -> int:
+        """hspf_ancestors_device(): level-L ancestor bit sets of every (root, vertex) of a previous run_device(); all
+        `*_ptr` are device pointers.  Returns 0, or E_TOO_MANY_SLOTS (-5) when n_words is too small (level counts are
+        filled in either way)."""
+        roots = np.ascontiguousarray(roots, dtype=np.uint32)
+        rc = self.lib.hspf_ancestors_device(self.handle, graph.handle, _u32(roots), len(roots), run_flags, dist_ptr, hops_ptr,
+                                            flags_ptr, level, n_words, level_rank_ptr or None, level_count_ptr, anc_ptr)
+        if rc not in (0, E_TOO_MANY_SLOTS):
+            raise HspfError(rc, "hspf_ancestors_device", self.last_error())
+        return rc
 
     def routes_device(self, n_vertices: int, n_roots: int, mask_words: int, dist_ptr: int, flags_ptr: int,
                       mask_ptr: int, pfx_ptr, pfx_vertex, pfx_metric, *, best_metric_ptr: int,

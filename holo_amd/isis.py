@@ -681,6 +681,121 @@ def reflood_list(cache: Dict[bytes, NeighborCache], local_system_id: bytes, tn: 
     return sorted(out)
 
 
+# ---- flooding::manet with the ancestor queries answered from device-built bit sets ------------------
+
+@dataclass
+class DeviceNeighborCache:
+    """What reflood_list needs of one neighbour's hop-count SPT, taken from hspf_ancestors_device instead of a walk
+    over parent links: the remote-neighbour list with each member's bit in the level-1 sets, the second hops with (a)
+    their own level-2 bit and (b) the set of first hops above them, and the level-2 set of every vertex (row of this
+    root) for "which second hops lie on a shortest path to the LSP originator"."""
+    remote_nbr_list: Dict[bytes, str]
+    rnl_bit: Dict[bytes, int]                 # first-hop router -> bit index in the level-1 sets
+    second: List[Tuple[bytes, int, int]]      # second-hop routers: (system id, level-2 bit, level-1 ancestor set as int)
+    anc2_of: Dict[bytes, int]                 # router system id -> its level-2 ancestor set as int (0 when not in the SPT)
+    fallback: Optional[NeighborCache] = None  # root handled by the sequential kernel: host walk
+
+
+def _bits(row) -> int:
+    x = 0
+    for w, word in enumerate(row.tolist()):
+        x |= int(word) << (64 * w)
+    return x
+
+
+def manet_init_cache_device(level: int, instance: Instance, engine, flooding_algo_of=None,
+                            device="cuda:0") -> Dict[bytes, DeviceNeighborCache]:
+    """flooding::manet::init_cache (holo-isis/src/flooding/manet.rs:39-97) with everything reflood_list asks of the
+    SPTs computed on the device: ONE batched hop-count run (results stay in HBM), then hspf_ancestors_device for levels
+    1 and 2.  What comes back to the host is the remote-neighbour list, the second hops and the bit sets."""
+    import torch
+    nbrs: List[bytes] = []
+    for iface in instance.interfaces_by_name():
+        for adj in iface.adjacencies:
+            if adj.state == "up" and adj.system_id not in nbrs:
+                nbrs.append(adj.system_id)
+    g = LevelGraph(instance, level, None, True)
+    out: Dict[bytes, DeviceNeighborCache] = {}
+    have = [(sid, g.index.get(vertex_id((sid, 0)))) for sid in nbrs]
+    for sid, r in have:
+        if r is None:                        # root without any LSP: alone in its SPT (spf.rs:552-561), empty RNL
+            out[sid] = DeviceNeighborCache({}, {}, [], {})
+    run = [(sid, r) for sid, r in have if r is not None]
+    if not run:
+        return out
+    roots = np.asarray([r for _, r in run], np.uint32)
+    R, n = len(roots), g.n
+    G = g.device(engine)
+    dev = torch.device(device)
+    dist = torch.empty((R, n), dtype=torch.int32, device=dev)
+    hops = torch.empty((R, n), dtype=torch.int16, device=dev)
+    flags = torch.empty((R, n), dtype=torch.int16, device=dev)
+    engine.run_device(G, roots, g.run_flags, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(), flags_ptr=flags.data_ptr())
+    levels = {}
+    for L in (1, 2):
+        W = 1
+        while True:
+            rank = torch.empty((R, n), dtype=torch.int32, device=dev)
+            cnt = torch.empty((R,), dtype=torch.int32, device=dev)
+            anc = torch.empty((R, n, W), dtype=torch.int64, device=dev)
+            rc = engine.ancestors_device(G, roots, g.run_flags, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(),
+                                         flags_ptr=flags.data_ptr(), level=L, n_words=W, level_rank_ptr=rank.data_ptr(),
+                                         level_count_ptr=cnt.data_ptr(), anc_ptr=anc.data_ptr())
+            c = cnt.cpu().numpy().view(np.uint32)
+            if rc == 0:
+                break
+            W = int(max((int(x) + 63) // 64 for x in c if x != 0xFFFFFFFF))
+        levels[L] = (rank.cpu().numpy().view(np.uint32), c, anc.cpu().numpy().view(np.uint64))
+    routers = [(v, g.vids[v][1]) for v in range(n) if g.vids[v][0]]          # (vertex, system id) of router vertices
+    host_cache = None
+    for j, (sid, r) in enumerate(run):
+        if levels[1][1][j] == 0xFFFFFFFF:                                     # dynamic pop order: the host walk
+            if host_cache is None:
+                host_cache = manet_init_cache(level, instance, engine, flooding_algo_of)
+            hc = host_cache[sid]
+            out[sid] = DeviceNeighborCache(hc.remote_nbr_list, {}, [], {}, hc)
+            continue
+        rank1, rank2 = levels[1][0][j], levels[2][0][j]
+        anc1, anc2 = levels[1][2][j], levels[2][2][j]
+        rnl_bit = {s2: int(rank1[v]) for v, s2 in routers if rank1[v] != 0xFFFFFFFF}
+        rnl = {s2: (flooding_algo_of(s2) if flooding_algo_of else "zero-pruner") for s2 in rnl_bit}
+        second = [(s2, int(rank2[v]), _bits(anc1[v])) for v, s2 in routers if rank2[v] != 0xFFFFFFFF]
+        anc2_of = {s2: _bits(anc2[v]) for v, s2 in routers}
+        out[sid] = DeviceNeighborCache(dict(sorted(rnl.items())), rnl_bit, second, anc2_of)
+    return out
+
+
+def reflood_list_device(cache: Dict[bytes, DeviceNeighborCache], local_system_id: bytes, tn: bytes,
+                        lsp_id: Tuple[bytes, int, int]) -> List[bytes]:
+    """flooding::manet::reflood_list (holo-isis/src/flooding/manet.rs:99-173) on the device-built sets: every
+    Spt::is_on_path of the reference is one bit test here."""
+    c = cache.get(tn)
+    if c is None or not c.remote_nbr_list:
+        return []
+    if c.fallback is not None:
+        return reflood_list({tn: c.fallback}, local_system_id, tn, lsp_id)
+    originator = lsp_id[0]
+    on_path_to_orig = c.anc2_of.get(originator, 0)                           # level-2 routers above (or equal to) the originator
+    thl = sorted((s2, a1) for s2, bit2, a1 in c.second                       # :120-132
+                 if s2 != originator and not (on_path_to_orig >> bit2) & 1)
+    rnl = list(c.remote_nbr_list.items())
+    rnum = len(rnl)
+    n0 = flood_reduction_hash(lsp_id) % rnum
+    out: List[bytes] = []
+    for k in range(rnum):
+        if not thl:
+            break
+        sid, algo = rnl[(n0 + k) % rnum]
+        b = c.rnl_bit[sid]
+        if sid == local_system_id:
+            out = [t for t, a1 in thl if (a1 >> b) & 1]
+            break
+        if algo != "modified-manet":
+            continue
+        thl = [(t, a1) for t, a1 in thl if not (a1 >> b) & 1]
+    return sorted(out)
+
+
 def should_flood(iface: Interface, reflood: Sequence[bytes]) -> bool:      # manet.rs:176-186
     rs = set(reflood)
     return any(a.state == "up" and a.system_id in rs for a in iface.adjacencies)

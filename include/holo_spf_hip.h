@@ -292,6 +292,22 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
                        const uint32_t *dist_dev, const uint16_t *flags_dev, const uint64_t *mask_dev,
                        const hspf_prefix_table *table, hspf_routes *out_dev);
 
+/* ---- ancestor sets on device (the queries of flooding::manet::reflood_list) ------------------------
+ * For every root of a previous hspf_run_device() and a level L (1 = first hops / remote-neighbour list, 2 = second
+ * hops): the root's level-L routers = router vertices of its SPT with hops == L, numbered in ascending vertex index
+ * (level_rank, 0xFFFFFFFF elsewhere; level_count = how many), and anc[root][v] = the n_words x 64 bit set of the level-L
+ * routers that are ancestors of v in the SPT's parent DAG, or v itself — holo-isis Spt::is_on_path(a, d)
+ * (holo-isis/src/spf.rs:261-286) for a level-L router a is then bit level_rank[a] of anc[root][d].
+ * roots / run_flags: as passed to the run.  dist / hops / flags / level_rank / level_count / anc are DEVICE pointers
+ * ([n_roots][n_vertices] row-major, anc with n_words words per entry; level_rank may be NULL).
+ * A root that needed the sequential exact kernel (dynamic pop order) gets level_count 0xFFFFFFFF and no sets: the
+ * caller keeps its own walk for it.  Returns HSPF_E_TOO_MANY_SLOTS when a root has more than 64 x n_words level-L
+ * routers (level_count is filled in either way: call again with enough words). */
+int hspf_ancestors_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                          const uint32_t *dist_dev, const uint16_t *hops_dev, const uint16_t *flags_dev,
+                          uint32_t level, uint32_t n_words, uint32_t *level_rank_dev, uint32_t *level_count_dev,
+                          uint64_t *anc_dev);
+
 /* ---- several GPUs --------------------------------------------------------------------------
  * SPF roots are independent units over a read-only graph: the graph is replicated on every GPU, whole 64-root
  * wavefront batches are dealt to the ranks (hspf_shard_bounds), every rank runs its slice, and ONE all-gather per

@@ -75,3 +75,43 @@ MANET_FILES = sorted(glob.glob(os.path.join(GOLD, "isis", "*.json")))[::2]
 @pytest.mark.parametrize("path", MANET_FILES, ids=[os.path.basename(p)[:-5] for p in MANET_FILES])
 def test_manet_reflood_lists_on_gpu_match_literal_restatement(spf_ctx, path):
     assert check_reflood_lists(json.load(open(path)), spf_ctx) > 0
+
+
+# ---- the same lists with the is_on_path queries answered from device-built ancestor sets (hspf_ancestors_device) ------
+from holo_amd import isis as H                       # noqa: E402
+from oracle import isis_ref as R                     # noqa: E402
+from test_host_manet import ALGOS                    # noqa: E402
+
+
+def check_reflood_lists_device(vec, engine):
+    inst = H.Instance.from_vector(vec)
+    local = inst.config.system_id
+    n_lists = 0
+    for level in inst.config.levels():
+        if level not in inst.lsdb:
+            continue
+        systems = sorted({l.system_id for l in inst.lsdb[level].iter()})
+        lsp_ids = [(s, 0, 0) for s in systems] + [(systems[0], 3, 9), (systems[-1], 0, 17)]
+        for name, algo_of in ALGOS.items():
+            cache = H.manet_init_cache_device(level, inst, engine, algo_of)
+            for tn in cache:
+                for lsp_id in lsp_ids:
+                    got = H.reflood_list_device(cache, local, tn, lsp_id)
+                    want = R.reflood_list(vec, level, local, tn, lsp_id, algo_of)
+                    assert got == want, (level, name, tn.hex(), lsp_id)
+                    n_lists += 1
+    return n_lists
+
+
+@pytest.mark.parametrize("path", MANET_FILES, ids=[os.path.basename(p)[:-5] for p in MANET_FILES])
+def test_manet_reflood_lists_from_device_ancestor_sets(spf_ctx, path):
+    assert check_reflood_lists_device(json.load(open(path)), spf_ctx) > 0
+
+
+@pytest.mark.parametrize("block", range(2))
+def test_manet_reflood_lists_from_device_ancestor_sets_random_instances(spf_ctx, block):
+    from _random_isis import make
+    total = 0
+    for seed in range(2000 + block * 15, 2000 + block * 15 + 15):
+        total += check_reflood_lists_device(make(seed), spf_ctx)
+    assert total > 50
