@@ -122,7 +122,8 @@ def latency_1root(ctx, dev) -> dict:
         ok = bool(np.array_equal(d.cpu().numpy().view(np.uint32), ref.dist) and np.array_equal(h.cpu().numpy().view(np.uint16), ref.hops)
                   and np.array_equal(m.cpu().numpy().view(np.uint64), ref.mask))
         out[name] = {"gpu_wall_ms": round(float(np.median(wall[3:])), 4), "gpu_device_ms": round(float(np.median(devms[3:])), 4),
-                     "launches": launches, "path": st.get("path", ""), "cpu_heap_1thread_ms": round(float(min(tc)), 4), "identical_to_oracle": ok}
+                     "launches": launches,
+                     "path": "k_single" if st.get("single_wg") else ("k_lv" if st.get("lane_vertex") else "k_fused sweeps"), "cpu_heap_1thread_ms": round(float(min(tc)), 4), "identical_to_oracle": ok}
         G.free()
     return out
 

@@ -36,7 +36,7 @@ class HspfStats(ctypes.Structure):
                 ("ms_total", ctypes.c_float), ("ms_relax", ctypes.c_float), ("ms_dag", ctypes.c_float),
                 ("ms_finish", ctypes.c_float), ("ms_d2h", ctypes.c_float),
                 ("state_bytes", ctypes.c_uint32), ("narrow_overflow", ctypes.c_uint32),
-                ("rows_recomputed", ctypes.c_uint64), ("single_wg", ctypes.c_uint32), ("reserved_", ctypes.c_uint32),
+                ("rows_recomputed", ctypes.c_uint64), ("single_wg", ctypes.c_uint32), ("lane_vertex", ctypes.c_uint32),
                 ("dbg", ctypes.c_uint32 * 4)]
 
 

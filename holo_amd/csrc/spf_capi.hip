@@ -109,6 +109,9 @@ struct hspf_ctx {
   uint32_t variant = 0;                    // HSPF_VARIANT env: kernel A/B switches (tuning only)
   uint32_t single_attr = 0;                // per k_single instantiation: its dynamic-LDS attribute has been set
   uint32_t single_max_n = 1024;            // HSPF_SINGLE_MAX_N env: largest graph that takes the one-workgroup-per-root kernel
+  uint32_t lv_max_roots = 2;               // HSPF_LV_MAX_ROOTS env: runs of at most this many roots take the lane = vertex kernel (0: never)
+  uint32_t lv_min_n = 32768;               // HSPF_LV_MIN_N env: ... on graphs of at least this many vertices
+  uint32_t est_lv = 24;
   hspf_stats stats = {};
 };
 
@@ -345,6 +348,8 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   ctx->device = device_ordinal;
   if (const char *v = getenv("HSPF_VARIANT")) ctx->variant = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_SINGLE_MAX_N")) ctx->single_max_n = (uint32_t)strtoul(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_LV_MAX_ROOTS")) ctx->lv_max_roots = (uint32_t)strtoul(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_LV_MIN_N")) ctx->lv_min_n = (uint32_t)strtoul(v, nullptr, 0);
   if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return HSPF_E_NODEV; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
   for (auto &e : ctx->ev)
@@ -941,6 +946,40 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     // one batch of roots.
     const uint32_t smax = std::min(n_roots <= 64 ? ctx->single_max_n * 2u : ctx->single_max_n, SINGLE_MAX_N);
     const bool single = n <= smax && g->e_kept <= SINGLE_MAX_E;
+    // A few roots on a larger graph: lane = vertex (k_lv), one launch per sweep over the root's own row-major state.  The
+    // lane = root engine spends a 256-byte row per useful 4-8 bytes there (isis-100k, one root: 25 launches x 21 us);
+    // the scattered gathers of k_lv cost less than that up to a handful of roots (profiles/r02_notes.md, r02k).
+    const bool lv = !single && n_roots <= ctx->lv_max_roots && n >= ctx->lv_min_n;
+    auto lv_run = [&]() -> int {
+      int r2;
+      if ((r2 = ensure(ctx, ctx->stamp, (size_t)n_roots * n * 4))) return r2;
+      uint32_t *a_stamp = (uint32_t *)ctx->stamp.p;
+      hipError_t er = hipMemsetAsync(d_lf, 0, (size_t)L * 4, s);
+      if (er == hipSuccess) er = hipMemsetAsync(d_st, 0xFF, (size_t)n_roots * n * 8, s);
+      if (er == hipSuccess) er = hipMemsetAsync(a_stamp, 0, (size_t)n_roots * n * 4, s);
+      if (er == hipSuccess && count_rows) er = hipMemsetAsync(d_kcnt, 0, 256 * 4, s);
+      if (er != hipSuccess) { ctx->last_error = std::string("lv init: ") + hipGetErrorString(er); return HSPF_E_HIP; }
+      hipLaunchKernelGGL(k_init_lv, dim3((n_roots + 63) / 64), dim3(64), 0, s, gd, d_st, a_stamp, d_roots, n_roots);
+      LvArgs la{gd, tabs, d_kcnt, d_roots, fp_wide, net_nh, ignore_ovl, n_roots, count_rows ? 1u : 0u, d_st, a_stamp, d_changed, 0, d_lf};
+      const bool mi = g->max_path_metric == HSPF_DIST_INF;
+      const dim3 lgrid((n + 255) / 256, n_roots);
+      uint32_t n_f = 0;
+      r2 = run_phase(ctx->est_lv, [&](uint32_t sweep) {
+        la.sweep = (int)sweep;
+        if (mi) hipLaunchKernelGGL((k_lv<true>), lgrid, dim3(256), 0, s, la);
+        else    hipLaunchKernelGGL((k_lv<false>), lgrid, dim3(256), 0, s, la);
+      }, n_f, [&]() {
+        (void)hipEventRecord(ctx->ev[2], s);
+        (void)hipEventRecord(ctx->ev[3], s);
+        hipLaunchKernelGGL(k_emit_lv, lgrid, dim3(256), 0, s, n, (const uint64_t *)d_st, fp_wide, od);
+      });
+      if (r2) return r2;
+      ctx->est_lv = n_f + 1;
+      st.n_relax_launches += n_f;
+      st.lane_vertex = 1;
+      if (count_rows) for (uint32_t i = 0; i < 128; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
+      return HSPF_OK;
+    };
     if (single) {
       hipError_t er = hipMemsetAsync(d_lf, 0, (size_t)L * 4, s);
       if (er == hipSuccess && count_rows) er = hipMemsetAsync(d_kcnt, 0, 256 * 4, s);
@@ -977,6 +1016,9 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         for (uint32_t i = 0; i < 3; ++i) st.dbg[i] = ctx->h_lane_flags[L + 128 + i];   // sweeps, shader cycles, 100 MHz ticks of workgroup 0
       }
       narrow = false;
+    } else if (lv) {
+      if ((rc = lv_run())) return rc;
+      narrow = false;
     } else if (narrow) {
       if ((rc = fused_run(true))) return rc;
       // did any lane leave the 4-byte fields?  (run_phase has brought the per-root status bits back)
@@ -984,7 +1026,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);
       if (ovf) { g->narrow_bad = true; narrow = false; st.narrow_overflow = 1; }
     }
-    if (!single && !narrow && (rc = fused_run(false))) return rc;
+    if (!single && !lv && !narrow && (rc = fused_run(false))) return rc;
     if (!narrow && fp_wide.hmax < 0xFFFFu) {                       // more than 16 mask bits: did the hop field hold?
       bool ovf = false;
       for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);

@@ -868,6 +868,7 @@ struct SingleArgs {
   uint32_t net_nexthops, ignore_ovl, n_roots, count_rows, lds_links;
   uint32_t *lane_flags;
   OutDev o;
+  __device__ __forceinline__ const SlotTabs &slot_tabs() const { return gp->tabs; }
 };
 
 // LDS layout (dynamic): state words [n] | when the links are staged, per link: source|NT, cost, position in the source's
@@ -882,10 +883,10 @@ constexpr uint32_t SINGLE_VPT_MAX = SINGLE_MAX_N / SINGLE_THREADS;     // vertic
 
 // One link into the row accumulator: the per-lane form of fused_row_any's loop body.  RARE = the row has an
 // overloaded source, a zero-cost link from a higher-numbered source, or the graph is hop-count-like.
-template <bool MAXINF, bool RARE>
+template <bool MAXINF, bool RARE, typename Args, typename FPos>
 __device__ __forceinline__ void single_link(RowAcc &r, uint32_t &bd_all, uint32_t &zb, uint32_t &zm, uint32_t &zh,
-                                            uint32_t sw, uint32_t w, uint32_t fpos, uint64_t q, uint32_t v, uint32_t v_router,
-                                            uint32_t my_root, uint32_t root_slot, const SingleArgs &a, const FusedParams &P,
+                                            uint32_t sw, uint32_t w, FPos &&fpos_of, uint64_t q, uint32_t v, uint32_t v_router,
+                                            uint32_t my_root, uint32_t root_slot, const Args &a, const FusedParams &P,
                                             uint32_t mmask) {
   const uint32_t u = sw & SRC_MASK;
   uint32_t d = (uint32_t)(q >> 32);
@@ -900,8 +901,8 @@ __device__ __forceinline__ void single_link(RowAcc &r, uint32_t &bd_all, uint32_
   const uint32_t hh = pay >> P.mbits;
   uint32_t contrib = pay & mmask;
   if ((lt || eq) && hh == 0u && c < P.inf_t) {                               // parent: root or hops-0 network
-    const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(a.gp->tabs, root_slot, u);
-    const uint32_t sidx = base_s + fpos;
+    const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(a.slot_tabs(), root_slot, u);
+    const uint32_t sidx = base_s + fpos_of();
     contrib = ((v_router || a.net_nexthops) && sidx < P.mbits) ? (1u << sidx) : 0u;
   }
   if (hz) { if (lt) { zb = c; zm = contrib; zh = hh; } return; }             // see fused_row_any
@@ -999,8 +1000,9 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
 #pragma unroll
         for (uint32_t k = 0; k < PF; ++k) {
           if (eb + k >= e1) break;
-          if (rare) single_link<MAXINF, true>(r, bd_all, zb, zm, zh, rs[k], rw[k], rf[k], qs[k], v, v_router, my_root, root_slot, a, P, mmask);
-          else      single_link<MAXINF, false>(r, bd_all, zb, zm, zh, rs[k], rw[k], rf[k], qs[k], v, v_router, my_root, root_slot, a, P, mmask);
+          const uint32_t fk = rf[k];
+          if (rare) single_link<MAXINF, true>(r, bd_all, zb, zm, zh, rs[k], rw[k], [fk]() { return fk; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
+          else      single_link<MAXINF, false>(r, bd_all, zb, zm, zh, rs[k], rw[k], [fk]() { return fk; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
         }
       }
       if (rare && P.hc) {
@@ -1044,6 +1046,125 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
       a.gp->rows_done[129] = (uint32_t)(clock64() - t_clk0);
       a.gp->rows_done[130] = (uint32_t)(wall_clock64() - t_wall0);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_lv — a few roots on a graph too large for k_single: lane = VERTEX.
+//
+// run_area / compute_spt are called with ONE root per area / level (holo-ospf/src/spf.rs:540-542,
+// holo-isis/src/spf.rs:746-761).  On the lane = root engine such a run keeps one lane of every 64 busy: a sweep walks
+// 256-byte rows for 4 useful bytes (isis-100k, one root: 25 launches x 21 us).  Here the state of a root is one row-major
+// array of packed 8-byte words [dist32 | hops | mask] (the k_single / wide k_fused word, <= 24 first-hop slots) in
+// HBM — 0.8 MB at 100 k vertices, i.e. L2 resident — thread t of block b owns vertex 256 b + t of root blockIdx.y, and
+// a sweep is one launch over the vertices whose activation stamp says that an in-neighbour changed (the push-stamp
+// protocol of k_fused).  Same fixed point, same row routine (single_link / finish_row), same exactness flags; a
+// neighbour's word is ONE 8-byte access, so a (distance, hops, mask) triple is never torn and a stale one is a triple
+// the neighbour held earlier in the run ("memory is monotone", as in k_fused).  Neighbour states are scattered 8-byte
+// gathers, which is why this layout loses against lane = root beyond a handful of roots (run_impl picks by root count).
+struct LvArgs {
+  GraphDev g;                  // by value: one kernarg fetch instead of a dependent trip through a descriptor in HBM
+  SlotTabs tabs;
+  uint32_t *rows_done;
+  const uint32_t *roots;
+  FusedParams P;               // the 8-byte state's parameters (sh = 0)
+  uint32_t net_nexthops, ignore_ovl, n_roots, count_rows;
+  uint64_t *st;                // [n_roots][n]
+  uint32_t *act;               // [n_roots][n] activation stamps
+  int *changed;
+  int sweep;
+  uint32_t *lane_flags;
+  __device__ __forceinline__ const SlotTabs &slot_tabs() const { return tabs; }
+};
+
+// A launch is a chain of dependent round trips, not a stream of bytes (one root on isis-100k: ~43 k due vertices per
+// sweep): everything that depends only on the thread's vertex comes in ONE trip (stamp, row bounds, flags, old word),
+// then the records of up to LV_PF links in one, then their sources' words in one.  The position of a link in its
+// source row is only fetched for links out of a hops-0 parent (the root's neighbours).
+constexpr uint32_t LV_PF = 16;
+
+template <bool MAXINF>
+__global__ __launch_bounds__(256) void k_lv(LvArgs a) {
+  if (a.sweep > 0 && a.changed[a.sweep - 1] == 0) return;
+  const GraphDev &g = a.g;
+  const uint32_t n = g.n;
+  const uint32_t root_slot = blockIdx.y;
+  const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+  if (v >= n) return;
+  const uint32_t cur = (uint32_t)a.sweep + 2u;
+  uint32_t *A = a.act + (size_t)root_slot * n;
+  uint64_t *S = a.st + (size_t)root_slot * n;
+  const uint32_t my_root = a.roots[root_slot];
+  const uint32_t av = A[v];
+  const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
+  const uint32_t rf = g.rowflags[v], vf = g.vflags[v];
+  const uint64_t old = S[v];
+  if (my_root == INF || av < cur || v == my_root) return;          // nothing changed around this vertex
+  const FusedParams P = a.P;
+  const uint32_t mmask = (1u << P.mbits) - 1u;
+  const bool rare = P.hc != 0u || (!a.ignore_ovl && (rf & RF_NT)) || (rf & RF_ZERO);
+  const uint32_t v_router = (vf & 1u) ? 0u : 1u;
+  RowAcc r{INF, 0u, INF, 0u, false};
+  uint32_t bd_all = INF, zb = INF, zm = 0u, zh = 0u;
+  for (uint32_t eb = e0; eb < e1; eb += LV_PF) {
+    uint32_t rs[LV_PF], rw[LV_PF];
+    uint64_t qs[LV_PF];
+#pragma unroll
+    for (uint32_t k = 0; k < LV_PF; ++k) {
+      const uint32_t e = min(eb + k, e1 - 1u);
+      rs[k] = g.in_src[e]; rw[k] = g.in_w[e];
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < LV_PF; ++k) qs[k] = S[rs[k] & SRC_MASK];
+#pragma unroll
+    for (uint32_t k = 0; k < LV_PF; ++k) {
+      if (eb + k >= e1) break;
+      const uint32_t *fp = g.in_fpos + (eb + k);
+      if (rare) single_link<MAXINF, true>(r, bd_all, zb, zm, zh, rs[k], rw[k], [fp]() { return *fp; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
+      else      single_link<MAXINF, false>(r, bd_all, zb, zm, zh, rs[k], rw[k], [fp]() { return *fp; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
+    }
+  }
+  if (rare && P.hc) {
+    const bool late = zb < r.bd;
+    r.bm = late ? zm : r.bm; r.bh = late ? zh : r.bh; r.bd = late ? zb : r.bd;
+  }
+  const RowOut<uint64_t> o = finish_row<uint64_t>(r, v, my_root, v_router, bd_all, P);
+  if (o.nw != old) {
+    S[v] = o.nw;
+    a.changed[a.sweep] = 1;
+    for (uint32_t k = g.out_ptr[v], k1 = g.out_ptr[v + 1]; k < k1; ++k) A[g.out_dst[k]] = cur + 1u;   // wake the out-neighbours up
+  }
+  if (a.count_rows) atomicAdd(&a.rows_done[(blockIdx.x + threadIdx.x) & 127u], 1u);
+  uint32_t lf = 0;
+  if ((MAXINF && o.sat) || o.need_exact) lf |= LF_NEED_EXACT;
+  if (o.ovf) lf |= LF_OVERFLOW;
+  if (lf) atomicOr(&a.lane_flags[root_slot], lf);
+}
+
+// init for k_lv (state = all ones, stamps = 0 by memset): the root's word = (0, 0, 0), its out-neighbours due in sweep 0.
+__global__ void k_init_lv(GraphDev g, uint64_t *st, uint32_t *act, const uint32_t *roots, uint32_t n_roots) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_roots) return;
+  const uint32_t r = roots[i];
+  if (r == INF) return;
+  st[(size_t)i * g.n + r] = 0ull;
+  for (uint32_t k = g.out_ptr[r]; k < g.out_ptr[r + 1]; ++k) act[(size_t)i * g.n + g.out_dst[k]] = 2u;
+}
+
+// results of k_lv: the state is row-major already, one thread per (root, vertex)
+__global__ __launch_bounds__(256) void k_emit_lv(uint32_t n, const uint64_t *__restrict__ st, FusedParams P, OutDev o) {
+  const uint32_t v = blockIdx.x * 256u + threadIdx.x, r = blockIdx.y;
+  if (v >= n) return;
+  const uint64_t x = st[(size_t)r * n + v];
+  const size_t idx = o.row(r) * n + v;
+  const bool in = x != ~0ull;
+  const uint32_t pay = (uint32_t)x;
+  o.dist[idx] = in ? (uint32_t)(x >> 32) : INF;
+  if (o.hops) o.hops[idx] = in ? (uint16_t)(pay >> P.mbits) : (uint16_t)0;
+  if (o.flags) o.flags[idx] = in ? 1 : 0;
+  if (o.mask) {
+    o.mask[idx * o.out_words] = in ? (uint64_t)(pay & ((1u << P.mbits) - 1u)) : 0ull;
+    for (uint32_t k = 1; k < o.out_words; ++k) o.mask[idx * o.out_words + k] = 0;
   }
 }
 

@@ -1,6 +1,6 @@
 """Which engine configuration a GPU test runs with (see the spf_ctx fixture in conftest.py)."""
 import pytest
 
-both_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps"], indirect=True)
+both_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps", "lanevertex"], indirect=True)
 sweeps_engine = pytest.mark.parametrize("spf_ctx", ["sweeps"], indirect=True)
-all_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps", "twophase"], indirect=True)
+all_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps", "twophase", "lanevertex"], indirect=True)

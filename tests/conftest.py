@@ -23,14 +23,19 @@ def _ctx_pool():
 @pytest.fixture
 def spf_ctx(request, _ctx_pool):
     """Engine contexts shared by the GPU tests of a session.  "default" is the product configuration (small graphs
-    take the one-workgroup-per-root kernel, k_single); "sweeps" has that kernel switched off (HSPF_SINGLE_MAX_N=0), so
-    that the batched sweep engine keeps its coverage on the small adversarial graphs of the suite; "twophase" additionally
-    sends runs with more than 24 first-hop slots down the older k_relax + k_dag path instead of k_fw (HSPF_VARIANT bit6).
+    take the one-workgroup-per-root kernel, k_single, runs of a few roots on larger ones the lane = vertex kernel, k_lv);
+    "sweeps" has both switched off (HSPF_SINGLE_MAX_N=0, HSPF_LV_MAX_ROOTS=0), so that the batched lane = root sweep
+    engine keeps its coverage on the small adversarial graphs of the suite; "twophase" additionally sends runs with more
+    than 24 first-hop slots down the older k_relax + k_dag path instead of k_fw (HSPF_VARIANT bit6); "lanevertex" sends
+    every run of up to 64 roots (with at most 24 first-hop slots) through k_lv (HSPF_SINGLE_MAX_N=0, HSPF_LV_MAX_ROOTS=64,
+    HSPF_LV_MIN_N=0).
     Tests choose with tests/_engines.py (indirect parametrisation); unmarked tests get "default"."""
     mode = getattr(request, "param", "default")
     if mode not in _ctx_pool:
         from holo_amd.engine import SpfContext
-        env = {"sweeps": {"HSPF_SINGLE_MAX_N": "0"}, "twophase": {"HSPF_SINGLE_MAX_N": "0", "HSPF_VARIANT": "64"}}.get(mode, {})
+        env = {"sweeps": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0"},
+               "twophase": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "64"},
+               "lanevertex": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "64", "HSPF_LV_MIN_N": "0"}}.get(mode, {})
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
