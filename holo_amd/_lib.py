@@ -42,7 +42,8 @@ class HspfStats(ctypes.Structure):
 
 class HspfPrefixTable(ctypes.Structure):
     _fields_ = [("n_prefixes", ctypes.c_uint32), ("n_entries", ctypes.c_uint32),
-                ("pfx_ptr", u32p), ("pfx_vertex", u32p), ("pfx_metric", u32p), ("flags", ctypes.c_uint32)]
+                ("pfx_ptr", u32p), ("pfx_vertex", u32p), ("pfx_metric", u32p), ("flags", ctypes.c_uint32),
+                ("pfx_origin", u32p), ("init_exists", u8p), ("init_metric", u32p), ("init_origin", u32p)]
 
 
 class HspfRows(ctypes.Structure):

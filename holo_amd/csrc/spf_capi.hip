@@ -88,7 +88,7 @@ struct hspf_ctx {
   DevBuf dist, hv, mask, lane_flags, changed, st64, stamp, hnb, kcnt;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
-  DevBuf pf_ptr, pf_vtx, pf_met;                    // prefix table of hspf_routes_device
+  DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
   DevBuf gb, gb_delta;                              // graph build scratch, patch delta
   BuildInfo *h_info = nullptr;     // pinned
   int *h_changed = nullptr;        // pinned, h_changed_cap ints: per-sweep "something changed" flags of a phase
@@ -367,7 +367,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->gb, &ctx->gb_delta, &ctx->kcnt})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->kcnt})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
@@ -1292,12 +1292,18 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
   if (!ctx || !t || !out || !dist_dev || !flags_dev || !mask_dev || !out->best_metric || !out->best_entry ||
       !out->nexthop_mask || n_roots == 0 || n_mask_words == 0 || !t->pfx_ptr || (t->n_entries && (!t->pfx_vertex || !t->pfx_metric)))
     return HSPF_E_INVAL;
-  if (t->flags & ~(HSPF_PFX_SATURATING | HSPF_PFX_LAST_MIN)) { ctx->last_error = "hspf_prefix_table: unknown flags"; return HSPF_E_INVAL; }
+  if (t->flags & ~(HSPF_PFX_SATURATING | HSPF_PFX_LAST_MIN | HSPF_PFX_ORDERED)) { ctx->last_error = "hspf_prefix_table: unknown flags"; return HSPF_E_INVAL; }
+  const bool ordered = (t->flags & HSPF_PFX_ORDERED) != 0;
+  if (ordered && ((t->flags & HSPF_PFX_LAST_MIN) || (t->n_entries && !t->pfx_origin) ||
+                  (t->init_exists && (!t->init_metric || !t->init_origin)))) {
+    ctx->last_error = "hspf_prefix_table: HSPF_PFX_ORDERED needs pfx_origin (and init_metric / init_origin with init_exists), not LAST_MIN";
+    return HSPF_E_INVAL;
+  }
   if (t->pfx_ptr[0] != 0 || t->pfx_ptr[t->n_prefixes] != t->n_entries) { ctx->last_error = "pfx_ptr malformed"; return HSPF_E_INVAL; }
   for (uint32_t p = 0; p < t->n_prefixes; ++p)
     if (t->pfx_ptr[p + 1] < t->pfx_ptr[p]) { ctx->last_error = "pfx_ptr not monotone"; return HSPF_E_INVAL; }
   for (uint32_t e = 0; e < t->n_entries; ++e)
-    if (t->pfx_vertex[e] >= n_vertices) { ctx->last_error = "pfx_vertex out of range"; return HSPF_E_INVAL; }
+    if ((ordered ? (t->pfx_vertex[e] & ~HSPF_PFX_ENTRY_NETWORK) : t->pfx_vertex[e]) >= n_vertices) { ctx->last_error = "pfx_vertex out of range"; return HSPF_E_INVAL; }
   if (t->n_prefixes == 0) return HSPF_OK;
   (void)hipSetDevice(ctx->device);
   int rc;
@@ -1310,10 +1316,32 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
     HIPCHK(ctx, hipMemcpyAsync(ctx->pf_vtx.p, t->pfx_vertex, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(ctx->pf_met.p, t->pfx_metric, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
   }
+  const uint8_t *d_iex = nullptr;
+  const uint32_t *d_imet = nullptr, *d_iorg = nullptr;
+  if (ordered) {
+    // origins, then the optional initial state: [n_entries] u32 | [n_prefixes] u32 metric | [n_prefixes] u32 origin | [n_prefixes] u8
+    const size_t ne = std::max<size_t>(t->n_entries, 1), np = t->n_prefixes;
+    if ((rc = ensure(ctx, ctx->pf_org, (ne + 2 * np) * 4 + np))) return rc;
+    uint32_t *base = (uint32_t *)ctx->pf_org.p;
+    if (t->n_entries) HIPCHK(ctx, hipMemcpyAsync(base, t->pfx_origin, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
+    if (t->init_exists) {
+      HIPCHK(ctx, hipMemcpyAsync(base + ne, t->init_metric, np * 4, hipMemcpyHostToDevice, s));
+      HIPCHK(ctx, hipMemcpyAsync(base + ne + np, t->init_origin, np * 4, hipMemcpyHostToDevice, s));
+      HIPCHK(ctx, hipMemcpyAsync(base + ne + 2 * np, t->init_exists, np, hipMemcpyHostToDevice, s));
+      d_imet = base + ne; d_iorg = base + ne + np; d_iex = (const uint8_t *)(base + ne + 2 * np);
+    }
+  }
   // gridDim.y is capped at 65535: "every router as a root" on a large LSDB goes in slabs of roots
   for (uint32_t r0 = 0; r0 < n_roots; r0 += 65535u) {
     const uint32_t nr = std::min(65535u, n_roots - r0);
     const size_t ov = (size_t)r0 * n_vertices, op = (size_t)r0 * t->n_prefixes;
+    if (ordered)
+      hipLaunchKernelGGL(k_routes_ordered, dim3((t->n_prefixes + 255) / 256, nr), dim3(256), 0, s, n_vertices, nr, n_mask_words,
+                         t->n_prefixes, (const uint32_t *)ctx->pf_ptr.p, (const uint32_t *)ctx->pf_vtx.p,
+                         (const uint32_t *)ctx->pf_met.p, (const uint32_t *)ctx->pf_org.p, d_iex, d_imet, d_iorg,
+                         dist_dev + ov, flags_dev + ov, mask_dev + ov * n_mask_words,
+                         out->best_metric + op, out->best_entry + op, out->nexthop_mask + op * n_mask_words);
+    else
     hipLaunchKernelGGL(k_routes, dim3((t->n_prefixes + 255) / 256, nr), dim3(256), 0, s, n_vertices, nr, n_mask_words,
                        t->n_prefixes, (const uint32_t *)ctx->pf_ptr.p, (const uint32_t *)ctx->pf_vtx.p,
                        (const uint32_t *)ctx->pf_met.p, dist_dev + ov, flags_dev + ov, mask_dev + ov * n_mask_words,

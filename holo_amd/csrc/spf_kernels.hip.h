@@ -573,6 +573,29 @@ template <typename ST> struct Row16 {
 
 template <typename ST, bool MAXINF, int L>
 __device__ __forceinline__ void row16_compute(Row16<ST> &r) {
+  if constexpr (sizeof(ST) == 4) {
+    // 4-byte state: add the shifted cost to the WHOLE word — the pay bits ride along in the low sh bits, the sum
+    // leaves 32 bits exactly when the distance leaves its field — so the field is never masked out per link (one
+    // v_and less of 8 vector instructions), the min runs over whole words (its distance field is the min distance), a
+    // link is tight iff its word is <= (min distance | all pay bits), and the pay bits come out of the sum itself.
+    const uint32_t paym = (1u << r.P.sh) - 1u;
+    uint32_t m = INF;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      r.c[j] = add_sat(PayBits<ST>::of(r.q[j]), rdlane(r.wk, j));
+      m = min(m, r.c[j]);
+    }
+    const uint32_t thr = m | paym;
+    uint32_t macc = 0u, bpay = 0u;
+#pragma unroll
+    for (int j = L - 1; j >= 0; --j) {
+      const bool t = r.c[j] <= thr;
+      macc |= t ? r.c[j] : 0u;
+      bpay = t ? r.c[j] : bpay;
+    }
+    r.bd = m & ~paym; r.macc = macc; r.bpay = bpay;
+    return;
+  }
   uint32_t bd = INF;
 #pragma unroll
   for (int j = 0; j < L; ++j) {
@@ -1654,6 +1677,56 @@ __global__ __launch_bounds__(256) void k_routes(uint32_t n, uint32_t n_roots, ui
   }
 }
 
+
+// HSPF_PFX_ORDERED: the order-dependent fold of update_rib_intra_area (holo-ospf/src/route.rs:343-448) over entries in
+// the reference's iteration order (OSPFv3: Intra-Area-Prefix-LSAs in LSDB order, ospfv3/spf.rs:421-478).  One thread per
+// (root, prefix) walks its entries once per mask word: the decisions do not depend on the masks, so word w > 0 simply
+// replays them.  State = the route so far: exists, metric, origin, owner entry (HSPF_PFX_KEPT_INIT: the route another
+// area left), union of the merged masks.
+__global__ __launch_bounds__(256) void k_routes_ordered(uint32_t n, uint32_t n_roots, uint32_t W, uint32_t n_pfx,
+                                                        const uint32_t *__restrict__ pfx_ptr,
+                                                        const uint32_t *__restrict__ pfx_vertex,
+                                                        const uint32_t *__restrict__ pfx_metric,
+                                                        const uint32_t *__restrict__ pfx_origin,
+                                                        const uint8_t *__restrict__ init_exists,
+                                                        const uint32_t *__restrict__ init_metric,
+                                                        const uint32_t *__restrict__ init_origin,
+                                                        const uint32_t *__restrict__ dist,
+                                                        const uint16_t *__restrict__ flags,
+                                                        const uint64_t *__restrict__ mask,
+                                                        uint32_t *__restrict__ best_metric,
+                                                        uint32_t *__restrict__ best_entry,
+                                                        uint64_t *__restrict__ nh_mask) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t r = blockIdx.y;
+  if (p >= n_pfx) return;
+  const uint32_t *D = dist + (size_t)r * n;
+  const uint16_t *F = flags + (size_t)r * n;
+  const uint64_t *M = mask + (size_t)r * n * W;
+  const uint32_t a = pfx_ptr[p], b = pfx_ptr[p + 1];
+  const bool ex0 = init_exists && init_exists[p] != 0;
+  const uint32_t bm0 = ex0 ? init_metric[p] : INF, bo0 = ex0 ? init_origin[p] : 0u;
+  const size_t o = (size_t)r * n_pfx + p;
+  for (uint32_t w = 0; w < W; ++w) {
+    bool exists = ex0;
+    uint32_t bm = bm0, bo = bo0, be = ex0 ? HSPF_PFX_KEPT_INIT : INF;
+    uint64_t acc = 0;
+    for (uint32_t e = a; e < b; ++e) {
+      const uint32_t pv = pfx_vertex[e], v = pv & 0x7FFFFFFFu;
+      if (!(F[v] & 1u)) continue;                          // `area.state.spt.get(&vid)`: vertex not in this root's SPT
+      const uint32_t m = add_sat(D[v], pfx_metric[e]);     // stub.vertex.distance.saturating_add(stub.metric), :362-366
+      if (exists && m > bm) continue;                      // :371-375
+      if ((pv & HSPF_PFX_ENTRY_NETWORK) && exists) {       // :388-400
+        if (m < bm || (m == bm && pfx_origin[e] > bo)) exists = false;
+        else continue;
+      }
+      if (!exists || m < bm) { exists = true; bm = m; bo = pfx_origin[e]; be = e; acc = M[(size_t)v * W + w]; }
+      else acc |= M[(size_t)v * W + w];                    // m == bm: merge (route_update, :918-965)
+    }
+    if (w == 0) { best_metric[o] = exists ? bm : INF; best_entry[o] = be; }
+    nh_mask[o * W + w] = acc;
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Ancestor sets over the SPT's parent DAG: what holo-isis answers with a stack DFS over

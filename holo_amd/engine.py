@@ -24,6 +24,9 @@ E_TOO_MANY_SLOTS = -5
 
 PFX_SATURATING = 0x1
 PFX_LAST_MIN = 0x2
+PFX_ORDERED = 0x4
+PFX_ENTRY_NETWORK = 0x80000000
+PFX_KEPT_INIT = 0xFFFFFFFE
 
 RF_IN_SPT = 0x0001
 RF_EXACT = 0x0002
@@ -261,13 +264,25 @@ class SpfContext:
 
     def routes_device(self, n_vertices: int, n_roots: int, mask_words: int, dist_ptr: int, flags_ptr: int,
                       mask_ptr: int, pfx_ptr, pfx_vertex, pfx_metric, *, best_metric_ptr: int,
-                      best_entry_ptr: int, nexthop_mask_ptr: int, flags: int = 0) -> None:
+                      best_entry_ptr: int, nexthop_mask_ptr: int, flags: int = 0, pfx_origin=None,
+                      init_exists=None, init_metric=None, init_origin=None) -> None:
         """hspf_routes_device(): prefix attachment for every root of a previous run_device(); all
-        `*_ptr` arguments are device pointers, the prefix table is host numpy."""
+        `*_ptr` arguments are device pointers, the prefix table is host numpy.  PFX_ORDERED tables also pass
+        pfx_origin (and, optionally, the per-prefix route an earlier area left: init_exists / init_metric / init_origin)."""
         pfx_ptr = np.ascontiguousarray(pfx_ptr, np.uint32)
         pfx_vertex = np.ascontiguousarray(pfx_vertex, np.uint32)
         pfx_metric = np.ascontiguousarray(pfx_metric, np.uint32)
-        t = L.HspfPrefixTable(len(pfx_ptr) - 1, len(pfx_vertex), _u32(pfx_ptr), _u32(pfx_vertex), _u32(pfx_metric), flags)
+        keep = []
+
+        def opt(a, dt, ptr_t):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dt)
+            keep.append(a)
+            return a.ctypes.data_as(ptr_t)
+        t = L.HspfPrefixTable(len(pfx_ptr) - 1, len(pfx_vertex), _u32(pfx_ptr), _u32(pfx_vertex), _u32(pfx_metric), flags,
+                              opt(pfx_origin, np.uint32, L.u32p), opt(init_exists, np.uint8, L.u8p),
+                              opt(init_metric, np.uint32, L.u32p), opt(init_origin, np.uint32, L.u32p))
         o = L.HspfRoutes(best_metric_ptr, best_entry_ptr, nexthop_mask_ptr)
         rc = self.lib.hspf_routes_device(self.handle, n_vertices, n_roots, mask_words, dist_ptr, flags_ptr, mask_ptr,
                                          ctypes.byref(t), ctypes.byref(o))

@@ -300,3 +300,133 @@ def ospf_intra_area_device_routes(router_id: str, areas: Sequence["O.Area"], max
     return [{"prefix": rib[k]["prefix"], "metric": rib[k]["metric"], "type": "intra-area",
              "nexthops": [[rib[k]["nexthops"][a][1], rib[k]["nexthops"][a][0]] for a in sorted(rib[k]["nexthops"])]}
             for k in sorted(rib)]
+
+
+# ---- OSPFv3: update_rib_intra_area with the ORDERED prefix fold on the GPU -------------------------------------------
+
+@dataclass
+class Ospfv3PrefixTable:
+    """CSR-by-prefix table of one OSPFv3 area (root independent) for HSPF_PFX_ORDERED: the stub networks as
+    `Ospfv3::intra_area_networks` yields them (holo-ospf/src/ospfv3/spf.rs:421-478) — Intra-Area-Prefix-LSAs in LSDB
+    order (adv_rtr, LS-ID), MaxAge skipped, the referenced vertex looked up by (ref type, ref LS-ID, ref adv_rtr),
+    NU-bit prefixes dropped — grouped by prefix, the reference's order kept inside a prefix.  Entries whose referenced
+    vertex is not in the graph at all can never be in an SPT and are left out."""
+    prefixes: List[str]
+    pfx_ptr: np.ndarray
+    pfx_vertex: np.ndarray            # vertex | PFX_ENTRY_NETWORK
+    pfx_metric: np.ndarray
+    pfx_origin: np.ndarray            # `stub.vertex.lsa.origin().lsa_id`
+
+    @classmethod
+    def build(cls, g) -> "Ospfv3PrefixTable":
+        from . import ospfv3 as V3
+        rows = []
+        for lsa in sorted(g.area.iaps, key=lambda l: (V3.ip(l.adv_rtr), l.lsa_id)):
+            if lsa.maxage:
+                continue
+            if lsa.ref_type == "ospfv3-router-lsa":
+                v = g.index.get((V3.RTR, V3.ip(lsa.ref_adv_rtr))) if lsa.ref_lsa_id == 0 else None
+            elif lsa.ref_type == "ospfv3-network-lsa":
+                v = g.index.get((V3.NET, V3.ip(lsa.ref_adv_rtr), lsa.ref_lsa_id))
+            else:
+                v = None
+            if v is None:
+                continue
+            is_net = g.vids[v][0] == V3.NET
+            vl = g.lsa_of(v)
+            origin = vl.lsa_id if is_net else vl[0].lsa_id
+            for p in lsa.prefixes:
+                if "nu-bit" in p["options"]:
+                    continue
+                rows.append((V3._net_key(p["prefix"]), p["prefix"], v | (E.PFX_ENTRY_NETWORK if is_net else 0), p["metric"], origin))
+        keys = sorted({r[0]: r[1] for r in rows}.items())
+        pid = {k: i for i, (k, _) in enumerate(keys)}
+        order = sorted(range(len(rows)), key=lambda i: (pid[rows[i][0]], i))          # stable: the reference's order
+        ptr = np.zeros(len(keys) + 1, np.uint64)
+        for r in rows:
+            ptr[pid[r[0]] + 1] += 1
+        return cls([p for _, p in keys], np.cumsum(ptr).astype(np.uint32),
+                   np.asarray([rows[i][2] for i in order], np.uint32), np.asarray([rows[i][3] for i in order], np.uint32),
+                   np.asarray([rows[i][4] for i in order], np.uint32))
+
+
+def ospfv3_area_device_routes(engine, g, root: int, table: Ospfv3PrefixTable, rib: dict, max_paths: int,
+                              device="cuda:0") -> None:
+    """run_area + update_rib_intra_area of one OSPFv3 area with the SPT and the ordered prefix fold on the device.  `rib`
+    is shared by the areas (holo-ospf/src/route.rs:146-160): what the earlier areas left for a prefix goes in as the
+    fold's initial state (init_*), so the result is the reference's sequential fold, not an approximation of it."""
+    import torch
+    from . import ospfv3 as V3
+    G = g.device(engine)
+    roots = np.asarray([root], np.uint32)
+    n, W = len(g.vids), G.mask_words(roots)
+    dev = torch.device(device)
+    dist = torch.empty((1, n), dtype=torch.int32, device=dev)
+    hops = torch.empty((1, n), dtype=torch.int16, device=dev)
+    flags = torch.empty((1, n), dtype=torch.int16, device=dev)
+    mask = torch.empty((1, n, W), dtype=torch.int64, device=dev)
+    stats = engine.run_device(G, roots, E.RUN_NET_NEXTHOPS, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(),
+                              flags_ptr=flags.data_ptr(), mask_ptr=mask.data_ptr(), mask_words=W)
+    P = len(table.prefixes)
+    if P == 0:
+        return
+    keys = [V3._net_key(p) for p in table.prefixes]
+    iex = np.asarray([1 if k in rib else 0 for k in keys], np.uint8)
+    imet = np.asarray([rib[k]["metric"] if k in rib else 0 for k in keys], np.uint32)
+    iorg = np.asarray([rib[k]["origin"] if k in rib else 0 for k in keys], np.uint32)
+    bm = torch.empty((1, P), dtype=torch.int32, device=dev)
+    be = torch.empty((1, P), dtype=torch.int32, device=dev)
+    nm = torch.empty((1, P, W), dtype=torch.int64, device=dev)
+    engine.routes_device(n, 1, W, dist.data_ptr(), flags.data_ptr(), mask.data_ptr(), table.pfx_ptr, table.pfx_vertex,
+                         table.pfx_metric, best_metric_ptr=bm.data_ptr(), best_entry_ptr=be.data_ptr(),
+                         nexthop_mask_ptr=nm.data_ptr(), flags=E.PFX_SATURATING | E.PFX_ORDERED, pfx_origin=table.pfx_origin,
+                         init_exists=iex, init_metric=imet, init_origin=iorg)
+    torch.cuda.synchronize(dev)
+    bm = bm.cpu().numpy().view(np.uint32)[0]; be = be.cpu().numpy().view(np.uint32)[0]; nm = nm.cpu().numpy().view(np.uint64)[0]
+    res = E.SpfResult(dist.cpu().numpy().view(np.uint32), hops.cpu().numpy().view(np.uint16),
+                      flags.cpu().numpy().view(np.uint16), mask.cpu().numpy().view(np.uint64), None, stats)
+    slot_nh: dict = {}
+    O.spt_from_engine(g, root, engine, V3.calc_nexthops, res=res, slots_out=slot_nh)
+
+    def expand(mrow) -> dict:
+        nhs = {}
+        for w in range(len(mrow)):
+            m = int(mrow[w])
+            while m:
+                b = (m & -m).bit_length() - 1
+                m &= m - 1
+                nh = slot_nh.get(w * 64 + b)
+                if nh:
+                    nhs.update(nh)
+        return nhs
+
+    for p, prefix in enumerate(table.prefixes):
+        key = keys[p]
+        if be[p] == 0xFFFFFFFF:
+            continue                                        # no entry in the SPT, nothing in the RIB
+        if be[p] == E.PFX_KEPT_INIT:
+            cur = rib[key]
+            cur["nexthops"].update(expand(nm[p]))           # equal-cost entries of this area merged into the earlier route
+        else:
+            cur = rib[key] = {"prefix": prefix, "metric": int(bm[p]), "origin": int(table.pfx_origin[be[p]]),
+                              "nexthops": expand(nm[p])}
+        if len(cur["nexthops"]) > max_paths:
+            cur["nexthops"] = {k: cur["nexthops"][k] for k in sorted(cur["nexthops"])[:max_paths]}
+
+
+def ospfv3_intra_area_device_routes(router_id: str, areas, max_paths: int, engine, af: str = "ipv6",
+                                    device="cuda:0") -> List[dict]:
+    """holo_amd.ospfv3.compute_spf_intra_area with SPT and prefix attachment on the GPU; same rows."""
+    from . import ospfv3 as V3
+    rib: dict = {}
+    for area in sorted(areas, key=lambda a: V3.ip(a.area_id)):
+        g = V3.AreaGraph3(area, af)
+        root = g.index.get((V3.RTR, V3.ip(router_id)))
+        if root is None:
+            continue
+        ospfv3_area_device_routes(engine, g, root, Ospfv3PrefixTable.build(g), rib, max_paths, device)
+        if g._dev is not None:
+            g._dev[1].free()
+    return [{"prefix": rib[k]["prefix"], "metric": rib[k]["metric"], "type": "intra-area",
+             "nexthops": [[rib[k]["nexthops"][a][1], rib[k]["nexthops"][a][0]] for a in sorted(rib[k]["nexthops"])]}
+            for k in sorted(rib)]

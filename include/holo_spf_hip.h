@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define HSPF_ABI_VERSION 3u
+#define HSPF_ABI_VERSION 4u
 
 /* ---- error codes ------------------------------------------------------------------- */
 #define HSPF_OK                 0
@@ -270,13 +270,37 @@ int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out);
  */
 #define HSPF_PFX_SATURATING 0x1u
 #define HSPF_PFX_LAST_MIN   0x2u
+/*
+ *   HSPF_PFX_ORDERED      the literal, ORDER-DEPENDENT fold of update_rib_intra_area (route.rs:343-448) for tables
+ *                         whose entries do not come in vertex order: OSPFv3 reads its stub networks off the
+ *                         Intra-Area-Prefix-LSAs in LSDB order (holo-ospf/src/ospfv3/spf.rs:421-478), router and
+ *                         network vertices interleaved.  The entries of a prefix are listed in the reference's
+ *                         iteration order; bit 31 of pfx_vertex (HSPF_PFX_ENTRY_NETWORK) marks an entry whose vertex
+ *                         is a network, pfx_origin[e] is the Link State ID of that vertex's LSA (`stub.vertex.lsa
+ *                         .origin().lsa_id`); metrics add saturating.  Per entry, as the reference: worse than the
+ *                         route so far -> skipped (:371-375); a network entry meeting a route replaces it when shorter
+ *                         or equal with a GREATER origin and is skipped otherwise (:388-400); then route_update
+ *                         (:918-965): better replaces, equal merges the next hops.  init_* (optional, [n_prefixes],
+ *                         the same for every root): the route an earlier area left in the RIB for that prefix
+ *                         (the RIB is shared by the areas, route.rs:146-160) — init_exists[p] != 0, its metric and
+ *                         origin; best_entry == HSPF_PFX_KEPT_INIT then says that this route still owns the prefix
+ *                         and nexthop_mask holds what the table's entries merged INTO it.
+ */
+#define HSPF_PFX_ORDERED    0x4u
+#define HSPF_PFX_ENTRY_NETWORK 0x80000000u
+#define HSPF_PFX_KEPT_INIT  0xFFFFFFFEu
 typedef struct {
   uint32_t        n_prefixes;
   uint32_t        n_entries;
   const uint32_t *pfx_ptr;      /* [n_prefixes+1]                                                */
-  const uint32_t *pfx_vertex;   /* [n_entries] advertising vertex                                */
+  const uint32_t *pfx_vertex;   /* [n_entries] advertising vertex (| HSPF_PFX_ENTRY_NETWORK with HSPF_PFX_ORDERED) */
   const uint32_t *pfx_metric;   /* [n_entries] advertised metric                                 */
   uint32_t        flags;        /* HSPF_PFX_*; 0 = the IS-IS rule                                */
+  /* HSPF_PFX_ORDERED only (ABI 4; NULL otherwise): */
+  const uint32_t *pfx_origin;   /* [n_entries]  Link State ID of the entry's vertex LSA          */
+  const uint8_t  *init_exists;  /* [n_prefixes] or NULL                                          */
+  const uint32_t *init_metric;  /* [n_prefixes] or NULL                                          */
+  const uint32_t *init_origin;  /* [n_prefixes] or NULL                                          */
 } hspf_prefix_table;
 
 typedef struct {

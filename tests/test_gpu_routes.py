@@ -149,3 +149,96 @@ def test_device_routes_ospf_rules_many_roots_vs_restatement(spf_ctx, seed, mode)
                 elif m == best:
                     acc |= ref.mask[r, v]
             assert bm[r, p] == best and be[r, p] == ent and np.array_equal(nm[r, p], acc), (r, p)
+
+
+# ---- OSPFv3: the ordered fold of update_rib_intra_area on device (HSPF_PFX_ORDERED) -----------------------------------
+from holo_amd import ospfv3 as H3            # noqa: E402
+from oracle import ospfv3_ref as R3          # noqa: E402
+from _random_ospfv3 import make as make_v3   # noqa: E402
+
+OSPF3 = sorted(glob.glob(os.path.join(GOLD, "ospfv3", "*.json")))
+
+
+@pytest.mark.parametrize("path", OSPF3, ids=[os.path.basename(p)[:-5] for p in OSPF3])
+def test_ospfv3_device_routes_reproduce_reference_intra_area_rib(spf_ctx, path):
+    vec = json.load(open(path))
+    areas = [H3.Area3.from_vector(a) for a in vec["areas"]]
+    got = RT.ospfv3_intra_area_device_routes(vec["router_id"], areas, vec["max_paths"], spf_ctx, vec["af"])
+    assert got == R3.intra_area_rib(vec)                                   # literal restatement, every vector
+    if not vec["has_vlinks"]:                                              # the reference's own recorded answer
+        want = sorted([r for r in vec["rib"] if r["type"] == "intra-area"], key=lambda r: R3._net_key(r["prefix"]))
+        assert got == want
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_ospfv3_device_routes_random_areas(spf_ctx, block):
+    for seed in range(block * 20, block * 20 + 20):
+        vec = make_v3(seed)
+        areas = [H3.Area3.from_vector(a) for a in vec["areas"]]
+        got = RT.ospfv3_intra_area_device_routes(vec["router_id"], areas, vec["max_paths"], spf_ctx, vec["af"])
+        assert got == R3.intra_area_rib(vec), seed
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_device_routes_ordered_fold_many_roots_vs_restatement(spf_ctx, seed):
+    """holo-ospf/src/route.rs:343-448 restated entry by entry on the oracle's SPT tables: entries in arbitrary (not
+    vertex) order, network entries with the greater-origin rule, an initial route per prefix for a third of the
+    prefixes, metrics that saturate."""
+    import torch
+    rng = np.random.default_rng(70 + seed)
+    g = synth.random_lsdb(120, 12, 3.0, 950 + seed, metric_hi=4, max_path=0xFFFFFFFF)
+    n = g.n
+    roots = np.arange(12, 12 + 70, dtype=np.uint32)
+    P, n_e = 300, 900
+    pfx = np.sort(rng.integers(0, P, n_e))
+    vtx = rng.integers(0, n, n_e).astype(np.uint32)
+    isnet = rng.random(n_e) < 0.4
+    met = rng.integers(0, 3, n_e).astype(np.uint32)
+    big = rng.random(n_e) < 0.05
+    met[big] = (0xFFFFFFFF - rng.integers(0, 6, int(big.sum()))).astype(np.uint32)
+    org = rng.integers(0, 6, n_e).astype(np.uint32)
+    ptr = np.zeros(P + 1, np.uint32)
+    np.add.at(ptr, pfx + 1, 1)
+    ptr = np.cumsum(ptr, dtype=np.uint64).astype(np.uint32)
+    iex = (rng.random(P) < 0.33).astype(np.uint8)
+    imet = rng.integers(0, 12, P).astype(np.uint32)
+    iorg = rng.integers(0, 6, P).astype(np.uint32)
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, E.RUN_NET_NEXTHOPS, go.HEAP)
+    W = ref.mask.shape[2]
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    dev = torch.device("cuda:0")
+    Rn = len(roots)
+    dist = torch.empty((Rn, n), dtype=torch.int32, device=dev); hops = torch.empty((Rn, n), dtype=torch.int16, device=dev)
+    flags = torch.empty((Rn, n), dtype=torch.int16, device=dev); mask = torch.empty((Rn, n, W), dtype=torch.int64, device=dev)
+    spf_ctx.run_device(G, roots, E.RUN_NET_NEXTHOPS, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(),
+                       flags_ptr=flags.data_ptr(), mask_ptr=mask.data_ptr(), mask_words=W)
+    bm = torch.empty((Rn, P), dtype=torch.int32, device=dev); be = torch.empty((Rn, P), dtype=torch.int32, device=dev)
+    nm = torch.empty((Rn, P, W), dtype=torch.int64, device=dev)
+    pv = vtx | np.where(isnet, E.PFX_ENTRY_NETWORK, 0).astype(np.uint32)
+    spf_ctx.routes_device(n, Rn, W, dist.data_ptr(), flags.data_ptr(), mask.data_ptr(), ptr, pv, met,
+                          best_metric_ptr=bm.data_ptr(), best_entry_ptr=be.data_ptr(), nexthop_mask_ptr=nm.data_ptr(),
+                          flags=E.PFX_SATURATING | E.PFX_ORDERED, pfx_origin=org, init_exists=iex, init_metric=imet, init_origin=iorg)
+    torch.cuda.synchronize()
+    G.free()
+    bm = bm.cpu().numpy().view(np.uint32); be = be.cpu().numpy().view(np.uint32); nm = nm.cpu().numpy().view(np.uint64)
+    for r in range(Rn):
+        for p in range(P):
+            exists = bool(iex[p])
+            best, bo, ent, acc = (int(imet[p]), int(iorg[p]), E.PFX_KEPT_INIT, np.zeros(W, np.uint64)) if exists else (0xFFFFFFFF, 0, 0xFFFFFFFF, np.zeros(W, np.uint64))
+            for e in range(ptr[p], ptr[p + 1]):
+                v = vtx[e]
+                if not ref.flags[r, v]:
+                    continue
+                m = min(int(ref.dist[r, v]) + int(met[e]), 0xFFFFFFFF)
+                if exists and m > best:
+                    continue
+                if isnet[e] and exists:
+                    if m < best or (m == best and int(org[e]) > bo):
+                        exists = False
+                    else:
+                        continue
+                if not exists or m < best:
+                    exists, best, bo, ent, acc = True, m, int(org[e]), e, ref.mask[r, v].copy()
+                else:
+                    acc = acc | ref.mask[r, v]
+            assert bm[r, p] == (best if exists else 0xFFFFFFFF) and be[r, p] == ent and np.array_equal(nm[r, p], acc), (r, p)
