@@ -92,6 +92,9 @@ SYMBOLS = [
     ("hspf_routes_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.POINTER(HspfPrefixTable), ctypes.POINTER(HspfRoutes)]),
+    ("hspf_routes_diff_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                               ctypes.POINTER(HspfRoutes), ctypes.POINTER(HspfRoutes),
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     ("hspf_ancestors_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -245,11 +245,11 @@ kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__r
 // Work-balanced XCD ranges (GraphDev::xcd_start): cost of a 16-vertex chunk prefix k = in-links of the first 16k
 // vertices + 8 per vertex (a row costs about 8 links' worth of fixed work); XCD x starts at the first chunk whose
 // prefix reaches x/8 of the total.  Seven binary searches, one thread each.
-__global__ void kb_xcd(uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *__restrict__ info) {
+__global__ void kb_xcd(uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *__restrict__ info, uint32_t row_cost) {
   const uint32_t x = threadIdx.x;
   if (x > 8u) return;
   const uint32_t nb = (n + 15u) / 16u;
-  auto cost = [&](uint32_t k) -> uint64_t { const uint32_t v = min(k * 16u, n); return (uint64_t)in_ptr[v] + 8ull * v; };
+  auto cost = [&](uint32_t k) -> uint64_t { const uint32_t v = min(k * 16u, n); return (uint64_t)in_ptr[v] + (uint64_t)row_cost * v; };
   const uint64_t total = cost(nb), want = total * x / 8ull;
   uint32_t lo = 0, hi = nb;                       // smallest k with cost(k) >= want
   while (lo < hi) {

@@ -112,6 +112,7 @@ struct hspf_ctx {
   uint32_t lv_max_roots = 2;               // HSPF_LV_MAX_ROOTS env: runs of at most this many roots take the lane = vertex kernel (0: never)
   uint32_t lv_min_n = 32768;               // HSPF_LV_MIN_N env: ... on graphs of at least this many vertices
   uint32_t est_lv = 24;
+  uint32_t xcd_row_cost = 8;               // HSPF_XCD_ROW_COST env: fixed cost of a row, in links, when the XCD ranges are cut
   hspf_stats stats = {};
 };
 
@@ -268,7 +269,7 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   }
   hipLaunchKernelGGL(kb_rowflags, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
                      (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info);
-  hipLaunchKernelGGL(kb_xcd, dim3(1), dim3(64), 0, s, n, (const uint32_t *)g->d_in_ptr, info);
+  hipLaunchKernelGGL(kb_xcd, dim3(1), dim3(64), 0, s, n, (const uint32_t *)g->d_in_ptr, info, ctx->xcd_row_cost);
   hipLaunchKernelGGL(kb_pads, dim3(1), dim3(64), 0, s, n, (const BuildInfo *)info, g->d_in_ptr, g->d_out_ptr,
                      g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos);
   HIPCHK(ctx, hipGetLastError());
@@ -350,6 +351,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   if (const char *v = getenv("HSPF_SINGLE_MAX_N")) ctx->single_max_n = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_LV_MAX_ROOTS")) ctx->lv_max_roots = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_LV_MIN_N")) ctx->lv_min_n = (uint32_t)strtoul(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_XCD_ROW_COST")) ctx->xcd_row_cost = (uint32_t)strtoul(v, nullptr, 0);
   if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return HSPF_E_NODEV; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
   for (auto &e : ctx->ev)
@@ -1350,6 +1352,37 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
   HIPCHK(ctx, hipStreamSynchronize(s));       // the table was read from caller-owned host memory
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { ctx->last_error = std::string("k_routes: ") + hipGetErrorString(le); return HSPF_E_HIP; }
+  return HSPF_OK;
+}
+
+int hspf_routes_diff_device(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes, uint32_t n_mask_words,
+                            const hspf_routes *old_dev, const hspf_routes *new_dev,
+                            uint8_t *action_dev, uint32_t *changed_dev, uint32_t *changed_ptr_dev) {
+  if (!ctx || !old_dev || !new_dev || !action_dev || !changed_dev || !changed_ptr_dev || n_roots == 0 || n_mask_words == 0 ||
+      !old_dev->best_metric || !old_dev->best_entry || !old_dev->nexthop_mask ||
+      !new_dev->best_metric || !new_dev->best_entry || !new_dev->nexthop_mask)
+    return HSPF_E_INVAL;
+  const uint64_t count64 = (uint64_t)n_roots * n_prefixes;
+  if (count64 >= 0xFFFFFFF0ull) { ctx->last_error = "hspf_routes_diff_device: more than 2^32 (root, prefix) pairs"; return HSPF_E_INVAL; }
+  (void)hipSetDevice(ctx->device);
+  hipStream_t s = ctx->stream;
+  const uint32_t count = (uint32_t)count64;
+  // scratch: pos[count + 1] | sums | flag[count] (u8)
+  const size_t nsums = (size_t)count / GB_TILE + 4;
+  int rc = ensure(ctx, ctx->gb, ((size_t)count + 1 + nsums) * 4 + count + 64);
+  if (rc) return rc;
+  uint32_t *pos = (uint32_t *)ctx->gb.p, *sums = pos + count + 1;
+  uint8_t *flag = (uint8_t *)(sums + nsums);
+  const dim3 grid((unsigned)(((size_t)count + 1 + 255) / 256));
+  if (count)
+    hipLaunchKernelGGL(k_routes_diff, grid, dim3(256), 0, s, (size_t)count, n_mask_words, old_dev->best_metric, old_dev->best_entry,
+                       old_dev->nexthop_mask, new_dev->best_metric, new_dev->best_entry, new_dev->nexthop_mask, action_dev, flag);
+  gb_scan<uint8_t>(s, flag, count, pos, sums);
+  hipLaunchKernelGGL(k_routes_diff_scatter, dim3((unsigned)(((size_t)std::max(count, n_roots + 1) + 255) / 256)), dim3(256), 0, s,
+                     (size_t)count, n_prefixes, n_roots, (const uint8_t *)flag, (const uint32_t *)pos, changed_dev, changed_ptr_dev);
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  hipError_t le = hipGetLastError();
+  if (le != hipSuccess) { ctx->last_error = std::string("k_routes_diff: ") + hipGetErrorString(le); return HSPF_E_HIP; }
   return HSPF_OK;
 }
 

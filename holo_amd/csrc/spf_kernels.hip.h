@@ -1728,6 +1728,40 @@ __global__ __launch_bounds__(256) void k_routes_ordered(uint32_t n, uint32_t n_r
   }
 }
 
+// RIB diff: update_global_rib's comparison (holo-isis/src/route.rs:254-312) on two result sets of
+// k_routes.  One thread per (root, prefix); HBM bound: 2 x (8 + 8W) bytes read, 1 + 1 written per pair.
+__global__ __launch_bounds__(256) void k_routes_diff(size_t count, uint32_t W,
+                                                     const uint32_t *__restrict__ om, const uint32_t *__restrict__ oe,
+                                                     const uint64_t *__restrict__ on,
+                                                     const uint32_t *__restrict__ nm, const uint32_t *__restrict__ ne,
+                                                     const uint64_t *__restrict__ nn,
+                                                     uint8_t *__restrict__ action, uint8_t *__restrict__ flag) {
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= count) return;
+  const bool had = oe[i] != INF, has = ne[i] != INF;
+  bool same_nh = true, old_nh = false, new_nh = false;
+  for (uint32_t w = 0; w < W; ++w) {
+    const uint64_t a = on[i * W + w], b = nn[i * W + w];
+    same_nh = same_nh && a == b;
+    old_nh = old_nh || a != 0ull;
+    new_nh = new_nh || b != 0ull;
+  }
+  uint32_t act;
+  if (has) act = (had && om[i] == nm[i] && same_nh) ? HSPF_DIFF_SAME : (new_nh ? HSPF_DIFF_INSTALL : HSPF_DIFF_SILENT);
+  else act = had ? (old_nh ? HSPF_DIFF_WITHDRAW : HSPF_DIFF_SILENT) : HSPF_DIFF_SAME;
+  action[i] = (uint8_t)act;
+  flag[i] = (act == HSPF_DIFF_INSTALL || act == HSPF_DIFF_WITHDRAW) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_routes_diff_scatter(size_t count, uint32_t n_pfx, uint32_t n_roots,
+                                                             const uint8_t *__restrict__ flag, const uint32_t *__restrict__ pos,
+                                                             uint32_t *__restrict__ changed, uint32_t *__restrict__ changed_ptr) {
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (i <= n_roots) changed_ptr[i] = pos[i * (size_t)n_pfx];       // pos[count] = total
+  if (i >= count) return;
+  if (flag[i]) changed[pos[i]] = (uint32_t)(i % n_pfx);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Ancestor sets over the SPT's parent DAG: what holo-isis answers with a stack DFS over
 // `Vertex.parents` (Spt::is_on_path, holo-isis/src/spf.rs:261-286) for flooding::manet::reflood_list

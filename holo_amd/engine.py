@@ -27,6 +27,7 @@ PFX_LAST_MIN = 0x2
 PFX_ORDERED = 0x4
 PFX_ENTRY_NETWORK = 0x80000000
 PFX_KEPT_INIT = 0xFFFFFFFE
+DIFF_SAME, DIFF_INSTALL, DIFF_WITHDRAW, DIFF_SILENT = 0, 1, 2, 3
 
 RF_IN_SPT = 0x0001
 RF_EXACT = 0x0002
@@ -288,6 +289,16 @@ class SpfContext:
                                          ctypes.byref(t), ctypes.byref(o))
         if rc != 0:
             raise HspfError(rc, "hspf_routes_device", self.last_error())
+
+    def routes_diff_device(self, n_roots: int, n_prefixes: int, mask_words: int, old: tuple, new: tuple, *,
+                           action_ptr: int, changed_ptr: int, changed_ptr_ptr: int) -> None:
+        """hspf_routes_diff_device(): old / new = (best_metric_ptr, best_entry_ptr, nexthop_mask_ptr) of two
+        hspf_routes_device() result sets over the same prefix list; all device pointers."""
+        o, n = L.HspfRoutes(*old), L.HspfRoutes(*new)
+        rc = self.lib.hspf_routes_diff_device(self.handle, n_roots, n_prefixes, mask_words, ctypes.byref(o), ctypes.byref(n),
+                                              action_ptr, changed_ptr, changed_ptr_ptr)
+        if rc != 0:
+            raise HspfError(rc, "hspf_routes_diff_device", self.last_error())
 
     def close(self):
         if self.handle:

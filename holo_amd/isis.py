@@ -959,3 +959,31 @@ def compute_spf(instance: Instance, engine, cache: Optional[GraphCache] = None,
         rows.append({"prefix": r.prefix, "metric": r.metric, "level": r.level,
                      "nexthops": [[r.nexthops[k][0], r.nexthops[k][1]] for k in sorted(r.nexthops)]})
     return rows
+
+
+# ---- the wire step after the path: update_global_rib, holo-isis/src/route.rs:254-312 ------------------
+
+def update_global_rib(new_rows: List[dict], old_rows: List[dict], ifindex: Dict[str, int],
+                      unchanged: Optional[Iterable[str]] = None) -> List[dict]:
+    """The RouteIpAdd / RouteIpDel messages a new local RIB puts on the ibus, in emission order (rows as compute_spf
+    returns them).  `unchanged`: prefixes a device-side diff (hspf_routes_diff_device through holo_amd.routes) has already
+    found identical — they are skipped without comparing next hops on the host; everything else is compared here.
+    Same rules as the reference: unchanged routes are not re-sent (:268-277), CONNECTED / next-hop-less routes are not
+    installed (:283-287), old routes that were installed and are gone are withdrawn (:303-310)."""
+    import ipaddress
+    skip = set(unchanged or ())
+    old = {_net_key(r["prefix"]): r for r in old_rows}
+    msgs: List[dict] = []
+    for r in sorted(new_rows, key=lambda r: _net_key(r["prefix"])):
+        o = old.pop(_net_key(r["prefix"]), None)
+        if o is not None and (r["prefix"] in skip or (o["metric"] == r["metric"]
+                              and sorted(map(tuple, o["nexthops"])) == sorted(map(tuple, r["nexthops"])))):
+            continue
+        if r["nexthops"]:
+            nhs = sorted(((ifindex[ifname], addr) for addr, ifname in r["nexthops"]),
+                         key=lambda t: (t[0], ipaddress.ip_address(t[1]).version, int(ipaddress.ip_address(t[1]))))
+            msgs.append({"op": "add", "prefix": r["prefix"], "metric": r["metric"], "nexthops": [list(t) for t in nhs]})
+    for k in sorted(old):
+        if old[k]["nexthops"]:
+            msgs.append({"op": "del", "prefix": old[k]["prefix"]})
+    return msgs

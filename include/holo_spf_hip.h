@@ -316,6 +316,32 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
                        const uint32_t *dist_dev, const uint16_t *flags_dev, const uint64_t *mask_dev,
                        const hspf_prefix_table *table, hspf_routes *out_dev);
 
+/* ---- RIB diff on device (the first half of the wire step after the path) -------------------------
+ * update_global_rib (holo-isis/src/route.rs:254-312, holo-ospf/src/route.rs:856-916) walks the new RIB, skips every route
+ * whose metric and next hops are what the old RIB held, sends a RouteIpAdd for the rest and a RouteIpDel for what
+ * vanished — per-route host work and messages that dominate once an LSDB carries 100 k+ prefixes.  On
+ * the tables hspf_routes_device() writes, that comparison is "same best_metric and same nexthop_mask": this call does it
+ * for every (root, prefix) of two such result sets in HBM and compacts the indices that need a message.
+ * PRECONDITION (the caller's): both sets index the same prefix list, and a first-hop slot means the same next hop in both
+ * runs (the rows of the root and of its hops-0 networks did not change) — otherwise compare on the host.
+ *   action[r][p]   HSPF_DIFF_SAME      nothing to send (:268-277)
+ *                  HSPF_DIFF_INSTALL   new or changed, and the new route has next hops: RouteIpAdd (:283-295)
+ *                  HSPF_DIFF_WITHDRAW  the old route had next hops (was installed) and the prefix has no route any
+ *                                      more: RouteIpDel (:303-310)
+ *                  HSPF_DIFF_SILENT    changed, but nothing goes on the wire (a route without next hops: CONNECTED, or
+ *                                      unresolved next hops)
+ *   changed / changed_ptr   per root r the prefix indices with INSTALL or WITHDRAW, ascending (the reference's emission
+ *                  order is the prefix order): changed[changed_ptr[r] .. changed_ptr[r+1]); changed has room for
+ *                  n_roots * n_prefixes entries.  All pointers are DEVICE pointers.
+ */
+#define HSPF_DIFF_SAME     0u
+#define HSPF_DIFF_INSTALL  1u
+#define HSPF_DIFF_WITHDRAW 2u
+#define HSPF_DIFF_SILENT   3u
+int hspf_routes_diff_device(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes, uint32_t n_mask_words,
+                            const hspf_routes *old_dev, const hspf_routes *new_dev,
+                            uint8_t *action_dev, uint32_t *changed_dev, uint32_t *changed_ptr_dev);
+
 /* ---- ancestor sets on device (the queries of flooding::manet::reflood_list) ------------------------
  * For every root of a previous hspf_run_device() and a level L (1 = first hops / remote-neighbour list, 2 = second
  * hops): the root's level-L routers = router vertices of its SPT with hops == L, numbered in ascending vertex index

@@ -411,3 +411,31 @@ def reflood_list(vec, level, local_system_id, tn, lsp_id, algo_of=None):
             continue
         thl = [t for t in thl if not _is_on_path(spt, sid, t)]
     return sorted(out)
+
+
+# ---- the wire step after the path: update_global_rib (holo-isis/src/route.rs:254-312) --------------------------------
+
+def update_global_rib(new_rows, old_rows, ifindex):
+    """route.rs:254-312 + ibus::tx::route_install / route_uninstall (holo-isis/src/ibus/tx.rs:35-110), on rows of the
+    YANG `local-rib` list (what local_rib() returns): for every route of the new RIB in BTreeMap<IpNetwork, _> order —
+    drop the prefix from the old RIB; unchanged (metric and next hops; `tag` is never set on this path) -> nothing;
+    otherwise, unless CONNECTED or without next hops, a RouteIpAdd carrying the next hops as a
+    BTreeSet<Nexthop::Address{ifindex, addr, labels}>; then a RouteIpDel for every INSTALLED route left in the old RIB.
+    A row without next hops stands for a CONNECTED route (its vertex has hops == 0 and therefore no next hops) or for
+    one whose next hops failed to resolve: neither is installed (:283-287).  Summary routes (RouteFlags::SUMMARY,
+    configuration, not SPF output) are not modelled.  Returns the message list in emission order."""
+    import ipaddress
+    old = {_net_key(r["prefix"]): r for r in old_rows}
+    msgs = []
+    for r in sorted(new_rows, key=lambda r: _net_key(r["prefix"])):
+        o = old.pop(_net_key(r["prefix"]), None)
+        if o is not None and o["metric"] == r["metric"] and sorted(map(tuple, o["nexthops"])) == sorted(map(tuple, r["nexthops"])):
+            continue                                           # :268-277
+        if r["nexthops"]:                                      # :283-295
+            nhs = sorted(((ifindex[ifname], addr) for addr, ifname in r["nexthops"]),
+                         key=lambda t: (t[0], ipaddress.ip_address(t[1]).version, int(ipaddress.ip_address(t[1]))))
+            msgs.append({"op": "add", "prefix": r["prefix"], "metric": r["metric"], "nexthops": [list(t) for t in nhs]})
+    for k in sorted(old):                                      # :303-310: INSTALLED = it had been installed with next hops
+        if old[k]["nexthops"]:
+            msgs.append({"op": "del", "prefix": old[k]["prefix"]})
+    return msgs

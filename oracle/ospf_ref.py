@@ -219,3 +219,34 @@ def intra_area_rib(vec: dict):
         nhs = [[r["nexthops"][k][1], r["nexthops"][k][0]] for k in sorted(r["nexthops"])]
         rows.append({"prefix": r["prefix"], "metric": r["metric"], "type": "intra-area", "nexthops": nhs})
     return rows
+
+
+# ---- the wire step after the path: update_global_rib (holo-ospf/src/route.rs:856-916) --------------------------------
+
+def update_global_rib(new_rows, old_rows, ifindex):
+    """route.rs:856-916 + ibus::tx::route_install / route_uninstall (holo-ospf/src/ibus/tx.rs:32-77), on rows of the YANG
+    `local-rib` list (all route types: the diff does not look at them).  For every route of the new RIB in
+    BTreeMap<IpNetwork, _> order: drop the prefix from the old RIB; same metric and next hops (`tag` / `sr_label` are
+    not set on this path) -> nothing; else, unless CONNECTED or without next hops, a RouteIpAdd with the next hops as
+    a BTreeSet of Nexthop::Address{ifindex, addr}; finally a RouteIpDel for every INSTALLED route left in the old RIB.
+    The rows do not carry the flags: a route is CONNECTED iff none of its next hops has an address (the vertex is a
+    hops-0 network, `Ospfv2::calc_nexthops` gives (iface, None), ospfv2/spf.rs:296-302), INSTALLED iff it is not
+    CONNECTED and has next hops (:887-899).  Returns the message list in emission order."""
+    import ipaddress
+
+    def installable(r):
+        return any(a is not None for a, _ in r["nexthops"])
+    old = {_net_key(r["prefix"]): r for r in old_rows}
+    msgs = []
+    for r in sorted(new_rows, key=lambda r: _net_key(r["prefix"])):
+        o = old.pop(_net_key(r["prefix"]), None)
+        if o is not None and o["metric"] == r["metric"] and sorted(map(str, o["nexthops"])) == sorted(map(str, r["nexthops"])):
+            continue                                           # :875-885
+        if installable(r):                                     # :890-901
+            nhs = sorted(((ifindex[ifname], addr) for addr, ifname in r["nexthops"]),
+                         key=lambda t: (t[0], int(ipaddress.ip_address(t[1]))))
+            msgs.append({"op": "add", "prefix": r["prefix"], "metric": r["metric"], "nexthops": [list(t) for t in nhs]})
+    for k in sorted(old):                                      # :908-914
+        if installable(old[k]):
+            msgs.append({"op": "del", "prefix": old[k]["prefix"]})
+    return msgs

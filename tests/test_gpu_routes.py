@@ -242,3 +242,72 @@ def test_device_routes_ordered_fold_many_roots_vs_restatement(spf_ctx, seed):
                 else:
                     acc = acc | ref.mask[r, v]
             assert bm[r, p] == (best if exists else 0xFFFFFFFF) and be[r, p] == ent and np.array_equal(nm[r, p], acc), (r, p)
+
+
+# ---- the wire step after the path: RIB diff on device (hspf_routes_diff_device) ---------------------
+
+@pytest.mark.parametrize("seed", range(3))
+def test_routes_diff_device_vs_restatement(spf_ctx, seed):
+    """update_global_rib's comparison (holo-isis/src/route.rs:254-312) per (root, prefix) on two result sets of
+    hspf_routes_device: the SPTs of 70 roots before and after a handful of link costs changed (same prefix table, the
+    roots' own rows untouched), against a per-pair restatement; the compacted index lists are ascending per root."""
+    import torch
+    rng = np.random.default_rng(90 + seed)
+    g = synth.random_lsdb(150, 10, 3.0, 990 + seed, metric_hi=5)
+    n = g.n
+    roots = np.arange(10, 10 + 70, dtype=np.uint32)
+    P, n_e = 400, 900
+    pfx = np.sort(rng.integers(0, P, n_e))
+    vtx = rng.integers(0, n, n_e)
+    order = np.lexsort((vtx, pfx))
+    pfx, vtx = pfx[order], vtx[order].astype(np.uint32)
+    met = rng.integers(0, 4, n_e).astype(np.uint32)
+    ptr = np.zeros(P + 1, np.uint32)
+    np.add.at(ptr, pfx + 1, 1)
+    ptr = np.cumsum(ptr, dtype=np.uint64).astype(np.uint32)
+    m2 = g.metric.copy()
+    rp = g.row_ptr.astype(np.int64)
+    far = np.nonzero(np.repeat(np.arange(n), np.diff(rp)) >= 90)[0]           # rows of non-root vertices only
+    pick = rng.choice(far, size=12, replace=False)
+    m2[pick] = m2[pick] + rng.integers(1, 4, 12).astype(np.uint32)
+    dev = torch.device("cuda:0")
+    Rn = len(roots)
+    sets, refs = [], []
+    for metric in (g.metric, m2):
+        G = spf_ctx.upload(g.row_ptr, g.col, metric, g.vflags, g.max_path_metric)
+        W = G.mask_words(roots)
+        dist = torch.empty((Rn, n), dtype=torch.int32, device=dev); hops = torch.empty((Rn, n), dtype=torch.int16, device=dev)
+        flags = torch.empty((Rn, n), dtype=torch.int16, device=dev); mask = torch.empty((Rn, n, W), dtype=torch.int64, device=dev)
+        spf_ctx.run_device(G, roots, 0, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(), flags_ptr=flags.data_ptr(),
+                           mask_ptr=mask.data_ptr(), mask_words=W)
+        bm = torch.empty((Rn, P), dtype=torch.int32, device=dev); be = torch.empty((Rn, P), dtype=torch.int32, device=dev)
+        nm = torch.empty((Rn, P, W), dtype=torch.int64, device=dev)
+        spf_ctx.routes_device(n, Rn, W, dist.data_ptr(), flags.data_ptr(), mask.data_ptr(), ptr, vtx, met,
+                              best_metric_ptr=bm.data_ptr(), best_entry_ptr=be.data_ptr(), nexthop_mask_ptr=nm.data_ptr())
+        G.free()
+        sets.append((bm, be, nm))
+        refs.append((bm.cpu().numpy().view(np.uint32), be.cpu().numpy().view(np.uint32), nm.cpu().numpy().view(np.uint64)))
+    act = torch.empty((Rn, P), dtype=torch.uint8, device=dev)
+    chg = torch.empty((Rn * P,), dtype=torch.int32, device=dev)
+    cptr = torch.empty((Rn + 1,), dtype=torch.int32, device=dev)
+    spf_ctx.routes_diff_device(Rn, P, W, tuple(t.data_ptr() for t in sets[0]), tuple(t.data_ptr() for t in sets[1]),
+                               action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(), changed_ptr_ptr=cptr.data_ptr())
+    torch.cuda.synchronize()
+    act = act.cpu().numpy(); chg = chg.cpu().numpy().view(np.uint32); cptr = cptr.cpu().numpy().view(np.uint32)
+    (om, oe, on), (nm_, ne, nn) = refs
+    n_changed = 0
+    for r in range(Rn):
+        want_idx = []
+        for p in range(P):
+            had, has = oe[r, p] != 0xFFFFFFFF, ne[r, p] != 0xFFFFFFFF
+            if has:
+                same = had and om[r, p] == nm_[r, p] and np.array_equal(on[r, p], nn[r, p])
+                a = E.DIFF_SAME if same else (E.DIFF_INSTALL if nn[r, p].any() else E.DIFF_SILENT)
+            else:
+                a = (E.DIFF_WITHDRAW if on[r, p].any() else E.DIFF_SILENT) if had else E.DIFF_SAME
+            assert act[r, p] == a, (r, p)
+            if a in (E.DIFF_INSTALL, E.DIFF_WITHDRAW):
+                want_idx.append(p)
+        assert chg[cptr[r]:cptr[r + 1]].tolist() == want_idx, r
+        n_changed += len(want_idx)
+    assert cptr[0] == 0 and cptr[Rn] == n_changed and 0 < n_changed < Rn * P

@@ -25,6 +25,20 @@ def test_compute_spf_reproduces_reference_local_rib(path):
     assert H.compute_spf(inst, OracleEngine()) == want
 
 
+ISIS_WIRE = [p for p in ISIS_STEPS if "summary" not in os.path.basename(p)]
+
+
+@pytest.mark.parametrize("path", ISIS_WIRE, ids=[os.path.basename(p)[:-5] for p in ISIS_WIRE])
+def test_update_global_rib_reproduces_recorded_ibus_messages(path):
+    """SPF + route build of the host twin, then the wire step (update_global_rib): the RouteIpAdd / RouteIpDel messages
+    the reference recorded for the step, in order."""
+    vec = json.load(open(path))
+    inst = H.Instance.from_vector(vec)
+    want = [{k: m[k] for k in m if k != "distance"} for m in vec["ibus_routes"]]
+    got = H.update_global_rib(H.compute_spf(inst, OracleEngine()), vec["rib_before"], vec["ifindex"])
+    assert got == want and got == R.update_global_rib(R.local_rib(vec), vec["rib_before"], vec["ifindex"])
+
+
 def check_spts_against_ref(vec, inst, engine):
     """Every system as root in one batched run (the flooding::manet::init_cache shape), local and
     hop-count variants, against the literal restatement: distance, hops, next-hop system ids and

@@ -51,6 +51,22 @@ def test_isis_ref_reproduces_reference_local_rib(path):
     assert R.local_rib(vec) == want
 
 
+# the wire step: the route messages the reference recorded on the ibus for the step.  Summary routes
+# are configuration, not SPF output (RouteFlags::SUMMARY): the two summary tests are left out.
+ISIS_WIRE = [p for p in ISIS_STEPS if "summary" not in os.path.basename(p)]
+
+
+@pytest.mark.parametrize("path", ISIS_WIRE, ids=[os.path.basename(p)[:-5] for p in ISIS_WIRE])
+def test_isis_ref_update_global_rib_reproduces_recorded_ibus_messages(path):
+    vec = _load(path)
+    want = [{k: m[k] for k in m if k != "distance"} for m in vec["ibus_routes"]]
+    assert want, "step vectors are the ones whose last step put routes on the ibus"
+    # 1. the diff alone, on the recorded RIBs before / after the step
+    assert R.update_global_rib(vec["rib"], vec["rib_before"], vec["ifindex"]) == want
+    # 2. the whole chain: SPF + route build of the restatement, then the diff
+    assert R.update_global_rib(R.local_rib(vec), vec["rib_before"], vec["ifindex"]) == want
+
+
 @pytest.mark.parametrize("path", ISIS, ids=[os.path.basename(p)[:-5] for p in ISIS])
 def test_graph_oracle_agrees_with_isis_ref(path):
     vec = _load(path)
@@ -98,6 +114,19 @@ def test_ospf_golden_vectors_present():
 
 def _intra(vec):
     return sorted([r for r in vec["rib"] if r["type"] == "intra-area"], key=lambda r: RO._net_key(r["prefix"]))
+
+
+OSPF_STEPS = sorted(glob.glob(os.path.join(GOLD, "ospfv2_steps", "*.json")))
+
+
+@pytest.mark.parametrize("path", OSPF_STEPS, ids=[os.path.basename(p)[:-5] for p in OSPF_STEPS])
+def test_ospf_ref_update_global_rib_reproduces_recorded_ibus_messages(path):
+    """The wire step on the reference's recorded RIBs before / after the step (all route types): the
+    RouteIpAdd / RouteIpDel messages it recorded on the ibus, in order."""
+    vec = _load(path)
+    want = [{k: m[k] for k in m if k != "distance"} for m in vec["ibus_routes"]]
+    assert want
+    assert RO.update_global_rib(vec["rib"], vec["rib_before"], vec["ifindex"]) == want
 
 
 @pytest.mark.parametrize("path", OSPF, ids=OSPF_IDS)

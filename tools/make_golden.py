@@ -159,14 +159,33 @@ def isis_vector(rt_dir: str) -> dict:
             })
         lsdb[str(lv["level"])] = lsps
 
+    rib = _rib_rows(st)
+    return {"source": os.path.relpath(rt_dir, REF), "proto": "isis", "config": config,
+            "interfaces": ifaces, "lsdb": lsdb, "rib": rib}
+
+
+def _rib_rows(st):
     rib = []
     for r in st.get("local-rib", {}).get("route", []):
         nhs = [[n.get("next-hop"), n.get("outgoing-interface")]
                for n in r.get("next-hops", {}).get("next-hop", [])]
         rib.append({"prefix": r["prefix"], "metric": int(r["metric"]), "level": int(r["level"]),
                     "nexthops": nhs})
-    return {"source": os.path.relpath(rt_dir, REF), "proto": "isis", "config": config,
-            "interfaces": ifaces, "lsdb": lsdb, "rib": rib}
+    return rib
+
+
+def _ibus_routes(path):
+    """RouteIpAdd / RouteIpDel messages of one recorded ibus output, in order."""
+    out = []
+    for line in open(path):
+        m = json.loads(line)
+        if "RouteIpAdd" in m:
+            a = m["RouteIpAdd"]
+            out.append({"op": "add", "prefix": a["prefix"], "metric": a["metric"], "distance": a["distance"],
+                        "nexthops": [[n["Address"]["ifindex"], n["Address"]["addr"]] for n in a["nexthops"] if "Address" in n]})
+        elif "RouteIpDel" in m:
+            out.append({"op": "del", "prefix": m["RouteIpDel"]["prefix"]})
+    return out
 
 
 def make_isis():
@@ -242,6 +261,21 @@ def make_isis_steps():
         finally:
             shutil.rmtree(tmp)
         v["source"] = f"holo-isis/tests/conformance/{name} (snapshot {topo}/{rt}, state {os.path.basename(states[-1])})"
+        # The wire step after the path: the route messages this step put on the ibus
+        # (update_global_rib, holo-isis/src/route.rs:254-312 -> ibus::tx::route_install / route_uninstall), the local RIB
+        # BEFORE the step (the previous recorded state of the test, else the topology snapshot) and the interface
+        # indices the harness had announced (InterfaceUpd events of the snapshot and of the test's own ibus inputs).
+        prev = states[-2] if len(states) > 1 else os.path.join(base, "topologies", topo, rt, "output", "northbound-state.json")
+        v["rib_before"] = _rib_rows(_proto(json.load(open(prev)), "ietf-isis:isis"))
+        v["ibus_routes"] = _ibus_routes(ibus)
+        ifx = {}
+        for evf in [os.path.join(base, "topologies", topo, rt, "events.jsonl")] + sorted(glob.glob(os.path.join(d, "*-input-ibus.jsonl"))):
+            for line in open(evf):
+                ev = json.loads(line)
+                ev = ev.get("Ibus", ev)
+                if isinstance(ev, dict) and "InterfaceUpd" in ev:
+                    ifx[ev["InterfaceUpd"]["ifname"]] = ev["InterfaceUpd"]["ifindex"]
+        v["ifindex"] = ifx
         json.dump(v, open(os.path.join(out, f"{name}.json"), "w"), separators=(",", ":"), sort_keys=True)
         n += 1
     print(f"isis step tests: {n} vectors -> {out}")

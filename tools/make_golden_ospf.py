@@ -256,6 +256,23 @@ def make_ospfv2_steps():
         finally:
             shutil.rmtree(tmp)
         v["source"] = f"holo-ospf/tests/conformance/ospfv2/{name} (snapshot {topo}/{rt}, state {os.path.basename(states[-1])})"
+        # the wire step after the path (update_global_rib, holo-ospf/src/route.rs:856-916): the route
+        # messages this step put on the ibus, the whole local RIB before the step, the announced interface indices
+        from make_golden import _ibus_routes
+        prev = states[-2] if len(states) > 1 else os.path.join(base, "topologies", topo, rt, "output", "northbound-state.json")
+        pst = _proto(json.load(open(prev)), "ietf-ospf:ospf")
+        v["rib_before"] = [{"prefix": r["prefix"], "metric": int(r["metric"]), "type": r["route-type"],
+                            "nexthops": [[n.get("next-hop"), n.get("outgoing-interface")] for n in r.get("next-hops", {}).get("next-hop", [])]}
+                           for r in pst.get("local-rib", {}).get("route", [])]
+        v["ibus_routes"] = _ibus_routes(ibus)
+        ifx = {}
+        for evf in [os.path.join(base, "topologies", topo, rt, "events.jsonl")] + sorted(glob.glob(os.path.join(d, "*-input-ibus.jsonl"))):
+            for line in open(evf):
+                ev = json.loads(line)
+                ev = ev.get("Ibus", ev)
+                if isinstance(ev, dict) and "InterfaceUpd" in ev:
+                    ifx[ev["InterfaceUpd"]["ifname"]] = ev["InterfaceUpd"]["ifindex"]
+        v["ifindex"] = ifx
         json.dump(v, open(os.path.join(out, f"{name}.json"), "w"), separators=(",", ":"), sort_keys=True)
         n += 1
     print(f"ospfv2 step tests: {n} vectors -> {out}")
