@@ -37,8 +37,10 @@ struct BuildInfo {       // device-resident summary of one build, copied back on
   uint32_t wmax;         // largest kept cost
   uint32_t hc_bad;       // some kept link breaks the hop-count shape
   uint32_t hc_net;       // some network row has a kept in-link
-  uint32_t xcd_start[9]; // GraphDev::xcd_start: work-balanced chunk ranges of the 8 XCDs
-  uint32_t pad[2];
+  uint32_t xcd_start[9]; // GraphDev::xcd_start: work-balanced chunk ranges of the 8 XCDs (no heavy chunk), else even
+                         // shares of the normal units
+  uint32_t n_heavy;      // heavy 16-vertex chunks (a row of more than UNIT_HEAVY_DEG in-links): 4 work units each
+  uint32_t pad[1];
 };
 
 constexpr int GB_BLOCK = 256;
@@ -242,13 +244,44 @@ kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__r
   if (net && b > a) info->hc_net = 1u;
 }
 
-// Work-balanced XCD ranges (GraphDev::xcd_start): cost of a 16-vertex chunk prefix k = in-links of the first 16k
-// vertices + 8 per vertex (a row costs about 8 links' worth of fixed work); XCD x starts at the first chunk whose
-// prefix reaches x/8 of the total.  Seven binary searches, one thread each.
+// Work units (GraphDev::unit_first): heavy flag per 16-vertex chunk, then (after a scan of the flags) the unit table
+// [4 units per heavy chunk | 1 unit per other chunk], each class in vertex order.
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_unit_count(uint32_t n, const uint32_t *__restrict__ in_ptr, uint32_t *__restrict__ hf) {
+  const uint32_t c = blockIdx.x * GB_BLOCK + threadIdx.x;
+  const uint32_t nb = (n + 15u) / 16u;
+  if (c >= nb) return;
+  bool heavy = false;
+  for (uint32_t v = c * 16u; v < min(c * 16u + 16u, n); ++v) heavy = heavy || (in_ptr[v + 1] - in_ptr[v] > UNIT_HEAVY_DEG);
+  hf[c] = heavy ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_unit_fill(uint32_t n, const uint32_t *__restrict__ hf, const uint32_t *__restrict__ hpos, uint32_t *__restrict__ unit_first,
+             BuildInfo *__restrict__ info) {
+  const uint32_t c = blockIdx.x * GB_BLOCK + threadIdx.x;
+  const uint32_t nb = (n + 15u) / 16u;
+  const uint32_t nh = hpos[nb];                       // heavy chunks
+  if (c == 0) info->n_heavy = nh;
+  if (c >= nb) return;
+  const uint32_t hb = hpos[c];                        // heavy chunks before c
+  if (hf[c]) for (uint32_t k = 0; k < 4u; ++k) unit_first[4u * hb + k] = min(c * 16u + 4u * k, n) | UNIT_SPLIT;
+  else unit_first[4u * nh + (c - hb)] = c * 16u;
+}
+
+// Work-balanced XCD ranges for graphs without heavy chunks (GraphDev::xcd_start): cost of a 16-vertex chunk prefix k =
+// in-links of the first 16k vertices + 8 per vertex (a row costs about 8 links' worth of fixed work; HSPF_XCD_ROW_COST);
+// XCD x starts at the first chunk whose prefix reaches x/8 of the total.  Seven binary searches, one thread each.
+// With heavy chunks: even shares of the normal units (the heavy ones are split evenly by the host, GraphDev::xcd_heavy).
 __global__ void kb_xcd(uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *__restrict__ info, uint32_t row_cost) {
   const uint32_t x = threadIdx.x;
   if (x > 8u) return;
   const uint32_t nb = (n + 15u) / 16u;
+  if (info->n_heavy) {
+    const uint32_t nn = nb - info->n_heavy;
+    info->xcd_start[x] = (uint32_t)((uint64_t)nn * x / 8ull);
+    return;
+  }
   auto cost = [&](uint32_t k) -> uint64_t { const uint32_t v = min(k * 16u, n); return (uint64_t)in_ptr[v] + (uint64_t)row_cost * v; };
   const uint64_t total = cost(nb), want = total * x / 8ull;
   uint32_t lo = 0, hi = nb;                       // smallest k with cost(k) >= want

@@ -40,7 +40,12 @@ struct hspf_graph {
   bool hopcount_like = false;        // every kept link into a network costs 0 (from a router), into a router 1
   bool heavy_rows = false;           // a quarter or more of the links sit in rows of more than 32 (fat-tree switches, big LANs)
   uint32_t xcd_start[9] = {};        // work-balanced chunk ranges of the 8 XCDs (GraphDev::xcd_start)
-  uint32_t xcd_blocks() const { uint32_t m = 0; for (int x = 0; x < 8; ++x) m = std::max(m, xcd_start[x + 1] - xcd_start[x]); return 8u * std::max(m, 1u); }
+  uint32_t xcd_heavy(int x) const { return (uint32_t)((uint64_t)n_heavy_chunks * 4u * (uint32_t)x / 8ull); }   // even shares of the heavy units
+  uint32_t xcd_blocks() const {
+    uint32_t m = 0;
+    for (int x = 0; x < 8; ++x) m = std::max(m, xcd_start[x + 1] - xcd_start[x] + xcd_heavy(x + 1) - xcd_heavy(x));
+    return 8u * std::max(m, 1u);
+  }
   // host mirrors: slot tables walk the root's neighbourhood on the host
   std::vector<uint32_t> row_ptr, col;
   std::vector<uint8_t> twoway;     // per original link (computed on device, copied back)
@@ -53,6 +58,8 @@ struct hspf_graph {
   uint32_t *d_in_ptr = nullptr, *d_in_src = nullptr, *d_in_w = nullptr, *d_in_fpos = nullptr;
   uint32_t *d_out_ptr = nullptr, *d_out_dst = nullptr, *d_out_w = nullptr, *d_out_fpos = nullptr;
   uint8_t *d_vflags = nullptr, *d_rowflags = nullptr;
+  uint32_t *d_unit_first = nullptr;                               // work units (GraphDev::unit_first), n / 4 + 4 entries
+  uint32_t n_heavy_chunks = 0;                                    // > 0: the kernels go through unit_first
   // Carves the arrays out of `base` for n vertices / cap links; returns the bytes needed.
   size_t layout(char *base, uint32_t nv, uint32_t cap) {
     size_t off = 0;
@@ -65,6 +72,7 @@ struct hspf_graph {
     d_in_src = (uint32_t *)carve(lb); d_in_w = (uint32_t *)carve(lb); d_in_fpos = (uint32_t *)carve(lb);
     d_out_dst = (uint32_t *)carve(lb); d_out_w = (uint32_t *)carve(lb); d_out_fpos = (uint32_t *)carve(lb);
     d_vflags = (uint8_t *)carve(nv); d_rowflags = (uint8_t *)carve(nv);
+    d_unit_first = (uint32_t *)carve((size_t(nv) / 4 + 8) * 4);
     return off;
   }
   GraphDev dev() const {
@@ -74,6 +82,9 @@ struct hspf_graph {
     g.vflags = d_vflags; g.rowflags = d_rowflags;
     g.out_ptr = d_out_ptr; g.out_dst = d_out_dst; g.out_w = d_out_w; g.out_fpos = d_out_fpos;
     for (int x = 0; x < 9; ++x) g.xcd_start[x] = xcd_start[x];
+    g.unit_first = n_heavy_chunks ? d_unit_first : nullptr;
+    g.n_heavy_units = n_heavy_chunks * 4u;
+    for (int x = 0; x < 9; ++x) g.xcd_heavy[x] = xcd_heavy(x);
     return g;
   }
 };
@@ -269,6 +280,16 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   }
   hipLaunchKernelGGL(kb_rowflags, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
                      (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info);
+  {
+    // work units: heavy flag per chunk -> heavy chunks before each chunk -> unit_first (scratch: in_cnt, n + 17 words, is
+    // free again and holds both: nb flags, then nb + 1 positions)
+    const uint32_t nb = (n + 15u) / 16u;
+    uint32_t *hpos = in_cnt + nb + 1;
+    hipLaunchKernelGGL(kb_unit_count, dim3((nb + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, in_cnt);
+    gb_scan<uint32_t>(s, in_cnt, nb, hpos, sums);
+    hipLaunchKernelGGL(kb_unit_fill, dim3((nb + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)in_cnt,
+                       (const uint32_t *)hpos, g->d_unit_first, info);
+  }
   hipLaunchKernelGGL(kb_xcd, dim3(1), dim3(64), 0, s, n, (const uint32_t *)g->d_in_ptr, info, ctx->xcd_row_cost);
   hipLaunchKernelGGL(kb_pads, dim3(1), dim3(64), 0, s, n, (const BuildInfo *)info, g->d_in_ptr, g->d_out_ptr,
                      g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos);
@@ -291,6 +312,7 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
     g->heavy_rows = heavy * 4u >= (uint64_t)std::max<uint32_t>(e, 1u);
   }
   for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
+  g->n_heavy_chunks = bi.n_heavy;
   g->narrow_bad = false;
   g->wide24_bad = false;
   return HSPF_OK;
@@ -914,7 +936,9 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       uint32_t n_f = 0;
       const bool maxinf = g->max_path_metric == HSPF_DIST_INF;
       int r2 = run_phase(ctx->est_fused, [&](uint32_t sweep) {
-#define HSPF_LAUNCH_FUSED(ST_, MI_, CN_, stp_) hipLaunchKernelGGL((k_fused<ST_, MI_, CN_>), fgrid, dim3(256), 0, s, d_fg, stp_, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf)
+#define HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, UN_, stp_) hipLaunchKernelGGL((k_fused<ST_, MI_, CN_, UN_>), fgrid, dim3(256), 0, s, d_fg, stp_, d_stamp, (const uint8_t *)ctx->hnb.p, d_roots, P, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf)
+#define HSPF_LAUNCH_FUSED(ST_, MI_, CN_, stp_) do { if (units) HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, true, stp_); else HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, false, stp_); } while (0)
+        const bool units = g->n_heavy_chunks != 0;
         if (count_rows) {
           if (nar)         HSPF_LAUNCH_FUSED(uint32_t, false, true, (uint32_t *)d_st);
           else if (maxinf) HSPF_LAUNCH_FUSED(uint64_t, true, true, d_st);
@@ -924,6 +948,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
           else if (maxinf) HSPF_LAUNCH_FUSED(uint64_t, true, false, d_st);
           else             HSPF_LAUNCH_FUSED(uint64_t, false, false, d_st);
         }
+#undef HSPF_LAUNCH_FUSED2
 #undef HSPF_LAUNCH_FUSED
       }, n_f, [&]() {
         // results out of the packed state (speculative: valid when this chunk reached the fixed point and, for the
@@ -1041,13 +1066,14 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   } else {
   // More than 24 first-hop slots: two ways.  k_fw = ONE fused fixed point over (distance, hops, W mask words): half the
   // launches, but a label-correcting sweep re-reads the masks of ALL in-links of a row every time the row is revisited.
-  // k_relax + k_dag = distances first (4 bytes per lane and link), then every row's masks ONCE, when its tight parents are
-  // final.  Measured (profiles/r02g_wide_mask*.jsonl): isis-100k with its roots on a 48-router LAN (one mask word): 2.51
-  // vs 2.47 ms, a tie; fat-tree k = 100 (100-link switch rows, two mask words): 5.04 vs 4.38 ms — the two-phase path
-  // wins where most links sit in heavy rows.  So: k_fw for graphs up to 65 536 vertices (launch-bound: 24 instead of 48
-  // launches) and for large graphs without heavy rows; the two-phase path for large graphs with them, for hop-count-like
-  // graphs with more than 4 mask words (the plateau rule doubles k_fw's mask registers), and when HSPF_VARIANT bit6 asks.
-  const bool use_fw = !(ctx->variant & 64u) && (!g->hopcount_like || W <= 4) && (n <= 65536u || !g->heavy_rows);
+  // k_relax + k_dag = distances first (4 bytes per lane and link), then the masks over the tight-link DAG.
+  // Measured (profiles/r02g_wide_mask*.jsonl, r02m_*): while a chunk of 100-link rows was four rows per wave the two-phase
+  // path won on the fat-tree (4.38 vs 5.04 ms); with heavy chunks cut into one-row-per-wave work units (GraphDev) k_fw
+  // wins there too (3.04 vs 3.45 ms) and ties on isis-100k with its roots on a 48-router LAN (2.52 vs 2.55 ms).  So k_fw
+  // it is, except for hop-count-like graphs with more than 4 mask words (the plateau rule doubles k_fw's mask
+  // registers) and when HSPF_VARIANT bit6 asks for the two-phase path (kept: it is the independent second implementation
+  // the "twophase" configuration of the GPU suite runs).
+  const bool use_fw = !(ctx->variant & 64u) && (!g->hopcount_like || W <= 4);
   if (use_fw) {
     const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
     HIPCHK(ctx, hipMemsetAsync(d_mask, 0, rows * 8 * W, s));

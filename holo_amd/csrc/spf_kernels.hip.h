@@ -66,7 +66,21 @@ struct GraphDev {
   // (in-links + a per-row constant), not equal vertex counts: in a fat-tree all 12 500 hundred-link switch rows come
   // first in VertexId order and would otherwise all land on XCD 0.
   uint32_t xcd_start[9];
+  // Work units (null: a unit is a 16-vertex chunk and xcd_start is all there is).  A wave walks the in-links of its rows
+  // one after the other in groups of a few requests, so a chunk of 100-link rows (fat-tree switches, LAN pseudonodes) is
+  // one long latency chain on four waves while the rest of the chip idles.  Graphs with such chunks are cut into HEAVY
+  // units — a chunk that holds a row of more than UNIT_HEAVY_DEG in-links becomes four units of 4 vertices, ONE row per
+  // wave — and normal units (16 vertices, four rows per wave): unit_first = [heavy units | normal units], each class in
+  // vertex order, unit_first[u] = first vertex | UNIT_SPLIT.  Every XCD gets an equal, contiguous share of BOTH classes
+  // (xcd_heavy / xcd_start index into their class) and runs its heavy units first: one cost model cannot balance rows
+  // that are bound by their link count against rows that are bound by the fixed cost of a wave (measured, fat-tree:
+  // every weighting of a single range loses to the even split; profiles/r02_notes.md r02m).
+  const uint32_t *unit_first;
+  uint32_t n_heavy_units;
+  uint32_t xcd_heavy[9];
 };
+constexpr uint32_t UNIT_SPLIT = 0x80000000u;
+constexpr uint32_t UNIT_HEAVY_DEG = 32u;
 
 struct OutDev {
   uint32_t *dist; uint16_t *hops; uint16_t *flags; uint64_t *mask; uint32_t out_words;
@@ -96,6 +110,31 @@ __device__ __forceinline__ uint32_t xcd_chunk(const uint32_t *xcd_start, uint32_
   const uint32_t x = bx & 7u, j = bx >> 3;
   const uint32_t s0 = xcd_start[x], s1 = xcd_start[x + 1];
   return j < s1 - s0 ? s0 + j : 0xFFFFFFFFu;
+}
+
+// Rows of wave `wave` of block bx: first vertex and how many consecutive rows (4, or 1 in a heavy unit); false = nothing.
+__device__ __forceinline__ bool wave_rows(const GraphDev &g, uint32_t bx, uint32_t wave, uint32_t &vbeg, uint32_t &nrows) {
+  if (!g.unit_first) {
+    const uint32_t u = xcd_chunk(g.xcd_start, bx);
+    if (u == 0xFFFFFFFFu) return false;
+    nrows = (uint32_t)VPW;
+    vbeg = u * (uint32_t)VPB + wave * (uint32_t)VPW;
+    return vbeg < g.n;
+  }
+  const uint32_t x = bx & 7u;
+  uint32_t j = bx >> 3, u;
+  const uint32_t h0 = g.xcd_heavy[x], nh = g.xcd_heavy[x + 1] - h0;
+  if (j < nh) u = h0 + j;
+  else {
+    j -= nh;
+    const uint32_t s0 = g.xcd_start[x];
+    if (j >= g.xcd_start[x + 1] - s0) return false;
+    u = g.n_heavy_units + s0 + j;
+  }
+  const uint32_t uf = g.unit_first[u];
+  nrows = (uf & UNIT_SPLIT) ? 1u : (uint32_t)VPW;
+  vbeg = (uf & ~UNIT_SPLIT) + wave * nrows;
+  return vbeg < g.n;
 }
 
 __device__ __forceinline__ uint32_t slot_base_of(const SlotTabs &t, uint32_t root_slot, uint32_t u) {
@@ -161,11 +200,9 @@ __global__ __launch_bounds__(256) void k_relax(GraphDev g, uint32_t *__restrict_
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t batch = blockIdx.y;
-  const uint32_t chunk = xcd_chunk(g.xcd_start, blockIdx.x);
-  if (chunk == 0xFFFFFFFFu) return;
-  const uint32_t vbeg = chunk * VPB + wave * VPW;
   const uint32_t n = g.n;
-  if (vbeg >= n) return;
+  uint32_t vbeg, nrows;
+  if (!wave_rows(g, blockIdx.x, wave, vbeg, nrows)) return;
   const uint32_t *__restrict__ in_ptr = g.in_ptr;
   const uint32_t *__restrict__ in_src = g.in_src;
   const uint32_t *__restrict__ in_w = g.in_w;
@@ -178,7 +215,7 @@ __global__ __launch_bounds__(256) void k_relax(GraphDev g, uint32_t *__restrict_
 #pragma unroll
   for (int i = 0; i < VPW; ++i) {
     const uint32_t v = vbeg + i;
-    if (v >= n) break;
+    if (v >= n || (uint32_t)i >= nrows) break;
     const uint32_t e0 = rdlane(pv, i), e1 = rdlane(pv, i + 1);
     const uint32_t d_old = ld_row(D, v * 256u + lane4);
     uint32_t best = d_old;
@@ -247,11 +284,9 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t batch = blockIdx.y;
-  const uint32_t chunk = xcd_chunk(g.xcd_start, blockIdx.x);
-  if (chunk == 0xFFFFFFFFu) return;
-  const uint32_t vbeg = chunk * VPB + wave * VPW;
   const uint32_t n = g.n;
-  if (vbeg >= n) return;
+  uint32_t vbeg, nrows;
+  if (!wave_rows(g, blockIdx.x, wave, vbeg, nrows)) return;
   const uint32_t *__restrict__ in_ptr = g.in_ptr;
   const uint32_t *__restrict__ in_src = g.in_src;
   const uint32_t *__restrict__ in_w = g.in_w;
@@ -272,7 +307,7 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
 #pragma unroll 1
   for (int i = 0; i < VPW; ++i) {
     const uint32_t v = vbeg + i;
-    if (v >= n) break;
+    if (v >= n || (uint32_t)i >= nrows) break;
     if (rdlane(av, i) < (uint32_t)sweep) continue;       // none of its in-neighbours changed in the last sweep
     const uint32_t cur = ld_row(H, v * 256u + lane4);
     const bool need0 = (cur >> HV_EPOCH_SHIFT) == 0;
@@ -753,7 +788,7 @@ constexpr int FQ = 1;          // measured: FQ = 4 makes sparse sweeps cheaper (
 constexpr int FVPW = FQ * VPW;                    // vertices per wave (<= 63: one lane per vertex + 1)
 constexpr int FVPB = WAVES_PER_BLOCK * FVPW;      // vertices per block of the fused kernel
 
-template <typename ST, bool MAXINF, bool COUNT>
+template <typename ST, bool MAXINF, bool COUNT, bool UNITS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fused(
     const FusedGraph *__restrict__ gp, ST *__restrict__ st, uint32_t *__restrict__ act,
     const uint8_t *__restrict__ hnb, const uint32_t *__restrict__ roots, FusedParams P,
@@ -765,11 +800,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t batch = blockIdx.y;
-  const uint32_t chunk = xcd_chunk(gp->g.xcd_start, blockIdx.x);
-  if (chunk == 0xFFFFFFFFu) return;
-  const uint32_t wbeg = chunk * FVPB + wave * FVPW;
+  // UNITS: the graph has heavy chunks and the blocks go through the work-unit table (GraphDev::unit_first); its own
+  // instantiation, so that the common case keeps its compile-time row count (measured: a run-time one costs 3 %)
   const uint32_t n = gp->g.n;
-  if (wbeg >= n) return;
+  uint32_t wbeg, nrows_rt = (uint32_t)FVPW;
+  if (UNITS) {
+    if (!wave_rows(gp->g, blockIdx.x, wave, wbeg, nrows_rt)) return;
+  } else {
+    const uint32_t chunk = xcd_chunk(gp->g.xcd_start, blockIdx.x);
+    if (chunk == 0xFFFFFFFFu) return;
+    wbeg = chunk * FVPB + wave * FVPW;
+    if (wbeg >= n) return;
+  }
+  const uint32_t nrows = UNITS ? nrows_rt : (uint32_t)FVPW;
   uint32_t *A = act + (size_t)batch * n;
   const uint32_t cur = (uint32_t)sweep + 2u;
   // ---- round trip 1: stamps, row bounds, flags of ALL the wave's vertices (lanes 0..FVPW)
@@ -780,7 +823,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   const uint32_t po = gp->g.out_ptr[vl];
   const uint32_t hb = hnb[(size_t)batch * n + vlc] & (ignore_ovl ? ~RF_NT : ~0u);
   const uint32_t vf = gp->g.vflags[vlc];
-  const uint64_t due = __ballot(lane < (uint32_t)FVPW && wbeg + lane < n && av >= cur);
+  const uint64_t due = __ballot(lane < nrows && wbeg + lane < n && av >= cur);
   if (due == 0ull) return;
   const uint32_t root_slot = batch * 64 + lane;
   const uint32_t my_root = roots[root_slot];
@@ -827,7 +870,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
     auto row = [&](auto I) {                                      // explicit 4x instantiation
       constexpr int i = decltype(I)::value;
       const uint32_t v = vbeg + i;
-      if (v >= n) return;
+      if (v >= n || (uint32_t)i >= nrows) return;
       if (rdlane(av, lb + i) < cur) return;                       // nothing changed around this row
       const uint32_t e0 = rdlane(pv, lb + i), e1 = rdlane(pv, lb + i + 1);
       const uint32_t v_router = (rdlane(vf, lb + i) & 1u) ? 0u : 1u;
@@ -1355,14 +1398,12 @@ __global__ __launch_bounds__(256) void k_fw(const FusedGraph *__restrict__ gp, u
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t batch = blockIdx.y;
-  const uint32_t chunk = xcd_chunk(g.xcd_start, blockIdx.x);
-  if (chunk == 0xFFFFFFFFu) return;
-  const uint32_t vbeg = chunk * VPB + wave * VPW;
   const uint32_t n = g.n;
-  if (vbeg >= n) return;
+  uint32_t vbeg, nrows;
+  if (!wave_rows(g, blockIdx.x, wave, vbeg, nrows)) return;
   uint32_t *A = act + (size_t)batch * n;
   const uint32_t av = A[min(vbeg + min(lane, (uint32_t)VPW - 1u), n - 1)];
-  const uint64_t due = __ballot(lane < (uint32_t)VPW && vbeg + lane < n && av >= (uint32_t)sweep + 1u);
+  const uint64_t due = __ballot(lane < nrows && vbeg + lane < n && av >= (uint32_t)sweep + 1u);
   if (due == 0ull) return;
   const uint32_t *__restrict__ in_src = g.in_src;
   const uint32_t *__restrict__ in_w = g.in_w;

@@ -272,6 +272,32 @@ def test_star_rows_with_more_than_64_links(spf_ctx, fanout):
     assert res.first_hop_mask.shape[2] == (fanout + 63) // 64
 
 
+@all_engines
+@pytest.mark.parametrize("n,hubs", [(530, (0, 17, 300, 529)), (96, (95,)), (1000, (15, 16, 31, 32, 999)), (40, (3,))])
+def test_heavy_chunks_become_one_row_per_wave_work_units(spf_ctx, n, hubs):
+    """Hubs of 40-130 links at the first / last / chunk-boundary vertices of a sparse random graph (n not a multiple of
+    16): chunks with a row of more than 32 in-links are cut into one-row-per-wave work units and every XCD takes an even
+    share of both unit classes (GraphDev::unit_first); results of every kernel that walks units — fused, wide-mask,
+    two-phase, lane = vertex — against the oracle, roots on and off the hubs."""
+    rng = np.random.default_rng(n)
+    s = list(rng.integers(0, n, 2 * n)); d = list(rng.integers(0, n, 2 * n))
+    for h in hubs:
+        fan = int(rng.integers(40, 131))
+        nb = rng.choice(np.setdiff1d(np.arange(n), [h]), size=min(fan, n - 1), replace=False)
+        s += [h] * len(nb); d += list(nb)
+    s, d = np.asarray(s), np.asarray(d)
+    keep = s != d
+    s, d = s[keep], d[keep]
+    s, d = np.concatenate([s, d]), np.concatenate([d, s])              # both directions: every link is two-way
+    m = rng.integers(1, 6, len(s))
+    row_ptr, col, met = synth._csr_from_links(n, s, d, m)
+    g = synth.CsrGraph(row_ptr, col, met, np.zeros(n, np.uint8), synth.MAX_PATH_METRIC_WIDE)
+    leaf_roots = [int(v) for v in rng.choice(np.setdiff1d(np.arange(n), hubs), size=min(70, n - len(hubs)), replace=False)]
+    check(spf_ctx, g, leaf_roots, expect_exact=False)                   # <= 24 slots mostly: fused path
+    check(spf_ctx, g, list(hubs) + leaf_roots[:5], expect_exact=False)  # hubs as roots: wide masks (k_fw / two-phase)
+    check(spf_ctx, g, [leaf_roots[0]], expect_exact=False)
+
+
 def _properties(g, roots, res, sample, variant=go.HEAP, run_flags=0):
     """Full-size check: the roots in `sample` (None: ALL of them) bit for bit against the oracle, all roots through
     size-independent properties (root at distance 0, fixed point of relaxation on every kept link,
