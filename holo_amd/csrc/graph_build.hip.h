@@ -247,12 +247,12 @@ kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__r
 // Work units (GraphDev::unit_first): heavy flag per 16-vertex chunk, then (after a scan of the flags) the unit table
 // [4 units per heavy chunk | 1 unit per other chunk], each class in vertex order.
 __global__ void __launch_bounds__(GB_BLOCK)
-kb_unit_count(uint32_t n, const uint32_t *__restrict__ in_ptr, uint32_t *__restrict__ hf) {
+kb_unit_count(uint32_t n, const uint32_t *__restrict__ in_ptr, uint32_t *__restrict__ hf, uint32_t heavy_deg) {
   const uint32_t c = blockIdx.x * GB_BLOCK + threadIdx.x;
   const uint32_t nb = (n + 15u) / 16u;
   if (c >= nb) return;
   bool heavy = false;
-  for (uint32_t v = c * 16u; v < min(c * 16u + 16u, n); ++v) heavy = heavy || (in_ptr[v + 1] - in_ptr[v] > UNIT_HEAVY_DEG);
+  for (uint32_t v = c * 16u; v < min(c * 16u + 16u, n); ++v) heavy = heavy || (in_ptr[v + 1] - in_ptr[v] > heavy_deg);
   hf[c] = heavy ? 1u : 0u;
 }
 

@@ -123,6 +123,7 @@ struct hspf_ctx {
   uint32_t lv_max_roots = 2;               // HSPF_LV_MAX_ROOTS env: runs of at most this many roots take the lane = vertex kernel (0: never)
   uint32_t lv_min_n = 32768;               // HSPF_LV_MIN_N env: ... on graphs of at least this many vertices
   uint32_t est_lv = 24;
+  uint32_t unit_heavy_deg = UNIT_HEAVY_DEG; // HSPF_UNIT_HEAVY_DEG env: a chunk with a row of more in-links than this runs one row per wave
   uint32_t xcd_row_cost = 8;               // HSPF_XCD_ROW_COST env: fixed cost of a row, in links, when the XCD ranges are cut
   hspf_stats stats = {};
 };
@@ -285,7 +286,7 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
     // free again and holds both: nb flags, then nb + 1 positions)
     const uint32_t nb = (n + 15u) / 16u;
     uint32_t *hpos = in_cnt + nb + 1;
-    hipLaunchKernelGGL(kb_unit_count, dim3((nb + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, in_cnt);
+    hipLaunchKernelGGL(kb_unit_count, dim3((nb + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, in_cnt, ctx->unit_heavy_deg);
     gb_scan<uint32_t>(s, in_cnt, nb, hpos, sums);
     hipLaunchKernelGGL(kb_unit_fill, dim3((nb + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)in_cnt,
                        (const uint32_t *)hpos, g->d_unit_first, info);
@@ -374,6 +375,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   if (const char *v = getenv("HSPF_LV_MAX_ROOTS")) ctx->lv_max_roots = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_LV_MIN_N")) ctx->lv_min_n = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_XCD_ROW_COST")) ctx->xcd_row_cost = (uint32_t)strtoul(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_UNIT_HEAVY_DEG")) ctx->unit_heavy_deg = (uint32_t)strtoul(v, nullptr, 0);
   if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return HSPF_E_NODEV; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
   for (auto &e : ctx->ev)
