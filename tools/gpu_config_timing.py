@@ -37,6 +37,48 @@ def main():
         tot += ms; roots_n += len(g.meta["roots"])
     print(json.dumps({"config": "ospf multi-area 10 x 5000 routers, 1000 roots per area", "roots": roots_n,
                       "device_ms_total": round(tot, 2), "runs_per_s": round(roots_n / tot * 1e3), "state_bytes": st["state_bytes"]}))
+    # the same ten areas, each on its own context and host thread (the reference runs one OS thread per protocol instance,
+    # holo-protocol/src/lib.rs:427-430; SURVEY.md §8b: distinct contexts work concurrently): wall time of the whole set
+    import threading
+    import time
+    import torch
+    areas = synth.ospf_multi_area()
+    ctxs = [E.SpfContext(0) for _ in areas]
+    dev = torch.device("cuda:0")
+    jobs = []
+    for c, g in zip(ctxs, areas):
+        G = c.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        roots = np.asarray(g.meta["roots"], np.uint32)
+        W = G.mask_words(roots)
+        R, n = len(roots), g.n
+        bufs = (torch.empty((R, n), dtype=torch.int32, device=dev), torch.empty((R, n), dtype=torch.int16, device=dev),
+                torch.empty((R, n), dtype=torch.int16, device=dev), torch.empty((R, n, W), dtype=torch.int64, device=dev))
+        jobs.append((c, G, roots, W, bufs))
+
+    def work(j):
+        c, G, roots, W, b = j
+        c.run_device(G, roots, E.RUN_NET_NEXTHOPS, dist_ptr=b[0].data_ptr(), hops_ptr=b[1].data_ptr(), flags_ptr=b[2].data_ptr(),
+                     mask_ptr=b[3].data_ptr(), mask_words=W)
+    walls = {}
+    for mode in ("sequential", "threads"):
+        ts = []
+        for rep in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if mode == "sequential":
+                for j in jobs:
+                    work(j)
+            else:
+                th = [threading.Thread(target=work, args=(j,)) for j in jobs]
+                for t in th: t.start()
+                for t in th: t.join()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        walls[mode] = round(float(np.median(ts[1:])), 2)
+    print(json.dumps({"config": "ospf multi-area, wall time of all 10 areas x 1000 roots", "one_context_after_the_other_ms": walls["sequential"],
+                      "ten_contexts_on_ten_threads_ms": walls["threads"], "runs_per_s_threads": round(roots_n / walls["threads"] * 1e3)}))
+    for c, G, *_ in jobs:
+        G.free(); c.close()
     g = synth.isis_fattree(100)
     ms, st, W = run(ctx, g, g.meta["roots"], 0)
     print(json.dumps({"config": "isis fat-tree k=100 (262 500 vertices / 1.5 M entries), 101 roots", "mask_words": W,
