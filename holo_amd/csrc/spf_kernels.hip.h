@@ -790,19 +790,23 @@ constexpr int FVPB = WAVES_PER_BLOCK * FVPW;      // vertices per block of the f
 
 template <typename ST, bool MAXINF, bool COUNT, bool UNITS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fused(
-    const FusedGraph *__restrict__ gp, ST *__restrict__ st, uint32_t *__restrict__ act,
-    const uint8_t *__restrict__ hnb, const uint32_t *__restrict__ roots, FusedParams P,
-    uint32_t net_nexthops, uint32_t ignore_ovl, int *changed, int sweep, uint32_t *lane_flags) {
-  // The graph / slot-table descriptors live in device memory and are fetched (scalar loads) where
-  // they are used: as by-value kernel arguments they pinned ~40 SGPRs for the whole kernel, and
-  // above 96 SGPRs a CU only admits 6 of these workgroups instead of 8 (MI355X_MICROARCH.md).
+    const FusedGraph *__restrict__ gp, int *changed, int sweep, uint32_t *__restrict__ act,
+    const uint8_t *__restrict__ hnb, uint32_t n_arg, const uint32_t *__restrict__ a_in_ptr, const uint32_t *__restrict__ a_out_ptr,
+    const uint8_t *__restrict__ a_vflags, ST *__restrict__ st, const uint32_t *__restrict__ roots, uint32_t *lane_flags,
+    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P) {
+  // Argument order: the first 16 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count=16,
+  // holo_amd/build.py): the flag array of the sweeps, the vertex count and the arrays of the first round trip arrive
+  // without a load — before, every wave fetched its arguments, then the graph descriptor, then issued round trip 1
+  // (measured: 75.6 k -> 78.5 k runs/s; computing equal XCD ranges from n alone instead of reading xcd_start added nothing).
+  // The rest of the graph / slot-table descriptors stays in device memory and is fetched (scalar loads) where it is
+  // used: as by-value arguments they pinned ~40 SGPRs, and above 96 SGPRs a CU admits 6 of these workgroups instead of 8.
   if (sweep > 0 && changed[sweep - 1] == 0) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t batch = blockIdx.y;
   // UNITS: the graph has heavy chunks and the blocks go through the work-unit table (GraphDev::unit_first); its own
   // instantiation, so that the common case keeps its compile-time row count (measured: a run-time one costs 3 %)
-  const uint32_t n = gp->g.n;
+  const uint32_t n = n_arg;
   uint32_t wbeg, nrows_rt = (uint32_t)FVPW;
   if (UNITS) {
     if (!wave_rows(gp->g, blockIdx.x, wave, wbeg, nrows_rt)) return;
@@ -819,10 +823,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   const uint32_t vl = min(wbeg + min(lane, (uint32_t)FVPW), n);   // in_ptr / out_ptr have n+1 (+16) entries
   const uint32_t vlc = min(vl, n - 1);
   const uint32_t av = A[vlc];
-  const uint32_t pv = gp->g.in_ptr[vl];
-  const uint32_t po = gp->g.out_ptr[vl];
+  const uint32_t pv = a_in_ptr[vl];
+  const uint32_t po = a_out_ptr[vl];
   const uint32_t hb = hnb[(size_t)batch * n + vlc] & (ignore_ovl ? ~RF_NT : ~0u);
-  const uint32_t vf = gp->g.vflags[vlc];
+  const uint32_t vf = a_vflags[vlc];
   const uint64_t due = __ballot(lane < nrows && wbeg + lane < n && av >= cur);
   if (due == 0ull) return;
   const uint32_t root_slot = batch * 64 + lane;
