@@ -938,7 +938,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       uint32_t n_f = 0;
       const bool maxinf = g->max_path_metric == HSPF_DIST_INF;
       int r2 = run_phase(ctx->est_fused, [&](uint32_t sweep) {
-#define HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, UN_, stp_) hipLaunchKernelGGL((k_fused<ST_, MI_, CN_, UN_>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, gd.in_ptr, gd.out_ptr, gd.vflags, stp_, d_roots, d_lf, net_nh, ignore_ovl, P)
+#define HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, UN_, stp_) hipLaunchKernelGGL((k_fused<ST_, MI_, CN_, UN_>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, gd.in_ptr, gd.out_ptr, gd.vflags, stp_, d_roots, d_lf, net_nh, ignore_ovl, P, gd.in_src, gd.in_w, gd.out_dst, gd.e_in)
 #define HSPF_LAUNCH_FUSED(ST_, MI_, CN_, stp_) do { if (units) HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, true, stp_); else HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, false, stp_); } while (0)
         const bool units = g->n_heavy_chunks != 0;
         if (count_rows) {

@@ -793,7 +793,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
     const FusedGraph *__restrict__ gp, int *changed, int sweep, uint32_t *__restrict__ act,
     const uint8_t *__restrict__ hnb, uint32_t n_arg, const uint32_t *__restrict__ a_in_ptr, const uint32_t *__restrict__ a_out_ptr,
     const uint8_t *__restrict__ a_vflags, ST *__restrict__ st, const uint32_t *__restrict__ roots, uint32_t *lane_flags,
-    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P) {
+    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P, const uint32_t *__restrict__ a_in_src,
+    const uint32_t *__restrict__ a_in_w, const uint32_t *__restrict__ a_out_dst, uint32_t a_e_in) {
   // Argument order: the first 16 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count=16,
   // holo_amd/build.py): the flag array of the sweeps, the vertex count and the arrays of the first round trip arrive
   // without a load — before, every wave fetched its arguments, then the graph descriptor, then issued round trip 1
@@ -834,10 +835,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   ST *S = st + (size_t)batch * n * 64;
   const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, n << StIO<ST>::ROW_SHIFT);
   const __amdgpu_buffer_rsrc_t ra = st_rsrc(A, n * 4u);
-  const uint32_t ebytes = (gp->g.e_in + 16u) * 4u;
-  const __amdgpu_buffer_rsrc_t rsrc_src = st_rsrc(gp->g.in_src, ebytes);
-  const __amdgpu_buffer_rsrc_t rsrc_w = st_rsrc(gp->g.in_w, ebytes);
-  const __amdgpu_buffer_rsrc_t rsrc_od = st_rsrc(gp->g.out_dst, ebytes);
+  const uint32_t ebytes = (a_e_in + 16u) * 4u;                   // link arrays: arguments too (fetched with the others at
+  const __amdgpu_buffer_rsrc_t rsrc_src = st_rsrc(a_in_src, ebytes);   // wave start, not through the descriptor between
+  const __amdgpu_buffer_rsrc_t rsrc_w = st_rsrc(a_in_w, ebytes);       // round trips 1 and 2)
+  const __amdgpu_buffer_rsrc_t rsrc_od = st_rsrc(a_out_dst, ebytes);
   const uint32_t lvo = lane * (uint32_t)sizeof(ST);
   const uint32_t lane4 = lane * 4u;
   bool any = false, sat = false, need_exact = false, ovf = false;
