@@ -859,10 +859,11 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   uint64_t *d_st = (uint64_t *)ctx->st64.p;
   uint32_t *d_stamp = (uint32_t *)ctx->stamp.p;
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
-  HIPCHK(ctx, hipMemsetAsync(d_lf, 0, (size_t)L * 4, s));
   if (fused) {
-    // state / stamps are initialised by fused_run (it may run twice: narrow, then wide)
+    // state / stamps / status bits are initialised by fused_run (it may run twice: narrow, then wide), lv_run or the
+    // one-workgroup path
   } else {
+    HIPCHK(ctx, hipMemsetAsync(d_lf, 0, (size_t)L * 4, s));
     HIPCHK(ctx, hipMemsetAsync(d_dist, 0xFF, rows * 4, s));
     HIPCHK(ctx, hipMemsetAsync(d_hv, 0, rows * 4, s));
     hipLaunchKernelGGL(k_init_roots, dim3((L + 255) / 256), dim3(256), 0, s, n, d_dist, d_roots, L);
@@ -881,10 +882,12 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // `post` is enqueued behind every chunk of sweeps, BEFORE the host knows whether the chunk reached the fixed point:
   // work that is only needed once (the emit of the fused path) then starts without waiting for the host's round
   // trip; after a chunk that did not converge it is simply enqueued again behind the next one.
-  auto run_phase = [&](uint32_t est, auto &&launch, uint32_t &n_launch, auto &&post) -> int {
-    hipError_t er = hipMemsetAsync(d_changed, 0, (size_t)std::min<uint32_t>(CHANGED_CAP, est + 4096) * 4, s);
-    if (er != hipSuccess) { ctx->last_error = hipGetErrorString(er); return HSPF_E_HIP; }
+  // pre_zeroed: how many leading sweep flags the caller's own init kernel has already cleared (0: cleared here)
+  auto run_phase = [&](uint32_t est, uint32_t pre_zeroed, auto &&launch, uint32_t &n_launch, auto &&post) -> int {
+    hipError_t er = hipSuccess;
     uint32_t zeroed = std::min<uint32_t>(CHANGED_CAP, est + 4096);
+    if (pre_zeroed < zeroed) er = hipMemsetAsync(d_changed + pre_zeroed, 0, (size_t)(zeroed - pre_zeroed) * 4, s);
+    if (er != hipSuccess) { ctx->last_error = hipGetErrorString(er); return HSPF_E_HIP; }
     uint32_t sweep = 0, chunk = std::max(2u, est);
     for (;;) {
       if (sweep + chunk > zeroed) {
@@ -927,17 +930,16 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     auto fused_run = [&](bool nar) -> int {
       const FusedParams P = nar ? fp_narrow : fp_wide;
       const size_t esz = nar ? 4 : 8;
-      hipError_t er = hipMemsetAsync(d_lf, 0, (size_t)L * 4, s);
-      if (er == hipSuccess) er = hipMemsetAsync(d_st, 0xFF, rows * esz, s);
-      if (er == hipSuccess) er = hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s);
-      if (er == hipSuccess && count_rows) er = hipMemsetAsync(d_kcnt, 0, 256 * 4, s);
-      if (er != hipSuccess) { ctx->last_error = std::string("fused init: ") + hipGetErrorString(er); return HSPF_E_HIP; }
-      hipLaunchKernelGGL(k_fill_rowflags, dim3((unsigned)(((size_t)B * n + 255) / 256)), dim3(256), 0, s, n, B, g->d_rowflags, (uint8_t *)ctx->hnb.p);
-      if (nar) hipLaunchKernelGGL((k_init_fused<uint32_t>), dim3((L + 255) / 256), dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
-      else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 255) / 256), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
+      // one fill launch (state, stamps, row flags, sweep flags, status bits, row counter), one launch for the roots
+      const uint32_t pre_zeroed = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
+      hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, rows * esz / 16, d_stamp, (size_t)B * n,
+                         (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, pre_zeroed, d_lf, L,
+                         count_rows ? d_kcnt : (uint32_t *)nullptr);
+      if (nar) hipLaunchKernelGGL((k_init_fused<uint32_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
+      else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
       uint32_t n_f = 0;
       const bool maxinf = g->max_path_metric == HSPF_DIST_INF;
-      int r2 = run_phase(ctx->est_fused, [&](uint32_t sweep) {
+      int r2 = run_phase(ctx->est_fused, pre_zeroed, [&](uint32_t sweep) {
 #define HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, UN_, stp_) hipLaunchKernelGGL((k_fused<ST_, MI_, CN_, UN_>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, gd.in_ptr, gd.out_ptr, gd.vflags, stp_, d_roots, d_lf, net_nh, ignore_ovl, P, gd.in_src, gd.in_w, gd.out_dst, gd.e_in)
 #define HSPF_LAUNCH_FUSED(ST_, MI_, CN_, stp_) do { if (units) HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, true, stp_); else HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, false, stp_); } while (0)
         const bool units = g->n_heavy_chunks != 0;
@@ -993,7 +995,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       const bool mi = g->max_path_metric == HSPF_DIST_INF;
       const dim3 lgrid((n + 255) / 256, n_roots);
       uint32_t n_f = 0;
-      r2 = run_phase(ctx->est_lv, [&](uint32_t sweep) {
+      r2 = run_phase(ctx->est_lv, 0u, [&](uint32_t sweep) {
         la.sweep = (int)sweep;
         if (mi) hipLaunchKernelGGL((k_lv<true>), lgrid, dim3(256), 0, s, la);
         else    hipLaunchKernelGGL((k_lv<false>), lgrid, dim3(256), 0, s, la);
@@ -1083,7 +1085,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     hipLaunchKernelGGL(k_init_fw, dim3((L + 255) / 256), dim3(256), 0, s, gd, d_dist, d_stamp, d_roots, L);
     const bool mi = g->max_path_metric == HSPF_DIST_INF, hcl = g->hopcount_like;
     uint32_t n_fw = 0;
-    rc = run_phase(ctx->est_fw, [&](uint32_t sweep) {
+    rc = run_phase(ctx->est_fw, 0u, [&](uint32_t sweep) {
 #define HSPF_FW(W_) do { \
       if (hcl) { if (mi) hipLaunchKernelGGL((k_fw<(W_ <= 4 ? W_ : 1), true, true>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); \
                  else    hipLaunchKernelGGL((k_fw<(W_ <= 4 ? W_ : 1), false, true>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); } \
@@ -1105,7 +1107,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
   } else {
   uint32_t n_relax = 0;
-  rc = run_phase(ctx->est_relax, [&](uint32_t sweep) {
+  rc = run_phase(ctx->est_relax, 0u, [&](uint32_t sweep) {
     if (g->max_path_metric == HSPF_DIST_INF)
       hipLaunchKernelGGL((k_relax<true>), grid, dim3(256), 0, s, gd, d_dist, d_roots, g->max_path_metric, ignore_ovl, d_changed, (int)sweep, d_lf);
     else
@@ -1121,7 +1123,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   HIPCHK(ctx, hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s));       // activation stamps: every row due in sweep 0
   uint32_t n_dag = 0;
   uint32_t epoch = 1;
-  rc = run_phase(ctx->est_dag, [&](uint32_t sweep) {
+  rc = run_phase(ctx->est_dag, 0u, [&](uint32_t sweep) {
     if (epoch >= HV_EPOCH_MAX) {
       hipLaunchKernelGGL(k_rebase, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, d_hv, rows);
       epoch = 2;

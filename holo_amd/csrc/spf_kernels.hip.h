@@ -1239,34 +1239,47 @@ __global__ __launch_bounds__(256) void k_emit_lv(uint32_t n, const uint64_t *__r
   }
 }
 
-// Per-batch row flags = the graph's static ones (k_init_fused then adds RF_HNB).
-__global__ void k_fill_rowflags(uint32_t n, uint32_t n_batches, const uint8_t *__restrict__ rowflags, uint8_t *__restrict__ hnb) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)n * n_batches) return;
-  hnb[i] = rowflags[i % n];
+// Everything a fused run starts from, in ONE launch instead of five fills: packed state = all ones, activation stamps =
+// 0, per-batch row flags = the graph's static ones (k_init_fused then adds RF_HNB), sweep flags = 0, per-root status
+// bits = 0, row counter = 0.  (A run of 64 roots on isis-100k spent ~45 us in seven tiny launches before its first sweep.)
+__global__ __launch_bounds__(256) void k_init_fill(uint4 *__restrict__ st16, size_t n_st16, uint32_t *__restrict__ act, size_t n_act,
+                                                   const uint8_t *__restrict__ rowflags, uint8_t *__restrict__ hnb, uint32_t n,
+                                                   int *__restrict__ changed, uint32_t n_changed,
+                                                   uint32_t *__restrict__ lane_flags, uint32_t n_lf, uint32_t *__restrict__ kcnt) {
+  const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x, T = (size_t)gridDim.x * 256u;
+  const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  for (size_t i = t; i < n_st16; i += T) st16[i] = ones;
+  for (size_t i = t; i < n_act; i += T) { act[i] = 0u; hnb[i] = rowflags[i % n]; }
+  for (size_t i = t; i < n_changed; i += T) changed[i] = 0;
+  for (size_t i = t; i < n_lf; i += T) lane_flags[i] = 0u;
+  if (kcnt && t < 256) kcnt[t] = 0u;
 }
 
 // init for the fused path: roots' own lanes = (0, 0, 0); their out-neighbours are due in the
 // first sweep (id 2); out-neighbours of every vertex that can have hops == 0 for some root of the
-// batch (the root and its slot-table networks) are marked for the general row routine.
+// batch (the root and its slot-table networks) are marked for the general row routine.  One wave per root: the lanes
+// walk the out-links (a thread per root walked them one dependent load at a time: 13 us).
 template <typename ST>
-__global__ void k_init_fused(GraphDev g, ST *st, uint32_t *act, uint8_t *hnb, const uint32_t *roots,
-                             SlotTabs tabs, uint32_t n_lanes) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_init_fused(GraphDev g, ST *st, uint32_t *act, uint8_t *hnb, const uint32_t *roots,
+                                                    SlotTabs tabs, uint32_t n_lanes) {
+  const uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6, ln = threadIdx.x & 63u;
   if (i >= n_lanes) return;
   const uint32_t r = roots[i];
   if (r == INF) return;
   const uint32_t n = g.n;
   const uint32_t batch = i >> 6, lane = i & 63;
-  st[((size_t)batch * n + r) * 64 + lane] = (ST)0;
-  for (uint32_t k = g.out_ptr[r]; k < g.out_ptr[r + 1]; ++k) {
-    act[(size_t)batch * n + g.out_dst[k]] = 2u;
-    hnb[(size_t)batch * n + g.out_dst[k]] = (uint8_t)(g.rowflags[g.out_dst[k]] | RF_HNB);
+  if (ln == 0) st[((size_t)batch * n + r) * 64 + lane] = (ST)0;
+  for (uint32_t k = g.out_ptr[r] + ln; k < g.out_ptr[r + 1]; k += 64) {
+    const uint32_t d = g.out_dst[k];
+    act[(size_t)batch * n + d] = 2u;
+    hnb[(size_t)batch * n + d] = (uint8_t)(g.rowflags[d] | RF_HNB);
   }
   for (uint32_t j = tabs.ptr[i]; j < tabs.ptr[i + 1]; ++j) {
     const uint32_t h = tabs.vtx[j];
-    for (uint32_t k = g.out_ptr[h]; k < g.out_ptr[h + 1]; ++k)
-      hnb[(size_t)batch * n + g.out_dst[k]] = (uint8_t)(g.rowflags[g.out_dst[k]] | RF_HNB);
+    for (uint32_t k = g.out_ptr[h] + ln; k < g.out_ptr[h + 1]; k += 64) {
+      const uint32_t d = g.out_dst[k];
+      hnb[(size_t)batch * n + d] = (uint8_t)(g.rowflags[d] | RF_HNB);
+    }
   }
 }
 
