@@ -924,7 +924,11 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     return HSPF_OK;
   };
 
-  HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
+  // An event record is a barrier packet: two of them between kernels cost ~10 us of stream time (kernel trace, r02n).  The
+  // paths that do not have a second phase record three events per run (start, end of the sweeps, results in place)
+  // instead of six and the missing ones alias their neighbours.
+  bool two_events = !fused;                              // only k_relax + k_dag has a second timed phase
+  if (!fused) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
   if (fused) {
     const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
     auto fused_run = [&](bool nar) -> int {
@@ -958,7 +962,6 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         // results out of the packed state (speculative: valid when this chunk reached the fixed point and, for the
         // 4-byte state, no lane overflowed; otherwise redone behind the next chunk / the wide run)
         (void)hipEventRecord(ctx->ev[2], s);
-        (void)hipEventRecord(ctx->ev[3], s);
         if (nar) hipLaunchKernelGGL((k_emit_fused<uint32_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint32_t *)d_st, P, od);
         else     hipLaunchKernelGGL((k_emit_fused<uint64_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint64_t *)d_st, P, od);
       });
@@ -1001,7 +1004,6 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         else    hipLaunchKernelGGL((k_lv<false>), lgrid, dim3(256), 0, s, la);
       }, n_f, [&]() {
         (void)hipEventRecord(ctx->ev[2], s);
-        (void)hipEventRecord(ctx->ev[3], s);
         hipLaunchKernelGGL(k_emit_lv, lgrid, dim3(256), 0, s, n, (const uint64_t *)d_st, fp_wide, od);
       });
       if (r2) return r2;
@@ -1035,7 +1037,6 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       }
       hipLaunchKernelGGL(kern, dim3(n_roots), dim3(thr), lds, s, sa);
       (void)hipEventRecord(ctx->ev[2], s);
-      (void)hipEventRecord(ctx->ev[3], s);
       er = hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s);
       if (er == hipSuccess && count_rows) er = hipMemcpyAsync(ctx->h_lane_flags + L, d_kcnt, 256 * 4, hipMemcpyDeviceToHost, s);
       if (er == hipSuccess) er = hipStreamSynchronize(s);
@@ -1104,7 +1105,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     ctx->est_fw = n_fw + 1;
     st.n_relax_launches = n_fw;
     HIPCHK(ctx, hipEventRecord(ctx->ev[2], s));
-    HIPCHK(ctx, hipEventRecord(ctx->ev[3], s));
+    two_events = false;
   } else {
   uint32_t n_relax = 0;
   rc = run_phase(ctx->est_relax, 0u, [&](uint32_t sweep) {
@@ -1197,17 +1198,22 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     if (out->first_hop_mask) HIPCHK(ctx, hipMemcpyAsync(out->first_hop_mask, od.mask, rn * 8 * out_words, hipMemcpyDeviceToHost, s));
     if ((run_flags & HSPF_RUN_POP_RANK) && out->pop_rank) HIPCHK(ctx, hipMemcpyAsync(out->pop_rank, d_rank, rn * 4, hipMemcpyDeviceToHost, s));
   }
-  HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
+  if (host_out) HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
   HIPCHK(ctx, hipStreamSynchronize(s));
   {
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { ctx->last_error = std::string("kernel launch: ") + hipGetErrorString(le); return HSPF_E_HIP; }
   }
-  (void)hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[4]);
-  (void)hipEventElapsedTime(&st.ms_relax, ctx->ev[1], ctx->ev[2]);
-  (void)hipEventElapsedTime(&st.ms_dag, ctx->ev[2], ctx->ev[3]);
-  (void)hipEventElapsedTime(&st.ms_finish, ctx->ev[3], ctx->ev[4]);
-  (void)hipEventElapsedTime(&st.ms_d2h, ctx->ev[4], ctx->ev[5]);
+  {
+    hipEvent_t e1 = fused ? ctx->ev[0] : ctx->ev[1], e3 = two_events ? ctx->ev[3] : ctx->ev[2];
+    (void)hipEventElapsedTime(&st.ms_total, ctx->ev[0], ctx->ev[4]);
+    (void)hipEventElapsedTime(&st.ms_relax, e1, ctx->ev[2]);
+    st.ms_dag = 0.f;
+    if (two_events) (void)hipEventElapsedTime(&st.ms_dag, ctx->ev[2], ctx->ev[3]);
+    (void)hipEventElapsedTime(&st.ms_finish, e3, ctx->ev[4]);
+    st.ms_d2h = 0.f;
+    if (host_out) (void)hipEventElapsedTime(&st.ms_d2h, ctx->ev[4], ctx->ev[5]);
+  }
   return HSPF_OK;
 }
 
