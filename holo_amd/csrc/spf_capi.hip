@@ -604,6 +604,7 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
     case HSPF_GX_OUT_POS: src = g->d_out_fpos; bytes = kb; break;
     case HSPF_GX_ROWFLAGS: src = g->d_rowflags; bytes = g->n; break;
     case HSPF_GX_TWOWAY: bytes = g->e; break;                       // host mirror
+    case HSPF_GX_UNITS: src = g->d_unit_first; bytes = g->n_heavy_chunks ? ((size_t)g->n_heavy_chunks * 3 + (g->n + 15u) / 16u) * 4 : 0; break;
     default: ctx->last_error = "hspf_graph_export: unknown array"; return HSPF_E_INVAL;
   }
   if (out_bytes) *out_bytes = bytes;

@@ -219,6 +219,9 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows);
 #define HSPF_GX_OUT_POS  11u   /* u32 [kept]                                                      */
 #define HSPF_GX_ROWFLAGS 12u   /* u8  [n]      internal per-row flags of the fused sweep          */
 #define HSPF_GX_TWOWAY   13u   /* u8  [e]      1 = the target's row lists the source              */
+#define HSPF_GX_UNITS    14u   /* u32 [...]    work units of the sweep kernels: empty when no 16-vertex chunk holds a row
+                                  of more than 32 in-links; else [4 units per heavy chunk | 1 unit per other chunk],
+                                  each class in vertex order, entry = first vertex (| 0x80000000: one row per wave) */
 int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *dst, size_t cap_bytes,
                       size_t *out_bytes);
 

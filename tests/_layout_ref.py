@@ -43,8 +43,17 @@ def layout(row_ptr, col, metric, vflags):
         if ((w_o[a:b] == 0) & (s_o[a:b] >= t)).any():
             f |= RF_ZERO
         rowflags[t] = f
+    # work units of the sweep kernels: a 16-vertex chunk with a row of more than 32 in-links = 4 units of one row per wave
+    deg = np.diff(in_ptr)
+    nb = (n + 15) // 16
+    heavy = np.array([bool((deg[c * 16:c * 16 + 16] > 32).any()) for c in range(nb)], dtype=bool)
+    units = np.zeros(0, np.uint32)
+    if heavy.any():
+        hv = [min(c * 16 + 4 * k, n) | 0x80000000 for c in np.nonzero(heavy)[0] for k in range(4)]
+        nv = [c * 16 for c in np.nonzero(~heavy)[0]]
+        units = np.asarray(hv + nv, np.uint32)
     return {
-        "twoway": twoway,
+        "twoway": twoway, "units": units,
         "in_ptr": in_ptr.astype(np.uint32), "in_src": in_src, "in_cost": w_o.astype(np.uint32),
         "in_pos": kp[order].astype(np.uint32),
         "out_ptr": out_ptr.astype(np.uint32), "out_dst": kt.astype(np.uint32), "out_cost": kw.astype(np.uint32),

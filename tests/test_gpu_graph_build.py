@@ -12,7 +12,7 @@ from _layout_ref import layout
 
 pytestmark = pytest.mark.gpu
 
-BUILT = ("twoway", "in_ptr", "in_src", "in_cost", "in_pos", "out_ptr", "out_dst", "out_cost", "out_pos", "rowflags")
+BUILT = ("twoway", "in_ptr", "in_src", "in_cost", "in_pos", "out_ptr", "out_dst", "out_cost", "out_pos", "rowflags", "units")
 RAW = ("row_ptr", "col", "metric", "vflags")
 
 
@@ -33,9 +33,10 @@ def graphs():
     yield synth.random_lsdb(40, 1, 3.0, 4, lan_size=40)                 # one LAN with 40 members: rows > 16 links
     yield synth.random_lsdb(3000, 100, 4.0, 5, metric_hi=2, zero_cost_router_links=True)   # several scan tiles
     yield synth.ospf_500()
+    yield synth.random_lsdb(700, 9, 3.0, 6, lan_size=90)                # heavy chunks (work units) in the middle of the range
 
 
-@pytest.mark.parametrize("i", range(6))
+@pytest.mark.parametrize("i", range(7))
 def test_device_layout_matches_restatement(spf_ctx, i):
     g = list(graphs())[i]
     G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
