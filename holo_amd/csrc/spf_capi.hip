@@ -929,6 +929,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // paths that do not have a second phase record three events per run (start, end of the sweeps, results in place)
   // instead of six and the missing ones alias their neighbours.
   bool two_events = !fused;                              // only k_relax + k_dag has a second timed phase
+  bool tail_done = false;        // ev[4] sits behind the emit already and the phase's own synchronisation covered it
   if (!fused) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
   if (fused) {
     const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
@@ -965,6 +966,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         (void)hipEventRecord(ctx->ev[2], s);
         if (nar) hipLaunchKernelGGL((k_emit_fused<uint32_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint32_t *)d_st, P, od);
         else     hipLaunchKernelGGL((k_emit_fused<uint64_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint64_t *)d_st, P, od);
+        (void)hipEventRecord(ctx->ev[4], s);      // "results in place": the phase's read-back synchronises behind it
+        tail_done = true;
       });
       if (r2) return r2;
       ctx->est_fused = n_f + 1;
@@ -1006,6 +1009,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       }, n_f, [&]() {
         (void)hipEventRecord(ctx->ev[2], s);
         hipLaunchKernelGGL(k_emit_lv, lgrid, dim3(256), 0, s, n, (const uint64_t *)d_st, fp_wide, od);
+        (void)hipEventRecord(ctx->ev[4], s);
+        tail_done = true;
       });
       if (r2) return r2;
       ctx->est_lv = n_f + 1;
@@ -1189,7 +1194,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     for (uint32_t r = 0; r < n_roots; ++r)
       if (roots[r] == HSPF_NO_ROOT) HIPCHK(ctx, hipMemsetAsync(d_rank + (size_t)(row_map ? row_map[r] : r) * n, 0xFF, (size_t)n * 4, s));
   }
-  HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
+  // Nothing was enqueued behind the emit (no sequential roots, no padding ranks, device-resident results): the run is
+  // complete and synchronised already — a second event record + stream synchronisation cost 12 us per run.
+  const bool finished = tail_done && ex.empty() && !host_out && !((run_flags & HSPF_RUN_POP_RANK) && d_rank);
+  if (!finished) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
 
   // ---- results to the caller
   if (host_out) {
@@ -1200,7 +1208,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     if ((run_flags & HSPF_RUN_POP_RANK) && out->pop_rank) HIPCHK(ctx, hipMemcpyAsync(out->pop_rank, d_rank, rn * 4, hipMemcpyDeviceToHost, s));
   }
   if (host_out) HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
-  HIPCHK(ctx, hipStreamSynchronize(s));
+  if (!finished) HIPCHK(ctx, hipStreamSynchronize(s));
   {
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { ctx->last_error = std::string("kernel launch: ") + hipGetErrorString(le); return HSPF_E_HIP; }
