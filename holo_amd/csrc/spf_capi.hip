@@ -998,7 +998,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       if (er == hipSuccess && count_rows) er = hipMemsetAsync(d_kcnt, 0, 256 * 4, s);
       if (er != hipSuccess) { ctx->last_error = std::string("lv init: ") + hipGetErrorString(er); return HSPF_E_HIP; }
       hipLaunchKernelGGL(k_init_lv, dim3((n_roots + 63) / 64), dim3(64), 0, s, gd, d_st, a_stamp, d_roots, n_roots);
-      LvArgs la{gd, tabs, d_kcnt, d_roots, fp_wide, net_nh, ignore_ovl, n_roots, count_rows ? 1u : 0u, d_st, a_stamp, d_changed, 0, d_lf};
+      LvArgs la{d_changed, 0, n, a_stamp, d_st, d_roots, gd.in_ptr, gd.rowflags, gd.vflags,
+                gd, tabs, d_kcnt, fp_wide, net_nh, ignore_ovl, n_roots, count_rows ? 1u : 0u, d_lf};
       const bool mi = g->max_path_metric == HSPF_DIST_INF;
       const dim3 lgrid((n + 255) / 256, n_roots);
       uint32_t n_f = 0;

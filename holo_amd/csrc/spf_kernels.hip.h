@@ -1134,16 +1134,23 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
 // the neighbour held earlier in the run ("memory is monotone", as in k_fused).  Neighbour states are scattered 8-byte
 // gathers, which is why this layout loses against lane = root beyond a handful of roots (run_impl picks by root count).
 struct LvArgs {
-  GraphDev g;                  // by value: one kernarg fetch instead of a dependent trip through a descriptor in HBM
-  SlotTabs tabs;
-  uint32_t *rows_done;
-  const uint32_t *roots;
-  FusedParams P;               // the 8-byte state's parameters (sh = 0)
-  uint32_t net_nexthops, ignore_ovl, n_roots, count_rows;
-  uint64_t *st;                // [n_roots][n]
-  uint32_t *act;               // [n_roots][n] activation stamps
+  // the first 16 dwords are preloaded into SGPRs at wave launch (holo_amd/build.py): what the early exit and the first
+  // round trip of a thread need
   int *changed;
   int sweep;
+  uint32_t n;
+  uint32_t *act;               // [n_roots][n] activation stamps
+  uint64_t *st;                // [n_roots][n]
+  const uint32_t *roots;
+  const uint32_t *in_ptr;
+  const uint8_t *rowflags;
+  const uint8_t *vflags;
+  // the rest comes with the ordinary argument load
+  GraphDev g;
+  SlotTabs tabs;
+  uint32_t *rows_done;
+  FusedParams P;               // the 8-byte state's parameters (sh = 0)
+  uint32_t net_nexthops, ignore_ovl, n_roots, count_rows;
   uint32_t *lane_flags;
   __device__ __forceinline__ const SlotTabs &slot_tabs() const { return tabs; }
 };
@@ -1158,7 +1165,7 @@ template <bool MAXINF>
 __global__ __launch_bounds__(256) void k_lv(LvArgs a) {
   if (a.sweep > 0 && a.changed[a.sweep - 1] == 0) return;
   const GraphDev &g = a.g;
-  const uint32_t n = g.n;
+  const uint32_t n = a.n;
   const uint32_t root_slot = blockIdx.y;
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
   if (v >= n) return;
@@ -1167,8 +1174,8 @@ __global__ __launch_bounds__(256) void k_lv(LvArgs a) {
   uint64_t *S = a.st + (size_t)root_slot * n;
   const uint32_t my_root = a.roots[root_slot];
   const uint32_t av = A[v];
-  const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
-  const uint32_t rf = g.rowflags[v], vf = g.vflags[v];
+  const uint32_t e0 = a.in_ptr[v], e1 = a.in_ptr[v + 1];
+  const uint32_t rf = a.rowflags[v], vf = a.vflags[v];
   const uint64_t old = S[v];
   if (my_root == INF || av < cur || v == my_root) return;          // nothing changed around this vertex
   const FusedParams P = a.P;
