@@ -146,6 +146,68 @@ int main(int argc, char **argv) {
         CHECK(hbm[o] == best && hbe[o] == ent, "route metric / entry");
         for (u32 w = 0; w < W; ++w) CHECK(hnm[o * W + w] == acc[w], "route next-hop mask");
       }
+    // HSPF_PFX_ORDERED (OSPFv3's order-dependent fold, holo-ospf/src/route.rs:343-448): the same entries in REVERSED
+    // order inside each prefix, every second entry a network entry with an origin, an initial route for every third prefix
+    {
+      std::vector<u32> pv2(pv.size()), pm2(pm.size()), org(pv.size()), imet(P), iorg(P); std::vector<uint8_t> iex(P);
+      for (u32 p = 0; p < P; ++p) {
+        const u32 a = pptr[p], b = pptr[p + 1];
+        for (u32 e = a; e < b; ++e) {
+          const u32 src = a + (b - 1 - e);
+          pv2[e] = pv[src] | ((e & 1u) ? HSPF_PFX_ENTRY_NETWORK : 0u); pm2[e] = pm[src]; org[e] = (7 * e + p) % 5;
+        }
+        iex[p] = (p % 3 == 0) ? 1 : 0; imet[p] = 3 + p % 9; iorg[p] = p % 5;
+      }
+      hspf_prefix_table tab2{P, (u32)pv2.size(), pptr.data(), pv2.data(), pm2.data(), HSPF_PFX_SATURATING | HSPF_PFX_ORDERED,
+                             org.data(), iex.data(), imet.data(), iorg.data()};
+      u32 *bm2, *be2; uint64_t *nm2;
+      hipMalloc(&bm2, (size_t)R * P * 4); hipMalloc(&be2, (size_t)R * P * 4); hipMalloc(&nm2, (size_t)R * P * 8 * W);
+      hspf_routes ro2{bm2, be2, nm2};
+      CHECK(hspf_routes_device(eng.raw(), n, R, W, dd, df, dm, &tab2, &ro2) == HSPF_OK, "hspf_routes_device (ordered)");
+      std::vector<u32> hb2((size_t)R * P), he2((size_t)R * P); std::vector<uint64_t> hn2((size_t)R * P * W);
+      hipMemcpy(hb2.data(), bm2, hb2.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(he2.data(), be2, he2.size() * 4, hipMemcpyDeviceToHost);
+      hipMemcpy(hn2.data(), nm2, hn2.size() * 8, hipMemcpyDeviceToHost);
+      for (u32 r = 0; r < R; ++r)
+        for (u32 p = 0; p < P; ++p) {
+          bool ex = iex[p] != 0; u32 best = ex ? imet[p] : 0xFFFFFFFFu, bo = ex ? iorg[p] : 0, ent = ex ? HSPF_PFX_KEPT_INIT : 0xFFFFFFFFu;
+          std::vector<uint64_t> acc(W, 0);
+          for (u32 e = pptr[p]; e < pptr[p + 1]; ++e) {
+            const u32 v = pv2[e] & 0x7FFFFFFFu; const size_t i = (size_t)r * n + v;
+            if (!(t.flags[i] & 1)) continue;
+            const uint64_t s64 = (uint64_t)t.dist[i] + pm2[e]; const u32 mm = s64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)s64;
+            if (ex && mm > best) continue;
+            if ((pv2[e] & HSPF_PFX_ENTRY_NETWORK) && ex) { if (mm < best || (mm == best && org[e] > bo)) ex = false; else continue; }
+            if (!ex || mm < best) { ex = true; best = mm; bo = org[e]; ent = e; for (u32 w = 0; w < W; ++w) acc[w] = t.mask[i * W + w]; }
+            else for (u32 w = 0; w < W; ++w) acc[w] |= t.mask[i * W + w];
+          }
+          const size_t o = (size_t)r * P + p;
+          CHECK(hb2[o] == (ex ? best : 0xFFFFFFFFu) && he2[o] == ent, "ordered fold: metric / owner entry");
+          for (u32 w = 0; w < W; ++w) CHECK(hn2[o * W + w] == acc[w], "ordered fold: next-hop mask");
+        }
+      // RIB diff (update_global_rib's comparison, holo-isis/src/route.rs:254-312): the IS-IS table against the ordered one
+      uint8_t *act; u32 *chg, *cptr;
+      hipMalloc(&act, (size_t)R * P); hipMalloc(&chg, (size_t)R * P * 4); hipMalloc(&cptr, ((size_t)R + 1) * 4);
+      CHECK(hspf_routes_diff_device(eng.raw(), R, P, W, &ro, &ro2, act, chg, cptr) == HSPF_OK, "hspf_routes_diff_device");
+      std::vector<uint8_t> ha((size_t)R * P); std::vector<u32> hc((size_t)R * P), hp(R + 1);
+      hipMemcpy(ha.data(), act, ha.size(), hipMemcpyDeviceToHost); hipMemcpy(hc.data(), chg, hc.size() * 4, hipMemcpyDeviceToHost);
+      hipMemcpy(hp.data(), cptr, hp.size() * 4, hipMemcpyDeviceToHost);
+      u32 pos = 0;
+      for (u32 r = 0; r < R; ++r) {
+        CHECK(hp[r] == pos, "diff: changed_ptr");
+        for (u32 p = 0; p < P; ++p) {
+          const size_t o = (size_t)r * P + p;
+          const bool had = hbe[o] != 0xFFFFFFFFu, has = he2[o] != 0xFFFFFFFFu;
+          bool same = true, onh = false, nnh = false;
+          for (u32 w = 0; w < W; ++w) { same = same && hnm[o * W + w] == hn2[o * W + w]; onh = onh || hnm[o * W + w]; nnh = nnh || hn2[o * W + w]; }
+          u32 a = has ? ((had && hbm[o] == hb2[o] && same) ? HSPF_DIFF_SAME : (nnh ? HSPF_DIFF_INSTALL : HSPF_DIFF_SILENT))
+                      : (had ? (onh ? HSPF_DIFF_WITHDRAW : HSPF_DIFF_SILENT) : HSPF_DIFF_SAME);
+          CHECK(ha[o] == a, "diff: action");
+          if (a == HSPF_DIFF_INSTALL || a == HSPF_DIFF_WITHDRAW) { CHECK(hc[pos] == p, "diff: compacted index"); ++pos; }
+        }
+      }
+      CHECK(hp[R] == pos, "diff: total");
+      hipFree(bm2); hipFree(be2); hipFree(nm2); hipFree(act); hipFree(chg); hipFree(cptr);
+    }
     hipFree(dd); hipFree(dh); hipFree(df); hipFree(dm); hipFree(bm); hipFree(be); hipFree(nm);
   }
   // incremental update: rows replaced through hspf::Graph::patch, results against the oracle on the patched CSR
