@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <new>
 #include <string>
 #include <vector>
@@ -60,6 +61,7 @@ struct hspf_graph {
   uint8_t *d_vflags = nullptr, *d_rowflags = nullptr;
   uint32_t *d_unit_first = nullptr;                               // work units (GraphDev::unit_first), n / 4 + 4 entries
   uint32_t n_heavy_chunks = 0;                                    // > 0: the kernels go through unit_first
+  uint64_t build_id = 0;                                          // changes with every device build (upload, patch)
   // Carves the arrays out of `base` for n vertices / cap links; returns the bytes needed.
   size_t layout(char *base, uint32_t nv, uint32_t cap) {
     size_t off = 0;
@@ -123,6 +125,9 @@ struct hspf_ctx {
   uint32_t lv_max_roots = 2;               // HSPF_LV_MAX_ROOTS env: runs of at most this many roots take the lane = vertex kernel (0: never)
   uint32_t lv_min_n = 32768;               // HSPF_LV_MIN_N env: ... on graphs of at least this many vertices
   uint32_t est_lv = 24;
+  // A fused run's scratch, filled for the NEXT run behind this one's results (k_init_fill costs 14 us at the head of a
+  // run, and the GPU idles for longer than that while the host turns a run around): valid for exactly these parameters
+  struct Prefill { bool valid = false; uint64_t build_id = 0; uint32_t n = 0, B = 0, esz = 0, n_changed = 0, L = 0; bool kcnt = false; } prefill;
   uint32_t unit_heavy_deg = UNIT_HEAVY_DEG; // HSPF_UNIT_HEAVY_DEG env: a chunk with a row of more in-links than this runs one row per wave
   uint32_t xcd_row_cost = 8;               // HSPF_XCD_ROW_COST env: fixed cost of a row, in links, when the XCD ranges are cut
   hspf_stats stats = {};
@@ -159,6 +164,7 @@ int guarded(hspf_ctx *ctx, F &&body) {
 
 int ensure(hspf_ctx *ctx, DevBuf &b, size_t bytes) {
   if (bytes <= b.cap) return HSPF_OK;
+  ctx->prefill.valid = false;
   if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
   size_t want = bytes + bytes / 8;
   hipError_t e = hipMalloc(&b.p, want);
@@ -314,6 +320,7 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   }
   for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
   g->n_heavy_chunks = bi.n_heavy;
+  { static std::atomic<uint64_t> next_build{1}; g->build_id = next_build.fetch_add(1); }
   g->narrow_bad = false;
   g->wide24_bad = false;
   return HSPF_OK;
@@ -408,7 +415,9 @@ void hspf_shutdown(hspf_ctx *ctx) {
 int hspf_set_stream(hspf_ctx *ctx, void *hip_stream) {
   if (!ctx) return HSPF_E_INVAL;
   (void)hipSetDevice(ctx->device);
-  if (ctx->own_stream && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);        // (a prefill of the next run may still be in flight)
+  ctx->prefill.valid = false;
+  if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   ctx->stream = (hipStream_t)hip_stream;
   ctx->own_stream = false;
   return HSPF_OK;
@@ -716,6 +725,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   hspf_stats &st = ctx->stats;
   st = hspf_stats{};
   st.n_roots = n_roots; st.n_batches = B;
+  hspf_ctx::Prefill pf = ctx->prefill;      // what the previous run left for this one; whoever does not take it loses it
+  ctx->prefill.valid = false;
 
   // ---- slot tables (host, O(deg) per root) and mask width
   std::vector<uint32_t> &tab_ptr = ctx->hb_tab_ptr, &tab_vtx = ctx->hb_tab_vtx, &tab_base = ctx->hb_tab_base;
@@ -933,14 +944,21 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if (!fused) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
   if (fused) {
     const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
+    uint32_t last_esz = 0;                    // state width of the last fused_run (0: none ran)
     auto fused_run = [&](bool nar) -> int {
       const FusedParams P = nar ? fp_narrow : fp_wide;
       const size_t esz = nar ? 4 : 8;
       // one fill launch (state, stamps, row flags, sweep flags, status bits, row counter), one launch for the roots
-      const uint32_t pre_zeroed = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
-      hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, rows * esz / 16, d_stamp, (size_t)B * n,
-                         (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, pre_zeroed, d_lf, L,
-                         count_rows ? d_kcnt : (uint32_t *)nullptr);
+      uint32_t pre_zeroed = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
+      const bool have = pf.valid && pf.build_id == g->build_id && pf.n == n && pf.B == B && pf.esz == (uint32_t)esz &&
+                        pf.L == L && (pf.kcnt || !count_rows) && pf.n_changed >= std::min<uint32_t>(CHANGED_CAP, 2u);
+      pf.valid = false;
+      if (have) pre_zeroed = pf.n_changed;      // run_phase clears whatever it needs beyond that
+      else
+        hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, rows * esz / 16, d_stamp, (size_t)B * n,
+                           (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, pre_zeroed, d_lf, L,
+                           count_rows ? d_kcnt : (uint32_t *)nullptr);
+      last_esz = (uint32_t)esz;
       if (nar) hipLaunchKernelGGL((k_init_fused<uint32_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
       else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
       uint32_t n_f = 0;
@@ -1075,6 +1093,13 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       }
     }
     st.state_bytes = narrow ? 4 : 8;
+    if (last_esz && !(ctx->variant & 2048u)) {
+      // the next run's scratch, behind this one's emit (same shape assumed: an SPF instance repeats its root set)
+      const uint32_t nz = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
+      hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, rows * last_esz / 16, d_stamp, (size_t)B * n,
+                         (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, nz, d_lf, L, d_kcnt);
+      ctx->prefill = hspf_ctx::Prefill{true, g->build_id, n, B, last_esz, nz, L, true};
+    }
   } else {
   // More than 24 first-hop slots: two ways.  k_fw = ONE fused fixed point over (distance, hops, W mask words): half the
   // launches, but a label-correcting sweep re-reads the masks of ALL in-links of a row every time the row is revisited.

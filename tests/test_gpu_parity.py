@@ -298,6 +298,36 @@ def test_heavy_chunks_become_one_row_per_wave_work_units(spf_ctx, n, hubs):
     check(spf_ctx, g, [leaf_roots[0]], expect_exact=False)
 
 
+@sweeps_engine
+def test_scratch_prefilled_for_the_next_run_is_only_taken_when_it_fits(spf_ctx):
+    """A fused run leaves the NEXT run's scratch filled behind its results (state, stamps, per-batch row flags of ITS
+    graph).  Alternating two graphs of the same size whose row flags differ (overloaded sources / none), a patch in
+    between, another root count and the other state width: every run against the oracle."""
+    ga = synth.random_lsdb(300, 12, 3.0, 4242, metric_hi=5, p_overload=0.25)
+    gb = synth.random_lsdb(300, 12, 3.0, 4243, metric_hi=5, p_overload=0.0)
+    assert ga.n == gb.n
+    roots = list(range(12, 12 + 64))
+    Ga = spf_ctx.upload(ga.row_ptr, ga.col, ga.metric, ga.vflags, ga.max_path_metric)
+    Gb = spf_ctx.upload(gb.row_ptr, gb.col, gb.metric, gb.vflags, gb.max_path_metric)
+    try:
+        for it in range(3):
+            for G, g in ((Ga, ga), (Gb, gb), (Gb, gb), (Ga, ga)):
+                for rs in (roots, roots[:40], roots + roots[:30]):
+                    res = spf_ctx.run(G, rs, 0)
+                    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, np.asarray(rs, np.uint32), 0, go.HEAP,
+                                 mask_words_=res.first_hop_mask.shape[2])
+                    assert np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops)
+                    assert np.array_equal(res.first_hop_mask, ref.mask)
+            # replace one row of ga: same vertex count, other row flags
+            v = 20 + it
+            cols = ga.col[ga.row_ptr[v]:ga.row_ptr[v + 1]].copy(); mets = ga.metric[ga.row_ptr[v]:ga.row_ptr[v + 1]].copy() + 1
+            nf = np.uint8(int(ga.vflags[v]) ^ synth.VF_NO_TRANSIT)
+            Ga.patch([v], [(cols, mets)], [nf])
+            ga = synth.CsrGraph(Ga.row_ptr.copy(), Ga.col.copy(), Ga.metric.copy(), Ga.vflags.copy(), ga.max_path_metric)
+    finally:
+        Ga.free(); Gb.free()
+
+
 def _properties(g, roots, res, sample, variant=go.HEAP, run_flags=0):
     """Full-size check: the roots in `sample` (None: ALL of them) bit for bit against the oracle, all roots through
     size-independent properties (root at distance 0, fixed point of relaxation on every kept link,
