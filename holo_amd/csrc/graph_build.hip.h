@@ -40,7 +40,8 @@ struct BuildInfo {       // device-resident summary of one build, copied back on
   uint32_t xcd_start[9]; // GraphDev::xcd_start: work-balanced chunk ranges of the 8 XCDs (no heavy chunk), else even
                          // shares of the normal units
   uint32_t n_heavy;      // heavy 16-vertex chunks (a row of more than UNIT_HEAVY_DEG in-links): 4 work units each
-  uint32_t pad[1];
+  uint32_t max_in_deg;   // largest kept in-degree
+  uint32_t any_rowflags; // OR of the rows' static flags (RF_*)
 };
 
 constexpr int GB_BLOCK = 256;
@@ -240,6 +241,8 @@ kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__r
     else bad |= w != 1u;
   }
   rowflags[t] = (uint8_t)f;
+  atomicMax(&info->max_in_deg, b - a);
+  if (f) atomicOr(&info->any_rowflags, f);
   if (bad) info->hc_bad = 1u;                 // plain stores: every writer stores the same value
   if (net && b > a) info->hc_net = 1u;
 }

@@ -62,6 +62,8 @@ struct hspf_graph {
   uint32_t *d_unit_first = nullptr;                               // work units (GraphDev::unit_first), n / 4 + 4 entries
   uint32_t n_heavy_chunks = 0;                                    // > 0: the kernels go through unit_first
   uint64_t build_id = 0;                                          // changes with every device build (upload, patch)
+  uint32_t max_in_deg = 0;                                        // largest kept in-degree
+  bool lean = false;                                              // no network vertex, no static row flag, in-degrees <= 8: k_single_lean
   // Carves the arrays out of `base` for n vertices / cap links; returns the bytes needed.
   size_t layout(char *base, uint32_t nv, uint32_t cap) {
     size_t off = 0;
@@ -249,7 +251,8 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   const size_t le = (size_t)e + 16;
   const size_t nsums = (size_t)std::max(e, n) / GB_TILE + 4;
   // scratch: src_of, kpre, tmp_w, tmp_src, tmp_fpos, tmp_t (u32 x le each) | in_cnt (n+1) | sums | info | keep, twoway (u8)
-  const size_t words = 6 * le + (size_t)n + 17 + nsums + 16;
+  static_assert(sizeof(BuildInfo) <= 32 * 4, "BuildInfo scratch slot");
+  const size_t words = 6 * le + (size_t)n + 17 + nsums + 32;
   const size_t bytes = words * 4 + 2 * le + 64;
   int rc = ensure(ctx, ctx->gb, bytes);
   if (rc != HSPF_OK) return rc;
@@ -262,7 +265,7 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   uint32_t *tmp_t = w; w += le;
   uint32_t *in_cnt = w; w += (size_t)n + 17;
   uint32_t *sums = w; w += nsums;
-  BuildInfo *info = (BuildInfo *)w; w += 16;
+  BuildInfo *info = (BuildInfo *)w; w += 32;
   uint8_t *keep = (uint8_t *)w;
   uint8_t *twoway = keep + le;
   const uint32_t *row_ptr = g->d_row_ptr[g->cur], *col = g->d_col[g->cur], *metric = g->d_metric[g->cur];
@@ -320,6 +323,12 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   }
   for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
   g->n_heavy_chunks = bi.n_heavy;
+  g->max_in_deg = bi.max_in_deg;
+  {
+    bool any_net = false;
+    for (uint32_t v = 0; v < n && !any_net; ++v) any_net = (g->vflags[v] & HSPF_VF_NETWORK) != 0;
+    g->lean = !any_net && bi.any_rowflags == 0 && bi.max_in_deg <= SINGLE_RL && !g->hopcount_like;
+  }
   { static std::atomic<uint64_t> next_build{1}; g->build_id = next_build.fetch_add(1); }
   g->narrow_bad = false;
   g->wide24_bad = false;
@@ -1060,6 +1069,12 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SINGLE_LDS_MAX);
         ctx->single_attr |= 1u << slot;
       }
+      // the plainest graphs (routers only, no row flag, in-degrees <= 8) with one vertex per thread: the lean kernel
+      const bool lean = g->lean && n <= (uint32_t)SINGLE_THREADS && !(ctx->variant & 4096u);
+      if (lean) {
+        if (mi) hipLaunchKernelGGL((k_single_lean<true>), dim3(n_roots), dim3(thr), (size_t)n * 8, s, sa);
+        else    hipLaunchKernelGGL((k_single_lean<false>), dim3(n_roots), dim3(thr), (size_t)n * 8, s, sa);
+      } else
       hipLaunchKernelGGL(kern, dim3(n_roots), dim3(thr), lds, s, sa);
       (void)hipEventRecord(ctx->ev[2], s);
       er = hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s);
@@ -1070,7 +1085,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       st.n_relax_launches = 1; st.single_wg = 1;
       if (count_rows) {
         for (uint32_t i = 0; i < 128; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
-        for (uint32_t i = 0; i < 3; ++i) st.dbg[i] = ctx->h_lane_flags[L + 128 + i];   // sweeps, shader cycles, 100 MHz ticks of workgroup 0
+        for (uint32_t i = 0; i < 4; ++i) st.dbg[i] = ctx->h_lane_flags[L + 128 + i];   // sweeps, shader cycles, 100 MHz ticks, set-up cycles of workgroup 0
       }
       narrow = false;
     } else if (lv) {

@@ -951,6 +951,8 @@ __host__ __device__ inline size_t single_lds_bytes(uint32_t n, uint32_t e, bool 
 }
 
 constexpr uint32_t SINGLE_VPT_MAX = SINGLE_MAX_N / SINGLE_THREADS;     // vertices per thread at most (8)
+constexpr uint32_t SINGLE_RL = 8;                                      // in-links a thread keeps in registers
+constexpr uint32_t SINGLE_FREE = 7;                                    // free-running sweeps between two checked ones
 
 // One link into the row accumulator: the per-lane form of fused_row_any's loop body.  RARE = the row has an
 // overloaded source, a zero-cost link from a higher-numbered source, or the graph is hop-count-like.
@@ -1041,12 +1043,79 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
       cur[i] = (v == my_root) ? 0ull : ~0ull;
     }
   }
+  // One vertex per thread (the reference's own 500-router case): a PLAIN vertex — at most SINGLE_RL in-links, none of
+  // the rare conditions, no source that can have hops == 0 (the root, a network vertex) — keeps its link records in
+  // REGISTERS for the whole run and takes the lean accumulation (acc_link): a sweep is then one LDS round trip (the
+  // sources' words) plus ~15 vector instructions per link, instead of two round trips and the general per-link routine
+  // (51 sweeps on ospf-500: 3 700 -> ~1 000 cycles each).
+  uint32_t ls[SINGLE_RL], lw[SINGLE_RL], lb[SINGLE_RL];   // source, cost, slot bit of a link out of the ROOT (its word is 0:
+  bool plain = false;                                      // OR-ing the bit into the pay bits is the whole "direct" case)
+  if (SINGLE_VPT == 1) {
+    const uint32_t v = tid;
+#pragma unroll
+    for (uint32_t k = 0; k < SINGLE_RL; ++k) { ls[k] = min(v, n - 1u); lw[k] = INF; lb[k] = 0u; }
+    if (v < n && v != my_root) {
+      const uint32_t e0 = ce0[0], e1 = ce1[0] & 0x3FFFFFFFu;
+      const bool v_rt = !(ce1[0] >> 31);
+      plain = !(ce1[0] & 0x40000000u) && e1 - e0 <= SINGLE_RL;
+#pragma unroll
+      for (uint32_t k = 0; k < SINGLE_RL; ++k)
+        if (e0 + k < e1) {
+          ls[k] = g.in_src[e0 + k] & SRC_MASK; lw[k] = g.in_w[e0 + k];
+          plain = plain && !(g.vflags[ls[k]] & 1u);           // a network source may have hops == 0: general routine
+          if (ls[k] == my_root) {
+            const uint32_t sidx = g.in_fpos[e0 + k];          // the root's slot base is 0
+            lb[k] = ((v_rt || a.net_nexthops) && sidx < P.mbits) ? (1u << sidx) : 0u;
+          }
+        }
+    }
+  }
   __syncthreads();
   bool sat = false, need_exact = false, ovf = false;
   const uint32_t max_sweeps = 4u * n + 64u;        // far beyond any run; a run that gets there is handed to k_exact
   uint32_t sweep = 0;
+  const uint64_t t_loop0 = clock64();
+  // Sweeps run FREE in groups of SINGLE_FREE: no barrier, no flag — reads of a neighbour's word race with its owner's
+  // write anyway, a stale word is a word the neighbour held earlier, and values only decrease — then one CHECKED sweep
+  // between two barriers: it starts after every write of the free sweeps is visible, and if no thread changes anything
+  // in it, every thread has read the final state.  (A barrier + flag round trip per sweep was half of a sweep's time on
+  // the 500-router case.)
   for (;; ++sweep) {
+    const bool checked = sweep % (SINGLE_FREE + 1u) == SINGLE_FREE;
+    const uint32_t round = sweep / (SINGLE_FREE + 1u);
+    if (checked) __syncthreads();
     bool any = false;
+    if (SINGLE_VPT == 1 && plain) {
+      const uint32_t v = tid;
+      uint64_t qs[SINGLE_RL];
+#pragma unroll
+      for (uint32_t k = 0; k < SINGLE_RL; ++k) qs[k] = s_st[ls[k]];
+      // two passes as in row16_compute (independent per-link work, short dependency chains: two waves per SIMD cannot
+      // hide a 50-deep chain): candidates and their minimum, then the tight links — the in-row order (cost descending,
+      // source ascending) makes the FIRST tight link the first discoverer, so the walk goes backwards and overwrites
+      uint32_t c[SINGLE_RL];
+      bool sat1 = false;
+#pragma unroll
+      for (uint32_t k = 0; k < SINGLE_RL; ++k) {
+        const uint32_t d = (uint32_t)(qs[k] >> 32);
+        c[k] = add_sat(d, lw[k]);                                // padding links cost all ones: never reached
+        if (MAXINF && c[k] == INF && d != INF && lw[k] != INF) sat1 = true;
+      }
+      const uint32_t bd = min(min(min(c[0], c[1]), min(c[2], c[3])), min(min(c[4], c[5]), min(c[6], c[7])));
+      static_assert(SINGLE_RL == 8, "min tree");
+      uint32_t macc = 0u, bpay = 0u;
+#pragma unroll
+      for (int k = (int)SINGLE_RL - 1; k >= 0; --k) {
+        const bool t = c[k] == bd;
+        const uint32_t pb = (uint32_t)qs[k] | lb[k];
+        macc |= t ? pb : 0u;
+        bpay = t ? pb : bpay;
+      }
+      RowAcc r{bd, macc & mmask, 0u, bpay >> P.mbits, sat1};
+      const RowOut<uint64_t> o = finish_row<uint64_t>(r, v, my_root, (ce1[0] >> 31) ^ 1u, INF, P);
+      sat = sat || o.sat; ovf = ovf || o.ovf;
+      if (o.nw != cur[0]) { cur[0] = o.nw; s_st[v] = o.nw; any = true; }
+    } else
 #pragma unroll
     for (uint32_t i = 0; i < SINGLE_VPT; ++i) {
       const uint32_t v = tid + i * nthr;
@@ -1084,13 +1153,14 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
       sat = sat || o.sat; need_exact = need_exact || o.need_exact; ovf = ovf || o.ovf;
       if (o.nw != cur[i]) { cur[i] = o.nw; s_st[v] = o.nw; any = true; }
     }
-    // ONE barrier per sweep: flag slot sweep & 3 is set during sweep `sweep`, read after its barrier, and cleared by
-    // thread 0 during sweep + 2 — after every thread has passed the barrier of sweep + 1 and therefore finished reading
-    // it, and two barriers before sweep + 4 sets it again.
-    if (any) s_changed[sweep & 3u] = 1;
-    if (tid == 0) s_changed[(sweep + 2u) & 3u] = 0;
+    if (!checked) continue;
+    // flag slot round & 3 is set during the checked sweep of `round`, read after its barrier, and cleared by thread 0
+    // during round + 2 — after every thread has passed the barriers of round + 1 and therefore finished reading it, and
+    // long before round + 4 sets it again.
+    if (any) s_changed[round & 3u] = 1;
+    if (tid == 0) s_changed[(round + 2u) & 3u] = 0;
     __syncthreads();
-    if (s_changed[sweep & 3u] == 0) break;
+    if (s_changed[round & 3u] == 0) break;
     if (sweep >= max_sweeps) { need_exact = true; break; }
   }
   // results: one row of the row-major outputs per root, consecutive threads = consecutive vertices
@@ -1116,6 +1186,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
       a.gp->rows_done[128] = sweep + 1u;
       a.gp->rows_done[129] = (uint32_t)(clock64() - t_clk0);
       a.gp->rows_done[130] = (uint32_t)(wall_clock64() - t_wall0);
+      a.gp->rows_done[131] = (uint32_t)(t_loop0 - t_clk0);          // cycles before the first sweep (staging, set-up)
     }
   }
 }
@@ -1243,6 +1314,126 @@ __global__ __launch_bounds__(256) void k_emit_lv(uint32_t n, const uint64_t *__r
   if (o.mask) {
     o.mask[idx * o.out_words] = in ? (uint64_t)(pay & ((1u << P.mbits) - 1u)) : 0ull;
     for (uint32_t k = 1; k < o.out_words; ++k) o.mask[idx * o.out_words + k] = 0;
+  }
+}
+
+// k_single_lean — the reference's own case in its plainest form (BASELINE configs[0]: 500 routers, p2p links): a graph
+// without network vertices, without any static row flag (no overloaded source, no zero-cost link from a higher-numbered
+// source, in-degrees <= SINGLE_RL) and not hop-count-like (hspf_graph::lean).  One workgroup per root, ONE vertex per
+// thread, the vertex' link records in registers for the whole run, the 8-byte words of all vertices in LDS; a sweep is
+// one LDS round trip (the sources' words), the two-pass row routine on registers (candidates + minimum, then the tight
+// links walked backwards: in-row order makes the first tight link the first discoverer) and one LDS store.  A link out
+// of the ROOT contributes its first-hop slot bit instead of the root's (empty) mask: the root's word is 0, so OR-ing the
+// precomputed bit into the loaded pay bits is the whole `hops == 0` case.  Sweeps run free in groups of SINGLE_FREE
+// between checked ones (see k_single).  k_single carries the general routine next to this path and spills its scalar
+// state around every sweep; alone, the loop is ~70 vector instructions.
+template <bool MAXINF>
+__global__ __launch_bounds__(SINGLE_THREADS) void k_single_lean(SingleArgs a) {
+  extern __shared__ uint64_t s_st[];
+  __shared__ int s_changed[4];
+  const GraphDev &g = a.gp->g;
+  const uint32_t n = g.n;
+  const uint32_t root_slot = blockIdx.x;
+  const uint32_t my_root = a.roots[root_slot];
+  const uint32_t v = threadIdx.x;
+  const FusedParams P = a.P;
+  const uint32_t mmask = (1u << P.mbits) - 1u;
+  const size_t orow = a.o.row(root_slot) * (size_t)n;
+  const bool mine = v < n;
+  if (my_root == INF) {                            // padding root: empty SPT
+    if (mine) {
+      a.o.dist[orow + v] = INF;
+      if (a.o.hops) a.o.hops[orow + v] = 0;
+      if (a.o.flags) a.o.flags[orow + v] = 0;
+      if (a.o.mask) for (uint32_t k = 0; k < a.o.out_words; ++k) a.o.mask[(orow + v) * a.o.out_words + k] = 0;
+    }
+    return;
+  }
+  const uint64_t t_clk0 = clock64(), t_wall0 = wall_clock64();
+  uint32_t ls[SINGLE_RL], lw[SINGLE_RL], lb[SINGLE_RL];
+  const uint32_t vc = min(v, n - 1u);
+  const uint32_t e0 = g.in_ptr[vc], e1 = mine ? g.in_ptr[vc + 1] : e0;
+  const uint32_t v_router = 1u;                    // no network vertices in a lean graph
+#pragma unroll
+  for (uint32_t k = 0; k < SINGLE_RL; ++k) {
+    const bool in = e0 + k < e1;
+    const uint32_t e = in ? e0 + k : e0;           // (arrays are padded: e0 is readable even for an empty row)
+    const uint32_t sv = g.in_src[e] & SRC_MASK, wv = g.in_w[e], fp = g.in_fpos[e];
+    ls[k] = in ? sv : vc;
+    lw[k] = in ? wv : INF;                         // padding: a candidate of all ones, never reached
+    lb[k] = (in && sv == my_root && fp < P.mbits) ? (1u << fp) : 0u;   // the root's slot base is 0
+  }
+  uint64_t cur = (mine && v == my_root) ? 0ull : ~0ull;
+  if (mine) s_st[v] = cur;
+  if (v < 4) s_changed[v] = 0;
+  __syncthreads();
+  const bool live = mine && v != my_root;
+  bool sat = false, ovf = false, need_exact = false;
+  const uint32_t max_sweeps = 4u * n + 64u;
+  uint32_t sweep = 0;
+  const uint64_t t_loop0 = clock64();
+  for (;; ++sweep) {
+    const bool checked = sweep % (SINGLE_FREE + 1u) == SINGLE_FREE;
+    const uint32_t round = sweep / (SINGLE_FREE + 1u);
+    if (checked) __syncthreads();
+    bool any = false;
+    if (live) {
+      uint64_t qs[SINGLE_RL];
+#pragma unroll
+      for (uint32_t k = 0; k < SINGLE_RL; ++k) qs[k] = s_st[ls[k]];
+      uint32_t c[SINGLE_RL];
+      bool sat1 = false;
+#pragma unroll
+      for (uint32_t k = 0; k < SINGLE_RL; ++k) {
+        const uint32_t d = (uint32_t)(qs[k] >> 32);
+        c[k] = add_sat(d, lw[k]);
+        if (MAXINF && c[k] == INF && d != INF && lw[k] != INF) sat1 = true;
+      }
+      const uint32_t bd = min(min(min(c[0], c[1]), min(c[2], c[3])), min(min(c[4], c[5]), min(c[6], c[7])));
+      static_assert(SINGLE_RL == 8, "min tree");
+      uint32_t macc = 0u, bpay = 0u;
+#pragma unroll
+      for (int k = (int)SINGLE_RL - 1; k >= 0; --k) {
+        const bool t = c[k] == bd;
+        const uint32_t pb = (uint32_t)qs[k] | lb[k];
+        macc |= t ? pb : 0u;
+        bpay = t ? pb : bpay;
+      }
+      RowAcc r{bd, macc & mmask, 0u, bpay >> P.mbits, sat1};
+      const RowOut<uint64_t> o = finish_row<uint64_t>(r, v, my_root, v_router, INF, P);
+      sat = sat || o.sat; ovf = ovf || o.ovf;
+      if (o.nw != cur) { cur = o.nw; s_st[v] = o.nw; any = true; }
+    }
+    if (!checked) continue;
+    if (any) s_changed[round & 3u] = 1;
+    if (v == 0) s_changed[(round + 2u) & 3u] = 0;
+    __syncthreads();
+    if (s_changed[round & 3u] == 0) break;
+    if (sweep >= max_sweeps) { need_exact = true; break; }
+  }
+  if (mine) {
+    const bool in = cur != ~0ull;
+    const uint32_t pay = (uint32_t)cur;
+    a.o.dist[orow + v] = in ? (uint32_t)(cur >> 32) : INF;
+    if (a.o.hops) a.o.hops[orow + v] = in ? (uint16_t)(pay >> P.mbits) : (uint16_t)0;
+    if (a.o.flags) a.o.flags[orow + v] = in ? 1 : 0;
+    if (a.o.mask) {
+      a.o.mask[(orow + v) * a.o.out_words] = in ? (uint64_t)(pay & mmask) : 0ull;
+      for (uint32_t k = 1; k < a.o.out_words; ++k) a.o.mask[(orow + v) * a.o.out_words + k] = 0;
+    }
+  }
+  uint32_t lf = 0;
+  if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
+  if (ovf) lf |= LF_OVERFLOW;
+  if (lf) atomicOr(&a.lane_flags[root_slot], lf);
+  if (a.count_rows && v == 0) {
+    atomicAdd(&a.gp->rows_done[root_slot & 127u], (sweep + 1u) * n);
+    if (root_slot == 0) {
+      a.gp->rows_done[128] = sweep + 1u;
+      a.gp->rows_done[129] = (uint32_t)(clock64() - t_clk0);
+      a.gp->rows_done[130] = (uint32_t)(wall_clock64() - t_wall0);
+      a.gp->rows_done[131] = (uint32_t)(t_loop0 - t_clk0);
+    }
   }
 }
 

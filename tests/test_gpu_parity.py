@@ -298,6 +298,26 @@ def test_heavy_chunks_become_one_row_per_wave_work_units(spf_ctx, n, hubs):
     check(spf_ctx, g, [leaf_roots[0]], expect_exact=False)
 
 
+@pytest.mark.parametrize("rows,cols,chords,maxpath", [(20, 25, 0, synth.MAX_PATH_METRIC_OSPF), (8, 9, 20, synth.MAX_PATH_METRIC_WIDE),
+                                                      (30, 33, 60, synth.MAX_PATH_METRIC_OSPF), (1, 2, 0, synth.MAX_PATH_METRIC_WIDE),
+                                                      (5, 5, 0, 40)])
+def test_lean_graphs_take_the_register_resident_kernel(spf_ctx, rows, cols, chords, maxpath):
+    """Router-only graphs without row flags and with in-degrees <= 8 (hspf_graph::lean: the reference's 500-router
+    benchmark shape) run k_single_lean: one vertex per thread, links in registers, free-running sweeps.  Corner, centre
+    and every-vertex root sets, tie-heavy costs, a tight max path metric; against the oracle."""
+    n = rows * cols
+    links = synth._grid4_links(rows, cols)
+    if chords:
+        links = synth._add_chords(n, links, len(links) + chords, 17 + n)
+    g = synth._routers_only(n, links, 99 + n, 1, 4, maxpath, f"lean-{n}", {})
+    deg = np.diff(g.row_ptr.astype(np.int64))
+    if deg.max() > 8:
+        pytest.skip("a chord made a vertex too wide for the lean kernel")
+    for roots in ([0], [n - 1, n // 2], list(range(n))[:96]):
+        res, ref = check(spf_ctx, g, roots, expect_exact=False)
+        assert res.stats["single_wg"] == 1
+
+
 @sweeps_engine
 def test_scratch_prefilled_for_the_next_run_is_only_taken_when_it_fits(spf_ctx):
     """A fused run leaves the NEXT run's scratch filled behind its results (state, stamps, per-batch row flags of ITS
