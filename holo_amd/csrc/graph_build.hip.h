@@ -19,6 +19,17 @@
 //   kb_rowflags  per-row static flags for the fused sweep; hop-count shape of the graph; pads.
 //   kb_splice    (patch) new raw CSR = old rows, except the replaced ones taken from the delta.
 //
+// Hub mode (some row lists more than HUB_DEG links — a LAN pseudonode with thousands of members): the per-link row scans
+// of kb_links and kb_rank would be quadratic in such a row, so the same layout is derived from two stable device-wide
+// radix sorts (hub_sort.h) instead:
+//   kb_hub_keys     key (source, target) per link -> sorted: every row's targets ascending, rows in place
+//   kb_hub_links    kb_links with the two-way check as a binary search in the target's sorted row
+//   kb_hub_scatter  forward arrays as kb_scatter; key (target, ~cost) per kept link in forward order (= source, position
+//                   ascending), dropped links keyed behind all kept ones -> stable sort = the in-row order of kb_rank
+//   kb_hub_in_ptr   in-row bounds = first sorted key of every target (no in-degree histogram: no atomics on a hub's counter)
+//   kb_hub_gather   in-link arrays from the sorted keys and the permutation
+// Every per-link step is then O(log degree).  The layouts of the two modes are identical array by array.
+//
 // Everything is integer streaming work bound by HBM / L2 bandwidth; no MFMA, no LDS tiling beyond the scans.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -43,6 +54,8 @@ struct BuildInfo {       // device-resident summary of one build, copied back on
   uint32_t max_in_deg;   // largest kept in-degree
   uint32_t any_rowflags; // OR of the rows' static flags (RF_*)
 };
+
+constexpr uint32_t HUB_DEG = 512;        // rows with more links than this: hub mode (HSPF_HUB_DEG)
 
 constexpr int GB_BLOCK = 256;
 constexpr int GB_ITEMS = 8;                       // scan: items per thread
@@ -203,11 +216,12 @@ __global__ void __launch_bounds__(GB_BLOCK)
 kb_rank(uint32_t e, const BuildInfo *__restrict__ info, const uint32_t *__restrict__ in_ptr,
         const uint32_t *__restrict__ tmp_w, const uint32_t *__restrict__ tmp_src,
         const uint32_t *__restrict__ tmp_fpos, const uint32_t *__restrict__ tmp_t,
-        uint32_t *__restrict__ in_src, uint32_t *__restrict__ in_w, uint32_t *__restrict__ in_fpos) {
+        uint32_t *__restrict__ in_src, uint32_t *__restrict__ in_w, uint32_t *__restrict__ in_fpos, uint32_t hub_deg) {
   const uint32_t i = blockIdx.x * GB_BLOCK + threadIdx.x;
   if (i >= e || i >= info->kept) return;
   const uint32_t t = tmp_t[i];
   const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
+  if (b - a > hub_deg) return;      // parallel links piled onto one row: the host sees max_in_deg and rebuilds in hub mode
   const uint32_t w = tmp_w[i], sraw = tmp_src[i], s = sraw & SRC_MASK, f = tmp_fpos[i];
   uint32_t rank = 0;
   for (uint32_t j = a; j < b; ++j) {
@@ -220,6 +234,105 @@ kb_rank(uint32_t e, const BuildInfo *__restrict__ info, const uint32_t *__restri
   in_fpos[a + rank] = f;
 }
 
+// ---- hub mode ------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_hub_keys(uint32_t n, uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
+            uint32_t *__restrict__ src_of, uint64_t *__restrict__ key) {
+  const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (k >= e) return;
+  const uint32_t u = gb_row_of(row_ptr, n, k);
+  src_of[k] = u;
+  key[k] = ((uint64_t)u << 32) | (uint64_t)col[k];        // an out-of-range target is reported by kb_hub_links
+}
+
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_hub_links(uint32_t n, uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
+             const uint32_t *__restrict__ metric, const uint8_t *__restrict__ vflags,
+             const uint32_t *__restrict__ src_of, const uint64_t *__restrict__ sorted, uint8_t *__restrict__ twoway,
+             uint8_t *__restrict__ keep, BuildInfo *__restrict__ info) {
+  const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (k >= e) return;
+  const uint32_t u = src_of[k], t = col[k];
+  uint32_t bad = 0;
+  if (t >= n) bad |= GB_ERR_COL;
+  if (metric[k] == INF) bad |= GB_ERR_METRIC;
+  if (bad) {
+    atomicOr(&info->err, bad);
+    twoway[k] = 0; keep[k] = 0;
+    return;
+  }
+  // two-way connectivity: (t, u) is among the sorted keys of row t
+  const uint64_t want = ((uint64_t)t << 32) | (uint64_t)u;
+  uint32_t lo = row_ptr[t], hi = row_ptr[t + 1];
+  const uint32_t end = hi;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (sorted[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  const bool two = lo < end && sorted[lo] == want;
+  const bool kp = two && !(vflags[u] & HSPF_VF_NO_EXPAND);
+  twoway[k] = two ? 1 : 0;
+  keep[k] = kp ? 1 : 0;            // no in-degree histogram here (400 000 atomics on one counter): kb_hub_in_ptr
+}
+
+// in_ptr[t] = kept links whose target precedes t = first sorted (target << 32 | ~cost) key >= t << 32; dropped links sort
+// behind every target, so in_ptr[n] = kept
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_hub_in_ptr(uint32_t n, uint32_t e, const uint64_t *__restrict__ sorted, uint32_t *__restrict__ in_ptr) {
+  const uint32_t t = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (t > n) return;
+  const uint64_t want = (uint64_t)t << 32;
+  uint32_t lo = 0, hi = e;
+  while (lo < hi) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (sorted[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  in_ptr[t] = lo;
+}
+
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_hub_scatter(uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
+               const uint32_t *__restrict__ metric, const uint8_t *__restrict__ vflags,
+               const uint32_t *__restrict__ src_of, const uint8_t *__restrict__ keep, const uint32_t *__restrict__ kpre,
+               uint32_t *__restrict__ out_dst, uint32_t *__restrict__ out_w, uint32_t *__restrict__ out_fpos,
+               uint64_t *__restrict__ key, uint32_t *__restrict__ val, uint32_t *__restrict__ srcflag,
+               uint64_t dropped, BuildInfo *__restrict__ info) {
+  __shared__ uint32_t bmax;
+  if (threadIdx.x == 0) bmax = 0;
+  __syncthreads();
+  const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (k < e) {
+    if (keep[k]) {
+      const uint32_t u = src_of[k], t = col[k], w = metric[k];
+      const uint32_t fpos = k - row_ptr[u];
+      const uint32_t o = kpre[k];
+      out_dst[o] = t; out_w[o] = w; out_fpos[o] = fpos;
+      const uint32_t uf = vflags[u];                       // see kb_scatter
+      srcflag[o] = u | (((uf & HSPF_VF_NO_TRANSIT) && !(uf & HSPF_VF_NETWORK)) ? SRC_NO_TRANSIT : 0u);
+      key[k] = ((uint64_t)t << 32) | (uint64_t)(~w);       // cost descending
+      val[k] = o;
+      atomicMax(&bmax, w);
+    } else {
+      key[k] = dropped; val[k] = 0;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && bmax) atomicMax(&info->wmax, bmax);
+}
+
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_hub_gather(uint32_t e, const BuildInfo *__restrict__ info, const uint64_t *__restrict__ sorted,
+              const uint32_t *__restrict__ perm, const uint32_t *__restrict__ srcflag, const uint32_t *__restrict__ out_fpos,
+              uint32_t *__restrict__ in_src, uint32_t *__restrict__ in_w, uint32_t *__restrict__ in_fpos) {
+  const uint32_t i = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (i >= e || i >= info->kept) return;
+  const uint32_t o = perm[i];
+  in_w[i] = ~(uint32_t)sorted[i];
+  in_src[i] = srcflag[o];
+  in_fpos[i] = out_fpos[o];
+}
+
 // Static reasons why a row needs the general fused routine (RF_*), the hop-count shape of the graph
 // (MetricMode::HopCount graphs, holo-isis/src/spf.rs:1131-1146: cost 0 into a pseudonode, 1 into a router), and the
 // 16 zero entries behind every array that the kernels' fixed-size fetches may touch.
@@ -227,19 +340,38 @@ __global__ void __launch_bounds__(GB_BLOCK)
 kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ in_src,
             const uint32_t *__restrict__ in_w, const uint8_t *__restrict__ vflags, uint8_t *__restrict__ rowflags,
             BuildInfo *__restrict__ info) {
+  // one thread per row; a row of more than 64 in-links is walked by its whole wave (a LAN with thousands of members
+  // would otherwise be one thread's serial loop)
   const uint32_t t = blockIdx.x * GB_BLOCK + threadIdx.x;
-  if (t >= n) return;
-  const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
-  const bool net = vflags[t] & HSPF_VF_NETWORK;
+  const uint32_t lane = threadIdx.x & 63u;
+  const bool valid = t < n;
+  const uint32_t a = valid ? in_ptr[t] : 0u, b = valid ? in_ptr[t + 1] : 0u;
+  const bool net = valid && (vflags[t] & HSPF_VF_NETWORK);
+  const bool wide = b - a > 64u;
   uint32_t f = b - a > 16u ? RF_MANY : 0u;
   bool bad = false;
-  for (uint32_t i = a; i < b; ++i) {
+  auto link = [&](uint32_t i, uint32_t row, bool row_net, uint32_t &ff, bool &bb) {
     const uint32_t sraw = in_src[i], u = sraw & SRC_MASK, w = in_w[i];
-    if (sraw & SRC_NO_TRANSIT) f |= RF_NT;
-    if (w == 0u && u >= t) f |= RF_ZERO;
-    if (net) bad |= !(w == 0u && !(vflags[u] & HSPF_VF_NETWORK) && u > t);
-    else bad |= w != 1u;
+    if (sraw & SRC_NO_TRANSIT) ff |= RF_NT;
+    if (w == 0u && u >= row) ff |= RF_ZERO;
+    if (row_net) bb |= !(w == 0u && !(vflags[u] & HSPF_VF_NETWORK) && u > row);
+    else bb |= w != 1u;
+  };
+  if (!wide)
+    for (uint32_t i = a; i < b; ++i) link(i, t, net, f, bad);
+  for (uint64_t todo = __ballot(wide); todo != 0ull; todo &= todo - 1ull) {
+    const int l = __ffsll((unsigned long long)todo) - 1;
+    const uint32_t row = __shfl(t, l), ra = __shfl(a, l), rb = __shfl(b, l);
+    const bool row_net = __shfl((int)net, l) != 0;
+    uint32_t ff = 0;
+    bool bb = false;
+#pragma unroll 4
+    for (uint32_t i = ra + lane; i < rb; i += 64u) link(i, row, row_net, ff, bb);
+    const uint32_t all = (__ballot(ff & RF_NT) ? RF_NT : 0u) | (__ballot(ff & RF_ZERO) ? RF_ZERO : 0u);
+    const bool any_bad = __ballot(bb) != 0ull;
+    if ((int)lane == l) { f |= all; bad = any_bad; }
   }
+  if (!valid) return;
   rowflags[t] = (uint8_t)f;
   atomicMax(&info->max_in_deg, b - a);
   if (f) atomicOr(&info->any_rowflags, f);

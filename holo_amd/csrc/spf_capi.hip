@@ -9,6 +9,7 @@
 #include "../../include/holo_spf_hip.h"
 #include "spf_kernels.hip.h"
 #include "graph_build.hip.h"
+#include "hub_sort.h"
 
 #include <algorithm>
 #include <chrono>
@@ -63,6 +64,7 @@ struct hspf_graph {
   uint32_t n_heavy_chunks = 0;                                    // > 0: the kernels go through unit_first
   uint64_t build_id = 0;                                          // changes with every device build (upload, patch)
   uint32_t max_in_deg = 0;                                        // largest kept in-degree
+  bool hub_built = false;                                         // the last build ran in hub mode (sorted keys)
   bool lean = false;                                              // no network vertex, no static row flag, in-degrees <= 8: k_single_lean
   // Carves the arrays out of `base` for n vertices / cap links; returns the bytes needed.
   size_t layout(char *base, uint32_t nv, uint32_t cap) {
@@ -104,7 +106,8 @@ struct hspf_ctx {
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
-  DevBuf gb, gb_delta;                              // graph build scratch, patch delta
+  DevBuf gb, gb_delta, gb_hub;                      // graph build scratch, patch delta, hub-mode sort buffers
+  uint32_t hub_deg = HUB_DEG;                       // HSPF_HUB_DEG env: rows with more links than this -> graph build from sorted keys
   BuildInfo *h_info = nullptr;     // pinned
   int *h_changed = nullptr;        // pinned, h_changed_cap ints: per-sweep "something changed" flags of a phase
   size_t h_changed_cap = 0;
@@ -245,7 +248,9 @@ void gb_scan(hipStream_t s, const T *in, uint32_t m, uint32_t *out, uint32_t *su
 // Builds everything the SPF kernels read from the live raw CSR of g (d_row_ptr/d_col/d_metric[g->cur],
 // d_vflags), on the ctx stream, and refreshes the host-side summary (e_kept, wmax, hop-count shape, two-way
 // flags for the slot tables).  Synchronises the stream once at the end.
-int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
+constexpr int HSPF_RETRY_HUB = 1000;    // build_pass -> build_on_device only
+
+int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   const uint32_t n = g->n, e = g->e;
   hipStream_t s = ctx->stream;
   const size_t le = (size_t)e + 16;
@@ -269,24 +274,60 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   uint8_t *keep = (uint8_t *)w;
   uint8_t *twoway = keep + le;
   const uint32_t *row_ptr = g->d_row_ptr[g->cur], *col = g->d_col[g->cur], *metric = g->d_metric[g->cur];
+  // hub mode: key | sorted (u64 x le each) | val | perm | srcflag (u32 x le each) | temporary storage of the sorts
+  uint64_t *hkey = nullptr, *hsorted = nullptr;
+  uint32_t *hval = nullptr, *hperm = nullptr, *hsrcflag = nullptr;
+  void *htmp = nullptr;
+  size_t htmp_bytes = 0;
+  unsigned nbits = 1;
+  while (nbits < 32 && (1ull << nbits) < (uint64_t)n) ++nbits;
+  if (hub && e) {
+    size_t t1 = 0, t2 = 0;
+    HIPCHK(ctx, (hipError_t)hub_sort_keys(nullptr, &t1, nullptr, nullptr, e, 32 + nbits, s));
+    HIPCHK(ctx, (hipError_t)hub_sort_pairs(nullptr, &t2, nullptr, nullptr, nullptr, nullptr, e, 33 + nbits, s));
+    htmp_bytes = std::max(t1, t2);
+    rc = ensure(ctx, ctx->gb_hub, 16 * le + 12 * le + htmp_bytes + 256);
+    if (rc != HSPF_OK) return rc;
+    hkey = (uint64_t *)ctx->gb_hub.p; hsorted = hkey + le;
+    hval = (uint32_t *)(hsorted + le); hperm = hval + le; hsrcflag = hperm + le;
+    htmp = (void *)(((uintptr_t)(hsrcflag + le) + 255) & ~(uintptr_t)255);
+  }
 
   HIPCHK(ctx, hipMemsetAsync(in_cnt, 0, ((size_t)n + 1) * 4, s));
   HIPCHK(ctx, hipMemsetAsync(info, 0, sizeof(BuildInfo), s));
   const dim3 ge((e + GB_BLOCK - 1) / GB_BLOCK), gn((n + 1 + GB_BLOCK - 1) / GB_BLOCK);
-  if (e)
+  if (e && hub) {
+    hipLaunchKernelGGL(kb_hub_keys, ge, dim3(GB_BLOCK), 0, s, n, e, row_ptr, col, src_of, hkey);
+    size_t tb = htmp_bytes;
+    HIPCHK(ctx, (hipError_t)hub_sort_keys(htmp, &tb, hkey, hsorted, e, 32 + nbits, s));
+    hipLaunchKernelGGL(kb_hub_links, ge, dim3(GB_BLOCK), 0, s, n, e, row_ptr, col, metric, (const uint8_t *)g->d_vflags,
+                       (const uint32_t *)src_of, (const uint64_t *)hsorted, twoway, keep, info);
+  } else if (e) {
     hipLaunchKernelGGL(kb_links, ge, dim3(GB_BLOCK), 0, s, n, e, row_ptr, col, metric, (const uint8_t *)g->d_vflags,
                        src_of, twoway, keep, in_cnt, info);
+  }
   gb_scan<uint8_t>(s, keep, e, kpre, sums);
   hipLaunchKernelGGL(kb_out_ptr, gn, dim3(GB_BLOCK), 0, s, n, row_ptr, (const uint32_t *)kpre, g->d_out_ptr, info, e);
-  gb_scan<uint32_t>(s, in_cnt, n, g->d_in_ptr, sums);
-  if (e) {
+  if (!(e && hub)) gb_scan<uint32_t>(s, in_cnt, n, g->d_in_ptr, sums);
+  if (e && hub) {
+    const uint64_t dropped = 1ull << (32 + nbits);                  // behind every (target << 32 | ~cost)
+    hipLaunchKernelGGL(kb_hub_scatter, ge, dim3(GB_BLOCK), 0, s, e, row_ptr, col, metric, (const uint8_t *)g->d_vflags,
+                       (const uint32_t *)src_of, (const uint8_t *)keep, (const uint32_t *)kpre, g->d_out_dst, g->d_out_w,
+                       g->d_out_fpos, hkey, hval, hsrcflag, dropped, info);
+    size_t tb = htmp_bytes;
+    HIPCHK(ctx, (hipError_t)hub_sort_pairs(htmp, &tb, hkey, hsorted, hval, hperm, e, 33 + nbits, s));
+    hipLaunchKernelGGL(kb_hub_in_ptr, gn, dim3(GB_BLOCK), 0, s, n, e, (const uint64_t *)hsorted, g->d_in_ptr);
+    hipLaunchKernelGGL(kb_hub_gather, ge, dim3(GB_BLOCK), 0, s, e, (const BuildInfo *)info, (const uint64_t *)hsorted,
+                       (const uint32_t *)hperm, (const uint32_t *)hsrcflag, (const uint32_t *)g->d_out_fpos, g->d_in_src,
+                       g->d_in_w, g->d_in_fpos);
+  } else if (e) {
     hipLaunchKernelGGL(kb_scatter, ge, dim3(GB_BLOCK), 0, s, e, row_ptr, col, metric, (const uint8_t *)g->d_vflags,
                        (const uint32_t *)src_of, (const uint8_t *)keep, (const uint32_t *)kpre,
                        (const uint32_t *)g->d_in_ptr, in_cnt, g->d_out_dst, g->d_out_w, g->d_out_fpos,
                        tmp_w, tmp_src, tmp_fpos, tmp_t, info);
     hipLaunchKernelGGL(kb_rank, ge, dim3(GB_BLOCK), 0, s, e, (const BuildInfo *)info, (const uint32_t *)g->d_in_ptr,
                        (const uint32_t *)tmp_w, (const uint32_t *)tmp_src, (const uint32_t *)tmp_fpos,
-                       (const uint32_t *)tmp_t, g->d_in_src, g->d_in_w, g->d_in_fpos);
+                       (const uint32_t *)tmp_t, g->d_in_src, g->d_in_w, g->d_in_fpos, ctx->hub_deg);
   }
   hipLaunchKernelGGL(kb_rowflags, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
                      (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info);
@@ -321,6 +362,8 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
     for (uint32_t v = 0; v < n; ++v) { const uint32_t d = g->row_ptr[v + 1] - g->row_ptr[v]; if (d > 32u) heavy += d; }
     g->heavy_rows = heavy * 4u >= (uint64_t)std::max<uint32_t>(e, 1u);
   }
+  if (!hub && bi.max_in_deg > ctx->hub_deg) return HSPF_RETRY_HUB;     // kb_rank left those rows out
+  g->hub_built = hub;
   for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
   g->n_heavy_chunks = bi.n_heavy;
   g->max_in_deg = bi.max_in_deg;
@@ -333,6 +376,18 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   g->narrow_bad = false;
   g->wide24_bad = false;
   return HSPF_OK;
+}
+
+// Hub mode when some row of the caller's CSR lists more than hub_deg links (then a target row scan of kb_links could be
+// that long), or when the plain pass found a row with more kept in-links than that (parallel links piled onto one row:
+// only then can the in-degree exceed every out-degree).
+int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
+  uint32_t max_out = 0;
+  for (uint32_t v = 0; v < g->n; ++v) max_out = std::max(max_out, g->row_ptr[v + 1] - g->row_ptr[v]);
+  const bool hub = max_out > ctx->hub_deg;
+  int rc = build_pass(ctx, g, hub);
+  if (rc == HSPF_RETRY_HUB) rc = build_pass(ctx, g, true);
+  return rc;
 }
 
 int alloc_arena(hspf_ctx *ctx, hspf_graph *g, uint32_t n, uint32_t cap) {
@@ -392,6 +447,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   if (const char *v = getenv("HSPF_LV_MIN_N")) ctx->lv_min_n = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_XCD_ROW_COST")) ctx->xcd_row_cost = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_UNIT_HEAVY_DEG")) ctx->unit_heavy_deg = (uint32_t)strtoul(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_HUB_DEG")) ctx->hub_deg = (uint32_t)strtoul(v, nullptr, 0);
   if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return HSPF_E_NODEV; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
   for (auto &e : ctx->ev)
@@ -409,7 +465,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->kcnt})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->kcnt})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
@@ -622,6 +678,7 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
     case HSPF_GX_OUT_POS: src = g->d_out_fpos; bytes = kb; break;
     case HSPF_GX_ROWFLAGS: src = g->d_rowflags; bytes = g->n; break;
     case HSPF_GX_TWOWAY: bytes = g->e; break;                       // host mirror
+    case HSPF_GX_BUILD_MODE: bytes = 4; break;                       // host value
     case HSPF_GX_UNITS: src = g->d_unit_first; bytes = g->n_heavy_chunks ? ((size_t)g->n_heavy_chunks * 3 + (g->n + 15u) / 16u) * 4 : 0; break;
     default: ctx->last_error = "hspf_graph_export: unknown array"; return HSPF_E_INVAL;
   }
@@ -629,6 +686,7 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
   if (!dst) return HSPF_OK;
   if (cap_bytes < bytes) { ctx->last_error = "hspf_graph_export: buffer too small"; return HSPF_E_INVAL; }
   if (which == HSPF_GX_TWOWAY) { if (bytes) memcpy(dst, g->twoway.data(), bytes); return HSPF_OK; }
+  if (which == HSPF_GX_BUILD_MODE) { const uint32_t m = g->hub_built ? 1u : 0u; memcpy(dst, &m, 4); return HSPF_OK; }
   (void)hipSetDevice(ctx->device);
   if (bytes) {
     HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -108,7 +108,8 @@ class SpfGraph:
     GX = {"row_ptr": (0, np.uint32), "col": (1, np.uint32), "metric": (2, np.uint32), "vflags": (3, np.uint8),
           "in_ptr": (4, np.uint32), "in_src": (5, np.uint32), "in_cost": (6, np.uint32), "in_pos": (7, np.uint32),
           "out_ptr": (8, np.uint32), "out_dst": (9, np.uint32), "out_cost": (10, np.uint32),
-          "out_pos": (11, np.uint32), "rowflags": (12, np.uint8), "twoway": (13, np.uint8), "units": (14, np.uint32)}
+          "out_pos": (11, np.uint32), "rowflags": (12, np.uint8), "twoway": (13, np.uint8), "units": (14, np.uint32),
+          "build_mode": (15, np.uint32)}
 
     def export(self, name: str) -> np.ndarray:
         """One array of the graph as it sits on the device (hspf_graph_export)."""

@@ -222,6 +222,9 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows);
 #define HSPF_GX_UNITS    14u   /* u32 [...]    work units of the sweep kernels: empty when no 16-vertex chunk holds a row
                                   of more than 32 in-links; else [4 units per heavy chunk | 1 unit per other chunk],
                                   each class in vertex order, entry = first vertex (| 0x80000000: one row per wave) */
+#define HSPF_GX_BUILD_MODE 15u /* u32 [1]      how the last upload / patch derived the layout: 0 = per-link row scans,
+                                  1 = hub mode (a row of more than 512 links: two device-wide sorts, O(log degree) per
+                                  link).  The layout itself does not depend on the mode                             */
 int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *dst, size_t cap_bytes,
                       size_t *out_bytes);
 

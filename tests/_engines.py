@@ -4,3 +4,5 @@ import pytest
 both_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps", "lanevertex"], indirect=True)
 sweeps_engine = pytest.mark.parametrize("spf_ctx", ["sweeps"], indirect=True)
 all_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps", "twophase", "lanevertex"], indirect=True)
+hub_engines = pytest.mark.parametrize("spf_ctx", ["default", "hubsort"], indirect=True)
+hubsort_engine = pytest.mark.parametrize("spf_ctx", ["hubsort"], indirect=True)

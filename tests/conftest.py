@@ -28,14 +28,16 @@ def spf_ctx(request, _ctx_pool):
     engine keeps its coverage on the small adversarial graphs of the suite; "twophase" additionally sends runs with more
     than 24 first-hop slots down the older k_relax + k_dag path instead of k_fw (HSPF_VARIANT bit6); "lanevertex" sends
     every run of up to 64 roots (with at most 24 first-hop slots) through k_lv (HSPF_SINGLE_MAX_N=0, HSPF_LV_MAX_ROOTS=64,
-    HSPF_LV_MIN_N=0).
+    HSPF_LV_MIN_N=0); "hubsort" is the default engine with every graph built in hub mode (HSPF_HUB_DEG=0: two-way check and
+    in-row order from device-wide sorts instead of per-link row scans).
     Tests choose with tests/_engines.py (indirect parametrisation); unmarked tests get "default"."""
     mode = getattr(request, "param", "default")
     if mode not in _ctx_pool:
         from holo_amd.engine import SpfContext
         env = {"sweeps": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0"},
                "twophase": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "64"},
-               "lanevertex": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "64", "HSPF_LV_MIN_N": "0"}}.get(mode, {})
+               "lanevertex": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "64", "HSPF_LV_MIN_N": "0"},
+               "hubsort": {"HSPF_HUB_DEG": "0"}}.get(mode, {})
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:

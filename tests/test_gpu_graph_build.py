@@ -9,6 +9,7 @@ from holo_amd import synth
 from holo_amd import engine as E
 from oracle import graph_oracle as go
 from _layout_ref import layout
+from _engines import hub_engines, hubsort_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -42,6 +43,123 @@ def test_device_layout_matches_restatement(spf_ctx, i):
     G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
     try:
         assert_layout(G, g)
+    finally:
+        G.free()
+
+
+@hubsort_engine
+@pytest.mark.parametrize("i", range(7))
+def test_hub_mode_layout_matches_restatement(spf_ctx, i):
+    """Every graph through the sorted-key build (HSPF_HUB_DEG=0): the layout is the one the row scans give."""
+    g = list(graphs())[i]
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        assert int(G.export("build_mode")[0]) == 1
+        assert_layout(G, g)
+    finally:
+        G.free()
+
+
+def hub_lsdb(seed, n_leaves=3000, hub_links=2500, parallel=0):
+    """Routers only: one router with `hub_links` point-to-point neighbours (a row far beyond HUB_DEG = 512 links), a sparse
+    random mesh among the others, a few one-way links and, with `parallel`, that many routers each listing `parallel`
+    links to one target that lists each of them once (in-degree beyond every out-degree)."""
+    rng = np.random.default_rng(seed)
+    n = n_leaves + 1
+    hub = n // 3
+    src, dst, met = [], [], []
+    others = np.array([v for v in range(n) if v != hub])
+    for v in rng.choice(others, size=hub_links, replace=False).tolist():
+        src += [hub, v]; dst += [v, hub]; met += [int(rng.integers(1, 9)), int(rng.integers(1, 9))]
+        if rng.random() < 0.05:                                   # a second, parallel link one way
+            src.append(v); dst.append(hub); met.append(int(rng.integers(1, 9)))
+    for _ in range(2 * n_leaves):
+        u, v = rng.choice(others, size=2, replace=False).tolist()
+        src.append(u); dst.append(v); met.append(int(rng.integers(1, 9)))
+        if rng.random() > 0.1:
+            src.append(v); dst.append(u); met.append(int(rng.integers(1, 9)))
+    if parallel:
+        t = int(others[7])
+        for u in others[100:100 + parallel].tolist():
+            src.append(t); dst.append(u); met.append(3)
+            for _ in range(parallel):
+                src.append(u); dst.append(t); met.append(int(rng.integers(1, 4)))
+    src = np.array(src, np.int64); dst = np.array(dst, np.int64); met = np.array(met, np.int64)
+    perm = rng.permutation(len(src))
+    row_ptr, col, metric = synth._csr_from_links(n, src[perm], dst[perm], met[perm])
+    vflags = np.zeros(n, np.uint8)
+    vflags[rng.random(n) < 0.02] |= synth.VF_NO_TRANSIT
+    vflags[hub] = 0
+    return synth.CsrGraph(row_ptr, col, metric, vflags, synth.MAX_PATH_METRIC_WIDE, f"hub-{seed}", {"hub": hub})
+
+
+def test_hub_row_takes_the_sorted_build(spf_ctx):
+    """A 2 500-link row: the default context builds from sorted keys (mode 1), the layout is the restated one, SPF from
+    leaves and from the hub's neighbours matches the oracle; a patch that cuts the hub down to 40 links goes back to the
+    row scans (mode 0)."""
+    g = hub_lsdb(1)
+    hub = g.meta["hub"]
+    assert int(np.diff(g.row_ptr).max()) >= 2500
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        assert int(G.export("build_mode")[0]) == 1
+        assert_layout(G, g)
+        roots = np.array([0, 1, 2, hub + 1, g.n - 1] + list(range(50, 109)), np.uint32)
+        roots = roots[roots != hub]
+        check_spf(spf_ctx, G, g, roots)
+        a = int(g.row_ptr[hub])
+        G.patch([hub], [(g.col[a:a + 40].copy(), g.metric[a:a + 40].copy())], [0])
+        g2 = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
+        assert int(G.export("build_mode")[0]) == 0
+        assert_layout(G, g2)
+        check_spf(spf_ctx, G, g2, roots)
+    finally:
+        G.free()
+
+
+def test_parallel_links_piled_onto_one_row_rebuild_in_hub_mode(spf_ctx):
+    """No row lists more than 512 links, but 30 routers x 30 parallel links land on one vertex (900 in-links): the plain
+    pass reports the in-degree, the build runs again from sorted keys, and the layout is the restated one."""
+    g = hub_lsdb(2, n_leaves=600, hub_links=300, parallel=30)
+    assert int(np.diff(g.row_ptr).max()) <= 512
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        assert int(np.diff(G.export("in_ptr")).max()) > 512
+        assert int(G.export("build_mode")[0]) == 1
+        assert_layout(G, g)
+        check_spf(spf_ctx, G, g, np.arange(0, 64, dtype=np.uint32))
+    finally:
+        G.free()
+
+
+def test_star_of_100k_links(spf_ctx):
+    """One router with 100 000 neighbours: upload, two-way flags and in-row order against numpy, SPF from 16 leaves
+    against the heap oracle."""
+    g = hub_lsdb(3, n_leaves=100_000, hub_links=100_000)
+    hub = g.meta["hub"]
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        assert int(G.export("build_mode")[0]) == 1
+        n = g.n
+        src = np.repeat(np.arange(n, dtype=np.int64), np.diff(g.row_ptr.astype(np.int64)))
+        fwd = src * n + g.col.astype(np.int64)
+        two = np.isin(g.col.astype(np.int64) * n + src, fwd)
+        assert np.array_equal(G.export("twoway"), two.astype(np.uint8))
+        keep = two                                                # no HSPF_VF_NO_EXPAND in this graph
+        ks, kt, kw = src[keep], g.col[keep].astype(np.int64), g.metric[keep].astype(np.int64)
+        kp = (np.arange(len(src), dtype=np.int64) - g.row_ptr.astype(np.int64)[src])[keep]
+        order = np.lexsort((kp, ks, -kw, kt))
+        assert np.array_equal(G.export("in_src") & 0x7FFFFFFF, ks[order].astype(np.uint32))
+        assert np.array_equal(G.export("in_cost"), kw[order].astype(np.uint32))
+        assert np.array_equal(G.export("in_pos"), kp[order].astype(np.uint32))
+        assert np.array_equal(G.export("out_dst"), kt.astype(np.uint32))
+        roots = (np.arange(16, dtype=np.uint64) * (n - 1) // 16).astype(np.uint32)
+        roots = roots[roots != hub]
+        res = spf_ctx.run(G, roots)
+        ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 0, go.HEAP,
+                     mask_words_=res.first_hop_mask.shape[2])
+        assert np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops)
+        assert np.array_equal(res.first_hop_mask, ref.mask)
     finally:
         G.free()
 
@@ -106,6 +224,7 @@ def check_spf(ctx, G, g, roots, run_flags=0):
     assert np.array_equal(res.first_hop_mask, ref.mask)
 
 
+@hub_engines
 @pytest.mark.parametrize("seed", range(6))
 def test_patch_equals_fresh_upload(spf_ctx, seed):
     rng = np.random.default_rng(seed)
