@@ -113,18 +113,19 @@ int run_map(const Graph &g, uint32_t root, uint32_t run_flags, bool ref_shape, O
   std::vector<Vertex> spt;                              // in pop order
   std::vector<uint32_t> spt_idx(g.n, INF);              // id -> pop index ("spt.contains")
   std::vector<uint32_t> cand_dist;                      // id -> key.first while on cand list
-  if (!ref_shape) cand_dist.assign(g.n, INF);
+  std::vector<uint8_t> on_cand;                         // id -> on the cand list (a saturated candidate's distance IS
+  if (!ref_shape) { cand_dist.assign(g.n, INF); on_cand.assign(g.n, 0); }   // 0xFFFFFFFF: no sentinel value is free)
   uint64_t work = 0;
 
   cand.emplace(Key{0, root}, Vertex{root, 0, 0, {}, {}});
-  if (!ref_shape) cand_dist[root] = 0;
+  if (!ref_shape) { cand_dist[root] = 0; on_cand[root] = 1; }
 
   while (!cand.empty()) {
     // pop_first
     auto first = cand.begin();
     Vertex cv = std::move(first->second);
     cand.erase(first);
-    if (!ref_shape) cand_dist[cv.id] = INF;
+    if (!ref_shape) on_cand[cv.id] = 0;
     const uint32_t vidx = (uint32_t)spt.size();
     spt_idx[cv.id] = vidx;
     spt.push_back(std::move(cv));
@@ -166,13 +167,13 @@ int run_map(const Graph &g, uint32_t root, uint32_t run_flags, bool ref_shape, O
           if (distance < it->second.distance) cand.erase(it);
           else if (distance > it->second.distance) continue;
         }
-      } else if (cand_dist[t] != INF) {
+      } else if (on_cand[t]) {
         if (distance < cand_dist[t]) cand.erase(Key{cand_dist[t], t});
         else if (distance > cand_dist[t]) continue;
       }
       auto ins = cand.emplace(Key{distance, t}, Vertex{t, distance, hops, {}, {}});
       Vertex &c = ins.first->second;                     // or_insert_with: keeps old hops on Equal
-      if (!ref_shape) cand_dist[t] = distance;
+      if (!ref_shape) { cand_dist[t] = distance; on_cand[t] = 1; }
       c.parents.push_back(vidx);
       const Vertex &pv = spt[vidx];
       if (vhops == 0) {
