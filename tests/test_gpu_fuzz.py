@@ -19,6 +19,12 @@ def test_random_lsdbs_runs_and_patches_against_the_oracle(spf_ctx, first):
     assert ok == runs and runs == 150
 
 
+def test_random_lsdbs_with_big_lans_up_to_15_mask_words(spf_ctx):
+    import gpu_fuzz
+    ok, runs = gpu_fuzz.fuzz_wide(spf_ctx, 0, 30, verbose=False)
+    assert ok == runs and runs == 60
+
+
 def test_random_layouts_and_arbitrary_row_patches_against_the_restatement(spf_ctx):
     import gpu_fuzz
     # spf=True: after every round of arbitrary row replacements (links between any two vertices, any flags) an SPF

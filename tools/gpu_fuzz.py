@@ -4,6 +4,7 @@ padding entries, network vertices as roots), every run flag combination, optiona
 engine against the CPU oracle, bit for bit.  Not part of the pytest suite (minutes, not seconds):
 
     python tools/gpu_fuzz.py [first_seed] [n_graphs]
+    FUZZ_WIDE=n python tools/gpu_fuzz.py [first_seed]      (n graphs with LANs of 150-900 routers: up to 15 mask words)
 """
 import os
 import sys
@@ -84,6 +85,38 @@ def fuzz(ctx, first, count, verbose=True):
         G.free()
     if verbose:
         print(f"fuzz: {ok}/{runs} runs bit-exact over {count} graphs in {time.time() - t0:.1f} s", flush=True)
+    return ok, runs
+
+
+def fuzz_wide(ctx, first, count, verbose=True):
+    """Many first-hop slots: one to three LANs of 150-900 routers (up to 15 mask words, k_fw<W> for every W, rows far beyond
+    32 in-links = work units; 1 000+ members = hub-mode graph build), roots on and off the LANs, LAN vertices as roots."""
+    ok = runs = 0
+    t0 = time.time()
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(130_000 + seed)
+        lan = int(rng.choice([150, 260, 400, 640, 900]))
+        nr = lan + int(rng.integers(0, 300))
+        nn = int(rng.integers(1, 4))
+        hop = rng.random() < 0.15
+        g = synth.random_lsdb(nr, nn, float(rng.uniform(1.0, 3.0)), 140_000 + seed, metric_lo=1, metric_hi=int(rng.integers(1, 12)),
+                              p_oneway=float(rng.choice([0.0, 0.05])), p_parallel=float(rng.choice([0.0, 0.1])),
+                              p_overload=float(rng.choice([0.0, 0.05])), p_noexpand=float(rng.choice([0.0, 0.02])),
+                              zero_cost_router_links=bool(rng.random() < 0.1), lan_size=lan, hopcount=hop)
+        G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        for rep in range(2):
+            k = int(rng.integers(1, 90))
+            roots = rng.choice(g.n, size=k, replace=False).astype(np.uint32)
+            if rep == 0:
+                roots[0] = int(rng.integers(0, nn))                       # a LAN vertex itself
+            flags = int(rng.choice([0, E.RUN_NET_NEXTHOPS, E.RUN_IGNORE_OVERLOAD, 3]))
+            if hop:
+                flags |= E.RUN_IGNORE_OVERLOAD
+            runs += 1
+            ok += compare(ctx, G, g, roots, flags, ("wide", seed, rep, flags, k))
+        G.free()
+    if verbose:
+        print(f"fuzz_wide: {ok}/{runs} runs bit-exact over {count} graphs in {time.time() - t0:.1f} s", flush=True)
     return ok, runs
 
 
@@ -197,6 +230,9 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     ctx = E.SpfContext(0)
+    if os.environ.get("FUZZ_WIDE"):                                 # only the wide-mask graphs
+        ok, runs = fuzz_wide(ctx, first, int(os.environ["FUZZ_WIDE"]))
+        sys.exit(0 if ok == runs else 1)
     ok, runs = fuzz(ctx, first, count)
     ok2, runs2 = fuzz_layout(ctx, first, max(count // 4, 20), spf=bool(os.environ.get("FUZZ_ARBITRARY")))
     ok3, runs3 = fuzz_routes(ctx, first, max(count // 20, 5))
