@@ -339,7 +339,7 @@ kb_hub_gather(uint32_t e, const BuildInfo *__restrict__ info, const uint64_t *__
 __global__ void __launch_bounds__(GB_BLOCK)
 kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ in_src,
             const uint32_t *__restrict__ in_w, const uint8_t *__restrict__ vflags, uint8_t *__restrict__ rowflags,
-            BuildInfo *__restrict__ info) {
+            BuildInfo *__restrict__ info, uint32_t giant_deg) {
   // one thread per row; a row of more than 64 in-links is walked by its whole wave (a LAN with thousands of members
   // would otherwise be one thread's serial loop)
   const uint32_t t = blockIdx.x * GB_BLOCK + threadIdx.x;
@@ -348,7 +348,7 @@ kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__r
   const uint32_t a = valid ? in_ptr[t] : 0u, b = valid ? in_ptr[t + 1] : 0u;
   const bool net = valid && (vflags[t] & HSPF_VF_NETWORK);
   const bool wide = b - a > 64u;
-  uint32_t f = b - a > 16u ? RF_MANY : 0u;
+  uint32_t f = (b - a > 16u ? RF_MANY : 0u) | (b - a > giant_deg ? RF_GIANT : 0u);
   bool bad = false;
   auto link = [&](uint32_t i, uint32_t row, bool row_net, uint32_t &ff, bool &bb) {
     const uint32_t sraw = in_src[i], u = sraw & SRC_MASK, w = in_w[i];

@@ -61,6 +61,8 @@ struct hspf_graph {
   uint32_t *d_out_ptr = nullptr, *d_out_dst = nullptr, *d_out_w = nullptr, *d_out_fpos = nullptr;
   uint8_t *d_vflags = nullptr, *d_rowflags = nullptr;
   uint32_t *d_unit_first = nullptr;                               // work units (GraphDev::unit_first), n / 4 + 4 entries
+  uint32_t *d_giant = nullptr;                                    // giant rows: vertex list [n_giant] | first slices [n_giant + 1]
+  uint32_t n_giant = 0, n_giant_slices = 0;                       // rows of more than GIANT_DEG in-links (GraphDev::giant_vtx)
   uint32_t n_heavy_chunks = 0;                                    // > 0: the kernels go through unit_first
   uint64_t build_id = 0;                                          // changes with every device build (upload, patch)
   uint32_t max_in_deg = 0;                                        // largest kept in-degree
@@ -79,6 +81,7 @@ struct hspf_graph {
     d_out_dst = (uint32_t *)carve(lb); d_out_w = (uint32_t *)carve(lb); d_out_fpos = (uint32_t *)carve(lb);
     d_vflags = (uint8_t *)carve(nv); d_rowflags = (uint8_t *)carve(nv);
     d_unit_first = (uint32_t *)carve((size_t(nv) / 4 + 8) * 4);
+    d_giant = (uint32_t *)carve((size_t(cap) / (GIANT_DEG / 2) + 8) * 4);
     return off;
   }
   GraphDev dev() const {
@@ -91,6 +94,7 @@ struct hspf_graph {
     g.unit_first = n_heavy_chunks ? d_unit_first : nullptr;
     g.n_heavy_units = n_heavy_chunks * 4u;
     for (int x = 0; x < 9; ++x) g.xcd_heavy[x] = xcd_heavy(x);
+    g.giant_vtx = d_giant; g.giant_slice0 = d_giant + n_giant; g.n_giant = n_giant;
     return g;
   }
 };
@@ -106,7 +110,7 @@ struct hspf_ctx {
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
-  DevBuf gb, gb_delta, gb_hub;                      // graph build scratch, patch delta, hub-mode sort buffers
+  DevBuf gb, gb_delta, gb_hub, giant_part;                      // graph build scratch, patch delta, hub-mode sort buffers
   uint32_t hub_deg = HUB_DEG;                       // HSPF_HUB_DEG env: rows with more links than this -> graph build from sorted keys
   BuildInfo *h_info = nullptr;     // pinned
   int *h_changed = nullptr;        // pinned, h_changed_cap ints: per-sweep "something changed" flags of a phase
@@ -330,7 +334,7 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
                        (const uint32_t *)tmp_t, g->d_in_src, g->d_in_w, g->d_in_fpos, ctx->hub_deg);
   }
   hipLaunchKernelGGL(kb_rowflags, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
-                     (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info);
+                     (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info, GIANT_DEG);
   {
     // work units: heavy flag per chunk -> heavy chunks before each chunk -> unit_first (scratch: in_cnt, n + 17 words, is
     // free again and holds both: nb flags, then nb + 1 positions)
@@ -367,6 +371,22 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
   g->n_heavy_chunks = bi.n_heavy;
   g->max_in_deg = bi.max_in_deg;
+  g->n_giant = 0; g->n_giant_slices = 0;
+  if (bi.max_in_deg > GIANT_DEG) {
+    // giant rows (GraphDev::giant_vtx): a rare shape, so the in-row bounds simply come back once and the two small
+    // tables are made here
+    std::vector<uint32_t> ip((size_t)n + 1), tab, s0;
+    HIPCHK(ctx, hipMemcpy(ip.data(), g->d_in_ptr, ((size_t)n + 1) * 4, hipMemcpyDeviceToHost));
+    uint32_t total = 0;
+    for (uint32_t v = 0; v < n; ++v) {
+      const uint32_t d = ip[v + 1] - ip[v];
+      if (d > GIANT_DEG) { tab.push_back(v); s0.push_back(total); total += (d + GIANT_SLICE - 1) / GIANT_SLICE; }
+    }
+    s0.push_back(total);
+    g->n_giant = (uint32_t)tab.size(); g->n_giant_slices = total;
+    tab.insert(tab.end(), s0.begin(), s0.end());
+    HIPCHK(ctx, hipMemcpy(g->d_giant, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+  }
   {
     bool any_net = false;
     for (uint32_t v = 0; v < n && !any_net; ++v) any_net = (g->vflags[v] & HSPF_VF_NETWORK) != 0;
@@ -465,7 +485,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->kcnt})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->kcnt})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
@@ -888,6 +908,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lane_flags, ((size_t)L + 256) * 4, hipHostMallocDefault));
     ctx->h_lane_cap = L;
   }
+  // slices of the giant rows (FusedGraph::giant_part): tags, then GIANT_WORDS x 64 words per (batch, slice)
+  const bool giant = g->n_giant != 0 && g->n_heavy_chunks != 0;
+  const size_t giant_tags = ((size_t)B * g->n_giant + 63) & ~size_t(63);
+  if (giant && (rc = ensure(ctx, ctx->giant_part, (giant_tags + (size_t)B * g->n_giant_slices * GIANT_WORDS * 64) * 4))) return rc;
   // work counter of the fused kernel (HSPF_RUN_COUNT_ROWS): [256] rows recomputed
   if ((rc = ensure(ctx, ctx->kcnt, 256 * 4))) return rc;
   uint32_t *d_kcnt = (uint32_t *)ctx->kcnt.p;
@@ -930,7 +954,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     std::copy(tab_vtx.begin(), tab_vtx.end(), h + w_vtx);
     std::copy(tab_base.begin(), tab_base.end(), h + w_base);
     for (uint32_t r = 0; r < L; ++r) h[w_map + r] = (row_map && r < n_roots) ? row_map[r] : r;
-    const FusedGraph fg{gd, tabs, d_kcnt, {0u, 0u}};
+    const FusedGraph fg{gd, tabs, d_kcnt, (uint32_t *)ctx->giant_part.p};
     memcpy(h + w_fg, &fg, sizeof(FusedGraph));
     HIPCHK(ctx, hipMemcpyAsync(d_up, h, up_bytes, hipMemcpyHostToDevice, s));
     // the pinned block belongs to the ctx and is rewritten by the next run only, after this one has synchronised
@@ -1026,6 +1050,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
                            (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, pre_zeroed, d_lf, L,
                            count_rows ? d_kcnt : (uint32_t *)nullptr);
       last_esz = (uint32_t)esz;
+      if (giant && hipMemsetAsync(ctx->giant_part.p, 0, giant_tags * 4, s) != hipSuccess) { ctx->last_error = "giant tags"; return HSPF_E_HIP; }
       if (nar) hipLaunchKernelGGL((k_init_fused<uint32_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
       else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
       uint32_t n_f = 0;
@@ -1034,6 +1059,15 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 #define HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, UN_, stp_) hipLaunchKernelGGL((k_fused<ST_, MI_, CN_, UN_>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, gd.in_ptr, gd.out_ptr, gd.vflags, stp_, d_roots, d_lf, net_nh, ignore_ovl, P, gd.in_src, gd.in_w, gd.out_dst, gd.e_in)
 #define HSPF_LAUNCH_FUSED(ST_, MI_, CN_, stp_) do { if (units) HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, true, stp_); else HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, false, stp_); } while (0)
         const bool units = g->n_heavy_chunks != 0;
+        if (giant) {                                   // slices of the due giant rows, ahead of the sweep that merges them
+          const dim3 ggrid(g->n_giant_slices, B);
+#define HSPF_LAUNCH_GIANT(ST_, MI_, stp_) do { if (P.hc) hipLaunchKernelGGL((k_giant_part<ST_, MI_, true>), ggrid, dim3(256), 0, s, d_fg, (const int *)d_changed, (int)sweep, (const uint32_t *)d_stamp, n, (const ST_ *)stp_, (const uint32_t *)d_roots, net_nh, ignore_ovl, P); \
+                                            else hipLaunchKernelGGL((k_giant_part<ST_, MI_, false>), ggrid, dim3(256), 0, s, d_fg, (const int *)d_changed, (int)sweep, (const uint32_t *)d_stamp, n, (const ST_ *)stp_, (const uint32_t *)d_roots, net_nh, ignore_ovl, P); } while (0)
+          if (nar)         HSPF_LAUNCH_GIANT(uint32_t, false, (uint32_t *)d_st);
+          else if (maxinf) HSPF_LAUNCH_GIANT(uint64_t, true, d_st);
+          else             HSPF_LAUNCH_GIANT(uint64_t, false, d_st);
+#undef HSPF_LAUNCH_GIANT
+        }
         if (count_rows) {
           if (nar)         HSPF_LAUNCH_FUSED(uint32_t, false, true, (uint32_t *)d_st);
           else if (maxinf) HSPF_LAUNCH_FUSED(uint64_t, true, true, d_st);

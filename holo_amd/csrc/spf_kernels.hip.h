@@ -78,9 +78,20 @@ struct GraphDev {
   const uint32_t *unit_first;
   uint32_t n_heavy_units;
   uint32_t xcd_heavy[9];
+  // Giant rows (more than GIANT_DEG in-links: the pseudonode of a LAN with hundreds or thousands of routers).  Even one
+  // row per wave is then a chain of hundreds of dependent round trips per visit (isis-100k plus ONE 1 000-router LAN: 3.1
+  // instead of 0.9 ms per 64-root run, 5 000 routers: 12 ms).  Such a row is cut into slices of GIANT_SLICE links;
+  // k_giant_part evaluates the slices of the due giant rows in parallel before every sweep (one workgroup per slice) and
+  // the sweep's own visit of the row merges the slices' accumulators in row order instead of walking the links.
+  const uint32_t *giant_vtx;     // [n_giant] ascending
+  const uint32_t *giant_slice0;  // [n_giant + 1] first slice of every giant row; [n_giant] = number of slices
+  uint32_t n_giant;
 };
 constexpr uint32_t UNIT_SPLIT = 0x80000000u;
 constexpr uint32_t UNIT_HEAVY_DEG = 32u;
+constexpr uint32_t GIANT_DEG = 256u;
+constexpr uint32_t GIANT_SLICE = 256u;          // links per slice: one workgroup, 64 links per wave
+constexpr uint32_t GIANT_WORDS = 8u;            // accumulator words per lane and slice (AnyAcc)
 
 struct OutDev {
   uint32_t *dist; uint16_t *hops; uint16_t *flags; uint64_t *mask; uint32_t out_words;
@@ -93,6 +104,7 @@ constexpr uint32_t RF_MANY = 1u;      // more than 16 kept in-links
 constexpr uint32_t RF_NT = 2u;        // an in-link from an overloaded (no-transit) source
 constexpr uint32_t RF_ZERO = 4u;      // a zero-cost in-link from a higher- or equal-numbered source
 constexpr uint32_t RF_HNB = 8u;       // an in-neighbour that can have hops == 0 for some root of the batch
+constexpr uint32_t RF_GIANT = 16u;    // more than GIANT_DEG kept in-links: the row is evaluated in slices (k_giant_part)
 
 struct SlotTabs {           // per root: H vertices and their slot bases (include/holo_spf_hip.h)
   const uint32_t *ptr;      // [n_root_slots+1]
@@ -475,7 +487,9 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
 // evaluated, spread over 256 words and summed by the host (hspf_stats.rows_recomputed).  Not touched otherwise: even
 // one fire-and-forget atomic per wave behind a scalar pointer load measurably lengthens the ~10 us life of a wave
 // (profiles/r02_notes.md: 0.93 vs 0.85 ms per batch).
-struct FusedGraph { GraphDev g; SlotTabs tabs; uint32_t *rows_done; uint32_t pad_[2]; };   // device-resident descriptor of one run
+// giant_part: [tags: batches x n_giant, padded to 64 words | accumulators: batches x slices x GIANT_WORDS x 64 lanes]; a tag
+// holds sweep + 1 of the sweep whose k_giant_part filled the row's slices for that batch (0: never)
+struct FusedGraph { GraphDev g; SlotTabs tabs; uint32_t *rows_done; uint32_t *giant_part; };   // device-resident descriptor of one run
 
 struct FusedParams {
   uint32_t sh;        // bit position of the dist field (narrow) / 0 (wide: dist is the high word)
@@ -689,39 +703,35 @@ __device__ __forceinline__ RowOut<ST> fused_row16(__amdgpu_buffer_rsrc_t rs, uin
 // General row routine (rare: rows next to a vertex that can have hops == 0, overloaded sources,
 // zero-cost links from higher-numbered sources, more than 16 links): rolled loops, four neighbour rows in flight.
 // Inlined all the same: a real call would need a stack, i.e. scratch memory.
-template <typename ST, bool MAXINF, bool HC>
-__device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v,
-                                                    uint32_t e0, uint32_t e1, uint32_t sv0, uint32_t wv0,
-                                                    uint32_t lane, uint32_t lvo, uint32_t my_root,
-                                                    uint32_t root_slot, const SlotTabs &tabs,
-                                                    uint32_t net_nexthops, uint32_t ignore_ovl,
-                                                    const FusedParams &P) {
-  const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
-  RowAcc a{INF, 0u, INF, 0u, false};
-  uint32_t bd_all = INF;
-  uint32_t zb = INF, zm = 0u, zh = 0u;      // hop-count-like graphs: best zero-cost link from a higher-numbered source
-  for (uint32_t eb = e0; eb < e1; eb += 64) {
-    const uint32_t cnt = min(64u, e1 - eb);
-    uint32_t sv = sv0, wv = wv0;
-    if (eb != e0) {
-      sv = lane < cnt ? g.in_src[eb + lane] : v;
-      wv = lane < cnt ? g.in_w[eb + lane] : INF;
-    }
-    const bool has_nt = !ignore_ovl && __ballot(lane < cnt && (sv & SRC_NO_TRANSIT) != 0) != 0ull;
-    const uint32_t zv = (lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
-    const bool has_z = __ballot(zv != 0u) != 0ull;
-    const uint32_t so = (lane < cnt ? (sv & SRC_MASK) : v) << StIO<ST>::ROW_SHIFT;
-    const uint32_t wk = lane < cnt ? (wv << P.sh) : INF;
-    // PF neighbour rows are requested before the first of them is consumed: a row with 100 links (a fat-tree switch, a
-    // big LAN) otherwise pays 100 dependent round trips.  Lanes >= cnt of `so` point at the own row: harmless loads.
-    constexpr uint32_t PF = 4;
+// Accumulator of the general routine: RowAcc + the zero-cost-link side state.
+struct AnyAcc { RowAcc a; uint32_t bd_all, zb, zm, zh; };
+__device__ __forceinline__ AnyAcc any_acc_init() { return AnyAcc{RowAcc{INF, 0u, INF, 0u, false}, INF, INF, 0u, 0u}; }
+
+// Up to 64 links (lane j of sv / wv = link eb + j: source | NT bit, cost; lanes >= cnt: the row itself / INF) into x.
+template <typename ST, bool MAXINF, bool HC, int PFN>
+__device__ __forceinline__ void row_any_chunk(AnyAcc &x, const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v,
+                                              uint32_t v_router, uint32_t eb, uint32_t cnt, uint32_t sv, uint32_t wv,
+                                              uint32_t lane, uint32_t lvo, uint32_t my_root, uint32_t root_slot,
+                                              const SlotTabs &tabs, uint32_t net_nexthops, uint32_t ignore_ovl,
+                                              const FusedParams &P) {
+  RowAcc &a = x.a;
+  const bool has_nt = !ignore_ovl && __ballot(lane < cnt && (sv & SRC_NO_TRANSIT) != 0) != 0ull;
+  const uint32_t zv = (lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
+  const bool has_z = __ballot(zv != 0u) != 0ull;
+  const uint32_t so = (lane < cnt ? (sv & SRC_MASK) : v) << StIO<ST>::ROW_SHIFT;
+  const uint32_t wk = lane < cnt ? (wv << P.sh) : INF;
+  // PF neighbour rows are requested before the first of them is consumed: a row with 100 links (a fat-tree switch, a
+  // big LAN) otherwise pays 100 dependent round trips.  Lanes >= cnt of `so` point at the own row: harmless loads.
+  // 4 in the sweep kernel (the registers of more cost the headline 9 %, r02m; 16 in the work-unit instantiation alone cost
+  // isis-100k + a 100-router LAN 0.84 -> 0.96 ms, r02t), 16 in k_giant_part.
+  constexpr uint32_t PF = (uint32_t)PFN;
 #pragma unroll 1
-    for (uint32_t j0 = 0; j0 < cnt; j0 += PF) {
-      typename StIO<ST>::Raw qq[PF];
+  for (uint32_t j0 = 0; j0 < cnt; j0 += PF) {
+    typename StIO<ST>::Raw qq[PF];
 #pragma unroll
-      for (uint32_t k = 0; k < PF; ++k) qq[k] = StIO<ST>::ld(rs, lvo, rdlane(so, min(j0 + k, 63u)));
+    for (uint32_t k = 0; k < PF; ++k) qq[k] = StIO<ST>::ld(rs, lvo, rdlane(so, min(j0 + k, 63u)));
 #pragma unroll
-      for (uint32_t k = 0; k < PF; ++k) {
+    for (uint32_t k = 0; k < PF; ++k) {
       const uint32_t j = j0 + k;
       if (j >= cnt) break;
       typename StIO<ST>::Raw q = qq[k];
@@ -733,8 +743,8 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
       const uint32_t c = add_sat(d, w);
       if (MAXINF && sizeof(ST) == 8 && c == INF && d != INF && w != INF) a.sat = true;
       const bool zlink = has_z && rdlane(zv, j) != 0u;            // uniform
-      if (zlink && !HC) { bd_all = min(bd_all, c); continue; }
-      const bool lt = (HC && zlink) ? (c < zb) : (c < a.bd), eq = !(HC && zlink) && c == a.bd;
+      if (zlink && !HC) { x.bd_all = min(x.bd_all, c); continue; }
+      const bool lt = (HC && zlink) ? (c < x.zb) : (c < a.bd), eq = !(HC && zlink) && c == a.bd;
       const uint32_t hh = pay >> P.mbits;
       uint32_t contrib = pay & ((1u << P.mbits) - 1u);
       const bool direct = (lt || eq) && hh == 0u && c < P.inf_t;  // parent: root or hops-0 network
@@ -753,7 +763,7 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
         // list by the FIRST of them to be popped — the lowest-numbered one, rows list equal-cost links
         // by ascending source — and, its own index being lower than any router's, is popped next:
         // the later routers find it on the SPT already (spf.rs:630-632).  One parent, no union.
-        if (lt) { zb = c; zm = contrib; zh = hh; }
+        if (lt) { x.zb = c; x.zm = contrib; x.zh = hh; }
         continue;
       }
       const uint32_t m_or = a.bm | contrib;
@@ -762,16 +772,149 @@ __device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_
       a.bpd = newp ? d : a.bpd;
       a.bh = newp ? hh : a.bh;
       a.bd = min(a.bd, c);
-      }
     }
   }
+}
+
+template <typename ST, bool HC>
+__device__ __forceinline__ RowOut<ST> any_finish(AnyAcc &x, uint32_t v, uint32_t my_root, uint32_t v_router,
+                                                 const FusedParams &P) {
+  RowAcc &a = x.a;
   if (HC) {                                 // late vertex: strictly better through the zero-cost links
-    const bool late = zb < a.bd;
-    a.bm = late ? zm : a.bm;
-    a.bh = late ? zh : a.bh;
-    a.bd = late ? zb : a.bd;
+    const bool late = x.zb < a.bd;
+    a.bm = late ? x.zm : a.bm;
+    a.bh = late ? x.zh : a.bh;
+    a.bd = late ? x.zb : a.bd;
   }
-  return finish_row<ST>(a, v, my_root, v_router, bd_all, P);
+  return finish_row<ST>(a, v, my_root, v_router, x.bd_all, P);
+}
+
+template <typename ST, bool MAXINF, bool HC, int PFN>
+__device__ __forceinline__ RowOut<ST> fused_row_any(const GraphDev &g, __amdgpu_buffer_rsrc_t rs, uint32_t v,
+                                                    uint32_t e0, uint32_t e1, uint32_t sv0, uint32_t wv0,
+                                                    uint32_t lane, uint32_t lvo, uint32_t my_root,
+                                                    uint32_t root_slot, const SlotTabs &tabs,
+                                                    uint32_t net_nexthops, uint32_t ignore_ovl,
+                                                    const FusedParams &P) {
+  const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
+  AnyAcc x = any_acc_init();
+  for (uint32_t eb = e0; eb < e1; eb += 64) {
+    const uint32_t cnt = min(64u, e1 - eb);
+    uint32_t sv = sv0, wv = wv0;
+    if (eb != e0) {
+      sv = lane < cnt ? g.in_src[eb + lane] : v;
+      wv = lane < cnt ? g.in_w[eb + lane] : INF;
+    }
+    row_any_chunk<ST, MAXINF, HC, PFN>(x, g, rs, v, v_router, eb, cnt, sv, wv, lane, lvo, my_root, root_slot, tabs,
+                                       net_nexthops, ignore_ovl, P);
+  }
+  return any_finish<ST, HC>(x, v, my_root, v_router, P);
+}
+
+// ---- giant rows ----------------------------------------------------------------------------------------
+// Merge of two accumulators, `y` covering links that FOLLOW those of `x` in row order: what walking y's links after x's
+// would have left (strictly smaller candidate replaces, equal one ORs the mask and takes over the parent only with a
+// strictly smaller parent distance; the zero-cost side state: strictly smaller only).
+__device__ __forceinline__ void any_merge(AnyAcc &x, const AnyAcc &y) {
+  const bool lt = y.a.bd < x.a.bd, eq = y.a.bd == x.a.bd;
+  const bool newp = lt || (eq && y.a.bpd < x.a.bpd);
+  x.a.bm = lt ? y.a.bm : (eq ? (x.a.bm | y.a.bm) : x.a.bm);
+  x.a.bpd = newp ? y.a.bpd : x.a.bpd;
+  x.a.bh = newp ? y.a.bh : x.a.bh;
+  x.a.bd = min(x.a.bd, y.a.bd);
+  x.a.sat = x.a.sat || y.a.sat;
+  x.bd_all = min(x.bd_all, y.bd_all);
+  const bool zl = y.zb < x.zb;
+  x.zm = zl ? y.zm : x.zm; x.zh = zl ? y.zh : x.zh; x.zb = min(x.zb, y.zb);
+}
+
+__device__ __forceinline__ uint32_t giant_index(const GraphDev &g, uint32_t v) {      // v is a giant row
+  uint32_t lo = 0, hi = g.n_giant;
+  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (g.giant_vtx[mid] <= v) lo = mid; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ uint32_t giant_tag_words(uint32_t batches, uint32_t n_giant) { return (batches * n_giant + 63u) & ~63u; }
+
+// One workgroup per (slice of a giant row, batch): wave w evaluates links [64 w, 64 w + 64) of the slice with the general
+// routine, the four accumulators are merged in row order through LDS and stored (GIANT_WORDS x 64 lanes).  Launched
+// before every sweep of k_fused on graphs with giant rows; a row that is not due costs its slices one load each.
+template <typename ST, bool MAXINF, bool HC>
+__global__ __launch_bounds__(256) void k_giant_part(const FusedGraph *__restrict__ gp, const int *changed, int sweep,
+                                                    const uint32_t *__restrict__ act, uint32_t n, const ST *__restrict__ st,
+                                                    const uint32_t *__restrict__ roots, uint32_t net_nexthops,
+                                                    uint32_t ignore_ovl, FusedParams P) {
+  __shared__ uint32_t sh[3][GIANT_WORDS][64];
+  if (sweep > 0 && changed[sweep - 1] == 0) return;
+  const GraphDev &g = gp->g;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t slice = blockIdx.x, batch = blockIdx.y;
+  uint32_t gi = 0;                                     // the giant row that owns the slice
+  { uint32_t lo = 0, hi = g.n_giant;
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (g.giant_slice0[mid] <= slice) lo = mid; else hi = mid; }
+    gi = lo; }
+  const uint32_t v = g.giant_vtx[gi];
+  if (act[(size_t)batch * n + v] < (uint32_t)sweep + 2u) return;          // not due in this sweep (uniform)
+  const uint32_t s_in_row = slice - g.giant_slice0[gi];
+  const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
+  const uint32_t eb = e0 + s_in_row * GIANT_SLICE + wave * 64u;
+  const uint32_t cnt = eb < e1 ? min(64u, e1 - eb) : 0u;
+  const uint32_t root_slot = batch * 64 + lane;
+  const uint32_t my_root = roots[root_slot];
+  const ST *S = st + (size_t)batch * n * 64;
+  const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, n << StIO<ST>::ROW_SHIFT);
+  const uint32_t lvo = lane * (uint32_t)sizeof(ST);
+  const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
+  AnyAcc x = any_acc_init();
+  if (cnt) {
+    const uint32_t sv = lane < cnt ? g.in_src[eb + lane] : v;
+    const uint32_t wv = lane < cnt ? g.in_w[eb + lane] : INF;
+    row_any_chunk<ST, MAXINF, HC, 16>(x, g, rs, v, v_router, eb, cnt, sv, wv, lane, lvo, my_root, root_slot, gp->tabs,
+                                      net_nexthops, ignore_ovl, P);
+  }
+  if (wave) {
+    uint32_t (*o)[64] = sh[wave - 1u];
+    o[0][lane] = x.a.bd; o[1][lane] = x.a.bm; o[2][lane] = x.a.bpd; o[3][lane] = x.a.bh | (x.a.sat ? 0x80000000u : 0u);
+    o[4][lane] = x.bd_all; o[5][lane] = x.zb; o[6][lane] = x.zm; o[7][lane] = x.zh;
+  }
+  __syncthreads();
+  if (wave) return;
+  for (uint32_t k = 0; k < 3u; ++k) {
+    const uint32_t (*o)[64] = sh[k];
+    AnyAcc y{RowAcc{o[0][lane], o[1][lane], o[2][lane], o[3][lane] & 0x7FFFFFFFu, (o[3][lane] >> 31) != 0u},
+             o[4][lane], o[5][lane], o[6][lane], o[7][lane]};
+    any_merge(x, y);
+  }
+  const uint32_t B = gridDim.y, n_slices = g.giant_slice0[g.n_giant];
+  uint32_t *part = gp->giant_part + giant_tag_words(B, g.n_giant) + ((size_t)batch * n_slices + slice) * (GIANT_WORDS * 64u);
+  part[0 * 64 + lane] = x.a.bd; part[1 * 64 + lane] = x.a.bm; part[2 * 64 + lane] = x.a.bpd;
+  part[3 * 64 + lane] = x.a.bh | (x.a.sat ? 0x80000000u : 0u);
+  part[4 * 64 + lane] = x.bd_all; part[5 * 64 + lane] = x.zb; part[6 * 64 + lane] = x.zm; part[7 * 64 + lane] = x.zh;
+  if (s_in_row == 0u && lane == 0u) gp->giant_part[(size_t)batch * g.n_giant + gi] = (uint32_t)sweep + 1u;
+}
+
+// The sweep's visit of a giant row: the slices' accumulators of THIS sweep merged in row order.  false: k_giant_part did
+// not evaluate the row for this sweep (it was stamped after that launch had looked) — the row stays stamped and is due
+// in the next sweep, which exists because whoever stamped it has set this sweep's flag.
+template <typename ST, bool HC>
+__device__ __forceinline__ bool fused_row_giant(const FusedGraph *gp, uint32_t v, uint32_t batch, uint32_t batches,
+                                                int sweep, uint32_t lane, uint32_t my_root, uint32_t v_router,
+                                                const FusedParams &P, RowOut<ST> &out) {
+  const GraphDev &g = gp->g;
+  const uint32_t gi = giant_index(g, v);
+  if (gp->giant_part[(size_t)batch * g.n_giant + gi] != (uint32_t)sweep + 1u) return false;
+  const uint32_t s0 = g.giant_slice0[gi], s1 = g.giant_slice0[gi + 1], n_slices = g.giant_slice0[g.n_giant];
+  const uint32_t *part = gp->giant_part + giant_tag_words(batches, g.n_giant) + ((size_t)batch * n_slices + s0) * (GIANT_WORDS * 64u);
+  AnyAcc x = any_acc_init();
+#pragma unroll 2
+  for (uint32_t sidx = s0; sidx < s1; ++sidx, part += GIANT_WORDS * 64u) {
+    const uint32_t w3 = part[3 * 64 + lane];
+    AnyAcc y{RowAcc{part[0 * 64 + lane], part[1 * 64 + lane], part[2 * 64 + lane], w3 & 0x7FFFFFFFu, (w3 >> 31) != 0u},
+             part[4 * 64 + lane], part[5 * 64 + lane], part[6 * 64 + lane], part[7 * 64 + lane]};
+    any_merge(x, y);
+  }
+  out = any_finish<ST, HC>(x, v, my_root, v_router, P);
+  return true;
 }
 
 // Wave schedule (what the sweep time is made of: SIMD utilisation = resident waves x compute /
@@ -882,10 +1025,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
       RowOut<ST> r;
       if (rdlane(hb, lb + i) == 0u)
         r = fused_row16<ST, MAXINF>(rs, v, e1 - e0, svv[i], wvv[i], lvo, my_root, v_router, P);
-      else if (P.hc)       // hop-count-like graphs only (MANET): its own instantiation keeps the usual one lean
-        r = fused_row_any<ST, MAXINF, true>(gp->g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
+      else if (UNITS && (rdlane(hb, lb + i) & RF_GIANT)) {        // slices evaluated by k_giant_part before this launch
+        const bool got = P.hc ? fused_row_giant<ST, true>(gp, v, batch, gridDim.y, sweep, lane, my_root, v_router, P, r)
+                              : fused_row_giant<ST, false>(gp, v, batch, gridDim.y, sweep, lane, my_root, v_router, P, r);
+        if (!got) return;
+      } else if (P.hc)       // hop-count-like graphs only (MANET): its own instantiation keeps the usual one lean
+        r = fused_row_any<ST, MAXINF, true, 4>(gp->g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
       else
-        r = fused_row_any<ST, MAXINF, false>(gp->g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
+        r = fused_row_any<ST, MAXINF, false, 4>(gp->g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
       sat = sat || r.sat;
       need_exact = need_exact || r.need_exact;
       ovf = ovf || r.ovf;

@@ -12,7 +12,7 @@ Semantics restated (include/holo_spf_hip.h, hspf_graph_export):
 import numpy as np
 
 VF_NETWORK, VF_NO_TRANSIT, VF_NO_EXPAND = 1, 2, 4
-RF_MANY, RF_NT, RF_ZERO = 1, 2, 4
+RF_MANY, RF_NT, RF_ZERO, RF_GIANT = 1, 2, 4, 16
 
 
 def layout(row_ptr, col, metric, vflags):
@@ -37,7 +37,7 @@ def layout(row_ptr, col, metric, vflags):
     t_o, w_o, s_o = kt[order], kw[order], ks[order]
     for t in range(n):
         a, b = in_ptr[t], in_ptr[t + 1]
-        f = RF_MANY if b - a > 16 else 0
+        f = (RF_MANY if b - a > 16 else 0) | (RF_GIANT if b - a > 256 else 0)
         if nt[a:b].any():
             f |= RF_NT
         if ((w_o[a:b] == 0) & (s_o[a:b] >= t)).any():

@@ -527,3 +527,40 @@ def test_wide_mask_hop_field_overflow_falls_back_to_two_phase(spf_ctx):
             assert res.stats["state_bytes"] == 0                 # ended on the u16-hops path (k_fw, or k_relax + k_dag)
     finally:
         G.free()
+
+
+@both_engines
+@pytest.mark.parametrize("hopcount", [False, True])
+@pytest.mark.parametrize("run_flags", [0, E.RUN_NET_NEXTHOPS | E.RUN_IGNORE_OVERLOAD])
+def test_giant_rows_are_evaluated_in_slices(spf_ctx, hopcount, run_flags):
+    """Three LANs of 700 routers among 3 000 (pseudonode rows of ~700 in-links: three slices each, k_giant_part), overloaded
+    members, roots off the LANs (one mask word: the packed fused path), one batch and three ragged ones; then a row patch
+    that shrinks one LAN below the giant threshold."""
+    g = synth.random_lsdb(3000, 3, 2.5, 4242, metric_hi=9, lan_size=700, p_overload=0.05, hopcount=hopcount)
+    if hopcount:
+        run_flags |= E.RUN_IGNORE_OVERLOAD
+    on_lan = np.zeros(g.n, bool)
+    for net in range(3):
+        on_lan[g.col[g.row_ptr[net]:g.row_ptr[net + 1]]] = True
+    off = np.nonzero(~on_lan)[0]
+    off = off[off >= 3].astype(np.uint32)
+    assert len(off) > 300
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        assert int(np.diff(G.export("in_ptr")).max()) > 256 and int(((G.export("rowflags") & 16) != 0).sum()) == 3
+        for roots in (off[:64], off[40:40 + 170]):
+            res = spf_ctx.run(G, roots, run_flags)
+            ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, run_flags & 3, go.HEAP,
+                         mask_words_=res.first_hop_mask.shape[2])
+            assert res.first_hop_mask.shape[2] == 1
+            for f in ("dist", "hops", "first_hop_mask"):
+                assert np.array_equal(getattr(res, f), getattr(ref, "mask" if f == "first_hop_mask" else f)), f
+        a, b = int(g.row_ptr[1]), int(g.row_ptr[2])
+        G.patch([1], [(g.col[a:a + 100].copy(), g.metric[a:a + 100].copy())], [g.vflags[1]])
+        assert int(((G.export("rowflags") & 16) != 0).sum()) == 2
+        g2 = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
+        res = spf_ctx.run(G, off[:64], run_flags)
+        ref = go.run(g2.row_ptr, g2.col, g2.metric, g2.vflags, g2.max_path_metric, off[:64], run_flags & 3, go.HEAP, mask_words_=1)
+        assert np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops) and np.array_equal(res.first_hop_mask, ref.mask)
+    finally:
+        G.free()

@@ -96,7 +96,8 @@ def fuzz_wide(ctx, first, count, verbose=True):
     for seed in range(first, first + count):
         rng = np.random.default_rng(130_000 + seed)
         lan = int(rng.choice([150, 260, 400, 640, 900]))
-        nr = lan + int(rng.integers(0, 300))
+        nr = lan + int(rng.integers(0, 300)) if rng.random() < 0.5 else lan * int(rng.integers(2, 5))   # most routers off the LAN:
+                                                                  # one mask word, the LAN's row is a giant row of k_fused
         nn = int(rng.integers(1, 4))
         hop = rng.random() < 0.15
         g = synth.random_lsdb(nr, nn, float(rng.uniform(1.0, 3.0)), 140_000 + seed, metric_lo=1, metric_hi=int(rng.integers(1, 12)),
