@@ -1106,7 +1106,9 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     // A few roots on a larger graph: lane = vertex (k_lv), one launch per sweep over the root's own row-major state.  The
     // lane = root engine spends a 256-byte row per useful 4-8 bytes there (isis-100k, one root: 25 launches x 21 us);
     // the scattered gathers of k_lv cost less than that up to a handful of roots (profiles/r02_notes.md, r02k).
-    const bool lv = !single && n_roots <= ctx->lv_max_roots && n >= ctx->lv_min_n;
+    // (not on graphs with giant rows: a lane of k_lv walks its row alone — one root on isis-100k + a 5 000-router LAN took
+    // 6.9 ms there against 0.9 ms for 64 roots on the sweep engine with the row in slices, r02t)
+    const bool lv = !single && n_roots <= ctx->lv_max_roots && n >= ctx->lv_min_n && !giant;
     auto lv_run = [&]() -> int {
       int r2;
       if ((r2 = ensure(ctx, ctx->stamp, (size_t)n_roots * n * 4))) return r2;

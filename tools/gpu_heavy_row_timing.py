@@ -37,7 +37,7 @@ def main():
     dev = torch.device("cuda:0")
     ctx = E.SpfContext(0)
     base = synth.isis_100k()
-    for D in (0, 100, 1000, 5000, 20000):
+    for D in (0, 100, 900, 1000, 5000, 20000):
         g = with_lan(base, D) if D else base
         n = g.n
         roots = ((np.arange(64, dtype=np.int64) * (n - 1)) // 64 + 1).astype(np.uint32)
@@ -56,6 +56,24 @@ def main():
             ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots[:8], 0, go.HEAP, mask_words_=W)
             rec["verified_8_roots"] = bool(np.array_equal(d[:8].cpu().numpy().view(np.uint32), ref.dist)
                                            and np.array_equal(m[:8].cpu().numpy().view(np.uint64), ref.mask))
+        # one root (k_lv on a graph of this size) and, for a LAN the mask words can hold, 64 roots that are MEMBERS (k_fw)
+        r1 = roots[:1]
+        ms1 = []
+        for _ in range(5):
+            st = ctx.run_device(G, r1, 0, dist_ptr=d.data_ptr(), hops_ptr=h.data_ptr(), flags_ptr=f.data_ptr(),
+                                mask_ptr=m.data_ptr(), mask_words=W)
+            ms1.append(st["ms_total"])
+        rec["one_root_ms"] = round(float(np.median(ms1[2:])), 3); rec["one_root_lv"] = st["lane_vertex"]
+        if 0 < D <= 900:
+            mem = g.col[g.row_ptr[0]:g.row_ptr[1]][:64].astype(np.uint32)
+            Wm = G.mask_words(mem)
+            mm = torch.empty((64, n, Wm), dtype=torch.int64, device=dev)
+            msm = []
+            for _ in range(5):
+                st = ctx.run_device(G, mem, 0, dist_ptr=d.data_ptr(), hops_ptr=h.data_ptr(), flags_ptr=f.data_ptr(),
+                                    mask_ptr=mm.data_ptr(), mask_words=Wm)
+                msm.append(st["ms_total"])
+            rec["member_roots_ms"] = round(float(np.median(msm[2:])), 3); rec["member_roots_words"] = Wm
         print(json.dumps(rec), flush=True)
         G.free()
 
