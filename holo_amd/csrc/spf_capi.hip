@@ -909,9 +909,13 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     ctx->h_lane_cap = L;
   }
   // slices of the giant rows (FusedGraph::giant_part): tags, then GIANT_WORDS x 64 words per (batch, slice)
-  const bool giant = g->n_giant != 0 && g->n_heavy_chunks != 0;
+  const bool giant = g->n_giant != 0 && g->n_heavy_chunks != 0 && !(ctx->variant & 8192u);   // HSPF_VARIANT bit13: rows walked whole
   const size_t giant_tags = ((size_t)B * g->n_giant + 63) & ~size_t(63);
-  if (giant && (rc = ensure(ctx, ctx->giant_part, (giant_tags + (size_t)B * g->n_giant_slices * GIANT_WORDS * 64) * 4))) return rc;
+  if (giant) {                                           // packed path: one accumulator per slice; k_fw: one per 64 links, W-word masks
+    const size_t packed = (size_t)B * g->n_giant_slices * GIANT_WORDS * 64 * 4;
+    const size_t wide = (size_t)B * g->n_giant_slices * 4 * (6 * 64 * 4 + 2 * (size_t)W * 64 * 8);
+    if ((rc = ensure(ctx, ctx->giant_part, giant_tags * 4 + std::max(packed, wide)))) return rc;
+  }
   // work counter of the fused kernel (HSPF_RUN_COUNT_ROWS): [256] rows recomputed
   if ((rc = ensure(ctx, ctx->kcnt, 256 * 4))) return rc;
   uint32_t *d_kcnt = (uint32_t *)ctx->kcnt.p;
@@ -954,7 +958,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     std::copy(tab_vtx.begin(), tab_vtx.end(), h + w_vtx);
     std::copy(tab_base.begin(), tab_base.end(), h + w_base);
     for (uint32_t r = 0; r < L; ++r) h[w_map + r] = (row_map && r < n_roots) ? row_map[r] : r;
-    const FusedGraph fg{gd, tabs, d_kcnt, (uint32_t *)ctx->giant_part.p};
+    const FusedGraph fg{gd, tabs, d_kcnt, giant ? (uint32_t *)ctx->giant_part.p : (uint32_t *)nullptr};
     memcpy(h + w_fg, &fg, sizeof(FusedGraph));
     HIPCHK(ctx, hipMemcpyAsync(d_up, h, up_bytes, hipMemcpyHostToDevice, s));
     // the pinned block belongs to the ctx and is rewritten by the next run only, after this one has synchronised
@@ -1225,10 +1229,15 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     HIPCHK(ctx, hipMemsetAsync(d_mask, 0, rows * 8 * W, s));
     HIPCHK(ctx, hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s));
     hipLaunchKernelGGL(k_init_fw, dim3((L + 255) / 256), dim3(256), 0, s, gd, d_dist, d_stamp, d_roots, L);
+    if (giant) HIPCHK(ctx, hipMemsetAsync(ctx->giant_part.p, 0, giant_tags * 4, s));
     const bool mi = g->max_path_metric == HSPF_DIST_INF, hcl = g->hopcount_like;
+    const dim3 ggrid(std::max(g->n_giant_slices, 1u), B);
     uint32_t n_fw = 0;
     rc = run_phase(ctx->est_fw, 0u, [&](uint32_t sweep) {
+#define HSPF_FWG(W_, MI_, HC_) hipLaunchKernelGGL((k_fw_giant_part<W_, MI_, HC_>), ggrid, dim3(256), 0, s, d_fg, (const uint32_t *)d_dist, (const uint32_t *)d_hv, (const uint64_t *)d_mask, (const uint32_t *)d_stamp, (const uint32_t *)d_roots, net_nh, ignore_ovl, (const int *)d_changed, (int)sweep)
 #define HSPF_FW(W_) do { \
+      if (giant) { if (hcl) { if (mi) HSPF_FWG((W_ <= 4 ? W_ : 1), true, true); else HSPF_FWG((W_ <= 4 ? W_ : 1), false, true); } \
+                   else     { if (mi) HSPF_FWG(W_, true, false); else HSPF_FWG(W_, false, false); } } \
       if (hcl) { if (mi) hipLaunchKernelGGL((k_fw<(W_ <= 4 ? W_ : 1), true, true>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); \
                  else    hipLaunchKernelGGL((k_fw<(W_ <= 4 ? W_ : 1), false, true>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); } \
       else     { if (mi) hipLaunchKernelGGL((k_fw<W_, true, false>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); \
@@ -1241,6 +1250,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         default: HSPF_FW(16); break;
       }
 #undef HSPF_FW
+#undef HSPF_FWG
     }, n_fw, []() {});
     if (rc) return rc;
     ctx->est_fw = n_fw + 1;

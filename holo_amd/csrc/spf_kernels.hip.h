@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
       RowOut<ST> r;
       if (rdlane(hb, lb + i) == 0u)
         r = fused_row16<ST, MAXINF>(rs, v, e1 - e0, svv[i], wvv[i], lvo, my_root, v_router, P);
-      else if (UNITS && (rdlane(hb, lb + i) & RF_GIANT)) {        // slices evaluated by k_giant_part before this launch
+      else if (UNITS && (rdlane(hb, lb + i) & RF_GIANT) && gp->giant_part != nullptr) {   // slices evaluated by k_giant_part before this launch
         const bool got = P.hc ? fused_row_giant<ST, true>(gp, v, batch, gridDim.y, sweep, lane, my_root, v_router, P, r)
                               : fused_row_giant<ST, false>(gp, v, batch, gridDim.y, sweep, lane, my_root, v_router, P, r);
         if (!got) return;
@@ -1746,16 +1746,199 @@ __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t n_roots,
 // a row that changes in sweep s stamps s + 2 on its out-neighbours (due next sweep — and in this one if not yet
 // visited).  Row routine: the per-lane accumulator of fused_row_any with W-word masks; hops and masks of a neighbour
 // are only requested when its candidate is <= the running minimum for some lane.
+// Row accumulator of k_fw: RowAcc with W-word masks + the zero-cost side state.
+template <int W, bool HC> struct FwAcc {
+  uint32_t bd, bpd, bh, bd_all, zb, zh;
+  bool sat;
+  uint64_t am[W];
+  uint64_t zm[HC ? W : 1];
+};
+template <int W, bool HC> __device__ __forceinline__ FwAcc<W, HC> fw_acc_init() {
+  FwAcc<W, HC> x;
+  x.bd = INF; x.bpd = INF; x.bh = 0u; x.bd_all = INF; x.zb = INF; x.zh = 0u; x.sat = false;
+#pragma unroll
+  for (int q = 0; q < W; ++q) x.am[q] = 0ull;
+#pragma unroll
+  for (int q = 0; q < (HC ? W : 1); ++q) x.zm[q] = 0ull;
+  return x;
+}
+
+// Up to 64 links (lane j of sv / wv = link eb + j) into x: the per-lane accumulator of fused_row_any with W-word masks;
+// the whole triple (distance, hops, W mask words) of DG links is requested in ONE round trip.  The sweep is bound by
+// dependent round trips, not bytes, on most rows: asking for the hops and masks only after the distances have shown
+// which links are tight — what k_dag does — doubles the chain.
+template <int W, bool MAXINF, bool HC>
+__device__ __forceinline__ void fw_chunk(FwAcc<W, HC> &x, const FusedGraph *__restrict__ gp, const uint32_t *D, const uint32_t *H,
+                                         const uint64_t *M, uint32_t v, uint32_t v_router, uint32_t eb, uint32_t cnt,
+                                         uint32_t sv, uint32_t wv, uint32_t lane, uint32_t my_root, uint32_t root_slot,
+                                         uint32_t net_nexthops, uint32_t ignore_ovl) {
+  constexpr int DG = W <= 2 ? 8 : (W <= 4 ? 4 : (W <= 8 ? 2 : 1));
+  const GraphDev &g = gp->g;
+  const uint32_t lane4 = lane * 4u, lane8 = lane * 8u;
+  const bool has_nt = !ignore_ovl && __ballot(lane < cnt && (sv & SRC_NO_TRANSIT) != 0) != 0ull;
+  const uint32_t zv = (lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
+  const bool has_z = __ballot(zv != 0u) != 0ull;
+#pragma unroll 1
+  for (uint32_t j0 = 0; j0 < cnt; j0 += DG) {
+    uint32_t du[DG], hu[DG];
+    uint64_t mu[DG][W];
+#pragma unroll
+    for (int k = 0; k < DG; ++k) {
+      const uint32_t u = rdlane(sv, min(j0 + (uint32_t)k, 63u)) & SRC_MASK;
+      const bool in = (j0 + k) < cnt;                                // uniform: no requests for a short row's padding
+      du[k] = in ? ld_row(D, u * 256u + lane4) : INF;
+      hu[k] = in ? ld_row(H, u * 256u + lane4) : 0u;
+#pragma unroll
+      for (int q = 0; q < W; ++q) mu[k][q] = in ? ld_row64(M, ((size_t)u * W + q) * 512u + lane8) : 0ull;
+    }
+    uint32_t cc[DG];
+#pragma unroll
+    for (int k = 0; k < DG; ++k) {
+      const uint32_t j = min(j0 + (uint32_t)k, 63u);
+      const uint32_t w = rdlane(wv, j);
+      uint32_t d = du[k];
+      if (has_nt) {
+        const uint32_t sw = rdlane(sv, j);
+        if ((sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;     // overloaded source
+      }
+      du[k] = d;
+      cc[k] = (j0 + k) < cnt ? add_sat(d, w) : INF;
+      if (MAXINF && cc[k] == INF && d != INF && w != INF) x.sat = true;
+    }
+#pragma unroll
+    for (int k = 0; k < DG; ++k) {
+      const uint32_t j = j0 + k;
+      if (j >= cnt) break;
+      const uint32_t c = cc[k], d = du[k];
+      const bool zlink = has_z && rdlane(zv, j) != 0u;              // uniform
+      if (zlink && !HC) { x.bd_all = min(x.bd_all, c); continue; }
+      const bool hz = HC && zlink;
+      const bool lt = hz ? (c < x.zb) : (c < x.bd), eq = !hz && c == x.bd && c != INF;
+      const uint32_t hh = hu[k] & 0xFFFFu;
+      uint64_t contrib[W];
+#pragma unroll
+      for (int q = 0; q < W; ++q) contrib[q] = mu[k][q];
+      const bool direct = (lt || eq) && hh == 0u && c != INF;      // parent: root or hops-0 network
+      if (__ballot(direct) != 0ull) {
+        const uint32_t u = rdlane(sv, j) & SRC_MASK;
+        const uint32_t fpos = g.in_fpos[eb + j];
+        if (direct) {
+          const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(gp->tabs, root_slot, u);
+          const uint32_t sidx = base_s + fpos;
+          const bool on = (v_router || net_nexthops) && sidx < (uint32_t)W * 64u;
+#pragma unroll
+          for (int q = 0; q < W; ++q) contrib[q] = (on && (sidx >> 6) == (uint32_t)q) ? (1ull << (sidx & 63u)) : 0ull;
+        }
+      }
+      if (hz) {
+        if (lt) {
+          x.zb = c; x.zh = hh;
+#pragma unroll
+          for (int q = 0; q < (HC ? W : 1); ++q) x.zm[q] = contrib[HC ? q : 0];
+        }
+        continue;
+      }
+#pragma unroll
+      for (int q = 0; q < W; ++q) x.am[q] = lt ? contrib[q] : (eq ? (x.am[q] | contrib[q]) : x.am[q]);
+      const bool newp = lt || (eq && d < x.bpd);
+      x.bpd = newp ? d : x.bpd;
+      x.bh = newp ? hh : x.bh;
+      x.bd = min(x.bd, c);
+    }
+  }
+}
+
+// y covers links that FOLLOW x's in row order (any_merge with W-word masks).  Candidates equal to INF never merge masks
+// (fw_chunk: eq requires c != INF).
+template <int W, bool HC>
+__device__ __forceinline__ void fw_merge(FwAcc<W, HC> &x, const FwAcc<W, HC> &y) {
+  const bool lt = y.bd < x.bd, eq = y.bd == x.bd && y.bd != INF;
+  const bool newp = lt || (eq && y.bpd < x.bpd);
+#pragma unroll
+  for (int q = 0; q < W; ++q) x.am[q] = lt ? y.am[q] : (eq ? (x.am[q] | y.am[q]) : x.am[q]);
+  x.bpd = newp ? y.bpd : x.bpd;
+  x.bh = newp ? y.bh : x.bh;
+  x.bd = min(x.bd, y.bd);
+  x.sat = x.sat || y.sat;
+  x.bd_all = min(x.bd_all, y.bd_all);
+  const bool zl = y.zb < x.zb;
+#pragma unroll
+  for (int q = 0; q < (HC ? W : 1); ++q) x.zm[q] = zl ? y.zm[q] : x.zm[q];
+  x.zh = zl ? y.zh : x.zh; x.zb = min(x.zb, y.zb);
+}
+
+// Slices of a giant row on the wide-mask path (see k_giant_part): one WAVE per 64 links, its accumulator stored as
+// [6 words x 64 lanes | am: W x 64 u64 | zm: W x 64 u64]; the tags are those of FusedGraph::giant_part.
+template <int W> __host__ __device__ constexpr size_t fw_part_bytes() { return 6u * 64u * 4u + 2u * (size_t)W * 64u * 8u; }
+
+template <int W, bool HC>
+__device__ __forceinline__ void fw_part_store(char *p, const FwAcc<W, HC> &x, uint32_t lane) {
+  uint32_t *w = (uint32_t *)p;
+  w[0 * 64 + lane] = x.bd; w[1 * 64 + lane] = x.bpd; w[2 * 64 + lane] = x.bh | (x.sat ? 0x80000000u : 0u);
+  w[3 * 64 + lane] = x.bd_all; w[4 * 64 + lane] = x.zb; w[5 * 64 + lane] = x.zh;
+  uint64_t *m = (uint64_t *)(p + 6 * 64 * 4);
+#pragma unroll
+  for (int q = 0; q < W; ++q) { m[q * 64 + lane] = x.am[q]; m[(W + q) * 64 + lane] = HC ? x.zm[HC ? q : 0] : 0ull; }
+}
+template <int W, bool HC>
+__device__ __forceinline__ FwAcc<W, HC> fw_part_load(const char *p, uint32_t lane) {
+  const uint32_t *w = (const uint32_t *)p;
+  FwAcc<W, HC> x;
+  const uint32_t w2 = w[2 * 64 + lane];
+  x.bd = w[0 * 64 + lane]; x.bpd = w[1 * 64 + lane]; x.bh = w2 & 0x7FFFFFFFu; x.sat = (w2 >> 31) != 0u;
+  x.bd_all = w[3 * 64 + lane]; x.zb = w[4 * 64 + lane]; x.zh = w[5 * 64 + lane];
+  const uint64_t *m = (const uint64_t *)(p + 6 * 64 * 4);
+#pragma unroll
+  for (int q = 0; q < W; ++q) x.am[q] = m[q * 64 + lane];
+#pragma unroll
+  for (int q = 0; q < (HC ? W : 1); ++q) x.zm[q] = HC ? m[(W + q) * 64 + lane] : 0ull;
+  return x;
+}
+
+template <int W, bool MAXINF, bool HC>
+__global__ __launch_bounds__(256) void k_fw_giant_part(const FusedGraph *__restrict__ gp, const uint32_t *__restrict__ dist,
+                                                       const uint32_t *__restrict__ hv, const uint64_t *__restrict__ mask,
+                                                       const uint32_t *__restrict__ act, const uint32_t *__restrict__ roots,
+                                                       uint32_t net_nexthops, uint32_t ignore_ovl, const int *changed, int sweep) {
+  if (sweep > 0 && changed[sweep - 1] == 0) return;
+  const GraphDev &g = gp->g;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t slice = blockIdx.x, batch = blockIdx.y, n = g.n;
+  uint32_t gi = 0;
+  { uint32_t lo = 0, hi = g.n_giant;
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (g.giant_slice0[mid] <= slice) lo = mid; else hi = mid; }
+    gi = lo; }
+  const uint32_t v = g.giant_vtx[gi];
+  if (act[(size_t)batch * n + v] < (uint32_t)sweep + 1u) return;          // not due in this sweep (k_fw: due <=> stamp >= sweep + 1)
+  const uint32_t s_in_row = slice - g.giant_slice0[gi];
+  const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
+  const uint32_t eb = e0 + s_in_row * GIANT_SLICE + wave * 64u;
+  const uint32_t cnt = eb < e1 ? min(64u, e1 - eb) : 0u;
+  const uint32_t root_slot = batch * 64 + lane;
+  const uint32_t my_root = roots[root_slot];
+  const uint32_t *D = dist + (size_t)batch * n * 64;
+  const uint32_t *H = hv + (size_t)batch * n * 64;
+  const uint64_t *M = mask + (size_t)batch * n * 64 * W;
+  const uint32_t v_router = (g.vflags[v] & 1u) ? 0u : 1u;
+  FwAcc<W, HC> x = fw_acc_init<W, HC>();
+  if (cnt) {
+    const uint32_t sv = lane < cnt ? g.in_src[eb + lane] : v;
+    const uint32_t wv = lane < cnt ? g.in_w[eb + lane] : INF;
+    fw_chunk<W, MAXINF, HC>(x, gp, D, H, M, v, v_router, eb, cnt, sv, wv, lane, my_root, root_slot, net_nexthops, ignore_ovl);
+  }
+  const uint32_t B = gridDim.y, n_ws = g.giant_slice0[g.n_giant] * 4u;
+  char *base = (char *)(gp->giant_part + giant_tag_words(B, g.n_giant));
+  fw_part_store<W, HC>(base + ((size_t)batch * n_ws + (size_t)slice * 4u + wave) * fw_part_bytes<W>(), x, lane);
+  if (s_in_row == 0u && wave == 0u && lane == 0u) gp->giant_part[(size_t)batch * g.n_giant + gi] = (uint32_t)sweep + 1u;
+}
+
 template <int W, bool MAXINF, bool HC>
 __global__ __launch_bounds__(256) void k_fw(const FusedGraph *__restrict__ gp, uint32_t *__restrict__ dist,
                                             uint32_t *__restrict__ hv, uint64_t *__restrict__ mask,
                                             uint32_t *__restrict__ act, const uint32_t *__restrict__ roots,
                                             uint32_t maxpath, uint32_t net_nexthops, uint32_t ignore_ovl,
                                             int *changed, int sweep, uint32_t *lane_flags) {
-  // Neighbour rows requested together: the whole triple (distance, hops, W mask words) of DG links in ONE round trip.
-  // The sweep is bound by dependent round trips, not bytes (a fat-tree switch row has 100 links): asking for the hops
-  // and masks only after the distances have shown which links are tight — what k_dag does — doubles the chain.
-  constexpr int DG = W <= 2 ? 8 : (W <= 4 ? 4 : (W <= 8 ? 2 : 1));
   if (sweep > 0 && changed[sweep - 1] == 0) return;
   const GraphDev &g = gp->g;
   const uint32_t lane = threadIdx.x & 63u;
@@ -1791,94 +1974,38 @@ __global__ __launch_bounds__(256) void k_fw(const FusedGraph *__restrict__ gp, u
     uint64_t om[W];
 #pragma unroll
     for (int q = 0; q < W; ++q) om[q] = ld_row64(M, ((size_t)v * W + q) * 512u + lane8);
-    uint32_t bd = INF, bpd = INF, bh = 0u, bd_all = INF;
-    uint64_t am[W];
-#pragma unroll
-    for (int q = 0; q < W; ++q) am[q] = 0ull;
-    uint32_t zb = INF, zh = 0u;            // HC: best zero-cost link from a higher-numbered source (see fused_row_any)
-    uint64_t zm[HC ? W : 1];
-#pragma unroll
-    for (int q = 0; q < (HC ? W : 1); ++q) zm[q] = 0ull;
-    for (uint32_t eb = e0; eb < e1; eb += 64) {
-      const uint32_t cnt = min(64u, e1 - eb);
-      const uint32_t sv = lane < cnt ? in_src[eb + lane] : v;
-      const uint32_t wv = lane < cnt ? in_w[eb + lane] : INF;
-      const bool has_nt = !ignore_ovl && __ballot(lane < cnt && (sv & SRC_NO_TRANSIT) != 0) != 0ull;
-      const uint32_t zv = (lane < cnt && wv == 0u && (sv & SRC_MASK) >= v) ? 1u : 0u;
-      const bool has_z = __ballot(zv != 0u) != 0ull;
-#pragma unroll 1
-      for (uint32_t j0 = 0; j0 < cnt; j0 += DG) {
-        uint32_t du[DG], hu[DG];
-        uint64_t mu[DG][W];
-#pragma unroll
-        for (int k = 0; k < DG; ++k) {
-          const uint32_t u = rdlane(sv, min(j0 + (uint32_t)k, 63u)) & SRC_MASK;
-          const bool in = (j0 + k) < cnt;                                // uniform: no requests for a short row's padding
-          du[k] = in ? ld_row(D, u * 256u + lane4) : INF;
-          hu[k] = in ? ld_row(H, u * 256u + lane4) : 0u;
-#pragma unroll
-          for (int q = 0; q < W; ++q) mu[k][q] = in ? ld_row64(M, ((size_t)u * W + q) * 512u + lane8) : 0ull;
-        }
-        uint32_t cc[DG];
-#pragma unroll
-        for (int k = 0; k < DG; ++k) {
-          const uint32_t j = min(j0 + (uint32_t)k, 63u);
-          const uint32_t w = rdlane(wv, j);
-          uint32_t d = du[k];
-          if (has_nt) {
-            const uint32_t sw = rdlane(sv, j);
-            if ((sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;     // overloaded source
-          }
-          du[k] = d;
-          cc[k] = (j0 + k) < cnt ? add_sat(d, w) : INF;
-          if (MAXINF && cc[k] == INF && d != INF && w != INF) sat = true;
-        }
-#pragma unroll
-        for (int k = 0; k < DG; ++k) {
-          const uint32_t j = j0 + k;
-          if (j >= cnt) break;
-          const uint32_t c = cc[k], d = du[k];
-          const bool zlink = has_z && rdlane(zv, j) != 0u;              // uniform
-          if (zlink && !HC) { bd_all = min(bd_all, c); continue; }
-          const bool hz = HC && zlink;
-          const bool lt = hz ? (c < zb) : (c < bd), eq = !hz && c == bd && c != INF;
-          const uint32_t hh = hu[k] & 0xFFFFu;
-          uint64_t contrib[W];
-#pragma unroll
-          for (int q = 0; q < W; ++q) contrib[q] = mu[k][q];
-          const bool direct = (lt || eq) && hh == 0u && c != INF;      // parent: root or hops-0 network
-          if (__ballot(direct) != 0ull) {
-            const uint32_t u = rdlane(sv, j) & SRC_MASK;
-            const uint32_t fpos = g.in_fpos[eb + j];
-            if (direct) {
-              const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(gp->tabs, root_slot, u);
-              const uint32_t sidx = base_s + fpos;
-              const bool on = (v_router || net_nexthops) && sidx < (uint32_t)W * 64u;
-#pragma unroll
-              for (int q = 0; q < W; ++q) contrib[q] = (on && (sidx >> 6) == (uint32_t)q) ? (1ull << (sidx & 63u)) : 0ull;
-            }
-          }
-          if (hz) {
-            if (lt) {
-              zb = c; zh = hh;
-#pragma unroll
-              for (int q = 0; q < (HC ? W : 1); ++q) zm[q] = contrib[HC ? q : 0];
-            }
-            continue;
-          }
-#pragma unroll
-          for (int q = 0; q < W; ++q) am[q] = lt ? contrib[q] : (eq ? (am[q] | contrib[q]) : am[q]);
-          const bool newp = lt || (eq && d < bpd);
-          bpd = newp ? d : bpd;
-          bh = newp ? hh : bh;
-          bd = min(bd, c);
-        }
+    FwAcc<W, HC> x = fw_acc_init<W, HC>();
+    bool have = true;
+    if (e1 - e0 > GIANT_DEG && g.n_giant != 0u && gp->giant_part != nullptr) {
+      // giant row: the accumulators k_fw_giant_part stored for THIS sweep, merged in row order (see fused_row_giant)
+      const uint32_t gi = giant_index(g, v);
+      have = gp->giant_part[(size_t)batch * g.n_giant + gi] == (uint32_t)sweep + 1u;
+      if (have) {
+        const uint32_t n_ws = g.giant_slice0[g.n_giant] * 4u;
+        const char *p = (const char *)(gp->giant_part + giant_tag_words(gridDim.y, g.n_giant)) +
+                        ((size_t)batch * n_ws + (size_t)g.giant_slice0[gi] * 4u) * fw_part_bytes<W>();
+        const uint32_t cntp = (e1 - e0 + 63u) / 64u;
+        for (uint32_t k = 0; k < cntp; ++k, p += fw_part_bytes<W>()) fw_merge<W, HC>(x, fw_part_load<W, HC>(p, lane));
+      }
+    } else {
+      for (uint32_t eb = e0; eb < e1; eb += 64) {
+        const uint32_t cnt = min(64u, e1 - eb);
+        const uint32_t sv = lane < cnt ? in_src[eb + lane] : v;
+        const uint32_t wv = lane < cnt ? in_w[eb + lane] : INF;
+        fw_chunk<W, MAXINF, HC>(x, gp, D, H, M, v, v_router, eb, cnt, sv, wv, lane, my_root, root_slot, net_nexthops, ignore_ovl);
       }
     }
+    if (!have) continue;                       // stamped after k_fw_giant_part had looked: due again in the next sweep
+    uint32_t bd = x.bd, bh = x.bh;
+    const uint32_t bd_all = x.bd_all, zb = x.zb, zh = x.zh;
+    uint64_t am[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) am[q] = x.am[q];
+    sat = sat || x.sat;
     if (HC) {
       const bool late = zb < bd;
 #pragma unroll
-      for (int q = 0; q < (HC ? W : 1); ++q) am[HC ? q : 0] = late ? zm[q] : am[HC ? q : 0];
+      for (int q = 0; q < (HC ? W : 1); ++q) am[HC ? q : 0] = late ? x.zm[q] : am[HC ? q : 0];
       bh = late ? zh : bh;
       bd = late ? zb : bd;
     }

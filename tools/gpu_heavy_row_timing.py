@@ -15,32 +15,43 @@ from holo_amd import engine as E               # noqa: E402
 from oracle import graph_oracle as go          # noqa: E402
 
 
-def with_lan(g, D, seed=5):
-    """Vertex 0 becomes a pseudonode (network vertices sort first in the reference): every router index shifts by one."""
-    n = g.n + 1
-    src = np.repeat(np.arange(g.n, dtype=np.int64), np.diff(g.row_ptr.astype(np.int64))) + 1
-    dst = g.col.astype(np.int64) + 1
+def with_lan(g, D, seed=5, second=0):
+    """Vertex 0 becomes a pseudonode with D members (network vertices sort first in the reference): every router index
+    shifts.  `second`: one more pseudonode whose members are main()'s first `second` roots (roots with many slots)."""
+    k = 2 if second else 1
+    n = g.n + k
+    src = np.repeat(np.arange(g.n, dtype=np.int64), np.diff(g.row_ptr.astype(np.int64))) + k
+    dst = g.col.astype(np.int64) + k
     met = g.metric.astype(np.int64)
     rng = np.random.default_rng(seed)
-    roots = (np.arange(64, dtype=np.int64) * (n - 1)) // 64 + 1        # main()'s roots stay off the LAN (a member root of a
-    mem = rng.choice(np.setdiff1d(np.arange(1, n), roots), size=D, replace=False)   # 1 000-router LAN has > 1 024 slots)
+    roots = (np.arange(64, dtype=np.int64) * (n - k)) // 64 + k          # main()'s roots stay off the big LAN (a member root
+    mem = rng.choice(np.setdiff1d(np.arange(k, n), roots), size=D, replace=False)   # of a 1 000-router LAN has > 1 024 slots)
     src = np.concatenate([src, mem, np.zeros(D, np.int64)])
     dst = np.concatenate([dst, np.zeros(D, np.int64), mem])
     met = np.concatenate([met, rng.integers(1, 101, D), np.zeros(D, np.int64)])
+    if second:
+        m2 = roots[:second]
+        src = np.concatenate([src, m2, np.ones(second, np.int64)])
+        dst = np.concatenate([dst, np.ones(second, np.int64), m2])
+        met = np.concatenate([met, rng.integers(1, 101, second), np.zeros(second, np.int64)])
     row_ptr, col, metric = synth._csr_from_links(n, src, dst, met)
-    vf = np.zeros(n, np.uint8); vf[0] = synth.VF_NETWORK
-    return synth.CsrGraph(row_ptr, col, metric, vf, g.max_path_metric, f"isis-100k+lan{D}", {})
+    vf = np.zeros(n, np.uint8); vf[:k] = synth.VF_NETWORK
+    return synth.CsrGraph(row_ptr, col, metric, vf, g.max_path_metric, f"isis-100k+lan{D}" + (f"+lan{second}" if second else ""), {"k": k})
 
 
 def main():
     import torch
     dev = torch.device("cuda:0")
     ctx = E.SpfContext(0)
+    os.environ["HSPF_VARIANT"] = "8192"                  # the same engine with giant rows walked whole (no slices)
+    ctx_whole = E.SpfContext(0)
+    del os.environ["HSPF_VARIANT"]
     base = synth.isis_100k()
-    for D in (0, 100, 900, 1000, 5000, 20000):
-        g = with_lan(base, D) if D else base
+    for D, second in ((0, 0), (100, 0), (900, 0), (1000, 0), (5000, 0), (20000, 0), (1000, 40), (5000, 40)):
+        g = with_lan(base, D, second=second) if D else base
         n = g.n
-        roots = ((np.arange(64, dtype=np.int64) * (n - 1)) // 64 + 1).astype(np.uint32)
+        k = g.meta.get("k", 1)
+        roots = ((np.arange(64, dtype=np.int64) * (n - k)) // 64 + k).astype(np.uint32)   # `second`: the first 40 share a LAN
         G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
         W = G.mask_words(roots)
         d = torch.empty((64, n), dtype=torch.int32, device=dev); h = torch.empty((64, n), dtype=torch.int16, device=dev)
@@ -64,7 +75,7 @@ def main():
                                 mask_ptr=m.data_ptr(), mask_words=W)
             ms1.append(st["ms_total"])
         rec["one_root_ms"] = round(float(np.median(ms1[2:])), 3); rec["one_root_lv"] = st["lane_vertex"]
-        if 0 < D <= 900:
+        if 0 < D <= 900 and not second:
             mem = g.col[g.row_ptr[0]:g.row_ptr[1]][:64].astype(np.uint32)
             Wm = G.mask_words(mem)
             mm = torch.empty((64, n, Wm), dtype=torch.int64, device=dev)
@@ -74,6 +85,17 @@ def main():
                                     mask_ptr=mm.data_ptr(), mask_words=Wm)
                 msm.append(st["ms_total"])
             rec["member_roots_ms"] = round(float(np.median(msm[2:])), 3); rec["member_roots_words"] = Wm
+        if second or D >= 900:
+            Gw = ctx_whole.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+            Ww = Gw.mask_words(roots)
+            mw = torch.empty((64, n, Ww), dtype=torch.int64, device=dev)
+            msw = []
+            for _ in range(4):
+                st = ctx_whole.run_device(Gw, roots, 0, dist_ptr=d.data_ptr(), hops_ptr=h.data_ptr(), flags_ptr=f.data_ptr(),
+                                          mask_ptr=mw.data_ptr(), mask_words=Ww)
+                msw.append(st["ms_total"])
+            rec["rows_walked_whole_ms"] = round(float(np.median(msw[1:])), 3)
+            Gw.free()
         print(json.dumps(rec), flush=True)
         G.free()
 
