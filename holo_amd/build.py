@@ -35,13 +35,26 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     # -amdgpu-kernarg-preload-count: the first 16 kernel-argument dwords arrive in SGPRs at wave launch instead of through
     # a scalar load — one dependent round trip less at the head of every wave (measured: +1.2 % on the bench, more on the
     # latency-bound sparse sweeps); the compiler keeps a compatible prologue for firmware that does not preload
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-ldl", "-pthread", "-o", LIB + ".tmp"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+             "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+    # one object per source, compiled side by side (the engine and the rocPRIM sorts of the hub-mode graph build), then linked
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src + ".o")
+        cmd = [hipcc_path()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-pthread", "-o", LIB + ".tmp"]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+        print(" ".join(link))
+    subprocess.check_call(link, cwd=CSRC)
+    for obj in objs:
+        os.remove(obj)
     os.replace(LIB + ".tmp", LIB)
     return LIB
 
