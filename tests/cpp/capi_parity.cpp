@@ -308,6 +308,42 @@ int main(int argc, char **argv) {
     hspf_multi_graph_free(m, mg);
     hspf_multi_shutdown(m);
   }
-  std::printf("capi_parity: %d graph runs bit-exact, %d patched generations bit-exact, error contract ok, device route derivation ok, %d sharded tables identical to the unsharded run\n", checked, patched, sharded);
+  // a LAN of 3 000 routers on a 4 000-router graph: the graph is built from sorted keys (hub mode) and the pseudonode's
+  // row is evaluated in slices (giant row); roots off the LAN (a member would need 3 000+ first-hop slots)
+  int big_lan = 0;
+  {
+    rng_state = 0xABCDEF12345ull;
+    const u32 n_rtr = 4000, n = n_rtr + 1, lan = 3000;
+    std::vector<std::vector<std::pair<u32, u32>>> rows(n);
+    for (u32 i = 0; i < n_rtr * 2; ++i) {
+      const u32 u = 1 + rnd(n_rtr), v = 1 + rnd(n_rtr);
+      if (u == v) continue;
+      rows[u].push_back({v, 1 + rnd(9)}); rows[v].push_back({u, 1 + rnd(9)});
+    }
+    for (u32 r = 1; r <= lan; ++r) { rows[r].push_back({0, 1 + rnd(9)}); rows[0].push_back({r, 0}); }
+    Lsdb g; g.n = n; g.row_ptr.assign(n + 1, 0); g.vflags.assign(n, 0); g.vflags[0] = HSPF_VF_NETWORK;
+    for (u32 u = 0; u < n; ++u) {
+      for (auto &e : rows[u]) { g.col.push_back(e.first); g.metric.push_back(e.second); }
+      g.row_ptr[u + 1] = (u32)g.col.size();
+      if (u && rnd(100) < 3) g.vflags[u] |= HSPF_VF_NO_TRANSIT;
+    }
+    hspf::Graph G = eng.upload(g.row_ptr, g.col, g.metric, g.vflags, 0xFE000000u);
+    u32 mode = 7; size_t got = 0;
+    CHECK(hspf_graph_export(eng.raw(), G.raw(), HSPF_GX_BUILD_MODE, &mode, 4, &got) == HSPF_OK && got == 4 && mode == 1, "hub-mode build expected");
+    std::vector<u32> roots;
+    for (u32 r = lan + 1; r < lan + 1 + 100; ++r) roots.push_back(r);         // off the LAN: one mask word
+    for (u32 flags : {0u, (u32)(HSPF_RUN_NET_NEXTHOPS | HSPF_RUN_IGNORE_OVERLOAD)}) {
+      hspf::Tables t = eng.run(G, roots, flags);
+      CHECK(t.mask_words == 1, "roots off the LAN need one mask word");
+      const size_t rn = (size_t)roots.size() * n;
+      std::vector<u32> d(rn), pr(rn), nn(rn), np(rn); std::vector<uint16_t> h(rn), f(rn); std::vector<uint64_t> mk(rn), wk(roots.size());
+      CHECK(oracle(n, (u32)g.col.size(), g.row_ptr.data(), g.col.data(), g.metric.data(), g.vflags.data(), 0xFE000000u, roots.data(),
+                   (u32)roots.size(), flags, /*variant HEAP*/ 2, d.data(), h.data(), f.data(), pr.data(), mk.data(), 1, nn.data(),
+                   np.data(), wk.data()) == 0, "oracle failed");
+      CHECK(d == t.dist && h == t.hops && mk == t.mask, "big LAN: run differs from the oracle");
+      ++big_lan;
+    }
+  }
+  std::printf("capi_parity: %d graph runs bit-exact, %d patched generations bit-exact, error contract ok, device route derivation ok, %d sharded tables identical to the unsharded run, %d runs on a 3 000-router LAN (hub-mode build, giant row) bit-exact\n", checked, patched, sharded, big_lan);
   return 0;
 }
