@@ -1146,7 +1146,11 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       return HSPF_OK;
     };
     if (single) {
-      hipError_t er = hipMemsetAsync(d_lf, 0, (size_t)L * 4, s);
+      // every workgroup STORES its root's status word straight into the pinned host array: no memset, no copy back
+      uint32_t *d_hlf = nullptr;
+      hipError_t er = hipHostGetDevicePointer((void **)&d_hlf, ctx->h_lane_flags, 0);
+      if (er != hipSuccess) { ctx->last_error = std::string("single: pinned status words: ") + hipGetErrorString(er); return HSPF_E_HIP; }
+      for (uint32_t r = n_roots; r < L; ++r) ctx->h_lane_flags[r] = 0u;
       if (er == hipSuccess && count_rows) er = hipMemsetAsync(d_kcnt, 0, 256 * 4, s);
       if (er != hipSuccess) { ctx->last_error = std::string("single init: ") + hipGetErrorString(er); return HSPF_E_HIP; }
       // the link records are staged in LDS when they fit next to the state; with many roots only while two workgroups
@@ -1156,7 +1160,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       const size_t lds = single_lds_bytes(n, g->e_kept, lds_links);
       const uint32_t thr = std::min<uint32_t>(SINGLE_THREADS, std::max<uint32_t>(64u, (n + 63u) / 64u * 64u));
       const uint32_t need_vpt = (n + thr - 1) / thr;                  // 1 .. 8
-      SingleArgs sa{d_fg, d_roots, fp_wide, net_nh, ignore_ovl, n_roots, count_rows ? 1u : 0u, lds_links ? 1u : 0u, d_lf, od};
+      SingleArgs sa{d_fg, d_roots, fp_wide, net_nh, ignore_ovl, n_roots, count_rows ? 1u : 0u, lds_links ? 1u : 0u, d_hlf, od};
       const bool mi = g->max_path_metric == HSPF_DIST_INF;
       void (*kern)(SingleArgs) = nullptr;
 #define HSPF_PICK(V_) (lds_links ? (mi ? k_single<true, V_, true> : k_single<false, V_, true>) : (mi ? k_single<true, V_, false> : k_single<false, V_, false>))
@@ -1175,11 +1179,15 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       } else
       hipLaunchKernelGGL(kern, dim3(n_roots), dim3(thr), lds, s, sa);
       (void)hipEventRecord(ctx->ev[2], s);
-      er = hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s);
-      if (er == hipSuccess && count_rows) er = hipMemcpyAsync(ctx->h_lane_flags + L, d_kcnt, 256 * 4, hipMemcpyDeviceToHost, s);
+      er = hipSuccess;
+      if (count_rows) er = hipMemcpyAsync(ctx->h_lane_flags + L, d_kcnt, 256 * 4, hipMemcpyDeviceToHost, s);
+      const hipError_t el = hipGetLastError();                         // the launch itself
       if (er == hipSuccess) er = hipStreamSynchronize(s);
-      if (er == hipSuccess) er = hipGetLastError();
-      if (er != hipSuccess) { ctx->last_error = std::string("k_single: ") + hipGetErrorString(er); return HSPF_E_HIP; }
+      if (er != hipSuccess || el != hipSuccess) {
+        ctx->last_error = std::string("k_single: ") + hipGetErrorString(er) + " / launch: " + hipGetErrorString(el) + " threads " +
+                          std::to_string(thr) + " lds " + std::to_string(lds);
+        return HSPF_E_HIP;
+      }
       st.n_relax_launches = 1; st.single_wg = 1;
       if (count_rows) {
         for (uint32_t i = 0; i < 128; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];

@@ -1079,6 +1079,18 @@ constexpr uint32_t SINGLE_MAX_N = 8192;          // 64 KB of LDS state
 constexpr uint32_t SINGLE_MAX_E = 65536;
 constexpr size_t SINGLE_LDS_MAX = 160 * 1024 - 64;   // dynamic LDS a workgroup may ask for (one workgroup per CU then)
 
+// The status word of a root in the one-workgroup kernels: the workgroup owns it, so it is reduced over the block (through
+// a word of LDS the sweeps no longer need) and STORED once (SingleArgs::lane_flags may be pinned host memory: no memset
+// before the launch, no copy after it).  No __syncthreads_or: its hidden LDS word would not fit next to 160 KB - 64.
+__device__ __forceinline__ void single_store_flags(uint32_t *lane_flags, uint32_t root_slot, uint32_t lf, int *word) {
+  __syncthreads();
+  if (threadIdx.x == 0) *word = 0;
+  __syncthreads();
+  if (lf) atomicOr(word, (int)lf);
+  __syncthreads();
+  if (threadIdx.x == 0) lane_flags[root_slot] = (uint32_t)*word;
+}
+
 struct SingleArgs {
   const FusedGraph *gp;
   const uint32_t *roots;
@@ -1158,6 +1170,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
       if (a.o.flags) a.o.flags[orow + v] = 0;
       if (a.o.mask) for (uint32_t k = 0; k < a.o.out_words; ++k) a.o.mask[(orow + v) * a.o.out_words + k] = 0;
     }
+    if (tid == 0) a.lane_flags[root_slot] = 0u;
     return;
   }
   const uint64_t t_clk0 = clock64(), t_wall0 = wall_clock64();
@@ -1326,7 +1339,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
   uint32_t lf = 0;
   if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
   if (ovf) lf |= LF_OVERFLOW;
-  if (lf) atomicOr(&a.lane_flags[root_slot], lf);
+  single_store_flags(a.lane_flags, root_slot, lf, &s_changed[0]);
   if (a.count_rows && tid == 0) {                  // HSPF_RUN_COUNT_ROWS: rows evaluated; workgroup 0 also leaves its sweep
     atomicAdd(&a.gp->rows_done[root_slot & 127u], (sweep + 1u) * n);   // count, shader cycles and 100 MHz wall ticks
     if (root_slot == 0) {
@@ -1494,6 +1507,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single_lean(SingleArgs a) {
       if (a.o.flags) a.o.flags[orow + v] = 0;
       if (a.o.mask) for (uint32_t k = 0; k < a.o.out_words; ++k) a.o.mask[(orow + v) * a.o.out_words + k] = 0;
     }
+    if (v == 0) a.lane_flags[root_slot] = 0u;
     return;
   }
   const uint64_t t_clk0 = clock64(), t_wall0 = wall_clock64();
@@ -1572,7 +1586,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single_lean(SingleArgs a) {
   uint32_t lf = 0;
   if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
   if (ovf) lf |= LF_OVERFLOW;
-  if (lf) atomicOr(&a.lane_flags[root_slot], lf);
+  single_store_flags(a.lane_flags, root_slot, lf, &s_changed[0]);
   if (a.count_rows && v == 0) {
     atomicAdd(&a.gp->rows_done[root_slot & 127u], (sweep + 1u) * n);
     if (root_slot == 0) {
