@@ -72,6 +72,14 @@ class Lsp:
     ext_ipv4: List[Tuple[str, int, bool]] = field(default_factory=list)    # TLV 135 (+X flag)
     ipv6: List[Tuple[str, int, bool]] = field(default_factory=list)        # TLV 236
     mt_ipv6: List[Tuple[int, str, int, bool]] = field(default_factory=list)  # TLV 237
+    # Segment routing (Router Capability TLV 242 and the Prefix-SID sub-TLVs of algorithm SPF, kept beside the entries:
+    # prefix_sids[kind][i] for entry i of ext_ipv4 / ipv6 / mt_ipv6): only compute_routes' SR step reads them
+    sr_cap: Optional[dict] = None                      # {"flags": ["I", "V"], "srgb": [[first label, range], ...]}
+    sr_algos: List[int] = field(default_factory=list)  # 0 = SPF
+    prefix_sids: Dict[str, Dict[int, dict]] = field(default_factory=dict)
+
+    def prefix_sid(self, kind: str, i: int) -> Optional[dict]:
+        return self.prefix_sids.get(kind, {}).get(i)
 
     @property
     def lan_id(self) -> LanId:
@@ -121,6 +129,7 @@ class InstanceCfg:
     max_paths: int = 16
     att_ignore: bool = False
     area_addrs: List[str] = field(default_factory=list)
+    sr_enabled: bool = False
 
     def is_af_enabled(self, af: str) -> bool:
         return self.ipv4_enabled if af == "ipv4" else self.ipv6_enabled
@@ -152,6 +161,9 @@ class Lsdb:
     def iter_for_lan_id(self, lan_id: LanId):
         return [l for k, l in sorted(self._by_id.items()) if k[0] == lan_id[0] and k[1] == lan_id[1]]
 
+    def iter_for_system_id(self, system_id: bytes):
+        return [l for k, l in sorted(self._by_id.items()) if k[0] == system_id]
+
     def zeroth_lsp(self, lan_id: LanId) -> Optional[Lsp]:      # spf.rs:1299-1309
         l = self._by_id.get((lan_id[0], lan_id[1], 0))
         return l if (l is not None and l.live()) else None
@@ -181,7 +193,8 @@ class Instance:
                           metric_type={1: c["metric_type"]["1"], 2: c["metric_type"]["2"]},
                           ipv4_enabled=c["afs"].get("ipv4", True), ipv6_enabled=c["afs"].get("ipv6", True),
                           mt_ipv6_unicast=c["mt_ipv6_unicast"], max_paths=c["max_paths"],
-                          att_ignore=c["att_ignore"], area_addrs=list(c["area_addrs"]))
+                          att_ignore=c["att_ignore"], area_addrs=list(c["area_addrs"]),
+                          sr_enabled=bool(c.get("sr_enabled", False)))
         ifaces = []
         for i in vec["interfaces"]:
             adjs = [Adjacency(system_id_from_str(a["system_id"]), a["usage"], a["state"], list(a["ipv4"]),
@@ -204,7 +217,9 @@ class Instance:
                     mt_is_reach=[(t, lan_id_from_str(n), m) for t, n, m in l["mt_is_reach"]],
                     ipv4_internal=[tuple(x) for x in l["ipv4_int"]], ipv4_external=[tuple(x) for x in l["ipv4_ext"]],
                     ext_ipv4=[tuple(x) for x in l["ext_ipv4"]], ipv6=[tuple(x) for x in l["ipv6"]],
-                    mt_ipv6=[tuple(x) for x in l["mt_ipv6"]]))
+                    mt_ipv6=[tuple(x) for x in l["mt_ipv6"]],
+                    sr_cap=l.get("sr_cap"), sr_algos=list(l.get("sr_algos", [])),
+                    prefix_sids={k: {int(i): sid for i, sid in d.items()} for k, d in l.get("prefix_sids", {}).items()}))
             lsdb[int(lv)] = Lsdb(out)
         return cls(cfg, ifaces, lsdb)
 
@@ -820,12 +835,14 @@ class Route:                               # holo-isis/src/route.rs:27-37
     level: int
     external: bool
     connected: bool
-    nexthops: Dict[tuple, Tuple[str, str, bytes]]   # addr key -> (addr, iface, system id)
+    nexthops: Dict[tuple, Tuple[str, str, bytes, Optional[int]]]   # addr key -> (addr, iface, system id, SR output label)
+    prefix_sid: Optional[dict] = None       # the Prefix-SID of the network the route was CREATED from (route.rs:78-103)
+    sr_label: Optional[int] = None          # SR input label
 
 
-def vertex_networks(instance: Instance, level: int, mt_id: int, lan_id: LanId, att_bit: bool,
-                    l2_attached: bool, ipv4_enabled: bool, ipv6_enabled: bool):
-    """holo-isis/src/spf.rs:1149-1296."""
+def vertex_networks_sr(instance: Instance, level: int, mt_id: int, lan_id: LanId, att_bit: bool,
+                       l2_attached: bool, ipv4_enabled: bool, ipv6_enabled: bool):
+    """holo-isis/src/spf.rs:1149-1296: (prefix, metric, external, Prefix-SID of algorithm SPF or None)."""
     cfg = instance.config
     metric_type = cfg.metric_type[level]
     std_on = metric_type in ("standard", "both")
@@ -835,25 +852,33 @@ def vertex_networks(instance: Instance, level: int, mt_id: int, lan_id: LanId, a
             continue
         if att_bit and level == 1 and (cfg.level_type == "level-1" or not l2_attached):
             if ipv4_enabled:
-                yield "0.0.0.0/0", 0, False
+                yield "0.0.0.0/0", 0, False, None
             if ipv6_enabled:
-                yield "::/0", 0, False
+                yield "::/0", 0, False, None
         if mt_id == MT_STANDARD and ipv4_enabled:
             if std_on:
                 for p, m in lsp.ipv4_internal:
-                    yield p, m, False
+                    yield p, m, False, None
                 for p, m in lsp.ipv4_external:
-                    yield p, m, True
+                    yield p, m, True, None
             if wide_on:
-                for p, m, x in lsp.ext_ipv4:
+                for i, (p, m, x) in enumerate(lsp.ext_ipv4):
                     if m <= MAX_PATH_METRIC_WIDE:
-                        yield p, m, x
+                        yield p, m, x, lsp.prefix_sid("ext_ipv4", i)
         if ipv6_enabled:
-            it = ([(p, m, x) for t, p, m, x in lsp.mt_ipv6 if t == MT_IPV6_UNICAST]
-                  if mt_id == MT_IPV6_UNICAST else lsp.ipv6)
-            for p, m, x in it:
+            it = ([(p, m, x, lsp.prefix_sid("mt_ipv6", i)) for i, (t, p, m, x) in enumerate(lsp.mt_ipv6) if t == MT_IPV6_UNICAST]
+                  if mt_id == MT_IPV6_UNICAST else
+                  [(p, m, x, lsp.prefix_sid("ipv6", i)) for i, (p, m, x) in enumerate(lsp.ipv6)])
+            for p, m, x, sid in it:
                 if m <= MAX_PATH_METRIC_WIDE:
-                    yield p, m, x
+                    yield p, m, x, sid
+
+
+def vertex_networks(instance: Instance, level: int, mt_id: int, lan_id: LanId, att_bit: bool,
+                    l2_attached: bool, ipv4_enabled: bool, ipv6_enabled: bool):
+    """(prefix, metric, external) of holo-isis/src/spf.rs:1149-1296 (what route derivation on the device needs)."""
+    for p, m, x, _sid in vertex_networks_sr(instance, level, mt_id, lan_id, att_bit, l2_attached, ipv4_enabled, ipv6_enabled):
+        yield p, m, x
 
 
 def _build_nexthops(vertex: Vertex, prefix: str):          # route.rs:118-142
@@ -862,8 +887,68 @@ def _build_nexthops(vertex: Vertex, prefix: str):          # route.rs:118-142
     for nh in vertex.nexthops:
         addr = nh.ipv6 if v6 else nh.ipv4
         if addr is not None:
-            out[_addr_key(addr)] = (addr, nh.iface_name, nh.system_id)
+            out[_addr_key(addr)] = (addr, nh.iface_name, nh.system_id, None)
     return out
+
+
+# ---- SR Prefix-SID bookkeeping of compute_routes (holo-isis/src/spf.rs:931-946, sr.rs:34-94, 165-300) ---------------------
+# The SPT feeds it two bits per route update: local = (vertex.hops == 0), last_hop = (vertex.hops == 1).
+
+LABEL_IMPLICIT_NULL, LABEL_EXPLICIT_NULL_V4, LABEL_EXPLICIT_NULL_V6 = 3, 0, 2
+
+
+def _sr_cap(lsdb: "Lsdb", system_id: bytes) -> Optional[dict]:
+    for lsp in lsdb.iter_for_system_id(system_id):
+        if lsp.live() and lsp.sr_cap is not None:
+            return lsp.sr_cap
+    return None
+
+
+def sr_index_to_label(index: int, srgbs) -> Optional[int]:             # sr.rs:270-300
+    for first, rng in srgbs:
+        if index >= rng:
+            index -= rng
+            continue
+        return first + index
+    return None
+
+
+def prefix_sid_update(instance: Instance, level: int, adv_rtr: LanId, prefix: str, route: Route, local: bool,
+                      last_hop: bool):
+    """sr.rs:34-94: SR input label of the route, output label of every next hop; a label that cannot be resolved stays."""
+    sid = route.prefix_sid
+    lsdb = instance.lsdb[level]
+    if sid is None or not any(lsp.live() and 0 in lsp.sr_algos for lsp in lsdb.iter_for_lan_id(adv_rtr)):
+        return
+    flags = sid["flags"]
+    v6 = ":" in prefix
+    # input label (sr.rs:165-205)
+    if local and ("P" not in flags or "E" in flags):
+        route.sr_label = None
+    elif "index" in sid:
+        cap = _sr_cap(lsdb, instance.config.system_id)
+        label = sr_index_to_label(sid["index"], cap["srgb"]) if cap is not None else None
+        if label is not None:
+            route.sr_label = label
+    else:
+        route.sr_label = sid["label"]
+    # output labels (sr.rs:208-267)
+    for k, (addr, iface, system_id, old) in list(route.nexthops.items()):
+        if last_hop and "P" not in flags:
+            label = LABEL_IMPLICIT_NULL
+        else:
+            cap = _sr_cap(lsdb, system_id)
+            if cap is None or ("V" if v6 else "I") not in cap["flags"]:
+                continue
+            if last_hop and "E" in flags:
+                label = LABEL_EXPLICIT_NULL_V6 if v6 else LABEL_EXPLICIT_NULL_V4
+            elif "index" in sid:
+                label = sr_index_to_label(sid["index"], cap["srgb"])
+                if label is None:
+                    continue
+            else:
+                label = sid["label"] if last_hop else LABEL_IMPLICIT_NULL
+        route.nexthops[k] = (addr, iface, system_id, label)
 
 
 def compute_routes(level: int, mt_id: int, instance: Instance, spt: Spt, rib: Dict[tuple, Route]):
@@ -880,20 +965,22 @@ def compute_routes(level: int, mt_id: int, instance: Instance, spt: Spt, rib: Di
         if z is None:
             continue
         att = (not cfg.att_ignore) and z.att_bit(mt_id) and not z.overload_bit(mt_id)
-        for prefix, metric, external in vertex_networks(instance, level, mt_id, lan, att, l2_attached,
-                                                        ipv4_enabled, ipv6_enabled):
+        for prefix, metric, external, sid in vertex_networks_sr(instance, level, mt_id, lan, att, l2_attached,
+                                                                ipv4_enabled, ipv6_enabled):
             key = _net_key(prefix)
             route_metric = vertex.distance + metric
             cur = rib.get(key)
             if cur is None or route_metric < cur.metric:
                 cur = rib[key] = Route(prefix, route_metric, level, external, vertex.hops == 0,
-                                       _build_nexthops(vertex, prefix))
+                                       _build_nexthops(vertex, prefix), prefix_sid=sid)
             elif route_metric == cur.metric:
                 cur.nexthops.update(_build_nexthops(vertex, prefix))
             else:
                 continue
             if len(cur.nexthops) > cfg.max_paths:
                 cur.nexthops = {k: cur.nexthops[k] for k in sorted(cur.nexthops)[:cfg.max_paths]}
+            if cfg.sr_enabled and cur.prefix_sid is not None:                       # spf.rs:931-946
+                prefix_sid_update(instance, level, lan, prefix, cur, vertex.hops == 0, vertex.hops == 1)
 
 
 class GraphCache:
@@ -956,8 +1043,12 @@ def compute_spf(instance: Instance, engine, cache: Optional[GraphCache] = None,
     rows = []
     for key in sorted(merged):
         r = merged[key]
-        rows.append({"prefix": r.prefix, "metric": r.metric, "level": r.level,
-                     "nexthops": [[r.nexthops[k][0], r.nexthops[k][1]] for k in sorted(r.nexthops)]})
+        row = {"prefix": r.prefix, "metric": r.metric, "level": r.level,
+               "nexthops": [[r.nexthops[k][0], r.nexthops[k][1]] for k in sorted(r.nexthops)]}
+        if cfg.sr_enabled:                                        # the SR columns only where SR is on
+            row["sr_label"] = r.sr_label
+            row["nexthop_labels"] = [r.nexthops[k][3] for k in sorted(r.nexthops)]
+        rows.append(row)
     return rows
 
 

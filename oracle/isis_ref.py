@@ -77,6 +77,13 @@ class Lsdb:
                 if l.get("seqno", 1) != 0 and l.get("lifetime", 1) != 0:
                     yield l
 
+    def iter_for_system_id(self, sysid):     # collections.rs: every LSP of the system (any pseudonode / fragment), id order
+        for k in self.order:
+            if k[0] == sysid:
+                l = self.by_id[k]
+                if l.get("seqno", 1) != 0 and l.get("lifetime", 1) != 0:
+                    yield l
+
     def zeroth_lsp(self, lan_id):            # spf.rs:1299-1309
         l = self.by_id.get((lan_id[0], lan_id[1], 0))
         if l is None or l.get("seqno", 1) == 0 or l.get("lifetime", 1) == 0:
@@ -241,35 +248,41 @@ def is_l2_attached_to_backbone(vec, mt_id):             # holo-isis/src/instance
     return False
 
 
+def _sid(lsp, kind, i):
+    """Prefix-SID sub-TLV of algorithm SPF of entry i of a reachability TLV, or None (vectors keep them beside the
+    entries: lsp["prefix_sids"][kind][str(i)] = {"flags": [...], "index": n} | {"flags": [...], "label": n})."""
+    return lsp.get("prefix_sids", {}).get(kind, {}).get(str(i))
+
+
 def vertex_networks(vec, level, mt_id, vertex, att, l2_attached, metric_type, v4_on, v6_on, lsdb):
-    """spf.rs:1149-1296 -> (prefix str, metric, external)."""
+    """spf.rs:1149-1296 -> (prefix str, metric, external, prefix_sid)."""
     level_type = vec["config"]["level_type"]
     std_on = metric_type in ("standard", "both")
     wide_on = metric_type in ("wide", "both")
     for lsp in lsdb.iter_for_lan_id((vertex.id[1], vertex.id[2])):
         if att and level == 1 and (level_type == "level-1" or not l2_attached):
             if v4_on:
-                yield "0.0.0.0/0", 0, False
+                yield "0.0.0.0/0", 0, False, None
             if v6_on:
-                yield "::/0", 0, False
+                yield "::/0", 0, False, None
         if mt_id == MT_STANDARD and v4_on:
             if std_on:
                 for p, m in lsp["ipv4_int"]:
-                    yield p, m, False
+                    yield p, m, False, None
                 for p, m in lsp["ipv4_ext"]:
-                    yield p, m, True
+                    yield p, m, True, None
             if wide_on:
-                for p, m, x in lsp["ext_ipv4"]:
+                for i, (p, m, x) in enumerate(lsp["ext_ipv4"]):
                     if m <= MAX_PATH_METRIC_WIDE:
-                        yield p, m, x
+                        yield p, m, x, _sid(lsp, "ext_ipv4", i)
         if v6_on:
             if mt_id == MT_IPV6_UNICAST:
-                it = [(p, m, x) for t, p, m, x in lsp["mt_ipv6"] if t == MT_IPV6_UNICAST]
+                it = [(p, m, x, _sid(lsp, "mt_ipv6", i)) for i, (t, p, m, x) in enumerate(lsp["mt_ipv6"]) if t == MT_IPV6_UNICAST]
             else:
-                it = lsp["ipv6"]
-            for p, m, x in it:
+                it = [(p, m, x, _sid(lsp, "ipv6", i)) for i, (p, m, x) in enumerate(lsp["ipv6"])]
+            for p, m, x, sid in it:
                 if m <= MAX_PATH_METRIC_WIDE:
-                    yield p, m, x
+                    yield p, m, x, sid
 
 
 def _addr_key(a: str):
@@ -289,12 +302,83 @@ def build_nexthops(vertex, prefix):                # route.rs:118-142
         addr = nh["ipv6"] if v6 else nh["ipv4"]
         if addr is None:
             continue
-        out[_addr_key(addr)] = (addr, nh["iface"])  # BTreeMap<IpAddr, Nexthop>: last insert wins
-    return out
+        out[_addr_key(addr)] = (addr, nh["iface"], nh["system_id"], None)  # BTreeMap<IpAddr, Nexthop>: last insert wins;
+    return out                                                           # (addr, iface, system id, sr_label = None)
+
+
+# ---- SR Prefix-SID bookkeeping (holo-isis/src/sr.rs:34-94, 165-300) -------------------------------------------------
+# NOT pinned to recorded reference output: `sr.enabled` is off in every conformance fixture that records a RIB.  Literal
+# restatement of the cited lines; tests compare the host twin with it and with hand-computed labels.
+
+LABEL_IMPLICIT_NULL, LABEL_EXPLICIT_NULL_V4, LABEL_EXPLICIT_NULL_V6 = 3, 0, 2     # holo-utils/src/mpls.rs
+
+
+def _sr_cap(lsdb, system_id):                     # sr.rs:183-193, 223-233
+    for lsp in lsdb.iter_for_system_id(system_id):
+        if lsp.get("sr_cap") is not None:
+            return lsp["sr_cap"]
+    return None
+
+
+def index_to_label(index, srgbs):                 # sr.rs:270-300 (label-based SRGB entries only; Err -> None)
+    for first, rng in srgbs:
+        if index >= rng:
+            index -= rng
+            continue
+        return first + index
+    return None
+
+
+def prefix_sid_input_label(vec, sid, local, lsdb):
+    """sr.rs:165-205 -> (ok, label or None)."""
+    if local and ("P" not in sid["flags"] or "E" in sid["flags"]):
+        return True, None
+    if "index" in sid:
+        cap = _sr_cap(lsdb, parse_lan_id(vec["config"]["system_id"] + ".00")[0])
+        if cap is None:
+            return False, None
+        label = index_to_label(sid["index"], cap["srgb"])
+        if label is None:
+            return False, None
+        return True, label
+    return True, sid["label"]
+
+
+def prefix_sid_output_label(af, sid, nh_system_id, last_hop, lsdb):
+    """sr.rs:208-267 -> (ok, label)."""
+    if last_hop and "P" not in sid["flags"]:
+        return True, LABEL_IMPLICIT_NULL
+    cap = _sr_cap(lsdb, nh_system_id)
+    if cap is None:
+        return False, None
+    if ("I" if af == 4 else "V") not in cap["flags"]:
+        return False, None
+    if last_hop and "E" in sid["flags"]:
+        return True, LABEL_EXPLICIT_NULL_V4 if af == 4 else LABEL_EXPLICIT_NULL_V6
+    if "index" in sid:
+        label = index_to_label(sid["index"], cap["srgb"])
+        return (label is not None), label
+    return True, (sid["label"] if last_hop else LABEL_IMPLICIT_NULL)
+
+
+def prefix_sid_update(vec, adv_rtr, af, route, local, last_hop, lsdb):
+    """sr.rs:34-94."""
+    sid = route["prefix_sid"]
+    if sid is None:
+        return
+    if not any(0 in lsp.get("sr_algos", []) for lsp in lsdb.iter_for_lan_id(adv_rtr)):     # IgpAlgoType::Spf = 0
+        return
+    ok, label = prefix_sid_input_label(vec, sid, local, lsdb)
+    if ok:
+        route["sr_label"] = label
+    for k, (addr, iface, system_id, old) in list(route["nexthops"].items()):
+        ok, label = prefix_sid_output_label(af, sid, system_id, last_hop, lsdb)
+        if ok:
+            route["nexthops"][k] = (addr, iface, system_id, label)
 
 
 def compute_routes(vec, level, mt_id, spt, rib):
-    """spf.rs:840-949 (SR prefix-SID bookkeeping left out: it does not touch metric/next hops)."""
+    """spf.rs:840-949, incl. the SR Prefix-SID update of :931-946 (config "sr_enabled")."""
     cfg = vec["config"]
     lsdb = Lsdb(vec["lsdb"].get(str(level), []))
     metric_type = cfg["metric_type"][str(level)]
@@ -308,14 +392,15 @@ def compute_routes(vec, level, mt_id, spt, rib):
         if z is None:
             continue
         att = (not cfg["att_ignore"]) and att_bit(z, mt_id) and not overload_bit(z, mt_id)
-        for prefix, metric, external in vertex_networks(vec, level, mt_id, vertex, att, l2_attached,
-                                                        metric_type, v4_on, v6_on, lsdb):
+        for prefix, metric, external, sid in vertex_networks(vec, level, mt_id, vertex, att, l2_attached,
+                                                             metric_type, v4_on, v6_on, lsdb):
             key = _net_key(prefix)
             route_metric = vertex.distance + metric
             cur = rib.get(key)
             if cur is None or route_metric < cur["metric"]:
                 cur = rib[key] = {"prefix": prefix, "metric": route_metric, "level": level,
                                   "external": external, "connected": vertex.hops == 0,
+                                  "prefix_sid": sid, "sr_label": None,            # Route::new, route.rs:78-103
                                   "nexthops": build_nexthops(vertex, prefix)}
             elif route_metric == cur["metric"]:
                 cur["nexthops"].update(build_nexthops(vertex, prefix))
@@ -325,6 +410,9 @@ def compute_routes(vec, level, mt_id, spt, rib):
             if len(cur["nexthops"]) > mp:
                 keep = sorted(cur["nexthops"])[:mp]
                 cur["nexthops"] = {k: cur["nexthops"][k] for k in keep}
+            if cfg.get("sr_enabled") and cur["prefix_sid"] is not None:          # spf.rs:931-946
+                prefix_sid_update(vec, (vid[1], vid[2]), 6 if ":" in prefix else 4, cur, vertex.hops == 0,
+                                  vertex.hops == 1, lsdb)
 
 
 def levels_of(vec):
@@ -353,8 +441,12 @@ def local_rib(vec):
     rows = []
     for key in sorted(merged):
         r = merged[key]
-        nhs = [list(r["nexthops"][k]) for k in sorted(r["nexthops"])]
-        rows.append({"prefix": r["prefix"], "metric": r["metric"], "level": r["level"], "nexthops": nhs})
+        nhs = [list(r["nexthops"][k][:2]) for k in sorted(r["nexthops"])]
+        row = {"prefix": r["prefix"], "metric": r["metric"], "level": r["level"], "nexthops": nhs}
+        if vec["config"].get("sr_enabled"):                   # the SR columns only where SR is on (fixtures have it off)
+            row["sr_label"] = r["sr_label"]
+            row["nexthop_labels"] = [r["nexthops"][k][3] for k in sorted(r["nexthops"])]
+        rows.append(row)
     return rows
 
 

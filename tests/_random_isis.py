@@ -103,3 +103,39 @@ def make(seed: int) -> dict:
                        "afs": {"ipv4": bool(rng.random() > 0.1), "ipv6": bool(rng.random() > 0.2)}, "mt_ipv6_unicast": False,
                        "max_paths": int(rng.choice([1, 2, 16])), "att_ignore": bool(rng.random() < 0.2), "area_addrs": ["49.0000"]},
             "interfaces": ifaces, "lsdb": {"2": lsps}, "rib": []}
+
+
+def add_sr(vec: dict, seed: int) -> dict:
+    """Segment-routing data on top of make(seed) (its own generator: make() is unchanged): sr_enabled, per router an
+    SR-Capabilities entry (I / V flags, one or two SRGB ranges; sometimes missing), the SR-Algorithm list (sometimes
+    without SPF), Prefix-SIDs of algorithm SPF on wide IPv4 and on IPv6 entries (index — sometimes beyond the SRGB — or
+    absolute label; P / E flags).  Shared prefixes get different SIDs from different advertisers."""
+    import copy
+    rng = np.random.default_rng(900_000 + seed)
+    v = copy.deepcopy(vec)
+    v["config"]["sr_enabled"] = True
+    for l in v["lsdb"]["2"]:
+        lan, frag = l["id"].rsplit("-", 1)
+        if not lan.endswith(".00"):
+            continue                                           # pseudonode LSP
+        r = int(lan.split(".")[2], 16)
+        if frag == "00":
+            if rng.random() < 0.88:
+                flags = ["I", "V"] if rng.random() < 0.75 else ([["I"], ["V"], []][int(rng.integers(0, 3))])
+                srgb = [[16000 + 1000 * r, int(rng.integers(20, 120))]]
+                if rng.random() < 0.3:
+                    srgb.append([40000 + 1000 * r, int(rng.integers(20, 120))])
+                l["sr_cap"] = {"flags": flags, "srgb": srgb}
+            l["sr_algos"] = [0] if rng.random() < 0.9 else ([1] if rng.random() < 0.5 else [])
+        sids = {}
+        for kind in ("ext_ipv4", "ipv6"):
+            for i in range(len(l[kind])):
+                if rng.random() < 0.75:
+                    fl = [f for f in ("P", "E") if rng.random() < 0.35]
+                    if rng.random() < 0.15:
+                        sids.setdefault(kind, {})[str(i)] = {"flags": fl + ["V", "L"], "label": int(rng.integers(5000, 6000))}
+                    else:
+                        sids.setdefault(kind, {})[str(i)] = {"flags": fl, "index": int(rng.integers(0, 150))}
+        if sids:
+            l["prefix_sids"] = sids
+    return v
