@@ -816,6 +816,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   hspf_stats &st = ctx->stats;
   st = hspf_stats{};
   st.n_roots = n_roots; st.n_batches = B;
+  const auto t_entry = std::chrono::steady_clock::now();      // hspf_stats::dbg[2..3]: host time of the call (us)
   hspf_ctx::Prefill pf = ctx->prefill;      // what the previous run left for this one; whoever does not take it loses it
   ctx->prefill.valid = false;
 
@@ -969,6 +970,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     // An SPF instance repeats its runs (same graph, same roots): when the block is byte for byte the one the device
     // already holds — same allocation, nothing in it is ever written by a kernel — the copy is skipped (HSPF_VARIANT bit
     // 14 keeps it).  Otherwise the halves swap: the block just built becomes the reference.
+    st.dbg[2] = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_entry).count();
     const bool same = ctx->up_valid && ctx->up_len == up_bytes && !(ctx->variant & 16384u) && memcmp(h, prev, up_bytes) == 0;
     if (!same) {
       HIPCHK(ctx, hipMemcpyAsync(d_up, h, up_bytes, hipMemcpyHostToDevice, s));
@@ -1203,7 +1205,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       st.n_relax_launches = 1; st.single_wg = 1;
       if (count_rows) {
         for (uint32_t i = 0; i < 128; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
-        for (uint32_t i = 0; i < 4; ++i) st.dbg[i] = ctx->h_lane_flags[L + 128 + i];   // sweeps, shader cycles, 100 MHz ticks, set-up cycles of workgroup 0
+        for (uint32_t i = 0; i < 4; ++i) st.dbg[i] = ctx->h_lane_flags[L + 128 + i];   // sweeps, shader cycles, 100 MHz ticks, set-up cycles of workgroup 0 (this flag only: overwrites the host times)
       }
       narrow = false;
     } else if (lv) {
@@ -1388,6 +1390,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     st.ms_d2h = 0.f;
     if (host_out) (void)hipEventElapsedTime(&st.ms_d2h, ctx->ev[4], ctx->ev[5]);
   }
+  if (!(count_rows && st.single_wg))
+    st.dbg[3] = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_entry).count();
   return HSPF_OK;
 }
 
