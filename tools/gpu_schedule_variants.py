@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--reps", type=int, default=9)
     ap.add_argument("--variants", default="0")
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--only", default="", help="comma-separated root-set names (default: all)")
     a = ap.parse_args()
     import torch
     g = {"isis-100k": synth.isis_100k, "ospf-10k": synth.ospf_10k, "ospf-500": synth.ospf_500}[a.graph]()
@@ -57,6 +58,8 @@ def main():
         ctx = E.SpfContext(0)
         G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
         for name, roots in root_sets.items():
+            if a.only and name not in a.only.split(","):
+                continue
             R = len(roots)
             W = G.mask_words(roots)
             dist = torch.empty((R, n), dtype=torch.int32, device=dev); hops = torch.empty((R, n), dtype=torch.int16, device=dev)
