@@ -427,6 +427,35 @@ __global__ void kb_xcd(uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInf
   info->xcd_start[x] = x == 8u ? nb : lo;
 }
 
+// Fixed-stride (ELL) copy of the link records for k_fused_lean: 16 entries per vertex, rows 0 .. n (row n = all pad).
+//   ell_so[16 v + j] = byte offset of the source's state row (source << 8); j >= in-degree: the pad row n (never reached);
+//                      the low byte of entry 0 carries  in-degree (0 .. 16; more: 0x1F) | (more than 16 out-links) << 5 |
+//                      network << 7
+//   ell_w [16 v + j] = cost; pad entries 0
+//   ell_od[16 v + j] = byte offset of out-neighbour j's activation stamp (target << 2); j >= out-degree: 0xFFFFFFFF (a
+//                      buffer store at that offset is out of range and dropped)
+// Only rows of at most 16 in-links are read through it (longer rows carry RF_MANY and take the general routine).
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_ell(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ in_src, const uint32_t *__restrict__ in_w,
+       const uint32_t *__restrict__ out_ptr, const uint32_t *__restrict__ out_dst, const uint8_t *__restrict__ vflags,
+       uint32_t *__restrict__ ell_so, uint32_t *__restrict__ ell_w, uint32_t *__restrict__ ell_od, uint32_t probe_self) {
+  const uint32_t t = blockIdx.x * GB_BLOCK + threadIdx.x;
+  const uint32_t v = t >> 4, j = t & 15u;
+  if (v > n) return;
+  uint32_t so = n << 8, w = 0u, od = 0xFFFFFFFFu, info = 0u;
+  if (v < n) {
+    const uint32_t e0 = in_ptr[v], deg = in_ptr[v + 1] - e0;
+    const uint32_t o0 = out_ptr[v], odeg = out_ptr[v + 1] - o0;
+    info = (deg <= 16u ? deg : 0x1Fu) | (odeg > 16u ? 0x20u : 0u) | ((vflags[v] & HSPF_VF_NETWORK) ? 0x80u : 0u);
+    if (deg <= 16u && j < deg) { so = (probe_self ? v : (in_src[e0 + j] & SRC_MASK)) << 8; w = in_w[e0 + j]; }   // probe_self: measurement only (HSPF_PROBE_SELF)
+    if (j < odeg) od = out_dst[o0 + j] << 2;
+  }
+  if (j == 0u) so |= info;
+  ell_so[t] = so;
+  ell_w[t] = w;
+  ell_od[t] = od;
+}
+
 __global__ void kb_pads(uint32_t n, const BuildInfo *__restrict__ info, uint32_t *in_ptr, uint32_t *out_ptr,
                         uint32_t *a0, uint32_t *a1, uint32_t *a2, uint32_t *a3, uint32_t *a4, uint32_t *a5) {
   const uint32_t i = threadIdx.x;

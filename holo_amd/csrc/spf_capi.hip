@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <functional>
 #include <new>
 #include <string>
 #include <vector>
@@ -39,6 +40,7 @@ struct hspf_graph {
   uint32_t wmax = 0;                 // largest cost among the kept links
   mutable bool narrow_bad = false;   // a run overflowed the 4-byte fused state: use the 8-byte one
   mutable bool wide24_bad = false;   // a run overflowed the hop field of the 8-byte state with > 16 mask bits
+  mutable bool lean_bad = false;     // a run overflowed the fields of the lean 4-byte state (k_fused_lean): k_fused from now on
   bool hopcount_like = false;        // every kept link into a network costs 0 (from a router), into a router 1
   bool heavy_rows = false;           // a quarter or more of the links sit in rows of more than 32 (fat-tree switches, big LANs)
   uint32_t xcd_start[9] = {};        // work-balanced chunk ranges of the 8 XCDs (GraphDev::xcd_start)
@@ -62,6 +64,7 @@ struct hspf_graph {
   uint8_t *d_vflags = nullptr, *d_rowflags = nullptr;
   uint32_t *d_unit_first = nullptr;                               // work units (GraphDev::unit_first), n / 4 + 4 entries
   uint32_t *d_giant = nullptr;                                    // giant rows: vertex list [n_giant] | first slices [n_giant + 1]
+  uint32_t *d_ell_so = nullptr, *d_ell_w = nullptr, *d_ell_od = nullptr;   // fixed-stride link records of k_fused_lean (kb_ell): 16 per vertex, rows 0 .. n
   uint32_t n_giant = 0, n_giant_slices = 0;                       // rows of more than GIANT_DEG in-links (GraphDev::giant_vtx)
   uint32_t n_heavy_chunks = 0;                                    // > 0: the kernels go through unit_first
   uint64_t build_id = 0;                                          // changes with every device build (upload, patch)
@@ -82,6 +85,7 @@ struct hspf_graph {
     d_vflags = (uint8_t *)carve(nv); d_rowflags = (uint8_t *)carve(nv);
     d_unit_first = (uint32_t *)carve((size_t(nv) / 4 + 8) * 4);
     d_giant = (uint32_t *)carve((size_t(cap) / (GIANT_DEG / 2) + 8) * 4);
+    d_ell_so = (uint32_t *)carve((size_t(nv) + 1) * 64); d_ell_w = (uint32_t *)carve((size_t(nv) + 1) * 64); d_ell_od = (uint32_t *)carve((size_t(nv) + 1) * 64);
     return off;
   }
   GraphDev dev() const {
@@ -139,7 +143,8 @@ struct hspf_ctx {
   uint32_t est_lv = 24;
   // A fused run's scratch, filled for the NEXT run behind this one's results (k_init_fill costs 14 us at the head of a
   // run, and the GPU idles for longer than that while the host turns a run around): valid for exactly these parameters
-  struct Prefill { bool valid = false; uint64_t build_id = 0; uint32_t n = 0, B = 0, esz = 0, n_changed = 0, L = 0; bool kcnt = false; } prefill;
+  struct Prefill { bool valid = false; uint64_t build_id = 0; uint32_t n = 0, B = 0, esz = 0, n_changed = 0, L = 0; bool kcnt = false;
+                   uint32_t ns = 0, fillw = 0; } prefill;      // ns: state rows per batch slab; fillw: the "not reached" word
   uint32_t unit_heavy_deg = UNIT_HEAVY_DEG; // HSPF_UNIT_HEAVY_DEG env: a chunk with a row of more in-links than this runs one row per wave
   uint32_t xcd_row_cost = 8;               // HSPF_XCD_ROW_COST env: fixed cost of a row, in links, when the XCD ranges are cut
   hspf_stats stats = {};
@@ -339,6 +344,9 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   }
   hipLaunchKernelGGL(kb_rowflags, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
                      (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info, GIANT_DEG);
+  hipLaunchKernelGGL(kb_ell, dim3((uint32_t)((((size_t)n + 1) * 16 + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr,
+                     (const uint32_t *)g->d_in_src, (const uint32_t *)g->d_in_w, (const uint32_t *)g->d_out_ptr, (const uint32_t *)g->d_out_dst,
+                     (const uint8_t *)g->d_vflags, g->d_ell_so, g->d_ell_w, g->d_ell_od, getenv("HSPF_PROBE_SELF") ? 1u : 0u);
   {
     // work units: heavy flag per chunk -> heavy chunks before each chunk -> unit_first (scratch: in_cnt, n + 17 words, is
     // free again and holds both: nb flags, then nb + 1 positions)
@@ -399,6 +407,7 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   { static std::atomic<uint64_t> next_build{1}; g->build_id = next_build.fetch_add(1); }
   g->narrow_bad = false;
   g->wide24_bad = false;
+  g->lean_bad = false;
   return HSPF_OK;
 }
 
@@ -860,9 +869,9 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   const bool fused = !no_fused && max_slots <= fused_max_slots && n < (1u << 23) && !(ctx->variant & 1u);
   const uint32_t Mw = std::max(16u, max_slots);
   FusedParams fp_wide{0u, Mw, Mw == 16u ? 0xFFFFu : (1u << (32u - Mw)) - 1u, 0xFFFFFFFFu, g->max_path_metric, 0xFFFFFFFFu,
-                      g->hopcount_like ? 1u : 0u};
-  FusedParams fp_narrow = fp_wide;
-  bool narrow = false;
+                      g->hopcount_like ? 1u : 0u, 0xFFFFFFFFu};
+  FusedParams fp_narrow = fp_wide, fp_lean = fp_wide;
+  bool narrow = false, lean = false;
   if (fused && !g->narrow_bad && !(ctx->variant & 2u)) {
     // field split of the 4-byte state: M mask bits = slots of this run, 7 hop bits (6 when that
     // leaves fewer than 13 distance bits), the rest distance; used when a link cost is at most
@@ -875,7 +884,26 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       narrow = true;
       fp_narrow = FusedParams{sh, M, (1u << H) - 1u, dmax << sh,
                               g->max_path_metric >= dmax ? 0xFFFFFFFFu : (g->max_path_metric << sh),
-                              (dmax - g->wmax) << sh, g->hopcount_like ? 1u : 0u};
+                              (dmax - g->wmax) << sh, g->hopcount_like ? 1u : 0u, 0xFFFFFFFFu};
+    }
+  }
+  // The lean sweep (k_fused_lean): [dist | 3 tag bits (zero in stored words) | hops | mask].  "Not reached" = inf_t =
+  // (dmax - wmax) << sh, so that a DPP add (no saturation) of any cost stays inside 32 bits; a FINAL word at or above
+  // ovf_t = (dmax - 2 wmax) << sh, or with the hop field at its maximum, raises LF_OVERFLOW in k_emit_fused (-> lean_bad:
+  // the run is redone by k_fused and the graph remembers).  The tag costs 3 of the 32 bits: 7 hop bits when that leaves a
+  // distance field of at least 8 x wmax, else 6 and at least 4 x wmax.  Needs max_path_metric beyond the field (nothing to
+  // prune inside it), no heavy work units, no giant rows.  HSPF_VARIANT bit 15: k_fused everywhere (A/B).
+  if (fused && !g->lean_bad && !(ctx->variant & (2u | 32768u)) && g->n_heavy_chunks == 0 && g->n_giant == 0) {
+    const uint32_t M = std::max(max_slots, 1u);
+    uint32_t H = 7u;
+    if (M + 3u + H + 4u > 32u || (1u << (32u - M - 3u - H)) < 8u * (g->wmax + 1u)) H = 6u;
+    if (M + 3u + H + 4u <= 32u) {
+      const uint32_t sh = M + H + 3u, D = 32u - sh, dmax = (1u << D) - 1u;
+      if (dmax >= 4u * (g->wmax + 1u) && g->max_path_metric >= dmax) {
+        lean = true;
+        fp_lean = FusedParams{sh, M, (1u << H) - 1u, (dmax - g->wmax) << sh, 0xFFFFFFFFu, (dmax - 2u * g->wmax) << sh,
+                              g->hopcount_like ? 1u : 0u, (dmax - g->wmax) << sh};
+      }
     }
   }
   // ---- scratch
@@ -1004,6 +1032,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // work that is only needed once (the emit of the fused path) then starts without waiting for the host's round
   // trip; after a chunk that did not converge it is simply enqueued again behind the next one.
   // pre_zeroed: how many leading sweep flags the caller's own init kernel has already cleared (0: cleared here)
+  std::function<void()> on_retry;      // set by a path whose `post` leaves something behind that a non-final chunk must undo
   auto run_phase = [&](uint32_t est, uint32_t pre_zeroed, auto &&launch, uint32_t &n_launch, auto &&post) -> int {
     hipError_t er = hipSuccess;
     uint32_t zeroed = std::min<uint32_t>(CHANGED_CAP, est + 4096);
@@ -1036,6 +1065,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       if (er == hipSuccess) er = hipStreamSynchronize(s);
       if (er != hipSuccess) { ctx->last_error = std::string("phase: ") + hipGetErrorString(er); return HSPF_E_HIP; }
       if (ctx->h_changed[sweep - 1] == 0) break;
+      if (on_retry) on_retry();
       chunk = 4;
     }
     // count the launches that did work (for stats and the next estimate)
@@ -1054,29 +1084,45 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if (fused) {
     const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
     uint32_t last_esz = 0;                    // state width of the last fused_run (0: none ran)
-    auto fused_run = [&](bool nar) -> int {
-      const FusedParams P = nar ? fp_narrow : fp_wide;
+    uint32_t last_ns = n, last_fillw = 0xFFFFFFFFu;
+    auto fused_run = [&](int mode) -> int {       // 0: 8-byte state, 1: 4-byte state (k_fused), 2: 4-byte state, lean sweep
+      const bool nar = mode != 0, use_lean = mode == 2;
+      const FusedParams P = use_lean ? fp_lean : (nar ? fp_narrow : fp_wide);
       const size_t esz = nar ? 4 : 8;
+      const uint32_t ns = use_lean ? n + 1u : n;                 // rows per batch slab (the lean sweep's pad row)
+      const size_t rows = (size_t)B * ns * 64;
+      const uint32_t fillw = use_lean ? P.infw : 0xFFFFFFFFu;
       // one fill launch (state, stamps, row flags, sweep flags, status bits, row counter), one launch for the roots
       uint32_t pre_zeroed = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
       const bool have = pf.valid && pf.build_id == g->build_id && pf.n == n && pf.B == B && pf.esz == (uint32_t)esz &&
+                        pf.ns == ns && pf.fillw == fillw &&
                         pf.L == L && (pf.kcnt || !count_rows) && pf.n_changed >= std::min<uint32_t>(CHANGED_CAP, 2u);
       pf.valid = false;
       if (have) pre_zeroed = pf.n_changed;      // run_phase clears whatever it needs beyond that
       else
-        hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, rows * esz / 16, d_stamp, (size_t)B * n,
+        hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, rows * esz / 16, fillw, d_stamp, (size_t)B * n,
                            (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, pre_zeroed, d_lf, L,
                            count_rows ? d_kcnt : (uint32_t *)nullptr);
-      last_esz = (uint32_t)esz;
+      last_esz = (uint32_t)esz; last_ns = ns; last_fillw = fillw;
+      if (use_lean) st.dbg[0] = 1;                               // hspf_stats::dbg[0]: the run took the lean sweep
+      // k_emit_fused checks the lean state's fields on FINAL words; an emit behind a chunk that had not converged saw
+      // transient ones: its LF_OVERFLOW bits are dropped before the next chunk (the final emit tests every word again)
+      on_retry = nullptr;
+      if (use_lean) on_retry = [&, L]() { hipLaunchKernelGGL(k_clear_lane_flag, dim3((L + 255) / 256), dim3(256), 0, s, d_lf, L, (uint32_t)LF_OVERFLOW); };
       if (giant && hipMemsetAsync(ctx->giant_part.p, 0, giant_tags * 4, s) != hipSuccess) { ctx->last_error = "giant tags"; return HSPF_E_HIP; }
-      if (nar) hipLaunchKernelGGL((k_init_fused<uint32_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
-      else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L);
+      if (nar) hipLaunchKernelGGL((k_init_fused<uint32_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L, ns);
+      else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L, ns);
       uint32_t n_f = 0;
       const bool maxinf = g->max_path_metric == HSPF_DIST_INF;
       int r2 = run_phase(ctx->est_fused, pre_zeroed, [&](uint32_t sweep) {
 #define HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, UN_, stp_) hipLaunchKernelGGL((k_fused<ST_, MI_, CN_, UN_>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, gd.in_ptr, gd.out_ptr, gd.vflags, stp_, d_roots, d_lf, net_nh, ignore_ovl, P, gd.in_src, gd.in_w, gd.out_dst, gd.e_in)
 #define HSPF_LAUNCH_FUSED(ST_, MI_, CN_, stp_) do { if (units) HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, true, stp_); else HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, false, stp_); } while (0)
         const bool units = g->n_heavy_chunks != 0;
+        if (use_lean) {
+          if (count_rows) hipLaunchKernelGGL((k_fused_lean<true>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P);
+          else            hipLaunchKernelGGL((k_fused_lean<false>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P);
+          return;
+        }
         if (giant) {                                   // slices of the due giant rows, ahead of the sweep that merges them
           const dim3 ggrid(g->n_giant_slices, B);
 #define HSPF_LAUNCH_GIANT(ST_, MI_, stp_) do { if (P.hc) hipLaunchKernelGGL((k_giant_part<ST_, MI_, true>), ggrid, dim3(256), 0, s, d_fg, (const int *)d_changed, (int)sweep, (const uint32_t *)d_stamp, n, (const ST_ *)stp_, (const uint32_t *)d_roots, net_nh, ignore_ovl, P); \
@@ -1101,12 +1147,23 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         // results out of the packed state (speculative: valid when this chunk reached the fixed point and, for the
         // 4-byte state, no lane overflowed; otherwise redone behind the next chunk / the wide run)
         (void)hipEventRecord(ctx->ev[2], s);
-        if (nar) hipLaunchKernelGGL((k_emit_fused<uint32_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint32_t *)d_st, P, od);
-        else     hipLaunchKernelGGL((k_emit_fused<uint64_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint64_t *)d_st, P, od);
+        if (nar) hipLaunchKernelGGL((k_emit_fused<uint32_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint32_t *)d_st, P, od, ns, use_lean ? d_lf : (uint32_t *)nullptr);
+        else     hipLaunchKernelGGL((k_emit_fused<uint64_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint64_t *)d_st, P, od, ns, (uint32_t *)nullptr);
         (void)hipEventRecord(ctx->ev[4], s);      // "results in place": the phase's read-back synchronises behind it
         tail_done = true;
       });
       if (r2) return r2;
+      if (use_lean && getenv("HSPF_PROBE")) {
+        // measurement only: forced dense sweeps over the CONVERGED state (sweep = -2: every stamp is due; nothing changes)
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, s);
+        for (int k = 0; k < 20; ++k)
+          hipLaunchKernelGGL((k_fused_lean<false>), fgrid, dim3(256), 0, s, d_fg, d_changed + 8, -2, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P);
+        (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "[hspf probe] %.2f us per forced dense read-only sweep (k_fused_lean)\n", ms * 50.0f);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      }
       ctx->est_fused = n_f + 1;
       st.n_relax_launches += n_f;
       if (count_rows) for (uint32_t i = 0; i < 256; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
@@ -1211,14 +1268,23 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     } else if (lv) {
       if ((rc = lv_run())) return rc;
       narrow = false;
-    } else if (narrow) {
-      if ((rc = fused_run(true))) return rc;
-      // did any lane leave the 4-byte fields?  (run_phase has brought the per-root status bits back)
-      bool ovf = false;
-      for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);
-      if (ovf) { g->narrow_bad = true; narrow = false; st.narrow_overflow = 1; }
+    } else if (lean || narrow) {
+      auto overflowed = [&]() { bool o = false; for (uint32_t r = 0; r < L; ++r) o = o || (ctx->h_lane_flags[r] & LF_OVERFLOW); return o; };
+      bool done = false;
+      if (lean) {
+        if ((rc = fused_run(2))) return rc;
+        // the lean state's fields are tighter (three tag bits, "not reached" one link cost lower, a saturating hop field):
+        // a lane at their edge sends the run to k_fused, and the graph remembers
+        if (overflowed()) { g->lean_bad = true; st.dbg[0] = 0; } else done = true;
+      }
+      if (!done && narrow) {
+        if ((rc = fused_run(1))) return rc;
+        // did any lane leave the 4-byte fields?  (run_phase has brought the per-root status bits back)
+        if (overflowed()) { g->narrow_bad = true; st.narrow_overflow = 1; } else done = true;
+      }
+      narrow = done;                                             // a 4-byte run holds the results
     }
-    if (!single && !lv && !narrow && (rc = fused_run(false))) return rc;
+    if (!single && !lv && !narrow && (rc = fused_run(0))) return rc;
     if (!narrow && fp_wide.hmax < 0xFFFFu) {                       // more than 16 mask bits: did the hop field hold?
       bool ovf = false;
       for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);
@@ -1231,9 +1297,9 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     if (last_esz && !(ctx->variant & 2048u)) {
       // the next run's scratch, behind this one's emit (same shape assumed: an SPF instance repeats its root set)
       const uint32_t nz = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
-      hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, rows * last_esz / 16, d_stamp, (size_t)B * n,
+      hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, (size_t)B * last_ns * 64 * last_esz / 16, last_fillw, d_stamp, (size_t)B * n,
                          (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, nz, d_lf, L, d_kcnt);
-      ctx->prefill = hspf_ctx::Prefill{true, g->build_id, n, B, last_esz, nz, L, true};
+      ctx->prefill = hspf_ctx::Prefill{true, g->build_id, n, B, last_esz, nz, L, true, last_ns, last_fillw};
     }
   } else {
   // More than 24 first-hop slots: two ways.  k_fw = ONE fused fixed point over (distance, hops, W mask words): half the

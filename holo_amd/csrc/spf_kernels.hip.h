@@ -499,6 +499,7 @@ struct FusedParams {
   uint32_t maxkey;    // dkey >  maxkey <=> beyond max_path_metric
   uint32_t ovf_t;     // narrow: dkey >= ovf_t (and reached) -> a later sum could leave the field
   uint32_t hc;        // 1: hop-count-like graph (every link into a network costs 0, into a router 1)
+  uint32_t infw;      // narrow: the word stored for "not reached" (all ones; inf_t for the lean sweep, whose sums must not wrap)
 };
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -569,7 +570,7 @@ __device__ __forceinline__ RowOut<ST> finish_row(const RowAcc &a, uint32_t v, ui
   o.sat = a.sat;
   o.ovf = false;
   if (v == my_root) o.nw = (ST)0;                                 // dist 0, hops 0, no next hops
-  else if (a.bd >= P.inf_t || a.bd > P.maxkey) o.nw = (ST)~(ST)0;
+  else if (a.bd >= P.inf_t || a.bd > P.maxkey) o.nw = sizeof(ST) == 8 ? (ST)~(ST)0 : (ST)P.infw;
   else {
     uint32_t hops = a.bh + v_router;
     // 16 hop bits: the reference's u16 saturating_add; fewer (4-byte state, or the 8-byte one with more than 16 mask
@@ -1055,6 +1056,207 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   uint32_t lf = 0;
   if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
   if (ovf) lf |= LF_OVERFLOW;
+  if (lf) atomicOr(&lane_flags[root_slot], lf);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fused_lean — the sweep of the 4-byte fused state, rewritten for instruction count AND memory-level parallelism.
+//
+// Round 3 measured what a dense sweep of k_fused is made of (profiles/r03_notes.md): 237 instructions per row evaluation
+// for ~10 links — ~9 per link (two v_readlane, the load, a wait per link, add, min, compare, two selects, or) and ~150
+// of per-row overhead —, a wave's life = six dependent round trips with at most ~10 row loads out, and an L1 that stalls
+// on pending misses half of the time because a CU never has enough of them in flight.  This kernel:
+//   * link records in a fixed-stride (ELL) copy built with the graph (kb_ell): 16 source byte offsets + 16 costs + 16
+//     wake-up offsets per vertex at addresses that depend on the vertex alone.  The source offsets come through the
+//     SCALAR cache (s_load) straight into the SGPRs the buffer loads take as row offset: no v_readlane, no hazard s_nop;
+//     the costs are one vector load per row with the 16 costs replicated in every 16-lane DPP row, so that
+//     `v_add_u32_dpp ... row_newbcast:j` adds cost j to a neighbour's word in ONE instruction;
+//   * a DPP add cannot saturate, so "not reached" is stored as inf_t = (dmax - wmax) << sh instead of all ones: a sum
+//     with any cost stays inside 32 bits, and whatever reaches inf_t is "not reached" again;
+//   * ONE s_waitcnt per row (explicit: the compiler's own is one per link); rows padded to an even number of links with a
+//     link from a never-reached pad row (state row n of every batch slab): 9 straight-line cases instead of 16;
+//   * a 3-bit TAG field between distance and hops (zero in stored words): the cost vector adds j & 7 there, so the min
+//     over whole candidate words is (smallest distance, first link in row order, ITS hops) at once and the second pass is
+//     min + or per link instead of compare + two selects (lean_reduce);
+//   * field checks out of the loop: the hop field saturates (one v_min) and k_emit_fused tests every FINAL word once
+//     (a clipped transient is a weaker upper bound and harmless); no root test (root rows carry RF_HNB and take the
+//     general routine); a changed row is stored whole (unchanged lanes rewrite their own value: single writer);
+//   * per-wave masks (due, fast) as SGPR bit sets instead of per-row lane read-backs; the wake-up offsets of a row are
+//     one ELL load in the set-up round trip (no out-row bounds, no dependent out-link load).
+// Rows with a per-batch or static flag take k_fused's general routine on the CSR arrays, unchanged.
+template <int J> __device__ __forceinline__ uint32_t dpp_bcast16(uint32_t v) {     // lane 16 r + J of every DPP row r
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + J, 0xF, 0xF, false);
+}
+
+struct LeanOut { uint32_t m, macc, bpay; };
+
+template <int J> struct LeanLinks {
+  // sov: lane 16 r + j = row byte offset of link j's source (low byte of link 0: the row's info byte, masked by the caller)
+  static __device__ __forceinline__ void load(uint32_t (&q)[16], __amdgpu_buffer_rsrc_t rs, uint32_t lane4, uint32_t sov) {
+    LeanLinks<J - 1>::load(q, rs, lane4, sov);
+    q[J - 1] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, rdlane(sov, J - 1), 0);
+  }
+  static __device__ __forceinline__ void add(uint32_t (&q)[16], uint32_t wk) {
+    LeanLinks<J - 1>::add(q, wk);
+    q[J - 1] = dpp_bcast16<J - 1>(wk) + q[J - 1];
+  }
+};
+template <> struct LeanLinks<0> {
+  static __device__ __forceinline__ void load(uint32_t (&)[16], __amdgpu_buffer_rsrc_t, uint32_t, uint32_t) {}
+  static __device__ __forceinline__ void add(uint32_t (&)[16], uint32_t) {}
+};
+
+// Candidates c[0 .. L) of one row -> (word of the FIRST tight link in row order, OR of the tight links' words).
+// The state word is [dist | tag (3 zero bits) | hops | mask]; the cost vector carries (cost << P.sh) + (j & 7) << tag
+// position, so a candidate is [dist | j & 7 | hops | mask] and ONE min over whole words yields the smallest distance and,
+// among the links that attain it, the first in row order together with its hop count — k_fused's second pass (compare +
+// two selects per link) shrinks to min(c, threshold) + or.  Rows of more than 8 links: two halves of 8, the second one
+// wins only with a strictly smaller distance.
+template <int L>
+__device__ __forceinline__ LeanOut lean_reduce(uint32_t (&c)[16], uint32_t wk, uint32_t paym) {
+  LeanLinks<L>::add(c, wk);
+  uint32_t m = INF;
+#pragma unroll
+  for (int j = 0; j < (L < 8 ? L : 8); ++j) m = min(m, c[j]);
+  if (L > 8) {
+    uint32_t mb = INF;
+#pragma unroll
+    for (int j = 8; j < L; ++j) mb = min(mb, c[j]);
+    m = mb < (m & ~paym) ? mb : m;
+  }
+  const uint32_t thr1 = (m | paym) + 1u;                          // (all ones + 1 = 0: nothing reached, nothing tight)
+  uint32_t macc = 0u;
+#pragma unroll
+  for (int j = 0; j < L; ++j) macc |= min(c[j], thr1);            // a tight link: its word; the others: low bits zero
+  return LeanOut{m, macc, m};
+}
+
+template <int L>
+__device__ __forceinline__ LeanOut lean_case(__amdgpu_buffer_rsrc_t rs, uint32_t lane4, uint32_t sov, uint32_t wk, uint32_t paym) {
+  uint32_t c[16];
+  LeanLinks<L>::load(c, rs, lane4, sov);
+  __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0): one wait for the row
+  return lean_reduce<L>(c, wk, paym);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fused_lean(
+    const FusedGraph *__restrict__ gp, int *changed, int sweep, uint32_t *__restrict__ act,
+    const uint8_t *__restrict__ hnb, uint32_t n_arg, const uint32_t *__restrict__ ell_so, const uint32_t *__restrict__ ell_w,
+    uint32_t *__restrict__ st, const uint32_t *__restrict__ ell_od, const uint32_t *__restrict__ roots, uint32_t *lane_flags,
+    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P) {
+  typedef uint32_t ST;
+  if (sweep > 0 && changed[sweep - 1] == 0) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t batch = blockIdx.y;
+  const uint32_t n = n_arg;
+  const uint32_t chunk = xcd_chunk(gp->g.xcd_start, blockIdx.x);
+  if (chunk == 0xFFFFFFFFu) return;
+  const uint32_t wbeg = chunk * (uint32_t)FVPB + wave * (uint32_t)FVPW;
+  if (wbeg >= n) return;
+  uint32_t *A = act + (size_t)batch * n;
+  const uint32_t cur = (uint32_t)sweep + 2u;
+  // ---- ONE set-up round trip: everything whose address depends on the wave's vertex range alone (ELL row n exists: all pad)
+  const uint32_t vl = min(wbeg + min(lane, (uint32_t)VPW - 1u), n - 1);
+  const uint32_t av = A[vl];
+  const uint32_t hb = hnb[(size_t)batch * n + vl] & (ignore_ovl ? ~RF_NT : ~0u);
+  ST *S = st + (size_t)batch * (n + 1u) * 64;                      // slab of n + 1 rows: row n = the pad row (never reached)
+  const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, (n + 1u) << 8);
+  const uint32_t lane4 = lane * 4u;
+  uint32_t sov[VPW], wk[VPW], od[VPW], oldq[VPW];
+#pragma unroll
+  for (int i = 0; i < VPW; ++i) {
+    const uint32_t e = (min(wbeg + i, n) * 16u + (lane & 15u)) * 4u;          // byte offset into the ELL arrays (n < 2^23)
+    sov[i] = *(const uint32_t *)((const char *)ell_so + e);
+    wk[i] = *(const uint32_t *)((const char *)ell_w + e);
+    od[i] = *(const uint32_t *)((const char *)ell_od + e);
+    oldq[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, min(wbeg + i, n - 1) << 8, 0);
+  }
+  const uint32_t due4 = (uint32_t)__ballot(lane < (uint32_t)VPW && wbeg + lane < n && av >= cur);
+  if (due4 == 0u) return;
+  const uint32_t fast4 = (uint32_t)__ballot(lane < (uint32_t)VPW && hb == 0u) & due4;
+  const uint32_t root_slot = batch * 64 + lane;
+  const __amdgpu_buffer_rsrc_t ra = st_rsrc(A, n * 4u);
+  uint32_t info[VPW];                                             // low byte of ELL entry 0: in-degree | (> 16 out-links) << 5 | network << 7
+#pragma unroll
+  for (int i = 0; i < VPW; ++i) {
+    info[i] = rdlane(sov[i], 0) & 0xFFu;
+    sov[i] &= ~0xFFu;
+    wk[i] = (wk[i] << P.sh) + ((lane & 7u) << (P.sh - 3u));       // cost in the distance field, j & 7 in the tag field below it
+    od[i] = lane < 16u ? od[i] : 0xFFFFFFFFu;                     // byte offsets into A; pad / upper lanes: out of range = dropped
+  }
+  const uint32_t paym = (1u << P.sh) - 1u;
+  const uint32_t hopm = P.hmax << P.mbits, maskm = (1u << P.mbits) - 1u;
+  uint64_t any = 0ull;
+  bool need_exact = false;
+  uint32_t n_done = 0;
+  // result of fast row i -> state, wake-ups (info bit 5: more than 16 out-links: they are walked, k_fused's loop)
+  auto commit = [&](auto I, uint32_t nw) {
+    constexpr int i = decltype(I)::value;
+    const uint32_t v = wbeg + i;
+    if (COUNT) ++n_done;
+    const uint64_t ch = __ballot(nw != oldq[i]);
+    if (ch == 0ull) return;
+    __builtin_amdgcn_raw_buffer_store_b32(nw, rs, lane4, v << 8, 0);          // the whole row: unchanged lanes rewrite their own value
+    any |= ch;
+    if (!(info[i] & 0x20u)) { __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, od[i], 0, 0); return; }   // wake the out-neighbours up
+    const GraphDev &g = gp->g;
+    const uint32_t o0 = g.out_ptr[v], o1 = g.out_ptr[v + 1];
+    for (uint32_t ob = o0 + lane; ob < o1; ob += 64) __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, g.out_dst[ob] * 4u, 0, 0);
+  };
+  auto finish = [&](const LeanOut &r, uint32_t inf) -> uint32_t {
+    const uint32_t hinc = (inf & 0x80u) ? 0u : (1u << P.mbits);   // a network does not count as a hop
+    const uint32_t hops = min((r.bpay & hopm) + hinc, hopm);      // saturating: P.hmax in a FINAL word = overflow (k_emit_fused)
+    return min((r.m & ~paym) | hops | (r.macc & maskm), P.infw);  // a sum that reached inf_t: not reached
+  };
+  auto row = [&](auto I) {                                        // a due fast row: even number of links (pad link from the pad row)
+    constexpr int i = decltype(I)::value;
+    if (!((fast4 >> i) & 1u)) return;
+    LeanOut r{INF, 0u, INF};
+    switch (((info[i] & 0x1Fu) + 1u) >> 1) {
+      case 0: break;
+      case 1: r = lean_case<2>(rs, lane4, sov[i], wk[i], paym); break;
+      case 2: r = lean_case<4>(rs, lane4, sov[i], wk[i], paym); break;
+      case 3: r = lean_case<6>(rs, lane4, sov[i], wk[i], paym); break;
+      case 4: r = lean_case<8>(rs, lane4, sov[i], wk[i], paym); break;
+      case 5: r = lean_case<10>(rs, lane4, sov[i], wk[i], paym); break;
+      case 6: r = lean_case<12>(rs, lane4, sov[i], wk[i], paym); break;
+      case 7: r = lean_case<14>(rs, lane4, sov[i], wk[i], paym); break;
+      default: r = lean_case<16>(rs, lane4, sov[i], wk[i], paym); break;
+    }
+    commit(I, finish(r, info[i]));
+  };
+  static_assert(VPW == 4, "row() is instantiated four times");
+  row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{});
+  row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
+  // ---- the due rows that carry a flag: k_fused's general routine on the CSR arrays (rare: one code instance, run-time row)
+#pragma unroll 1
+  for (uint32_t gm = due4 & ~fast4; gm != 0u; gm &= gm - 1u) {
+    const uint32_t v = wbeg + (uint32_t)__builtin_ctz(gm);
+    const GraphDev &g = gp->g;
+    const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
+    const uint32_t cnt = min(64u, e1 - e0);
+    const uint32_t sv = lane < cnt ? g.in_src[e0 + lane] : v;
+    const uint32_t wv = lane < cnt ? g.in_w[e0 + lane] : INF;
+    const uint32_t my_root = roots[root_slot];
+    const uint32_t old = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, v << 8, 0);
+    RowOut<ST> r;
+    if (P.hc) r = fused_row_any<ST, false, true, 4>(g, rs, v, e0, e1, sv, wv, lane, lane4, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
+    else r = fused_row_any<ST, false, false, 4>(g, rs, v, e0, e1, sv, wv, lane, lane4, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
+    need_exact = need_exact || r.need_exact;       // (r.ovf is a per-evaluation test of TRANSIENT values: the lean state's fields are tested on the final words, k_emit_fused)
+    if (COUNT) ++n_done;
+    const uint64_t ch = __ballot(r.nw != old);
+    if (ch == 0ull) continue;
+    __builtin_amdgcn_raw_buffer_store_b32(r.nw, rs, lane4, v << 8, 0);
+    any |= ch;
+    const uint32_t o0 = g.out_ptr[v], o1 = g.out_ptr[v + 1];
+    for (uint32_t ob = o0 + lane; ob < o1; ob += 64) __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, g.out_dst[ob] * 4u, 0, 0);
+  }
+  if (any != 0ull && lane == 0) changed[sweep] = 1;
+  if (COUNT && lane == 0) atomicAdd(&gp->rows_done[(blockIdx.x + wave) & 255u], n_done);
+  uint32_t lf = 0;
+  if (need_exact) lf |= LF_NEED_EXACT;
   if (lf) atomicOr(&lane_flags[root_slot], lf);
 }
 
@@ -1601,12 +1803,12 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single_lean(SingleArgs a) {
 // Everything a fused run starts from, in ONE launch instead of five fills: packed state = all ones, activation stamps =
 // 0, per-batch row flags = the graph's static ones (k_init_fused then adds RF_HNB), sweep flags = 0, per-root status
 // bits = 0, row counter = 0.  (A run of 64 roots on isis-100k spent ~45 us in seven tiny launches before its first sweep.)
-__global__ __launch_bounds__(256) void k_init_fill(uint4 *__restrict__ st16, size_t n_st16, uint32_t *__restrict__ act, size_t n_act,
+__global__ __launch_bounds__(256) void k_init_fill(uint4 *__restrict__ st16, size_t n_st16, uint32_t fillw, uint32_t *__restrict__ act, size_t n_act,
                                                    const uint8_t *__restrict__ rowflags, uint8_t *__restrict__ hnb, uint32_t n,
                                                    int *__restrict__ changed, uint32_t n_changed,
                                                    uint32_t *__restrict__ lane_flags, uint32_t n_lf, uint32_t *__restrict__ kcnt) {
   const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x, T = (size_t)gridDim.x * 256u;
-  const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  const uint4 ones = make_uint4(fillw, fillw, fillw, fillw);            // "not reached": all ones, or FusedParams::infw
   for (size_t i = t; i < n_st16; i += T) st16[i] = ones;
   for (size_t i = t; i < n_act; i += T) { act[i] = 0u; hnb[i] = rowflags[i % n]; }
   for (size_t i = t; i < n_changed; i += T) changed[i] = 0;
@@ -1620,14 +1822,19 @@ __global__ __launch_bounds__(256) void k_init_fill(uint4 *__restrict__ st16, siz
 // walk the out-links (a thread per root walked them one dependent load at a time: 13 us).
 template <typename ST>
 __global__ __launch_bounds__(256) void k_init_fused(GraphDev g, ST *st, uint32_t *act, uint8_t *hnb, const uint32_t *roots,
-                                                    SlotTabs tabs, uint32_t n_lanes) {
+                                                    SlotTabs tabs, uint32_t n_lanes, uint32_t ns) {
   const uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6, ln = threadIdx.x & 63u;
   if (i >= n_lanes) return;
   const uint32_t r = roots[i];
   if (r == INF) return;
   const uint32_t n = g.n;
   const uint32_t batch = i >> 6, lane = i & 63;
-  if (ln == 0) st[((size_t)batch * n + r) * 64 + lane] = (ST)0;
+  // ns: rows per batch slab (n, or n + 1 for the lean sweep's never-reached pad row).  The root's own row takes the
+  // general routine (it is the one that keeps a root's lane at zero): the lean fast routine never sees a root row.
+  if (ln == 0) {
+    st[((size_t)batch * ns + r) * 64 + lane] = (ST)0;
+    hnb[(size_t)batch * n + r] = (uint8_t)(g.rowflags[r] | RF_HNB);
+  }
   for (uint32_t k = g.out_ptr[r] + ln; k < g.out_ptr[r + 1]; k += 64) {
     const uint32_t d = g.out_dst[k];
     act[(size_t)batch * n + d] = 2u;
@@ -1642,18 +1849,34 @@ __global__ __launch_bounds__(256) void k_init_fused(GraphDev g, ST *st, uint32_t
   }
 }
 
+__global__ void k_clear_lane_flag(uint32_t *lane_flags, uint32_t n_lf, uint32_t bit) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_lf) lane_flags[i] &= ~bit;
+}
+
 // Emit for the fused path: packed lane-major state -> row-major results.
 template <typename ST>
 __global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots, const ST *__restrict__ st,
-                                                    FusedParams P, OutDev o) {
+                                                    FusedParams P, OutDev o, uint32_t ns, uint32_t *lane_flags) {
   __shared__ ST tt[64][65];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t batch = blockIdx.y, v0 = blockIdx.x * 64;
   const uint32_t nv = min(64u, n - v0);
   const uint32_t r0 = batch * 64;
   const uint32_t nr = min(64u, n_roots - r0);
-  const ST *S = st + ((size_t)batch * n + v0) * 64;
-  for (uint32_t j = wave; j < nv; j += 4) tt[j][lane] = S[(size_t)j * 64 + lane];
+  const ST *S = st + ((size_t)batch * ns + v0) * 64;
+  // lane_flags != null (lean sweep, 4-byte state): the fields are checked HERE, once per final word, instead of in
+  // every row evaluation — a reached lane within one link cost of "not reached" (P.ovf_t), or a hop count that
+  // saturated (P.hmax), means some value on the way may have been clipped: LF_OVERFLOW, the run is redone wide.  Clipped
+  // TRANSIENT values are harmless (a weaker upper bound; every evaluation is a pure function of the in-neighbours).
+  bool ovf = false;
+  for (uint32_t j = wave; j < nv; j += 4) {
+    const ST x = S[(size_t)j * 64 + lane];
+    tt[j][lane] = x;
+    if (sizeof(ST) == 4 && lane_flags)
+      ovf = ovf || ((uint32_t)x < P.inf_t && ((uint32_t)x >= P.ovf_t || (((uint32_t)x >> P.mbits) & P.hmax) == P.hmax));
+  }
+  if (ovf) atomicOr(&lane_flags[r0 + lane], LF_OVERFLOW);
   __syncthreads();
   for (uint32_t r = wave; r < nr; r += 4)
     if (lane < nv) {
@@ -1662,7 +1885,7 @@ __global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots
       uint32_t d, pay;
       if (sizeof(ST) == 8) { d = (uint32_t)((uint64_t)x >> 32); pay = (uint32_t)x; }
       else { d = (uint32_t)x >> P.sh; pay = (uint32_t)x & ((1u << P.sh) - 1u); }
-      const bool in = x != (ST)~(ST)0;
+      const bool in = sizeof(ST) == 8 ? x != (ST)~(ST)0 : (uint32_t)x < P.inf_t;
       o.dist[idx] = in ? d : INF;
       if (o.hops) o.hops[idx] = in ? (uint16_t)(pay >> P.mbits) : (uint16_t)0;
       if (o.flags) o.flags[idx] = in ? 1 : 0;
