@@ -438,7 +438,7 @@ __global__ void kb_xcd(uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInf
 __global__ void __launch_bounds__(GB_BLOCK)
 kb_ell(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ in_src, const uint32_t *__restrict__ in_w,
        const uint32_t *__restrict__ out_ptr, const uint32_t *__restrict__ out_dst, const uint8_t *__restrict__ vflags,
-       uint32_t *__restrict__ ell_so, uint32_t *__restrict__ ell_w, uint32_t *__restrict__ ell_od, uint32_t probe_self) {
+       uint32_t *__restrict__ ell_so, uint32_t *__restrict__ ell_w, uint32_t *__restrict__ ell_od) {
   const uint32_t t = blockIdx.x * GB_BLOCK + threadIdx.x;
   const uint32_t v = t >> 4, j = t & 15u;
   if (v > n) return;
@@ -447,7 +447,7 @@ kb_ell(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__restri
     const uint32_t e0 = in_ptr[v], deg = in_ptr[v + 1] - e0;
     const uint32_t o0 = out_ptr[v], odeg = out_ptr[v + 1] - o0;
     info = (deg <= 16u ? deg : 0x1Fu) | (odeg > 16u ? 0x20u : 0u) | ((vflags[v] & HSPF_VF_NETWORK) ? 0x80u : 0u);
-    if (deg <= 16u && j < deg) { so = (probe_self ? v : (in_src[e0 + j] & SRC_MASK)) << 8; w = in_w[e0 + j]; }   // probe_self: measurement only (HSPF_PROBE_SELF)
+    if (deg <= 16u && j < deg) { so = (in_src[e0 + j] & SRC_MASK) << 8; w = in_w[e0 + j]; }
     if (j < odeg) od = out_dst[o0 + j] << 2;
   }
   if (j == 0u) so |= info;

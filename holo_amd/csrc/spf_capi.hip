@@ -346,7 +346,7 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
                      (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info, GIANT_DEG);
   hipLaunchKernelGGL(kb_ell, dim3((uint32_t)((((size_t)n + 1) * 16 + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr,
                      (const uint32_t *)g->d_in_src, (const uint32_t *)g->d_in_w, (const uint32_t *)g->d_out_ptr, (const uint32_t *)g->d_out_dst,
-                     (const uint8_t *)g->d_vflags, g->d_ell_so, g->d_ell_w, g->d_ell_od, getenv("HSPF_PROBE_SELF") ? 1u : 0u);
+                     (const uint8_t *)g->d_vflags, g->d_ell_so, g->d_ell_w, g->d_ell_od);
   {
     // work units: heavy flag per chunk -> heavy chunks before each chunk -> unit_first (scratch: in_cnt, n + 17 words, is
     // free again and holds both: nb flags, then nb + 1 positions)
@@ -1153,17 +1153,6 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         tail_done = true;
       });
       if (r2) return r2;
-      if (use_lean && getenv("HSPF_PROBE")) {
-        // measurement only: forced dense sweeps over the CONVERGED state (sweep = -2: every stamp is due; nothing changes)
-        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        (void)hipEventRecord(e0, s);
-        for (int k = 0; k < 20; ++k)
-          hipLaunchKernelGGL((k_fused_lean<false>), fgrid, dim3(256), 0, s, d_fg, d_changed + 8, -2, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P);
-        (void)hipEventRecord(e1, s); (void)hipEventSynchronize(e1);
-        float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1);
-        fprintf(stderr, "[hspf probe] %.2f us per forced dense read-only sweep (k_fused_lean)\n", ms * 50.0f);
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-      }
       ctx->est_fused = n_f + 1;
       st.n_relax_launches += n_f;
       if (count_rows) for (uint32_t i = 0; i < 256; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];

@@ -1140,7 +1140,7 @@ __device__ __forceinline__ LeanOut lean_case(__amdgpu_buffer_rsrc_t rs, uint32_t
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fused_lean(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fused_lean(
     const FusedGraph *__restrict__ gp, int *changed, int sweep, uint32_t *__restrict__ act,
     const uint8_t *__restrict__ hnb, uint32_t n_arg, const uint32_t *__restrict__ ell_so, const uint32_t *__restrict__ ell_w,
     uint32_t *__restrict__ st, const uint32_t *__restrict__ ell_od, const uint32_t *__restrict__ roots, uint32_t *lane_flags,
@@ -1157,10 +1157,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   if (wbeg >= n) return;
   uint32_t *A = act + (size_t)batch * n;
   const uint32_t cur = (uint32_t)sweep + 2u;
-  // ---- ONE set-up round trip: everything whose address depends on the wave's vertex range alone (ELL row n exists: all pad)
+  // ---- stamps and flags first: in the sparse head and tail of a run most waves end here, and what the sweep is short
+  // of is vector memory instructions, not round trips (profiles/r03_notes.md)
   const uint32_t vl = min(wbeg + min(lane, (uint32_t)VPW - 1u), n - 1);
   const uint32_t av = A[vl];
   const uint32_t hb = hnb[(size_t)batch * n + vl] & (ignore_ovl ? ~RF_NT : ~0u);
+  const uint32_t due4 = (uint32_t)__ballot(lane < (uint32_t)VPW && wbeg + lane < n && av >= cur);
+  if (due4 == 0u) return;
+  // ---- everything else whose address depends on the wave's vertex range alone (ELL row n exists: all pad)
   ST *S = st + (size_t)batch * (n + 1u) * 64;                      // slab of n + 1 rows: row n = the pad row (never reached)
   const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, (n + 1u) << 8);
   const uint32_t lane4 = lane * 4u;
@@ -1173,8 +1177,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
     od[i] = *(const uint32_t *)((const char *)ell_od + e);
     oldq[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, min(wbeg + i, n - 1) << 8, 0);
   }
-  const uint32_t due4 = (uint32_t)__ballot(lane < (uint32_t)VPW && wbeg + lane < n && av >= cur);
-  if (due4 == 0u) return;
   const uint32_t fast4 = (uint32_t)__ballot(lane < (uint32_t)VPW && hb == 0u) & due4;
   const uint32_t root_slot = batch * 64 + lane;
   const __amdgpu_buffer_rsrc_t ra = st_rsrc(A, n * 4u);
