@@ -123,8 +123,79 @@ def latency_1root(ctx, dev) -> dict:
                   and np.array_equal(m.cpu().numpy().view(np.uint64), ref.mask))
         out[name] = {"gpu_wall_ms": round(float(np.median(wall[3:])), 4), "gpu_device_ms": round(float(np.median(devms[3:])), 4),
                      "launches": launches,
-                     "path": "k_single" if st.get("single_wg") else ("k_lv" if st.get("lane_vertex") else "k_fused sweeps"), "cpu_heap_1thread_ms": round(float(min(tc)), 4), "identical_to_oracle": ok}
+                     "path": path_of(st), "cpu_heap_1thread_ms": round(float(min(tc)), 4), "identical_to_oracle": ok}
         G.free()
+    return out
+
+
+def path_of(st) -> str:
+    """Which engine path a run took, from its hspf_stats."""
+    if st.get("single_wg"):
+        return "k_single (one workgroup per root)"
+    if st.get("lane_vertex"):
+        return "k_lv (lane = vertex)"
+    if st["state_bytes"] == 4:
+        return "k_fused_lean, 4-byte state" if st.get("dbg", [0])[0] else "k_fused, 4-byte state"
+    if st["state_bytes"] == 8:
+        return "k_fused, 8-byte state"
+    return "k_relax + k_dag (two-phase)" if st["n_dag_launches"] else "k_fw (wide masks)"
+
+
+def other_configs(ctx, dev) -> dict:
+    """The other single-GPU BASELINE configs through the same C ABI entry point (hspf_run_device), results in HBM:
+    device time (median of 5 after 2 warm-up runs), runs/s, fraction of the HBM roofline by SURVEY.md 8(d)'s B_alg, the
+    engine path, and EVERY (root, vertex) result compared bit for bit with the CPU oracle (outside the timed runs)."""
+    import torch
+    from holo_amd import synth
+    from holo_amd import engine as E
+    from oracle import graph_oracle as go
+    thr = min(64, os.cpu_count() or 1)
+
+    def one(g, roots, fl):
+        roots = np.asarray(roots, np.uint32)
+        G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        W = G.mask_words(roots)
+        R, n = len(roots), g.n
+        d = torch.empty((R, n), dtype=torch.int32, device=dev); h = torch.empty((R, n), dtype=torch.int16, device=dev)
+        f = torch.empty((R, n), dtype=torch.int16, device=dev); m = torch.empty((R, n, W), dtype=torch.int64, device=dev)
+        ms = []
+        for _ in range(7):
+            st = ctx.run_device(G, roots, fl, dist_ptr=d.data_ptr(), hops_ptr=h.data_ptr(), flags_ptr=f.data_ptr(),
+                                mask_ptr=m.data_ptr(), mask_words=W)
+            ms.append(st["ms_total"])
+        ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, fl, go.HEAP, mask_words_=W, threads=thr)
+        ok = bool(np.array_equal(d.cpu().numpy().view(np.uint32), ref.dist) and np.array_equal(h.cpu().numpy().view(np.uint16), ref.hops)
+                  and np.array_equal(f.cpu().numpy().view(np.uint16) & 1, ref.flags) and np.array_equal(m.cpu().numpy().view(np.uint64), ref.mask))
+        G.free()
+        del d, h, f, m, ref
+        return float(np.median(ms[2:])), st, W, ok
+
+    out = {}
+    g10 = synth.ospf_10k()
+    for R in (64, 1024):
+        roots = ((np.arange(R, dtype=np.int64) * g10.n) // R).astype(np.uint32)
+        ms, st, W, ok = one(g10, roots, E.RUN_NET_NEXTHOPS)
+        rps = R / (ms * 1e-3)
+        out[f"ospf-10k, {R} roots (configs[1] graph)"] = {
+            "device_ms": round(ms, 4), "runs_per_s": round(rps), "roofline_frac": round(rps * b_alg(g10.n, g10.e, W) / HBM_PEAK, 5),
+            "alg_bytes_per_run": b_alg(g10.n, g10.e, W), "path": path_of(st), "launches": st["n_relax_launches"] + st["n_dag_launches"],
+            "roots_verified": R, "identical_to_oracle": ok}
+    # configs[3]: 10 areas x 1000 roots, each area its own graph, one after the other on this context
+    tot, nroots, allok, ba, last = 0.0, 0, True, 0, None
+    for g in synth.ospf_multi_area():
+        ms, st, W, ok = one(g, g.meta["roots"], E.RUN_NET_NEXTHOPS)
+        tot += ms; nroots += len(g.meta["roots"]); allok = allok and ok; ba = b_alg(g.n, g.e, W); last = st
+    rps = nroots / (tot * 1e-3)
+    out["ospf multi-area, 10 areas x 5000 routers x 1000 roots (configs[3], one GPU)"] = {
+        "device_ms": round(tot, 3), "runs_per_s": round(rps), "roofline_frac": round(rps * ba / HBM_PEAK, 5), "alg_bytes_per_run": ba,
+        "path": path_of(last), "roots_verified": nroots, "identical_to_oracle": allok}
+    gf = synth.isis_fattree(100)
+    ms, st, W, ok = one(gf, gf.meta["roots"], 0)
+    rps = len(gf.meta["roots"]) / (ms * 1e-3)
+    out["isis fat-tree k=100, 262 500 vertices / 1.5 M entries, 101 roots (configs[4], one GPU)"] = {
+        "device_ms": round(ms, 3), "runs_per_s": round(rps), "roofline_frac": round(rps * b_alg(gf.n, gf.e, W) / HBM_PEAK, 5),
+        "alg_bytes_per_run": b_alg(gf.n, gf.e, W), "mask_words": W, "path": path_of(st),
+        "launches": st["n_relax_launches"] + st["n_dag_launches"], "roots_verified": len(gf.meta["roots"]), "identical_to_oracle": ok}
     return out
 
 
@@ -242,6 +313,7 @@ def main():
             phase["n_relax"] += st["n_relax_launches"]; phase["n_dag"] += st["n_dag_launches"]
             phase["n_exact"] += st["n_exact_roots"]
             phase["state_bytes"] = st["state_bytes"]; phase["narrow_overflow"] += st["narrow_overflow"]
+            phase["lean"] = int(st.get("dbg", [0])[0])
 
     def fence():
         if pending[0] is not None:
@@ -314,7 +386,7 @@ def main():
         relax_avg = phase["relax_ms"] / max(phase["n_relax"], 1) * 1e-3
         dag_avg = phase["dag_ms"] / max(phase["n_dag"], 1) * 1e-3
         if phase["n_dag"] == 0:
-            dominant = "k_fused"          # fused fast path: one kernel does distances + hops + masks
+            dominant = "k_fused_lean" if phase.get("lean") else "k_fused"      # fused fast path: one kernel does distances + hops + masks
         else:
             dominant = "k_dag" if phase["dag_ms"] >= phase["relax_ms"] else "k_relax"
         avg = dag_avg if dominant == "k_dag" else relax_avg
@@ -356,7 +428,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, roots)
-            out["latency_1root"] = latency_1root(E.SpfContext(local_rank), dev)
+            ctx1 = E.SpfContext(local_rank)
+            out["latency_1root"] = latency_1root(ctx1, dev)
+            out["configs"] = other_configs(ctx1, dev)
         print(json.dumps(out), flush=True)
 
     m.free_graph(mg)
