@@ -101,6 +101,7 @@ SYMBOLS = [
     # several GPUs
     ("hspf_multi_unique_id", ctypes.c_int, [u8p]),
     ("hspf_multi_init", ctypes.c_int, [ctypes.POINTER(HspfMultiConfig), ctypes.POINTER(ctypes.c_void_p)]),
+    ("hspf_multi_init_error", ctypes.c_char_p, []),
     ("hspf_multi_shutdown", None, [ctypes.c_void_p]),
     ("hspf_multi_last_error", ctypes.c_char_p, [ctypes.c_void_p]),
     ("hspf_multi_ctx", ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_uint32]),

@@ -58,13 +58,16 @@ struct hspf_multi {
   std::vector<hipStream_t> cstream;                  // per local device: the stream the gathers run on
   struct Pending { const void *key; hipEvent_t ev; uint32_t local; };
   std::vector<Pending> pending;                      // asynchronous gathers in flight, keyed by the dist table they fill
-  std::vector<hipEvent_t> free_events;
+  bool force_bcast = false;
+  std::vector<std::vector<hipEvent_t>> free_events;  // per LOCAL device: an event is only ever recorded on the device it was created on
   std::string last_error;
 };
 
 struct hspf_multi_graph {
   std::vector<hspf_graph *> g;
 };
+
+static thread_local std::string g_multi_init_error;   // why the last hspf_multi_init of this thread failed (it has no handle to carry the text)
 
 extern "C" {
 
@@ -120,7 +123,7 @@ void hspf_multi_shutdown(hspf_multi *m) {
   for (size_t i = 0; i < m->cstream.size(); ++i)
     if (m->cstream[i]) { (void)hipSetDevice(m->dev[i]); (void)hipStreamSynchronize(m->cstream[i]); }
   for (auto &p : m->pending) (void)hipEventDestroy(p.ev);
-  for (auto &e : m->free_events) (void)hipEventDestroy(e);
+  for (auto &v : m->free_events) for (auto &e : v) (void)hipEventDestroy(e);
   for (size_t i = 0; i < m->comm.size(); ++i)
     if (m->comm[i]) { (void)hipSetDevice(m->dev[i]); (void)m->rccl.CommDestroy(m->comm[i]); }
   for (size_t i = 0; i < m->cstream.size(); ++i)
@@ -128,6 +131,8 @@ void hspf_multi_shutdown(hspf_multi *m) {
   for (hspf_ctx *c : m->ctx) hspf_shutdown(c);
   delete m;
 }
+
+const char *hspf_multi_init_error(void) { return g_multi_init_error.c_str(); }
 
 int hspf_multi_init(const hspf_multi_config *cfg, hspf_multi **out) {
   if (!cfg || !out || cfg->n_local == 0 || !cfg->device_ordinals || cfg->world < cfg->n_local ||
@@ -137,6 +142,7 @@ int hspf_multi_init(const hspf_multi_config *cfg, hspf_multi **out) {
   hspf_multi *m = nullptr;
   try { m = new hspf_multi(); } catch (...) { return HSPF_E_NOMEM; }
   m->world = cfg->world; m->first_rank = cfg->first_rank;
+  m->force_bcast = getenv("HSPF_GATHER_FORCE_BCAST") != nullptr;
   try {
     for (uint32_t i = 0; i < cfg->n_local; ++i) {
       hspf_ctx *c = nullptr;
@@ -147,6 +153,7 @@ int hspf_multi_init(const hspf_multi_config *cfg, hspf_multi **out) {
       (void)hipSetDevice(cfg->device_ordinals[i]);
       if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) { hspf_multi_shutdown(m); return HSPF_E_HIP; }
       m->cstream.push_back(cs);
+      m->free_events.emplace_back();
     }
     // direct device-to-device copies between the local devices (errors ignored: already enabled / same device)
     for (uint32_t i = 0; i < cfg->n_local; ++i)
@@ -161,7 +168,7 @@ int hspf_multi_init(const hspf_multi_config *cfg, hspf_multi **out) {
         }
     if (cfg->unique_id) {
       std::string err;
-      if (!rccl_load(m->rccl, err)) { hspf_multi_shutdown(m); return HSPF_E_NODEV; }
+      if (!rccl_load(m->rccl, err)) { try { g_multi_init_error = err; } catch (...) {} hspf_multi_shutdown(m); return HSPF_E_NODEV; }
       RcclId id{};
       memcpy(id.internal, cfg->unique_id, HSPF_COMM_ID_BYTES);
       m->comm.assign(cfg->n_local, nullptr);
@@ -172,7 +179,10 @@ int hspf_multi_init(const hspf_multi_config *cfg, hspf_multi **out) {
       }
       const int rc2 = m->rccl.GroupEnd();
       if (rc == 0) rc = rc2;
-      if (rc != 0) { hspf_multi_shutdown(m); return HSPF_E_HIP; }
+      if (rc != 0) {
+        try { g_multi_init_error = std::string("rccl communicator: ") + (m->rccl.GetErrorString ? m->rccl.GetErrorString(rc) : "error") + " (code " + std::to_string(rc) + ")"; } catch (...) {}
+        hspf_multi_shutdown(m); return HSPF_E_HIP;
+      }
       m->use_rccl = true;
     }
   } catch (...) { hspf_multi_shutdown(m); return HSPF_E_NOMEM; }
@@ -220,7 +230,7 @@ static int allgather_rows_impl(hspf_multi *m, void *const *tables, size_t row_by
   int rc = HSPF_OK;
   if (m->use_rccl) {
     // equal slices: one ncclAllGather, in place (send = own slice of recv); ragged: one broadcast per rank, grouped
-    bool equal = true;
+    bool equal = !m->force_bcast;                // HSPF_GATHER_FORCE_BCAST (tests): the ragged branch even when the slices are equal
     uint32_t b0, e0;
     hspf_shard_bounds(n_roots, m->world, 0, &b0, &e0);
     for (uint32_t r = 1; r < m->world; ++r) { uint32_t b, e; hspf_shard_bounds(n_roots, m->world, r, &b, &e); equal = equal && (e - b == e0 - b0); }
@@ -275,7 +285,7 @@ int hspf_multi_wait(hspf_multi *m) {
     (void)hipSetDevice(m->dev[i]);
     if (hipStreamSynchronize(m->cstream[i]) != hipSuccess) rc = HSPF_E_HIP;
   }
-  for (auto &p : m->pending) m->free_events.push_back(p.ev);
+  for (auto &p : m->pending) m->free_events[p.local].push_back(p.ev);
   m->pending.clear();
   return rc;
 }
@@ -289,7 +299,7 @@ int hspf_multi_run(hspf_multi *m, const hspf_multi_graph *g, const uint32_t *roo
     auto &p = m->pending[k];
     if (p.key == (const void *)all[p.local].dist) {
       (void)hipEventSynchronize(p.ev);
-      m->free_events.push_back(p.ev);
+      m->free_events[p.local].push_back(p.ev);
       m->pending.erase(m->pending.begin() + (long)k);
     } else ++k;
   }
@@ -339,9 +349,15 @@ int hspf_multi_run(hspf_multi *m, const hspf_multi_graph *g, const uint32_t *roo
     for (uint32_t i = 0; i < nl; ++i) {
       hipEvent_t ev = nullptr;
       (void)hipSetDevice(m->dev[i]);
-      if (!m->free_events.empty()) { ev = m->free_events.back(); m->free_events.pop_back(); }
+      auto &pool = m->free_events[i];
+      if (!pool.empty()) { ev = pool.back(); pool.pop_back(); }
       else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { m->last_error = "gather event"; return HSPF_E_HIP; }
-      (void)hipEventRecord(ev, m->cstream[i]);
+      if (hipEventRecord(ev, m->cstream[i]) != hipSuccess) {
+        // no marker for this gather: finish it here, so that a later run into the same tables cannot overtake it
+        pool.push_back(ev);
+        if (hipStreamSynchronize(m->cstream[i]) != hipSuccess) { m->last_error = "gather event record / stream sync"; return HSPF_E_HIP; }
+        continue;
+      }
       m->pending.push_back(hspf_multi::Pending{(const void *)all[i].dist, ev, i});
     }
   }

@@ -368,7 +368,7 @@ class MultiEngine:
         h = ctypes.c_void_p()
         rc = self.lib.hspf_multi_init(ctypes.byref(cfg), ctypes.byref(h))
         if rc != 0:
-            raise HspfError(rc, "hspf_multi_init")
+            raise HspfError(rc, "hspf_multi_init", (self.lib.hspf_multi_init_error() or b"").decode())
         self.handle = h
         self.graph = None
 

@@ -17,18 +17,17 @@ BATCH = 64          # roots per wavefront batch (lane = root)
 
 
 def shard_bounds(n_roots: int, world: int) -> List[Tuple[int, int]]:
-    """[begin, end) of every rank's slice: whole 64-root batches are dealt out as evenly as possible
-    (the first `extra` ranks take one more), the ragged tail batch goes to the last rank that has
-    work.  Ranks beyond the number of batches get an empty slice."""
-    n_batches = (n_roots + BATCH - 1) // BATCH
-    base, extra = divmod(n_batches, world)
-    out, b = [], 0
-    for r in range(world):
-        nb = base + (1 if r < extra else 0)
-        lo, hi = min(b * BATCH, n_roots), min((b + nb) * BATCH, n_roots)
-        out.append((lo, hi))
-        b += nb
-    return out
+    """[begin, end) of every rank's slice — the C ABI's hspf_shard_bounds (include/holo_spf_hip.h), the ONE place the
+    slicing rule lives: whole 64-root batches dealt out as evenly as possible, the ragged tail batch to the last rank
+    that has work, empty slices beyond the number of batches.  (Pure host arithmetic: the library loads without a GPU.)"""
+    from . import engine as E
+    return [E.shard_bounds(n_roots, world, r) for r in range(world)]
+
+
+def plan_areas(roots_per_area: Sequence[int], world: int):
+    """Areas first, then roots (BASELINE configs[3]) — the C ABI's hspf_plan_areas: list of (rank, area, begin, end)."""
+    from . import engine as E
+    return E.plan_areas(roots_per_area, world)
 
 
 def shard_roots(roots: Sequence[int], rank: int, world: int) -> np.ndarray:

@@ -396,6 +396,8 @@ typedef struct {
 
 int         hspf_multi_unique_id(uint8_t id[HSPF_COMM_ID_BYTES]);      /* needs librccl.so                        */
 int         hspf_multi_init(const hspf_multi_config *cfg, hspf_multi **out);
+/* Detail of the last failed hspf_multi_init on the calling thread (e.g. RCCL's own message); "" if none. */
+const char *hspf_multi_init_error(void);
 void        hspf_multi_shutdown(hspf_multi *m);
 const char *hspf_multi_last_error(const hspf_multi *m);
 hspf_ctx   *hspf_multi_ctx(hspf_multi *m, uint32_t local_index);      /* the rank's context, for the one-device calls */

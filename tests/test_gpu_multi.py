@@ -102,3 +102,104 @@ def test_rccl_backend_loads_and_gathers_with_one_rank():
         assert torch.equal(t, want)
     finally:
         m.close()
+
+
+def test_rccl_ragged_branch_grouped_broadcasts_with_one_rank(monkeypatch):
+    """The ragged-slices branch of the RCCL back end (one grouped ncclBroadcast per rank instead of the in-place
+    ncclAllGather), forced with HSPF_GATHER_FORCE_BCAST on a one-rank communicator and a root count that is not a
+    multiple of 64: the only way to run it on one GPU (RCCL refuses two ranks on one device, see
+    profiles/r03_rccl_two_ranks_one_gpu.txt)."""
+    import torch
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("HSPF_GATHER_FORCE_BCAST", "1")
+    m = E.MultiEngine([0], world=1, first_rank=0, unique_id=E.multi_unique_id())
+    try:
+        t = torch.arange(70 * 13, dtype=torch.int32, device=dev).reshape(70, 13)
+        want = t.clone()
+        torch.cuda.synchronize()
+        m.allgather_rows([t.data_ptr()], 13 * 4, 70)
+        assert torch.equal(t, want)
+        g = synth.ospf_10k()
+        roots = ((np.arange(70, dtype=np.uint64) * g.n) // 70).astype(np.uint32)
+        mg = m.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        W = m.mask_words(mg, roots)
+        tab = _tables(torch, dev, 70, g.n, W)
+        m.run(mg, roots, E.RUN_NET_NEXTHOPS, [_ptrs(tab, W)], E.GATHER_DIST | E.GATHER_HOPS | E.GATHER_ASYNC)
+        m.wait()
+        ctx = E.SpfContext(0)
+        G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        ref = ctx.run(G, roots, E.RUN_NET_NEXTHOPS)
+        assert np.array_equal(tab["dist"].cpu().numpy().view(np.uint32), ref.dist)
+        assert np.array_equal(tab["hops"].cpu().numpy().view(np.uint16), ref.hops)
+        G.free(); ctx.close(); m.free_graph(mg)
+    finally:
+        m.close()
+
+
+def test_two_async_gathers_into_the_same_tables_back_to_back():
+    """a second asynchronous run into tables whose gather is still in flight must wait for exactly that
+    gather (events are kept per local device), and a third run reuses the recycled events."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = synth.ospf_10k()
+    n, n_ctx, n_roots = g.n, 3, 192
+    m = E.MultiEngine([0] * n_ctx)
+    try:
+        mg = m.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        sets = [((np.arange(n_roots, dtype=np.uint64) * n) // n_roots + k * 7).astype(np.uint32) % n for k in range(3)]
+        W = max(m.mask_words(mg, r) for r in sets)
+        tabs = [_tables(torch, dev, n_roots, n, W) for _ in range(n_ctx)]
+        mode = E.GATHER_DIST | E.GATHER_HOPS | E.GATHER_ASYNC
+        for roots in sets:                      # no wait in between: run k + 1 must not overtake gather k
+            m.run(mg, roots, E.RUN_NET_NEXTHOPS, [_ptrs(t, W) for t in tabs], mode)
+        m.wait()
+        ctx = E.SpfContext(0)
+        G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        ref = ctx.run(G, sets[-1], E.RUN_NET_NEXTHOPS)
+        for t in tabs:
+            assert np.array_equal(t["dist"].cpu().numpy().view(np.uint32), ref.dist)
+            assert np.array_equal(t["hops"].cpu().numpy().view(np.uint16), ref.hops)
+        G.free(); ctx.close(); m.free_graph(mg)
+    finally:
+        m.close()
+
+
+def _rccl_rank(rank, uid, q):
+    try:
+        from holo_amd import engine as E2
+        m = E2.MultiEngine([0], world=2, first_rank=rank, unique_id=uid)
+        q.put((rank, "ok", ""))
+        m.close()
+    except Exception as ex:     # noqa: BLE001
+        q.put((rank, "error", str(ex)))
+
+
+def test_two_rccl_ranks_on_one_gpu_are_refused_or_work(tmp_path):
+    """Two PROCESSES, one GPU, hspf_multi_init(world = 2) from a shared communicator id.  RCCL refuses two ranks on one
+    device ("Duplicate GPU detected"): then the library must fail cleanly (an HspfError, no hang, no crash) and the
+    text goes to gpurun_out/ for the record; should a future RCCL allow it, both ranks must come up."""
+    import multiprocessing as mp
+    import os
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    uid = E.multi_unique_id()
+    procs = [ctx.Process(target=_rccl_rank, args=(r, uid, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        for _ in range(2):
+            got.append(q.get(timeout=90))
+    except Exception:           # noqa: BLE001   (a hang is a failure of the library, not of the test harness)
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        pytest.fail("hspf_multi_init with two ranks on one GPU did not return within 90 s")
+    for p in procs:
+        p.join(timeout=30)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/rccl_two_ranks_one_gpu.txt", "w") as f:
+        for r in sorted(got):
+            f.write(f"rank {r[0]}: {r[1]} {r[2]}\n")
+    states = {r[1] for r in got}
+    assert states in ({"ok"}, {"error"}), got

@@ -72,3 +72,56 @@ def test_two_rank_sharded_run_equals_single_process(n_roots):
         assert np.array_equal(got[rank]["hops"].view(np.uint16), ref.hops)
         W = got[rank]["first_hop_mask"].shape[2]
         assert np.array_equal(got[rank]["first_hop_mask"].view(np.uint64)[:, :, :ref.mask.shape[2]], ref.mask[:, :, :W])
+
+
+def _area_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, HERE)
+    from _oracle_engine import OracleEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        areas = [synth.random_lsdb(60 + 10 * a, 6, 3.0, 100 + a, metric_hi=6) for a in range(3)]
+        roots = [np.arange(0, g.n, 1 + a, dtype=np.uint32)[: (70, 130, 20)[a]] for a, g in enumerate(areas)]
+        # the ONLY source of slicing: the C ABI's area plan (areas first, then roots; whole 64-root batches)
+        plan = [s for s in shard.plan_areas([len(r) for r in roots], world) if s[0] == rank]
+        eng = OracleEngine()
+        mine = []
+        for _, a, lo, hi in plan:
+            g = areas[a]
+            G = eng.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+            res = eng.run(G, roots[a][lo:hi], 0)
+            mine.append((a, lo, hi, res.dist.copy(), res.hops.copy()))
+        everything = [None] * world
+        dist.all_gather_object(everything, mine)              # the exchange step (RCCL all-gather of per-root tables on GPUs)
+        q.put((rank, everything))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_area_plan_from_the_c_abi_covers_every_root_once():
+    """configs[3] shape on CPU: areas sharded over 2 ranks by hspf_plan_areas, each rank runs ITS (area, root range)
+    slices, one exchange, and every rank holds every root's table exactly once, equal to the single-process run."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_area_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    areas = [synth.random_lsdb(60 + 10 * a, 6, 3.0, 100 + a, metric_hi=6) for a in range(3)]
+    roots = [np.arange(0, g.n, 1 + a, dtype=np.uint32)[: (70, 130, 20)[a]] for a, g in enumerate(areas)]
+    refs = [go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, r, 0, go.MAP) for g, r in zip(areas, roots)]
+    for rank in range(world):
+        seen = [np.zeros(len(r), np.int32) for r in roots]
+        for part in got[rank]:
+            for a, lo, hi, d, h in part:
+                seen[a][lo:hi] += 1
+                assert np.array_equal(d, refs[a].dist[lo:hi]) and np.array_equal(h, refs[a].hops[lo:hi])
+        assert all((s == 1).all() for s in seen)
