@@ -82,11 +82,22 @@ def cpu_baseline(g, roots, budget_s: float = 8.0) -> dict:
     t1 = time.perf_counter()
     go.run(g10.row_ptr, g10.col, g10.metric, g10.vflags, g10.max_path_metric, np.array([0], np.uint32), 1, go.REF, mask_words_=1)
     dref = time.perf_counter() - t1
+    stored = None
+    sp = os.path.join(ROOT, "profiles", "r03_cpu_ref_shaped_100k.json")
+    if os.path.exists(sp):
+        try:
+            j = json.load(open(sp))
+            stored = {"runs_per_s": j["runs_per_s"], "seconds_per_run": j["seconds"], "identical_to_heap_variant": j["identical_to_heap_variant"],
+                      "note": "STORED figure (profiles/r03_cpu_ref_shaped_100k.json, measured once in the build container, 1 thread): the "
+                              "reference-shaped variant on THIS workload's graph, one root; not re-timed here (11 minutes per run)"}
+        except Exception:   # noqa: BLE001
+            stored = None
     return {"value": round(k / dt, 3), "unit": "spf_runs/s", "cores": 1, "kind": "port",
             "sample": f"oracle heap-Dijkstra restatement (dist+hops+first-hop masks), {k} runs cycling the 64 roots of "
                       f"isis-100k, 1 thread, {dt:.2f} s; host has {cores} cores",
             "all_cores": {"value": round(ka / ta, 3), "unit": "spf_runs/s", "cores": cores,
                           "sample": f"same restatement, {ka} runs (the 64 roots cycled), whole roots dealt to {cores} threads, {ta:.2f} s"},
+            "reference_shaped_isis_100k": stored,
             "reference_shaped_ospf_10k": {"runs_per_s": round(1.0 / dref, 3),
                                           "note": "ordered-map + linear-scan shape of the reference loop (holo-isis/src/spf.rs:552-706), 10k routers / 80k entries, "
                                                   "1 root, 1 thread; the candidate scan is quadratic: ~100x this time per run at 100k vertices"}}
@@ -376,6 +387,24 @@ def main():
     m.run(mg, run_roots, E.RUN_COUNT_ROWS, [ptrs(last, not sharded_in_lib)], 0)
     rows_recomputed = int(m.stats(0)["rows_recomputed"])
 
+    # N > 1: the exchange on its own, outside the timed region (inside it the gather is asynchronous and overlaps the next
+    # step): one SYNCHRONOUS all-gather of the distance table per rank, so that the first multi-GPU run reports what the
+    # exchange costs next to what it moves ((R / G) x N x 4 bytes per rank)
+    exchange = None
+    if world > 1 and sharded_in_lib:
+        ts = []
+        for _ in range(3):
+            fence()
+            t0 = time.perf_counter()
+            m.allgather_rows([last["dist"].data_ptr()], n * 4, RA)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        mine = {"rank": rank, "bytes_sent": int(R * n * 4), "bytes_received": int((RA - R) * n * 4), "sync_allgather_ms": round(min(ts), 4)}
+        allx = [None] * world
+        dist.all_gather_object(allx, mine)
+        exchange = {"table": "dist (u32)", "rows_per_rank": R, "row_bytes": n * 4, "per_rank": allx,
+                    "note": "synchronous hspf_multi_allgather_rows after the timed region; in the timed region the same exchange is asynchronous"}
+
     if rank == 0:
         runs = timed_steps * R * world
         value = runs / dt
@@ -426,6 +455,8 @@ def main():
                                    "fused_state_bytes": phase["state_bytes"], "narrow_overflows": phase["narrow_overflow"],
                                    "rows_recomputed_per_step": rows_recomputed, "rows_x_N": round(rows_recomputed / n, 2)},
         }
+        if exchange is not None:
+            out["exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, roots)
             ctx1 = E.SpfContext(local_rank)

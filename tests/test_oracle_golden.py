@@ -129,6 +129,22 @@ def test_ospf_ref_update_global_rib_reproduces_recorded_ibus_messages(path):
     assert RO.update_global_rib(vec["rib"], vec["rib_before"], vec["ifindex"]) == want
 
 
+def _assert_vlink_endpoint(got, want):
+    """A virtual-link endpoint: run_area leaves the routes reached THROUGH the virtual link without next hops
+    (holo-ospf/src/ospfv2/spf.rs:202-207); they are filled in by the transit-area examination of the Type-3 summary-LSAs
+    (update_rib_transit_area, holo-ospf/src/route.rs:536-640: RFC 2328 16.3) — inter-area route calculation, outside the
+    SPF path.  What the path itself determines is compared: the set of prefixes, every metric and
+    type, and the next hops of every route that does not hang off the virtual link."""
+    assert [(r["prefix"], r["metric"], r["type"]) for r in got] == [(r["prefix"], r["metric"], r["type"]) for r in want]
+    through_vlink = 0
+    for g, w in zip(got, want):
+        if g["nexthops"] or not w["nexthops"]:
+            assert g["nexthops"] == w["nexthops"], g["prefix"]
+        else:
+            through_vlink += 1
+    assert through_vlink <= 3
+
+
 @pytest.mark.parametrize("path", OSPF, ids=OSPF_IDS)
 def test_ospf_ref_reproduces_reference_intra_area_rib(path):
     """57 routers (p2p, broadcast/DR, multi-area ABRs, stub areas, unnumbered, ECMP); the 6
@@ -136,7 +152,8 @@ def test_ospf_ref_reproduces_reference_intra_area_rib(path):
     area::update_virtual_links (holo-ospf/src/area.rs:207), which is not on the SPF path."""
     vec = _load(path)
     if vec["has_vlinks"]:
-        pytest.skip("virtual-link endpoint: next hops completed outside run_area")
+        _assert_vlink_endpoint(RO.intra_area_rib(vec), _intra(vec))
+        return
     assert RO.intra_area_rib(vec) == _intra(vec)
 
 
@@ -161,6 +178,29 @@ def test_graph_oracle_agrees_with_ospf_ref(path):
             assert [g.index[v] for v in order] == np.argsort(o.pop_rank[0], kind="stable")[:len(order)].tolist()
 
 
+def test_ospf_interface_slot_order_rule():
+    """The interface arena slot (first key of the next-hop map, holo-ospf/src/route.rs:92-98) is an input of the path
+    that no fixture file carries.  The extractor derives it from config.json alone — interface-NAME order — and takes
+    the order the recorded ECMP routes show ONLY where that contradicts the rule (tools/make_golden_ospf.py::
+    _iface_order).  Pinned here: that happens for exactly two routers of the segment-routing topology; for the other
+    105 OSPFv2 / OSPFv3 vectors the slot order, hence the ECMP order the oracles must reproduce, owes nothing to the
+    answer."""
+    recorded, by_name = [], 0
+    paths = sorted(glob.glob(os.path.join(GOLD, "ospfv2", "*.json"))) + sorted(glob.glob(os.path.join(GOLD, "ospfv3", "*.json")))
+    assert len(paths) == 107
+    for path in paths:
+        vec = _load(path)
+        slots = {i["name"]: i["index"] for a in vec["areas"] for i in a["interfaces"] if i["index"] < 1000}
+        if vec["iface_slot_order"] == "recorded":
+            recorded.append(os.path.relpath(path, GOLD))
+            continue
+        by_name += 1
+        names = sorted(slots)
+        assert sorted(slots, key=slots.get) == names, path          # slot order == name order
+    assert recorded == ["ospfv2/topo2-4_rt2.json", "ospfv2/topo2-4_rt3.json"]
+    assert by_name == 105
+
+
 # ---- OSPFv3 -----------------------------------------------------------------------------------------
 from oracle import ospfv3_ref as R3      # noqa: E402
 
@@ -176,7 +216,8 @@ def test_ospfv3_ref_reproduces_reference_intra_area_rib(path):
     """38 routers (the fixtures exist although the module is commented out upstream,
     holo-ospf/tests/conformance/mod.rs:7-8); 6 virtual-link endpoints excluded as for OSPFv2."""
     vec = _load(path)
-    if vec["has_vlinks"]:
-        pytest.skip("virtual-link endpoint: next hops completed outside run_area")
     want = sorted([r for r in vec["rib"] if r["type"] == "intra-area"], key=lambda r: R3._net_key(r["prefix"]))
+    if vec["has_vlinks"]:
+        _assert_vlink_endpoint(R3.intra_area_rib(vec), want)
+        return
     assert R3.intra_area_rib(vec) == want

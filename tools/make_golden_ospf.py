@@ -30,32 +30,14 @@ def ospfv2_vector(rt_dir: str) -> dict:
     st_doc = json.load(open(os.path.join(rt_dir, "output", "northbound-state.json")))
     cfg = _proto(cfg_doc, "ietf-ospf:ospf")
     st = _proto(st_doc, "ietf-ospf:ospf")
-    # Interface arena slot (generational_arena::Index, first component of NexthopKey,
-    # holo-ospf/src/route.rs:92-98) is RUNTIME state of the recorded run: it is not in config.json
-    # nor in the state dump (same config order gives eth-rt4-1 < eth-sw1 in topo2-1..2-3 and the
-    # opposite in topo2-4).  Default: name order; where the recorded ECMP routes show another
-    # relative order between two interfaces, that observed order is taken as the slot order (it is
-    # an INPUT of the path — `iface_idx` — that happens to be visible only through the answer).
-    order, iftype, has_vlinks = {}, {}, False
-    names = []
+    # Interface arena slot (generational_arena::Index, first component of NexthopKey, holo-ospf/src/route.rs:92-98):
+    # see _iface_order below — interface-NAME order, derived from config.json alone, except where the recorded run
+    # demonstrably had another one.
+    iftype, has_vlinks = {}, False
     for a in cfg.get("areas", {}).get("area", []):
         for i in a.get("interfaces", {}).get("interface", []):
-            names.append(i["name"])
             iftype[i["name"]] = i.get("interface-type", "broadcast")
-    names = sorted(set(names))
-    before = set()
-    for r in st.get("local-rib", {}).get("route", []):
-        seq = []
-        for n in r.get("next-hops", {}).get("next-hop", []):
-            if n.get("outgoing-interface") and (not seq or seq[-1] != n["outgoing-interface"]):
-                seq.append(n["outgoing-interface"])
-        before |= {(x, y) for x, y in zip(seq, seq[1:])}
-    placed = []
-    while len(placed) < len(names):
-        nxt = next(n for n in names if n not in placed
-                   and not any((m, n) in before for m in names if m not in placed and m != n))
-        placed.append(nxt)
-    order = {n: k for k, n in enumerate(placed)}
+    order, order_source = _iface_order(cfg, st)
     for a in cfg.get("areas", {}).get("area", []):
         if a.get("virtual-links", {}).get("virtual-link"):
             has_vlinks = True
@@ -95,7 +77,7 @@ def ospfv2_vector(rt_dir: str) -> dict:
         rib.append({"prefix": r["prefix"], "metric": int(r["metric"]), "type": r["route-type"], "nexthops": nhs})
     return {"source": os.path.relpath(rt_dir, REF), "proto": "ospfv2", "router_id": st["router-id"],
             "max_paths": int(cfg.get("spf-control", {}).get("paths", 16)), "has_vlinks": has_vlinks,
-            "areas": areas, "rib": rib}
+            "iface_slot_order": order_source, "areas": areas, "rib": rib}
 
 
 def make_ospfv2():
@@ -121,7 +103,15 @@ if __name__ == "__main__":
 # --------------------------------------------------------------------------------------------
 
 def _iface_order(cfg, st):
-    """Same arena-slot recovery as for OSPFv2 (see ospfv2_vector)."""
+    """Interface arena slots (`iface_idx`, the first key of a route's next-hop map): an INPUT of the path that is runtime
+    state of the recorded session — neither config.json nor the state dump carries it.  Rule used: interfaces are
+    inserted in NAME order (the northbound tree hands the `interface` list entries over sorted by key).  The rule needs
+    nothing from the answer, and the recorded ECMP routes CHECK it: over the 107 OSPFv2 / OSPFv3 topology routers they
+    show 80 ordered interface pairs, 78 of them in name order.  The two that are not (ospfv2 topo2-4 rt2 / rt3, the
+    segment-routing topology: eth-sw1 before eth-rt4-* / eth-rt5-*) contradict config order in topo2-1..2-3 as well,
+    i.e. no rule derived from the fixture's inputs reproduces both: for those two routers the observed order is taken
+    (`iface_slot_order: "recorded"`) and their ECMP ORDER is not independently pinned; everywhere else it is
+    (`"name"`; tests/test_oracle_golden.py::test_ospf_interface_slot_order_rule).  Returns (slot of every name, source)."""
     names = sorted({i["name"] for a in cfg.get("areas", {}).get("area", [])
                     for i in a.get("interfaces", {}).get("interface", [])})
     before = set()
@@ -131,12 +121,15 @@ def _iface_order(cfg, st):
             if n.get("outgoing-interface") and (not seq or seq[-1] != n["outgoing-interface"]):
                 seq.append(n["outgoing-interface"])
         before |= {(x, y) for x, y in zip(seq, seq[1:])}
+    by_name = {n: k for k, n in enumerate(names)}
+    if all(by_name[x] < by_name[y] for x, y in before if x in by_name and y in by_name):
+        return by_name, "name"
     placed = []
     while len(placed) < len(names):
         nxt = next(n for n in names if n not in placed
                    and not any((m, n) in before for m in names if m not in placed and m != n))
         placed.append(nxt)
-    return {n: k for k, n in enumerate(placed)}
+    return {n: k for k, n in enumerate(placed)}, "recorded"
 
 
 def ospfv3_vector(rt_dir: str) -> dict:
@@ -144,7 +137,7 @@ def ospfv3_vector(rt_dir: str) -> dict:
     st_doc = json.load(open(os.path.join(rt_dir, "output", "northbound-state.json")))
     cfg = _proto(cfg_doc, "ietf-ospf:ospf")
     st = _proto(st_doc, "ietf-ospf:ospf")
-    order = _iface_order(cfg, st)
+    order, order_source = _iface_order(cfg, st)
     iftype, has_vlinks = {}, False
     for a in cfg.get("areas", {}).get("area", []):
         for i in a.get("interfaces", {}).get("interface", []):
@@ -201,7 +194,7 @@ def ospfv3_vector(rt_dir: str) -> dict:
     af = "ipv4" if any("." in r["prefix"].split("/")[0] and ":" not in r["prefix"] for r in rib) else "ipv6"
     return {"source": os.path.relpath(rt_dir, REF), "proto": "ospfv3", "router_id": st["router-id"], "af": af,
             "max_paths": int(cfg.get("spf-control", {}).get("paths", 16)), "has_vlinks": has_vlinks,
-            "areas": areas, "rib": rib}
+            "iface_slot_order": order_source, "areas": areas, "rib": rib}
 
 
 def make_ospfv3():
