@@ -1557,9 +1557,9 @@ int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out) {
   return HSPF_OK;
 }
 
-int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uint32_t n_mask_words,
-                       const uint32_t *dist_dev, const uint16_t *flags_dev, const uint64_t *mask_dev,
-                       const hspf_prefix_table *t, hspf_routes *out) {
+static int routes_device_impl(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uint32_t n_mask_words,
+                              const uint32_t *dist_dev, const uint16_t *flags_dev, const uint64_t *mask_dev,
+                              const hspf_prefix_table *t, hspf_routes *out) {
   if (!ctx || !t || !out || !dist_dev || !flags_dev || !mask_dev || !out->best_metric || !out->best_entry ||
       !out->nexthop_mask || n_roots == 0 || n_mask_words == 0 || !t->pfx_ptr || (t->n_entries && (!t->pfx_vertex || !t->pfx_metric)))
     return HSPF_E_INVAL;
@@ -1624,9 +1624,17 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
   return HSPF_OK;
 }
 
-int hspf_routes_diff_device(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes, uint32_t n_mask_words,
-                            const hspf_routes *old_dev, const hspf_routes *new_dev,
-                            uint8_t *action_dev, uint32_t *changed_dev, uint32_t *changed_ptr_dev) {
+// (entry points that assign strings / grow scratch run through guarded(): nothing unwinds across the C boundary)
+int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uint32_t n_mask_words,
+                       const uint32_t *dist_dev, const uint16_t *flags_dev, const uint64_t *mask_dev,
+                       const hspf_prefix_table *t, hspf_routes *out) {
+  if (!ctx) return HSPF_E_INVAL;
+  return guarded(ctx, [&]() -> int { return routes_device_impl(ctx, n_vertices, n_roots, n_mask_words, dist_dev, flags_dev, mask_dev, t, out); });
+}
+
+static int routes_diff_device_impl(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes, uint32_t n_mask_words,
+                                   const hspf_routes *old_dev, const hspf_routes *new_dev,
+                                   uint8_t *action_dev, uint32_t *changed_dev, uint32_t *changed_ptr_dev) {
   if (!ctx || !old_dev || !new_dev || !action_dev || !changed_dev || !changed_ptr_dev || n_roots == 0 || n_mask_words == 0 ||
       !old_dev->best_metric || !old_dev->best_entry || !old_dev->nexthop_mask ||
       !new_dev->best_metric || !new_dev->best_entry || !new_dev->nexthop_mask)
@@ -1636,6 +1644,11 @@ int hspf_routes_diff_device(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes
   (void)hipSetDevice(ctx->device);
   hipStream_t s = ctx->stream;
   const uint32_t count = (uint32_t)count64;
+  if (count == 0) {                                          // no prefixes: every root's list is empty
+    HIPCHK(ctx, hipMemsetAsync(changed_ptr_dev, 0, ((size_t)n_roots + 1) * 4, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    return HSPF_OK;
+  }
   // scratch: pos[count + 1] | sums | flag[count] (u8)
   const size_t nsums = (size_t)count / GB_TILE + 4;
   int rc = ensure(ctx, ctx->gb, ((size_t)count + 1 + nsums) * 4 + count + 64);
@@ -1655,6 +1668,13 @@ int hspf_routes_diff_device(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes
   return HSPF_OK;
 }
 
+int hspf_routes_diff_device(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes, uint32_t n_mask_words,
+                            const hspf_routes *old_dev, const hspf_routes *new_dev,
+                            uint8_t *action_dev, uint32_t *changed_dev, uint32_t *changed_ptr_dev) {
+  if (!ctx) return HSPF_E_INVAL;
+  return guarded(ctx, [&]() -> int { return routes_diff_device_impl(ctx, n_roots, n_prefixes, n_mask_words, old_dev, new_dev, action_dev, changed_dev, changed_ptr_dev); });
+}
+
 int hspf_ancestors_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
                           const uint32_t *dist_dev, const uint16_t *hops_dev, const uint16_t *flags_dev,
                           uint32_t level, uint32_t n_words, uint32_t *level_rank_dev, uint32_t *level_count_dev,
@@ -1665,6 +1685,7 @@ int hspf_ancestors_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *ro
   return guarded(ctx, [&]() -> int {
     (void)hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
+    ctx->prefill.valid = false;                // ctx->changed serves as flag scratch below: what a previous run prefilled is gone
     const uint32_t n = g->n, nb = (n + 255) / 256;
     for (uint32_t r = 0; r < n_roots; ++r)
       if (roots[r] != HSPF_NO_ROOT && roots[r] >= n) { ctx->last_error = "root out of range"; return HSPF_E_INVAL; }

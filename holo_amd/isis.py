@@ -1054,6 +1054,13 @@ def compute_spf(instance: Instance, engine, cache: Optional[GraphCache] = None,
 
 # ---- the wire step after the path: update_global_rib, holo-isis/src/route.rs:254-312 ------------------
 
+def _nh_key(row: dict):
+    """Next hops as the reference compares them (whole Nexthop structs, holo-isis/src/route.rs:270-272): address,
+    interface and SR output label (rows of an SR-enabled instance carry `nexthop_labels`)."""
+    labels = row.get("nexthop_labels") or [None] * len(row["nexthops"])
+    return sorted((tuple(nh), -1 if lb is None else lb) for nh, lb in zip(row["nexthops"], labels))
+
+
 def update_global_rib(new_rows: List[dict], old_rows: List[dict], ifindex: Dict[str, int],
                       unchanged: Optional[Iterable[str]] = None) -> List[dict]:
     """The RouteIpAdd / RouteIpDel messages a new local RIB puts on the ibus, in emission order (rows as compute_spf
@@ -1067,8 +1074,9 @@ def update_global_rib(new_rows: List[dict], old_rows: List[dict], ifindex: Dict[
     msgs: List[dict] = []
     for r in sorted(new_rows, key=lambda r: _net_key(r["prefix"])):
         o = old.pop(_net_key(r["prefix"]), None)
-        if o is not None and (r["prefix"] in skip or (o["metric"] == r["metric"]
-                              and sorted(map(tuple, o["nexthops"])) == sorted(map(tuple, r["nexthops"])))):
+        # (a device-side diff sees metric and next-hop masks, not SR labels: with labels in play the host compares)
+        labelled = any(lb is not None for row in (r, o or {}) for lb in (row.get("nexthop_labels") or ()))
+        if o is not None and ((r["prefix"] in skip and not labelled) or (o["metric"] == r["metric"] and _nh_key(o) == _nh_key(r))):
             continue
         if r["nexthops"]:
             nhs = sorted(((ifindex[ifname], addr) for addr, ifname in r["nexthops"]),

@@ -507,6 +507,13 @@ def reflood_list(vec, level, local_system_id, tn, lsp_id, algo_of=None):
 
 # ---- the wire step after the path: update_global_rib (holo-isis/src/route.rs:254-312) --------------------------------
 
+def _nh_key(row):
+    """Next hops as the reference compares them (`old_route.nexthops == route.nexthops`, route.rs:270-272: whole Nexthop
+    structs): (address, interface, SR output label) — the label column exists only in rows of an SR-enabled instance."""
+    labels = row.get("nexthop_labels") or [None] * len(row["nexthops"])
+    return sorted((tuple(nh), -1 if lb is None else lb) for nh, lb in zip(row["nexthops"], labels))
+
+
 def update_global_rib(new_rows, old_rows, ifindex):
     """route.rs:254-312 + ibus::tx::route_install / route_uninstall (holo-isis/src/ibus/tx.rs:35-110), on rows of the
     YANG `local-rib` list (what local_rib() returns): for every route of the new RIB in BTreeMap<IpNetwork, _> order —
@@ -521,8 +528,8 @@ def update_global_rib(new_rows, old_rows, ifindex):
     msgs = []
     for r in sorted(new_rows, key=lambda r: _net_key(r["prefix"])):
         o = old.pop(_net_key(r["prefix"]), None)
-        if o is not None and o["metric"] == r["metric"] and sorted(map(tuple, o["nexthops"])) == sorted(map(tuple, r["nexthops"])):
-            continue                                           # :268-277
+        if o is not None and o["metric"] == r["metric"] and _nh_key(o) == _nh_key(r):
+            continue                                           # :268-277 (whole Nexthop structs: address, interface AND SR label)
         if r["nexthops"]:                                      # :283-295
             nhs = sorted(((ifindex[ifname], addr) for addr, ifname in r["nexthops"]),
                          key=lambda t: (t[0], ipaddress.ip_address(t[1]).version, int(ipaddress.ip_address(t[1]))))

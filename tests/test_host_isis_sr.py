@@ -90,3 +90,15 @@ def test_random_instances_with_sr_against_the_restatement(block):
             for l in r["nexthop_labels"]:
                 seen.add("null" if l in (0, 2, 3) else ("none" if l is None else "label"))
     assert {"in", "noin", "null", "none", "label"} <= seen
+
+
+def test_update_global_rib_reinstalls_a_route_whose_only_change_is_an_sr_label():
+    """the reference compares whole Nexthop structs (holo-isis/src/route.rs:268-277), SR output label
+    included — a neighbour's SRGB change re-sends the route although metric, address and interface are the same; a
+    device-side 'unchanged' verdict (metric + next-hop mask) must not suppress it."""
+    old = [{"prefix": "10.0.0.0/24", "metric": 20, "level": 2, "nexthops": [["10.1.1.2", "eth0"]], "sr_label": 16005, "nexthop_labels": [17005]}]
+    new = [{"prefix": "10.0.0.0/24", "metric": 20, "level": 2, "nexthops": [["10.1.1.2", "eth0"]], "sr_label": 16005, "nexthop_labels": [18005]}]
+    for f in (H.update_global_rib, R.update_global_rib):
+        assert f(new, old, {"eth0": 3}) == [{"op": "add", "prefix": "10.0.0.0/24", "metric": 20, "nexthops": [[3, "10.1.1.2"]]}]
+        assert f(old, old, {"eth0": 3}) == []
+    assert H.update_global_rib(new, old, {"eth0": 3}, unchanged=["10.0.0.0/24"]) != []
