@@ -95,6 +95,9 @@ SYMBOLS = [
     ("hspf_routes_diff_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                                ctypes.POINTER(HspfRoutes), ctypes.POINTER(HspfRoutes),
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    ("hspf_routes_diff_count", ctypes.c_uint32, [ctypes.c_void_p]),
+    ("hspf_routes_pack", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(HspfRoutes),
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, u32p]),
     ("hspf_ancestors_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -114,6 +114,8 @@ struct hspf_ctx {
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
+  DevBuf pack;                                      // record stream of hspf_routes_pack
+  uint32_t last_diff_count = 0;                     // changed pairs of the last hspf_routes_diff_device (hspf_routes_diff_count)
   DevBuf gb, gb_delta, gb_hub, giant_part;                      // graph build scratch, patch delta, hub-mode sort buffers
   uint32_t hub_deg = HUB_DEG;                       // HSPF_HUB_DEG env: rows with more links than this -> graph build from sorted keys
   BuildInfo *h_info = nullptr;     // pinned
@@ -498,7 +500,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->kcnt})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->kcnt, &ctx->pack})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
@@ -1644,6 +1646,7 @@ static int routes_diff_device_impl(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_p
   (void)hipSetDevice(ctx->device);
   hipStream_t s = ctx->stream;
   const uint32_t count = (uint32_t)count64;
+  ctx->last_diff_count = 0;
   if (count == 0) {                                          // no prefixes: every root's list is empty
     HIPCHK(ctx, hipMemsetAsync(changed_ptr_dev, 0, ((size_t)n_roots + 1) * 4, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
@@ -1662,7 +1665,10 @@ static int routes_diff_device_impl(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_p
   gb_scan<uint8_t>(s, flag, count, pos, sums);
   hipLaunchKernelGGL(k_routes_diff_scatter, dim3((unsigned)(((size_t)std::max(count, n_roots + 1) + 255) / 256)), dim3(256), 0, s,
                      (size_t)count, n_prefixes, n_roots, (const uint8_t *)flag, (const uint32_t *)pos, changed_dev, changed_ptr_dev);
+  // the total rides back with the synchronisation this call ends on anyway (the hand-off sizes its one copy by it)
+  HIPCHK(ctx, hipMemcpyAsync(&ctx->h_info->kept, pos + count, 4, hipMemcpyDeviceToHost, s));
   HIPCHK(ctx, hipStreamSynchronize(s));
+  ctx->last_diff_count = ctx->h_info->kept;
   hipError_t le = hipGetLastError();
   if (le != hipSuccess) { ctx->last_error = std::string("k_routes_diff: ") + hipGetErrorString(le); return HSPF_E_HIP; }
   return HSPF_OK;
@@ -1673,6 +1679,32 @@ int hspf_routes_diff_device(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes
                             uint8_t *action_dev, uint32_t *changed_dev, uint32_t *changed_ptr_dev) {
   if (!ctx) return HSPF_E_INVAL;
   return guarded(ctx, [&]() -> int { return routes_diff_device_impl(ctx, n_roots, n_prefixes, n_mask_words, old_dev, new_dev, action_dev, changed_dev, changed_ptr_dev); });
+}
+
+uint32_t hspf_routes_diff_count(const hspf_ctx *ctx) { return ctx ? ctx->last_diff_count : 0u; }
+
+int hspf_routes_pack(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes, uint32_t n_mask_words, const hspf_routes *new_dev,
+                     const uint8_t *action_dev, const uint32_t *changed_dev, const uint32_t *changed_ptr_dev,
+                     uint32_t n_records, uint32_t *records_host) {
+  if (!ctx || !new_dev || !action_dev || !changed_dev || !changed_ptr_dev || n_roots == 0 || n_mask_words == 0 ||
+      !new_dev->best_metric || !new_dev->best_entry || !new_dev->nexthop_mask || (n_records && !records_host))
+    return HSPF_E_INVAL;
+  if (n_records == 0) return HSPF_OK;
+  return guarded(ctx, [&]() -> int {
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    const size_t bytes = (size_t)n_records * (ROUTE_REC_WORDS + 2u * n_mask_words) * 4;
+    int rc = ensure(ctx, ctx->pack, bytes);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_routes_pack, dim3((n_records + 255u) / 256u), dim3(256), 0, s, n_records, n_roots, n_prefixes, n_mask_words,
+                       changed_dev, changed_ptr_dev, action_dev, (const uint32_t *)new_dev->best_metric, (const uint32_t *)new_dev->best_entry,
+                       (const uint64_t *)new_dev->nexthop_mask, (uint32_t *)ctx->pack.p);
+    HIPCHK(ctx, hipMemcpyAsync(records_host, ctx->pack.p, bytes, hipMemcpyDeviceToHost, s));      // THE copy of the hand-off
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { ctx->last_error = std::string("k_routes_pack: ") + hipGetErrorString(le); return HSPF_E_HIP; }
+    return HSPF_OK;
+  });
 }
 
 int hspf_ancestors_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,

@@ -2532,6 +2532,31 @@ __global__ __launch_bounds__(256) void k_routes_diff_scatter(size_t count, uint3
   if (flag[i]) changed[pos[i]] = (uint32_t)(i % n_pfx);
 }
 
+// The hand-off of the diff: record k of the stream = the k-th changed (root, prefix) pair in emission
+// order (roots ascending, prefixes ascending inside a root — the order of `changed`).  ROUTE_REC_WORDS + 2 W u32 words:
+// [root, prefix, action, metric, entry, 0 | W mask words (lo, hi)] — everything route_install / route_uninstall put on the
+// ibus per route (holo-isis/src/ibus/tx.rs:35-110, holo-ospf/src/ibus/tx.rs:32-77) short of the addresses, which the host
+// resolves per first-hop slot.  The owning root of position k: the last r with changed_ptr[r] <= k.
+constexpr uint32_t ROUTE_REC_WORDS = 6u;
+__global__ __launch_bounds__(256) void k_routes_pack(uint32_t n_records, uint32_t n_roots, uint32_t n_pfx, uint32_t W,
+                                                     const uint32_t *__restrict__ changed, const uint32_t *__restrict__ changed_ptr,
+                                                     const uint8_t *__restrict__ action, const uint32_t *__restrict__ best_metric,
+                                                     const uint32_t *__restrict__ best_entry, const uint64_t *__restrict__ nexthop_mask,
+                                                     uint32_t *__restrict__ rec) {
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= n_records) return;
+  uint32_t lo = 0, hi = n_roots;                       // changed_ptr[lo] <= k < changed_ptr[hi]
+  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (changed_ptr[mid] <= k) lo = mid; else hi = mid; }
+  const uint32_t p = changed[k];
+  const size_t i = (size_t)lo * n_pfx + p;
+  uint32_t *o = rec + (size_t)k * (ROUTE_REC_WORDS + 2u * W);
+  o[0] = lo; o[1] = p; o[2] = action[i]; o[3] = best_metric[i]; o[4] = best_entry[i]; o[5] = 0u;
+  for (uint32_t w = 0; w < W; ++w) {
+    const uint64_t m = nexthop_mask[i * W + w];
+    o[ROUTE_REC_WORDS + 2u * w] = (uint32_t)m; o[ROUTE_REC_WORDS + 2u * w + 1u] = (uint32_t)(m >> 32);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Ancestor sets over the SPT's parent DAG: what holo-isis answers with a stack DFS over
 // `Vertex.parents` (Spt::is_on_path, holo-isis/src/spf.rs:261-286) for flooding::manet::reflood_list

@@ -301,6 +301,20 @@ class SpfContext:
         if rc != 0:
             raise HspfError(rc, "hspf_routes_diff_device", self.last_error())
 
+    def routes_pack(self, n_roots: int, n_prefixes: int, mask_words: int, new: tuple, *, action_ptr: int, changed_ptr: int,
+                    changed_ptr_ptr: int) -> np.ndarray:
+        """hspf_routes_pack(): the changed (root, prefix) pairs of the last routes_diff_device() as ONE record stream,
+        one device-to-host copy.  Returns [n_records, 6 + 2 W] u32: root, prefix, action, metric, entry, 0, mask words."""
+        k = int(self.lib.hspf_routes_diff_count(self.handle))
+        rec = np.zeros((k, 6 + 2 * mask_words), np.uint32)
+        if k:
+            n = L.HspfRoutes(*new)
+            rc = self.lib.hspf_routes_pack(self.handle, n_roots, n_prefixes, mask_words, ctypes.byref(n), action_ptr, changed_ptr,
+                                           changed_ptr_ptr, k, _u32(rec))
+            if rc != 0:
+                raise HspfError(rc, "hspf_routes_pack", self.last_error())
+        return rec
+
     def close(self):
         if self.handle:
             self.lib.hspf_shutdown(self.handle)

@@ -166,6 +166,137 @@ def compute_spf_device_routes(instance: I.Instance, engine, device="cuda:0") -> 
             for k in sorted(merged)]
 
 
+# ---- the wire step from device tables: diff on the device, ONE packed copy, messages on the host -----
+
+def expand_route_records(records: np.ndarray, prefixes: Sequence[str], slot_nh: Dict[int, object], old_rows: Dict[tuple, dict],
+                         ifindex: Dict[str, int], max_paths: int) -> List[dict]:
+    """The record stream of hspf_routes_pack (one root) -> the RouteIpAdd / RouteIpDel sequence of update_global_rib
+    (holo-isis/src/route.rs:254-312) in the reference's order: installs in prefix order, then the withdrawals of the
+    prefixes that have no route any more.  A record is a CANDIDATE: the device compared metric and first-hop slot
+    masks, which is finer than the reference's comparison of next-hop sets (two slots may resolve to one adjacency; the
+    host truncates to max-paths) — each candidate is confirmed against the old row here, on the few records only."""
+    import ipaddress
+    adds, dels = [], []
+    W = (records.shape[1] - 6) // 2 if len(records) else 0
+    for rec in records:
+        p, action, metric, entry = int(rec[1]), int(rec[2]), int(rec[3]), int(rec[4])
+        prefix = prefixes[p]
+        if action == E.DIFF_WITHDRAW:
+            if entry == 0xFFFFFFFF:
+                dels.append({"op": "del", "prefix": prefix})
+            continue
+        if action != E.DIFF_INSTALL:
+            continue
+        v6 = ":" in prefix
+        nhs = {}
+        for w in range(W):
+            m = int(rec[6 + 2 * w]) | (int(rec[7 + 2 * w]) << 32)
+            while m:
+                b = (m & -m).bit_length() - 1
+                m &= m - 1
+                nh = slot_nh.get(w * 64 + b)
+                if nh is None:
+                    continue
+                addr = nh.ipv6 if v6 else nh.ipv4
+                if addr is not None:
+                    nhs[I._addr_key(addr)] = (addr, nh.iface_name)
+        keep = [nhs[k] for k in sorted(nhs)[:max_paths]]
+        o = old_rows.get(I._net_key(prefix))
+        if o is not None and o["metric"] == metric and sorted(map(tuple, o["nexthops"])) == sorted(keep):
+            continue                                               # the reference's "unchanged" (:268-277)
+        if keep:
+            wire = sorted(((ifindex[ifn], a) for a, ifn in keep),
+                          key=lambda t: (t[0], ipaddress.ip_address(t[1]).version, int(ipaddress.ip_address(t[1]))))
+            adds.append({"op": "add", "prefix": prefix, "metric": metric, "nexthops": [list(t) for t in wire]})
+    return adds + dels
+
+
+def update_global_rib_device(instance: I.Instance, engine, rib_before: List[dict], ifindex: Dict[str, int], device="cuda:0"):
+    """compute_spf + update_global_rib with the SPT, the prefix attachment, the comparison with the previous RIB and the
+    compaction of what changed ALL on the device; one record stream comes back (hspf_routes_pack).  For instances with
+    one (level, topology) table — the shape of every IS-IS step fixture; the L1/L2 merge of a two-level instance is host
+    logic (holo_amd.isis.compute_spf).  Returns (messages, number of records copied, number of prefixes compared)."""
+    import torch
+    cfg = instance.config
+    tabs = [(lv, mt) for lv in cfg.levels() for mt in (I.MT_STANDARD, I.MT_IPV6_UNICAST) if cfg.is_topology_enabled(mt)]
+    if len(tabs) != 1:
+        raise ValueError("update_global_rib_device: one (level, topology) table only")
+    level, mt_id = tabs[0]
+    if level not in instance.lsdb:
+        instance.lsdb[level] = I.Lsdb()
+    old_rows = {I._net_key(r["prefix"]): r for r in rib_before}
+    g = I.LevelGraph(instance, level, mt_id, False)
+    root = g.index.get(I.vertex_id((cfg.system_id, 0)))
+    table = PrefixTable.build(instance, level, mt_id, g) if root is not None else None
+    if root is None or not table.prefixes:
+        # no SPT / nothing advertised: the new RIB is empty and every installed route goes (host, nothing to compare)
+        return I.update_global_rib([], rib_before, ifindex), 0, 0
+    # ONE prefix list for both sides: the table's prefixes plus those only the old RIB knows (no entries: no new route)
+    keys = {I._net_key(p): p for p in table.prefixes}
+    for k, r in old_rows.items():
+        keys.setdefault(k, r["prefix"])
+    order = sorted(keys)
+    prefixes = [keys[k] for k in order]
+    P = len(prefixes)
+    cnt = np.zeros(P + 1, np.uint32)
+    where = {k: i for i, k in enumerate(order)}
+    tpos = [where[I._net_key(p)] for p in table.prefixes]
+    for j, i in enumerate(tpos):
+        cnt[i + 1] = table.pfx_ptr[j + 1] - table.pfx_ptr[j]
+    ptr = np.cumsum(cnt, dtype=np.uint64).astype(np.uint32)           # table.prefixes is sorted the same way: entries keep their order
+    roots = np.asarray([root], np.uint32)
+    n = g.n
+    G = g.device(engine)
+    W = G.mask_words(roots)
+    dev = torch.device(device)
+    dist = torch.empty((1, n), dtype=torch.int32, device=dev); hops = torch.empty((1, n), dtype=torch.int16, device=dev)
+    flags = torch.empty((1, n), dtype=torch.int16, device=dev); mask = torch.empty((1, n, W), dtype=torch.int64, device=dev)
+    engine.run_device(G, roots, g.run_flags, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(), flags_ptr=flags.data_ptr(),
+                      mask_ptr=mask.data_ptr(), mask_words=W)
+    bm = torch.empty((1, P), dtype=torch.int32, device=dev); be = torch.empty((1, P), dtype=torch.int32, device=dev)
+    nm = torch.empty((1, P, W), dtype=torch.int64, device=dev)
+    engine.routes_device(n, 1, W, dist.data_ptr(), flags.data_ptr(), mask.data_ptr(), ptr, table.pfx_vertex, table.pfx_metric,
+                         best_metric_ptr=bm.data_ptr(), best_entry_ptr=be.data_ptr(), nexthop_mask_ptr=nm.data_ptr())
+    # first-hop slots -> next hops (needs Interface / Adjacency objects: host, once per slot)
+    hd, hh = dist.cpu().numpy().view(np.uint32)[0], hops.cpu().numpy().view(np.uint16)[0]
+    hf = flags.cpu().numpy().view(np.uint16)[0]
+    in_spt = (hf & E.RF_IN_SPT) != 0
+    if (hf & E.RF_EXACT).any():
+        pr = engine.run(G, roots, g.run_flags | E.RUN_POP_RANK).pop_rank[0]
+        rank_key = lambda v: (int(pr[v]), 0)                          # noqa: E731
+    else:
+        rank_key = lambda v: (int(hd[v]), v)                          # noqa: E731
+    slot_nh = I._slot_nexthops(g, G, root, hd, hh, in_spt, rank_key, True, level, instance)
+    # the OLD RIB in the same index space: metric, and the slots whose next hop the old route used.  A next hop of the old
+    # route that no slot resolves to any more (its adjacency is gone) cannot be expressed: the metric is poisoned so that
+    # the pair compares unequal and the host decides.
+    om = np.full((1, P), 0xFFFFFFFF, np.uint32); oe = np.full((1, P), 0xFFFFFFFF, np.uint32); on = np.zeros((1, P, W), np.uint64)
+    for k, r in old_rows.items():
+        i = where[k]
+        v6 = ":" in r["prefix"]
+        want = {tuple(nh) for nh in r["nexthops"]}
+        seen = set()
+        for slot, nh in slot_nh.items():
+            addr = nh.ipv6 if v6 else nh.ipv4
+            if addr is not None and (addr, nh.iface_name) in want:
+                on[0, i, slot // 64] |= np.uint64(1) << np.uint64(slot % 64)
+                seen.add((addr, nh.iface_name))
+        # (more next hops than max-paths allows NOW: the new route will be truncated on the host: not comparable by mask)
+        om[0, i] = r["metric"] if seen == want and len(want) <= cfg.max_paths else 0xFFFFFFFE
+        oe[0, i] = 0
+        if want and not on[0, i].any():
+            on[0, i, 0] = np.uint64(1)            # "it was installed with next hops" (the poisoned metric keeps the pair unequal)
+    t_om = torch.from_numpy(om.view(np.int32)).to(dev); t_oe = torch.from_numpy(oe.view(np.int32)).to(dev)
+    t_on = torch.from_numpy(on.view(np.int64)).to(dev)
+    act = torch.empty((1, P), dtype=torch.uint8, device=dev)
+    chg = torch.empty((P,), dtype=torch.int32, device=dev); cptr = torch.empty((2,), dtype=torch.int32, device=dev)
+    new = (bm.data_ptr(), be.data_ptr(), nm.data_ptr())
+    engine.routes_diff_device(1, P, W, (t_om.data_ptr(), t_oe.data_ptr(), t_on.data_ptr()), new,
+                              action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(), changed_ptr_ptr=cptr.data_ptr())
+    rec = engine.routes_pack(1, P, W, new, action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(), changed_ptr_ptr=cptr.data_ptr())
+    return expand_route_records(rec, prefixes, slot_nh, old_rows, ifindex, cfg.max_paths), len(rec), P
+
+
 # ---- OSPFv2: update_rib_intra_area with the prefix attachment on the GPU ---------------------------------------------
 
 @dataclass

@@ -349,6 +349,25 @@ int hspf_routes_diff_device(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes
                             const hspf_routes *old_dev, const hspf_routes *new_dev,
                             uint8_t *action_dev, uint32_t *changed_dev, uint32_t *changed_ptr_dev);
 
+/* ---- the hand-off of the diff (second quarter) ----------------------------------------------------
+ * route_install sends ONE message per route (holo-isis/src/ibus/tx.rs:35-110, holo-ospf/src/ibus/tx.rs:32-77 ->
+ * holo-routing/src/rib.rs:92-135).  hspf_routes_pack turns the changed list of the last hspf_routes_diff_device into ONE
+ * contiguous record stream in the reference's emission order and brings it to the host with ONE copy: what a single
+ * batched RouteIpAdd / RouteIpDel message carries.  Record k (HSPF_ROUTE_REC_WORDS + 2 * n_mask_words u32 words):
+ *     [0] root index   [1] prefix index   [2] action (HSPF_DIFF_INSTALL | HSPF_DIFF_WITHDRAW)   [3] metric of the NEW route
+ *     [4] best_entry of the new route (0xFFFFFFFF: the prefix has no route any more)   [5] 0
+ *     [6 ..] the new route's next-hop mask words, low half first
+ * roots ascending, prefixes ascending inside a root.  The caller expands a record into its message: prefix text from its
+ * own prefix list, next hops = the resolved first-hop slots of the mask (holo_amd.routes.expand_route_records is the twin
+ * that reproduces the reference's recorded RouteIpAdd / RouteIpDel sequence from it).
+ * hspf_routes_diff_count: number of records the last hspf_routes_diff_device left (it came back with that call's own
+ * synchronisation), i.e. n_records and the size of records_host. */
+#define HSPF_ROUTE_REC_WORDS 6u
+uint32_t hspf_routes_diff_count(const hspf_ctx *ctx);
+int hspf_routes_pack(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes, uint32_t n_mask_words, const hspf_routes *new_dev,
+                     const uint8_t *action_dev, const uint32_t *changed_dev, const uint32_t *changed_ptr_dev,
+                     uint32_t n_records, uint32_t *records_host);
+
 /* ---- ancestor sets on device (the queries of flooding::manet::reflood_list) ------------------------
  * For every root of a previous hspf_run_device() and a level L (1 = first hops / remote-neighbour list, 2 = second
  * hops): the root's level-L routers = router vertices of its SPT with hops == L, numbered in ascending vertex index

@@ -311,3 +311,20 @@ def test_routes_diff_device_vs_restatement(spf_ctx, seed):
         assert chg[cptr[r]:cptr[r + 1]].tolist() == want_idx, r
         n_changed += len(want_idx)
     assert cptr[0] == 0 and cptr[Rn] == n_changed and 0 < n_changed < Rn * P
+
+
+ISIS_WIRE = sorted(p for p in glob.glob(os.path.join(GOLD, "isis_steps", "*.json")) if "summary" not in os.path.basename(p))
+
+
+@pytest.mark.parametrize("path", ISIS_WIRE, ids=[os.path.basename(p)[:-5] for p in ISIS_WIRE])
+def test_hand_off_from_device_tables_reproduces_recorded_ibus_messages(spf_ctx, path):
+    """SURVEY.md 8f-4 end to end: SPT, prefix attachment, the comparison with the RIB the reference held BEFORE the step
+    and the compaction of what changed on the device, ONE packed record stream to the host (hspf_routes_pack), expanded
+    into messages — equal to the RouteIpAdd / RouteIpDel sequence the reference recorded on the ibus for the step, in
+    order; and the stream is the changed routes, not the RIB."""
+    vec = json.load(open(path))
+    inst = H.Instance.from_vector(vec)
+    want = [{k: m[k] for k in m if k != "distance"} for m in vec["ibus_routes"]]
+    got, n_rec, n_pfx = RT.update_global_rib_device(inst, spf_ctx, vec["rib_before"], vec["ifindex"])
+    assert got == want
+    assert n_rec <= n_pfx and (n_pfx == 0 or n_rec <= len(want) + 4)
