@@ -25,7 +25,9 @@ def spf_ctx(request, _ctx_pool):
     """Engine contexts shared by the GPU tests of a session.  "default" is the product configuration (small graphs
     take the one-workgroup-per-root kernel, k_single, runs of a few roots on larger ones the lane = vertex kernel, k_lv);
     "sweeps" has both switched off (HSPF_SINGLE_MAX_N=0, HSPF_LV_MAX_ROOTS=0), so that the batched lane = root sweep
-    engine keeps its coverage on the small adversarial graphs of the suite; "twophase" additionally sends runs with more
+    engine keeps its coverage on the small adversarial graphs of the suite — since round 3 that is k_fused_lean wherever
+    its 4-byte state fits, so "kfused" is "sweeps" with the lean sweep off (HSPF_VARIANT bit15): k_fused on both state
+    widths; "twophase" additionally sends runs with more
     than 24 first-hop slots down the older k_relax + k_dag path instead of k_fw (HSPF_VARIANT bit6); "lanevertex" sends
     every run of up to 64 roots (with at most 24 first-hop slots) through k_lv (HSPF_SINGLE_MAX_N=0, HSPF_LV_MAX_ROOTS=64,
     HSPF_LV_MIN_N=0); "hubsort" is the default engine with every graph built in hub mode (HSPF_HUB_DEG=0: two-way check and
@@ -35,6 +37,7 @@ def spf_ctx(request, _ctx_pool):
     if mode not in _ctx_pool:
         from holo_amd.engine import SpfContext
         env = {"sweeps": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0"},
+               "kfused": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "32768"},
                "twophase": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "64"},
                "lanevertex": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "64", "HSPF_LV_MIN_N": "0"},
                "hubsort": {"HSPF_HUB_DEG": "0"}}.get(mode, {})

@@ -564,3 +564,67 @@ def test_giant_rows_are_evaluated_in_slices(spf_ctx, hopcount, run_flags):
         assert np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops) and np.array_equal(res.first_hop_mask, ref.mask)
     finally:
         G.free()
+
+
+# ---- the lean sweep (k_fused_lean): taken where its 4-byte state fits, left cleanly where it does not ------------------
+
+@sweeps_engine
+def test_lean_sweep_is_taken_and_bit_identical(spf_ctx):
+    """The sweep engine on adversarial LSDBs: wherever the run's 4-byte state fits it must be k_fused_lean's
+    (hspf_stats.dbg[0]) and agree with the oracle — rows with odd and even link counts (pad links), more than 16 links,
+    none at all, network vertices, overloaded sources and zero-cost links (the general routine next to the fast one)."""
+    lean = 0
+    for seed in range(10):
+        g = synth.random_lsdb(300, 20, 3.0 + (seed % 3), 4000 + seed, metric_hi=9, zero_cost_router_links=(seed % 4 == 3))
+        roots = np.arange(20, 20 + 64 + seed, dtype=np.uint32)
+        res, _ = check(spf_ctx, g, roots, E.RUN_NET_NEXTHOPS if seed & 1 else 0)
+        if res.stats["state_bytes"] == 4:
+            assert res.stats["dbg"][0] == 1, seed
+            lean += 1
+    assert lean >= 2
+
+
+@sweeps_engine
+def test_lean_sweep_on_grids_with_every_degree(spf_ctx):
+    """8-neighbour grid + chords: in-degrees 3 .. 12+, ties everywhere (costs 1 .. 3): the first-discoverer rule through
+    the tag field, both halves of rows with more than 8 links."""
+    n = 40 * 50
+    links = synth._add_chords(n, synth._grid8_links(40, 50), 9000, 77)
+    g = synth._routers_only(n, links, 78, 1, 3, synth.MAX_PATH_METRIC_WIDE, "grid-ties", {})
+    roots = ((np.arange(100, dtype=np.uint64) * n) // 100).astype(np.uint32)
+    res, _ = check(spf_ctx, g, roots)
+    assert res.stats["dbg"][0] == 1
+
+
+@sweeps_engine
+def test_lean_sweep_overflow_falls_back_to_k_fused_and_the_graph_remembers(spf_ctx):
+    """Distances beyond the lean state's distance field (three bits go to the tag): k_emit_fused raises LF_OVERFLOW on
+    the final words, the run is redone by k_fused with identical results, and the next run on the graph goes there
+    directly."""
+    n = 120
+    a = np.arange(n - 1, dtype=np.int64)
+    links = np.stack([a, a + 1], axis=1)
+    g = synth._routers_only(n, links, 5, 20000, 20000, synth.MAX_PATH_METRIC_WIDE, "long-chain", {})
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        roots = np.array([0, 1, 60, 119], np.uint32)
+        ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 0, go.MAP)
+        for it in range(2):
+            res = spf_ctx.run(G, roots, 0)
+            assert np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops)
+            assert np.array_equal(res.first_hop_mask, ref.mask[:, :, :res.first_hop_mask.shape[2]])
+            assert res.stats["dbg"][0] == 0                      # the results come from k_fused
+        assert int(ref.dist.max()) > (1 << 20)
+    finally:
+        G.free()
+
+
+@sweeps_engine
+def test_lean_sweep_hop_field_saturation_is_an_overflow(spf_ctx):
+    """A chain longer than the hop field: the lean sweep's hop count saturates (no per-row test any more), the final-word
+    check catches it, and the wider states give the oracle's hops."""
+    n = 300
+    a = np.arange(n - 1, dtype=np.int64)
+    g = synth._routers_only(n, np.stack([a, a + 1], axis=1), 6, 1, 2, synth.MAX_PATH_METRIC_WIDE, "deep-chain", {})
+    res, ref = check(spf_ctx, g, np.array([0, 150, 299], np.uint32))
+    assert int(ref.hops.max()) == 299 and res.stats["dbg"][0] == 0
