@@ -139,6 +139,92 @@ def latency_1root(ctx, dev) -> dict:
     return out
 
 
+def pipeline_1root(ctx, dev) -> dict:
+    """What one LSP refresh with changed costs costs end to end for one root on the headline graph (SURVEY.md 8f-1, 8f-2,
+    8f-4 chained): hspf_graph_patch of the router's row -> hspf_run_device -> hspf_routes_device over 120 000 prefixes
+    -> hspf_routes_diff_device against the previous table -> hspf_routes_pack (the changed routes, one copy to the
+    host).  Wall time of the five C calls, median of 20 after 3 warm-ups, alternating between two cost sets; the SPT,
+    the route table and the record stream of the last iteration are checked against the oracle and a numpy fold."""
+    import torch
+    from holo_amd import synth
+    from oracle import graph_oracle as go
+    g = synth.isis_100k()
+    n = g.n
+    rng = np.random.default_rng(12)
+    n2 = 20000                                            # prefixes 0 .. n-1: one owner each; then n2 with two owners
+    two = np.sort(rng.integers(0, n, (n2, 2)), axis=1)
+    two[:, 1] = np.where(two[:, 1] == two[:, 0], (two[:, 0] + 1) % n, two[:, 1]); two.sort(axis=1)
+    vtx = np.concatenate([np.arange(n), two.reshape(-1)]).astype(np.uint32)
+    ptr = np.concatenate([np.arange(n), n + 2 * np.arange(n2 + 1)]).astype(np.uint32)
+    met = np.concatenate([np.arange(n) % 7, rng.integers(0, 10, 2 * n2)]).astype(np.uint32)
+    P = n + n2
+    roots = np.array([0], np.uint32)
+    G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    W = G.mask_words(roots)
+    d = torch.empty((1, n), dtype=torch.int32, device=dev); h = torch.empty((1, n), dtype=torch.int16, device=dev)
+    f = torch.empty((1, n), dtype=torch.int16, device=dev); m = torch.empty((1, n, W), dtype=torch.int64, device=dev)
+    sets = [(torch.empty((1, P), dtype=torch.int32, device=dev), torch.empty((1, P), dtype=torch.int32, device=dev),
+             torch.empty((1, P, W), dtype=torch.int64, device=dev)) for _ in range(2)]
+    act = torch.empty((1, P), dtype=torch.uint8, device=dev); chg = torch.empty((P,), dtype=torch.int32, device=dev)
+    cptr = torch.empty((2,), dtype=torch.int32, device=dev)
+    u = n // 3
+    a, b = int(g.row_ptr[u]), int(g.row_ptr[u + 1])
+    costs = [g.metric[a:b] + 5, g.metric[a:b].copy()]
+    col_u, vf_u = g.col[a:b].copy(), [g.vflags[u]]
+
+    def spt_and_routes(k):
+        ctx.run_device(G, roots, 0, dist_ptr=d.data_ptr(), hops_ptr=h.data_ptr(), flags_ptr=f.data_ptr(), mask_ptr=m.data_ptr(), mask_words=W)
+        ctx.routes_device(n, 1, W, d.data_ptr(), f.data_ptr(), m.data_ptr(), ptr, vtx, met, best_metric_ptr=sets[k][0].data_ptr(),
+                          best_entry_ptr=sets[k][1].data_ptr(), nexthop_mask_ptr=sets[k][2].data_ptr())
+    spt_and_routes(0)
+    cur, stages, rec = 0, [], None
+    for it in range(23):
+        t = [time.perf_counter()]
+        G.patch([u], [(col_u, costs[it & 1])], vf_u); t.append(time.perf_counter())
+        ctx.run_device(G, roots, 0, dist_ptr=d.data_ptr(), hops_ptr=h.data_ptr(), flags_ptr=f.data_ptr(), mask_ptr=m.data_ptr(), mask_words=W)
+        t.append(time.perf_counter())
+        ctx.routes_device(n, 1, W, d.data_ptr(), f.data_ptr(), m.data_ptr(), ptr, vtx, met, best_metric_ptr=sets[cur ^ 1][0].data_ptr(),
+                          best_entry_ptr=sets[cur ^ 1][1].data_ptr(), nexthop_mask_ptr=sets[cur ^ 1][2].data_ptr())
+        t.append(time.perf_counter())
+        ctx.routes_diff_device(1, P, W, tuple(x.data_ptr() for x in sets[cur]), tuple(x.data_ptr() for x in sets[cur ^ 1]),
+                               action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(), changed_ptr_ptr=cptr.data_ptr())
+        t.append(time.perf_counter())
+        rec = ctx.routes_pack(1, P, W, tuple(x.data_ptr() for x in sets[cur ^ 1]), action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(),
+                              changed_ptr_ptr=cptr.data_ptr())
+        t.append(time.perf_counter())
+        stages.append(np.diff(t) * 1e3)
+        cur ^= 1
+    mode = int(G.export("build_mode")[0])
+    # ---- check of the last iteration (it = 22: costs[0], before it costs[1])
+    def fold(metric):
+        ref = go.run(g.row_ptr, g.col, metric, g.vflags, g.max_path_metric, roots, 0, go.HEAP, mask_words_=W)
+        dd = ref.dist[0].astype(np.uint64); reach = (ref.flags[0] & 1) != 0
+        cand = np.where(reach[vtx], (dd[vtx] + met) & 0xFFFFFFFF, np.uint64(1) << 40)
+        bm = np.minimum.reduceat(cand, ptr[:-1].astype(np.int64))
+        tie = cand == np.repeat(bm, np.diff(ptr.astype(np.int64)))
+        mk = np.where(tie[:, None] & reach[vtx][:, None], ref.mask[0][vtx], 0).astype(np.uint64)
+        nh = np.bitwise_or.reduceat(mk, ptr[:-1].astype(np.int64), axis=0)
+        return ref, bm, nh
+    m_new = g.metric.copy(); m_new[a:b] = costs[0]
+    (_, bm_old, nh_old), (ref, bm_new, nh_new) = fold(g.metric), fold(m_new)
+    ok_spt = bool(np.array_equal(d.cpu().numpy().view(np.uint32), ref.dist) and np.array_equal(h.cpu().numpy().view(np.uint16), ref.hops)
+                  and np.array_equal(m.cpu().numpy().view(np.uint64), ref.mask))
+    got_bm = sets[cur][0].cpu().numpy().view(np.uint32)[0]; got_nh = sets[cur][2].cpu().numpy().view(np.uint64)[0]
+    has = bm_new < (1 << 40)
+    ok_routes = bool(np.array_equal(got_bm[has], bm_new[has].astype(np.uint32)) and np.array_equal(got_nh[has], nh_new[has]))
+    want = np.nonzero(((bm_old != bm_new) | (nh_old != nh_new).any(axis=1)) & has & nh_new.any(axis=1))[0]
+    ok_rec = bool(np.array_equal(rec[:, 1], want.astype(np.uint32)) and np.array_equal(rec[:, 3], bm_new[want].astype(np.uint32))
+                  and np.array_equal(rec[:, 6:].copy().view(np.uint64).reshape(len(rec), W), nh_new[want]))
+    G.free()
+    st = np.median(np.array(stages[3:]), axis=0)
+    return {"graph": "isis-100k", "roots": 1, "prefixes": int(P), "prefix_entries": int(len(vtx)), "changed_row": int(u),
+            "wall_ms": round(float(np.median(np.array(stages[3:]).sum(axis=1))), 4),
+            "stages_ms": {k: round(float(v), 4) for k, v in zip(("graph_patch", "run_device", "routes_device", "routes_diff_device", "routes_pack"), st)},
+            "patch_mode": {0: "rebuild", 1: "rebuild (hub)", 2: "costs in place"}[mode], "records_to_host": int(len(rec)),
+            "record_bytes": int(rec.nbytes), "spt_identical_to_oracle": ok_spt, "routes_identical_to_fold": ok_routes,
+            "records_identical_to_fold": ok_rec}
+
+
 def path_of(st) -> str:
     """Which engine path a run took, from its hspf_stats."""
     if st.get("single_wg"):
@@ -461,6 +547,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(g, roots)
             ctx1 = E.SpfContext(local_rank)
             out["latency_1root"] = latency_1root(ctx1, dev)
+            out["pipeline_1root"] = pipeline_1root(ctx1, dev)
             out["configs"] = other_configs(ctx1, dev)
         print(json.dumps(out), flush=True)
 

@@ -53,6 +53,8 @@ struct BuildInfo {       // device-resident summary of one build, copied back on
   uint32_t n_heavy;      // heavy 16-vertex chunks (a row of more than UNIT_HEAVY_DEG in-links): 4 work units each
   uint32_t max_in_deg;   // largest kept in-degree
   uint32_t any_rowflags; // OR of the rows' static flags (RF_*)
+  uint32_t n_zero_rows;  // rows with RF_ZERO
+  uint32_t n_bad_rows;   // rows with an in-link off the hop-count shape (hc_bad != 0 exactly when this is)
 };
 
 constexpr uint32_t HUB_DEG = 512;        // rows with more links than this: hub mode (HSPF_HUB_DEG)
@@ -375,7 +377,8 @@ kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__r
   rowflags[t] = (uint8_t)f;
   atomicMax(&info->max_in_deg, b - a);
   if (f) atomicOr(&info->any_rowflags, f);
-  if (bad) info->hc_bad = 1u;                 // plain stores: every writer stores the same value
+  if (bad) { info->hc_bad = 1u; atomicAdd(&info->n_bad_rows, 1u); }   // plain store: every writer stores the same value
+  if (f & RF_ZERO) atomicAdd(&info->n_zero_rows, 1u);
   if (net && b > a) info->hc_net = 1u;
 }
 
@@ -490,6 +493,93 @@ kb_splice(uint32_t n, uint32_t e_new, const uint32_t *__restrict__ new_row_ptr,
     new_col[k] = old_col[old_row_ptr[u] + off];
     new_metric[k] = old_metric[old_row_ptr[u] + off];
   }
+}
+
+// ---- patch, fast path: the replaced rows list the SAME targets in the same order with the same flags, only costs differ
+// (a metric change: the commonest reason an LSP / LSA is re-originated; holo-isis/src/spf.rs:144, 733-735 `trigger_lsps`).
+// Nothing moves: kept sets, degrees, row bounds, work units and XCD ranges stay; what changes is the cost of the
+// replaced rows' links in the raw CSR, the forward arrays and the in-rows of their targets, whose ORDER (cost descending,
+// source ascending, position ascending) then has to be restored, together with the targets' row flags and ELL records.
+// Work: O(links of the replaced rows x in-degree of their targets), two launches.  The layout equals a fresh upload's.
+struct PatchInfo { uint32_t wmax; uint32_t stale; int32_t d_zero; int32_t d_bad; };
+
+// one workgroup per replaced row b (vertex changed[b]): raw costs and forward costs
+__global__ void __launch_bounds__(256)
+kb_pc_apply(const uint32_t *__restrict__ changed, const uint32_t *__restrict__ dptr, const uint32_t *__restrict__ dmet,
+            const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ metric, const uint32_t *__restrict__ out_ptr,
+            uint32_t *__restrict__ out_w, const uint32_t *__restrict__ out_fpos) {
+  const uint32_t b = blockIdx.x, u = changed[b];
+  const uint32_t d0 = dptr[b], len = dptr[b + 1] - d0, r0 = row_ptr[u];
+  for (uint32_t k = threadIdx.x; k < len; k += 256u) metric[r0 + k] = dmet[d0 + k];
+  for (uint32_t o = out_ptr[u] + threadIdx.x; o < out_ptr[u + 1]; o += 256u) out_w[o] = dmet[d0 + out_fpos[o]];
+}
+
+// one workgroup per affected target (in-degree <= 256): the new costs of its entries (sources looked up in the sorted
+// changed list), their order (cost descending, then source, then position: kb_rank / kb_hub_gather), the row's flags
+// (kb_rowflags) and ELL records (kb_ell), and what the summary of the build needs: largest new cost, whether a link that
+// carried the old maximum got cheaper, and the change in the counts of RF_ZERO rows and of rows off the hop-count shape
+__global__ void __launch_bounds__(256)
+kb_pc_resort(uint32_t n_changed, const uint32_t *__restrict__ changed, const uint32_t *__restrict__ dptr,
+             const uint32_t *__restrict__ dmet, const uint32_t *__restrict__ targets, const uint32_t *__restrict__ in_ptr,
+             uint32_t *__restrict__ in_src, uint32_t *__restrict__ in_w, uint32_t *__restrict__ in_fpos,
+             const uint8_t *__restrict__ vflags, uint8_t *__restrict__ rowflags, uint32_t *__restrict__ ell_so,
+             uint32_t *__restrict__ ell_w, uint32_t giant_deg, uint32_t wmax_old, PatchInfo *__restrict__ pinfo) {
+  __shared__ uint32_t s_src[256], s_w[256], s_pos[256];
+  const uint32_t t = targets[blockIdx.x], a = in_ptr[t], d = in_ptr[t + 1] - a, i = threadIdx.x;
+  const bool row_net = (vflags[t] & HSPF_VF_NETWORK) != 0;
+  uint32_t sraw = 0, w = 0, f = 0, src = 0;
+  bool bad_old = false, bad_new = false, zero_new = false, nt = false;
+  if (i < d) {
+    sraw = in_src[a + i]; w = in_w[a + i]; f = in_fpos[a + i]; src = sraw & SRC_MASK;
+    uint32_t lo = 0, hi = n_changed;                      // first index with changed[index] >= src
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (changed[mid] < src) lo = mid + 1; else hi = mid; }
+    uint32_t wn = w;
+    if (lo < n_changed && changed[lo] == src) {
+      wn = dmet[dptr[lo] + f];
+      atomicMax(&pinfo->wmax, wn);
+      if (w == wmax_old && wn < w) pinfo->stale = 1u;
+    }
+    const bool src_net = (vflags[src] & HSPF_VF_NETWORK) != 0;
+    bad_old = row_net ? !(w == 0u && !src_net && src > t) : w != 1u;
+    bad_new = row_net ? !(wn == 0u && !src_net && src > t) : wn != 1u;
+    zero_new = wn == 0u && src >= t;
+    nt = (sraw & SRC_NO_TRANSIT) != 0u;
+    w = wn;
+    s_src[i] = src; s_w[i] = w; s_pos[i] = f;
+  }
+  __syncthreads();
+  uint32_t rank = 0;
+  if (i < d) {
+    for (uint32_t j = 0; j < d; ++j) {
+      const uint32_t wj = s_w[j], sj = s_src[j], fj = s_pos[j];
+      rank += (wj > w || (wj == w && (sj < src || (sj == src && fj < f)))) ? 1u : 0u;
+    }
+    in_src[a + rank] = sraw; in_w[a + rank] = w; in_fpos[a + rank] = f;
+  }
+  const int any_zero = __syncthreads_or(zero_new ? 1 : 0), any_nt = __syncthreads_or(nt ? 1 : 0);
+  const int any_bad_old = __syncthreads_or(bad_old ? 1 : 0), any_bad_new = __syncthreads_or(bad_new ? 1 : 0);
+  if (i == 0) {
+    const uint32_t was = rowflags[t];
+    const uint32_t fl = (d > 16u ? RF_MANY : 0u) | (d > giant_deg ? RF_GIANT : 0u) | (any_nt ? RF_NT : 0u) | (any_zero ? RF_ZERO : 0u);
+    rowflags[t] = (uint8_t)fl;
+    const int dz = (int)((fl & RF_ZERO) != 0u) - (int)((was & RF_ZERO) != 0u), db = (any_bad_new != 0) - (any_bad_old != 0);
+    if (dz) atomicAdd(&pinfo->d_zero, dz);
+    if (db) atomicAdd(&pinfo->d_bad, db);
+  }
+  if (d <= 16u && i < d) {
+    const uint32_t info = d | (row_net ? 0x80u : 0u) | (ell_so[(size_t)t * 16u] & 0x20u);   // bit 5 (out-links) is untouched
+    ell_so[(size_t)t * 16u + rank] = (src << 8) | (rank == 0u ? info : 0u);
+    ell_w[(size_t)t * 16u + rank] = w;
+  }
+}
+
+// largest kept cost, for the patch that made a link carrying the old maximum cheaper
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_pc_wmax(uint32_t e_kept, const uint32_t *__restrict__ out_w, PatchInfo *__restrict__ pinfo) {
+  uint32_t m = 0;
+  for (uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x; k < e_kept; k += gridDim.x * GB_BLOCK) m = max(m, out_w[k]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63u) == 0u && m) atomicMax(&pinfo->wmax, m);
 }
 
 __global__ void __launch_bounds__(GB_BLOCK)

@@ -69,7 +69,10 @@ struct hspf_graph {
   uint32_t n_heavy_chunks = 0;                                    // > 0: the kernels go through unit_first
   uint64_t build_id = 0;                                          // changes with every device build (upload, patch)
   uint32_t max_in_deg = 0;                                        // largest kept in-degree
+  uint32_t n_zero_rows = 0, n_bad_rows = 0, any_rowflags = 0;    // BuildInfo's counts, kept current by cost patches
+  bool hc_net = false, any_net = false;                           // a network row has a kept in-link / a network vertex exists
   bool hub_built = false;                                         // the last build ran in hub mode (sorted keys)
+  bool costs_only = false;                                        // the last patch changed costs only: nothing was rebuilt
   bool lean = false;                                              // no network vertex, no static row flag, in-degrees <= 8: k_single_lean
   // Carves the arrays out of `base` for n vertices / cap links; returns the bytes needed.
   size_t layout(char *base, uint32_t nv, uint32_t cap) {
@@ -134,6 +137,9 @@ struct hspf_ctx {
   size_t up_len = 0;
   std::vector<uint32_t> mark;      // visited stamps of build_slot_table, kept across calls (no O(n) fill per run)
   uint32_t mark_epoch = 0;
+  uint32_t *h_patch = nullptr;      // pinned staging block of the cost-only patch
+  std::vector<uint32_t> patch_targets;
+  size_t h_patch_cap = 0;           // words
   uint32_t *h_lane_flags = nullptr; // pinned: per-root status bits, then the 256 rows_done words of the fused kernel
   size_t h_lane_cap = 0;
   uint32_t est_relax = 12, est_dag = 12, est_fused = 12, est_fw = 12;   // launch-ahead estimates (adapted run to run)
@@ -265,6 +271,17 @@ void gb_scan(hipStream_t s, const T *in, uint32_t m, uint32_t *out, uint32_t *su
 // flags for the slot tables).  Synchronises the stream once at the end.
 constexpr int HSPF_RETRY_HUB = 1000;    // build_pass -> build_on_device only
 
+// What a build or a cost patch leaves to derive from the counts it brought back.
+void finish_summary(hspf_graph *g) {
+  g->hopcount_like = g->n_bad_rows == 0 && g->hc_net;
+  g->lean = !g->any_net && g->any_rowflags == 0 && g->max_in_deg <= SINGLE_RL && !g->hopcount_like;
+  static std::atomic<uint64_t> next_build{1};
+  g->build_id = next_build.fetch_add(1);
+  g->narrow_bad = false;
+  g->wide24_bad = false;
+  g->lean_bad = false;
+}
+
 int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   const uint32_t n = g->n, e = g->e;
   hipStream_t s = ctx->stream;
@@ -374,6 +391,7 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   }
   g->e_kept = bi.kept;
   g->wmax = bi.wmax;
+  g->hc_net = bi.hc_net != 0; g->n_bad_rows = bi.n_bad_rows; g->n_zero_rows = bi.n_zero_rows; g->any_rowflags = bi.any_rowflags;
   g->hopcount_like = !bi.hc_bad && bi.hc_net;
   {
     uint64_t heavy = 0;                                   // from the host mirror of the caller's rows (out-degrees)
@@ -382,6 +400,7 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   }
   if (!hub && bi.max_in_deg > ctx->hub_deg) return HSPF_RETRY_HUB;     // kb_rank left those rows out
   g->hub_built = hub;
+  g->costs_only = false;
   for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
   g->n_heavy_chunks = bi.n_heavy;
   g->max_in_deg = bi.max_in_deg;
@@ -401,15 +420,9 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
     tab.insert(tab.end(), s0.begin(), s0.end());
     HIPCHK(ctx, hipMemcpy(g->d_giant, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
   }
-  {
-    bool any_net = false;
-    for (uint32_t v = 0; v < n && !any_net; ++v) any_net = (g->vflags[v] & HSPF_VF_NETWORK) != 0;
-    g->lean = !any_net && bi.any_rowflags == 0 && bi.max_in_deg <= SINGLE_RL && !g->hopcount_like;
-  }
-  { static std::atomic<uint64_t> next_build{1}; g->build_id = next_build.fetch_add(1); }
-  g->narrow_bad = false;
-  g->wide24_bad = false;
-  g->lean_bad = false;
+  g->any_net = false;
+  for (uint32_t v = 0; v < n && !g->any_net; ++v) g->any_net = (g->vflags[v] & HSPF_VF_NETWORK) != 0;
+  finish_summary(g);
   return HSPF_OK;
 }
 
@@ -504,6 +517,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
+  if (ctx->h_patch) (void)hipHostFree(ctx->h_patch);
   if (ctx->h_up) (void)hipHostFree(ctx->h_up);
   release(ctx->up);
   if (ctx->h_info) (void)hipHostFree(ctx->h_info);
@@ -602,6 +616,77 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
   }
   (void)hipSetDevice(ctx->device);
   hipStream_t s = ctx->stream;
+  // ---- fast path: every replaced row lists the same targets in the same order with the same flags — only costs differ
+  // (kb_pc_apply / kb_pc_resort, graph_build.hip.h): nothing is rebuilt, no per-link array crosses the bus, the host
+  // mirrors stay as they are.  HSPF_VARIANT bit 16 switches it off (A/B, tests of the rebuild path).
+  if (!(ctx->variant & 65536u) && g->max_in_deg <= 256u && g->n_giant == 0) {
+    bool same = true;
+    for (uint32_t j = 0; j < m && same; ++j) {
+      const uint32_t v = rows->vertex[j], a = g->row_ptr[v], len = g->row_ptr[v + 1] - a;
+      same = rows->row_ptr[j + 1] - rows->row_ptr[j] == len && rows->vflags[j] == g->vflags[v] &&
+             (len == 0 || memcmp(rows->col + rows->row_ptr[j], &g->col[a], (size_t)len * 4) == 0);
+    }
+    if (same) {
+      return guarded(ctx, [&]() -> int {
+        // affected targets: those of the replaced rows' links, each once (dropped links name targets whose rows do not
+        // hold them; such a row is re-ranked into the order it already has)
+        std::vector<uint32_t> &tg = ctx->patch_targets;
+        tg.assign(rows->col, rows->col + de);
+        std::sort(tg.begin(), tg.end());
+        tg.erase(std::unique(tg.begin(), tg.end()), tg.end());
+        const uint32_t nt = (uint32_t)tg.size();
+        // one staging block, one copy: PatchInfo | changed[m] | dptr[m + 1] | dmet[de] | targets[nt]
+        const size_t words = 4 + (size_t)m + (m + 1) + de + nt;
+        int rc = ensure(ctx, ctx->gb_delta, words * 4);
+        if (rc != HSPF_OK) return rc;
+        if (ctx->h_patch_cap < words) {
+          (void)hipStreamSynchronize(s);
+          if (ctx->h_patch) (void)hipHostFree(ctx->h_patch);
+          ctx->h_patch = nullptr; ctx->h_patch_cap = 0;
+          HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_patch, (words + 1024) * 4, hipHostMallocDefault));
+          ctx->h_patch_cap = words + 1024;
+        }
+        uint32_t *h = ctx->h_patch;
+        h[0] = h[1] = h[2] = h[3] = 0;
+        memcpy(h + 4, rows->vertex, (size_t)m * 4);
+        memcpy(h + 4 + m, rows->row_ptr, ((size_t)m + 1) * 4);
+        if (de) memcpy(h + 4 + m + m + 1, rows->metric, (size_t)de * 4);
+        if (nt) memcpy(h + 4 + m + m + 1 + de, tg.data(), (size_t)nt * 4);
+        uint32_t *d = (uint32_t *)ctx->gb_delta.p;
+        PatchInfo *d_pi = (PatchInfo *)d;
+        const uint32_t *d_changed = d + 4, *d_dptr = d_changed + m, *d_dmet = d_dptr + m + 1, *d_tg = d_dmet + de;
+        HIPCHK(ctx, hipMemcpyAsync(d, h, words * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(kb_pc_apply, dim3(m), dim3(256), 0, s, d_changed, d_dptr, d_dmet, (const uint32_t *)g->d_row_ptr[g->cur],
+                           g->d_metric[g->cur], (const uint32_t *)g->d_out_ptr, g->d_out_w, (const uint32_t *)g->d_out_fpos);
+        if (nt)
+          hipLaunchKernelGGL(kb_pc_resort, dim3(nt), dim3(256), 0, s, m, d_changed, d_dptr, d_dmet, d_tg, (const uint32_t *)g->d_in_ptr,
+                             g->d_in_src, g->d_in_w, g->d_in_fpos, (const uint8_t *)g->d_vflags, g->d_rowflags, g->d_ell_so, g->d_ell_w,
+                             GIANT_DEG, g->wmax, d_pi);
+        HIPCHK(ctx, hipMemcpyAsync(h, d_pi, sizeof(PatchInfo), hipMemcpyDeviceToHost, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        PatchInfo pi = *(const PatchInfo *)h;
+        if (pi.stale) {                                        // a link that carried the largest cost got cheaper: look again
+          HIPCHK(ctx, hipMemsetAsync(d_pi, 0, 4, s));
+          if (g->e_kept) hipLaunchKernelGGL(kb_pc_wmax, dim3(std::min<uint32_t>((g->e_kept + GB_BLOCK - 1) / GB_BLOCK, 1024u)), dim3(GB_BLOCK), 0, s,
+                                            g->e_kept, (const uint32_t *)g->d_out_w, d_pi);
+          HIPCHK(ctx, hipMemcpyAsync(h, d_pi, 4, hipMemcpyDeviceToHost, s));
+          HIPCHK(ctx, hipStreamSynchronize(s));
+          g->wmax = h[0];
+        } else {
+          g->wmax = std::max(g->wmax, pi.wmax);
+        }
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { ctx->last_error = std::string("hspf_graph_patch (costs): ") + hipGetErrorString(le); return HSPF_E_HIP; }
+        g->n_zero_rows = (uint32_t)((int64_t)g->n_zero_rows + pi.d_zero);
+        g->n_bad_rows = (uint32_t)((int64_t)g->n_bad_rows + pi.d_bad);
+        g->any_rowflags = (g->any_rowflags & ~RF_ZERO) | (g->n_zero_rows ? RF_ZERO : 0u);
+        finish_summary(g);
+        g->costs_only = true;
+        ctx->prefill.valid = false;
+        return HSPF_OK;
+      });
+    }
+  }
   // New row bounds and the spliced host mirror of col: the rows between two replaced ones keep their
   // contents and stay contiguous, so each such run is one memcpy.
   std::vector<uint32_t> nrp, ncol;
@@ -714,6 +799,10 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
     case HSPF_GX_ROWFLAGS: src = g->d_rowflags; bytes = g->n; break;
     case HSPF_GX_TWOWAY: bytes = g->e; break;                       // host mirror
     case HSPF_GX_BUILD_MODE: bytes = 4; break;                       // host value
+    case HSPF_GX_ELL_SRC: src = g->d_ell_so; bytes = ((size_t)g->n + 1) * 64; break;
+    case HSPF_GX_ELL_COST: src = g->d_ell_w; bytes = ((size_t)g->n + 1) * 64; break;
+    case HSPF_GX_ELL_OUT: src = g->d_ell_od; bytes = ((size_t)g->n + 1) * 64; break;
+    case HSPF_GX_SUMMARY: bytes = 32; break;                         // host values
     case HSPF_GX_UNITS: src = g->d_unit_first; bytes = g->n_heavy_chunks ? ((size_t)g->n_heavy_chunks * 3 + (g->n + 15u) / 16u) * 4 : 0; break;
     default: ctx->last_error = "hspf_graph_export: unknown array"; return HSPF_E_INVAL;
   }
@@ -721,7 +810,12 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
   if (!dst) return HSPF_OK;
   if (cap_bytes < bytes) { ctx->last_error = "hspf_graph_export: buffer too small"; return HSPF_E_INVAL; }
   if (which == HSPF_GX_TWOWAY) { if (bytes) memcpy(dst, g->twoway.data(), bytes); return HSPF_OK; }
-  if (which == HSPF_GX_BUILD_MODE) { const uint32_t m = g->hub_built ? 1u : 0u; memcpy(dst, &m, 4); return HSPF_OK; }
+  if (which == HSPF_GX_BUILD_MODE) { const uint32_t m = g->costs_only ? 2u : g->hub_built ? 1u : 0u; memcpy(dst, &m, 4); return HSPF_OK; }
+  if (which == HSPF_GX_SUMMARY) {
+    const uint32_t v[8] = {g->wmax, g->hopcount_like ? 1u : 0u, g->lean ? 1u : 0u, g->any_rowflags, g->n_zero_rows, g->n_bad_rows, g->max_in_deg, g->e_kept};
+    memcpy(dst, v, 32);
+    return HSPF_OK;
+  }
   (void)hipSetDevice(ctx->device);
   if (bytes) {
     HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));

@@ -109,7 +109,8 @@ class SpfGraph:
           "in_ptr": (4, np.uint32), "in_src": (5, np.uint32), "in_cost": (6, np.uint32), "in_pos": (7, np.uint32),
           "out_ptr": (8, np.uint32), "out_dst": (9, np.uint32), "out_cost": (10, np.uint32),
           "out_pos": (11, np.uint32), "rowflags": (12, np.uint8), "twoway": (13, np.uint8), "units": (14, np.uint32),
-          "build_mode": (15, np.uint32)}
+          "build_mode": (15, np.uint32), "ell_src": (16, np.uint32), "ell_cost": (17, np.uint32),
+          "ell_out": (18, np.uint32), "summary": (19, np.uint32)}
 
     def export(self, name: str) -> np.ndarray:
         """One array of the graph as it sits on the device (hspf_graph_export)."""
@@ -143,8 +144,20 @@ class SpfGraph:
         rc = self.ctx.lib.hspf_graph_patch(self.ctx.handle, self.handle, ctypes.byref(r))
         if rc != 0:
             raise HspfError(rc, "hspf_graph_patch", self.ctx.last_error())
+        lens = self.row_ptr[vs.astype(np.int64) + 1] - self.row_ptr[vs]
+        if np.array_equal(lens, np.diff(rp)):                  # same row lengths: the mirrors change in place
+            if not getattr(self, "_own_mirrors", False):       # the caller's arrays until now: never written through
+                self.col, self.metric, self.vflags = self.col.copy(), self.metric.copy(), self.vflags.copy()
+                self._own_mirrors = True
+            for v, c, m in zip(vs.tolist(), cols, mets):
+                a = int(self.row_ptr[v])
+                self.col[a:a + len(c)] = c
+                self.metric[a:a + len(m)] = m
+            self.vflags[vs] = nf
+            return
         self.row_ptr, self.col, self.metric, self.vflags = splice_rows(
             self.row_ptr, self.col, self.metric, self.vflags, vs, cols, mets, nf)
+        self._own_mirrors = True
 
     def mask_words(self, roots) -> int:
         roots = np.ascontiguousarray(roots, dtype=np.uint32)

@@ -225,7 +225,18 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows);
                                   each class in vertex order, entry = first vertex (| 0x80000000: one row per wave) */
 #define HSPF_GX_BUILD_MODE 15u /* u32 [1]      how the last upload / patch derived the layout: 0 = per-link row scans,
                                   1 = hub mode (a row of more than 512 links: two device-wide sorts, O(log degree) per
-                                  link).  The layout itself does not depend on the mode                             */
+                                  link), 2 = the last patch changed costs only (same targets, order and flags in every
+                                  replaced row): the affected rows were re-ranked in place, nothing was rebuilt.  The
+                                  layout itself does not depend on the mode                                          */
+#define HSPF_GX_ELL_SRC  16u   /* u32 [16(n+1)] fixed-stride copy of the in-rows of at most 16 links: source << 8, the low
+                                  byte of a row's first entry = in-degree (0x1F: more than 16) | more than 16 out-links
+                                  << 5 | network << 7; unused entries name the pad row n                            */
+#define HSPF_GX_ELL_COST 17u   /* u32 [16(n+1)] their costs (unused entries 0)                                       */
+#define HSPF_GX_ELL_OUT  18u   /* u32 [16(n+1)] out-neighbour j << 2 (unused entries 0xFFFFFFFF)                     */
+#define HSPF_GX_SUMMARY  19u   /* u32 [8]      what a build derives from the links and a patch must keep current:
+                                  largest kept cost, hop-count shape (0/1), smallest-graph kernel allowed (0/1), OR of
+                                  the row flags, rows with a zero-cost link from a higher-numbered source, rows off the
+                                  hop-count shape, largest in-degree, kept links                                     */
 int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *dst, size_t cap_bytes,
                       size_t *out_bytes);
 

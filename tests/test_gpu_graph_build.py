@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 BUILT = ("twoway", "in_ptr", "in_src", "in_cost", "in_pos", "out_ptr", "out_dst", "out_cost", "out_pos", "rowflags", "units")
 RAW = ("row_ptr", "col", "metric", "vflags")
+DERIVED = ("ell_src", "ell_cost", "ell_out", "summary")      # no restatement: compared patched against fresh
 
 
 def assert_layout(G, g):
@@ -238,13 +239,94 @@ def test_patch_equals_fresh_upload(spf_ctx, seed):
             g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
             F = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
             try:
-                for name in BUILT + RAW:
+                for name in BUILT + RAW + DERIVED:
                     assert np.array_equal(G.export(name), F.export(name)), (rnd, name)
                 assert G.n_edges_kept == F.n_edges_kept
             finally:
                 F.free()
             assert_layout(G, g)
             check_spf(spf_ctx, G, g, roots, E.RUN_NET_NEXTHOPS)
+    finally:
+        G.free()
+
+
+def cost_rows(g, rng, k, lo, hi):
+    """k rows with the same targets, order and flags and new costs in [lo, hi] (links into a network keep theirs
+    with probability 1/2, so ties and zero costs stay around)."""
+    vs = np.sort(rng.choice(g.n, size=min(k, g.n), replace=False))
+    rows = []
+    for v in vs.tolist():
+        c = g.col[g.row_ptr[v]:g.row_ptr[v + 1]].copy()
+        m = g.metric[g.row_ptr[v]:g.row_ptr[v + 1]].copy()
+        m = np.where(rng.random(len(m)) < 0.6, rng.integers(lo, hi + 1, len(m)), m).astype(np.uint32)
+        rows.append((c, m))
+    return vs, rows, g.vflags[vs].copy()
+
+
+def cost_graphs():
+    yield synth.random_lsdb(70, 9, 3.0, 900, metric_hi=6), 0, 6
+    yield synth.random_lsdb(90, 10, 2.5, 901, metric_hi=3, p_oneway=0.3, p_parallel=0.4, p_noexpand=0.2, p_overload=0.3), 0, 3
+    yield synth.random_lsdb(300, 20, 4.0, 902, metric_hi=2, zero_cost_router_links=True), 0, 2
+    yield synth.random_lsdb(50, 8, 2.5, 903, hopcount=True), 0, 1
+    yield synth.random_lsdb(40, 1, 3.0, 904, lan_size=40), 1, 9          # rows of more than 16 links
+    yield synth.random_lsdb(200, 0, 4.0, 905, metric_hi=60), 1, 1000      # routers only: the largest cost moves up and down
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_cost_only_patch_equals_fresh_upload(spf_ctx, i):
+    """Rows replaced with the same targets and new costs take the in-place path (build mode 2: nothing rebuilt, no
+    per-link array uploaded) and leave every device array and every derived value as a fresh upload of the patched
+    CSR has them — also when the change moves the hop-count shape, the RF_ZERO rows or the largest cost."""
+    g, lo, hi = list(cost_graphs())[i]
+    rng = np.random.default_rng(40 + i)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    nn = g.meta.get("n_networks", 0)
+    roots = np.arange(nn, nn + min(40, g.n - nn), dtype=np.uint32)
+    try:
+        for rnd in range(6):
+            if rnd == 4:                                      # 0 into a network, 1 into a router: the largest cost shrinks, hop-count shape returns
+                vs = np.arange(g.n)
+                rows = [(g.col[g.row_ptr[v]:g.row_ptr[v + 1]],
+                         (g.col[g.row_ptr[v]:g.row_ptr[v + 1]] >= nn).astype(np.uint32)) for v in vs]
+                flags = g.vflags.copy()
+            else:
+                vs, rows, flags = cost_rows(g, rng, [1, 3, 10, g.n, 1, 2][rnd], lo, hi)
+            G.patch(vs, rows, flags)
+            assert int(G.export("build_mode")[0]) == 2, rnd
+            g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
+            F = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+            try:
+                for name in BUILT + RAW + DERIVED:
+                    assert np.array_equal(G.export(name), F.export(name)), (rnd, name)
+            finally:
+                F.free()
+            assert_layout(G, g)
+            check_spf(spf_ctx, G, g, roots, E.RUN_NET_NEXTHOPS)
+    finally:
+        G.free()
+
+
+def test_cost_only_patch_full_size(spf_ctx):
+    """isis-100k: one router's costs change (the headline's incremental update); arrays as a fresh upload has them,
+    results equal, and the lean sweep still takes the run."""
+    g = synth.isis_100k()
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    roots = (np.arange(64, dtype=np.uint64) * g.n // 64).astype(np.uint32)
+    rng = np.random.default_rng(3)
+    try:
+        for u in (5000, 0, g.n - 1):
+            a, b = int(g.row_ptr[u]), int(g.row_ptr[u + 1])
+            G.patch([u], [(g.col[a:b], rng.integers(1, 101, b - a).astype(np.uint32))], [g.vflags[u]])
+            assert int(G.export("build_mode")[0]) == 2
+        F = spf_ctx.upload(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
+        try:
+            for name in BUILT + RAW + DERIVED:
+                assert np.array_equal(G.export(name), F.export(name)), name
+            r1, r2 = spf_ctx.run(G, roots), spf_ctx.run(F, roots)
+            for f in ("dist", "hops", "flags", "first_hop_mask"):
+                assert np.array_equal(getattr(r1, f), getattr(r2, f)), f
+        finally:
+            F.free()
     finally:
         G.free()
 

@@ -51,8 +51,18 @@ def main():
         r = L.HspfRows(1, vs.ctypes.data_as(L.u32p), rp.ctypes.data_as(L.u32p), col.ctypes.data_as(L.u32p),
                        met.ctypes.data_as(L.u32p), vf.ctypes.data_as(L.u8p))
         t_patch_c = med(lambda: ctx.lib.hspf_graph_patch(ctx.handle, G.handle, ctypes.byref(r)), 20)
+        mode = int(G.export("build_mode")[0])                   # 2: costs changed in place, nothing rebuilt
+        # a structural change: the row loses its last link and gets it back (splice + rebuild)
+        srows = [(g.col[a:b - 1], g.metric[a:b - 1])], [(g.col[a:b], g.metric[a:b])]
+        sstate = [0]
+
+        def spatch():
+            G.patch([u], srows[sstate[0] & 1], [g.vflags[u]]); sstate[0] += 1
+        spatch(); spatch()
+        t_spatch = med(spatch, 10)
         print(json.dumps({"graph": name, "n": g.n, "e": g.e, "upload_ms": round(t_up, 3),
-                          "patch_1_row_ms": round(t_patch_c, 3), "patch_1_row_with_numpy_mirror_ms": round(t_patch, 3)}))
+                          "patch_1_row_ms": round(t_patch_c, 3), "patch_1_row_with_numpy_mirror_ms": round(t_patch, 3),
+                          "patch_1_row_mode": mode, "patch_1_row_structural_with_numpy_mirror_ms": round(t_spatch, 3)}))
         G.free()
 
 
