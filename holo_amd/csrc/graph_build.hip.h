@@ -55,6 +55,7 @@ struct BuildInfo {       // device-resident summary of one build, copied back on
   uint32_t any_rowflags; // OR of the rows' static flags (RF_*)
   uint32_t n_zero_rows;  // rows with RF_ZERO
   uint32_t n_bad_rows;   // rows with an in-link off the hop-count shape (hc_bad != 0 exactly when this is)
+  uint32_t n_leaf;       // leaves (GraphDev::leaf)
 };
 
 constexpr uint32_t HUB_DEG = 512;        // rows with more links than this: hub mode (HSPF_HUB_DEG)
@@ -428,6 +429,28 @@ __global__ void kb_xcd(uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInf
     if (cost(mid) >= want) hi = mid; else lo = mid + 1;
   }
   info->xcd_start[x] = x == 8u ? nb : lo;
+}
+
+// Leaves (GraphDev::leaf): exactly one kept in-link, and the kept out-links (at most one) lead back to its source.
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_leaf_mark(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ in_src,
+             const uint32_t *__restrict__ out_ptr, const uint32_t *__restrict__ out_dst, uint8_t *__restrict__ leaf,
+             BuildInfo *__restrict__ info) {
+  const uint32_t v = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (v >= n) return;
+  const uint32_t e0 = in_ptr[v], o0 = out_ptr[v], od = out_ptr[v + 1] - o0;
+  const bool is = in_ptr[v + 1] - e0 == 1u && (od == 0u || (od == 1u && out_dst[o0] == (in_src[e0] & SRC_MASK)));
+  leaf[v] = is ? 1u : 0u;
+  if (is) atomicAdd(&info->n_leaf, 1u);
+}
+
+// ... and SRC_LEAF on every link that comes from one
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_leaf_links(uint32_t e, const BuildInfo *__restrict__ info, uint32_t *__restrict__ in_src, const uint8_t *__restrict__ leaf) {
+  const uint32_t i = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (i >= e || i >= info->kept) return;
+  const uint32_t s = in_src[i];
+  if (leaf[s & SRC_MASK]) in_src[i] = s | SRC_LEAF;
 }
 
 // Fixed-stride (ELL) copy of the link records for k_fused_lean: 16 entries per vertex, rows 0 .. n (row n = all pad).

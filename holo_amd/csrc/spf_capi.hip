@@ -61,7 +61,8 @@ struct hspf_graph {
   uint32_t *d_row_ptr[2] = {}, *d_col[2] = {}, *d_metric[2] = {};  // caller's CSR (ping-pong for patches)
   uint32_t *d_in_ptr = nullptr, *d_in_src = nullptr, *d_in_w = nullptr, *d_in_fpos = nullptr;
   uint32_t *d_out_ptr = nullptr, *d_out_dst = nullptr, *d_out_w = nullptr, *d_out_fpos = nullptr;
-  uint8_t *d_vflags = nullptr, *d_rowflags = nullptr;
+  uint8_t *d_vflags = nullptr, *d_rowflags = nullptr, *d_leaf = nullptr;   // d_leaf: GraphDev::leaf
+  uint32_t n_leaf = 0;
   uint32_t *d_unit_first = nullptr;                               // work units (GraphDev::unit_first), n / 4 + 4 entries
   uint32_t *d_giant = nullptr;                                    // giant rows: vertex list [n_giant] | first slices [n_giant + 1]
   uint32_t *d_ell_so = nullptr, *d_ell_w = nullptr, *d_ell_od = nullptr;   // fixed-stride link records of k_fused_lean (kb_ell): 16 per vertex, rows 0 .. n
@@ -85,7 +86,7 @@ struct hspf_graph {
     d_in_ptr = (uint32_t *)carve(vb); d_out_ptr = (uint32_t *)carve(vb);
     d_in_src = (uint32_t *)carve(lb); d_in_w = (uint32_t *)carve(lb); d_in_fpos = (uint32_t *)carve(lb);
     d_out_dst = (uint32_t *)carve(lb); d_out_w = (uint32_t *)carve(lb); d_out_fpos = (uint32_t *)carve(lb);
-    d_vflags = (uint8_t *)carve(nv); d_rowflags = (uint8_t *)carve(nv);
+    d_vflags = (uint8_t *)carve(nv); d_rowflags = (uint8_t *)carve(nv); d_leaf = (uint8_t *)carve(nv);
     d_unit_first = (uint32_t *)carve((size_t(nv) / 4 + 8) * 4);
     d_giant = (uint32_t *)carve((size_t(cap) / (GIANT_DEG / 2) + 8) * 4);
     d_ell_so = (uint32_t *)carve((size_t(nv) + 1) * 64); d_ell_w = (uint32_t *)carve((size_t(nv) + 1) * 64); d_ell_od = (uint32_t *)carve((size_t(nv) + 1) * 64);
@@ -95,7 +96,7 @@ struct hspf_graph {
     GraphDev g;
     g.n = n; g.e_in = e_kept;
     g.in_ptr = d_in_ptr; g.in_src = d_in_src; g.in_w = d_in_w; g.in_fpos = d_in_fpos;
-    g.vflags = d_vflags; g.rowflags = d_rowflags;
+    g.vflags = d_vflags; g.rowflags = d_rowflags; g.leaf = d_leaf;
     g.out_ptr = d_out_ptr; g.out_dst = d_out_dst; g.out_w = d_out_w; g.out_fpos = d_out_fpos;
     for (int x = 0; x < 9; ++x) g.xcd_start[x] = xcd_start[x];
     g.unit_first = n_heavy_chunks ? d_unit_first : nullptr;
@@ -253,8 +254,9 @@ void launch_dag(dim3 grid, hipStream_t s, GraphDev g, const uint32_t *dist, uint
 }
 template <int W>
 void launch_emit(dim3 grid, hipStream_t s, uint32_t n, uint32_t nr, const uint32_t *dist, const uint32_t *hv,
-                 const uint64_t *mask, OutDev o) {
-  hipLaunchKernelGGL((k_emit<W>), grid, dim3(256), 0, s, n, nr, dist, hv, mask, o);
+                 const uint64_t *mask, OutDev o, bool leaves, EmitLeaf el) {
+  if (leaves) hipLaunchKernelGGL((k_emit<W, true>), grid, dim3(256), 0, s, n, nr, dist, hv, mask, o, el);
+  else hipLaunchKernelGGL((k_emit<W, false>), grid, dim3(256), 0, s, n, nr, dist, hv, mask, o, el);
 }
 
 // Exclusive prefix sums of in[0..m) into out[0..m], out[m] = total (graph_build.hip.h).
@@ -363,6 +365,9 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   }
   hipLaunchKernelGGL(kb_rowflags, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
                      (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info, GIANT_DEG);
+  hipLaunchKernelGGL(kb_leaf_mark, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
+                     (const uint32_t *)g->d_out_ptr, (const uint32_t *)g->d_out_dst, g->d_leaf, info);
+  if (e) hipLaunchKernelGGL(kb_leaf_links, ge, dim3(GB_BLOCK), 0, s, e, (const BuildInfo *)info, g->d_in_src, (const uint8_t *)g->d_leaf);
   hipLaunchKernelGGL(kb_ell, dim3((uint32_t)((((size_t)n + 1) * 16 + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr,
                      (const uint32_t *)g->d_in_src, (const uint32_t *)g->d_in_w, (const uint32_t *)g->d_out_ptr, (const uint32_t *)g->d_out_dst,
                      (const uint8_t *)g->d_vflags, g->d_ell_so, g->d_ell_w, g->d_ell_od);
@@ -404,6 +409,7 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
   g->n_heavy_chunks = bi.n_heavy;
   g->max_in_deg = bi.max_in_deg;
+  g->n_leaf = bi.n_leaf;
   g->n_giant = 0; g->n_giant_slices = 0;
   if (bi.max_in_deg > GIANT_DEG) {
     // giant rows (GraphDev::giant_vtx): a rare shape, so the in-row bounds simply come back once and the two small
@@ -803,6 +809,7 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
     case HSPF_GX_ELL_COST: src = g->d_ell_w; bytes = ((size_t)g->n + 1) * 64; break;
     case HSPF_GX_ELL_OUT: src = g->d_ell_od; bytes = ((size_t)g->n + 1) * 64; break;
     case HSPF_GX_SUMMARY: bytes = 32; break;                         // host values
+    case HSPF_GX_LEAF: src = g->d_leaf; bytes = g->n; break;
     case HSPF_GX_UNITS: src = g->d_unit_first; bytes = g->n_heavy_chunks ? ((size_t)g->n_heavy_chunks * 3 + (g->n + 15u) / 16u) * 4 : 0; break;
     default: ctx->last_error = "hspf_graph_export: unknown array"; return HSPF_E_INVAL;
   }
@@ -1103,10 +1110,27 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   }
   uint64_t *d_st = (uint64_t *)ctx->st64.p;
   uint32_t *d_stamp = (uint32_t *)ctx->stamp.p;
+  // Wide masks: k_fw unless the graph is hop-count-like with more than 4 mask words or HSPF_VARIANT bit6 asks for the
+  // two-phase path (see below).  Leaves (GraphDev::leaf) stay out of k_fw's fixed point and are derived in the emit,
+  // when there are any and neither the saturating-distance nor the hop-count instantiation is needed (HSPF_VARIANT
+  // bit17: leaves take part like any row).
+  const bool use_fw = !fused && !(ctx->variant & 64u) && (!g->hopcount_like || W <= 4);
+  const bool defer = use_fw && g->n_leaf != 0 && g->max_path_metric != HSPF_DIST_INF && !g->hopcount_like && !(ctx->variant & 131072u);
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
   if (fused) {
     // state / stamps / status bits are initialised by fused_run (it may run twice: narrow, then wide), lv_run or the
     // one-workgroup path
+  } else if (defer) {
+    // k_fw with the leaves left to the emit: only the rows that take part are filled (distance, hops AND masks)
+    HIPCHK(ctx, hipMemsetAsync(d_lf, 0, (size_t)L * 4, s));
+    const dim3 ig((unsigned)std::min<size_t>((rows / 64 + 3) / 4, 8192));
+    switch (W) {
+      case 1: hipLaunchKernelGGL(k_init_fw_state<1>, ig, dim3(256), 0, s, n, B, (const uint8_t *)g->d_leaf, d_dist, d_hv, d_mask); break;
+      case 2: hipLaunchKernelGGL(k_init_fw_state<2>, ig, dim3(256), 0, s, n, B, (const uint8_t *)g->d_leaf, d_dist, d_hv, d_mask); break;
+      case 4: hipLaunchKernelGGL(k_init_fw_state<4>, ig, dim3(256), 0, s, n, B, (const uint8_t *)g->d_leaf, d_dist, d_hv, d_mask); break;
+      case 8: hipLaunchKernelGGL(k_init_fw_state<8>, ig, dim3(256), 0, s, n, B, (const uint8_t *)g->d_leaf, d_dist, d_hv, d_mask); break;
+      default: hipLaunchKernelGGL(k_init_fw_state<16>, ig, dim3(256), 0, s, n, B, (const uint8_t *)g->d_leaf, d_dist, d_hv, d_mask); break;
+    }
   } else {
     HIPCHK(ctx, hipMemsetAsync(d_lf, 0, (size_t)L * 4, s));
     HIPCHK(ctx, hipMemsetAsync(d_dist, 0xFF, rows * 4, s));
@@ -1396,10 +1420,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // it is, except for hop-count-like graphs with more than 4 mask words (the plateau rule doubles k_fw's mask
   // registers) and when HSPF_VARIANT bit6 asks for the two-phase path (kept: it is the independent second implementation
   // the "twophase" configuration of the GPU suite runs).
-  const bool use_fw = !(ctx->variant & 64u) && (!g->hopcount_like || W <= 4);
   if (use_fw) {
     const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
-    HIPCHK(ctx, hipMemsetAsync(d_mask, 0, rows * 8 * W, s));
+    if (!defer) HIPCHK(ctx, hipMemsetAsync(d_mask, 0, rows * 8 * W, s));
+    if (defer) st.dbg[1] = 1;                                    // hspf_stats::dbg[1]: the leaves were left to the emit
     HIPCHK(ctx, hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s));
     hipLaunchKernelGGL(k_init_fw, dim3((L + 255) / 256), dim3(256), 0, s, gd, d_dist, d_stamp, d_roots, L);
     if (giant) HIPCHK(ctx, hipMemsetAsync(ctx->giant_part.p, 0, giant_tags * 4, s));
@@ -1410,10 +1434,11 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 #define HSPF_FWG(W_, MI_, HC_) hipLaunchKernelGGL((k_fw_giant_part<W_, MI_, HC_>), ggrid, dim3(256), 0, s, d_fg, (const uint32_t *)d_dist, (const uint32_t *)d_hv, (const uint64_t *)d_mask, (const uint32_t *)d_stamp, (const uint32_t *)d_roots, net_nh, ignore_ovl, (const int *)d_changed, (int)sweep)
 #define HSPF_FW(W_) do { \
       if (giant) { if (hcl) { if (mi) HSPF_FWG((W_ <= 4 ? W_ : 1), true, true); else HSPF_FWG((W_ <= 4 ? W_ : 1), false, true); } \
-                   else     { if (mi) HSPF_FWG(W_, true, false); else HSPF_FWG(W_, false, false); } } \
+                   else     { if (mi) HSPF_FWG(W_, true, false); else if (defer) hipLaunchKernelGGL((k_fw_giant_part<W_, false, false, true>), ggrid, dim3(256), 0, s, d_fg, (const uint32_t *)d_dist, (const uint32_t *)d_hv, (const uint64_t *)d_mask, (const uint32_t *)d_stamp, (const uint32_t *)d_roots, net_nh, ignore_ovl, (const int *)d_changed, (int)sweep); else HSPF_FWG(W_, false, false); } } \
       if (hcl) { if (mi) hipLaunchKernelGGL((k_fw<(W_ <= 4 ? W_ : 1), true, true>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); \
                  else    hipLaunchKernelGGL((k_fw<(W_ <= 4 ? W_ : 1), false, true>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); } \
       else     { if (mi) hipLaunchKernelGGL((k_fw<W_, true, false>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); \
+                 else if (defer) hipLaunchKernelGGL((k_fw<W_, false, false, true>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); \
                  else    hipLaunchKernelGGL((k_fw<W_, false, false>), grid, dim3(256), 0, s, d_fg, d_dist, d_hv, d_mask, d_stamp, d_roots, g->max_path_metric, net_nh, ignore_ovl, d_changed, (int)sweep, d_lf); } } while (0)
       switch (W) {
         case 1: HSPF_FW(1); break;
@@ -1470,13 +1495,14 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   }
   // ---- emit row-major results
   {
-    const dim3 egrid((n + 63) / 64, B);
+    const dim3 egrid((n + 63) / 64, B, 1 + W);
+    const EmitLeaf el{(const FusedGraph *)(d_up + w_fg), d_roots, g->max_path_metric, net_nh, ignore_ovl};
     switch (W) {
-      case 1: launch_emit<1>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
-      case 2: launch_emit<2>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
-      case 4: launch_emit<4>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
-      case 8: launch_emit<8>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
-      default: launch_emit<16>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od); break;
+      case 1: launch_emit<1>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od, defer, el); break;
+      case 2: launch_emit<2>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od, defer, el); break;
+      case 4: launch_emit<4>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od, defer, el); break;
+      case 8: launch_emit<8>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od, defer, el); break;
+      default: launch_emit<16>(egrid, s, n, n_roots, d_dist, d_hv, d_mask, od, defer, el); break;
     }
   }
 
@@ -1622,6 +1648,7 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
     acc.state_bytes = std::max(acc.state_bytes, p.state_bytes); acc.narrow_overflow += p.narrow_overflow;
     acc.rows_recomputed += p.rows_recomputed;
+    acc.dbg[0] |= p.dbg[0]; acc.dbg[1] |= p.dbg[1]; acc.dbg[2] += p.dbg[2]; acc.dbg[3] += p.dbg[3];
   }
   if (host_out) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));

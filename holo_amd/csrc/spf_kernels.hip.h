@@ -29,7 +29,8 @@ namespace hspf {
 
 constexpr uint32_t INF = 0xFFFFFFFFu;
 constexpr uint32_t SRC_NO_TRANSIT = 0x80000000u;   // bit31 of in_src: source has the overload bit
-constexpr uint32_t SRC_MASK = 0x7FFFFFFFu;
+constexpr uint32_t SRC_LEAF = 0x40000000u;         // bit30 of in_src: source is a leaf (GraphDev::leaf); read by k_fw<.., LEAF> only
+constexpr uint32_t SRC_MASK = 0x3FFFFFFFu;
 
 // hv word: [15:0] hops, [31:16] epoch.  epoch == 0: not final yet; epoch == e: became final in the
 // DAG launch with epoch e.  A reader in launch E only trusts rows with 0 < epoch < E, i.e. rows
@@ -56,6 +57,11 @@ struct GraphDev {
   const uint32_t *in_fpos;  // [e_in] position of the link inside its source row (for slots)
   const uint8_t *vflags;    // [n]
   const uint8_t *rowflags;  // [n] RF_* : static reasons why a row needs the general fused routine
+  // Leaves: a vertex with exactly one kept in-link whose kept out-links (at most one) lead back to that link's source — a
+  // single-homed host, a stub LAN's pseudonode.  No shortest path runs THROUGH a leaf, so it takes no part in the fixed
+  // point: its row is evaluated once, from its neighbour's final state, inside the emit (k_emit<W, true>), and a link
+  // FROM a leaf only counts in the lane whose root the leaf is (k_fw<.., LEAF>).  The definition does not depend on costs.
+  const uint8_t *leaf;      // [n] 1 = leaf
   // forward CSR (kept links only) for k_exact
   const uint32_t *out_ptr;  // [n+1]
   const uint32_t *out_dst;  // [e_in]
@@ -1910,57 +1916,178 @@ __global__ void k_rebase(uint32_t *hv, size_t count) {
 // Emit: lane-major state -> row-major results.  One block = 64 vertices x 64 roots of one batch.
 // grid = (ceil(n/64), n_batches), block = 256.
 
+// k_fw<.., LEAF>: "not reached" in the rows that take part (the leaves' rows are never read or written: on a fat-tree
+// with single-homed hosts that is 95 % of the 800 MB the three fills of the other path write).
 template <int W>
+__global__ __launch_bounds__(256) void k_init_fw_state(uint32_t n, uint32_t n_batches, const uint8_t *__restrict__ leaf,
+                                                       uint32_t *__restrict__ dist, uint32_t *__restrict__ hv, uint64_t *__restrict__ mask) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const size_t rows = (size_t)n * n_batches;
+  for (size_t r = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6); r < rows; r += (size_t)gridDim.x * 4u) {
+    if (leaf[r % n]) continue;
+    dist[r * 64 + lane] = INF;
+    hv[r * 64 + lane] = 0u;
+#pragma unroll
+    for (int q = 0; q < W; ++q) mask[(r * W + q) * 64 + lane] = 0ull;
+  }
+}
+
+// The row of a leaf v (one in-link, from u): what k_fw's visit of the row would store — fw_chunk over that one link,
+// then the finish — from u's FINAL triple (d_in, h_in, mu = word q of its mask; not read when u is a leaf itself).  The
+// zero-cost rule of fused_row_any (a zero-cost link from a higher-numbered source is left to the sequential kernel)
+// guards the order in which several tight parents were found; one link has no order to guard, so it is taken as it is.
+template <int W, bool WANTMASK>
+__device__ __forceinline__ void fw_leaf_apply(const FusedGraph *__restrict__ gp, uint32_t v, uint32_t sraw, uint32_t w, uint32_t fpos,
+                                              uint32_t v_router, uint32_t d_in, uint32_t h_in, uint64_t mu, uint32_t q,
+                                              uint32_t my_root, uint32_t root_slot, uint32_t maxpath, uint32_t net_nexthops,
+                                              uint32_t ignore_ovl, uint32_t &nd, uint32_t &nh, uint64_t &nm) {
+  const uint32_t u = sraw & SRC_MASK;
+  uint32_t d = d_in, hh = h_in & 0xFFFFu;
+  if (sraw & SRC_LEAF) { d = (u == my_root) ? 0u : INF; hh = 0u; mu = 0ull; }   // the neighbour is a leaf itself (a two-vertex component)
+  if (!ignore_ovl && (sraw & SRC_NO_TRANSIT) && u != my_root) d = INF;           // overloaded source
+  const uint32_t c = add_sat(d, w);
+  nd = (v == my_root) ? 0u : ((c == INF || c > maxpath) ? INF : c);
+  const bool live = v != my_root && nd != INF;
+  nh = live ? min(hh + v_router, 0xFFFFu) : 0u;
+  nm = 0ull;
+  if (WANTMASK) {
+    nm = (live && hh != 0u) ? mu : 0ull;
+    if (__ballot(live && hh == 0u) != 0ull) {                                     // parent: root or hops-0 network -> the link's own slot
+      if (live && hh == 0u) {
+        const uint32_t base_s = (u == my_root) ? 0u : slot_base_of(gp->tabs, root_slot, u);
+        const uint32_t sidx = base_s + fpos;
+        const bool on = (v_router || net_nexthops) && sidx < (uint32_t)W * 64u;
+        nm = (on && (sidx >> 6) == q) ? (1ull << (sidx & 63u)) : 0ull;
+      }
+    }
+  }
+}
+
+// LEAF: the rows of leaves (GraphDev::leaf) were left out of the fixed point; their triples are derived here, per lane,
+// from the neighbour's final one (fw_leaf_row) on the way into the transposition tile — once per pass (distance, hops,
+// each mask word): the neighbour's row is shared by all the leaves behind it and stays in L1 / L2, so deriving again
+// is cheaper than holding 2 + 2 W values per vertex across the passes.
+struct EmitLeaf {
+  const FusedGraph *gp;
+  const uint32_t *roots;
+  uint32_t maxpath, net_nexthops, ignore_ovl;
+};
+
+// grid = (ceil(n / 64), batches, 1 + W), independent blocks instead of passes of one block (a block that walked distance,
+// hops and every mask word one after the other, two barriers each, wrote 321 MB in 325 us):
+//   z == 0      distances, in-SPT flags and hops of 64 vertices x 64 roots
+//   z == 1 + s  ALL W mask words of the 64 / W vertices v0 + s * 64 / W ..: tile row l = (vertex l / W, word l % W), so
+//               that a root's 64 values are one contiguous 512-byte run of its output row (a block per mask word wrote
+//               every other 8 bytes of it)
+template <int W, bool LEAF>
 __global__ __launch_bounds__(256) void k_emit(uint32_t n, uint32_t n_roots,
                                               const uint32_t *__restrict__ dist,
                                               const uint32_t *__restrict__ hv,
-                                              const uint64_t *__restrict__ mask, OutDev o) {
-  __shared__ uint32_t t32[64][65];
+                                              const uint64_t *__restrict__ mask, OutDev o, EmitLeaf el) {
   __shared__ uint64_t t64[64][65];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t (*td)[65] = (uint32_t (*)[65])&t64[0][0];          // z == 0: two 32-bit tiles in the same space
+  uint32_t (*th)[65] = (uint32_t (*)[65])&t64[32][0];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t batch = blockIdx.y, v0 = blockIdx.x * 64;
   const uint32_t nv = min(64u, n - v0);
   const uint32_t r0 = batch * 64;
   const uint32_t nr = min(64u, n_roots - r0);
-  const uint32_t *D = dist + ((size_t)batch * n + v0) * 64;
-  const uint32_t *H = hv + ((size_t)batch * n + v0) * 64;
-  const uint64_t *M = mask + ((size_t)batch * n + v0) * 64 * W;
-  // dist (+ flags: in SPT <=> dist != INF on this path; saturated roots go through k_exact)
-  for (uint32_t j = wave; j < nv; j += 4) t32[j][lane] = D[(size_t)j * 64 + lane];
-  __syncthreads();
-  for (uint32_t r = wave; r < nr; r += 4)
-    if (lane < nv) {
-      const uint32_t x = t32[lane][r];
-      const size_t idx = o.row(r0 + r) * n + v0 + lane;
-      o.dist[idx] = x;
-      if (o.flags) o.flags[idx] = (x != INF) ? 1 : 0;
+  const uint32_t *Db = dist + (size_t)batch * n * 64, *Hb = hv + (size_t)batch * n * 64;
+  const uint64_t *Mb = mask + (size_t)batch * n * 64 * W;
+  const uint32_t root_slot = r0 + lane;
+  const uint32_t my_root = LEAF ? el.roots[root_slot] : 0u;
+  // LEAF: lane j holds what the derivation of vertex v0 + j needs (its one in-link), read once, side by side
+  uint32_t m_src = 0u, m_w = 0u, m_fpos = 0u, m_fl = 0u;       // m_fl: bit0 leaf, bit1 router
+  if (LEAF && lane < nv) {
+    const GraphDev &g = el.gp->g;
+    const uint32_t v = v0 + lane;
+    m_fl = (g.leaf[v] ? 1u : 0u) | ((g.vflags[v] & 1u) ? 0u : 2u);
+    if (m_fl & 1u) { const uint32_t e0 = g.in_ptr[v]; m_src = g.in_src[e0]; m_w = g.in_w[e0]; m_fpos = g.in_fpos[e0]; }
+  }
+  // the state row a tile row is read from: its own, or (leaf) its neighbour's
+  auto src_row = [&](uint32_t j) -> uint32_t {
+    if (!LEAF) return v0 + j;
+    const uint32_t fl = rdlane(m_fl, j), sraw = rdlane(m_src, j);
+    return ((fl & 1u) && !(sraw & SRC_LEAF)) ? (sraw & SRC_MASK) : v0 + j;
+  };
+  if (blockIdx.z == 0) {
+    // dist + flags (in SPT <=> dist != INF on this path; saturated roots go through k_exact) + hops
+#pragma unroll 1
+    for (uint32_t jb = wave; jb < nv; jb += 32u) {             // 8 tile rows per step: their loads are in flight together
+      uint32_t dd[8], hh[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t j = min(jb + 4u * i, nv - 1u), row = src_row(j);
+        dd[i] = Db[(size_t)row * 64 + lane];
+        hh[i] = (o.hops || LEAF) ? Hb[(size_t)row * 64 + lane] : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t j = jb + 4u * i;
+        if (j >= nv) break;
+        uint32_t nd = dd[i], nh = hh[i];
+        if (LEAF && (rdlane(m_fl, j) & 1u)) {
+          uint64_t nm;
+          fw_leaf_apply<W, false>(el.gp, v0 + j, rdlane(m_src, j), rdlane(m_w, j), rdlane(m_fpos, j), (rdlane(m_fl, j) >> 1) & 1u, dd[i], hh[i],
+                                  0ull, 0u, my_root, root_slot, el.maxpath, el.net_nexthops, el.ignore_ovl, nd, nh, nm);
+        }
+        td[j][lane] = nd; th[j][lane] = nh;
+      }
     }
-  __syncthreads();
-  // hops + flags
-  if (o.hops) {
-    for (uint32_t j = wave; j < nv; j += 4) t32[j][lane] = H[(size_t)j * 64 + lane];
     __syncthreads();
     for (uint32_t r = wave; r < nr; r += 4)
       if (lane < nv) {
-        o.hops[o.row(r0 + r) * n + v0 + lane] = (uint16_t)(t32[lane][r] & 0xFFFFu);
+        const uint32_t x = td[lane][r];
+        const size_t idx = o.row(r0 + r) * n + v0 + lane;
+        o.dist[idx] = x;
+        if (o.flags) o.flags[idx] = (x != INF) ? 1 : 0;
+        if (o.hops) o.hops[idx] = (uint16_t)(th[lane][r] & 0xFFFFu);
       }
-    __syncthreads();
+    return;
   }
-  if (o.mask) {
-    // W is the run's word count rounded up to 1/2/4/8/16; the caller's rows have out_words >= the words really needed
-    // (maybe fewer than W, e.g. 3): the surplus internal words are zero and must not be written past a row's end
-    for (int k = 0; k < W && (uint32_t)k < o.out_words; ++k) {
-      for (uint32_t j = wave; j < nv; j += 4) t64[j][lane] = M[((size_t)j * W + k) * 64 + lane];
-      __syncthreads();
-      for (uint32_t r = wave; r < nr; r += 4)
-        if (lane < nv)
-          o.mask[(o.row(r0 + r) * n + v0 + lane) * o.out_words + k] = t64[lane][r];
-      __syncthreads();
+  if (!o.mask) return;
+  // W is the run's word count rounded up to 1/2/4/8/16; the caller's rows have out_words >= the words really needed
+  // (maybe fewer than W, e.g. 3): the surplus internal words are zero and must not be written past a row's end
+  constexpr uint32_t VB = 64u / (uint32_t)W;                   // vertices of this block
+  const uint32_t vb0 = (blockIdx.z - 1u) * VB;                 // first of them inside the tile
+  if (vb0 >= nv) return;
+  const uint32_t nvb = min(VB, nv - vb0), nl = nvb * W;
+#pragma unroll 1
+  for (uint32_t lb = wave; lb < nl; lb += 32u) {
+    uint32_t dd[8], hh[8];
+    uint64_t mm[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t l = min(lb + 4u * i, nl - 1u), j = vb0 + l / W, k = l % W, row = src_row(j);
+      mm[i] = Mb[((size_t)row * W + k) * 64 + lane];
+      dd[i] = LEAF ? Db[(size_t)row * 64 + lane] : 0u;
+      hh[i] = LEAF ? Hb[(size_t)row * 64 + lane] : 0u;
     }
-    // words beyond W (caller capacity larger than needed) are zero
-    for (uint32_t k = W; k < o.out_words; ++k)
-      for (uint32_t r = wave; r < nr; r += 4)
-        if (lane < nv) o.mask[(o.row(r0 + r) * n + v0 + lane) * o.out_words + k] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t l = lb + 4u * i;
+      if (l >= nl) break;
+      const uint32_t j = vb0 + l / W, k = l % W;
+      uint64_t nm = mm[i];
+      if (LEAF && (rdlane(m_fl, j) & 1u)) {
+        uint32_t nd, nh;
+        fw_leaf_apply<W, true>(el.gp, v0 + j, rdlane(m_src, j), rdlane(m_w, j), rdlane(m_fpos, j), (rdlane(m_fl, j) >> 1) & 1u, dd[i], hh[i],
+                               mm[i], k, my_root, root_slot, el.maxpath, el.net_nexthops, el.ignore_ovl, nd, nh, nm);
+      }
+      t64[l][lane] = nm;
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t j = lane / W, k = lane % W;
+    for (uint32_t r = wave; r < nr; r += 4) {
+      const size_t base = (o.row(r0 + r) * n + v0 + vb0) * o.out_words;
+      if (j < nvb && k < o.out_words) o.mask[base + (size_t)j * o.out_words + k] = t64[lane][r];
+      // words beyond W (caller capacity larger than needed) are zero
+      if (o.out_words > (uint32_t)W && lane < nvb)
+        for (uint32_t kk = W; kk < o.out_words; ++kk) o.mask[base + (size_t)lane * o.out_words + kk] = 0;
+    }
   }
 }
 
@@ -2006,7 +2133,7 @@ template <int W, bool HC> __device__ __forceinline__ FwAcc<W, HC> fw_acc_init() 
 // the whole triple (distance, hops, W mask words) of DG links is requested in ONE round trip.  The sweep is bound by
 // dependent round trips, not bytes, on most rows: asking for the hops and masks only after the distances have shown
 // which links are tight — what k_dag does — doubles the chain.
-template <int W, bool MAXINF, bool HC>
+template <int W, bool MAXINF, bool HC, bool LEAF = false>
 __device__ __forceinline__ void fw_chunk(FwAcc<W, HC> &x, const FusedGraph *__restrict__ gp, const uint32_t *D, const uint32_t *H,
                                          const uint64_t *M, uint32_t v, uint32_t v_router, uint32_t eb, uint32_t cnt,
                                          uint32_t sv, uint32_t wv, uint32_t lane, uint32_t my_root, uint32_t root_slot,
@@ -2023,8 +2150,8 @@ __device__ __forceinline__ void fw_chunk(FwAcc<W, HC> &x, const FusedGraph *__re
     uint64_t mu[DG][W];
 #pragma unroll
     for (int k = 0; k < DG; ++k) {
-      const uint32_t u = rdlane(sv, min(j0 + (uint32_t)k, 63u)) & SRC_MASK;
-      const bool in = (j0 + k) < cnt;                                // uniform: no requests for a short row's padding
+      const uint32_t sraw = rdlane(sv, min(j0 + (uint32_t)k, 63u)), u = sraw & SRC_MASK;
+      const bool in = (j0 + k) < cnt && !(LEAF && (sraw & SRC_LEAF));   // uniform: no requests for a short row's padding, nor for a leaf's row (not kept)
       du[k] = in ? ld_row(D, u * 256u + lane4) : INF;
       hu[k] = in ? ld_row(H, u * 256u + lane4) : 0u;
 #pragma unroll
@@ -2036,6 +2163,10 @@ __device__ __forceinline__ void fw_chunk(FwAcc<W, HC> &x, const FusedGraph *__re
       const uint32_t j = min(j0 + (uint32_t)k, 63u);
       const uint32_t w = rdlane(wv, j);
       uint32_t d = du[k];
+      if (LEAF) {
+        const uint32_t sw = rdlane(sv, j);
+        if (sw & SRC_LEAF) d = ((sw & SRC_MASK) == my_root) ? 0u : INF;      // a leaf is on nobody's path but its own (hops 0, mask 0 were not requested)
+      }
       if (has_nt) {
         const uint32_t sw = rdlane(sv, j);
         if ((sw & SRC_NO_TRANSIT) && (sw & SRC_MASK) != my_root) d = INF;     // overloaded source
@@ -2049,6 +2180,7 @@ __device__ __forceinline__ void fw_chunk(FwAcc<W, HC> &x, const FusedGraph *__re
       const uint32_t j = j0 + k;
       if (j >= cnt) break;
       const uint32_t c = cc[k], d = du[k];
+      if (LEAF && (rdlane(sv, j) & SRC_LEAF) && __ballot(c != INF) == 0ull) continue;   // a leaf that is no root of this batch
       const bool zlink = has_z && rdlane(zv, j) != 0u;              // uniform
       if (zlink && !HC) { x.bd_all = min(x.bd_all, c); continue; }
       const bool hz = HC && zlink;
@@ -2134,7 +2266,7 @@ __device__ __forceinline__ FwAcc<W, HC> fw_part_load(const char *p, uint32_t lan
   return x;
 }
 
-template <int W, bool MAXINF, bool HC>
+template <int W, bool MAXINF, bool HC, bool LEAF = false>
 __global__ __launch_bounds__(256) void k_fw_giant_part(const FusedGraph *__restrict__ gp, const uint32_t *__restrict__ dist,
                                                        const uint32_t *__restrict__ hv, const uint64_t *__restrict__ mask,
                                                        const uint32_t *__restrict__ act, const uint32_t *__restrict__ roots,
@@ -2164,7 +2296,7 @@ __global__ __launch_bounds__(256) void k_fw_giant_part(const FusedGraph *__restr
   if (cnt) {
     const uint32_t sv = lane < cnt ? g.in_src[eb + lane] : v;
     const uint32_t wv = lane < cnt ? g.in_w[eb + lane] : INF;
-    fw_chunk<W, MAXINF, HC>(x, gp, D, H, M, v, v_router, eb, cnt, sv, wv, lane, my_root, root_slot, net_nexthops, ignore_ovl);
+    fw_chunk<W, MAXINF, HC, LEAF>(x, gp, D, H, M, v, v_router, eb, cnt, sv, wv, lane, my_root, root_slot, net_nexthops, ignore_ovl);
   }
   const uint32_t B = gridDim.y, n_ws = g.giant_slice0[g.n_giant] * 4u;
   char *base = (char *)(gp->giant_part + giant_tag_words(B, g.n_giant));
@@ -2172,7 +2304,7 @@ __global__ __launch_bounds__(256) void k_fw_giant_part(const FusedGraph *__restr
   if (s_in_row == 0u && wave == 0u && lane == 0u) gp->giant_part[(size_t)batch * g.n_giant + gi] = (uint32_t)sweep + 1u;
 }
 
-template <int W, bool MAXINF, bool HC>
+template <int W, bool MAXINF, bool HC, bool LEAF = false>
 __global__ __launch_bounds__(256) void k_fw(const FusedGraph *__restrict__ gp, uint32_t *__restrict__ dist,
                                             uint32_t *__restrict__ hv, uint64_t *__restrict__ mask,
                                             uint32_t *__restrict__ act, const uint32_t *__restrict__ roots,
@@ -2188,7 +2320,8 @@ __global__ __launch_bounds__(256) void k_fw(const FusedGraph *__restrict__ gp, u
   if (!wave_rows(g, blockIdx.x, wave, vbeg, nrows)) return;
   uint32_t *A = act + (size_t)batch * n;
   const uint32_t av = A[min(vbeg + min(lane, (uint32_t)VPW - 1u), n - 1)];
-  const uint64_t due = __ballot(lane < nrows && vbeg + lane < n && av >= (uint32_t)sweep + 1u);
+  const uint32_t lfv = LEAF ? (uint32_t)g.leaf[min(vbeg + min(lane, (uint32_t)VPW - 1u), n - 1)] : 0u;   // leaves wait for the emit
+  const uint64_t due = __ballot(lane < nrows && vbeg + lane < n && av >= (uint32_t)sweep + 1u && lfv == 0u);
   if (due == 0ull) return;
   const uint32_t *__restrict__ in_src = g.in_src;
   const uint32_t *__restrict__ in_w = g.in_w;
@@ -2231,7 +2364,7 @@ __global__ __launch_bounds__(256) void k_fw(const FusedGraph *__restrict__ gp, u
         const uint32_t cnt = min(64u, e1 - eb);
         const uint32_t sv = lane < cnt ? in_src[eb + lane] : v;
         const uint32_t wv = lane < cnt ? in_w[eb + lane] : INF;
-        fw_chunk<W, MAXINF, HC>(x, gp, D, H, M, v, v_router, eb, cnt, sv, wv, lane, my_root, root_slot, net_nexthops, ignore_ovl);
+        fw_chunk<W, MAXINF, HC, LEAF>(x, gp, D, H, M, v, v_router, eb, cnt, sv, wv, lane, my_root, root_slot, net_nexthops, ignore_ovl);
       }
     }
     if (!have) continue;                       // stamped after k_fw_giant_part had looked: due again in the next sweep

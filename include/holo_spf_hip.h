@@ -205,7 +205,8 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows);
 /* Copies one array of the device-resident graph back to the host (inspection, tests, debugging).
  * dst == NULL: only *out_bytes is set.  The layout: kept links = two-way and source expandable; in-rows
  * (links INTO a vertex) ordered by (cost descending, source ascending, position in the source row
- * ascending), IN_SRC carries the source's HSPF_VF_NO_TRANSIT in bit 31; out-rows in the caller's order. */
+ * ascending), IN_SRC carries the source's HSPF_VF_NO_TRANSIT in bit 31 and whether it is a leaf (HSPF_GX_LEAF) in
+ * bit 30; out-rows in the caller's order. */
 #define HSPF_GX_ROW_PTR   0u   /* u32 [n+1]    caller's CSR as resident on the device             */
 #define HSPF_GX_COL       1u   /* u32 [e]                                                         */
 #define HSPF_GX_METRIC    2u   /* u32 [e]                                                         */
@@ -233,6 +234,8 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows);
                                   << 5 | network << 7; unused entries name the pad row n                            */
 #define HSPF_GX_ELL_COST 17u   /* u32 [16(n+1)] their costs (unused entries 0)                                       */
 #define HSPF_GX_ELL_OUT  18u   /* u32 [16(n+1)] out-neighbour j << 2 (unused entries 0xFFFFFFFF)                     */
+#define HSPF_GX_LEAF     20u   /* u8  [n]      1 = leaf: exactly one kept in-link, and the kept out-links (at most one) lead
+                                  back to its source.  IN_SRC carries the source's leaf bit in bit 30                */
 #define HSPF_GX_SUMMARY  19u   /* u32 [8]      what a build derives from the links and a patch must keep current:
                                   largest kept cost, hop-count shape (0/1), smallest-graph kernel allowed (0/1), OR of
                                   the row flags, rows with a zero-cost link from a higher-numbered source, rows off the

@@ -3,6 +3,6 @@ import pytest
 
 both_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps", "kfused", "lanevertex"], indirect=True)
 sweeps_engine = pytest.mark.parametrize("spf_ctx", ["sweeps"], indirect=True)
-all_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps", "kfused", "twophase", "lanevertex"], indirect=True)
+all_engines = pytest.mark.parametrize("spf_ctx", ["default", "sweeps", "kfused", "twophase", "widemask", "lanevertex"], indirect=True)
 hub_engines = pytest.mark.parametrize("spf_ctx", ["default", "hubsort"], indirect=True)
 hubsort_engine = pytest.mark.parametrize("spf_ctx", ["hubsort"], indirect=True)

@@ -8,6 +8,8 @@ Semantics restated (include/holo_spf_hip.h, hspf_graph_export):
   out-rows        kept links in the caller's order
   in-rows         kept links into a vertex by (cost descending, source ascending, position ascending);
                   bit 31 of the source = HSPF_VF_NO_TRANSIT of the source (routers only: ignored on network vertices)
+  leaves          exactly one kept in-link, and the kept out-links (at most one) lead back to its source; bit 30 of the
+                  source of every in-row entry = the source is a leaf
 """
 import numpy as np
 
@@ -32,7 +34,12 @@ def layout(row_ptr, col, metric, vflags):
     np.add.at(in_ptr, kt + 1, 1)
     in_ptr = np.cumsum(in_ptr)
     nt = ((vflags[ks[order]] & VF_NO_TRANSIT) != 0) & ((vflags[ks[order]] & VF_NETWORK) == 0)   # routers only
-    in_src = (ks[order] | (nt.astype(np.int64) << 31)).astype(np.uint32)
+    deg_in, deg_out = np.diff(in_ptr), np.diff(out_ptr)
+    leaf = np.zeros(n, np.uint8)
+    for v in range(n):
+        if deg_in[v] == 1 and (deg_out[v] == 0 or (deg_out[v] == 1 and kt[out_ptr[v]] == ks[order][in_ptr[v]])):
+            leaf[v] = 1
+    in_src = (ks[order] | (nt.astype(np.int64) << 31) | (leaf[ks[order]].astype(np.int64) << 30)).astype(np.uint32)
     rowflags = np.zeros(n, np.uint8)
     t_o, w_o, s_o = kt[order], kw[order], ks[order]
     for t in range(n):
@@ -57,5 +64,5 @@ def layout(row_ptr, col, metric, vflags):
         "in_ptr": in_ptr.astype(np.uint32), "in_src": in_src, "in_cost": w_o.astype(np.uint32),
         "in_pos": kp[order].astype(np.uint32),
         "out_ptr": out_ptr.astype(np.uint32), "out_dst": kt.astype(np.uint32), "out_cost": kw.astype(np.uint32),
-        "out_pos": kp.astype(np.uint32), "rowflags": rowflags,
+        "out_pos": kp.astype(np.uint32), "rowflags": rowflags, "leaf": leaf,
     }

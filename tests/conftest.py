@@ -28,7 +28,9 @@ def spf_ctx(request, _ctx_pool):
     engine keeps its coverage on the small adversarial graphs of the suite — since round 3 that is k_fused_lean wherever
     its 4-byte state fits, so "kfused" is "sweeps" with the lean sweep off (HSPF_VARIANT bit15): k_fused on both state
     widths; "twophase" additionally sends runs with more
-    than 24 first-hop slots down the older k_relax + k_dag path instead of k_fw (HSPF_VARIANT bit6); "lanevertex" sends
+    than 24 first-hop slots down the older k_relax + k_dag path instead of k_fw (HSPF_VARIANT bit6); "widemask" sends EVERY
+    run down k_fw, the wide-mask fixed point (HSPF_VARIANT bit0: no packed state) — with the leaves of the graph left
+    to the emit wherever it has any, which the adversarial graphs do (stub LANs, one-way links); "lanevertex" sends
     every run of up to 64 roots (with at most 24 first-hop slots) through k_lv (HSPF_SINGLE_MAX_N=0, HSPF_LV_MAX_ROOTS=64,
     HSPF_LV_MIN_N=0); "hubsort" is the default engine with every graph built in hub mode (HSPF_HUB_DEG=0: two-way check and
     in-row order from device-wide sorts instead of per-link row scans).
@@ -39,12 +41,14 @@ def spf_ctx(request, _ctx_pool):
         env = {"sweeps": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0"},
                "kfused": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "32768"},
                "twophase": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "64"},
+               "widemask": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "1"},
                "lanevertex": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "64", "HSPF_LV_MIN_N": "0"},
                "hubsort": {"HSPF_HUB_DEG": "0"}}.get(mode, {})
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:
             _ctx_pool[mode] = SpfContext(0)          # the switches are read once, at hspf_init
+            _ctx_pool[mode].mode = mode
         finally:
             for k, v in old.items():
                 if v is None:

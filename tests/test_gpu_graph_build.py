@@ -13,7 +13,7 @@ from _engines import hub_engines, hubsort_engine
 
 pytestmark = pytest.mark.gpu
 
-BUILT = ("twoway", "in_ptr", "in_src", "in_cost", "in_pos", "out_ptr", "out_dst", "out_cost", "out_pos", "rowflags", "units")
+BUILT = ("twoway", "in_ptr", "in_src", "in_cost", "in_pos", "out_ptr", "out_dst", "out_cost", "out_pos", "rowflags", "units", "leaf")
 RAW = ("row_ptr", "col", "metric", "vflags")
 DERIVED = ("ell_src", "ell_cost", "ell_out", "summary")      # no restatement: compared patched against fresh
 
@@ -150,7 +150,7 @@ def test_star_of_100k_links(spf_ctx):
         ks, kt, kw = src[keep], g.col[keep].astype(np.int64), g.metric[keep].astype(np.int64)
         kp = (np.arange(len(src), dtype=np.int64) - g.row_ptr.astype(np.int64)[src])[keep]
         order = np.lexsort((kp, ks, -kw, kt))
-        assert np.array_equal(G.export("in_src") & 0x7FFFFFFF, ks[order].astype(np.uint32))
+        assert np.array_equal(G.export("in_src") & 0x3FFFFFFF, ks[order].astype(np.uint32))
         assert np.array_equal(G.export("in_cost"), kw[order].astype(np.uint32))
         assert np.array_equal(G.export("in_pos"), kp[order].astype(np.uint32))
         assert np.array_equal(G.export("out_dst"), kt.astype(np.uint32))
