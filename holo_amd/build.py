@@ -37,6 +37,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     # latency-bound sparse sweeps); the compiler keeps a compatible prologue for firmware that does not preload
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              "-mllvm", "-amdgpu-kernarg-preload-count=16"]
+    flags += os.environ.get("HSPF_BUILD_DEFS", "").split()      # experiments: -DNAME=value
     # one object per source, compiled side by side (the engine and the rocPRIM sorts of the hub-mode graph build), then linked
     objs, procs = [], []
     for src in SOURCES:

@@ -1425,7 +1425,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     if (!defer) HIPCHK(ctx, hipMemsetAsync(d_mask, 0, rows * 8 * W, s));
     if (defer) st.dbg[1] = 1;                                    // hspf_stats::dbg[1]: the leaves were left to the emit
     HIPCHK(ctx, hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s));
-    hipLaunchKernelGGL(k_init_fw, dim3((L + 255) / 256), dim3(256), 0, s, gd, d_dist, d_stamp, d_roots, L);
+    hipLaunchKernelGGL(k_init_fw, dim3((L + 3) / 4), dim3(256), 0, s, gd, d_dist, d_stamp, d_roots, L);
     if (giant) HIPCHK(ctx, hipMemsetAsync(ctx->giant_part.p, 0, giant_tags * 4, s));
     const bool mi = g->max_path_metric == HSPF_DIST_INF, hcl = g->hopcount_like;
     const dim3 ggrid(std::max(g->n_giant_slices, 1u), B);

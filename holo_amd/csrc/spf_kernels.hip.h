@@ -2133,12 +2133,15 @@ template <int W, bool HC> __device__ __forceinline__ FwAcc<W, HC> fw_acc_init() 
 // the whole triple (distance, hops, W mask words) of DG links is requested in ONE round trip.  The sweep is bound by
 // dependent round trips, not bytes, on most rows: asking for the hops and masks only after the distances have shown
 // which links are tight — what k_dag does — doubles the chain.
+#ifndef FW_DG2
+#define FW_DG2 8
+#endif
 template <int W, bool MAXINF, bool HC, bool LEAF = false>
-__device__ __forceinline__ void fw_chunk(FwAcc<W, HC> &x, const FusedGraph *__restrict__ gp, const uint32_t *D, const uint32_t *H,
+__device__ __forceinline__ void fw_chunk_1p(FwAcc<W, HC> &x, const FusedGraph *__restrict__ gp, const uint32_t *D, const uint32_t *H,
                                          const uint64_t *M, uint32_t v, uint32_t v_router, uint32_t eb, uint32_t cnt,
                                          uint32_t sv, uint32_t wv, uint32_t lane, uint32_t my_root, uint32_t root_slot,
                                          uint32_t net_nexthops, uint32_t ignore_ovl) {
-  constexpr int DG = W <= 2 ? 8 : (W <= 4 ? 4 : (W <= 8 ? 2 : 1));
+  constexpr int DG = W <= 2 ? FW_DG2 : (W <= 4 ? 4 : (W <= 8 ? 2 : 1));
   const GraphDev &g = gp->g;
   const uint32_t lane4 = lane * 4u, lane8 = lane * 8u;
   const bool has_nt = !ignore_ovl && __ballot(lane < cnt && (sv & SRC_NO_TRANSIT) != 0) != 0ull;
@@ -2217,6 +2220,14 @@ __device__ __forceinline__ void fw_chunk(FwAcc<W, HC> &x, const FusedGraph *__re
       x.bd = min(x.bd, c);
     }
   }
+}
+
+template <int W, bool MAXINF, bool HC, bool LEAF = false>
+__device__ __forceinline__ void fw_chunk(FwAcc<W, HC> &x, const FusedGraph *__restrict__ gp, const uint32_t *D, const uint32_t *H,
+                                         const uint64_t *M, uint32_t v, uint32_t v_router, uint32_t eb, uint32_t cnt,
+                                         uint32_t sv, uint32_t wv, uint32_t lane, uint32_t my_root, uint32_t root_slot,
+                                         uint32_t net_nexthops, uint32_t ignore_ovl) {
+  fw_chunk_1p<W, MAXINF, HC, LEAF>(x, gp, D, H, M, v, v_router, eb, cnt, sv, wv, lane, my_root, root_slot, net_nexthops, ignore_ovl);
 }
 
 // y covers links that FOLLOW x's in row order (any_merge with W-word masks).  Candidates equal to INF never merge masks
@@ -2410,14 +2421,16 @@ __global__ __launch_bounds__(256) void k_fw(const FusedGraph *__restrict__ gp, u
 }
 
 // init for k_fw: the roots' own distance (dist = 0; hv / mask are zero already) and the first activation stamps.
-__global__ void k_init_fw(GraphDev g, uint32_t *dist, uint32_t *act, const uint32_t *roots, uint32_t n_lanes) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per root: its lanes walk the out-links (a thread per root walked a fat-tree switch's hundred links one
+// dependent load at a time: 31 us).
+__global__ __launch_bounds__(256) void k_init_fw(GraphDev g, uint32_t *dist, uint32_t *act, const uint32_t *roots, uint32_t n_lanes) {
+  const uint32_t i = (blockIdx.x * 256u + threadIdx.x) >> 6, ln = threadIdx.x & 63u;
   if (i >= n_lanes) return;
   const uint32_t r = roots[i];
   if (r == INF) return;
   const uint32_t n = g.n, batch = i >> 6, lane = i & 63;
-  dist[((size_t)batch * n + r) * 64 + lane] = 0;
-  for (uint32_t k = g.out_ptr[r]; k < g.out_ptr[r + 1]; ++k) act[(size_t)batch * n + g.out_dst[k]] = 1u;
+  if (ln == 0) dist[((size_t)batch * n + r) * 64 + lane] = 0;
+  for (uint32_t k = g.out_ptr[r] + ln; k < g.out_ptr[r + 1]; k += 64u) act[(size_t)batch * n + g.out_dst[k]] = 1u;
 }
 
 // ---------------------------------------------------------------------------------------------
