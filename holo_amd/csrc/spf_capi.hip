@@ -1353,12 +1353,17 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       }
       // the plainest graphs (routers only, no row flag, in-degrees <= 8) with one vertex per thread: the lean kernel
       const bool lean = g->lean && n <= (uint32_t)SINGLE_THREADS && !(ctx->variant & 4096u);
-      if (lean) {
-        if (mi) hipLaunchKernelGGL((k_single_lean<true>), dim3(n_roots), dim3(thr), (size_t)n * 8, s, sa);
-        else    hipLaunchKernelGGL((k_single_lean<false>), dim3(n_roots), dim3(thr), (size_t)n * 8, s, sa);
+      if (lean && g->max_in_deg <= 4u && !(ctx->variant & 262144u)) {   // HSPF_VARIANT bit18: eight link records per thread whatever the rows hold
+        if (mi) hipLaunchKernelGGL((k_single_lean<true, 4>), dim3(n_roots), dim3(thr), (size_t)n * 8, s, sa);
+        else    hipLaunchKernelGGL((k_single_lean<false, 4>), dim3(n_roots), dim3(thr), (size_t)n * 8, s, sa);
+      } else if (lean) {
+        if (mi) hipLaunchKernelGGL((k_single_lean<true, 8>), dim3(n_roots), dim3(thr), (size_t)n * 8, s, sa);
+        else    hipLaunchKernelGGL((k_single_lean<false, 8>), dim3(n_roots), dim3(thr), (size_t)n * 8, s, sa);
       } else
       hipLaunchKernelGGL(kern, dim3(n_roots), dim3(thr), lds, s, sa);
       (void)hipEventRecord(ctx->ev[2], s);
+      (void)hipEventRecord(ctx->ev[4], s);          // the kernel wrote the results in place: the run ends here, and the
+      tail_done = true;                             // synchronisation below covers it (as behind the emit of the other paths)
       er = hipSuccess;
       if (count_rows) er = hipMemcpyAsync(ctx->h_lane_flags + L, d_kcnt, 256 * 4, hipMemcpyDeviceToHost, s);
       const hipError_t el = hipGetLastError();                         // the launch itself

@@ -1697,7 +1697,8 @@ __global__ __launch_bounds__(256) void k_emit_lv(uint32_t n, const uint64_t *__r
 // precomputed bit into the loaded pay bits is the whole `hops == 0` case.  Sweeps run free in groups of SINGLE_FREE
 // between checked ones (see k_single).  k_single carries the general routine next to this path and spills its scalar
 // state around every sweep; alone, the loop is ~70 vector instructions.
-template <bool MAXINF>
+// RL = link records per thread: 4 when no row has more (the reference's own p2p grid: 1 400 -> ~900 cycles per sweep), else 8.
+template <bool MAXINF, int RL>
 __global__ __launch_bounds__(SINGLE_THREADS) void k_single_lean(SingleArgs a) {
   extern __shared__ uint64_t s_st[];
   __shared__ int s_changed[4];
@@ -1721,12 +1722,12 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single_lean(SingleArgs a) {
     return;
   }
   const uint64_t t_clk0 = clock64(), t_wall0 = wall_clock64();
-  uint32_t ls[SINGLE_RL], lw[SINGLE_RL], lb[SINGLE_RL];
+  uint32_t ls[RL], lw[RL], lb[RL];
   const uint32_t vc = min(v, n - 1u);
   const uint32_t e0 = g.in_ptr[vc], e1 = mine ? g.in_ptr[vc + 1] : e0;
   const uint32_t v_router = 1u;                    // no network vertices in a lean graph
 #pragma unroll
-  for (uint32_t k = 0; k < SINGLE_RL; ++k) {
+  for (uint32_t k = 0; k < (uint32_t)RL; ++k) {
     const bool in = e0 + k < e1;
     const uint32_t e = in ? e0 + k : e0;           // (arrays are padded: e0 is readable even for an empty row)
     const uint32_t sv = g.in_src[e] & SRC_MASK, wv = g.in_w[e], fp = g.in_fpos[e];
@@ -1749,22 +1750,23 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single_lean(SingleArgs a) {
     if (checked) __syncthreads();
     bool any = false;
     if (live) {
-      uint64_t qs[SINGLE_RL];
+      uint64_t qs[RL];
 #pragma unroll
-      for (uint32_t k = 0; k < SINGLE_RL; ++k) qs[k] = s_st[ls[k]];
-      uint32_t c[SINGLE_RL];
+      for (uint32_t k = 0; k < (uint32_t)RL; ++k) qs[k] = s_st[ls[k]];
+      uint32_t c[RL];
       bool sat1 = false;
 #pragma unroll
-      for (uint32_t k = 0; k < SINGLE_RL; ++k) {
+      for (uint32_t k = 0; k < (uint32_t)RL; ++k) {
         const uint32_t d = (uint32_t)(qs[k] >> 32);
         c[k] = add_sat(d, lw[k]);
         if (MAXINF && c[k] == INF && d != INF && lw[k] != INF) sat1 = true;
       }
-      const uint32_t bd = min(min(min(c[0], c[1]), min(c[2], c[3])), min(min(c[4], c[5]), min(c[6], c[7])));
-      static_assert(SINGLE_RL == 8, "min tree");
+      uint32_t bd = min(min(c[0], c[1]), min(c[2], c[3]));
+      if constexpr (RL == 8) bd = min(bd, min(min(c[4], c[5]), min(c[6], c[7])));
+      static_assert(RL == 4 || RL == 8, "min tree");
       uint32_t macc = 0u, bpay = 0u;
 #pragma unroll
-      for (int k = (int)SINGLE_RL - 1; k >= 0; --k) {
+      for (int k = RL - 1; k >= 0; --k) {
         const bool t = c[k] == bd;
         const uint32_t pb = (uint32_t)qs[k] | lb[k];
         macc |= t ? pb : 0u;
