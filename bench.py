@@ -231,10 +231,16 @@ def path_of(st) -> str:
         return "k_single (one workgroup per root)"
     if st.get("lane_vertex"):
         return "k_lv (lane = vertex)"
+    dbg = st.get("dbg", [0, 0, 0, 0])
+    packed = None
     if st["state_bytes"] == 4:
-        return "k_fused_lean, 4-byte state" if st.get("dbg", [0])[0] else "k_fused, 4-byte state"
+        packed = "k_fused_lean, 4-byte state" if dbg[0] else "k_fused, 4-byte state"
     if st["state_bytes"] == 8:
-        return "k_fused, 8-byte state"
+        packed = "k_fused, 8-byte state"
+    if dbg[1]:                               # a wide-mask class ran with the graph's leaves left to the emit
+        return "k_fw (wide masks, leaves derived in the emit)" + (" + " + packed + " for the roots that fit it" if packed else "")
+    if packed:
+        return packed
     return "k_relax + k_dag (two-phase)" if st["n_dag_launches"] else "k_fw (wide masks)"
 
 
