@@ -139,6 +139,55 @@ def latency_1root(ctx, dev) -> dict:
     return out
 
 
+def two_instances(g, dev, steps_each: int = 150) -> dict:
+    """TWO independent SPF instances on the one GPU (what a router with IS-IS level 1 and level 2, or two OSPF areas,
+    is): each its own hspf_ctx, stream and host thread, each running 64-root batches of the headline workload back to
+    back (its own root set).  The sparse head and tail of a run leave most of the chip idle (28 launches, 10 of them
+    under 12 us); the other instance's dense sweeps fill it.  Reported NEXT TO the headline, never as it: `value` stays
+    one instance, one batch in flight.  The last run of both instances is compared with the oracle, every (root, vertex)."""
+    import threading
+    import torch
+    from holo_amd import engine as E
+    from oracle import graph_oracle as go
+    n = g.n
+    inst = []
+    for i in range(2):
+        c = E.SpfContext(dev.index or 0)
+        G = c.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        r = (((np.arange(64, dtype=np.int64) * n) // 64 + 7 * i) % n).astype(np.uint32)
+        b = (torch.empty((64, n), dtype=torch.int32, device=dev), torch.empty((64, n), dtype=torch.int16, device=dev),
+             torch.empty((64, n), dtype=torch.int16, device=dev), torch.empty((64, n, 1), dtype=torch.int64, device=dev))
+        inst.append((c, G, r, b))
+
+    def loop(i, k):
+        c, G, r, (d, h, f, m) = inst[i]
+        for _ in range(k):
+            c.run_device(G, r, 0, dist_ptr=d.data_ptr(), hops_ptr=h.data_ptr(), flags_ptr=f.data_ptr(), mask_ptr=m.data_ptr(), mask_words=1)
+    for i in range(2):
+        loop(i, 5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter(); loop(0, steps_each); torch.cuda.synchronize(); t1 = time.perf_counter() - t0
+    ts = [threading.Thread(target=loop, args=(i, steps_each)) for i in range(2)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter() - t0
+    ok = True
+    for c, G, r, (d, h, f, m) in inst:
+        ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, r, 0, go.HEAP, mask_words_=1, threads=min(64, os.cpu_count() or 1))
+        ok = ok and bool(np.array_equal(d.cpu().numpy().view(np.uint32), ref.dist) and np.array_equal(h.cpu().numpy().view(np.uint16), ref.hops)
+                         and np.array_equal(m.cpu().numpy().view(np.uint64), ref.mask))
+        G.free(); c.close()
+    one, two = 64 * steps_each / t1, 64 * 2 * steps_each / t2
+    ba = b_alg(n, g.e, 1)
+    return {"instances": 2, "roots_per_run": 64, "runs_each": steps_each, "runs_per_s": round(two), "one_instance_same_loop_runs_per_s": round(one),
+            "ms_per_64_root_run": round(t2 / (2 * steps_each) * 1e3, 4), "whole_run_frac": round(two * ba / HBM_PEAK, 5),
+            "identical_to_oracle": ok}
+
+
 def pipeline_1root(ctx, dev) -> dict:
     """What one LSP refresh with changed costs costs end to end for one root on the headline graph (SURVEY.md 8f-1, 8f-2,
     8f-4 chained): hspf_graph_patch of the router's row -> hspf_run_device -> hspf_routes_device over 120 000 prefixes
@@ -554,6 +603,7 @@ def main():
             ctx1 = E.SpfContext(local_rank)
             out["latency_1root"] = latency_1root(ctx1, dev)
             out["pipeline_1root"] = pipeline_1root(ctx1, dev)
+            out["two_instances"] = two_instances(g, dev)
             out["configs"] = other_configs(ctx1, dev)
         print(json.dumps(out), flush=True)
 
