@@ -28,6 +28,14 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.hspf_strerror(-5).decode().startswith("too many")
 
 
+def test_integration_md_binds_every_declared_symbol():
+    """INTEGRATION.md section 2 claims to be 1:1 with the header: every function the header declares has a `pub fn` there."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    bound = set(re.findall(r"pub fn (hspf_[a-z0-9_]+)\s*\(", text))
+    missing = sorted(declared_symbols() - bound)
+    assert not missing, f"INTEGRATION.md extern block lacks {missing}"
+
+
 def test_no_device_is_an_error_code_not_a_crash():
     """On the CPU-only build container hspf_init must fail with HSPF_E_NODEV (no CPU fallback)."""
     import torch
