@@ -69,18 +69,24 @@ def fuzz(ctx, first, count, verbose=True):
             if rng.random() < 0.08:
                 flags |= E.RUN_POP_RANK
             runs += 1
+            t_run = time.time()
             ok += compare(ctx, G, g, roots, flags, (seed, rep, flags, k))
+            if os.environ.get("FUZZ_TIMING") and time.time() - t_run > float(os.environ["FUZZ_TIMING"]):
+                print(f"SLOW seed {seed} rep {rep} n {g.n} roots {k} flags {flags} hop {hop} maxpath {g.max_path_metric:#x}: {time.time() - t_run:.2f} s, stats {ctx.stats()}", flush=True)
             if rep < 2 and rng.random() < 0.5:                      # re-originate a few rows in between
                 vs = np.sort(rng.choice(g.n, size=int(rng.integers(1, 6)), replace=False))
                 rows, fl = [], []
+                costs_only = rng.random() < 0.5                     # a metric change: applied in place (build mode 2)
                 for v in vs.tolist():
                     c = g.col[g.row_ptr[v]:g.row_ptr[v + 1]]; m = g.metric[g.row_ptr[v]:g.row_ptr[v + 1]]
-                    keep = rng.random(len(c)) > 0.25
+                    keep = rng.random(len(c)) > (-1.0 if costs_only else 0.25)
                     c, m = c[keep], m[keep].copy()
-                    if len(m) and v >= nn and not hop:
-                        m[rng.random(len(m)) < 0.5] = int(rng.integers(1, 9))
-                    rows.append((c, m)); fl.append(int(g.vflags[v]) ^ (synth.VF_NO_TRANSIT if (v >= nn and rng.random() < 0.3) else 0))
+                    if len(m) and (v >= nn or costs_only):
+                        m[rng.random(len(m)) < 0.5] = int(rng.integers(0 if costs_only else 1, 9)) if not hop else int(rng.integers(0, 2))
+                    rows.append((c, m)); fl.append(int(g.vflags[v]) ^ (synth.VF_NO_TRANSIT if (v >= nn and not costs_only and rng.random() < 0.3) else 0))
                 G.patch(vs, rows, fl)
+                if costs_only and int(G.export("build_mode")[0]) != 2 and int(np.diff(G.export("in_ptr")).max(initial=0)) <= 256:
+                    print("COST PATCH NOT IN PLACE", seed, rep, flush=True); ok -= 1
                 g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
         G.free()
     if verbose:
@@ -126,7 +132,8 @@ def fuzz_layout(ctx, first, count, verbose=True, spf=False):
     (tests/_layout_ref.py), and a patched graph against a fresh upload of the patched CSR."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
     from _layout_ref import layout
-    built = ("twoway", "in_ptr", "in_src", "in_cost", "in_pos", "out_ptr", "out_dst", "out_cost", "out_pos", "rowflags")
+    built = ("twoway", "in_ptr", "in_src", "in_cost", "in_pos", "out_ptr", "out_dst", "out_cost", "out_pos", "rowflags", "leaf")
+    derived = ("ell_src", "ell_cost", "ell_out", "summary")
     ok = runs = 0
     t0 = time.time()
     for seed in range(first, first + count):
@@ -153,6 +160,21 @@ def fuzz_layout(ctx, first, count, verbose=True, spf=False):
                 rows.append((rng.integers(0, n, deg).astype(np.uint32), rng.integers(0, 6, deg).astype(np.uint32)))
                 fl.append(int(rng.integers(0, 8)))
             G.patch(vs, rows, fl)
+            if rng.random() < 0.6:                             # ... then new costs on some rows, in place; arrays and summary as a fresh upload's
+                vs2 = np.sort(rng.choice(n, size=int(rng.integers(1, min(n, 12) + 1)), replace=False))
+                rows2 = []
+                for v in vs2.tolist():
+                    c = G.col[G.row_ptr[v]:G.row_ptr[v + 1]].copy()
+                    rows2.append((c, rng.integers(0, 6, len(c)).astype(np.uint32)))
+                G.patch(vs2, rows2, G.vflags[vs2].copy())
+                F = ctx.upload(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
+                good = all(np.array_equal(G.export(k), F.export(k)) for k in built + derived)
+                good = good and (int(G.export("build_mode")[0]) == 2 or int(np.diff(G.export("in_ptr")).max(initial=0)) > 256)
+                F.free()
+                runs += 1
+                ok += good
+                if not good:
+                    print("COST PATCH MISMATCH", seed, rep, flush=True)
             if spf:                                            # SPF on whatever graph the arbitrary rows made
                 gg = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
                 roots = rng.choice(n, size=int(rng.integers(1, min(n, 70) + 1)), replace=False).astype(np.uint32)
