@@ -401,3 +401,38 @@ def compute_spf_intra_area(router_id: str, areas: List[Area], max_paths: int, en
         rows.append({"prefix": r["prefix"], "metric": r["metric"], "type": "intra-area",
                      "nexthops": [[r["nexthops"][k][1], r["nexthops"][k][0]] for k in sorted(r["nexthops"])]})
     return rows
+
+
+# ---- the wire step after the path: update_global_rib --------------------------------------------------
+
+def update_global_rib(new_rows: List[dict], old_rows: List[dict], ifindex: Dict[str, int]) -> List[dict]:
+    """holo-ospf/src/route.rs:856-916 + ibus::tx::route_install / route_uninstall (holo-ospf/src/ibus/tx.rs:32-77) on rows
+    shaped like the YANG `local-rib` list (compute_spf_intra_area's rows, plus whatever inter-area / external rows the
+    calculations outside this path produced: the comparison does not look at the route type).  New RIB in
+    BTreeMap<IpNetwork, _> order: the prefix leaves the old RIB; equal metric and equal next-hop set -> nothing to send
+    (:875-885); otherwise a RouteIpAdd unless the route is CONNECTED or has no next hops (:887-901) — a route is
+    CONNECTED iff none of its next hops carries an address (the vertex is a hops-0 network: `Ospfv2::calc_nexthops`
+    yields (iface, None), ospfv2/spf.rs:296-302) —, next hops as the BTreeSet of Nexthop::Address { ifindex, addr } the
+    message carries; then a RouteIpDel for every installed route the old RIB still holds (:908-914).  Messages in emission
+    order: what the reference recorded on the ibus for its step tests (tests/test_host_ospf.py)."""
+    import ipaddress
+
+    def installed(r) -> bool:
+        return any(a is not None for a, _ in r["nexthops"])
+
+    def nh_set(r):
+        return sorted((str(a), str(i)) for a, i in r["nexthops"])
+    old = {_net_key(r["prefix"]): r for r in old_rows}
+    msgs: List[dict] = []
+    for r in sorted(new_rows, key=lambda r: _net_key(r["prefix"])):
+        o = old.pop(_net_key(r["prefix"]), None)
+        if o is not None and o["metric"] == r["metric"] and nh_set(o) == nh_set(r):
+            continue
+        if installed(r):
+            nhs = sorted(((ifindex[ifname], addr) for addr, ifname in r["nexthops"]),
+                         key=lambda t: (t[0], int(ipaddress.ip_address(t[1]))))
+            msgs.append({"op": "add", "prefix": r["prefix"], "metric": r["metric"], "nexthops": [list(t) for t in nhs]})
+    for k in sorted(old):
+        if installed(old[k]):
+            msgs.append({"op": "del", "prefix": old[k]["prefix"]})
+    return msgs

@@ -95,6 +95,22 @@ def test_ospf_device_routes_reproduce_reference_intra_area_rib(spf_ctx, path):
         assert got == want
 
 
+OSPF_WIRE = [p for p in sorted(glob.glob(os.path.join(GOLD, "ospfv2_steps", "*.json"))) if "ibus_routes" in json.load(open(p))]
+
+
+@pytest.mark.parametrize("path", OSPF_WIRE, ids=[os.path.basename(p)[:-5] for p in OSPF_WIRE])
+def test_ospf_wire_step_from_device_routes_reproduces_recorded_ibus_messages(spf_ctx, path):
+    """SURVEY.md 8f-4 for OSPFv2: SPT and both prefix reductions of every area on the device, the fold into the RIB and
+    the wire step (holo_amd.ospf.update_global_rib) on the host: the RouteIpAdd / RouteIpDel sequence the reference
+    recorded for the step (inter-area rows, where a step has any, come from the recording)."""
+    vec = json.load(open(path))
+    want = [{k: m[k] for k in m if k != "distance"} for m in vec["ibus_routes"]]
+    areas = [HO.Area.from_vector(a) for a in vec["areas"]]
+    rows = RT.ospf_intra_area_device_routes(vec["router_id"], areas, vec["max_paths"], spf_ctx)
+    rows = rows + [r for r in vec["rib"] if r["type"] != "intra-area"]
+    assert HO.update_global_rib(rows, vec["rib_before"], vec["ifindex"]) == want
+
+
 @pytest.mark.parametrize("seed", range(3))
 @pytest.mark.parametrize("mode", [E.PFX_SATURATING, E.PFX_SATURATING | E.PFX_LAST_MIN, E.PFX_LAST_MIN])
 def test_device_routes_ospf_rules_many_roots_vs_restatement(spf_ctx, seed, mode):

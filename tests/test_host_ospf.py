@@ -41,6 +41,29 @@ def test_run_area_and_intra_area_rib(path):
     check_ospf_vector(json.load(open(path)), OracleEngine())
 
 
+OSPF_STEPS = [p for p in sorted(glob.glob(os.path.join(GOLD, "ospfv2_steps", "*.json"))) if "ibus_routes" in json.load(open(p))]
+
+
+def wire_rows(vec, intra_rows):
+    """The RIB after the step as the wire step sees it: this path's intra-area rows + the rows of the calculations
+    outside it (inter-area, external), which the vectors record."""
+    return intra_rows + [r for r in vec["rib"] if r["type"] != "intra-area"]
+
+
+@pytest.mark.parametrize("path", OSPF_STEPS, ids=[os.path.basename(p)[:-5] for p in OSPF_STEPS])
+def test_update_global_rib_reproduces_recorded_ibus_messages(path):
+    """SPF + intra-area route build of the host twin, then the wire step: the RouteIpAdd / RouteIpDel messages the
+    reference recorded on the ibus for the step, in order (7 of the 11 steps hold intra-area routes only; the other four
+    take their inter-area rows from the recording: that calculation is outside this path)."""
+    vec = json.load(open(path))
+    want = [{k: m[k] for k in m if k != "distance"} for m in vec["ibus_routes"]]
+    areas = [HO.Area.from_vector(a) for a in vec["areas"]]
+    rows = HO.compute_spf_intra_area(vec["router_id"], areas, vec["max_paths"], OracleEngine())
+    got = HO.update_global_rib(wire_rows(vec, rows), vec["rib_before"], vec["ifindex"])
+    assert got == want
+    assert got == RO.update_global_rib(wire_rows(vec, RO.intra_area_rib(vec)), vec["rib_before"], vec["ifindex"])
+
+
 # ---- OSPFv3 -----------------------------------------------------------------------------------------
 from holo_amd import ospfv3 as H3        # noqa: E402
 from oracle import ospfv3_ref as R3      # noqa: E402
