@@ -114,7 +114,10 @@ struct hspf_ctx {
   std::string last_error;
   hipEvent_t ev[6] = {};
   // scratch (grown on demand, reused across runs)
-  DevBuf dist, hv, mask, lane_flags, changed, st64, stamp, hnb, kcnt;
+  DevBuf dist, hv, mask, lane_flags, changed, st64, stamp, hnb, kcnt, swcnt;
+  std::vector<uint8_t> lean_sched;   // k_fused_lean's mode per sweep, learned on an earlier run of (lean_sched_graph, same upload block)
+  const void *lean_sched_graph = nullptr;
+  uint32_t lean_sched_roots = 0, lean_dense_pct = 90;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
@@ -188,10 +191,11 @@ int guarded(hspf_ctx *ctx, F &&body) {
   }
 }
 
-int ensure(hspf_ctx *ctx, DevBuf &b, size_t bytes) {
+// run_scratch = false: a buffer that neither the prefilled scratch nor the run's upload block refers to (graph-patch
+// staging, sweep counters): growing it leaves both valid
+int ensure(hspf_ctx *ctx, DevBuf &b, size_t bytes, bool run_scratch = true) {
   if (bytes <= b.cap) return HSPF_OK;
-  ctx->prefill.valid = false;
-  ctx->up_valid = false;
+  if (run_scratch) { ctx->prefill.valid = false; ctx->up_valid = false; }
   if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
   size_t want = bytes + bytes / 8;
   hipError_t e = hipMalloc(&b.p, want);
@@ -497,6 +501,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   ctx->device = device_ordinal;
   if (const char *v = getenv("HSPF_VARIANT")) ctx->variant = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_SINGLE_MAX_N")) ctx->single_max_n = (uint32_t)strtoul(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_DENSE_PCT")) ctx->lean_dense_pct = (uint32_t)strtoul(v, nullptr, 0);   // rows due (% of all) from which a sweep of k_fused_lean runs dense
   if (const char *v = getenv("HSPF_LV_MAX_ROOTS")) ctx->lv_max_roots = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_LV_MIN_N")) ctx->lv_min_n = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_XCD_ROW_COST")) ctx->xcd_row_cost = (uint32_t)strtoul(v, nullptr, 0);
@@ -519,7 +524,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->kcnt, &ctx->pack})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->kcnt, &ctx->pack, &ctx->swcnt})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
@@ -643,7 +648,7 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
         const uint32_t nt = (uint32_t)tg.size();
         // one staging block, one copy: PatchInfo | changed[m] | dptr[m + 1] | dmet[de] | targets[nt]
         const size_t words = 4 + (size_t)m + (m + 1) + de + nt;
-        int rc = ensure(ctx, ctx->gb_delta, words * 4);
+        int rc = ensure(ctx, ctx->gb_delta, words * 4, false);
         if (rc != HSPF_OK) return rc;
         if (ctx->h_patch_cap < words) {
           (void)hipStreamSynchronize(s);
@@ -779,6 +784,7 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
   for (uint32_t j = 0; j < m; ++j) g->vflags[rows->vertex[j]] = rows->vflags[j];
   g->row_ptr.swap(nrp);
   g->col.swap(ncol);
+  if (ctx->lean_sched_graph == (const void *)g) ctx->lean_sched_graph = nullptr;    // another topology: the sweep schedule is learned again
   rc = build_on_device(ctx, g);
   if (rc != HSPF_OK) (void)hipStreamSynchronize(s);
   return rc;
@@ -835,6 +841,7 @@ void hspf_graph_free(hspf_ctx *ctx, hspf_graph *g) {
   if (!g) return;
   if (ctx) { (void)hipSetDevice(ctx->device); if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); }
   if (g->arena) (void)hipFree(g->arena);
+  if (ctx && ctx->lean_sched_graph == (const void *)g) ctx->lean_sched_graph = nullptr;
   delete g;
 }
 
@@ -1086,6 +1093,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   const uint32_t net_nh = (run_flags & HSPF_RUN_NET_NEXTHOPS) ? 1u : 0u;
 
   // ---- upload roots / slot tables / descriptor (one pinned block, one copy), init state
+  bool same_block = false;          // this run's block is byte for byte the previous run's (same roots, tables, graph arrays)
   {
     uint32_t *h = ctx->h_up + (ctx->h_up_sel ? ctx->h_up_cap / 8 : 0);
     const uint32_t *prev = ctx->h_up + (ctx->h_up_sel ? 0 : ctx->h_up_cap / 8);
@@ -1103,6 +1111,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     // 14 keeps it).  Otherwise the halves swap: the block just built becomes the reference.
     st.dbg[2] = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_entry).count();
     const bool same = ctx->up_valid && ctx->up_len == up_bytes && !(ctx->variant & 16384u) && memcmp(h, prev, up_bytes) == 0;
+    same_block = same;
     if (!same) {
       HIPCHK(ctx, hipMemcpyAsync(d_up, h, up_bytes, hipMemcpyHostToDevice, s));
       ctx->up_valid = true; ctx->up_len = up_bytes; ctx->h_up_sel ^= 1;
@@ -1234,13 +1243,36 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L, ns);
       uint32_t n_f = 0;
       const bool maxinf = g->max_path_metric == HSPF_DIST_INF;
+      // The lean sweep's mode schedule (k_fused_lean): an SPF instance repeats its runs — same graph handle, same
+      // roots, costs patched in between —, and which sweeps are dense is a property of the topology and the roots.  The
+      // first run of a (graph, upload block) is plain mode 0; when the next run brings the same block again, it counts
+      // the rows evaluated per sweep (LEARN), and the runs after that follow the schedule.  A stale schedule costs time,
+      // never correctness (modes 1 / 2 evaluate a superset of the due rows).  HSPF_VARIANT bit19: always mode 0.
+      const bool sched_want = use_lean && !count_rows && !(ctx->variant & 524288u) && same_block;
+      const bool sched_on = sched_want && ctx->lean_sched_graph == (const void *)g && ctx->lean_sched_roots == n_roots;
+      const bool learn = sched_want && !sched_on;
+      if (learn) {
+        int e2 = ensure(ctx, ctx->swcnt, 256 * 256 * 4, false);
+        if (e2) return e2;
+        if (hipMemsetAsync(ctx->swcnt.p, 0, 256 * 256 * 4, s) != hipSuccess) { ctx->last_error = "sweep counters"; return HSPF_E_HIP; }
+      } else if (use_lean) {
+        int e2 = ensure(ctx, ctx->swcnt, 256 * 256 * 4, false);      // (the kernel takes the pointer in every mode)
+        if (e2) return e2;
+      }
       int r2 = run_phase(ctx->est_fused, pre_zeroed, [&](uint32_t sweep) {
 #define HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, UN_, stp_) hipLaunchKernelGGL((k_fused<ST_, MI_, CN_, UN_>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, gd.in_ptr, gd.out_ptr, gd.vflags, stp_, d_roots, d_lf, net_nh, ignore_ovl, P, gd.in_src, gd.in_w, gd.out_dst, gd.e_in)
 #define HSPF_LAUNCH_FUSED(ST_, MI_, CN_, stp_) do { if (units) HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, true, stp_); else HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, false, stp_); } while (0)
         const bool units = g->n_heavy_chunks != 0;
         if (use_lean) {
-          if (count_rows) hipLaunchKernelGGL((k_fused_lean<true>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P);
-          else            hipLaunchKernelGGL((k_fused_lean<false>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P);
+#define HSPF_LAUNCH_LEAN(CN_, MD_, LR_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, LR_>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, (uint32_t *)ctx->swcnt.p)
+          const int md = (sched_on && sweep < ctx->lean_sched.size()) ? ctx->lean_sched[sweep] : 0;
+          if (md == 1) ++st.dbg[1];                                   // hspf_stats::dbg[1] (lean sweep): launches in dense mode
+          if (count_rows)  HSPF_LAUNCH_LEAN(true, 0, false);
+          else if (learn)  HSPF_LAUNCH_LEAN(false, 0, true);
+          else if (md == 1) HSPF_LAUNCH_LEAN(false, 1, false);
+          else if (md == 2) HSPF_LAUNCH_LEAN(false, 2, false);
+          else             HSPF_LAUNCH_LEAN(false, 0, false);
+#undef HSPF_LAUNCH_LEAN
           return;
         }
         if (giant) {                                   // slices of the due giant rows, ahead of the sweep that merges them
@@ -1276,6 +1308,23 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       ctx->est_fused = n_f + 1;
       st.n_relax_launches += n_f;
       if (count_rows) for (uint32_t i = 0; i < 256; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
+      if (learn) {
+        // rows evaluated per sweep -> dense where (nearly) every row was due, then ONE all-due stamped sweep
+        std::vector<uint32_t> cnt(256 * 256);
+        if (hipMemcpy(cnt.data(), ctx->swcnt.p, cnt.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { ctx->last_error = "sweep counters"; return HSPF_E_HIP; }
+        const uint64_t all = (uint64_t)n * B;
+        const uint32_t ns_ = std::min<uint32_t>(n_f, 256u);
+        ctx->lean_sched.assign(ns_ + 1u, 0);
+        for (uint32_t sw = 0; sw < ns_; ++sw) {
+          uint64_t rows_ = 0;
+          for (uint32_t k = 0; k < 256; ++k) rows_ += cnt[sw * 256 + k];
+          if (rows_ * 100u >= all * (uint64_t)ctx->lean_dense_pct) ctx->lean_sched[sw] = 1;
+        }
+        for (uint32_t sw = 0; sw < ns_; ++sw)
+          if (ctx->lean_sched[sw] == 1 && ctx->lean_sched[sw + 1] != 1) ctx->lean_sched[sw + 1] = 2;
+        if (ns_ && ctx->lean_sched[0] == 1) ctx->lean_sched[0] = 2;     // (the first sweep follows k_init_fused's stamps; never dense in practice)
+        ctx->lean_sched_graph = (const void *)g; ctx->lean_sched_roots = n_roots;
+      }
       return HSPF_OK;
     };
     // Small graphs: one workgroup per root, the whole state in LDS, ONE launch (k_single) instead of a launch per sweep.

@@ -1145,12 +1145,21 @@ __device__ __forceinline__ LeanOut lean_case(__amdgpu_buffer_rsrc_t rs, uint32_t
   return lean_reduce<L>(c, wk, paym);
 }
 
-template <bool COUNT>
+// MODE (chosen per launch by the host from the schedule it LEARNed on the previous run of the same graph and roots):
+//   0  stamped: a row is due when an in-neighbour changed in the previous sweep (activation stamps), the form above;
+//   1  dense:   every row is evaluated, no stamp is read or written — in the middle of a run (sweeps ~4-19 of 28 on
+//               isis-100k) every row IS due, and the stamps cost a dependent round trip at the head of every wave
+//               (stamps before records), a 64-byte offset row per vertex and a scattered store per changed row;
+//   2  all due, stamped: the first sweep after a dense stretch (the stamps are stale: every row is evaluated, changed rows
+//               stamp their out-neighbours again, and mode 0 can follow).
+// Any schedule is correct: modes 1 and 2 evaluate a superset of the due rows.  LEARN (mode 0 only): rows evaluated per
+// sweep, added to swcnt[256 sweep + ...] (first 256 sweeps; 256 counters per sweep: 25 000 waves adding to 16 took 5 ms a run).
+template <bool COUNT, int MODE, bool LEARN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fused_lean(
     const FusedGraph *__restrict__ gp, int *changed, int sweep, uint32_t *__restrict__ act,
     const uint8_t *__restrict__ hnb, uint32_t n_arg, const uint32_t *__restrict__ ell_so, const uint32_t *__restrict__ ell_w,
     uint32_t *__restrict__ st, const uint32_t *__restrict__ ell_od, const uint32_t *__restrict__ roots, uint32_t *lane_flags,
-    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P) {
+    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P, uint32_t *__restrict__ swcnt) {
   typedef uint32_t ST;
   if (sweep > 0 && changed[sweep - 1] == 0) return;
   const uint32_t lane = threadIdx.x & 63u;
@@ -1166,10 +1175,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
   // ---- stamps and flags first: in the sparse head and tail of a run most waves end here, and what the sweep is short
   // of is vector memory instructions, not round trips (profiles/r03_notes.md)
   const uint32_t vl = min(wbeg + min(lane, (uint32_t)VPW - 1u), n - 1);
-  const uint32_t av = A[vl];
+  const uint32_t av = MODE == 0 ? A[vl] : cur;
   const uint32_t hb = hnb[(size_t)batch * n + vl] & (ignore_ovl ? ~RF_NT : ~0u);
   const uint32_t due4 = (uint32_t)__ballot(lane < (uint32_t)VPW && wbeg + lane < n && av >= cur);
-  if (due4 == 0u) return;
+  if (MODE == 0 && due4 == 0u) return;
   // ---- everything else whose address depends on the wave's vertex range alone (ELL row n exists: all pad)
   ST *S = st + (size_t)batch * (n + 1u) * 64;                      // slab of n + 1 rows: row n = the pad row (never reached)
   const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, (n + 1u) << 8);
@@ -1180,7 +1189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
     const uint32_t e = (min(wbeg + i, n) * 16u + (lane & 15u)) * 4u;          // byte offset into the ELL arrays (n < 2^23)
     sov[i] = *(const uint32_t *)((const char *)ell_so + e);
     wk[i] = *(const uint32_t *)((const char *)ell_w + e);
-    od[i] = *(const uint32_t *)((const char *)ell_od + e);
+    od[i] = MODE == 1 ? 0u : *(const uint32_t *)((const char *)ell_od + e);
     oldq[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, min(wbeg + i, n - 1) << 8, 0);
   }
   const uint32_t fast4 = (uint32_t)__ballot(lane < (uint32_t)VPW && hb == 0u) & due4;
@@ -1208,6 +1217,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
     if (ch == 0ull) return;
     __builtin_amdgcn_raw_buffer_store_b32(nw, rs, lane4, v << 8, 0);          // the whole row: unchanged lanes rewrite their own value
     any |= ch;
+    if (MODE == 1) return;                                                    // dense: nobody reads stamps
     if (!(info[i] & 0x20u)) { __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, od[i], 0, 0); return; }   // wake the out-neighbours up
     const GraphDev &g = gp->g;
     const uint32_t o0 = g.out_ptr[v], o1 = g.out_ptr[v + 1];
@@ -1258,11 +1268,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
     if (ch == 0ull) continue;
     __builtin_amdgcn_raw_buffer_store_b32(r.nw, rs, lane4, v << 8, 0);
     any |= ch;
+    if (MODE == 1) continue;
     const uint32_t o0 = g.out_ptr[v], o1 = g.out_ptr[v + 1];
     for (uint32_t ob = o0 + lane; ob < o1; ob += 64) __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, g.out_dst[ob] * 4u, 0, 0);
   }
   if (any != 0ull && lane == 0) changed[sweep] = 1;
   if (COUNT && lane == 0) atomicAdd(&gp->rows_done[(blockIdx.x + wave) & 255u], n_done);
+  if (LEARN && lane == 0 && sweep < 256) atomicAdd(&swcnt[(uint32_t)sweep * 256u + ((blockIdx.x * 4u + wave) & 255u)], (uint32_t)__builtin_popcount(due4));
   uint32_t lf = 0;
   if (need_exact) lf |= LF_NEED_EXACT;
   if (lf) atomicOr(&lane_flags[root_slot], lf);

@@ -30,7 +30,7 @@ def test_random_layouts_and_arbitrary_row_patches_against_the_restatement(spf_ct
     # spf=True: after every round of arbitrary row replacements (links between any two vertices, any flags) an SPF
     # run on whatever graph that made, against the oracle
     ok, runs = gpu_fuzz.fuzz_layout(spf_ctx, 0, 40, verbose=False, spf=True)
-    assert ok == runs and runs == 240
+    assert ok == runs and runs >= 240          # 40 graphs x 3 rounds x (layout + SPF), plus the in-place cost patches
 
 
 def test_random_prefix_tables_on_device_against_the_restatement(spf_ctx):

@@ -722,3 +722,55 @@ def test_fattree_full_size_leaves_deferred(spf_ctx):
                  threads=ORACLE_THREADS)
     assert np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops)
     assert np.array_equal(res.flags & 1, ref.flags) and np.array_equal(res.first_hop_mask, ref.mask)
+
+
+# ---- the lean sweep's learned mode schedule (dense sweeps without activation stamps) --------------------------------
+
+@sweeps_engine
+@pytest.mark.parametrize("shape", ["grid", "isis-100k"])
+def test_lean_dense_schedule_repeated_runs(spf_ctx, shape):
+    """An instance that repeats a run (same graph handle, same roots) gets k_fused_lean's mode schedule from its own
+    second run: dense sweeps (no stamps read or written), one all-due stamped sweep after them.  Every run of the
+    sequence — plain, learning, scheduled, scheduled after a cost patch, plain again after a change of roots — equals
+    the oracle bit for bit; hspf_stats::dbg[1] shows the dense launches."""
+    if shape == "grid":
+        side = 30                                       # (hop counts stay inside the 4-byte state's 7 hop bits)
+        idx = np.arange(side * side).reshape(side, side)
+        a = np.concatenate([idx[:, :-1].ravel(), idx[:-1, :].ravel(), idx[:-1, :-1].ravel()])
+        b = np.concatenate([idx[:, 1:].ravel(), idx[1:, :].ravel(), idx[1:, 1:].ravel()])
+        rng = np.random.default_rng(8)
+        m = rng.integers(1, 30, len(a))
+        row_ptr, col, met = synth._csr_from_links(side * side, np.concatenate([a, b]), np.concatenate([b, a]), np.concatenate([m, m]))
+        g = synth.CsrGraph(row_ptr, col, met, np.zeros(side * side, np.uint8), synth.MAX_PATH_METRIC_WIDE)
+        roots = (np.arange(64, dtype=np.int64) * g.n // 64).astype(np.uint32)
+    else:
+        g = synth.isis_100k()
+        roots = (np.arange(64, dtype=np.int64) * g.n // 64).astype(np.uint32)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+
+    def one(rts, graph):
+        res = spf_ctx.run(G, rts, 0)
+        ref = go.run(graph.row_ptr, graph.col, graph.metric, graph.vflags, graph.max_path_metric, rts, 0, go.HEAP,
+                     mask_words_=res.first_hop_mask.shape[2], threads=ORACLE_THREADS)
+        assert np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops)
+        assert np.array_equal(res.flags & 1, ref.flags) and np.array_equal(res.first_hop_mask, ref.mask)
+        return res.stats
+    try:
+        dense = []
+        for _ in range(6):
+            st = one(roots, g)
+            assert st["state_bytes"] == 4 and st["dbg"][0] == 1
+            dense.append(st["dbg"][1])
+        # plain run(s), the learning run, then the schedule: from its first use on, the same number of dense launches
+        first = next(i for i, x in enumerate(dense) if x > 0)
+        assert 2 <= first <= 3 and all(x == dense[first] for x in dense[first:]), dense
+        dense = [0, 0, dense[first]]
+        u = g.n // 3
+        a0, b0 = int(g.row_ptr[u]), int(g.row_ptr[u + 1])
+        G.patch([u], [(g.col[a0:b0], g.metric[a0:b0] + 3)], [g.vflags[u]])                     # costs only: the schedule stays
+        g2 = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
+        assert one(roots, g2)["dbg"][1] == dense[2]
+        other = ((roots.astype(np.int64) + 11) % g.n).astype(np.uint32)
+        assert one(other, g2)["dbg"][1] == 0                                                    # other roots: plain again
+    finally:
+        G.free()
