@@ -196,6 +196,7 @@ def pipeline_1root(ctx, dev) -> dict:
     the route table and the record stream of the last iteration are checked against the oracle and a numpy fold."""
     import torch
     from holo_amd import synth
+    from holo_amd import engine as E
     from oracle import graph_oracle as go
     g = synth.isis_100k()
     n = g.n
@@ -233,7 +234,8 @@ def pipeline_1root(ctx, dev) -> dict:
         ctx.run_device(G, roots, 0, dist_ptr=d.data_ptr(), hops_ptr=h.data_ptr(), flags_ptr=f.data_ptr(), mask_ptr=m.data_ptr(), mask_words=W)
         t.append(time.perf_counter())
         ctx.routes_device(n, 1, W, d.data_ptr(), f.data_ptr(), m.data_ptr(), ptr, vtx, met, best_metric_ptr=sets[cur ^ 1][0].data_ptr(),
-                          best_entry_ptr=sets[cur ^ 1][1].data_ptr(), nexthop_mask_ptr=sets[cur ^ 1][2].data_ptr())
+                          best_entry_ptr=sets[cur ^ 1][1].data_ptr(), nexthop_mask_ptr=sets[cur ^ 1][2].data_ptr(),
+                          flags=E.PFX_RESIDENT)                  # the prefix table did not change: a metric refresh, not a new prefix
         t.append(time.perf_counter())
         ctx.routes_diff_device(1, P, W, tuple(x.data_ptr() for x in sets[cur]), tuple(x.data_ptr() for x in sets[cur ^ 1]),
                                action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(), changed_ptr_ptr=cptr.data_ptr())

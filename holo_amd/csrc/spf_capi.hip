@@ -121,6 +121,9 @@ struct hspf_ctx {
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
+  bool pf_shadow_ok = false;                        // the device holds a plain table; what it was uploaded from (HSPF_PFX_RESIDENT):
+  uint32_t pf_shadow_nv = 0, pf_res_np = 0, pf_res_ne = 0;
+  const void *pf_res_ptr = nullptr, *pf_res_vtx = nullptr, *pf_res_met = nullptr;
   DevBuf pack;                                      // record stream of hspf_routes_pack
   uint32_t last_diff_count = 0;                     // changed pairs of the last hspf_routes_diff_device (hspf_routes_diff_count)
   DevBuf gb, gb_delta, gb_hub, giant_part;                      // graph build scratch, patch delta, hub-mode sort buffers
@@ -1740,29 +1743,47 @@ static int routes_device_impl(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roo
   if (!ctx || !t || !out || !dist_dev || !flags_dev || !mask_dev || !out->best_metric || !out->best_entry ||
       !out->nexthop_mask || n_roots == 0 || n_mask_words == 0 || !t->pfx_ptr || (t->n_entries && (!t->pfx_vertex || !t->pfx_metric)))
     return HSPF_E_INVAL;
-  if (t->flags & ~(HSPF_PFX_SATURATING | HSPF_PFX_LAST_MIN | HSPF_PFX_ORDERED)) { ctx->last_error = "hspf_prefix_table: unknown flags"; return HSPF_E_INVAL; }
+  if (t->flags & ~(HSPF_PFX_SATURATING | HSPF_PFX_LAST_MIN | HSPF_PFX_ORDERED | HSPF_PFX_RESIDENT)) { ctx->last_error = "hspf_prefix_table: unknown flags"; return HSPF_E_INVAL; }
   const bool ordered = (t->flags & HSPF_PFX_ORDERED) != 0;
   if (ordered && ((t->flags & HSPF_PFX_LAST_MIN) || (t->n_entries && !t->pfx_origin) ||
                   (t->init_exists && (!t->init_metric || !t->init_origin)))) {
     ctx->last_error = "hspf_prefix_table: HSPF_PFX_ORDERED needs pfx_origin (and init_metric / init_origin with init_exists), not LAST_MIN";
     return HSPF_E_INVAL;
   }
-  if (t->pfx_ptr[0] != 0 || t->pfx_ptr[t->n_prefixes] != t->n_entries) { ctx->last_error = "pfx_ptr malformed"; return HSPF_E_INVAL; }
-  for (uint32_t p = 0; p < t->n_prefixes; ++p)
-    if (t->pfx_ptr[p + 1] < t->pfx_ptr[p]) { ctx->last_error = "pfx_ptr not monotone"; return HSPF_E_INVAL; }
-  for (uint32_t e = 0; e < t->n_entries; ++e)
-    if ((ordered ? (t->pfx_vertex[e] & ~HSPF_PFX_ENTRY_NETWORK) : t->pfx_vertex[e]) >= n_vertices) { ctx->last_error = "pfx_vertex out of range"; return HSPF_E_INVAL; }
+  // A prefix table changes with the LSDB, not with every SPF run.  HSPF_PFX_RESIDENT is the caller's word that the three
+  // main arrays are exactly what its previous call on this context passed (same pointers, same sizes, contents untouched):
+  // the checks and the three pageable copies — most of the call at 120 000 prefixes — are skipped.  Anything that does not
+  // match what was recorded then takes the full path.  Ordered tables (origins, initial state) always do.
+  const size_t np1 = (size_t)t->n_prefixes + 1, ne_ = t->n_entries;
+  const bool resident = (t->flags & HSPF_PFX_RESIDENT) && !ordered && ctx->pf_shadow_ok && ctx->pf_shadow_nv == n_vertices &&
+                        ctx->pf_res_np == t->n_prefixes && ctx->pf_res_ne == t->n_entries && ctx->pf_res_ptr == (const void *)t->pfx_ptr &&
+                        ctx->pf_res_vtx == (const void *)t->pfx_vertex && ctx->pf_res_met == (const void *)t->pfx_metric;
+  if (!resident) {
+    ctx->pf_shadow_ok = false;
+    if (t->pfx_ptr[0] != 0 || t->pfx_ptr[t->n_prefixes] != t->n_entries) { ctx->last_error = "pfx_ptr malformed"; return HSPF_E_INVAL; }
+    for (uint32_t p = 0; p < t->n_prefixes; ++p)
+      if (t->pfx_ptr[p + 1] < t->pfx_ptr[p]) { ctx->last_error = "pfx_ptr not monotone"; return HSPF_E_INVAL; }
+    for (uint32_t e = 0; e < t->n_entries; ++e)
+      if ((ordered ? (t->pfx_vertex[e] & ~HSPF_PFX_ENTRY_NETWORK) : t->pfx_vertex[e]) >= n_vertices) { ctx->last_error = "pfx_vertex out of range"; return HSPF_E_INVAL; }
+  }
   if (t->n_prefixes == 0) return HSPF_OK;
   (void)hipSetDevice(ctx->device);
   int rc;
-  if ((rc = ensure(ctx, ctx->pf_ptr, (size_t)(t->n_prefixes + 1) * 4))) return rc;
-  if ((rc = ensure(ctx, ctx->pf_vtx, std::max<size_t>(t->n_entries, 1) * 4))) return rc;
-  if ((rc = ensure(ctx, ctx->pf_met, std::max<size_t>(t->n_entries, 1) * 4))) return rc;
   hipStream_t s = ctx->stream;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->pf_ptr.p, t->pfx_ptr, (size_t)(t->n_prefixes + 1) * 4, hipMemcpyHostToDevice, s));
-  if (t->n_entries) {
-    HIPCHK(ctx, hipMemcpyAsync(ctx->pf_vtx.p, t->pfx_vertex, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->pf_met.p, t->pfx_metric, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
+  if (!resident) {
+    if ((rc = ensure(ctx, ctx->pf_ptr, (size_t)(t->n_prefixes + 1) * 4, false))) return rc;
+    if ((rc = ensure(ctx, ctx->pf_vtx, std::max<size_t>(t->n_entries, 1) * 4, false))) return rc;
+    if ((rc = ensure(ctx, ctx->pf_met, std::max<size_t>(t->n_entries, 1) * 4, false))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pf_ptr.p, t->pfx_ptr, (size_t)(t->n_prefixes + 1) * 4, hipMemcpyHostToDevice, s));
+    if (t->n_entries) {
+      HIPCHK(ctx, hipMemcpyAsync(ctx->pf_vtx.p, t->pfx_vertex, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->pf_met.p, t->pfx_metric, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
+    }
+    if (!ordered) {
+      ctx->pf_res_np = t->n_prefixes; ctx->pf_res_ne = t->n_entries; ctx->pf_res_ptr = t->pfx_ptr; ctx->pf_res_vtx = t->pfx_vertex;
+      ctx->pf_res_met = t->pfx_metric; ctx->pf_shadow_nv = n_vertices;
+      ctx->pf_shadow_ok = true;       // (the copies above are enqueued on the context's stream: every later use is ordered behind them)
+    }
   }
   const uint8_t *d_iex = nullptr;
   const uint32_t *d_imet = nullptr, *d_iorg = nullptr;

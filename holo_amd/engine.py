@@ -25,6 +25,7 @@ E_TOO_MANY_SLOTS = -5
 PFX_SATURATING = 0x1
 PFX_LAST_MIN = 0x2
 PFX_ORDERED = 0x4
+PFX_RESIDENT = 0x8        # the three main arrays are what the previous routes_device call on this context passed
 PFX_ENTRY_NETWORK = 0x80000000
 PFX_KEPT_INIT = 0xFFFFFFFE
 DIFF_SAME, DIFF_INSTALL, DIFF_WITHDRAW, DIFF_SILENT = 0, 1, 2, 3

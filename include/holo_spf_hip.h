@@ -308,6 +308,14 @@ int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out);
  *                         and nexthop_mask holds what the table's entries merged INTO it.
  */
 #define HSPF_PFX_ORDERED    0x4u
+/*
+ *   HSPF_PFX_RESIDENT     the caller's word that pfx_ptr / pfx_vertex / pfx_metric are exactly what its previous
+ *                         hspf_routes_device call on this context passed (same pointers, same sizes, contents
+ *                         untouched since — a prefix table changes with the LSDB, not with every SPF run): the range
+ *                         checks and the host-to-device copies are skipped.  A table that does not match what was
+ *                         recorded then (or an ordered one) is uploaded as usual.
+ */
+#define HSPF_PFX_RESIDENT   0x8u
 #define HSPF_PFX_ENTRY_NETWORK 0x80000000u
 #define HSPF_PFX_KEPT_INIT  0xFFFFFFFEu
 typedef struct {

@@ -344,3 +344,49 @@ def test_hand_off_from_device_tables_reproduces_recorded_ibus_messages(spf_ctx, 
     got, n_rec, n_pfx = RT.update_global_rib_device(inst, spf_ctx, vec["rib_before"], vec["ifindex"])
     assert got == want
     assert n_rec <= n_pfx and (n_pfx == 0 or n_rec <= len(want) + 4)
+
+
+def test_resident_prefix_table_skips_the_upload_and_gives_the_same_routes(spf_ctx):
+    """HSPF_PFX_RESIDENT: the second call with the caller's unchanged arrays skips checks and copies; results equal the
+    first call's; a table in OTHER arrays with the flag set is uploaded as usual (nothing recorded matches), and so is
+    the old table again afterwards."""
+    import torch
+    rng = np.random.default_rng(3)
+    g = synth.random_lsdb(120, 8, 3.0, 4711, metric_hi=5)
+    n = g.n
+    roots = np.arange(8, 8 + 20, dtype=np.uint32)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    dev = torch.device("cuda:0")
+    W, Rn = G.mask_words(roots), len(roots)
+    dist = torch.empty((Rn, n), dtype=torch.int32, device=dev); hops = torch.empty((Rn, n), dtype=torch.int16, device=dev)
+    flags = torch.empty((Rn, n), dtype=torch.int16, device=dev); mask = torch.empty((Rn, n, W), dtype=torch.int64, device=dev)
+    spf_ctx.run_device(G, roots, 0, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(), flags_ptr=flags.data_ptr(),
+                       mask_ptr=mask.data_ptr(), mask_words=W)
+    G.free()
+
+    def table(P, ne):
+        pfx = np.sort(rng.integers(0, P, ne)); vtx = rng.integers(0, n, ne)
+        order = np.lexsort((vtx, pfx))
+        ptr = np.zeros(P + 1, np.uint32); np.add.at(ptr, pfx + 1, 1)
+        return np.cumsum(ptr, dtype=np.uint64).astype(np.uint32), vtx[order].astype(np.uint32), rng.integers(0, 4, ne).astype(np.uint32)
+
+    def routes(t, fl):
+        P = len(t[0]) - 1
+        bm = torch.empty((Rn, P), dtype=torch.int32, device=dev); be = torch.empty((Rn, P), dtype=torch.int32, device=dev)
+        nm = torch.empty((Rn, P, W), dtype=torch.int64, device=dev)
+        spf_ctx.routes_device(n, Rn, W, dist.data_ptr(), flags.data_ptr(), mask.data_ptr(), t[0], t[1], t[2],
+                              best_metric_ptr=bm.data_ptr(), best_entry_ptr=be.data_ptr(), nexthop_mask_ptr=nm.data_ptr(), flags=fl)
+        return bm.cpu().numpy().copy(), be.cpu().numpy().copy(), nm.cpu().numpy().copy()
+    t1, t2 = table(300, 700), table(300, 700)
+    a = routes(t1, 0)
+    b = routes(t1, E.PFX_RESIDENT)
+    c = routes(t2, E.PFX_RESIDENT)                           # other arrays: not what was recorded -> full path
+    d = routes(t2, 0)
+    e = routes(t1, E.PFX_RESIDENT)                           # t2 is resident now: t1 is uploaded again
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    for x, y in zip(c, d):
+        assert np.array_equal(x, y)
+    for x, y in zip(a, e):
+        assert np.array_equal(x, y)
+    assert not np.array_equal(a[0], c[0])
