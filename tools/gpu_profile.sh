@@ -36,12 +36,16 @@ traffic = {}
 for k, v in out.items():
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         key = k.replace("hspf::", "").split("<")[0]
-        rec = {
-            "kernel": k, "fetch_kib_per_launch": v["FETCH_SIZE"]["mean_all"], "write_kib_per_launch": v["WRITE_SIZE"]["mean_all"],
-            "hbm_bytes_per_launch": int((2 * v["FETCH_SIZE"]["mean_all"] + v["WRITE_SIZE"]["mean_all"]) * 1024),
-            "launches_sampled": v["FETCH_SIZE"]["launches"], "fetch_correction": 2.0}
-        if key not in traffic or rec["launches_sampled"] > traffic[key]["launches_sampled"]:    # several instantiations: the one that ran most
-            traffic[key] = rec
+        nl = v["FETCH_SIZE"]["launches"]
+        t = traffic.setdefault(key, {"kernel": [], "fetch_kib_per_launch": 0.0, "write_kib_per_launch": 0.0, "launches_sampled": 0, "fetch_correction": 2.0})
+        # several instantiations of one kernel (k_fused_lean's launch modes): the mean over ALL their launches
+        t["fetch_kib_per_launch"] = (t["fetch_kib_per_launch"] * t["launches_sampled"] + v["FETCH_SIZE"]["mean_all"] * nl) / (t["launches_sampled"] + nl)
+        t["write_kib_per_launch"] = (t["write_kib_per_launch"] * t["launches_sampled"] + v["WRITE_SIZE"]["mean_all"] * v["WRITE_SIZE"]["launches"]) / (t["launches_sampled"] + nl)
+        t["launches_sampled"] += nl
+        t["kernel"].append(k)
+for t in traffic.values():
+    t["hbm_bytes_per_launch"] = int((2 * t["fetch_kib_per_launch"] + t["write_kib_per_launch"]) * 1024)
+    t["kernel"] = ", ".join(t["kernel"])
 json.dump(traffic, open("gpurun_out/prof/traffic.json", "w"), indent=1)
 print(json.dumps(traffic, indent=1))
 PY
