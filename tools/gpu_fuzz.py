@@ -71,6 +71,10 @@ def fuzz(ctx, first, count, verbose=True):
             runs += 1
             t_run = time.time()
             ok += compare(ctx, G, g, roots, flags, (seed, rep, flags, k))
+            if rng.random() < 0.12:                                  # an instance repeating its run: the lean sweep learns its mode schedule
+                for again in range(4):                                # (plain, learning, scheduled, scheduled)
+                    runs += 1
+                    ok += compare(ctx, G, g, roots, flags, (seed, rep, flags, k, "repeat", again))
             if os.environ.get("FUZZ_TIMING") and time.time() - t_run > float(os.environ["FUZZ_TIMING"]):
                 print(f"SLOW seed {seed} rep {rep} n {g.n} roots {k} flags {flags} hop {hop} maxpath {g.max_path_metric:#x}: {time.time() - t_run:.2f} s, stats {ctx.stats()}", flush=True)
             if rep < 2 and rng.random() < 0.5:                      # re-originate a few rows in between
