@@ -73,7 +73,7 @@ int main(int argc, char **argv) {
   CHECK(oracle, "oracle_spf_run");
 
   hspf::Engine eng(0);
-  int checked = 0;
+  int checked = 0, packed = 0;
   for (u32 seed = 0; seed < 6; ++seed)
     for (u32 flags : {0u, (u32)HSPF_RUN_NET_NEXTHOPS, (u32)HSPF_RUN_IGNORE_OVERLOAD}) {
       Lsdb g = make(120 + 37 * seed, 10 + seed, seed);
@@ -206,12 +206,46 @@ int main(int argc, char **argv) {
         }
       }
       CHECK(hp[R] == pos, "diff: total");
+      // the hand-off: the changed routes as ONE record stream, one copy
+      {
+        const u32 nrec = hspf_routes_diff_count(eng.raw());
+        CHECK(nrec == pos, "hspf_routes_diff_count");
+        const u32 rw = HSPF_ROUTE_REC_WORDS + 2 * W;
+        std::vector<u32> rec((size_t)nrec * rw);
+        CHECK(hspf_routes_pack(eng.raw(), R, P, W, &ro2, act, chg, cptr, nrec, rec.data()) == HSPF_OK, "hspf_routes_pack");
+        u32 k = 0;
+        for (u32 r = 0; r < R; ++r)
+          for (u32 q = hp[r]; q < hp[r + 1]; ++q, ++k) {
+            const u32 p = hc[q]; const size_t o = (size_t)r * P + p; const u32 *x = &rec[(size_t)k * rw];
+            CHECK(x[0] == r && x[1] == p && x[2] == ha[o] && x[3] == hb2[o] && x[4] == he2[o] && x[5] == 0, "packed record header");
+            for (u32 w = 0; w < W; ++w)
+              CHECK((((uint64_t)x[HSPF_ROUTE_REC_WORDS + 2 * w + 1] << 32) | x[HSPF_ROUTE_REC_WORDS + 2 * w]) == hn2[o * W + w], "packed record mask");
+          }
+        CHECK(k == nrec, "packed record count");
+        ++packed;
+      }
+      // HSPF_PFX_RESIDENT: the caller's unchanged plain table again (uploaded afresh after the ordered one), then resident
+      {
+        u32 *bm3, *be3; uint64_t *nm3;
+        hipMalloc(&bm3, (size_t)R * P * 4); hipMalloc(&be3, (size_t)R * P * 4); hipMalloc(&nm3, (size_t)R * P * 8 * W);
+        hspf_routes ro3{bm3, be3, nm3};
+        hspf_prefix_table tab3 = tab; tab3.flags |= HSPF_PFX_RESIDENT;
+        for (int pass = 0; pass < 2; ++pass) {                     // pass 0: nothing recorded matches (the ordered table was last) -> upload; pass 1: resident
+          hipMemset(bm3, 0xEE, (size_t)R * P * 4);
+          CHECK(hspf_routes_device(eng.raw(), n, R, W, dd, df, dm, &tab3, &ro3) == HSPF_OK, "hspf_routes_device (resident)");
+          std::vector<u32> hb3((size_t)R * P), he3((size_t)R * P); std::vector<uint64_t> hn3((size_t)R * P * W);
+          hipMemcpy(hb3.data(), bm3, hb3.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(he3.data(), be3, he3.size() * 4, hipMemcpyDeviceToHost);
+          hipMemcpy(hn3.data(), nm3, hn3.size() * 8, hipMemcpyDeviceToHost);
+          CHECK(hb3 == hbm && he3 == hbe && hn3 == hnm, "resident table: routes differ");
+        }
+        hipFree(bm3); hipFree(be3); hipFree(nm3);
+      }
       hipFree(bm2); hipFree(be2); hipFree(nm2); hipFree(act); hipFree(chg); hipFree(cptr);
     }
     hipFree(dd); hipFree(dh); hipFree(df); hipFree(dm); hipFree(bm); hipFree(be); hipFree(nm);
   }
   // incremental update: rows replaced through hspf::Graph::patch, results against the oracle on the patched CSR
-  int patched = 0;
+  int patched = 0, cost_patched = 0;
   {
     Lsdb g = make(150, 10, 21);
     hspf::Graph G = eng.upload(g.row_ptr, g.col, g.metric, g.vflags, 0xFE000000u);
@@ -252,6 +286,34 @@ int main(int argc, char **argv) {
       CHECK(d == t.dist && h == t.hops && m == t.mask, "patched graph differs from the oracle on the patched CSR");
       ++patched;
     }
+    // metric-only refreshes: same targets, order and flags -> applied in place (build mode 2), results as the oracle's
+    for (u32 round = 0; round < 4; ++round) {
+      std::vector<hspf::Graph::Row> rows;
+      for (u32 j = 0; j < 1 + 2 * round; ++j) {
+        const u32 u = 10 + rnd(150);
+        bool dup = false; for (auto &r : rows) dup |= r.vertex == u;
+        if (dup) continue;
+        hspf::Graph::Row row{u, {}, {}, g.vflags[u]};
+        for (u32 k = g.row_ptr[u]; k < g.row_ptr[u + 1]; ++k) {
+          if (g.col[k] >= 10) g.metric[k] = 1 + rnd(9);                          // links into a network keep their cost
+          row.col.push_back(g.col[k]); row.metric.push_back(g.metric[k]);
+        }
+        rows.push_back(row);
+      }
+      G.patch(rows);
+      u32 mode = 7; size_t got = 0;
+      CHECK(hspf_graph_export(eng.raw(), G.raw(), HSPF_GX_BUILD_MODE, &mode, 4, &got) == HSPF_OK && mode == 2, "cost-only patch must be applied in place");
+      hspf::Tables t = eng.run(G, roots, HSPF_RUN_NET_NEXTHOPS);
+      const size_t rn = (size_t)roots.size() * g.n;
+      std::vector<u32> d(rn), pr(rn), nn(rn), np(rn); std::vector<uint16_t> h(rn), f(rn); std::vector<uint64_t> m(rn * t.mask_words), wk(roots.size());
+      CHECK(oracle(g.n, (u32)g.col.size(), g.row_ptr.data(), g.col.data(), g.metric.data(), g.vflags.data(), 0xFE000000u,
+                   roots.data(), (u32)roots.size(), HSPF_RUN_NET_NEXTHOPS, 1, d.data(), h.data(), f.data(), pr.data(), m.data(),
+                   t.mask_words, nn.data(), np.data(), wk.data()) == 0, "oracle failed");
+      CHECK(d == t.dist && h == t.hops && m == t.mask, "cost-patched graph differs from the oracle");
+      ++cost_patched;
+    }
+    std::vector<uint8_t> leaf(g.n); size_t lb = 0;
+    CHECK(hspf_graph_export(eng.raw(), G.raw(), HSPF_GX_LEAF, leaf.data(), leaf.size(), &lb) == HSPF_OK && lb == g.n, "HSPF_GX_LEAF");
     hspf_rows bad{1, nullptr, nullptr, nullptr, nullptr, nullptr};
     CHECK(hspf_graph_patch(eng.raw(), G.raw(), &bad) == HSPF_E_INVAL, "NULL arrays in a patch must be HSPF_E_INVAL");
   }
@@ -344,6 +406,6 @@ int main(int argc, char **argv) {
       ++big_lan;
     }
   }
-  std::printf("capi_parity: %d graph runs bit-exact, %d patched generations bit-exact, error contract ok, device route derivation ok, %d sharded tables identical to the unsharded run, %d runs on a 3 000-router LAN (hub-mode build, giant row) bit-exact\n", checked, patched, sharded, big_lan);
+  std::printf("capi_parity: %d graph runs bit-exact, %d patched generations + %d in-place cost patches bit-exact, error contract ok, device route derivation ok, %d packed record stream(s) ok, %d sharded tables identical to the unsharded run, %d runs on a 3 000-router LAN (hub-mode build, giant row) bit-exact\n", checked, patched, cost_patched, packed, sharded, big_lan);
   return 0;
 }
