@@ -112,7 +112,7 @@ struct hspf_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = true;
   std::string last_error;
-  hipEvent_t ev[6] = {};
+  hipEvent_t ev[7] = {};             // [6]: behind the flag read-back of a chunk of sweeps (run_phase)
   // scratch (grown on demand, reused across runs)
   DevBuf dist, hv, mask, lane_flags, changed, st64, stamp, hnb, kcnt, swcnt;
   std::vector<uint8_t> lean_sched;   // k_fused_lean's mode per sweep, learned on an earlier run of (lean_sched_graph, same upload block)
@@ -1165,6 +1165,11 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // trip; after a chunk that did not converge it is simply enqueued again behind the next one.
   // pre_zeroed: how many leading sweep flags the caller's own init kernel has already cleared (0: cleared here)
   std::function<void()> on_retry;      // set by a path whose `post` leaves something behind that a non-final chunk must undo
+  // set by the fused path: enqueue the NEXT run's scratch fill behind this chunk's flag read-back, guarded on the device by
+  // "the chunk's last sweep changed nothing" (k_init_fill); run_phase then waits for the read-back only, and the fill
+  // (15 us + a launch latency) runs while the host wakes up, returns and prepares the next run.  Argument: index of
+  // the chunk's last sweep.
+  std::function<void(uint32_t)> spec_fill;
   auto run_phase = [&](uint32_t est, uint32_t pre_zeroed, auto &&launch, uint32_t &n_launch, auto &&post) -> int {
     hipError_t er = hipSuccess;
     uint32_t zeroed = std::min<uint32_t>(CHANGED_CAP, est + 4096);
@@ -1194,7 +1199,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       er = hipMemcpyAsync(ctx->h_changed, d_changed, (size_t)sweep * sizeof(int), hipMemcpyDeviceToHost, s);
       if (er == hipSuccess) er = hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s);
       if (er == hipSuccess && fused && count_rows) er = hipMemcpyAsync(ctx->h_lane_flags + L, d_kcnt, 256 * 4, hipMemcpyDeviceToHost, s);
-      if (er == hipSuccess) er = hipStreamSynchronize(s);
+      if (er == hipSuccess && spec_fill) {
+        er = hipEventRecord(ctx->ev[6], s);
+        if (er == hipSuccess) { spec_fill(sweep - 1u); er = hipEventSynchronize(ctx->ev[6]); }
+      } else if (er == hipSuccess) er = hipStreamSynchronize(s);
       if (er != hipSuccess) { ctx->last_error = std::string("phase: ") + hipGetErrorString(er); return HSPF_E_HIP; }
       if (ctx->h_changed[sweep - 1] == 0) break;
       if (on_retry) on_retry();
@@ -1217,6 +1225,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
     uint32_t last_esz = 0;                    // state width of the last fused_run (0: none ran)
     uint32_t last_ns = n, last_fillw = 0xFFFFFFFFu;
+    bool spec_done = false;                   // the last fused_run's speculative fill was enqueued behind its last chunk
+    uint32_t spec_nz = 0;
     auto fused_run = [&](int mode) -> int {       // 0: 8-byte state, 1: 4-byte state (k_fused), 2: 4-byte state, lean sweep
       const bool nar = mode != 0, use_lean = mode == 2;
       const FusedParams P = use_lean ? fp_lean : (nar ? fp_narrow : fp_wide);
@@ -1234,8 +1244,19 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       else
         hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, rows * esz / 16, fillw, d_stamp, (size_t)B * n,
                            (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, pre_zeroed, d_lf, L,
-                           count_rows ? d_kcnt : (uint32_t *)nullptr);
+                           count_rows ? d_kcnt : (uint32_t *)nullptr, -1);
       last_esz = (uint32_t)esz; last_ns = ns; last_fillw = fillw;
+      ctx->prefill.valid = false;                                // (a speculative fill of an earlier fused_run of this call is gone now)
+      spec_done = false;
+      spec_fill = nullptr;
+      if (!(ctx->variant & (2048u | 2097152u)))                  // HSPF_VARIANT bit11: no prefill at all; bit21: only after the run, as before
+        spec_fill = [&, esz, ns, fillw, rows](uint32_t last_sweep) {
+          const uint32_t nz = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
+          hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, rows * esz / 16, fillw, d_stamp, (size_t)B * n,
+                             (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, nz, d_lf, L, d_kcnt, (int)last_sweep);
+          spec_nz = nz;
+          spec_done = true;                                      // (valid only if the host finds the chunk converged, see below)
+        };
       if (use_lean) st.dbg[0] = 1;                               // hspf_stats::dbg[0]: the run took the lean sweep
       // k_emit_fused checks the lean state's fields on FINAL words; an emit behind a chunk that had not converged saw
       // transient ones: its LF_OVERFLOW bits are dropped before the next chunk (the final emit tests every word again)
@@ -1307,7 +1328,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         (void)hipEventRecord(ctx->ev[4], s);      // "results in place": the phase's read-back synchronises behind it
         tail_done = true;
       });
+      spec_fill = nullptr;
       if (r2) return r2;
+      // run_phase returned: its last chunk converged, so the speculative fill behind that chunk's read-back went through
+      if (spec_done) ctx->prefill = hspf_ctx::Prefill{true, g->build_id, n, B, (uint32_t)esz, spec_nz, L, true, ns, fillw};
       ctx->est_fused = n_f + 1;
       st.n_relax_launches += n_f;
       if (count_rows) for (uint32_t i = 0; i < 256; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
@@ -1460,11 +1484,12 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       }
     }
     st.state_bytes = narrow ? 4 : 8;
-    if (last_esz && !(ctx->variant & 2048u)) {
-      // the next run's scratch, behind this one's emit (same shape assumed: an SPF instance repeats its root set)
+    if (last_esz && !(ctx->variant & 2048u) && !ctx->prefill.valid) {
+      // the next run's scratch, behind this one's emit (same shape assumed: an SPF instance repeats its root set) — unless
+      // the speculative fill behind the last chunk's read-back has done it already
       const uint32_t nz = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
       hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, (size_t)B * last_ns * 64 * last_esz / 16, last_fillw, d_stamp, (size_t)B * n,
-                         (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, nz, d_lf, L, d_kcnt);
+                         (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, nz, d_lf, L, d_kcnt, -1);
       ctx->prefill = hspf_ctx::Prefill{true, g->build_id, n, B, last_esz, nz, L, true, last_ns, last_fillw};
     }
   } else {

@@ -1828,7 +1828,13 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single_lean(SingleArgs a) {
 __global__ __launch_bounds__(256) void k_init_fill(uint4 *__restrict__ st16, size_t n_st16, uint32_t fillw, uint32_t *__restrict__ act, size_t n_act,
                                                    const uint8_t *__restrict__ rowflags, uint8_t *__restrict__ hnb, uint32_t n,
                                                    int *__restrict__ changed, uint32_t n_changed,
-                                                   uint32_t *__restrict__ lane_flags, uint32_t n_lf, uint32_t *__restrict__ kcnt) {
+                                                   uint32_t *__restrict__ lane_flags, uint32_t n_lf, uint32_t *__restrict__ kcnt,
+                                                   int guard_sweep) {
+  // guard_sweep >= 0: enqueued SPECULATIVELY behind the emit and the flag read-back of a chunk of sweeps, before the host
+  // knows whether the chunk reached the fixed point: a chunk whose last sweep still changed something is not over, its
+  // state must stay.  (Every thread reads the flag before any thread can have zeroed it to a different value: a
+  // converged chunk's flag IS zero.)
+  if (guard_sweep >= 0 && changed[guard_sweep] != 0) return;
   const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x, T = (size_t)gridDim.x * 256u;
   const uint4 ones = make_uint4(fillw, fillw, fillw, fillw);            // "not reached": all ones, or FusedParams::infw
   for (size_t i = t; i < n_st16; i += T) st16[i] = ones;

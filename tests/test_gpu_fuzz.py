@@ -16,7 +16,7 @@ pytestmark = [pytest.mark.gpu, all_engines]
 def test_random_lsdbs_runs_and_patches_against_the_oracle(spf_ctx, first):
     import gpu_fuzz
     ok, runs = gpu_fuzz.fuzz(spf_ctx, first, 50, verbose=False)
-    assert ok == runs and runs == 150
+    assert ok == runs and runs >= 150          # 50 graphs x 3 runs, plus the repeated runs (learned sweep schedule)
 
 
 def test_random_lsdbs_with_big_lans_up_to_15_mask_words(spf_ctx):
