@@ -295,6 +295,49 @@ def path_of(st) -> str:
     return "k_relax + k_dag (two-phase)" if st["n_dag_launches"] else "k_fw (wide masks)"
 
 
+def areas_on_two_contexts(dev) -> float:
+    """configs[3] as the reference runs it — every area its own SPF instance —, two instances at a time: the ten areas
+    dealt to two contexts / host threads (graphs resident, results in HBM), wall time for all 10 000 SPTs, best of 3.
+    (One context after the other is `device_ms`; more than two contexts bring nothing on one GPU.)"""
+    import threading
+    import torch
+    from holo_amd import synth
+    from holo_amd import engine as E
+    areas = synth.ospf_multi_area()
+    ctxs = [E.SpfContext(dev.index or 0) for _ in range(2)]
+    jobs = [[], []]
+    for i, g in enumerate(areas):
+        c = ctxs[i & 1]
+        roots = np.asarray(g.meta["roots"], np.uint32)
+        G = c.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        W, R, n = G.mask_words(roots), len(roots), g.n
+        bufs = (torch.empty((R, n), dtype=torch.int32, device=dev), torch.empty((R, n), dtype=torch.int16, device=dev),
+                torch.empty((R, n), dtype=torch.int16, device=dev), torch.empty((R, n, W), dtype=torch.int64, device=dev))
+        jobs[i & 1].append((G, roots, W, bufs))
+
+    def work(k):
+        for G, roots, W, (d, h, f, m) in jobs[k]:
+            ctxs[k].run_device(G, roots, E.RUN_NET_NEXTHOPS, dist_ptr=d.data_ptr(), hops_ptr=h.data_ptr(), flags_ptr=f.data_ptr(),
+                               mask_ptr=m.data_ptr(), mask_words=W)
+    best = 1e9
+    for rep in range(4):
+        ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        torch.cuda.synchronize()
+        if rep:
+            best = min(best, (time.perf_counter() - t0) * 1e3)
+    for k in range(2):
+        for G, *_ in jobs[k]:
+            G.free()
+        ctxs[k].close()
+    return round(best, 3)
+
+
 def other_configs(ctx, dev) -> dict:
     """The other single-GPU BASELINE configs through the same C ABI entry point (hspf_run_device), results in HBM:
     device time (median of 5 after 2 warm-up runs), runs/s, fraction of the HBM roofline by SURVEY.md 8(d)'s B_alg, the
@@ -342,7 +385,8 @@ def other_configs(ctx, dev) -> dict:
     rps = nroots / (tot * 1e-3)
     out["ospf multi-area, 10 areas x 5000 routers x 1000 roots (configs[3], one GPU)"] = {
         "device_ms": round(tot, 3), "runs_per_s": round(rps), "roofline_frac": round(rps * ba / HBM_PEAK, 5), "alg_bytes_per_run": ba,
-        "path": path_of(last), "roots_verified": nroots, "identical_to_oracle": allok}
+        "path": path_of(last), "roots_verified": nroots, "identical_to_oracle": allok,
+        "wall_ms_areas_on_two_contexts": areas_on_two_contexts(dev)}
     gf = synth.isis_fattree(100)
     ms, st, W, ok = one(gf, gf.meta["roots"], 0)
     rps = len(gf.meta["roots"]) / (ms * 1e-3)
