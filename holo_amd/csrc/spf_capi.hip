@@ -1025,7 +1025,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if (fused) {
     if ((rc = ensure(ctx, ctx->st64, rows * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stamp, (size_t)B * n * 4))) return rc;
-    if ((rc = ensure(ctx, ctx->hnb, (size_t)B * n))) return rc;
+    if ((rc = ensure(ctx, ctx->hnb, (size_t)B * n + 8))) return rc;       // (+8: k_init_fused ORs marks into whole words)
   } else {
     if ((rc = ensure(ctx, ctx->dist, rows * 4))) return rc;
     if ((rc = ensure(ctx, ctx->hv, rows * 4))) return rc;

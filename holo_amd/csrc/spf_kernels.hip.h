@@ -110,6 +110,8 @@ constexpr uint32_t RF_MANY = 1u;      // more than 16 kept in-links
 constexpr uint32_t RF_NT = 2u;        // an in-link from an overloaded (no-transit) source
 constexpr uint32_t RF_ZERO = 4u;      // a zero-cost in-link from a higher- or equal-numbered source
 constexpr uint32_t RF_HNB = 8u;       // an in-neighbour that can have hops == 0 for some root of the batch
+constexpr uint32_t RF_HNBN = 32u;     // ... and not only because that in-neighbour IS a root: a row behind a hops-0 network (k_init_fused)
+constexpr uint32_t RF_ROOT = 64u;     // the row of a root of the batch (its own lane stays 0)
 constexpr uint32_t RF_GIANT = 16u;    // more than GIANT_DEG kept in-links: the row is evaluated in slices (k_giant_part)
 
 struct SlotTabs {           // per root: H vertices and their slot bases (include/holo_spf_hip.h)
@@ -1119,8 +1121,14 @@ template <> struct LeanLinks<0> {
 // two selects per link) shrinks to min(c, threshold) + or.  Rows of more than 8 links: two halves of 8, the second one
 // wins only with a strictly smaller distance.
 template <int L>
+__device__ __forceinline__ LeanOut lean_minor(uint32_t (&c)[16], uint32_t paym);
+template <int L>
 __device__ __forceinline__ LeanOut lean_reduce(uint32_t (&c)[16], uint32_t wk, uint32_t paym) {
   LeanLinks<L>::add(c, wk);
+  return lean_minor<L>(c, paym);
+}
+template <int L>
+__device__ __forceinline__ LeanOut lean_minor(uint32_t (&c)[16], uint32_t paym) {
   uint32_t m = INF;
 #pragma unroll
   for (int j = 0; j < (L < 8 ? L : 8); ++j) m = min(m, c[j]);
@@ -1193,6 +1201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
     oldq[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, min(wbeg + i, n - 1) << 8, 0);
   }
   const uint32_t fast4 = (uint32_t)__ballot(lane < (uint32_t)VPW && hb == 0u) & due4;
+  const uint32_t fasth4 = (uint32_t)__ballot(lane < (uint32_t)VPW && (hb & ~RF_ROOT) == RF_HNB) & due4;   // next to a root of the batch (or the row of one), nothing else
   const uint32_t root_slot = batch * 64 + lane;
   const __amdgpu_buffer_rsrc_t ra = st_rsrc(A, n * 4u);
   uint32_t info[VPW];                                             // low byte of ELL entry 0: in-degree | (> 16 out-links) << 5 | network << 7
@@ -1248,9 +1257,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
   static_assert(VPW == 4, "row() is instantiated four times");
   row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{});
   row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
+  // ---- rows next to a root (64 roots x ~14 neighbours = 1 % of the rows, and through the general routine 14 % of the
+  // run: each kept its wave ~10 us behind the others).  A root's word is all zero in its own lane, so the candidate
+  // through the link from the root is [cost | tag | hops 0 | mask 0] there, and what fused_row_any does for a hops-0
+  // parent — the link's own first-hop slot instead of the parent's mask — is ONE or of `1 << position` into that lane's
+  // candidate (the root's slot base is 0).  All 16 record slots are walked (the pad links never win): one code instance.
+  if (fasth4 != 0u) {
+    const uint32_t my_root = roots[root_slot];
+#pragma unroll 1
+    for (uint32_t hm = fasth4; hm != 0u; hm &= hm - 1u) {
+      const uint32_t i = (uint32_t)__builtin_ctz(hm);
+      const uint32_t v = wbeg + i;
+      const uint32_t sov_i = i == 0 ? sov[0] : i == 1 ? sov[1] : i == 2 ? sov[2] : sov[3];
+      const uint32_t wk_i = i == 0 ? wk[0] : i == 1 ? wk[1] : i == 2 ? wk[2] : wk[3];
+      const uint32_t od_i = i == 0 ? od[0] : i == 1 ? od[1] : i == 2 ? od[2] : od[3];
+      const uint32_t old_i = i == 0 ? oldq[0] : i == 1 ? oldq[1] : i == 2 ? oldq[2] : oldq[3];
+      const uint32_t inf_i = i == 0 ? info[0] : i == 1 ? info[1] : i == 2 ? info[2] : info[3];
+      const uint32_t deg = inf_i & 0x1Fu;                                 // <= 16 (a longer row carries RF_MANY)
+      const uint32_t e0 = gp->g.in_ptr[v];
+      const uint32_t fpv = gp->g.in_fpos[e0 + min(lane & 15u, deg - 1u)];  // lane j (< 16) = position of link j in its source row
+      uint32_t c[16];
+      LeanLinks<16>::load(c, rs, lane4, sov_i);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      LeanLinks<16>::add(c, wk_i);
+      const bool slots_on = !(inf_i & 0x80u) || net_nexthops != 0u;       // next hops of a network vertex only on request
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const uint32_t u = rdlane(sov_i, j) >> 8, fp = rdlane(fpv, j);
+        const uint32_t bit = (slots_on && (uint32_t)j < deg && fp < P.mbits) ? (1u << fp) : 0u;
+        c[j] |= (my_root == u) ? bit : 0u;
+      }
+      const LeanOut r = lean_minor<16>(c, paym);
+      const uint32_t nw = my_root == v ? 0u : finish(r, inf_i);          // a root's own lane: distance 0, hops 0, no next hops
+      if (COUNT) ++n_done;
+      const uint64_t ch = __ballot(nw != old_i);
+      if (ch == 0ull) continue;
+      __builtin_amdgcn_raw_buffer_store_b32(nw, rs, lane4, v << 8, 0);
+      any |= ch;
+      if (MODE == 1) continue;
+      if (!(inf_i & 0x20u)) { __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, od_i, 0, 0); continue; }
+      const GraphDev &g = gp->g;
+      const uint32_t o0 = g.out_ptr[v], o1 = g.out_ptr[v + 1];
+      for (uint32_t ob = o0 + lane; ob < o1; ob += 64) __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, g.out_dst[ob] * 4u, 0, 0);
+    }
+  }
   // ---- the due rows that carry a flag: k_fused's general routine on the CSR arrays (rare: one code instance, run-time row)
 #pragma unroll 1
-  for (uint32_t gm = due4 & ~fast4; gm != 0u; gm &= gm - 1u) {
+  for (uint32_t gm = due4 & ~fast4 & ~fasth4; gm != 0u; gm &= gm - 1u) {
     const uint32_t v = wbeg + (uint32_t)__builtin_ctz(gm);
     const GraphDev &g = gp->g;
     const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
@@ -1858,22 +1911,27 @@ __global__ __launch_bounds__(256) void k_init_fused(GraphDev g, ST *st, uint32_t
   const uint32_t n = g.n;
   const uint32_t batch = i >> 6, lane = i & 63;
   // ns: rows per batch slab (n, or n + 1 for the lean sweep's never-reached pad row).  The root's own row takes the
-  // general routine (it is the one that keeps a root's lane at zero): the lean fast routine never sees a root row.
+  // general routine or the lean sweep's root-neighbour path (they keep a root's lane at zero): the plain fast routine never sees a root row.
+  // The marks are OR-ed into the byte k_init_fill left there (the graph's static flags), through the aligned word that
+  // holds it: a row can be next to one lane's root AND behind another lane's hops-0 network, and a plain byte store of
+  // either mark could drop the other.  RF_HNB alone = "some in-neighbour is a root of the batch, nothing else": the
+  // lean sweep handles that inline (the root's link contributes its slot bit); RF_HNBN = the general routine.
+  auto mark = [&](uint32_t row, uint32_t bits) {
+    const size_t idx = (size_t)batch * n + row;
+    atomicOr((uint32_t *)(hnb + (idx & ~(size_t)3)), bits << (8u * (uint32_t)(idx & 3u)));
+  };
   if (ln == 0) {
     st[((size_t)batch * ns + r) * 64 + lane] = (ST)0;
-    hnb[(size_t)batch * n + r] = (uint8_t)(g.rowflags[r] | RF_HNB);
+    mark(r, RF_HNB | RF_ROOT);
   }
   for (uint32_t k = g.out_ptr[r] + ln; k < g.out_ptr[r + 1]; k += 64) {
     const uint32_t d = g.out_dst[k];
     act[(size_t)batch * n + d] = 2u;
-    hnb[(size_t)batch * n + d] = (uint8_t)(g.rowflags[d] | RF_HNB);
+    mark(d, RF_HNB);
   }
   for (uint32_t j = tabs.ptr[i]; j < tabs.ptr[i + 1]; ++j) {
     const uint32_t h = tabs.vtx[j];
-    for (uint32_t k = g.out_ptr[h] + ln; k < g.out_ptr[h + 1]; k += 64) {
-      const uint32_t d = g.out_dst[k];
-      hnb[(size_t)batch * n + d] = (uint8_t)(g.rowflags[d] | RF_HNB);
-    }
+    for (uint32_t k = g.out_ptr[h] + ln; k < g.out_ptr[h + 1]; k += 64) mark(g.out_dst[k], RF_HNB | RF_HNBN);
   }
 }
 
