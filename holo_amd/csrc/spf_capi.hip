@@ -117,7 +117,7 @@ struct hspf_ctx {
   DevBuf dist, hv, mask, lane_flags, changed, st64, stamp, hnb, kcnt, swcnt;
   std::vector<uint8_t> lean_sched;   // k_fused_lean's mode per sweep, learned on an earlier run of (lean_sched_graph, same upload block)
   const void *lean_sched_graph = nullptr;
-  uint32_t lean_sched_roots = 0, lean_dense_pct = 90;
+  uint32_t lean_sched_roots = 0, lean_dense_pct = 90, lean_dense_passes = 16;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
@@ -504,6 +504,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   ctx->device = device_ordinal;
   if (const char *v = getenv("HSPF_VARIANT")) ctx->variant = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_SINGLE_MAX_N")) ctx->single_max_n = (uint32_t)strtoul(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_DENSE_PASSES")) ctx->lean_dense_passes = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(v, nullptr, 0), 1u), 32u);
   if (const char *v = getenv("HSPF_DENSE_PCT")) ctx->lean_dense_pct = (uint32_t)strtoul(v, nullptr, 0);   // rows due (% of all) from which a sweep of k_fused_lean runs dense
   if (const char *v = getenv("HSPF_LV_MAX_ROOTS")) ctx->lv_max_roots = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_LV_MIN_N")) ctx->lv_min_n = (uint32_t)strtoul(v, nullptr, 0);
@@ -1288,14 +1289,16 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 #define HSPF_LAUNCH_FUSED(ST_, MI_, CN_, stp_) do { if (units) HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, true, stp_); else HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, false, stp_); } while (0)
         const bool units = g->n_heavy_chunks != 0;
         if (use_lean) {
-#define HSPF_LAUNCH_LEAN(CN_, MD_, LR_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, LR_>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, (uint32_t *)ctx->swcnt.p)
-          const int md = (sched_on && sweep < ctx->lean_sched.size()) ? ctx->lean_sched[sweep] : 0;
-          if (md == 1) ++st.dbg[1];                                   // hspf_stats::dbg[1] (lean sweep): launches in dense mode
-          if (count_rows)  HSPF_LAUNCH_LEAN(true, 0, false);
-          else if (learn)  HSPF_LAUNCH_LEAN(false, 0, true);
-          else if (md == 1) HSPF_LAUNCH_LEAN(false, 1, false);
-          else if (md == 2) HSPF_LAUNCH_LEAN(false, 2, false);
-          else             HSPF_LAUNCH_LEAN(false, 0, false);
+#define HSPF_LAUNCH_LEAN(CN_, MD_, LR_, grid_, pb_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, LR_>), grid_, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, (uint32_t *)ctx->swcnt.p, pb_)
+          const int md = (sched_on && sweep < ctx->lean_sched.size()) ? (ctx->lean_sched[sweep] & 3) : 0;
+          const uint32_t passes = (sched_on && sweep < ctx->lean_sched.size()) ? std::max<uint32_t>(ctx->lean_sched[sweep] >> 2, 1u) : 1u;
+          if (md == 1) st.dbg[1] += passes;                           // hspf_stats::dbg[1] (lean sweep): dense passes
+          if (count_rows)  HSPF_LAUNCH_LEAN(true, 0, false, fgrid, 0u);
+          else if (learn)  HSPF_LAUNCH_LEAN(false, 0, true, fgrid, 0u);
+          else if (md == 1 && passes > 1u) HSPF_LAUNCH_LEAN(false, 1, false, dim3(fgrid.x * passes, B), fgrid.x);
+          else if (md == 1) HSPF_LAUNCH_LEAN(false, 1, false, fgrid, 0u);
+          else if (md == 2) HSPF_LAUNCH_LEAN(false, 2, false, fgrid, 0u);
+          else             HSPF_LAUNCH_LEAN(false, 0, false, fgrid, 0u);
 #undef HSPF_LAUNCH_LEAN
           return;
         }
@@ -1350,6 +1353,25 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         for (uint32_t sw = 0; sw < ns_; ++sw)
           if (ctx->lean_sched[sw] == 1 && ctx->lean_sched[sw + 1] != 1) ctx->lean_sched[sw + 1] = 2;
         if (ns_ && ctx->lean_sched[0] == 1) ctx->lean_sched[0] = 2;     // (the first sweep follows k_init_fused's stamps; never dense in practice)
+        // a stretch of D dense sweeps -> ceil(D / K) launches of K passes each (entry = mode | passes << 2): no kernel
+        // boundary inside a launch (HSPF_DENSE_PASSES, default 16; 1: one sweep per launch)
+        // (only where a pass is long against what the chip holds at once — 2 048 workgroups —: on a small graph pass p + 1
+        // would run NEXT TO pass p instead of behind it and read the same stale rows: ospf-10k, 1 024 roots 0.92 -> 1.21 ms)
+        if (ctx->lean_dense_passes > 1u && fgrid.x >= 4096u) {
+          std::vector<uint8_t> out;
+          for (size_t sw = 0; sw < ctx->lean_sched.size();) {
+            if (ctx->lean_sched[sw] != 1) { out.push_back(ctx->lean_sched[sw++]); continue; }
+            size_t e2 = sw;
+            while (e2 < ctx->lean_sched.size() && ctx->lean_sched[e2] == 1) ++e2;
+            for (size_t left = e2 - sw; left != 0;) {
+              const uint32_t k = (uint32_t)std::min<size_t>(left, ctx->lean_dense_passes);
+              out.push_back((uint8_t)(1u | (k << 2)));
+              left -= k;
+            }
+            sw = e2;
+          }
+          ctx->lean_sched.swap(out);
+        }
         ctx->lean_sched_graph = (const void *)g; ctx->lean_sched_roots = n_roots;
       }
       return HSPF_OK;

@@ -30,8 +30,11 @@ print(json.dumps({"first3_ms": [round(x, 4) for x in ms[:3]], "median_ms": round
 """ % ROOT
 
 if __name__ == "__main__":
-    for name, env in (("schedule off", {"HSPF_VARIANT": "524288"}), ("pct 90", {}), ("pct 75", {"HSPF_DENSE_PCT": "75"}), ("pct 97", {"HSPF_DENSE_PCT": "97"}),
-                      ("pct 50", {"HSPF_DENSE_PCT": "50"})):
+    sets = [("schedule off", {"HSPF_VARIANT": "524288"}), ("passes 1", {"HSPF_DENSE_PASSES": "1"}), ("default (passes 16)", {})]
+    sets += [(f"passes {k}", {"HSPF_DENSE_PASSES": str(k)}) for k in (2, 4, 8)]
+    if len(sys.argv) > 1 and sys.argv[1] == "pct":
+        sets = [("schedule off", {"HSPF_VARIANT": "524288"}), ("pct 90", {}), ("pct 75", {"HSPF_DENSE_PCT": "75"}), ("pct 97", {"HSPF_DENSE_PCT": "97"}), ("pct 50", {"HSPF_DENSE_PCT": "50"})]
+    for name, env in sets:
         e = dict(os.environ); e.update(env)
         out = subprocess.run([sys.executable, "-c", CHILD], env=e, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
