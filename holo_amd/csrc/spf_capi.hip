@@ -1289,13 +1289,13 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 #define HSPF_LAUNCH_FUSED(ST_, MI_, CN_, stp_) do { if (units) HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, true, stp_); else HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, false, stp_); } while (0)
         const bool units = g->n_heavy_chunks != 0;
         if (use_lean) {
-#define HSPF_LAUNCH_LEAN(CN_, MD_, LR_, grid_, pb_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, LR_>), grid_, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, (uint32_t *)ctx->swcnt.p, pb_)
+#define HSPF_LAUNCH_LEAN(CN_, MD_, LR_, grid_, pb_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, LR_>), grid_, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, (uint32_t *)ctx->swcnt.p, pb_, B)
           const int md = (sched_on && sweep < ctx->lean_sched.size()) ? (ctx->lean_sched[sweep] & 3) : 0;
           const uint32_t passes = (sched_on && sweep < ctx->lean_sched.size()) ? std::max<uint32_t>(ctx->lean_sched[sweep] >> 2, 1u) : 1u;
           if (md == 1) st.dbg[1] += passes;                           // hspf_stats::dbg[1] (lean sweep): dense passes
           if (count_rows)  HSPF_LAUNCH_LEAN(true, 0, false, fgrid, 0u);
           else if (learn)  HSPF_LAUNCH_LEAN(false, 0, true, fgrid, 0u);
-          else if (md == 1 && passes > 1u) HSPF_LAUNCH_LEAN(false, 1, false, dim3(fgrid.x * passes, B), fgrid.x);
+          else if (md == 1 && passes > 1u) HSPF_LAUNCH_LEAN(false, 1, false, dim3(fgrid.x * B * passes), fgrid.x);
           else if (md == 1) HSPF_LAUNCH_LEAN(false, 1, false, fgrid, 0u);
           else if (md == 2) HSPF_LAUNCH_LEAN(false, 2, false, fgrid, 0u);
           else             HSPF_LAUNCH_LEAN(false, 0, false, fgrid, 0u);
@@ -1355,9 +1355,9 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         if (ns_ && ctx->lean_sched[0] == 1) ctx->lean_sched[0] = 2;     // (the first sweep follows k_init_fused's stamps; never dense in practice)
         // a stretch of D dense sweeps -> ceil(D / K) launches of K passes each (entry = mode | passes << 2): no kernel
         // boundary inside a launch (HSPF_DENSE_PASSES, default 16; 1: one sweep per launch)
-        // (only where a pass is long against what the chip holds at once — 2 048 workgroups —: on a small graph pass p + 1
-        // would run NEXT TO pass p instead of behind it and read the same stale rows: ospf-10k, 1 024 roots 0.92 -> 1.21 ms)
-        if (ctx->lean_dense_passes > 1u && fgrid.x >= 4096u) {
+        // (only where a pass — all batches of the call — is long against what the chip holds at once, 2 048 workgroups: a
+        // short pass would run NEXT TO its successor instead of ahead of it and both would read the same stale rows)
+        if (ctx->lean_dense_passes > 1u && (uint64_t)fgrid.x * B >= 4096u && (uint64_t)fgrid.x * B * ctx->lean_dense_passes < (1ull << 31)) {
           std::vector<uint8_t> out;
           for (size_t sw = 0; sw < ctx->lean_sched.size();) {
             if (ctx->lean_sched[sw] != 1) { out.push_back(ctx->lean_sched[sw++]); continue; }

@@ -1167,18 +1167,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
     const FusedGraph *__restrict__ gp, int *changed, int sweep, uint32_t *__restrict__ act,
     const uint8_t *__restrict__ hnb, uint32_t n_arg, const uint32_t *__restrict__ ell_so, const uint32_t *__restrict__ ell_w,
     uint32_t *__restrict__ st, const uint32_t *__restrict__ ell_od, const uint32_t *__restrict__ roots, uint32_t *lane_flags,
-    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P, uint32_t *__restrict__ swcnt, uint32_t pass_blocks) {
+    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P, uint32_t *__restrict__ swcnt, uint32_t pass_blocks, uint32_t pass_batches) {
   typedef uint32_t ST;
   if (sweep > 0 && changed[sweep - 1] == 0) return;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t batch = blockIdx.y;
-  const uint32_t n = n_arg;
-  // Dense launches may carry SEVERAL passes over the rows: a grid of passes x blocks, pass p = blocks [p G, (p + 1) G).
+  // Dense launches may carry SEVERAL passes over the rows: a 1-D grid of passes x batches x blocks, pass p = blocks
+  // [p G B, (p + 1) G B), batch-major inside a pass (so that a pass spans ALL batches of the call: 16 batches of a 10 000-
+  // vertex graph make a pass of 10 000 workgroups, long enough to keep its successor behind it).
   // Blocks are dispatched in order, so a pass starts while the one before it drains — no kernel boundary between two dense
   // sweeps (a dense sweep keeps ~76 % of the wave slots busy: ramp and drain) — and reads what that pass has written
   // except in the rows still in flight; any interleaving is a valid chaotic iteration of the same monotone fixed point,
-  // and the run's end is decided by stamped sweeps behind the stretch.  pass_blocks = G (0: one pass).
+  // and the run's end is decided by stamped sweeps behind the stretch.  pass_blocks = G (0: one pass, 2-D grid), pass_batches = B.
+  const uint32_t batch = (MODE == 1 && pass_blocks != 0u) ? (blockIdx.x / pass_blocks) % pass_batches : blockIdx.y;
+  const uint32_t n = n_arg;
   const uint32_t bx = (MODE == 1 && pass_blocks != 0u) ? blockIdx.x % pass_blocks : blockIdx.x;
   const uint32_t chunk = xcd_chunk(gp->g.xcd_start, bx);
   if (chunk == 0xFFFFFFFFu) return;
