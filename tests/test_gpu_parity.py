@@ -727,7 +727,7 @@ def test_fattree_full_size_leaves_deferred(spf_ctx):
 # ---- the lean sweep's learned mode schedule (dense sweeps without activation stamps) --------------------------------
 
 @sweeps_engine
-@pytest.mark.parametrize("shape", ["grid", "isis-100k"])
+@pytest.mark.parametrize("shape", ["grid", "isis-100k", "ospf-10k x 1024 roots"])
 def test_lean_dense_schedule_repeated_runs(spf_ctx, shape):
     """An instance that repeats a run (same graph handle, same roots) gets k_fused_lean's mode schedule from its own
     second run: dense sweeps (no stamps read or written), one all-due stamped sweep after them.  Every run of the
@@ -743,9 +743,12 @@ def test_lean_dense_schedule_repeated_runs(spf_ctx, shape):
         row_ptr, col, met = synth._csr_from_links(side * side, np.concatenate([a, b]), np.concatenate([b, a]), np.concatenate([m, m]))
         g = synth.CsrGraph(row_ptr, col, met, np.zeros(side * side, np.uint8), synth.MAX_PATH_METRIC_WIDE)
         roots = (np.arange(64, dtype=np.int64) * g.n // 64).astype(np.uint32)
-    else:
+    elif shape == "isis-100k":                          # one batch, a pass of 6 250 workgroups: dense stretches as multi-pass launches
         g = synth.isis_100k()
         roots = (np.arange(64, dtype=np.int64) * g.n // 64).astype(np.uint32)
+    else:                                               # 16 batches x 625 workgroups: a pass spans all batches
+        g = synth.ospf_10k()
+        roots = (np.arange(1024, dtype=np.int64) * g.n // 1024).astype(np.uint32)
     G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
 
     def one(rts, graph):
