@@ -232,6 +232,7 @@ int main(int argc, char **argv) {
         hspf_prefix_table tab3 = tab; tab3.flags |= HSPF_PFX_RESIDENT;
         for (int pass = 0; pass < 2; ++pass) {                     // pass 0: nothing recorded matches (the ordered table was last) -> upload; pass 1: resident
           hipMemset(bm3, 0xEE, (size_t)R * P * 4);
+          hipDeviceSynchronize();                                  // (the engine's stream does not wait for the null stream)
           CHECK(hspf_routes_device(eng.raw(), n, R, W, dd, df, dm, &tab3, &ro3) == HSPF_OK, "hspf_routes_device (resident)");
           std::vector<u32> hb3((size_t)R * P), he3((size_t)R * P); std::vector<uint64_t> hn3((size_t)R * P * W);
           hipMemcpy(hb3.data(), bm3, hb3.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(he3.data(), be3, he3.size() * 4, hipMemcpyDeviceToHost);
