@@ -117,7 +117,7 @@ struct hspf_ctx {
   DevBuf dist, hv, mask, lane_flags, changed, st64, stamp, hnb, kcnt, swcnt;
   std::vector<uint8_t> lean_sched;   // k_fused_lean's mode per sweep, learned on an earlier run of (lean_sched_graph, same upload block)
   const void *lean_sched_graph = nullptr;
-  uint32_t lean_sched_roots = 0, lean_dense_pct = 90, lean_dense_passes = 16;
+  uint32_t lean_sched_roots = 0, lean_dense_pct = 50, lean_dense_passes = 16;
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device

@@ -33,7 +33,7 @@ if __name__ == "__main__":
     sets = [("schedule off", {"HSPF_VARIANT": "524288"}), ("passes 1", {"HSPF_DENSE_PASSES": "1"}), ("default (passes 16)", {})]
     sets += [(f"passes {k}", {"HSPF_DENSE_PASSES": str(k)}) for k in (2, 4, 8)]
     if len(sys.argv) > 1 and sys.argv[1] == "pct":
-        sets = [("schedule off", {"HSPF_VARIANT": "524288"}), ("pct 90", {}), ("pct 75", {"HSPF_DENSE_PCT": "75"}), ("pct 97", {"HSPF_DENSE_PCT": "97"}), ("pct 50", {"HSPF_DENSE_PCT": "50"})]
+        sets = [("pct 90", {}), ("pct 70", {"HSPF_DENSE_PCT": "70"}), ("pct 50", {"HSPF_DENSE_PCT": "50"}), ("pct 30", {"HSPF_DENSE_PCT": "30"}), ("pct 15", {"HSPF_DENSE_PCT": "15"})]
     for name, env in sets:
         e = dict(os.environ); e.update(env)
         out = subprocess.run([sys.executable, "-c", CHILD], env=e, capture_output=True, text=True)
