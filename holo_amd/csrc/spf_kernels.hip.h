@@ -1091,7 +1091,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
 //     general routine); a changed row is stored whole (unchanged lanes rewrite their own value: single writer);
 //   * per-wave masks (due, fast) as SGPR bit sets instead of per-row lane read-backs; the wake-up offsets of a row are
 //     one ELL load in the set-up round trip (no out-row bounds, no dependent out-link load).
-// Rows with a per-batch or static flag take k_fused's general routine on the CSR arrays, unchanged.
+// Rows with a per-batch or static flag take k_fused's general routine on the CSR arrays, unchanged — except the rows
+// next to a root of the batch and the roots' own rows (RF_HNB / RF_ROOT and nothing else), which have a path of their own
+// below: 1 % of the rows, and through the general routine 14 % of the run, because a sweep ends with its LAST wave.
+// What moved the run after the per-row cost had stopped mattering (profiles/r03_notes.md r03k, r03o, r03q): that path;
+// launches WITHOUT activation stamps for the sweeps in which nearly every row is due (MODE, learned schedule); and a
+// whole stretch of such sweeps as ONE launch of several passes (pass_blocks), so that a pass starts while the one
+// before it drains instead of behind a kernel boundary.
 template <int J> __device__ __forceinline__ uint32_t dpp_bcast16(uint32_t v) {     // lane 16 r + J of every DPP row r
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + J, 0xF, 0xF, false);
 }
