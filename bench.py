@@ -288,7 +288,7 @@ def path_of(st) -> str:
         packed = "k_fused_lean, 4-byte state" if dbg[0] else "k_fused, 4-byte state"
     if st["state_bytes"] == 8:
         packed = "k_fused, 8-byte state"
-    if dbg[1]:                               # a wide-mask class ran with the graph's leaves left to the emit
+    if dbg[1] & 0x80000000:                  # a wide-mask class ran with the graph's leaves left to the emit (low bits: dense passes of the lean sweep)
         return "k_fw (wide masks, leaves derived in the emit)" + (" + " + packed + " for the roots that fit it" if packed else "")
     if packed:
         return packed

@@ -1527,7 +1527,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if (use_fw) {
     const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
     if (!defer) HIPCHK(ctx, hipMemsetAsync(d_mask, 0, rows * 8 * W, s));
-    if (defer) st.dbg[1] = 1;                                    // hspf_stats::dbg[1]: the leaves were left to the emit
+    if (defer) st.dbg[1] |= 0x80000000u;                         // hspf_stats::dbg[1] bit 31: the leaves were left to the emit
     HIPCHK(ctx, hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s));
     hipLaunchKernelGGL(k_init_fw, dim3((L + 3) / 4), dim3(256), 0, s, gd, d_dist, d_stamp, d_roots, L);
     if (giant) HIPCHK(ctx, hipMemsetAsync(ctx->giant_part.p, 0, giant_tags * 4, s));
@@ -1752,7 +1752,8 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
     acc.state_bytes = std::max(acc.state_bytes, p.state_bytes); acc.narrow_overflow += p.narrow_overflow;
     acc.rows_recomputed += p.rows_recomputed;
-    acc.dbg[0] |= p.dbg[0]; acc.dbg[1] |= p.dbg[1]; acc.dbg[2] += p.dbg[2]; acc.dbg[3] += p.dbg[3];
+    acc.dbg[0] |= p.dbg[0]; acc.dbg[1] = ((acc.dbg[1] | p.dbg[1]) & 0x80000000u) | ((acc.dbg[1] & 0x7FFFFFFFu) + (p.dbg[1] & 0x7FFFFFFFu));
+    acc.dbg[2] += p.dbg[2]; acc.dbg[3] += p.dbg[3];
   }
   if (host_out) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));

@@ -158,8 +158,8 @@ typedef struct {
                                   (holo-isis/src/spf.rs:552-556), i.e. n_batches * n_vertices rows would be 1x */
   uint32_t single_wg;          /* 1: small graph, the run took the one-workgroup-per-root kernel (one launch)     */
   uint32_t lane_vertex;        /* 1: a few roots on a larger graph, the run took the lane = vertex kernel (k_lv)   */
-  uint32_t dbg[4];             /* [0]: 1 = the run took the lean sweep (k_fused_lean); [1]: dense passes of that sweep's
-                                  learned schedule, or 1 = a wide-mask run left the graph's leaves to the emit;
+  uint32_t dbg[4];             /* [0]: 1 = the run took the lean sweep (k_fused_lean); [1]: bits 0-30 = dense passes of that sweep's
+                                  learned schedule, bit 31 = a wide-mask run left the graph's leaves to the emit;
                                   [2], [3]: host microseconds from the entry of the (last) run to its first enqueue /
                                   to its return.  HSPF_RUN_COUNT_ROWS on the one-workgroup path instead: sweeps,
                                   shader cycles, 100 MHz wall ticks and set-up cycles of the first root's workgroup  */

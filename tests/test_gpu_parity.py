@@ -662,7 +662,7 @@ def test_leaves_are_derived_in_the_emit(spf_ctx):
     for roots in ([6, 0, 9, 15, 16, 3, 14], list(range(17)), [9], [2]):
         for fl in (0, E.RUN_IGNORE_OVERLOAD):
             res, _ = check(spf_ctx, g, roots, fl, expect_exact=False)
-            assert res.stats["dbg"][1] == 1 or spf_ctx.mode != "widemask"
+            assert (res.stats["dbg"][1] >> 31) == 1 or spf_ctx.mode != "widemask"
     # zero-cost links: host 6 behind a zero-cost link (host < router and host > router both exist: 6 > 0, and 16 > 15)
     m0 = g.metric.copy()
     rp = g.row_ptr.astype(np.int64)
@@ -703,7 +703,7 @@ def test_stub_lans_and_hosts_random(spf_ctx, seed):
     roots = np.concatenate([host_ids[:12], routers[:20], lr[:3], host_ids[-2:]]).astype(np.uint32)
     for fl in (0, E.RUN_NET_NEXTHOPS):
         res, _ = check(spf_ctx, g2, roots, fl)
-        assert res.stats["dbg"][1] == 1 or spf_ctx.mode != "widemask"
+        assert (res.stats["dbg"][1] >> 31) == 1 or spf_ctx.mode != "widemask"
 
 
 def test_fattree_full_size_leaves_deferred(spf_ctx):
