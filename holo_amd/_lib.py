@@ -89,6 +89,12 @@ SYMBOLS = [
     ("hspf_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(HspfResult)]),
     ("hspf_run_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(HspfResult)]),
     ("hspf_get_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(HspfStats)]),
+    ("hspf_run_device_async", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.POINTER(HspfResult), u64p]),
+    ("hspf_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(HspfStats)]),
+    ("hspf_wait_all", ctypes.c_int, [ctypes.c_void_p]),
+    ("hspf_async_lanes", ctypes.c_uint32, [ctypes.c_void_p]),
+    ("hspf_recommend_cpu", ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     ("hspf_routes_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.POINTER(HspfPrefixTable), ctypes.POINTER(HspfRoutes)]),
@@ -119,6 +125,9 @@ SYMBOLS = [
     ("hspf_multi_run", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,
                                       ctypes.POINTER(HspfResult), ctypes.c_uint32]),
     ("hspf_multi_wait", ctypes.c_int, [ctypes.c_void_p]),
+    ("hspf_multi_run_async", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,
+                                            ctypes.POINTER(HspfResult), u64p]),
+    ("hspf_multi_run_wait", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(HspfResult), ctypes.c_uint32]),
     ("hspf_multi_allgather_rows", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint32]),
     ("hspf_multi_get_stats", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(HspfStats)]),
 ]

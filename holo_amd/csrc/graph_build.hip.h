@@ -224,8 +224,15 @@ kb_rank(uint32_t e, const BuildInfo *__restrict__ info, const uint32_t *__restri
   if (i >= e || i >= info->kept) return;
   const uint32_t t = tmp_t[i];
   const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
-  if (b - a > hub_deg) return;      // parallel links piled onto one row: the host sees max_in_deg and rebuilds in hub mode
   const uint32_t w = tmp_w[i], sraw = tmp_src[i], s = sraw & SRC_MASK, f = tmp_fpos[i];
+  if (b - a > hub_deg) {
+    // parallel links piled onto one row: the host sees max_in_deg and rebuilds in hub mode.  The row is still WRITTEN —
+    // unsorted, at its scatter position —: the remaining kernels of this (discarded) pass index other arrays with its
+    // sources, and whatever the freshly allocated arena held before would send them anywhere (a GPU memory fault when
+    // that was the 0xFFFFFFFF of a freed state slab: round 4, tests/test_gpu_graph_build.py after the async tests).
+    in_w[i] = w; in_src[i] = sraw; in_fpos[i] = f;
+    return;
+  }
   uint32_t rank = 0;
   for (uint32_t j = a; j < b; ++j) {
     const uint32_t wj = tmp_w[j], sj = tmp_src[j] & SRC_MASK, fj = tmp_fpos[j];

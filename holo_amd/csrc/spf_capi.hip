@@ -17,7 +17,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <vector>
@@ -38,9 +41,10 @@ struct hspf_graph {
   uint32_t cap_e = 0;                // link capacity of the device arrays (>= e; patches grow into it)
   uint32_t max_path_metric = 0;
   uint32_t wmax = 0;                 // largest cost among the kept links
-  mutable bool narrow_bad = false;   // a run overflowed the 4-byte fused state: use the 8-byte one
-  mutable bool wide24_bad = false;   // a run overflowed the hop field of the 8-byte state with > 16 mask bits
-  mutable bool lean_bad = false;     // a run overflowed the fields of the lean 4-byte state (k_fused_lean): k_fused from now on
+  // (atomic: the lanes of an asynchronous context run on the same graph handle from their own host threads)
+  mutable std::atomic<bool> narrow_bad{false};   // a run overflowed the 4-byte fused state: use the 8-byte one
+  mutable std::atomic<bool> wide24_bad{false};   // a run overflowed the hop field of the 8-byte state with > 16 mask bits
+  mutable std::atomic<bool> lean_bad{false};     // a run overflowed the fields of the lean 4-byte state (k_fused_lean): k_fused from now on
   bool hopcount_like = false;        // every kept link into a network costs 0 (from a router), into a router 1
   bool heavy_rows = false;           // a quarter or more of the links sit in rows of more than 32 (fat-tree switches, big LANs)
   uint32_t xcd_start[9] = {};        // work-balanced chunk ranges of the 8 XCDs (GraphDev::xcd_start)
@@ -115,9 +119,14 @@ struct hspf_ctx {
   hipEvent_t ev[7] = {};             // [6]: behind the flag read-back of a chunk of sweeps (run_phase)
   // scratch (grown on demand, reused across runs)
   DevBuf dist, hv, mask, lane_flags, changed, st64, stamp, hnb, kcnt, swcnt;
-  std::vector<uint8_t> lean_sched;   // k_fused_lean's mode per sweep, learned on an earlier run of (lean_sched_graph, same upload block)
-  const void *lean_sched_graph = nullptr;
-  uint32_t lean_sched_roots = 0, lean_dense_pct = 50, lean_dense_passes = 16;
+  // k_fused_lean's plan: head sweeps, dense passes, one all-due sweep, tail sweeps.  The launches decide on the device
+  // whether they still have a job (LEAN_CTL_*, spf_kernels.hip.h); the host only sizes the plan, from what the previous
+  // run of this context used (any graph, any roots: a wrong guess costs a few skipped launches or passes, nothing else).
+  uint32_t lean_head = 4, lean_passes = 16;          // a first run: four head sweeps, a dense stretch of up to 16 passes
+  uint32_t lean_dense_pct = 30;                      // HSPF_DENSE_PCT: a head sweep with this share of the rows due is the last one
+  uint32_t lean_stay_pct = 10;                       // HSPF_DENSE_STAY_PCT: the stretch ends when a pass changes a smaller share of the rows
+  uint32_t lean_dense_passes = 16;                   // HSPF_DENSE_PASSES: passes per dense launch (1: a launch per dense sweep)
+  uint32_t lean_max_passes = 48;                     // longest dense stretch a plan may hold
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
@@ -150,6 +159,7 @@ struct hspf_ctx {
   uint32_t *h_lane_flags = nullptr; // pinned: per-root status bits, then the 256 rows_done words of the fused kernel
   size_t h_lane_cap = 0;
   uint32_t est_relax = 12, est_dag = 12, est_fused = 12, est_fw = 12;   // launch-ahead estimates (adapted run to run)
+  bool est_seen = false;                   // est_fused comes from a run of this context (not the initial guess)
   uint32_t variant = 0;                    // HSPF_VARIANT env: kernel A/B switches (tuning only)
   uint32_t single_attr = 0;                // per k_single instantiation: its dynamic-LDS attribute has been set
   uint32_t single_max_n = 1024;            // HSPF_SINGLE_MAX_N env: largest graph that takes the one-workgroup-per-root kernel
@@ -163,6 +173,36 @@ struct hspf_ctx {
   uint32_t unit_heavy_deg = UNIT_HEAVY_DEG; // HSPF_UNIT_HEAVY_DEG env: a chunk with a row of more in-links than this runs one row per wave
   uint32_t xcd_row_cost = 8;               // HSPF_XCD_ROW_COST env: fixed cost of a row, in links, when the XCD ranges are cut
   hspf_stats stats = {};
+  // ---- asynchronous runs (hspf_run_device_async / hspf_wait): LANES = private engine contexts on this device, each with
+  // its own stream, scratch and host thread.  A caller that keeps N runs in flight starts them together, and they stay
+  // together: all in their sparse first sweeps at once, all dense at once, all in the tail at once (kernel trace,
+  // profiles/r04_notes.md r04d).  That lockstep is what pays: the chains of small dependent launches of the N runs
+  // interleave (N sparse sweeps in the time of ~1.3), the dense stretches share the chip at no loss.  What does NOT pay on
+  // this hardware is a sparse sweep next to ANOTHER run's dense launch: its 6 250 workgroups wait for slots behind the
+  // 100 000 of the dense grid (65-80 us instead of 6), whatever the stream priorities, and with a wave slot per SIMD kept
+  // free by an LDS reservation the kernel boundaries of the sparse chain stretch to ~60 us instead — a dense stretch
+  // handed from lane to lane (events, or one low-priority stream for all dense launches) measured 118-141 k runs/s
+  // against 150 k for lanes left alone (r04d-r04f; removed).  HSPF_ASYNC_LANES (default 3).
+  std::vector<struct hspf_lane *> lanes;
+  uint64_t next_ticket = 1;
+  uint32_t lanes_cfg = 3;
+  hspf_ctx *parent = nullptr;                       // in a lane's context: the context the caller holds
+};
+
+// One lane of an asynchronous context: a job slot, the thread that runs it, the last few results.
+struct hspf_lane {
+  hspf_ctx *sub = nullptr;
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool has_job = false, quit = false;
+  const hspf_graph *g = nullptr;
+  std::vector<uint32_t> roots;
+  uint32_t flags = 0;
+  hspf_result out{};
+  uint64_t ticket = 0;
+  struct Done { uint64_t ticket = 0; int rc = 0; hspf_stats st{}; std::string err; } done[4];
+  uint64_t last_done = 0;
 };
 
 namespace {
@@ -469,6 +509,9 @@ int alloc_arena(hspf_ctx *ctx, hspf_graph *g, uint32_t n, uint32_t cap) {
 
 extern "C" {
 
+static void lanes_quiesce(hspf_ctx *ctx);
+static void lanes_shutdown(hspf_ctx *ctx);
+
 uint32_t hspf_abi_version(void) { return HSPF_ABI_VERSION; }
 
 int hspf_device_count(void) {
@@ -476,6 +519,15 @@ int hspf_device_count(void) {
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) return e == hipErrorNoDevice ? 0 : HSPF_E_HIP;
   return n;
+}
+
+int hspf_recommend_cpu(uint32_t n_vertices, uint32_t n_edges, uint32_t n_roots) {
+  if (n_vertices == 0 || n_roots == 0) return 1;
+  const double n = (double)n_vertices;
+  const double dens = std::max(1.0, (double)n_edges / (8.0 * n));
+  const double cpu_ms = (double)n_roots * dens * (2.4e-4 * n + 7e-7 * n * n);   // reference-shaped loop, one core
+  const double gpu_ms = 0.032 + 3.5e-5 * n;                                     // one launch + one synchronisation + the sweeps (k_single_lean; tools/gpu_r04_probe.py tiny)
+  return cpu_ms < gpu_ms ? 1 : 0;
 }
 
 const char *hspf_strerror(int code) {
@@ -505,12 +557,15 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   if (const char *v = getenv("HSPF_VARIANT")) ctx->variant = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_SINGLE_MAX_N")) ctx->single_max_n = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_DENSE_PASSES")) ctx->lean_dense_passes = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(v, nullptr, 0), 1u), 32u);
-  if (const char *v = getenv("HSPF_DENSE_PCT")) ctx->lean_dense_pct = (uint32_t)strtoul(v, nullptr, 0);   // rows due (% of all) from which a sweep of k_fused_lean runs dense
+  if (const char *v = getenv("HSPF_DENSE_PCT")) ctx->lean_dense_pct = (uint32_t)strtoul(v, nullptr, 0);   // rows due (% of all) in a head sweep of k_fused_lean from which the dense stretch starts
+  if (const char *v = getenv("HSPF_DENSE_STAY_PCT")) ctx->lean_stay_pct = (uint32_t)strtoul(v, nullptr, 0);   // rows changed (% of all) by a dense pass below which the stretch ends
+  if (const char *v = getenv("HSPF_LEAN_HEAD")) ctx->lean_head = std::min<uint32_t>((uint32_t)strtoul(v, nullptr, 0), 60u);   // a first run's head sweeps
   if (const char *v = getenv("HSPF_LV_MAX_ROOTS")) ctx->lv_max_roots = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_LV_MIN_N")) ctx->lv_min_n = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_XCD_ROW_COST")) ctx->xcd_row_cost = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_UNIT_HEAVY_DEG")) ctx->unit_heavy_deg = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_HUB_DEG")) ctx->hub_deg = (uint32_t)strtoul(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_ASYNC_LANES")) ctx->lanes_cfg = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(v, nullptr, 0), 1u), 8u);
   if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return HSPF_E_NODEV; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
   for (auto &e : ctx->ev)
@@ -524,6 +579,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
 
 void hspf_shutdown(hspf_ctx *ctx) {
   if (!ctx) return;
+  lanes_shutdown(ctx);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
@@ -612,6 +668,7 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
 
 int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
   if (!ctx || !g || !rows) return HSPF_E_INVAL;
+  lanes_quiesce(ctx);                 // asynchronous runs of this context may still read the arrays a patch rewrites
   const uint32_t m = rows->n_changed, n = g->n;
   if (m == 0) return HSPF_OK;
   if (!rows->vertex || !rows->row_ptr || !rows->vflags) { ctx->last_error = "hspf_graph_patch: NULL array"; return HSPF_E_INVAL; }
@@ -788,7 +845,6 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
   for (uint32_t j = 0; j < m; ++j) g->vflags[rows->vertex[j]] = rows->vflags[j];
   g->row_ptr.swap(nrp);
   g->col.swap(ncol);
-  if (ctx->lean_sched_graph == (const void *)g) ctx->lean_sched_graph = nullptr;    // another topology: the sweep schedule is learned again
   rc = build_on_device(ctx, g);
   if (rc != HSPF_OK) (void)hipStreamSynchronize(s);
   return rc;
@@ -843,9 +899,9 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
 
 void hspf_graph_free(hspf_ctx *ctx, hspf_graph *g) {
   if (!g) return;
+  if (ctx) lanes_quiesce(ctx);
   if (ctx) { (void)hipSetDevice(ctx->device); if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); }
   if (g->arena) (void)hipFree(g->arena);
-  if (ctx && ctx->lean_sched_graph == (const void *)g) ctx->lean_sched_graph = nullptr;
   delete g;
 }
 
@@ -1052,7 +1108,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if (ctx->h_lane_cap < L) {
     if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
     ctx->h_lane_flags = nullptr; ctx->h_lane_cap = 0;
-    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lane_flags, ((size_t)L + 256) * 4, hipHostMallocDefault));
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lane_flags, ((size_t)L + 256 + LEAN_CTL_WORDS) * 4, hipHostMallocDefault));   // status bits | row counters | lean plan counters
     ctx->h_lane_cap = L;
   }
   // slices of the giant rows (FusedGraph::giant_part): tags, then GIANT_WORDS x 64 words per (batch, slice)
@@ -1171,6 +1227,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // (15 us + a launch latency) runs while the host wakes up, returns and prepares the next run.  Argument: index of
   // the chunk's last sweep.
   std::function<void(uint32_t)> spec_fill;
+  uint32_t *rb_ctl = nullptr;          // set by the lean path: its plan counters come back with every chunk's flags
+  uint32_t chunk_last = 0;             // index of the last sweep of the chunk `post` is enqueued behind
   auto run_phase = [&](uint32_t est, uint32_t pre_zeroed, auto &&launch, uint32_t &n_launch, auto &&post) -> int {
     hipError_t er = hipSuccess;
     uint32_t zeroed = std::min<uint32_t>(CHANGED_CAP, est + 4096);
@@ -1187,6 +1245,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       }
       for (uint32_t i = 0; i < chunk; ++i) launch(sweep + i);
       sweep += chunk;
+      chunk_last = sweep - 1u;
       post();
       // ONE read-back per chunk: the flags of every sweep launched so far and the per-root status bits
       if (ctx->h_changed_cap < sweep) {
@@ -1200,6 +1259,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       er = hipMemcpyAsync(ctx->h_changed, d_changed, (size_t)sweep * sizeof(int), hipMemcpyDeviceToHost, s);
       if (er == hipSuccess) er = hipMemcpyAsync(ctx->h_lane_flags, d_lf, (size_t)L * 4, hipMemcpyDeviceToHost, s);
       if (er == hipSuccess && fused && count_rows) er = hipMemcpyAsync(ctx->h_lane_flags + L, d_kcnt, 256 * 4, hipMemcpyDeviceToHost, s);
+      if (er == hipSuccess && rb_ctl) er = hipMemcpyAsync(ctx->h_lane_flags + L + 256, rb_ctl, LEAN_CTL_WORDS * 4, hipMemcpyDeviceToHost, s);
       if (er == hipSuccess && spec_fill) {
         er = hipEventRecord(ctx->ev[6], s);
         if (er == hipSuccess) { spec_fill(sweep - 1u); er = hipEventSynchronize(ctx->ev[6]); }
@@ -1227,6 +1287,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     uint32_t last_esz = 0;                    // state width of the last fused_run (0: none ran)
     uint32_t last_ns = n, last_fillw = 0xFFFFFFFFu;
     bool spec_done = false;                   // the last fused_run's speculative fill was enqueued behind its last chunk
+    bool emit_reset = false;                  // the emit of the current chunk resets the state it has read (k_emit_fused reset_guard)
     uint32_t spec_nz = 0;
     auto fused_run = [&](int mode) -> int {       // 0: 8-byte state, 1: 4-byte state (k_fused), 2: 4-byte state, lean sweep
       const bool nar = mode != 0, use_lean = mode == 2;
@@ -1245,7 +1306,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       else
         hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, rows * esz / 16, fillw, d_stamp, (size_t)B * n,
                            (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, pre_zeroed, d_lf, L,
-                           count_rows ? d_kcnt : (uint32_t *)nullptr, -1);
+                           count_rows ? d_kcnt : (uint32_t *)nullptr, -1, (uint32_t *)ctx->swcnt.p, ctx->swcnt.p ? LEAN_CTL_WORDS : 0u);
       last_esz = (uint32_t)esz; last_ns = ns; last_fillw = fillw;
       ctx->prefill.valid = false;                                // (a speculative fill of an earlier fused_run of this call is gone now)
       spec_done = false;
@@ -1253,8 +1314,9 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       if (!(ctx->variant & (2048u | 2097152u)))                  // HSPF_VARIANT bit11: no prefill at all; bit21: only after the run, as before
         spec_fill = [&, esz, ns, fillw, rows](uint32_t last_sweep) {
           const uint32_t nz = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
-          hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, rows * esz / 16, fillw, d_stamp, (size_t)B * n,
-                             (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, nz, d_lf, L, d_kcnt, (int)last_sweep);
+          // (the emit in front of this launch has reset the state slab under the same guard: stamps, flags and counters are left)
+          hipLaunchKernelGGL(k_init_fill, dim3(emit_reset ? 256 : 2048), dim3(256), 0, s, (uint4 *)d_st, emit_reset ? (size_t)0 : rows * esz / 16, fillw, d_stamp, (size_t)B * n,
+                             (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, nz, d_lf, L, d_kcnt, (int)last_sweep, (uint32_t *)ctx->swcnt.p, ctx->swcnt.p ? LEAN_CTL_WORDS : 0u);
           spec_nz = nz;
           spec_done = true;                                      // (valid only if the host finds the chunk converged, see below)
         };
@@ -1268,37 +1330,53 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L, ns);
       uint32_t n_f = 0;
       const bool maxinf = g->max_path_metric == HSPF_DIST_INF;
-      // The lean sweep's mode schedule (k_fused_lean): an SPF instance repeats its runs — same graph handle, same
-      // roots, costs patched in between —, and which sweeps are dense is a property of the topology and the roots.  The
-      // first run of a (graph, upload block) is plain mode 0; when the next run brings the same block again, it counts
-      // the rows evaluated per sweep (LEARN), and the runs after that follow the schedule.  A stale schedule costs time,
-      // never correctness (modes 1 / 2 evaluate a superset of the due rows).  HSPF_VARIANT bit19: always mode 0.
-      const bool sched_want = use_lean && !count_rows && !(ctx->variant & 524288u) && same_block;
-      const bool sched_on = sched_want && ctx->lean_sched_graph == (const void *)g && ctx->lean_sched_roots == n_roots;
-      const bool learn = sched_want && !sched_on;
-      if (learn) {
-        int e2 = ensure(ctx, ctx->swcnt, 256 * 256 * 4, false);
-        if (e2) return e2;
-        if (hipMemsetAsync(ctx->swcnt.p, 0, 256 * 256 * 4, s) != hipSuccess) { ctx->last_error = "sweep counters"; return HSPF_E_HIP; }
-      } else if (use_lean) {
-        int e2 = ensure(ctx, ctx->swcnt, 256 * 256 * 4, false);      // (the kernel takes the pointer in every mode)
+      // The lean sweep's plan (k_fused_lean): launch index -> what the launch is.  [0, h) head sweeps (stamped, counting
+      // their due rows; skipped on the device once one of them saw the frontier cover `lean_dense_pct` of the rows),
+      // [h, h + nd) the dense stretch (launches of up to HSPF_DENSE_PASSES passes, `P` passes in all; a pass is skipped on
+      // the device when the passes before it changed less than `lean_stay_pct` of the rows), h + nd the all-due stamped
+      // sweep that makes the stamps valid again, then stamped tail sweeps until one changes nothing.  h and P are what
+      // the previous run of this context used (+ 1 spare pass): a cost or structural patch, other roots, another graph
+      // all start from there, and a fresh context from (4, 16).  HSPF_VARIANT bit19: stamped sweeps only.
+      const bool plan_on = use_lean && !(ctx->variant & 524288u);
+      // several passes per launch only where a pass — all batches of the call — is long against what the chip holds at
+      // once (2 048 workgroups): a short pass would run NEXT TO its successor instead of ahead of it
+      const bool multi = ctx->lean_dense_passes > 1u && (uint64_t)fgrid.x * B >= 4096u;
+      const uint32_t per_launch = multi ? (uint32_t)std::min<uint64_t>(ctx->lean_dense_passes, ((1ull << 31) - 1u) / ((uint64_t)fgrid.x * B)) : 1u;
+      const uint32_t plan_h = plan_on ? std::min(ctx->lean_head, 60u) : 0u;
+      const uint32_t plan_P = plan_on ? std::min(std::max(ctx->lean_passes, 2u), std::min(ctx->lean_max_passes, 62u)) : 0u;
+      const uint32_t plan_nd = plan_on ? (plan_P + per_launch - 1u) / per_launch : 0u;
+      const uint64_t all_rows = (uint64_t)n * B;
+      // thresholds in sampled units (LEAN_SAMPLE): at least 1, so that "nothing counted" always reads as below
+      const uint32_t thr_enter = (uint32_t)std::min<uint64_t>(0xFFFFFFF0u, std::max<uint64_t>(1u, all_rows * ctx->lean_dense_pct / (100u * LEAN_SAMPLE)));
+      const uint32_t thr_stay = ctx->lean_stay_pct == 0u ? 0u : (uint32_t)std::min<uint64_t>(0xFFFFFFF0u, std::max<uint64_t>(1u, all_rows * ctx->lean_stay_pct / (100u * LEAN_SAMPLE)));
+      if (use_lean) {
+        int e2 = ensure(ctx, ctx->swcnt, LEAN_CTL_WORDS * 4, false);      // (the kernel takes the pointer in every mode)
         if (e2) return e2;
       }
+      uint32_t *d_ctl = (uint32_t *)ctx->swcnt.p;
+      // the run's launch-ahead estimate must reach past the all-due sweep: a chunk that ended inside the plan would pay a
+      // read-back (and an emit) for nothing
+      // (a context's first fused run starts from est_fused = 12: with the plan in front of them that would be six tail sweeps,
+      // and every further chunk costs a read-back and a speculative emit — twelve tail sweeps are launched ahead instead;
+      // a surplus launch exits at once)
+      if (plan_on) ctx->est_fused = std::max(ctx->est_fused, plan_h + plan_nd + (ctx->est_seen ? 2u : 13u));
+      ctx->est_seen = true;
+      rb_ctl = plan_on ? d_ctl : nullptr;
       int r2 = run_phase(ctx->est_fused, pre_zeroed, [&](uint32_t sweep) {
 #define HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, UN_, stp_) hipLaunchKernelGGL((k_fused<ST_, MI_, CN_, UN_>), fgrid, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, gd.in_ptr, gd.out_ptr, gd.vflags, stp_, d_roots, d_lf, net_nh, ignore_ovl, P, gd.in_src, gd.in_w, gd.out_dst, gd.e_in)
 #define HSPF_LAUNCH_FUSED(ST_, MI_, CN_, stp_) do { if (units) HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, true, stp_); else HSPF_LAUNCH_FUSED2(ST_, MI_, CN_, false, stp_); } while (0)
         const bool units = g->n_heavy_chunks != 0;
         if (use_lean) {
-#define HSPF_LAUNCH_LEAN(CN_, MD_, LR_, grid_, pb_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, LR_>), grid_, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, (uint32_t *)ctx->swcnt.p, pb_, B)
-          const int md = (sched_on && sweep < ctx->lean_sched.size()) ? (ctx->lean_sched[sweep] & 3) : 0;
-          const uint32_t passes = (sched_on && sweep < ctx->lean_sched.size()) ? std::max<uint32_t>(ctx->lean_sched[sweep] >> 2, 1u) : 1u;
-          if (md == 1) st.dbg[1] += passes;                           // hspf_stats::dbg[1] (lean sweep): dense passes
-          if (count_rows)  HSPF_LAUNCH_LEAN(true, 0, false, fgrid, 0u);
-          else if (learn)  HSPF_LAUNCH_LEAN(false, 0, true, fgrid, 0u);
-          else if (md == 1 && passes > 1u) HSPF_LAUNCH_LEAN(false, 1, false, dim3(fgrid.x * B * passes), fgrid.x);
-          else if (md == 1) HSPF_LAUNCH_LEAN(false, 1, false, fgrid, 0u);
-          else if (md == 2) HSPF_LAUNCH_LEAN(false, 2, false, fgrid, 0u);
-          else             HSPF_LAUNCH_LEAN(false, 0, false, fgrid, 0u);
+#define HSPF_LAUNCH_LEAN(CN_, MD_, HD_, grid_, pb_, base_, thr_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, HD_>), grid_, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, d_ctl, pb_, B, base_, thr_)
+#define HSPF_LAUNCH_LEAN_C(MD_, HD_, grid_, pb_, base_, thr_) do { if (count_rows) HSPF_LAUNCH_LEAN(true, MD_, HD_, grid_, pb_, base_, thr_); else HSPF_LAUNCH_LEAN(false, MD_, HD_, grid_, pb_, base_, thr_); } while (0)
+          if (sweep < plan_h) HSPF_LAUNCH_LEAN_C(0, true, fgrid, 0u, 0u, thr_enter);
+          else if (sweep < plan_h + plan_nd) {
+            const uint32_t base = (sweep - plan_h) * per_launch, np = std::min(per_launch, plan_P - base);
+            if (np > 1u) HSPF_LAUNCH_LEAN_C(1, false, dim3(fgrid.x * B * np), fgrid.x, base, thr_stay);
+            else         HSPF_LAUNCH_LEAN_C(1, false, fgrid, 0u, base, thr_stay);
+          } else if (plan_on && sweep == plan_h + plan_nd) HSPF_LAUNCH_LEAN_C(2, false, fgrid, 0u, 0u, 0u);
+          else HSPF_LAUNCH_LEAN_C(0, false, fgrid, 0u, 0u, 0u);
+#undef HSPF_LAUNCH_LEAN_C
 #undef HSPF_LAUNCH_LEAN
           return;
         }
@@ -1326,8 +1404,11 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         // results out of the packed state (speculative: valid when this chunk reached the fixed point and, for the
         // 4-byte state, no lane overflowed; otherwise redone behind the next chunk / the wide run)
         (void)hipEventRecord(ctx->ev[2], s);
-        if (nar) hipLaunchKernelGGL((k_emit_fused<uint32_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint32_t *)d_st, P, od, ns, use_lean ? d_lf : (uint32_t *)nullptr);
-        else     hipLaunchKernelGGL((k_emit_fused<uint64_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (const uint64_t *)d_st, P, od, ns, (uint32_t *)nullptr);
+        // (with the speculative fill on, the emit resets the tiles it has read: first half of the next run's scratch fill)
+        const int rg = spec_fill ? (int)chunk_last : -1;
+        emit_reset = rg >= 0;
+        if (nar) hipLaunchKernelGGL((k_emit_fused<uint32_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (uint32_t *)d_st, P, od, ns, use_lean ? d_lf : (uint32_t *)nullptr, (const int *)d_changed, rg, fillw);
+        else     hipLaunchKernelGGL((k_emit_fused<uint64_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, d_st, P, od, ns, (uint32_t *)nullptr, (const int *)d_changed, rg, fillw);
         (void)hipEventRecord(ctx->ev[4], s);      // "results in place": the phase's read-back synchronises behind it
         tail_done = true;
       });
@@ -1338,41 +1419,22 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       ctx->est_fused = n_f + 1;
       st.n_relax_launches += n_f;
       if (count_rows) for (uint32_t i = 0; i < 256; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
-      if (learn) {
-        // rows evaluated per sweep -> dense where (nearly) every row was due, then ONE all-due stamped sweep
-        std::vector<uint32_t> cnt(256 * 256);
-        if (hipMemcpy(cnt.data(), ctx->swcnt.p, cnt.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { ctx->last_error = "sweep counters"; return HSPF_E_HIP; }
-        const uint64_t all = (uint64_t)n * B;
-        const uint32_t ns_ = std::min<uint32_t>(n_f, 256u);
-        ctx->lean_sched.assign(ns_ + 1u, 0);
-        for (uint32_t sw = 0; sw < ns_; ++sw) {
-          uint64_t rows_ = 0;
-          for (uint32_t k = 0; k < 256; ++k) rows_ += cnt[sw * 256 + k];
-          if (rows_ * 100u >= all * (uint64_t)ctx->lean_dense_pct) ctx->lean_sched[sw] = 1;
-        }
-        for (uint32_t sw = 0; sw < ns_; ++sw)
-          if (ctx->lean_sched[sw] == 1 && ctx->lean_sched[sw + 1] != 1) ctx->lean_sched[sw + 1] = 2;
-        if (ns_ && ctx->lean_sched[0] == 1) ctx->lean_sched[0] = 2;     // (the first sweep follows k_init_fused's stamps; never dense in practice)
-        // a stretch of D dense sweeps -> ceil(D / K) launches of K passes each (entry = mode | passes << 2): no kernel
-        // boundary inside a launch (HSPF_DENSE_PASSES, default 16; 1: one sweep per launch)
-        // (only where a pass — all batches of the call — is long against what the chip holds at once, 2 048 workgroups: a
-        // short pass would run NEXT TO its successor instead of ahead of it and both would read the same stale rows)
-        if (ctx->lean_dense_passes > 1u && (uint64_t)fgrid.x * B >= 4096u && (uint64_t)fgrid.x * B * ctx->lean_dense_passes < (1ull << 31)) {
-          std::vector<uint8_t> out;
-          for (size_t sw = 0; sw < ctx->lean_sched.size();) {
-            if (ctx->lean_sched[sw] != 1) { out.push_back(ctx->lean_sched[sw++]); continue; }
-            size_t e2 = sw;
-            while (e2 < ctx->lean_sched.size() && ctx->lean_sched[e2] == 1) ++e2;
-            for (size_t left = e2 - sw; left != 0;) {
-              const uint32_t k = (uint32_t)std::min<size_t>(left, ctx->lean_dense_passes);
-              out.push_back((uint8_t)(1u | (k << 2)));
-              left -= k;
-            }
-            sw = e2;
-          }
-          ctx->lean_sched.swap(out);
-        }
-        ctx->lean_sched_graph = (const void *)g; ctx->lean_sched_roots = n_roots;
+      if (plan_on) {
+        // what the plan's launches decided (counters read back with the sweep flags): the next plan
+        const uint32_t *hc = ctx->h_lane_flags + L + 256;
+        uint32_t trig = plan_h;                                    // first head sweep that was skipped (the sentinel), or none
+        for (uint32_t k = 0; k < plan_h; ++k) if (hc[LEAN_CTL_DUE + k * LEAN_CTL_STRIDE] == LEAN_SENTINEL) { trig = k; break; }
+        uint32_t used = 0;                                         // dense passes that did work
+        for (uint32_t k = 0; k < plan_P; ++k) if (hc[LEAN_CTL_PCH + k * LEAN_CTL_STRIDE] != 0u) used = k + 1u;
+        // hspf_stats::dbg[1] (lean sweep): dense passes that did work | head sweeps that ran << 8 | passes planned << 16 | head sweeps planned << 24
+        st.dbg[1] = (used & 0xFFu) | ((trig & 0xFFu) << 8) | ((plan_P & 0xFFu) << 16) | ((plan_h & 0x7Fu) << 24);
+        // every head sweep ran and the last one still was below the threshold: one more next time (the dense stretch
+        // starts a sweep later); some were skipped: exactly as many as ran
+        const bool last_triggers = plan_h != 0u && hc[LEAN_CTL_DUE + (plan_h - 1u) * LEAN_CTL_STRIDE] != LEAN_SENTINEL && hc[LEAN_CTL_DUE + (plan_h - 1u) * LEAN_CTL_STRIDE] >= thr_enter;
+        if (trig < plan_h) ctx->lean_head = std::max(trig, 1u);
+        else if (plan_h != 0u && !last_triggers && used >= 2u) ctx->lean_head = std::min(plan_h + 1u, 60u);
+        // the stretch: one spare pass beyond what did work; a stretch that used every pass grows by half
+        ctx->lean_passes = used >= plan_P ? std::min(ctx->lean_max_passes, plan_P + plan_P / 2u + 1u) : std::max(used + 1u, 2u);
       }
       return HSPF_OK;
     };
@@ -1511,7 +1573,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       // the speculative fill behind the last chunk's read-back has done it already
       const uint32_t nz = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
       hipLaunchKernelGGL(k_init_fill, dim3(2048), dim3(256), 0, s, (uint4 *)d_st, (size_t)B * last_ns * 64 * last_esz / 16, last_fillw, d_stamp, (size_t)B * n,
-                         (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, nz, d_lf, L, d_kcnt, -1);
+                         (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, nz, d_lf, L, d_kcnt, -1, (uint32_t *)ctx->swcnt.p, ctx->swcnt.p ? LEAN_CTL_WORDS : 0u);
       ctx->prefill = hspf_ctx::Prefill{true, g->build_id, n, B, last_esz, nz, L, true, last_ns, last_fillw};
     }
   } else {
@@ -1784,6 +1846,113 @@ int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out) {
   *out = ctx->stats;
   return HSPF_OK;
 }
+
+// ---- asynchronous runs ------------------------------------------------------------------------
+// The reference runs one SPF per instance thread at a time (holo-protocol/src/lib.rs:427-430); what it does have is
+// SEVERAL independent runs per event: one per area (holo-ospf/src/spf.rs:540-542), per level and topology
+// (holo-isis/src/spf.rs:746-761), per neighbour (flooding/manet.rs:59-69).  These entry points let ONE caller thread keep
+// several of them in flight on one GPU.
+
+static int lanes_ensure(hspf_ctx *ctx) {
+  if (!ctx->lanes.empty()) return HSPF_OK;
+  if (ctx->parent) { ctx->last_error = "asynchronous runs on a lane context"; return HSPF_E_INVAL; }
+  (void)hipSetDevice(ctx->device);
+  for (uint32_t i = 0; i < ctx->lanes_cfg; ++i) {
+    hspf_lane *ln = new (std::nothrow) hspf_lane();
+    if (!ln) { lanes_shutdown(ctx); return HSPF_E_NOMEM; }
+    int rc = hspf_init(ctx->device, &ln->sub);
+    if (rc == HSPF_OK) {
+      hspf_ctx *c = ln->sub;
+      c->parent = ctx;
+      // the caller's context decides the tunables (a lane's own hspf_init read the environment of a later moment)
+      c->variant = ctx->variant; c->single_max_n = ctx->single_max_n; c->lv_max_roots = ctx->lv_max_roots; c->lv_min_n = ctx->lv_min_n;
+      c->lean_dense_pct = ctx->lean_dense_pct; c->lean_stay_pct = ctx->lean_stay_pct; c->lean_dense_passes = ctx->lean_dense_passes;
+      c->lean_head = ctx->lean_head; c->lean_passes = ctx->lean_passes; c->hub_deg = ctx->hub_deg;
+      c->unit_heavy_deg = ctx->unit_heavy_deg; c->xcd_row_cost = ctx->xcd_row_cost;
+    }
+    if (rc != HSPF_OK) { if (ln->sub) hspf_shutdown(ln->sub); delete ln; lanes_shutdown(ctx); ctx->last_error = "could not create a lane context"; return rc; }
+    ctx->lanes.push_back(ln);
+    ln->th = std::thread([ln, nl = ctx->lanes_cfg]() {
+      for (;;) {
+        std::unique_lock<std::mutex> lk(ln->mu);
+        ln->cv.wait(lk, [&] { return ln->has_job || ln->quit; });
+        if (!ln->has_job) return;                                   // quit, nothing pending
+        const hspf_graph *g = ln->g; const uint32_t flags = ln->flags; hspf_result out = ln->out; const uint64_t t = ln->ticket;
+        lk.unlock();
+        (void)hipSetDevice(ln->sub->device);
+        const int rc = guarded(ln->sub, [&]() { return run_classes(ln->sub, g, ln->roots.data(), (uint32_t)ln->roots.size(), flags, &out, false); });
+        lk.lock();
+        hspf_lane::Done &d = ln->done[(t / nl) & 3u];
+        d.ticket = t; d.rc = rc; d.st = ln->sub->stats;
+        try { d.err = rc ? ln->sub->last_error : std::string(); } catch (...) {}
+        ln->last_done = t; ln->has_job = false;
+        ln->cv.notify_all();
+      }
+    });
+  }
+  return HSPF_OK;
+}
+
+static void lanes_quiesce(hspf_ctx *ctx) {
+  for (hspf_lane *ln : ctx->lanes) {
+    std::unique_lock<std::mutex> lk(ln->mu);
+    ln->cv.wait(lk, [&] { return !ln->has_job; });
+    // a finished run leaves the next run's scratch fill behind on the lane's stream, and that launch reads the graph's row flags
+    (void)hipSetDevice(ln->sub->device);
+    if (ln->sub->stream) (void)hipStreamSynchronize(ln->sub->stream);
+  }
+}
+
+static void lanes_shutdown(hspf_ctx *ctx) {
+  for (hspf_lane *ln : ctx->lanes) {
+    { std::lock_guard<std::mutex> lk(ln->mu); ln->quit = true; }
+    ln->cv.notify_all();
+    if (ln->th.joinable()) ln->th.join();
+    if (ln->sub) hspf_shutdown(ln->sub);
+    delete ln;
+  }
+  ctx->lanes.clear();
+}
+
+int hspf_run_device_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                          const hspf_result *out_device, uint64_t *ticket) {
+  if (!ctx || !g || !roots || !out_device || !ticket || n_roots == 0 || !out_device->dist) return HSPF_E_INVAL;
+  return guarded(ctx, [&]() {
+    int rc = lanes_ensure(ctx);
+    if (rc) return rc;
+    const uint64_t t = ctx->next_ticket++;
+    hspf_lane *ln = ctx->lanes[t % ctx->lanes.size()];
+    std::unique_lock<std::mutex> lk(ln->mu);
+    ln->cv.wait(lk, [&] { return !ln->has_job; });                  // the lane's previous run (ticket t - lanes) has to be over
+    ln->g = g; ln->roots.assign(roots, roots + n_roots); ln->flags = run_flags; ln->out = *out_device; ln->ticket = t;
+    ln->has_job = true;
+    lk.unlock();
+    ln->cv.notify_all();
+    *ticket = t;
+    return (int)HSPF_OK;
+  });
+}
+
+int hspf_wait(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats) {
+  if (!ctx || ticket == 0 || ticket >= ctx->next_ticket || ctx->lanes.empty()) return HSPF_E_INVAL;
+  hspf_lane *ln = ctx->lanes[ticket % ctx->lanes.size()];
+  std::unique_lock<std::mutex> lk(ln->mu);
+  ln->cv.wait(lk, [&] { return ln->last_done >= ticket; });
+  const hspf_lane::Done &d = ln->done[(ticket / ctx->lanes.size()) & 3u];
+  if (d.ticket != ticket) { ctx->last_error = "hspf_wait: the ticket's result is gone (more than four later runs on its lane)"; return HSPF_E_INVAL; }
+  ctx->stats = d.st;
+  if (stats) *stats = d.st;
+  if (d.rc) { try { ctx->last_error = d.err; } catch (...) {} }
+  return d.rc;
+}
+
+int hspf_wait_all(hspf_ctx *ctx) {
+  if (!ctx) return HSPF_E_INVAL;
+  lanes_quiesce(ctx);
+  return HSPF_OK;
+}
+
+uint32_t hspf_async_lanes(const hspf_ctx *ctx) { return ctx ? (ctx->lanes.empty() ? ctx->lanes_cfg : (uint32_t)ctx->lanes.size()) : 0u; }
 
 static int routes_device_impl(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uint32_t n_mask_words,
                               const uint32_t *dist_dev, const uint16_t *flags_dev, const uint64_t *mask_dev,

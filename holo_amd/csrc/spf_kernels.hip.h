@@ -1159,23 +1159,47 @@ __device__ __forceinline__ LeanOut lean_case(__amdgpu_buffer_rsrc_t rs, uint32_t
   return lean_reduce<L>(c, wk, paym);
 }
 
-// MODE (chosen per launch by the host from the schedule it LEARNed on the previous run of the same graph and roots):
+// MODE (per launch; the host enqueues a PLAN — head sweeps, dense stretch, one all-due sweep, tail sweeps — and the
+// launches decide ON THE DEVICE, from counters earlier launches / passes left in `ctl`, whether they still have a job):
 //   0  stamped: a row is due when an in-neighbour changed in the previous sweep (activation stamps), the form above;
+//      HEAD (the sweeps before the dense stretch): a sample of the waves adds its due rows to ctl[LEAN_CTL_DUE + sweep];
+//      a head sweep whose predecessor counted at least `thr` (sampled units) — or was itself skipped: the sentinel —
+//      does nothing but pass the sentinel on: the frontier covers the graph, the dense stretch is next;
 //   1  dense:   every row is evaluated, no stamp is read or written — in the middle of a run (sweeps ~4-19 of 28 on
 //               isis-100k) every row IS due, and the stamps cost a dependent round trip at the head of every wave
-//               (stamps before records), a 64-byte offset row per vertex and a scattered store per changed row;
+//               (stamps before records), a 64-byte offset row per vertex and a scattered store per changed row; a
+//               sample of the waves adds its changed rows to ctl[LEAN_CTL_PCH + pass], and pass p does nothing when
+//               pass p - 2 or p - 3 counted fewer than `thr`: the stretch ends where the corrections thin out, wherever
+//               the host guessed its end (a first run on an unknown graph guesses long);
 //   2  all due, stamped: the first sweep after a dense stretch (the stamps are stale: every row is evaluated, changed rows
 //               stamp their out-neighbours again, and mode 0 can follow).
-// Any schedule is correct: modes 1 and 2 evaluate a superset of the due rows.  LEARN (mode 0 only): rows evaluated per
-// sweep, added to swcnt[256 sweep + ...] (first 256 sweeps; 256 counters per sweep: 25 000 waves adding to 16 took 5 ms a run).
-template <bool COUNT, int MODE, bool LEARN>
+// Any plan and any outcome of the device-side decisions is correct: modes 1 and 2 evaluate a superset of the due rows, a
+// skipped launch or pass sets its `changed` flag so that the chain of launches reaches the all-due sweep, and the run
+// ends only behind a stamped (or all-rows) launch that changed nothing.  No rehearsal run, nothing learned per graph:
+// the first run of a fresh context takes the same path as the thousandth (round 3 LEARNed a schedule on the second
+// identical run and lost it with every structural patch).
+// Every counter has a 128-byte line of its own (LEAN_CTL_STRIDE words): a pass reads the counters of the passes two and
+// three before it with PLAIN loads — the line of pass p - 2 is touched for the first time when pass p starts, i.e. when
+// pass p - 2 is over, so the first fetch of an XCD's L2 brings the final count and every later one may hit.  (Counters
+// sharing a line would be served stale from L2 for the rest of the launch; agent-scope loads by every wave — 50 000 per
+// pass at ONE address — made a dense pass 4x slower, profiles/r04_notes.md r04a.)
+constexpr uint32_t LEAN_CTL_STRIDE = 32u;
+constexpr uint32_t LEAN_CTL_DUE = 0u, LEAN_CTL_PCH = 64u * LEAN_CTL_STRIDE, LEAN_CTL_WORDS = 128u * LEAN_CTL_STRIDE;   // 64 head sweeps, 64 dense passes
+constexpr uint32_t LEAN_SAMPLE = 32u;                                             // wave 0 of every 8th block of an XCD's range counts
+constexpr uint32_t LEAN_SENTINEL = 0xFFFFFFFFu;
+template <bool COUNT, int MODE, bool HEAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fused_lean(
     const FusedGraph *__restrict__ gp, int *changed, int sweep, uint32_t *__restrict__ act,
     const uint8_t *__restrict__ hnb, uint32_t n_arg, const uint32_t *__restrict__ ell_so, const uint32_t *__restrict__ ell_w,
     uint32_t *__restrict__ st, const uint32_t *__restrict__ ell_od, const uint32_t *__restrict__ roots, uint32_t *lane_flags,
-    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P, uint32_t *__restrict__ swcnt, uint32_t pass_blocks, uint32_t pass_batches) {
+    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P, uint32_t *__restrict__ ctl, uint32_t pass_blocks, uint32_t pass_batches,
+    uint32_t pass_base, uint32_t thr) {
   typedef uint32_t ST;
   if (sweep > 0 && changed[sweep - 1] == 0) return;
+  if (HEAD && sweep > 0 && ctl[LEAN_CTL_DUE + ((uint32_t)sweep - 1u) * LEAN_CTL_STRIDE] >= thr) {   // the dense stretch is due: pass the word on, keep the chain alive
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { ctl[LEAN_CTL_DUE + (uint32_t)sweep * LEAN_CTL_STRIDE] = LEAN_SENTINEL; changed[sweep] = 1; }
+    return;
+  }
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // Dense launches may carry SEVERAL passes over the rows: a 1-D grid of passes x batches x blocks, pass p = blocks
@@ -1188,7 +1212,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
   const uint32_t batch = (MODE == 1 && pass_blocks != 0u) ? (blockIdx.x / pass_blocks) % pass_batches : blockIdx.y;
   const uint32_t n = n_arg;
   const uint32_t bx = (MODE == 1 && pass_blocks != 0u) ? blockIdx.x % pass_blocks : blockIdx.x;
+  // dense pass p of the stretch (counted across its launches): nothing to do when pass p - 2 or p - 3 saw the corrections
+  // thin out (their counters: plain loads, one line each, see LEAN_CTL_STRIDE)
+  const uint32_t pg = MODE == 1 ? pass_base + (pass_blocks != 0u ? blockIdx.x / (pass_blocks * pass_batches) : 0u) : 0u;
+  uint32_t pc2 = LEAN_SENTINEL, pc3 = LEAN_SENTINEL;
+  if (MODE == 1 && thr != 0u && pg >= 2u && pg < 64u) {                 // thr = 0 (HSPF_DENSE_STAY_PCT=0): every planned pass runs
+    pc2 = ctl[LEAN_CTL_PCH + (pg - 2u) * LEAN_CTL_STRIDE];
+    if (pg >= 3u) pc3 = ctl[LEAN_CTL_PCH + (pg - 3u) * LEAN_CTL_STRIDE];
+  }
+  const bool sampler = wave == 0u && ((bx >> 3) & 7u) == 0u;
   const uint32_t chunk = xcd_chunk(gp->g.xcd_start, bx);
+  if (MODE == 1 && min(pc2, pc3) < thr) {                       // a stopped pass must not read as "nothing left to do"
+    if (bx == 0u && batch == 0u && threadIdx.x == 0) changed[sweep] = 1;
+    return;
+  }
   if (chunk == 0xFFFFFFFFu) return;
   const uint32_t wbeg = chunk * (uint32_t)FVPB + wave * (uint32_t)FVPW;
   if (wbeg >= n) return;
@@ -1201,6 +1238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
   const uint32_t hb = hnb[(size_t)batch * n + vl] & (ignore_ovl ? ~RF_NT : ~0u);
   const uint32_t due4 = (uint32_t)__ballot(lane < (uint32_t)VPW && wbeg + lane < n && av >= cur);
   if (MODE == 0 && due4 == 0u) return;
+  if (HEAD && sampler && lane == 0 && (uint32_t)sweep < 64u) atomicAdd(&ctl[LEAN_CTL_DUE + (uint32_t)sweep * LEAN_CTL_STRIDE], (uint32_t)__builtin_popcount(due4));
   // ---- everything else whose address depends on the wave's vertex range alone (ELL row n exists: all pad)
   ST *S = st + (size_t)batch * (n + 1u) * 64;                      // slab of n + 1 rows: row n = the pad row (never reached)
   const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, (n + 1u) << 8);
@@ -1230,7 +1268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
   const uint32_t hopm = P.hmax << P.mbits, maskm = (1u << P.mbits) - 1u;
   uint64_t any = 0ull;
   bool need_exact = false;
-  uint32_t n_done = 0;
+  uint32_t n_done = 0, n_chg = 0;
   // result of fast row i -> state, wake-ups (info bit 5: more than 16 out-links: they are walked, k_fused's loop)
   auto commit = [&](auto I, uint32_t nw) {
     constexpr int i = decltype(I)::value;
@@ -1240,7 +1278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
     if (ch == 0ull) return;
     __builtin_amdgcn_raw_buffer_store_b32(nw, rs, lane4, v << 8, 0);          // the whole row: unchanged lanes rewrite their own value
     any |= ch;
-    if (MODE == 1) return;                                                    // dense: nobody reads stamps
+    if (MODE == 1) { ++n_chg; return; }                                       // dense: nobody reads stamps
     if (!(info[i] & 0x20u)) { __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, od[i], 0, 0); return; }   // wake the out-neighbours up
     const GraphDev &g = gp->g;
     const uint32_t o0 = g.out_ptr[v], o1 = g.out_ptr[v + 1];
@@ -1308,7 +1346,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
       if (ch == 0ull) continue;
       __builtin_amdgcn_raw_buffer_store_b32(nw, rs, lane4, v << 8, 0);
       any |= ch;
-      if (MODE == 1) continue;
+      if (MODE == 1) { ++n_chg; continue; }
       if (!(inf_i & 0x20u)) { __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, od_i, 0, 0); continue; }
       const GraphDev &g = gp->g;
       const uint32_t o0 = g.out_ptr[v], o1 = g.out_ptr[v + 1];
@@ -1335,13 +1373,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
     if (ch == 0ull) continue;
     __builtin_amdgcn_raw_buffer_store_b32(r.nw, rs, lane4, v << 8, 0);
     any |= ch;
-    if (MODE == 1) continue;
+    if (MODE == 1) { ++n_chg; continue; }
     const uint32_t o0 = g.out_ptr[v], o1 = g.out_ptr[v + 1];
     for (uint32_t ob = o0 + lane; ob < o1; ob += 64) __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, g.out_dst[ob] * 4u, 0, 0);
   }
   if (any != 0ull && lane == 0) changed[sweep] = 1;
   if (COUNT && lane == 0) atomicAdd(&gp->rows_done[(blockIdx.x + wave) & 255u], n_done);
-  if (LEARN && lane == 0 && sweep < 256) atomicAdd(&swcnt[(uint32_t)sweep * 256u + ((blockIdx.x * 4u + wave) & 255u)], (uint32_t)__builtin_popcount(due4));
+  if (MODE == 1 && sampler && lane == 0 && n_chg != 0u && pg < 64u) atomicAdd(&ctl[LEAN_CTL_PCH + pg * LEAN_CTL_STRIDE], n_chg);
   uint32_t lf = 0;
   if (need_exact) lf |= LF_NEED_EXACT;
   if (lf) atomicOr(&lane_flags[root_slot], lf);
@@ -1896,7 +1934,7 @@ __global__ __launch_bounds__(256) void k_init_fill(uint4 *__restrict__ st16, siz
                                                    const uint8_t *__restrict__ rowflags, uint8_t *__restrict__ hnb, uint32_t n,
                                                    int *__restrict__ changed, uint32_t n_changed,
                                                    uint32_t *__restrict__ lane_flags, uint32_t n_lf, uint32_t *__restrict__ kcnt,
-                                                   int guard_sweep) {
+                                                   int guard_sweep, uint32_t *__restrict__ ctl = nullptr, uint32_t n_ctl = 0u) {
   // guard_sweep >= 0: enqueued SPECULATIVELY behind the emit and the flag read-back of a chunk of sweeps, before the host
   // knows whether the chunk reached the fixed point: a chunk whose last sweep still changed something is not over, its
   // state must stay.  (Every thread reads the flag before any thread can have zeroed it to a different value: a
@@ -1909,6 +1947,7 @@ __global__ __launch_bounds__(256) void k_init_fill(uint4 *__restrict__ st16, siz
   for (size_t i = t; i < n_changed; i += T) changed[i] = 0;
   for (size_t i = t; i < n_lf; i += T) lane_flags[i] = 0u;
   if (kcnt && t < 256) kcnt[t] = 0u;
+  if (ctl && t < n_ctl) ctl[t] = 0u;                                    // the lean sweep's due / changed counters (LEAN_CTL_WORDS)
 }
 
 // init for the fused path: roots' own lanes = (0, 0, 0); their out-neighbours are due in the
@@ -1955,16 +1994,23 @@ __global__ void k_clear_lane_flag(uint32_t *lane_flags, uint32_t n_lf, uint32_t 
 }
 
 // Emit for the fused path: packed lane-major state -> row-major results.
+// reset_guard >= 0: the emit is also the first half of the NEXT run's scratch fill — a tile that has been read is
+// overwritten with "not reached" (fillw), provided the chunk of sweeps in front of this emit reached the fixed point
+// (changed[reset_guard] == 0: the flag k_init_fill's speculative launch tests, which then skips the 25.6 MB state slab:
+// 14 us -> ~3 us per run).  An emit behind a chunk that had not converged leaves the state alone.
 template <typename ST>
-__global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots, const ST *__restrict__ st,
-                                                    FusedParams P, OutDev o, uint32_t ns, uint32_t *lane_flags) {
+__global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots, ST *__restrict__ st,
+                                                    FusedParams P, OutDev o, uint32_t ns, uint32_t *lane_flags,
+                                                    const int *__restrict__ changed, int reset_guard, uint32_t fillw) {
   __shared__ ST tt[64][65];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t batch = blockIdx.y, v0 = blockIdx.x * 64;
   const uint32_t nv = min(64u, n - v0);
   const uint32_t r0 = batch * 64;
   const uint32_t nr = min(64u, n_roots - r0);
-  const ST *S = st + ((size_t)batch * ns + v0) * 64;
+  ST *S = st + ((size_t)batch * ns + v0) * 64;
+  const bool reset = reset_guard >= 0 && changed[reset_guard] == 0;
+  const ST fillv = sizeof(ST) == 8 ? (ST)(((uint64_t)fillw << 32) | fillw) : (ST)fillw;
   // lane_flags != null (lean sweep, 4-byte state): the fields are checked HERE, once per final word, instead of in
   // every row evaluation — a reached lane within one link cost of "not reached" (P.ovf_t), or a hop count that
   // saturated (P.hmax), means some value on the way may have been clipped: LF_OVERFLOW, the run is redone wide.  Clipped
@@ -1973,6 +2019,7 @@ __global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots
   for (uint32_t j = wave; j < nv; j += 4) {
     const ST x = S[(size_t)j * 64 + lane];
     tt[j][lane] = x;
+    if (reset) S[(size_t)j * 64 + lane] = fillv;
     if (sizeof(ST) == 4 && lane_flags)
       ovf = ovf || ((uint32_t)x < P.inf_t && ((uint32_t)x >= P.ovf_t || (((uint32_t)x >> P.mbits) & P.hmax) == P.hmax));
   }

@@ -59,6 +59,9 @@ struct hspf_multi {
   struct Pending { const void *key; hipEvent_t ev; uint32_t local; };
   std::vector<Pending> pending;                      // asynchronous gathers in flight, keyed by the dist table they fill
   bool force_bcast = false;
+  struct Ticket { uint64_t id; std::vector<uint64_t> t; std::vector<uint8_t> has; uint32_t n_roots; size_t n_vertices; };
+  std::vector<Ticket> tickets;                       // hspf_multi_run_async calls not yet waited for
+  uint64_t next_ticket = 1;
   std::vector<std::vector<hipEvent_t>> free_events;  // per LOCAL device: an event is only ever recorded on the device it was created on
   std::string last_error;
 };
@@ -290,11 +293,23 @@ int hspf_multi_wait(hspf_multi *m) {
   return rc;
 }
 
-int hspf_multi_run(hspf_multi *m, const hspf_multi_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
-                   hspf_result *all, uint32_t gather) {
-  if (!m || !g || !roots || !all || n_roots == 0 || g->g.size() != m->ctx.size()) return HSPF_E_INVAL;
-  const uint32_t nl = (uint32_t)m->ctx.size();
-  // an asynchronous gather of an earlier call may still be filling these very tables: wait for THAT one only
+// rows of local device i for this job: its slice of the roots, its tables moved to the slice's first row
+static bool multi_slice(const hspf_multi *m, const hspf_multi_graph *g, uint32_t i, uint32_t n_roots, const hspf_result *all,
+                        uint32_t &b, uint32_t &e, hspf_result &part) {
+  hspf_shard_bounds(n_roots, m->world, m->first_rank + i, &b, &e);
+  part = all[i];
+  if (e == b) return false;
+  const size_t n = g->g[i]->n, off = (size_t)b * n;
+  part.dist = all[i].dist + off;
+  if (all[i].hops) part.hops = all[i].hops + off;
+  if (all[i].vflags_out) part.vflags_out = all[i].vflags_out + off;
+  if (all[i].first_hop_mask) part.first_hop_mask = all[i].first_hop_mask + off * all[i].n_mask_words;
+  if (all[i].pop_rank) part.pop_rank = all[i].pop_rank + off;
+  return true;
+}
+
+// an asynchronous gather of an earlier call may still be filling these very tables: wait for THAT one only
+static void multi_wait_pending_into(hspf_multi *m, const hspf_result *all) {
   for (size_t k = 0; k < m->pending.size();) {
     auto &p = m->pending[k];
     if (p.key == (const void *)all[p.local].dist) {
@@ -303,35 +318,14 @@ int hspf_multi_run(hspf_multi *m, const hspf_multi_graph *g, const uint32_t *roo
       m->pending.erase(m->pending.begin() + (long)k);
     } else ++k;
   }
-  std::vector<int> rcs(nl, HSPF_OK);
-  auto one = [&](uint32_t i) {
-    uint32_t b, e; hspf_shard_bounds(n_roots, m->world, m->first_rank + i, &b, &e);
-    m->ctx[i]->stats = hspf_stats{};
-    if (e == b) return;
-    const size_t n = m->ctx[i] ? g->g[i]->n : 0, off = (size_t)b * n;
-    hspf_result part = all[i];
-    if (!part.dist) { rcs[i] = HSPF_E_INVAL; return; }
-    part.dist = all[i].dist + off;
-    if (all[i].hops) part.hops = all[i].hops + off;
-    if (all[i].vflags_out) part.vflags_out = all[i].vflags_out + off;
-    if (all[i].first_hop_mask) part.first_hop_mask = all[i].first_hop_mask + off * all[i].n_mask_words;
-    if (all[i].pop_rank) part.pop_rank = all[i].pop_rank + off;
-    rcs[i] = hspf_run_device(m->ctx[i], g->g[i], roots + b, e - b, run_flags, &part);
-  };
-  try {
-    if (nl == 1) one(0);
-    else {
-      std::vector<std::thread> th;
-      for (uint32_t i = 0; i < nl; ++i) th.emplace_back(one, i);
-      for (auto &t : th) t.join();
-    }
-  } catch (...) { m->last_error = "hspf_multi_run: could not start the per-device host threads"; return HSPF_E_NOMEM; }
-  for (uint32_t i = 0; i < nl; ++i)
-    if (rcs[i]) { m->last_error = m->ctx[i]->last_error; return rcs[i]; }
+}
+
+// the exchange behind a run (hspf_multi_run / hspf_multi_run_wait): the tables selected in `gather`, all-gathered in place
+static int multi_gather(hspf_multi *m, size_t n, uint32_t n_roots, hspf_result *all, uint32_t gather) {
+  const uint32_t nl = (uint32_t)m->ctx.size();
   if (!(gather & 0xFu) || m->world == 1) return HSPF_OK;
   const bool async = (gather & HSPF_GATHER_ASYNC) != 0;
   std::vector<void *> tabs(nl);
-  const size_t n = g->g[0]->n;
   struct T { uint32_t bit; size_t row_bytes; int which; };
   for (const T &t : {T{HSPF_GATHER_DIST, n * 4, 0}, T{HSPF_GATHER_HOPS, n * 2, 1}, T{HSPF_GATHER_FLAGS, n * 2, 2}, T{HSPF_GATHER_MASK, 0, 3}}) {
     if (!(gather & t.bit)) continue;
@@ -362,6 +356,70 @@ int hspf_multi_run(hspf_multi *m, const hspf_multi_graph *g, const uint32_t *roo
     }
   }
   return HSPF_OK;
+}
+
+int hspf_multi_run_async(hspf_multi *m, const hspf_multi_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                         const hspf_result *all, uint64_t *ticket) {
+  if (!m || !g || !roots || !all || !ticket || n_roots == 0 || g->g.size() != m->ctx.size()) return HSPF_E_INVAL;
+  const uint32_t nl = (uint32_t)m->ctx.size();
+  multi_wait_pending_into(m, all);
+  try {
+    hspf_multi::Ticket tk{m->next_ticket, std::vector<uint64_t>(nl, 0), std::vector<uint8_t>(nl, 0), n_roots, (size_t)g->g[0]->n};
+    for (uint32_t i = 0; i < nl; ++i) {
+      uint32_t b, e; hspf_result part;
+      m->ctx[i]->stats = hspf_stats{};
+      if (!all[i].dist) return HSPF_E_INVAL;
+      if (!multi_slice(m, g, i, n_roots, all, b, e, part)) continue;
+      const int rc = hspf_run_device_async(m->ctx[i], g->g[i], roots + b, e - b, run_flags, &part, &tk.t[i]);
+      if (rc) {                                       // what was handed out already is waited for: no run may outlive its tables
+        for (uint32_t j = 0; j < i; ++j) if (tk.has[j]) (void)hspf_wait(m->ctx[j], tk.t[j], nullptr);
+        m->last_error = m->ctx[i]->last_error; return rc;
+      }
+      tk.has[i] = 1;
+    }
+    m->tickets.push_back(std::move(tk));
+  } catch (...) { m->last_error = "hspf_multi_run_async: host allocation failed"; return HSPF_E_NOMEM; }
+  *ticket = m->next_ticket++;
+  return HSPF_OK;
+}
+
+int hspf_multi_run_wait(hspf_multi *m, uint64_t ticket, hspf_result *all, uint32_t gather) {
+  if (!m || !all) return HSPF_E_INVAL;
+  size_t k = 0;
+  while (k < m->tickets.size() && m->tickets[k].id != ticket) ++k;
+  if (k == m->tickets.size()) return HSPF_E_INVAL;
+  const hspf_multi::Ticket tk = m->tickets[k];
+  m->tickets.erase(m->tickets.begin() + (long)k);
+  int rc = HSPF_OK;
+  for (uint32_t i = 0; i < (uint32_t)m->ctx.size(); ++i) {
+    if (!tk.has[i]) continue;
+    const int r = hspf_wait(m->ctx[i], tk.t[i], nullptr);         // (leaves the run's statistics in ctx[i]->stats)
+    if (r && rc == HSPF_OK) { rc = r; m->last_error = m->ctx[i]->last_error; }
+  }
+  if (rc) return rc;
+  return multi_gather(m, tk.n_vertices, tk.n_roots, all, gather);
+}
+
+int hspf_multi_run(hspf_multi *m, const hspf_multi_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                   hspf_result *all, uint32_t gather) {
+  if (!m || !g || !roots || !all || n_roots == 0 || g->g.size() != m->ctx.size()) return HSPF_E_INVAL;
+  const uint32_t nl = (uint32_t)m->ctx.size();
+  if (nl == 1) {                                       // one local device: on the caller's thread, on the context's own stream
+    multi_wait_pending_into(m, all);
+    uint32_t b, e; hspf_result part;
+    m->ctx[0]->stats = hspf_stats{};
+    if (!all[0].dist) return HSPF_E_INVAL;
+    if (multi_slice(m, g, 0, n_roots, all, b, e, part)) {
+      const int rc = hspf_run_device(m->ctx[0], g->g[0], roots + b, e - b, run_flags, &part);
+      if (rc) { m->last_error = m->ctx[0]->last_error; return rc; }
+    }
+  } else {                                             // several: every device's slice on a lane of its context, all at once
+    uint64_t t = 0;
+    int rc = hspf_multi_run_async(m, g, roots, n_roots, run_flags, all, &t);
+    if (rc == HSPF_OK) rc = hspf_multi_run_wait(m, t, all, 0u);
+    if (rc) return rc;
+  }
+  return multi_gather(m, g->g[0]->n, n_roots, all, gather);
 }
 
 int hspf_multi_get_stats(const hspf_multi *m, uint32_t i, hspf_stats *out) {

@@ -266,6 +266,35 @@ class SpfContext:
             raise HspfError(rc, "hspf_run_device", self.last_error())
         return self.stats()
 
+    def run_device_async(self, graph: SpfGraph, roots: Sequence[int], run_flags: int, *, dist_ptr: int,
+                         hops_ptr: int = 0, flags_ptr: int = 0, mask_ptr: int = 0, mask_words: int = 1) -> int:
+        """hspf_run_device_async(): hands the run to a lane of this context and returns its ticket at once; the device
+        buffers must stay valid (and unshared with other runs in flight) until wait(ticket)."""
+        roots = np.ascontiguousarray(roots, dtype=np.uint32)
+        res = L.HspfResult(dist_ptr or None, hops_ptr or None, flags_ptr or None, mask_ptr or None, mask_words, None)
+        t = ctypes.c_uint64()
+        rc = self.lib.hspf_run_device_async(self.handle, graph.handle, _u32(roots), len(roots), run_flags,
+                                            ctypes.byref(res), ctypes.byref(t))
+        if rc != 0:
+            raise HspfError(rc, "hspf_run_device_async", self.last_error())
+        return int(t.value)
+
+    def wait(self, ticket: int) -> dict:
+        """hspf_wait(): blocks until the run behind `ticket` is over; returns its stats."""
+        s = L.HspfStats()
+        rc = self.lib.hspf_wait(self.handle, ticket, ctypes.byref(s))
+        if rc != 0:
+            raise HspfError(rc, "hspf_wait", self.last_error())
+        out = {name: getattr(s, name) for name, _ in L.HspfStats._fields_}
+        out["dbg"] = list(out["dbg"])
+        return out
+
+    def wait_all(self) -> None:
+        self.lib.hspf_wait_all(self.handle)
+
+    def async_lanes(self) -> int:
+        return int(self.lib.hspf_async_lanes(self.handle))
+
     def ancestors_device(self, graph: SpfGraph, roots: Sequence[int], run_flags: int, *, dist_ptr: int, hops_ptr: int,
                          flags_ptr: int, level: int, n_words: int, level_rank_ptr: int, level_count_ptr: int, anc_ptr: int) -> int:
         """hspf_ancestors_device(): level-L ancestor bit sets of every (root, vertex) of a previous run_device(); all
@@ -439,6 +468,28 @@ class MultiEngine:
         rc = self.lib.hspf_multi_run(self.handle, g, _u32(roots), len(roots), run_flags, arr, gather)
         if rc != 0:
             raise HspfError(rc, "hspf_multi_run", self.last_error())
+
+    def _results(self, results: Sequence[dict]):
+        arr = (L.HspfResult * len(results))()
+        for i, r in enumerate(results):
+            arr[i] = L.HspfResult(r["dist"], r.get("hops") or None, r.get("flags") or None, r.get("mask") or None,
+                                  r.get("mask_words", 1), None)
+        return arr
+
+    def run_async(self, g, roots, run_flags: int, results: Sequence[dict]) -> int:
+        """hspf_multi_run_async: every local device's slice goes to a lane of its context; returns the ticket."""
+        roots = np.ascontiguousarray(roots, np.uint32)
+        t = ctypes.c_uint64()
+        rc = self.lib.hspf_multi_run_async(self.handle, g, _u32(roots), len(roots), run_flags, self._results(results), ctypes.byref(t))
+        if rc != 0:
+            raise HspfError(rc, "hspf_multi_run_async", self.last_error())
+        return int(t.value)
+
+    def run_wait(self, ticket: int, results: Sequence[dict], gather: int) -> None:
+        """hspf_multi_run_wait: the slices of `ticket` are complete; then the exchange selected in `gather`."""
+        rc = self.lib.hspf_multi_run_wait(self.handle, ticket, self._results(results), gather)
+        if rc != 0:
+            raise HspfError(rc, "hspf_multi_run_wait", self.last_error())
 
     def wait(self) -> None:
         rc = self.lib.hspf_multi_wait(self.handle)

@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define HSPF_ABI_VERSION 5u   /* 5: + hspf_routes_diff_count / hspf_routes_pack, hspf_multi_init_error, HSPF_PFX_RESIDENT, HSPF_GX_ELL_* / LEAF / SUMMARY (additions only) */
+#define HSPF_ABI_VERSION 6u   /* 6: + hspf_run_device_async / hspf_wait / hspf_wait_all / hspf_async_lanes, hspf_multi_run_async / hspf_multi_run_wait, hspf_recommend_cpu (additions only);
+                                 5: + hspf_routes_diff_count / hspf_routes_pack, hspf_multi_init_error, HSPF_PFX_RESIDENT, HSPF_GX_ELL_* / LEAF / SUMMARY */
 
 /* ---- error codes ------------------------------------------------------------------- */
 #define HSPF_OK                 0
@@ -158,8 +159,10 @@ typedef struct {
                                   (holo-isis/src/spf.rs:552-556), i.e. n_batches * n_vertices rows would be 1x */
   uint32_t single_wg;          /* 1: small graph, the run took the one-workgroup-per-root kernel (one launch)     */
   uint32_t lane_vertex;        /* 1: a few roots on a larger graph, the run took the lane = vertex kernel (k_lv)   */
-  uint32_t dbg[4];             /* [0]: 1 = the run took the lean sweep (k_fused_lean); [1]: bits 0-30 = dense passes of that sweep's
-                                  learned schedule, bit 31 = a wide-mask run left the graph's leaves to the emit;
+  uint32_t dbg[4];             /* [0]: 1 = the run took the lean sweep (k_fused_lean); [1]: lean sweep: bits 0-7 = dense passes that did
+                                  work, 8-15 = head sweeps that ran, 16-23 = dense passes planned, 24-30 = head sweeps planned
+                                  (the plan is sized from the previous run, the launches decide on the device);
+                                  bit 31 = a wide-mask run left the graph's leaves to the emit;
                                   [2], [3]: host microseconds from the entry of the (last) run to its first enqueue /
                                   to its return.  HSPF_RUN_COUNT_ROWS on the one-workgroup path instead: sweeps,
                                   shader cycles, 100 MHz wall ticks and set-up cycles of the first root's workgroup  */
@@ -172,6 +175,17 @@ int         hspf_init(int device_ordinal, hspf_ctx **out);
 void        hspf_shutdown(hspf_ctx *ctx);
 const char *hspf_strerror(int code);
 const char *hspf_last_error(const hspf_ctx *ctx);          /* detail of the last failure       */
+/* Where the GPU path pays (no GPU needed; pure arithmetic): 1 when the caller's own CPU loop is expected to finish
+ * these runs sooner than the engine can, 0 otherwise.  One root on a small LSDB is the reference's everyday call
+ * (run_area / compute_spt, one root per area / level: holo-ospf/src/spf.rs:540-542, holo-isis/src/spf.rs:746-761);
+ * the engine's floor for any run is one launch + one stream synchronisation (measured wall on MI355X, one root on 4-neighbour
+ * grids: 0.033 ms at 25-64 vertices, 0.036 at 100, 0.039 at 144-256, 0.046 at 400, 0.050 at 500: ~0.032 + 3.5e-5 n), the
+ * reference-shaped loop (ordered map, linear candidate scan, per-edge two-way rescan) costs
+ * ~(2.4e-4 n + 7e-7 n^2) ms per root on one host core (n = 100: 0.03, 196: 0.09, 484: 0.29 ms; tools/cpu_small_graph_table.py),
+ * so: CPU iff n_roots * (2.4e-4 n + 7e-7 n^2) < 0.032 + 3.5e-5 n — one root below ~110 vertices, two below ~60, never from
+ * 8 roots up.  n_edges is taken for callers whose links-per-router ratio is far from the grid-like 4-8 the table was measured on
+ * (the per-root cost is scaled by max(1, n_edges / (8 n))).  INTEGRATION.md section 6 shows the call site. */
+int hspf_recommend_cpu(uint32_t n_vertices, uint32_t n_edges, uint32_t n_roots);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the ctx's own. */
 int         hspf_set_stream(hspf_ctx *ctx, void *hip_stream);
 void       *hspf_get_stream(const hspf_ctx *ctx);
@@ -264,6 +278,28 @@ int hspf_run(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t
 int hspf_run_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots,
                     uint32_t run_flags, hspf_result *out_device);
 int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out);
+
+/* ---- asynchronous runs (ABI 6) ----------------------------------------------------------- */
+/*
+ * The reference runs ONE SPF at a time per instance thread (holo-protocol/src/lib.rs:427-430), but an SPF event holds
+ * several independent runs: one per area (holo-ospf/src/spf.rs:540-542), per level and topology
+ * (holo-isis/src/spf.rs:746-761), per neighbour (holo-isis/src/flooding/manet.rs:59-69).  hspf_run_device_async
+ * hands a run to one of the context's LANES — private engine contexts on the same device, each with its own stream,
+ * scratch and host thread (HSPF_ASYNC_LANES, default 3) — and returns a ticket at once; hspf_wait blocks until that run
+ * is over and returns its code (and statistics).  Lanes are taken in ticket order (ticket % lanes): the call blocks only
+ * while the lane's previous run (ticket - lanes) is still going.  The roots are copied; `out_device` buffers must stay
+ * valid, and must not be shared between runs in flight, until the ticket has been waited for.  A run alone leaves most
+ * of the chip idle during its sparse first and last sweeps (chains of small dependent launches); runs in flight on
+ * several lanes move in lockstep and interleave those chains (isis-100k, 64-root runs: 150 k runs/s with three in flight
+ * against 124 k one after the other).  Results are bit-identical to hspf_run_device's.  hspf_graph_patch /
+ * hspf_graph_free on the context wait for its runs in flight first; results of a ticket are kept until four later runs
+ * of its lane have finished.  Same threading contract as every other call: one caller thread per context.
+ */
+int hspf_run_device_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots,
+                          uint32_t run_flags, const hspf_result *out_device, uint64_t *ticket);
+int hspf_wait(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats /* may be NULL */);
+int hspf_wait_all(hspf_ctx *ctx);                  /* every run in flight is over (codes: hspf_wait)        */
+uint32_t hspf_async_lanes(const hspf_ctx *ctx);    /* how many runs can be in flight                        */
 
 /* ---- route derivation on device (the step right after the SPT) ------------------- */
 /*
@@ -482,6 +518,16 @@ int hspf_multi_mask_words(hspf_multi *m, const hspf_multi_graph *g, const uint32
 int hspf_multi_wait(hspf_multi *m);
 int hspf_multi_run(hspf_multi *m, const hspf_multi_graph *g, const uint32_t *roots, uint32_t n_roots,
                    uint32_t run_flags, hspf_result *all, uint32_t gather);
+
+/* hspf_multi_run in two halves (ABI 6): the first hands every local device's slice to a lane of its context
+ * (hspf_run_device_async) and returns a ticket; the second waits for the slices and then does what hspf_multi_run does
+ * with `gather` (the exchange, synchronous or HSPF_GATHER_ASYNC).  Several tickets may be in flight, into DIFFERENT
+ * tables; wait for them in ticket order (every rank the same order: the exchange is a collective).  No host thread is
+ * created per call: the lanes' threads live as long as the context (hspf_multi_run itself uses them when it drives
+ * more than one local device). */
+int hspf_multi_run_async(hspf_multi *m, const hspf_multi_graph *g, const uint32_t *roots, uint32_t n_roots,
+                         uint32_t run_flags, const hspf_result *all, uint64_t *ticket);
+int hspf_multi_run_wait(hspf_multi *m, uint64_t ticket, hspf_result *all, uint32_t gather);
 
 /* The collective on its own, for any per-root table (route tables after hspf_routes_device: "a single all-gather of
  * per-root route tables", BASELINE north_star): tables[i] is a device buffer on local device i of n_roots rows of

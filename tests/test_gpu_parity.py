@@ -724,15 +724,16 @@ def test_fattree_full_size_leaves_deferred(spf_ctx):
     assert np.array_equal(res.flags & 1, ref.flags) and np.array_equal(res.first_hop_mask, ref.mask)
 
 
-# ---- the lean sweep's learned mode schedule (dense sweeps without activation stamps) --------------------------------
+# ---- the lean sweep's plan: head sweeps, dense stretch, all-due sweep, tail — decided on the device -------------------
 
 @sweeps_engine
 @pytest.mark.parametrize("shape", ["grid", "isis-100k", "ospf-10k x 1024 roots"])
-def test_lean_dense_schedule_repeated_runs(spf_ctx, shape):
-    """An instance that repeats a run (same graph handle, same roots) gets k_fused_lean's mode schedule from its own
-    second run: dense sweeps (no stamps read or written), one all-due stamped sweep after them.  Every run of the
-    sequence — plain, learning, scheduled, scheduled after a cost patch, plain again after a change of roots — equals
-    the oracle bit for bit; hspf_stats::dbg[1] shows the dense launches."""
+def test_lean_plan_first_run_and_repeated_runs(spf_ctx, shape):
+    """k_fused_lean's launches decide on the device whether they still have a job (head sweep skipped once the frontier
+    covers the graph, dense pass skipped once the corrections thin out); the host only sizes the plan from the
+    previous run.  Every run of the sequence — the first of a fresh graph handle, repeats, after a cost patch, after a
+    structural patch, with other roots — equals the oracle bit for bit, and the dense stretch is there from the FIRST
+    run (hspf_stats::dbg[1]: passes that did work | head sweeps that ran << 8 | planned << 16 / << 24)."""
     if shape == "grid":
         side = 30                                       # (hop counts stay inside the 4-byte state's 7 hop bits)
         idx = np.arange(side * side).reshape(side, side)
@@ -757,23 +758,41 @@ def test_lean_dense_schedule_repeated_runs(spf_ctx, shape):
                      mask_words_=res.first_hop_mask.shape[2], threads=ORACLE_THREADS)
         assert np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops)
         assert np.array_equal(res.flags & 1, ref.flags) and np.array_equal(res.first_hop_mask, ref.mask)
-        return res.stats
+        d = res.stats["dbg"][1]
+        return res.stats, {"used": d & 0xFF, "head": (d >> 8) & 0xFF, "planned": (d >> 16) & 0xFF, "head_planned": (d >> 24) & 0x7F}
     try:
-        dense = []
-        for _ in range(6):
-            st = one(roots, g)
+        plans = []
+        for _ in range(5):
+            st, pl = one(roots, g)
             assert st["state_bytes"] == 4 and st["dbg"][0] == 1
-            dense.append(st["dbg"][1])
-        # plain run(s), the learning run, then the schedule: from its first use on, the same number of dense launches
-        first = next(i for i, x in enumerate(dense) if x > 0)
-        assert 2 <= first <= 3 and all(x == dense[first] for x in dense[first:]), dense
-        dense = [0, 0, dense[first]]
+            plans.append(pl)
+        stamped_only = bool(int(os.environ.get("HSPF_VARIANT", "0"), 0) & 524288)
+        if not stamped_only:
+            assert all(p["used"] >= 1 and p["used"] <= p["planned"] for p in plans), plans     # dense passes from the first run on
+            assert all(p["head"] <= p["head_planned"] for p in plans), plans
+            # the plan settles where the corrections thin out within the longest stretch a plan may hold: isis-100k (random
+            # chords: ~28 sweeps) on the same head sweeps and stretch from the third run on (+- a pass: sampled counters);
+            # a chordless grid is corrected for as many sweeps as it is wide, its stretch simply grows to the cap
+            if shape == "isis-100k":
+                assert abs(plans[-1]["used"] - plans[-2]["used"]) <= 1 and plans[-1]["head"] == plans[-2]["head"], plans
+            assert all(p["planned"] <= 62 for p in plans), plans
         u = g.n // 3
         a0, b0 = int(g.row_ptr[u]), int(g.row_ptr[u + 1])
-        G.patch([u], [(g.col[a0:b0], g.metric[a0:b0] + 3)], [g.vflags[u]])                     # costs only: the schedule stays
+        G.patch([u], [(g.col[a0:b0], g.metric[a0:b0] + 3)], [g.vflags[u]])                     # costs only
         g2 = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
-        assert one(roots, g2)["dbg"][1] == dense[2]
+        _, pl = one(roots, g2)
+        assert stamped_only or pl["used"] >= 1
+        v = int(g.col[a0])                                                                      # structural: the link u - v goes away
+        c0, d0 = int(G.row_ptr[v]), int(G.row_ptr[v + 1])
+        keep_v = np.array([k for k in range(c0, d0) if int(G.col[k]) != u], dtype=np.int64)
+        a1, b1 = int(G.row_ptr[u]), int(G.row_ptr[u + 1])
+        keep_u = np.array([k for k in range(a1, b1) if int(G.col[k]) != v], dtype=np.int64)
+        G.patch([u, v], [(G.col[keep_u], G.metric[keep_u]), (G.col[keep_v], G.metric[keep_v])], [g.vflags[u], g.vflags[v]])
+        g3 = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
+        _, pl = one(roots, g3)
+        assert stamped_only or pl["used"] >= 1                                                  # the first run after the change: dense stretch there
         other = ((roots.astype(np.int64) + 11) % g.n).astype(np.uint32)
-        assert one(other, g2)["dbg"][1] == 0                                                    # other roots: plain again
+        _, pl = one(other, g3)
+        assert stamped_only or pl["used"] >= 1                                                  # other roots: the same plan, decided on the device again
     finally:
         G.free()

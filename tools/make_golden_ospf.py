@@ -25,6 +25,15 @@ def _strip(s):
     return s.split(":", 1)[1] if s.startswith("ietf-ospf:") else s
 
 
+def _vlinks(area_state: dict) -> list:
+    """The virtual links an area's operational state shows: `cost` is what update_virtual_link copied out of the TRANSIT
+    area's router table (`area.state.routers[endpoint].metric`, holo-ospf/src/area.rs:304-333, filled by run_area at
+    holo-ospf/src/spf.rs:627-643), and the link is only up when that entry exists and carries the ABR flag — the one
+    place where the recorded fixtures expose run_area's router table."""
+    return [{"transit_area": v["transit-area-id"], "router_id": v["router-id"], "cost": int(v["cost"]), "state": v.get("state")}
+            for v in area_state.get("virtual-links", {}).get("virtual-link", []) if "cost" in v]
+
+
 def ospfv2_vector(rt_dir: str) -> dict:
     cfg_doc = json.load(open(os.path.join(rt_dir, "config.json")))
     st_doc = json.load(open(os.path.join(rt_dir, "output", "northbound-state.json")))
@@ -41,7 +50,7 @@ def ospfv2_vector(rt_dir: str) -> dict:
     for a in cfg.get("areas", {}).get("area", []):
         if a.get("virtual-links", {}).get("virtual-link"):
             has_vlinks = True
-    areas = []
+    areas, vlinks = [], []
     for a in st.get("areas", {}).get("area", []):
         routers, networks = [], []
         for t in a.get("database", {}).get("area-scope-lsa-type", []):
@@ -69,15 +78,19 @@ def ospfv2_vector(rt_dir: str) -> dict:
                                          for n in i.get("neighbors", {}).get("neighbor", [])]})
         if a.get("virtual-links", {}).get("virtual-link"):
             has_vlinks = True
+        vlinks += _vlinks(a)
         areas.append({"area_id": a["area-id"], "routers": routers, "networks": networks, "interfaces": ifaces})
     rib = []
     for r in st.get("local-rib", {}).get("route", []):
         nhs = [[n.get("next-hop"), n.get("outgoing-interface")]
                for n in r.get("next-hops", {}).get("next-hop", [])]
         rib.append({"prefix": r["prefix"], "metric": int(r["metric"]), "type": r["route-type"], "nexthops": nhs})
-    return {"source": os.path.relpath(rt_dir, REF), "proto": "ospfv2", "router_id": st["router-id"],
-            "max_paths": int(cfg.get("spf-control", {}).get("paths", 16)), "has_vlinks": has_vlinks,
-            "iface_slot_order": order_source, "areas": areas, "rib": rib}
+    out = {"source": os.path.relpath(rt_dir, REF), "proto": "ospfv2", "router_id": st["router-id"],
+           "max_paths": int(cfg.get("spf-control", {}).get("paths", 16)), "has_vlinks": has_vlinks,
+           "iface_slot_order": order_source, "areas": areas, "rib": rib}
+    if vlinks:
+        out["vlinks"] = vlinks
+    return out
 
 
 def make_ospfv2():
@@ -144,7 +157,7 @@ def ospfv3_vector(rt_dir: str) -> dict:
             iftype[i["name"]] = i.get("interface-type", "broadcast")
         if a.get("virtual-links", {}).get("virtual-link"):
             has_vlinks = True
-    areas = []
+    areas, vlinks = [], []
     for a in st.get("areas", {}).get("area", []):
         routers, networks, iaps = [], [], []
         for t in a.get("database", {}).get("area-scope-lsa-type", []):
@@ -186,15 +199,19 @@ def ospfv3_vector(rt_dir: str) -> dict:
                            "link_lsas": links})
         if a.get("virtual-links", {}).get("virtual-link"):
             has_vlinks = True
+        vlinks += _vlinks(a)
         areas.append({"area_id": a["area-id"], "routers": routers, "networks": networks, "iaps": iaps, "interfaces": ifaces})
     rib = []
     for r in st.get("local-rib", {}).get("route", []):
         nhs = [[n.get("next-hop"), n.get("outgoing-interface")] for n in r.get("next-hops", {}).get("next-hop", [])]
         rib.append({"prefix": r["prefix"], "metric": int(r["metric"]), "type": r["route-type"], "nexthops": nhs})
     af = "ipv4" if any("." in r["prefix"].split("/")[0] and ":" not in r["prefix"] for r in rib) else "ipv6"
-    return {"source": os.path.relpath(rt_dir, REF), "proto": "ospfv3", "router_id": st["router-id"], "af": af,
-            "max_paths": int(cfg.get("spf-control", {}).get("paths", 16)), "has_vlinks": has_vlinks,
-            "iface_slot_order": order_source, "areas": areas, "rib": rib}
+    out = {"source": os.path.relpath(rt_dir, REF), "proto": "ospfv3", "router_id": st["router-id"], "af": af,
+           "max_paths": int(cfg.get("spf-control", {}).get("paths", 16)), "has_vlinks": has_vlinks,
+           "iface_slot_order": order_source, "areas": areas, "rib": rib}
+    if vlinks:
+        out["vlinks"] = vlinks
+    return out
 
 
 def make_ospfv3():
