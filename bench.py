@@ -276,6 +276,228 @@ def pipeline_1root(ctx, dev) -> dict:
             "records_identical_to_fold": ok_rec}
 
 
+def _bufs(torch, dev, R, n, W):
+    return dict(dist=torch.empty((R, n), dtype=torch.int32, device=dev), hops=torch.empty((R, n), dtype=torch.int16, device=dev),
+                flags=torch.empty((R, n), dtype=torch.int16, device=dev), mask=torch.empty((R, n, W), dtype=torch.int64, device=dev))
+
+
+def _kw(b, W):
+    return dict(dist_ptr=b["dist"].data_ptr(), hops_ptr=b["hops"].data_ptr(), flags_ptr=b["flags"].data_ptr(),
+                mask_ptr=b["mask"].data_ptr(), mask_words=W)
+
+
+def _same(b, ref) -> bool:
+    return bool(np.array_equal(b["dist"].cpu().numpy().view(np.uint32), ref.dist) and np.array_equal(b["hops"].cpu().numpy().view(np.uint16), ref.hops)
+                and np.array_equal(b["flags"].cpu().numpy().view(np.uint16) & 1, ref.flags) and np.array_equal(b["mask"].cpu().numpy().view(np.uint64), ref.mask))
+
+
+def cold_block(g, dev, roots) -> dict:
+    """What a run costs when nothing is warm: the FIRST run of a fresh context on a fresh graph
+    handle, the first run with OTHER roots, the first run after a STRUCTURAL one-row patch (a link taken out on both
+    sides), next to the steady state of the same loop — one run at a time (hspf_run_device), device ms by HIP events and
+    wall ms.  The lean sweep's plan (head sweeps / dense stretch / tail) is sized from the previous run of the context and
+    decided on the device, so there is no rehearsal run to lose; `ratio_device` = cold device ms / steady device ms.
+    Every run is compared with the oracle."""
+    import torch
+    from holo_amd import engine as E
+    from oracle import graph_oracle as go
+    thr = min(64, os.cpu_count() or 1)
+    n = g.n
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 0, go.HEAP, mask_words_=1, threads=thr)
+    b = _bufs(torch, dev, len(roots), n, 1)
+    ctx = E.SpfContext(dev.index or 0)
+    G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+
+    def one(rts):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = ctx.run_device(G, rts, 0, **_kw(b, 1))
+        return {"wall_ms": round((time.perf_counter() - t0) * 1e3, 4), "device_ms": round(st["ms_total"], 4), "launches": st["n_relax_launches"],
+                "dense_passes": st["dbg"][1] & 0xFF}
+    first = one(roots); first["identical_to_oracle"] = _same(b, ref)
+    second = one(roots)
+    for _ in range(6):
+        one(roots)
+    steady = [one(roots) for _ in range(30)]
+    sd, sw = float(np.median([x["device_ms"] for x in steady])), float(np.median([x["wall_ms"] for x in steady]))
+    other = ((roots.astype(np.int64) + 777) % n).astype(np.uint32)
+    oth = one(other)
+    oth["identical_to_oracle"] = _same(b, go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, other, 0, go.HEAP, mask_words_=1, threads=thr))
+    one(roots)
+    u = n // 3
+    a0, b0 = int(g.row_ptr[u]), int(g.row_ptr[u + 1])
+    v = int(g.col[a0])
+    c0, d0 = int(g.row_ptr[v]), int(g.row_ptr[v + 1])
+    keep_u = np.arange(a0, b0)[1:]
+    keep_v = np.array([k for k in range(c0, d0) if int(g.col[k]) != u], dtype=np.int64)
+    t0 = time.perf_counter()
+    G.patch([u, v], [(g.col[keep_u], g.metric[keep_u]), (g.col[keep_v], g.metric[keep_v])], [g.vflags[u], g.vflags[v]])
+    tp = (time.perf_counter() - t0) * 1e3
+    pat = one(roots)
+    pat["identical_to_oracle"] = _same(b, go.run(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, roots, 0, go.HEAP, mask_words_=1, threads=thr))
+    pat["patch_wall_ms"] = round(tp, 4)
+    G.free(); ctx.close()
+    for x in (first, second, oth, pat):
+        x["ratio_device"] = round(x["device_ms"] / sd, 3)
+    return {"steady_one_at_a_time": {"device_ms": round(sd, 4), "wall_ms": round(sw, 4), "runs_per_s": round(len(roots) / sw * 1e3)},
+            "fresh_context_first_run": first, "fresh_context_second_run": second, "other_roots_first_run": oth,
+            "after_structural_patch_first_run": pat,
+            "note": "first runs include the first touch of the context's scratch (wall) — device ms is the like-for-like figure"}
+
+
+def consumer_64root(dev) -> dict:
+    """What a CONSUMER of a 64-root batch gets, two ways, on the headline graph:
+    `pipeline_64root` — nothing but the changed routes leaves the device: cost patch of one router's row ->
+    hspf_run_device (64 roots) -> hspf_routes_device (120 000 prefixes x 64 roots) -> hspf_routes_diff_device against the
+    previous tables -> hspf_routes_pack; wall ms of the five calls (median of 12 after 3), records checked against a numpy
+    fold over the oracle's SPTs for all 64 roots;
+    `hspf_run_64root_host` — the SPT tables themselves in HOST memory ("GPU side times hspf_run wall-clock
+    including D2H of results"): hspf_run into pinned buffers (102 MB per batch over PCIe), and the same with the copy of
+    batch k overlapping the run of batch k + 1 (hspf_run_device_async into device tables + a copy stream)."""
+    import ctypes
+    import torch
+    from holo_amd import synth
+    from holo_amd import engine as E
+    from holo_amd import _lib as L
+    from oracle import graph_oracle as go
+    thr = min(64, os.cpu_count() or 1)
+    g = synth.isis_100k()
+    n, R = g.n, 64
+    roots = ((np.arange(R, dtype=np.int64) * n) // R).astype(np.uint32)
+    ctx = E.SpfContext(dev.index or 0)
+    G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    W = G.mask_words(roots)
+    out = {}
+    # ---- (a) routes pipeline, 64 roots
+    rng = np.random.default_rng(12)
+    n2 = 20000
+    two = np.sort(rng.integers(0, n, (n2, 2)), axis=1)
+    two[:, 1] = np.where(two[:, 1] == two[:, 0], (two[:, 0] + 1) % n, two[:, 1]); two.sort(axis=1)
+    vtx = np.concatenate([np.arange(n), two.reshape(-1)]).astype(np.uint32)
+    ptr = np.concatenate([np.arange(n), n + 2 * np.arange(n2 + 1)]).astype(np.uint32)
+    met = np.concatenate([np.arange(n) % 7, rng.integers(0, 10, 2 * n2)]).astype(np.uint32)
+    P = n + n2
+    b = _bufs(torch, dev, R, n, W)
+    sets = [(torch.empty((R, P), dtype=torch.int32, device=dev), torch.empty((R, P), dtype=torch.int32, device=dev),
+             torch.empty((R, P, W), dtype=torch.int64, device=dev)) for _ in range(2)]
+    act = torch.empty((R, P), dtype=torch.uint8, device=dev); chg = torch.empty((R * P,), dtype=torch.int32, device=dev)
+    cptr = torch.empty((R + 1,), dtype=torch.int32, device=dev)
+    u = n // 3
+    a0, b0 = int(g.row_ptr[u]), int(g.row_ptr[u + 1])
+    costs = [g.metric[a0:b0] + 5, g.metric[a0:b0].copy()]
+    col_u, vf_u = g.col[a0:b0].copy(), [g.vflags[u]]
+
+    def routes(k, fl=0):
+        ctx.routes_device(n, R, W, b["dist"].data_ptr(), b["flags"].data_ptr(), b["mask"].data_ptr(), ptr, vtx, met,
+                          best_metric_ptr=sets[k][0].data_ptr(), best_entry_ptr=sets[k][1].data_ptr(), nexthop_mask_ptr=sets[k][2].data_ptr(), flags=fl)
+    ctx.run_device(G, roots, 0, **_kw(b, W)); routes(0)
+    cur, stages, rec = 0, [], None
+    for it in range(15):
+        t = [time.perf_counter()]
+        G.patch([u], [(col_u, costs[it & 1])], vf_u); t.append(time.perf_counter())
+        ctx.run_device(G, roots, 0, **_kw(b, W)); t.append(time.perf_counter())
+        routes(cur ^ 1, E.PFX_RESIDENT); t.append(time.perf_counter())
+        ctx.routes_diff_device(R, P, W, tuple(x.data_ptr() for x in sets[cur]), tuple(x.data_ptr() for x in sets[cur ^ 1]),
+                               action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(), changed_ptr_ptr=cptr.data_ptr())
+        t.append(time.perf_counter())
+        rec = ctx.routes_pack(R, P, W, tuple(x.data_ptr() for x in sets[cur ^ 1]), action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(),
+                              changed_ptr_ptr=cptr.data_ptr())
+        t.append(time.perf_counter())
+        stages.append(np.diff(t) * 1e3)
+        cur ^= 1
+    # check of the last iteration (it = 14: costs[0]; before it costs[1] = the original costs): every root
+    def fold(metric):
+        ref = go.run(g.row_ptr, g.col, metric, g.vflags, g.max_path_metric, roots, 0, go.HEAP, mask_words_=W, threads=thr)
+        bms, nhs = [], []
+        for r in range(R):
+            dd = ref.dist[r].astype(np.uint64); reach = (ref.flags[r] & 1) != 0
+            cand = np.where(reach[vtx], (dd[vtx] + met) & 0xFFFFFFFF, np.uint64(1) << 40)
+            bm = np.minimum.reduceat(cand, ptr[:-1].astype(np.int64))
+            tie = cand == np.repeat(bm, np.diff(ptr.astype(np.int64)))
+            mk = np.where(tie[:, None] & reach[vtx][:, None], ref.mask[r][vtx], 0).astype(np.uint64)
+            bms.append(bm); nhs.append(np.bitwise_or.reduceat(mk, ptr[:-1].astype(np.int64), axis=0))
+        return ref, np.stack(bms), np.stack(nhs)
+    m_new = g.metric.copy(); m_new[a0:b0] = costs[0]
+    (_, bm_old, nh_old), (ref, bm_new, nh_new) = fold(g.metric), fold(m_new)
+    ok_spt = _same(b, ref)
+    has = bm_new < (1 << 40)
+    want_r, want_p = np.nonzero(((bm_old != bm_new) | (nh_old != nh_new).any(axis=2)) & has & nh_new.any(axis=2))
+    ok_rec = bool(len(rec) == len(want_r) and np.array_equal(rec[:, 0], want_r.astype(np.uint32)) and np.array_equal(rec[:, 1], want_p.astype(np.uint32))
+                  and np.array_equal(rec[:, 3], bm_new[want_r, want_p].astype(np.uint32))
+                  and np.array_equal(rec[:, 6:].copy().view(np.uint64).reshape(len(rec), W), nh_new[want_r, want_p]))
+    st = np.median(np.array(stages[3:]), axis=0)
+    wall = float(np.median(np.array(stages[3:]).sum(axis=1)))
+    out["pipeline_64root"] = {"graph": "isis-100k", "roots": R, "prefixes": int(P), "changed_row": int(u), "wall_ms": round(wall, 4),
+                              "runs_per_s": round(R / wall * 1e3),
+                              "stages_ms": {k: round(float(v), 4) for k, v in zip(("graph_patch", "run_device", "routes_device", "routes_diff_device", "routes_pack"), st)},
+                              "records_to_host": int(len(rec)), "record_bytes": int(rec.nbytes), "spt_identical_to_oracle": ok_spt,
+                              "identical_to_oracle": bool(ok_spt and ok_rec)}
+    del sets, act, chg
+    # ---- (b) SPT tables to the host
+    G.patch([u], [(col_u, costs[1])], vf_u)                           # the original costs again
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 0, go.HEAP, mask_words_=W, threads=thr)
+    hb = [dict(dist=torch.empty((R, n), dtype=torch.int32).pin_memory(), hops=torch.empty((R, n), dtype=torch.int16).pin_memory(),
+               flags=torch.empty((R, n), dtype=torch.int16).pin_memory(), mask=torch.empty((R, n, W), dtype=torch.int64).pin_memory()) for _ in range(2)]
+    res = L.HspfResult(hb[0]["dist"].data_ptr(), hb[0]["hops"].data_ptr(), hb[0]["flags"].data_ptr(), hb[0]["mask"].data_ptr(), W, None)
+    rp = roots.ctypes.data_as(L.u32p)
+    ts = []
+    for it in range(9):
+        t0 = time.perf_counter()
+        rc = ctx.lib.hspf_run(ctx.handle, G.handle, rp, R, 0, ctypes.byref(res))
+        ts.append((time.perf_counter() - t0) * 1e3)
+        assert rc == 0, ctx.last_error()
+    st1 = ctx.stats()
+    ok_host = bool(np.array_equal(hb[0]["dist"].numpy().view(np.uint32), ref.dist) and np.array_equal(hb[0]["hops"].numpy().view(np.uint16), ref.hops)
+                   and np.array_equal(hb[0]["mask"].numpy().view(np.uint64), ref.mask))
+    sync_ms = float(np.median(ts[2:]))
+    # overlapped: run k + 1 on the lanes while batch k crosses the bus on a copy stream
+    db = [_bufs(torch, dev, R, n, W) for _ in range(3)]
+    cs = torch.cuda.Stream(device=dev)
+    K = 24
+
+    def overlapped(K):
+        tickets, copies = [], []
+        t0 = time.perf_counter()
+        for i in range(K):
+            tickets.append((ctx.run_device_async(G, roots, 0, **_kw(db[i % 3], W)), i))
+            if len(tickets) >= 2:
+                tk, j = tickets.pop(0)
+                ctx.wait(tk)
+                if len(copies) >= 2:
+                    copies.pop(0).synchronize()                   # the host buffer of batch j - 2 is free again
+                with torch.cuda.stream(cs):
+                    for key in ("dist", "hops", "flags", "mask"):
+                        hb[j & 1][key].copy_(db[j % 3][key], non_blocking=True)
+                    ev = torch.cuda.Event(); ev.record(cs); copies.append(ev)
+        while tickets:
+            tk, j = tickets.pop(0)
+            ctx.wait(tk)
+            if len(copies) >= 2:
+                copies.pop(0).synchronize()
+            with torch.cuda.stream(cs):
+                for key in ("dist", "hops", "flags", "mask"):
+                    hb[j & 1][key].copy_(db[j % 3][key], non_blocking=True)
+                ev = torch.cuda.Event(); ev.record(cs); copies.append(ev)
+        for ev in copies:
+            ev.synchronize()
+        return (time.perf_counter() - t0) / K * 1e3
+    overlapped(6)
+    ov_ms = overlapped(K)
+    last = hb[(K - 1) & 1]
+    ok_ov = bool(np.array_equal(last["dist"].numpy().view(np.uint32), ref.dist) and np.array_equal(last["hops"].numpy().view(np.uint16), ref.hops)
+                 and np.array_equal(last["mask"].numpy().view(np.uint64), ref.mask))
+    bytes_per_batch = R * n * (8 + 8 * W)
+    out["hspf_run_64root_host"] = {"graph": "isis-100k", "roots": R, "bytes_to_host_per_batch": int(bytes_per_batch), "pinned": True,
+                                   "hspf_run_wall_ms": round(sync_ms, 4), "hspf_run_device_ms": round(st1["ms_total"], 4), "hspf_run_d2h_ms": round(st1["ms_d2h"], 4),
+                                   "hspf_run_runs_per_s": round(R / sync_ms * 1e3),
+                                   "overlapped_wall_ms_per_batch": round(ov_ms, 4), "overlapped_runs_per_s": round(R / ov_ms * 1e3),
+                                   "overlapped_pcie_GBps": round(bytes_per_batch / ov_ms / 1e6, 1),
+                                   "identical_to_oracle": bool(ok_host and ok_ov),
+                                   "note": "PCIe-inclusive: 102 MB of tables per 64-root batch; never the headline `value` (results resident in HBM)"}
+    G.free(); ctx.close()
+    return out
+
+
 def path_of(st) -> str:
     """Which engine path a run took, from its hspf_stats."""
     if st.get("single_wg"):
@@ -411,6 +633,9 @@ def main():
 
     # the host driver only supports dmabuf IPC (RCCL / cross-process device memory); harmless when already set
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the lanes of the asynchronous runs are streams of their own: with the HIP default of 4 hardware queues two of them
+    # share one and run one after the other (137 k vs 149 k runs/s); read when the HIP runtime starts, i.e. before torch.cuda
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -476,9 +701,16 @@ def main():
     RA = len(all_roots) if (sharded_in_lib or (world > 1 and args.gather == "dist")) else R
     row0 = lo if RA == len(all_roots) else 0                       # where this rank's rows sit in its tables
 
-    # double-buffered device results (row-major [root][vertex]); the distance table holds ALL roots when gathered
+    # The timed loop keeps `depth` steps IN FLIGHT (hspf_multi_run_async / hspf_multi_run_wait, ABI 6): a step alone leaves
+    # most of the chip idle during the chains of small launches at its head and tail; the lanes of one context interleave
+    # those of the steps in flight.  Every step is still ONE 64-root batch of configs[2], complete (results in HBM, exchange
+    # issued) when its wait returns; `value` = steps retired per second.  depth = 1 (HSPF_BENCH_DEPTH=1) is one step at a
+    # time, reported anyway as `pipeline.one_at_a_time`.
+    depth = max(1, int(os.environ.get("HSPF_BENCH_DEPTH", "4")))
+    nb = depth + 1
+    # device results (row-major [root][vertex]), one set per step in flight + 1; the distance table holds ALL roots when gathered
     bufs = []
-    for _ in range(2):
+    for _ in range(nb + 1):                    # (+ 1: the untimed one-at-a-time pass and the row-count run keep out of the timed steps' tables)
         bufs.append(dict(
             dist=torch.empty((RA, n), dtype=torch.int32, device=dev),
             hops=torch.empty((RA if sharded_in_lib else R, n), dtype=torch.int16, device=dev),
@@ -487,33 +719,50 @@ def main():
 
     pending = [None]
     phase = {"relax_ms": 0.0, "dag_ms": 0.0, "finish_ms": 0.0, "total_ms": 0.0, "n_relax": 0, "n_dag": 0,
-             "n_exact": 0, "state_bytes": 0, "narrow_overflow": 0}
+             "n_exact": 0, "state_bytes": 0, "narrow_overflow": 0, "steps": 0}
 
     def ptrs(b, own_rows_only: bool):
         off = row0 * n if own_rows_only else 0
         return dict(dist=b["dist"].data_ptr() + off * 4, hops=b["hops"].data_ptr(), flags=b["flags"].data_ptr(),
                     mask=b["mask"].data_ptr(), mask_words=W)
 
-    def step(i: int, record: bool):
-        b = bufs[i & 1]
+    def record_stats():
+        st = m.stats(0)
+        phase["relax_ms"] += st["ms_relax"]; phase["dag_ms"] += st["ms_dag"]
+        phase["finish_ms"] += st["ms_finish"]; phase["total_ms"] += st["ms_total"]
+        phase["n_relax"] += st["n_relax_launches"]; phase["n_dag"] += st["n_dag_launches"]
+        phase["n_exact"] += st["n_exact_roots"]
+        phase["state_bytes"] = st["state_bytes"]; phase["narrow_overflow"] += st["narrow_overflow"]
+        phase["lean"] = int(st.get("dbg", [0])[0]); phase["dense_passes"] = int(st.get("dbg", [0, 0])[1]) & 0xFF
+        phase["steps"] += 1
+
+    inflight = []
+
+    def retire(record: bool):
+        t, b = inflight.pop(0)
         if sharded_in_lib:
-            m.run(mg, run_roots, 0, [ptrs(b, False)], E.GATHER_DIST | E.GATHER_ASYNC)
+            m.run_wait(t, [ptrs(b, False)], E.GATHER_DIST | E.GATHER_ASYNC)
         else:
-            m.run(mg, run_roots, 0, [ptrs(b, True)], 0)
+            m.run_wait(t, [ptrs(b, True)], 0)
             if world > 1 and args.gather == "dist":
                 if pending[0] is not None:
                     pending[0].wait()
                 pending[0] = dist.all_gather_into_tensor(b["dist"], b["dist"][row0:row0 + R], async_op=True)
-        if record:
-            st = m.stats(0)
-            phase["relax_ms"] += st["ms_relax"]; phase["dag_ms"] += st["ms_dag"]
-            phase["finish_ms"] += st["ms_finish"]; phase["total_ms"] += st["ms_total"]
-            phase["n_relax"] += st["n_relax_launches"]; phase["n_dag"] += st["n_dag_launches"]
-            phase["n_exact"] += st["n_exact_roots"]
-            phase["state_bytes"] = st["state_bytes"]; phase["narrow_overflow"] += st["narrow_overflow"]
-            phase["lean"] = int(st.get("dbg", [0])[0])
+        if record and depth == 1:
+            record_stats()
+
+    def step(i: int, record: bool):
+        b = bufs[i % nb]
+        inflight.append((m.run_async(mg, run_roots, 0, [ptrs(b, not sharded_in_lib)]), b))
+        if len(inflight) >= depth:
+            retire(record)
+
+    def drain(record: bool = False):
+        while inflight:
+            retire(record)
 
     def fence():
+        drain()
         if pending[0] is not None:
             pending[0].wait()
             pending[0] = None
@@ -529,17 +778,17 @@ def main():
     fence()
     tw = time.perf_counter() - tw
     # The timed region: --steps steps, repeated in whole multiples until it holds >= --min-timed-ms of work (one clock
-    # hiccup must not move the headline; 20 steps are 17 ms).  The multiple is fixed BEFORE timing, from the warm-up
+    # hiccup must not move the headline; 20 steps are 9 ms).  The multiple is fixed BEFORE timing, from the warm-up
     # rate (max over ranks), so every rank times the same number of steps.
     est = tw / max(args.warmup, 1) if args.warmup else 1e-3
-    # The warm-up holds the slow runs of a fresh instance (first touch of every buffer, the run that learns the sweep
-    # schedule): its rate under-counts how many steps 200 ms take.  A few more untimed steps give the rate the timed
-    # region will run at (they are warm-up too: nothing of them is reported).
+    # The warm-up holds the slow runs of a fresh instance (first touch of every buffer): its rate under-counts how many
+    # steps 200 ms take.  A few more untimed steps give the rate the timed region will run at (warm-up too: nothing of
+    # them is reported).
     tc = time.perf_counter()
-    for i in range(8):
+    for i in range(12):
         step(i, False)
     fence()
-    est = min(est, (time.perf_counter() - tc) / 8)
+    est = min(est, (time.perf_counter() - tc) / 12)
     if world > 1:
         t = torch.tensor([est], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -556,7 +805,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    last = bufs[(timed_steps - 1) & 1]
+    # One step at a time on the same context, UNTIMED for the headline: the per-kernel figures of the roofline block come
+    # from here (a lane's HIP events also span the launches of the other steps in flight), and so does the rate a caller
+    # gets that has only one batch to run.
+    one_steps = 60
+    for i in range(4):
+        m.run(mg, run_roots, 0, [ptrs(bufs[nb], not sharded_in_lib)], 0)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(one_steps):
+        m.run(mg, run_roots, 0, [ptrs(bufs[nb], not sharded_in_lib)], 0)
+        if depth != 1:
+            record_stats()
+    torch.cuda.synchronize()
+    one_dt = (time.perf_counter() - t1) / one_steps
+
+    last = bufs[(timed_steps - 1) % nb]
     own = slice(row0, row0 + R)
     hrow = own if sharded_in_lib else slice(0, R)
     assert phase["n_exact"] == 0, "headline workload must stay on the wavefront-parallel path"
@@ -579,7 +843,7 @@ def main():
         verified_gathered = len(chk) if world > 1 else 0
         del ref
     # one extra, untimed run with the row counter on (the counting kernel instantiation is slower)
-    m.run(mg, run_roots, E.RUN_COUNT_ROWS, [ptrs(last, not sharded_in_lib)], 0)
+    m.run(mg, run_roots, E.RUN_COUNT_ROWS, [ptrs(bufs[nb], not sharded_in_lib)], 0)
     rows_recomputed = int(m.stats(0)["rows_recomputed"])
 
     # N > 1: the exchange on its own, outside the timed region (inside it the gather is asynchronous and overlaps the next
@@ -604,9 +868,9 @@ def main():
         runs = timed_steps * R * world
         value = runs / dt
         ba = b_alg(n, e, W)
-        # dominant kernel = the phase with the larger device time; its average launch duration is
-        # HIP-event time of the phase / launches (events recorded on the engine's own stream).
-        K = timed_steps
+        # dominant kernel = the phase with the larger device time; its average launch duration is HIP-event time of the
+        # phase / launches (events recorded on the engine's own stream), from the one-step-at-a-time pass.
+        K = max(phase["steps"], 1)
         relax_avg = phase["relax_ms"] / max(phase["n_relax"], 1) * 1e-3
         dag_avg = phase["dag_ms"] / max(phase["n_dag"], 1) * 1e-3
         if phase["n_dag"] == 0:
@@ -616,14 +880,24 @@ def main():
         avg = dag_avg if dominant == "k_dag" else relax_avg
         launches_per_step = (phase["n_relax"] + phase["n_dag"]) / K
         bytes_per_launch = R * ba / launches_per_step          # §8d figure x units per launch
-        achieved = bytes_per_launch / avg
-        traffic = None
+        kernel_achieved = bytes_per_launch / avg
+        # whole-run figure = what `value` is: algorithmic bytes of the runs retired per second (emit, init and the idle
+        # gaps between launches included)
+        achieved = value / world * ba
+        # HBM-side traffic of ONE step, all kernels (rocprofv3 PMC, separate passes: profiles/traffic.json, made from the
+        # binary whose git revision it records): sum over kernels of launches x (2 x FETCH_SIZE + WRITE_SIZE) — the x2 is
+        # the guide's gfx950 correction for FETCH_SIZE, calibrated on the emit kernel
+        traffic = traffic_step = traffic_rev = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dominant, {}).get("hbm_bytes_per_launch")
-            except Exception:
+                tj = json.load(open(tpath))
+                traffic = tj.get(dominant, {}).get("hbm_bytes_per_launch")
+                traffic_step = tj.get("per_step", {}).get("hbm_bytes")
+                traffic_rev = tj.get("git_rev")
+            except Exception:   # noqa: BLE001
                 traffic = None
+        dev_ms = phase["total_ms"] / K
         out = {
             "metric": "full-SPF runs/sec on 100k-vertex synthetic LSDB",
             "value": round(value, 2), "unit": "spf_runs/s", "n_gpus": world, "steps": args.steps,
@@ -636,17 +910,30 @@ def main():
                                    "64 concurrent SPF roots per GPU per step (BASELINE.json configs[2])",
                        "n_vertices": n, "n_entries": e, "roots_per_step_per_gpu": R, "mask_words": W,
                        "outputs": "dist u32 + hops u16 + flags u16 + first-hop mask u64 per (root,vertex), in HBM",
-                       "parallelism": f"roots sharded over {world} GPU(s) by hspf_multi_run (C ABI), graph replicated",
+                       "parallelism": f"roots sharded over {world} GPU(s) by hspf_multi_run_async / _wait (C ABI), graph replicated",
+                       "steps_in_flight": depth,
                        "gather": gather_via},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved / 1e9, 3),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5),
-                         "traffic": traffic,
-                         "alg_bytes_per_run": ba, "launches_per_step": round(launches_per_step, 2),
-                         "avg_launch_us": round(avg * 1e6, 2),
+                         "frac_is": "whole run: value x B_alg / peak (emit, init and launch gaps included)",
+                         "traffic": traffic, "traffic_unit": "HBM-side bytes per LAUNCH of the dominant kernel (PMC)",
+                         "alg_bytes_per_run": ba, "alg_bytes_per_step": R * ba,
+                         "traffic_per_step": traffic_step, "traffic_ratio": (round(traffic_step / (R * ba), 3) if traffic_step else None),
+                         "hbm_gbps_counter": (round(traffic_step / (dev_ms * 1e-3) / 1e9, 1) if traffic_step and dev_ms else None),
+                         "hbm_frac_counter": (round(traffic_step / (dev_ms * 1e-3) / HBM_PEAK, 4) if traffic_step and dev_ms else None),
+                         "traffic_git_rev": traffic_rev,
+                         "kernel_achieved": round(kernel_achieved / 1e9, 3), "kernel_frac": round(kernel_achieved / HBM_PEAK, 5),
+                         "kernel_frac_is": "sweep launches only, one step at a time: 64 B_alg / launches per step / average launch duration",
+                         "launches_per_step": round(launches_per_step, 2), "avg_launch_us": round(avg * 1e6, 2),
                          "whole_run_frac": round(value / world * ba / HBM_PEAK, 5)},
-            "phases_ms_per_step": {"relax": round(phase["relax_ms"] / K, 4), "dag": round(phase["dag_ms"] / K, 4),
+            "pipeline": {"steps_in_flight": depth, "lanes": E.SpfContext.async_lanes_of(m.ctx_handle(0)),
+                         "one_at_a_time": {"runs_per_s": round(R / one_dt), "ms_per_step": round(one_dt * 1e3, 4),
+                                           "whole_run_frac": round(R / one_dt * ba / HBM_PEAK, 5), "steps": one_steps}},
+            "phases_ms_per_step": {"measured": "one step at a time (the events of a step in flight also span the other steps' launches)",
+                                   "relax": round(phase["relax_ms"] / K, 4), "dag": round(phase["dag_ms"] / K, 4),
                                    "finish": round(phase["finish_ms"] / K, 4), "device_total": round(phase["total_ms"] / K, 4),
                                    "relax_launches": phase["n_relax"] / K, "dag_launches": phase["n_dag"] / K,
+                                   "dense_passes": phase.get("dense_passes"),
                                    "fused_state_bytes": phase["state_bytes"], "narrow_overflows": phase["narrow_overflow"],
                                    "rows_recomputed_per_step": rows_recomputed, "rows_x_N": round(rows_recomputed / n, 2)},
         }
@@ -657,6 +944,8 @@ def main():
             ctx1 = E.SpfContext(local_rank)
             out["latency_1root"] = latency_1root(ctx1, dev)
             out["pipeline_1root"] = pipeline_1root(ctx1, dev)
+            out["cold"] = cold_block(g, dev, roots)
+            out.update(consumer_64root(dev))
             out["two_instances"] = two_instances(g, dev)
             out["configs"] = other_configs(ctx1, dev)
         print(json.dumps(out), flush=True)

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -189,21 +190,22 @@ struct hspf_ctx {
   hspf_ctx *parent = nullptr;                       // in a lane's context: the context the caller holds
 };
 
-// One lane of an asynchronous context: a job slot, the thread that runs it, the last few results.
+// One lane of an asynchronous context: a short queue of jobs, the thread that runs them one after the other, the last
+// few results.  (A queue, not a slot: with one slot a lane idles from the end of its run until the caller has woken up,
+// collected the result and handed it the next one — ~10 % of a 0.4 ms run from Python.)
 struct hspf_lane {
   hspf_ctx *sub = nullptr;
   std::thread th;
   std::mutex mu;
   std::condition_variable cv;
-  bool has_job = false, quit = false;
-  const hspf_graph *g = nullptr;
-  std::vector<uint32_t> roots;
-  uint32_t flags = 0;
-  hspf_result out{};
-  uint64_t ticket = 0;
-  struct Done { uint64_t ticket = 0; int rc = 0; hspf_stats st{}; std::string err; } done[4];
+  struct Job { const hspf_graph *g; std::vector<uint32_t> roots; uint32_t flags; hspf_result out; uint64_t ticket; };
+  std::deque<Job> jobs;                // waiting, in ticket order
+  bool running = false, quit = false;
+  struct Done { uint64_t ticket = 0; int rc = 0; hspf_stats st{}; std::string err; } done[8];
   uint64_t last_done = 0;
+  bool idle() const { return jobs.empty() && !running; }
 };
+constexpr size_t LANE_QUEUE_MAX = 3;   // jobs waiting per lane (+ the one running): results of a ticket survive 8 later ones of its lane
 
 namespace {
 
@@ -506,6 +508,14 @@ int alloc_arena(hspf_ctx *ctx, hspf_graph *g, uint32_t n, uint32_t cap) {
 }
 
 }  // namespace
+
+// The lanes of an asynchronous context are HIP streams of their own; the HIP runtime maps a process's streams onto
+// GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run one after the other.  Context stream +
+// three lanes + the caller's own stream(s) are more than four: measured 137 k runs/s with the default against 149 k with
+// 6 or 8 queues (bench.py, three steps in flight).  The variable is read when the HIP runtime initialises, so a default is
+// planted when this library is loaded — never over a value the user has set, and without effect when HIP is already up
+// (then: export GPU_MAX_HW_QUEUES=8 before starting the process).
+__attribute__((constructor)) static void hspf_plant_env_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" {
 
@@ -1875,17 +1885,21 @@ static int lanes_ensure(hspf_ctx *ctx) {
     ln->th = std::thread([ln, nl = ctx->lanes_cfg]() {
       for (;;) {
         std::unique_lock<std::mutex> lk(ln->mu);
-        ln->cv.wait(lk, [&] { return ln->has_job || ln->quit; });
-        if (!ln->has_job) return;                                   // quit, nothing pending
-        const hspf_graph *g = ln->g; const uint32_t flags = ln->flags; hspf_result out = ln->out; const uint64_t t = ln->ticket;
+        ln->cv.wait(lk, [&] { return !ln->jobs.empty() || ln->quit; });
+        if (ln->jobs.empty()) return;                               // quit, nothing pending
+        hspf_lane::Job job = std::move(ln->jobs.front());
+        ln->jobs.pop_front();
+        ln->running = true;
         lk.unlock();
+        ln->cv.notify_all();                                        // (a submitter may be waiting for room in the queue)
         (void)hipSetDevice(ln->sub->device);
-        const int rc = guarded(ln->sub, [&]() { return run_classes(ln->sub, g, ln->roots.data(), (uint32_t)ln->roots.size(), flags, &out, false); });
+        const int rc = guarded(ln->sub, [&]() { return run_classes(ln->sub, job.g, job.roots.data(), (uint32_t)job.roots.size(), job.flags, &job.out, false); });
         lk.lock();
-        hspf_lane::Done &d = ln->done[(t / nl) & 3u];
-        d.ticket = t; d.rc = rc; d.st = ln->sub->stats;
+        hspf_lane::Done &d = ln->done[(job.ticket / nl) & 7u];
+        d.ticket = job.ticket; d.rc = rc; d.st = ln->sub->stats;
         try { d.err = rc ? ln->sub->last_error : std::string(); } catch (...) {}
-        ln->last_done = t; ln->has_job = false;
+        ln->last_done = job.ticket; ln->running = false;
+        lk.unlock();
         ln->cv.notify_all();
       }
     });
@@ -1896,7 +1910,7 @@ static int lanes_ensure(hspf_ctx *ctx) {
 static void lanes_quiesce(hspf_ctx *ctx) {
   for (hspf_lane *ln : ctx->lanes) {
     std::unique_lock<std::mutex> lk(ln->mu);
-    ln->cv.wait(lk, [&] { return !ln->has_job; });
+    ln->cv.wait(lk, [&] { return ln->idle(); });
     // a finished run leaves the next run's scratch fill behind on the lane's stream, and that launch reads the graph's row flags
     (void)hipSetDevice(ln->sub->device);
     if (ln->sub->stream) (void)hipStreamSynchronize(ln->sub->stream);
@@ -1922,10 +1936,10 @@ int hspf_run_device_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *ro
     if (rc) return rc;
     const uint64_t t = ctx->next_ticket++;
     hspf_lane *ln = ctx->lanes[t % ctx->lanes.size()];
+    hspf_lane::Job job{g, std::vector<uint32_t>(roots, roots + n_roots), run_flags, *out_device, t};
     std::unique_lock<std::mutex> lk(ln->mu);
-    ln->cv.wait(lk, [&] { return !ln->has_job; });                  // the lane's previous run (ticket t - lanes) has to be over
-    ln->g = g; ln->roots.assign(roots, roots + n_roots); ln->flags = run_flags; ln->out = *out_device; ln->ticket = t;
-    ln->has_job = true;
+    ln->cv.wait(lk, [&] { return ln->jobs.size() < LANE_QUEUE_MAX; });   // room in the lane's queue (it runs its jobs in ticket order)
+    ln->jobs.push_back(std::move(job));
     lk.unlock();
     ln->cv.notify_all();
     *ticket = t;
@@ -1938,8 +1952,8 @@ int hspf_wait(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats) {
   hspf_lane *ln = ctx->lanes[ticket % ctx->lanes.size()];
   std::unique_lock<std::mutex> lk(ln->mu);
   ln->cv.wait(lk, [&] { return ln->last_done >= ticket; });
-  const hspf_lane::Done &d = ln->done[(ticket / ctx->lanes.size()) & 3u];
-  if (d.ticket != ticket) { ctx->last_error = "hspf_wait: the ticket's result is gone (more than four later runs on its lane)"; return HSPF_E_INVAL; }
+  const hspf_lane::Done &d = ln->done[(ticket / ctx->lanes.size()) & 7u];
+  if (d.ticket != ticket) { ctx->last_error = "hspf_wait: the ticket's result is gone (more than eight later runs on its lane)"; return HSPF_E_INVAL; }
   ctx->stats = d.st;
   if (stats) *stats = d.st;
   if (d.rc) { try { ctx->last_error = d.err; } catch (...) {} }
@@ -2103,6 +2117,8 @@ int hspf_routes_pack(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes, uint3
       !new_dev->best_metric || !new_dev->best_entry || !new_dev->nexthop_mask || (n_records && !records_host))
     return HSPF_E_INVAL;
   if (n_records == 0) return HSPF_OK;
+  // more records than the last hspf_routes_diff_device of this context compacted: the kernel would read list entries nobody wrote
+  if (n_records > ctx->last_diff_count) { ctx->last_error = "hspf_routes_pack: n_records exceeds hspf_routes_diff_count()"; return HSPF_E_INVAL; }
   return guarded(ctx, [&]() -> int {
     (void)hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;

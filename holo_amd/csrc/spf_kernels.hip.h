@@ -2833,8 +2833,13 @@ __global__ __launch_bounds__(256) void k_routes_pack(uint32_t n_records, uint32_
   uint32_t lo = 0, hi = n_roots;                       // changed_ptr[lo] <= k < changed_ptr[hi]
   while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (changed_ptr[mid] <= k) lo = mid; else hi = mid; }
   const uint32_t p = changed[k];
-  const size_t i = (size_t)lo * n_pfx + p;
   uint32_t *o = rec + (size_t)k * (ROUTE_REC_WORDS + 2u * W);
+  if (p >= n_pfx) {                                     // (a list the caller did not get from hspf_routes_diff_device: nothing is read through it)
+    o[0] = lo; o[1] = p; o[2] = 0u; o[3] = 0u; o[4] = 0u; o[5] = 1u;
+    for (uint32_t w = 0; w < 2u * W; ++w) o[ROUTE_REC_WORDS + w] = 0u;
+    return;
+  }
+  const size_t i = (size_t)lo * n_pfx + p;
   o[0] = lo; o[1] = p; o[2] = action[i]; o[3] = best_metric[i]; o[4] = best_entry[i]; o[5] = 0u;
   for (uint32_t w = 0; w < W; ++w) {
     const uint64_t m = nexthop_mask[i * W + w];

@@ -295,6 +295,11 @@ class SpfContext:
     def async_lanes(self) -> int:
         return int(self.lib.hspf_async_lanes(self.handle))
 
+    @staticmethod
+    def async_lanes_of(ctx_handle) -> int:
+        """hspf_async_lanes of a raw hspf_ctx handle (e.g. MultiEngine.ctx_handle(i))."""
+        return int(L.load().hspf_async_lanes(ctx_handle))
+
     def ancestors_device(self, graph: SpfGraph, roots: Sequence[int], run_flags: int, *, dist_ptr: int, hops_ptr: int,
                          flags_ptr: int, level: int, n_words: int, level_rank_ptr: int, level_count_ptr: int, anc_ptr: int) -> int:
         """hspf_ancestors_device(): level-L ancestor bit sets of every (root, vertex) of a previous run_device(); all
@@ -314,9 +319,14 @@ class SpfContext:
         """hspf_routes_device(): prefix attachment for every root of a previous run_device(); all
         `*_ptr` arguments are device pointers, the prefix table is host numpy.  PFX_ORDERED tables also pass
         pfx_origin (and, optionally, the per-prefix route an earlier area left: init_exists / init_metric / init_origin)."""
+        src = (pfx_ptr, pfx_vertex, pfx_metric)
         pfx_ptr = np.ascontiguousarray(pfx_ptr, np.uint32)
         pfx_vertex = np.ascontiguousarray(pfx_vertex, np.uint32)
         pfx_metric = np.ascontiguousarray(pfx_metric, np.uint32)
+        if flags & PFX_RESIDENT and any(a is not b for a, b in zip(src, (pfx_ptr, pfx_vertex, pfx_metric))):
+            # HSPF_PFX_RESIDENT tells the library "the table at THESE host addresses is the one you hold": a converted
+            # copy is a temporary whose address the next temporary may reuse, and a stale device table would be used silently
+            raise ValueError("routes_device: PFX_RESIDENT needs the caller's own contiguous uint32 arrays (a conversion made a copy)")
         keep = []
 
         def opt(a, dt, ptr_t):

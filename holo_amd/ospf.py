@@ -303,6 +303,26 @@ def run_area(router_id: str, area: Area, engine, graph: Optional[AreaGraph] = No
     return spt_from_engine(g, root, engine, calc_nexthops)
 
 
+def routers_table(area_id: str, spt: Dict[tuple, Vertex]):
+    """The two side outputs of run_area's loop (holo-ospf/src/spf.rs:627-643), from the SPT the engine gave: the area's
+    "router" routing table — RouteRtr{area, IntraArea, options, flags, distance, next hops} per router vertex, what
+    area::update_virtual_link (area.rs:304-333), the ASBR lookups of the external route calculation and the Type-4
+    summaries read — and TransitCapability (some router of the SPT is a virtual-link endpoint).  A vertex's next hops are
+    final when it is popped, so the table built from the finished SPT is the one the loop builds pop by pop.  Version
+    generic: an OSPFv3 router vertex is its list of Router-LSA fragments, the FIRST one gives flags and options
+    (ospfv3/spf.rs:70-80).  Returns (dict router id -> route dict, transit_capability)."""
+    routers, transit = {}, False
+    for vid, v in spt.items():
+        if vid[0] != RTR:
+            continue
+        lsa = v.lsa[0] if isinstance(v.lsa, list) else v.lsa
+        flags = sorted(getattr(lsa, "bits", []))
+        routers[vid[1]] = {"area_id": area_id, "path_type": "intra-area", "options": sorted(getattr(lsa, "options", [])),
+                           "flags": flags, "metric": v.distance, "nexthops": dict(v.nexthops)}
+        transit = transit or "vlink-end-bit" in flags
+    return routers, transit
+
+
 def intra_area_networks(spt: Dict[VertexId, Vertex]):          # ospfv2/spf.rs:462-538
     for vid in sorted(spt):
         v = spt[vid]
@@ -403,6 +423,46 @@ def compute_spf_intra_area(router_id: str, areas: List[Area], max_paths: int, en
     return rows
 
 
+class SpfState:
+    """What compute_spf keeps between runs for OSPFv2 (holo-ospf/src/spf.rs:489-584): per area the SPT of the last FULL
+    run (`area.state.spt`), its "router" routing table and TransitCapability (`area.state.routers`,
+    `area.state.transit_capability`, :627-643), and the intra-area RIB.  `run` dispatches like the reference
+    (`Ospfv2::spf_computation_type`, ospfv2/spf.rs:99-170): a change of a Router- / Network-LSA (or of the SR opaque
+    LSAs) is a Full computation — every area goes through the engine —; Type-3 / Type-4 / Type-5 changes are Partial
+    ones whose intra-area part is EMPTY in OSPFv2 (:124-126): the engine is not called, SPTs, router tables and the
+    intra-area RIB stay as they are (what the partial run recomputes — inter-area and external routes — reads
+    `routers` and the SPTs, and lies outside this path)."""
+
+    def __init__(self, router_id: str, max_paths: int, engine):
+        from . import ospfv3 as _v3                      # the version-generic classification lives with SpfState of OSPFv3
+        self._classify = _v3.spf_computation_type
+        self.router_id, self.max_paths, self.engine = router_id, max_paths, engine
+        self.cache = GraphCache()
+        self.spts: Dict[str, Optional[Dict[tuple, Vertex]]] = {}
+        self.routers: Dict[str, dict] = {}
+        self.transit_capability: Dict[str, bool] = {}
+        self.rows: List[dict] = []
+        self.engine_runs = 0
+
+    def run(self, areas: List[Area], trigger_lsas=None, trigger_vertices: Optional[Dict[str, Iterable[VertexId]]] = None) -> List[dict]:
+        kind, _partial = ("full", None) if trigger_lsas is None else self._classify(trigger_lsas, 2)
+        if kind != "full":
+            return self.rows
+        rib: dict = {}
+        for area in sorted(areas, key=lambda a: ip(a.area_id)):
+            graph = self.cache.get(area, None if trigger_vertices is None else trigger_vertices.get(area.area_id, ()))
+            spt = run_area(self.router_id, area, self.engine, graph)
+            self.engine_runs += 1
+            self.spts[area.area_id] = spt
+            self.routers[area.area_id], self.transit_capability[area.area_id] = ({}, False) if spt is None else routers_table(area.area_id, spt)
+            if spt is not None:
+                update_rib_intra_area(rib, spt, self.max_paths)
+        self.rows = [{"prefix": rib[k]["prefix"], "metric": rib[k]["metric"], "type": "intra-area",
+                      "nexthops": [[rib[k]["nexthops"][n][1], rib[k]["nexthops"][n][0]] for n in sorted(rib[k]["nexthops"])]}
+                     for k in sorted(rib)]
+        return self.rows
+
+
 # ---- the wire step after the path (SURVEY.md 8f-4): update_global_rib --------------------------------------------------
 
 def update_global_rib(new_rows: List[dict], old_rows: List[dict], ifindex: Dict[str, int]) -> List[dict]:
@@ -422,16 +482,27 @@ def update_global_rib(new_rows: List[dict], old_rows: List[dict], ifindex: Dict[
 
     def nh_set(r):
         return sorted((str(a), str(i)) for a, i in r["nexthops"])
+
+    def same(o, r) -> bool:
+        # :875-879 — metric, tag, SR label and the next-hop set (inter-area / external rows carry `tag`, SR-enabled
+        # instances `sr_label`; a row without the key has None, like the reference's Option)
+        return (o["metric"] == r["metric"] and o.get("tag") == r.get("tag") and o.get("sr_label") == r.get("sr_label")
+                and nh_set(o) == nh_set(r))
     old = {_net_key(r["prefix"]): r for r in old_rows}
     msgs: List[dict] = []
     for r in sorted(new_rows, key=lambda r: _net_key(r["prefix"])):
         o = old.pop(_net_key(r["prefix"]), None)
-        if o is not None and o["metric"] == r["metric"] and nh_set(o) == nh_set(r):
+        if o is not None and same(o, r):
             continue
         if installed(r):
-            nhs = sorted(((ifindex[ifname], addr) for addr, ifname in r["nexthops"]),
+            # (a route whose next hops are partly interface-only keeps the addressed ones in the Address variant; the
+            # reference's BTreeSet<Nexthop> would order Interface variants after them, never seen on an installed OSPF route)
+            nhs = sorted(((ifindex[ifname], addr) for addr, ifname in r["nexthops"] if addr is not None),
                          key=lambda t: (t[0], int(ipaddress.ip_address(t[1]))))
-            msgs.append({"op": "add", "prefix": r["prefix"], "metric": r["metric"], "nexthops": [list(t) for t in nhs]})
+            msg = {"op": "add", "prefix": r["prefix"], "metric": r["metric"], "nexthops": [list(t) for t in nhs]}
+            if r.get("tag") is not None:
+                msg["tag"] = r["tag"]
+            msgs.append(msg)
     for k in sorted(old):
         if installed(old[k]):
             msgs.append({"op": "del", "prefix": old[k]["prefix"]})

@@ -33,6 +33,7 @@ class RouterLsa3:
     options: List[str]
     links: List[RouterLink3]
     maxage: bool = False
+    bits: List[str] = field(default_factory=list)      # router flags (B / E / V ...): area.state.routers, TransitCapability
 
 
 @dataclass
@@ -76,7 +77,7 @@ class Area3:
         return cls(a["area_id"],
                    [RouterLsa3(r["adv_rtr"], r["lsa_id"], r["options"],
                                [RouterLink3(k["type"], k["iface_id"], k["nbr_iface_id"], k["nbr_router_id"], k["metric"])
-                                for k in r["links"]]) for r in a["routers"]],
+                                for k in r["links"]], bits=list(r.get("bits", []))) for r in a["routers"]],
                    [NetworkLsa3(n["adv_rtr"], n["lsa_id"], n["attached"]) for n in a["networks"]],
                    [IntraAreaPrefixLsa(p["adv_rtr"], p["lsa_id"], p["ref_type"], p["ref_lsa_id"], p["ref_adv_rtr"], p["prefixes"])
                     for p in a["iaps"]],

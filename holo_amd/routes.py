@@ -218,6 +218,12 @@ def update_global_rib_device(instance: I.Instance, engine, rib_before: List[dict
     logic (holo_amd.isis.compute_spf).  Returns (messages, number of records copied, number of prefixes compared)."""
     import torch
     cfg = instance.config
+    # The device comparison sees metric + first-hop slots.  SR labels (route.sr_label, per-next-hop labels) are compared by
+    # the host rule only (holo_amd.isis.update_global_rib, holo-isis/src/route.rs:254-312: a label-only change re-sends the
+    # route): an SR-enabled instance, or an old RIB that carries labels, takes the host path — never a silent skip.
+    if getattr(cfg, "sr_enabled", False) or any(r.get("sr_label") is not None or r.get("nexthop_labels") for r in rib_before):
+        new_rows = I.compute_spf(instance, engine)
+        return I.update_global_rib(new_rows, rib_before, ifindex), 0, 0
     tabs = [(lv, mt) for lv in cfg.levels() for mt in (I.MT_STANDARD, I.MT_IPV6_UNICAST) if cfg.is_topology_enabled(mt)]
     if len(tabs) != 1:
         raise ValueError("update_global_rib_device: one (level, topology) table only")

@@ -286,13 +286,13 @@ int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out);
  * (holo-isis/src/spf.rs:746-761), per neighbour (holo-isis/src/flooding/manet.rs:59-69).  hspf_run_device_async
  * hands a run to one of the context's LANES — private engine contexts on the same device, each with its own stream,
  * scratch and host thread (HSPF_ASYNC_LANES, default 3) — and returns a ticket at once; hspf_wait blocks until that run
- * is over and returns its code (and statistics).  Lanes are taken in ticket order (ticket % lanes): the call blocks only
- * while the lane's previous run (ticket - lanes) is still going.  The roots are copied; `out_device` buffers must stay
+ * is over and returns its code (and statistics).  Lanes are taken in ticket order (ticket % lanes), each runs its tickets
+ * one after the other from a short queue: the call blocks only while three tickets of that lane are already waiting.  The roots are copied; `out_device` buffers must stay
  * valid, and must not be shared between runs in flight, until the ticket has been waited for.  A run alone leaves most
  * of the chip idle during its sparse first and last sweeps (chains of small dependent launches); runs in flight on
  * several lanes move in lockstep and interleave those chains (isis-100k, 64-root runs: 150 k runs/s with three in flight
  * against 124 k one after the other).  Results are bit-identical to hspf_run_device's.  hspf_graph_patch /
- * hspf_graph_free on the context wait for its runs in flight first; results of a ticket are kept until four later runs
+ * hspf_graph_free on the context wait for its runs in flight first; results of a ticket are kept until eight later runs
  * of its lane have finished.  Same threading contract as every other call: one caller thread per context.
  */
 int hspf_run_device_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots,

@@ -115,9 +115,23 @@ def calc_nexthops_v2(db: AreaDb, parent: Vertex, parent_link, dest_id, dest_lsa)
     return out
 
 
-def run_area(vec: dict, area: dict):
-    """holo-ospf/src/spf.rs:587-729 -> (spt dict VertexId -> Vertex, pop order) or None."""
+def router_route(area_id: str, vertex) -> dict:
+    """RouteRtr::new(area_id, PathType::IntraArea, options, flags, distance, nexthops) (holo-ospf/src/spf.rs:629-637,
+    route.rs:59-66) of a router vertex at the moment it is popped.  `flags` = the Router-LSA's bits (for OSPFv3 those of
+    the FIRST fragment, ospfv3/spf.rs:76-80); `options` are not in the extracted vectors for OSPFv2 (LSA header options)."""
+    lsa = vertex.lsa[0] if isinstance(vertex.lsa, list) else vertex.lsa
+    return {"area_id": area_id, "path_type": "intra-area", "options": sorted(lsa.get("options", [])),
+            "flags": sorted(lsa.get("bits", [])), "metric": vertex.distance, "nexthops": dict(vertex.nexthops)}
+
+
+def run_area(vec: dict, area: dict, side: dict = None):
+    """holo-ospf/src/spf.rs:587-729 -> (spt dict VertexId -> Vertex, pop order) or None.
+    `side` (optional dict) receives the loop's two side outputs: side["routers"] = area.state.routers (router id ->
+    RouteRtr, :627-638) and side["transit_capability"] (:596, :640-643: some router vertex of the SPT is a virtual-link
+    endpoint)."""
     db = AreaDb(area)
+    if side is not None:
+        side["routers"], side["transit_capability"] = {}, False      # :596 transit_capability = false; :620 routers.clear()
     root_id = (RTR, ip(vec["router_id"]))
     root_lsa = db.vertex_lsa_find(root_id)
     if root_lsa is None:
@@ -129,6 +143,11 @@ def run_area(vec: dict, area: dict):
         vertex = cand.pop(key)
         spt[vertex.id] = vertex
         order.append(vertex.id)
+        if side is not None and vertex.id[0] == RTR:                # :627-643
+            r = router_route(area["area_id"], vertex)
+            side["routers"][vertex.id[1]] = r
+            if "vlink-end-bit" in r["flags"]:
+                side["transit_capability"] = True
         for parent_link, lid, llsa, cost in db.vertex_lsa_links(vertex.id, vertex.lsa):
             if not any(b == vertex.id for _, b, _, _ in db.vertex_lsa_links(lid, llsa)):
                 continue

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import ipaddress
 
-from oracle.ospf_ref import NET, RTR, U32_MAX, Vertex, ip
+from oracle.ospf_ref import NET, RTR, U32_MAX, Vertex, ip, router_route
 
 
 class AreaDb3:
@@ -98,8 +98,11 @@ def calc_nexthops_v3(db: AreaDb3, parent: Vertex, parent_link, dest_id, dest_lsa
     return out
 
 
-def run_area(vec: dict, area: dict):
+def run_area(vec: dict, area: dict, side: dict = None):
+    """`side`: as oracle/ospf_ref.py::run_area — area.state.routers and transit_capability (holo-ospf/src/spf.rs:627-643)."""
     db = AreaDb3(vec, area)
+    if side is not None:
+        side["routers"], side["transit_capability"] = {}, False
     root_id = (RTR, ip(vec["router_id"]))
     root_lsa = db.vertex_lsa_find(root_id)
     if root_lsa is None:
@@ -111,6 +114,11 @@ def run_area(vec: dict, area: dict):
         vertex = cand.pop(key)
         spt[vertex.id] = vertex
         order.append(vertex.id)
+        if side is not None and vertex.id[0] == RTR:
+            r = router_route(area["area_id"], vertex)
+            side["routers"][vertex.id[1]] = r
+            if "vlink-end-bit" in r["flags"]:
+                side["transit_capability"] = True
         for parent_link, lid, llsa, cost in db.vertex_lsa_links(vertex.id, vertex.lsa):
             if not any(b == vertex.id for _, b, _, _ in db.vertex_lsa_links(lid, llsa)):
                 continue

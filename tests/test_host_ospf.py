@@ -15,6 +15,30 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 OSPF = sorted(glob.glob(os.path.join(GOLD, "ospfv2", "*.json"))) + sorted(glob.glob(os.path.join(GOLD, "ospfv2_steps", "*.json")))
 
 
+def check_router_tables(vec, ref_side_of, twin_spt_of, areas):
+    """run_area's side outputs (holo-ospf/src/spf.rs:627-643): `area.state.routers` and TransitCapability from the
+    twin's engine SPT against the literal loop — and, where the fixture exposes them, against the reference's own
+    record: a virtual link's operational `cost` IS `routers[endpoint].metric` of the transit area, and the link is only
+    up when that entry exists with the ABR flag (holo-ospf/src/area.rs:304-333)."""
+    tables = {}
+    for a, area in zip(vec["areas"], areas):
+        side = ref_side_of(a)
+        spt = twin_spt_of(area)
+        if spt is None:
+            assert side["routers"] == {} and side["transit_capability"] is False
+            continue
+        routers, transit = HO.routers_table(area.area_id, spt)
+        assert routers == side["routers"], a["area_id"]
+        assert transit == side["transit_capability"], a["area_id"]
+        tables[a["area_id"]] = (routers, transit)
+    for vl in vec.get("vlinks", []):
+        routers, transit = tables[vl["transit_area"]]
+        r = routers[RO.ip(vl["router_id"])]
+        assert "abr-bit" in r["flags"] and r["metric"] == vl["cost"] and vl["state"] == "point-to-point"
+        assert transit          # the endpoints of a virtual link set V in their Router-LSAs of the transit area (RFC 2328 12.4.1)
+    return tables
+
+
 def check_ospf_vector(vec, engine):
     areas = [HO.Area.from_vector(a) for a in vec["areas"]]
     got = HO.compute_spf_intra_area(vec["router_id"], areas, vec["max_paths"], engine)
@@ -30,6 +54,11 @@ def check_ospf_vector(vec, engine):
         for vid, vx in ref[0].items():
             assert (spt[vid].distance, spt[vid].hops) == (vx.distance, vx.hops)
             assert spt[vid].nexthops == vx.nexthops
+    def ref_side(a):
+        side = {}
+        RO.run_area(vec, a, side)
+        return side
+    check_router_tables(vec, ref_side, lambda area: HO.run_area(vec["router_id"], area, engine), areas)
     # 2. against the reference's own recorded answer
     if not vec["has_vlinks"]:
         want = sorted([r for r in vec["rib"] if r["type"] == "intra-area"], key=lambda r: RO._net_key(r["prefix"]))
@@ -85,6 +114,12 @@ def check_ospfv3_vector(vec, engine):
         for vid, vx in ref[0].items():
             assert (spt[vid].distance, spt[vid].hops) == (vx.distance, vx.hops)
             assert spt[vid].nexthops == vx.nexthops
+
+    def ref_side(a):
+        side = {}
+        R3.run_area(vec, a, side)
+        return side
+    check_router_tables(vec, ref_side, lambda area: H3.run_area(vec["router_id"], area, engine, vec["af"]), areas)
     if not vec["has_vlinks"]:
         want = sorted([r for r in vec["rib"] if r["type"] == "intra-area"], key=lambda r: R3._net_key(r["prefix"]))
         assert got == want

@@ -83,3 +83,33 @@ def test_classification_full_vs_partial():
     for fn in H3.FULL_FUNCTIONS_V2:
         assert H3.spf_computation_type([{"new": {"function": fn}, "old": None}], 2) == ("full", None)
     assert H3.spf_computation_type([{"new": {"function": "summary-network"}, "old": None}], 2) == ("partial", {"intra": set()})
+
+
+def test_ospfv2_dispatch_full_runs_the_engine_partial_keeps_spt_routers_and_rib():
+    """OSPFv2 (ospfv2/spf.rs:99-170): Router- / Network-LSA changes are Full computations — every area through the
+    engine, SPTs / router tables / TransitCapability / intra-area RIB rebuilt and equal to the literal loop's —;
+    summary and external LSA changes are Partial ones with an EMPTY intra-area part: no engine call, nothing of the
+    path's state moves."""
+    import glob
+    import json
+    import os
+    from holo_amd import ospf as HO
+    from oracle import ospf_ref as RO
+    eng = OracleEngine()
+    gold = os.path.join(os.path.dirname(__file__), "golden", "ospfv2")
+    for path in sorted(glob.glob(os.path.join(gold, "topo3-*_rt*.json")))[:8] + sorted(glob.glob(os.path.join(gold, "topo2-*_rt1.json"))):
+        vec = json.load(open(path))
+        areas = [HO.Area.from_vector(a) for a in vec["areas"]]
+        st = HO.SpfState(vec["router_id"], vec["max_paths"], eng)
+        rows = st.run(areas)
+        assert rows == RO.intra_area_rib(vec) and st.engine_runs == len(areas)
+        for a in vec["areas"]:
+            side = {}
+            RO.run_area(vec, a, side)
+            assert st.routers[a["area_id"]] == side["routers"] and st.transit_capability[a["area_id"]] == side["transit_capability"]
+        runs, spts, routers = st.engine_runs, dict(st.spts), dict(st.routers)
+        for fn in ("summary-network", "summary-router", "as-external"):
+            assert st.run(areas, [{"new": {"function": fn}, "old": None}]) == rows
+            assert st.engine_runs == runs and st.spts == spts and st.routers == routers
+        assert st.run(areas, [{"new": {"function": "router"}, "old": None}]) == rows        # a Full one: the engine again
+        assert st.engine_runs == runs + len(areas)

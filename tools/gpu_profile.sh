@@ -46,8 +46,21 @@ for k, v in out.items():
 for t in traffic.values():
     t["hbm_bytes_per_launch"] = int((2 * t["fetch_kib_per_launch"] + t["write_kib_per_launch"]) * 1024)
     t["kernel"] = ", ".join(t["kernel"])
+# ONE STEP (= one 64-root run of the headline workload), all its kernels: every launch of the run's kernels in the PMC
+# passes, summed, divided by the number of runs (k_init_fused is launched exactly once per run)
+import os
+step_kernels = ("k_fused_lean", "k_emit_fused", "k_init_fill", "k_init_fused", "k_clear_lane_flag")
+runs = traffic.get("k_init_fused", {}).get("launches_sampled", 0)
+if runs:
+    tot = sum(traffic[k]["hbm_bytes_per_launch"] * traffic[k]["launches_sampled"] for k in step_kernels if k in traffic)
+    traffic["per_step"] = {"hbm_bytes": int(tot / runs), "runs_sampled": runs,
+                           "kernels": {k: {"launches_per_step": round(traffic[k]["launches_sampled"] / runs, 2),
+                                           "hbm_bytes_per_step": int(traffic[k]["hbm_bytes_per_launch"] * traffic[k]["launches_sampled"] / runs)}
+                                       for k in step_kernels if k in traffic},
+                           "note": "2 x FETCH_SIZE + WRITE_SIZE (KiB counters; x2 = the guide's gfx950 FETCH_SIZE correction), separate --pmc passes"}
+traffic["git_rev"] = os.environ.get("GIT_REV", "unknown")
 json.dump(traffic, open("gpurun_out/prof/traffic.json", "w"), indent=1)
-print(json.dumps(traffic, indent=1))
+print(json.dumps({k: traffic[k] for k in ("per_step", "git_rev", "k_fused_lean", "k_emit_fused") if k in traffic}, indent=1))
 PY
 cp $OUT/trace/spf_kernel_stats.csv $OUT/kernel_stats.csv
 rm -rf $OUT/pmc_*/ ; find $OUT -name "*kernel_trace.csv" -size +2M -delete
