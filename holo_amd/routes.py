@@ -439,6 +439,181 @@ def ospf_intra_area_device_routes(router_id: str, areas: Sequence["O.Area"], max
             for k in sorted(rib)]
 
 
+# ---- OSPFv2: the wire step from device tables -----------------------------------------------------------
+
+@dataclass
+class Ospfv2OrderedTable:
+    """ONE CSR-by-prefix table of an OSPFv2 area for HSPF_PFX_ORDERED: the stub networks exactly as
+    `Ospfv2::intra_area_networks` yields them (holo-ospf/src/ospfv2/spf.rs:462-538) — the SPT in VertexId order, i.e. all
+    Network-LSA vertices (their own prefix, metric 0) before all Router-LSA vertices (their stub links in LSA order) —,
+    grouped by prefix with that order kept inside a prefix.  The ordered fold (k_routes_ordered) then IS
+    update_rib_intra_area (route.rs:343-448): network-entry rule, saturating add, better replaces, equal merges — one
+    result row per prefix, which is what the RIB comparison on the device needs (the two-table form above leaves the fold
+    of its two results to the host)."""
+    prefixes: List[str]
+    pfx_ptr: np.ndarray
+    pfx_vertex: np.ndarray            # vertex | PFX_ENTRY_NETWORK
+    pfx_metric: np.ndarray
+    pfx_origin: np.ndarray            # LS-ID of the vertex's LSA (route.rs:380-381)
+
+    @classmethod
+    def build(cls, g: "O.AreaGraph") -> "Ospfv2OrderedTable":
+        import ipaddress
+        rows = []
+        for v, vid in enumerate(g.vids):                       # index order = VertexId order = spt.values()
+            lsa = g.lsa_of(v)
+            if vid[0] == O.NET:
+                try:
+                    p = str(ipaddress.ip_network((lsa.lsa_id, lsa.mask), strict=False))
+                except ValueError:
+                    continue
+                rows.append((O._net_key(p), p, v | E.PFX_ENTRY_NETWORK, 0, O.ip(lsa.lsa_id)))
+            else:
+                for link in lsa.links:
+                    if link.link_type != "stub-network-link":
+                        continue
+                    try:
+                        p = str(ipaddress.ip_network((link.link_id, link.link_data), strict=False))
+                    except ValueError:
+                        continue
+                    rows.append((O._net_key(p), p, v, link.metric, O.ip(lsa.adv_rtr)))
+        keys = sorted({r[0]: r[1] for r in rows}.items())
+        pid = {k: i for i, (k, _) in enumerate(keys)}
+        order = sorted(range(len(rows)), key=lambda i: (pid[rows[i][0]], i))
+        ptr = np.zeros(len(keys) + 1, np.uint64)
+        for r in rows:
+            ptr[pid[r[0]] + 1] += 1
+        return cls([p for _, p in keys], np.cumsum(ptr).astype(np.uint32),
+                   np.asarray([rows[i][2] for i in order], np.uint32), np.asarray([rows[i][3] for i in order], np.uint32),
+                   np.asarray([rows[i][4] for i in order], np.uint32))
+
+
+def ospf_update_global_rib_device(router_id: str, areas: Sequence["O.Area"], max_paths: int, engine, rib_before: List[dict],
+                                  ifindex: Dict[str, int], other_rows: Sequence[dict] = (), device="cuda:0"):
+    """compute_spf's intra-area part + update_global_rib (holo-ospf/src/route.rs:856-916, ibus/tx.rs:32-77) for OSPFv2 with
+    the SPT, the ORDERED prefix fold, the comparison with the RIB held before and the compaction of what changed all on
+    the device: one record stream comes back (hspf_routes_pack) and is expanded into the RouteIpAdd / RouteIpDel sequence.
+    `other_rows`: the inter-area / external rows of the new RIB (calculations outside this path): compared on the host and
+    merged into the sequence in prefix order.  One area with the root's Router-LSA in it — first-hop slots of different
+    areas are different numberings, a multi-area instance takes the host fold (ospf_intra_area_device_routes +
+    holo_amd.ospf.update_global_rib).  Returns (messages, records copied, prefixes compared)."""
+    import ipaddress
+    import torch
+    live = [a for a in sorted(areas, key=lambda a: O.ip(a.area_id))]
+    if len(live) != 1:
+        rows = ospf_intra_area_device_routes(router_id, areas, max_paths, engine, device) + list(other_rows)
+        return O.update_global_rib(rows, rib_before, ifindex), 0, 0
+    g = O.AreaGraph(live[0])
+    root = g.index.get((O.RTR, O.ip(router_id)))
+    old_intra = {O._net_key(r["prefix"]): r for r in rib_before if r.get("type", "intra-area") == "intra-area"}
+    old_other = [r for r in rib_before if r.get("type", "intra-area") != "intra-area"]
+    table = Ospfv2OrderedTable.build(g) if root is not None else None
+    if root is None or not table.prefixes:
+        return O.update_global_rib(list(other_rows), rib_before, ifindex), 0, 0
+    # ONE prefix list for both sides: the table's prefixes plus those only the old RIB knows (no entries: no new route)
+    keys = {O._net_key(p): p for p in table.prefixes}
+    for k, r in old_intra.items():
+        keys.setdefault(k, r["prefix"])
+    order = sorted(keys)
+    prefixes = [keys[k] for k in order]
+    P = len(prefixes)
+    where = {k: i for i, k in enumerate(order)}
+    cnt = np.zeros(P + 1, np.uint32)
+    for j, p in enumerate(table.prefixes):
+        cnt[where[O._net_key(p)] + 1] = table.pfx_ptr[j + 1] - table.pfx_ptr[j]
+    ptr = np.cumsum(cnt, dtype=np.uint64).astype(np.uint32)           # table.prefixes is sorted the same way: entries keep their order
+    roots = np.asarray([root], np.uint32)
+    n = len(g.vids)
+    G = g.device(engine)
+    W = G.mask_words(roots)
+    dev = torch.device(device)
+    dist = torch.empty((1, n), dtype=torch.int32, device=dev); hops = torch.empty((1, n), dtype=torch.int16, device=dev)
+    flags = torch.empty((1, n), dtype=torch.int16, device=dev); mask = torch.empty((1, n, W), dtype=torch.int64, device=dev)
+    stats = engine.run_device(G, roots, E.RUN_NET_NEXTHOPS, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(),
+                              flags_ptr=flags.data_ptr(), mask_ptr=mask.data_ptr(), mask_words=W)
+    bm = torch.empty((1, P), dtype=torch.int32, device=dev); be = torch.empty((1, P), dtype=torch.int32, device=dev)
+    nm = torch.empty((1, P, W), dtype=torch.int64, device=dev)
+    engine.routes_device(n, 1, W, dist.data_ptr(), flags.data_ptr(), mask.data_ptr(), ptr, table.pfx_vertex, table.pfx_metric,
+                         best_metric_ptr=bm.data_ptr(), best_entry_ptr=be.data_ptr(), nexthop_mask_ptr=nm.data_ptr(),
+                         flags=E.PFX_SATURATING | E.PFX_ORDERED, pfx_origin=table.pfx_origin)
+    # first-hop slots -> next hops (needs Interface / Neighbor objects: host, once per slot)
+    res = E.SpfResult(dist.cpu().numpy().view(np.uint32), hops.cpu().numpy().view(np.uint16),
+                      flags.cpu().numpy().view(np.uint16), mask.cpu().numpy().view(np.uint64), None, stats)
+    slot_nh: dict = {}
+    O.spt_from_engine(g, root, engine, O.calc_nexthops, res=res, slots_out=slot_nh)
+    slot_sets = {s: {(addr, name) for (_i, _a), (name, addr) in nh.items()} for s, nh in slot_nh.items() if nh}
+    # the OLD RIB in the same index space: metric, and the slots whose next hops the old route used; a next hop no slot
+    # resolves to any more, or more next hops than max-paths allows, cannot be expressed: the metric is poisoned so that the
+    # pair compares unequal and the host decides on that record
+    om = np.full((1, P), 0xFFFFFFFF, np.uint32); oe = np.full((1, P), 0xFFFFFFFF, np.uint32); on = np.zeros((1, P, W), np.uint64)
+    for k, r in old_intra.items():
+        i = where[k]
+        want = {(a, ifn) for a, ifn in r["nexthops"]}
+        seen = set()
+        for s, nhs in slot_sets.items():
+            if nhs <= want:
+                on[0, i, s // 64] |= np.uint64(1) << np.uint64(s % 64)
+                seen |= nhs
+        om[0, i] = r["metric"] if seen == want and len(want) <= max_paths else 0xFFFFFFFE
+        oe[0, i] = 0
+        if want and not on[0, i].any():
+            on[0, i, 0] = np.uint64(1)
+    t_om = torch.from_numpy(om.view(np.int32)).to(dev); t_oe = torch.from_numpy(oe.view(np.int32)).to(dev)
+    t_on = torch.from_numpy(on.view(np.int64)).to(dev)
+    act = torch.empty((1, P), dtype=torch.uint8, device=dev)
+    chg = torch.empty((P,), dtype=torch.int32, device=dev); cptr = torch.empty((2,), dtype=torch.int32, device=dev)
+    newp = (bm.data_ptr(), be.data_ptr(), nm.data_ptr())
+    engine.routes_diff_device(1, P, W, (t_om.data_ptr(), t_oe.data_ptr(), t_on.data_ptr()), newp,
+                              action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(), changed_ptr_ptr=cptr.data_ptr())
+    rec = engine.routes_pack(1, P, W, newp, action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(), changed_ptr_ptr=cptr.data_ptr())
+    if g._dev is not None:
+        g._dev[1].free()
+
+    def installed(nhs) -> bool:
+        return any(a is not None for a, _ in nhs)
+    walk, gone = {}, {}                  # messages of the walk over the new RIB (prefix order) / of the routes that vanished
+    for r in rec:
+        p, action, metric, entry = int(r[1]), int(r[2]), int(r[3]), int(r[4])
+        prefix = prefixes[p]
+        o = old_intra.get(order[p])
+        if action == E.DIFF_WITHDRAW:
+            if entry == 0xFFFFFFFF and o is not None and installed(o["nexthops"]):
+                gone[order[p]] = {"op": "del", "prefix": prefix}
+            continue
+        if action not in (E.DIFF_INSTALL, E.DIFF_SILENT):
+            continue
+        nhs = {}
+        for w in range(W):
+            m = int(r[6 + 2 * w]) | (int(r[7 + 2 * w]) << 32)
+            while m:
+                b = (m & -m).bit_length() - 1
+                m &= m - 1
+                nhs.update(slot_nh.get(w * 64 + b) or {})
+        keep = [[nhs[k][1], nhs[k][0]] for k in sorted(nhs)[:max_paths]]        # rows carry [addr, iface name]
+        if o is not None and o["metric"] == metric and sorted(map(tuple, o["nexthops"]), key=str) == sorted(map(tuple, keep), key=str):
+            continue                                                             # the reference's "unchanged" (:875-885)
+        if installed(keep):
+            wire = sorted(((ifindex[ifn], a) for a, ifn in keep if a is not None), key=lambda t: (t[0], int(ipaddress.ip_address(t[1]))))
+            walk[order[p]] = {"op": "add", "prefix": prefix, "metric": metric, "nexthops": [list(t) for t in wire]}
+        # (a route that turns CONNECTED / loses its next hops: the reference's `else if INSTALLED` branch (:902-905) looks at
+        # the NEW route object, which never carries the flag when it changed — nothing goes out, and the old route has left
+        # old_rib at :870, so no withdrawal follows either; the host twin, pinned to the recorded messages, does the same)
+    # the rows of the other route types: the host rule among themselves (route.rs:856-916 does not look at the type); a
+    # prefix that changed its type is one route to the reference: the new row's message stands, no withdrawal
+    for m in O.update_global_rib(list(other_rows), old_other, ifindex):
+        k = O._net_key(m["prefix"])
+        if m["op"] == "add":
+            walk[k] = m
+            gone.pop(k, None)
+        elif k not in walk and k not in {O._net_key(p) for p in table.prefixes}:
+            gone[k] = m
+    for k in list(gone):
+        if k in walk:
+            del gone[k]
+    msgs = [walk[k] for k in sorted(walk)] + [gone[k] for k in sorted(gone)]
+    return msgs, len(rec), P
+
+
 # ---- OSPFv3: update_rib_intra_area with the ORDERED prefix fold on the GPU -------------------------------------------
 
 @dataclass

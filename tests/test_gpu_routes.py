@@ -111,6 +111,67 @@ def test_ospf_wire_step_from_device_routes_reproduces_recorded_ibus_messages(spf
     assert HO.update_global_rib(rows, vec["rib_before"], vec["ifindex"]) == want
 
 
+@pytest.mark.parametrize("path", OSPF_WIRE, ids=[os.path.basename(p)[:-5] for p in OSPF_WIRE])
+def test_ospf_hand_off_from_device_tables_reproduces_recorded_ibus_messages(spf_ctx, path):
+    """SURVEY.md 8f-4 for OSPFv2, END TO END on the device like the IS-IS one: SPT, the ORDERED prefix fold (ONE table in
+    Ospfv2::intra_area_networks order, so that the device result IS the RIB row), the comparison with the RIB the
+    reference held before the step, the compaction and the packing; one record stream comes back and is expanded into
+    the exact RouteIpAdd / RouteIpDel sequence the reference recorded (inter-area rows, where a step has any, come from
+    the recording and go through the host rule).  The two two-area steps take the documented host fold."""
+    vec = json.load(open(path))
+    want = [{k: m[k] for k in m if k != "distance"} for m in vec["ibus_routes"]]
+    areas = [HO.Area.from_vector(a) for a in vec["areas"]]
+    other = [r for r in vec["rib"] if r["type"] != "intra-area"]
+    msgs, n_rec, n_pfx = RT.ospf_update_global_rib_device(vec["router_id"], areas, vec["max_paths"], spf_ctx, vec["rib_before"],
+                                                          vec["ifindex"], other)
+    assert msgs == want
+    if len(areas) == 1:
+        assert n_pfx >= len([r for r in vec["rib"] if r["type"] == "intra-area"]) and n_rec <= n_pfx
+        # the device fold alone: the rows of the ordered table equal the twin's intra-area RIB
+        assert RT.ospf_intra_area_device_routes(vec["router_id"], areas, vec["max_paths"], spf_ctx) == \
+            HO.compute_spf_intra_area(vec["router_id"], areas, vec["max_paths"], spf_ctx)
+
+
+def test_ospf_hand_off_random_areas_before_and_after_a_change_equal_the_host_rule(spf_ctx):
+    """Random OSPFv2 areas (tests/_random_ospf.py: parallel links, transit networks, one-way links, shared stub prefixes,
+    MaxAge LSAs, max-paths 1 / 2 / 16): the RIB of the area as it is, then remote routers change link costs, lose a
+    Router-LSA or a Network-LSA; the device hand-off (SPT, ordered fold, comparison with the old RIB, record stream)
+    must give the message sequence of the host rule on the twin's two RIBs — which is the restatement pinned to the
+    reference's recorded ibus output (tests/test_oracle_golden.py)."""
+    import copy
+    import random
+    from _random_ospf import make
+    checked = nonempty = 0
+    for seed in range(2000, 2060):
+        vec = make(seed)
+        rng = random.Random(seed)
+        a0 = vec["areas"][0]
+        ifindex = {i["name"]: 10 + k for k, i in enumerate(sorted(a0["interfaces"], key=lambda i: i["name"]))}
+        before = HO.compute_spf_intra_area(vec["router_id"], [HO.Area.from_vector(a0)], vec["max_paths"], spf_ctx)
+        a1 = copy.deepcopy(a0)
+        for r in a1["routers"]:
+            if r["adv_rtr"] == vec["router_id"]:
+                continue                                       # the root's own row keeps its first-hop slots comparable by construction
+            what = rng.random()
+            if what < 0.25:
+                for l in r["links"]:
+                    if rng.random() < 0.5:
+                        l["metric"] = rng.randint(1, 12)
+            elif what < 0.32:
+                r["maxage"] = True
+        for nl in a1["networks"]:
+            if rng.random() < 0.15:
+                nl["maxage"] = not nl["maxage"]
+        area1 = HO.Area.from_vector(a1)
+        after = HO.compute_spf_intra_area(vec["router_id"], [area1], vec["max_paths"], spf_ctx)
+        want = HO.update_global_rib(after, before, ifindex)
+        got, n_rec, n_pfx = RT.ospf_update_global_rib_device(vec["router_id"], [area1], vec["max_paths"], spf_ctx, before, ifindex)
+        assert got == want, seed
+        checked += 1
+        nonempty += bool(want)
+    assert checked == 60 and nonempty >= 15
+
+
 @pytest.mark.parametrize("seed", range(3))
 @pytest.mark.parametrize("mode", [E.PFX_SATURATING, E.PFX_SATURATING | E.PFX_LAST_MIN, E.PFX_LAST_MIN])
 def test_device_routes_ospf_rules_many_roots_vs_restatement(spf_ctx, seed, mode):

@@ -54,3 +54,32 @@ def test_plan_areas_multi_area_config_keeps_areas_whole_when_it_can():
     for rank, area, b, e in plan:
         per_rank.setdefault(rank, []).append(area)
     assert len(per_rank) == 8 and all(len(v) <= 3 for v in per_rank.values())
+
+
+def test_world_8_plans_of_the_baseline_configs_are_balanced_to_one_batch():
+    """The 8-GPU shapes of BASELINE.json (no 8-GPU node has been available to any session: the plan is what can be checked):
+    configs[2] weak scaling = 8 x 64 roots -> one batch per rank; configs[3] = 10 areas x 1000 roots -> hspf_plan_areas;
+    configs[4] = 101 roots of the fat-tree -> two batches on two ranks, six ranks idle (the roots of one job do not fill
+    eight GPUs: that config shards by class of root).  Per-rank batch counts differ by at most one, every
+    root is covered exactly once, and the slices a rank receives are what hspf_multi_run computes (hspf_shard_bounds)."""
+    from holo_amd import synth
+    # configs[2], weak scaling
+    c2 = [E.shard_bounds(8 * 64, 8, r) for r in range(8)]
+    assert [(hi - lo) for lo, hi in c2] == [64] * 8
+    # configs[3]: the real root lists
+    areas = synth.ospf_multi_area()
+    rpa = [len(g.meta["roots"]) for g in areas]
+    plan = E.plan_areas(rpa, 8)
+    load = [0] * 8
+    covered = {a: [] for a in range(len(rpa))}
+    for rank, area, b, e in plan:
+        load[rank] += (e - b + 63) // 64
+        covered[area].append((b, e))
+    assert max(load) - min(load) <= 1 and sum(load) == sum((r + 63) // 64 for r in rpa)
+    for a, segs in covered.items():
+        assert segs[0][0] == 0 and segs[-1][1] == rpa[a] and all(x[1] == y[0] for x, y in zip(segs, segs[1:]))
+    # configs[4]: 101 roots
+    gf = synth.isis_fattree(100)
+    c4 = [E.shard_bounds(len(gf.meta["roots"]), 8, r) for r in range(8)]
+    sizes = [(hi - lo + 63) // 64 for lo, hi in c4]
+    assert sum(hi - lo for lo, hi in c4) == 101 and max(sizes) - min(sizes) <= 1 and sizes.count(1) == 2
