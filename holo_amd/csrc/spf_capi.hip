@@ -128,6 +128,7 @@ struct hspf_ctx {
   uint32_t lean_stay_pct = 10;                       // HSPF_DENSE_STAY_PCT: the stretch ends when a pass changes a smaller share of the rows
   uint32_t lean_dense_passes = 16;                   // HSPF_DENSE_PASSES: passes per dense launch (1: a launch per dense sweep)
   uint32_t lean_max_passes = 48;                     // longest dense stretch a plan may hold
+  uint32_t lean_multi_min_wgs = 4096;                // HSPF_DENSE_MIN_WGS: workgroups per pass from which a dense launch carries several passes
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
@@ -569,6 +570,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   if (const char *v = getenv("HSPF_DENSE_PASSES")) ctx->lean_dense_passes = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(v, nullptr, 0), 1u), 32u);
   if (const char *v = getenv("HSPF_DENSE_PCT")) ctx->lean_dense_pct = (uint32_t)strtoul(v, nullptr, 0);   // rows due (% of all) in a head sweep of k_fused_lean from which the dense stretch starts
   if (const char *v = getenv("HSPF_DENSE_STAY_PCT")) ctx->lean_stay_pct = (uint32_t)strtoul(v, nullptr, 0);   // rows changed (% of all) by a dense pass below which the stretch ends
+  if (const char *v = getenv("HSPF_DENSE_MIN_WGS")) ctx->lean_multi_min_wgs = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_LEAN_HEAD")) ctx->lean_head = std::min<uint32_t>((uint32_t)strtoul(v, nullptr, 0), 60u);   // a first run's head sweeps
   if (const char *v = getenv("HSPF_LV_MAX_ROOTS")) ctx->lv_max_roots = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_LV_MIN_N")) ctx->lv_min_n = (uint32_t)strtoul(v, nullptr, 0);
@@ -1330,7 +1332,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
           spec_nz = nz;
           spec_done = true;                                      // (valid only if the host finds the chunk converged, see below)
         };
-      if (use_lean) st.dbg[0] = 1;                               // hspf_stats::dbg[0]: the run took the lean sweep
+      if (use_lean) st.dbg[0] = 1;                               // hspf_stats::dbg[0]: 1 = the run took the lean sweep
       // k_emit_fused checks the lean state's fields on FINAL words; an emit behind a chunk that had not converged saw
       // transient ones: its LF_OVERFLOW bits are dropped before the next chunk (the final emit tests every word again)
       on_retry = nullptr;
@@ -1350,7 +1352,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       const bool plan_on = use_lean && !(ctx->variant & 524288u);
       // several passes per launch only where a pass — all batches of the call — is long against what the chip holds at
       // once (2 048 workgroups): a short pass would run NEXT TO its successor instead of ahead of it
-      const bool multi = ctx->lean_dense_passes > 1u && (uint64_t)fgrid.x * B >= 4096u;
+      const bool multi = ctx->lean_dense_passes > 1u && (uint64_t)fgrid.x * B >= ctx->lean_multi_min_wgs;
       const uint32_t per_launch = multi ? (uint32_t)std::min<uint64_t>(ctx->lean_dense_passes, ((1ull << 31) - 1u) / ((uint64_t)fgrid.x * B)) : 1u;
       const uint32_t plan_h = plan_on ? std::min(ctx->lean_head, 60u) : 0u;
       const uint32_t plan_P = plan_on ? std::min(std::max(ctx->lean_passes, 2u), std::min(ctx->lean_max_passes, 62u)) : 0u;
@@ -1877,7 +1879,7 @@ static int lanes_ensure(hspf_ctx *ctx) {
       // the caller's context decides the tunables (a lane's own hspf_init read the environment of a later moment)
       c->variant = ctx->variant; c->single_max_n = ctx->single_max_n; c->lv_max_roots = ctx->lv_max_roots; c->lv_min_n = ctx->lv_min_n;
       c->lean_dense_pct = ctx->lean_dense_pct; c->lean_stay_pct = ctx->lean_stay_pct; c->lean_dense_passes = ctx->lean_dense_passes;
-      c->lean_head = ctx->lean_head; c->lean_passes = ctx->lean_passes; c->hub_deg = ctx->hub_deg;
+      c->lean_head = ctx->lean_head; c->lean_passes = ctx->lean_passes; c->hub_deg = ctx->hub_deg; c->lean_multi_min_wgs = ctx->lean_multi_min_wgs;
       c->unit_heavy_deg = ctx->unit_heavy_deg; c->xcd_row_cost = ctx->xcd_row_cost;
     }
     if (rc != HSPF_OK) { if (ln->sub) hspf_shutdown(ln->sub); delete ln; lanes_shutdown(ctx); ctx->last_error = "could not create a lane context"; return rc; }

@@ -1159,116 +1159,22 @@ __device__ __forceinline__ LeanOut lean_case(__amdgpu_buffer_rsrc_t rs, uint32_t
   return lean_reduce<L>(c, wk, paym);
 }
 
-// MODE (per launch; the host enqueues a PLAN — head sweeps, dense stretch, one all-due sweep, tail sweeps — and the
-// launches decide ON THE DEVICE, from counters earlier launches / passes left in `ctl`, whether they still have a job):
-//   0  stamped: a row is due when an in-neighbour changed in the previous sweep (activation stamps), the form above;
-//      HEAD (the sweeps before the dense stretch): a sample of the waves adds its due rows to ctl[LEAN_CTL_DUE + sweep];
-//      a head sweep whose predecessor counted at least `thr` (sampled units) — or was itself skipped: the sentinel —
-//      does nothing but pass the sentinel on: the frontier covers the graph, the dense stretch is next;
-//   1  dense:   every row is evaluated, no stamp is read or written — in the middle of a run (sweeps ~4-19 of 28 on
-//               isis-100k) every row IS due, and the stamps cost a dependent round trip at the head of every wave
-//               (stamps before records), a 64-byte offset row per vertex and a scattered store per changed row; a
-//               sample of the waves adds its changed rows to ctl[LEAN_CTL_PCH + pass], and pass p does nothing when
-//               pass p - 2 or p - 3 counted fewer than `thr`: the stretch ends where the corrections thin out, wherever
-//               the host guessed its end (a first run on an unknown graph guesses long);
-//   2  all due, stamped: the first sweep after a dense stretch (the stamps are stale: every row is evaluated, changed rows
-//               stamp their out-neighbours again, and mode 0 can follow).
-// Any plan and any outcome of the device-side decisions is correct: modes 1 and 2 evaluate a superset of the due rows, a
-// skipped launch or pass sets its `changed` flag so that the chain of launches reaches the all-due sweep, and the run
-// ends only behind a stamped (or all-rows) launch that changed nothing.  No rehearsal run, nothing learned per graph:
-// the first run of a fresh context takes the same path as the thousandth (round 3 LEARNed a schedule on the second
-// identical run and lost it with every structural patch).
-// Every counter has a 128-byte line of its own (LEAN_CTL_STRIDE words): a pass reads the counters of the passes two and
-// three before it with PLAIN loads — the line of pass p - 2 is touched for the first time when pass p starts, i.e. when
-// pass p - 2 is over, so the first fetch of an XCD's L2 brings the final count and every later one may hit.  (Counters
-// sharing a line would be served stale from L2 for the rest of the launch; agent-scope loads by every wave — 50 000 per
-// pass at ONE address — made a dense pass 4x slower, profiles/r04_notes.md r04a.)
-constexpr uint32_t LEAN_CTL_STRIDE = 32u;
-constexpr uint32_t LEAN_CTL_DUE = 0u, LEAN_CTL_PCH = 64u * LEAN_CTL_STRIDE, LEAN_CTL_WORDS = 128u * LEAN_CTL_STRIDE;   // 64 head sweeps, 64 dense passes
-constexpr uint32_t LEAN_SAMPLE = 32u;                                             // wave 0 of every 8th block of an XCD's range counts
-constexpr uint32_t LEAN_SENTINEL = 0xFFFFFFFFu;
-template <bool COUNT, int MODE, bool HEAD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fused_lean(
-    const FusedGraph *__restrict__ gp, int *changed, int sweep, uint32_t *__restrict__ act,
-    const uint8_t *__restrict__ hnb, uint32_t n_arg, const uint32_t *__restrict__ ell_so, const uint32_t *__restrict__ ell_w,
-    uint32_t *__restrict__ st, const uint32_t *__restrict__ ell_od, const uint32_t *__restrict__ roots, uint32_t *lane_flags,
-    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P, uint32_t *__restrict__ ctl, uint32_t pass_blocks, uint32_t pass_batches,
-    uint32_t pass_base, uint32_t thr) {
+// The rows of one wave's group (up to four consecutive rows of one batch) evaluated and committed: the fast rows through
+// the straight-line cases, the rows next to a root through their own path, flagged rows through k_fused's general routine.
+// (A function of its own since round 4's experiment with a persistent dense kernel — every wave on its own rows for the
+// whole stretch, link records staged once in LDS: 25.6 us per pass instead of 20.0 and a stretch that converges like plain
+// Jacobi, because it loses what the in-order grid gives for free: a row reads the lower-numbered neighbours of the SAME
+// pass.  profiles/r04_notes.md r04t; removed.)  Everything is passed in registers.
+template <bool COUNT, int MODE>
+__device__ __forceinline__ void lean_group(const FusedGraph *__restrict__ gp, const __amdgpu_buffer_rsrc_t rs, const __amdgpu_buffer_rsrc_t ra,
+                                           const uint32_t lane, const uint32_t lane4, const uint32_t wbeg, const uint32_t cur, const FusedParams &P,
+                                           const uint32_t *__restrict__ roots, const uint32_t root_slot, const uint32_t net_nexthops,
+                                           const uint32_t ignore_ovl, const uint32_t due4, const uint32_t fast4, const uint32_t fasth4,
+                                           uint32_t (&sov)[VPW], uint32_t (&wk)[VPW], uint32_t (&od)[VPW], uint32_t (&oldq)[VPW], uint32_t (&info)[VPW],
+                                           uint64_t &any, bool &need_exact, uint32_t &n_done, uint32_t &n_chg) {
   typedef uint32_t ST;
-  if (sweep > 0 && changed[sweep - 1] == 0) return;
-  if (HEAD && sweep > 0 && ctl[LEAN_CTL_DUE + ((uint32_t)sweep - 1u) * LEAN_CTL_STRIDE] >= thr) {   // the dense stretch is due: pass the word on, keep the chain alive
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { ctl[LEAN_CTL_DUE + (uint32_t)sweep * LEAN_CTL_STRIDE] = LEAN_SENTINEL; changed[sweep] = 1; }
-    return;
-  }
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // Dense launches may carry SEVERAL passes over the rows: a 1-D grid of passes x batches x blocks, pass p = blocks
-  // [p G B, (p + 1) G B), batch-major inside a pass (so that a pass spans ALL batches of the call: 16 batches of a 10 000-
-  // vertex graph make a pass of 10 000 workgroups, long enough to keep its successor behind it).
-  // Blocks are dispatched in order, so a pass starts while the one before it drains — no kernel boundary between two dense
-  // sweeps (a dense sweep keeps ~76 % of the wave slots busy: ramp and drain) — and reads what that pass has written
-  // except in the rows still in flight; any interleaving is a valid chaotic iteration of the same monotone fixed point,
-  // and the run's end is decided by stamped sweeps behind the stretch.  pass_blocks = G (0: one pass, 2-D grid), pass_batches = B.
-  const uint32_t batch = (MODE == 1 && pass_blocks != 0u) ? (blockIdx.x / pass_blocks) % pass_batches : blockIdx.y;
-  const uint32_t n = n_arg;
-  const uint32_t bx = (MODE == 1 && pass_blocks != 0u) ? blockIdx.x % pass_blocks : blockIdx.x;
-  // dense pass p of the stretch (counted across its launches): nothing to do when pass p - 2 or p - 3 saw the corrections
-  // thin out (their counters: plain loads, one line each, see LEAN_CTL_STRIDE)
-  const uint32_t pg = MODE == 1 ? pass_base + (pass_blocks != 0u ? blockIdx.x / (pass_blocks * pass_batches) : 0u) : 0u;
-  uint32_t pc2 = LEAN_SENTINEL, pc3 = LEAN_SENTINEL;
-  if (MODE == 1 && thr != 0u && pg >= 2u && pg < 64u) {                 // thr = 0 (HSPF_DENSE_STAY_PCT=0): every planned pass runs
-    pc2 = ctl[LEAN_CTL_PCH + (pg - 2u) * LEAN_CTL_STRIDE];
-    if (pg >= 3u) pc3 = ctl[LEAN_CTL_PCH + (pg - 3u) * LEAN_CTL_STRIDE];
-  }
-  const bool sampler = wave == 0u && ((bx >> 3) & 7u) == 0u;
-  const uint32_t chunk = xcd_chunk(gp->g.xcd_start, bx);
-  if (MODE == 1 && min(pc2, pc3) < thr) {                       // a stopped pass must not read as "nothing left to do"
-    if (bx == 0u && batch == 0u && threadIdx.x == 0) changed[sweep] = 1;
-    return;
-  }
-  if (chunk == 0xFFFFFFFFu) return;
-  const uint32_t wbeg = chunk * (uint32_t)FVPB + wave * (uint32_t)FVPW;
-  if (wbeg >= n) return;
-  uint32_t *A = act + (size_t)batch * n;
-  const uint32_t cur = (uint32_t)sweep + 2u;
-  // ---- stamps and flags first: in the sparse head and tail of a run most waves end here, and what the sweep is short
-  // of is vector memory instructions, not round trips (profiles/r03_notes.md)
-  const uint32_t vl = min(wbeg + min(lane, (uint32_t)VPW - 1u), n - 1);
-  const uint32_t av = MODE == 0 ? A[vl] : cur;
-  const uint32_t hb = hnb[(size_t)batch * n + vl] & (ignore_ovl ? ~RF_NT : ~0u);
-  const uint32_t due4 = (uint32_t)__ballot(lane < (uint32_t)VPW && wbeg + lane < n && av >= cur);
-  if (MODE == 0 && due4 == 0u) return;
-  if (HEAD && sampler && lane == 0 && (uint32_t)sweep < 64u) atomicAdd(&ctl[LEAN_CTL_DUE + (uint32_t)sweep * LEAN_CTL_STRIDE], (uint32_t)__builtin_popcount(due4));
-  // ---- everything else whose address depends on the wave's vertex range alone (ELL row n exists: all pad)
-  ST *S = st + (size_t)batch * (n + 1u) * 64;                      // slab of n + 1 rows: row n = the pad row (never reached)
-  const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, (n + 1u) << 8);
-  const uint32_t lane4 = lane * 4u;
-  uint32_t sov[VPW], wk[VPW], od[VPW], oldq[VPW];
-#pragma unroll
-  for (int i = 0; i < VPW; ++i) {
-    const uint32_t e = (min(wbeg + i, n) * 16u + (lane & 15u)) * 4u;          // byte offset into the ELL arrays (n < 2^23)
-    sov[i] = *(const uint32_t *)((const char *)ell_so + e);
-    wk[i] = *(const uint32_t *)((const char *)ell_w + e);
-    od[i] = MODE == 1 ? 0u : *(const uint32_t *)((const char *)ell_od + e);
-    oldq[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, min(wbeg + i, n - 1) << 8, 0);
-  }
-  const uint32_t fast4 = (uint32_t)__ballot(lane < (uint32_t)VPW && hb == 0u) & due4;
-  const uint32_t fasth4 = (uint32_t)__ballot(lane < (uint32_t)VPW && (hb & ~RF_ROOT) == RF_HNB) & due4;   // next to a root of the batch (or the row of one), nothing else
-  const uint32_t root_slot = batch * 64 + lane;
-  const __amdgpu_buffer_rsrc_t ra = st_rsrc(A, n * 4u);
-  uint32_t info[VPW];                                             // low byte of ELL entry 0: in-degree | (> 16 out-links) << 5 | network << 7
-#pragma unroll
-  for (int i = 0; i < VPW; ++i) {
-    info[i] = rdlane(sov[i], 0) & 0xFFu;
-    sov[i] &= ~0xFFu;
-    wk[i] = (wk[i] << P.sh) + ((lane & 7u) << (P.sh - 3u));       // cost in the distance field, j & 7 in the tag field below it
-    od[i] = lane < 16u ? od[i] : 0xFFFFFFFFu;                     // byte offsets into A; pad / upper lanes: out of range = dropped
-  }
   const uint32_t paym = (1u << P.sh) - 1u;
   const uint32_t hopm = P.hmax << P.mbits, maskm = (1u << P.mbits) - 1u;
-  uint64_t any = 0ull;
-  bool need_exact = false;
-  uint32_t n_done = 0, n_chg = 0;
   // result of fast row i -> state, wake-ups (info bit 5: more than 16 out-links: they are walked, k_fused's loop)
   auto commit = [&](auto I, uint32_t nw) {
     constexpr int i = decltype(I)::value;
@@ -1377,6 +1283,118 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
     const uint32_t o0 = g.out_ptr[v], o1 = g.out_ptr[v + 1];
     for (uint32_t ob = o0 + lane; ob < o1; ob += 64) __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, g.out_dst[ob] * 4u, 0, 0);
   }
+}
+
+// MODE (per launch; the host enqueues a PLAN — head sweeps, dense stretch, one all-due sweep, tail sweeps — and the
+// launches decide ON THE DEVICE, from counters earlier launches / passes left in `ctl`, whether they still have a job):
+//   0  stamped: a row is due when an in-neighbour changed in the previous sweep (activation stamps), the form above;
+//      HEAD (the sweeps before the dense stretch): a sample of the waves adds its due rows to ctl[LEAN_CTL_DUE + sweep];
+//      a head sweep whose predecessor counted at least `thr` (sampled units) — or was itself skipped: the sentinel —
+//      does nothing but pass the sentinel on: the frontier covers the graph, the dense stretch is next;
+//   1  dense:   every row is evaluated, no stamp is read or written — in the middle of a run (sweeps ~4-19 of 28 on
+//               isis-100k) every row IS due, and the stamps cost a dependent round trip at the head of every wave
+//               (stamps before records), a 64-byte offset row per vertex and a scattered store per changed row; a
+//               sample of the waves adds its changed rows to ctl[LEAN_CTL_PCH + pass], and pass p does nothing when
+//               pass p - 2 or p - 3 counted fewer than `thr`: the stretch ends where the corrections thin out, wherever
+//               the host guessed its end (a first run on an unknown graph guesses long);
+//   2  all due, stamped: the first sweep after a dense stretch (the stamps are stale: every row is evaluated, changed rows
+//               stamp their out-neighbours again, and mode 0 can follow).
+// Any plan and any outcome of the device-side decisions is correct: modes 1 and 2 evaluate a superset of the due rows, a
+// skipped launch or pass sets its `changed` flag so that the chain of launches reaches the all-due sweep, and the run
+// ends only behind a stamped (or all-rows) launch that changed nothing.  No rehearsal run, nothing learned per graph:
+// the first run of a fresh context takes the same path as the thousandth (round 3 LEARNed a schedule on the second
+// identical run and lost it with every structural patch).
+// Every counter has a 128-byte line of its own (LEAN_CTL_STRIDE words): a pass reads the counters of the passes two and
+// three before it with PLAIN loads — the line of pass p - 2 is touched for the first time when pass p starts, i.e. when
+// pass p - 2 is over, so the first fetch of an XCD's L2 brings the final count and every later one may hit.  (Counters
+// sharing a line would be served stale from L2 for the rest of the launch; agent-scope loads by every wave — 50 000 per
+// pass at ONE address — made a dense pass 4x slower, profiles/r04_notes.md r04a.)
+constexpr uint32_t LEAN_CTL_STRIDE = 32u;
+constexpr uint32_t LEAN_CTL_DUE = 0u, LEAN_CTL_PCH = 64u * LEAN_CTL_STRIDE, LEAN_CTL_WORDS = 128u * LEAN_CTL_STRIDE;   // 64 head sweeps, 64 dense passes
+constexpr uint32_t LEAN_SAMPLE = 32u;                                             // wave 0 of every 8th block of an XCD's range counts
+constexpr uint32_t LEAN_SENTINEL = 0xFFFFFFFFu;
+template <bool COUNT, int MODE, bool HEAD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fused_lean(
+    const FusedGraph *__restrict__ gp, int *changed, int sweep, uint32_t *__restrict__ act,
+    const uint8_t *__restrict__ hnb, uint32_t n_arg, const uint32_t *__restrict__ ell_so, const uint32_t *__restrict__ ell_w,
+    uint32_t *__restrict__ st, const uint32_t *__restrict__ ell_od, const uint32_t *__restrict__ roots, uint32_t *lane_flags,
+    uint32_t net_nexthops, uint32_t ignore_ovl, FusedParams P, uint32_t *__restrict__ ctl, uint32_t pass_blocks, uint32_t pass_batches,
+    uint32_t pass_base, uint32_t thr) {
+  typedef uint32_t ST;
+  if (sweep > 0 && changed[sweep - 1] == 0) return;
+  if (HEAD && sweep > 0 && ctl[LEAN_CTL_DUE + ((uint32_t)sweep - 1u) * LEAN_CTL_STRIDE] >= thr) {   // the dense stretch is due: pass the word on, keep the chain alive
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { ctl[LEAN_CTL_DUE + (uint32_t)sweep * LEAN_CTL_STRIDE] = LEAN_SENTINEL; changed[sweep] = 1; }
+    return;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // Dense launches may carry SEVERAL passes over the rows: a 1-D grid of passes x batches x blocks, pass p = blocks
+  // [p G B, (p + 1) G B), batch-major inside a pass (so that a pass spans ALL batches of the call: 16 batches of a 10 000-
+  // vertex graph make a pass of 10 000 workgroups, long enough to keep its successor behind it).
+  // Blocks are dispatched in order, so a pass starts while the one before it drains — no kernel boundary between two dense
+  // sweeps (a dense sweep keeps ~76 % of the wave slots busy: ramp and drain) — and reads what that pass has written
+  // except in the rows still in flight; any interleaving is a valid chaotic iteration of the same monotone fixed point,
+  // and the run's end is decided by stamped sweeps behind the stretch.  pass_blocks = G (0: one pass, 2-D grid), pass_batches = B.
+  const uint32_t batch = (MODE == 1 && pass_blocks != 0u) ? (blockIdx.x / pass_blocks) % pass_batches : blockIdx.y;
+  const uint32_t n = n_arg;
+  const uint32_t bx = (MODE == 1 && pass_blocks != 0u) ? blockIdx.x % pass_blocks : blockIdx.x;
+  // dense pass p of the stretch (counted across its launches): nothing to do when pass p - 2 or p - 3 saw the corrections
+  // thin out (their counters: plain loads, one line each, see LEAN_CTL_STRIDE)
+  const uint32_t pg = MODE == 1 ? pass_base + (pass_blocks != 0u ? blockIdx.x / (pass_blocks * pass_batches) : 0u) : 0u;
+  uint32_t pc2 = LEAN_SENTINEL, pc3 = LEAN_SENTINEL;
+  if (MODE == 1 && thr != 0u && pg >= 2u && pg < 64u) {                 // thr = 0 (HSPF_DENSE_STAY_PCT=0): every planned pass runs
+    pc2 = ctl[LEAN_CTL_PCH + (pg - 2u) * LEAN_CTL_STRIDE];
+    if (pg >= 3u) pc3 = ctl[LEAN_CTL_PCH + (pg - 3u) * LEAN_CTL_STRIDE];
+  }
+  const bool sampler = wave == 0u && ((bx >> 3) & 7u) == 0u;
+  const uint32_t chunk = xcd_chunk(gp->g.xcd_start, bx);
+  if (MODE == 1 && min(pc2, pc3) < thr) {                       // a stopped pass must not read as "nothing left to do"
+    if (bx == 0u && batch == 0u && threadIdx.x == 0) changed[sweep] = 1;
+    return;
+  }
+  if (chunk == 0xFFFFFFFFu) return;
+  const uint32_t wbeg = chunk * (uint32_t)FVPB + wave * (uint32_t)FVPW;
+  if (wbeg >= n) return;
+  uint32_t *A = act + (size_t)batch * n;
+  const uint32_t cur = (uint32_t)sweep + 2u;
+  // ---- stamps and flags first: in the sparse head and tail of a run most waves end here, and what the sweep is short
+  // of is vector memory instructions, not round trips (profiles/r03_notes.md)
+  const uint32_t vl = min(wbeg + min(lane, (uint32_t)VPW - 1u), n - 1);
+  const uint32_t av = MODE == 0 ? A[vl] : cur;
+  const uint32_t hb = hnb[(size_t)batch * n + vl] & (ignore_ovl ? ~RF_NT : ~0u);
+  const uint32_t due4 = (uint32_t)__ballot(lane < (uint32_t)VPW && wbeg + lane < n && av >= cur);
+  if (MODE == 0 && due4 == 0u) return;
+  if (HEAD && sampler && lane == 0 && (uint32_t)sweep < 64u) atomicAdd(&ctl[LEAN_CTL_DUE + (uint32_t)sweep * LEAN_CTL_STRIDE], (uint32_t)__builtin_popcount(due4));
+  // ---- everything else whose address depends on the wave's vertex range alone (ELL row n exists: all pad)
+  ST *S = st + (size_t)batch * (n + 1u) * 64;                      // slab of n + 1 rows: row n = the pad row (never reached)
+  const __amdgpu_buffer_rsrc_t rs = st_rsrc(S, (n + 1u) << 8);
+  const uint32_t lane4 = lane * 4u;
+  uint32_t sov[VPW], wk[VPW], od[VPW], oldq[VPW];
+#pragma unroll
+  for (int i = 0; i < VPW; ++i) {
+    const uint32_t e = (min(wbeg + i, n) * 16u + (lane & 15u)) * 4u;          // byte offset into the ELL arrays (n < 2^23)
+    sov[i] = *(const uint32_t *)((const char *)ell_so + e);
+    wk[i] = *(const uint32_t *)((const char *)ell_w + e);
+    od[i] = MODE == 1 ? 0u : *(const uint32_t *)((const char *)ell_od + e);
+    oldq[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, lane4, min(wbeg + i, n - 1) << 8, 0);
+  }
+  const uint32_t fast4 = (uint32_t)__ballot(lane < (uint32_t)VPW && hb == 0u) & due4;
+  const uint32_t fasth4 = (uint32_t)__ballot(lane < (uint32_t)VPW && (hb & ~RF_ROOT) == RF_HNB) & due4;   // next to a root of the batch (or the row of one), nothing else
+  const uint32_t root_slot = batch * 64 + lane;
+  const __amdgpu_buffer_rsrc_t ra = st_rsrc(A, n * 4u);
+  uint32_t info[VPW];                                             // low byte of ELL entry 0: in-degree | (> 16 out-links) << 5 | network << 7
+#pragma unroll
+  for (int i = 0; i < VPW; ++i) {
+    info[i] = rdlane(sov[i], 0) & 0xFFu;
+    sov[i] &= ~0xFFu;
+    wk[i] = (wk[i] << P.sh) + ((lane & 7u) << (P.sh - 3u));       // cost in the distance field, j & 7 in the tag field below it
+    od[i] = lane < 16u ? od[i] : 0xFFFFFFFFu;                     // byte offsets into A; pad / upper lanes: out of range = dropped
+  }
+  uint64_t any = 0ull;
+  bool need_exact = false;
+  uint32_t n_done = 0, n_chg = 0;
+  lean_group<COUNT, MODE>(gp, rs, ra, lane, lane4, wbeg, cur, P, roots, root_slot, net_nexthops, ignore_ovl, due4, fast4, fasth4,
+                          sov, wk, od, oldq, info, any, need_exact, n_done, n_chg);
   if (any != 0ull && lane == 0) changed[sweep] = 1;
   if (COUNT && lane == 0) atomicAdd(&gp->rows_done[(blockIdx.x + wave) & 255u], n_done);
   if (MODE == 1 && sampler && lane == 0 && n_chg != 0u && pg < 64u) atomicAdd(&ctl[LEAN_CTL_PCH + pg * LEAN_CTL_STRIDE], n_chg);

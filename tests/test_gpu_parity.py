@@ -579,7 +579,7 @@ def test_lean_sweep_is_taken_and_bit_identical(spf_ctx):
         roots = np.arange(20, 20 + 64 + seed, dtype=np.uint32)
         res, _ = check(spf_ctx, g, roots, E.RUN_NET_NEXTHOPS if seed & 1 else 0)
         if res.stats["state_bytes"] == 4:
-            assert res.stats["dbg"][0] == 1, seed
+            assert (res.stats["dbg"][0] & 1) == 1, seed
             lean += 1
     assert lean >= 2
 
@@ -593,7 +593,7 @@ def test_lean_sweep_on_grids_with_every_degree(spf_ctx):
     g = synth._routers_only(n, links, 78, 1, 3, synth.MAX_PATH_METRIC_WIDE, "grid-ties", {})
     roots = ((np.arange(100, dtype=np.uint64) * n) // 100).astype(np.uint32)
     res, _ = check(spf_ctx, g, roots)
-    assert res.stats["dbg"][0] == 1
+    assert (res.stats["dbg"][0] & 1) == 1
 
 
 @sweeps_engine
@@ -764,7 +764,7 @@ def test_lean_plan_first_run_and_repeated_runs(spf_ctx, shape):
         plans = []
         for _ in range(5):
             st, pl = one(roots, g)
-            assert st["state_bytes"] == 4 and st["dbg"][0] == 1
+            assert st["state_bytes"] == 4 and (st["dbg"][0] & 1) == 1
             plans.append(pl)
         stamped_only = bool(int(os.environ.get("HSPF_VARIANT", "0"), 0) & 524288)
         if not stamped_only:
