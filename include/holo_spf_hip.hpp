@@ -145,6 +145,28 @@ class Engine {
     return t;
   }
 
+  // ABI 6: several runs in flight from one caller thread (one per area / level / neighbour set).  `out_device` holds
+  // DEVICE pointers sized for roots.size() rows; they must stay valid, and unshared with other runs in flight, until
+  // wait(ticket) has returned.  Results are bit-identical to hspf_run_device's.
+  uint64_t run_device_async(const Graph &g, const std::vector<uint32_t> &roots, uint32_t run_flags, const hspf_result &out_device) {
+    uint64_t ticket = 0;
+    const int rc = hspf_run_device_async(ctx_, g.raw(), roots.data(), (uint32_t)roots.size(), run_flags, &out_device, &ticket);
+    if (rc != HSPF_OK) throw Error(rc, std::string("hspf_run_device_async (") + hspf_last_error(ctx_) + ")");
+    return ticket;
+  }
+  hspf_stats wait(uint64_t ticket) {
+    hspf_stats st{};
+    const int rc = hspf_wait(ctx_, ticket, &st);
+    if (rc != HSPF_OK) throw Error(rc, std::string("hspf_wait (") + hspf_last_error(ctx_) + ")");
+    return st;
+  }
+  void wait_all() { (void)hspf_wait_all(ctx_); }
+  uint32_t async_lanes() const { return hspf_async_lanes(ctx_); }
+  // true: these runs are too small to pay for a launch — the caller keeps its own CPU loop (hspf_recommend_cpu)
+  static bool recommend_cpu(uint32_t n_vertices, uint32_t n_edges, uint32_t n_roots) {
+    return hspf_recommend_cpu(n_vertices, n_edges, n_roots) != 0;
+  }
+
  private:
   std::shared_ptr<CtxHolder> holder_;
   hspf_ctx *ctx_ = nullptr;
