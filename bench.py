@@ -247,8 +247,8 @@ def pipeline_1root(ctx, dev) -> dict:
         cur ^= 1
     mode = int(G.export("build_mode")[0])
     # ---- check of the last iteration (it = 22: costs[0], before it costs[1])
-    def fold(metric):
-        ref = go.run(g.row_ptr, g.col, metric, g.vflags, g.max_path_metric, roots, 0, go.HEAP, mask_words_=W)
+    def fold(metric, row_ptr=None, col=None):
+        ref = go.run(g.row_ptr if row_ptr is None else row_ptr, g.col if col is None else col, metric, g.vflags, g.max_path_metric, roots, 0, go.HEAP, mask_words_=W)
         dd = ref.dist[0].astype(np.uint64); reach = (ref.flags[0] & 1) != 0
         cand = np.where(reach[vtx], (dd[vtx] + met) & 0xFFFFFFFF, np.uint64(1) << 40)
         bm = np.minimum.reduceat(cand, ptr[:-1].astype(np.int64))
@@ -266,9 +266,50 @@ def pipeline_1root(ctx, dev) -> dict:
     want = np.nonzero(((bm_old != bm_new) | (nh_old != nh_new).any(axis=1)) & has & nh_new.any(axis=1))[0]
     ok_rec = bool(np.array_equal(rec[:, 1], want.astype(np.uint32)) and np.array_equal(rec[:, 3], bm_new[want].astype(np.uint32))
                   and np.array_equal(rec[:, 6:].copy().view(np.uint64).reshape(len(rec), W), nh_new[want]))
+    # ---- the same chain behind a STRUCTURAL change: the router's last link withdrawn / announced again, so
+    # the row changes its length, every later row moves and the link's far end loses / regains its two-way partner
+    rows2 = [(col_u[:-1].copy(), g.metric[a:b][:-1].copy()), (col_u, g.metric[a:b].copy())]
+    G.patch([u], [rows2[1]], vf_u)
+    spt_and_routes(cur)
+    stages2, rec2, calls2 = [], None, []
+    for it in range(13):
+        t = [time.perf_counter()]
+        G.patch([u], [rows2[it & 1]], vf_u); t.append(time.perf_counter()); calls2.append(G.last_patch_call_ms)
+        ctx.run_device(G, roots, 0, dist_ptr=d.data_ptr(), hops_ptr=h.data_ptr(), flags_ptr=f.data_ptr(), mask_ptr=m.data_ptr(), mask_words=W)
+        t.append(time.perf_counter())
+        ctx.routes_device(n, 1, W, d.data_ptr(), f.data_ptr(), m.data_ptr(), ptr, vtx, met, best_metric_ptr=sets[cur ^ 1][0].data_ptr(),
+                          best_entry_ptr=sets[cur ^ 1][1].data_ptr(), nexthop_mask_ptr=sets[cur ^ 1][2].data_ptr(), flags=E.PFX_RESIDENT)
+        t.append(time.perf_counter())
+        ctx.routes_diff_device(1, P, W, tuple(x.data_ptr() for x in sets[cur]), tuple(x.data_ptr() for x in sets[cur ^ 1]),
+                               action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(), changed_ptr_ptr=cptr.data_ptr())
+        t.append(time.perf_counter())
+        rec2 = ctx.routes_pack(1, P, W, tuple(x.data_ptr() for x in sets[cur ^ 1]), action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(),
+                               changed_ptr_ptr=cptr.data_ptr())
+        t.append(time.perf_counter())
+        stages2.append(np.diff(t) * 1e3)
+        cur ^= 1
+    mode2 = int(G.export("build_mode")[0])
+    # last iteration (it = 12): the link withdrawn, before it the original rows
+    (_, bm_o, nh_o), (ref2, bm_w, nh_w) = fold(g.metric), fold(G.metric, G.row_ptr, G.col)
+    ok_spt2 = bool(np.array_equal(d.cpu().numpy().view(np.uint32), ref2.dist) and np.array_equal(h.cpu().numpy().view(np.uint16), ref2.hops)
+                   and np.array_equal(m.cpu().numpy().view(np.uint64), ref2.mask))
+    got_bm = sets[cur][0].cpu().numpy().view(np.uint32)[0]; got_nh = sets[cur][2].cpu().numpy().view(np.uint64)[0]
+    has2 = bm_w < (1 << 40)
+    ok_routes2 = bool(np.array_equal(got_bm[has2], bm_w[has2].astype(np.uint32)) and np.array_equal(got_nh[has2], nh_w[has2]))
+    want2 = np.nonzero(((bm_o != bm_w) | (nh_o != nh_w).any(axis=1)) & has2 & nh_w.any(axis=1))[0]
+    ok_rec2 = bool(np.array_equal(rec2[:, 1], want2.astype(np.uint32)) and np.array_equal(rec2[:, 3], bm_w[want2].astype(np.uint32))
+                   and np.array_equal(rec2[:, 6:].copy().view(np.uint64).reshape(len(rec2), W), nh_w[want2]))
+    st2 = np.median(np.array(stages2[3:]), axis=0)
+    structural = {"change": "the router's last link withdrawn / announced again (row length, every later row's position and the far end's two-way partner change)",
+                  "wall_ms": round(float(np.median(np.array(stages2[3:]).sum(axis=1))), 4),
+                  "stages_ms": {k: round(float(v), 4) for k, v in zip(("graph_patch", "run_device", "routes_device", "routes_diff_device", "routes_pack"), st2)},
+                  "graph_patch_c_call_ms": round(float(np.median(calls2[3:])), 4),
+                  "graph_patch_is": "stages_ms.graph_patch = the Python twin's G.patch (C call + splice of its numpy mirrors of 1 M links); graph_patch_c_call_ms = hspf_graph_patch alone",
+                  "patch_mode": {0: "rebuild", 1: "rebuild (hub)", 2: "costs in place"}[mode2], "records_to_host": int(len(rec2)),
+                  "spt_identical_to_oracle": ok_spt2, "routes_identical_to_fold": ok_routes2, "records_identical_to_fold": ok_rec2}
     G.free()
     st = np.median(np.array(stages[3:]), axis=0)
-    return {"graph": "isis-100k", "roots": 1, "prefixes": int(P), "prefix_entries": int(len(vtx)), "changed_row": int(u),
+    return {"graph": "isis-100k", "roots": 1, "prefixes": int(P), "prefix_entries": int(len(vtx)), "changed_row": int(u), "structural": structural,
             "wall_ms": round(float(np.median(np.array(stages[3:]).sum(axis=1))), 4),
             "stages_ms": {k: round(float(v), 4) for k, v in zip(("graph_patch", "run_device", "routes_device", "routes_diff_device", "routes_pack"), st)},
             "patch_mode": {0: "rebuild", 1: "rebuild (hub)", 2: "costs in place"}[mode], "records_to_host": int(len(rec)),
@@ -335,7 +376,8 @@ def cold_block(g, dev, roots) -> dict:
     tp = (time.perf_counter() - t0) * 1e3
     pat = one(roots)
     pat["identical_to_oracle"] = _same(b, go.run(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, roots, 0, go.HEAP, mask_words_=1, threads=thr))
-    pat["patch_wall_ms"] = round(tp, 4)
+    pat["patch_wall_ms"] = round(tp, 4)                   # the first structural patch of the context (scratch allocated), Python twin included
+    pat["patch_c_call_ms"] = round(G.last_patch_call_ms, 4)
     G.free(); ctx.close()
     for x in (first, second, oth, pat):
         x["ratio_device"] = round(x["device_ms"] / sd, 3)

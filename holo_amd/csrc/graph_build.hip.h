@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(GB_BLOCK)
 kb_links(uint32_t n, uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
          const uint32_t *__restrict__ metric, const uint8_t *__restrict__ vflags, uint32_t *__restrict__ src_of,
          uint8_t *__restrict__ twoway, uint8_t *__restrict__ keep, uint32_t *__restrict__ in_cnt,
-         BuildInfo *__restrict__ info) {
+         uint32_t *__restrict__ lslot, BuildInfo *__restrict__ info) {
   const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
   if (k >= e) return;
   const uint32_t u = gb_row_of(row_ptr, n, k);
@@ -100,7 +100,8 @@ kb_links(uint32_t n, uint32_t e, const uint32_t *__restrict__ row_ptr, const uin
   const bool kp = two && !(vflags[u] & HSPF_VF_NO_EXPAND);
   twoway[k] = two ? 1 : 0;
   keep[k] = kp ? 1 : 0;
-  if (kp) atomicAdd(&in_cnt[t], 1u);
+  if (kp) lslot[k] = atomicAdd(&in_cnt[t], 1u);      // the link's place in the target's in-row (any order: kb_rank fixes the
+                                                     // final one); kb_scatter took it with a second atomic per link before
 }
 
 // ---- exclusive scan of m items (u8 or u32) into out[0..m], out[m] = total ----------------------------
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(GB_BLOCK)
 kb_scatter(uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
            const uint32_t *__restrict__ metric, const uint8_t *__restrict__ vflags,
            const uint32_t *__restrict__ src_of, const uint8_t *__restrict__ keep, const uint32_t *__restrict__ kpre,
-           const uint32_t *__restrict__ in_ptr, uint32_t *__restrict__ in_cnt,
+           const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ lslot,
            uint32_t *__restrict__ out_dst, uint32_t *__restrict__ out_w, uint32_t *__restrict__ out_fpos,
            uint32_t *__restrict__ tmp_w, uint32_t *__restrict__ tmp_src, uint32_t *__restrict__ tmp_fpos,
            uint32_t *__restrict__ tmp_t, BuildInfo *__restrict__ info) {
@@ -197,8 +198,7 @@ kb_scatter(uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__r
     const uint32_t fpos = k - row_ptr[u];
     const uint32_t o = kpre[k];
     out_dst[o] = t; out_w[o] = w; out_fpos[o] = fpos;
-    const uint32_t slot = atomicSub(&in_cnt[t], 1u) - 1u;      // any order: kb_rank fixes the final one
-    const uint32_t i = in_ptr[t] + slot;
+    const uint32_t i = in_ptr[t] + lslot[k];
     tmp_w[i] = w;
     // the overload gate only exists for routers (holo-isis/src/spf.rs:568-574: `!vertex.id.is_pseudonode()`): the bit on
     // a network vertex is ignored, as k_exact and the oracle do
@@ -381,13 +381,17 @@ kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__r
     const bool any_bad = __ballot(bb) != 0ull;
     if ((int)lane == l) { f |= all; bad = any_bad; }
   }
-  if (!valid) return;
-  rowflags[t] = (uint8_t)f;
-  atomicMax(&info->max_in_deg, b - a);
-  if (f) atomicOr(&info->any_rowflags, f);
-  if (bad) { info->hc_bad = 1u; atomicAdd(&info->n_bad_rows, 1u); }   // plain store: every writer stores the same value
-  if (f & RF_ZERO) atomicAdd(&info->n_zero_rows, 1u);
-  if (net && b > a) info->hc_net = 1u;
+  if (valid) rowflags[t] = (uint8_t)f;
+  // the summary, reduced over the wave first: one atomic per ROW on these five words was 40-130 us of a 100 000-row build
+  uint32_t mx = valid ? b - a : 0u, fo = valid ? f : 0u;
+  for (int o = 32; o; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); fo |= (uint32_t)__shfl_xor((int)fo, o); }
+  const uint64_t m_bad = __ballot(valid && bad), m_zero = __ballot(valid && (f & RF_ZERO)), m_net = __ballot(valid && net && b > a);
+  if (lane != 0u) return;
+  if (mx) atomicMax(&info->max_in_deg, mx);
+  if (fo) atomicOr(&info->any_rowflags, fo);
+  if (m_bad) { info->hc_bad = 1u; atomicAdd(&info->n_bad_rows, (uint32_t)__popcll(m_bad)); }   // plain store: every writer stores the same value
+  if (m_zero) atomicAdd(&info->n_zero_rows, (uint32_t)__popcll(m_zero));
+  if (m_net) info->hc_net = 1u;
 }
 
 // Work units (GraphDev::unit_first): heavy flag per 16-vertex chunk, then (after a scan of the flags) the unit table
@@ -499,6 +503,22 @@ __global__ void kb_pads(uint32_t n, const BuildInfo *__restrict__ info, uint32_t
 }
 
 // ---- patch: replace whole rows of the raw CSR ----------------------------------------------------------
+
+// Row bounds after a patch, from the old ones: row v starts later by the length changes of the replaced rows in front of
+// it (shift[j] = sum over the first j replaced rows of new length - old length; the host knows both).  Replaces a
+// 400 KB upload of the bounds per patch at 100 000 rows.
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_patch_row_ptr(uint32_t n, const uint32_t *__restrict__ old_row_ptr, uint32_t n_changed, const uint32_t *__restrict__ changed,
+                 const uint32_t *__restrict__ shift, uint32_t *__restrict__ new_row_ptr) {
+  const uint32_t v = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (v > n) return;
+  uint32_t lo = 0, hi = n_changed;                       // replaced rows in front of v
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (changed[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  new_row_ptr[v] = old_row_ptr[v] + shift[lo];           // modulo 2^32: a negative shift wraps back
+}
 
 __global__ void __launch_bounds__(GB_BLOCK)
 kb_splice(uint32_t n, uint32_t e_new, const uint32_t *__restrict__ new_row_ptr,

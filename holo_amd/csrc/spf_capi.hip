@@ -77,6 +77,18 @@ struct hspf_graph {
   uint32_t max_in_deg = 0;                                        // largest kept in-degree
   uint32_t n_zero_rows = 0, n_bad_rows = 0, any_rowflags = 0;    // BuildInfo's counts, kept current by cost patches
   bool hc_net = false, any_net = false;                           // a network row has a kept in-link / a network vertex exists
+  // of the caller's rows (host mirrors), kept current by hspf_graph_patch without walking all rows:
+  uint32_t max_out = 0, n_net = 0;                                // longest row; network vertices
+  uint64_t heavy_links = 0;                                       // links in rows of more than 32
+  void host_summary_full() {
+    max_out = 0; n_net = 0; heavy_links = 0;
+    for (uint32_t v = 0; v < n; ++v) {
+      const uint32_t d = row_ptr[v + 1] - row_ptr[v];
+      max_out = std::max(max_out, d);
+      if (d > 32u) heavy_links += d;
+      if (vflags[v] & HSPF_VF_NETWORK) ++n_net;
+    }
+  }
   bool hub_built = false;                                         // the last build ran in hub mode (sorted keys)
   bool costs_only = false;                                        // the last patch changed costs only: nothing was rebuilt
   bool lean = false;                                              // no network vertex, no static row flag, in-degrees <= 8: k_single_lean
@@ -139,6 +151,7 @@ struct hspf_ctx {
   uint32_t last_diff_count = 0;                     // changed pairs of the last hspf_routes_diff_device (hspf_routes_diff_count)
   DevBuf gb, gb_delta, gb_hub, giant_part;                      // graph build scratch, patch delta, hub-mode sort buffers
   uint32_t hub_deg = HUB_DEG;                       // HSPF_HUB_DEG env: rows with more links than this -> graph build from sorted keys
+  uint64_t tw_host_max = 2000000;                   // HSPF_TW_HOST_MAX env: row entries a structural patch may scan to keep the two-way mirror itself
   BuildInfo *h_info = nullptr;     // pinned
   int *h_changed = nullptr;        // pinned, h_changed_cap ints: per-sweep "something changed" flags of a phase
   size_t h_changed_cap = 0;
@@ -334,14 +347,19 @@ void finish_summary(hspf_graph *g) {
   g->lean_bad = false;
 }
 
-int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
+// build_launch enqueues the whole build (and the read-back of its counts) on the ctx stream and returns; build_finish
+// waits for it and derives the host-side summary.  hspf_graph_patch does its host work (mirrors, two-way flags) between
+// the two, behind the kernels.
+struct BuildScratch { BuildInfo *info = nullptr; uint8_t *twoway = nullptr; };
+
+int build_launch(hspf_ctx *ctx, hspf_graph *g, bool hub, BuildScratch &bs) {
   const uint32_t n = g->n, e = g->e;
   hipStream_t s = ctx->stream;
   const size_t le = (size_t)e + 16;
   const size_t nsums = (size_t)std::max(e, n) / GB_TILE + 4;
-  // scratch: src_of, kpre, tmp_w, tmp_src, tmp_fpos, tmp_t (u32 x le each) | in_cnt (n+1) | sums | info | keep, twoway (u8)
+  // scratch: src_of, kpre, tmp_w, tmp_src, tmp_fpos, tmp_t, lslot (u32 x le each) | in_cnt (n+1) | sums | info | keep, twoway (u8)
   static_assert(sizeof(BuildInfo) <= 32 * 4, "BuildInfo scratch slot");
-  const size_t words = 6 * le + (size_t)n + 17 + nsums + 32;
+  const size_t words = 7 * le + (size_t)n + 17 + nsums + 32;
   const size_t bytes = words * 4 + 2 * le + 64;
   int rc = ensure(ctx, ctx->gb, bytes);
   if (rc != HSPF_OK) return rc;
@@ -352,6 +370,7 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   uint32_t *tmp_src = w; w += le;
   uint32_t *tmp_fpos = w; w += le;
   uint32_t *tmp_t = w; w += le;
+  uint32_t *lslot = w; w += le;
   uint32_t *in_cnt = w; w += (size_t)n + 17;
   uint32_t *sums = w; w += nsums;
   BuildInfo *info = (BuildInfo *)w; w += 32;
@@ -388,7 +407,7 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
                        (const uint32_t *)src_of, (const uint64_t *)hsorted, twoway, keep, info);
   } else if (e) {
     hipLaunchKernelGGL(kb_links, ge, dim3(GB_BLOCK), 0, s, n, e, row_ptr, col, metric, (const uint8_t *)g->d_vflags,
-                       src_of, twoway, keep, in_cnt, info);
+                       src_of, twoway, keep, in_cnt, lslot, info);
   }
   gb_scan<uint8_t>(s, keep, e, kpre, sums);
   hipLaunchKernelGGL(kb_out_ptr, gn, dim3(GB_BLOCK), 0, s, n, row_ptr, (const uint32_t *)kpre, g->d_out_ptr, info, e);
@@ -407,7 +426,7 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   } else if (e) {
     hipLaunchKernelGGL(kb_scatter, ge, dim3(GB_BLOCK), 0, s, e, row_ptr, col, metric, (const uint8_t *)g->d_vflags,
                        (const uint32_t *)src_of, (const uint8_t *)keep, (const uint32_t *)kpre,
-                       (const uint32_t *)g->d_in_ptr, in_cnt, g->d_out_dst, g->d_out_w, g->d_out_fpos,
+                       (const uint32_t *)g->d_in_ptr, (const uint32_t *)lslot, g->d_out_dst, g->d_out_w, g->d_out_fpos,
                        tmp_w, tmp_src, tmp_fpos, tmp_t, info);
     hipLaunchKernelGGL(kb_rank, ge, dim3(GB_BLOCK), 0, s, e, (const BuildInfo *)info, (const uint32_t *)g->d_in_ptr,
                        (const uint32_t *)tmp_w, (const uint32_t *)tmp_src, (const uint32_t *)tmp_fpos,
@@ -436,9 +455,29 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
                      g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_info, info, sizeof(BuildInfo), hipMemcpyDeviceToHost, s));
-  g->twoway.resize(e);
-  if (e) HIPCHK(ctx, hipMemcpyAsync(g->twoway.data(), twoway, e, hipMemcpyDeviceToHost, s));
+  bs.info = info; bs.twoway = twoway;
+  return HSPF_OK;
+}
+
+// fetch_twoway: the per-link two-way flags come back from the device (upload); a patch keeps the host mirror current
+// itself (1 MB less over the bus per patch at a million links).
+int build_finish(hspf_ctx *ctx, hspf_graph *g, bool hub, const BuildScratch &bs, bool fetch_twoway) {
+  const uint32_t n = g->n, e = g->e;
+  hipStream_t s = ctx->stream;
+  const bool tdbg = getenv("HSPF_PATCH_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!tdbg) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[hspf build] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
+  if (fetch_twoway) {
+    g->twoway.resize(e);
+    if (e) HIPCHK(ctx, hipMemcpyAsync(g->twoway.data(), bs.twoway, e, hipMemcpyDeviceToHost, s));
+  }
   HIPCHK(ctx, hipStreamSynchronize(s));
+  lap("wait for the build");
   const BuildInfo bi = *ctx->h_info;
   if (bi.err) {
     ctx->last_error = (bi.err & GB_ERR_COL) ? "col out of range" : "metric 0xFFFFFFFF is reserved";
@@ -448,12 +487,8 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
   g->wmax = bi.wmax;
   g->hc_net = bi.hc_net != 0; g->n_bad_rows = bi.n_bad_rows; g->n_zero_rows = bi.n_zero_rows; g->any_rowflags = bi.any_rowflags;
   g->hopcount_like = !bi.hc_bad && bi.hc_net;
-  {
-    uint64_t heavy = 0;                                   // from the host mirror of the caller's rows (out-degrees)
-    for (uint32_t v = 0; v < n; ++v) { const uint32_t d = g->row_ptr[v + 1] - g->row_ptr[v]; if (d > 32u) heavy += d; }
-    g->heavy_rows = heavy * 4u >= (uint64_t)std::max<uint32_t>(e, 1u);
-  }
-  if (!hub && bi.max_in_deg > ctx->hub_deg) return HSPF_RETRY_HUB;     // kb_rank left those rows out
+  g->heavy_rows = g->heavy_links * 4u >= (uint64_t)std::max<uint32_t>(e, 1u);   // from the caller's rows (out-degrees)
+  if (!hub && bi.max_in_deg > ctx->hub_deg) return HSPF_RETRY_HUB;     // kb_rank left those rows unsorted
   g->hub_built = hub;
   g->costs_only = false;
   for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
@@ -476,21 +511,27 @@ int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub) {
     tab.insert(tab.end(), s0.begin(), s0.end());
     HIPCHK(ctx, hipMemcpy(g->d_giant, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
   }
-  g->any_net = false;
-  for (uint32_t v = 0; v < n && !g->any_net; ++v) g->any_net = (g->vflags[v] & HSPF_VF_NETWORK) != 0;
+  g->any_net = g->n_net != 0;
   finish_summary(g);
+  lap("host summary");
   return HSPF_OK;
+}
+
+int build_pass(hspf_ctx *ctx, hspf_graph *g, bool hub, bool fetch_twoway) {
+  BuildScratch bs;
+  int rc = build_launch(ctx, g, hub, bs);
+  if (rc != HSPF_OK) return rc;
+  return build_finish(ctx, g, hub, bs, fetch_twoway);
 }
 
 // Hub mode when some row of the caller's CSR lists more than hub_deg links (then a target row scan of kb_links could be
 // that long), or when the plain pass found a row with more kept in-links than that (parallel links piled onto one row:
 // only then can the in-degree exceed every out-degree).
 int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
-  uint32_t max_out = 0;
-  for (uint32_t v = 0; v < g->n; ++v) max_out = std::max(max_out, g->row_ptr[v + 1] - g->row_ptr[v]);
-  const bool hub = max_out > ctx->hub_deg;
-  int rc = build_pass(ctx, g, hub);
-  if (rc == HSPF_RETRY_HUB) rc = build_pass(ctx, g, true);
+  g->host_summary_full();
+  const bool hub = g->max_out > ctx->hub_deg;
+  int rc = build_pass(ctx, g, hub, true);
+  if (rc == HSPF_RETRY_HUB) rc = build_pass(ctx, g, true, true);
   return rc;
 }
 
@@ -577,6 +618,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   if (const char *v = getenv("HSPF_XCD_ROW_COST")) ctx->xcd_row_cost = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_UNIT_HEAVY_DEG")) ctx->unit_heavy_deg = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_HUB_DEG")) ctx->hub_deg = (uint32_t)strtoul(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_TW_HOST_MAX")) ctx->tw_host_max = strtoull(v, nullptr, 0);
   if (const char *v = getenv("HSPF_ASYNC_LANES")) ctx->lanes_cfg = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(v, nullptr, 0), 1u), 8u);
   if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return HSPF_E_NODEV; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
@@ -771,39 +813,32 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
       });
     }
   }
-  // New row bounds and the spliced host mirror of col: the rows between two replaced ones keep their
-  // contents and stay contiguous, so each such run is one memcpy.
-  std::vector<uint32_t> nrp, ncol;
+  const bool tdbg = getenv("HSPF_PATCH_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!tdbg) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[hspf patch] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
+  // ---- structural patch.  The device derives everything from the old arrays and the delta (new row bounds: kb_patch_row_ptr,
+  // raw CSR: kb_splice, then the build), all enqueued first; the host mirrors (rows, two-way flags, the summary of the
+  // caller's rows) are brought up to date BEHIND the kernels, in O(replaced rows x their targets' rows) + one block move of
+  // the mirrors.  (Round 3: mirrors first, 400 KB of row bounds up and 1 MB of two-way flags down the bus, three walks over
+  // all rows: 0.59-0.68 ms at 100 000 rows / 1 000 000 links, now hidden or gone: profiles/r04_notes.md.)
   uint64_t e_new64 = g->e;
+  uint32_t new_max_len = 0;
+  bool max_row_shrinks = false;
   for (uint32_t j = 0; j < m; ++j) {
     const uint32_t v = rows->vertex[j];
-    e_new64 += (uint64_t)(rows->row_ptr[j + 1] - rows->row_ptr[j]);
-    e_new64 -= (uint64_t)(g->row_ptr[v + 1] - g->row_ptr[v]);
+    const uint32_t nl = rows->row_ptr[j + 1] - rows->row_ptr[j], ol = g->row_ptr[v + 1] - g->row_ptr[v];
+    e_new64 += (uint64_t)nl;
+    e_new64 -= (uint64_t)ol;
+    new_max_len = std::max(new_max_len, nl);
+    if (ol == g->max_out && nl < ol) max_row_shrinks = true;
   }
   if (e_new64 > HSPF_MAX_LINKS) { ctx->last_error = "hspf_graph_patch: too many links"; return HSPF_E_INVAL; }
   const uint32_t e_new = (uint32_t)e_new64;
-  try {
-    nrp.resize((size_t)n + 1);
-    ncol.resize(e_new);
-    uint32_t j = 0, pos = 0;
-    for (uint32_t u = 0; u < n;) {
-      if (j < m && rows->vertex[j] == u) {
-        const uint32_t len = rows->row_ptr[j + 1] - rows->row_ptr[j];
-        nrp[u] = pos;
-        if (len) memcpy(&ncol[pos], rows->col + rows->row_ptr[j], (size_t)len * 4);
-        pos += len; ++j; ++u;
-      } else {
-        const uint32_t u_end = j < m ? rows->vertex[j] : n;          // unchanged rows [u, u_end)
-        const uint32_t a = g->row_ptr[u], b = g->row_ptr[u_end];
-        if (b > a) memcpy(&ncol[pos], &g->col[a], (size_t)(b - a) * 4);
-        for (uint32_t x = u; x < u_end; ++x) nrp[x] = pos + (g->row_ptr[x] - a);
-        pos += b - a; u = u_end;
-      }
-    }
-    nrp[n] = pos;
-  } catch (const std::bad_alloc &) {
-    return HSPF_E_NOMEM;
-  }
   // grow the arena when the patched graph does not fit (raw CSR and flags move device-to-device)
   if (e_new > g->cap_e) {
     char *old_arena = g->arena;
@@ -826,22 +861,42 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
     (void)hipFree(old_arena);
     if (er != hipSuccess) { ctx->last_error = std::string("hspf_graph_patch: grow: ") + hipGetErrorString(er); return HSPF_E_HIP; }
   }
-  // delta to the device: changed[m] | delta_ptr[m+1] | delta_col[de] | delta_metric[de] | flags[m]
-  const size_t dwords = (size_t)m + (m + 1) + 2 * (size_t)de;
-  int rc = ensure(ctx, ctx->gb_delta, dwords * 4 + m + 64);
+  // the delta, one pinned staging block, one copy: changed[m] | delta_ptr[m+1] | shift[m+1] | delta_col[de] | delta_metric[de] | flags[m] (bytes)
+  const size_t dwords = (size_t)m + 2 * ((size_t)m + 1) + 2 * (size_t)de + ((size_t)m + 3) / 4;
+  int rc = ensure(ctx, ctx->gb_delta, dwords * 4 + 64, false);
   if (rc != HSPF_OK) return rc;
+  if (ctx->h_patch_cap < dwords) {
+    (void)hipStreamSynchronize(s);
+    if (ctx->h_patch) (void)hipHostFree(ctx->h_patch);
+    ctx->h_patch = nullptr; ctx->h_patch_cap = 0;
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_patch, (dwords + 1024) * 4, hipHostMallocDefault));
+    ctx->h_patch_cap = dwords + 1024;
+  }
+  {
+    uint32_t *h = ctx->h_patch;
+    memcpy(h, rows->vertex, (size_t)m * 4);
+    memcpy(h + m, rows->row_ptr, ((size_t)m + 1) * 4);
+    uint32_t *sh = h + m + (m + 1);
+    uint32_t acc = 0;                                       // modulo 2^32 (kb_patch_row_ptr)
+    for (uint32_t j = 0; j < m; ++j) {
+      sh[j] = acc;
+      const uint32_t v = rows->vertex[j];
+      acc += (rows->row_ptr[j + 1] - rows->row_ptr[j]) - (g->row_ptr[v + 1] - g->row_ptr[v]);
+    }
+    sh[m] = acc;
+    if (de) {
+      memcpy(sh + m + 1, rows->col, (size_t)de * 4);
+      memcpy(sh + m + 1 + de, rows->metric, (size_t)de * 4);
+    }
+    memcpy(sh + m + 1 + 2 * (size_t)de, rows->vflags, m);
+  }
   uint32_t *d_changed = (uint32_t *)ctx->gb_delta.p;
-  uint32_t *d_dptr = d_changed + m, *d_dcol = d_dptr + m + 1, *d_dmet = d_dcol + de;
+  uint32_t *d_dptr = d_changed + m, *d_shift = d_dptr + m + 1, *d_dcol = d_shift + m + 1, *d_dmet = d_dcol + de;
   uint8_t *d_nf = (uint8_t *)(d_dmet + de);
   const int nxt = g->cur ^ 1;
-  HIPCHK(ctx, hipMemcpyAsync(d_changed, rows->vertex, (size_t)m * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(ctx, hipMemcpyAsync(d_dptr, rows->row_ptr, ((size_t)m + 1) * 4, hipMemcpyHostToDevice, s));
-  if (de) {
-    HIPCHK(ctx, hipMemcpyAsync(d_dcol, rows->col, (size_t)de * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipMemcpyAsync(d_dmet, rows->metric, (size_t)de * 4, hipMemcpyHostToDevice, s));
-  }
-  HIPCHK(ctx, hipMemcpyAsync(d_nf, rows->vflags, m, hipMemcpyHostToDevice, s));
-  HIPCHK(ctx, hipMemcpyAsync(g->d_row_ptr[nxt], nrp.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(d_changed, ctx->h_patch, dwords * 4, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(kb_patch_row_ptr, dim3((n + 1 + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_row_ptr[g->cur], m,
+                     (const uint32_t *)d_changed, (const uint32_t *)d_shift, g->d_row_ptr[nxt]);
   if (e_new)
     hipLaunchKernelGGL(kb_splice, dim3((e_new + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, e_new,
                        (const uint32_t *)g->d_row_ptr[nxt], (const uint32_t *)g->d_row_ptr[g->cur],
@@ -850,15 +905,114 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
                        (const uint32_t *)d_dmet, g->d_col[nxt], g->d_metric[nxt]);
   hipLaunchKernelGGL(kb_set_vflags, dim3((m + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, m,
                      (const uint32_t *)d_changed, (const uint8_t *)d_nf, g->d_vflags);
-  // the pageable host buffers above must be consumed before nrp goes out of scope: build_on_device
-  // synchronises the stream before returning
+  // the summary of the caller's rows, from the replaced rows alone (the longest row is looked for again only when it
+  // was one of them and got shorter)
+  const uint32_t e_old = g->e;
+  uint32_t max_out_new = std::max(g->max_out, new_max_len);
+  if (max_row_shrinks) {
+    max_out_new = new_max_len;
+    uint32_t j = 0;
+    for (uint32_t v = 0; v < n; ++v) {
+      if (j < m && rows->vertex[j] == v) { ++j; continue; }
+      max_out_new = std::max(max_out_new, g->row_ptr[v + 1] - g->row_ptr[v]);
+    }
+  }
   g->cur = nxt;
   g->e = e_new;
+  const bool hub = max_out_new > ctx->hub_deg;
+  BuildScratch bs;
+  rc = build_launch(ctx, g, hub, bs);
+  if (rc != HSPF_OK) {                                       // nothing of the host side was touched: the graph is unusable only if the device failed
+    (void)hipStreamSynchronize(s);
+    g->cur = nxt ^ 1; g->e = e_old;
+    return rc;
+  }
+  lap("staging + launches");
+  // ---- behind the kernels: the host mirrors.  Rows between two replaced ones keep their contents and stay contiguous,
+  // so each such run is one memcpy.
+  // Two-way flags of the mirror: a link u -> t is two-way when row t lists u.  Replacing row u changes the flags of u's
+  // own links and of the links t -> u in the rows of its old and new targets, nothing else.  Long rows would make the
+  // membership scans quadratic, so beyond a work bound the flags come back from the device as after an upload.
+  uint64_t tw_work = 0;
+  for (uint32_t j = 0; j < m; ++j) {
+    const uint32_t v = rows->vertex[j];
+    for (uint32_t k = rows->row_ptr[j]; k < rows->row_ptr[j + 1]; ++k) { const uint32_t t = rows->col[k]; tw_work += g->row_ptr[t + 1] - g->row_ptr[t] + 1u; }
+    for (uint32_t k = g->row_ptr[v]; k < g->row_ptr[v + 1]; ++k) { const uint32_t t = g->col[k]; tw_work += g->row_ptr[t + 1] - g->row_ptr[t] + 1u; }
+  }
+  tw_work += 2ull * de;                                       // rows of replaced targets are read at their new length
+  const bool tw_host = tw_work <= ctx->tw_host_max && g->twoway.size() == e_old;
+  std::vector<uint32_t> nrp, ncol, old_targets;
+  std::vector<uint8_t> ntw;
+  uint64_t heavy_new = g->heavy_links;
+  uint32_t n_net_new = g->n_net;
+  try {
+    nrp.resize((size_t)n + 1);
+    ncol.resize(e_new);
+    if (tw_host) ntw.resize(e_new);
+    uint32_t j = 0, pos = 0;
+    for (uint32_t u = 0; u < n;) {
+      if (j < m && rows->vertex[j] == u) {
+        const uint32_t len = rows->row_ptr[j + 1] - rows->row_ptr[j], ol = g->row_ptr[u + 1] - g->row_ptr[u];
+        nrp[u] = pos;
+        if (len) memcpy(&ncol[pos], rows->col + rows->row_ptr[j], (size_t)len * 4);
+        if (ol > 32u) heavy_new -= ol;
+        if (len > 32u) heavy_new += len;
+        if (g->vflags[u] & HSPF_VF_NETWORK) --n_net_new;
+        if (rows->vflags[j] & HSPF_VF_NETWORK) ++n_net_new;
+        if (tw_host) old_targets.insert(old_targets.end(), g->col.begin() + g->row_ptr[u], g->col.begin() + g->row_ptr[u + 1]);
+        pos += len; ++j; ++u;
+      } else {
+        const uint32_t u_end = j < m ? rows->vertex[j] : n;          // unchanged rows [u, u_end)
+        const uint32_t a = g->row_ptr[u], b = g->row_ptr[u_end];
+        if (b > a) {
+          memcpy(&ncol[pos], &g->col[a], (size_t)(b - a) * 4);
+          if (tw_host) memcpy(&ntw[pos], &g->twoway[a], (size_t)(b - a));
+        }
+        const uint32_t d = pos - a;                                   // modulo 2^32
+        for (uint32_t x = u; x < u_end; ++x) nrp[x] = g->row_ptr[x] + d;
+        pos += b - a; u = u_end;
+      }
+    }
+    nrp[n] = pos;
+    if (tw_host) {
+      // per replaced row u: its own links, then the links t -> u of its old and new targets (old_targets holds the old
+      // rows back to back, in the order of rows->vertex)
+      size_t ot = 0;
+      std::vector<uint32_t> mine;
+      for (uint32_t j2 = 0; j2 < m; ++j2) {
+        const uint32_t u = rows->vertex[j2];
+        const uint32_t ua = nrp[u], ub = nrp[u + 1];
+        const size_t ol = g->row_ptr[u + 1] - g->row_ptr[u];
+        mine.assign(ncol.begin() + ua, ncol.begin() + ub);
+        std::sort(mine.begin(), mine.end());
+        auto lists = [&](uint32_t t) { return std::binary_search(mine.begin(), mine.end(), t); };
+        auto back_links = [&](uint32_t t) {                              // links t -> u in the (new) row of t
+          const bool two = lists(t);
+          bool t_lists_u = false;
+          for (uint32_t k = nrp[t]; k < nrp[t + 1]; ++k)
+            if (ncol[k] == u) { ntw[k] = two ? 1 : 0; t_lists_u = true; }
+          return t_lists_u;
+        };
+        for (uint32_t k = ua; k < ub; ++k) ntw[k] = back_links(ncol[k]) ? 1 : 0;
+        for (size_t k = 0; k < ol; ++k) (void)back_links(old_targets[ot + k]);
+        ot += ol;
+      }
+    }
+  } catch (const std::bad_alloc &) {
+    (void)hipStreamSynchronize(s);
+    g->cur = nxt ^ 1; g->e = e_old;
+    return HSPF_E_NOMEM;
+  }
   for (uint32_t j = 0; j < m; ++j) g->vflags[rows->vertex[j]] = rows->vflags[j];
   g->row_ptr.swap(nrp);
   g->col.swap(ncol);
-  rc = build_on_device(ctx, g);
+  if (tw_host) g->twoway.swap(ntw);
+  g->max_out = max_out_new; g->heavy_links = heavy_new; g->n_net = n_net_new;
+  lap("host mirrors");
+  rc = build_finish(ctx, g, hub, bs, !tw_host);
+  if (rc == HSPF_RETRY_HUB) rc = build_pass(ctx, g, true, !tw_host);
   if (rc != HSPF_OK) (void)hipStreamSynchronize(s);
+  lap("wait + summary");
   return rc;
 }
 
@@ -886,7 +1040,7 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
     case HSPF_GX_ELL_SRC: src = g->d_ell_so; bytes = ((size_t)g->n + 1) * 64; break;
     case HSPF_GX_ELL_COST: src = g->d_ell_w; bytes = ((size_t)g->n + 1) * 64; break;
     case HSPF_GX_ELL_OUT: src = g->d_ell_od; bytes = ((size_t)g->n + 1) * 64; break;
-    case HSPF_GX_SUMMARY: bytes = 32; break;                         // host values
+    case HSPF_GX_SUMMARY: bytes = 48; break;                         // host values
     case HSPF_GX_LEAF: src = g->d_leaf; bytes = g->n; break;
     case HSPF_GX_UNITS: src = g->d_unit_first; bytes = g->n_heavy_chunks ? ((size_t)g->n_heavy_chunks * 3 + (g->n + 15u) / 16u) * 4 : 0; break;
     default: ctx->last_error = "hspf_graph_export: unknown array"; return HSPF_E_INVAL;
@@ -897,8 +1051,9 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
   if (which == HSPF_GX_TWOWAY) { if (bytes) memcpy(dst, g->twoway.data(), bytes); return HSPF_OK; }
   if (which == HSPF_GX_BUILD_MODE) { const uint32_t m = g->costs_only ? 2u : g->hub_built ? 1u : 0u; memcpy(dst, &m, 4); return HSPF_OK; }
   if (which == HSPF_GX_SUMMARY) {
-    const uint32_t v[8] = {g->wmax, g->hopcount_like ? 1u : 0u, g->lean ? 1u : 0u, g->any_rowflags, g->n_zero_rows, g->n_bad_rows, g->max_in_deg, g->e_kept};
-    memcpy(dst, v, 32);
+    const uint32_t v[12] = {g->wmax, g->hopcount_like ? 1u : 0u, g->lean ? 1u : 0u, g->any_rowflags, g->n_zero_rows, g->n_bad_rows, g->max_in_deg, g->e_kept,
+                            g->max_out, g->n_net, (uint32_t)g->heavy_links, g->heavy_rows ? 1u : 0u};
+    memcpy(dst, v, 48);
     return HSPF_OK;
   }
   (void)hipSetDevice(ctx->device);

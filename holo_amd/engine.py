@@ -7,6 +7,7 @@ in the HIP library; there is no Python or CPU fallback.
 from __future__ import annotations
 
 import ctypes
+import time
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -142,7 +143,9 @@ class SpfGraph:
         if len(dcol) == 0:
             dcol = np.zeros(1, np.uint32); dmet = np.zeros(1, np.uint32)     # non-NULL pointers
         r = L.HspfRows(len(vs), _u32(vs), _u32(rp), _u32(dcol), _u32(dmet), nf.ctypes.data_as(L.u8p))
+        t0 = time.perf_counter()
         rc = self.ctx.lib.hspf_graph_patch(self.ctx.handle, self.handle, ctypes.byref(r))
+        self.last_patch_call_ms = (time.perf_counter() - t0) * 1e3     # the C call alone (the numpy mirrors below are this twin's own)
         if rc != 0:
             raise HspfError(rc, "hspf_graph_patch", self.ctx.last_error())
         lens = self.row_ptr[vs.astype(np.int64) + 1] - self.row_ptr[vs]

@@ -252,10 +252,12 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows);
 #define HSPF_GX_ELL_OUT  18u   /* u32 [16(n+1)] out-neighbour j << 2 (unused entries 0xFFFFFFFF)                     */
 #define HSPF_GX_LEAF     20u   /* u8  [n]      1 = leaf: exactly one kept in-link, and the kept out-links (at most one) lead
                                   back to its source.  IN_SRC carries the source's leaf bit in bit 30                */
-#define HSPF_GX_SUMMARY  19u   /* u32 [8]      what a build derives from the links and a patch must keep current:
+#define HSPF_GX_SUMMARY  19u   /* u32 [12]     what a build derives from the links and a patch must keep current:
                                   largest kept cost, hop-count shape (0/1), smallest-graph kernel allowed (0/1), OR of
                                   the row flags, rows with a zero-cost link from a higher-numbered source, rows off the
-                                  hop-count shape, largest in-degree, kept links                                     */
+                                  hop-count shape, largest in-degree, kept links; of the caller's rows (a structural
+                                  patch updates them from the replaced rows alone): longest row, network vertices,
+                                  links in rows of more than 32, "a quarter of the links sit in such rows" (0/1)      */
 int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *dst, size_t cap_bytes,
                       size_t *out_bytes);
 

@@ -33,7 +33,8 @@ def spf_ctx(request, _ctx_pool):
     to the emit wherever it has any, which the adversarial graphs do (stub LANs, one-way links); "lanevertex" sends
     every run of up to 64 roots (with at most 24 first-hop slots) through k_lv (HSPF_SINGLE_MAX_N=0, HSPF_LV_MAX_ROOTS=64,
     HSPF_LV_MIN_N=0); "hubsort" is the default engine with every graph built in hub mode (HSPF_HUB_DEG=0: two-way check and
-    in-row order from device-wide sorts instead of per-link row scans).
+    in-row order from device-wide sorts instead of per-link row scans; HSPF_TW_HOST_MAX=0: a structural patch fetches the
+    two-way flags of its host mirror from the device, as it does for rows too long to scan, instead of keeping them itself).
     Tests choose with tests/_engines.py (indirect parametrisation); unmarked tests get "default"."""
     mode = getattr(request, "param", "default")
     if mode not in _ctx_pool:
@@ -43,7 +44,7 @@ def spf_ctx(request, _ctx_pool):
                "twophase": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "64"},
                "widemask": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "1"},
                "lanevertex": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "64", "HSPF_LV_MIN_N": "0"},
-               "hubsort": {"HSPF_HUB_DEG": "0"}}.get(mode, {})
+               "hubsort": {"HSPF_HUB_DEG": "0", "HSPF_TW_HOST_MAX": "0"}}.get(mode, {})
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:

@@ -250,6 +250,63 @@ def test_patch_equals_fresh_upload(spf_ctx, seed):
         G.free()
 
 
+@hub_engines
+def test_structural_patch_keeps_the_host_side_current(spf_ctx):
+    """A structural patch enqueues the device build and brings the host side up to date behind it: the mirror of the rows,
+    their two-way flags (from the replaced rows and their old and new targets alone) and the summary of the caller's rows
+    (longest row, network vertices, links in long rows) — all as a fresh upload has them, for the changes that exercise each
+    rule: the longest row shrinks, rows that list each other are replaced together, a self-link, an emptied row, a vertex
+    changing its kind, everything returning."""
+    g0 = synth.random_lsdb(300, 6, 3.0, 4242, lan_size=60, metric_hi=5)
+    g = g0
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    nn = 6
+    roots = np.arange(nn, nn + 40, dtype=np.uint32)
+
+    def row(v):
+        return g.col[g.row_ptr[v]:g.row_ptr[v + 1]].copy(), g.metric[g.row_ptr[v]:g.row_ptr[v + 1]].copy()
+
+    def step(tag, vs, rows, flags, spf=True):
+        nonlocal g
+        G.patch(vs, rows, flags)
+        g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
+        F = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        try:
+            for name in BUILT + RAW + DERIVED:
+                assert np.array_equal(G.export(name), F.export(name)), (tag, name)
+        finally:
+            F.free()
+        assert_layout(G, g)
+        if spf:
+            check_spf(spf_ctx, G, g, roots, E.RUN_NET_NEXTHOPS)
+
+    try:
+        lens = np.diff(g.row_ptr.astype(np.int64))
+        big = int(np.argmax(lens))
+        assert lens[big] > 32 and int(G.export("summary")[8]) == lens[big]
+        c, m = row(big)
+        step("longest row shrinks", [big], [(c[:5], m[:5])], [g.vflags[big]])
+        assert int(G.export("summary")[8]) == int(np.diff(g.row_ptr.astype(np.int64)).max())
+        # two routers that list each other: one drops the other and lists itself instead, the other reverses its row
+        u = next(v for v in range(nn, g.n) if any(t >= nn and v in row(int(t))[0] for t in row(v)[0]))
+        t = int(next(t for t in row(u)[0] if t >= nn and u in row(int(t))[0]))
+        cu, mu = row(u); ct, mt = row(t)
+        cu2 = np.where(cu == t, u, cu).astype(np.uint32)
+        vs = sorted([u, t])
+        rows = {u: (cu2, mu), t: (ct[::-1].copy(), mt[::-1].copy())}
+        step("partners replaced together, self-link", vs, [rows[v] for v in vs], [g.vflags[v] for v in vs])
+        step("row emptied", [u], [(np.zeros(0, np.uint32), np.zeros(0, np.uint32))], [g.vflags[u]])
+        # a network vertex becomes a router vertex and a router a network vertex (odd LSDBs are still graphs): layouts only
+        step("kinds change", [0, u], [row(0), (cu, mu)], [g.vflags[0] ^ synth.VF_NETWORK, g.vflags[u] ^ synth.VF_NETWORK], spf=False)
+        assert int(G.export("summary")[9]) == int((g.vflags & synth.VF_NETWORK != 0).sum())
+        # everything returns
+        vs = sorted({0, u, t, big})
+        step("all back", vs, [(g0.col[g0.row_ptr[v]:g0.row_ptr[v + 1]], g0.metric[g0.row_ptr[v]:g0.row_ptr[v + 1]]) for v in vs], [g0.vflags[v] for v in vs])
+        assert np.array_equal(G.col, g0.col) and np.array_equal(G.row_ptr, g0.row_ptr)
+    finally:
+        G.free()
+
+
 def cost_rows(g, rng, k, lo, hi):
     """k rows with the same targets, order and flags and new costs in [lo, hi] (links into a network keep theirs
     with probability 1/2, so ties and zero costs stay around)."""
