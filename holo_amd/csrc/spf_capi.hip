@@ -212,7 +212,10 @@ struct hspf_lane {
   std::thread th;
   std::mutex mu;
   std::condition_variable cv;
-  struct Job { const hspf_graph *g; std::vector<uint32_t> roots; uint32_t flags; hspf_result out; uint64_t ticket; };
+  struct Job {
+    const hspf_graph *g; std::vector<uint32_t> roots; uint32_t flags; hspf_result out; uint64_t ticket;
+    std::vector<uint32_t> dest; uint32_t n_total = 0;   // a class of a larger run (run_classes): output row of each root, rows of the whole run
+  };
   std::deque<Job> jobs;                // waiting, in ticket order
   bool running = false, quit = false;
   struct Done { uint64_t ticket = 0; int rc = 0; hspf_stats st{}; std::string err; } done[8];
@@ -563,6 +566,9 @@ extern "C" {
 
 static void lanes_quiesce(hspf_ctx *ctx);
 static void lanes_shutdown(hspf_ctx *ctx);
+static int lanes_ensure(hspf_ctx *ctx);
+static uint64_t lane_submit(hspf_ctx *ctx, hspf_lane::Job &&job);
+static int lane_collect(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats);
 
 uint32_t hspf_abi_version(void) { return HSPF_ABI_VERSION; }
 
@@ -1969,12 +1975,34 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     if (want_rank) { if ((rc = ensure(ctx, ctx->o_rank, rn * 4))) return rc; U.pop_rank = (uint32_t *)ctx->o_rank.p; }
   }
   hspf_stats acc{};
-  for (int c = 0; c < 3; ++c) {
+  // The classes are independent runs (own roots, own state, own rows of the output): on a context that may have lanes
+  // (hspf_run_device_async) all but the last go to the lanes and run NEXT TO each other.  configs[4] (fat-tree, 51 switch
+  // roots through k_fw + 50 host roots through k_fused): the k_fused class is a chain of latency-bound sweeps over the
+  // switches' 100-link rows, the k_fw class is bound by the bytes of its 24-byte state — side by side they take little
+  // more than the longer one (profiles/r04_notes.md, r04w).  HSPF_VARIANT bit 20: one after the other (A/B).
+  int n_cls = 0, last_cls = -1;
+  for (int c = 0; c < 3; ++c) if (start[c + 1] > start[c]) { ++n_cls; last_cls = c; }
+  const bool side_by_side = n_cls >= 2 && !ctx->parent && ctx->lanes_cfg > 0 && !(ctx->variant & 1048576u) &&
+                            (uint64_t)n * n_roots >= (1ull << 22) && lanes_ensure(ctx) == HSPF_OK;
+  uint64_t cls_ticket[3] = {0, 0, 0};
+  const auto t_cls = std::chrono::steady_clock::now();
+  if (side_by_side)
+    for (int c = 0; c < 3; ++c) {
+      const uint32_t off = start[c], nr = start[c + 1] - start[c];
+      if (nr == 0 || c == last_cls) continue;
+      hspf_lane::Job job{g, std::vector<uint32_t>(proots.begin() + off, proots.begin() + off + nr), run_flags, U, 0,
+                         std::vector<uint32_t>(dest.begin() + off, dest.begin() + off + nr), n_roots};
+      cls_ticket[c] = lane_submit(ctx, std::move(job));
+    }
+  int rc_first = HSPF_OK;
+  for (int c = 2; c >= 0; --c) {                                 // the class this context runs itself first, then the lanes' results
     const uint32_t off = start[c], nr = start[c + 1] - start[c];
     if (nr == 0) continue;
-    rc = run_impl(ctx, g, proots.data() + off, nr, run_flags, &U, false, dest.data() + off, n_roots);
-    if (rc) return rc;
-    const hspf_stats &p = ctx->stats;
+    hspf_stats lane_st{};
+    if (cls_ticket[c]) rc = lane_collect(ctx, cls_ticket[c], &lane_st);
+    else rc = run_impl(ctx, g, proots.data() + off, nr, run_flags, &U, false, dest.data() + off, n_roots);
+    if (rc) { if (!rc_first) rc_first = rc; continue; }          // (every submitted class is collected before the call returns)
+    const hspf_stats &p = cls_ticket[c] ? lane_st : ctx->stats;
     acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
     acc.n_dag_launches += p.n_dag_launches; acc.n_exact_roots += p.n_exact_roots;
     acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
@@ -1983,6 +2011,14 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     acc.rows_recomputed += p.rows_recomputed;
     acc.dbg[0] |= p.dbg[0]; acc.dbg[1] = ((acc.dbg[1] | p.dbg[1]) & 0x80000000u) | ((acc.dbg[1] & 0x7FFFFFFFu) + (p.dbg[1] & 0x7FFFFFFFu));
     acc.dbg[2] += p.dbg[2]; acc.dbg[3] += p.dbg[3];
+  }
+  if (rc_first) return rc_first;
+  if (side_by_side) {                                            // what the classes took together, not their sum
+    const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_cls).count();
+    if (wall < acc.ms_total) {
+      const float k = wall / acc.ms_total;
+      acc.ms_total = wall; acc.ms_relax *= k; acc.ms_dag *= k; acc.ms_finish *= k;
+    }
   }
   if (host_out) {
     HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
@@ -2050,7 +2086,11 @@ static int lanes_ensure(hspf_ctx *ctx) {
         lk.unlock();
         ln->cv.notify_all();                                        // (a submitter may be waiting for room in the queue)
         (void)hipSetDevice(ln->sub->device);
-        const int rc = guarded(ln->sub, [&]() { return run_classes(ln->sub, job.g, job.roots.data(), (uint32_t)job.roots.size(), job.flags, &job.out, false); });
+        const int rc = guarded(ln->sub, [&]() {
+          if (!job.dest.empty())                                    // one class of a run that the caller's context split (run_classes)
+            return run_impl(ln->sub, job.g, job.roots.data(), (uint32_t)job.roots.size(), job.flags, &job.out, false, job.dest.data(), job.n_total);
+          return run_classes(ln->sub, job.g, job.roots.data(), (uint32_t)job.roots.size(), job.flags, &job.out, false);
+        });
         lk.lock();
         hspf_lane::Done &d = ln->done[(job.ticket / nl) & 7u];
         d.ticket = job.ticket; d.rc = rc; d.st = ln->sub->stats;
@@ -2091,30 +2131,45 @@ int hspf_run_device_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *ro
   return guarded(ctx, [&]() {
     int rc = lanes_ensure(ctx);
     if (rc) return rc;
-    const uint64_t t = ctx->next_ticket++;
-    hspf_lane *ln = ctx->lanes[t % ctx->lanes.size()];
-    hspf_lane::Job job{g, std::vector<uint32_t>(roots, roots + n_roots), run_flags, *out_device, t};
-    std::unique_lock<std::mutex> lk(ln->mu);
-    ln->cv.wait(lk, [&] { return ln->jobs.size() < LANE_QUEUE_MAX; });   // room in the lane's queue (it runs its jobs in ticket order)
-    ln->jobs.push_back(std::move(job));
-    lk.unlock();
-    ln->cv.notify_all();
-    *ticket = t;
+    hspf_lane::Job job{g, std::vector<uint32_t>(roots, roots + n_roots), run_flags, *out_device, 0, {}, 0};
+    *ticket = lane_submit(ctx, std::move(job));
     return (int)HSPF_OK;
   });
 }
 
-int hspf_wait(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats) {
-  if (!ctx || ticket == 0 || ticket >= ctx->next_ticket || ctx->lanes.empty()) return HSPF_E_INVAL;
+// Next ticket, onto its lane's queue (lanes exist: lanes_ensure).
+static uint64_t lane_submit(hspf_ctx *ctx, hspf_lane::Job &&job) {
+  const uint64_t t = ctx->next_ticket++;
+  hspf_lane *ln = ctx->lanes[t % ctx->lanes.size()];
+  job.ticket = t;
+  std::unique_lock<std::mutex> lk(ln->mu);
+  ln->cv.wait(lk, [&] { return ln->jobs.size() < LANE_QUEUE_MAX; });   // room in the lane's queue (it runs its jobs in ticket order)
+  ln->jobs.push_back(std::move(job));
+  lk.unlock();
+  ln->cv.notify_all();
+  return t;
+}
+
+// Waits for a ticket; its result code, statistics and (on failure) error text.  Does not touch ctx->stats.
+static int lane_collect(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats) {
   hspf_lane *ln = ctx->lanes[ticket % ctx->lanes.size()];
   std::unique_lock<std::mutex> lk(ln->mu);
   ln->cv.wait(lk, [&] { return ln->last_done >= ticket; });
   const hspf_lane::Done &d = ln->done[(ticket / ctx->lanes.size()) & 7u];
   if (d.ticket != ticket) { ctx->last_error = "hspf_wait: the ticket's result is gone (more than eight later runs on its lane)"; return HSPF_E_INVAL; }
-  ctx->stats = d.st;
   if (stats) *stats = d.st;
   if (d.rc) { try { ctx->last_error = d.err; } catch (...) {} }
   return d.rc;
+}
+
+int hspf_wait(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats) {
+  if (!ctx || ticket == 0 || ticket >= ctx->next_ticket || ctx->lanes.empty()) return HSPF_E_INVAL;
+  hspf_stats st{};
+  const int rc = lane_collect(ctx, ticket, &st);
+  if (rc == HSPF_E_INVAL && ctx->last_error.rfind("hspf_wait: the ticket", 0) == 0) return rc;
+  ctx->stats = st;
+  if (stats) *stats = st;
+  return rc;
 }
 
 int hspf_wait_all(hspf_ctx *ctx) {

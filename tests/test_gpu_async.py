@@ -139,3 +139,46 @@ def test_random_lsdbs_async_equal_sync():
             G.free()
     finally:
         ctx.close()
+
+
+def test_classes_of_one_run_side_by_side():
+    """A synchronous run whose roots fall into two state classes (fat-tree k=64: the edge switch and its 32 aggregation
+    switches have 64 first-hop slots -> k_fw, its 32 hosts have one -> the packed path) sends one class to a lane and runs
+    the other itself (run_classes): same tables as one class after the other (HSPF_VARIANT bit 20) and as the oracle —
+    also with an asynchronous ticket of another run queued on the lanes in front of it, and through the host-output call."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = synth.isis_fattree(64)
+    roots = np.asarray(g.meta["roots"], np.uint32)
+    assert len(roots) == 65 and g.n * len(roots) >= 1 << 22
+    g2 = synth.ospf_10k()
+    roots2 = np.arange(64, dtype=np.uint32) * 150
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 0, go.HEAP, mask_words_=1, threads=ORACLE_THREADS)
+    ref2 = go.run(g2.row_ptr, g2.col, g2.metric, g2.vflags, g2.max_path_metric, roots2, 0, go.HEAP, mask_words_=1, threads=ORACLE_THREADS)
+    launches = {}
+    for name, env in (("side by side", {}), ("one after the other", {"HSPF_VARIANT": 1048576})):
+        ctx = _ctx(**env)
+        try:
+            G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+            G2 = ctx.upload(g2.row_ptr, g2.col, g2.metric, g2.vflags, g2.max_path_metric)
+            W = G.mask_words(roots)
+            assert W == 1
+            t, t2 = _tables(torch, dev, len(roots), g.n, W), _tables(torch, dev, 64, g2.n, 1)
+            for rep in range(3):
+                for x in t.values():
+                    x.zero_()
+                tk = ctx.run_device_async(G2, roots2, 0, **_kw(t2, 1)) if rep == 1 else None
+                st = ctx.run_device(G, roots, 0, **_kw(t, W))
+                if tk is not None:
+                    ctx.wait(tk)
+                    _check(t2, ref2)
+                _check(t, ref)
+                assert st["n_roots"] == len(roots)
+            launches[name] = st["n_relax_launches"]
+            res = ctx.run(G, roots, 0)                                  # host outputs: the classes write into the staging, one copy out
+            assert np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops)
+            assert np.array_equal(res.flags & 1, ref.flags) and np.array_equal(res.first_hop_mask, ref.mask)
+            G.free(); G2.free()
+        finally:
+            ctx.close()
+    assert launches["side by side"] == launches["one after the other"]
