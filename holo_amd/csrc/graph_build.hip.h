@@ -58,6 +58,29 @@ struct BuildInfo {       // device-resident summary of one build, copied back on
   uint32_t n_leaf;       // leaves (GraphDev::leaf)
 };
 
+// Counts that every row may add to (rows off the hop-count shape, RF_ZERO rows, leaves) do not go to BuildInfo directly: an
+// atomic on ONE address costs ~10 ns whoever issues it (15 600 of them made kb_scatter 180 us, 100 000 made kb_rowflags
+// 40-130 us), so each count has 64 counters in 64 different 128-byte lines behind BuildInfo, a block adds to counter
+// blockIdx & 63, and the single-workgroup kernel at the end of the build (kb_units_small / kb_xcd) sums them into BuildInfo.
+constexpr uint32_t GB_SC_BAD = 0, GB_SC_ZERO = 1, GB_SC_LEAF = 2, GB_SC_COUNTS = 3;
+constexpr uint32_t GB_SC_WORDS = GB_SC_COUNTS * 64u * 32u;
+__device__ __forceinline__ uint32_t *gb_spread(BuildInfo *info, uint32_t which) {
+  return (uint32_t *)info + 32u + (which * 64u + (blockIdx.x & 63u)) * 32u;
+}
+// one wave (lanes 0..63 of `lane`): BuildInfo's counts from the spread counters
+__device__ __forceinline__ void gb_counts_finish(BuildInfo *info, uint32_t lane) {
+  uint32_t v[GB_SC_COUNTS];
+  for (uint32_t c = 0; c < GB_SC_COUNTS; ++c) {
+    v[c] = ((const uint32_t *)info)[32u + (c * 64u + lane) * 32u];
+    for (int o = 32; o; o >>= 1) v[c] += (uint32_t)__shfl_xor((int)v[c], o);
+  }
+  if (lane == 0u) {
+    info->n_bad_rows = v[GB_SC_BAD]; info->hc_bad = v[GB_SC_BAD] ? 1u : 0u;
+    info->n_zero_rows = v[GB_SC_ZERO];
+    info->n_leaf = v[GB_SC_LEAF];
+  }
+}
+
 constexpr uint32_t HUB_DEG = 512;        // rows with more links than this: hub mode (HSPF_HUB_DEG)
 
 constexpr int GB_BLOCK = 256;
@@ -74,14 +97,49 @@ __device__ __forceinline__ uint32_t gb_row_of(const uint32_t *__restrict__ row_p
   return lo;
 }
 
+// in_cnt[0 .. n] and BuildInfo + its spread counters, zeroed by ONE launch (two hipMemsetAsync of these sizes are six fill
+// kernels of the runtime: aligned part + tails)
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_clear(uint32_t *__restrict__ in_cnt, uint32_t n_cnt, uint32_t *__restrict__ info_words, uint32_t n_info) {
+  const uint32_t i = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (i < n_cnt) in_cnt[i] = 0u;
+  if (i < n_info) info_words[i] = 0u;
+}
+
 __global__ void __launch_bounds__(GB_BLOCK)
 kb_links(uint32_t n, uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
          const uint32_t *__restrict__ metric, const uint8_t *__restrict__ vflags, uint32_t *__restrict__ src_of,
          uint8_t *__restrict__ twoway, uint8_t *__restrict__ keep, uint32_t *__restrict__ in_cnt,
          uint32_t *__restrict__ lslot, BuildInfo *__restrict__ info) {
-  const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
+  // The owning row: the block's 256 consecutive links span the rows [u0, u1] — two searches over all rows per BLOCK, the
+  // bounds of those rows in LDS, a search over at most 257 of them per link there (a search over all rows per link was 17
+  // dependent global loads).  Blocks whose links span more rows than fit (runs of empty rows) search globally as before.
+  __shared__ uint32_t rp[GB_BLOCK + 2];
+  __shared__ uint32_t s_u0, s_cnt;
+  const uint32_t k0 = blockIdx.x * GB_BLOCK;
+  if (threadIdx.x == 0) {
+    const uint32_t u0 = gb_row_of(row_ptr, n, k0), u1 = gb_row_of(row_ptr, n, min(k0 + GB_BLOCK - 1u, e - 1u));
+    s_u0 = u0; s_cnt = u1 - u0 + 1u;
+  }
+  __syncthreads();
+  const uint32_t u0 = s_u0, cnt = s_cnt;
+  const bool in_lds = cnt <= (uint32_t)GB_BLOCK + 1u;
+  if (in_lds)
+    for (uint32_t i = threadIdx.x; i < cnt; i += GB_BLOCK) rp[i] = row_ptr[u0 + i];
+  __syncthreads();
+  const uint32_t k = k0 + threadIdx.x;
   if (k >= e) return;
-  const uint32_t u = gb_row_of(row_ptr, n, k);
+  uint32_t u;
+  if (in_lds) {
+    uint32_t lo = 0, hi = cnt;                          // largest i with rp[i] <= k (rp[0] <= k0 <= k)
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (rp[mid] <= k) lo = mid; else hi = mid;
+    }
+    u = u0 + lo;
+  } else {
+    u = gb_row_of(row_ptr, n, k);
+  }
   const uint32_t t = col[k];
   src_of[k] = u;
   uint32_t bad = 0;
@@ -95,8 +153,11 @@ kb_links(uint32_t n, uint32_t e, const uint32_t *__restrict__ row_ptr, const uin
   // two-way connectivity: the target's row lists the source, cost not compared
   bool two = false;
   const uint32_t b = row_ptr[t + 1];
-  for (uint32_t k2 = row_ptr[t]; k2 < b; ++k2)
-    if (col[k2] == u) { two = true; break; }
+  for (uint32_t k2 = row_ptr[t]; k2 < b && !two; k2 += 4u) {     // four entries per step: the loop waits for its loads once per four
+    const uint32_t c0 = col[k2], c1 = k2 + 1u < b ? col[k2 + 1u] : INF, c2 = k2 + 2u < b ? col[k2 + 2u] : INF,
+                   c3 = k2 + 3u < b ? col[k2 + 3u] : INF;          // (u < n <= 2^24: INF never matches)
+    two = c0 == u || c1 == u || c2 == u || c3 == u;
+  }
   const bool kp = two && !(vflags[u] & HSPF_VF_NO_EXPAND);
   twoway[k] = two ? 1 : 0;
   keep[k] = kp ? 1 : 0;
@@ -187,29 +248,26 @@ kb_scatter(uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__r
            const uint32_t *__restrict__ src_of, const uint8_t *__restrict__ keep, const uint32_t *__restrict__ kpre,
            const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ lslot,
            uint32_t *__restrict__ out_dst, uint32_t *__restrict__ out_w, uint32_t *__restrict__ out_fpos,
-           uint32_t *__restrict__ tmp_w, uint32_t *__restrict__ tmp_src, uint32_t *__restrict__ tmp_fpos,
-           uint32_t *__restrict__ tmp_t, BuildInfo *__restrict__ info) {
-  __shared__ uint32_t bmax;
-  if (threadIdx.x == 0) bmax = 0;
-  __syncthreads();
+           uint4 *__restrict__ tmp, BuildInfo *__restrict__ info) {
+  // the in-row copy of a link goes to a random place: ONE 16-byte record (cost, source | NT, position, target) instead of
+  // four 4-byte stores to four arrays (4 M scattered stores at 1 M links were most of this kernel's 56 us)
   const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
+  uint32_t wmax = 0;
   if (k < e && keep[k]) {
     const uint32_t u = src_of[k], t = col[k], w = metric[k];
     const uint32_t fpos = k - row_ptr[u];
     const uint32_t o = kpre[k];
     out_dst[o] = t; out_w[o] = w; out_fpos[o] = fpos;
     const uint32_t i = in_ptr[t] + lslot[k];
-    tmp_w[i] = w;
     // the overload gate only exists for routers (holo-isis/src/spf.rs:568-574: `!vertex.id.is_pseudonode()`): the bit on
     // a network vertex is ignored, as k_exact and the oracle do
     const uint32_t uf = vflags[u];
-    tmp_src[i] = u | (((uf & HSPF_VF_NO_TRANSIT) && !(uf & HSPF_VF_NETWORK)) ? SRC_NO_TRANSIT : 0u);
-    tmp_fpos[i] = fpos;
-    tmp_t[i] = t;
-    atomicMax(&bmax, w);
+    tmp[i] = make_uint4(w, u | (((uf & HSPF_VF_NO_TRANSIT) && !(uf & HSPF_VF_NETWORK)) ? SRC_NO_TRANSIT : 0u), fpos, t);
+    wmax = w;
   }
-  __syncthreads();
-  if (threadIdx.x == 0 && bmax) atomicMax(&info->wmax, bmax);
+  for (int o = 32; o; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
+  // only a wave that would raise the maximum touches it (a stale read costs one atomic too many, never a wrong maximum)
+  if ((threadIdx.x & 63u) == 0u && wmax > *(volatile uint32_t *)&info->wmax) atomicMax(&info->wmax, wmax);
 }
 
 // In-links of a row by (cost descending, source ascending, position ascending): among tight links, i.e. equal
@@ -217,14 +275,14 @@ kb_scatter(uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__r
 // first discoverer (earliest popped tight parent).  k_fused relies on it; k_dag / k_exact do not care.
 __global__ void __launch_bounds__(GB_BLOCK)
 kb_rank(uint32_t e, const BuildInfo *__restrict__ info, const uint32_t *__restrict__ in_ptr,
-        const uint32_t *__restrict__ tmp_w, const uint32_t *__restrict__ tmp_src,
-        const uint32_t *__restrict__ tmp_fpos, const uint32_t *__restrict__ tmp_t,
+        const uint4 *__restrict__ tmp,
         uint32_t *__restrict__ in_src, uint32_t *__restrict__ in_w, uint32_t *__restrict__ in_fpos, uint32_t hub_deg) {
   const uint32_t i = blockIdx.x * GB_BLOCK + threadIdx.x;
   if (i >= e || i >= info->kept) return;
-  const uint32_t t = tmp_t[i];
+  const uint4 me = tmp[i];                                // (cost, source | NT, position, target)
+  const uint32_t t = me.w;
   const uint32_t a = in_ptr[t], b = in_ptr[t + 1];
-  const uint32_t w = tmp_w[i], sraw = tmp_src[i], s = sraw & SRC_MASK, f = tmp_fpos[i];
+  const uint32_t w = me.x, sraw = me.y, s = sraw & SRC_MASK, f = me.z;
   if (b - a > hub_deg) {
     // parallel links piled onto one row: the host sees max_in_deg and rebuilds in hub mode.  The row is still WRITTEN —
     // unsorted, at its scatter position —: the remaining kernels of this (discarded) pass index other arrays with its
@@ -235,7 +293,8 @@ kb_rank(uint32_t e, const BuildInfo *__restrict__ info, const uint32_t *__restri
   }
   uint32_t rank = 0;
   for (uint32_t j = a; j < b; ++j) {
-    const uint32_t wj = tmp_w[j], sj = tmp_src[j] & SRC_MASK, fj = tmp_fpos[j];
+    const uint4 o = tmp[j];
+    const uint32_t wj = o.x, sj = o.y & SRC_MASK, fj = o.z;
     const bool before = wj > w || (wj == w && (sj < s || (sj == s && fj < f)));
     rank += before ? 1u : 0u;
   }
@@ -350,15 +409,18 @@ __global__ void __launch_bounds__(GB_BLOCK)
 kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ in_src,
             const uint32_t *__restrict__ in_w, const uint8_t *__restrict__ vflags, uint8_t *__restrict__ rowflags,
             BuildInfo *__restrict__ info, uint32_t giant_deg) {
-  // one thread per row; a row of more than 64 in-links is walked by its whole wave (a LAN with thousands of members
-  // would otherwise be one thread's serial loop)
-  const uint32_t t = blockIdx.x * GB_BLOCK + threadIdx.x;
+  // sixteen lanes per row (a wave = four rows): a row's links arrive in one coalesced load per array and sixteen links,
+  // all rows of the wave in flight together (one thread per row walked its links one dependent load after the other:
+  // 50-130 us for 100 000 rows of ten links); a row of more than 256 in-links is walked by its whole wave afterwards (a
+  // LAN with thousands of members would otherwise be sixteen lanes' serial loop)
+  const uint32_t gt = blockIdx.x * GB_BLOCK + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t t = gt >> 4, j = gt & 15u;
   const bool valid = t < n;
   const uint32_t a = valid ? in_ptr[t] : 0u, b = valid ? in_ptr[t + 1] : 0u;
   const bool net = valid && (vflags[t] & HSPF_VF_NETWORK);
-  const bool wide = b - a > 64u;
-  uint32_t f = (b - a > 16u ? RF_MANY : 0u) | (b - a > giant_deg ? RF_GIANT : 0u);
+  const bool wide = b - a > 256u;
+  uint32_t f = 0;
   bool bad = false;
   auto link = [&](uint32_t i, uint32_t row, bool row_net, uint32_t &ff, bool &bb) {
     const uint32_t sraw = in_src[i], u = sraw & SRC_MASK, w = in_w[i];
@@ -368,8 +430,13 @@ kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__r
     else bb |= w != 1u;
   };
   if (!wide)
-    for (uint32_t i = a; i < b; ++i) link(i, t, net, f, bad);
-  for (uint64_t todo = __ballot(wide); todo != 0ull; todo &= todo - 1ull) {
+    for (uint32_t i = a + j; i < b; i += 16u) link(i, t, net, f, bad);
+  for (int o = 8; o; o >>= 1) {                            // the row's sixteen lanes (xor below 16 stays inside the group)
+    const int ob = __shfl_xor((int)bad, o);                // (every lane shuffles: no short-circuit around it)
+    f |= (uint32_t)__shfl_xor((int)f, o);
+    bad = bad || ob != 0;
+  }
+  for (uint64_t todo = __ballot(wide && j == 0u); todo != 0ull; todo &= todo - 1ull) {
     const int l = __ffsll((unsigned long long)todo) - 1;
     const uint32_t row = __shfl(t, l), ra = __shfl(a, l), rb = __shfl(b, l);
     const bool row_net = __shfl((int)net, l) != 0;
@@ -381,17 +448,28 @@ kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__r
     const bool any_bad = __ballot(bb) != 0ull;
     if ((int)lane == l) { f |= all; bad = any_bad; }
   }
-  if (valid) rowflags[t] = (uint8_t)f;
-  // the summary, reduced over the wave first: one atomic per ROW on these five words was 40-130 us of a 100 000-row build
-  uint32_t mx = valid ? b - a : 0u, fo = valid ? f : 0u;
+  f |= (b - a > 16u ? RF_MANY : 0u) | (b - a > giant_deg ? RF_GIANT : 0u);
+  const bool head = valid && j == 0u;
+  if (head) rowflags[t] = (uint8_t)f;
+  // the summary: reduced over the wave, then over the block; maximum and OR only touch BuildInfo when they would change
+  // it, the two counts go to the spread counters (gb_spread)
+  __shared__ uint32_t red[4][5];
+  uint32_t mx = head ? b - a : 0u, fo = head ? f : 0u;
   for (int o = 32; o; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); fo |= (uint32_t)__shfl_xor((int)fo, o); }
-  const uint64_t m_bad = __ballot(valid && bad), m_zero = __ballot(valid && (f & RF_ZERO)), m_net = __ballot(valid && net && b > a);
-  if (lane != 0u) return;
-  if (mx) atomicMax(&info->max_in_deg, mx);
-  if (fo) atomicOr(&info->any_rowflags, fo);
-  if (m_bad) { info->hc_bad = 1u; atomicAdd(&info->n_bad_rows, (uint32_t)__popcll(m_bad)); }   // plain store: every writer stores the same value
-  if (m_zero) atomicAdd(&info->n_zero_rows, (uint32_t)__popcll(m_zero));
-  if (m_net) info->hc_net = 1u;
+  const uint64_t m_bad = __ballot(head && bad), m_zero = __ballot(head && (f & RF_ZERO)), m_net = __ballot(head && net && b > a);
+  if (lane == 0u) {
+    uint32_t *r = red[threadIdx.x >> 6];
+    r[0] = mx; r[1] = fo; r[2] = (uint32_t)__popcll(m_bad); r[3] = (uint32_t)__popcll(m_zero); r[4] = m_net ? 1u : 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0u) return;
+  uint32_t bmx = 0, bfo = 0, nbad = 0, nzero = 0, bnet = 0;
+  for (int w = 0; w < GB_BLOCK / 64; ++w) { bmx = max(bmx, red[w][0]); bfo |= red[w][1]; nbad += red[w][2]; nzero += red[w][3]; bnet |= red[w][4]; }
+  if (bmx > *(volatile uint32_t *)&info->max_in_deg) atomicMax(&info->max_in_deg, bmx);
+  if (bfo & ~*(volatile uint32_t *)&info->any_rowflags) atomicOr(&info->any_rowflags, bfo);
+  if (nbad) atomicAdd(gb_spread(info, GB_SC_BAD), nbad);
+  if (nzero) atomicAdd(gb_spread(info, GB_SC_ZERO), nzero);
+  if (bnet && !*(volatile uint32_t *)&info->hc_net) info->hc_net = 1u;   // plain store: every writer stores the same value
 }
 
 // Work units (GraphDev::unit_first): heavy flag per 16-vertex chunk, then (after a scan of the flags) the unit table
@@ -419,16 +497,63 @@ kb_unit_fill(uint32_t n, const uint32_t *__restrict__ hf, const uint32_t *__rest
   else unit_first[4u * nh + (c - hb)] = c * 16u;
 }
 
+// scan + kb_unit_fill + kb_xcd + kb_pads in ONE workgroup behind kb_unit_count, for graphs of up to 65 536 chunks (1 M
+// vertices): six dependent launches of a few microseconds of work each were a fifth of a structural patch's launch chain.
+// Thread t owns the chunks [t ipt, (t + 1) ipt): heavy flags in a bit mask, heavy chunks in front of its range by a block scan.
+constexpr int GB_UNITS_THREADS = 1024;
+constexpr uint32_t GB_UNITS_MAX_CHUNKS = 65536;
+__device__ __forceinline__ void kb_xcd_body(uint32_t x, uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *__restrict__ info,
+                                            uint32_t row_cost, uint32_t n_heavy);
+__global__ void __launch_bounds__(GB_UNITS_THREADS)
+kb_units_small(uint32_t n, const uint32_t *__restrict__ in_ptr_c, const uint32_t *__restrict__ hf, uint32_t *__restrict__ unit_first,
+               BuildInfo *__restrict__ info, uint32_t row_cost, uint32_t *in_ptr, uint32_t *out_ptr,
+               uint32_t *a0, uint32_t *a1, uint32_t *a2, uint32_t *a3, uint32_t *a4, uint32_t *a5) {
+  __shared__ uint32_t sh[GB_UNITS_THREADS];
+  const uint32_t t = threadIdx.x;
+  const uint32_t nb = (n + 15u) / 16u;
+  const uint32_t ipt = (nb + GB_UNITS_THREADS - 1u) / GB_UNITS_THREADS;     // <= 64
+  const uint32_t c0 = min(t * ipt, nb), c1 = min(c0 + ipt, nb);
+  uint64_t heavy = 0ull;                                   // the flags of kb_unit_count (the pass over the rows stays a grid's work)
+  for (uint32_t c = c0; c < c1; ++c)
+    if (hf[c]) heavy |= 1ull << (c - c0);
+  const uint32_t mine = (uint32_t)__popcll(heavy);
+  sh[t] = mine;
+  __syncthreads();
+  for (int d = 1; d < GB_UNITS_THREADS; d <<= 1) {
+    const uint32_t add = (int)t >= d ? sh[t - d] : 0u;
+    __syncthreads();
+    sh[t] += add;
+    __syncthreads();
+  }
+  const uint32_t nh = sh[GB_UNITS_THREADS - 1];
+  uint32_t hb = sh[t] - mine;                                    // heavy chunks before c0
+  for (uint32_t c = c0; c < c1; ++c) {
+    if ((heavy >> (c - c0)) & 1ull) {
+      for (uint32_t k = 0; k < 4u; ++k) unit_first[4u * hb + k] = min(c * 16u + 4u * k, n) | UNIT_SPLIT;
+      ++hb;
+    } else {
+      unit_first[4u * nh + (c - hb)] = c * 16u;
+    }
+  }
+  if (t == 0u) info->n_heavy = nh;
+  if (t < 9u) kb_xcd_body(t, n, in_ptr_c, info, row_cost, nh);
+  if (t >= 128u && t < 192u) gb_counts_finish(info, t - 128u);
+  if (t >= 64u && t < 80u) {                                     // kb_pads (info->kept was written by kb_out_ptr, launches ago)
+    const uint32_t i = t - 64u, kept = info->kept;
+    in_ptr[n + 1 + i] = 0; out_ptr[n + 1 + i] = 0;
+    a0[kept + i] = 0; a1[kept + i] = 0; a2[kept + i] = 0; a3[kept + i] = 0; a4[kept + i] = 0; a5[kept + i] = 0;
+  }
+}
+
 // Work-balanced XCD ranges for graphs without heavy chunks (GraphDev::xcd_start): cost of a 16-vertex chunk prefix k =
 // in-links of the first 16k vertices + 8 per vertex (a row costs about 8 links' worth of fixed work; HSPF_XCD_ROW_COST);
 // XCD x starts at the first chunk whose prefix reaches x/8 of the total.  Seven binary searches, one thread each.
 // With heavy chunks: even shares of the normal units (the heavy ones are split evenly by the host, GraphDev::xcd_heavy).
-__global__ void kb_xcd(uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *__restrict__ info, uint32_t row_cost) {
-  const uint32_t x = threadIdx.x;
-  if (x > 8u) return;
+__device__ __forceinline__ void kb_xcd_body(uint32_t x, uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *__restrict__ info,
+                                            uint32_t row_cost, uint32_t n_heavy) {
   const uint32_t nb = (n + 15u) / 16u;
-  if (info->n_heavy) {
-    const uint32_t nn = nb - info->n_heavy;
+  if (n_heavy) {
+    const uint32_t nn = nb - n_heavy;
     info->xcd_start[x] = (uint32_t)((uint64_t)nn * x / 8ull);
     return;
   }
@@ -441,6 +566,10 @@ __global__ void kb_xcd(uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInf
   }
   info->xcd_start[x] = x == 8u ? nb : lo;
 }
+__global__ void kb_xcd(uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *__restrict__ info, uint32_t row_cost) {
+  if (threadIdx.x <= 8u) kb_xcd_body(threadIdx.x, n, in_ptr, info, row_cost, info->n_heavy);
+  gb_counts_finish(info, threadIdx.x);                      // (launched with 64 threads)
+}
 
 // Leaves (GraphDev::leaf): exactly one kept in-link, and the kept out-links (at most one) lead back to its source.
 __global__ void __launch_bounds__(GB_BLOCK)
@@ -448,11 +577,14 @@ kb_leaf_mark(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__
              const uint32_t *__restrict__ out_ptr, const uint32_t *__restrict__ out_dst, uint8_t *__restrict__ leaf,
              BuildInfo *__restrict__ info) {
   const uint32_t v = blockIdx.x * GB_BLOCK + threadIdx.x;
-  if (v >= n) return;
-  const uint32_t e0 = in_ptr[v], o0 = out_ptr[v], od = out_ptr[v + 1] - o0;
-  const bool is = in_ptr[v + 1] - e0 == 1u && (od == 0u || (od == 1u && out_dst[o0] == (in_src[e0] & SRC_MASK)));
-  leaf[v] = is ? 1u : 0u;
-  if (is) atomicAdd(&info->n_leaf, 1u);
+  bool is = false;
+  if (v < n) {
+    const uint32_t e0 = in_ptr[v], o0 = out_ptr[v], od = out_ptr[v + 1] - o0;
+    is = in_ptr[v + 1] - e0 == 1u && (od == 0u || (od == 1u && out_dst[o0] == (in_src[e0] & SRC_MASK)));
+    leaf[v] = is ? 1u : 0u;
+  }
+  const uint64_t m = __ballot(is);                         // (a fat-tree has 250 000 leaves: not one atomic each on one word)
+  if ((threadIdx.x & 63u) == 0u && m) atomicAdd(gb_spread(info, GB_SC_LEAF), (uint32_t)__popcll(m));
 }
 
 // ... and SRC_LEAF on every link that comes from one
@@ -509,8 +641,10 @@ __global__ void kb_pads(uint32_t n, const BuildInfo *__restrict__ info, uint32_t
 // 400 KB upload of the bounds per patch at 100 000 rows.
 __global__ void __launch_bounds__(GB_BLOCK)
 kb_patch_row_ptr(uint32_t n, const uint32_t *__restrict__ old_row_ptr, uint32_t n_changed, const uint32_t *__restrict__ changed,
-                 const uint32_t *__restrict__ shift, uint32_t *__restrict__ new_row_ptr) {
+                 const uint32_t *__restrict__ shift, uint32_t *__restrict__ new_row_ptr, const uint8_t *__restrict__ nf,
+                 uint8_t *__restrict__ vflags) {
   const uint32_t v = blockIdx.x * GB_BLOCK + threadIdx.x;
+  for (uint32_t i = v; i < n_changed; i += gridDim.x * GB_BLOCK) vflags[changed[i]] = nf[i];   // the replaced rows' new flags ride along
   if (v > n) return;
   uint32_t lo = 0, hi = n_changed;                       // replaced rows in front of v
   while (lo < hi) {
@@ -520,29 +654,34 @@ kb_patch_row_ptr(uint32_t n, const uint32_t *__restrict__ old_row_ptr, uint32_t 
   new_row_ptr[v] = old_row_ptr[v] + shift[lo];           // modulo 2^32: a negative shift wraps back
 }
 
+// New raw CSR = the old one with the replaced rows taken from the delta.  A link's source is found among the REPLACED rows
+// (their new starts old_row_ptr[changed[j]] + shift[j] are ascending), not among all rows: J = replaced rows that start at
+// or before k; k inside the last of them -> the delta, otherwise the old link k - shift[J] (everything behind J replaced
+// rows has moved by their length changes).  (Round 3 searched row_ptr for every link: 17 dependent loads, 19 us at 1 M links.)
 __global__ void __launch_bounds__(GB_BLOCK)
-kb_splice(uint32_t n, uint32_t e_new, const uint32_t *__restrict__ new_row_ptr,
-          const uint32_t *__restrict__ old_row_ptr, const uint32_t *__restrict__ old_col,
+kb_splice(uint32_t e_new, const uint32_t *__restrict__ old_row_ptr, const uint32_t *__restrict__ old_col,
           const uint32_t *__restrict__ old_metric, uint32_t n_changed, const uint32_t *__restrict__ changed,
-          const uint32_t *__restrict__ delta_ptr, const uint32_t *__restrict__ delta_col,
+          const uint32_t *__restrict__ shift, const uint32_t *__restrict__ delta_ptr, const uint32_t *__restrict__ delta_col,
           const uint32_t *__restrict__ delta_metric, uint32_t *__restrict__ new_col, uint32_t *__restrict__ new_metric) {
   const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
   if (k >= e_new) return;
-  const uint32_t u = gb_row_of(new_row_ptr, n, k);
-  const uint32_t off = k - new_row_ptr[u];
-  // is u one of the replaced rows?  (changed[] is strictly ascending)
-  uint32_t lo = 0, hi = n_changed;
+  uint32_t lo = 0, hi = n_changed;                        // J = first j whose new start is behind k
   while (lo < hi) {
     const uint32_t mid = (lo + hi) >> 1;
-    if (changed[mid] < u) lo = mid + 1; else hi = mid;
+    if (old_row_ptr[changed[mid]] + shift[mid] <= k) lo = mid + 1; else hi = mid;
   }
-  if (lo < n_changed && changed[lo] == u) {
-    new_col[k] = delta_col[delta_ptr[lo] + off];
-    new_metric[k] = delta_metric[delta_ptr[lo] + off];
-  } else {
-    new_col[k] = old_col[old_row_ptr[u] + off];
-    new_metric[k] = old_metric[old_row_ptr[u] + off];
+  if (lo != 0u) {
+    const uint32_t j = lo - 1u;
+    const uint32_t off = k - (old_row_ptr[changed[j]] + shift[j]);
+    if (off < delta_ptr[j + 1] - delta_ptr[j]) {          // inside replaced row j
+      new_col[k] = delta_col[delta_ptr[j] + off];
+      new_metric[k] = delta_metric[delta_ptr[j] + off];
+      return;
+    }
   }
+  const uint32_t ko = k - shift[lo];                      // modulo 2^32
+  new_col[k] = old_col[ko];
+  new_metric[k] = old_metric[ko];
 }
 
 // ---- patch, fast path: the replaced rows list the SAME targets in the same order with the same flags, only costs differ
@@ -630,13 +769,6 @@ kb_pc_wmax(uint32_t e_kept, const uint32_t *__restrict__ out_w, PatchInfo *__res
   for (uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x; k < e_kept; k += gridDim.x * GB_BLOCK) m = max(m, out_w[k]);
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
   if ((threadIdx.x & 63u) == 0u && m) atomicMax(&pinfo->wmax, m);
-}
-
-__global__ void __launch_bounds__(GB_BLOCK)
-kb_set_vflags(uint32_t n_changed, const uint32_t *__restrict__ changed, const uint8_t *__restrict__ nf,
-              uint8_t *__restrict__ vflags) {
-  const uint32_t i = blockIdx.x * GB_BLOCK + threadIdx.x;
-  if (i < n_changed) vflags[changed[i]] = nf[i];
 }
 
 }  // namespace hspf

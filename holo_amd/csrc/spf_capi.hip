@@ -360,23 +360,20 @@ int build_launch(hspf_ctx *ctx, hspf_graph *g, bool hub, BuildScratch &bs) {
   hipStream_t s = ctx->stream;
   const size_t le = (size_t)e + 16;
   const size_t nsums = (size_t)std::max(e, n) / GB_TILE + 4;
-  // scratch: src_of, kpre, tmp_w, tmp_src, tmp_fpos, tmp_t, lslot (u32 x le each) | in_cnt (n+1) | sums | info | keep, twoway (u8)
+  // scratch: tmp (uint4 x le: the in-row records before ranking), src_of, kpre, lslot (u32 x le each) | in_cnt (n+1) | sums | info | keep, twoway (u8)
   static_assert(sizeof(BuildInfo) <= 32 * 4, "BuildInfo scratch slot");
-  const size_t words = 7 * le + (size_t)n + 17 + nsums + 32;
+  const size_t words = 7 * le + (size_t)n + 17 + nsums + 32 + GB_SC_WORDS;
   const size_t bytes = words * 4 + 2 * le + 64;
   int rc = ensure(ctx, ctx->gb, bytes);
   if (rc != HSPF_OK) return rc;
   uint32_t *w = (uint32_t *)ctx->gb.p;
+  uint4 *tmp = (uint4 *)w; w += 4 * le;                  // first: 16-byte aligned
   uint32_t *src_of = w; w += le;
   uint32_t *kpre = w; w += le;
-  uint32_t *tmp_w = w; w += le;
-  uint32_t *tmp_src = w; w += le;
-  uint32_t *tmp_fpos = w; w += le;
-  uint32_t *tmp_t = w; w += le;
   uint32_t *lslot = w; w += le;
   uint32_t *in_cnt = w; w += (size_t)n + 17;
   uint32_t *sums = w; w += nsums;
-  BuildInfo *info = (BuildInfo *)w; w += 32;
+  BuildInfo *info = (BuildInfo *)w; w += 32 + GB_SC_WORDS;     // + the spread counters (gb_spread), zeroed with it
   uint8_t *keep = (uint8_t *)w;
   uint8_t *twoway = keep + le;
   const uint32_t *row_ptr = g->d_row_ptr[g->cur], *col = g->d_col[g->cur], *metric = g->d_metric[g->cur];
@@ -399,8 +396,10 @@ int build_launch(hspf_ctx *ctx, hspf_graph *g, bool hub, BuildScratch &bs) {
     htmp = (void *)(((uintptr_t)(hsrcflag + le) + 255) & ~(uintptr_t)255);
   }
 
-  HIPCHK(ctx, hipMemsetAsync(in_cnt, 0, ((size_t)n + 1) * 4, s));
-  HIPCHK(ctx, hipMemsetAsync(info, 0, sizeof(BuildInfo), s));
+  {
+    const uint32_t n_info = 32u + GB_SC_WORDS, n_clear = std::max(n + 1u, n_info);
+    hipLaunchKernelGGL(kb_clear, dim3((n_clear + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, in_cnt, n + 1u, (uint32_t *)info, n_info);
+  }
   const dim3 ge((e + GB_BLOCK - 1) / GB_BLOCK), gn((n + 1 + GB_BLOCK - 1) / GB_BLOCK);
   if (e && hub) {
     hipLaunchKernelGGL(kb_hub_keys, ge, dim3(GB_BLOCK), 0, s, n, e, row_ptr, col, src_of, hkey);
@@ -430,12 +429,11 @@ int build_launch(hspf_ctx *ctx, hspf_graph *g, bool hub, BuildScratch &bs) {
     hipLaunchKernelGGL(kb_scatter, ge, dim3(GB_BLOCK), 0, s, e, row_ptr, col, metric, (const uint8_t *)g->d_vflags,
                        (const uint32_t *)src_of, (const uint8_t *)keep, (const uint32_t *)kpre,
                        (const uint32_t *)g->d_in_ptr, (const uint32_t *)lslot, g->d_out_dst, g->d_out_w, g->d_out_fpos,
-                       tmp_w, tmp_src, tmp_fpos, tmp_t, info);
+                       tmp, info);
     hipLaunchKernelGGL(kb_rank, ge, dim3(GB_BLOCK), 0, s, e, (const BuildInfo *)info, (const uint32_t *)g->d_in_ptr,
-                       (const uint32_t *)tmp_w, (const uint32_t *)tmp_src, (const uint32_t *)tmp_fpos,
-                       (const uint32_t *)tmp_t, g->d_in_src, g->d_in_w, g->d_in_fpos, ctx->hub_deg);
+                       (const uint4 *)tmp, g->d_in_src, g->d_in_w, g->d_in_fpos, ctx->hub_deg);
   }
-  hipLaunchKernelGGL(kb_rowflags, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
+  hipLaunchKernelGGL(kb_rowflags, dim3((uint32_t)(((size_t)n * 16 + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
                      (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info, GIANT_DEG);
   hipLaunchKernelGGL(kb_leaf_mark, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
                      (const uint32_t *)g->d_out_ptr, (const uint32_t *)g->d_out_dst, g->d_leaf, info);
@@ -443,7 +441,13 @@ int build_launch(hspf_ctx *ctx, hspf_graph *g, bool hub, BuildScratch &bs) {
   hipLaunchKernelGGL(kb_ell, dim3((uint32_t)((((size_t)n + 1) * 16 + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr,
                      (const uint32_t *)g->d_in_src, (const uint32_t *)g->d_in_w, (const uint32_t *)g->d_out_ptr, (const uint32_t *)g->d_out_dst,
                      (const uint8_t *)g->d_vflags, g->d_ell_so, g->d_ell_w, g->d_ell_od);
-  {
+  if ((n + 15u) / 16u <= GB_UNITS_MAX_CHUNKS) {
+    // work units, XCD ranges and the pads behind the arrays: heavy flag per chunk (in_cnt is free again), the rest in one workgroup
+    const uint32_t nb = (n + 15u) / 16u;
+    hipLaunchKernelGGL(kb_unit_count, dim3((nb + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, in_cnt, ctx->unit_heavy_deg);
+    hipLaunchKernelGGL(kb_units_small, dim3(1), dim3(GB_UNITS_THREADS), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)in_cnt, g->d_unit_first, info,
+                       ctx->xcd_row_cost, g->d_in_ptr, g->d_out_ptr, g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos);
+  } else {
     // work units: heavy flag per chunk -> heavy chunks before each chunk -> unit_first (scratch: in_cnt, n + 17 words, is
     // free again and holds both: nb flags, then nb + 1 positions)
     const uint32_t nb = (n + 15u) / 16u;
@@ -452,10 +456,10 @@ int build_launch(hspf_ctx *ctx, hspf_graph *g, bool hub, BuildScratch &bs) {
     gb_scan<uint32_t>(s, in_cnt, nb, hpos, sums);
     hipLaunchKernelGGL(kb_unit_fill, dim3((nb + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)in_cnt,
                        (const uint32_t *)hpos, g->d_unit_first, info);
+    hipLaunchKernelGGL(kb_xcd, dim3(1), dim3(64), 0, s, n, (const uint32_t *)g->d_in_ptr, info, ctx->xcd_row_cost);
+    hipLaunchKernelGGL(kb_pads, dim3(1), dim3(64), 0, s, n, (const BuildInfo *)info, g->d_in_ptr, g->d_out_ptr,
+                       g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos);
   }
-  hipLaunchKernelGGL(kb_xcd, dim3(1), dim3(64), 0, s, n, (const uint32_t *)g->d_in_ptr, info, ctx->xcd_row_cost);
-  hipLaunchKernelGGL(kb_pads, dim3(1), dim3(64), 0, s, n, (const BuildInfo *)info, g->d_in_ptr, g->d_out_ptr,
-                     g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(ctx->h_info, info, sizeof(BuildInfo), hipMemcpyDeviceToHost, s));
   bs.info = info; bs.twoway = twoway;
@@ -902,15 +906,12 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
   const int nxt = g->cur ^ 1;
   HIPCHK(ctx, hipMemcpyAsync(d_changed, ctx->h_patch, dwords * 4, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(kb_patch_row_ptr, dim3((n + 1 + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_row_ptr[g->cur], m,
-                     (const uint32_t *)d_changed, (const uint32_t *)d_shift, g->d_row_ptr[nxt]);
+                     (const uint32_t *)d_changed, (const uint32_t *)d_shift, g->d_row_ptr[nxt], (const uint8_t *)d_nf, g->d_vflags);
   if (e_new)
-    hipLaunchKernelGGL(kb_splice, dim3((e_new + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, e_new,
-                       (const uint32_t *)g->d_row_ptr[nxt], (const uint32_t *)g->d_row_ptr[g->cur],
-                       (const uint32_t *)g->d_col[g->cur], (const uint32_t *)g->d_metric[g->cur], m,
-                       (const uint32_t *)d_changed, (const uint32_t *)d_dptr, (const uint32_t *)d_dcol,
+    hipLaunchKernelGGL(kb_splice, dim3((e_new + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, e_new,
+                       (const uint32_t *)g->d_row_ptr[g->cur], (const uint32_t *)g->d_col[g->cur], (const uint32_t *)g->d_metric[g->cur], m,
+                       (const uint32_t *)d_changed, (const uint32_t *)d_shift, (const uint32_t *)d_dptr, (const uint32_t *)d_dcol,
                        (const uint32_t *)d_dmet, g->d_col[nxt], g->d_metric[nxt]);
-  hipLaunchKernelGGL(kb_set_vflags, dim3((m + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, m,
-                     (const uint32_t *)d_changed, (const uint8_t *)d_nf, g->d_vflags);
   // the summary of the caller's rows, from the replaced rows alone (the longest row is looked for again only when it
   // was one of them and got shorter)
   const uint32_t e_old = g->e;
