@@ -258,6 +258,9 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows);
                                   hop-count shape, largest in-degree, kept links; of the caller's rows (a structural
                                   patch updates them from the replaced rows alone): longest row, network vertices,
                                   links in rows of more than 32, "a quarter of the links sit in such rows" (0/1)      */
+#define HSPF_GX_HOST_ROW_PTR 21u /* u32 [n+1]  the HOST mirror of the caller's row bounds (slot tables are made from it; a
+                                  structural patch splices it in place): equals ROW_PTR                              */
+#define HSPF_GX_HOST_COL 22u   /* u32 [e]      ... and of the caller's targets: equals COL                           */
 int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *dst, size_t cap_bytes,
                       size_t *out_bytes);
 

@@ -25,6 +25,7 @@ def assert_layout(G, g):
         assert np.array_equal(got, want[name]), name
     for name in RAW:
         assert np.array_equal(G.export(name), getattr(g, name)), name
+    assert np.array_equal(G.export("host_row_ptr"), g.row_ptr) and np.array_equal(G.export("host_col"), g.col)   # the host mirrors
     assert G.n_edges_kept == len(want["in_src"])
 
 

@@ -152,6 +152,7 @@ def fuzz_layout(ctx, first, count, verbose=True, spf=False):
             want = layout(G.row_ptr, G.col, G.metric, G.vflags)
             good = all(np.array_equal(G.export(k), want[k]) for k in built) and G.n_edges_kept == len(want["in_src"])
             good = good and all(np.array_equal(G.export(k), getattr(G, k)) for k in ("row_ptr", "col", "metric", "vflags"))
+            good = good and np.array_equal(G.export("host_row_ptr"), G.row_ptr) and np.array_equal(G.export("host_col"), G.col)   # the library's host mirrors
             runs += 1
             ok += good
             if not good:
