@@ -1,18 +1,28 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): bench + rocprofv3 kernel-trace stats + PMC passes -> gpurun_out/prof
 # usage: bash tools/gpu_profile.sh <tag>      (summaries are then copied to profiles/<tag>_* by hand)
+#        STAGE=1 bash tools/gpu_profile.sh <tag>   bench + kernel trace only        (two shorter gpurun calls instead of one:
+#        STAGE=2 bash tools/gpu_profile.sh <tag>   PMC passes + traffic summary only  gpurun_out/ of both merges back)
 set -u
 export TMPDIR=/tmp
+STAGE=${STAGE:-0}
 R=$(pwd); OUT=$R/gpurun_out/prof; rm -rf $OUT; mkdir -p $OUT
-python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
+if [ "$STAGE" != "2" ]; then
+python bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err < /dev/null
 tail -c 2500 $OUT/bench.json
 cd /tmp
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o spf -- python $R/bench.py --steps 10 --warmup 2 --min-timed-ms 0 --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o spf -- python $R/bench.py --steps 10 --warmup 2 --min-timed-ms 0 --no-cpu-baseline > $OUT/trace.log 2>&1 < /dev/null
+cp $OUT/trace/spf_kernel_stats.csv $OUT/kernel_stats.csv
+find $OUT -name "*kernel_trace.csv" -size +2M -delete
+cd $R
+fi
+if [ "$STAGE" = "1" ]; then exit 0; fi
+cd /tmp
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
             "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
             "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
   i=$(echo "$pass" | md5sum | cut -c1-6)
-  timeout -k 5 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$i -o q -- python $R/bench.py --steps 3 --warmup 1 --min-timed-ms 0 --no-cpu-baseline > $OUT/pmc_$i.log 2>&1
+  timeout -k 5 120 rocprofv3 --pmc $pass --output-format csv -d $OUT/pmc_$i -o q -- python $R/bench.py --steps 3 --warmup 1 --min-timed-ms 0 --no-cpu-baseline > $OUT/pmc_$i.log 2>&1 < /dev/null
 done
 cd $R
 python - <<'PY'
@@ -62,5 +72,4 @@ traffic["git_rev"] = os.environ.get("GIT_REV", "unknown")
 json.dump(traffic, open("gpurun_out/prof/traffic.json", "w"), indent=1)
 print(json.dumps({k: traffic[k] for k in ("per_step", "git_rev", "k_fused_lean", "k_emit_fused") if k in traffic}, indent=1))
 PY
-cp $OUT/trace/spf_kernel_stats.csv $OUT/kernel_stats.csv
-rm -rf $OUT/pmc_*/ ; find $OUT -name "*kernel_trace.csv" -size +2M -delete
+rm -rf $OUT/pmc_*/
