@@ -89,18 +89,63 @@ class SpfGraph:
 
     def __init__(self, ctx: "SpfContext", row_ptr, col, metric, vflags, max_path_metric: int):
         self.ctx = ctx
-        self.row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint32)
-        self.col = np.ascontiguousarray(col, dtype=np.uint32)
-        self.metric = np.ascontiguousarray(metric, dtype=np.uint32)
-        self.vflags = np.ascontiguousarray(vflags, dtype=np.uint8)
-        self.n = len(self.row_ptr) - 1
-        csr = L.HspfCsr(self.n, len(self.col), _u32(self.row_ptr), _u32(self.col), _u32(self.metric),
-                        self.vflags.ctypes.data_as(L.u8p), ctypes.c_uint32(max_path_metric))
+        # numpy mirrors of the caller's CSR (tests and tools read them back; the library keeps its own): patches are
+        # recorded and spliced in when a mirror is next READ (row_ptr / col / metric / vflags are properties)
+        self._rp = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+        self._col = np.ascontiguousarray(col, dtype=np.uint32)
+        self._met = np.ascontiguousarray(metric, dtype=np.uint32)
+        self._vf = np.ascontiguousarray(vflags, dtype=np.uint8)
+        self._pending = []
+        self._own_mirrors = False
+        self.n = len(self._rp) - 1
+        csr = L.HspfCsr(self.n, len(self._col), _u32(self._rp), _u32(self._col), _u32(self._met),
+                        self._vf.ctypes.data_as(L.u8p), ctypes.c_uint32(max_path_metric))
         h = ctypes.c_void_p()
         rc = ctx.lib.hspf_graph_upload(ctx.handle, ctypes.byref(csr), ctypes.byref(h))
         if rc != 0:
             raise HspfError(rc, "hspf_graph_upload", ctx.last_error())
         self.handle = h
+
+    def _flush(self) -> None:
+        for vs, cols, mets, nf in self._pending:
+            lens = self._rp[vs.astype(np.int64) + 1] - self._rp[vs]
+            if np.array_equal(lens, [len(c) for c in cols]):       # same row lengths: the mirrors change in place
+                if not self._own_mirrors:                           # the caller's arrays until now: never written through
+                    self._col, self._met, self._vf = self._col.copy(), self._met.copy(), self._vf.copy()
+                    self._own_mirrors = True
+                for v, c, m in zip(vs.tolist(), cols, mets):
+                    a = int(self._rp[v])
+                    self._col[a:a + len(c)] = c
+                    self._met[a:a + len(m)] = m
+                self._vf[vs] = nf
+            else:
+                self._rp, self._col, self._met, self._vf = splice_rows(self._rp, self._col, self._met, self._vf, vs, cols, mets, nf)
+                self._own_mirrors = True
+        self._pending = []
+
+    @property
+    def row_ptr(self) -> np.ndarray:
+        if self._pending:
+            self._flush()
+        return self._rp
+
+    @property
+    def col(self) -> np.ndarray:
+        if self._pending:
+            self._flush()
+        return self._col
+
+    @property
+    def metric(self) -> np.ndarray:
+        if self._pending:
+            self._flush()
+        return self._met
+
+    @property
+    def vflags(self) -> np.ndarray:
+        if self._pending:
+            self._flush()
+        return self._vf
 
     @property
     def n_edges_kept(self) -> int:
@@ -149,20 +194,8 @@ class SpfGraph:
         self.last_patch_call_ms = (time.perf_counter() - t0) * 1e3     # the C call alone (the numpy mirrors below are this twin's own)
         if rc != 0:
             raise HspfError(rc, "hspf_graph_patch", self.ctx.last_error())
-        lens = self.row_ptr[vs.astype(np.int64) + 1] - self.row_ptr[vs]
-        if np.array_equal(lens, np.diff(rp)):                  # same row lengths: the mirrors change in place
-            if not getattr(self, "_own_mirrors", False):       # the caller's arrays until now: never written through
-                self.col, self.metric, self.vflags = self.col.copy(), self.metric.copy(), self.vflags.copy()
-                self._own_mirrors = True
-            for v, c, m in zip(vs.tolist(), cols, mets):
-                a = int(self.row_ptr[v])
-                self.col[a:a + len(c)] = c
-                self.metric[a:a + len(m)] = m
-            self.vflags[vs] = nf
-            return
-        self.row_ptr, self.col, self.metric, self.vflags = splice_rows(
-            self.row_ptr, self.col, self.metric, self.vflags, vs, cols, mets, nf)
-        self._own_mirrors = True
+        # the numpy mirrors follow when they are next read (copies: the caller may reuse its arrays)
+        self._pending.append((vs, [c.copy() for c in cols], [m_.copy() for m_ in mets], nf.copy()))
 
     def mask_words(self, roots) -> int:
         roots = np.ascontiguousarray(roots, dtype=np.uint32)
