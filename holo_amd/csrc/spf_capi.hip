@@ -151,7 +151,7 @@ struct hspf_ctx {
   uint32_t last_diff_count = 0;                     // changed pairs of the last hspf_routes_diff_device (hspf_routes_diff_count)
   DevBuf gb, gb_delta, gb_hub, giant_part;                      // graph build scratch, patch delta, hub-mode sort buffers
   uint32_t hub_deg = HUB_DEG;                       // HSPF_HUB_DEG env: rows with more links than this -> graph build from sorted keys
-  uint64_t tw_host_max = 2000000;                   // HSPF_TW_HOST_MAX env: row entries a structural patch may scan to keep the two-way mirror itself
+  uint64_t tw_host_max = UINT64_MAX;                // HSPF_TW_HOST_MAX env: row entries a structural patch may scan to keep the two-way mirror itself (unset: max(4096, links / 32))
   BuildInfo *h_info = nullptr;     // pinned
   int *h_changed = nullptr;        // pinned, h_changed_cap ints: per-sweep "something changed" flags of a phase
   size_t h_changed_cap = 0;
@@ -947,7 +947,10 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
     for (uint32_t k = g->row_ptr[v]; k < g->row_ptr[v + 1]; ++k) { const uint32_t t = g->col[k]; tw_work += g->row_ptr[t + 1] - g->row_ptr[t] + 1u; }
   }
   tw_work += 2ull * de;                                       // rows of replaced targets are read at their new length
-  const bool tw_host = tw_work <= ctx->tw_host_max && g->twoway.size() == e_old;
+  // (a scanned entry costs ~5 ns, a byte of flags over the bus ~0.1 ns + a fixed ~20 us: the patch keeps the flags itself
+  // while that is the cheaper side — every ordinary LSP; a replaced hub row of 100 000 links is not)
+  const uint64_t tw_bound = ctx->tw_host_max == UINT64_MAX ? std::max<uint64_t>(4096u, e_new / 32u) : ctx->tw_host_max;
+  const bool tw_host = tw_work <= tw_bound && g->twoway.size() == e_old;
   // In place: the runs of unchanged rows between two replaced ones move by the length changes in front of them — the runs
   // that move towards the front first, front to back, then those that move towards the back, back to front (a run's new
   // place never reaches into a run that has not moved yet: the order of the runs is the same before and after) — then the
@@ -1351,7 +1354,6 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   const uint32_t net_nh = (run_flags & HSPF_RUN_NET_NEXTHOPS) ? 1u : 0u;
 
   // ---- upload roots / slot tables / descriptor (one pinned block, one copy), init state
-  bool same_block = false;          // this run's block is byte for byte the previous run's (same roots, tables, graph arrays)
   {
     uint32_t *h = ctx->h_up + (ctx->h_up_sel ? ctx->h_up_cap / 8 : 0);
     const uint32_t *prev = ctx->h_up + (ctx->h_up_sel ? 0 : ctx->h_up_cap / 8);
@@ -1369,7 +1371,6 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     // 14 keeps it).  Otherwise the halves swap: the block just built becomes the reference.
     st.dbg[2] = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_entry).count();
     const bool same = ctx->up_valid && ctx->up_len == up_bytes && !(ctx->variant & 16384u) && memcmp(h, prev, up_bytes) == 0;
-    same_block = same;
     if (!same) {
       HIPCHK(ctx, hipMemcpyAsync(d_up, h, up_bytes, hipMemcpyHostToDevice, s));
       ctx->up_valid = true; ctx->up_len = up_bytes; ctx->h_up_sel ^= 1;
@@ -1510,7 +1511,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       spec_done = false;
       spec_fill = nullptr;
       if (!(ctx->variant & (2048u | 2097152u)))                  // HSPF_VARIANT bit11: no prefill at all; bit21: only after the run, as before
-        spec_fill = [&, esz, ns, fillw, rows](uint32_t last_sweep) {
+        spec_fill = [&, esz, fillw, rows](uint32_t last_sweep) {
           const uint32_t nz = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
           // (the emit in front of this launch has reset the state slab under the same guard: stamps, flags and counters are left)
           hipLaunchKernelGGL(k_init_fill, dim3(emit_reset ? 256 : 2048), dim3(256), 0, s, (uint4 *)d_st, emit_reset ? (size_t)0 : rows * esz / 16, fillw, d_stamp, (size_t)B * n,
@@ -2222,7 +2223,6 @@ static int routes_device_impl(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roo
   // main arrays are exactly what its previous call on this context passed (same pointers, same sizes, contents untouched):
   // the checks and the three pageable copies — most of the call at 120 000 prefixes — are skipped.  Anything that does not
   // match what was recorded then takes the full path.  Ordered tables (origins, initial state) always do.
-  const size_t np1 = (size_t)t->n_prefixes + 1, ne_ = t->n_entries;
   const bool resident = (t->flags & HSPF_PFX_RESIDENT) && !ordered && ctx->pf_shadow_ok && ctx->pf_shadow_nv == n_vertices &&
                         ctx->pf_res_np == t->n_prefixes && ctx->pf_res_ne == t->n_entries && ctx->pf_res_ptr == (const void *)t->pfx_ptr &&
                         ctx->pf_res_vtx == (const void *)t->pfx_vertex && ctx->pf_res_met == (const void *)t->pfx_metric;

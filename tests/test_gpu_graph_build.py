@@ -308,6 +308,36 @@ def test_structural_patch_keeps_the_host_side_current(spf_ctx):
         G.free()
 
 
+def test_structural_patch_of_a_hub_row_fetches_the_two_way_flags(spf_ctx):
+    """Replacing a row with thousands of links (a LAN's pseudonode losing half of its members, then getting them back) is
+    beyond what the patch scans on the host to keep its two-way mirror (HSPF_TW_HOST_MAX: max(4096, links / 32) row entries):
+    the flags come back from the device, as after an upload — same arrays as a fresh upload either way."""
+    g = synth.random_lsdb(3000, 1, 2.0, 515, lan_size=2500, metric_hi=4)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        lan = 0
+        a, b = int(g.row_ptr[lan]), int(g.row_ptr[lan + 1])
+        assert b - a >= 2000
+        full = (g.col[a:b].copy(), g.metric[a:b].copy())
+        for tag, row in (("half", (full[0][::2].copy(), full[1][::2].copy())), ("back", full)):
+            G.patch([lan], [row], [g.vflags[lan]])
+            F = spf_ctx.upload(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
+            try:
+                for name in BUILT + RAW + DERIVED + ("host_row_ptr", "host_col"):
+                    if name == "units":
+                        continue
+                    assert np.array_equal(G.export(name), F.export(name)), (tag, name)
+            finally:
+                F.free()
+        g2 = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
+        members = set(full[0].tolist())
+        roots = np.array([v for v in range(1, g.n) if v not in members][:40], np.uint32)     # (a member has 2 500 first-hop slots: over the limit)
+        assert len(roots) == 40
+        check_spf(spf_ctx, G, g2, roots, E.RUN_NET_NEXTHOPS)
+    finally:
+        G.free()
+
+
 def cost_rows(g, rng, k, lo, hi):
     """k rows with the same targets, order and flags and new costs in [lo, hi] (links into a network keep theirs
     with probability 1/2, so ties and zero costs stay around)."""
