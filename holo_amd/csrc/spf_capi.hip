@@ -150,6 +150,7 @@ struct hspf_ctx {
   DevBuf pack;                                      // record stream of hspf_routes_pack
   uint32_t last_diff_count = 0;                     // changed pairs of the last hspf_routes_diff_device (hspf_routes_diff_count)
   DevBuf gb, gb_delta, gb_hub, giant_part;                      // graph build scratch, patch delta, hub-mode sort buffers
+  DevBuf leaf_jobs;                                             // run_classes: the rows derived for leaf roots (LeafRootJob)
   uint32_t hub_deg = HUB_DEG;                       // HSPF_HUB_DEG env: rows with more links than this -> graph build from sorted keys
   uint64_t tw_host_max = UINT64_MAX;                // HSPF_TW_HOST_MAX env: row entries a structural patch may scan to keep the two-way mirror itself (unset: max(4096, links / 32))
   BuildInfo *h_info = nullptr;     // pinned
@@ -648,7 +649,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->kcnt, &ctx->pack, &ctx->swcnt})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt})
     release(*b);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
@@ -1969,20 +1970,65 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
       cnt[cls[r]]++;
     }
   }
+  // LEAF ROOTS: a root whose only kept link leads to a router that is a root of the same call (a single-homed host next to
+  // its switch, a stub router next to its neighbour: "every neighbour of this router" root sets hold many) needs no run of
+  // its own — its rows are its neighbour's, one link further (k_leaf_root_rows, where the rule is spelled out).  Class 3;
+  // configs[4]: 50 of the 101 roots.  Not on hop-count-like graphs, not when sums may saturate (max-path metric
+  // 0xFFFFFFFF: the sweep kernels send such roots to the sequential kernel), not behind an overloaded or non-expandable
+  // neighbour (its tree as a root is not its tree as a transit hop).  HSPF_VARIANT bit 23: off (A/B).
+  std::vector<LeafRootJob> leaf_jobs;
+  if (!(ctx->variant & 8388608u) && !g->hopcount_like && g->max_path_metric != HSPF_DIST_INF && g->twoway.size() == g->e) {
+    std::vector<std::pair<uint32_t, uint32_t>> where;          // (vertex, first index among the roots)
+    where.reserve(n_roots);
+    for (uint32_t i = 0; i < n_roots; ++i) if (roots[i] != HSPF_NO_ROOT) where.emplace_back(roots[i], i);
+    std::sort(where.begin(), where.end());
+    auto row_of = [&](uint32_t vtx) -> int64_t {
+      auto it = std::lower_bound(where.begin(), where.end(), std::make_pair(vtx, 0u));
+      return it != where.end() && it->first == vtx ? (int64_t)it->second : -1;
+    };
+    std::vector<int64_t> parent_row(n_roots, -1);
+    std::vector<uint32_t> link_of(n_roots, 0);
+    for (uint32_t i = 0; i < n_roots; ++i) {
+      const uint32_t h = roots[i];
+      if (h == HSPF_NO_ROOT || (g->vflags[h] & (HSPF_VF_NETWORK | HSPF_VF_NO_EXPAND))) continue;
+      uint32_t kept = 0, link = 0;
+      for (uint32_t k = g->row_ptr[h]; k < g->row_ptr[h + 1] && kept < 2u; ++k) if (g->twoway[k]) { ++kept; link = k; }
+      if (kept != 1u) continue;
+      const uint32_t pv = g->col[link];
+      if (pv == h || (g->vflags[pv] & (HSPF_VF_NETWORK | HSPF_VF_NO_TRANSIT | HSPF_VF_NO_EXPAND))) continue;
+      if (g->row_ptr[pv + 1] - g->row_ptr[pv] > 65536u) continue;   // (the scan below; such a neighbour's leaves take the ordinary path)
+      uint32_t back = 0;                                             // p's links to h: exactly one (two would be two kept in-links)
+      for (uint32_t k = g->row_ptr[pv]; k < g->row_ptr[pv + 1]; ++k) back += g->col[k] == h ? 1u : 0u;
+      if (back != 1u) continue;
+      const int64_t pr = row_of(pv);
+      if (pr < 0) continue;
+      parent_row[i] = pr; link_of[i] = link;
+    }
+    for (uint32_t i = 0; i < n_roots; ++i) {
+      if (parent_row[i] < 0 || parent_row[(size_t)parent_row[i]] >= 0) continue;    // (two leaves facing each other: both run)
+      leaf_jobs.push_back(LeafRootJob{roots[i], (uint32_t)parent_row[i], i, link_of[i], link_of[i] - g->row_ptr[roots[i]]});
+      cnt[cls[i]]--;
+      cls[i] = 3;
+    }
+  }
+  const uint32_t n_run = n_roots - (uint32_t)leaf_jobs.size();
   const bool fused_ok = n < (1u << 23) && !(ctx->variant & 1u);
   // off the two-phase path with everybody who does not need it, when that saves at least one 64-root batch there (a
   // two-phase batch moves 8W-byte mask rows and costs several fused ones)
-  const bool split2 = fused_ok && cnt[2] > 0 && cnt[0] + cnt[1] > 0 && (cnt[2] + 63) / 64 < (n_roots + 63) / 64;
+  const bool split2 = fused_ok && cnt[2] > 0 && cnt[0] + cnt[1] > 0 && (cnt[2] + 63) / 64 < (n_run + 63) / 64;
   const bool split1 = fused_ok && m_narrow > 0 && cnt[1] > 0 && cnt[0] >= 256;  // keep the narrow ones narrow
-  if ((cnt[2] > 0 && !split2) || (!split1 && !split2))        // one run as before (two-phase for all / fused for all)
-    return run_impl(ctx, g, roots, n_roots, run_flags, out, host_out);
-  if (!split1) for (auto &c : cls) if (c == 1) c = 0;           // classes 0 and 1 share one fused run
+  if ((cnt[2] > 0 && !split2) || (!split1 && !split2)) {       // one run as before (two-phase for all / fused for all)
+    if (leaf_jobs.empty()) return run_impl(ctx, g, roots, n_roots, run_flags, out, host_out);
+    for (auto &c : cls) if (c != 3) c = 0;                      // ... of the roots that are not derived
+  } else if (!split1) {
+    for (auto &c : cls) if (c == 1) c = 0;                      // classes 0 and 1 share one fused run
+  }
   // class order, stable inside a class
-  std::vector<uint32_t> proots(n_roots), dest(n_roots);
+  std::vector<uint32_t> proots(n_run), dest(n_run);
   uint32_t start[4] = {0, 0, 0, 0};
-  { uint32_t c0 = 0, c1 = 0, c2 = 0; for (auto c : cls) (c == 0 ? c0 : c == 1 ? c1 : c2)++; start[1] = c0; start[2] = c0 + c1; start[3] = n_roots; }
+  { uint32_t c0 = 0, c1 = 0; for (auto c : cls) { c0 += c == 0; c1 += c == 1; } start[1] = c0; start[2] = c0 + c1; start[3] = n_run; }
   { uint32_t pos[3] = {start[0], start[1], start[2]};
-    for (uint32_t r = 0; r < n_roots; ++r) { const uint32_t i = pos[cls[r]]++; proots[i] = roots[r]; dest[i] = r; } }
+    for (uint32_t r = 0; r < n_roots; ++r) { if (cls[r] == 3) continue; const uint32_t i = pos[cls[r]]++; proots[i] = roots[r]; dest[i] = r; } }
   const size_t rn = (size_t)n_roots * n;
   const bool want_mask = out->first_hop_mask != nullptr, want_rank = (run_flags & HSPF_RUN_POP_RANK) && out->pop_rank;
   if (want_mask && out->n_mask_words == 0) return HSPF_E_INVAL;
@@ -2039,6 +2085,17 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     acc.dbg[2] += p.dbg[2]; acc.dbg[3] += p.dbg[3];
   }
   if (rc_first) return rc_first;
+  if (!leaf_jobs.empty()) {                                      // the leaf roots' rows, from their neighbours' finished ones
+    (void)hipSetDevice(ctx->device);
+    if ((rc = ensure(ctx, ctx->leaf_jobs, leaf_jobs.size() * sizeof(LeafRootJob), false))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->leaf_jobs.p, leaf_jobs.data(), leaf_jobs.size() * sizeof(LeafRootJob), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_leaf_root_rows, dim3((n + 255u) / 256u, (uint32_t)leaf_jobs.size()), dim3(256), 0, s, n,
+                       (const LeafRootJob *)ctx->leaf_jobs.p, (const uint32_t *)g->d_metric[g->cur], g->max_path_metric, W, U.dist, U.hops,
+                       U.vflags_out, U.first_hop_mask);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(s));                         // (the pageable job list; and a run returns when its results are there)
+    acc.n_roots += (uint32_t)leaf_jobs.size();
+  }
   if (side_by_side) {                                            // what the classes took together, not their sum
     const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_cls).count();
     if (wall < acc.ms_total) {

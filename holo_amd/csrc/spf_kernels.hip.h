@@ -2006,6 +2006,33 @@ __global__ __launch_bounds__(256) void k_init_fused(GraphDev g, ST *st, uint32_t
   }
 }
 
+// Rows of LEAF ROOTS (run_classes, spf_capi.hip): a root h whose only kept link leads to a router p that is a root of the
+// same call has p's tree behind that one link — every path from h starts h -> p, and h is on no path of p's tree but its
+// own: distance + cost of the link (beyond the max-path metric: not reached, as the reference prunes the relaxation that
+// would exceed it: holo-isis/src/spf.rs:640-646), hops + 1 (p is a router; u16 saturating), ONE first-hop slot — the link's
+// position in h's row — for every vertex reached, and (0, 0, no next hop) for h itself.  Reads p's finished row of the
+// caller's tables, writes h's: no fixed point.  grid = (ceil(n / 256), jobs).
+struct LeafRootJob { uint32_t h, p_row, h_row, link, fpos; };
+__global__ __launch_bounds__(256) void k_leaf_root_rows(uint32_t n, const LeafRootJob *__restrict__ jobs, const uint32_t *__restrict__ metric_raw,
+                                                        uint32_t maxpath, uint32_t W, uint32_t *dist, uint16_t *hops, uint16_t *flags,
+                                                        uint64_t *mask) {
+  const LeafRootJob j = jobs[blockIdx.y];
+  const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+  if (v >= n) return;
+  const uint32_t w = metric_raw[j.link];
+  const size_t pi = (size_t)j.p_row * n + v, hi = (size_t)j.h_row * n + v;
+  const uint32_t pd = dist[pi];
+  const uint64_t sum = (uint64_t)pd + w;
+  const bool self = v == j.h;
+  const bool reach = self || (pd != INF && sum <= (uint64_t)maxpath);
+  dist[hi] = self ? 0u : (reach ? (uint32_t)sum : INF);
+  if (hops) hops[hi] = (self || !reach) ? (uint16_t)0 : (uint16_t)min((uint32_t)hops[pi] + 1u, 0xFFFFu);
+  if (flags) flags[hi] = self ? (uint16_t)1 : (reach ? (uint16_t)(flags[pi] | 1u) : (uint16_t)0);
+  if (mask)
+    for (uint32_t q = 0; q < W; ++q)
+      mask[hi * W + q] = (!self && reach && (j.fpos >> 6) == q) ? (1ull << (j.fpos & 63u)) : 0ull;
+}
+
 __global__ void k_clear_lane_flag(uint32_t *lane_flags, uint32_t n_lf, uint32_t bit) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_lf) lane_flags[i] &= ~bit;

@@ -302,7 +302,9 @@ int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out);
  * The lanes are also where a SYNCHRONOUS run of more than 64 roots goes when its roots fall into different state classes
  * (a few roots with many first-hop slots among many with few: each class is a run of its own): all classes but one are
  * handed to lanes and run side by side (fat-tree k=100, 51 switch roots + 50 host roots: 1.69 ms instead of 2.01).  The
- * lanes are created by the first call that needs them (~15 ms once per context).
+ * lanes are created by the first call that needs them (~15 ms once per context).  In the same calls a LEAF root — a router
+ * whose only two-way link leads to a router that is a root of the same call — is not run at all: its rows are its
+ * neighbour's, one link further (distance + link cost up to the max-path metric, hops + 1, its one first-hop slot).
  */
 int hspf_run_device_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots,
                           uint32_t run_flags, const hspf_result *out_device, uint64_t *ticket);

@@ -796,3 +796,56 @@ def test_lean_plan_first_run_and_repeated_runs(spf_ctx, shape):
         assert stamped_only or pl["used"] >= 1                                                  # other roots: the same plan, decided on the device again
     finally:
         G.free()
+
+
+# ---- leaf roots: rows derived from the neighbour's (run_classes / k_leaf_root_rows) ------------------------------------
+
+def _caterpillar(seed):
+    """A ring of routers with chords, each with stub routers hanging off it: single-homed stubs (leaves), a stub of a stub,
+    a stub on two parallel links, a stub behind an overloaded router, a stub whose neighbour does not list it back, a stub
+    on a tight max-path metric — every vertex is a root."""
+    rng = np.random.default_rng(seed)
+    ring = 30
+    links = []                                                   # (u, v, cost u->v, cost v->u); None = one-way
+    for i in range(ring):
+        links.append((i, (i + 1) % ring, int(rng.integers(1, 9)), int(rng.integers(1, 9))))
+    for _ in range(12):
+        a, b = rng.choice(ring, 2, replace=False)
+        links.append((int(a), int(b), int(rng.integers(1, 9)), int(rng.integers(1, 9))))
+    n = ring
+    stubs = []
+    for i in range(ring):
+        for _ in range(int(rng.integers(1, 4))):
+            links.append((i, n, int(rng.integers(1, 9)), int(rng.integers(1, 9)))); stubs.append(n); n += 1
+    links.append((stubs[0], n, 3, 2)); n += 1                    # a stub of a stub (its neighbour is no leaf: two kept links)
+    links.append((1, n, 2, 2)); links.append((1, n, 5, 5)); n += 1   # two parallel links: not a leaf
+    links.append((2, n, 4, None)); n += 1                        # the ring router does not list it back: one-way, tree = itself
+    rows = [[] for _ in range(n)]
+    for u, v, cuv, cvu in links:
+        if cuv is not None: rows[u].append((v, cuv))
+        if cvu is not None: rows[v].append((u, cvu))
+    for r in rows:
+        rng.shuffle(r)
+    row_ptr = np.zeros(n + 1, np.uint32); row_ptr[1:] = np.cumsum([len(r) for r in rows])
+    col = np.array([t for r in rows for t, _ in r], np.uint32); met = np.array([c for r in rows for _, c in r], np.uint32)
+    vflags = np.zeros(n, np.uint8)
+    vflags[3] |= synth.VF_NO_TRANSIT                            # stubs behind an overloaded router are not derived
+    vflags[stubs[5]] |= synth.VF_NO_TRANSIT                      # an overloaded stub is still the root of its own tree
+    return synth.CsrGraph(row_ptr, col, met, vflags, synth.MAX_PATH_METRIC_WIDE, "caterpillar", {})
+
+
+@both_engines
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("run_flags", [0, E.RUN_NET_NEXTHOPS | E.RUN_IGNORE_OVERLOAD])
+def test_leaf_roots_derived_from_their_neighbour(spf_ctx, seed, run_flags):
+    """Every vertex as a root (> 64 roots: the call goes through run_classes): the rows of single-homed stubs come from their
+    neighbour's rows, everything else runs — all equal to the oracle's, also with a max-path metric that cuts the stubs'
+    trees short of their neighbours'."""
+    g = _caterpillar(seed)
+    roots = np.arange(g.n, dtype=np.uint32)
+    np.random.default_rng(seed).shuffle(roots)
+    res, _ = check(spf_ctx, g, roots, run_flags)
+    assert res.stats["n_roots"] == g.n
+    assert res.stats["n_batches"] <= 1 + (g.n - 40) // 64        # the stubs (more than half of the vertices) took no batch
+    g2 = synth.CsrGraph(g.row_ptr, g.col, g.metric, g.vflags, 14, g.name, g.meta)    # trees cut at distance 14
+    check(spf_ctx, g2, roots, run_flags)
