@@ -2086,6 +2086,7 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
   }
   if (rc_first) return rc_first;
   if (!leaf_jobs.empty()) {                                      // the leaf roots' rows, from their neighbours' finished ones
+    const auto t_leaf = std::chrono::steady_clock::now();
     (void)hipSetDevice(ctx->device);
     if ((rc = ensure(ctx, ctx->leaf_jobs, leaf_jobs.size() * sizeof(LeafRootJob), false))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->leaf_jobs.p, leaf_jobs.data(), leaf_jobs.size() * sizeof(LeafRootJob), hipMemcpyHostToDevice, s));
@@ -2095,6 +2096,8 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(s));                         // (the pageable job list; and a run returns when its results are there)
     acc.n_roots += (uint32_t)leaf_jobs.size();
+    const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_leaf).count();
+    acc.ms_total += ms; acc.ms_finish += ms;                       // (host clock: copy of the job list, the launch, the wait)
   }
   if (side_by_side) {                                            // what the classes took together, not their sum
     const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_cls).count();
