@@ -1569,14 +1569,26 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         if (use_lean) {
 #define HSPF_LAUNCH_LEAN(CN_, MD_, HD_, grid_, pb_, base_, thr_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, HD_>), grid_, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, d_ctl, pb_, B, base_, thr_)
 #define HSPF_LAUNCH_LEAN_C(MD_, HD_, grid_, pb_, base_, thr_) do { if (count_rows) HSPF_LAUNCH_LEAN(true, MD_, HD_, grid_, pb_, base_, thr_); else HSPF_LAUNCH_LEAN(false, MD_, HD_, grid_, pb_, base_, thr_); } while (0)
+          // dense multi-pass launch in batch-major placement (k_fused_lean: bit 31 of pass_batches; pass_blocks = row blocks of one batch)
+#define HSPF_LAUNCH_LEAN_BM(CN_, MD_, HD_, grid_, pb_, base_, thr_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, HD_>), grid_, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, d_ctl, pb_, B | 0x80000000u, base_, thr_)
+#define HSPF_LAUNCH_LEAN_B(MD_, HD_, grid_, pb_, base_, thr_) do { if (count_rows) HSPF_LAUNCH_LEAN_BM(true, MD_, HD_, grid_, pb_, base_, thr_); else HSPF_LAUNCH_LEAN_BM(false, MD_, HD_, grid_, pb_, base_, thr_); } while (0)
+          // at least 8 batches: each XCD takes whole batches (their state stays in its L2 across the passes); HSPF_VARIANT bit 24: off (A/B)
+          const uint32_t bm_blocks = (n + (uint32_t)FVPB - 1u) / (uint32_t)FVPB;
+          const bool bmaj = B >= 8u && !(ctx->variant & 16777216u) && 8ull * ((B + 7u) / 8u) * bm_blocks * per_launch < (1ull << 31);
+          const dim3 bgrid(8u * ((B + 7u) / 8u) * bm_blocks);        // one pass over all batches, batch-major
+          // (the stamped sweeps keep the row-major placement: in batch-major form they were slower — 4.48 against 4.33 ms for the
+          // ten areas of configs[3], profiles/r04_notes.md r04y)
           if (sweep < plan_h) HSPF_LAUNCH_LEAN_C(0, true, fgrid, 0u, 0u, thr_enter);
           else if (sweep < plan_h + plan_nd) {
             const uint32_t base = (sweep - plan_h) * per_launch, np = std::min(per_launch, plan_P - base);
-            if (np > 1u) HSPF_LAUNCH_LEAN_C(1, false, dim3(fgrid.x * B * np), fgrid.x, base, thr_stay);
-            else         HSPF_LAUNCH_LEAN_C(1, false, fgrid, 0u, base, thr_stay);
+            if (bmaj)         HSPF_LAUNCH_LEAN_B(1, false, dim3(bgrid.x * np), bm_blocks, base, thr_stay);
+            else if (np > 1u) HSPF_LAUNCH_LEAN_C(1, false, dim3(fgrid.x * B * np), fgrid.x, base, thr_stay);
+            else              HSPF_LAUNCH_LEAN_C(1, false, fgrid, 0u, base, thr_stay);
           } else if (plan_on && sweep == plan_h + plan_nd) HSPF_LAUNCH_LEAN_C(2, false, fgrid, 0u, 0u, 0u);
           else HSPF_LAUNCH_LEAN_C(0, false, fgrid, 0u, 0u, 0u);
 #undef HSPF_LAUNCH_LEAN_C
+#undef HSPF_LAUNCH_LEAN_B
+#undef HSPF_LAUNCH_LEAN_BM
 #undef HSPF_LAUNCH_LEAN
           return;
         }
