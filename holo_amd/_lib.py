@@ -9,7 +9,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libholo_spf_hip.so")
+LIB_PATH = os.environ.get("HSPF_LIB") or os.path.join(HERE, "libholo_spf_hip.so")     # HSPF_LIB: another build of the library (A/B measurements)
 
 u8p = ctypes.POINTER(ctypes.c_uint8)
 u16p = ctypes.POINTER(ctypes.c_uint16)

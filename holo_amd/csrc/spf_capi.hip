@@ -1569,8 +1569,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         if (use_lean) {
 #define HSPF_LAUNCH_LEAN(CN_, MD_, HD_, grid_, pb_, base_, thr_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, HD_>), grid_, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, d_ctl, pb_, B, base_, thr_)
 #define HSPF_LAUNCH_LEAN_C(MD_, HD_, grid_, pb_, base_, thr_) do { if (count_rows) HSPF_LAUNCH_LEAN(true, MD_, HD_, grid_, pb_, base_, thr_); else HSPF_LAUNCH_LEAN(false, MD_, HD_, grid_, pb_, base_, thr_); } while (0)
-          // dense multi-pass launch in batch-major placement (k_fused_lean: bit 31 of pass_batches; pass_blocks = row blocks of one batch)
-#define HSPF_LAUNCH_LEAN_BM(CN_, MD_, HD_, grid_, pb_, base_, thr_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, HD_>), grid_, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, d_ctl, pb_, B | 0x80000000u, base_, thr_)
+          // dense launch in batch-major placement (k_fused_lean<.., BMAJ>; pass_blocks = row blocks of one batch)
+#define HSPF_LAUNCH_LEAN_BM(CN_, MD_, HD_, grid_, pb_, base_, thr_) hipLaunchKernelGGL((k_fused_lean<CN_, MD_, HD_, true>), grid_, dim3(256), 0, s, d_fg, d_changed, (int)sweep, d_stamp, (const uint8_t *)ctx->hnb.p, n, (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (uint32_t *)d_st, (const uint32_t *)g->d_ell_od, d_roots, d_lf, net_nh, ignore_ovl, P, d_ctl, pb_, B, base_, thr_)
 #define HSPF_LAUNCH_LEAN_B(MD_, HD_, grid_, pb_, base_, thr_) do { if (count_rows) HSPF_LAUNCH_LEAN_BM(true, MD_, HD_, grid_, pb_, base_, thr_); else HSPF_LAUNCH_LEAN_BM(false, MD_, HD_, grid_, pb_, base_, thr_); } while (0)
           // at least 8 batches: each XCD takes whole batches (their state stays in its L2 across the passes); HSPF_VARIANT bit 24: off (A/B)
           const uint32_t bm_blocks = (n + (uint32_t)FVPB - 1u) / (uint32_t)FVPB;

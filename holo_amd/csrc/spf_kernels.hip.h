@@ -1313,7 +1313,7 @@ constexpr uint32_t LEAN_CTL_STRIDE = 32u;
 constexpr uint32_t LEAN_CTL_DUE = 0u, LEAN_CTL_PCH = 64u * LEAN_CTL_STRIDE, LEAN_CTL_WORDS = 128u * LEAN_CTL_STRIDE;   // 64 head sweeps, 64 dense passes
 constexpr uint32_t LEAN_SAMPLE = 32u;                                             // wave 0 of every 8th block of an XCD's range counts
 constexpr uint32_t LEAN_SENTINEL = 0xFFFFFFFFu;
-template <bool COUNT, int MODE, bool HEAD>
+template <bool COUNT, int MODE, bool HEAD, bool BMAJ = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fused_lean(
     const FusedGraph *__restrict__ gp, int *changed, int sweep, uint32_t *__restrict__ act,
     const uint8_t *__restrict__ hnb, uint32_t n_arg, const uint32_t *__restrict__ ell_so, const uint32_t *__restrict__ ell_w,
@@ -1335,25 +1335,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
   // sweeps (a dense sweep keeps ~76 % of the wave slots busy: ramp and drain) — and reads what that pass has written
   // except in the rows still in flight; any interleaving is a valid chaotic iteration of the same monotone fixed point,
   // and the run's end is decided by stamped sweeps behind the stretch.  pass_blocks = G (0: one pass, 2-D grid), pass_batches = B.
-  // BATCH-MAJOR placement (bit 31 of pass_batches; multi-pass launches of calls with at least 8 batches): consecutive
+  // BATCH-MAJOR placement (template BMAJ; dense launches of calls with at least 8 batches): consecutive
   // workgroups go round-robin to the 8 XCDs, so block f of a pass belongs to XCD f % 8 — which then owns the batches
   // x, x + 8, ... whole (all their rows, pass after pass) instead of an eighth of the rows of every batch: the state of a batch
   // of a 5 000-router area is 1.3 MB, two of them and the link records stay in the XCD's 4 MB L2 for the whole stretch,
   // and every neighbour row a wave reads was written on its own XCD (no stale line of another L2 in the way of the pass
   // order).  pass_blocks = row blocks of ONE batch in this form.  Speed only: any placement gives the same result.
-  // (pass_blocks != 0: a 1-D grid — the multi-pass dense launches, and EVERY launch of a run in batch-major placement, so
-  // that a batch stays on its XCD from the head sweeps to the tail)
-  const bool lin = pass_blocks != 0u;
-  const bool bmaj = lin && (pass_batches & 0x80000000u) != 0u;
-  const uint32_t nbat = pass_batches & 0x7FFFFFFFu;
-  const uint32_t per_pass = lin ? (bmaj ? 8u * ((nbat + 7u) >> 3) * pass_blocks : pass_blocks * nbat) : 1u;      // blocks of one pass
-  const uint32_t fpass = lin ? blockIdx.x % per_pass : 0u;
-  const uint32_t batch = bmaj ? (fpass & 7u) + 8u * ((fpass >> 3) / pass_blocks) : (lin ? (blockIdx.x / pass_blocks) % nbat : blockIdx.y);
+  // (BMAJ: its own instantiation — the index arithmetic of both forms in one kernel cost the one-batch headline 3-4 %)
+  const bool bmaj = BMAJ && MODE == 1;
+  const uint32_t nbat = pass_batches;
+  const uint32_t per_pass = bmaj ? 8u * ((nbat + 7u) >> 3) * pass_blocks : pass_blocks * nbat;      // blocks of one pass
+  const uint32_t fpass = bmaj ? blockIdx.x % per_pass : 0u;
+  const uint32_t batch = bmaj ? (fpass & 7u) + 8u * ((fpass >> 3) / pass_blocks)
+                              : ((MODE == 1 && pass_blocks != 0u) ? (blockIdx.x / pass_blocks) % pass_batches : blockIdx.y);
   const uint32_t n = n_arg;
-  const uint32_t bx = bmaj ? (fpass >> 3) % pass_blocks : (lin ? blockIdx.x % pass_blocks : blockIdx.x);
+  const uint32_t bx = bmaj ? (fpass >> 3) % pass_blocks : ((MODE == 1 && pass_blocks != 0u) ? blockIdx.x % pass_blocks : blockIdx.x);
   // dense pass p of the stretch (counted across its launches): nothing to do when pass p - 2 or p - 3 saw the corrections
   // thin out (their counters: plain loads, one line each, see LEAN_CTL_STRIDE)
-  const uint32_t pg = MODE == 1 ? pass_base + (lin ? blockIdx.x / per_pass : 0u) : 0u;
+  const uint32_t pg = MODE == 1 ? pass_base + (pass_blocks != 0u ? blockIdx.x / per_pass : 0u) : 0u;
   uint32_t pc2 = LEAN_SENTINEL, pc3 = LEAN_SENTINEL;
   if (MODE == 1 && thr != 0u && pg >= 2u && pg < 64u) {                 // thr = 0 (HSPF_DENSE_STAY_PCT=0): every planned pass runs
     pc2 = ctl[LEAN_CTL_PCH + (pg - 2u) * LEAN_CTL_STRIDE];
@@ -1365,7 +1364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
     if (bx == 0u && batch == 0u && threadIdx.x == 0) changed[sweep] = 1;
     return;
   }
-  if (chunk == 0xFFFFFFFFu || batch >= nbat) return;
+  if (chunk == 0xFFFFFFFFu || (bmaj && batch >= nbat)) return;
   const uint32_t wbeg = chunk * (uint32_t)FVPB + wave * (uint32_t)FVPW;
   if (wbeg >= n) return;
   uint32_t *A = act + (size_t)batch * n;
