@@ -529,14 +529,96 @@ def consumer_64root(dev) -> dict:
     ok_ov = bool(np.array_equal(last["dist"].numpy().view(np.uint32), ref.dist) and np.array_equal(last["hops"].numpy().view(np.uint16), ref.hops)
                  and np.array_equal(last["mask"].numpy().view(np.uint64), ref.mask))
     bytes_per_batch = R * n * (8 + 8 * W)
+    # ---- (c) the PACKED hand-off (ABI 7): the engine's own word per (root, vertex) — 4 bytes here — instead of 16
+    pb = [ctx.host_alloc(8 * R * n) for _ in range(4)]
+    tp = []
+    for it in range(9):
+        t0 = time.perf_counter()
+        pr = ctx.run_packed(G, roots, 0, buffer=pb[0])
+        tp.append((time.perf_counter() - t0) * 1e3)
+    st_p = pr.stats
+    ok_packed = bool(np.array_equal(pr.dist, ref.dist) and np.array_equal(pr.hops, ref.hops) and np.array_equal(pr.first_hop_mask, ref.mask[..., :1])
+                     and np.array_equal(pr.in_spt, (ref.flags & 1) != 0))
+    packed_sync_ms = float(np.median(tp[2:]))
+    word_bytes = pr.word_bytes
+
+    def packed_in_flight(K, depth):
+        hs = []
+        t0 = time.perf_counter()
+        last = None
+        for i in range(K):
+            if len(hs) >= depth:
+                last = ctx.wait_packed(hs.pop(0))
+            hs.append(ctx.run_packed_async(G, roots, 0, pb[i % len(pb)]))
+        while hs:
+            last = ctx.wait_packed(hs.pop(0))
+        return (time.perf_counter() - t0) / K * 1e3, last
+    packed_in_flight(8, 3)
+    pk_ov_ms, last_pr = packed_in_flight(48, 3)
+    ok_packed_ov = bool(np.array_equal(last_pr.dist, ref.dist) and np.array_equal(last_pr.first_hop_mask, ref.mask[..., :1]))
+    pageable = np.zeros(8 * R * n + 4096, np.uint8)[4096:]
+    tq = []
+    for it in range(5):
+        t0 = time.perf_counter()
+        prq = ctx.run_packed(G, roots, 0, buffer=pageable)
+        tq.append((time.perf_counter() - t0) * 1e3)
+    ok_pageable = bool(np.array_equal(prq.words, last_pr.words))
+    t0 = time.perf_counter()
+    _ = (last_pr.dist, last_pr.hops, last_pr.first_hop_mask)
+    decode_all_ms = (time.perf_counter() - t0) * 1e3
+    packed_bytes = R * n * word_bytes
     out["hspf_run_64root_host"] = {"graph": "isis-100k", "roots": R, "bytes_to_host_per_batch": int(bytes_per_batch), "pinned": True,
                                    "hspf_run_wall_ms": round(sync_ms, 4), "hspf_run_device_ms": round(st1["ms_total"], 4), "hspf_run_d2h_ms": round(st1["ms_d2h"], 4),
                                    "hspf_run_runs_per_s": round(R / sync_ms * 1e3),
                                    "overlapped_wall_ms_per_batch": round(ov_ms, 4), "overlapped_runs_per_s": round(R / ov_ms * 1e3),
                                    "overlapped_pcie_GBps": round(bytes_per_batch / ov_ms / 1e6, 1),
                                    "identical_to_oracle": bool(ok_host and ok_ov),
-                                   "note": "PCIe-inclusive: 102 MB of tables per 64-root batch; never the headline `value` (results resident in HBM)"}
+                                   "packed": {"entry": "hspf_run_packed / hspf_run_packed_async + hspf_wait_packed (ABI 7)", "word_bytes": int(word_bytes),
+                                              "bytes_to_host_per_batch": int(packed_bytes),
+                                              "sync_wall_ms": round(packed_sync_ms, 4), "sync_runs_per_s": round(R / packed_sync_ms * 1e3),
+                                              "sync_device_ms": round(st_p["ms_total"], 4), "sync_d2h_ms": round(st_p["ms_d2h"], 4),
+                                              "in_flight_wall_ms_per_batch": round(pk_ov_ms, 4), "in_flight_runs_per_s": round(R / pk_ov_ms * 1e3),
+                                              "in_flight_pcie_GBps": round(packed_bytes / pk_ov_ms / 1e6, 1), "tickets_in_flight": 3,
+                                              "pageable_sync_wall_ms": round(float(np.median(tq[1:])), 4), "pageable_runs_per_s": round(R / float(np.median(tq[1:])) * 1e3),
+                                              "numpy_decode_all_tables_ms": round(decode_all_ms, 2),
+                                              "identical_to_oracle_after_decode": bool(ok_packed and ok_packed_ov and ok_pageable)},
+                                   "note": "PCIe-inclusive: 102 MB of tables per 64-root batch (25.6 MB packed); never the headline `value` (results resident in HBM)"}
+    for b_ in pb:
+        b_.free()
     G.free(); ctx.close()
+    return out
+
+
+def dropin_e2e() -> dict:
+    """What the drop-in costs END TO END, through the compiled C++ host side (include/holo_spf_isis.hpp on HipEngine = the
+    C ABI; tests/cpp/dropin_e2e.cpp, built by __graft_entry__.build()): a synthetic isis-100k LSDB at LSP level ->
+    LSDB->CSR (first and incremental), run + hand-off (packed, and hspf_run's 16 bytes per vertex for comparison), the
+    `Spt` rebuild (holo-isis/src/spf.rs:224-242), compute_routes (:840-949), the persistent device pipeline — next to the
+    SAME host code on the CPU stand-in for the engine (oracle heap loop, the cpu_baseline leg) and the stored figure of the
+    reference-shaped loop.  The RIB of a down-sized twin of this LSDB is compared with oracle/isis_ref.py in
+    tests/test_dropin_e2e.py."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_e2e")
+    if not os.path.exists(exe):
+        return {"error": "tests/cpp/dropin_e2e is not built (__graft_entry__.build())"}
+
+    def run(*args):
+        try:
+            p = subprocess.run([exe, *args], capture_output=True, text=True, timeout=240)
+            if p.returncode != 0:
+                return {"error": f"rc {p.returncode}: {p.stderr.strip()[-300:]}"}
+            return json.loads(p.stdout.strip().splitlines()[-1])
+        except Exception as ex:  # noqa: BLE001
+            return {"error": repr(ex)}
+    out = {"host_side": "C++17 twin of the Rust glue (include/holo_spf_isis.hpp), one core", "lsdb": "isis-100k at LSP level: 100 000 LSPs, 1 000 000 TLV-22 adjacencies, 120 000 prefix entries",
+           "hip": run("--engine", "hip", "--n", "100000", "--reps", "5", "--batch", "16"),
+           "hip_full_tables": run("--engine", "hip", "--n", "100000", "--reps", "3", "--batch", "16", "--no-packed"),
+           "cpu_engine_same_host_code": run("--engine", "oracle", "--n", "100000", "--reps", "2", "--batch", "4")}
+    try:
+        ref = json.load(open(os.path.join(ROOT, "profiles", "r03_cpu_ref_shaped_100k.json")))
+        out["reference_shaped_loop_s_per_run"] = ref.get("seconds")
+    except Exception:  # noqa: BLE001
+        pass
     return out
 
 
@@ -1019,6 +1101,7 @@ def main():
             out.update(consumer_64root(dev))
             out["two_instances"] = two_instances(g, dev)
             out["configs"] = other_configs(ctx1, dev)
+            out["dropin_e2e"] = dropin_e2e()
         print(json.dumps(out), flush=True)
 
     m.free_graph(mg)

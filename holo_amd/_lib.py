@@ -40,6 +40,12 @@ class HspfStats(ctypes.Structure):
                 ("dbg", ctypes.c_uint32 * 4)]
 
 
+class HspfPackedLayout(ctypes.Structure):
+    _fields_ = [("word_bytes", ctypes.c_uint32), ("dist_shift", ctypes.c_uint32), ("hops_shift", ctypes.c_uint32),
+                ("hops_mask", ctypes.c_uint32), ("mask_bits", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("not_reached", ctypes.c_uint64)]
+
+
 class HspfPrefixTable(ctypes.Structure):
     _fields_ = [("n_prefixes", ctypes.c_uint32), ("n_entries", ctypes.c_uint32),
                 ("pfx_ptr", u32p), ("pfx_vertex", u32p), ("pfx_metric", u32p), ("flags", ctypes.c_uint32),
@@ -95,6 +101,16 @@ SYMBOLS = [
     ("hspf_wait_all", ctypes.c_int, [ctypes.c_void_p]),
     ("hspf_async_lanes", ctypes.c_uint32, [ctypes.c_void_p]),
     ("hspf_recommend_cpu", ctypes.c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
+    # packed results (ABI 7)
+    ("hspf_host_alloc", ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    ("hspf_host_free", None, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("hspf_run_packed", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,
+                                       ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(HspfPackedLayout), u8p]),
+    ("hspf_run_packed_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,
+                                              ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(HspfPackedLayout), u8p]),
+    ("hspf_run_packed_async", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.c_void_p, ctypes.c_size_t, u8p, u64p]),
+    ("hspf_wait_packed", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(HspfPackedLayout), ctypes.POINTER(HspfStats)]),
     ("hspf_routes_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.POINTER(HspfPrefixTable), ctypes.POINTER(HspfRoutes)]),
@@ -151,6 +167,10 @@ def load():
         import torch  # noqa: F401
     except Exception:  # noqa: BLE001  (torch is optional for the engine itself)
         pass
+    # Runs in flight on the lanes of a context are HIP streams of their own; the runtime maps streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams sharing one serialise.  It is a property of the PROCESS:
+    # the host sets it (here: this Python host, before HIP initialises), the library does not.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = ctypes.CDLL(LIB_PATH)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported

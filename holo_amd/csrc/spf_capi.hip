@@ -142,6 +142,10 @@ struct hspf_ctx {
   uint32_t lean_max_passes = 48;                     // longest dense stretch a plan may hold
   uint32_t lean_multi_min_wgs = 4096;                // HSPF_DENSE_MIN_WGS: workgroups per pass from which a dense launch carries several passes
   DevBuf o_dist, o_hops, o_flags, o_mask, o_rank;   // device staging of row-major outputs
+  DevBuf o_pack, pk_flag;                            // hspf_run_packed: device staging of the packed words (host destinations); misfit flag of k_pack_full
+  char *h_stage = nullptr;                           // pinned: two blocks through which a copy to pageable host memory is staged (copy_to_host)
+  size_t h_stage_cap = 0;                            // bytes (both blocks)
+  hipEvent_t ev_stage[2] = {};
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
   bool pf_shadow_ok = false;                        // the device holds a plain table; what it was uploaded from (HSPF_PFX_RESIDENT):
@@ -205,6 +209,19 @@ struct hspf_ctx {
   hspf_ctx *parent = nullptr;                       // in a lane's context: the context the caller holds
 };
 
+// hspf_run_packed* (ABI 7): where the packed words of a run go, and what the run reports back.
+struct PackedReq {
+  void *dst = nullptr;              // host or device destination, rows of the whole call
+  size_t cap = 0;                   // bytes
+  bool host = true;
+  uint8_t *root_status = nullptr;   // host, [n_roots of the whole call] or null
+  hspf_packed_layout layout{};      // out
+  // set by the group loop of run_impl (calls of more roots than one pass holds):
+  size_t row_off = 0;               // first row of this group
+  uint32_t min_slots = 0;           // first-hop slots of the whole call: every group uses the same field split
+  bool force_wide = false;          // 8-byte words for every group (a group's layout differed from the first one's)
+};
+
 // One lane of an asynchronous context: a short queue of jobs, the thread that runs them one after the other, the last
 // few results.  (A queue, not a slot: with one slot a lane idles from the end of its run until the caller has woken up,
 // collected the result and handed it the next one — ~10 % of a 0.4 ms run from Python.)
@@ -216,10 +233,11 @@ struct hspf_lane {
   struct Job {
     const hspf_graph *g; std::vector<uint32_t> roots; uint32_t flags; hspf_result out; uint64_t ticket;
     std::vector<uint32_t> dest; uint32_t n_total = 0;   // a class of a larger run (run_classes): output row of each root, rows of the whole run
+    bool packed = false; PackedReq pk;                  // hspf_run_packed_async: the run and its copy to the host
   };
   std::deque<Job> jobs;                // waiting, in ticket order
   bool running = false, quit = false;
-  struct Done { uint64_t ticket = 0; int rc = 0; hspf_stats st{}; std::string err; } done[8];
+  struct Done { uint64_t ticket = 0; int rc = 0; hspf_stats st{}; std::string err; hspf_packed_layout layout{}; } done[8];
   uint64_t last_done = 0;
   bool idle() const { return jobs.empty() && !running; }
 };
@@ -562,10 +580,10 @@ int alloc_arena(hspf_ctx *ctx, hspf_graph *g, uint32_t n, uint32_t cap) {
 // The lanes of an asynchronous context are HIP streams of their own; the HIP runtime maps a process's streams onto
 // GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run one after the other.  Context stream +
 // three lanes + the caller's own stream(s) are more than four: measured 137 k runs/s with the default against 149 k with
-// 6 or 8 queues (bench.py, three steps in flight).  The variable is read when the HIP runtime initialises, so a default is
-// planted when this library is loaded — never over a value the user has set, and without effect when HIP is already up
-// (then: export GPU_MAX_HW_QUEUES=8 before starting the process).
-__attribute__((constructor)) static void hspf_plant_env_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// 6 or 8 queues (bench.py, three steps in flight).  The variable is read when the HIP runtime initialises and belongs to
+// the PROCESS, not to this library: since ABI 7 nothing is set from in here (round 4 planted a default from a library
+// constructor — a process-global side effect inside someone else's daemon).  A host that keeps runs in flight exports
+// GPU_MAX_HW_QUEUES=8 itself before its first HIP call (bench.py and holo_amd/_lib.py do).
 
 extern "C" {
 
@@ -573,7 +591,7 @@ static void lanes_quiesce(hspf_ctx *ctx);
 static void lanes_shutdown(hspf_ctx *ctx);
 static int lanes_ensure(hspf_ctx *ctx);
 static uint64_t lane_submit(hspf_ctx *ctx, hspf_lane::Job &&job);
-static int lane_collect(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats);
+static int lane_collect(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats, hspf_packed_layout *layout = nullptr);
 
 uint32_t hspf_abi_version(void) { return HSPF_ABI_VERSION; }
 
@@ -602,6 +620,7 @@ const char *hspf_strerror(int code) {
     case HSPF_E_NOMEM: return "out of memory";
     case HSPF_E_TOO_MANY_SLOTS: return "too many first-hop slots for n_mask_words";
     case HSPF_E_INTERNAL: return "internal invariant violated";
+    case HSPF_E_NO_PACKED: return "results do not fit packed words";
     default: return "unknown error";
   }
 }
@@ -649,8 +668,10 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag})
     release(*b);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  for (auto &e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
   if (ctx->h_patch) (void)hipHostFree(ctx->h_patch);
@@ -1150,10 +1171,47 @@ int hspf_slot_table(hspf_ctx *ctx, const hspf_graph *g, uint32_t root, uint32_t 
 
 // row_map (host array, may be null): output row of roots[r] inside `out` (device buffers of total_rows rows; only with
 // host_out == false) — used by run_classes to let every class write straight into the caller's row order.
+// Device -> host on the ctx stream.  Page-locked destinations (hspf_host_alloc, hipHostMalloc, hipHostRegister) take ONE
+// asynchronous copy at bus speed, left in flight (the caller synchronises).  Anything else is staged through two
+// page-locked blocks of the context: block k + 1 crosses the bus while the host copies block k out — bounded by one host
+// memcpy (~10 GB/s), which is why the wrappers hand out page-locked result buffers.  Returns with the data in place then.
+constexpr size_t STAGE_BLOCK = 8u << 20;
+static int copy_to_host(hspf_ctx *ctx, void *dst, const void *src_dev, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return HSPF_OK;
+  hipPointerAttribute_t at{};
+  const bool locked = hipPointerGetAttributes(&at, dst) == hipSuccess && at.type == hipMemoryTypeHost;
+  if (!locked) (void)hipGetLastError();                             // (an unregistered pointer is reported as an error)
+  if (locked) { HIPCHK(ctx, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, s)); return HSPF_OK; }
+  if (!ctx->h_stage) {
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_stage, 2 * STAGE_BLOCK, hipHostMallocDefault));
+    ctx->h_stage_cap = 2 * STAGE_BLOCK;
+    for (auto &e : ctx->ev_stage) HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const size_t nb = (bytes + STAGE_BLOCK - 1) / STAGE_BLOCK;
+  auto issue = [&](size_t k) -> hipError_t {
+    const size_t o = k * STAGE_BLOCK, len = std::min(STAGE_BLOCK, bytes - o);
+    hipError_t e = hipMemcpyAsync(ctx->h_stage + (k & 1) * STAGE_BLOCK, (const char *)src_dev + o, len, hipMemcpyDeviceToHost, s);
+    return e != hipSuccess ? e : hipEventRecord(ctx->ev_stage[k & 1], s);
+  };
+  HIPCHK(ctx, issue(0));
+  for (size_t k = 0; k < nb; ++k) {
+    if (k + 1 < nb) HIPCHK(ctx, issue(k + 1));                       // (its block was copied out at the end of the previous turn)
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev_stage[k & 1]));
+    const size_t o = k * STAGE_BLOCK;
+    memcpy((char *)dst + o, ctx->h_stage + (k & 1) * STAGE_BLOCK, std::min(STAGE_BLOCK, bytes - o));
+  }
+  return HSPF_OK;
+}
+
 static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
                     hspf_result *out, bool host_out, const uint32_t *row_map = nullptr, uint32_t total_rows = 0,
-                    bool no_fused = false) {
-  if (!ctx || !g || !roots || !out || n_roots == 0 || !out->dist || (row_map && host_out)) return HSPF_E_INVAL;
+                    bool no_fused = false, PackedReq *pk = nullptr) {
+  // packed results (hspf_run_packed*): `out` is not read; host_out says whether pk->dst is host memory
+  hspf_result pk_none{};
+  if (pk) { out = &pk_none; host_out = pk->host; }
+  if (!ctx || !g || !roots || !out || n_roots == 0 || (!pk && !out->dist) || (row_map && host_out) || (pk && (row_map || !pk->dst))) return HSPF_E_INVAL;
+  if (pk && (run_flags & HSPF_RUN_POP_RANK)) { ctx->last_error = "HSPF_RUN_POP_RANK with packed results"; return HSPF_E_INVAL; }
+  if (pk && no_fused) { ctx->last_error = "packed results: hop counts beyond the hop field of a run with more than 16 first-hop slots"; return HSPF_E_NO_PACKED; }
   if (!row_map) total_rows = n_roots;
   (void)hipSetDevice(ctx->device);
   const uint32_t n = g->n;
@@ -1163,6 +1221,44 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   {
     const uint64_t max_pairs = 1ull << 26;
     uint32_t group = (uint32_t)std::max<uint64_t>(64, (max_pairs / std::max<uint32_t>(n, 1)) / 64 * 64);
+    if (n_roots > group && pk) {
+      // every group must come in ONE layout: the field split is made from the slots of ALL roots (min_slots), and when a
+      // group still comes back with another layout than the first (a 4-byte overflow that only its roots run into, a ragged
+      // last group on the lane = vertex path) the call starts over with 8-byte words for everybody
+      uint32_t all_slots = pk->min_slots;
+      {
+        std::vector<uint32_t> hv, hb;
+        for (uint32_t r = 0; r < n_roots; ++r) {
+          if (roots[r] == HSPF_NO_ROOT) continue;
+          if (roots[r] >= n) { ctx->last_error = "root out of range"; return HSPF_E_INVAL; }
+          uint32_t total = 0;
+          build_slot_table(g, roots[r], hv, hb, total, ctx->mark, next_mark(ctx, n));
+          all_slots = std::max(all_slots, total);
+        }
+      }
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        hspf_stats acc{};
+        bool again = false;
+        hspf_packed_layout first{};
+        for (uint32_t off = 0; off < n_roots && !again; off += group) {
+          const uint32_t nr = std::min(group, n_roots - off);
+          PackedReq part = *pk;
+          part.row_off = pk->row_off + off; part.min_slots = all_slots; part.force_wide = pk->force_wide || attempt == 1;
+          const int rc = run_impl(ctx, g, roots + off, nr, run_flags, nullptr, host_out, nullptr, 0, no_fused, &part);
+          if (rc) return rc;
+          if (off == 0) first = part.layout;
+          else if (memcmp(&first, &part.layout, sizeof(first)) != 0) { again = true; break; }
+          const hspf_stats &p = ctx->stats;
+          acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
+          acc.n_exact_roots += p.n_exact_roots; acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
+          acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_finish += p.ms_finish; acc.ms_d2h += p.ms_d2h;
+          acc.state_bytes = std::max(acc.state_bytes, p.state_bytes); acc.narrow_overflow += p.narrow_overflow; acc.rows_recomputed += p.rows_recomputed;
+        }
+        if (!again) { pk->layout = first; ctx->stats = acc; return HSPF_OK; }
+      }
+      ctx->last_error = "packed results: the groups of the call did not agree on a layout";
+      return HSPF_E_INTERNAL;
+    }
     if (n_roots > group) {
       hspf_stats acc{};
       if (out->first_hop_mask && out->n_mask_words == 0) return HSPF_E_INVAL;
@@ -1220,7 +1316,13 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       tab_ptr[r + 1] = (uint32_t)tab_vtx.size();
     }
   }
-  const bool want_mask = out->first_hop_mask != nullptr;
+  if (pk) max_slots = std::max(max_slots, pk->min_slots);
+  const bool want_mask = pk || out->first_hop_mask != nullptr;
+  if (pk) { pk_none.n_mask_words = 1; }
+  if (pk && (need_words > 1 || max_slots > (g->wide24_bad ? 16u : 24u) || n >= (1u << 23) || (ctx->variant & 1u))) {
+    ctx->last_error = "packed results: a root of the run has more than " + std::to_string(g->wide24_bad ? 16 : 24) + " first-hop slots (or the fused path is off)";
+    return HSPF_E_NO_PACKED;
+  }
   if (want_mask && out->n_mask_words < need_words) {
     ctx->last_error = "n_mask_words too small: need " + std::to_string(need_words);
     return HSPF_E_TOO_MANY_SLOTS;
@@ -1244,7 +1346,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
                       g->hopcount_like ? 1u : 0u, 0xFFFFFFFFu};
   FusedParams fp_narrow = fp_wide, fp_lean = fp_wide;
   bool narrow = false, lean = false;
-  if (fused && !g->narrow_bad && !(ctx->variant & 2u)) {
+  const bool pk_wide = pk && pk->force_wide;
+  if (fused && !g->narrow_bad && !(ctx->variant & 2u) && !pk_wide) {
     // field split of the 4-byte state: M mask bits = slots of this run, 7 hop bits (6 when that
     // leaves fewer than 13 distance bits), the rest distance; used when a link cost is at most
     // 1/8 of the distance range and there are at least 12 distance bits
@@ -1265,7 +1368,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // the run is redone by k_fused and the graph remembers).  The tag costs 3 of the 32 bits: 7 hop bits when that leaves a
   // distance field of at least 8 x wmax, else 6 and at least 4 x wmax.  Needs max_path_metric beyond the field (nothing to
   // prune inside it), no heavy work units, no giant rows.  HSPF_VARIANT bit 15: k_fused everywhere (A/B).
-  if (fused && !g->lean_bad && !(ctx->variant & (2u | 32768u)) && g->n_heavy_chunks == 0 && g->n_giant == 0) {
+  if (fused && !g->lean_bad && !(ctx->variant & (2u | 32768u)) && g->n_heavy_chunks == 0 && g->n_giant == 0 && !pk_wide) {
     const uint32_t M = std::max(max_slots, 1u);
     uint32_t H = 7u;
     if (M + 3u + H + 4u > 32u || (1u << (32u - M - 3u - H)) < 8u * (g->wmax + 1u)) H = 6u;
@@ -1310,7 +1413,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if (ctx->h_lane_cap < L) {
     if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
     ctx->h_lane_flags = nullptr; ctx->h_lane_cap = 0;
-    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lane_flags, ((size_t)L + 256 + LEAN_CTL_WORDS) * 4, hipHostMallocDefault));   // status bits | row counters | lean plan counters
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_lane_flags, ((size_t)L + 256 + LEAN_CTL_WORDS + 4) * 4, hipHostMallocDefault));   // status bits | row counters | lean plan counters | misfit flag of a packed run
     ctx->h_lane_cap = L;
   }
   // slices of the giant rows (FusedGraph::giant_part): tags, then GIANT_WORDS x 64 words per (batch, slice)
@@ -1325,11 +1428,43 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if ((rc = ensure(ctx, ctx->kcnt, 256 * 4))) return rc;
   uint32_t *d_kcnt = (uint32_t *)ctx->kcnt.p;
   const bool count_rows = (run_flags & HSPF_RUN_COUNT_ROWS) != 0;
+  // which of the fused path's kernels takes the run (the comments are at their use below)
+  const uint32_t smax = std::min(n_roots <= 64 ? ctx->single_max_n * 2u : ctx->single_max_n, SINGLE_MAX_N);
+  const bool single = fused && n <= smax && g->e_kept <= SINGLE_MAX_E;
+  const bool lv = fused && !single && n_roots <= ctx->lv_max_roots && n >= ctx->lv_min_n && !giant;
   // row-major output targets (device): the caller's device buffers, or staging for host output
   OutDev od{};
   const size_t rn = (size_t)total_rows * n;               // rows of the output arrays (== n_roots unless mapped)
   uint32_t *d_rank = nullptr;
-  if (host_out) {
+  // packed results: the fused emit writes the words themselves (od.packed, set per fused_run: the word size is the run's);
+  // k_single / k_lv write row-major tables into staging, which k_pack_full then packs (8-byte words)
+  const bool pk_full = pk && (single || lv);
+  uint32_t *d_misfit = nullptr;
+  // device address of this run's first row of packed words of `esz` bytes: staging for a host destination, else the
+  // caller's buffer at the group's row offset
+  auto pk_dev = [&](size_t esz) -> char * { return pk->host ? (char *)ctx->o_pack.p : (char *)pk->dst + pk->row_off * (size_t)n * esz; };
+  int pk_mode = -1;                                        // which fused_run produced the words: 2 lean, 1 narrow, 0 wide; -1: k_pack_full (wide layout)
+  if (pk) {
+    if (pk->host && (rc = ensure(ctx, ctx->o_pack, rn * 8, false))) return rc;
+    if ((rc = ensure(ctx, ctx->pk_flag, 256, false))) return rc;
+    d_misfit = (uint32_t *)ctx->pk_flag.p;
+    HIPCHK(ctx, hipMemsetAsync(d_misfit, 0, 4, ctx->stream));
+  }
+  auto pk_staging = [&]() -> int {                         // row-major staging tables of a packed run (k_single / k_lv / k_exact write them)
+    int r2;
+    if ((r2 = ensure(ctx, ctx->o_dist, rn * 4, false))) return r2;
+    if ((r2 = ensure(ctx, ctx->o_hops, rn * 2, false))) return r2;
+    if ((r2 = ensure(ctx, ctx->o_flags, rn * 2, false))) return r2;
+    if ((r2 = ensure(ctx, ctx->o_mask, rn * 8, false))) return r2;
+    return HSPF_OK;
+  };
+  if (pk) {
+    od.out_words = 1;
+    if (pk_full) {
+      if ((rc = pk_staging())) return rc;
+      od.dist = (uint32_t *)ctx->o_dist.p; od.hops = (uint16_t *)ctx->o_hops.p; od.flags = (uint16_t *)ctx->o_flags.p; od.mask = (uint64_t *)ctx->o_mask.p;
+    }
+  } else if (host_out) {
     if ((rc = ensure(ctx, ctx->o_dist, rn * 4))) return rc;
     if ((rc = ensure(ctx, ctx->o_hops, rn * 2))) return rc;
     if ((rc = ensure(ctx, ctx->o_flags, rn * 2))) return rc;
@@ -1493,6 +1628,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       const bool nar = mode != 0, use_lean = mode == 2;
       const FusedParams P = use_lean ? fp_lean : (nar ? fp_narrow : fp_wide);
       const size_t esz = nar ? 4 : 8;
+      OutDev ode = od;                                           // packed results: the emit writes the state words of THIS width
+      if (pk) { ode.packed = pk_dev(esz); pk_mode = mode; }
       const uint32_t ns = use_lean ? n + 1u : n;                 // rows per batch slab (the lean sweep's pad row)
       const size_t rows = (size_t)B * ns * 64;
       const uint32_t fillw = use_lean ? P.infw : 0xFFFFFFFFu;
@@ -1619,8 +1756,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         // (with the speculative fill on, the emit resets the tiles it has read: first half of the next run's scratch fill)
         const int rg = spec_fill ? (int)chunk_last : -1;
         emit_reset = rg >= 0;
-        if (nar) hipLaunchKernelGGL((k_emit_fused<uint32_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (uint32_t *)d_st, P, od, ns, use_lean ? d_lf : (uint32_t *)nullptr, (const int *)d_changed, rg, fillw);
-        else     hipLaunchKernelGGL((k_emit_fused<uint64_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, d_st, P, od, ns, (uint32_t *)nullptr, (const int *)d_changed, rg, fillw);
+        if (nar) hipLaunchKernelGGL((k_emit_fused<uint32_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, (uint32_t *)d_st, P, ode, ns, use_lean ? d_lf : (uint32_t *)nullptr, (const int *)d_changed, rg, fillw);
+        else     hipLaunchKernelGGL((k_emit_fused<uint64_t>), dim3((n + 63) / 64, B), dim3(256), 0, s, n, n_roots, d_st, P, ode, ns, (uint32_t *)nullptr, (const int *)d_changed, rg, fillw);
         (void)hipEventRecord(ctx->ev[4], s);      // "results in place": the phase's read-back synchronises behind it
         tail_done = true;
       });
@@ -1657,14 +1794,13 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     // cycles), so it wins only while the sweep engine is bound by its ~50 kernel boundaries.  Hence: up to
     // ctx->single_max_n vertices (HSPF_SINGLE_MAX_N, default 1024; 0 switches the kernel off), twice that for at most
     // one batch of roots.
-    const uint32_t smax = std::min(n_roots <= 64 ? ctx->single_max_n * 2u : ctx->single_max_n, SINGLE_MAX_N);
-    const bool single = n <= smax && g->e_kept <= SINGLE_MAX_E;
+    // (smax / single: decided above, next to the output targets)
     // A few roots on a larger graph: lane = vertex (k_lv), one launch per sweep over the root's own row-major state.  The
     // lane = root engine spends a 256-byte row per useful 4-8 bytes there (isis-100k, one root: 25 launches x 21 us);
     // the scattered gathers of k_lv cost less than that up to a handful of roots (profiles/r02_notes.md, r02k).
     // (not on graphs with giant rows: a lane of k_lv walks its row alone — one root on isis-100k + a 5 000-router LAN took
     // 6.9 ms there against 0.9 ms for 64 roots on the sweep engine with the row in slices, r02t)
-    const bool lv = !single && n_roots <= ctx->lv_max_roots && n >= ctx->lv_min_n && !giant;
+    // (lv: decided above)
     auto lv_run = [&]() -> int {
       int r2;
       if ((r2 = ensure(ctx, ctx->stamp, (size_t)n_roots * n * 4))) return r2;
@@ -1776,7 +1912,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);
       if (ovf) {
         g->wide24_bad = true;
-        return run_impl(ctx, g, roots, n_roots, run_flags, out, host_out, row_map, total_rows, true);
+        return run_impl(ctx, g, roots, n_roots, run_flags, out, host_out, row_map, total_rows, true, pk);
       }
     }
     st.state_bytes = narrow ? 4 : 8;
@@ -1898,6 +2034,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     ExactArgs a{};
     a.g = gd; a.roots = d_roots; a.n_exact = (uint32_t)ex.size();
     a.maxpath = g->max_path_metric; a.net_nexthops = net_nh; a.ignore_ovl = ignore_ovl; a.tabs = tabs;
+    if (pk && !pk_full) {                                          // packed run on the fused emit: the sequential kernel's rows go through staging
+      if ((rc = pk_staging())) return rc;
+      od.dist = (uint32_t *)ctx->o_dist.p; od.hops = (uint16_t *)ctx->o_hops.p; od.flags = (uint16_t *)ctx->o_flags.p; od.mask = (uint64_t *)ctx->o_mask.p;
+    }
     a.dist = od.dist; a.hops = od.hops; a.flags = od.flags; a.mask = od.mask; a.words = out_words; a.pop_rank = d_rank;
     a.row_map = od.row_map;
     if (!a.hops) { if ((rc = ensure(ctx, ctx->o_hops, rn * 2))) return rc; a.hops = (uint16_t *)ctx->o_hops.p; }
@@ -1918,11 +2058,42 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   }
   // Nothing was enqueued behind the emit (no sequential roots, no padding ranks, device-resident results): the run is
   // complete and synchronised already — a second event record + stream synchronisation cost 12 us per run.
-  const bool finished = tail_done && ex.empty() && !host_out && !((run_flags & HSPF_RUN_POP_RANK) && d_rank);
+  // ---- packed results: rows that did not come out of the fused emit, the layout, the copy
+  size_t pk_esz = 0;
+  if (pk) {
+    const FusedParams PP = pk_mode == 2 ? fp_lean : pk_mode == 1 ? fp_narrow : fp_wide;
+    pk_esz = (pk_mode == 2 || pk_mode == 1) ? 4 : 8;
+    if (pk_full || !ex.empty()) {
+      const uint32_t nrows = pk_full ? n_roots : (uint32_t)ex.size();
+      const uint32_t *rows_list = pk_full ? (const uint32_t *)nullptr : (const uint32_t *)ctx->ex_list.p;
+      const dim3 pg((n + 255u) / 256u, nrows);
+      if (pk_esz == 4) hipLaunchKernelGGL((k_pack_full<4>), pg, dim3(256), 0, s, n, nrows, rows_list, (const uint32_t *)od.dist, (const uint16_t *)od.hops, (const uint16_t *)od.flags, (const uint64_t *)od.mask, 1u, PP, (void *)pk_dev(4), d_misfit);
+      else             hipLaunchKernelGGL((k_pack_full<8>), pg, dim3(256), 0, s, n, nrows, rows_list, (const uint32_t *)od.dist, (const uint16_t *)od.hops, (const uint16_t *)od.flags, (const uint64_t *)od.mask, 1u, PP, (void *)pk_dev(8), d_misfit);
+      HIPCHK(ctx, hipMemcpyAsync(ctx->h_lane_flags + L + 256 + LEAN_CTL_WORDS, d_misfit, 4, hipMemcpyDeviceToHost, s));
+    }
+    hspf_packed_layout &ly = pk->layout;
+    ly = hspf_packed_layout{};
+    ly.word_bytes = (uint32_t)pk_esz;
+    ly.dist_shift = pk_esz == 4 ? PP.sh : 32u; ly.hops_shift = PP.mbits; ly.hops_mask = PP.hmax; ly.mask_bits = PP.mbits;
+    ly.not_reached = pk_esz == 4 ? (uint64_t)PP.inf_t : ~0ull;
+    if (pk->root_status) {
+      for (uint32_t r = 0; r < n_roots; ++r) pk->root_status[pk->row_off + r] = 0;
+      for (uint32_t r : ex) pk->root_status[pk->row_off + r] = HSPF_ROOT_EXACT;
+    }
+  }
+  const bool finished = tail_done && ex.empty() && !host_out && !pk_full && !((run_flags & HSPF_RUN_POP_RANK) && d_rank);
   if (!finished) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
 
   // ---- results to the caller
-  if (host_out) {
+  if (pk) {
+    if (pk->host) {
+      const size_t bytes = (size_t)n_roots * n * pk_esz, off = pk->row_off * (size_t)n * pk_esz;
+      if (off + bytes > pk->cap) { (void)hipStreamSynchronize(s); ctx->last_error = "packed results: buffer too small, need " + std::to_string(off + bytes) + " bytes"; return HSPF_E_INVAL; }
+      if ((rc = copy_to_host(ctx, (char *)pk->dst + off, pk_dev(pk_esz), bytes, s))) return rc;
+    } else if (pk->row_off * (size_t)n * pk_esz + (size_t)n_roots * n * pk_esz > pk->cap) {
+      (void)hipStreamSynchronize(s); ctx->last_error = "packed results: buffer too small"; return HSPF_E_INVAL;
+    }
+  } else if (host_out) {
     HIPCHK(ctx, hipMemcpyAsync(out->dist, od.dist, rn * 4, hipMemcpyDeviceToHost, s));
     if (out->hops) HIPCHK(ctx, hipMemcpyAsync(out->hops, od.hops, rn * 2, hipMemcpyDeviceToHost, s));
     if (out->vflags_out) HIPCHK(ctx, hipMemcpyAsync(out->vflags_out, od.flags, rn * 2, hipMemcpyDeviceToHost, s));
@@ -1931,6 +2102,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   }
   if (host_out) HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
   if (!finished) HIPCHK(ctx, hipStreamSynchronize(s));
+  if (pk && (pk_full || !ex.empty()) && ctx->h_lane_flags[L + 256 + LEAN_CTL_WORDS] != 0u) {
+    ctx->last_error = "packed results: a value of a row from the one-workgroup / lane = vertex / sequential kernel does not fit the run's fields";
+    return HSPF_E_NO_PACKED;
+  }
   {
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { ctx->last_error = std::string("kernel launch: ") + hipGetErrorString(le); return HSPF_E_HIP; }
@@ -2142,6 +2317,41 @@ int hspf_run_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   return guarded(ctx, [&]() { return run_classes(ctx, g, roots, n_roots, run_flags, out_device, false); });
 }
 
+// ---- packed results (ABI 7) ---------------------------------------------------------------------
+int hspf_host_alloc(hspf_ctx *ctx, size_t bytes, void **out) {
+  if (!ctx || !out || bytes == 0) return HSPF_E_INVAL;
+  *out = nullptr;
+  (void)hipSetDevice(ctx->device);
+  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) { *out = nullptr; try { ctx->last_error = std::string("hipHostMalloc: ") + hipGetErrorString(e); } catch (...) {} return HSPF_E_NOMEM; }
+  return HSPF_OK;
+}
+void hspf_host_free(hspf_ctx *ctx, void *p) {
+  if (!p) return;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  (void)hipHostFree(p);
+}
+
+static int run_packed_entry(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                            void *words, size_t cap_bytes, bool host, hspf_packed_layout *layout, uint8_t *root_status) {
+  if (!ctx || !g || !roots || n_roots == 0 || !words || !layout) return HSPF_E_INVAL;
+  return guarded(ctx, [&]() {
+    PackedReq pk;
+    pk.dst = words; pk.cap = cap_bytes; pk.host = host; pk.root_status = root_status;
+    const int rc = run_impl(ctx, g, roots, n_roots, run_flags, nullptr, host, nullptr, 0, false, &pk);
+    if (rc == HSPF_OK) *layout = pk.layout;
+    return rc;
+  });
+}
+int hspf_run_packed(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                    void *words_host, size_t cap_bytes, hspf_packed_layout *layout, uint8_t *root_status) {
+  return run_packed_entry(ctx, g, roots, n_roots, run_flags, words_host, cap_bytes, true, layout, root_status);
+}
+int hspf_run_packed_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                           void *words_dev, size_t cap_bytes, hspf_packed_layout *layout, uint8_t *root_status) {
+  return run_packed_entry(ctx, g, roots, n_roots, run_flags, words_dev, cap_bytes, false, layout, root_status);
+}
+
 int hspf_get_stats(const hspf_ctx *ctx, hspf_stats *out) {
   if (!ctx || !out) return HSPF_E_INVAL;
   *out = ctx->stats;
@@ -2185,13 +2395,15 @@ static int lanes_ensure(hspf_ctx *ctx) {
         ln->cv.notify_all();                                        // (a submitter may be waiting for room in the queue)
         (void)hipSetDevice(ln->sub->device);
         const int rc = guarded(ln->sub, [&]() {
+          if (job.packed)                                           // hspf_run_packed_async: the run and its copy to the host
+            return run_impl(ln->sub, job.g, job.roots.data(), (uint32_t)job.roots.size(), job.flags, nullptr, true, nullptr, 0, false, &job.pk);
           if (!job.dest.empty())                                    // one class of a run that the caller's context split (run_classes)
             return run_impl(ln->sub, job.g, job.roots.data(), (uint32_t)job.roots.size(), job.flags, &job.out, false, job.dest.data(), job.n_total);
           return run_classes(ln->sub, job.g, job.roots.data(), (uint32_t)job.roots.size(), job.flags, &job.out, false);
         });
         lk.lock();
         hspf_lane::Done &d = ln->done[(job.ticket / nl) & 7u];
-        d.ticket = job.ticket; d.rc = rc; d.st = ln->sub->stats;
+        d.ticket = job.ticket; d.rc = rc; d.st = ln->sub->stats; d.layout = job.pk.layout;
         try { d.err = rc ? ln->sub->last_error : std::string(); } catch (...) {}
         ln->last_done = job.ticket; ln->running = false;
         lk.unlock();
@@ -2235,6 +2447,20 @@ int hspf_run_device_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *ro
   });
 }
 
+int hspf_run_packed_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                          void *words_host, size_t cap_bytes, uint8_t *root_status, uint64_t *ticket) {
+  if (!ctx || !g || !roots || !words_host || !ticket || n_roots == 0) return HSPF_E_INVAL;
+  return guarded(ctx, [&]() {
+    int rc = lanes_ensure(ctx);
+    if (rc) return rc;
+    hspf_lane::Job job{g, std::vector<uint32_t>(roots, roots + n_roots), run_flags, hspf_result{}, 0, {}, 0};
+    job.packed = true;
+    job.pk.dst = words_host; job.pk.cap = cap_bytes; job.pk.host = true; job.pk.root_status = root_status;
+    *ticket = lane_submit(ctx, std::move(job));
+    return (int)HSPF_OK;
+  });
+}
+
 // Next ticket, onto its lane's queue (lanes exist: lanes_ensure).
 static uint64_t lane_submit(hspf_ctx *ctx, hspf_lane::Job &&job) {
   const uint64_t t = ctx->next_ticket++;
@@ -2249,13 +2475,14 @@ static uint64_t lane_submit(hspf_ctx *ctx, hspf_lane::Job &&job) {
 }
 
 // Waits for a ticket; its result code, statistics and (on failure) error text.  Does not touch ctx->stats.
-static int lane_collect(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats) {
+static int lane_collect(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats, hspf_packed_layout *layout) {
   hspf_lane *ln = ctx->lanes[ticket % ctx->lanes.size()];
   std::unique_lock<std::mutex> lk(ln->mu);
   ln->cv.wait(lk, [&] { return ln->last_done >= ticket; });
   const hspf_lane::Done &d = ln->done[(ticket / ctx->lanes.size()) & 7u];
   if (d.ticket != ticket) { ctx->last_error = "hspf_wait: the ticket's result is gone (more than eight later runs on its lane)"; return HSPF_E_INVAL; }
   if (stats) *stats = d.st;
+  if (layout) *layout = d.layout;
   if (d.rc) { try { ctx->last_error = d.err; } catch (...) {} }
   return d.rc;
 }
@@ -2264,6 +2491,16 @@ int hspf_wait(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats) {
   if (!ctx || ticket == 0 || ticket >= ctx->next_ticket || ctx->lanes.empty()) return HSPF_E_INVAL;
   hspf_stats st{};
   const int rc = lane_collect(ctx, ticket, &st);
+  if (rc == HSPF_E_INVAL && ctx->last_error.rfind("hspf_wait: the ticket", 0) == 0) return rc;
+  ctx->stats = st;
+  if (stats) *stats = st;
+  return rc;
+}
+
+int hspf_wait_packed(hspf_ctx *ctx, uint64_t ticket, hspf_packed_layout *layout, hspf_stats *stats) {
+  if (!ctx || !layout || ticket == 0 || ticket >= ctx->next_ticket || ctx->lanes.empty()) return HSPF_E_INVAL;
+  hspf_stats st{};
+  const int rc = lane_collect(ctx, ticket, &st, layout);
   if (rc == HSPF_E_INVAL && ctx->last_error.rfind("hspf_wait: the ticket", 0) == 0) return rc;
   ctx->stats = st;
   if (stats) *stats = st;

@@ -102,6 +102,7 @@ constexpr uint32_t GIANT_WORDS = 8u;            // accumulator words per lane an
 struct OutDev {
   uint32_t *dist; uint16_t *hops; uint16_t *flags; uint64_t *mask; uint32_t out_words;
   const uint32_t *row_map;   // output row of the run's root r (null: r itself) — runs regrouped by state class
+  void *packed;              // hspf_run_packed (ABI 7): the fused emit writes the state WORD itself, row-major, instead of the four arrays
   __device__ __forceinline__ size_t row(uint32_t r) const { return row_map ? row_map[r] : r; }
 };
 
@@ -2086,6 +2087,7 @@ __global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots
     if (lane < nv) {
       const ST x = tt[lane][r];
       const size_t idx = o.row(r0 + r) * n + v0 + lane;
+      if (o.packed) { ((ST *)o.packed)[idx] = x; continue; }       // the word is the result (include/holo_spf_hip.h "packed results")
       uint32_t d, pay;
       if (sizeof(ST) == 8) { d = (uint32_t)((uint64_t)x >> 32); pay = (uint32_t)x; }
       else { d = (uint32_t)x >> P.sh; pay = (uint32_t)x & ((1u << P.sh) - 1u); }
@@ -2098,6 +2100,43 @@ __global__ __launch_bounds__(256) void k_emit_fused(uint32_t n, uint32_t n_roots
         for (uint32_t k = 1; k < o.out_words; ++k) o.mask[idx * o.out_words + k] = 0;
       }
     }
+}
+
+// hspf_run_packed for the rows that do not come out of the fused emit — the one-workgroup and lane = vertex kernels write
+// row-major tables, so does the sequential kernel for the roots it takes over —: row-major (dist, hops, flags, mask word 0)
+// -> packed words of the run's layout (FusedParams P; WB = 4: [dist | .. | hops | mask] with dist at P.sh, WB = 8:
+// [dist32 | hops | mask]).  rows == null: all n_rows rows, else the listed ones.  A value that does not fit its field
+// raises *misfit (the call then returns HSPF_E_NO_PACKED: nothing a caller could mistake for a result).
+template <int WB>
+__global__ __launch_bounds__(256) void k_pack_full(uint32_t n, uint32_t n_rows, const uint32_t *__restrict__ rows, const uint32_t *__restrict__ dist,
+                                                   const uint16_t *__restrict__ hops, const uint16_t *__restrict__ flags,
+                                                   const uint64_t *__restrict__ mask, uint32_t mask_words, FusedParams P, void *out, uint32_t *misfit) {
+  const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+  if (v >= n || blockIdx.y >= n_rows) return;
+  const size_t idx = (size_t)(rows ? rows[blockIdx.y] : blockIdx.y) * n + v;
+  const bool in = (flags[idx] & 1u) != 0;
+  const uint32_t d = dist[idx], h = hops[idx];
+  const uint64_t m = mask[idx * mask_words];
+  bool bad = false;
+  if (WB == 8) {
+    uint64_t w = ~0ull;
+    if (in) {
+      bad = h > P.hmax || (m >> P.mbits) != 0ull;
+      w = ((uint64_t)d << 32) | ((uint64_t)(h & P.hmax) << P.mbits) | (m & ((1ull << P.mbits) - 1ull));
+      bad = bad || w == ~0ull;
+    }
+    ((uint64_t *)out)[idx] = w;
+  } else {
+    uint32_t w = P.infw;
+    if (in) {
+      const uint32_t dmax = (P.ovf_t >> P.sh);                     // reached distances stay below the overflow threshold
+      bad = d >= dmax || h >= P.hmax || (m >> P.mbits) != 0ull;
+      w = (d << P.sh) | ((h & P.hmax) << P.mbits) | (uint32_t)(m & ((1ull << P.mbits) - 1ull));
+      bad = bad || w >= P.inf_t;
+    }
+    ((uint32_t *)out)[idx] = w;
+  }
+  if (bad) atomicOr(misfit, 1u);
 }
 
 // Epoch rebase (only when a DAG phase needs more than 65534 launches): every final row -> epoch 1.

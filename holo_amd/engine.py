@@ -22,6 +22,8 @@ RUN_FORCE_EXACT = 0x04
 RUN_POP_RANK = 0x08
 RUN_COUNT_ROWS = 0x10
 E_TOO_MANY_SLOTS = -5
+E_NO_PACKED = -7
+ROOT_EXACT = 0x01
 
 PFX_SATURATING = 0x1
 PFX_LAST_MIN = 0x2
@@ -53,6 +55,67 @@ class SpfResult:
     first_hop_mask: np.ndarray       # [R, N, W] u64
     pop_rank: Optional[np.ndarray]   # [R, N] u32 or None
     stats: dict
+
+
+@dataclass
+class PackedResult:
+    """hspf_run_packed(): ONE machine word per (root, vertex), row-major, plus the field positions of the run
+    (include/holo_spf_hip.h "packed results").  The accessors decode whole tables with numpy; a caller that looks at a
+    vertex once decodes only what it touches."""
+    words: np.ndarray                # [R, N] u32 or u64 (a view of the caller's / the wrapper's buffer)
+    word_bytes: int
+    dist_shift: int
+    hops_shift: int
+    hops_mask: int
+    mask_bits: int
+    not_reached: int
+    root_status: np.ndarray          # [R] u8, ROOT_EXACT
+    stats: dict
+
+    @property
+    def in_spt(self) -> np.ndarray:
+        return self.words < self.words.dtype.type(self.not_reached)     # (4-byte words: not_reached fits 32 bits)
+
+    @property
+    def dist(self) -> np.ndarray:
+        d = (self.words >> self.words.dtype.type(self.dist_shift)).astype(np.uint32)
+        return np.where(self.in_spt, d, np.uint32(DIST_INF))
+
+    @property
+    def hops(self) -> np.ndarray:
+        h = ((self.words >> self.words.dtype.type(self.hops_shift)) & self.words.dtype.type(self.hops_mask)).astype(np.uint16)
+        return np.where(self.in_spt, h, np.uint16(0))
+
+    @property
+    def first_hop_mask(self) -> np.ndarray:
+        m = (self.words & self.words.dtype.type((1 << self.mask_bits) - 1)).astype(np.uint64)
+        return np.where(self.in_spt, m, np.uint64(0))[..., None]
+
+
+class PinnedBuffer:
+    """Page-locked host memory from hspf_host_alloc (freed with the object)."""
+
+    def __init__(self, ctx: "SpfContext", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = ctypes.c_void_p()
+        rc = ctx.lib.hspf_host_alloc(ctx.handle, self.nbytes, ctypes.byref(p))
+        if rc != 0:
+            raise HspfError(rc, "hspf_host_alloc", ctx.last_error())
+        self.ptr = p.value
+        self.array = np.ctypeslib.as_array((ctypes.c_uint8 * self.nbytes).from_address(self.ptr))
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.ctx.lib.hspf_host_free(self.ctx.handle, ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if getattr(self.ctx, "handle", None):
+                self.free()
+        except Exception:
+            pass
 
 
 def _u32(a):
@@ -288,6 +351,66 @@ class SpfContext:
         if rc != 0:
             raise HspfError(rc, "hspf_run", self.last_error())
         return SpfResult(dist, hops, flags, mask, rank, self.stats())
+
+    def host_alloc(self, nbytes: int) -> PinnedBuffer:
+        """hspf_host_alloc(): page-locked host memory for result buffers."""
+        return PinnedBuffer(self, nbytes)
+
+    def _packed_result(self, buf_u8: np.ndarray, R: int, n: int, ly, status, stats) -> PackedResult:
+        dt = np.uint32 if ly.word_bytes == 4 else np.uint64
+        words = buf_u8[: R * n * ly.word_bytes].view(dt).reshape(R, n)
+        return PackedResult(words, int(ly.word_bytes), int(ly.dist_shift), int(ly.hops_shift), int(ly.hops_mask), int(ly.mask_bits),
+                            int(ly.not_reached), status, stats)
+
+    def run_packed(self, graph: SpfGraph, roots: Sequence[int], run_flags: int = 0, *, buffer=None) -> PackedResult:
+        """hspf_run_packed(): packed words in host memory.  `buffer`: a PinnedBuffer (bus speed) or a writable numpy uint8
+        array of at least 8 * R * N bytes (staged by the library); default: a fresh numpy array.  Raises HspfError with
+        code E_NO_PACKED when the run's results do not fit packed words (the caller then uses run())."""
+        roots = np.ascontiguousarray(roots, dtype=np.uint32)
+        R, n = len(roots), graph.n
+        if buffer is None:
+            buffer = np.empty(8 * R * n, np.uint8)
+        arr = buffer.array if isinstance(buffer, PinnedBuffer) else buffer
+        status = np.zeros(R, np.uint8)
+        ly = L.HspfPackedLayout()
+        rc = self.lib.hspf_run_packed(self.handle, graph.handle, _u32(roots), R, run_flags, ctypes.c_void_p(arr.ctypes.data), arr.nbytes,
+                                      ctypes.byref(ly), status.ctypes.data_as(L.u8p))
+        if rc != 0:
+            raise HspfError(rc, "hspf_run_packed", self.last_error())
+        return self._packed_result(arr, R, n, ly, status, self.stats())
+
+    def run_packed_device(self, graph: SpfGraph, roots: Sequence[int], run_flags: int, *, words_ptr: int, cap_bytes: int):
+        """hspf_run_packed_device(): packed words at a device pointer; returns (layout struct, root status, stats)."""
+        roots = np.ascontiguousarray(roots, dtype=np.uint32)
+        status = np.zeros(len(roots), np.uint8)
+        ly = L.HspfPackedLayout()
+        rc = self.lib.hspf_run_packed_device(self.handle, graph.handle, _u32(roots), len(roots), run_flags, ctypes.c_void_p(words_ptr), cap_bytes,
+                                             ctypes.byref(ly), status.ctypes.data_as(L.u8p))
+        if rc != 0:
+            raise HspfError(rc, "hspf_run_packed_device", self.last_error())
+        return ly, status, self.stats()
+
+    def run_packed_async(self, graph: SpfGraph, roots: Sequence[int], run_flags: int, buffer) -> tuple:
+        """hspf_run_packed_async(): the run AND its copy to the host on a lane; returns a handle for wait_packed()."""
+        roots = np.ascontiguousarray(roots, dtype=np.uint32)
+        arr = buffer.array if isinstance(buffer, PinnedBuffer) else buffer
+        status = np.zeros(len(roots), np.uint8)
+        t = ctypes.c_uint64()
+        rc = self.lib.hspf_run_packed_async(self.handle, graph.handle, _u32(roots), len(roots), run_flags, ctypes.c_void_p(arr.ctypes.data), arr.nbytes,
+                                            status.ctypes.data_as(L.u8p), ctypes.byref(t))
+        if rc != 0:
+            raise HspfError(rc, "hspf_run_packed_async", self.last_error())
+        return (int(t.value), arr, len(roots), graph.n, status)
+
+    def wait_packed(self, handle: tuple) -> PackedResult:
+        ticket, arr, R, n, status = handle
+        ly, s = L.HspfPackedLayout(), L.HspfStats()
+        rc = self.lib.hspf_wait_packed(self.handle, ticket, ctypes.byref(ly), ctypes.byref(s))
+        if rc != 0:
+            raise HspfError(rc, "hspf_wait_packed", self.last_error())
+        st = {name: getattr(s, name) for name, _ in L.HspfStats._fields_}
+        st["dbg"] = list(st["dbg"])
+        return self._packed_result(arr, R, n, ly, status, st)
 
     def run_device(self, graph: SpfGraph, roots: Sequence[int], run_flags: int, *, dist_ptr: int,
                    hops_ptr: int = 0, flags_ptr: int = 0, mask_ptr: int = 0, mask_words: int = 1,

@@ -37,7 +37,10 @@
 extern "C" {
 #endif
 
-#define HSPF_ABI_VERSION 6u   /* 6: + hspf_run_device_async / hspf_wait / hspf_wait_all / hspf_async_lanes, hspf_multi_run_async / hspf_multi_run_wait, hspf_recommend_cpu (additions only);
+#define HSPF_ABI_VERSION 7u   /* 7: + packed results (hspf_run_packed / _device / _async, hspf_wait_packed, hspf_packed_layout + decode helpers),
+                                    hspf_host_alloc / hspf_host_free, HSPF_E_NO_PACKED (additions only); the library no longer sets
+                                    GPU_MAX_HW_QUEUES at load time;
+                                 6: + hspf_run_device_async / hspf_wait / hspf_wait_all / hspf_async_lanes, hspf_multi_run_async / hspf_multi_run_wait, hspf_recommend_cpu (additions only);
                                  5: + hspf_routes_diff_count / hspf_routes_pack, hspf_multi_init_error, HSPF_PFX_RESIDENT, HSPF_GX_ELL_* / LEAF / SUMMARY */
 
 /* ---- error codes ------------------------------------------------------------------- */
@@ -48,6 +51,9 @@ extern "C" {
 #define HSPF_E_NOMEM           -4   /* host or device allocation failed                        */
 #define HSPF_E_TOO_MANY_SLOTS  -5   /* a root has more first-hop slots than n_mask_words*64    */
 #define HSPF_E_INTERNAL        -6   /* invariant violated (never expected)                     */
+#define HSPF_E_NO_PACKED       -7   /* hspf_run_packed*: this run's results do not fit packed words
+                                       (more than 24 first-hop slots, hop counts beyond the hop field);
+                                       nothing was written, call hspf_run / hspf_run_device instead */
 
 /* ---- vertex flags (hspf_csr.vflags) -------------------------------------------------- */
 /* bit0: vertex is an OSPF network vertex / IS-IS pseudonode.  Reaching it does not
@@ -311,6 +317,68 @@ int hspf_run_device_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *ro
 int hspf_wait(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats /* may be NULL */);
 int hspf_wait_all(hspf_ctx *ctx);                  /* every run in flight is over (codes: hspf_wait)        */
 uint32_t hspf_async_lanes(const hspf_ctx *ctx);    /* how many runs can be in flight                        */
+
+/* ---- packed results (ABI 7) ---------------------------------------------------------------- */
+/*
+ * hspf_run delivers 16 bytes per (root, vertex) — 102 MB for 64 roots on a 100 000-vertex level, 1.8 ms over PCIe against
+ * 0.45 ms of compute — although the engine holds the whole answer in ONE machine word per (root, vertex):
+ * [distance | hop count | first-hop mask], 4 bytes when the fields fit (the usual case: checked on the device, never
+ * assumed), else 8.  hspf_run_packed hands exactly those words over, row-major [n_roots][n_vertices], together with the
+ * field positions of THIS run; the caller (whose next step looks at a vertex once: rebuilding `Vertex{distance, hops,
+ * nexthops}`, holo-isis/src/spf.rs:78-88, holo-ospf/src/spf.rs:38-46) decodes a word where it needs it:
+ *     in SPT     word <  not_reached                        (else: dist = HSPF_DIST_INF, hops = 0, mask = 0)
+ *     distance   word >> dist_shift
+ *     hops       (word >> hops_shift) & hops_mask
+ *     mask       word & ((1 << mask_bits) - 1)              first-hop slots 0 .. mask_bits - 1, as hspf_result.first_hop_mask
+ * (inline helpers below).  The values are bit for bit those of hspf_run.  What has no room in a word comes per root:
+ * root_status[r] & HSPF_ROOT_EXACT = the root went through the sequential kernel (HSPF_RF_EXACT of hspf_run: its pop
+ * order is not the static (distance, index) order; ask for pop_rank with hspf_run when the caller needs that order).
+ * HSPF_RUN_POP_RANK is not accepted.  A run whose roots have more than 24 first-hop slots, or whose hop counts outgrow
+ * the field, returns HSPF_E_NO_PACKED before / without writing anything: the caller then calls hspf_run.
+ *
+ * `words` must have room for 8 bytes per (root, vertex) — cap_bytes >= 8 * n_roots * n_vertices always suffices; only
+ * layout->word_bytes * n_roots * n_vertices bytes are written (and cross the bus).  Host destinations: memory from
+ * hspf_host_alloc (page-locked: the copy runs at bus speed) or any other host memory (the library then stages the copy
+ * through its own page-locked blocks, chunk by chunk, at the speed of one host memcpy).
+ */
+typedef struct {
+  uint32_t word_bytes;     /* 4 or 8                                                              */
+  uint32_t dist_shift;
+  uint32_t hops_shift;
+  uint32_t hops_mask;
+  uint32_t mask_bits;
+  uint32_t reserved;       /* 0                                                                   */
+  uint64_t not_reached;    /* word >= not_reached: the vertex is not in the SPT of that root      */
+} hspf_packed_layout;
+#define HSPF_ROOT_EXACT 0x01u
+
+static inline uint64_t hspf_packed_word(const hspf_packed_layout *l, const void *words, size_t index) {
+  return l->word_bytes == 4u ? (uint64_t)((const uint32_t *)words)[index] : ((const uint64_t *)words)[index];
+}
+static inline int      hspf_packed_in_spt(const hspf_packed_layout *l, uint64_t w) { return w < l->not_reached; }
+static inline uint32_t hspf_packed_dist(const hspf_packed_layout *l, uint64_t w) { return w < l->not_reached ? (uint32_t)(w >> l->dist_shift) : HSPF_DIST_INF; }
+static inline uint16_t hspf_packed_hops(const hspf_packed_layout *l, uint64_t w) { return w < l->not_reached ? (uint16_t)((w >> l->hops_shift) & l->hops_mask) : (uint16_t)0; }
+static inline uint64_t hspf_packed_mask(const hspf_packed_layout *l, uint64_t w) { return w < l->not_reached ? (w & ((1ull << l->mask_bits) - 1ull)) : 0ull; }
+
+/* Page-locked host memory for result buffers (hipHostMalloc / hipHostFree behind the boundary, so that the Rust side
+ * needs no HIP binding of its own).  Valid on every context of the process. */
+int  hspf_host_alloc(hspf_ctx *ctx, size_t bytes, void **out);
+void hspf_host_free(hspf_ctx *ctx, void *p);
+
+/* Synchronous, words in HOST memory (see above).  root_status: [n_roots] or NULL. */
+int hspf_run_packed(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                    void *words_host, size_t cap_bytes, hspf_packed_layout *layout, uint8_t *root_status);
+/* The same with `words_dev` in DEVICE memory (a quarter of the bytes of hspf_run_device's tables for consumers that stay
+ * on the GPU or send the rows on with hspf_multi_allgather_rows); root_status is a HOST array. */
+int hspf_run_packed_device(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                           void *words_dev, size_t cap_bytes, hspf_packed_layout *layout, uint8_t *root_status);
+/* Asynchronous form of hspf_run_packed on the context's lanes (hspf_run_device_async): the run AND its copy to the host
+ * belong to the ticket, so the copy of one batch crosses the bus while the next batch computes.  words_host /
+ * root_status must stay valid, and must not be shared between tickets in flight, until hspf_wait_packed has returned
+ * for the ticket; that call also fills `layout`.  hspf_wait works on such a ticket too (without the layout). */
+int hspf_run_packed_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                          void *words_host, size_t cap_bytes, uint8_t *root_status, uint64_t *ticket);
+int hspf_wait_packed(hspf_ctx *ctx, uint64_t ticket, hspf_packed_layout *layout, hspf_stats *stats /* may be NULL */);
 
 /* ---- route derivation on device (the step right after the SPT) ------------------- */
 /*

@@ -32,6 +32,43 @@ struct Tables {                       // row-major [root][vertex] host results o
   hspf_stats stats{};
 };
 
+// Page-locked host memory from hspf_host_alloc (results cross the bus at full speed into it), freed with the object.
+class PinnedBuffer {
+ public:
+  PinnedBuffer() = default;
+  PinnedBuffer(hspf_ctx *ctx, size_t bytes) : ctx_(ctx), bytes_(bytes) {
+    const int rc = hspf_host_alloc(ctx, bytes, &p_);
+    if (rc != HSPF_OK) throw Error(rc, "hspf_host_alloc");
+  }
+  PinnedBuffer(PinnedBuffer &&o) noexcept : ctx_(o.ctx_), p_(o.p_), bytes_(o.bytes_) { o.p_ = nullptr; o.bytes_ = 0; }
+  PinnedBuffer &operator=(PinnedBuffer &&o) noexcept { if (this != &o) { reset(); ctx_ = o.ctx_; p_ = o.p_; bytes_ = o.bytes_; o.p_ = nullptr; o.bytes_ = 0; } return *this; }
+  PinnedBuffer(const PinnedBuffer &) = delete;
+  PinnedBuffer &operator=(const PinnedBuffer &) = delete;
+  ~PinnedBuffer() { reset(); }
+  void reset() { if (p_) hspf_host_free(ctx_, p_); p_ = nullptr; bytes_ = 0; }
+  void *data() const { return p_; }
+  size_t size() const { return bytes_; }
+ private:
+  hspf_ctx *ctx_ = nullptr;
+  void *p_ = nullptr;
+  size_t bytes_ = 0;
+};
+
+// Packed results of one run (ABI 7): ONE word per (root, vertex) in a page-locked buffer + the run's field positions.
+// A vertex is decoded where it is looked at (the rebuild of `Vertex{distance, hops, nexthops}` touches each once).
+struct PackedTables {
+  uint32_t n_roots = 0, n_vertices = 0;
+  hspf_packed_layout layout{};
+  PinnedBuffer words;
+  std::vector<uint8_t> root_status;            // HSPF_ROOT_EXACT per root
+  hspf_stats stats{};
+  uint64_t word(uint32_t r, uint32_t v) const { return hspf_packed_word(&layout, words.data(), (size_t)r * n_vertices + v); }
+  bool in_spt(uint32_t r, uint32_t v) const { return hspf_packed_in_spt(&layout, word(r, v)) != 0; }
+  uint32_t dist(uint32_t r, uint32_t v) const { return hspf_packed_dist(&layout, word(r, v)); }
+  uint16_t hops(uint32_t r, uint32_t v) const { return hspf_packed_hops(&layout, word(r, v)); }
+  uint64_t mask(uint32_t r, uint32_t v) const { return hspf_packed_mask(&layout, word(r, v)); }
+};
+
 class Engine;
 
 // The engine context, shared by the Engine and every Graph made from it: a Graph that outlives its Engine (members
@@ -141,6 +178,23 @@ class Engine {
                     t.pop_rank.empty() ? nullptr : t.pop_rank.data()};
     const int rc = hspf_run(ctx_, g.raw(), roots.data(), t.n_roots, run_flags, &out);
     if (rc != HSPF_OK) throw Error(rc, std::string("hspf_run (") + hspf_last_error(ctx_) + ")");
+    hspf_get_stats(ctx_, &t.stats);
+    return t;
+  }
+
+  // ABI 7: packed results — a quarter of hspf_run's bytes over the bus.  `reuse`: a PackedTables of an earlier run whose
+  // buffer is taken over when it is large enough.  Throws Error with code HSPF_E_NO_PACKED when the run's results do not
+  // fit packed words (more than 24 first-hop slots): the caller then uses run().
+  PackedTables run_packed(const Graph &g, const std::vector<uint32_t> &roots, uint32_t run_flags = 0, PackedTables *reuse = nullptr) {
+    PackedTables t;
+    t.n_roots = (uint32_t)roots.size();
+    t.n_vertices = g.n_vertices();
+    const size_t need = (size_t)8 * t.n_roots * t.n_vertices;
+    if (reuse && reuse->words.size() >= need) t.words = std::move(reuse->words);
+    else t.words = PinnedBuffer(ctx_, need);
+    t.root_status.assign(t.n_roots, 0);
+    const int rc = hspf_run_packed(ctx_, g.raw(), roots.data(), t.n_roots, run_flags, t.words.data(), t.words.size(), &t.layout, t.root_status.data());
+    if (rc != HSPF_OK) throw Error(rc, std::string("hspf_run_packed (") + hspf_last_error(ctx_) + ")");
     hspf_get_stats(ctx_, &t.stats);
     return t;
   }

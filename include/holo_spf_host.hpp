@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -43,6 +44,24 @@ struct RoutesOut {                    // per (root, prefix), row-major: see hspf
   std::vector<uint32_t> best_metric, best_entry;
   std::vector<uint64_t> nexthop_mask;
 };
+// Route tables of one routes_device() call (or an uploaded set) left where the engine keeps them (HBM for the product
+// engine): operands of the RIB comparison (hspf_routes_diff_device).
+class DeviceRoutes {
+ public:
+  virtual ~DeviceRoutes() = default;
+  virtual RoutesOut host() = 0;
+  uint32_t n_roots = 0, n_prefixes = 0, mask_words = 1;
+};
+// The record stream of hspf_routes_pack: [count][HSPF_ROUTE_REC_WORDS + 2 mask_words] u32 (root, prefix, action, metric, entry, 0, mask words lo/hi)
+struct RouteRecords {
+  uint32_t mask_words = 1;
+  std::vector<uint32_t> words;
+  std::vector<uint32_t> old_words;     // the same records packed from the OLD set (metric, entry, masks of the route held before)
+  const uint32_t *old_rec(size_t k) const { return old_words.data() + k * stride(); }
+  size_t stride() const { return HSPF_ROUTE_REC_WORDS + 2u * mask_words; }
+  size_t count() const { return words.size() / stride(); }
+  const uint32_t *rec(size_t k) const { return words.data() + k * stride(); }
+};
 class Engine {
  public:
   virtual ~Engine() = default;
@@ -60,6 +79,13 @@ class Engine {
   virtual std::unique_ptr<DeviceRun> run_device(Graph &g, const std::vector<uint32_t> &roots, uint32_t run_flags) = 0;
   virtual RoutesOut routes(DeviceRun &run, const std::vector<uint32_t> &pfx_ptr, const std::vector<uint32_t> &pfx_vertex,
                            const std::vector<uint32_t> &pfx_metric, uint32_t flags) = 0;
+  // The wire step on the device: the same attachment with the tables LEFT on the device, a host table set
+  // brought there (the RIB held before), and the comparison + ordered compaction + ONE packed copy of what changed
+  // (hspf_routes_diff_device + hspf_routes_pack).  flags may carry HSPF_PFX_RESIDENT (same vectors as the previous call).
+  virtual std::unique_ptr<DeviceRoutes> routes_device(DeviceRun &run, const std::vector<uint32_t> &pfx_ptr, const std::vector<uint32_t> &pfx_vertex,
+                                                      const std::vector<uint32_t> &pfx_metric, uint32_t flags) = 0;
+  virtual std::unique_ptr<DeviceRoutes> routes_upload(const RoutesOut &t, uint32_t n_roots, uint32_t n_prefixes, uint32_t mask_words) = 0;
+  virtual RouteRecords routes_changed(DeviceRoutes &old_set, DeviceRoutes &new_set) = 0;
 };
 
 // CSR with the rows of `vertices` (strictly ascending) replaced — the host-side twin of hspf_graph_patch.
@@ -163,13 +189,33 @@ class HipDeviceRun : public DeviceRun {             // dist / hops / flags / mas
   }
   uint32_t *dist = nullptr; uint16_t *hops = nullptr, *flags = nullptr; uint64_t *mask = nullptr;
 };
+class HipDeviceRoutes : public DeviceRoutes {       // best_metric / best_entry / nexthop_mask of one table set in plain hipMalloc buffers
+ public:
+  ~HipDeviceRoutes() override { for (void *p : {(void *)bm, (void *)be, (void *)nm}) if (p) (void)hipFree(p); }
+  RoutesOut host() override {
+    RoutesOut o;
+    const size_t rp = (size_t)n_roots * n_prefixes;
+    o.best_metric.resize(rp); o.best_entry.resize(rp); o.nexthop_mask.resize(rp * mask_words);
+    if (rp && (hipMemcpy(o.best_metric.data(), bm, rp * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(o.best_entry.data(), be, rp * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+               hipMemcpy(o.nexthop_mask.data(), nm, rp * 8 * mask_words, hipMemcpyDeviceToHost) != hipSuccess))
+      throw std::runtime_error("hipMemcpy of the route tables failed");
+    return o;
+  }
+  bool alloc() {
+    const size_t rp = std::max<size_t>((size_t)n_roots * n_prefixes, 1);
+    return hipMalloc((void **)&bm, rp * 4) == hipSuccess && hipMalloc((void **)&be, rp * 4) == hipSuccess && hipMalloc((void **)&nm, rp * 8 * mask_words) == hipSuccess;
+  }
+  hspf_routes raw() const { return hspf_routes{bm, be, nm}; }
+  uint32_t *bm = nullptr, *be = nullptr; uint64_t *nm = nullptr;
+};
 class HipEngine : public Engine {
  public:
   explicit HipEngine(int device = 0) {
     const int rc = hspf_init(device, &ctx_);
     if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_init: ") + hspf_strerror(rc));   // no CPU fallback
   }
-  ~HipEngine() override { if (ctx_) hspf_shutdown(ctx_); }
+  ~HipEngine() override { if (diff_) (void)hipFree(diff_); if (pin_) hspf_host_free(ctx_, pin_); if (ctx_) hspf_shutdown(ctx_); }
+  hspf_ctx *raw() const { return ctx_; }
   std::unique_ptr<Graph> upload(const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col,
                                 const std::vector<uint32_t> &metric, const std::vector<uint8_t> &vflags,
                                 uint32_t max_path_metric) override {
@@ -179,22 +225,58 @@ class HipEngine : public Engine {
     if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_graph_upload: ") + hspf_last_error(ctx_));
     return std::make_unique<HipGraph>(ctx_, g);
   }
+  // One run, tables on the host.  Since ABI 7 through the PACKED hand-off (hspf_run_packed: one word per (root, vertex) into a
+  // page-locked buffer the engine keeps, a quarter of hspf_run's bytes over the bus) and decoded into the twins' tables
+  // here; runs whose results do not fit packed words (more than 24 first-hop slots), and runs that ask for the pop order,
+  // take hspf_run as before.  `last_handoff` says which way the last run went and what it cost.
+  struct Handoff { bool packed = false; uint32_t word_bytes = 0; double run_ms = 0, decode_ms = 0; };
+  Handoff last_handoff;
   Tables run(Graph &gr, const std::vector<uint32_t> &roots, uint32_t run_flags) override {
     hspf_graph *g = static_cast<HipGraph &>(gr).g;
     Tables t;
     t.n_roots = (uint32_t)roots.size();
     t.n_vertices = hspf_graph_n_vertices(g);
+    const size_t rn = (size_t)t.n_roots * t.n_vertices;
+    last_handoff = Handoff{};
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!(run_flags & HSPF_RUN_POP_RANK) && use_packed) {
+      if (pin_cap_ < rn * 8) {
+        if (pin_) hspf_host_free(ctx_, pin_);
+        pin_ = nullptr; pin_cap_ = 0;
+        if (hspf_host_alloc(ctx_, rn * 8, &pin_) != HSPF_OK) throw std::runtime_error(std::string("hspf_host_alloc: ") + hspf_last_error(ctx_));
+        pin_cap_ = rn * 8;
+      }
+      hspf_packed_layout ly{};
+      std::vector<uint8_t> status(t.n_roots, 0);
+      const int rc = hspf_run_packed(ctx_, g, roots.data(), t.n_roots, run_flags, pin_, pin_cap_, &ly, status.data());
+      if (rc == HSPF_OK) {
+        const auto t1 = std::chrono::steady_clock::now();
+        t.mask_words = 1;
+        t.dist.resize(rn); t.hops.resize(rn); t.flags.resize(rn); t.mask.resize(rn);
+        for (uint32_t r = 0; r < t.n_roots; ++r) {
+          const uint16_t ex = (status[r] & HSPF_ROOT_EXACT) ? (uint16_t)HSPF_RF_EXACT : (uint16_t)0;
+          const size_t o = (size_t)r * t.n_vertices;
+          if (ly.word_bytes == 4) decode_row<uint32_t>((const uint32_t *)pin_ + o, ly, ex, t, o);
+          else decode_row<uint64_t>((const uint64_t *)pin_ + o, ly, ex, t, o);
+        }
+        const auto t2 = std::chrono::steady_clock::now();
+        last_handoff = Handoff{true, ly.word_bytes, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count()};
+        return t;
+      }
+      if (rc != HSPF_E_NO_PACKED) throw std::runtime_error(std::string("hspf_run_packed: ") + hspf_last_error(ctx_));
+    }
     int rc = hspf_mask_words(ctx_, g, roots.data(), t.n_roots, &t.mask_words);
     if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_mask_words: ") + hspf_last_error(ctx_));
-    const size_t rn = (size_t)t.n_roots * t.n_vertices;
     t.dist.resize(rn); t.hops.resize(rn); t.flags.resize(rn); t.mask.resize(rn * t.mask_words);
     if (run_flags & HSPF_RUN_POP_RANK) t.pop_rank.resize(rn);
     hspf_result out{t.dist.data(), t.hops.data(), t.flags.data(), t.mask.data(), t.mask_words,
                     (run_flags & HSPF_RUN_POP_RANK) ? t.pop_rank.data() : nullptr};
     rc = hspf_run(ctx_, g, roots.data(), t.n_roots, run_flags, &out);
     if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_run: ") + hspf_last_error(ctx_));
+    last_handoff.run_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return t;
   }
+  bool use_packed = true;              // false: hspf_run for every run (the A/B of tests and of the end-to-end timing)
   SlotTable slot_table(Graph &gr, uint32_t root) override {
     hspf_graph *g = static_cast<HipGraph &>(gr).g;
     SlotTable st;
@@ -251,8 +333,84 @@ class HipEngine : public Engine {
     if (!ok) throw std::runtime_error(std::string("hspf_routes_device: ") + hspf_last_error(ctx_));
     return o;
   }
+  std::unique_ptr<DeviceRoutes> routes_device(DeviceRun &run, const std::vector<uint32_t> &pfx_ptr, const std::vector<uint32_t> &pfx_vertex,
+                                              const std::vector<uint32_t> &pfx_metric, uint32_t flags) override {
+    auto &r = static_cast<HipDeviceRun &>(run);
+    auto o = std::make_unique<HipDeviceRoutes>();
+    o->n_roots = r.n_roots; o->n_prefixes = (uint32_t)pfx_ptr.size() - 1; o->mask_words = r.mask_words;
+    if (!o->alloc()) throw std::runtime_error("hipMalloc of the route tables failed");
+    if (o->n_prefixes == 0) return o;
+    static const uint32_t zero = 0;
+    hspf_prefix_table tab{o->n_prefixes, (uint32_t)pfx_vertex.size(), pfx_ptr.data(), pfx_vertex.empty() ? &zero : pfx_vertex.data(),
+                          pfx_metric.empty() ? &zero : pfx_metric.data(), flags};
+    hspf_routes ro = o->raw();
+    const int rc = hspf_routes_device(ctx_, r.n_vertices, r.n_roots, r.mask_words, r.dist, r.flags, r.mask, &tab, &ro);
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_routes_device: ") + hspf_last_error(ctx_));
+    return o;
+  }
+  std::unique_ptr<DeviceRoutes> routes_upload(const RoutesOut &t, uint32_t n_roots, uint32_t n_prefixes, uint32_t mask_words) override {
+    auto o = std::make_unique<HipDeviceRoutes>();
+    o->n_roots = n_roots; o->n_prefixes = n_prefixes; o->mask_words = mask_words;
+    const size_t rp = (size_t)n_roots * n_prefixes;
+    if (t.best_metric.size() != rp || t.best_entry.size() != rp || t.nexthop_mask.size() != rp * mask_words) throw std::runtime_error("routes_upload: table sizes");
+    if (!o->alloc()) throw std::runtime_error("hipMalloc of the route tables failed");
+    if (rp && (hipMemcpy(o->bm, t.best_metric.data(), rp * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(o->be, t.best_entry.data(), rp * 4, hipMemcpyHostToDevice) != hipSuccess ||
+               hipMemcpy(o->nm, t.nexthop_mask.data(), rp * 8 * mask_words, hipMemcpyHostToDevice) != hipSuccess))
+      throw std::runtime_error("hipMemcpy of the route tables failed");
+    return o;
+  }
+  RouteRecords routes_changed(DeviceRoutes &old_set, DeviceRoutes &new_set) override {
+    auto &a = static_cast<HipDeviceRoutes &>(old_set);
+    auto &b = static_cast<HipDeviceRoutes &>(new_set);
+    if (a.n_roots != b.n_roots || a.n_prefixes != b.n_prefixes || a.mask_words != b.mask_words) throw std::runtime_error("routes_changed: the two sets differ in shape");
+    RouteRecords out;
+    out.mask_words = b.mask_words;
+    const size_t rp = (size_t)b.n_roots * b.n_prefixes;
+    if (rp == 0) return out;
+    // scratch of the comparison (action bytes, changed list, per-root bounds): kept by the engine, grown on demand
+    const size_t need = rp + rp * 4 + ((size_t)b.n_roots + 1) * 4 + 64;
+    if (diff_cap_ < need) {
+      if (diff_) (void)hipFree(diff_);
+      diff_ = nullptr; diff_cap_ = 0;
+      if (hipMalloc(&diff_, need) != hipSuccess) throw std::runtime_error("hipMalloc of the diff scratch failed");
+      diff_cap_ = need;
+    }
+    uint32_t *changed = (uint32_t *)diff_, *cptr = changed + rp;
+    uint8_t *action = (uint8_t *)(cptr + b.n_roots + 1);
+    hspf_routes ro = a.raw(), rn = b.raw();
+    int rc = hspf_routes_diff_device(ctx_, b.n_roots, b.n_prefixes, b.mask_words, &ro, &rn, action, changed, cptr);
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_routes_diff_device: ") + hspf_last_error(ctx_));
+    const uint32_t k = hspf_routes_diff_count(ctx_);
+    out.words.assign((size_t)k * out.stride(), 0u);
+    if (k) {
+      rc = hspf_routes_pack(ctx_, b.n_roots, b.n_prefixes, b.mask_words, &rn, action, changed, cptr, k, out.words.data());
+      if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_routes_pack: ") + hspf_last_error(ctx_));
+      out.old_words.assign(out.words.size(), 0u);                    // the same list packed from the old set: what the route was
+      rc = hspf_routes_pack(ctx_, b.n_roots, b.n_prefixes, b.mask_words, &ro, action, changed, cptr, k, out.old_words.data());
+      if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_routes_pack (old set): ") + hspf_last_error(ctx_));
+    }
+    return out;
+  }
  private:
+  void *diff_ = nullptr;
+  size_t diff_cap_ = 0;
+  template <typename WT>
+  static void decode_row(const WT *w, const hspf_packed_layout &ly, uint16_t exact_flag, Tables &t, size_t o) {
+    const WT nr = (WT)ly.not_reached, hm = (WT)ly.hops_mask, mm = (WT)((1ull << ly.mask_bits) - 1ull);
+    const uint32_t ds = ly.dist_shift, hs = ly.hops_shift, n = t.n_vertices;
+    uint32_t *d = t.dist.data() + o; uint16_t *h = t.hops.data() + o, *f = t.flags.data() + o; uint64_t *m = t.mask.data() + o;
+    for (uint32_t v = 0; v < n; ++v) {
+      const WT x = w[v];
+      const bool in = x < nr;
+      d[v] = in ? (uint32_t)(x >> ds) : 0xFFFFFFFFu;
+      h[v] = in ? (uint16_t)((x >> hs) & hm) : (uint16_t)0;
+      f[v] = in ? (uint16_t)(HSPF_RF_IN_SPT | exact_flag) : (uint16_t)0;
+      m[v] = in ? (uint64_t)(x & mm) : 0ull;
+    }
+  }
   hspf_ctx *ctx_ = nullptr;
+  void *pin_ = nullptr;
+  size_t pin_cap_ = 0;
 };
 
 }  // namespace host

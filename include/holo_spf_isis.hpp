@@ -19,6 +19,7 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cstdint>
 #include <functional>
 #include <map>
@@ -221,22 +222,42 @@ class LevelGraph {
   // `trigger_lsps`, holo-isis/src/spf.rs:144,735): only their rows are rebuilt and — when the graph is on the device —
   // replaced there with hspf_graph_patch.  false (nothing touched) when the change is not a set of row replacements (a
   // vertex appeared or vanished, or the configuration the rows depend on changed): the caller builds a new LevelGraph.
+  // Host work is O(changed LSPs x log N) (+ one rebuild of the host CSR arrays when a row changes length): only the fragments of
+  // the changed LAN ids are looked at — the vertex set can only change through one of THEM gaining its first or losing its
+  // last live fragment (round 5; until then every refresh re-walked the whole LSDB: 55 ms at 100 000 LSPs for a one-LSP change).
   bool refresh(const Instance &inst, const std::vector<LanId> &changed) {
     const InstanceCfg &cfg = inst.config;
     const Lsdb &lsdb = lsdb_of(inst);
     if (cfg_key(cfg) != cfg_key_) return false;
-    auto frags = live_fragments(lsdb);
-    if (frags.size() != vids.size()) return false;
-    for (auto &kv : frags) if (!index.count(vertex_id(kv.first))) return false;
+    std::map<LanId, std::vector<const Lsp *>> frags;
     std::set<uint32_t> vs;
-    for (auto &lan : changed) { auto it = index.find(vertex_id(lan)); if (it != index.end()) vs.insert(it->second); }
+    for (auto &lan : changed) {
+      std::vector<const Lsp *> live;
+      for (const Lsp *l : lsdb.iter_for_lan_id(lan)) if (l->live()) live.push_back(l);
+      auto it = index.find(vertex_id(lan));
+      if (live.empty() != (it == index.end())) return false;        // a vertex appeared or vanished
+      if (it == index.end()) continue;
+      vs.insert(it->second);
+      frags[lan] = std::move(live);
+    }
     if (vs.empty()) return true;
     std::vector<uint32_t> vv(vs.begin(), vs.end());
     std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> rows;
     std::vector<uint8_t> fl;
-    for (uint32_t i : vv) { auto r = row(vids[i].lan_id, frags, lsdb, cfg); rows.push_back({r.col, r.metric}); fl.push_back(r.flags); }
+    bool same_len = true;
+    for (uint32_t i : vv) {
+      auto r = row(vids[i].lan_id, frags, lsdb, cfg);
+      same_len = same_len && r.col.size() == row_ptr[i + 1] - row_ptr[i];
+      rows.push_back({r.col, r.metric}); fl.push_back(r.flags);
+    }
     if (dev_) dev_engine_->patch(*dev_, vv, rows, fl);
-    splice_rows(row_ptr, col, metric, vflags, vv, rows, fl);
+    if (same_len) {                                                   // rows keep their lengths: written in place
+      for (size_t j = 0; j < vv.size(); ++j) {
+        std::copy(rows[j].first.begin(), rows[j].first.end(), col.begin() + row_ptr[vv[j]]);
+        std::copy(rows[j].second.begin(), rows[j].second.end(), metric.begin() + row_ptr[vv[j]]);
+        vflags[vv[j]] = fl[j];
+      }
+    } else splice_rows(row_ptr, col, metric, vflags, vv, rows, fl);
     return true;
   }
   uint32_t n() const { return (uint32_t)vids.size(); }
@@ -803,6 +824,341 @@ inline std::vector<RibRow> compute_spf_device_routes(const Instance &inst, Engin
   }
   return rows;
 }
+
+// ---- the wire step: update_global_rib, holo-isis/src/route.rs:254-312 ---------------------------------
+// What goes on the ibus after an SPF: RouteIpAdd for every route that is new or differs from the RIB held before (metric
+// or next hops), nothing for an unchanged one (:268-277), nothing for a route without next hops (CONNECTED, :283-287),
+// RouteIpDel for what was installed and is gone (:303-310); adds in prefix order first, then the withdrawals.
+struct IbusMsg {
+  bool add = true;
+  std::string prefix;
+  uint32_t metric = 0;
+  std::vector<std::pair<int, std::string>> nexthops;       // (ifindex, address), as the reference's BTreeSet<Nexthop> orders them
+  bool operator==(const IbusMsg &o) const { return add == o.add && prefix == o.prefix && (!add || (metric == o.metric && nexthops == o.nexthops)); }
+};
+namespace detail {
+inline std::vector<std::pair<int, std::string>> wire_nexthops(const std::vector<std::pair<std::string, std::string>> &nhs, const std::map<std::string, int> &ifindex) {
+  std::vector<std::tuple<int, IpKey, std::string>> v;
+  for (auto &n : nhs) { IpKey k = parse_ip(n.first); v.push_back({ifindex.at(n.second), k, n.first}); }
+  std::sort(v.begin(), v.end(), [](auto &a, auto &b) { return std::tie(std::get<0>(a), std::get<1>(a)) < std::tie(std::get<0>(b), std::get<1>(b)); });
+  std::vector<std::pair<int, std::string>> out;
+  for (auto &t : v) out.push_back({std::get<0>(t), std::get<2>(t)});
+  return out;
+}
+inline bool same_nexthops(std::vector<std::pair<std::string, std::string>> a, std::vector<std::pair<std::string, std::string>> b) {
+  std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+  return a == b;
+}
+}  // namespace detail
+
+// Host form: new RIB rows (as compute_spf returns them) against the rows held before.
+inline std::vector<IbusMsg> update_global_rib(const std::vector<RibRow> &new_rows, const std::vector<RibRow> &old_rows, const std::map<std::string, int> &ifindex) {
+  std::map<IpKey, const RibRow *> old;
+  for (auto &r : old_rows) old[parse_ip(r.prefix)] = &r;
+  std::vector<std::pair<IpKey, const RibRow *>> fresh;
+  for (auto &r : new_rows) fresh.push_back({parse_ip(r.prefix), &r});
+  std::stable_sort(fresh.begin(), fresh.end(), [](auto &a, auto &b) { return a.first < b.first; });
+  std::vector<IbusMsg> msgs;
+  for (auto &kr : fresh) {
+    const RibRow &r = *kr.second;
+    auto it = old.find(kr.first);
+    const RibRow *o = it == old.end() ? nullptr : it->second;
+    if (it != old.end()) old.erase(it);
+    if (o && o->metric == r.metric && detail::same_nexthops(o->nexthops, r.nexthops)) continue;
+    if (!r.nexthops.empty()) msgs.push_back(IbusMsg{true, r.prefix, r.metric, detail::wire_nexthops(r.nexthops, ifindex)});
+  }
+  for (auto &kv : old)
+    if (!kv.second->nexthops.empty()) msgs.push_back(IbusMsg{false, kv.second->prefix, 0, {}});
+  return msgs;
+}
+
+// The record stream of hspf_routes_pack (one root) -> messages.  A record is a CANDIDATE: the device compared metric and
+// first-hop slot masks, which is finer than the reference's comparison of next-hop sets (two slots may resolve to one
+// adjacency, the host truncates to max-paths) — each is confirmed against the old row here, on the few records only.
+inline std::vector<IbusMsg> expand_route_records(const RouteRecords &rec, const std::vector<std::string> &prefixes,
+                                                 const std::map<uint32_t, std::shared_ptr<VertexNexthop>> &slot_nh,
+                                                 const std::map<IpKey, const RibRow *> &old_rows, const std::map<std::string, int> &ifindex, uint32_t max_paths,
+                                                 bool dels_need_old = false) {
+  std::vector<IbusMsg> adds, dels;
+  const uint32_t W = rec.mask_words;
+  for (size_t k = 0; k < rec.count(); ++k) {
+    const uint32_t *r = rec.rec(k);
+    const std::string &prefix = prefixes.at(r[1]);
+    if (r[2] == HSPF_DIFF_WITHDRAW) {
+      if (r[4] != 0xFFFFFFFFu) continue;
+      if (dels_need_old) { auto oi = old_rows.find(parse_ip(prefix)); if (oi == old_rows.end() || oi->second->nexthops.empty()) continue; }   // (was never installed)
+      dels.push_back(IbusMsg{false, prefix, 0, {}});
+      continue;
+    }
+    if (r[2] != HSPF_DIFF_INSTALL) continue;
+    const bool v6 = prefix.find(':') != std::string::npos;
+    std::map<IpKey, std::pair<std::string, std::string>> nhs;
+    for (uint32_t w = 0; w < W; ++w) {
+      uint64_t m = (uint64_t)r[HSPF_ROUTE_REC_WORDS + 2 * w] | ((uint64_t)r[HSPF_ROUTE_REC_WORDS + 2 * w + 1] << 32);
+      while (m) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        auto it = slot_nh.find(w * 64 + b);
+        if (it == slot_nh.end()) continue;
+        const auto &addr = v6 ? it->second->ipv6 : it->second->ipv4;
+        if (addr) nhs[parse_ip(*addr)] = {*addr, it->second->iface_name.value_or("")};
+      }
+    }
+    std::vector<std::pair<std::string, std::string>> keep;
+    for (auto &kv : nhs) { if (keep.size() >= max_paths) break; keep.push_back(kv.second); }
+    auto oi = old_rows.find(parse_ip(prefix));
+    if (oi != old_rows.end() && oi->second->metric == r[3] && detail::same_nexthops(oi->second->nexthops, keep)) continue;   // the reference's "unchanged" (:268-277)
+    if (!keep.empty()) adds.push_back(IbusMsg{true, prefix, r[3], detail::wire_nexthops(keep, ifindex)});
+  }
+  adds.insert(adds.end(), dels.begin(), dels.end());
+  return adds;
+}
+
+// compute_spf + update_global_rib with the SPT, the prefix attachment, the comparison with the RIB held before and the
+// compaction of what changed ALL on the device; one record stream comes back.  One (level, topology) table — the shape of
+// every IS-IS step fixture; the L1 / L2 merge of a two-level instance is host logic (compute_spf).  `n_records`: how many
+// records crossed the bus.  Python twin: holo_amd.routes.update_global_rib_device.
+inline std::vector<IbusMsg> update_global_rib_device(const Instance &inst, Engine &engine, const std::vector<RibRow> &rib_before,
+                                                     const std::map<std::string, int> &ifindex, size_t *n_records = nullptr, size_t *n_prefixes = nullptr) {
+  const InstanceCfg &cfg = inst.config;
+  if (n_records) *n_records = 0;
+  if (n_prefixes) *n_prefixes = 0;
+  std::vector<std::pair<int, int>> tabs;
+  for (int lv : cfg.levels()) for (int mt : {MT_STANDARD, MT_IPV6_UNICAST}) if (cfg.is_topology_enabled(mt)) tabs.push_back({lv, mt});
+  if (tabs.size() != 1) throw std::invalid_argument("update_global_rib_device: one (level, topology) table only");
+  const int level = tabs[0].first, mt_id = tabs[0].second;
+  std::map<IpKey, const RibRow *> old_rows;
+  for (auto &r : rib_before) old_rows[parse_ip(r.prefix)] = &r;
+  LevelGraph g(inst, level, mt_id, false);
+  auto ri = g.index.find(vertex_id(LanId{cfg.system_id, 0}));
+  PrefixTable table;
+  if (ri != g.index.end()) table = PrefixTable::build(inst, level, mt_id, g);
+  if (ri == g.index.end() || table.prefixes.empty()) return update_global_rib({}, rib_before, ifindex);   // no SPT / nothing advertised
+  // ONE prefix list for both sides: the table's prefixes plus those only the old RIB knows (no entries: no new route)
+  std::map<IpKey, std::string> keys;
+  for (auto &p : table.prefixes) keys[parse_ip(p)] = p;
+  for (auto &kv : old_rows) keys.emplace(kv.first, kv.second->prefix);
+  std::vector<std::string> prefixes;
+  std::map<IpKey, uint32_t> where;
+  for (auto &kv : keys) { where[kv.first] = (uint32_t)prefixes.size(); prefixes.push_back(kv.second); }
+  const uint32_t P = (uint32_t)prefixes.size();
+  std::vector<uint32_t> ptr(P + 1, 0);
+  for (size_t j = 0; j < table.prefixes.size(); ++j) ptr[where[parse_ip(table.prefixes[j])] + 1] = table.pfx_ptr[j + 1] - table.pfx_ptr[j];
+  for (uint32_t i = 0; i < P; ++i) ptr[i + 1] += ptr[i];               // (table.prefixes is sorted the same way: the entries keep their order)
+  Graph &dev = g.device(engine);
+  const uint32_t root = ri->second, n = g.n();
+  auto run = engine.run_device(dev, {root}, g.run_flags);
+  auto fresh = engine.routes_device(*run, ptr, table.pfx_vertex, table.pfx_metric, 0);
+  // first-hop slots -> next hops (needs Interface / Adjacency objects: host, once per slot)
+  auto res = std::make_shared<Tables>(run->host_tables());
+  const uint32_t W = res->mask_words;
+  detail::RunView r{res->dist.data(), res->hops.data(), res->flags.data(), res->mask.data(), W};
+  std::function<RankKey(uint32_t)> rank;
+  bool exact = false;
+  for (uint32_t v = 0; v < n; ++v) exact |= (res->flags[v] & HSPF_RF_EXACT) != 0;
+  std::shared_ptr<Tables> rr;
+  if (exact) {
+    rr = std::make_shared<Tables>(engine.run(dev, {root}, g.run_flags | HSPF_RUN_POP_RANK));
+    rank = [rr](uint32_t v) { return RankKey{rr->pop_rank[v], 0, 0, 0}; };
+  } else rank = [r](uint32_t v) { return RankKey{r.dist[v], v, 0, 0}; };
+  const auto slot_nh = detail::slot_nexthops(g, engine.slot_table(dev, root), r, rank, true, level, inst);
+  // the OLD RIB in the same index space: metric, and the slots whose next hop the old route used.  A next hop of the old
+  // route that no slot resolves to any more (its adjacency is gone) cannot be expressed: the metric is poisoned so that
+  // the pair compares unequal and the host decides.
+  RoutesOut old;
+  old.best_metric.assign(P, 0xFFFFFFFFu); old.best_entry.assign(P, 0xFFFFFFFFu); old.nexthop_mask.assign((size_t)P * W, 0);
+  for (auto &kv : old_rows) {
+    const uint32_t i = where[kv.first];
+    const RibRow &row = *kv.second;
+    const bool v6 = row.prefix.find(':') != std::string::npos;
+    std::set<std::pair<std::string, std::string>> want(row.nexthops.begin(), row.nexthops.end()), seen;
+    for (auto &sn : slot_nh) {
+      const auto &addr = v6 ? sn.second->ipv6 : sn.second->ipv4;
+      if (!addr) continue;
+      const std::pair<std::string, std::string> key{*addr, sn.second->iface_name.value_or("")};
+      if (want.count(key)) { old.nexthop_mask[(size_t)i * W + sn.first / 64] |= 1ull << (sn.first % 64); seen.insert(key); }
+    }
+    // (more next hops than max-paths allows NOW: the new route will be truncated on the host: not comparable by mask)
+    old.best_metric[i] = (seen == want && want.size() <= cfg.max_paths) ? row.metric : 0xFFFFFFFEu;
+    old.best_entry[i] = 0;
+    bool any = false;
+    for (uint32_t w = 0; w < W; ++w) any |= old.nexthop_mask[(size_t)i * W + w] != 0;
+    if (!want.empty() && !any) old.nexthop_mask[(size_t)i * W] = 1;      // "it was installed with next hops" (the poisoned metric keeps the pair unequal)
+  }
+  auto before = engine.routes_upload(old, 1, P, W);
+  const RouteRecords rec = engine.routes_changed(*before, *fresh);
+  if (n_records) *n_records = rec.count();
+  if (n_prefixes) *n_prefixes = P;
+  return expand_route_records(rec, prefixes, slot_nh, old_rows, ifindex, cfg.max_paths);
+}
+
+// The same step for a RUNNING instance: everything that does not change with one LSP is kept — the level graph on the
+// device (rows patched per changed LSP, LevelGraph::refresh), the prefix table on the device (HSPF_PFX_RESIDENT; rebuilt
+// only when a changed LSP's prefixes differ), and the route tables of the PREVIOUS run as the "RIB held before" (device
+// resident: nothing is uploaded, nothing but the changed records comes back — packed once from the new set and once from the
+// old one, so that the host sees what each changed route WAS).  The first-hop slots are resolved again every step (which
+// relaxations the root makes depends on distances elsewhere); when a slot comes to mean another next hop, or the prefix list
+// changed, the old tables are void and the step compares against the routes the host knows installed (`rib()`), record by
+// record.  step() = trigger_lsps -> messages.  One (level, topology), local root; interfaces / adjacencies as at
+// construction (an adjacency change is a new pipeline).
+class RibPipeline {
+ public:
+  RibPipeline(const Instance &inst, Engine &engine, int level, int mt_id, const std::map<std::string, int> &ifindex)
+      : engine_(engine), level_(level), mt_(mt_id), ifindex_(ifindex), graph_(std::make_unique<LevelGraph>(inst, level, mt_id, false)) {
+    rebuild_tables(inst);
+  }
+  struct Timing { double refresh_ms = 0, run_ms = 0, routes_ms = 0, slots_ms = 0, diff_pack_ms = 0, expand_ms = 0; size_t records = 0; bool full = false; };
+  Timing last;
+  // First call: every route is new (the RIB before is empty).  Later calls: `changed` = LAN ids whose LSPs differ.
+  std::vector<IbusMsg> step(const Instance &inst, const std::vector<LanId> &changed) {
+    using C = std::chrono::steady_clock;
+    auto ms = [](C::time_point a) { return std::chrono::duration<double, std::milli>(C::now() - a).count(); };
+    last = Timing{};
+    auto t = C::now();
+    if (!changed.empty()) {
+      if (!graph_->refresh(inst, changed)) { graph_ = std::make_unique<LevelGraph>(inst, level_, mt_, false); rebuild_tables(inst); prev_.reset(); last.full = true; }
+      else {
+        bool pfx = false;
+        for (auto &lan : changed) pfx = pfx || prefixes_of(inst, lan) != pfx_sig_[lan];
+        if (pfx) { rebuild_tables(inst); prev_.reset(); last.full = true; }
+      }
+    }
+    last.refresh_ms = ms(t);
+    const InstanceCfg &cfg = inst.config;
+    auto ri = graph_->index.find(vertex_id(LanId{cfg.system_id, 0}));
+    if (ri == graph_->index.end() || table_.prefixes.empty()) { prev_.reset(); return {}; }
+    t = C::now();
+    Graph &dev = graph_->device(engine_);
+    const uint32_t root = ri->second;
+    auto run = engine_.run_device(dev, {root}, graph_->run_flags);
+    last.run_ms = ms(t); t = C::now();
+    auto fresh = engine_.routes_device(*run, table_.pfx_ptr, table_.pfx_vertex, table_.pfx_metric, resident_ ? (uint32_t)HSPF_PFX_RESIDENT : 0u);
+    resident_ = true;
+    last.routes_ms = ms(t); t = C::now();
+    {
+      // first-hop slots -> next hops, every step: which relaxations the root makes, and in which order resolve_nexthop hands
+      // out adjacencies, depends on distances elsewhere in the graph (spf.rs:680-701), not only on the root's own rows
+      auto res = std::make_shared<Tables>(run->host_tables());
+      detail::RunView r{res->dist.data(), res->hops.data(), res->flags.data(), res->mask.data(), res->mask_words};
+      std::function<RankKey(uint32_t)> rank = [r](uint32_t v) { return RankKey{r.dist[v], v, 0, 0}; };
+      bool exact = false;
+      for (uint32_t v = 0; v < graph_->n(); ++v) exact |= (res->flags[v] & HSPF_RF_EXACT) != 0;
+      std::shared_ptr<Tables> rr;
+      if (exact) { rr = std::make_shared<Tables>(engine_.run(dev, {root}, graph_->run_flags | HSPF_RUN_POP_RANK)); rank = [rr](uint32_t v) { return RankKey{rr->pop_rank[v], 0, 0, 0}; }; }
+      auto nh = detail::slot_nexthops(*graph_, engine_.slot_table(dev, root), r, rank, true, level_, inst);
+      if (prev_ && !same_slots(nh, slot_nh_)) prev_.reset();           // a slot means another next hop now: the old masks are void
+      slot_nh_ = std::move(nh);
+    }
+    last.slots_ms = ms(t); t = C::now();
+    const uint32_t P = (uint32_t)table_.prefixes.size(), W = fresh->mask_words;
+    const bool host_old = !prev_;
+    if (host_old) {                                                   // nothing comparable on the device: the routes the host knows to be installed
+      RoutesOut old;
+      old.best_metric.assign(P, 0xFFFFFFFFu); old.best_entry.assign(P, 0xFFFFFFFFu); old.nexthop_mask.assign((size_t)P * W, 0);
+      for (auto &kv : rib_) {
+        auto wi = where_.find(kv.first);
+        if (wi == where_.end()) continue;
+        old.best_metric[wi->second] = 0xFFFFFFFEu; old.best_entry[wi->second] = 0;         // poisoned: every such pair comes back and the host decides
+        if (!kv.second.nexthops.empty()) old.nexthop_mask[(size_t)wi->second * W] = 1;
+      }
+      prev_ = engine_.routes_upload(old, 1, P, W);
+      last.full = true;
+    }
+    const RouteRecords rec = engine_.routes_changed(*prev_, *fresh);
+    last.diff_pack_ms = ms(t); t = C::now();
+    last.records = rec.count();
+    // the route each record REPLACES: from the host's view after a reset, else from the old set's own record (metric + slot
+    // masks resolved like the new ones: equal resolved next hops = the reference's "unchanged", route.rs:268-277)
+    std::vector<RibRow> old_store;
+    old_store.reserve(rec.count());
+    std::map<IpKey, const RibRow *> old_rows;
+    for (size_t k = 0; k < rec.count(); ++k) {
+      const std::string &prefix = table_.prefixes.at(rec.rec(k)[1]);
+      const IpKey key = parse_ip(prefix);
+      if (host_old) { auto it = rib_.find(key); if (it != rib_.end()) old_rows[key] = &it->second; continue; }
+      const uint32_t *o = rec.old_rec(k);
+      if (o[4] == 0xFFFFFFFFu) continue;                               // no route before
+      RibRow row{prefix, o[3], level_, {}};
+      const bool v6 = prefix.find(':') != std::string::npos;
+      std::map<IpKey, std::pair<std::string, std::string>> nhs;
+      for (uint32_t w = 0; w < W; ++w) {
+        uint64_t m = (uint64_t)o[HSPF_ROUTE_REC_WORDS + 2 * w] | ((uint64_t)o[HSPF_ROUTE_REC_WORDS + 2 * w + 1] << 32);
+        while (m) {
+          const int b = __builtin_ctzll(m);
+          m &= m - 1;
+          auto it = slot_nh_.find(w * 64 + b);
+          if (it == slot_nh_.end()) continue;
+          const auto &addr = v6 ? it->second->ipv6 : it->second->ipv4;
+          if (addr) nhs[parse_ip(*addr)] = {*addr, it->second->iface_name.value_or("")};
+        }
+      }
+      for (auto &kv : nhs) { if (row.nexthops.size() >= cfg.max_paths) break; row.nexthops.push_back(kv.second); }
+      old_store.push_back(std::move(row));
+      old_rows[key] = &old_store.back();
+    }
+    std::vector<IbusMsg> msgs = expand_route_records(rec, table_.prefixes, slot_nh_, old_rows, ifindex_, cfg.max_paths, true);
+    // prefixes the host knows installed and the (rebuilt) table does not list any more
+    if (host_old)
+      for (auto &kv : rib_) if (!where_.count(kv.first) && !kv.second.nexthops.empty()) msgs.push_back(IbusMsg{false, kv.second.prefix, 0, {}});
+    apply(msgs);
+    prev_ = std::move(fresh);
+    last.expand_ms = ms(t);
+    return msgs;
+  }
+  const std::map<IpKey, RibRow> &rib() const { return rib_; }         // the routes that were put on the wire (installed routes)
+  LevelGraph &graph() { return *graph_; }
+
+ private:
+  static bool same_slots(const std::map<uint32_t, std::shared_ptr<VertexNexthop>> &a, const std::map<uint32_t, std::shared_ptr<VertexNexthop>> &b) {
+    if (a.size() != b.size()) return false;
+    for (auto ia = a.begin(), ib = b.begin(); ia != a.end(); ++ia, ++ib)
+      if (ia->first != ib->first || ia->second->system_id != ib->second->system_id || ia->second->iface_name != ib->second->iface_name ||
+          ia->second->ipv4 != ib->second->ipv4 || ia->second->ipv6 != ib->second->ipv6) return false;
+    return true;
+  }
+  using PfxSig = std::vector<std::tuple<std::string, uint32_t, bool>>;
+  PfxSig prefixes_of(const Instance &inst, const LanId &lan) const {
+    PfxSig out;
+    auto li = inst.lsdb.find(level_);
+    if (li == inst.lsdb.end()) return out;
+    const Lsp *z = li->second.zeroth_lsp(lan);
+    if (!z) return out;
+    const InstanceCfg &cfg = inst.config;
+    const bool att = !cfg.att_ignore && z->att_bit(mt_) && !z->overload_bit(mt_);
+    const bool v4 = cfg.ipv4_enabled && mt_ == MT_STANDARD;
+    const bool v6 = cfg.ipv6_enabled && (mt_ == MT_STANDARD ? !cfg.is_topology_enabled(MT_IPV6_UNICAST) : true);
+    for (auto &nw : vertex_networks(inst, level_, mt_, lan, att, inst.is_l2_attached_to_backbone(mt_), v4, v6)) out.push_back({nw.prefix, nw.metric, nw.external});
+    return out;
+  }
+  void rebuild_tables(const Instance &inst) {
+    table_ = PrefixTable::build(inst, level_, mt_, *graph_);
+    where_.clear();
+    for (size_t i = 0; i < table_.prefixes.size(); ++i) where_[parse_ip(table_.prefixes[i])] = (uint32_t)i;
+    pfx_sig_.clear();
+    for (auto &vid : graph_->vids) pfx_sig_[vid.lan_id] = prefixes_of(inst, vid.lan_id);
+    resident_ = false;
+  }
+  void apply(const std::vector<IbusMsg> &msgs) {
+    for (auto &m : msgs) {
+      const IpKey k = parse_ip(m.prefix);
+      if (!m.add) { rib_.erase(k); continue; }
+      RibRow row{m.prefix, m.metric, level_, {}};
+      for (auto &nh : m.nexthops) { std::string ifn; for (auto &kv : ifindex_) if (kv.second == nh.first) ifn = kv.first; row.nexthops.push_back({nh.second, ifn}); }
+      rib_[k] = std::move(row);
+    }
+  }
+  Engine &engine_;
+  int level_, mt_;
+  std::map<std::string, int> ifindex_;
+  std::unique_ptr<LevelGraph> graph_;
+  PrefixTable table_;
+  std::map<IpKey, uint32_t> where_;
+  std::map<LanId, PfxSig> pfx_sig_;
+  std::map<uint32_t, std::shared_ptr<VertexNexthop>> slot_nh_;
+  std::unique_ptr<DeviceRoutes> prev_;
+  std::map<IpKey, RibRow> rib_;
+  bool resident_ = false;
+};
 
 // ---- flooding::manet (holo-isis/src/flooding/manet.rs) ---------------------------------------------------------------
 namespace flooding {

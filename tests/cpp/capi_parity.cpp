@@ -447,6 +447,78 @@ int main(int argc, char **argv) {
       ++big_lan;
     }
   }
+  // ABI 7: packed results through the C ABI — hspf_run_packed (page-locked and pageable destinations), hspf_run_packed_async
+  // with three tickets in flight, hspf_run_packed_device; every word decoded with the header's inline helpers against the
+  // oracle; HSPF_E_NO_PACKED for roots on a 40-router LAN
+  int packed_runs = 0;
+  {
+    rng_state = 0x5EED5EED5EEDull;
+    Lsdb g = make(900, 0, 71);
+    hspf::Graph G = eng.upload(g.row_ptr, g.col, g.metric, g.vflags, 0xFE000000u);
+    std::vector<std::vector<u32>> sets;
+    for (u32 base : {0u, 100u, 300u}) { std::vector<u32> r; for (u32 k = 0; k < 64 + base / 100; ++k) r.push_back(base + k); sets.push_back(r); }
+    auto check_words = [&](const std::vector<u32> &roots, const hspf_packed_layout &ly, const void *words, const uint8_t *status) -> int {
+      const size_t rn = (size_t)roots.size() * g.n;
+      std::vector<u32> d(rn), pr(rn), nn(rn), np(rn); std::vector<uint16_t> h(rn), f(rn); std::vector<uint64_t> m(rn), wk(roots.size());
+      CHECK(oracle(g.n, (u32)g.col.size(), g.row_ptr.data(), g.col.data(), g.metric.data(), g.vflags.data(), 0xFE000000u, roots.data(), (u32)roots.size(), 0, 2,
+                   d.data(), h.data(), f.data(), pr.data(), m.data(), 1, nn.data(), np.data(), wk.data()) == 0, "oracle failed");
+      CHECK(ly.word_bytes == 4 || ly.word_bytes == 8, "word_bytes");
+      for (size_t i = 0; i < rn; ++i) {
+        const uint64_t w = hspf_packed_word(&ly, words, i);
+        CHECK((hspf_packed_in_spt(&ly, w) != 0) == ((f[i] & 1) != 0) && hspf_packed_dist(&ly, w) == d[i] && hspf_packed_hops(&ly, w) == h[i] && hspf_packed_mask(&ly, w) == m[i],
+              "packed word differs from the oracle");
+      }
+      for (size_t r = 0; r < roots.size(); ++r) CHECK((status[r] & ~HSPF_ROOT_EXACT) == 0, "root status");
+      ++packed_runs;
+      return 0;
+    };
+    const size_t cap = (size_t)8 * 70 * g.n;
+    void *pin[3] = {nullptr, nullptr, nullptr};
+    for (auto &p : pin) CHECK(hspf_host_alloc(eng.raw(), cap, &p) == HSPF_OK && p, "hspf_host_alloc");
+    std::vector<uint8_t> pageable(cap), status(70);
+    for (auto &roots : sets) {
+      hspf_packed_layout ly{};
+      CHECK(hspf_run_packed(eng.raw(), G.raw(), roots.data(), (u32)roots.size(), 0, pin[0], cap, &ly, status.data()) == HSPF_OK, hspf_last_error(eng.raw()));
+      if (check_words(roots, ly, pin[0], status.data())) return 1;
+      CHECK(hspf_run_packed(eng.raw(), G.raw(), roots.data(), (u32)roots.size(), 0, pageable.data(), cap, &ly, status.data()) == HSPF_OK, hspf_last_error(eng.raw()));
+      if (check_words(roots, ly, pageable.data(), status.data())) return 1;
+    }
+    uint64_t tk[3]; std::vector<uint8_t> st3[3];
+    for (int i = 0; i < 3; ++i) { st3[i].assign(70, 0); CHECK(hspf_run_packed_async(eng.raw(), G.raw(), sets[i].data(), (u32)sets[i].size(), 0, pin[i], cap, st3[i].data(), &tk[i]) == HSPF_OK, "hspf_run_packed_async"); }
+    for (int i = 0; i < 3; ++i) {
+      hspf_packed_layout ly{}; hspf_stats st{};
+      CHECK(hspf_wait_packed(eng.raw(), tk[i], &ly, &st) == HSPF_OK && st.n_roots == sets[i].size(), hspf_last_error(eng.raw()));
+      if (check_words(sets[i], ly, pin[i], st3[i].data())) return 1;
+    }
+    {
+      void *dw = nullptr; hipMalloc(&dw, cap);
+      hspf_packed_layout ly{};
+      CHECK(hspf_run_packed_device(eng.raw(), G.raw(), sets[2].data(), (u32)sets[2].size(), 0, dw, cap, &ly, status.data()) == HSPF_OK, hspf_last_error(eng.raw()));
+      hipMemcpy(pageable.data(), dw, (size_t)ly.word_bytes * sets[2].size() * g.n, hipMemcpyDeviceToHost);
+      if (check_words(sets[2], ly, pageable.data(), status.data())) return 1;
+      hipFree(dw);
+    }
+    hspf_packed_layout ly{};
+    CHECK(hspf_run_packed(eng.raw(), G.raw(), sets[0].data(), 64, HSPF_RUN_POP_RANK, pin[0], cap, &ly, nullptr) == HSPF_E_INVAL, "pop rank with packed words must be HSPF_E_INVAL");
+    CHECK(hspf_run_packed(eng.raw(), G.raw(), sets[0].data(), 64, 0, pin[0], 1000, &ly, nullptr) == HSPF_E_INVAL, "a too small buffer must be HSPF_E_INVAL");
+    // a LAN of 40 routers: its members have 40+ first-hop slots
+    Lsdb l; l.n = 60; l.vflags.assign(60, 0); l.vflags[0] = HSPF_VF_NETWORK;
+    std::vector<std::vector<std::pair<u32, u32>>> rows(60);
+    for (u32 r = 1; r <= 40; ++r) { rows[r].push_back({0, 10}); rows[0].push_back({r, 0}); }
+    for (u32 r = 41; r < 60; ++r) { rows[r].push_back({r - 1, 3}); rows[r - 1].push_back({r, 3}); }
+    l.row_ptr.assign(61, 0);
+    for (u32 u = 0; u < 60; ++u) { for (auto &e : rows[u]) { l.col.push_back(e.first); l.metric.push_back(e.second); } l.row_ptr[u + 1] = (u32)l.col.size(); }
+    hspf::Graph GL = eng.upload(l.row_ptr, l.col, l.metric, l.vflags, 0xFE000000u);
+    const u32 on_lan[2] = {1, 50}, off_lan[2] = {50, 55};
+    CHECK(hspf_run_packed(eng.raw(), GL.raw(), on_lan, 2, 0, pin[0], cap, &ly, nullptr) == HSPF_E_NO_PACKED, "more than 24 slots must be HSPF_E_NO_PACKED");
+    CHECK(hspf_run_packed(eng.raw(), GL.raw(), off_lan, 2, 0, pin[0], cap, &ly, status.data()) == HSPF_OK, hspf_last_error(eng.raw()));
+    hspf::PackedTables pt = eng.run_packed(GL, std::vector<u32>{50, 55});
+    hspf::Tables tt = eng.run(GL, std::vector<u32>{50, 55});
+    for (u32 r = 0; r < 2; ++r) for (u32 v = 0; v < 60; ++v)
+      CHECK(pt.dist(r, v) == tt.dist[r * 60 + v] && pt.hops(r, v) == tt.hops[r * 60 + v] && pt.mask(r, v) == tt.mask[r * 60 + v] && pt.in_spt(r, v) == ((tt.flags[r * 60 + v] & 1) != 0), "PackedTables accessors");
+    for (auto &p : pin) hspf_host_free(eng.raw(), p);
+  }
+  std::printf("capi_parity: %d packed-result runs (pinned, pageable, in flight, device) bit-exact after decode\n", packed_runs);
   std::printf("capi_parity: %d graph runs bit-exact, %d patched generations + %d in-place cost patches bit-exact, error contract ok, device route derivation ok, %d packed record stream(s) ok, %d sharded tables identical to the unsharded run, %d runs on a 3 000-router LAN (hub-mode build, giant row) bit-exact, %d asynchronous runs (in flight on the lanes) identical to the synchronous ones\n", checked, patched, cost_patched, packed, sharded, big_lan, async_checked);
   return 0;
 }

@@ -6,8 +6,6 @@
 //   host_parity --engine oracle <files...>     CPU stand-in for the ENGINE ONLY (oracle/liboracle_spf.so, dlopen'ed;
 //                                              TEST INFRASTRUCTURE): checks the host logic where there is no GPU
 // Exit codes: 0 every vector reproduced, 1 mismatch / error, 77 --engine hip without a HIP device.
-#include <dlfcn.h>
-
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -20,118 +18,7 @@ using namespace hspf::host;
 namespace I = hspf::host::isis;
 namespace O = hspf::host::ospf;
 
-// ---- CPU stand-in for the engine (tests only) ----------------------------------------------------------------------
-typedef int (*oracle_run_t)(uint32_t, uint32_t, const uint32_t *, const uint32_t *, const uint32_t *, const uint8_t *, uint32_t,
-                            const uint32_t *, uint32_t, uint32_t, int, uint32_t *, uint16_t *, uint16_t *, uint32_t *, uint64_t *,
-                            uint32_t, uint32_t *, uint32_t *, uint64_t *);
-struct OracleGraph : Graph {
-  std::vector<uint32_t> row_ptr, col, metric;
-  std::vector<uint8_t> vflags;
-  uint32_t max_path;
-};
-class OracleEngine : public Engine {
- public:
-  explicit OracleEngine(const std::string &so) {
-    void *h = dlopen(so.c_str(), RTLD_NOW);
-    if (!h) throw std::runtime_error("dlopen " + so + " (run `make -C oracle`)");
-    run_ = (oracle_run_t)dlsym(h, "oracle_spf_run");
-    if (!run_) throw std::runtime_error("oracle_spf_run");
-  }
-  std::unique_ptr<Graph> upload(const std::vector<uint32_t> &rp, const std::vector<uint32_t> &c, const std::vector<uint32_t> &m,
-                                const std::vector<uint8_t> &vf, uint32_t mp) override {
-    auto g = std::make_unique<OracleGraph>();
-    g->row_ptr = rp; g->col = c; g->metric = m; g->vflags = vf; g->max_path = mp;
-    return g;
-  }
-  SlotTable slot_table(Graph &gr, uint32_t root) override {          // restatement of include/holo_spf_hip.h "first-hop slots"
-    auto &g = static_cast<OracleGraph &>(gr);
-    SlotTable st;
-    st.vertex = {root}; st.base = {0};
-    st.total = g.row_ptr[root + 1] - g.row_ptr[root];
-    std::vector<char> seen(g.vflags.size(), 0);
-    seen[root] = 1;
-    for (size_t qi = 0; qi < st.vertex.size(); ++qi) {
-      const uint32_t p = st.vertex[qi];
-      for (uint32_t k = g.row_ptr[p]; k < g.row_ptr[p + 1]; ++k) {
-        const uint32_t t = g.col[k];
-        bool back = false;
-        for (uint32_t k2 = g.row_ptr[t]; k2 < g.row_ptr[t + 1]; ++k2) back |= g.col[k2] == p;
-        if (seen[t] || !(g.vflags[t] & HSPF_VF_NETWORK) || !back) continue;
-        seen[t] = 1;
-        st.vertex.push_back(t); st.base.push_back(st.total);
-        st.total += g.row_ptr[t + 1] - g.row_ptr[t];
-      }
-    }
-    return st;
-  }
-  void patch(Graph &gr, const std::vector<uint32_t> &vertices,
-             const std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> &rows, const std::vector<uint8_t> &vflags) override {
-    auto &g = static_cast<OracleGraph &>(gr);
-    splice_rows(g.row_ptr, g.col, g.metric, g.vflags, vertices, rows, vflags);
-    ++patches;
-  }
-  int patches = 0;
-  struct OracleRun : DeviceRun { Tables t; Tables host_tables() override { return t; } };
-  std::unique_ptr<DeviceRun> run_device(Graph &gr, const std::vector<uint32_t> &roots, uint32_t run_flags) override {
-    auto r = std::make_unique<OracleRun>();
-    r->t = run(gr, roots, run_flags);
-    r->n_roots = r->t.n_roots; r->n_vertices = r->t.n_vertices; r->mask_words = r->t.mask_words;
-    return r;
-  }
-  // restatement of the per-prefix reduction of hspf_routes_device (include/holo_spf_hip.h)
-  RoutesOut routes(DeviceRun &run, const std::vector<uint32_t> &ptr, const std::vector<uint32_t> &vtx, const std::vector<uint32_t> &met, uint32_t flags) override {
-    const Tables &t = static_cast<OracleRun &>(run).t;
-    const uint32_t P = (uint32_t)ptr.size() - 1, W = t.mask_words, n = t.n_vertices;
-    RoutesOut o;
-    o.best_metric.assign((size_t)t.n_roots * P, 0xFFFFFFFFu); o.best_entry.assign((size_t)t.n_roots * P, 0xFFFFFFFFu); o.nexthop_mask.assign((size_t)t.n_roots * P * W, 0);
-    const bool sat = flags & HSPF_PFX_SATURATING, last = flags & HSPF_PFX_LAST_MIN;
-    for (uint32_t r = 0; r < t.n_roots; ++r)
-      for (uint32_t p = 0; p < P; ++p) {
-        uint32_t best = 0xFFFFFFFFu, ent = 0xFFFFFFFFu;
-        std::vector<uint64_t> acc(W, 0);
-        for (uint32_t e = ptr[p]; e < ptr[p + 1]; ++e) {
-          const size_t i = (size_t)r * n + vtx[e];
-          if (!(t.flags[i] & 1)) continue;
-          uint32_t m = t.dist[i] + met[e];
-          if (sat && m < t.dist[i]) m = 0xFFFFFFFFu;
-          if (ent == 0xFFFFFFFFu || m < best || (last && m == best)) { best = m; ent = e; for (uint32_t w = 0; w < W; ++w) acc[w] = t.mask[i * W + w]; }
-          else if (m == best) for (uint32_t w = 0; w < W; ++w) acc[w] |= t.mask[i * W + w];
-        }
-        const size_t oi = (size_t)r * P + p;
-        o.best_metric[oi] = best; o.best_entry[oi] = ent;
-        for (uint32_t w = 0; w < W; ++w) o.nexthop_mask[oi * W + w] = acc[w];
-      }
-    return o;
-  }
-  Tables run(Graph &gr, const std::vector<uint32_t> &roots, uint32_t run_flags) override {
-    auto &g = static_cast<OracleGraph &>(gr);
-    Tables t;
-    t.n_roots = (uint32_t)roots.size(); t.n_vertices = (uint32_t)g.vflags.size();
-    uint32_t words = 1;
-    for (uint32_t r : roots) words = std::max(words, (slot_table(gr, r).total + 63) / 64);
-    t.mask_words = words;
-    const size_t rn = (size_t)t.n_roots * t.n_vertices;
-    t.dist.resize(rn); t.hops.resize(rn); t.flags.resize(rn); t.pop_rank.resize(rn); t.mask.resize(rn * words);
-    const int rc = run_(t.n_vertices, (uint32_t)g.col.size(), g.row_ptr.data(), g.col.data(), g.metric.data(), g.vflags.data(), g.max_path,
-                        roots.data(), t.n_roots, run_flags & 3u, /*MAP*/ 1, t.dist.data(), t.hops.data(), t.flags.data(), t.pop_rank.data(),
-                        t.mask.data(), words, nullptr, nullptr, nullptr);
-    if (rc != 0) throw std::runtime_error("oracle_spf_run failed");
-    // like the real engine: tell the caller which roots did not pop in the static (distance, index) order
-    const uint32_t n = t.n_vertices;
-    for (uint32_t j = 0; j < t.n_roots; ++j) {
-      std::vector<uint32_t> mem;
-      for (uint32_t v = 0; v < n; ++v) if (t.flags[(size_t)j * n + v] & 1) mem.push_back(v);
-      auto a = mem, b = mem;
-      std::stable_sort(a.begin(), a.end(), [&](uint32_t x, uint32_t y) { return std::make_pair(t.dist[(size_t)j * n + x], x) < std::make_pair(t.dist[(size_t)j * n + y], y); });
-      std::stable_sort(b.begin(), b.end(), [&](uint32_t x, uint32_t y) { return t.pop_rank[(size_t)j * n + x] < t.pop_rank[(size_t)j * n + y]; });
-      if (a != b) for (uint32_t v : mem) t.flags[(size_t)j * n + v] |= HSPF_RF_EXACT;
-    }
-    if (!(run_flags & HSPF_RUN_POP_RANK)) t.pop_rank.clear();
-    return t;
-  }
- private:
-  oracle_run_t run_;
-};
+#include "oracle_engine.hpp"
 
 // ---- vector -> Instance (schema of tools/make_golden.py) -----------------------------------------------------------
 static I::SystemId sysid(const std::string &s) {                    // "0000.0000.0001"
@@ -343,6 +230,76 @@ static int replay_isis_step(const J &step, const std::string &golden_dir, Engine
   return 1;
 }
 
+// The wire step against what the reference RECORDED on the ibus for the step (`ibus_routes`), three ways:
+// the host rule (update_global_rib on compute_spf's rows and `rib_before`), the one-shot device form (SPT, attachment,
+// comparison with `rib_before`, compaction and packing on the engine: update_global_rib_device), and the running-instance
+// pipeline (RibPipeline: first step from an empty RIB on the SNAPSHOT, then the step's LSDB as a set of changed LSPs —
+// its messages must turn the snapshot's installed routes into the step's).  1 all equal, 0 a difference, -1 not a wire vector.
+static std::vector<I::RibRow> rib_rows(const J &rib) {
+  std::vector<I::RibRow> out;
+  for (auto &r : rib.arr) {
+    I::RibRow row{r["prefix"].s, (uint32_t)r["metric"].i(), (int)r["level"].i(), {}};
+    for (auto &nh : r["nexthops"].arr) row.nexthops.push_back({nh[0].s, nh[1].s});
+    out.push_back(std::move(row));
+  }
+  return out;
+}
+static int check_isis_wire(const J &vec, const std::string &golden_dir, Engine &eng, size_t &records, size_t &prefixes, int &pipelines) {
+  if (!vec.has("ibus_routes") || !vec.has("rib_before")) return -1;
+  if (vec["source"].s.find("nb-config-summary") != std::string::npos) return -1;   // summary routes are configuration, not SPF output (as in tests/test_host_isis.py)
+  std::map<std::string, int> ifindex;
+  for (auto &kv : vec["ifindex"].obj) ifindex[kv.first] = (int)kv.second.i();
+  std::vector<I::IbusMsg> want;
+  for (auto &m : vec["ibus_routes"].arr) {
+    I::IbusMsg w{m["op"].s == "add", m["prefix"].s, m.has("metric") ? (uint32_t)m["metric"].i() : 0u, {}};
+    if (m.has("nexthops")) for (auto &nh : m["nexthops"].arr) w.nexthops.push_back({(int)nh[0].i(), nh[1].s});
+    want.push_back(std::move(w));
+  }
+  const I::Instance inst = instance_from_vector(vec);
+  const std::vector<I::RibRow> before = rib_rows(vec["rib_before"]);
+  if (!(I::update_global_rib(I::compute_spf(inst, eng), before, ifindex) == want)) { std::fprintf(stderr, "  wire: host rule differs\n"); return 0; }
+  std::vector<std::pair<int, int>> tabs;
+  for (int lv : inst.config.levels()) for (int mt : {I::MT_STANDARD, I::MT_IPV6_UNICAST}) if (inst.config.is_topology_enabled(mt)) tabs.push_back({lv, mt});
+  if (tabs.size() != 1) return 1;                                    // (two tables: the L1 / L2 merge is host logic)
+  size_t nr = 0, np = 0;
+  if (!(I::update_global_rib_device(inst, eng, before, ifindex, &nr, &np) == want)) { std::fprintf(stderr, "  wire: device form differs\n"); return 0; }
+  if (nr > np || (np && nr > want.size() + 4)) { std::fprintf(stderr, "  wire: %zu records for %zu messages\n", nr, want.size()); return 0; }
+  records += nr; prefixes += np;
+  // the running instance: snapshot first, then the step as changed LSPs — when the step kept interfaces and configuration
+  const std::string src = vec["source"].s;
+  const size_t a = src.find("snapshot ");
+  if (golden_dir.empty() || a == std::string::npos) return 1;
+  const size_t sl = src.find('/', a), co = src.find(',', a);
+  const J base = load_json(golden_dir + "/isis/" + src.substr(a + 9, sl - a - 9) + "_" + src.substr(sl + 1, co - sl - 1) + ".json");
+  const I::Instance inst0 = instance_from_vector(base);
+  auto same_ifaces = [&]() {
+    if (inst0.interfaces.size() != inst.interfaces.size()) return false;
+    for (size_t i = 0; i < inst.interfaces.size(); ++i) {
+      const I::Interface &x = inst0.interfaces[i], &y = inst.interfaces[i];
+      if (x.name != y.name || x.interface_type != y.interface_type || x.metric != y.metric || x.adjacencies.size() != y.adjacencies.size()) return false;
+      for (size_t k = 0; k < x.adjacencies.size(); ++k)
+        if (x.adjacencies[k].system_id != y.adjacencies[k].system_id || x.adjacencies[k].state != y.adjacencies[k].state || x.adjacencies[k].ipv4_addrs != y.adjacencies[k].ipv4_addrs ||
+            x.adjacencies[k].ipv6_addrs != y.adjacencies[k].ipv6_addrs || x.adjacencies[k].level_usage != y.adjacencies[k].level_usage || x.adjacencies[k].topologies != y.adjacencies[k].topologies) return false;
+    }
+    const I::InstanceCfg &c0 = inst0.config, &c1 = inst.config;
+    return c0.level_type == c1.level_type && c0.metric_type == c1.metric_type && c0.ipv4_enabled == c1.ipv4_enabled && c0.ipv6_enabled == c1.ipv6_enabled &&
+           c0.mt_ipv6_unicast == c1.mt_ipv6_unicast && c0.att_ignore == c1.att_ignore && c0.max_paths == c1.max_paths && c0.area_addrs == c1.area_addrs;
+  };
+  if (!same_ifaces()) return 1;
+  const int level = tabs[0].first;
+  I::RibPipeline pipe(inst0, eng, level, tabs[0].second, ifindex);
+  const auto first = pipe.step(inst0, {});
+  if (!(first == I::update_global_rib(rib_rows(base["rib"]), {}, ifindex))) { std::fprintf(stderr, "  wire: pipeline first step differs\n"); return 0; }
+  static const I::Lsdb empty;
+  auto i0 = inst0.lsdb.find(level), i1 = inst.lsdb.find(level);
+  const auto trig = I::changed_lan_ids(i0 == inst0.lsdb.end() ? empty : i0->second, i1 == inst.lsdb.end() ? empty : i1->second);
+  const auto msgs = pipe.step(inst, trig);
+  // (the recorded sequence starts from `rib_before`, which is the snapshot's RIB whenever the step kept everything else)
+  if (!(msgs == I::update_global_rib(rib_rows(vec["rib"]), rib_rows(base["rib"]), ifindex))) { std::fprintf(stderr, "  wire: pipeline step differs (%zu messages)\n", msgs.size()); return 0; }
+  ++pipelines;
+  return 1;
+}
+
 static std::vector<O::v3::Area> areas3_from_vector(const J &vec) {
   std::vector<O::v3::Area> out;
   for (auto &a : vec["areas"].arr) {
@@ -434,6 +391,8 @@ int main(int argc, char **argv) {
     } else eng = std::make_unique<OracleEngine>(oracle_so);
   } catch (const std::exception &e) { std::fprintf(stderr, "engine: %s\n", e.what()); return 1; }
   int ok = 0, bad = 0, skipped = 0, manet_cases = 0, manet_bad = 0, steps_ok = 0, steps_bad = 0, steps_patched = 0, dev_ok = 0, dev_bad = 0;
+  int wire_ok = 0, wire_bad = 0, wire_pipelines = 0;
+  size_t wire_records = 0, wire_prefixes = 0;
   if (!check_hash_kat()) { std::fprintf(stderr, "flood_reduction_hash: reference vectors not reproduced\n"); return 1; }
   for (auto &path : files) {
     try {
@@ -457,6 +416,10 @@ int main(int argc, char **argv) {
       if (!golden_dir.empty() && vec["source"].s.find("snapshot ") != std::string::npos) {
         const int r = replay_isis_step(vec, golden_dir, *eng, steps_patched);
         if (r > 0) ++steps_ok; else if (r == 0) { ++steps_bad; std::fprintf(stderr, "STEP REPLAY MISMATCH %s\n", path.c_str()); }
+      }
+      {
+        const int w = check_isis_wire(vec, golden_dir, *eng, wire_records, wire_prefixes, wire_pipelines);
+        if (w > 0) ++wire_ok; else if (w == 0) { ++wire_bad; std::fprintf(stderr, "WIRE STEP MISMATCH %s\n", path.c_str()); }
       }
       const I::Instance inst = instance_from_vector(vec);
       if (vec.has("manet")) { const int mb = check_manet(vec, inst, *eng, path); manet_cases += (int)vec["manet"].size(); manet_bad += mb; }
@@ -484,5 +447,6 @@ int main(int argc, char **argv) {
   if (manet_cases) std::printf("host_parity: %d reflood lists checked, %d differ\n", manet_cases, manet_bad);
   if (steps_ok + steps_bad) std::printf("host_parity: %d step tests replayed through patched graphs (%d row-patch refreshes), %d differ\n", steps_ok + steps_bad, steps_patched, steps_bad);
   if (dev_ok + dev_bad) std::printf("host_parity: %d IS-IS RIBs also derived with the prefix attachment on the engine, %d differ\n", dev_ok + dev_bad, dev_bad);
-  return (bad || manet_bad || steps_bad || dev_bad) ? 1 : 0;
+  if (wire_ok + wire_bad) std::printf("host_parity: %d recorded ibus sequences (RouteIpAdd / RouteIpDel) reproduced by the host rule AND from engine tables (%zu records for %zu prefixes), %d differ; %d also through the running-instance pipeline\n", wire_ok, wire_records, wire_prefixes, wire_bad, wire_pipelines);
+  return (bad || manet_bad || steps_bad || dev_bad || wire_bad) ? 1 : 0;
 }

@@ -50,7 +50,7 @@ VECTORS = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "isis", "*.json
 
 
 def _build_host():
-    deps = [HOST + ".cpp", os.path.join(ROOT, "tests", "cpp", "mini_json.hpp")] + glob.glob(os.path.join(ROOT, "include", "*.h*"))
+    deps = [HOST + ".cpp", os.path.join(ROOT, "tests", "cpp", "mini_json.hpp"), os.path.join(ROOT, "tests", "cpp", "oracle_engine.hpp")] + glob.glob(os.path.join(ROOT, "include", "*.h*"))
     if not os.path.exists(HOST) or os.path.getmtime(HOST) < max(os.path.getmtime(d) for d in deps):
         from holo_amd import build as hb
         hb.build_lib()
@@ -73,6 +73,9 @@ def test_cpp_host_side_reproduces_recorded_ribs_with_the_oracle_as_engine():
     # the reference's step tests replayed as snapshot + row patches (LevelGraph / AreaGraph refresh, GraphCache)
     assert "30 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout
     assert "57 IS-IS RIBs also derived with the prefix attachment on the engine, 0 differ" in r.stdout
+    # the wire step (round 5): the reference's recorded RouteIpAdd / RouteIpDel sequences from the host rule, from engine
+    # tables (comparison, compaction, packing on the engine) and, where the step kept the interfaces, the running pipeline
+    assert "17 recorded ibus sequences" in r.stdout and ", 0 differ; 3 also through the running-instance pipeline" in r.stdout
 
 
 def test_cpp_host_side_without_a_device_reports_it():
@@ -92,6 +95,7 @@ def test_cpp_host_side_reproduces_recorded_ribs_on_gpu():
     assert "163 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
     assert "30 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout      # hspf_graph_patch
     assert "57 IS-IS RIBs also derived with the prefix attachment on the engine, 0 differ" in r.stdout     # hspf_routes_device
+    assert "17 recorded ibus sequences" in r.stdout and ", 0 differ; 3 also through the running-instance pipeline" in r.stdout   # hspf_routes_diff_device + hspf_routes_pack
 
 
 def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_path):
@@ -189,7 +193,7 @@ def test_cpp_host_side_under_asan_ubsan():
     graph_oracle.build()
     hb.build_lib()
     exe = HOST + "_asan"
-    deps = [HOST + ".cpp", os.path.join(ROOT, "tests", "cpp", "mini_json.hpp")] + glob.glob(os.path.join(ROOT, "include", "*.h*"))
+    deps = [HOST + ".cpp", os.path.join(ROOT, "tests", "cpp", "mini_json.hpp"), os.path.join(ROOT, "tests", "cpp", "oracle_engine.hpp")] + glob.glob(os.path.join(ROOT, "include", "*.h*"))
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
         r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
                             "-D__HIP_PLATFORM_AMD__", "-w", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",

@@ -1,0 +1,59 @@
+"""tests/cpp/dropin_e2e: the drop-in end to end through the compiled C++ host side.
+
+CPU: the driver on the oracle stand-in for the engine — the RIB of a down-sized twin of the synthetic isis-100k LSDB equals
+what the literal restatement oracle/isis_ref.py (pinned to the reference's recorded RIBs) computes from the SAME instance,
+the incrementally patched graph equals a graph derived from scratch, and the device-routes path gives the same rows.
+GPU: the same through the product engine (C ABI), packed hand-off and hspf_run's full tables.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "dropin_e2e")
+
+
+def _built():
+    if not os.path.exists(EXE):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__ as ge
+        ge.build()
+    return EXE
+
+
+def _run_and_check(engine_args, n, tmp_path):
+    from oracle import isis_ref
+    from oracle import graph_oracle
+    graph_oracle.build()
+    vec_p, rib_p = str(tmp_path / "inst.json"), str(tmp_path / "rib.json")
+    p = subprocess.run([_built(), *engine_args, "--n", str(n), "--reps", "1", "--batch", "5", "--dump-json", vec_p, "--dump-rib", rib_p],
+                       capture_output=True, text=True, timeout=600)
+    if p.returncode == 77:
+        pytest.skip("no HIP device")
+    assert p.returncode == 0, p.stderr
+    rep = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rep["lsdb_to_csr_incremental"]["patched_graph_identical"] is True
+    assert rep["device_routes_path"]["same_rib"] is True
+    assert rep["one_root"]["spt_vertices"] == n and rep["one_root"]["rib_routes"] == n + (n + 4) // 5
+    vec = json.load(open(vec_p))
+    got = [{"prefix": r["prefix"], "metric": r["metric"], "level": r["level"], "nexthops": [list(x) for x in r["nexthops"]]} for r in json.load(open(rib_p))]
+    want = isis_ref.local_rib(vec)
+    assert got == want
+    assert sum(1 for r in want if len(r["nexthops"]) > 1) > 0, "the twin has ECMP routes"
+    return rep
+
+
+@pytest.mark.parametrize("n", [60, 700])
+def test_cpu_engine_rib_of_the_downsized_twin_matches_the_literal_restatement(n, tmp_path):
+    _run_and_check(["--engine", "oracle"], n, tmp_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [[], ["--no-packed"]])
+@pytest.mark.parametrize("n", [700, 3000])
+def test_gpu_engine_rib_of_the_downsized_twin_matches_the_literal_restatement(n, args, tmp_path):
+    rep = _run_and_check(["--engine", "hip", *args], n, tmp_path)
+    assert rep["packed_handoff"] is (not args)
