@@ -554,7 +554,9 @@ def consumer_64root(dev) -> dict:
             last = ctx.wait_packed(hs.pop(0))
         return (time.perf_counter() - t0) / K * 1e3, last
     packed_in_flight(8, 3)
-    pk_ov_ms, last_pr = packed_in_flight(48, 3)
+    pk_ov3_ms, last_pr = packed_in_flight(48, 3)
+    pk_ov4_ms, last_pr = packed_in_flight(48, 4)
+    pk_ov_ms, pk_depth = min((pk_ov3_ms, 3), (pk_ov4_ms, 4))
     ok_packed_ov = bool(np.array_equal(last_pr.dist, ref.dist) and np.array_equal(last_pr.first_hop_mask, ref.mask[..., :1]))
     pageable = np.zeros(8 * R * n + 4096, np.uint8)[4096:]
     tq = []
@@ -578,7 +580,8 @@ def consumer_64root(dev) -> dict:
                                               "sync_wall_ms": round(packed_sync_ms, 4), "sync_runs_per_s": round(R / packed_sync_ms * 1e3),
                                               "sync_device_ms": round(st_p["ms_total"], 4), "sync_d2h_ms": round(st_p["ms_d2h"], 4),
                                               "in_flight_wall_ms_per_batch": round(pk_ov_ms, 4), "in_flight_runs_per_s": round(R / pk_ov_ms * 1e3),
-                                              "in_flight_pcie_GBps": round(packed_bytes / pk_ov_ms / 1e6, 1), "tickets_in_flight": 3,
+                                              "in_flight_pcie_GBps": round(packed_bytes / pk_ov_ms / 1e6, 1), "tickets_in_flight": pk_depth,
+                                              "in_flight_wall_ms_by_depth": {"3": round(pk_ov3_ms, 4), "4": round(pk_ov4_ms, 4)},
                                               "pageable_sync_wall_ms": round(float(np.median(tq[1:])), 4), "pageable_runs_per_s": round(R / float(np.median(tq[1:])) * 1e3),
                                               "numpy_decode_all_tables_ms": round(decode_all_ms, 2),
                                               "identical_to_oracle_after_decode": bool(ok_packed and ok_packed_ov and ok_pageable)},

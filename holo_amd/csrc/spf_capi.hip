@@ -206,6 +206,7 @@ struct hspf_ctx {
   std::vector<struct hspf_lane *> lanes;
   uint64_t next_ticket = 1;
   uint32_t lanes_cfg = 3;
+  hipStream_t copy_stream = nullptr;                // device -> host copies of packed tickets (hspf_run_packed_async), next to the lanes' runs
   hspf_ctx *parent = nullptr;                       // in a lane's context: the context the caller holds
 };
 
@@ -220,6 +221,10 @@ struct PackedReq {
   size_t row_off = 0;               // first row of this group
   uint32_t min_slots = 0;           // first-hop slots of the whole call: every group uses the same field split
   bool force_wide = false;          // 8-byte words for every group (a group's layout differed from the first one's)
+  // set by a lane for an asynchronous ticket with a page-locked destination: the words stay in `dev_stage` (device) and the
+  // lane sends them to the host on the context's COPY stream — the lane's own stream goes straight on to its next run
+  void *dev_stage = nullptr;
+  size_t copy_bytes = 0;            // out: bytes of this run's words in dev_stage
 };
 
 // One lane of an asynchronous context: a short queue of jobs, the thread that runs them one after the other, the last
@@ -234,10 +239,16 @@ struct hspf_lane {
     const hspf_graph *g; std::vector<uint32_t> roots; uint32_t flags; hspf_result out; uint64_t ticket;
     std::vector<uint32_t> dest; uint32_t n_total = 0;   // a class of a larger run (run_classes): output row of each root, rows of the whole run
     bool packed = false; PackedReq pk;                  // hspf_run_packed_async: the run and its copy to the host
+    bool pk_pinned = false;                             // ... into page-locked memory: the copy goes to the context's copy stream
   };
   std::deque<Job> jobs;                // waiting, in ticket order
   bool running = false, quit = false;
-  struct Done { uint64_t ticket = 0; int rc = 0; hspf_stats st{}; std::string err; hspf_packed_layout layout{}; } done[8];
+  struct Done { uint64_t ticket = 0; int rc = 0; hspf_stats st{}; std::string err; hspf_packed_layout layout{}; hipEvent_t copy_ev = nullptr; } done[8];
+  // packed tickets: two device staging blocks per lane, each with the event behind the last copy out of it
+  DevBuf stage[2];
+  hipEvent_t stage_ev[2] = {};
+  bool stage_busy[2] = {false, false};
+  int stage_sel = 0;
   uint64_t last_done = 0;
   bool idle() const { return jobs.empty() && !running; }
 };
@@ -1442,10 +1453,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   uint32_t *d_misfit = nullptr;
   // device address of this run's first row of packed words of `esz` bytes: staging for a host destination, else the
   // caller's buffer at the group's row offset
-  auto pk_dev = [&](size_t esz) -> char * { return pk->host ? (char *)ctx->o_pack.p : (char *)pk->dst + pk->row_off * (size_t)n * esz; };
+  auto pk_dev = [&](size_t esz) -> char * { return pk->dev_stage ? (char *)pk->dev_stage : pk->host ? (char *)ctx->o_pack.p : (char *)pk->dst + pk->row_off * (size_t)n * esz; };
   int pk_mode = -1;                                        // which fused_run produced the words: 2 lean, 1 narrow, 0 wide; -1: k_pack_full (wide layout)
   if (pk) {
-    if (pk->host && (rc = ensure(ctx, ctx->o_pack, rn * 8, false))) return rc;
+    if (pk->host && !pk->dev_stage && (rc = ensure(ctx, ctx->o_pack, rn * 8, false))) return rc;
     if ((rc = ensure(ctx, ctx->pk_flag, 256, false))) return rc;
     d_misfit = (uint32_t *)ctx->pk_flag.p;
     HIPCHK(ctx, hipMemsetAsync(d_misfit, 0, 4, ctx->stream));
@@ -2089,7 +2100,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     if (pk->host) {
       const size_t bytes = (size_t)n_roots * n * pk_esz, off = pk->row_off * (size_t)n * pk_esz;
       if (off + bytes > pk->cap) { (void)hipStreamSynchronize(s); ctx->last_error = "packed results: buffer too small, need " + std::to_string(off + bytes) + " bytes"; return HSPF_E_INVAL; }
-      if ((rc = copy_to_host(ctx, (char *)pk->dst + off, pk_dev(pk_esz), bytes, s))) return rc;
+      if (pk->dev_stage) pk->copy_bytes = bytes;                   // (the lane copies, on the copy stream, once this run is over)
+      else if ((rc = copy_to_host(ctx, (char *)pk->dst + off, pk_dev(pk_esz), bytes, s))) return rc;
     } else if (pk->row_off * (size_t)n * pk_esz + (size_t)n_roots * n * pk_esz > pk->cap) {
       (void)hipStreamSynchronize(s); ctx->last_error = "packed results: buffer too small"; return HSPF_E_INVAL;
     }
@@ -2382,6 +2394,8 @@ static int lanes_ensure(hspf_ctx *ctx) {
       c->unit_heavy_deg = ctx->unit_heavy_deg; c->xcd_row_cost = ctx->xcd_row_cost;
     }
     if (rc != HSPF_OK) { if (ln->sub) hspf_shutdown(ln->sub); delete ln; lanes_shutdown(ctx); ctx->last_error = "could not create a lane context"; return rc; }
+    for (auto &e : ln->stage_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) ctx->copy_stream = nullptr;
     ctx->lanes.push_back(ln);
     ln->th = std::thread([ln, nl = ctx->lanes_cfg]() {
       for (;;) {
@@ -2394,16 +2408,38 @@ static int lanes_ensure(hspf_ctx *ctx) {
         lk.unlock();
         ln->cv.notify_all();                                        // (a submitter may be waiting for room in the queue)
         (void)hipSetDevice(ln->sub->device);
+        hipEvent_t job_copy_ev = nullptr;
         const int rc = guarded(ln->sub, [&]() {
-          if (job.packed)                                           // hspf_run_packed_async: the run and its copy to the host
-            return run_impl(ln->sub, job.g, job.roots.data(), (uint32_t)job.roots.size(), job.flags, nullptr, true, nullptr, 0, false, &job.pk);
+          if (job.packed) {                                         // hspf_run_packed_async: the run and its copy to the host
+            hspf_ctx *par = ln->sub->parent;
+            const size_t need = (size_t)8 * job.roots.size() * job.g->n;
+            const uint64_t max_pairs = 1ull << 26;                  // (run_impl's pass size: a call of several passes copies pass by pass itself)
+            const bool one_pass = (uint64_t)job.roots.size() <= std::max<uint64_t>(64, (max_pairs / std::max<uint32_t>(job.g->n, 1)) / 64 * 64);
+            int sel = -1;
+            if (job.pk_pinned && one_pass && par && par->copy_stream) {
+              sel = ln->stage_sel; ln->stage_sel ^= 1;
+              if (ln->stage_busy[sel]) { (void)hipEventSynchronize(ln->stage_ev[sel]); ln->stage_busy[sel] = false; }   // its last copy is long over
+              const int e2 = ensure(ln->sub, ln->stage[sel], need, false);
+              if (e2) return e2;
+              job.pk.dev_stage = ln->stage[sel].p;
+            }
+            int r2 = run_impl(ln->sub, job.g, job.roots.data(), (uint32_t)job.roots.size(), job.flags, nullptr, true, nullptr, 0, false, &job.pk);
+            if (r2 == HSPF_OK && sel >= 0 && job.pk.copy_bytes) {
+              hipError_t er = hipMemcpyAsync(job.pk.dst, job.pk.dev_stage, job.pk.copy_bytes, hipMemcpyDeviceToHost, par->copy_stream);
+              if (er == hipSuccess) er = hipEventRecord(ln->stage_ev[sel], par->copy_stream);
+              if (er != hipSuccess) { ln->sub->last_error = std::string("packed copy: ") + hipGetErrorString(er); return (int)HSPF_E_HIP; }
+              ln->stage_busy[sel] = true;
+              job_copy_ev = ln->stage_ev[sel];
+            }
+            return r2;
+          }
           if (!job.dest.empty())                                    // one class of a run that the caller's context split (run_classes)
             return run_impl(ln->sub, job.g, job.roots.data(), (uint32_t)job.roots.size(), job.flags, &job.out, false, job.dest.data(), job.n_total);
           return run_classes(ln->sub, job.g, job.roots.data(), (uint32_t)job.roots.size(), job.flags, &job.out, false);
         });
         lk.lock();
         hspf_lane::Done &d = ln->done[(job.ticket / nl) & 7u];
-        d.ticket = job.ticket; d.rc = rc; d.st = ln->sub->stats; d.layout = job.pk.layout;
+        d.ticket = job.ticket; d.rc = rc; d.st = ln->sub->stats; d.layout = job.pk.layout; d.copy_ev = job_copy_ev;
         try { d.err = rc ? ln->sub->last_error : std::string(); } catch (...) {}
         ln->last_done = job.ticket; ln->running = false;
         lk.unlock();
@@ -2422,6 +2458,7 @@ static void lanes_quiesce(hspf_ctx *ctx) {
     (void)hipSetDevice(ln->sub->device);
     if (ln->sub->stream) (void)hipStreamSynchronize(ln->sub->stream);
   }
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
 }
 
 static void lanes_shutdown(hspf_ctx *ctx) {
@@ -2429,10 +2466,14 @@ static void lanes_shutdown(hspf_ctx *ctx) {
     { std::lock_guard<std::mutex> lk(ln->mu); ln->quit = true; }
     ln->cv.notify_all();
     if (ln->th.joinable()) ln->th.join();
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (auto &b : ln->stage) release(b);
+    for (auto &e : ln->stage_ev) if (e) (void)hipEventDestroy(e);
     if (ln->sub) hspf_shutdown(ln->sub);
     delete ln;
   }
   ctx->lanes.clear();
+  if (ctx->copy_stream) { (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; }
 }
 
 int hspf_run_device_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
@@ -2456,6 +2497,11 @@ int hspf_run_packed_async(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *ro
     hspf_lane::Job job{g, std::vector<uint32_t>(roots, roots + n_roots), run_flags, hspf_result{}, 0, {}, 0};
     job.packed = true;
     job.pk.dst = words_host; job.pk.cap = cap_bytes; job.pk.host = true; job.pk.root_status = root_status;
+    {
+      hipPointerAttribute_t at{};
+      job.pk_pinned = hipPointerGetAttributes(&at, words_host) == hipSuccess && at.type == hipMemoryTypeHost;
+      if (!job.pk_pinned) (void)hipGetLastError();
+    }
     *ticket = lane_submit(ctx, std::move(job));
     return (int)HSPF_OK;
   });
@@ -2484,7 +2530,13 @@ static int lane_collect(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats, hspf_
   if (stats) *stats = d.st;
   if (layout) *layout = d.layout;
   if (d.rc) { try { ctx->last_error = d.err; } catch (...) {} }
-  return d.rc;
+  const hipEvent_t cev = d.copy_ev;
+  const int drc = d.rc;
+  lk.unlock();
+  // a packed ticket: its words are on their way on the copy stream (a later copy out of the same staging block re-records
+  // the event: waiting for that one covers this one, the stream is in order)
+  if (drc == HSPF_OK && cev && hipEventSynchronize(cev) != hipSuccess) { ctx->last_error = "hspf_wait: the copy of the packed words failed"; return HSPF_E_HIP; }
+  return drc;
 }
 
 int hspf_wait(hspf_ctx *ctx, uint64_t ticket, hspf_stats *stats) {

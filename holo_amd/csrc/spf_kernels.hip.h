@@ -1408,6 +1408,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
   uint32_t n_done = 0, n_chg = 0;
   lean_group<COUNT, MODE>(gp, rs, ra, lane, lane4, wbeg, cur, P, roots, root_slot, net_nexthops, ignore_ovl, due4, fast4, fasth4,
                           sov, wk, od, oldq, info, any, need_exact, n_done, n_chg);
+  // (Round 5, r05c: INNER iterations — the wave evaluating its rows again with the records it holds, no set-up and no record
+  // round trip — were measured and rejected: an iteration that sees only its own rows' and some neighbouring waves' stores
+  // converges worse than a pass behind a pass; 2 / 3 iterations per pass: 22.2 / 25.8 x N rows evaluated instead of 17.9,
+  // 0.584 / 0.631 ms per run instead of 0.535.  profiles/r05_notes.md.)
   if (any != 0ull && lane == 0) changed[sweep] = 1;
   if (COUNT && lane == 0) atomicAdd(&gp->rows_done[(blockIdx.x + wave) & 255u], n_done);
   if (MODE == 1 && sampler && lane == 0 && n_chg != 0u && pg < 64u) atomicAdd(&ctl[LEAN_CTL_PCH + pg * LEAN_CTL_STRIDE], n_chg);

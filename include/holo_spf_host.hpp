@@ -229,7 +229,7 @@ class HipEngine : public Engine {
   // page-locked buffer the engine keeps, a quarter of hspf_run's bytes over the bus) and decoded into the twins' tables
   // here; runs whose results do not fit packed words (more than 24 first-hop slots), and runs that ask for the pop order,
   // take hspf_run as before.  `last_handoff` says which way the last run went and what it cost.
-  struct Handoff { bool packed = false; uint32_t word_bytes = 0; double run_ms = 0, decode_ms = 0; };
+  struct Handoff { bool packed = false; uint32_t word_bytes = 0; double run_ms = 0, alloc_ms = 0, decode_ms = 0; };   // alloc: the twins' own table vectors
   Handoff last_handoff;
   Tables run(Graph &gr, const std::vector<uint32_t> &roots, uint32_t run_flags) override {
     hspf_graph *g = static_cast<HipGraph &>(gr).g;
@@ -253,6 +253,7 @@ class HipEngine : public Engine {
         const auto t1 = std::chrono::steady_clock::now();
         t.mask_words = 1;
         t.dist.resize(rn); t.hops.resize(rn); t.flags.resize(rn); t.mask.resize(rn);
+        const auto t1b = std::chrono::steady_clock::now();
         for (uint32_t r = 0; r < t.n_roots; ++r) {
           const uint16_t ex = (status[r] & HSPF_ROOT_EXACT) ? (uint16_t)HSPF_RF_EXACT : (uint16_t)0;
           const size_t o = (size_t)r * t.n_vertices;
@@ -260,7 +261,8 @@ class HipEngine : public Engine {
           else decode_row<uint64_t>((const uint64_t *)pin_ + o, ly, ex, t, o);
         }
         const auto t2 = std::chrono::steady_clock::now();
-        last_handoff = Handoff{true, ly.word_bytes, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count()};
+        last_handoff = Handoff{true, ly.word_bytes, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t1b - t1).count(),
+                               std::chrono::duration<double, std::milli>(t2 - t1b).count()};
         return t;
       }
       if (rc != HSPF_E_NO_PACKED) throw std::runtime_error(std::string("hspf_run_packed: ") + hspf_last_error(ctx_));

@@ -16,6 +16,8 @@
 //   --dump-json F          the instance in the schema of tests/golden/isis/*.json (the literal restatement oracle/isis_ref.py reads it)
 //   --dump-rib F           the RIB rows compute_spf produced ("rib" of the same schema)
 // One JSON object on stdout.  Exit codes: 0 ok, 1 error, 77 --engine hip without a HIP device.
+#include <malloc.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -222,6 +224,11 @@ int main(int argc, char **argv) {
     else if (a == "--dump-rib") rib_path = next();
     else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 1; }
   }
+  // A long-running daemon's heap is warm: freed blocks are reused, not handed back to the kernel.  Without this every
+  // run's 1.6 MB of table vectors is a fresh mmap whose first touch faults page by page (2 ms per run on the GPU box's
+  // micro-VM against 0.09 ms for decoding the words: profiles/r05c_dropin_e2e_hip.json) — the harness, not the path.
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
   try {
     std::unique_ptr<Engine> eng;
     HipEngine *hip = nullptr;
@@ -254,7 +261,7 @@ int main(int argc, char **argv) {
     const double upload_ms = ms_since(t0);
 
     // ---- stage 2..4: one SPF of the instance's own root (the reference's everyday call), stage by stage
-    std::vector<double> run_v, rebuild_v, routes_v, total_v, decode_v;
+    std::vector<double> run_v, rebuild_v, routes_v, total_v, decode_v, alloc_v, call_v;
     std::vector<I::RibRow> rows;
     size_t spt_size = 0, rib_size = 0;
     for (uint32_t k = 0; k < reps + 1; ++k) {                       // (+1: the first repetition warms the engine up and is dropped)
@@ -269,7 +276,7 @@ int main(int argc, char **argv) {
       spt_size = spt.vertices.size(); rib_size = rib.size();
       if (k == 0) continue;
       run_v.push_back(te.run_ms); rebuild_v.push_back(spt_ms - te.run_ms); routes_v.push_back(rt_ms); total_v.push_back(spt_ms + rt_ms);
-      if (hip) decode_v.push_back(hip->last_handoff.decode_ms);
+      if (hip) { decode_v.push_back(hip->last_handoff.decode_ms); alloc_v.push_back(hip->last_handoff.alloc_ms); call_v.push_back(hip->last_handoff.run_ms); }
     }
     // the whole call as the caller sees it (graph from the cache): compute_spf
     const std::map<int, std::vector<I::LanId>> no_triggers;         // (no LSP changed: the cached graph is kept; without a list the cache rebuilds)
@@ -407,14 +414,14 @@ int main(int argc, char **argv) {
     printf("{\"engine\": \"%s\", \"packed_handoff\": %s, \"n_routers\": %u, \"adjacency_entries\": %zu, \"prefix_entries\": %zu, \"root_neighbours\": %zu, "
            "\"generate_ms\": %.2f, \"lsdb_to_csr_first_ms\": %.2f, \"graph_upload_ms\": %.3f, "
            "\"lsdb_to_csr_incremental\": {\"cost_only_ms\": %.3f, \"cost_only_engine_patch_ms\": %.3f, \"structural_ms\": %.3f, \"structural_engine_patch_ms\": %.3f, \"patched_graph_identical\": %s}, "
-           "\"one_root\": {\"run_and_handoff_ms\": %.3f, \"handoff_decode_ms\": %.3f, \"spt_rebuild_ms\": %.2f, \"compute_routes_ms\": %.2f, \"spt_plus_routes_ms\": %.2f, "
+           "\"one_root\": {\"run_and_handoff_ms\": %.3f, \"engine_call_ms\": %.3f, \"table_alloc_ms\": %.3f, \"handoff_decode_ms\": %.3f, \"spt_rebuild_ms\": %.2f, \"compute_routes_ms\": %.2f, \"spt_plus_routes_ms\": %.2f, "
            "\"compute_spf_call_ms\": %.2f, \"spt_vertices\": %zu, \"rib_routes\": %zu, \"slowest_stage\": \"%s\"}, "
            "\"device_routes_path\": {\"compute_spf_device_routes_ms\": %.2f, \"engine_calls_ms\": %.3f, \"same_rib\": %s}, "
            "\"running_instance_pipeline\": {\"first_step_ms\": %.2f, \"first_step_messages\": %zu, \"lsp_change_step_ms\": %.3f, \"stages_ms\": {\"refresh_patch\": %.3f, \"run_device\": %.3f, "
            "\"routes_device\": %.3f, \"slot_nexthops\": %.3f, \"diff_pack\": %.3f, \"expand\": %.3f}, \"records_to_host\": %zu, \"messages\": %zu, \"identical_to_host_rule\": %s}",
            engine.c_str(), (hip && packed) ? "true" : "false", n, S.entries, S.prefixes + (n + 4) / 5, inst.interfaces.size(),
            gen_ms, csr_first_ms, upload_ms, inc_cost_ms, inc_cost_patch_ms, inc_struct_ms, inc_struct_patch_ms, patched_ok ? "true" : "false",
-           run, median(decode_v), rebuild, routes, total, compute_spf_ms, spt_size, rib_size, slow->name,
+           run, median(call_v), median(alloc_v), median(decode_v), rebuild, routes, total, compute_spf_ms, spt_size, rib_size, slow->name,
            dev_routes_ms, dev_routes_engine_ms, dev_routes_same ? "true" : "false",
            pipe_first_ms, pipe_first_msgs, pipe_step_ms, pt.refresh_ms, pt.run_ms, pt.routes_ms, pt.slots_ms, pt.diff_pack_ms, pt.expand_ms, pipe_records, pipe_msgs, pipe_ok ? "true" : "false");
     if (batch) printf(", \"batch\": {\"roots\": %u, \"run_and_handoff_ms\": %.3f, \"handoff_decode_ms\": %.3f, \"spt_rebuild_ms\": %.2f}", batch, batch_run_ms, batch_decode_ms, batch_rebuild_ms);
