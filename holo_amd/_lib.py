@@ -104,6 +104,10 @@ SYMBOLS = [
     # packed results (ABI 7)
     ("hspf_host_alloc", ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
     ("hspf_host_free", None, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("hspf_device_alloc", ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]),
+    ("hspf_device_free", None, [ctypes.c_void_p, ctypes.c_void_p]),
+    ("hspf_device_to_host", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    ("hspf_host_to_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
     ("hspf_run_packed", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,
                                        ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(HspfPackedLayout), u8p]),
     ("hspf_run_packed_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, u32p, ctypes.c_uint32, ctypes.c_uint32,

@@ -92,6 +92,10 @@ struct hspf_graph {
   bool hub_built = false;                                         // the last build ran in hub mode (sorted keys)
   bool costs_only = false;                                        // the last patch changed costs only: nothing was rebuilt
   bool lean = false;                                              // no network vertex, no static row flag, in-degrees <= 8: k_single_lean
+  // A patch that failed after it had started to rewrite the device arrays or the host mirrors (HIP error, allocation failure)
+  // leaves the two out of step: the graph is marked and every later call on it returns HSPF_E_INVAL — the caller frees it
+  // and uploads again (include/holo_spf_hip.h: "after HSPF_E_HIP / HSPF_E_NOMEM the graph must be freed").
+  bool invalid = false;
   // Carves the arrays out of `base` for n vertices / cap links; returns the bytes needed.
   size_t layout(char *base, uint32_t nv, uint32_t cap) {
     size_t off = 0;
@@ -763,8 +767,21 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
   return HSPF_OK;
 }
 
+static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows, bool &committed);
+
+// Nothing unwinds through the boundary and nothing half-done is left usable: the whole patch — the in-place cost
+// path AND the structural path with its host-side splices, sorts and resizes — runs inside the exception guard, and a
+// failure after the first write to the device arrays or the mirrors (`committed`) marks the graph invalid.
 int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
   if (!ctx || !g || !rows) return HSPF_E_INVAL;
+  if (g->invalid) { try { ctx->last_error = "hspf_graph_patch: the graph is invalid after a failed patch (free it and upload again)"; } catch (...) {} return HSPF_E_INVAL; }
+  bool committed = false;
+  const int rc = guarded(ctx, [&]() { return graph_patch_impl(ctx, g, rows, committed); });
+  if (rc != HSPF_OK && committed) g->invalid = true;
+  return rc;
+}
+
+static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows, bool &committed) {
   lanes_quiesce(ctx);                 // asynchronous runs of this context may still read the arrays a patch rewrites
   const uint32_t m = rows->n_changed, n = g->n;
   if (m == 0) return HSPF_OK;
@@ -796,7 +813,7 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
              (len == 0 || memcmp(rows->col + rows->row_ptr[j], &g->col[a], (size_t)len * 4) == 0);
     }
     if (same) {
-      return guarded(ctx, [&]() -> int {
+      return [&]() -> int {
         // affected targets: those of the replaced rows' links, each once (dropped links name targets whose rows do not
         // hold them; such a row is re-ranked into the order it already has)
         std::vector<uint32_t> &tg = ctx->patch_targets;
@@ -824,6 +841,7 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
         uint32_t *d = (uint32_t *)ctx->gb_delta.p;
         PatchInfo *d_pi = (PatchInfo *)d;
         const uint32_t *d_changed = d + 4, *d_dptr = d_changed + m, *d_dmet = d_dptr + m + 1, *d_tg = d_dmet + de;
+        committed = true;                                      // from here on the device arrays change in place
         HIPCHK(ctx, hipMemcpyAsync(d, h, words * 4, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(kb_pc_apply, dim3(m), dim3(256), 0, s, d_changed, d_dptr, d_dmet, (const uint32_t *)g->d_row_ptr[g->cur],
                            g->d_metric[g->cur], (const uint32_t *)g->d_out_ptr, g->d_out_w, (const uint32_t *)g->d_out_fpos);
@@ -853,7 +871,7 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
         g->costs_only = true;
         ctx->prefill.valid = false;
         return HSPF_OK;
-      });
+      }();
     }
   }
   const bool tdbg = getenv("HSPF_PATCH_TIMING") != nullptr;
@@ -896,6 +914,7 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
       return rc;
     }
     g->cur = 0;
+    committed = true;                                          // the graph lives in the new arena from here on
     hipError_t er = hipMemcpyAsync(g->d_row_ptr[0], o_rp, ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, s);
     if (er == hipSuccess && g->e) er = hipMemcpyAsync(g->d_col[0], o_col, (size_t)g->e * 4, hipMemcpyDeviceToDevice, s);
     if (er == hipSuccess && g->e) er = hipMemcpyAsync(g->d_metric[0], o_met, (size_t)g->e * 4, hipMemcpyDeviceToDevice, s);
@@ -937,6 +956,7 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows) {
   uint32_t *d_dptr = d_changed + m, *d_shift = d_dptr + m + 1, *d_dcol = d_shift + m + 1, *d_dmet = d_dcol + de;
   uint8_t *d_nf = (uint8_t *)(d_dmet + de);
   const int nxt = g->cur ^ 1;
+  committed = true;                                            // kb_patch_row_ptr rewrites the vertex flags in place; the mirrors follow
   HIPCHK(ctx, hipMemcpyAsync(d_changed, ctx->h_patch, dwords * 4, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(kb_patch_row_ptr, dim3((n + 1 + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_row_ptr[g->cur], m,
                      (const uint32_t *)d_changed, (const uint32_t *)d_shift, g->d_row_ptr[nxt], (const uint8_t *)d_nf, g->d_vflags);
@@ -1147,7 +1167,7 @@ uint32_t hspf_graph_n_edges(const hspf_graph *g) { return g ? g->e : 0; }
 
 int hspf_mask_words(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t *out_words) {
   return guarded(ctx, [&]() -> int {
-  if (!ctx || !g || !roots || !out_words) return HSPF_E_INVAL;
+  if (!ctx || !g || !roots || !out_words || g->invalid) return HSPF_E_INVAL;
   std::vector<uint32_t> hv, hb;
   uint32_t w = 1;
   for (uint32_t r = 0; r < n_roots; ++r) {
@@ -1165,7 +1185,7 @@ int hspf_mask_words(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 int hspf_slot_table(hspf_ctx *ctx, const hspf_graph *g, uint32_t root, uint32_t *h_vertex, uint32_t *h_base,
                     uint32_t cap, uint32_t *out_total_slots) {
   return guarded(ctx, [&]() -> int {
-  if (!ctx || !g || root >= g->n) return HSPF_E_INVAL;
+  if (!ctx || !g || root >= g->n || g->invalid) return HSPF_E_INVAL;
   std::vector<uint32_t> hv, hb;
   uint32_t total = 0;
   build_slot_table(g, root, hv, hb, total, ctx->mark, next_mark(ctx, g->n));
@@ -1222,6 +1242,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if (pk) { out = &pk_none; host_out = pk->host; }
   if (!ctx || !g || !roots || !out || n_roots == 0 || (!pk && !out->dist) || (row_map && host_out) || (pk && (row_map || !pk->dst))) return HSPF_E_INVAL;
   if (pk && (run_flags & HSPF_RUN_POP_RANK)) { ctx->last_error = "HSPF_RUN_POP_RANK with packed results"; return HSPF_E_INVAL; }
+  if (g && g->invalid) { ctx->last_error = "the graph is invalid after a failed hspf_graph_patch (free it and upload again)"; return HSPF_E_INVAL; }
   if (pk && no_fused) { ctx->last_error = "packed results: hop counts beyond the hop field of a run with more than 16 first-hop slots"; return HSPF_E_NO_PACKED; }
   if (!row_map) total_rows = n_roots;
   (void)hipSetDevice(ctx->device);
@@ -2342,6 +2363,37 @@ void hspf_host_free(hspf_ctx *ctx, void *p) {
   if (!p) return;
   if (ctx) (void)hipSetDevice(ctx->device);
   (void)hipHostFree(p);
+}
+
+int hspf_device_alloc(hspf_ctx *ctx, size_t bytes, void **out) {
+  if (!ctx || !out || bytes == 0) return HSPF_E_INVAL;
+  *out = nullptr;
+  (void)hipSetDevice(ctx->device);
+  const hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) { *out = nullptr; try { ctx->last_error = std::string("hipMalloc: ") + hipGetErrorString(e); } catch (...) {} return HSPF_E_NOMEM; }
+  return HSPF_OK;
+}
+void hspf_device_free(hspf_ctx *ctx, void *p) {
+  if (!p) return;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  (void)hipFree(p);
+}
+int hspf_device_to_host(hspf_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+  if (!ctx || (bytes && (!dst_host || !src_dev))) return HSPF_E_INVAL;
+  if (bytes == 0) return HSPF_OK;
+  (void)hipSetDevice(ctx->device);
+  return guarded(ctx, [&]() -> int {
+    const int rc = copy_to_host(ctx, dst_host, src_dev, bytes, ctx->stream);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return HSPF_OK;
+  });
+}
+int hspf_host_to_device(hspf_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+  if (!ctx || (bytes && (!dst_dev || !src_host))) return HSPF_E_INVAL;
+  if (bytes == 0) return HSPF_OK;
+  (void)hipSetDevice(ctx->device);
+  return guarded(ctx, [&]() -> int { HIPCHK(ctx, hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice)); return HSPF_OK; });
 }
 
 static int run_packed_entry(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,

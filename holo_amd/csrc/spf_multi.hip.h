@@ -362,13 +362,13 @@ int hspf_multi_run_async(hspf_multi *m, const hspf_multi_graph *g, const uint32_
                          const hspf_result *all, uint64_t *ticket) {
   if (!m || !g || !roots || !all || !ticket || n_roots == 0 || g->g.size() != m->ctx.size()) return HSPF_E_INVAL;
   const uint32_t nl = (uint32_t)m->ctx.size();
+  for (uint32_t i = 0; i < nl; ++i) if (!all[i].dist) return HSPF_E_INVAL;       // every table set is looked at BEFORE anything is handed to a lane
   multi_wait_pending_into(m, all);
   try {
     hspf_multi::Ticket tk{m->next_ticket, std::vector<uint64_t>(nl, 0), std::vector<uint8_t>(nl, 0), n_roots, (size_t)g->g[0]->n};
     for (uint32_t i = 0; i < nl; ++i) {
       uint32_t b, e; hspf_result part;
       m->ctx[i]->stats = hspf_stats{};
-      if (!all[i].dist) return HSPF_E_INVAL;
       if (!multi_slice(m, g, i, n_roots, all, b, e, part)) continue;
       const int rc = hspf_run_device_async(m->ctx[i], g->g[i], roots + b, e - b, run_flags, &part, &tk.t[i]);
       if (rc) {                                       // what was handed out already is waited for: no run may outlive its tables

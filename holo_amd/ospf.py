@@ -453,10 +453,17 @@ class SpfState:
             graph = self.cache.get(area, None if trigger_vertices is None else trigger_vertices.get(area.area_id, ()))
             spt = run_area(self.router_id, area, self.engine, graph)
             self.engine_runs += 1
+            if spt is None:
+                # root LSA missing: run_area logs SpfRootNotFound and returns BEFORE `routers.clear()` and without touching
+                # `area.state.spt` (holo-ospf/src/spf.rs:596-620) — only transit_capability has been reset (:598); the
+                # router table and the SPT of the area keep what the previous run left
+                self.transit_capability[area.area_id] = False
+                self.spts.setdefault(area.area_id, None)
+                self.routers.setdefault(area.area_id, {})
+                continue
             self.spts[area.area_id] = spt
-            self.routers[area.area_id], self.transit_capability[area.area_id] = ({}, False) if spt is None else routers_table(area.area_id, spt)
-            if spt is not None:
-                update_rib_intra_area(rib, spt, self.max_paths)
+            self.routers[area.area_id], self.transit_capability[area.area_id] = routers_table(area.area_id, spt)
+            update_rib_intra_area(rib, spt, self.max_paths)
         self.rows = [{"prefix": rib[k]["prefix"], "metric": rib[k]["metric"], "type": "intra-area",
                       "nexthops": [[rib[k]["nexthops"][n][1], rib[k]["nexthops"][n][0]] for n in sorted(rib[k]["nexthops"])]}
                      for k in sorted(rib)]

@@ -572,10 +572,19 @@ def ospf_update_global_rib_device(router_id: str, areas: Sequence["O.Area"], max
     def installed(nhs) -> bool:
         return any(a is not None for a, _ in nhs)
     walk, gone = {}, {}                  # messages of the walk over the new RIB (prefix order) / of the routes that vanished
+    # The reference compares old and new route of a PREFIX whatever their types (route.rs:870-885): a prefix that moves between
+    # intra-area and inter-area / external with the same metric, tag, label and next hops is "unchanged" — no message (ADVICE
+    # r04: the type split of the two paths below used to see an install / a brand-new prefix there).
+    old_any = {O._net_key(r["prefix"]): r for r in rib_before}
+    new_other_keys = {O._net_key(r["prefix"]) for r in other_rows}
     for r in rec:
         p, action, metric, entry = int(r[1]), int(r[2]), int(r[3]), int(r[4])
         prefix = prefixes[p]
         o = old_intra.get(order[p])
+        if o is None:                                                 # held under another type before: still the same route to the reference
+            o2 = old_any.get(order[p])
+            if o2 is not None and o2.get("tag") is None and o2.get("sr_label") is None:
+                o = o2
         if action == E.DIFF_WITHDRAW:
             if entry == 0xFFFFFFFF and o is not None and installed(o["nexthops"]):
                 gone[order[p]] = {"op": "del", "prefix": prefix}
@@ -600,7 +609,8 @@ def ospf_update_global_rib_device(router_id: str, areas: Sequence["O.Area"], max
         # old_rib at :870, so no withdrawal follows either; the host twin, pinned to the recorded messages, does the same)
     # the rows of the other route types: the host rule among themselves (route.rs:856-916 does not look at the type); a
     # prefix that changed its type is one route to the reference: the new row's message stands, no withdrawal
-    for m in O.update_global_rib(list(other_rows), old_other, ifindex):
+    old_for_other = old_other + [old_intra[k] for k in new_other_keys if k in old_intra]      # (the same rule the other way round)
+    for m in O.update_global_rib(list(other_rows), old_for_other, ifindex):
         k = O._net_key(m["prefix"])
         if m["op"] == "add":
             walk[k] = m
@@ -608,7 +618,7 @@ def ospf_update_global_rib_device(router_id: str, areas: Sequence["O.Area"], max
         elif k not in walk and k not in {O._net_key(p) for p in table.prefixes}:
             gone[k] = m
     for k in list(gone):
-        if k in walk:
+        if k in walk or k in new_other_keys:          # the prefix lives on (under whatever type): one route, never withdrawn
             del gone[k]
     msgs = [walk[k] for k in sorted(walk)] + [gone[k] for k in sorted(gone)]
     return msgs, len(rec), P

@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define HSPF_ABI_VERSION 7u   /* 7: + packed results (hspf_run_packed / _device / _async, hspf_wait_packed, hspf_packed_layout + decode helpers),
-                                    hspf_host_alloc / hspf_host_free, HSPF_E_NO_PACKED (additions only); the library no longer sets
+                                    hspf_host_alloc / hspf_host_free, hspf_device_alloc / _free / _to_host / hspf_host_to_device, HSPF_E_NO_PACKED (additions only); the library no longer sets
                                     GPU_MAX_HW_QUEUES at load time;
                                  6: + hspf_run_device_async / hspf_wait / hspf_wait_all / hspf_async_lanes, hspf_multi_run_async / hspf_multi_run_wait, hspf_recommend_cpu (additions only);
                                  5: + hspf_routes_diff_count / hspf_routes_pack, hspf_multi_init_error, HSPF_PFX_RESIDENT, HSPF_GX_ELL_* / LEAF / SUMMARY */
@@ -364,6 +364,14 @@ static inline uint64_t hspf_packed_mask(const hspf_packed_layout *l, uint64_t w)
  * needs no HIP binding of its own).  Valid on every context of the process. */
 int  hspf_host_alloc(hspf_ctx *ctx, size_t bytes, void **out);
 void hspf_host_free(hspf_ctx *ctx, void *p);
+
+/* Device memory for callers that keep tables in HBM (hspf_run_device -> hspf_routes_device -> hspf_routes_diff_device)
+ * without a HIP binding of their own (the Rust wrapper): hipMalloc / hipFree / a synchronous device-to-host copy on the
+ * context's device. */
+int  hspf_device_alloc(hspf_ctx *ctx, size_t bytes, void **out);
+void hspf_device_free(hspf_ctx *ctx, void *p);
+int  hspf_device_to_host(hspf_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int  hspf_host_to_device(hspf_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 
 /* Synchronous, words in HOST memory (see above).  root_status: [n_roots] or NULL. */
 int hspf_run_packed(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,

@@ -17,10 +17,13 @@
 
 use std::cell::RefCell;
 use std::collections::{BTreeMap, BTreeSet};
+use std::net::IpAddr;
 
-use holo_spf_hip::{Csr, CsrCache, Engine, Tables, sys};
+use holo_spf_hip::{AncestorSets, Csr, CsrCache, DeviceRoutes, Engine, PrefixTable, RouteRecord, Tables, sys};
 
 use super::*;
+use crate::ibus;
+use crate::route::{Nexthop, RouteFlags};
 
 const VF_NETWORK: u8 = sys::HSPF_VF_NETWORK as u8;
 const VF_NO_TRANSIT: u8 = sys::HSPF_VF_NO_TRANSIT as u8;
@@ -101,7 +104,7 @@ fn level_csr(
 }
 
 // May vertex u be expanded in the SPT of this run (the gates, from the flags)?
-fn expandable(csr: &Csr, t: &Tables, r: u32, u: u32, ignore_overload: bool) -> bool {
+fn expandable(csr: &Csr, t: &Tables<'_>, r: u32, u: u32, ignore_overload: bool) -> bool {
     let f = csr.vflags[u as usize];
     if f & VF_NO_EXPAND != 0 {
         return false;
@@ -112,7 +115,7 @@ fn expandable(csr: &Csr, t: &Tables, r: u32, u: u32, ignore_overload: bool) -> b
 // The reference's pop order is (distance, VertexId) = (distance, index) — except on hop-count graphs, where a
 // pseudonode (cost 0 from every router) is popped right after the lowest-numbered router of its own distance that
 // lists it — and for roots the engine flagged HSPF_RF_EXACT, whose ranks come from `Engine::pop_ranks`.
-fn rank_key(csr: &Csr, t: &Tables, r: u32, v: u32, hopcount: bool, exact: Option<&[u32]>) -> (u32, u32, u32, u32) {
+fn rank_key(csr: &Csr, t: &Tables<'_>, r: u32, v: u32, hopcount: bool, exact: Option<&[u32]>) -> (u32, u32, u32, u32) {
     if let Some(rank) = exact {
         return (rank[(r * t.n_vertices + v) as usize], 0, 0, 0);
     }
@@ -143,7 +146,7 @@ fn slot_nexthops(
     csr: &Csr,
     vids: &[VertexId],
     slot_table: &[(u32, u32)],
-    t: &Tables,
+    t: &Tables<'_>,
     r: u32,
     key: &dyn Fn(u32) -> (u32, u32, u32, u32),
     local: bool,
@@ -226,7 +229,7 @@ fn spt_from_tables(
     csr: &Csr,
     vids: &[VertexId],
     slot_table: &[(u32, u32)],
-    t: &Tables,
+    t: &Tables<'_>,
     r: u32,
     exact: Option<&[u32]>,
     local: bool,
@@ -301,7 +304,8 @@ pub(crate) fn compute_spts(
             .map(|sid| vids.binary_search(&VertexId::from(*sid)).ok().map(|i| i as u32))
             .collect::<Option<_>>()?;
         let run_flags = if mt_id.is_none() { sys::HSPF_RUN_IGNORE_OVERLOAD } else { 0 };
-        let t = eng.run(graph, &roots, run_flags).map_err(|e| e.log()).ok()?;
+        // (packed hand-off: one word per (root, vertex) into page-locked memory — a quarter of the bytes of the four arrays)
+        let t = eng.run(graph, &roots, run_flags, None).map_err(|e| e.log()).ok()?;
         // roots whose pop order is dynamic (zero-cost plateaus): their exact pop ranks, one more run
         let any_exact = (0..t.n_roots).any(|r| (0..t.n_vertices).any(|v| t.exact(r, v)));
         let exact = if any_exact { Some(eng.pop_ranks(graph, &roots, run_flags).map_err(|e| e.log()).ok()?) } else { None };
@@ -332,4 +336,307 @@ pub(crate) fn compute_spt(
 ) -> Option<Spt> {
     compute_spts(level, &[root_system_id], local, mt_id, metric_mode, instance, interfaces, adjacencies, lsp_entries)?
         .pop()
+}
+
+
+// ---- routes on the device and the wire step -----------------------------------------------------
+//
+// compute_routes (spf.rs:840-949) + route::update_rib / update_global_rib (route.rs:185-312) for a RUNNING instance with
+// one RIB table (level_type != All, one topology, SR off): nobody walks 100 000 SPT vertices or rebuilds 120 000 Route
+// objects per SPF event.  What stays resident between events:
+//   the level graph on the device (CsrCache: rows of the changed LSPs are patched),
+//   the prefix table on the device (PrefixTable, HSPF_PFX_RESIDENT; rebuilt when a changed LSP's prefixes differ),
+//   the route tables of the PREVIOUS event on the device = the "RIB held before".
+// Per event: run_device -> routes_device -> routes_changed (comparison + ordered compaction + two small copies) ->
+// a `Route` is built ONLY for the records, the stored RIB is updated in place, route_install / route_uninstall are called
+// for them in the reference's order.  A mechanical translation of the COMPILED AND TESTED C++ form,
+// include/holo_spf_isis.hpp `RibPipeline` of the engine repository (its messages equal the reference's recorded ibus
+// sequences: tests/cpp/host_parity.cpp; measured 0.94 ms per LSP change at 100 000 routers: tests/cpp/dropin_e2e.cpp).
+// NOT compiled here.
+pub(crate) struct RibPipeline {
+    prefixes: Vec<IpNetwork>,                  // BTreeMap<IpNetwork, _> order = the table's prefix order
+    table: PrefixTable,
+    entries: Vec<(u32, VertexNetwork)>,        // per table entry: advertising vertex index, what Route::new needs of the network
+    signature: BTreeMap<LanId, Vec<(IpNetwork, u32, bool)>>,
+    resident: bool,
+    prev: Option<DeviceRoutes<'static>>,
+    slot_nh: BTreeMap<u32, VertexNexthop>,
+}
+
+thread_local! {
+    static RIBS: RefCell<BTreeMap<(LevelNumber, MtId), RibPipeline>> = RefCell::new(BTreeMap::new());
+}
+
+fn networks_of(
+    level: LevelNumber,
+    mt_id: MtId,
+    vid: &VertexId,
+    instance: &InstanceUpView<'_>,
+    interfaces: &Interfaces,
+    adjacencies: &Arena<Adjacency>,
+    lsp_entries: &Arena<LspEntry>,
+) -> Vec<VertexNetwork> {
+    let lsdb = instance.state.lsdb.get(level);
+    let Some(zeroth) = zeroth_lsp(vid.lan_id, lsdb, lsp_entries) else {
+        return vec![];
+    };
+    let att_bit = !instance.config.att_ignore && zeroth.att_bit(mt_id) && !zeroth.overload_bit(mt_id);
+    let ipv4_enabled = instance.config.is_af_enabled(AddressFamily::Ipv4) && mt_id == MtId::Standard;
+    let ipv6_enabled = instance.config.is_af_enabled(AddressFamily::Ipv6)
+        && match mt_id {
+            MtId::Standard => !instance.config.is_topology_enabled(MtId::Ipv6Unicast),
+            MtId::Ipv6Unicast => true,
+        };
+    let vertex = Vertex::new(*vid, 0, 0);
+    vertex_networks(
+        instance.config.level_type,
+        level,
+        mt_id,
+        &vertex,
+        att_bit,
+        instance.is_l2_attached_to_backbone(mt_id, interfaces, adjacencies),
+        instance.config.metric_type.get(level),
+        ipv4_enabled,
+        ipv6_enabled,
+        lsdb,
+        lsp_entries,
+    )
+    .collect()
+}
+
+impl RibPipeline {
+    // Every (vertex, prefix, metric) the unchanged vertex_networks yields, vertices in VertexId order, CSR by prefix.
+    fn build(
+        level: LevelNumber,
+        mt_id: MtId,
+        vids: &[VertexId],
+        instance: &InstanceUpView<'_>,
+        interfaces: &Interfaces,
+        adjacencies: &Arena<Adjacency>,
+        lsp_entries: &Arena<LspEntry>,
+    ) -> RibPipeline {
+        let mut by_prefix: BTreeMap<IpNetwork, Vec<(u32, VertexNetwork)>> = BTreeMap::new();
+        let mut signature = BTreeMap::new();
+        for (v, vid) in vids.iter().enumerate() {
+            let nets = networks_of(level, mt_id, vid, instance, interfaces, adjacencies, lsp_entries);
+            signature.insert(vid.lan_id, nets.iter().map(|n| (n.prefix, n.metric, n.external)).collect());
+            for n in nets {
+                by_prefix.entry(n.prefix).or_default().push((v as u32, n));
+            }
+        }
+        let mut table = PrefixTable { pfx_ptr: vec![0], ..Default::default() };
+        let (mut prefixes, mut entries) = (Vec::new(), Vec::new());
+        for (prefix, list) in by_prefix {
+            prefixes.push(prefix);
+            for (v, n) in list {
+                table.pfx_vertex.push(v);
+                table.pfx_metric.push(n.metric);
+                entries.push((v, n));
+            }
+            table.pfx_ptr.push(table.pfx_vertex.len() as u32);
+        }
+        RibPipeline { prefixes, table, entries, signature, resident: false, prev: None, slot_nh: BTreeMap::new() }
+    }
+
+    // The next hops a slot mask resolves to, as Route::build_nexthops would make them from a vertex's nexthop list
+    // (route.rs:118-142), truncated to max-paths like compute_routes (spf.rs:920-929).
+    fn nexthops_of(&self, mask: &[u64], af: AddressFamily, max_paths: u16) -> BTreeMap<IpAddr, Nexthop> {
+        RouteRecord::slots(mask)
+            .filter_map(|s| self.slot_nh.get(&s))
+            .filter_map(|nh| {
+                let addr = match af {
+                    AddressFamily::Ipv4 => nh.ipv4.map(IpAddr::V4),
+                    AddressFamily::Ipv6 => nh.ipv6.map(IpAddr::V6),
+                }?;
+                Some((addr, Nexthop { system_id: nh.system_id, iface_idx: nh.iface_idx?, addr, sr_label: None }))
+            })
+            .collect::<BTreeMap<_, _>>()
+            .into_iter()
+            .take(max_paths as usize)
+            .collect()
+    }
+}
+
+// compute_routes + route::update_rib for `level` from device tables.  `Some(())`: the instance's RIB and the global RIB are
+// up to date; `None`: not applicable / engine error (logged) — the caller runs compute_routes + route::update_rib as before.
+#[allow(clippy::too_many_arguments)]
+pub(crate) fn update_rib(
+    level: LevelNumber,
+    trigger_lans: &BTreeSet<LanId>,
+    instance: &mut InstanceUpView<'_>,
+    interfaces: &Interfaces,
+    adjacencies: &Arena<Adjacency>,
+    lsp_entries: &Arena<LspEntry>,
+) -> Option<()> {
+    let eng = ENGINE.with(|e| *e)?;
+    if instance.config.level_type == LevelType::All || instance.config.sr.enabled || instance.config.is_topology_enabled(MtId::Ipv6Unicast) {
+        return None; // L1/L2 merge, summaries, SR labels and a second topology stay with the host path
+    }
+    let mt_id = MtId::Standard;
+    let root_system_id = instance.config.system_id?;
+    let (vids, csr) = level_csr(level, Some(mt_id), MetricMode::Normal, instance, lsp_entries);
+    GRAPHS.with(|graphs| {
+        RIBS.with(|ribs| {
+            let mut graphs = graphs.borrow_mut();
+            let mut ribs = ribs.borrow_mut();
+            let cache = graphs.entry((level, Some(mt_id), false)).or_default();
+            let same_vertices = cache.keys == vids;
+            let graph = cache.get_or_patch(eng, vids, csr).map_err(|e| e.log()).ok()?;
+            let (vids, csr) = (&cache.keys, &cache.csr);
+            let root = vids.binary_search(&VertexId::from(root_system_id)).ok()? as u32;
+            // the prefix table: as long as the vertex set stands and no changed LSP advertises other prefixes than before
+            let stale = !same_vertices
+                || ribs.get(&(level, mt_id)).is_none_or(|p| {
+                    trigger_lans.iter().any(|lan| {
+                        let now: Vec<_> = networks_of(level, mt_id, &VertexId::from(*lan), instance, interfaces, adjacencies, lsp_entries)
+                            .iter()
+                            .map(|n| (n.prefix, n.metric, n.external))
+                            .collect();
+                        p.signature.get(lan).is_none_or(|was| *was != now)
+                    })
+                });
+            if stale {
+                ribs.insert((level, mt_id), RibPipeline::build(level, mt_id, vids, instance, interfaces, adjacencies, lsp_entries));
+            }
+            let pipe = ribs.get_mut(&(level, mt_id))?;
+            // SPT and prefix attachment on the device
+            let run = eng.run_device(graph, &[root], 0).map_err(|e| e.log()).ok()?;
+            let fresh = eng.routes_device(&run, &pipe.table, pipe.resident).map_err(|e| e.log()).ok()?;
+            pipe.resident = true;
+            // first-hop slots -> next hops, every event (which relaxations the root makes depends on distances elsewhere)
+            let t = run.to_host().map_err(|e| e.log()).ok()?;
+            let exact = if (0..t.n_vertices).any(|v| t.exact(0, v)) { Some(eng.pop_ranks(graph, &[root], 0).map_err(|e| e.log()).ok()?) } else { None };
+            let key = |v: u32| rank_key(csr, &t, 0, v, false, exact.as_deref());
+            let slot_table = graph.slot_table(root).map_err(|e| e.log()).ok()?;
+            let slot_nh = slot_nexthops(csr, vids, &slot_table, &t, 0, &key, true, level, Some(mt_id), interfaces, adjacencies);
+            let same_slots = slot_nh.len() == pipe.slot_nh.len()
+                && slot_nh.iter().zip(&pipe.slot_nh).all(|((sa, a), (sb, b))| {
+                    sa == sb && a.system_id == b.system_id && a.iface_idx == b.iface_idx && a.ipv4 == b.ipv4 && a.ipv6 == b.ipv6
+                });
+            if pipe.prev.is_some() && !same_slots {
+                pipe.prev = None; // a slot means another next hop now: the old masks are void
+            }
+            pipe.slot_nh = slot_nh;
+            let max_paths = instance.config.max_paths;
+            let rib = instance.state.rib_mut(instance.config.level_type);
+            // nothing comparable on the device: the stored RIB as "held before" (poisoned metric: every such pair comes back
+            // and is decided below, record by record)
+            let host_old = pipe.prev.is_none();
+            if host_old {
+                let (p, w) = (pipe.prefixes.len(), fresh.words as usize);
+                let (mut bm, mut be, mut nm) = (vec![u32::MAX; p], vec![u32::MAX; p], vec![0u64; p * w]);
+                for (i, prefix) in pipe.prefixes.iter().enumerate() {
+                    if let Some(route) = rib.get(prefix) {
+                        bm[i] = 0xFFFF_FFFE;
+                        be[i] = 0;
+                        if !route.nexthops.is_empty() {
+                            nm[i * w] = 1;
+                        }
+                    }
+                }
+                pipe.prev = Some(eng.routes_upload(1, p as u32, fresh.words, &bm, &be, &nm).map_err(|e| e.log()).ok()?);
+            }
+            let records = eng.routes_changed(pipe.prev.as_ref()?, &fresh).map_err(|e| e.log()).ok()?;
+            // the records: installs in prefix order, then the withdrawals (update_global_rib, route.rs:254-312)
+            let mut withdrawn = vec![];
+            for rec in &records {
+                let prefix = pipe.prefixes[rec.prefix as usize];
+                let af = prefix.address_family();
+                if rec.new_entry == u32::MAX {
+                    // no route any more: uninstall what was installed (:303-310)
+                    if let Some(old) = rib.remove(&prefix)
+                        && old.flags.contains(RouteFlags::INSTALLED)
+                    {
+                        withdrawn.push((prefix, old));
+                    }
+                    continue;
+                }
+                // the new route, built for THIS prefix only: owner entry = first vertex attaining the metric (Route::new),
+                // next hops = union over the tied vertices = the slot mask (merge_nexthops), max-paths applied
+                let (owner, network) = &pipe.entries[rec.new_entry as usize];
+                let vertex = Vertex::new(vids[*owner as usize], t.dist(0, *owner), t.hops(0, *owner));
+                let mut route = Route::new(&vertex, network, level);
+                route.metric = rec.new_metric;
+                route.nexthops = pipe.nexthops_of(&rec.new_mask, af, max_paths);
+                let mut old_sr_label = None;
+                if let Some(old) = rib.get(&prefix) {
+                    old_sr_label = old.sr_label;
+                    // the reference's "unchanged" (:268-277): compared on resolved next hops (two slots may resolve to one
+                    // adjacency), against what the route WAS — the old record when the previous tables were comparable
+                    let was_same = if host_old {
+                        old.metric == route.metric && old.tag == route.tag && old.nexthops == route.nexthops
+                    } else {
+                        rec.old_entry != u32::MAX
+                            && rec.old_metric == route.metric
+                            && pipe.nexthops_of(&rec.old_mask, af, max_paths) == route.nexthops
+                    };
+                    if was_same {
+                        if old.flags.contains(RouteFlags::INSTALLED) {
+                            route.flags.insert(RouteFlags::INSTALLED);
+                        }
+                        rib.insert(prefix, route);
+                        continue;
+                    }
+                }
+                if !route.flags.contains(RouteFlags::CONNECTED) && !route.nexthops.is_empty() {
+                    let distance = route.distance(instance.config);
+                    ibus::tx::route_install(&instance.tx.ibus, &prefix, &route, old_sr_label, distance, interfaces);
+                    route.flags.insert(RouteFlags::INSTALLED);
+                }
+                rib.insert(prefix, route);
+            }
+            for (prefix, route) in withdrawn {
+                ibus::tx::route_uninstall(&instance.tx.ibus, &prefix, &route);
+            }
+            pipe.prev = Some(fresh);
+            Some(())
+        })
+    })
+}
+
+// ---- flooding::manet on device tables -------------------------------------------------------------------
+//
+// reflood_list (flooding/manet.rs:99-173) asks Spt::is_on_path (a DFS over every parent, spf.rs:261-286) once per (second
+// hop, LSP originator) and once per (remote neighbour, second hop).  For the hop-count SPTs of ALL Up adjacencies — one
+// batched run — hspf_ancestors_device leaves, per neighbour root, the bit sets "level-1 / level-2 routers above vertex v":
+// every is_on_path of reflood_list becomes one bit test.  C++ form (tested against the literal restatement on the recorded
+// topologies): holo_amd.isis.manet_init_cache_device / reflood_list_device of the engine repository.
+#[derive(Debug)]
+pub(crate) struct ManetSets {
+    pub vids: Vec<VertexId>,
+    pub first_hops: AncestorSets,   // level 1: the remote-neighbour list
+    pub second_hops: AncestorSets,  // level 2
+}
+
+impl ManetSets {
+    // is_on_path(ancestor, descendant) in the hop-count SPT of neighbour row `r`; None: not answerable from the sets
+    // (ancestor is neither a first nor a second hop of that root, or the root ran on the sequential kernel): the caller
+    // keeps Spt::is_on_path.
+    pub(crate) fn is_on_path(&self, r: u32, ancestor: SystemId, descendant: SystemId) -> Option<bool> {
+        let a = self.vids.binary_search(&VertexId::from(ancestor)).ok()? as u32;
+        let d = self.vids.binary_search(&VertexId::from(descendant)).ok()? as u32;
+        self.first_hops.is_on_path(r, a, d).or_else(|| self.second_hops.is_on_path(r, a, d))
+    }
+}
+
+pub(crate) fn manet_sets(
+    level: LevelNumber,
+    nbrs: &[SystemId],
+    instance: &InstanceUpView<'_>,
+    lsp_entries: &Arena<LspEntry>,
+) -> Option<ManetSets> {
+    let eng = ENGINE.with(|e| *e)?;
+    let (vids, csr) = level_csr(level, None, MetricMode::HopCount, instance, lsp_entries);
+    GRAPHS.with(|graphs| {
+        let mut graphs = graphs.borrow_mut();
+        let cache = graphs.entry((level, None, true)).or_default();
+        let graph = cache.get_or_patch(eng, vids, csr).map_err(|e| e.log()).ok()?;
+        let roots: Vec<u32> =
+            nbrs.iter().map(|sid| cache.keys.binary_search(&VertexId::from(*sid)).ok().map(|i| i as u32)).collect::<Option<_>>()?;
+        let flags = sys::HSPF_RUN_IGNORE_OVERLOAD;
+        let run = eng.run_device(graph, &roots, flags).map_err(|e| e.log()).ok()?;
+        let first_hops = eng.ancestors_device(graph, &roots, flags, &run, 1).map_err(|e| e.log()).ok()?;
+        let second_hops = eng.ancestors_device(graph, &roots, flags, &run, 2).map_err(|e| e.log()).ok()?;
+        Some(ManetSets { vids: cache.keys.clone(), first_hops, second_hops })
+    })
 }

@@ -106,7 +106,7 @@ where
         let mut graphs = graphs.borrow_mut();
         let cache = graphs.entry(area.area_id).or_default();
         let graph = cache.get_or_patch(eng, keys, csr.clone()).map_err(|e| e.log()).ok()?;
-        let t = eng.run(graph, &[root], sys::HSPF_RUN_NET_NEXTHOPS).map_err(|e| e.log()).ok()?;
+        let t = eng.run(graph, &[root], sys::HSPF_RUN_NET_NEXTHOPS, None).map_err(|e| e.log()).ok()?;
         let slot_table = graph.slot_table(root).map_err(|e| e.log()).ok()?;
         Some((t, slot_table))
     })?;

@@ -10,7 +10,7 @@
 
 pub mod sys;
 
-use std::ffi::CStr;
+use std::ffi::{CStr, c_void};
 use std::fmt;
 use std::marker::PhantomData;
 use std::ptr;
@@ -72,40 +72,132 @@ pub struct RowPatch {
     pub vflags: u8,
 }
 
-/// Per (root, vertex) results of a run, row-major `[root][vertex]` (`hspf_result`).
-#[derive(Debug, Default)]
-pub struct Tables {
-    pub n_roots: u32,
-    pub n_vertices: u32,
-    pub words: u32,
-    pub dist: Vec<u32>,
-    pub hops: Vec<u16>,
-    pub flags: Vec<u16>,
-    pub mask: Vec<u64>,
+/// Page-locked host memory from `hspf_host_alloc`: packed results cross the bus at full speed into it.
+pub struct PinnedBuf<'e> {
+    eng: &'e Engine,
+    p: *mut c_void,
+    bytes: usize,
 }
 
-impl Tables {
+impl PinnedBuf<'_> {
+    pub fn len(&self) -> usize {
+        self.bytes
+    }
+    pub fn is_empty(&self) -> bool {
+        self.bytes == 0
+    }
+}
+
+impl Drop for PinnedBuf<'_> {
+    fn drop(&mut self) {
+        unsafe { sys::hspf_host_free(self.eng.ctx, self.p) }
+    }
+}
+
+/// Device memory from `hspf_device_alloc` (tables that stay in HBM between `run_device`, `routes_device` and
+/// `routes_changed`).
+pub struct DeviceBuf<'e> {
+    eng: &'e Engine,
+    p: *mut c_void,
+    bytes: usize,
+}
+
+impl DeviceBuf<'_> {
+    pub fn to_host<T: Copy + Default>(&self, count: usize) -> Result<Vec<T>, Error> {
+        let mut v = vec![T::default(); count];
+        let bytes = count * std::mem::size_of::<T>();
+        debug_assert!(bytes <= self.bytes);
+        let rc = unsafe { sys::hspf_device_to_host(self.eng.ctx, v.as_mut_ptr() as *mut c_void, self.p, bytes) };
+        if rc != sys::HSPF_OK {
+            return Err(self.eng.err(rc));
+        }
+        Ok(v)
+    }
+}
+
+impl Drop for DeviceBuf<'_> {
+    fn drop(&mut self) {
+        unsafe { sys::hspf_device_free(self.eng.ctx, self.p) }
+    }
+}
+
+/// Where the per-(root, vertex) values of a run live on the host.
+enum Repr<'e> {
+    /// `hspf_run`: four arrays, 8 + 8 `words` bytes per (root, vertex).
+    Full { words: u32, dist: Vec<u32>, hops: Vec<u16>, flags: Vec<u16>, mask: Vec<u64> },
+    /// `hspf_run_packed` (ABI 7): ONE 4- or 8-byte word per (root, vertex) in page-locked memory + the run's field
+    /// positions; a vertex is decoded where it is looked at (include/holo_spf_hip.h "packed results").
+    Packed { buf: PinnedBuf<'e>, layout: sys::hspf_packed_layout, root_status: Vec<u8> },
+}
+
+/// Per (root, vertex) results of a run, row-major `[root][vertex]`.
+pub struct Tables<'e> {
+    pub n_roots: u32,
+    pub n_vertices: u32,
+    repr: Repr<'e>,
+}
+
+impl<'e> Tables<'e> {
     #[inline]
     fn at(&self, root: u32, v: u32) -> usize {
         root as usize * self.n_vertices as usize + v as usize
     }
-    pub fn in_spt(&self, root: u32, v: u32) -> bool {
-        self.flags[self.at(root, v)] & sys::HSPF_RF_IN_SPT as u16 != 0
+    #[inline]
+    fn word(&self, buf: &PinnedBuf<'e>, layout: &sys::hspf_packed_layout, i: usize) -> u64 {
+        // (hspf_packed_word of the header)
+        unsafe {
+            if layout.word_bytes == 4 {
+                *(buf.p as *const u32).add(i) as u64
+            } else {
+                *(buf.p as *const u64).add(i)
+            }
+        }
     }
+    pub fn in_spt(&self, root: u32, v: u32) -> bool {
+        match &self.repr {
+            Repr::Full { flags, .. } => flags[self.at(root, v)] & sys::HSPF_RF_IN_SPT as u16 != 0,
+            Repr::Packed { buf, layout, .. } => self.word(buf, layout, self.at(root, v)) < layout.not_reached,
+        }
+    }
+    /// The root went through the sequential kernel (its pop order is not the static one): `Engine::pop_ranks`.
     pub fn exact(&self, root: u32, v: u32) -> bool {
-        self.flags[self.at(root, v)] & sys::HSPF_RF_EXACT as u16 != 0
+        match &self.repr {
+            Repr::Full { flags, .. } => flags[self.at(root, v)] & sys::HSPF_RF_EXACT as u16 != 0,
+            Repr::Packed { root_status, .. } => root_status[root as usize] & sys::HSPF_ROOT_EXACT as u8 != 0 && self.in_spt(root, v),
+        }
     }
     pub fn dist(&self, root: u32, v: u32) -> u32 {
-        self.dist[self.at(root, v)]
+        match &self.repr {
+            Repr::Full { dist, .. } => dist[self.at(root, v)],
+            Repr::Packed { buf, layout, .. } => {
+                let w = self.word(buf, layout, self.at(root, v));
+                if w < layout.not_reached { (w >> layout.dist_shift) as u32 } else { sys::HSPF_DIST_INF }
+            }
+        }
     }
     pub fn hops(&self, root: u32, v: u32) -> u16 {
-        self.hops[self.at(root, v)]
+        match &self.repr {
+            Repr::Full { hops, .. } => hops[self.at(root, v)],
+            Repr::Packed { buf, layout, .. } => {
+                let w = self.word(buf, layout, self.at(root, v));
+                if w < layout.not_reached { ((w >> layout.hops_shift) & layout.hops_mask as u64) as u16 } else { 0 }
+            }
+        }
     }
     /// First-hop slots of (root, v), ascending.
     pub fn slots(&self, root: u32, v: u32) -> impl Iterator<Item = u32> + '_ {
-        let base = self.at(root, v) * self.words as usize;
-        (0..self.words as usize).flat_map(move |w| {
-            let mut m = self.mask[base + w];
+        let (words, base) = match &self.repr {
+            Repr::Full { words, .. } => (*words as usize, self.at(root, v) * *words as usize),
+            Repr::Packed { .. } => (1usize, 0usize),
+        };
+        (0..words).flat_map(move |w| {
+            let mut m = match &self.repr {
+                Repr::Full { mask, .. } => mask[base + w],
+                Repr::Packed { buf, layout, .. } => {
+                    let x = self.word(buf, layout, self.at(root, v));
+                    if x < layout.not_reached { x & ((1u64 << layout.mask_bits) - 1) } else { 0 }
+                }
+            };
             std::iter::from_fn(move || {
                 if m == 0 {
                     return None;
@@ -115,6 +207,143 @@ impl Tables {
                 Some(w as u32 * 64 + b)
             })
         })
+    }
+    /// The page-locked buffer of a packed result, for the next run of the same size (`Engine::run_packed`).
+    pub fn into_buffer(self) -> Option<PinnedBuf<'e>> {
+        match self.repr {
+            Repr::Packed { buf, .. } => Some(buf),
+            Repr::Full { .. } => None,
+        }
+    }
+}
+
+/// `hspf_run_device` results left in HBM: input of `routes_device` / `ancestors_device`.
+pub struct DeviceTables<'e> {
+    pub n_roots: u32,
+    pub n_vertices: u32,
+    pub words: u32,
+    dist: DeviceBuf<'e>,
+    hops: DeviceBuf<'e>,
+    flags: DeviceBuf<'e>,
+    mask: DeviceBuf<'e>,
+}
+
+impl<'e> DeviceTables<'e> {
+    /// The copy the host side still needs for next-hop resolution (one root: 1.6 MB at 100 000 vertices).
+    pub fn to_host(&self) -> Result<Tables<'e>, Error> {
+        let cells = self.n_roots as usize * self.n_vertices as usize;
+        Ok(Tables {
+            n_roots: self.n_roots,
+            n_vertices: self.n_vertices,
+            repr: Repr::Full {
+                words: self.words,
+                dist: self.dist.to_host(cells)?,
+                hops: self.hops.to_host(cells)?,
+                flags: self.flags.to_host(cells)?,
+                mask: self.mask.to_host(cells * self.words as usize)?,
+            },
+        })
+    }
+}
+
+/// The (vertex, prefix, metric) advertisements of one level / topology as CSR by prefix (`hspf_prefix_table`): entries of
+/// a prefix in ascending vertex index = the reference's `Spt::iter` order.  Root independent: built once per LSDB
+/// generation, kept on the device (`HSPF_PFX_RESIDENT`).
+#[derive(Debug, Default, Clone)]
+pub struct PrefixTable {
+    pub pfx_ptr: Vec<u32>,
+    pub pfx_vertex: Vec<u32>,
+    pub pfx_metric: Vec<u32>,
+    pub flags: u32,
+}
+
+impl PrefixTable {
+    pub fn n_prefixes(&self) -> u32 {
+        self.pfx_ptr.len().saturating_sub(1) as u32
+    }
+}
+
+/// Route tables of one `routes_device` call (or an uploaded set) in HBM: `hspf_routes`.
+pub struct DeviceRoutes<'e> {
+    pub n_roots: u32,
+    pub n_prefixes: u32,
+    pub words: u32,
+    best_metric: DeviceBuf<'e>,
+    best_entry: DeviceBuf<'e>,
+    nexthop_mask: DeviceBuf<'e>,
+}
+
+impl DeviceRoutes<'_> {
+    fn raw(&self) -> sys::hspf_routes {
+        sys::hspf_routes {
+            best_metric: self.best_metric.p as *mut u32,
+            best_entry: self.best_entry.p as *mut u32,
+            nexthop_mask: self.nexthop_mask.p as *mut u64,
+        }
+    }
+}
+
+/// One changed (root, prefix) pair of `routes_changed`: what the route IS (`new_*`) and what it WAS (`old_*`).
+#[derive(Debug, Clone)]
+pub struct RouteRecord {
+    pub root: u32,
+    pub prefix: u32,
+    pub action: u32, // sys::HSPF_DIFF_INSTALL | sys::HSPF_DIFF_WITHDRAW
+    pub new_metric: u32,
+    pub new_entry: u32, // 0xFFFFFFFF: the prefix has no route any more
+    pub new_mask: Vec<u64>,
+    pub old_metric: u32,
+    pub old_entry: u32, // 0xFFFFFFFF: there was no route
+    pub old_mask: Vec<u64>,
+}
+
+impl RouteRecord {
+    pub fn slots(mask: &[u64]) -> impl Iterator<Item = u32> + '_ {
+        mask.iter().enumerate().flat_map(|(w, &m)| {
+            let mut m = m;
+            std::iter::from_fn(move || {
+                if m == 0 {
+                    return None;
+                }
+                let b = m.trailing_zeros();
+                m &= m - 1;
+                Some(w as u32 * 64 + b)
+            })
+        })
+    }
+}
+
+/// A `run_packed_async` in flight: buffer and status array stay here until `wait_packed` turns them into `Tables`.
+pub struct PackedTicket<'e> {
+    ticket: u64,
+    buf: PinnedBuf<'e>,
+    root_status: Box<[u8]>,
+    n_roots: u32,
+    n_vertices: u32,
+}
+
+/// Level-L ancestor bit sets of every (root, vertex) of a hop-count run (`hspf_ancestors_device`).
+#[derive(Debug, Default, Clone)]
+pub struct AncestorSets {
+    pub n_vertices: u32,
+    pub words: u32,
+    pub level_rank: Vec<u32>,  // [root][vertex]: rank among the root's level-L routers, u32::MAX elsewhere
+    pub level_count: Vec<u32>, // [root]; u32::MAX: no sets for this root (sequential kernel)
+    pub anc: Vec<u64>,         // [root][vertex][words]
+}
+
+impl AncestorSets {
+    pub fn available(&self, root: u32) -> bool {
+        self.level_count[root as usize] != u32::MAX
+    }
+    /// `Spt::is_on_path(ancestor, descendant)` for a level-L router `ancestor` of root row `root`.
+    pub fn is_on_path(&self, root: u32, ancestor: u32, descendant: u32) -> Option<bool> {
+        let rank = self.level_rank[root as usize * self.n_vertices as usize + ancestor as usize];
+        if rank == u32::MAX || !self.available(root) {
+            return None;
+        }
+        let base = (root as usize * self.n_vertices as usize + descendant as usize) * self.words as usize;
+        Some(self.anc[base + (rank / 64) as usize] >> (rank % 64) & 1 != 0)
     }
 }
 
@@ -185,28 +414,109 @@ impl Engine {
         Ok(Graph { eng: self, g, n: csr.n_vertices(), _not_sync: PhantomData })
     }
 
-    /// `hspf_mask_words` + `hspf_run`: results in host vectors.  `roots` may hold `HSPF_NO_ROOT` padding.
-    pub fn run(&self, g: &Graph<'_>, roots: &[u32], run_flags: u32) -> Result<Tables, Error> {
+    pub fn host_alloc(&self, bytes: usize) -> Result<PinnedBuf<'_>, Error> {
+        let mut p = ptr::null_mut();
+        let rc = unsafe { sys::hspf_host_alloc(self.ctx, bytes, &mut p) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(PinnedBuf { eng: self, p, bytes })
+    }
+
+    pub fn device_alloc(&self, bytes: usize) -> Result<DeviceBuf<'_>, Error> {
+        let mut p = ptr::null_mut();
+        let rc = unsafe { sys::hspf_device_alloc(self.ctx, bytes.max(1), &mut p) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(DeviceBuf { eng: self, p, bytes })
+    }
+
+    fn device_from<T: Copy>(&self, v: &[T]) -> Result<DeviceBuf<'_>, Error> {
+        let bytes = std::mem::size_of_val(v);
+        let d = self.device_alloc(bytes)?;
+        let rc = unsafe { sys::hspf_host_to_device(self.ctx, d.p, v.as_ptr() as *const c_void, bytes) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(d)
+    }
+
+    /// Results on the host.  First the PACKED hand-off (`hspf_run_packed`: one word per (root, vertex) into page-locked
+    /// memory, a quarter of `hspf_run`'s bytes over the bus; `reuse` = the buffer of an earlier result); runs whose
+    /// results do not fit packed words (`HSPF_E_NO_PACKED`: more than 24 first-hop slots) take `hspf_run`.  `roots` may
+    /// hold `HSPF_NO_ROOT` padding.
+    pub fn run<'e>(&'e self, g: &Graph<'_>, roots: &[u32], run_flags: u32, reuse: Option<PinnedBuf<'e>>) -> Result<Tables<'e>, Error> {
+        match self.run_packed(g, roots, run_flags, reuse) {
+            Err(e) if e.code == sys::HSPF_E_NO_PACKED => self.run_full(g, roots, run_flags),
+            other => other,
+        }
+    }
+
+    /// `hspf_run_packed` (ABI 7).
+    pub fn run_packed<'e>(&'e self, g: &Graph<'_>, roots: &[u32], run_flags: u32, reuse: Option<PinnedBuf<'e>>) -> Result<Tables<'e>, Error> {
+        let need = 8 * roots.len() * g.n as usize;
+        let buf = match reuse {
+            Some(b) if b.len() >= need => b,
+            _ => self.host_alloc(need)?,
+        };
+        let mut layout = std::mem::MaybeUninit::<sys::hspf_packed_layout>::zeroed();
+        let mut root_status = vec![0u8; roots.len()];
+        let rc = unsafe {
+            sys::hspf_run_packed(self.ctx, g.g, roots.as_ptr(), roots.len() as u32, run_flags, buf.p, buf.bytes, layout.as_mut_ptr(), root_status.as_mut_ptr())
+        };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(Tables { n_roots: roots.len() as u32, n_vertices: g.n, repr: Repr::Packed { buf, layout: unsafe { layout.assume_init() }, root_status } })
+    }
+
+    /// `hspf_run_packed_async`: the run AND its copy to the host belong to the ticket (the copy of one batch crosses the
+    /// bus while the next computes).  `wait_packed` gives the tables.
+    pub fn run_packed_async<'e>(&'e self, g: &Graph<'_>, roots: &[u32], run_flags: u32, reuse: Option<PinnedBuf<'e>>) -> Result<PackedTicket<'e>, Error> {
+        let need = 8 * roots.len() * g.n as usize;
+        let buf = match reuse {
+            Some(b) if b.len() >= need => b,
+            _ => self.host_alloc(need)?,
+        };
+        let mut root_status = vec![0u8; roots.len()].into_boxed_slice();
+        let mut ticket = 0u64;
+        let rc = unsafe {
+            sys::hspf_run_packed_async(self.ctx, g.g, roots.as_ptr(), roots.len() as u32, run_flags, buf.p, buf.bytes, root_status.as_mut_ptr(), &mut ticket)
+        };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(PackedTicket { ticket, buf, root_status, n_roots: roots.len() as u32, n_vertices: g.n })
+    }
+
+    pub fn wait_packed<'e>(&'e self, t: PackedTicket<'e>) -> Result<Tables<'e>, Error> {
+        let mut layout = std::mem::MaybeUninit::<sys::hspf_packed_layout>::zeroed();
+        let rc = unsafe { sys::hspf_wait_packed(self.ctx, t.ticket, layout.as_mut_ptr(), ptr::null_mut()) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(Tables {
+            n_roots: t.n_roots,
+            n_vertices: t.n_vertices,
+            repr: Repr::Packed { buf: t.buf, layout: unsafe { layout.assume_init() }, root_status: t.root_status.into_vec() },
+        })
+    }
+
+    /// `hspf_mask_words` + `hspf_run`: four arrays in host vectors.
+    pub fn run_full(&self, g: &Graph<'_>, roots: &[u32], run_flags: u32) -> Result<Tables<'_>, Error> {
         let mut words = 0u32;
         let rc = unsafe { sys::hspf_mask_words(self.ctx, g.g, roots.as_ptr(), roots.len() as u32, &mut words) };
         if rc != sys::HSPF_OK {
             return Err(self.err(rc));
         }
         let cells = roots.len() * g.n as usize;
-        let mut t = Tables {
-            n_roots: roots.len() as u32,
-            n_vertices: g.n,
-            words,
-            dist: vec![0; cells],
-            hops: vec![0; cells],
-            flags: vec![0; cells],
-            mask: vec![0; cells * words as usize],
-        };
+        let (mut dist, mut hops, mut flags, mut mask) = (vec![0u32; cells], vec![0u16; cells], vec![0u16; cells], vec![0u64; cells * words as usize]);
         let mut out = sys::hspf_result {
-            dist: t.dist.as_mut_ptr(),
-            hops: t.hops.as_mut_ptr(),
-            vflags_out: t.flags.as_mut_ptr(),
-            first_hop_mask: t.mask.as_mut_ptr(),
+            dist: dist.as_mut_ptr(),
+            hops: hops.as_mut_ptr(),
+            vflags_out: flags.as_mut_ptr(),
+            first_hop_mask: mask.as_mut_ptr(),
             n_mask_words: words,
             pop_rank: ptr::null_mut(),
         };
@@ -214,7 +524,171 @@ impl Engine {
         if rc != sys::HSPF_OK {
             return Err(self.err(rc));
         }
+        Ok(Tables { n_roots: roots.len() as u32, n_vertices: g.n, repr: Repr::Full { words, dist, hops, flags, mask } })
+    }
+
+    /// `hspf_run_device`: the tables stay in HBM (input of `routes_device` / `ancestors_device`).
+    pub fn run_device(&self, g: &Graph<'_>, roots: &[u32], run_flags: u32) -> Result<DeviceTables<'_>, Error> {
+        let mut words = 0u32;
+        let rc = unsafe { sys::hspf_mask_words(self.ctx, g.g, roots.as_ptr(), roots.len() as u32, &mut words) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        let cells = roots.len() * g.n as usize;
+        let t = DeviceTables {
+            n_roots: roots.len() as u32,
+            n_vertices: g.n,
+            words,
+            dist: self.device_alloc(cells * 4)?,
+            hops: self.device_alloc(cells * 2)?,
+            flags: self.device_alloc(cells * 2)?,
+            mask: self.device_alloc(cells * 8 * words as usize)?,
+        };
+        let mut out = sys::hspf_result {
+            dist: t.dist.p as *mut u32,
+            hops: t.hops.p as *mut u16,
+            vflags_out: t.flags.p as *mut u16,
+            first_hop_mask: t.mask.p as *mut u64,
+            n_mask_words: words,
+            pop_rank: ptr::null_mut(),
+        };
+        let rc = unsafe { sys::hspf_run_device(self.ctx, g.g, roots.as_ptr(), roots.len() as u32, run_flags, &mut out) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
         Ok(t)
+    }
+
+    /// `hspf_routes_device`: prefix attachment for every root of `run`, tables left in HBM.  `resident`: the table is the
+    /// one the previous call on this engine passed (same vectors, untouched): nothing is uploaded again.
+    pub fn routes_device(&self, run: &DeviceTables<'_>, table: &PrefixTable, resident: bool) -> Result<DeviceRoutes<'_>, Error> {
+        let (r, p, w) = (run.n_roots as usize, table.n_prefixes() as usize, run.words as usize);
+        let out = DeviceRoutes {
+            n_roots: run.n_roots,
+            n_prefixes: table.n_prefixes(),
+            words: run.words,
+            best_metric: self.device_alloc(r * p * 4)?,
+            best_entry: self.device_alloc(r * p * 4)?,
+            nexthop_mask: self.device_alloc(r * p * 8 * w)?,
+        };
+        if p == 0 {
+            return Ok(out);
+        }
+        let t = sys::hspf_prefix_table {
+            n_prefixes: table.n_prefixes(),
+            n_entries: table.pfx_vertex.len() as u32,
+            pfx_ptr: table.pfx_ptr.as_ptr(),
+            pfx_vertex: table.pfx_vertex.as_ptr(),
+            pfx_metric: table.pfx_metric.as_ptr(),
+            flags: table.flags | if resident { sys::HSPF_PFX_RESIDENT } else { 0 },
+            pfx_origin: ptr::null(),
+            init_exists: ptr::null(),
+            init_metric: ptr::null(),
+            init_origin: ptr::null(),
+        };
+        let mut ro = out.raw();
+        let rc = unsafe {
+            sys::hspf_routes_device(self.ctx, run.n_vertices, run.n_roots, run.words, run.dist.p as *const u32, run.flags.p as *const u16, run.mask.p as *const u64, &t, &mut ro)
+        };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(out)
+    }
+
+    /// A host table set brought to the device: the RIB held before, when no previous device set is comparable.
+    pub fn routes_upload(&self, n_roots: u32, n_prefixes: u32, words: u32, best_metric: &[u32], best_entry: &[u32], nexthop_mask: &[u64]) -> Result<DeviceRoutes<'_>, Error> {
+        Ok(DeviceRoutes {
+            n_roots,
+            n_prefixes,
+            words,
+            best_metric: self.device_from(best_metric)?,
+            best_entry: self.device_from(best_entry)?,
+            nexthop_mask: self.device_from(nexthop_mask)?,
+        })
+    }
+
+    /// `hspf_routes_diff_device` + `hspf_routes_pack` (twice: the changed list packed from the new set and from the old
+    /// one): the (root, prefix) pairs that need a RouteIpAdd / RouteIpDel, in the reference's emission order, with what the
+    /// route is and what it was.  ONE comparison on the device, two small copies to the host.
+    pub fn routes_changed(&self, old: &DeviceRoutes<'_>, new: &DeviceRoutes<'_>) -> Result<Vec<RouteRecord>, Error> {
+        if old.n_roots != new.n_roots || old.n_prefixes != new.n_prefixes || old.words != new.words {
+            return Err(Error { code: sys::HSPF_E_INVAL, detail: "routes_changed: the two sets differ in shape".into() });
+        }
+        let (r, p, w) = (new.n_roots as usize, new.n_prefixes as usize, new.words as usize);
+        if r * p == 0 {
+            return Ok(Vec::new());
+        }
+        let action = self.device_alloc(r * p)?;
+        let changed = self.device_alloc(r * p * 4)?;
+        let changed_ptr = self.device_alloc((r + 1) * 4)?;
+        let (ro, rn) = (old.raw(), new.raw());
+        let rc = unsafe {
+            sys::hspf_routes_diff_device(self.ctx, new.n_roots, new.n_prefixes, new.words, &ro, &rn, action.p as *mut u8, changed.p as *mut u32, changed_ptr.p as *mut u32)
+        };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        let k = unsafe { sys::hspf_routes_diff_count(self.ctx) } as usize;
+        let stride = sys::HSPF_ROUTE_REC_WORDS as usize + 2 * w;
+        let (mut rec_new, mut rec_old) = (vec![0u32; k * stride], vec![0u32; k * stride]);
+        if k != 0 {
+            for (set, rec) in [(&rn, &mut rec_new), (&ro, &mut rec_old)] {
+                let rc = unsafe {
+                    sys::hspf_routes_pack(self.ctx, new.n_roots, new.n_prefixes, new.words, set, action.p as *const u8, changed.p as *const u32, changed_ptr.p as *const u32, k as u32, rec.as_mut_ptr())
+                };
+                if rc != sys::HSPF_OK {
+                    return Err(self.err(rc));
+                }
+            }
+        }
+        let words_of = |rec: &[u32]| -> Vec<u64> { (0..w).map(|i| rec[6 + 2 * i] as u64 | (rec[7 + 2 * i] as u64) << 32).collect() };
+        Ok((0..k)
+            .map(|i| {
+                let (n, o) = (&rec_new[i * stride..(i + 1) * stride], &rec_old[i * stride..(i + 1) * stride]);
+                RouteRecord {
+                    root: n[0],
+                    prefix: n[1],
+                    action: n[2],
+                    new_metric: n[3],
+                    new_entry: n[4],
+                    new_mask: words_of(n),
+                    old_metric: o[3],
+                    old_entry: o[4],
+                    old_mask: words_of(o),
+                }
+            })
+            .collect())
+    }
+
+    /// `hspf_ancestors_device`: for every root of a hop-count `run_device` and level L (1 = first hops, 2 = second hops) the
+    /// bit sets that answer `Spt::is_on_path(a, d)` (holo-isis/src/spf.rs:261-286) for a level-L router `a` with one bit
+    /// test: `AncestorSets::is_on_path`.  A root that needed the sequential kernel has no sets (`level_count` all ones):
+    /// the caller keeps its own walk for it.
+    pub fn ancestors_device(&self, g: &Graph<'_>, roots: &[u32], run_flags: u32, run: &DeviceTables<'_>, level: u32) -> Result<AncestorSets, Error> {
+        let (r, n) = (roots.len(), g.n as usize);
+        let level_rank = self.device_alloc(r * n * 4)?;
+        let level_count = self.device_alloc(r * 4)?;
+        let mut words = 1u32;
+        loop {
+            let anc = self.device_alloc(r * n * 8 * words as usize)?;
+            let rc = unsafe {
+                sys::hspf_ancestors_device(
+                    self.ctx, g.g, roots.as_ptr(), r as u32, run_flags, run.dist.p as *const u32, run.hops.p as *const u16, run.flags.p as *const u16,
+                    level, words, level_rank.p as *mut u32, level_count.p as *mut u32, anc.p as *mut u64,
+                )
+            };
+            let count: Vec<u32> = level_count.to_host(r)?;
+            if rc == sys::HSPF_E_TOO_MANY_SLOTS {
+                let most = count.iter().copied().filter(|&c| c != u32::MAX).max().unwrap_or(0);
+                words = most.div_ceil(64).max(words + 1);
+                continue;
+            }
+            if rc != sys::HSPF_OK {
+                return Err(self.err(rc));
+            }
+            return Ok(AncestorSets { n_vertices: g.n, words, level_rank: level_rank.to_host(r * n)?, level_count: count, anc: anc.to_host(r * n * words as usize)? });
+        }
     }
 
     /// Pop ranks of roots whose pop order is dynamic (`HSPF_RF_EXACT`: zero-cost plateaus): `[root][vertex]`.
@@ -358,7 +832,16 @@ impl<'e, K: Ord + Clone> CsrCache<'e, K> {
                 }
             }
             if !rows.is_empty() {
-                self.graph.as_mut().unwrap().patch(&rows)?;
+                if let Err(e) = self.graph.as_mut().unwrap().patch(&rows) {
+                    // After a failed patch the library's graph is invalid (device arrays and host mirrors may be out of
+                    // step; every later call on it returns HSPF_E_INVAL) and `self.csr` no longer describes it: drop the
+                    // replica, so that the next call uploads afresh instead of diffing against a stale CSR.  The error
+                    // still goes up: the caller falls back to its CPU loop for this run.
+                    self.graph = None;
+                    self.keys.clear();
+                    self.csr = Csr::default();
+                    return Err(e);
+                }
                 self.csr = fresh;
             }
         } else {

@@ -113,3 +113,28 @@ def test_ospfv2_dispatch_full_runs_the_engine_partial_keeps_spt_routers_and_rib(
             assert st.engine_runs == runs and st.spts == spts and st.routers == routers
         assert st.run(areas, [{"new": {"function": "router"}, "old": None}]) == rows        # a Full one: the engine again
         assert st.engine_runs == runs + len(areas)
+
+
+def test_root_lsa_missing_keeps_the_router_table_and_spt_of_the_area():
+    """run_area returns at SpfRootNotFound BEFORE `routers.clear()` and without touching the area's SPT
+    (holo-ospf/src/spf.rs:596-620): only TransitCapability has been reset by then.  (the twin used to empty both.)"""
+    import copy
+    import glob
+    import json
+    import os
+    from holo_amd import ospf as HO
+    eng = OracleEngine()
+    gold = os.path.join(os.path.dirname(__file__), "golden", "ospfv2")
+    vec = json.load(open(sorted(glob.glob(os.path.join(gold, "topo2-1_rt1.json")))[0]))
+    st = HO.SpfState(vec["router_id"], vec["max_paths"], eng)
+    st.run([HO.Area.from_vector(a) for a in vec["areas"]])
+    aid = vec["areas"][0]["area_id"]
+    routers, spt = dict(st.routers[aid]), st.spts[aid]
+    assert routers and spt is not None
+    gone = copy.deepcopy(vec)
+    gone["areas"][0]["routers"] = [r for r in gone["areas"][0]["routers"] if r["adv_rtr"] != vec["router_id"]]
+    rows = st.run([HO.Area.from_vector(a) for a in gone["areas"]])
+    assert st.transit_capability[aid] is False
+    assert st.routers[aid] == routers and st.spts[aid] is spt, "the previous run's router table and SPT stay"
+    if len(vec["areas"]) == 1:
+        assert rows == []                           # no intra-area route comes out of an area without a root

@@ -29,6 +29,7 @@ def test_sys_rs_declares_every_function_of_the_header_with_the_same_arity():
     text = open(os.path.join(RUST, "holo-spf-hip", "src", "sys.rs")).read()
     src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "holo_spf_hip.h")).read(), flags=re.S)
     declared = set(re.findall(r"\b(hspf_[a-z0-9_]+)\s*\(", src))
+    declared -= set(re.findall(r"static inline [^;{(]*?\b(hspf_[a-z0-9_]+)\s*\(", src))     # the header's own decode helpers: nothing to bind
     bound = dict((m.group(1), m.group(2)) for m in re.finditer(r"pub fn (hspf_[a-z0-9_]+)\(([^)]*)\)", text))
     assert set(bound) == declared
     for ret, name, params in funcs:
@@ -105,6 +106,24 @@ def test_glue_calls_reference_items_that_exist_with_the_reference_arity():
     glue = open(os.path.join(RUST, "holo-isis", "src", "spf", "hip.rs")).read()
     assert glue.count("resolve_nexthop(&mut nexthop, level, mt_id, &parent, &link, &mut used_adjs, interfaces, adjacencies)") == 1
     assert "vertex_edges(vid, mt_id, metric_mode, metric_type, lsdb, lsp_entries)" in glue
+    # round 5: the routes / wire step from device tables (hip::update_rib) and the MANET ancestor sets
+    m = re.search(r"fn vertex_networks<'a>\(\s*(.*?)\)\s*->", isis, flags=re.S)
+    assert m and len([a for a in m.group(1).split(",") if a.strip()]) == 11
+    assert glue.count("vertex_networks(") == 1 and "Route::new(&vertex, network, level)" in glue
+    route = open(os.path.join(REF, "holo-isis", "src", "route.rs")).read()
+    for name in ("pub(crate) fn new(\n        vertex: &Vertex,\n        vertex_network: &VertexNetwork,\n        level: LevelNumber,", "const INSTALLED", "const CONNECTED",
+                 "pub(crate) const fn distance(&self, config: &InstanceCfg)", "pub struct Nexthop {"):
+        assert name in route, name
+    tx = open(os.path.join(REF, "holo-isis", "src", "ibus", "tx.rs")).read()
+    m = re.search(r"pub\(crate\) fn route_install\(\s*(.*?)\)\s*\{", tx, flags=re.S)
+    assert m and len([a for a in m.group(1).split(",") if a.strip()]) == 6
+    assert "ibus::tx::route_install(&instance.tx.ibus, &prefix, &route, old_sr_label, distance, interfaces)" in glue
+    m = re.search(r"pub\(crate\) fn route_uninstall\(\s*(.*?)\)\s*\{", tx, flags=re.S)
+    assert m and len([a for a in m.group(1).split(",") if a.strip()]) == 3
+    inst = open(os.path.join(REF, "holo-isis", "src", "instance.rs")).read()
+    assert "pub(crate) fn rib_mut(" in inst and "pub(crate) fn is_l2_attached_to_backbone(" in inst
+    manet = open(os.path.join(REF, "holo-isis", "src", "flooding", "manet.rs")).read()
+    assert manet.count("spt_hopcount.is_on_path(") + manet.count(".spt_hopcount\n                .is_on_path(") == 3     # the three queries the patch redirects
     ospf = open(os.path.join(REF, "holo-ospf", "src", "spf.rs")).read()
     for name in ("fn vertex_lsa_find(", "fn vertex_lsa_links<'a>(", "fn calc_nexthops(", "RouteRtr::new(", "is_vlink_endpoint()", "spf_run_count += 1"):
         assert name in ospf, name

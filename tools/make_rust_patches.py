@@ -28,7 +28,8 @@ EDITS = [
          "// MI355X path of compute_spt (holo-spf-hip): LSDB -> CSR, the SPT loop on the GPU, next hops through the\n"
          "// unchanged resolve_nexthop.  `None` from it = no engine / too small / engine error: the loop below runs.\n"
          "mod hip;\n"
-         "pub(crate) use hip::compute_spts as compute_spts_hip;\n"),
+         "pub(crate) use hip::compute_spts as compute_spts_hip;\n"
+         "pub(crate) use hip::{ManetSets, manet_sets as manet_sets_hip};\n"),
         ("    let mut used_adjs = BTreeSet::new();\n\n    // Get root vertex.\n",
          "    let mut used_adjs = BTreeSet::new();\n\n"
          "    // MI355X path (HOLO_SPF_HIP_DEVICE): same SPT, computed by the engine.\n"
@@ -37,8 +38,64 @@ EDITS = [
          "        instance,\n        interfaces,\n        adjacencies,\n        lsp_entries,\n    ) {\n"
          "        return spt;\n    }\n\n"
          "    // Get root vertex.\n"),
+        ("    let mut new_rib = BTreeMap::new();\n"
+         "    for mt_id in [MtId::Standard, MtId::Ipv6Unicast] {\n"
+         "        if instance.config.is_topology_enabled(mt_id) {\n"
+         "            compute_routes(\n"
+         "                level,\n                mt_id,\n                instance,\n                interfaces,\n"
+         "                adjacencies,\n                lsp_entries,\n                &mut new_rib,\n            );\n"
+         "        }\n    }\n\n"
+         "    // Update the local RIB and global RIB.\n"
+         "    route::update_rib(level, new_rib, instance, interfaces);\n",
+         "    //\n"
+         "    // MI355X path (spf/hip.rs `update_rib`): SPT, prefix attachment and the comparison with the RIB held\n"
+         "    // before on the device; a Route is built only for the routes that changed, and route_install /\n"
+         "    // route_uninstall are called for exactly those.  `None` = not applicable or engine error: as before.\n"
+         "    let trigger_lans = trigger_lsps\n"
+         "        .keys()\n"
+         "        .map(|lsp_id| LanId::from((lsp_id.system_id, lsp_id.pseudonode)))\n"
+         "        .collect();\n"
+         "    if hip::update_rib(\n"
+         "        level,\n        &trigger_lans,\n        instance,\n        interfaces,\n        adjacencies,\n        lsp_entries,\n    )\n"
+         "    .is_none()\n"
+         "    {\n"
+         "        let mut new_rib = BTreeMap::new();\n"
+         "        for mt_id in [MtId::Standard, MtId::Ipv6Unicast] {\n"
+         "            if instance.config.is_topology_enabled(mt_id) {\n"
+         "                compute_routes(\n"
+         "                    level,\n                    mt_id,\n                    instance,\n                    interfaces,\n"
+         "                    adjacencies,\n                    lsp_entries,\n                    &mut new_rib,\n                );\n"
+         "            }\n        }\n\n"
+         "        // Update the local RIB and global RIB.\n"
+         "        route::update_rib(level, new_rib, instance, interfaces);\n"
+         "    }\n"),
     ]),
     ("holo-isis.patch", "holo-isis/src/flooding/manet.rs", [
+        ("    pub remote_nbr_list: BTreeMap<SystemId, FloodingAlgo>,\n}\n",
+         "    pub remote_nbr_list: BTreeMap<SystemId, FloodingAlgo>,\n"
+         "    // MI355X path: ancestor bit sets of the batched hop-count run and this neighbor's row in them\n"
+         "    // (spf/hip.rs `ManetSets`): every is_on_path of reflood_list is one bit test.\n"
+         "    pub hip_sets: Option<(std::sync::Arc<spf::ManetSets>, u32)>,\n}\n"),
+        ("        let mut cache = NeighborCache::default();\n",
+         "        let mut cache = NeighborCache::default();\n"
+         "        cache.hip_sets = hip_sets.clone().map(|sets| (sets, hip_row));\n"
+         "        hip_row += 1;\n"),
+        ("    if cache.remote_nbr_list.is_empty() {\n        return BTreeSet::default();\n    }\n",
+         "    if cache.remote_nbr_list.is_empty() {\n        return BTreeSet::default();\n    }\n\n"
+         "    // Spt::is_on_path from the device's ancestor sets where they answer it (MI355X path), else the DFS.\n"
+         "    let on_path = |ancestor: SystemId, descendant: SystemId| -> bool {\n"
+         "        cache\n"
+         "            .hip_sets\n"
+         "            .as_ref()\n"
+         "            .and_then(|(sets, row)| sets.is_on_path(*row, ancestor, descendant))\n"
+         "            .unwrap_or_else(|| cache.spt_hopcount.is_on_path(ancestor, descendant))\n"
+         "    };\n"),
+        ("            !cache\n                .spt_hopcount\n                .is_on_path(vertex.id.lan_id.system_id, lsp_id.system_id)\n",
+         "            !on_path(vertex.id.lan_id.system_id, lsp_id.system_id)\n"),
+        ("                if cache.spt_hopcount.is_on_path(*rnl, thl_node) {\n",
+         "                if on_path(*rnl, thl_node) {\n"),
+        ("            .retain(|thl_node| !cache.spt_hopcount.is_on_path(*rnl, *thl_node));\n",
+         "            .retain(|thl_node| !on_path(*rnl, *thl_node));\n"),
         ("    // Process all adjacencies on active interfaces.\n    for adj in interfaces\n",
          "    // MI355X path: the hop-count SPTs of ALL Up adjacencies in ONE engine run (holo-spf-hip); when that is not\n"
          "    // available each neighbor is computed by spf::compute_spt below, as before.\n"
@@ -55,7 +112,11 @@ EDITS = [
          "    let mut batched = spf::compute_spts_hip(\n"
          "        level,\n        &nbrs,\n        false,\n        None,\n        MetricMode::HopCount,\n"
          "        instance,\n        interfaces,\n        adjacencies,\n        lsp_entries,\n    )\n"
-         "    .map(|spts| spts.into_iter());\n\n"
+         "    .map(|spts| spts.into_iter());\n"
+         "    // ... and, from the same graph, the ancestor sets that answer reflood_list's is_on_path queries\n"
+         "    let hip_sets = spf::manet_sets_hip(level, &nbrs, instance, lsp_entries)\n"
+         "        .map(std::sync::Arc::new);\n"
+         "    let mut hip_row = 0u32;\n\n"
          "    // Process all adjacencies on active interfaces.\n    for adj in interfaces\n"),
         ("        cache.spt_hopcount = spf::compute_spt(\n"
          "            level,\n            adj.system_id,\n            false,\n            None,\n"
