@@ -775,6 +775,28 @@ def other_configs(ctx, dev) -> dict:
     return out
 
 
+def preflight(rank: int, world: int, local_rank: int, dist) -> None:
+    """N > 1, before anything is timed: what each rank runs on and how the ranks see each other — device, the RCCL the
+    library will load, the peer-access row of this rank — gathered and printed by rank 0 on stderr (the first multi-GPU
+    run of this file should explain itself)."""
+    import torch
+    info = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
+            "visible_devices": torch.cuda.device_count(),
+            "peer_access": [bool(torch.cuda.can_device_access_peer(local_rank, j)) if j != local_rank else True
+                            for j in range(torch.cuda.device_count())],
+            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+            "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "rccl": None}
+    try:
+        import ctypes.util
+        info["rccl"] = ctypes.util.find_library("rccl") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    except Exception:  # noqa: BLE001
+        pass
+    allp = [None] * world
+    dist.all_gather_object(allp, info)
+    if rank == 0:
+        sys.stderr.write("[bench preflight] " + json.dumps(allp) + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -808,18 +830,35 @@ def main():
     import torch
     import torch.distributed as dist
     from holo_amd import synth
-    from holo_amd import engine as E
+    # HSPF_BENCH_STUB (tests/test_bench_ranks_gloo.py ONLY): a module that stands in for holo_amd.engine — the oracle behind the
+    # MultiEngine interface, tables in host memory — so that THIS file's rank code (launcher, id exchange, sharding offsets,
+    # in-flight loop, gather, exchange block, JSON assembly) runs at world size 2 under gloo where there is no GPU.  Never
+    # set by the driver; the line says "stub" in `data` when it is.
+    stub = os.environ.get("HSPF_BENCH_STUB")
+    if stub:
+        import importlib
+        E = importlib.import_module(stub)
+        dev = torch.device("cpu")
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
-                         "the SPF engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        class cuda:                                                   # noqa: N801
+            synchronize = staticmethod(lambda *a, **k: None)
+        backend = "gloo"
+    else:
+        from holo_amd import engine as E
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); "
+                             "the SPF engine has no CPU path")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        cuda = torch.cuda
+        backend = "nccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        if not stub:
+            preflight(rank, world, local_rank, dist)
 
-    g = synth.isis_100k()
+    g = E.bench_graph() if stub else synth.isis_100k()
     n, e = g.n, g.e
     # The sharded run goes through the C ABI's multi-GPU entry points (hspf_multi_*): one rank = one engine context on
     # this process's GPU; at N > 1 the communicator id of the library's own RCCL all-gather is created on rank 0 and
@@ -923,10 +962,10 @@ def main():
             pending[0].wait()
             pending[0] = None
         m.wait()
-        torch.cuda.synchronize()
+        cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        cuda.synchronize()
 
     tw = time.perf_counter()
     for i in range(args.warmup):
@@ -967,13 +1006,13 @@ def main():
     one_steps = 60
     for i in range(4):
         m.run(mg, run_roots, 0, [ptrs(bufs[nb], not sharded_in_lib)], 0)
-    torch.cuda.synchronize()
+    cuda.synchronize()
     t1 = time.perf_counter()
     for i in range(one_steps):
         m.run(mg, run_roots, 0, [ptrs(bufs[nb], not sharded_in_lib)], 0)
         if depth != 1:
             record_stats()
-    torch.cuda.synchronize()
+    cuda.synchronize()
     one_dt = (time.perf_counter() - t1) / one_steps
 
     last = bufs[(timed_steps - 1) % nb]
@@ -1012,7 +1051,7 @@ def main():
             fence()
             t0 = time.perf_counter()
             m.allgather_rows([last["dist"].data_ptr()], n * 4, RA)
-            torch.cuda.synchronize()
+            cuda.synchronize()
             ts.append((time.perf_counter() - t0) * 1e3)
         mine = {"rank": rank, "bytes_sent": int(R * n * 4), "bytes_received": int((RA - R) * n * 4), "sync_allgather_ms": round(min(ts), 4)}
         allx = [None] * world
@@ -1061,7 +1100,7 @@ def main():
             "timed_steps": timed_steps, "timed_ms": round(dt * 1e3, 2), "verified_roots": verified,
             "verified_gathered_dist_roots": verified_gathered,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
-            "data": "synthetic",
+            "data": "synthetic" if not stub else "synthetic (STUB engine: rank-code test, not a measurement)",
             "config": {"workload": "isis-100k: IS-IS L2 100000 routers / 1000000 directed entries, metrics U[1,100], "
                                    "64 concurrent SPF roots per GPU per step (BASELINE.json configs[2])",
                        "n_vertices": n, "n_entries": e, "roots_per_step_per_gpu": R, "mask_words": W,

@@ -184,3 +184,36 @@ def test_classes_of_one_run_side_by_side():
         finally:
             ctx.close()
     assert launches["side by side"] == launches["one after the other"]
+
+
+def test_thread_model_shutdown_with_tickets_in_flight_and_expired_tickets():
+    """The lanes are host threads owned by the context (DESIGN.md 7c "thread model"): hspf_shutdown with runs still in flight
+    drains them and joins the threads (no crash, no hang, the tables are written); a ticket whose result has been pushed out
+    of its lane's ring of eight is an error CODE (HSPF_E_INVAL with a text), never stale data."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = synth.ospf_10k()
+    n = g.n
+    roots = (np.arange(64, dtype=np.int64) * n // 64).astype(np.uint32)
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 0, go.HEAP, mask_words_=1, threads=ORACLE_THREADS)
+    ctx = _ctx(HSPF_ASYNC_LANES=2)
+    G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    tabs = [_tables(torch, dev, 64, n, 1) for _ in range(4)]
+    for t in tabs:
+        ctx.run_device_async(G, roots, 0, **_kw(t, 1))
+    ctx.close()                                       # four runs in flight: shutdown waits for them, then frees everything
+    torch.cuda.synchronize()
+    for t in tabs:
+        _check(t, ref)
+    ctx = _ctx(HSPF_ASYNC_LANES=1)
+    try:
+        G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        tickets = [ctx.run_device_async(G, roots, 0, **_kw(tabs[i % 4], 1)) for i in range(11)]
+        ctx.wait(tickets[-1])
+        with pytest.raises(E.HspfError) as ei:
+            ctx.wait(tickets[0])                      # ten later runs on its lane: the result slot has been reused
+        assert ei.value.code == -1 and "result is gone" in str(ei.value)
+        ctx.wait(tickets[-2])                         # still in the ring
+        G.free()
+    finally:
+        ctx.close()
