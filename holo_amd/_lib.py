@@ -61,6 +61,11 @@ class HspfRoutes(ctypes.Structure):
     _fields_ = [("best_metric", ctypes.c_void_p), ("best_entry", ctypes.c_void_p), ("nexthop_mask", ctypes.c_void_p)]
 
 
+class HspfRibDevice(ctypes.Structure):
+    _fields_ = [("n_prefixes", ctypes.c_uint32), ("n_mask_words", ctypes.c_uint32), ("best_metric", ctypes.c_void_p),
+                ("best_entry", ctypes.c_void_p), ("nexthop_mask", ctypes.c_void_p), ("origin", ctypes.c_void_p)]
+
+
 class HspfMultiConfig(ctypes.Structure):
     _fields_ = [("n_local", ctypes.c_uint32), ("device_ordinals", ctypes.POINTER(ctypes.c_int)),
                 ("world", ctypes.c_uint32), ("first_rank", ctypes.c_uint32), ("unique_id", u8p)]
@@ -118,6 +123,9 @@ SYMBOLS = [
     ("hspf_routes_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.POINTER(HspfPrefixTable), ctypes.POINTER(HspfRoutes)]),
+    ("hspf_rib_clear_device", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(HspfRibDevice)]),
+    ("hspf_rib_fold_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.POINTER(HspfPrefixTable), u32p, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(HspfRibDevice)]),
     ("hspf_routes_diff_device", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                                ctypes.POINTER(HspfRoutes), ctypes.POINTER(HspfRoutes),
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -2711,6 +2711,70 @@ int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uin
   return guarded(ctx, [&]() -> int { return routes_device_impl(ctx, n_vertices, n_roots, n_mask_words, dist_dev, flags_dev, mask_dev, t, out); });
 }
 
+// ---- several areas, one RIB: the fold on the device (include/holo_spf_hip.h) ----------------------------------------
+int hspf_rib_clear_device(hspf_ctx *ctx, const hspf_rib_device *rib) {
+  if (!ctx || !rib || !rib->best_metric || !rib->best_entry || !rib->nexthop_mask || !rib->origin || rib->n_mask_words == 0) return HSPF_E_INVAL;
+  if (rib->n_prefixes == 0) return HSPF_OK;
+  return guarded(ctx, [&]() -> int {
+    (void)hipSetDevice(ctx->device);
+    hipLaunchKernelGGL(k_rib_clear, dim3((rib->n_prefixes + 255) / 256), dim3(256), 0, ctx->stream, rib->n_prefixes, rib->n_mask_words,
+                       rib->best_metric, rib->best_entry, rib->nexthop_mask, rib->origin);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return HSPF_OK;
+  });
+}
+
+int hspf_rib_fold_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t area_mask_words, const uint32_t *dist_dev, const uint16_t *flags_dev,
+                         const uint64_t *mask_dev, const hspf_prefix_table *t, const uint32_t *prefix_map, uint32_t area_index, uint32_t word_offset,
+                         const hspf_rib_device *rib) {
+  if (!ctx || !t || !rib || !dist_dev || !flags_dev || !mask_dev || !rib->best_metric || !rib->best_entry || !rib->nexthop_mask || !rib->origin ||
+      area_mask_words == 0 || rib->n_mask_words == 0 || !t->pfx_ptr || (t->n_prefixes && !prefix_map) || (t->n_entries && (!t->pfx_vertex || !t->pfx_metric || !t->pfx_origin)))
+    return HSPF_E_INVAL;
+  return guarded(ctx, [&]() -> int {
+    if (!(t->flags & HSPF_PFX_ORDERED) || (t->flags & HSPF_PFX_LAST_MIN)) { ctx->last_error = "hspf_rib_fold_device: the table must be HSPF_PFX_ORDERED"; return HSPF_E_INVAL; }
+    if (area_index >= 255u || t->n_entries >= (1u << 24)) { ctx->last_error = "hspf_rib_fold_device: at most 255 areas, 2^24 entries per area table"; return HSPF_E_INVAL; }
+    if ((uint64_t)word_offset + area_mask_words > rib->n_mask_words) { ctx->last_error = "hspf_rib_fold_device: the area's mask words do not fit the instance-wide numbering"; return HSPF_E_INVAL; }
+    if (t->pfx_ptr[0] != 0 || t->pfx_ptr[t->n_prefixes] != t->n_entries) { ctx->last_error = "pfx_ptr malformed"; return HSPF_E_INVAL; }
+    for (uint32_t p = 0; p < t->n_prefixes; ++p) {
+      if (t->pfx_ptr[p + 1] < t->pfx_ptr[p]) { ctx->last_error = "pfx_ptr not monotone"; return HSPF_E_INVAL; }
+      if (prefix_map[p] >= rib->n_prefixes) { ctx->last_error = "prefix_map out of range"; return HSPF_E_INVAL; }
+    }
+    {                                                          // every instance prefix at most once (two threads must not share a state row)
+      std::vector<uint32_t> seen(prefix_map, prefix_map + t->n_prefixes);
+      std::sort(seen.begin(), seen.end());
+      if (std::adjacent_find(seen.begin(), seen.end()) != seen.end()) { ctx->last_error = "prefix_map names an instance prefix twice"; return HSPF_E_INVAL; }
+    }
+    for (uint32_t e = 0; e < t->n_entries; ++e)
+      if ((t->pfx_vertex[e] & ~HSPF_PFX_ENTRY_NETWORK) >= n_vertices) { ctx->last_error = "pfx_vertex out of range"; return HSPF_E_INVAL; }
+    if (t->n_prefixes == 0) return HSPF_OK;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t s = ctx->stream;
+    ctx->pf_shadow_ok = false;                                 // (the resident plain table, if any, is overwritten below)
+    int rc;
+    const size_t ne = std::max<size_t>(t->n_entries, 1), np = t->n_prefixes;
+    if ((rc = ensure(ctx, ctx->pf_ptr, (np + 1) * 4, false))) return rc;
+    if ((rc = ensure(ctx, ctx->pf_vtx, ne * 4, false))) return rc;
+    if ((rc = ensure(ctx, ctx->pf_met, ne * 4, false))) return rc;
+    if ((rc = ensure(ctx, ctx->pf_org, (ne + np) * 4, false))) return rc;
+    uint32_t *d_org = (uint32_t *)ctx->pf_org.p, *d_map = d_org + ne;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pf_ptr.p, t->pfx_ptr, (np + 1) * 4, hipMemcpyHostToDevice, s));
+    if (t->n_entries) {
+      HIPCHK(ctx, hipMemcpyAsync(ctx->pf_vtx.p, t->pfx_vertex, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->pf_met.p, t->pfx_metric, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
+      HIPCHK(ctx, hipMemcpyAsync(d_org, t->pfx_origin, (size_t)t->n_entries * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d_map, prefix_map, np * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_rib_fold, dim3((t->n_prefixes + 255) / 256), dim3(256), 0, s, n_vertices, area_mask_words, t->n_prefixes,
+                       (const uint32_t *)ctx->pf_ptr.p, (const uint32_t *)ctx->pf_vtx.p, (const uint32_t *)ctx->pf_met.p, (const uint32_t *)d_org,
+                       (const uint32_t *)d_map, dist_dev, flags_dev, mask_dev, area_index << 24, word_offset, rib->n_mask_words,
+                       rib->best_metric, rib->best_entry, rib->nexthop_mask, rib->origin);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(s));                      // the table was read from caller-owned host memory
+    return HSPF_OK;
+  });
+}
+
 static int routes_diff_device_impl(hspf_ctx *ctx, uint32_t n_roots, uint32_t n_prefixes, uint32_t n_mask_words,
                                    const hspf_routes *old_dev, const hspf_routes *new_dev,
                                    uint8_t *action_dev, uint32_t *changed_dev, uint32_t *changed_ptr_dev) {

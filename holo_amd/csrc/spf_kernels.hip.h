@@ -2883,6 +2883,69 @@ __global__ __launch_bounds__(256) void k_routes_ordered(uint32_t n, uint32_t n_r
   }
 }
 
+// Several areas, ONE RIB (include/holo_spf_hip.h hspf_rib_fold_device): k_routes_ordered's literal fold of one area's table
+// with the instance-wide state as initial state, written back in place.  One thread per AREA prefix p -> instance prefix
+// map[p] (each at most once: no two threads touch one state row).  The selection is recomputed per mask word, like
+// k_routes_ordered; the state's own words of OTHER areas are cleared when this area's entry takes the route over.
+__global__ __launch_bounds__(256) void k_rib_fold(uint32_t n, uint32_t W, uint32_t n_pfx, const uint32_t *__restrict__ pfx_ptr,
+                                                  const uint32_t *__restrict__ pfx_vertex, const uint32_t *__restrict__ pfx_metric,
+                                                  const uint32_t *__restrict__ pfx_origin, const uint32_t *__restrict__ map,
+                                                  const uint32_t *__restrict__ dist, const uint16_t *__restrict__ flags,
+                                                  const uint64_t *__restrict__ mask, uint32_t area_tag, uint32_t word_offset, uint32_t rib_words,
+                                                  uint32_t *__restrict__ rib_metric, uint32_t *__restrict__ rib_entry,
+                                                  uint64_t *__restrict__ rib_mask, uint32_t *__restrict__ rib_origin) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pfx) return;
+  const uint32_t ip = map[p];
+  const uint32_t a = pfx_ptr[p], b = pfx_ptr[p + 1];
+  const bool ex0 = rib_entry[ip] != INF;
+  const uint32_t bm0 = ex0 ? rib_metric[ip] : INF, bo0 = ex0 ? rib_origin[ip] : 0u;
+  bool exists = ex0;
+  uint32_t bm = bm0, bo = bo0, be = ex0 ? HSPF_PFX_KEPT_INIT : INF;
+  for (uint32_t e = a; e < b; ++e) {                       // who owns the route after this area (k_routes_ordered, word-independent part)
+    const uint32_t pv = pfx_vertex[e], v = pv & 0x7FFFFFFFu;
+    if (!(flags[v] & 1u)) continue;
+    const uint32_t m = add_sat(dist[v], pfx_metric[e]);
+    if (exists && m > bm) continue;
+    if ((pv & HSPF_PFX_ENTRY_NETWORK) && exists) {
+      if (m < bm || (m == bm && pfx_origin[e] > bo)) exists = false;
+      else continue;
+    }
+    if (!exists || m < bm) { exists = true; bm = m; bo = pfx_origin[e]; be = e; }
+  }
+  if (be == INF) return;                                   // no entry of this area in the SPT, nothing held before
+  uint64_t *R = rib_mask + (size_t)ip * rib_words;
+  if (be != HSPF_PFX_KEPT_INIT)
+    for (uint32_t w = 0; w < rib_words; ++w) R[w] = 0ull;  // the route changes hands: the earlier areas' next hops go
+  for (uint32_t w = 0; w < W; ++w) {                       // this area's next hops: the entries merged since the last take-over
+    bool ex = ex0;
+    uint32_t m0 = bm0, o0 = bo0;
+    uint64_t acc = 0;
+    for (uint32_t e = a; e < b; ++e) {
+      const uint32_t pv = pfx_vertex[e], v = pv & 0x7FFFFFFFu;
+      if (!(flags[v] & 1u)) continue;
+      const uint32_t m = add_sat(dist[v], pfx_metric[e]);
+      if (ex && m > m0) continue;
+      if ((pv & HSPF_PFX_ENTRY_NETWORK) && ex) {
+        if (m < m0 || (m == m0 && pfx_origin[e] > o0)) ex = false;
+        else continue;
+      }
+      if (!ex || m < m0) { ex = true; m0 = m; o0 = pfx_origin[e]; acc = mask[(size_t)v * W + w]; }
+      else acc |= mask[(size_t)v * W + w];
+    }
+    if (word_offset + w < rib_words) R[word_offset + w] |= acc;
+  }
+  if (be != HSPF_PFX_KEPT_INIT) { rib_metric[ip] = bm; rib_origin[ip] = bo; rib_entry[ip] = area_tag | be; }
+}
+
+__global__ __launch_bounds__(256) void k_rib_clear(uint32_t n_pfx, uint32_t rib_words, uint32_t *__restrict__ rib_metric, uint32_t *__restrict__ rib_entry,
+                                                   uint64_t *__restrict__ rib_mask, uint32_t *__restrict__ rib_origin) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pfx) return;
+  rib_metric[p] = INF; rib_entry[p] = INF; rib_origin[p] = 0u;
+  for (uint32_t w = 0; w < rib_words; ++w) rib_mask[(size_t)p * rib_words + w] = 0ull;
+}
+
 // RIB diff: update_global_rib's comparison (holo-isis/src/route.rs:254-312) on two result sets of
 // k_routes.  One thread per (root, prefix); HBM bound: 2 x (8 + 8W) bytes read, 1 + 1 written per pair.
 __global__ __launch_bounds__(256) void k_routes_diff(size_t count, uint32_t W,

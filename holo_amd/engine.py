@@ -504,6 +504,30 @@ class SpfContext:
         if rc != 0:
             raise HspfError(rc, "hspf_routes_device", self.last_error())
 
+    def rib_clear_device(self, n_prefixes: int, mask_words: int, *, best_metric_ptr: int, best_entry_ptr: int, nexthop_mask_ptr: int,
+                         origin_ptr: int) -> None:
+        """hspf_rib_clear_device(): the empty instance-wide RIB state in front of the first area (device pointers)."""
+        rib = L.HspfRibDevice(n_prefixes, mask_words, best_metric_ptr, best_entry_ptr, nexthop_mask_ptr, origin_ptr)
+        rc = self.lib.hspf_rib_clear_device(self.handle, ctypes.byref(rib))
+        if rc != 0:
+            raise HspfError(rc, "hspf_rib_clear_device", self.last_error())
+
+    def rib_fold_device(self, n_vertices: int, area_mask_words: int, dist_ptr: int, flags_ptr: int, mask_ptr: int, pfx_ptr, pfx_vertex,
+                        pfx_metric, pfx_origin, prefix_map, area_index: int, word_offset: int, *, n_prefixes: int, mask_words: int,
+                        best_metric_ptr: int, best_entry_ptr: int, nexthop_mask_ptr: int, origin_ptr: int) -> None:
+        """hspf_rib_fold_device(): the ordered fold of ONE area's table into the instance-wide RIB state on the device
+        (several areas, one RIB: holo-ospf/src/route.rs:343-448 on what the earlier areas left)."""
+        pfx_ptr = np.ascontiguousarray(pfx_ptr, np.uint32); pfx_vertex = np.ascontiguousarray(pfx_vertex, np.uint32)
+        pfx_metric = np.ascontiguousarray(pfx_metric, np.uint32); pfx_origin = np.ascontiguousarray(pfx_origin, np.uint32)
+        prefix_map = np.ascontiguousarray(prefix_map, np.uint32)
+        t = L.HspfPrefixTable(len(pfx_ptr) - 1, len(pfx_vertex), _u32(pfx_ptr), _u32(pfx_vertex), _u32(pfx_metric), PFX_SATURATING | PFX_ORDERED,
+                              _u32(pfx_origin), None, None, None)
+        rib = L.HspfRibDevice(n_prefixes, mask_words, best_metric_ptr, best_entry_ptr, nexthop_mask_ptr, origin_ptr)
+        rc = self.lib.hspf_rib_fold_device(self.handle, n_vertices, area_mask_words, dist_ptr, flags_ptr, mask_ptr, ctypes.byref(t), _u32(prefix_map),
+                                           area_index, word_offset, ctypes.byref(rib))
+        if rc != 0:
+            raise HspfError(rc, "hspf_rib_fold_device", self.last_error())
+
     def routes_diff_device(self, n_roots: int, n_prefixes: int, mask_words: int, old: tuple, new: tuple, *,
                            action_ptr: int, changed_ptr: int, changed_ptr_ptr: int) -> None:
         """hspf_routes_diff_device(): old / new = (best_metric_ptr, best_entry_ptr, nexthop_mask_ptr) of two

@@ -489,58 +489,82 @@ class Ospfv2OrderedTable:
 
 
 def ospf_update_global_rib_device(router_id: str, areas: Sequence["O.Area"], max_paths: int, engine, rib_before: List[dict],
-                                  ifindex: Dict[str, int], other_rows: Sequence[dict] = (), device="cuda:0"):
-    """compute_spf's intra-area part + update_global_rib (holo-ospf/src/route.rs:856-916, ibus/tx.rs:32-77) for OSPFv2 with
-    the SPT, the ORDERED prefix fold, the comparison with the RIB held before and the compaction of what changed all on
-    the device: one record stream comes back (hspf_routes_pack) and is expanded into the RouteIpAdd / RouteIpDel sequence.
-    `other_rows`: the inter-area / external rows of the new RIB (calculations outside this path): compared on the host and
-    merged into the sequence in prefix order.  One area with the root's Router-LSA in it — first-hop slots of different
-    areas are different numberings, a multi-area instance takes the host fold (ospf_intra_area_device_routes +
-    holo_amd.ospf.update_global_rib).  Returns (messages, records copied, prefixes compared)."""
+                                  ifindex: Dict[str, int], other_rows: Sequence[dict] = (), device="cuda:0", version: int = 2,
+                                  af: str = "ipv6"):
+    """compute_spf's intra-area part + update_global_rib (holo-ospf/src/route.rs:856-916, ibus/tx.rs:32-77) with the SPTs, the
+    ORDERED prefix fold of EVERY area into one RIB, the comparison with the RIB held before and the compaction of what
+    changed all on the device: one record stream comes back (hspf_routes_pack) and is expanded into the RouteIpAdd /
+    RouteIpDel sequence.  Several areas (round 5): the RIB is shared by the areas (route.rs:146-160, the per-area loop
+    spf.rs:540-542) — each area's table is folded into the device-resident state the earlier areas left
+    (hspf_rib_fold_device: better replaces, equal merges, the transit-network rule), in ONE instance-wide first-hop slot
+    numbering (area a's slots start at a word offset), so that a RIB row can carry next hops of several areas and the
+    comparison sees one table.  `version` 2 / 3 (OSPFv3: Intra-Area-Prefix-LSAs in LSDB order, `af`).  `other_rows`: the
+    inter-area / external rows of the new RIB (calculations outside this path): compared on the host and merged into the
+    sequence in prefix order.  Returns (messages, records copied, prefixes compared)."""
     import ipaddress
     import torch
-    live = [a for a in sorted(areas, key=lambda a: O.ip(a.area_id))]
-    if len(live) != 1:
-        rows = ospf_intra_area_device_routes(router_id, areas, max_paths, engine, device) + list(other_rows)
-        return O.update_global_rib(rows, rib_before, ifindex), 0, 0
-    g = O.AreaGraph(live[0])
-    root = g.index.get((O.RTR, O.ip(router_id)))
+    if version == 3:
+        from . import ospfv3 as V
+        mk_graph = lambda area: V.AreaGraph3(area, af)                                   # noqa: E731
+        mk_table, calc = Ospfv3PrefixTable.build, V.calc_nexthops
+    else:
+        V = O
+        mk_graph, mk_table, calc = O.AreaGraph, Ospfv2OrderedTable.build, O.calc_nexthops
+    dev = torch.device(device)
     old_intra = {O._net_key(r["prefix"]): r for r in rib_before if r.get("type", "intra-area") == "intra-area"}
     old_other = [r for r in rib_before if r.get("type", "intra-area") != "intra-area"]
-    table = Ospfv2OrderedTable.build(g) if root is not None else None
-    if root is None or not table.prefixes:
+    # ---- every area that holds the root's Router-LSA: SPT on the device, its table, its first-hop slots
+    infos, word_off = [], 0
+    for area in sorted(areas, key=lambda a: V.ip(a.area_id)):
+        g = mk_graph(area)
+        root = g.index.get((V.RTR, V.ip(router_id)))
+        if root is None:
+            continue
+        table = mk_table(g)
+        roots = np.asarray([root], np.uint32)
+        n = len(g.vids)
+        G = g.device(engine)
+        W = G.mask_words(roots)
+        dist = torch.empty((1, n), dtype=torch.int32, device=dev); hops = torch.empty((1, n), dtype=torch.int16, device=dev)
+        flags = torch.empty((1, n), dtype=torch.int16, device=dev); mask = torch.empty((1, n, W), dtype=torch.int64, device=dev)
+        stats = engine.run_device(G, roots, E.RUN_NET_NEXTHOPS, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(),
+                                  flags_ptr=flags.data_ptr(), mask_ptr=mask.data_ptr(), mask_words=W)
+        # first-hop slots -> next hops (needs Interface / Neighbor objects: host, once per slot)
+        res = E.SpfResult(dist.cpu().numpy().view(np.uint32), hops.cpu().numpy().view(np.uint16),
+                          flags.cpu().numpy().view(np.uint16), mask.cpu().numpy().view(np.uint64), None, stats)
+        slot_local: dict = {}
+        O.spt_from_engine(g, root, engine, calc, res=res, slots_out=slot_local)
+        infos.append(dict(g=g, n=n, table=table, W=W, off=word_off, dist=dist, flags=flags, mask=mask, slot_nh=slot_local))
+        word_off += W
+    if not infos or not any(i["table"].prefixes for i in infos):
+        for i in infos:
+            if i["g"]._dev is not None:
+                i["g"]._dev[1].free()
         return O.update_global_rib(list(other_rows), rib_before, ifindex), 0, 0
-    # ONE prefix list for both sides: the table's prefixes plus those only the old RIB knows (no entries: no new route)
-    keys = {O._net_key(p): p for p in table.prefixes}
+    W = max(word_off, 1)
+    # instance-wide first-hop slots: area a's slot s is slot 64 * off_a + s
+    slot_nh = {64 * i["off"] + s: nh for i in infos for s, nh in i["slot_nh"].items()}
+    table_keys = {O._net_key(p) for i in infos for p in i["table"].prefixes}
+    # ONE prefix list for both sides: the tables' prefixes plus those only the old RIB knows (no entries: no new route)
+    keys = {O._net_key(p): p for i in infos for p in i["table"].prefixes}
     for k, r in old_intra.items():
         keys.setdefault(k, r["prefix"])
     order = sorted(keys)
     prefixes = [keys[k] for k in order]
     P = len(prefixes)
     where = {k: i for i, k in enumerate(order)}
-    cnt = np.zeros(P + 1, np.uint32)
-    for j, p in enumerate(table.prefixes):
-        cnt[where[O._net_key(p)] + 1] = table.pfx_ptr[j + 1] - table.pfx_ptr[j]
-    ptr = np.cumsum(cnt, dtype=np.uint64).astype(np.uint32)           # table.prefixes is sorted the same way: entries keep their order
-    roots = np.asarray([root], np.uint32)
-    n = len(g.vids)
-    G = g.device(engine)
-    W = G.mask_words(roots)
-    dev = torch.device(device)
-    dist = torch.empty((1, n), dtype=torch.int32, device=dev); hops = torch.empty((1, n), dtype=torch.int16, device=dev)
-    flags = torch.empty((1, n), dtype=torch.int16, device=dev); mask = torch.empty((1, n, W), dtype=torch.int64, device=dev)
-    stats = engine.run_device(G, roots, E.RUN_NET_NEXTHOPS, dist_ptr=dist.data_ptr(), hops_ptr=hops.data_ptr(),
-                              flags_ptr=flags.data_ptr(), mask_ptr=mask.data_ptr(), mask_words=W)
+    # ---- the fold, area after area, on the device
     bm = torch.empty((1, P), dtype=torch.int32, device=dev); be = torch.empty((1, P), dtype=torch.int32, device=dev)
-    nm = torch.empty((1, P, W), dtype=torch.int64, device=dev)
-    engine.routes_device(n, 1, W, dist.data_ptr(), flags.data_ptr(), mask.data_ptr(), ptr, table.pfx_vertex, table.pfx_metric,
-                         best_metric_ptr=bm.data_ptr(), best_entry_ptr=be.data_ptr(), nexthop_mask_ptr=nm.data_ptr(),
-                         flags=E.PFX_SATURATING | E.PFX_ORDERED, pfx_origin=table.pfx_origin)
-    # first-hop slots -> next hops (needs Interface / Neighbor objects: host, once per slot)
-    res = E.SpfResult(dist.cpu().numpy().view(np.uint32), hops.cpu().numpy().view(np.uint16),
-                      flags.cpu().numpy().view(np.uint16), mask.cpu().numpy().view(np.uint64), None, stats)
-    slot_nh: dict = {}
-    O.spt_from_engine(g, root, engine, O.calc_nexthops, res=res, slots_out=slot_nh)
+    nm = torch.empty((1, P, W), dtype=torch.int64, device=dev); org = torch.empty((P,), dtype=torch.int32, device=dev)
+    ribkw = dict(n_prefixes=P, mask_words=W, best_metric_ptr=bm.data_ptr(), best_entry_ptr=be.data_ptr(), nexthop_mask_ptr=nm.data_ptr(), origin_ptr=org.data_ptr())
+    engine.rib_clear_device(P, W, best_metric_ptr=bm.data_ptr(), best_entry_ptr=be.data_ptr(), nexthop_mask_ptr=nm.data_ptr(), origin_ptr=org.data_ptr())
+    for ai, i in enumerate(infos):
+        t = i["table"]
+        if not t.prefixes:
+            continue
+        pmap = np.asarray([where[O._net_key(p)] for p in t.prefixes], np.uint32)
+        engine.rib_fold_device(i["n"], i["W"], i["dist"].data_ptr(), i["flags"].data_ptr(), i["mask"].data_ptr(), t.pfx_ptr, t.pfx_vertex,
+                               t.pfx_metric, t.pfx_origin, pmap, ai, i["off"], **ribkw)
     slot_sets = {s: {(addr, name) for (_i, _a), (name, addr) in nh.items()} for s, nh in slot_nh.items() if nh}
     # the OLD RIB in the same index space: metric, and the slots whose next hops the old route used; a next hop no slot
     # resolves to any more, or more next hops than max-paths allows, cannot be expressed: the metric is poisoned so that the
@@ -566,8 +590,9 @@ def ospf_update_global_rib_device(router_id: str, areas: Sequence["O.Area"], max
     engine.routes_diff_device(1, P, W, (t_om.data_ptr(), t_oe.data_ptr(), t_on.data_ptr()), newp,
                               action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(), changed_ptr_ptr=cptr.data_ptr())
     rec = engine.routes_pack(1, P, W, newp, action_ptr=act.data_ptr(), changed_ptr=chg.data_ptr(), changed_ptr_ptr=cptr.data_ptr())
-    if g._dev is not None:
-        g._dev[1].free()
+    for i in infos:
+        if i["g"]._dev is not None:
+            i["g"]._dev[1].free()
 
     def installed(nhs) -> bool:
         return any(a is not None for a, _ in nhs)
@@ -615,7 +640,7 @@ def ospf_update_global_rib_device(router_id: str, areas: Sequence["O.Area"], max
         if m["op"] == "add":
             walk[k] = m
             gone.pop(k, None)
-        elif k not in walk and k not in {O._net_key(p) for p in table.prefixes}:
+        elif k not in walk and k not in table_keys:
             gone[k] = m
     for k in list(gone):
         if k in walk or k in new_other_keys:          # the prefix lives on (under whatever type): one route, never withdrawn

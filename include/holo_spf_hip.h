@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define HSPF_ABI_VERSION 7u   /* 7: + packed results (hspf_run_packed / _device / _async, hspf_wait_packed, hspf_packed_layout + decode helpers),
-                                    hspf_host_alloc / hspf_host_free, hspf_device_alloc / _free / _to_host / hspf_host_to_device, HSPF_E_NO_PACKED (additions only); the library no longer sets
+                                    hspf_host_alloc / hspf_host_free, hspf_device_alloc / _free / _to_host / hspf_host_to_device, hspf_rib_clear_device / hspf_rib_fold_device (several areas, one RIB, on the device), HSPF_E_NO_PACKED (additions only); the library no longer sets
                                     GPU_MAX_HW_QUEUES at load time;
                                  6: + hspf_run_device_async / hspf_wait / hspf_wait_all / hspf_async_lanes, hspf_multi_run_async / hspf_multi_run_wait, hspf_recommend_cpu (additions only);
                                  5: + hspf_routes_diff_count / hspf_routes_pack, hspf_multi_init_error, HSPF_PFX_RESIDENT, HSPF_GX_ELL_* / LEAF / SUMMARY */
@@ -469,6 +469,35 @@ typedef struct {
 int hspf_routes_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t n_roots, uint32_t n_mask_words,
                        const uint32_t *dist_dev, const uint16_t *flags_dev, const uint64_t *mask_dev,
                        const hspf_prefix_table *table, hspf_routes *out_dev);
+
+/* ---- several areas, ONE RIB: the fold on device (ABI 7) ---------------------------------------
+ * An OSPF instance computes one SPT per area and folds the areas' stub networks into ONE routing table, area after area
+ * (the per-area loop holo-ospf/src/spf.rs:540-542; `update_rib_intra_area`, holo-ospf/src/route.rs:343-448, works on the
+ * RIB the earlier areas left: better replaces, equal merges, the transit-network rule on the larger LS-ID).  hspf_rib_device
+ * is that table on the device, over the INSTANCE-wide prefix list and an instance-wide first-hop slot numbering (area a's
+ * slots start at mask word `word_offset` of its fold call: word-aligned, so placing an area's mask is a word copy);
+ * hspf_rib_fold_device runs the literal ordered fold (HSPF_PFX_ORDERED) of ONE area's table with the state the earlier
+ * areas left as its initial state and writes the new state back — nothing crosses the bus between areas.  After the last
+ * area (best_metric, best_entry, nexthop_mask) IS an hspf_routes of one root over n_prefixes prefixes and n_mask_words
+ * words: hspf_routes_diff_device / hspf_routes_pack compare it with the tables of the previous SPF event as for one area.
+ *   best_entry   0xFFFFFFFF: no route; else area_index << 24 | entry index in that area's table (the route's owner:
+ *                attributes that need LSA objects come from it on the host)
+ *   origin       LS-ID of the owner's vertex LSA (the transit-network rule of the NEXT area's fold needs it)
+ * All hspf_rib_device pointers are DEVICE pointers; `table` and `prefix_map` (area prefix -> instance prefix index, every
+ * index at most once) are caller-owned HOST arrays.  table->flags must carry HSPF_PFX_ORDERED; init_* are ignored. */
+typedef struct {
+  uint32_t  n_prefixes;
+  uint32_t  n_mask_words;
+  uint32_t *best_metric;     /* [n_prefixes] */
+  uint32_t *best_entry;      /* [n_prefixes] */
+  uint64_t *nexthop_mask;    /* [n_prefixes][n_mask_words] */
+  uint32_t *origin;          /* [n_prefixes] */
+} hspf_rib_device;
+int hspf_rib_clear_device(hspf_ctx *ctx, const hspf_rib_device *rib);           /* the empty RIB in front of the first area */
+int hspf_rib_fold_device(hspf_ctx *ctx, uint32_t n_vertices, uint32_t area_mask_words,
+                         const uint32_t *dist_dev, const uint16_t *flags_dev, const uint64_t *mask_dev,   /* one root's rows of the area's run */
+                         const hspf_prefix_table *table, const uint32_t *prefix_map,
+                         uint32_t area_index, uint32_t word_offset, const hspf_rib_device *rib);
 
 /* ---- RIB diff on device (the first half of the wire step after the path) -------------------------
  * update_global_rib (holo-isis/src/route.rs:254-312, holo-ospf/src/route.rs:856-916) walks the new RIB, skips every route

@@ -117,7 +117,7 @@ def test_ospf_hand_off_from_device_tables_reproduces_recorded_ibus_messages(spf_
     Ospfv2::intra_area_networks order, so that the device result IS the RIB row), the comparison with the RIB the
     reference held before the step, the compaction and the packing; one record stream comes back and is expanded into
     the exact RouteIpAdd / RouteIpDel sequence the reference recorded (inter-area rows, where a step has any, come from
-    the recording and go through the host rule).  The two two-area steps take the documented host fold."""
+    the recording and go through the host rule).  The two two-area steps: both areas folded into one RIB ON THE DEVICE (round 5, hspf_rib_fold_device)."""
     vec = json.load(open(path))
     want = [{k: m[k] for k in m if k != "distance"} for m in vec["ibus_routes"]]
     areas = [HO.Area.from_vector(a) for a in vec["areas"]]
@@ -170,6 +170,123 @@ def test_ospf_hand_off_random_areas_before_and_after_a_change_equal_the_host_rul
         checked += 1
         nonempty += bool(want)
     assert checked == 60 and nonempty >= 15
+
+
+def _multi_area_instance(make, first_seed, rng, n_areas):
+    """A multi-area instance out of single-area random vectors that share the local router: areas 0.0.0.0, 0.0.0.1, ... (the
+    random vectors reuse one subnet numbering, so the areas advertise overlapping prefixes: ties, take-overs and merges across
+    areas); interface names made unique per area."""
+    import copy
+    base = make(first_seed)
+    areas, seed = [], first_seed
+    while len(areas) < n_areas:
+        v = make(seed) if seed != first_seed else base
+        seed += 1000
+        if v["router_id"] != base["router_id"]:
+            continue
+        a = copy.deepcopy(v["areas"][0])
+        a["area_id"] = f"0.0.0.{len(areas)}"
+        for i in a["interfaces"]:
+            i["name"] = f"a{len(areas)}-{i['name']}"
+        areas.append(a)
+    return base["router_id"], base["max_paths"], areas
+
+
+def _mutate_remote_routers(area, router_id, rng):
+    for r in area["routers"]:
+        if r["adv_rtr"] == router_id:
+            continue                                       # the root's own rows keep their first-hop slots comparable by construction
+        what = rng.random()
+        if what < 0.25:
+            for l in r["links"]:
+                if rng.random() < 0.5:
+                    l["metric"] = rng.randint(1, 12)
+        elif what < 0.32:
+            r["maxage"] = True
+    for nl in area["networks"]:
+        if rng.random() < 0.15:
+            nl["maxage"] = not nl["maxage"]
+
+
+def test_ospf_multi_area_fold_on_device_random_instances_equal_the_host_rule(spf_ctx):
+    """Round 5: SEVERAL areas folded into ONE RIB on the device (hspf_rib_fold_device:
+    update_rib_intra_area of each area on what the earlier areas left, one instance-wide first-hop slot numbering), compared
+    there with the RIB held before, one record stream back.  80 random 2- and 3-area OSPFv2 instances before / after remote
+    routers change: the messages must be those of the host rule on the twin's two multi-area RIBs."""
+    import copy
+    import random
+    from _random_ospf import make
+    checked = nonempty = shared = 0
+    for seed in range(5000, 5080):
+        rng = random.Random(seed)
+        router_id, max_paths, areas0 = _multi_area_instance(make, seed, rng, 2 + seed % 2)
+        ifindex = {i["name"]: 10 + k for k, i in enumerate(sorted((i for a in areas0 for i in a["interfaces"]), key=lambda i: i["name"]))}
+        before = HO.compute_spf_intra_area(router_id, [HO.Area.from_vector(a) for a in areas0], max_paths, spf_ctx)
+        areas1 = copy.deepcopy(areas0)
+        for a in areas1:
+            _mutate_remote_routers(a, router_id, rng)
+        live1 = [HO.Area.from_vector(a) for a in areas1]
+        after = HO.compute_spf_intra_area(router_id, live1, max_paths, spf_ctx)
+        want = HO.update_global_rib(after, before, ifindex)
+        got, n_rec, n_pfx = RT.ospf_update_global_rib_device(router_id, live1, max_paths, spf_ctx, before, ifindex)
+        assert got == want, seed
+        # the fold alone: from an empty RIB every installable route is announced, with the merged next hops
+        all_new, _, _ = RT.ospf_update_global_rib_device(router_id, live1, max_paths, spf_ctx, [], ifindex)
+        assert all_new == HO.update_global_rib(after, [], ifindex), seed
+        checked += 1
+        nonempty += bool(want)
+        pa = [{r["prefix"] for r in HO.compute_spf_intra_area(router_id, [x], max_paths, spf_ctx)} for x in live1]
+        shared += bool(set.intersection(*pa)) if len(pa) > 1 else 0
+    assert checked == 80 and nonempty >= 20 and shared >= 20, (checked, nonempty, shared)
+
+
+def test_ospfv3_wire_step_and_multi_area_fold_on_device_equal_the_host_rule(spf_ctx):
+    """The same for OSPFv3 (Intra-Area-Prefix-LSAs in LSDB order, per-entry origins, link-local next hops): one- and two-area
+    random instances before / after remote routers change their Intra-Area-Prefix / Router-LSAs; messages = the host rule on
+    the twin's RIBs (no ibus recording exists for OSPFv3: the conformance module is commented out upstream)."""
+    import copy
+    import random
+    from _random_ospfv3 import make
+    from holo_amd import ospfv3 as H3
+    checked = nonempty = 0
+    for seed in range(6000, 6060):
+        rng = random.Random(seed)
+        base = make(seed)
+        af = base["af"]
+        areas0, s2 = [], seed
+        while len(areas0) < 1 + seed % 2:
+            v = make(s2)
+            s2 += 1000
+            if v["router_id"] != base["router_id"] or v["af"] != af:
+                continue
+            a = copy.deepcopy(v["areas"][0])
+            a["area_id"] = f"0.0.0.{len(areas0)}"
+            for i in a["interfaces"]:
+                i["name"] = f"a{len(areas0)}-{i['name']}"
+            areas0.append(a)
+        router_id, max_paths = base["router_id"], base["max_paths"]
+        ifindex = {i["name"]: 10 + k for k, i in enumerate(sorted((i for a in areas0 for i in a["interfaces"]), key=lambda i: i["name"]))}
+        before = H3.compute_spf_intra_area(router_id, [H3.Area3.from_vector(a) for a in areas0], max_paths, spf_ctx, af)
+        areas1 = copy.deepcopy(areas0)
+        for a in areas1:
+            for l in a["iaps"]:
+                if l["adv_rtr"] != router_id and rng.random() < 0.3:
+                    for pfx in l["prefixes"]:
+                        pfx["metric"] = rng.randint(0, 9)
+            for r in a["routers"]:
+                if r["adv_rtr"] != router_id and rng.random() < 0.25:
+                    for k in r["links"]:
+                        k["metric"] = rng.randint(1, 12)
+        live1 = [H3.Area3.from_vector(a) for a in areas1]
+        after = H3.compute_spf_intra_area(router_id, live1, max_paths, spf_ctx, af)
+        want = HO.update_global_rib(after, before, ifindex)
+        got, n_rec, n_pfx = RT.ospf_update_global_rib_device(router_id, live1, max_paths, spf_ctx, before, ifindex, version=3, af=af)
+        assert got == want, seed
+        all_new, _, _ = RT.ospf_update_global_rib_device(router_id, live1, max_paths, spf_ctx, [], ifindex, version=3, af=af)
+        assert all_new == HO.update_global_rib(after, [], ifindex), seed
+        checked += 1
+        nonempty += bool(want)
+    assert checked == 60 and nonempty >= 10, (checked, nonempty)
 
 
 @pytest.mark.parametrize("seed", range(3))
