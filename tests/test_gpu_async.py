@@ -187,7 +187,7 @@ def test_classes_of_one_run_side_by_side():
 
 
 def test_thread_model_shutdown_with_tickets_in_flight_and_expired_tickets():
-    """The lanes are host threads owned by the context (DESIGN.md 7c "thread model"): hspf_shutdown with runs still in flight
+    """The lanes are host threads owned by the context (INTEGRATION.md 5f "thread model"): hspf_shutdown with runs still in flight
     drains them and joins the threads (no crash, no hang, the tables are written); a ticket whose result has been pushed out
     of its lane's ring of eight is an error CODE (HSPF_E_INVAL with a text), never stale data."""
     import torch

@@ -1,4 +1,4 @@
-"""CPU model of the argument in DESIGN.md section 5 for the dense multi-pass launches of the lean sweep: row evaluations of
+"""CPU model of the argument in DESIGN.md section 4 for the dense multi-pass launches of the lean sweep: row evaluations of
 arbitrary (stale) snapshots, applied in arbitrary order — so that a word can get WORSE for a while —, followed by what the
 engine does behind a dense stretch (one sweep over EVERY row that wakes the dependents of what it changes, then stamped
 sweeps until one changes nothing), end in the oracle's result.  The row function is the fixed point the kernels iterate:

@@ -60,7 +60,7 @@ def test_world_8_plans_of_the_baseline_configs_are_balanced_to_one_batch():
     """The 8-GPU shapes of BASELINE.json (no 8-GPU node has been available to any session: the plan is what can be checked):
     configs[2] weak scaling = 8 x 64 roots -> one batch per rank; configs[3] = 10 areas x 1000 roots -> hspf_plan_areas;
     configs[4] = 101 roots of the fat-tree -> two batches on two ranks, six ranks idle (the roots of one job do not fill
-    eight GPUs: that config shards by class of root, see DESIGN.md 7).  Per-rank batch counts differ by at most one, every
+    eight GPUs: that config shards by class of root, see DESIGN.md section 7).  Per-rank batch counts differ by at most one, every
     root is covered exactly once, and the slices a rank receives are what hspf_multi_run computes (hspf_shard_bounds)."""
     from holo_amd import synth
     # configs[2], weak scaling
