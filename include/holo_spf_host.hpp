@@ -86,6 +86,13 @@ class Engine {
                                                       const std::vector<uint32_t> &pfx_metric, uint32_t flags) = 0;
   virtual std::unique_ptr<DeviceRoutes> routes_upload(const RoutesOut &t, uint32_t n_roots, uint32_t n_prefixes, uint32_t mask_words) = 0;
   virtual RouteRecords routes_changed(DeviceRoutes &old_set, DeviceRoutes &new_set) = 0;
+  // Several areas, ONE RIB (hspf_rib_clear_device / hspf_rib_fold_device): an empty instance-wide state over `n_prefixes`
+  // prefixes and `mask_words` words of instance-wide first-hop slots, and the ordered fold (HSPF_PFX_ORDERED rules) of one
+  // area's table into it — `prefix_map`: area prefix -> instance prefix, the area's slots start at word `word_offset`.
+  virtual std::unique_ptr<DeviceRoutes> rib_new(uint32_t n_prefixes, uint32_t mask_words) = 0;
+  virtual void rib_fold(DeviceRoutes &rib, DeviceRun &run, const std::vector<uint32_t> &pfx_ptr, const std::vector<uint32_t> &pfx_vertex,
+                        const std::vector<uint32_t> &pfx_metric, const std::vector<uint32_t> &pfx_origin, const std::vector<uint32_t> &prefix_map,
+                        uint32_t area_index, uint32_t word_offset) = 0;
 };
 
 // CSR with the rows of `vertices` (strictly ascending) replaced — the host-side twin of hspf_graph_patch.
@@ -165,6 +172,15 @@ inline IpKey parse_ip(const std::string &text) {             // "a.b.c.d[/len]" 
 }
 
 
+// ---- the wire step's message (what goes on the ibus per route: RouteIpAdd / RouteIpDel) --------------------------------
+struct IbusMsg {
+  bool add = true;
+  std::string prefix;
+  uint32_t metric = 0;
+  std::vector<std::pair<int, std::string>> nexthops;       // (ifindex, address), as the reference's BTreeSet<Nexthop> orders them
+  bool operator==(const IbusMsg &o) const { return add == o.add && prefix == o.prefix && (!add || (metric == o.metric && nexthops == o.nexthops)); }
+};
+
 // ---- the product engine: libholo_spf_hip.so through the C ABI ---------------------------------------------------------
 class HipGraph : public Graph {
  public:
@@ -191,7 +207,7 @@ class HipDeviceRun : public DeviceRun {             // dist / hops / flags / mas
 };
 class HipDeviceRoutes : public DeviceRoutes {       // best_metric / best_entry / nexthop_mask of one table set in plain hipMalloc buffers
  public:
-  ~HipDeviceRoutes() override { for (void *p : {(void *)bm, (void *)be, (void *)nm}) if (p) (void)hipFree(p); }
+  ~HipDeviceRoutes() override { for (void *p : {(void *)bm, (void *)be, (void *)nm, (void *)org}) if (p) (void)hipFree(p); }
   RoutesOut host() override {
     RoutesOut o;
     const size_t rp = (size_t)n_roots * n_prefixes;
@@ -207,6 +223,7 @@ class HipDeviceRoutes : public DeviceRoutes {       // best_metric / best_entry 
   }
   hspf_routes raw() const { return hspf_routes{bm, be, nm}; }
   uint32_t *bm = nullptr, *be = nullptr; uint64_t *nm = nullptr;
+  uint32_t *org = nullptr;             // rib_new only: the owners' origins (hspf_rib_device.origin)
 };
 class HipEngine : public Engine {
  public:
@@ -360,6 +377,29 @@ class HipEngine : public Engine {
                hipMemcpy(o->nm, t.nexthop_mask.data(), rp * 8 * mask_words, hipMemcpyHostToDevice) != hipSuccess))
       throw std::runtime_error("hipMemcpy of the route tables failed");
     return o;
+  }
+  std::unique_ptr<DeviceRoutes> rib_new(uint32_t n_prefixes, uint32_t mask_words) override {
+    auto o = std::make_unique<HipDeviceRoutes>();
+    o->n_roots = 1; o->n_prefixes = n_prefixes; o->mask_words = mask_words;
+    if (!o->alloc() || hipMalloc((void **)&o->org, std::max<size_t>(n_prefixes, 1) * 4) != hipSuccess) throw std::runtime_error("hipMalloc of the RIB state failed");
+    const hspf_rib_device rib{n_prefixes, mask_words, o->bm, o->be, o->nm, o->org};
+    const int rc = hspf_rib_clear_device(ctx_, &rib);
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_rib_clear_device: ") + hspf_last_error(ctx_));
+    return o;
+  }
+  void rib_fold(DeviceRoutes &rib_set, DeviceRun &run, const std::vector<uint32_t> &pfx_ptr, const std::vector<uint32_t> &pfx_vertex,
+                const std::vector<uint32_t> &pfx_metric, const std::vector<uint32_t> &pfx_origin, const std::vector<uint32_t> &prefix_map,
+                uint32_t area_index, uint32_t word_offset) override {
+    auto &o = static_cast<HipDeviceRoutes &>(rib_set);
+    auto &r = static_cast<HipDeviceRun &>(run);
+    if (pfx_ptr.size() <= 1) return;
+    static const uint32_t zero = 0;
+    hspf_prefix_table tab{(uint32_t)pfx_ptr.size() - 1, (uint32_t)pfx_vertex.size(), pfx_ptr.data(), pfx_vertex.empty() ? &zero : pfx_vertex.data(),
+                          pfx_metric.empty() ? &zero : pfx_metric.data(), HSPF_PFX_SATURATING | HSPF_PFX_ORDERED, pfx_origin.empty() ? &zero : pfx_origin.data(),
+                          nullptr, nullptr, nullptr};
+    const hspf_rib_device rib{o.n_prefixes, o.mask_words, o.bm, o.be, o.nm, o.org};
+    const int rc = hspf_rib_fold_device(ctx_, r.n_vertices, r.mask_words, r.dist, r.flags, r.mask, &tab, prefix_map.data(), area_index, word_offset, &rib);
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_rib_fold_device: ") + hspf_last_error(ctx_));
   }
   RouteRecords routes_changed(DeviceRoutes &old_set, DeviceRoutes &new_set) override {
     auto &a = static_cast<HipDeviceRoutes &>(old_set);

@@ -829,13 +829,7 @@ inline std::vector<RibRow> compute_spf_device_routes(const Instance &inst, Engin
 // What goes on the ibus after an SPF: RouteIpAdd for every route that is new or differs from the RIB held before (metric
 // or next hops), nothing for an unchanged one (:268-277), nothing for a route without next hops (CONNECTED, :283-287),
 // RouteIpDel for what was installed and is gone (:303-310); adds in prefix order first, then the withdrawals.
-struct IbusMsg {
-  bool add = true;
-  std::string prefix;
-  uint32_t metric = 0;
-  std::vector<std::pair<int, std::string>> nexthops;       // (ifindex, address), as the reference's BTreeSet<Nexthop> orders them
-  bool operator==(const IbusMsg &o) const { return add == o.add && prefix == o.prefix && (!add || (metric == o.metric && nexthops == o.nexthops)); }
-};
+using hspf::host::IbusMsg;            // (holo_spf_host.hpp: shared with the OSPF twin)
 namespace detail {
 inline std::vector<std::pair<int, std::string>> wire_nexthops(const std::vector<std::pair<std::string, std::string>> &nhs, const std::map<std::string, int> &ifindex) {
   std::vector<std::tuple<int, IpKey, std::string>> v;

@@ -201,6 +201,9 @@ class TimedEngine : public Engine {
   }
   std::unique_ptr<DeviceRoutes> routes_upload(const RoutesOut &t, uint32_t a, uint32_t b, uint32_t c) override { return e_.routes_upload(t, a, b, c); }
   RouteRecords routes_changed(DeviceRoutes &o, DeviceRoutes &n) override { return e_.routes_changed(o, n); }
+  std::unique_ptr<DeviceRoutes> rib_new(uint32_t a, uint32_t b) override { return e_.rib_new(a, b); }
+  void rib_fold(DeviceRoutes &rib, DeviceRun &run, const std::vector<uint32_t> &a, const std::vector<uint32_t> &b, const std::vector<uint32_t> &c, const std::vector<uint32_t> &d,
+                const std::vector<uint32_t> &m, uint32_t ai, uint32_t off) override { e_.rib_fold(rib, run, a, b, c, d, m, ai, off); }
  private:
   Engine &e_;
 };

@@ -300,6 +300,45 @@ static int check_isis_wire(const J &vec, const std::string &golden_dir, Engine &
   return 1;
 }
 
+// OSPFv2: the recorded ibus sequences of the step vectors from the host rule and from ENGINE tables (every area folded into one
+// RIB on the engine: Engine::rib_fold = hspf_rib_fold_device).  1 equal, 0 a difference, -1 not a wire vector.
+static std::vector<O::RibRow> ospf_rib_rows(const J &rib) {
+  std::vector<O::RibRow> out;
+  for (auto &r : rib.arr) {
+    O::RibRow row{r["prefix"].s, (uint32_t)r["metric"].i(), {}};
+    row.type = r.has("type") ? r["type"].s : std::string("intra-area");
+    for (auto &nh : r["nexthops"].arr) row.nexthops.push_back({nh[0].is_null() ? std::optional<std::string>() : std::optional<std::string>(nh[0].s), nh[1].s});
+    out.push_back(std::move(row));
+  }
+  return out;
+}
+static int check_ospf_wire(const J &vec, Engine &eng, size_t &records, size_t &prefixes, int &multi_area) {
+  if (!vec.has("ibus_routes") || !vec.has("rib_before")) return -1;
+  std::map<std::string, int> ifindex;
+  for (auto &kv : vec["ifindex"].obj) ifindex[kv.first] = (int)kv.second.i();
+  std::vector<IbusMsg> want;
+  for (auto &m : vec["ibus_routes"].arr) {
+    IbusMsg w{m["op"].s == "add", m["prefix"].s, m.has("metric") ? (uint32_t)m["metric"].i() : 0u, {}};
+    if (m.has("nexthops")) for (auto &nh : m["nexthops"].arr) w.nexthops.push_back({(int)nh[0].i(), nh[1].s});
+    want.push_back(std::move(w));
+  }
+  const auto areas = areas_from_vector(vec);
+  const std::vector<O::RibRow> before = ospf_rib_rows(vec["rib_before"]);
+  std::vector<O::RibRow> other;
+  for (auto &r : ospf_rib_rows(vec["rib"])) if (r.type != "intra-area") other.push_back(r);
+  auto rows = O::compute_spf_intra_area(vec["router_id"].s, areas, (uint32_t)vec["max_paths"].i(), eng);
+  rows.insert(rows.end(), other.begin(), other.end());
+  if (!(O::update_global_rib(rows, before, ifindex) == want)) { std::fprintf(stderr, "  ospf wire: host rule differs\n"); return 0; }
+  size_t nr = 0, np = 0;
+  if (!(O::update_global_rib_device(vec["router_id"].s, areas, (uint32_t)vec["max_paths"].i(), eng, before, ifindex, other, &nr, &np) == want)) {
+    std::fprintf(stderr, "  ospf wire: device form differs\n");
+    return 0;
+  }
+  records += nr; prefixes += np;
+  if (areas.size() > 1) ++multi_area;
+  return 1;
+}
+
 static std::vector<O::v3::Area> areas3_from_vector(const J &vec) {
   std::vector<O::v3::Area> out;
   for (auto &a : vec["areas"].arr) {
@@ -391,7 +430,8 @@ int main(int argc, char **argv) {
     } else eng = std::make_unique<OracleEngine>(oracle_so);
   } catch (const std::exception &e) { std::fprintf(stderr, "engine: %s\n", e.what()); return 1; }
   int ok = 0, bad = 0, skipped = 0, manet_cases = 0, manet_bad = 0, steps_ok = 0, steps_bad = 0, steps_patched = 0, dev_ok = 0, dev_bad = 0;
-  int wire_ok = 0, wire_bad = 0, wire_pipelines = 0;
+  int wire_ok = 0, wire_bad = 0, wire_pipelines = 0, owire_ok = 0, owire_bad = 0, owire_multi = 0;
+  size_t owire_records = 0, owire_prefixes = 0;
   size_t wire_records = 0, wire_prefixes = 0;
   if (!check_hash_kat()) { std::fprintf(stderr, "flood_reduction_hash: reference vectors not reproduced\n"); return 1; }
   for (auto &path : files) {
@@ -401,6 +441,10 @@ int main(int argc, char **argv) {
         if (!golden_dir.empty() && vec["source"].s.find("snapshot ") != std::string::npos) {
           const int sr = replay_ospf_step(vec, golden_dir, *eng, steps_patched);
           if (sr > 0) ++steps_ok; else if (sr == 0) { ++steps_bad; std::fprintf(stderr, "STEP REPLAY MISMATCH %s\n", path.c_str()); }
+        }
+        {
+          const int w = check_ospf_wire(vec, *eng, owire_records, owire_prefixes, owire_multi);
+          if (w > 0) ++owire_ok; else if (w == 0) { ++owire_bad; std::fprintf(stderr, "OSPF WIRE STEP MISMATCH %s\n", path.c_str()); }
         }
         const int r = check_ospf(vec, *eng, path);
         if (r > 0) ++ok; else if (r == 0) ++bad; else ++skipped;
@@ -448,5 +492,6 @@ int main(int argc, char **argv) {
   if (steps_ok + steps_bad) std::printf("host_parity: %d step tests replayed through patched graphs (%d row-patch refreshes), %d differ\n", steps_ok + steps_bad, steps_patched, steps_bad);
   if (dev_ok + dev_bad) std::printf("host_parity: %d IS-IS RIBs also derived with the prefix attachment on the engine, %d differ\n", dev_ok + dev_bad, dev_bad);
   if (wire_ok + wire_bad) std::printf("host_parity: %d recorded ibus sequences (RouteIpAdd / RouteIpDel) reproduced by the host rule AND from engine tables (%zu records for %zu prefixes), %d differ; %d also through the running-instance pipeline\n", wire_ok, wire_records, wire_prefixes, wire_bad, wire_pipelines);
-  return (bad || manet_bad || steps_bad || dev_bad || wire_bad) ? 1 : 0;
+  if (owire_ok + owire_bad) std::printf("host_parity: %d recorded OSPFv2 ibus sequences reproduced by the host rule AND from engine tables (%zu records for %zu prefixes; %d of them two-area instances folded into one RIB on the engine), %d differ\n", owire_ok, owire_records, owire_prefixes, owire_multi, owire_bad);
+  return (bad || manet_bad || steps_bad || dev_bad || wire_bad || owire_bad) ? 1 : 0;
 }

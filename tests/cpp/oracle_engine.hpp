@@ -111,6 +111,44 @@ class OracleEngine : public Engine {
     o->t = t; o->n_roots = n_roots; o->n_prefixes = n_prefixes; o->mask_words = mask_words;
     return o;
   }
+  // several areas, one RIB: restatement of k_rib_fold (include/holo_spf_hip.h hspf_rib_fold_device) on host vectors
+  struct OracleRib : OracleRoutes { std::vector<uint32_t> origin; };
+  std::unique_ptr<DeviceRoutes> rib_new(uint32_t n_prefixes, uint32_t mask_words) override {
+    auto o = std::make_unique<OracleRib>();
+    o->n_roots = 1; o->n_prefixes = n_prefixes; o->mask_words = mask_words;
+    o->t.best_metric.assign(n_prefixes, 0xFFFFFFFFu); o->t.best_entry.assign(n_prefixes, 0xFFFFFFFFu); o->t.nexthop_mask.assign((size_t)n_prefixes * mask_words, 0);
+    o->origin.assign(n_prefixes, 0);
+    return o;
+  }
+  void rib_fold(DeviceRoutes &rib_set, DeviceRun &run, const std::vector<uint32_t> &ptr, const std::vector<uint32_t> &vtx, const std::vector<uint32_t> &met,
+                const std::vector<uint32_t> &org, const std::vector<uint32_t> &map, uint32_t area_index, uint32_t word_offset) override {
+    auto &rib = static_cast<OracleRib &>(rib_set);
+    const Tables &t = static_cast<OracleRun &>(run).t;
+    const uint32_t W = t.mask_words, RW = rib.mask_words;
+    for (uint32_t p = 0; p + 1 < ptr.size(); ++p) {
+      const uint32_t ip = map[p];
+      bool exists = rib.t.best_entry[ip] != 0xFFFFFFFFu;
+      uint32_t bm = exists ? rib.t.best_metric[ip] : 0xFFFFFFFFu, bo = exists ? rib.origin[ip] : 0u, be = exists ? HSPF_PFX_KEPT_INIT : 0xFFFFFFFFu;
+      std::vector<uint64_t> acc(W, 0);
+      for (uint32_t e = ptr[p]; e < ptr[p + 1]; ++e) {
+        const uint32_t v = vtx[e] & 0x7FFFFFFFu;
+        if (!(t.flags[v] & 1)) continue;
+        const uint64_t s = (uint64_t)t.dist[v] + met[e];
+        const uint32_t m = s > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)s;
+        if (exists && m > bm) continue;
+        if ((vtx[e] & HSPF_PFX_ENTRY_NETWORK) && exists) {
+          if (m < bm || (m == bm && org[e] > bo)) exists = false;
+          else continue;
+        }
+        if (!exists || m < bm) { exists = true; bm = m; bo = org[e]; be = e; for (uint32_t w = 0; w < W; ++w) acc[w] = t.mask[(size_t)v * W + w]; }
+        else for (uint32_t w = 0; w < W; ++w) acc[w] |= t.mask[(size_t)v * W + w];
+      }
+      if (be == 0xFFFFFFFFu) continue;
+      if (be != HSPF_PFX_KEPT_INIT) for (uint32_t w = 0; w < RW; ++w) rib.t.nexthop_mask[(size_t)ip * RW + w] = 0;
+      for (uint32_t w = 0; w < W; ++w) if (word_offset + w < RW) rib.t.nexthop_mask[(size_t)ip * RW + word_offset + w] |= acc[w];
+      if (be != HSPF_PFX_KEPT_INIT) { rib.t.best_metric[ip] = bm; rib.origin[ip] = bo; rib.t.best_entry[ip] = (area_index << 24) | be; }
+    }
+  }
   RouteRecords routes_changed(DeviceRoutes &old_set, DeviceRoutes &new_set) override {
     const RoutesOut &a = static_cast<OracleRoutes &>(old_set).t, &b = static_cast<OracleRoutes &>(new_set).t;
     const uint32_t R = new_set.n_roots, P = new_set.n_prefixes, W = new_set.mask_words;

@@ -76,6 +76,7 @@ def test_cpp_host_side_reproduces_recorded_ribs_with_the_oracle_as_engine():
     # the wire step (round 5): the reference's recorded RouteIpAdd / RouteIpDel sequences from the host rule, from engine
     # tables (comparison, compaction, packing on the engine) and, where the step kept the interfaces, the running pipeline
     assert "17 recorded ibus sequences" in r.stdout and ", 0 differ; 3 also through the running-instance pipeline" in r.stdout
+    assert "11 recorded OSPFv2 ibus sequences" in r.stdout and "2 of them two-area instances folded into one RIB on the engine), 0 differ" in r.stdout
 
 
 def test_cpp_host_side_without_a_device_reports_it():
@@ -96,6 +97,7 @@ def test_cpp_host_side_reproduces_recorded_ribs_on_gpu():
     assert "30 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout      # hspf_graph_patch
     assert "57 IS-IS RIBs also derived with the prefix attachment on the engine, 0 differ" in r.stdout     # hspf_routes_device
     assert "17 recorded ibus sequences" in r.stdout and ", 0 differ; 3 also through the running-instance pipeline" in r.stdout   # hspf_routes_diff_device + hspf_routes_pack
+    assert "11 recorded OSPFv2 ibus sequences" in r.stdout and "2 of them two-area instances folded into one RIB on the engine), 0 differ" in r.stdout   # hspf_rib_fold_device
 
 
 def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_path):
