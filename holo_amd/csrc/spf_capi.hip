@@ -1236,103 +1236,107 @@ static int copy_to_host(hspf_ctx *ctx, void *dst, const void *src_dev, size_t by
 
 static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
                     hspf_result *out, bool host_out, const uint32_t *row_map = nullptr, uint32_t total_rows = 0,
-                    bool no_fused = false, PackedReq *pk = nullptr) {
-  // packed results (hspf_run_packed*): `out` is not read; host_out says whether pk->dst is host memory
-  hspf_result pk_none{};
-  if (pk) { out = &pk_none; host_out = pk->host; }
-  if (!ctx || !g || !roots || !out || n_roots == 0 || (!pk && !out->dist) || (row_map && host_out) || (pk && (row_map || !pk->dst))) return HSPF_E_INVAL;
-  if (pk && (run_flags & HSPF_RUN_POP_RANK)) { ctx->last_error = "HSPF_RUN_POP_RANK with packed results"; return HSPF_E_INVAL; }
-  if (g && g->invalid) { ctx->last_error = "the graph is invalid after a failed hspf_graph_patch (free it and upload again)"; return HSPF_E_INVAL; }
-  if (pk && no_fused) { ctx->last_error = "packed results: hop counts beyond the hop field of a run with more than 16 first-hop slots"; return HSPF_E_NO_PACKED; }
-  if (!row_map) total_rows = n_roots;
-  (void)hipSetDevice(ctx->device);
-  const uint32_t n = g->n;
-  // Bound the scratch (state, stamps, staging) of one pass: the batch axis is processed in groups of
-  // at most ~2^26 (vertex, root) pairs (>= 1 batch of 64 roots), each group a complete run of its own,
-  // so that "every router as a root" on a large LSDB does not need state for all roots at once.
-  {
-    const uint64_t max_pairs = 1ull << 26;
-    uint32_t group = (uint32_t)std::max<uint64_t>(64, (max_pairs / std::max<uint32_t>(n, 1)) / 64 * 64);
-    if (n_roots > group && pk) {
-      // every group must come in ONE layout: the field split is made from the slots of ALL roots (min_slots), and when a
-      // group still comes back with another layout than the first (a 4-byte overflow that only its roots run into, a ragged
-      // last group on the lane = vertex path) the call starts over with 8-byte words for everybody
-      uint32_t all_slots = pk->min_slots;
-      {
-        std::vector<uint32_t> hv, hb;
-        for (uint32_t r = 0; r < n_roots; ++r) {
-          if (roots[r] == HSPF_NO_ROOT) continue;
-          if (roots[r] >= n) { ctx->last_error = "root out of range"; return HSPF_E_INVAL; }
-          uint32_t total = 0;
-          build_slot_table(g, roots[r], hv, hb, total, ctx->mark, next_mark(ctx, n));
-          all_slots = std::max(all_slots, total);
-        }
-      }
-      for (int attempt = 0; attempt < 2; ++attempt) {
-        hspf_stats acc{};
-        bool again = false;
-        hspf_packed_layout first{};
-        for (uint32_t off = 0; off < n_roots && !again; off += group) {
-          const uint32_t nr = std::min(group, n_roots - off);
-          PackedReq part = *pk;
-          part.row_off = pk->row_off + off; part.min_slots = all_slots; part.force_wide = pk->force_wide || attempt == 1;
-          const int rc = run_impl(ctx, g, roots + off, nr, run_flags, nullptr, host_out, nullptr, 0, no_fused, &part);
-          if (rc) return rc;
-          if (off == 0) first = part.layout;
-          else if (memcmp(&first, &part.layout, sizeof(first)) != 0) { again = true; break; }
-          const hspf_stats &p = ctx->stats;
-          acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
-          acc.n_exact_roots += p.n_exact_roots; acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
-          acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_finish += p.ms_finish; acc.ms_d2h += p.ms_d2h;
-          acc.state_bytes = std::max(acc.state_bytes, p.state_bytes); acc.narrow_overflow += p.narrow_overflow; acc.rows_recomputed += p.rows_recomputed;
-        }
-        if (!again) { pk->layout = first; ctx->stats = acc; return HSPF_OK; }
-      }
-      ctx->last_error = "packed results: the groups of the call did not agree on a layout";
-      return HSPF_E_INTERNAL;
-    }
-    if (n_roots > group) {
-      hspf_stats acc{};
-      if (out->first_hop_mask && out->n_mask_words == 0) return HSPF_E_INVAL;
-      for (uint32_t off = 0; off < n_roots; off += group) {
-        const uint32_t nr = std::min(group, n_roots - off);
-        hspf_result part = *out;
-        const size_t o = row_map ? 0 : (size_t)off * n;          // mapped rows are addressed through the map
-        part.dist = out->dist + o;
-        if (out->hops) part.hops = out->hops + o;
-        if (out->vflags_out) part.vflags_out = out->vflags_out + o;
-        if (out->first_hop_mask) part.first_hop_mask = out->first_hop_mask + o * out->n_mask_words;
-        if (out->pop_rank) part.pop_rank = out->pop_rank + o;
-        const int rc = run_impl(ctx, g, roots + off, nr, run_flags, &part, host_out, row_map ? row_map + off : nullptr, total_rows, no_fused);
-        if (rc) return rc;
-        const hspf_stats &p = ctx->stats;
-        acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
-        acc.n_dag_launches += p.n_dag_launches; acc.n_exact_roots += p.n_exact_roots;
-        acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
-        acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
-        acc.ms_d2h += p.ms_d2h; acc.state_bytes = std::max(acc.state_bytes, p.state_bytes);
-        acc.narrow_overflow += p.narrow_overflow; acc.rows_recomputed += p.rows_recomputed;
-      }
-      ctx->stats = acc;
-      return HSPF_OK;
-    }
+                    bool no_fused = false, PackedReq *pk = nullptr);
+
+}  // extern "C"  (the pass below has a member template)
+
+// ---- one pass of run_impl (at most one group of roots): the state of the call, one member function per step / engine path ----
+// (round 5: run_impl was one function of ~900 lines; the steps and the engine paths are separate functions now, the
+// dispatcher is Run::go.  Behaviour unchanged: the GPU suite and the fuzz campaign ran on this form.)
+namespace {
+struct Run {
+  // the call
+  hspf_ctx *ctx; const hspf_graph *g; const uint32_t *roots; uint32_t n_roots, run_flags; hspf_result *out; bool host_out;
+  const uint32_t *row_map; uint32_t total_rows; bool no_fused; PackedReq *pk; uint32_t n;
+  hspf_stats &st;                                                    // ctx->stats
+  std::vector<uint32_t> &tab_ptr, &tab_vtx, &tab_base;               // slot tables of the roots (host)
+  Run(hspf_ctx *c, const hspf_graph *gr, const uint32_t *r, uint32_t nr, uint32_t fl, hspf_result *o, bool ho, const uint32_t *rm, uint32_t tr, bool nf, PackedReq *p)
+      : ctx(c), g(gr), roots(r), n_roots(nr), run_flags(fl), out(o), host_out(ho), row_map(rm), total_rows(tr), no_fused(nf), pk(p), n(gr->n), st(c->stats),
+        tab_ptr(c->hb_tab_ptr), tab_vtx(c->hb_tab_vtx), tab_base(c->hb_tab_base) {}
+  // shape of the run
+  uint32_t B = 0, L = 0, need_words = 1, max_slots = 0, W = 1, out_words = 1;
+  hipStream_t s = nullptr;
+  std::chrono::steady_clock::time_point t_entry;
+  hspf_ctx::Prefill pf;
+  bool want_mask = false, fused = false, narrow = false, lean = false, giant = false, count_rows = false, single = false, lv = false, use_fw = false, defer = false;
+  FusedParams fp_wide{}, fp_narrow{}, fp_lean{};
+  size_t rows = 0, rn = 0, giant_tags = 0, up_bytes = 0, w_roots = 0, w_ptr = 0, w_vtx = 0, w_base = 0, w_map = 0, w_fg = 0;
+  int rc = 0;
+  // device pointers
+  OutDev od{};
+  uint32_t *d_kcnt = nullptr, *d_rank = nullptr, *d_misfit = nullptr, *d_up = nullptr, *d_dist = nullptr, *d_hv = nullptr, *d_roots = nullptr, *d_lf = nullptr, *d_stamp = nullptr;
+  uint64_t *d_mask = nullptr, *d_st = nullptr;
+  int *d_changed = nullptr;
+  const FusedGraph *d_fg = nullptr;
+  GraphDev gd{};
+  SlotTabs tabs{};
+  uint32_t ignore_ovl = 0, net_nh = 0;
+  dim3 grid, fgrid;
+  // phases
+  std::function<void()> on_retry;      // set by a path whose `post` leaves something behind that a non-final chunk must undo
+  std::function<void(uint32_t)> spec_fill;   // fused path: the NEXT run's scratch fill, enqueued behind a chunk's flag read-back
+  uint32_t *rb_ctl = nullptr;          // lean path: its plan counters come back with every chunk's flags
+  uint32_t chunk_last = 0;             // index of the last sweep of the chunk `post` is enqueued behind
+  bool two_events = false, tail_done = false, finished = false, delegated = false;
+  uint32_t last_esz = 0, last_ns = 0, last_fillw = 0xFFFFFFFFu, spec_nz = 0;
+  bool spec_done = false, emit_reset = false;
+  std::vector<uint32_t> ex;            // roots of the sequential kernel
+  // packed results
+  bool pk_full = false;
+  int pk_mode = -1;                    // which fused_run produced the words: 2 lean, 1 narrow, 0 wide; -1: k_pack_full (wide layout)
+  size_t pk_esz = 0;
+  // device address of this run's first row of packed words of `esz` bytes: staging for a host destination, else the
+  // caller's buffer at the group's row offset
+  char *pk_dev(size_t esz) const { return pk->dev_stage ? (char *)pk->dev_stage : pk->host ? (char *)ctx->o_pack.p : (char *)pk->dst + pk->row_off * (size_t)n * esz; }
+  int pk_staging() {                         // row-major staging tables of a packed run (k_single / k_lv / k_exact write them)
+    int r2;
+    if ((r2 = ensure(ctx, ctx->o_dist, rn * 4, false))) return r2;
+    if ((r2 = ensure(ctx, ctx->o_hops, rn * 2, false))) return r2;
+    if ((r2 = ensure(ctx, ctx->o_flags, rn * 2, false))) return r2;
+    if ((r2 = ensure(ctx, ctx->o_mask, rn * 8, false))) return r2;
+    return HSPF_OK;
   }
+  int prepare();
+  int choose_state();
+  int prepare_scratch();
+  int prepare_outputs();
+  int upload_block();
+  int init_state();
+  template <class Launch, class Post> int run_phase(uint32_t est, uint32_t pre_zeroed, Launch &&launch, uint32_t &n_launch, Post &&post);
+  int fused_run(int mode);
+  int lv_run();
+  int single_run();
+  int path_fused();
+  int path_wide();
+  int exact_roots();
+  int packed_finish();
+  int deliver();
+  int go() {
+    if ((rc = prepare()) || (rc = choose_state()) || (rc = prepare_scratch()) || (rc = prepare_outputs()) || (rc = upload_block()) || (rc = init_state())) return rc;
+    rc = fused ? path_fused() : path_wide();
+    if (rc || delegated) return rc;
+    if ((rc = exact_roots())) return rc;
+    if ((rc = packed_finish())) return rc;
+    return deliver();
+  }
+};
+
+// Validation of the roots, the first-hop slot tables (host, O(degree) per root), the mask width.
+int Run::prepare() {
   for (uint32_t r = 0; r < n_roots; ++r)
     if (roots[r] != HSPF_NO_ROOT && roots[r] >= n) { ctx->last_error = "root out of range"; return HSPF_E_INVAL; }
   if ((run_flags & HSPF_RUN_POP_RANK) && !out->pop_rank) { ctx->last_error = "HSPF_RUN_POP_RANK without pop_rank buffer"; return HSPF_E_INVAL; }
-  const uint32_t B = (n_roots + 63) / 64, L = B * 64;
-  hipStream_t s = ctx->stream;
-  hspf_stats &st = ctx->stats;
+  B = (n_roots + 63) / 64; L = B * 64;
+  s = ctx->stream;
   st = hspf_stats{};
   st.n_roots = n_roots; st.n_batches = B;
-  const auto t_entry = std::chrono::steady_clock::now();      // hspf_stats::dbg[2..3]: host time of the call (us)
-  hspf_ctx::Prefill pf = ctx->prefill;      // what the previous run left for this one; whoever does not take it loses it
+  t_entry = std::chrono::steady_clock::now();      // hspf_stats::dbg[2..3]: host time of the call (us)
+  pf = ctx->prefill;      // what the previous run left for this one; whoever does not take it loses it
   ctx->prefill.valid = false;
 
   // ---- slot tables (host, O(deg) per root) and mask width
-  std::vector<uint32_t> &tab_ptr = ctx->hb_tab_ptr, &tab_vtx = ctx->hb_tab_vtx, &tab_base = ctx->hb_tab_base;
   tab_ptr.assign(L + 1, 0); tab_vtx.clear(); tab_base.clear();
-  uint32_t need_words = 1, max_slots = 0;
+  need_words = 1; max_slots = 0;
   {
     std::vector<uint32_t> hv, hb;
     for (uint32_t r = 0; r < L; ++r) {
@@ -1349,8 +1353,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     }
   }
   if (pk) max_slots = std::max(max_slots, pk->min_slots);
-  const bool want_mask = pk || out->first_hop_mask != nullptr;
-  if (pk) { pk_none.n_mask_words = 1; }
+  want_mask = pk || out->first_hop_mask != nullptr;
+  if (pk) out->n_mask_words = 1;                              // (`out` is the wrapper's placeholder in packed mode)
   if (pk && (need_words > 1 || max_slots > (g->wide24_bad ? 16u : 24u) || n >= (1u << 23) || (ctx->variant & 1u))) {
     ctx->last_error = "packed results: a root of the run has more than " + std::to_string(g->wide24_bad ? 16 : 24) + " first-hop slots (or the fused path is off)";
     return HSPF_E_NO_PACKED;
@@ -1360,10 +1364,14 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     return HSPF_E_TOO_MANY_SLOTS;
   }
   if (need_words > 16) { ctx->last_error = "more than 1024 first-hop slots"; return HSPF_E_TOO_MANY_SLOTS; }
-  const uint32_t W = round_words(need_words);
-  const uint32_t out_words = want_mask ? out->n_mask_words : W;
+  W = round_words(need_words);
+  out_words = want_mask ? out->n_mask_words : W;
   st.n_mask_words = need_words;
+  return HSPF_OK;
+}
 
+// The state of the run: one fused fixed point over a packed word (4 bytes when the fields fit, else 8) or the wide-mask path.
+int Run::choose_state() {
   // Fast path: every root has <= 24 first-hop slots -> one fused fixed point over a packed state
   // (k_fused), 4 bytes per (vertex, root) when the slots, hop counts and distances fit (checked on
   // device, LF_OVERFLOW -> the run is redone with the 8-byte state and the graph remembers), else 8;
@@ -1372,12 +1380,12 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // 17-24 slots: the 8-byte state with a wider mask field and correspondingly fewer hop bits (32 - M); a root farther
   // than that many router hops from something raises LF_OVERFLOW and the run is redone on the two-phase path.
   const uint32_t fused_max_slots = g->wide24_bad ? 16u : 24u;
-  const bool fused = !no_fused && max_slots <= fused_max_slots && n < (1u << 23) && !(ctx->variant & 1u);
+  fused = !no_fused && max_slots <= fused_max_slots && n < (1u << 23) && !(ctx->variant & 1u);
   const uint32_t Mw = std::max(16u, max_slots);
-  FusedParams fp_wide{0u, Mw, Mw == 16u ? 0xFFFFu : (1u << (32u - Mw)) - 1u, 0xFFFFFFFFu, g->max_path_metric, 0xFFFFFFFFu,
+  fp_wide = FusedParams{0u, Mw, Mw == 16u ? 0xFFFFu : (1u << (32u - Mw)) - 1u, 0xFFFFFFFFu, g->max_path_metric, 0xFFFFFFFFu,
                       g->hopcount_like ? 1u : 0u, 0xFFFFFFFFu};
-  FusedParams fp_narrow = fp_wide, fp_lean = fp_wide;
-  bool narrow = false, lean = false;
+  fp_narrow = fp_wide; fp_lean = fp_wide;
+  narrow = false; lean = false;
   const bool pk_wide = pk && pk->force_wide;
   if (fused && !g->narrow_bad && !(ctx->variant & 2u) && !pk_wide) {
     // field split of the 4-byte state: M mask bits = slots of this run, 7 hop bits (6 when that
@@ -1413,9 +1421,13 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       }
     }
   }
+  return HSPF_OK;
+}
+
+// Scratch of the pass, the layout of the upload block, the pinned blocks.
+int Run::prepare_scratch() {
   // ---- scratch
-  int rc;
-  const size_t rows = (size_t)B * n * 64;
+  rows = (size_t)B * n * 64;
   if (fused) {
     if ((rc = ensure(ctx, ctx->st64, rows * 8))) return rc;
     if ((rc = ensure(ctx, ctx->stamp, (size_t)B * n * 4))) return rc;
@@ -1430,10 +1442,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   if ((rc = ensure(ctx, ctx->changed, (size_t)CHANGED_CAP * 4))) return rc;
   // upload block (u32 words): roots[L] | tab_ptr[L+1] | tab_vtx[nv] | tab_base[nv] | row_map[L] | pad to 16 B | FusedGraph
   const size_t nv = tab_vtx.size();
-  const size_t w_roots = 0, w_ptr = L, w_vtx = w_ptr + L + 1, w_base = w_vtx + std::max<size_t>(nv, 1);
-  const size_t w_map = w_base + std::max<size_t>(nv, 1);
-  const size_t w_fg = (w_map + L + 3) & ~size_t(3);
-  const size_t up_bytes = w_fg * 4 + sizeof(FusedGraph);
+  w_roots = 0; w_ptr = L; w_vtx = w_ptr + L + 1; w_base = w_vtx + std::max<size_t>(nv, 1);
+  w_map = w_base + std::max<size_t>(nv, 1);
+  w_fg = (w_map + L + 3) & ~size_t(3);
+  up_bytes = w_fg * 4 + sizeof(FusedGraph);
   if ((rc = ensure(ctx, ctx->up, up_bytes))) return rc;
   if (ctx->h_up_cap / 2 < up_bytes) {
     (void)hipStreamSynchronize(s);
@@ -1449,8 +1461,8 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     ctx->h_lane_cap = L;
   }
   // slices of the giant rows (FusedGraph::giant_part): tags, then GIANT_WORDS x 64 words per (batch, slice)
-  const bool giant = g->n_giant != 0 && g->n_heavy_chunks != 0 && !(ctx->variant & 8192u);   // HSPF_VARIANT bit13: rows walked whole
-  const size_t giant_tags = ((size_t)B * g->n_giant + 63) & ~size_t(63);
+  giant = g->n_giant != 0 && g->n_heavy_chunks != 0 && !(ctx->variant & 8192u);   // HSPF_VARIANT bit13: rows walked whole
+  giant_tags = ((size_t)B * g->n_giant + 63) & ~size_t(63);
   if (giant) {                                           // packed path: one accumulator per slice; k_fw: one per 64 links, W-word masks
     const size_t packed = (size_t)B * g->n_giant_slices * GIANT_WORDS * 64 * 4;
     const size_t wide = (size_t)B * g->n_giant_slices * 4 * (6 * 64 * 4 + 2 * (size_t)W * 64 * 8);
@@ -1458,38 +1470,33 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   }
   // work counter of the fused kernel (HSPF_RUN_COUNT_ROWS): [256] rows recomputed
   if ((rc = ensure(ctx, ctx->kcnt, 256 * 4))) return rc;
-  uint32_t *d_kcnt = (uint32_t *)ctx->kcnt.p;
-  const bool count_rows = (run_flags & HSPF_RUN_COUNT_ROWS) != 0;
+  d_kcnt = (uint32_t *)ctx->kcnt.p;
+  count_rows = (run_flags & HSPF_RUN_COUNT_ROWS) != 0;
+  return HSPF_OK;
+}
+
+// Which kernel of the fused path takes the run; where the results go (the caller's device tables, staging for host
+// output, packed words).
+int Run::prepare_outputs() {
   // which of the fused path's kernels takes the run (the comments are at their use below)
   const uint32_t smax = std::min(n_roots <= 64 ? ctx->single_max_n * 2u : ctx->single_max_n, SINGLE_MAX_N);
-  const bool single = fused && n <= smax && g->e_kept <= SINGLE_MAX_E;
-  const bool lv = fused && !single && n_roots <= ctx->lv_max_roots && n >= ctx->lv_min_n && !giant;
+  single = fused && n <= smax && g->e_kept <= SINGLE_MAX_E;
+  lv = fused && !single && n_roots <= ctx->lv_max_roots && n >= ctx->lv_min_n && !giant;
   // row-major output targets (device): the caller's device buffers, or staging for host output
-  OutDev od{};
-  const size_t rn = (size_t)total_rows * n;               // rows of the output arrays (== n_roots unless mapped)
-  uint32_t *d_rank = nullptr;
+  od = OutDev{};
+  rn = (size_t)total_rows * n;               // rows of the output arrays (== n_roots unless mapped)
+  d_rank = nullptr;
   // packed results: the fused emit writes the words themselves (od.packed, set per fused_run: the word size is the run's);
   // k_single / k_lv write row-major tables into staging, which k_pack_full then packs (8-byte words)
-  const bool pk_full = pk && (single || lv);
-  uint32_t *d_misfit = nullptr;
-  // device address of this run's first row of packed words of `esz` bytes: staging for a host destination, else the
-  // caller's buffer at the group's row offset
-  auto pk_dev = [&](size_t esz) -> char * { return pk->dev_stage ? (char *)pk->dev_stage : pk->host ? (char *)ctx->o_pack.p : (char *)pk->dst + pk->row_off * (size_t)n * esz; };
-  int pk_mode = -1;                                        // which fused_run produced the words: 2 lean, 1 narrow, 0 wide; -1: k_pack_full (wide layout)
+  pk_full = pk && (single || lv);
+  d_misfit = nullptr;
+  pk_mode = -1;                                        // which fused_run produced the words: 2 lean, 1 narrow, 0 wide; -1: k_pack_full (wide layout)
   if (pk) {
     if (pk->host && !pk->dev_stage && (rc = ensure(ctx, ctx->o_pack, rn * 8, false))) return rc;
     if ((rc = ensure(ctx, ctx->pk_flag, 256, false))) return rc;
     d_misfit = (uint32_t *)ctx->pk_flag.p;
     HIPCHK(ctx, hipMemsetAsync(d_misfit, 0, 4, ctx->stream));
   }
-  auto pk_staging = [&]() -> int {                         // row-major staging tables of a packed run (k_single / k_lv / k_exact write them)
-    int r2;
-    if ((r2 = ensure(ctx, ctx->o_dist, rn * 4, false))) return r2;
-    if ((r2 = ensure(ctx, ctx->o_hops, rn * 2, false))) return r2;
-    if ((r2 = ensure(ctx, ctx->o_flags, rn * 2, false))) return r2;
-    if ((r2 = ensure(ctx, ctx->o_mask, rn * 8, false))) return r2;
-    return HSPF_OK;
-  };
   if (pk) {
     od.out_words = 1;
     if (pk_full) {
@@ -1510,17 +1517,21 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   }
   od.row_map = nullptr;                                    // set below, once the upload block's address is known
 
-  uint32_t *d_up = (uint32_t *)ctx->up.p;
-  uint32_t *d_dist = (uint32_t *)ctx->dist.p, *d_hv = (uint32_t *)ctx->hv.p, *d_roots = d_up + w_roots;
-  uint64_t *d_mask = (uint64_t *)ctx->mask.p;
-  uint32_t *d_lf = (uint32_t *)ctx->lane_flags.p;
-  int *d_changed = (int *)ctx->changed.p;
-  const GraphDev gd = g->dev();
-  const SlotTabs tabs{d_up + w_ptr, d_up + w_vtx, d_up + w_base};
+  d_up = (uint32_t *)ctx->up.p;
+  d_dist = (uint32_t *)ctx->dist.p; d_hv = (uint32_t *)ctx->hv.p; d_roots = d_up + w_roots;
+  d_mask = (uint64_t *)ctx->mask.p;
+  d_lf = (uint32_t *)ctx->lane_flags.p;
+  d_changed = (int *)ctx->changed.p;
+  gd = g->dev();
+  tabs = SlotTabs{d_up + w_ptr, d_up + w_vtx, d_up + w_base};
   if (row_map) od.row_map = d_up + w_map;
-  const uint32_t ignore_ovl = (run_flags & HSPF_RUN_IGNORE_OVERLOAD) ? 1u : 0u;
-  const uint32_t net_nh = (run_flags & HSPF_RUN_NET_NEXTHOPS) ? 1u : 0u;
+  ignore_ovl = (run_flags & HSPF_RUN_IGNORE_OVERLOAD) ? 1u : 0u;
+  net_nh = (run_flags & HSPF_RUN_NET_NEXTHOPS) ? 1u : 0u;
+  return HSPF_OK;
+}
 
+// Roots, slot tables, the fused kernel's descriptor: one pinned block, one copy (skipped when the device holds it already).
+int Run::upload_block() {
   // ---- upload roots / slot tables / descriptor (one pinned block, one copy), init state
   {
     uint32_t *h = ctx->h_up + (ctx->h_up_sel ? ctx->h_up_cap / 8 : 0);
@@ -1544,14 +1555,19 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       ctx->up_valid = true; ctx->up_len = up_bytes; ctx->h_up_sel ^= 1;
     }
   }
-  uint64_t *d_st = (uint64_t *)ctx->st64.p;
-  uint32_t *d_stamp = (uint32_t *)ctx->stamp.p;
+  return HSPF_OK;
+}
+
+// State of the wide-mask path (the fused path initialises per fused_run), grids, the events.
+int Run::init_state() {
+  d_st = (uint64_t *)ctx->st64.p;
+  d_stamp = (uint32_t *)ctx->stamp.p;
   // Wide masks: k_fw unless the graph is hop-count-like with more than 4 mask words or HSPF_VARIANT bit6 asks for the
   // two-phase path (see below).  Leaves (GraphDev::leaf) stay out of k_fw's fixed point and are derived in the emit,
   // when there are any and neither the saturating-distance nor the hop-count instantiation is needed (HSPF_VARIANT
   // bit17: leaves take part like any row).
-  const bool use_fw = !fused && !(ctx->variant & 64u) && (!g->hopcount_like || W <= 4);
-  const bool defer = use_fw && g->n_leaf != 0 && g->max_path_metric != HSPF_DIST_INF && !g->hopcount_like && !(ctx->variant & 131072u);
+  use_fw = !fused && !(ctx->variant & 64u) && (!g->hopcount_like || W <= 4);
+  defer = use_fw && g->n_leaf != 0 && g->max_path_metric != HSPF_DIST_INF && !g->hopcount_like && !(ctx->variant & 131072u);
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
   if (fused) {
     // state / stamps / status bits are initialised by fused_run (it may run twice: narrow, then wide), lv_run or the
@@ -1576,11 +1592,19 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
 
   const uint32_t vblocks = (n + VPB - 1) / VPB;
   (void)vblocks;
-  const dim3 grid(g->xcd_blocks(), B);                     // 8 x the longest XCD range; shorter ranges leave idle blocks
+  grid = dim3(g->xcd_blocks(), B);                     // 8 x the longest XCD range; shorter ranges leave idle blocks
   const uint32_t fblocks = (n + FVPB - 1) / FVPB;
   (void)fblocks;
   static_assert(FVPB == VPB && VPB == 16, "xcd_start is in 16-vertex chunks for every kernel");
-  const dim3 fgrid(g->xcd_blocks(), B);
+  fgrid = dim3(g->xcd_blocks(), B);
+  // An event record is a barrier packet: two of them between kernels cost ~10 us of stream time (kernel trace, r02n).  The
+  // paths that do not have a second phase record three events per run (start, end of the sweeps, results in place)
+  // instead of six and the missing ones alias their neighbours.
+  two_events = !fused;                              // only k_relax + k_dag has a second timed phase
+  tail_done = false;        // ev[4] sits behind the emit already and the phase's own synchronisation covered it
+  if (!fused) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
+  return HSPF_OK;
+}
 
   // ---- phase 1: distances.  Launch ahead `est` sweeps (each launch exits at once when the
   // previous one changed nothing), then read ONE flag back; repeat in small chunks if needed.
@@ -1588,15 +1612,12 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // work that is only needed once (the emit of the fused path) then starts without waiting for the host's round
   // trip; after a chunk that did not converge it is simply enqueued again behind the next one.
   // pre_zeroed: how many leading sweep flags the caller's own init kernel has already cleared (0: cleared here)
-  std::function<void()> on_retry;      // set by a path whose `post` leaves something behind that a non-final chunk must undo
   // set by the fused path: enqueue the NEXT run's scratch fill behind this chunk's flag read-back, guarded on the device by
   // "the chunk's last sweep changed nothing" (k_init_fill); run_phase then waits for the read-back only, and the fill
   // (15 us + a launch latency) runs while the host wakes up, returns and prepares the next run.  Argument: index of
   // the chunk's last sweep.
-  std::function<void(uint32_t)> spec_fill;
-  uint32_t *rb_ctl = nullptr;          // set by the lean path: its plan counters come back with every chunk's flags
-  uint32_t chunk_last = 0;             // index of the last sweep of the chunk `post` is enqueued behind
-  auto run_phase = [&](uint32_t est, uint32_t pre_zeroed, auto &&launch, uint32_t &n_launch, auto &&post) -> int {
+template <class Launch, class Post>
+int Run::run_phase(uint32_t est, uint32_t pre_zeroed, Launch &&launch, uint32_t &n_launch, Post &&post) {
     hipError_t er = hipSuccess;
     uint32_t zeroed = std::min<uint32_t>(CHANGED_CAP, est + 4096);
     if (pre_zeroed < zeroed) er = hipMemsetAsync(d_changed + pre_zeroed, 0, (size_t)(zeroed - pre_zeroed) * 4, s);
@@ -1641,29 +1662,17 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     while (active < sweep && ctx->h_changed[active]) ++active;
     n_launch = active + 1;   // the launch that found the fixed point did a full pass too
     return HSPF_OK;
-  };
+  }
 
-  // An event record is a barrier packet: two of them between kernels cost ~10 us of stream time (kernel trace, r02n).  The
-  // paths that do not have a second phase record three events per run (start, end of the sweeps, results in place)
-  // instead of six and the missing ones alias their neighbours.
-  bool two_events = !fused;                              // only k_relax + k_dag has a second timed phase
-  bool tail_done = false;        // ev[4] sits behind the emit already and the phase's own synchronisation covered it
-  if (!fused) HIPCHK(ctx, hipEventRecord(ctx->ev[1], s));
-  if (fused) {
-    const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
-    uint32_t last_esz = 0;                    // state width of the last fused_run (0: none ran)
-    uint32_t last_ns = n, last_fillw = 0xFFFFFFFFu;
-    bool spec_done = false;                   // the last fused_run's speculative fill was enqueued behind its last chunk
-    bool emit_reset = false;                  // the emit of the current chunk resets the state it has read (k_emit_fused reset_guard)
-    uint32_t spec_nz = 0;
-    auto fused_run = [&](int mode) -> int {       // 0: 8-byte state, 1: 4-byte state (k_fused), 2: 4-byte state, lean sweep
+// One fixed point over the packed state.  mode 0: 8-byte state, 1: 4-byte state (k_fused), 2: 4-byte state, lean sweep (k_fused_lean).
+int Run::fused_run(int mode) {
       const bool nar = mode != 0, use_lean = mode == 2;
       const FusedParams P = use_lean ? fp_lean : (nar ? fp_narrow : fp_wide);
       const size_t esz = nar ? 4 : 8;
       OutDev ode = od;                                           // packed results: the emit writes the state words of THIS width
       if (pk) { ode.packed = pk_dev(esz); pk_mode = mode; }
       const uint32_t ns = use_lean ? n + 1u : n;                 // rows per batch slab (the lean sweep's pad row)
-      const size_t rows = (size_t)B * ns * 64;
+      const size_t rows = (size_t)B * ns * 64;                   // (state rows of THIS width: shadows the member on purpose)
       const uint32_t fillw = use_lean ? P.infw : 0xFFFFFFFFu;
       // one fill launch (state, stamps, row flags, sweep flags, status bits, row counter), one launch for the roots
       uint32_t pre_zeroed = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
@@ -1693,7 +1702,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       // k_emit_fused checks the lean state's fields on FINAL words; an emit behind a chunk that had not converged saw
       // transient ones: its LF_OVERFLOW bits are dropped before the next chunk (the final emit tests every word again)
       on_retry = nullptr;
-      if (use_lean) on_retry = [&, L]() { hipLaunchKernelGGL(k_clear_lane_flag, dim3((L + 255) / 256), dim3(256), 0, s, d_lf, L, (uint32_t)LF_OVERFLOW); };
+      if (use_lean) on_retry = [&]() { hipLaunchKernelGGL(k_clear_lane_flag, dim3((L + 255) / 256), dim3(256), 0, s, d_lf, L, (uint32_t)LF_OVERFLOW); };
       if (giant && hipMemsetAsync(ctx->giant_part.p, 0, giant_tags * 4, s) != hipSuccess) { ctx->last_error = "giant tags"; return HSPF_E_HIP; }
       if (nar) hipLaunchKernelGGL((k_init_fused<uint32_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L, ns);
       else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L, ns);
@@ -1818,22 +1827,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         ctx->lean_passes = used >= plan_P ? std::min(ctx->lean_max_passes, plan_P + plan_P / 2u + 1u) : std::max(used + 1u, 2u);
       }
       return HSPF_OK;
-    };
-    // Small graphs: one workgroup per root, the whole state in LDS, ONE launch (k_single) instead of a launch per sweep.
-    // Measured (profiles/r02e_single_threshold.jsonl, 4-neighbour grids, device time): 500 vertices 2.0-2.8x faster than
-    // the sweep engine for 1 / 64 / 1024 roots, 1024 vertices 1.7x / 2.0x / 1.0x, 2048 vertices 1.2x / 1.3x / 0.4x,
-    // 4096 vertices 0.4x: a sweep of the one-workgroup kernel is one long dependent chain at two waves per SIMD (~3 700
-    // cycles), so it wins only while the sweep engine is bound by its ~50 kernel boundaries.  Hence: up to
-    // ctx->single_max_n vertices (HSPF_SINGLE_MAX_N, default 1024; 0 switches the kernel off), twice that for at most
-    // one batch of roots.
-    // (smax / single: decided above, next to the output targets)
-    // A few roots on a larger graph: lane = vertex (k_lv), one launch per sweep over the root's own row-major state.  The
-    // lane = root engine spends a 256-byte row per useful 4-8 bytes there (isis-100k, one root: 25 launches x 21 us);
-    // the scattered gathers of k_lv cost less than that up to a handful of roots (profiles/r02_notes.md, r02k).
-    // (not on graphs with giant rows: a lane of k_lv walks its row alone — one root on isis-100k + a 5 000-router LAN took
-    // 6.9 ms there against 0.9 ms for 64 roots on the sweep engine with the row in slices, r02t)
-    // (lv: decided above)
-    auto lv_run = [&]() -> int {
+    }
+
+// A few roots on a large graph: lane = vertex (k_lv), one launch per sweep over the root's own row-major state.
+int Run::lv_run() {
       int r2;
       if ((r2 = ensure(ctx, ctx->stamp, (size_t)n_roots * n * 4))) return r2;
       uint32_t *a_stamp = (uint32_t *)ctx->stamp.p;
@@ -1864,8 +1861,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       st.lane_vertex = 1;
       if (count_rows) for (uint32_t i = 0; i < 128; ++i) st.rows_recomputed += ctx->h_lane_flags[L + i];
       return HSPF_OK;
-    };
-    if (single) {
+    }
+
+// Small graphs: ONE workgroup per root, the whole state in LDS, one launch (k_single / k_single_lean).
+int Run::single_run() {
       // every workgroup STORES its root's status word straight into the pinned host array: no memset, no copy back
       uint32_t *d_hlf = nullptr;
       hipError_t er = hipHostGetDevicePointer((void **)&d_hlf, ctx->h_lane_flags, 0);
@@ -1919,6 +1918,33 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         for (uint32_t i = 0; i < 4; ++i) st.dbg[i] = ctx->h_lane_flags[L + 128 + i];   // sweeps, shader cycles, 100 MHz ticks, set-up cycles of workgroup 0 (this flag only: overwrites the host times)
       }
       narrow = false;
+  return HSPF_OK;
+}
+
+// Every root has at most 24 first-hop slots: one fused fixed point over a packed state — which kernel, which width.
+int Run::path_fused() {
+    d_fg = (const FusedGraph *)(d_up + w_fg);
+    last_esz = 0;                    // state width of the last fused_run (0: none ran)
+    last_ns = n; last_fillw = 0xFFFFFFFFu;
+    spec_done = false;                   // the last fused_run's speculative fill was enqueued behind its last chunk
+    emit_reset = false;                  // the emit of the current chunk resets the state it has read (k_emit_fused reset_guard)
+    spec_nz = 0;
+    // Small graphs: one workgroup per root, the whole state in LDS, ONE launch (k_single) instead of a launch per sweep.
+    // Measured (profiles/r02e_single_threshold.jsonl, 4-neighbour grids, device time): 500 vertices 2.0-2.8x faster than
+    // the sweep engine for 1 / 64 / 1024 roots, 1024 vertices 1.7x / 2.0x / 1.0x, 2048 vertices 1.2x / 1.3x / 0.4x,
+    // 4096 vertices 0.4x: a sweep of the one-workgroup kernel is one long dependent chain at two waves per SIMD (~3 700
+    // cycles), so it wins only while the sweep engine is bound by its ~50 kernel boundaries.  Hence: up to
+    // ctx->single_max_n vertices (HSPF_SINGLE_MAX_N, default 1024; 0 switches the kernel off), twice that for at most
+    // one batch of roots.
+    // (smax / single: decided above, next to the output targets)
+    // A few roots on a larger graph: lane = vertex (k_lv), one launch per sweep over the root's own row-major state.  The
+    // lane = root engine spends a 256-byte row per useful 4-8 bytes there (isis-100k, one root: 25 launches x 21 us);
+    // the scattered gathers of k_lv cost less than that up to a handful of roots (profiles/r02_notes.md, r02k).
+    // (not on graphs with giant rows: a lane of k_lv walks its row alone — one root on isis-100k + a 5 000-router LAN took
+    // 6.9 ms there against 0.9 ms for 64 roots on the sweep engine with the row in slices, r02t)
+    // (lv: decided above)
+    if (single) {
+      if ((rc = single_run())) return rc;
     } else if (lv) {
       if ((rc = lv_run())) return rc;
       narrow = false;
@@ -1944,6 +1970,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);
       if (ovf) {
         g->wide24_bad = true;
+        delegated = true;                                        // (that call is the run: go() hands its code on)
         return run_impl(ctx, g, roots, n_roots, run_flags, out, host_out, row_map, total_rows, true, pk);
       }
     }
@@ -1956,7 +1983,10 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
                          (const uint8_t *)g->d_rowflags, (uint8_t *)ctx->hnb.p, n, d_changed, nz, d_lf, L, d_kcnt, -1, (uint32_t *)ctx->swcnt.p, ctx->swcnt.p ? LEAN_CTL_WORDS : 0u);
       ctx->prefill = hspf_ctx::Prefill{true, g->build_id, n, B, last_esz, nz, L, true, last_ns, last_fillw};
     }
-  } else {
+  return HSPF_OK;
+}
+
+int Run::path_wide() {
   // More than 24 first-hop slots: two ways.  k_fw = ONE fused fixed point over (distance, hops, W mask words): half the
   // launches, but a label-correcting sweep re-reads the masks of ALL in-links of a row every time the row is revisited.
   // k_relax + k_dag = distances first (4 bytes per lane and link), then the masks over the tight-link DAG.
@@ -1967,7 +1997,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
   // registers) and when HSPF_VARIANT bit6 asks for the two-phase path (kept: it is the independent second implementation
   // the "twophase" configuration of the GPU suite runs).
   if (use_fw) {
-    const FusedGraph *d_fg = (const FusedGraph *)(d_up + w_fg);
+    d_fg = (const FusedGraph *)(d_up + w_fg);
     if (!defer) HIPCHK(ctx, hipMemsetAsync(d_mask, 0, rows * 8 * W, s));
     if (defer) st.dbg[1] |= 0x80000000u;                         // hspf_stats::dbg[1] bit 31: the leaves were left to the emit
     HIPCHK(ctx, hipMemsetAsync(d_stamp, 0, (size_t)B * n * 4, s));
@@ -2052,10 +2082,13 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     }
   }
 
-  }
+  return HSPF_OK;
+}
 
+// Roots whose pop order is dynamic (or forced): the sequential exact kernel (status bits: last run_phase).
+int Run::exact_roots() {
   // ---- roots whose pop order is dynamic (or forced): sequential exact kernel (status bits: last run_phase)
-  std::vector<uint32_t> ex;
+  ex.clear();
   for (uint32_t r = 0; r < n_roots; ++r) {
     const bool forced = (run_flags & (HSPF_RUN_FORCE_EXACT | HSPF_RUN_POP_RANK)) != 0;
     if (roots[r] != HSPF_NO_ROOT && (forced || (ctx->h_lane_flags[r] & LF_NEED_EXACT))) ex.push_back(r);
@@ -2088,10 +2121,15 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     for (uint32_t r = 0; r < n_roots; ++r)
       if (roots[r] == HSPF_NO_ROOT) HIPCHK(ctx, hipMemsetAsync(d_rank + (size_t)(row_map ? row_map[r] : r) * n, 0xFF, (size_t)n * 4, s));
   }
+  return HSPF_OK;
+}
+
+// Packed results: rows that did not come out of the fused emit, the layout; then whether the run is over already.
+int Run::packed_finish() {
   // Nothing was enqueued behind the emit (no sequential roots, no padding ranks, device-resident results): the run is
   // complete and synchronised already — a second event record + stream synchronisation cost 12 us per run.
   // ---- packed results: rows that did not come out of the fused emit, the layout, the copy
-  size_t pk_esz = 0;
+  pk_esz = 0;
   if (pk) {
     const FusedParams PP = pk_mode == 2 ? fp_lean : pk_mode == 1 ? fp_narrow : fp_wide;
     pk_esz = (pk_mode == 2 || pk_mode == 1) ? 4 : 8;
@@ -2113,9 +2151,13 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
       for (uint32_t r : ex) pk->root_status[pk->row_off + r] = HSPF_ROOT_EXACT;
     }
   }
-  const bool finished = tail_done && ex.empty() && !host_out && !pk_full && !((run_flags & HSPF_RUN_POP_RANK) && d_rank);
+  finished = tail_done && ex.empty() && !host_out && !pk_full && !((run_flags & HSPF_RUN_POP_RANK) && d_rank);
   if (!finished) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
+  return HSPF_OK;
+}
 
+// Results to the caller (copies for host destinations), the last synchronisation, the statistics.
+int Run::deliver() {
   // ---- results to the caller
   if (pk) {
     if (pk->host) {
@@ -2157,6 +2199,97 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
     st.dbg[3] = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_entry).count();
   return HSPF_OK;
 }
+}  // namespace
+
+extern "C" {
+
+static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, uint32_t n_roots, uint32_t run_flags,
+                    hspf_result *out, bool host_out, const uint32_t *row_map, uint32_t total_rows,
+                    bool no_fused, PackedReq *pk) {
+  // packed results (hspf_run_packed*): `out` is not read; host_out says whether pk->dst is host memory
+  hspf_result pk_none{};
+  if (pk) { out = &pk_none; host_out = pk->host; }
+  if (!ctx || !g || !roots || !out || n_roots == 0 || (!pk && !out->dist) || (row_map && host_out) || (pk && (row_map || !pk->dst))) return HSPF_E_INVAL;
+  if (pk && (run_flags & HSPF_RUN_POP_RANK)) { ctx->last_error = "HSPF_RUN_POP_RANK with packed results"; return HSPF_E_INVAL; }
+  if (g && g->invalid) { ctx->last_error = "the graph is invalid after a failed hspf_graph_patch (free it and upload again)"; return HSPF_E_INVAL; }
+  if (pk && no_fused) { ctx->last_error = "packed results: hop counts beyond the hop field of a run with more than 16 first-hop slots"; return HSPF_E_NO_PACKED; }
+  if (!row_map) total_rows = n_roots;
+  (void)hipSetDevice(ctx->device);
+  const uint32_t n = g->n;
+  // Bound the scratch (state, stamps, staging) of one pass: the batch axis is processed in groups of
+  // at most ~2^26 (vertex, root) pairs (>= 1 batch of 64 roots), each group a complete run of its own,
+  // so that "every router as a root" on a large LSDB does not need state for all roots at once.
+  {
+    const uint64_t max_pairs = 1ull << 26;
+    uint32_t group = (uint32_t)std::max<uint64_t>(64, (max_pairs / std::max<uint32_t>(n, 1)) / 64 * 64);
+    if (n_roots > group && pk) {
+      // every group must come in ONE layout: the field split is made from the slots of ALL roots (min_slots), and when a
+      // group still comes back with another layout than the first (a 4-byte overflow that only its roots run into, a ragged
+      // last group on the lane = vertex path) the call starts over with 8-byte words for everybody
+      uint32_t all_slots = pk->min_slots;
+      {
+        std::vector<uint32_t> hv, hb;
+        for (uint32_t r = 0; r < n_roots; ++r) {
+          if (roots[r] == HSPF_NO_ROOT) continue;
+          if (roots[r] >= n) { ctx->last_error = "root out of range"; return HSPF_E_INVAL; }
+          uint32_t total = 0;
+          build_slot_table(g, roots[r], hv, hb, total, ctx->mark, next_mark(ctx, n));
+          all_slots = std::max(all_slots, total);
+        }
+      }
+      for (int attempt = 0; attempt < 2; ++attempt) {
+        hspf_stats acc{};
+        bool again = false;
+        hspf_packed_layout first{};
+        for (uint32_t off = 0; off < n_roots && !again; off += group) {
+          const uint32_t nr = std::min(group, n_roots - off);
+          PackedReq part = *pk;
+          part.row_off = pk->row_off + off; part.min_slots = all_slots; part.force_wide = pk->force_wide || attempt == 1;
+          const int rc = run_impl(ctx, g, roots + off, nr, run_flags, nullptr, host_out, nullptr, 0, no_fused, &part);
+          if (rc) return rc;
+          if (off == 0) first = part.layout;
+          else if (memcmp(&first, &part.layout, sizeof(first)) != 0) { again = true; break; }
+          const hspf_stats &p = ctx->stats;
+          acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
+          acc.n_exact_roots += p.n_exact_roots; acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
+          acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_finish += p.ms_finish; acc.ms_d2h += p.ms_d2h;
+          acc.state_bytes = std::max(acc.state_bytes, p.state_bytes); acc.narrow_overflow += p.narrow_overflow; acc.rows_recomputed += p.rows_recomputed;
+        }
+        if (!again) { pk->layout = first; ctx->stats = acc; return HSPF_OK; }
+      }
+      ctx->last_error = "packed results: the groups of the call did not agree on a layout";
+      return HSPF_E_INTERNAL;
+    }
+    if (n_roots > group) {
+      hspf_stats acc{};
+      if (out->first_hop_mask && out->n_mask_words == 0) return HSPF_E_INVAL;
+      for (uint32_t off = 0; off < n_roots; off += group) {
+        const uint32_t nr = std::min(group, n_roots - off);
+        hspf_result part = *out;
+        const size_t o = row_map ? 0 : (size_t)off * n;          // mapped rows are addressed through the map
+        part.dist = out->dist + o;
+        if (out->hops) part.hops = out->hops + o;
+        if (out->vflags_out) part.vflags_out = out->vflags_out + o;
+        if (out->first_hop_mask) part.first_hop_mask = out->first_hop_mask + o * out->n_mask_words;
+        if (out->pop_rank) part.pop_rank = out->pop_rank + o;
+        const int rc = run_impl(ctx, g, roots + off, nr, run_flags, &part, host_out, row_map ? row_map + off : nullptr, total_rows, no_fused);
+        if (rc) return rc;
+        const hspf_stats &p = ctx->stats;
+        acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
+        acc.n_dag_launches += p.n_dag_launches; acc.n_exact_roots += p.n_exact_roots;
+        acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
+        acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
+        acc.ms_d2h += p.ms_d2h; acc.state_bytes = std::max(acc.state_bytes, p.state_bytes);
+        acc.narrow_overflow += p.narrow_overflow; acc.rows_recomputed += p.rows_recomputed;
+      }
+      ctx->stats = acc;
+      return HSPF_OK;
+    }
+  }
+  Run run(ctx, g, roots, n_roots, run_flags, out, host_out, row_map, total_rows, no_fused, pk);
+  return run.go();
+}
+
 
 // A run takes the state its most demanding root needs: one root with more than 24 first-hop slots sends every root of
 // the call down the two-phase path, one with 15-24 slots makes the packed state 8 bytes wide for all.  With many roots

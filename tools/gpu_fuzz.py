@@ -36,6 +36,23 @@ def compare(ctx, G, g, roots, flags, tag):
     if not np.array_equal(res.flags & 1, ref.flags): bad.append("flags")
     if not np.array_equal(res.first_hop_mask, ref.mask): bad.append("mask")
     if res.pop_rank is not None and not np.array_equal(res.pop_rank, ref.pop_rank): bad.append("pop_rank")
+    # round 5: the same run through the packed hand-off (hspf_run_packed); a run whose results do not fit packed words must
+    # say so (HSPF_E_NO_PACKED), never deliver something else
+    if not (flags & E.RUN_POP_RANK) and os.environ.get("FUZZ_PACKED", "1") != "0":
+        try:
+            pr = ctx.run_packed(G, roots, flags)
+            if not np.array_equal(pr.dist, ref.dist): bad.append("packed dist")
+            if not np.array_equal(pr.hops, ref.hops): bad.append("packed hops")
+            if not np.array_equal(pr.in_spt, ref.flags.astype(bool)): bad.append("packed in-SPT")
+            if res.first_hop_mask.shape[2] != 1 or not np.array_equal(pr.first_hop_mask[..., 0], ref.mask[..., 0]): bad.append("packed mask")
+        except E.HspfError as e:
+            if e.code != E.E_NO_PACKED:
+                raise
+            slots = max((G.slot_table(int(r))[2] for r in np.unique(roots) if r != E.NO_ROOT), default=0)
+            fused_off = (int(os.environ.get("HSPF_VARIANT", "0") or "0", 0) & 1) or getattr(ctx, "mode", "") == "widemask"   # the A/B switch that turns
+            # the fused path off (tests/conftest.py "widemask"): every packed request is refused then, as the header says (include/holo_spf_hip.h)
+            if slots <= 16 and not fused_off:  # (17-24 slots: refused once the graph has seen a hop-field overflow)
+                bad.append("packed refused a run whose roots have at most 16 first-hop slots")
     if bad:
         print("MISMATCH", tag, bad, "stats", res.stats, flush=True)
     return not bad

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round 5 (every run also through hspf_run_packed); round 4's randomised differential campaign (tools/gpu_fuzz.py): the lean sweep's device-side plan under every way its
+# launches can decide — product thresholds, dense stretch from the first sweep on, stretches that stop after their second
+# pass, multi-pass launches on graphs so small that all passes run side by side — next to the unchanged configurations.
+# usage: bash tools/gpu_fuzz_round4.sh [graphs per configuration]
+# Two processes at a time, and keep a gpurun call under ~2 minutes (a few hundred graphs per configuration): the two calls
+# of this round that kept several fuzzers busy for ~3 minutes both lost their box (six at once with 3 000 graphs each; two
+# at once behind a minute of pytest) — no kernel of the engine waits on another, so that is not a hang of ours, but it is
+# not worth a strike to find out what it is.
+set -u
+N=${1:-400}
+OUT=gpurun_out/fuzz_r05.txt; mkdir -p gpurun_out; : > $OUT
+S="HSPF_SINGLE_MAX_N=0 HSPF_LV_MAX_ROOTS=0"
+(echo "default:        $(python tools/gpu_fuzz.py 120000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
+(echo "sweeps:         $(env $S python tools/gpu_fuzz.py 140000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
+wait
+(echo "dense at once:  $(env $S HSPF_DENSE_PCT=0 HSPF_LEAN_HEAD=1 python tools/gpu_fuzz.py 160000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
+(echo "early stop:     $(env $S HSPF_DENSE_STAY_PCT=95 python tools/gpu_fuzz.py 180000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
+wait
+(echo "side by side:   $(env $S HSPF_DENSE_MIN_WGS=1 HSPF_DENSE_PASSES=4 HSPF_DENSE_PCT=5 python tools/gpu_fuzz.py 200000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
+(echo "never dense:    $(env $S HSPF_DENSE_PCT=100000 python tools/gpu_fuzz.py 220000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
+wait
+(echo "kfused:         $(env $S HSPF_VARIANT=32768 python tools/gpu_fuzz.py 240000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
+(echo "widemask:       $(env $S HSPF_VARIANT=1 python tools/gpu_fuzz.py 260000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
+wait
+(echo "wide LANs:      $(FUZZ_WIDE=$((N / 8)) python tools/gpu_fuzz.py 3000 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
+wait
+cat $OUT
