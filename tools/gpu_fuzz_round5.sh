@@ -1,12 +1,11 @@
 #!/bin/bash
-# Round 5 (every run also through hspf_run_packed); round 4's randomised differential campaign (tools/gpu_fuzz.py): the lean sweep's device-side plan under every way its
-# launches can decide — product thresholds, dense stretch from the first sweep on, stretches that stop after their second
-# pass, multi-pass launches on graphs so small that all passes run side by side — next to the unchanged configurations.
-# usage: bash tools/gpu_fuzz_round4.sh [graphs per configuration]
-# Two processes at a time, and keep a gpurun call under ~2 minutes (a few hundred graphs per configuration): the two calls
-# of this round that kept several fuzzers busy for ~3 minutes both lost their box (six at once with 3 000 graphs each; two
-# at once behind a minute of pytest) — no kernel of the engine waits on another, so that is not a hang of ours, but it is
-# not worth a strike to find out what it is.
+# The randomised differential campaign (tools/gpu_fuzz.py) of round 5: every run is checked twice, through hspf_run (four
+# arrays) and through hspf_run_packed (ABI 7), under every way the lean sweep's launches can decide — product
+# thresholds, dense stretch from the first sweep on, stretches that stop after their second pass, multi-pass launches on
+# graphs so small that all passes run side by side — next to the older paths (k_fused everywhere, fused path off, LANs of
+# 150-900 routers).        usage: bash tools/gpu_fuzz_round5.sh [graphs per configuration]
+# Two processes at a time, and a gpurun call of this kept to a couple of minutes (a few hundred graphs per
+# configuration): round 4 lost two boxes under longer ones (tools/attic/README.md).
 set -u
 N=${1:-400}
 OUT=gpurun_out/fuzz_r05.txt; mkdir -p gpurun_out; : > $OUT
