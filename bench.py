@@ -627,6 +627,8 @@ def dropin_e2e() -> dict:
 
 def path_of(st) -> str:
     """Which engine path a run took, from its hspf_stats."""
+    if st.get("single_wg") == 2:
+        return "k_xcd (one XCD per root, state replicated in every CU's LDS, one launch)"
     if st.get("single_wg"):
         return "k_single (one workgroup per root)"
     if st.get("lane_vertex"):

@@ -46,6 +46,9 @@ struct hspf_graph {
   mutable std::atomic<bool> narrow_bad{false};   // a run overflowed the 4-byte fused state: use the 8-byte one
   mutable std::atomic<bool> wide24_bad{false};   // a run overflowed the hop field of the 8-byte state with > 16 mask bits
   mutable std::atomic<bool> lean_bad{false};     // a run overflowed the fields of the lean 4-byte state (k_fused_lean): k_fused from now on
+  // runs of 1-8 roots on a mid-size graph: device microseconds (+1; 0 = not measured yet) of the last such run by k_xcd / by
+  // the launch-per-sweep engine, per root count — the faster one takes the next run (Run::prepare_outputs)
+  mutable std::atomic<uint32_t> xcd_us[9] = {}, sweep_us[9] = {}, xcd_choices[9] = {};
   bool hopcount_like = false;        // every kept link into a network costs 0 (from a router), into a router 1
   bool heavy_rows = false;           // a quarter or more of the links sit in rows of more than 32 (fat-tree switches, big LANs)
   uint32_t xcd_start[9] = {};        // work-balanced chunk ranges of the 8 XCDs (GraphDev::xcd_start)
@@ -190,6 +193,17 @@ struct hspf_ctx {
   uint32_t lv_max_roots = 2;               // HSPF_LV_MAX_ROOTS env: runs of at most this many roots take the lane = vertex kernel (0: never)
   uint32_t lv_min_n = 32768;               // HSPF_LV_MIN_N env: ... on graphs of at least this many vertices
   uint32_t est_lv = 24;
+  // k_xcd (one XCD per root, the state replicated in every CU's LDS): runs of at most xcd_max_roots roots (HSPF_XCD_MAX_ROOTS
+  // env, at most 8, 0: never) on graphs too large for the one-workgroup kernel and of at most XCD_MAX_N vertices.  A run
+  // that gave up on one of its barriers (see the kernel) is redone on the launch-per-sweep path and switches the kernel off
+  // for this context.
+  uint32_t xcd_max_roots = 8;
+  bool xcd_always = false;                 // HSPF_XCD_ALWAYS env (tests): every eligible run takes k_xcd, whatever was measured
+  bool xcd_off = false;
+  uint32_t xcd_epoch = 0;                  // numbers the barrier flags of a run: nothing is cleared between runs
+  uint32_t xcd_attr = 0;
+  uint32_t xcd_timeout_ms = 20;            // HSPF_XCD_TIMEOUT_MS env
+  DevBuf xcd_ctl;
   // A fused run's scratch, filled for the NEXT run behind this one's results (k_init_fill costs 14 us at the head of a
   // run, and the GPU idles for longer than that while the host turns a run around): valid for exactly these parameters
   struct Prefill { bool valid = false; uint64_t build_id = 0; uint32_t n = 0, B = 0, esz = 0, n_changed = 0, L = 0; bool kcnt = false;
@@ -660,6 +674,9 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   if (const char *v = getenv("HSPF_LEAN_HEAD")) ctx->lean_head = std::min<uint32_t>((uint32_t)strtoul(v, nullptr, 0), 60u);   // a first run's head sweeps
   if (const char *v = getenv("HSPF_LV_MAX_ROOTS")) ctx->lv_max_roots = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_LV_MIN_N")) ctx->lv_min_n = (uint32_t)strtoul(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_XCD_MAX_ROOTS")) ctx->xcd_max_roots = std::min<uint32_t>((uint32_t)strtoul(v, nullptr, 0), XCD_MAX_ROOTS);
+  if (const char *v = getenv("HSPF_XCD_ALWAYS")) ctx->xcd_always = strtoul(v, nullptr, 0) != 0;
+  if (const char *v = getenv("HSPF_XCD_TIMEOUT_MS")) ctx->xcd_timeout_ms = (uint32_t)strtoul(v, nullptr, 0);   // (0: every barrier gives up at once — the test of the fallback)
   if (const char *v = getenv("HSPF_XCD_ROW_COST")) ctx->xcd_row_cost = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_UNIT_HEAVY_DEG")) ctx->unit_heavy_deg = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_HUB_DEG")) ctx->hub_deg = (uint32_t)strtoul(v, nullptr, 0);
@@ -683,7 +700,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag, &ctx->xcd_ctl})
     release(*b);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (auto &e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
@@ -1258,7 +1275,7 @@ struct Run {
   hipStream_t s = nullptr;
   std::chrono::steady_clock::time_point t_entry;
   hspf_ctx::Prefill pf;
-  bool want_mask = false, fused = false, narrow = false, lean = false, giant = false, count_rows = false, single = false, lv = false, use_fw = false, defer = false;
+  bool want_mask = false, fused = false, narrow = false, lean = false, giant = false, count_rows = false, single = false, lv = false, xcdp = false, xcd_ok = false, use_fw = false, defer = false;
   FusedParams fp_wide{}, fp_narrow{}, fp_lean{};
   size_t rows = 0, rn = 0, giant_tags = 0, up_bytes = 0, w_roots = 0, w_ptr = 0, w_vtx = 0, w_base = 0, w_map = 0, w_fg = 0;
   int rc = 0;
@@ -1305,6 +1322,7 @@ struct Run {
   template <class Launch, class Post> int run_phase(uint32_t est, uint32_t pre_zeroed, Launch &&launch, uint32_t &n_launch, Post &&post);
   int fused_run(int mode);
   int lv_run();
+  int xcd_run();
   int single_run();
   int path_fused();
   int path_wide();
@@ -1482,13 +1500,30 @@ int Run::prepare_outputs() {
   const uint32_t smax = std::min(n_roots <= 64 ? ctx->single_max_n * 2u : ctx->single_max_n, SINGLE_MAX_N);
   single = fused && n <= smax && g->e_kept <= SINGLE_MAX_E;
   lv = fused && !single && n_roots <= ctx->lv_max_roots && n >= ctx->lv_min_n && !giant;
+  // One to eight roots on a graph of at most XCD_MAX_N vertices: k_xcd (one launch, a barrier inside one XCD per sweep) or
+  // the launch-per-sweep engine.  Neither wins everywhere: k_xcd's sweeps are Jacobi across workgroups (ospf-10k 37 sweeps
+  // of ~4.5 us against ~36 launches of ~5.3 us; hop-count graphs and several roots 25-40 % faster; a 50 x 50 grid, 111
+  // sweeps against 63-98 launches, slower: profiles/r05_notes.md), so the graph remembers what each took last time for
+  // this many roots and the faster one runs (patches change the graph under the measurements: the other one is looked
+  // at again now and then).
+  xcd_ok = fused && !single && !lv && !ctx->xcd_off && n_roots >= 1 && n_roots <= ctx->xcd_max_roots && n <= XCD_MAX_N && g->n_giant == 0 &&
+           !(run_flags & HSPF_RUN_COUNT_ROWS);
+  xcdp = xcd_ok;
+  if (xcd_ok && !ctx->xcd_always) {
+    // choices 0-1: k_xcd, 2-4: the sweep engine (its first runs on a context still size their launch plan), then the
+    // faster of the two last times; every 256th choice the other one, to look again
+    const uint32_t c = g->xcd_choices[n_roots].fetch_add(1u, std::memory_order_relaxed);
+    const uint32_t tx = g->xcd_us[n_roots].load(std::memory_order_relaxed), ts = g->sweep_us[n_roots].load(std::memory_order_relaxed);
+    xcdp = c < 2u ? true : c < 5u ? false : (tx != 0u && (ts == 0u || tx <= ts));
+    if (c >= 5u && (c & 255u) == 255u) xcdp = !xcdp;
+  }
   // row-major output targets (device): the caller's device buffers, or staging for host output
   od = OutDev{};
   rn = (size_t)total_rows * n;               // rows of the output arrays (== n_roots unless mapped)
   d_rank = nullptr;
   // packed results: the fused emit writes the words themselves (od.packed, set per fused_run: the word size is the run's);
   // k_single / k_lv write row-major tables into staging, which k_pack_full then packs (8-byte words)
-  pk_full = pk && (single || lv);
+  pk_full = pk && (single || lv || xcdp);
   d_misfit = nullptr;
   pk_mode = -1;                                        // which fused_run produced the words: 2 lean, 1 narrow, 0 wide; -1: k_pack_full (wide layout)
   if (pk) {
@@ -1863,6 +1898,77 @@ int Run::lv_run() {
       return HSPF_OK;
     }
 
+// One to eight roots on a mid-size graph: one XCD per root, the state replicated in every CU's LDS, ONE launch (k_xcd).
+std::atomic<uint32_t> g_xcd_next{0};             // the XCD the next run's first root takes: concurrent runs (lanes, contexts) spread out
+int Run::xcd_run() {
+  int r2;
+  const bool fresh = ctx->xcd_ctl.cap == 0;
+  if ((r2 = ensure(ctx, ctx->xcd_ctl, (size_t)XCD_MAX_ROOTS * XCD_CTL_WORDS * 4, false))) return r2;
+  if (fresh || ctx->xcd_epoch >= (1u << 19) - 2u) {                 // flags compare as (epoch, sweep): zero once, and when the epoch wraps
+    HIPCHK(ctx, hipMemsetAsync(ctx->xcd_ctl.p, 0, (size_t)XCD_MAX_ROOTS * XCD_CTL_WORDS * 4, s));
+    ctx->xcd_epoch = 0;
+  }
+  const uint32_t n_pad = (n + 1u) & ~1u;
+  const uint32_t vw = std::max(64u, (((n + XCD_MAX_WG - 1u) / XCD_MAX_WG) + 1u) & ~1u);   // vertices per workgroup: even, one per thread
+  const uint32_t n_wg = (n + vw - 1u) / vw;
+  const uint32_t thr = (vw + 63u) / 64u * 64u;
+  // every workgroup STORES its last word (status bits of its vertices, sweeps, "gave up") into pinned host memory
+  uint32_t *d_hst = nullptr;
+  uint32_t *h_st = ctx->h_lane_flags + L;                            // (the 256 words behind the per-root status bits)
+  hipError_t er = hipHostGetDevicePointer((void **)&d_hst, h_st, 0);
+  if (er != hipSuccess) { ctx->last_error = std::string("k_xcd: pinned status words: ") + hipGetErrorString(er); return HSPF_E_HIP; }
+  std::fill(h_st, h_st + XCD_MAX_ROOTS * XCD_MAX_WG, 0u);
+  const bool mi = g->max_path_metric == HSPF_DIST_INF;
+  static const bool prof = getenv("HSPF_XCD_PROF") != nullptr;      // (tuning only: phase times of one workgroup on stderr)
+  void (*kern)(XcdArgs) = prof ? (mi ? k_xcd<true, true> : k_xcd<false, true>) : (mi ? k_xcd<true, false> : k_xcd<false, false>);
+  if (!(ctx->xcd_attr & (mi ? 2u : 1u))) {
+    // (the replica of the largest graph the path takes; the kernel's own few words of LDS sit next to it)
+    const hipError_t ea = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(XCD_MAX_N * 8u));
+    if (ea != hipSuccess) { ctx->last_error = std::string("k_xcd: dynamic LDS attribute: ") + hipGetErrorString(ea); return HSPF_E_HIP; }
+    ctx->xcd_attr |= mi ? 2u : 1u;
+  }
+  XcdArgs xa{d_fg, d_roots, fp_wide, net_nh, ignore_ovl, n_roots, ++ctx->xcd_epoch, n_wg, vw,
+             g_xcd_next.fetch_add(n_roots, std::memory_order_relaxed) & 7u, n_pad, (uint32_t)(((1ull << 32) + vw - 1u) / vw), d_st, (uint32_t *)ctx->xcd_ctl.p, d_hst,
+             (uint64_t)ctx->xcd_timeout_ms * 100000ull, od};
+  hipLaunchKernelGGL(kern, dim3(8u * n_wg), dim3(thr), (size_t)n * 8, s, xa);
+  (void)hipEventRecord(ctx->ev[2], s);
+  (void)hipEventRecord(ctx->ev[4], s);            // the kernel wrote the results in place (as k_single)
+  tail_done = true;
+  const hipError_t el = hipGetLastError();
+  er = hipStreamSynchronize(s);
+  if (er != hipSuccess || el != hipSuccess) {
+    ctx->last_error = std::string("k_xcd: ") + hipGetErrorString(er) + " / launch: " + hipGetErrorString(el) + " threads " + std::to_string(thr) +
+                      " workgroups " + std::to_string(n_wg);
+    return HSPF_E_HIP;
+  }
+  bool gave_up = false;
+  uint32_t sweeps = 0;
+  for (uint32_t r = 0; r < L; ++r) ctx->h_lane_flags[r] = 0u;
+  for (uint32_t r = 0; r < n_roots; ++r)
+    for (uint32_t w = 0; w < n_wg; ++w) {
+      const uint32_t x = h_st[r * XCD_MAX_WG + w];
+      if (!(x & XCD_ST_DONE) || (x & XCD_ST_ABORT)) gave_up = true;
+      ctx->h_lane_flags[r] |= x & (LF_NEED_EXACT | LF_OVERFLOW);
+      sweeps = std::max(sweeps, (x >> 8) & 0xFFFFu);
+      if (((x ^ h_st[r * XCD_MAX_WG]) >> 24) & 15u) st.dbg[1] |= 0x80000000u;   // the root's workgroups did not share an XCD (a run that finished is right all the same)
+    }
+  if (gave_up) {
+    // a workgroup was not resident, or not where its partners' stores are visible: the launch-per-sweep path redoes the
+    // run (nothing of this attempt is used), and this context stops trying
+    ctx->xcd_off = true;
+    delegated = true;
+    return run_impl(ctx, g, roots, n_roots, run_flags, out, host_out, row_map, total_rows, no_fused, pk);
+  }
+  if (prof && n_roots < XCD_MAX_ROOTS) {
+    const uint32_t *t = h_st + (XCD_MAX_ROOTS - 1) * XCD_MAX_WG + 28;
+    fprintf(stderr, "[hspf k_xcd] n %u workgroups %u x %u threads, %u sweeps: evaluate %.1f us, publish %.1f, barrier wait %.1f, re-read %.1f\n", n, n_wg, thr,
+            sweeps, t[0] / 100.0, t[1] / 100.0, t[2] / 100.0, t[3] / 100.0);
+  }
+  st.n_relax_launches = 1; st.single_wg = 2;                      // (2: the one-XCD-per-root kernel)
+  st.dbg[1] |= sweeps;
+  return HSPF_OK;
+}
+
 // Small graphs: ONE workgroup per root, the whole state in LDS, one launch (k_single / k_single_lean).
 int Run::single_run() {
       // every workgroup STORES its root's status word straight into the pinned host array: no memset, no copy back
@@ -1948,6 +2054,10 @@ int Run::path_fused() {
     } else if (lv) {
       if ((rc = lv_run())) return rc;
       narrow = false;
+    } else if (xcdp) {
+      if ((rc = xcd_run())) return rc;
+      if (delegated) return HSPF_OK;                             // gave up on a barrier: the launch-per-sweep path has done the run
+      narrow = false;
     } else if (lean || narrow) {
       auto overflowed = [&]() { bool o = false; for (uint32_t r = 0; r < L; ++r) o = o || (ctx->h_lane_flags[r] & LF_OVERFLOW); return o; };
       bool done = false;
@@ -1964,7 +2074,7 @@ int Run::path_fused() {
       }
       narrow = done;                                             // a 4-byte run holds the results
     }
-    if (!single && !lv && !narrow && (rc = fused_run(0))) return rc;
+    if (!single && !lv && !xcdp && !narrow && (rc = fused_run(0))) return rc;
     if (!narrow && fp_wide.hmax < 0xFFFFu) {                       // more than 16 mask bits: did the hop field hold?
       bool ovf = false;
       for (uint32_t r = 0; r < L; ++r) ovf = ovf || (ctx->h_lane_flags[r] & LF_OVERFLOW);
@@ -2197,6 +2307,8 @@ int Run::deliver() {
   }
   if (!(count_rows && st.single_wg))
     st.dbg[3] = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_entry).count();
+  if (xcd_ok && st.ms_total > 0.f)                                 // what this path took for this many roots (see prepare_outputs)
+    (xcdp ? g->xcd_us : g->sweep_us)[n_roots].store((uint32_t)(st.ms_total * 1000.f) + 1u, std::memory_order_relaxed);
   return HSPF_OK;
 }
 }  // namespace
@@ -2573,7 +2685,7 @@ static int lanes_ensure(hspf_ctx *ctx) {
       hspf_ctx *c = ln->sub;
       c->parent = ctx;
       // the caller's context decides the tunables (a lane's own hspf_init read the environment of a later moment)
-      c->variant = ctx->variant; c->single_max_n = ctx->single_max_n; c->lv_max_roots = ctx->lv_max_roots; c->lv_min_n = ctx->lv_min_n;
+      c->variant = ctx->variant; c->single_max_n = ctx->single_max_n; c->lv_max_roots = ctx->lv_max_roots; c->lv_min_n = ctx->lv_min_n; c->xcd_max_roots = ctx->xcd_max_roots; c->xcd_timeout_ms = ctx->xcd_timeout_ms; c->xcd_always = ctx->xcd_always;
       c->lean_dense_pct = ctx->lean_dense_pct; c->lean_stay_pct = ctx->lean_stay_pct; c->lean_dense_passes = ctx->lean_dense_passes;
       c->lean_head = ctx->lean_head; c->lean_passes = ctx->lean_passes; c->hub_deg = ctx->hub_deg; c->lean_multi_min_wgs = ctx->lean_multi_min_wgs;
       c->unit_heavy_deg = ctx->unit_heavy_deg; c->xcd_row_cost = ctx->xcd_row_cost;

@@ -1839,6 +1839,299 @@ __global__ __launch_bounds__(256) void k_emit_lv(uint32_t n, const uint64_t *__r
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_xcd — one root (up to eight) on a MID-SIZE graph: one XCD per root, the whole state replicated in every CU's LDS.
+//
+// The reference's real call pattern is one root per area / level (holo-ospf/src/spf.rs:540-542, holo-isis/src/spf.rs:
+// 746-761).  On a graph too large for the one-workgroup kernel (k_single: 1-2 k vertices) such a run was a chain of ~40
+// launches of ~5 us each (ospf-10k: 0.20 ms), whatever kernel ran inside them.  Here the chain stays inside ONE launch:
+//   * consecutive workgroups of a grid go to consecutive XCDs, so the workgroups b with equal b % 8 share one (observed
+//     placement, MI355X_MICROARCH.md — which XCD that is depends on where the previous dispatch stopped; never relied on
+//     for correctness: see "bounded" below; every workgroup reports its HW_REG_XCC_ID and the host notes a root whose
+//     workgroups did not share one); root r of the run takes the class (xcd0 + r) % 8, one workgroup per CU, each
+//     owning a contiguous range of `vw` vertices, one vertex per thread;
+//   * every workgroup keeps ALL n words of its root ([dist32 | hops | mask], the k_single / k_lv word) in LDS: a
+//     neighbour's word is an LDS read, never a round trip to the L2.  A plain vertex (k_single's definition) keeps its
+//     link records in registers for the whole run; the others walk their records in global memory with the general
+//     row routine (single_link / finish_row: same fixed point, same exactness flags as every other kernel);
+//   * a sweep = evaluate the own vertices from the replica, store what changed to the replica AND to the root's array in
+//     global memory (plain stores: the lines stay in this XCD's L2), then a barrier among the workgroups of the XCD made
+//     of plain flag stores and sc1 polling loads (L1 bypassed, L2 served: 0.55 us for up to 64 workgroups,
+//     tools/ubench/xcd_barrier.hip — a chip-wide barrier is 4-10 us because the eight L2s are not coherent).  The flag
+//     carries "something in my range changed"; after the barrier a workgroup re-reads (16-byte sc1 loads) exactly the
+//     ranges that changed.  No range changed = fixed point.  Jacobi across workgroups, in place inside one: 37 sweeps on
+//     ospf-10k where the sweep engine's dispatch-order Gauss-Seidel needs ~38 launches;
+//   * flags are numbered (run epoch, sweep) and double-buffered by sweep parity — a workgroup can be at most one barrier
+//     ahead of another — so nothing is cleared between runs;
+//   * BOUNDED: every wait gives up after `timeout_ticks` (a workgroup that is not resident, or not on the expected XCD,
+//     whose stores the pollers then may never see): the workgroup reports XCD_ST_ABORT in its status word (pinned host
+//     memory, one plain store per workgroup at the end) and the host redoes the run on the launch-per-sweep path.
+// Results go straight to the row-major output arrays (no emit launch), as in k_single.
+constexpr uint32_t XCD_MAX_WG = 32;            // workgroups per root: the CUs of one XCD
+constexpr uint32_t XCD_MAX_N = 20000;          // 160 000 bytes of LDS per workgroup
+constexpr uint32_t XCD_MAX_ROOTS = 8;
+constexpr uint32_t XCD_RL = 12;                // link records a plain vertex keeps in registers
+constexpr uint32_t XCD_CTL_WORDS = 2 * XCD_MAX_WG;
+constexpr uint32_t XCD_MAX_SWEEPS = 4000;      // (12 bits of a flag's counter)
+constexpr uint32_t XCD_ST_DONE = 0x80000000u, XCD_ST_ABORT = 0x40000000u;   // | HW_REG_XCC_ID << 24 | sweeps << 8 | LF_* bits
+
+struct XcdArgs {
+  const FusedGraph *gp;
+  const uint32_t *roots;
+  FusedParams P;                 // the 8-byte state's parameters (sh = 0)
+  uint32_t net_nexthops, ignore_ovl, n_roots, epoch;
+  uint32_t n_wg, vw, xcd0, n_pad;
+  uint32_t vw_inv;               // ceil(2^32 / vw): i / vw = __umulhi(i, vw_inv) for every vertex index
+  uint64_t *st;                  // [n_roots][n_pad]: every vertex' word; the owner's plain stores, everybody's sc1 loads
+  uint32_t *ctl;                 // [n_roots][XCD_CTL_WORDS] barrier flags: (epoch << 12 | sweep + 1) << 1 | changed
+  uint32_t *status;              // [n_roots][XCD_MAX_WG], pinned host memory
+  uint64_t timeout_ticks;        // 100 MHz ticks
+  OutDev o;
+  __device__ __forceinline__ const SlotTabs &slot_tabs() const { return gp->tabs; }
+};
+
+template <bool MAXINF, bool PROF>
+__global__ __launch_bounds__(640) void k_xcd(XcdArgs a) {     // (XCD_MAX_N / XCD_MAX_WG vertices, one per thread)
+  extern __shared__ uint64_t s_st[];
+  __shared__ uint32_t s_wany[16], s_mask, s_go, s_lf;
+  const uint32_t p = blockIdx.x >> 3;
+  const uint32_t root_slot = ((blockIdx.x & 7u) + 8u - a.xcd0) & 7u;
+  if (root_slot >= a.n_roots) return;
+  const GraphDev &g = a.gp->g;
+  const uint32_t n = g.n, tid = threadIdx.x, nthr = blockDim.x;
+  const uint32_t my_root = a.roots[root_slot];
+  const FusedParams P = a.P;
+  const uint32_t mmask = (1u << P.mbits) - 1u;
+  const size_t orow = a.o.row(root_slot) * (size_t)n;
+  const uint32_t v0 = p * a.vw, v1 = min(n, v0 + a.vw);
+  const uint32_t v = v0 + tid;
+  const bool mine = v < v1;
+  uint32_t *const status = a.status + root_slot * XCD_MAX_WG + p;
+  if (my_root == INF) {                            // padding root: empty SPT
+    if (mine) {
+      a.o.dist[orow + v] = INF;
+      if (a.o.hops) a.o.hops[orow + v] = 0;
+      if (a.o.flags) a.o.flags[orow + v] = 0;
+      if (a.o.mask) for (uint32_t k = 0; k < a.o.out_words; ++k) a.o.mask[(orow + v) * a.o.out_words + k] = 0;
+    }
+    if (tid == 0) *status = XCD_ST_DONE;
+    return;
+  }
+  const uint32_t xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;        // HW_REG_XCC_ID
+  uint64_t *const S = a.st + (size_t)root_slot * a.n_pad;
+  const __amdgpu_buffer_rsrc_t rS = st_rsrc(S, a.n_pad * 8u);
+  uint32_t *const F = a.ctl + root_slot * XCD_CTL_WORDS;
+  for (uint32_t i = tid; i < n; i += nthr) s_st[i] = (i == my_root) ? 0ull : ~0ull;
+  uint64_t cur = (v == my_root) ? 0ull : ~0ull;
+  if (mine) S[v] = cur;
+  if (tid == 0) s_lf = 0u;
+  // this thread's vertex: row bounds, kind, "needs the general routine"; a plain vertex' link records in registers
+  uint32_t e0 = 0u, e1 = 0u;
+  bool rare = P.hc != 0u, plain = false, regs = false;
+  uint32_t v_router = 1u;
+  uint32_t ls[XCD_RL], lw[XCD_RL], lb[XCD_RL];
+#pragma unroll
+  for (uint32_t k = 0; k < XCD_RL; ++k) { ls[k] = min(v, n - 1u); lw[k] = INF; lb[k] = 0u; }
+  if (mine && v != my_root) {
+    e0 = g.in_ptr[v]; e1 = g.in_ptr[v + 1];
+    v_router = (g.vflags[v] & 1u) ? 0u : 1u;
+    for (uint32_t e = e0; e < e1; ++e) {
+      const uint32_t sw = g.in_src[e];
+      rare = rare || (!a.ignore_ovl && (sw & SRC_NO_TRANSIT)) || (g.in_w[e] == 0u && (sw & SRC_MASK) >= v);
+    }
+    plain = !rare && e1 - e0 <= XCD_RL;
+#pragma unroll
+    for (uint32_t k = 0; k < XCD_RL; ++k)
+      if (e0 + k < e1) {
+        ls[k] = g.in_src[e0 + k] & SRC_MASK; lw[k] = g.in_w[e0 + k];
+        plain = plain && !(g.vflags[ls[k]] & 1u);               // a network source may have hops == 0: general routine
+        if (ls[k] == my_root) {
+          const uint32_t sidx = g.in_fpos[e0 + k];               // the root's slot base is 0
+          lb[k] = ((v_router || a.net_nexthops) && sidx < P.mbits) ? (1u << sidx) : 0u;
+        }
+      }
+    // a vertex that needs the general routine but has at most XCD_RL links keeps its records in the same registers, raw:
+    // source | SRC_NO_TRANSIT, cost, position of the link in its source row (the sweeps then never leave the CU either)
+    regs = !plain && e1 - e0 <= XCD_RL;
+    if (regs) {
+#pragma unroll
+      for (uint32_t k = 0; k < XCD_RL; ++k)
+        if (e0 + k < e1) { ls[k] = g.in_src[e0 + k]; lw[k] = g.in_w[e0 + k]; lb[k] = g.in_fpos[e0 + k]; }
+        else { ls[k] = min(v, n - 1u); lw[k] = INF; lb[k] = 0u; }
+    }
+  }
+  bool sat = false, need_exact = false, ovf = false, aborted = false;
+  const uint32_t max_sweeps = min(4u * n + 64u, XCD_MAX_SWEEPS);
+  uint32_t sweep = 0;
+  // PROF (HSPF_XCD_PROF, tuning only): 100 MHz ticks workgroup 0 of the first root spends evaluating / publishing / waiting
+  // at the barrier / re-reading ranges, left in the last four status words
+  uint64_t t_ph[4] = {0, 0, 0, 0}, t_mark = PROF ? wall_clock64() : 0;
+  __syncthreads();
+  for (;; ++sweep) {
+    bool any = false;
+    if (mine && v != my_root) {
+      RowOut<uint64_t> o;
+      if (plain) {
+        uint64_t qs[XCD_RL];
+#pragma unroll
+        for (uint32_t k = 0; k < XCD_RL; ++k) qs[k] = s_st[ls[k]];
+        uint32_t c[XCD_RL];
+        bool sat1 = false;
+        uint32_t bd = INF;
+#pragma unroll
+        for (uint32_t k = 0; k < XCD_RL; ++k) {
+          const uint32_t d = (uint32_t)(qs[k] >> 32);
+          c[k] = add_sat(d, lw[k]);                              // padding links cost all ones: never reached
+          if (MAXINF && c[k] == INF && d != INF && lw[k] != INF) sat1 = true;
+          bd = min(bd, c[k]);
+        }
+        uint32_t macc = 0u, bpay = 0u;                           // tight links walked backwards: the first one is the first discoverer
+#pragma unroll
+        for (int k = (int)XCD_RL - 1; k >= 0; --k) {
+          const bool t = c[k] == bd;
+          const uint32_t pb = (uint32_t)qs[k] | lb[k];
+          macc |= t ? pb : 0u;
+          bpay = t ? pb : bpay;
+        }
+        RowAcc r{bd, macc & mmask, 0u, bpay >> P.mbits, sat1};
+        o = finish_row<uint64_t>(r, v, my_root, v_router, INF, P);
+      } else if (regs) {
+        uint64_t qs[XCD_RL];
+#pragma unroll
+        for (uint32_t k = 0; k < XCD_RL; ++k) qs[k] = s_st[ls[k] & SRC_MASK];
+        RowAcc r{INF, 0u, INF, 0u, false};
+        uint32_t bd_all = INF, zb = INF, zm = 0u, zh = 0u;
+        const uint32_t cnt = e1 - e0;
+#pragma unroll
+        for (uint32_t k = 0; k < XCD_RL; ++k) {
+          if (k < cnt) {                                           // (no break: the loop has to unroll for the records to stay in registers)
+            const uint32_t fk = lb[k];
+            if (rare) single_link<MAXINF, true>(r, bd_all, zb, zm, zh, ls[k], lw[k], [fk]() { return fk; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
+            else      single_link<MAXINF, false>(r, bd_all, zb, zm, zh, ls[k], lw[k], [fk]() { return fk; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
+          }
+        }
+        if (rare && P.hc) {
+          const bool late = zb < r.bd;
+          r.bm = late ? zm : r.bm; r.bh = late ? zh : r.bh; r.bd = late ? zb : r.bd;
+        }
+        o = finish_row<uint64_t>(r, v, my_root, v_router, bd_all, P);
+      } else {
+        RowAcc r{INF, 0u, INF, 0u, false};
+        uint32_t bd_all = INF, zb = INF, zm = 0u, zh = 0u;
+        constexpr uint32_t PF = 4;
+        for (uint32_t eb = e0; eb < e1; eb += PF) {
+          uint32_t rs[PF], rw[PF], rf[PF];
+          uint64_t qs[PF];
+#pragma unroll
+          for (uint32_t k = 0; k < PF; ++k) {
+            const uint32_t e = min(eb + k, e1 - 1u);
+            rs[k] = g.in_src[e]; rw[k] = g.in_w[e]; rf[k] = g.in_fpos[e];
+          }
+#pragma unroll
+          for (uint32_t k = 0; k < PF; ++k) qs[k] = s_st[rs[k] & SRC_MASK];
+#pragma unroll
+          for (uint32_t k = 0; k < PF; ++k) {
+            if (eb + k >= e1) break;
+            const uint32_t fk = rf[k];
+            if (rare) single_link<MAXINF, true>(r, bd_all, zb, zm, zh, rs[k], rw[k], [fk]() { return fk; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
+            else      single_link<MAXINF, false>(r, bd_all, zb, zm, zh, rs[k], rw[k], [fk]() { return fk; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
+          }
+        }
+        if (rare && P.hc) {
+          const bool late = zb < r.bd;
+          r.bm = late ? zm : r.bm; r.bh = late ? zh : r.bh; r.bd = late ? zb : r.bd;
+        }
+        o = finish_row<uint64_t>(r, v, my_root, v_router, bd_all, P);
+      }
+      sat = sat || o.sat; need_exact = need_exact || o.need_exact; ovf = ovf || o.ovf;
+      if (o.nw != cur) { cur = o.nw; s_st[v] = o.nw; S[v] = o.nw; any = true; }
+    }
+    // ---- barrier among the workgroups of this root's XCD, carrying "my range changed"
+    if (PROF && tid == 0) { const uint64_t t = wall_clock64(); t_ph[0] += t - t_mark; t_mark = t; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this thread's stores have reached the L2
+    const bool wave_any = __any(any ? 1 : 0) != 0;
+    if ((tid & 63u) == 0u) s_wany[tid >> 6] = wave_any ? 1u : 0u;
+    __syncthreads();
+    if (tid < 64u) {
+      const uint32_t nw = (nthr + 63u) >> 6;
+      const bool wg_any = __any((tid < nw && s_wany[tid]) ? 1 : 0) != 0;
+      const uint32_t want = (a.epoch << 12) | (sweep + 1u);
+      uint32_t *const Fg = F + (sweep & 1u) * XCD_MAX_WG;
+      if (tid == 0) {
+        Fg[p] = (want << 1) | (wg_any ? 1u : 0u);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      const uint64_t t0 = wall_clock64();
+      if (PROF && tid == 0) { t_ph[1] += t0 - t_mark; t_mark = t0; }
+      uint32_t f = want << 1;
+      bool ok = true, gave_up = a.timeout_ticks == 0ull;           // (0: the test of the fallback — every workgroup gives up at its first barrier)
+      while (!gave_up) {
+        if (tid < a.n_wg) f = __hip_atomic_load(Fg + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = (f >> 1) >= want;
+        if (__all(ok ? 1 : 0)) break;
+        if (wall_clock64() - t0 > a.timeout_ticks) { gave_up = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      const uint64_t chg = __ballot((ok && tid < a.n_wg && (f & 1u)) ? 1 : 0);
+      if (tid == 0) { s_mask = (uint32_t)chg; s_go = gave_up ? 2u : 1u; }
+    }
+    __syncthreads();
+    if (PROF && tid == 0) { const uint64_t t = wall_clock64(); t_ph[2] += t - t_mark; t_mark = t; }
+    if (s_go == 2u) { aborted = true; break; }
+    const uint32_t cm = s_mask;
+    if (cm == 0u) break;                                          // nobody changed anything: every replica holds the fixed point
+    if (sweep + 1u >= max_sweeps) { need_exact = true; break; }   // far beyond any run: handed to k_exact
+    // ---- the ranges that changed, from the L2 into the replica (the own range is up to date): ONE pass over the whole
+    // array, eight 16-byte loads per thread in flight.  (Range by range the loop was a chain of dependent L2 round trips:
+    // 7.5 us per sweep on ospf-10k instead of 2.2.  Twelve loads in flight, and only the 64-vertex chunks this workgroup's
+    // vertices have in-links from — a third of them on ospf-10k's grid — measured SLOWER, 2.6 us: the loop is bound by its
+    // own instructions, not by the 80 KB it moves; profiles/r05_notes.md, r05h-r05k.)
+    const uint32_t want_ranges = cm & ~(1u << p);
+    constexpr uint32_t XU = 8;
+    for (uint32_t base = 2u * tid; base < n; base += 2u * nthr * XU) {
+      uint4 q[XU];
+      bool take[XU];
+#pragma unroll
+      for (uint32_t u = 0; u < XU; ++u) {
+        const uint32_t i = base + 2u * nthr * u;                   // vw is even and the array 16-byte aligned: a pair never straddles ranges
+        take[u] = i < n && ((want_ranges >> __umulhi(i, a.vw_inv)) & 1u);
+        if (take[u]) q[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rS, i * 8u, 0, 16));   // aux 16 = sc1
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < XU; ++u) {
+        const uint32_t i = base + 2u * nthr * u;
+        if (take[u]) {
+          s_st[i] = ((uint64_t)q[u].y << 32) | q[u].x;
+          if (i + 1u < n) s_st[i + 1u] = ((uint64_t)q[u].w << 32) | q[u].z;
+        }
+      }
+    }
+    if (PROF && tid == 0) { const uint64_t t = wall_clock64(); t_ph[3] += t - t_mark; t_mark = t; }
+    __syncthreads();
+  }
+  // ---- results of the own range, row-major
+  if (mine) {
+    const bool in = cur != ~0ull;
+    const uint32_t pay = (uint32_t)cur;
+    a.o.dist[orow + v] = in ? (uint32_t)(cur >> 32) : INF;
+    if (a.o.hops) a.o.hops[orow + v] = in ? (uint16_t)(pay >> P.mbits) : (uint16_t)0;
+    if (a.o.flags) a.o.flags[orow + v] = in ? 1 : 0;
+    if (a.o.mask) {
+      a.o.mask[(orow + v) * a.o.out_words] = in ? (uint64_t)(pay & mmask) : 0ull;
+      for (uint32_t k = 1; k < a.o.out_words; ++k) a.o.mask[(orow + v) * a.o.out_words + k] = 0;
+    }
+  }
+  uint32_t lf = 0;
+  if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
+  if (ovf) lf |= LF_OVERFLOW;
+  if (lf) atomicOr(&s_lf, lf);
+  __syncthreads();
+  if (tid == 0)
+    *status = XCD_ST_DONE | (aborted ? XCD_ST_ABORT : 0u) | (xcc << 24) | (min(sweep + 1u, 0xFFFFu) << 8) | s_lf;
+  if (PROF && tid == 0 && p == 0 && root_slot == 0 && a.n_roots < XCD_MAX_ROOTS)
+    for (int k = 0; k < 4; ++k) a.status[(XCD_MAX_ROOTS - 1) * XCD_MAX_WG + 28 + k] = (uint32_t)t_ph[k];
+}
+
 // k_single_lean — the reference's own case in its plainest form (BASELINE configs[0]: 500 routers, p2p links): a graph
 // without network vertices, without any static row flag (no overloaded source, no zero-cost link from a higher-numbered
 // source, in-degrees <= SINGLE_RL) and not hop-count-like (hspf_graph::lean).  One workgroup per root, ONE vertex per

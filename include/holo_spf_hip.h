@@ -163,7 +163,9 @@ typedef struct {
   uint64_t rows_recomputed;    /* HSPF_RUN_COUNT_ROWS: (vertex, 64-root batch) rows the fused fixed point evaluated, summed
                                   over its launches (0 without the flag); the reference settles each vertex once per root
                                   (holo-isis/src/spf.rs:552-556), i.e. n_batches * n_vertices rows would be 1x */
-  uint32_t single_wg;          /* 1: small graph, the run took the one-workgroup-per-root kernel (one launch)     */
+  uint32_t single_wg;          /* 1: small graph, the run took the one-workgroup-per-root kernel (one launch);
+                                  2: one to eight roots on a mid-size graph, one XCD per root (k_xcd, one launch):
+                                  dbg[1] then holds its sweeps (bits 0-15; bit 31: a workgroup ran on another XCD) */
   uint32_t lane_vertex;        /* 1: a few roots on a larger graph, the run took the lane = vertex kernel (k_lv)   */
   uint32_t dbg[4];             /* [0]: 1 = the run took the lean sweep (k_fused_lean); [1]: lean sweep: bits 0-7 = dense passes that did
                                   work, 8-15 = head sweeps that ran, 16-23 = dense passes planned, 24-30 = head sweeps planned

@@ -32,18 +32,23 @@ def spf_ctx(request, _ctx_pool):
     run down k_fw, the wide-mask fixed point (HSPF_VARIANT bit0: no packed state) — with the leaves of the graph left
     to the emit wherever it has any, which the adversarial graphs do (stub LANs, one-way links); "lanevertex" sends
     every run of up to 64 roots (with at most 24 first-hop slots) through k_lv (HSPF_SINGLE_MAX_N=0, HSPF_LV_MAX_ROOTS=64,
-    HSPF_LV_MIN_N=0); "hubsort" is the default engine with every graph built in hub mode (HSPF_HUB_DEG=0: two-way check and
+    HSPF_LV_MIN_N=0); "xcd" (round 5) has k_single and k_lv off, so that every run of at most eight roots — on the small
+    adversarial graphs too — takes k_xcd, one XCD per root with the state replicated in every CU's LDS, whatever it measured
+    before (HSPF_XCD_ALWAYS=1; in "default" the graphs between k_single's and 20 000 vertices take it or the sweep engine,
+    whichever was faster last time; the four sweep configurations switch it off: HSPF_XCD_MAX_ROOTS=0);
+    "hubsort" is the default engine with every graph built in hub mode (HSPF_HUB_DEG=0: two-way check and
     in-row order from device-wide sorts instead of per-link row scans; HSPF_TW_HOST_MAX=0: a structural patch fetches the
     two-way flags of its host mirror from the device, as it does for rows too long to scan, instead of keeping them itself).
     Tests choose with tests/_engines.py (indirect parametrisation); unmarked tests get "default"."""
     mode = getattr(request, "param", "default")
     if mode not in _ctx_pool:
         from holo_amd.engine import SpfContext
-        env = {"sweeps": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0"},
-               "kfused": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "32768"},
-               "twophase": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "64"},
-               "widemask": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_VARIANT": "1"},
+        env = {"sweeps": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_XCD_MAX_ROOTS": "0"},
+               "kfused": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_XCD_MAX_ROOTS": "0", "HSPF_VARIANT": "32768"},
+               "twophase": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_XCD_MAX_ROOTS": "0", "HSPF_VARIANT": "64"},
+               "widemask": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_XCD_MAX_ROOTS": "0", "HSPF_VARIANT": "1"},
                "lanevertex": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "64", "HSPF_LV_MIN_N": "0"},
+               "xcd": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_XCD_ALWAYS": "1"},
                "hubsort": {"HSPF_HUB_DEG": "0", "HSPF_TW_HOST_MAX": "0"}}.get(mode, {})
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)

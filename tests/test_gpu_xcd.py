@@ -1,0 +1,129 @@
+"""k_xcd — one to eight roots on a mid-size graph, one XCD per root, the state replicated in every CU's LDS, ONE launch with a
+barrier inside the XCD per sweep (holo_amd/csrc/spf_kernels.hip.h) — against the CPU oracle, bit for bit; the choice the
+product context makes between it and the launch-per-sweep engine; and the safety net: a run whose barrier gives up is redone
+on the launch-per-sweep path and the context stops trying.  (The "xcd" configuration of tests/_engines.py sends every
+small adversarial graph of the suite through the kernel as well.)"""
+import os
+
+import numpy as np
+import pytest
+
+from holo_amd import synth
+from holo_amd import engine as E
+from oracle import graph_oracle as go
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(**env):
+    env = {k: str(v) for k, v in env.items()}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return E.SpfContext(0)                     # the switches are read once, at hspf_init
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def _same(res, ref):
+    return (np.array_equal(res.dist, ref.dist) and np.array_equal(res.hops, ref.hops) and np.array_equal(res.flags & 1, ref.flags)
+            and np.array_equal(res.first_hop_mask, ref.mask))
+
+
+def _graphs():
+    yield synth.ospf_10k(), 1
+    yield synth.random_lsdb(5000, 300, 3.0, 77, metric_hi=60, lan_size=6), 1
+    yield synth.random_lsdb(18000, 800, 3.2, 78, metric_hi=60, lan_size=8, p_overload=0.02, p_oneway=0.03), 0
+    yield synth.random_lsdb(6000, 200, 3.0, 79, hopcount=True, lan_size=5), 2
+    yield synth.random_lsdb(3000, 40, 2.5, 80, metric_hi=3, lan_size=30, zero_cost_router_links=True), 3      # roots for the sequential kernel
+
+
+@pytest.fixture(scope="module")
+def xcd_ctx():
+    ctx = _ctx(HSPF_XCD_ALWAYS=1)
+    yield ctx
+    ctx.close()
+
+
+def test_one_to_eight_roots_on_mid_size_graphs(xcd_ctx):
+    rng = np.random.default_rng(5)
+    for g, fl in _graphs():
+        G = xcd_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        for k in (1, 2, 3, 5, 8):
+            roots = rng.choice(g.n, size=k, replace=False).astype(np.uint32)
+            if k == 5:
+                roots[2] = E.NO_ROOT                                   # a padding entry: empty SPT
+            if k == 3:
+                roots[0] = int(np.flatnonzero(g.vflags & 1)[0]) if (g.vflags & 1).any() else roots[0]   # a network vertex as root
+            res = xcd_ctx.run(G, roots, fl)
+            ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, fl & 3, go.MAP, mask_words_=res.first_hop_mask.shape[2])
+            assert _same(res, ref), (g.name, k, res.stats)
+            if res.first_hop_mask.shape[2] == 1 and res.stats["state_bytes"]:
+                assert res.stats["single_wg"] == 2 and (res.stats["dbg"][1] & 0xFFFF) > 0, res.stats      # k_xcd, and its sweeps
+                assert not res.stats["dbg"][1] >> 31, "the workgroups of a root did not share an XCD"
+                pr = xcd_ctx.run_packed(G, roots, fl)                  # the same run through the packed hand-off
+                assert np.array_equal(pr.dist, ref.dist) and np.array_equal(pr.hops, ref.hops) and np.array_equal(pr.in_spt, ref.flags.astype(bool))
+                assert np.array_equal(pr.first_hop_mask[..., 0], ref.mask[..., 0])
+        G.free()
+
+
+def test_patches_between_runs(xcd_ctx):
+    g = synth.random_lsdb(4000, 100, 3.0, 91, metric_hi=20, lan_size=6)
+    G = xcd_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    rng = np.random.default_rng(6)
+    roots = np.asarray([150, 2000], np.uint32)
+    for step in range(6):
+        vs = np.sort(rng.choice(np.arange(100, g.n), size=3, replace=False))
+        rows, fl = [], []
+        for v in vs.tolist():
+            c = G.col[G.row_ptr[v]:G.row_ptr[v + 1]]; m = G.metric[G.row_ptr[v]:G.row_ptr[v + 1]].copy()
+            if step % 2 and len(c) > 1:
+                c, m = c[1:], m[1:]                                    # a link goes away: structural
+            elif len(m):
+                m[:] = rng.integers(1, 30, size=len(m))                # costs only: in place
+            rows.append((c, m)); fl.append(int(G.vflags[v]))
+        G.patch(vs, rows, fl)
+        res = xcd_ctx.run(G, roots, 1)
+        ref = go.run(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, roots, 1, go.MAP, mask_words_=res.first_hop_mask.shape[2])
+        assert _same(res, ref), (step, res.stats)
+    G.free()
+
+
+def test_the_product_context_tries_both_and_keeps_the_faster():
+    ctx = E.SpfContext(0)
+    g = synth.ospf_10k()
+    G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    roots = np.asarray([0], np.uint32)
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 1, go.MAP, mask_words_=1)
+    paths, ms = [], {1: [], 2: []}
+    for it in range(12):
+        res = ctx.run(G, roots, 1)
+        assert _same(res, ref), (it, res.stats)
+        kind = 2 if res.stats["single_wg"] == 2 else 1
+        paths.append(kind); ms[kind].append(res.stats["ms_total"])
+    assert paths[:5] == [2, 2, 1, 1, 1], paths                            # k_xcd twice, the sweep engine three times, then the choice
+    assert len(set(paths[5:])) == 1, (paths, ms)
+    if abs(ms[2][1] - ms[1][2]) > 0.002:                                  # (the library compares whole microseconds)
+        assert paths[5] == (2 if ms[2][1] < ms[1][2] else 1), (paths, ms)
+    G.free()
+    ctx.close()
+
+
+def test_a_barrier_that_gives_up_sends_the_run_to_the_sweep_engine():
+    ctx = _ctx(HSPF_XCD_ALWAYS=1, HSPF_XCD_TIMEOUT_MS=0)                  # every wait of the kernel gives up at once
+    g = synth.random_lsdb(5000, 300, 3.0, 77, metric_hi=60, lan_size=6)
+    G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    roots = np.asarray([400, 900, 4000], np.uint32)
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 1, go.MAP, mask_words_=1)
+    for it in range(3):
+        res = ctx.run(G, roots, 1)
+        assert _same(res, ref), (it, res.stats)
+        assert res.stats["single_wg"] != 2, res.stats                     # the launch-per-sweep path delivered (and from run 2 on k_xcd is not tried)
+    pr = ctx.run_packed(G, roots, 1)
+    assert np.array_equal(pr.dist, ref.dist) and np.array_equal(pr.first_hop_mask[..., 0], ref.mask[..., 0])
+    G.free()
+    ctx.close()

@@ -77,6 +77,8 @@ def fuzz(ctx, first, count, verbose=True):
         G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
         for rep in range(3):
             k = int(rng.integers(1, min(g.n, 200 if g.n < 800 else 700) + 1))
+            if os.environ.get("FUZZ_MAX_ROOTS"):                     # (the one-XCD-per-root kernel takes runs of at most eight roots)
+                k = min(k, int(rng.integers(1, int(os.environ["FUZZ_MAX_ROOTS"]) + 1)))
             roots = rng.choice(g.n, size=k, replace=rng.random() < 0.2).astype(np.uint32)
             if k > 3 and rng.random() < 0.3:
                 roots[int(rng.integers(0, k))] = E.NO_ROOT

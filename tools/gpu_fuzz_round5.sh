@@ -9,7 +9,7 @@
 set -u
 N=${1:-400}
 OUT=gpurun_out/fuzz_r05.txt; mkdir -p gpurun_out; : > $OUT
-S="HSPF_SINGLE_MAX_N=0 HSPF_LV_MAX_ROOTS=0"
+S="HSPF_SINGLE_MAX_N=0 HSPF_LV_MAX_ROOTS=0 HSPF_XCD_MAX_ROOTS=0"
 (echo "default:        $(python tools/gpu_fuzz.py 120000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
 (echo "sweeps:         $(env $S python tools/gpu_fuzz.py 140000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
 wait
@@ -22,6 +22,7 @@ wait
 (echo "kfused:         $(env $S HSPF_VARIANT=32768 python tools/gpu_fuzz.py 240000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
 (echo "widemask:       $(env $S HSPF_VARIANT=1 python tools/gpu_fuzz.py 260000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
 wait
+(echo "xcd:            $(env HSPF_SINGLE_MAX_N=0 HSPF_LV_MAX_ROOTS=0 HSPF_XCD_ALWAYS=1 FUZZ_MAX_ROOTS=8 python tools/gpu_fuzz.py 280000 $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
 (echo "wide LANs:      $(FUZZ_WIDE=$((N / 8)) python tools/gpu_fuzz.py 3000 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
 wait
 cat $OUT
