@@ -334,6 +334,7 @@ inline void update_rib_intra_area(std::map<IpKey, RouteNet> &rib, const SptMap &
 }
 
 struct RibRow { std::string prefix; uint32_t metric; std::vector<std::pair<std::optional<std::string>, std::string>> nexthops; std::string type = "intra-area"; };
+inline bool operator==(const RibRow &a, const RibRow &b) { return a.prefix == b.prefix && a.metric == b.metric && a.nexthops == b.nexthops && a.type == b.type; }
 
 inline bool operator==(const RouterLink &a, const RouterLink &b) { return a.link_type == b.link_type && a.link_id == b.link_id && a.link_data == b.link_data && a.metric == b.metric; }
 inline bool operator==(const RouterLsa &a, const RouterLsa &b) { return a.adv_rtr == b.adv_rtr && a.links == b.links && a.maxage == b.maxage; }
@@ -626,99 +627,169 @@ struct OrderedTable {
   }
 };
 
-// compute_spf's intra-area part + update_global_rib with the SPTs, the ORDERED fold of EVERY area into one RIB
-// (Engine::rib_fold = hspf_rib_fold_device, one instance-wide first-hop slot numbering), the comparison with the RIB held
-// before and the compaction of what changed on the engine; one record stream comes back and is expanded into the RouteIpAdd /
-// RouteIpDel sequence.  `other_rows`: the inter-area / external rows of the new RIB (calculations outside this path): compared
-// on the host and merged into the sequence in prefix order.  Python twin: holo_amd.routes.ospf_update_global_rib_device.
-inline std::vector<IbusMsg> update_global_rib_device(const std::string &router_id, const std::vector<Area> &areas, uint32_t max_paths, Engine &engine,
-                                                     const std::vector<RibRow> &rib_before, const std::map<std::string, int> &ifindex,
-                                                     const std::vector<RibRow> &other_rows = {}, size_t *n_records = nullptr, size_t *n_prefixes = nullptr) {
-  if (n_records) *n_records = 0;
-  if (n_prefixes) *n_prefixes = 0;
-  std::map<IpKey, const RibRow *> old_intra, old_any;
-  std::vector<RibRow> old_other;
-  for (auto &r : rib_before) { const IpKey k = parse_ip(r.prefix); old_any[k] = &r; if (r.type == "intra-area") old_intra[k] = &r; else old_other.push_back(r); }
-  // ---- every area that holds the root's Router-LSA: SPT on the engine, its ordered table, its first-hop slots
+// What is version specific in the device route path below, as a traits object (`ver`): the area graph and its vertex / next-hop
+// types, the ordered prefix table, calc_nexthops for a first-hop slot.  OSPFv2 here, OSPFv3 (`v3::Ver`, with the address
+// family) below.
+struct Ver {
+  using Area = ospf::Area;
+  using AreaGraph = ospf::AreaGraph;
+  using Vertex = ospf::Vertex;
+  using Nexthops = ospf::Nexthops;
+  std::unique_ptr<AreaGraph> graph(const Area &a) const { return std::make_unique<AreaGraph>(a); }
+  static uint32_t area_key(const Area &a) { return ip4(a.area_id); }
+  static bool find_root(const AreaGraph &g, const std::string &router_id, uint32_t &root) {
+    auto ri = g.index.find({RTR, ip4(router_id)});
+    if (ri == g.index.end()) return false;
+    root = ri->second;
+    return true;
+  }
+  static OrderedTable table(const AreaGraph &g) { return OrderedTable::build(g); }
+  static Vertex vertex(const AreaGraph &g, uint32_t v) {
+    Vertex vx;
+    vx.id = g.vids[v];
+    if (vx.id.first == RTR) vx.rlsa = g.routers.at(vx.id.second); else vx.nlsa = g.networks.at(vx.id.second);
+    return vx;
+  }
+  static std::optional<Nexthops> slot_nexthops(const AreaGraph &g, const Vertex &parent, uint32_t k) {
+    const VertexId tv = g.vids[g.col[k]];
+    return calc_nexthops(g, parent, k, tv, tv.first == RTR ? g.routers.at(tv.second) : nullptr);
+  }
+};
+
+// Every area that holds the root's Router-LSA: its SPT on the engine, its ordered prefix table folded into ONE RIB there
+// (Engine::rib_fold = hspf_rib_fold_device, one instance-wide first-hop slot numbering: area a's slot s is slot 64 * off_a + s),
+// and the first-hop slots resolved to next hops on demand (needs Interface / Neighbor objects: host, once per slot).
+template <class V>
+struct RibOnEngine {
   struct AreaDev {
-    std::unique_ptr<AreaGraph> g; uint32_t root = 0, W = 1, off = 0; OrderedTable table; std::unique_ptr<DeviceRun> run; Tables res; SlotTable st;
-    std::map<uint32_t, Vertex> verts; std::map<uint32_t, std::optional<Nexthops>> slot_cache;
-    Vertex &vertex(uint32_t v) {
+    const V *ver = nullptr;
+    std::unique_ptr<typename V::AreaGraph> g; uint32_t root = 0, W = 1, off = 0; OrderedTable table; std::unique_ptr<DeviceRun> run; Tables res; SlotTable st;
+    std::map<uint32_t, typename V::Vertex> verts; std::map<uint32_t, std::optional<typename V::Nexthops>> slot_cache;
+    typename V::Vertex &vertex(uint32_t v) {
       auto it = verts.find(v);
       if (it != verts.end()) return it->second;
-      Vertex vx;
-      vx.id = g->vids[v];
-      if (vx.id.first == RTR) vx.rlsa = g->routers.at(vx.id.second); else vx.nlsa = g->networks.at(vx.id.second);
+      typename V::Vertex vx = V::vertex(*g, v);
       vx.distance = res.dist[v]; vx.hops = res.hops[v];
-      Vertex &ref = verts[v] = std::move(vx);
+      typename V::Vertex &ref = verts[v] = std::move(vx);
       for (uint32_t w = 0; w < W; ++w) {
         uint64_t m = res.mask[(size_t)v * W + w];
         while (m) { const int b = __builtin_ctzll(m); m &= m - 1; const auto &nh = resolve_slot(w * 64 + b); if (nh) for (auto &kv : *nh) ref.nexthops[kv.first] = kv.second; }
       }
       return ref;
     }
-    const std::optional<Nexthops> &resolve_slot(uint32_t s) {
+    const std::optional<typename V::Nexthops> &resolve_slot(uint32_t s) {
       auto it = slot_cache.find(s);
       if (it != slot_cache.end()) return it->second;
       const size_t i = std::upper_bound(st.base.begin(), st.base.end(), s) - st.base.begin() - 1;
       const uint32_t p = st.vertex[i], k = g->row_ptr[p] + (s - st.base[i]);
-      const VertexId tv = g->vids[g->col[k]];
-      auto r = calc_nexthops(*g, vertex(p), k, tv, tv.first == RTR ? g->routers.at(tv.second) : nullptr);
+      auto r = V::slot_nexthops(*g, vertex(p), k);
       return slot_cache[s] = std::move(r);
     }
   };
-  std::vector<const Area *> order;
-  for (auto &a : areas) order.push_back(&a);
-  std::stable_sort(order.begin(), order.end(), [](const Area *a, const Area *b) { return ip4(a->area_id) < ip4(b->area_id); });
   std::vector<std::unique_ptr<AreaDev>> devs;
-  uint32_t word_off = 0;
-  for (const Area *a : order) {
-    auto d = std::make_unique<AreaDev>();
-    d->g = std::make_unique<AreaGraph>(*a);
-    auto ri = d->g->index.find({RTR, ip4(router_id)});
-    if (ri == d->g->index.end()) continue;
-    d->root = ri->second;
-    d->table = OrderedTable::build(*d->g);
-    Graph &dev = d->g->device(engine);
-    d->run = engine.run_device(dev, {d->root}, HSPF_RUN_NET_NEXTHOPS);
-    d->res = d->run->host_tables();
-    d->W = d->res.mask_words;
-    d->st = engine.slot_table(dev, d->root);
-    d->off = word_off;
-    word_off += d->W;
-    devs.push_back(std::move(d));
-  }
-  bool any = false;
-  for (auto &d : devs) any = any || !d->table.prefixes.empty();
-  if (!any) return update_global_rib(other_rows, rib_before, ifindex);
-  const uint32_t W = std::max(word_off, 1u);
-  // ONE prefix list for both sides: the tables' prefixes plus those only the old RIB knows (no entries: no new route)
-  std::map<IpKey, std::string> keys;
-  std::set<IpKey> table_keys;
-  for (auto &d : devs) for (size_t i = 0; i < d->table.keys.size(); ++i) { keys.emplace(d->table.keys[i], d->table.prefixes[i]); table_keys.insert(d->table.keys[i]); }
-  for (auto &kv : old_intra) keys.emplace(kv.first, kv.second->prefix);
-  std::vector<std::string> prefixes;
+  std::vector<std::string> prefixes;             // ONE prefix list: the tables' prefixes plus `extra` (those only the old RIB knows)
   std::vector<IpKey> pkeys;
   std::map<IpKey, uint32_t> where;
-  for (auto &kv : keys) { where[kv.first] = (uint32_t)prefixes.size(); prefixes.push_back(kv.second); pkeys.push_back(kv.first); }
-  const uint32_t P = (uint32_t)prefixes.size();
-  // ---- the fold, area after area, on the engine
-  auto rib = engine.rib_new(P, W);
-  for (size_t ai = 0; ai < devs.size(); ++ai) {
-    AreaDev &d = *devs[ai];
-    if (d.table.prefixes.empty()) continue;
-    std::vector<uint32_t> pmap;
-    for (auto &k : d.table.keys) pmap.push_back(where[k]);
-    engine.rib_fold(*rib, *d.run, d.table.ptr, d.table.vertex, d.table.metric, d.table.origin, pmap, (uint32_t)ai, d.off);
+  std::set<IpKey> table_keys;
+  uint32_t P = 0, W = 1;
+  std::unique_ptr<DeviceRoutes> rib;             // null: no area has a prefix
+
+  RibOnEngine(const V &ver, const std::string &router_id, const std::vector<typename V::Area> &areas, Engine &engine,
+              const std::map<IpKey, std::string> &extra = {}) {
+    std::vector<const typename V::Area *> order;
+    for (auto &a : areas) order.push_back(&a);
+    std::stable_sort(order.begin(), order.end(), [](const typename V::Area *a, const typename V::Area *b) { return V::area_key(*a) < V::area_key(*b); });
+    uint32_t word_off = 0;
+    for (const typename V::Area *a : order) {
+      auto d = std::make_unique<AreaDev>();
+      d->ver = &ver;
+      d->g = ver.graph(*a);
+      if (!V::find_root(*d->g, router_id, d->root)) continue;
+      d->table = V::table(*d->g);
+      Graph &dev = d->g->device(engine);
+      d->run = engine.run_device(dev, {d->root}, HSPF_RUN_NET_NEXTHOPS);
+      d->res = d->run->host_tables();
+      d->W = d->res.mask_words;
+      d->st = engine.slot_table(dev, d->root);
+      d->off = word_off;
+      word_off += d->W;
+      devs.push_back(std::move(d));
+    }
+    bool any = false;
+    for (auto &d : devs) any = any || !d->table.prefixes.empty();
+    if (!any) return;
+    W = std::max(word_off, 1u);
+    std::map<IpKey, std::string> keys;
+    for (auto &d : devs) for (size_t i = 0; i < d->table.keys.size(); ++i) { keys.emplace(d->table.keys[i], d->table.prefixes[i]); table_keys.insert(d->table.keys[i]); }
+    for (auto &kv : extra) keys.emplace(kv.first, kv.second);
+    for (auto &kv : keys) { where[kv.first] = (uint32_t)prefixes.size(); prefixes.push_back(kv.second); pkeys.push_back(kv.first); }
+    P = (uint32_t)prefixes.size();
+    rib = engine.rib_new(P, W);                  // ---- the fold, area after area, on the engine
+    for (size_t ai = 0; ai < devs.size(); ++ai) {
+      AreaDev &d = *devs[ai];
+      if (d.table.prefixes.empty()) continue;
+      std::vector<uint32_t> pmap;
+      for (auto &k : d.table.keys) pmap.push_back(where[k]);
+      engine.rib_fold(*rib, *d.run, d.table.ptr, d.table.vertex, d.table.metric, d.table.origin, pmap, (uint32_t)ai, d.off);
+    }
   }
-  // an instance-wide slot -> the next hops it resolves to (area a's slot s is slot 64 * off_a + s)
-  auto slot_nexthops = [&](uint32_t gs) -> const std::optional<Nexthops> & {
-    static const std::optional<Nexthops> none;
+  // an instance-wide slot -> the next hops it resolves to
+  const std::optional<typename V::Nexthops> &slot_nexthops(uint32_t gs) {
+    static const std::optional<typename V::Nexthops> none;
     for (auto &d : devs) if (gs / 64 >= d->off && gs / 64 < d->off + d->W) return d->resolve_slot(gs - 64 * d->off);
     return none;
-  };
+  }
+  typename V::Nexthops expand(const uint64_t *mrow) {
+    typename V::Nexthops nhs;
+    for (uint32_t w = 0; w < W; ++w) {
+      uint64_t m = mrow[w];
+      while (m) { const int b = __builtin_ctzll(m); m &= m - 1; const auto &nh = slot_nexthops(64 * w + b); if (nh) for (auto &kv : *nh) nhs[kv.first] = kv.second; }
+    }
+    return nhs;
+  }
+};
+
+// compute_spf's intra-area part with SPTs and the ordered fold of every area on the engine: the rows of
+// compute_spf_intra_area, from the folded table (one copy back) and the first-hop slots.
+template <class V>
+inline std::vector<RibRow> intra_area_rib_device_t(const V &ver, const std::string &router_id, const std::vector<typename V::Area> &areas, uint32_t max_paths, Engine &engine) {
+  RibOnEngine<V> R(ver, router_id, areas, engine);
+  std::vector<RibRow> rows;
+  if (!R.rib) return rows;
+  const RoutesOut t = R.rib->host();
+  for (uint32_t p = 0; p < R.P; ++p) {
+    if (t.best_entry[p] == 0xFFFFFFFFu) continue;
+    RibRow row{R.prefixes[p], t.best_metric[p], {}};
+    for (auto &kv : R.expand(&t.nexthop_mask[(size_t)p * R.W])) { if (row.nexthops.size() >= max_paths) break; row.nexthops.push_back({kv.second.addr, kv.second.iface_name}); }
+    rows.push_back(std::move(row));
+  }
+  return rows;
+}
+
+// compute_spf's intra-area part + update_global_rib with the SPTs, the ORDERED fold of EVERY area into one RIB, the
+// comparison with the RIB held before and the compaction of what changed on the engine; one record stream comes back and
+// is expanded into the RouteIpAdd / RouteIpDel sequence.  `other_rows`: the inter-area / external rows of the new RIB
+// (calculations outside this path): compared on the host and merged into the sequence in prefix order.
+// Python twin: holo_amd.routes.ospf_update_global_rib_device (version 2 / 3).
+template <class V>
+inline std::vector<IbusMsg> update_global_rib_device_t(const V &ver, const std::string &router_id, const std::vector<typename V::Area> &areas, uint32_t max_paths,
+                                                       Engine &engine, const std::vector<RibRow> &rib_before, const std::map<std::string, int> &ifindex,
+                                                       const std::vector<RibRow> &other_rows = {}, size_t *n_records = nullptr, size_t *n_prefixes = nullptr) {
+  if (n_records) *n_records = 0;
+  if (n_prefixes) *n_prefixes = 0;
+  std::map<IpKey, const RibRow *> old_intra, old_any;
+  std::vector<RibRow> old_other;
+  std::map<IpKey, std::string> old_keys;
+  for (auto &r : rib_before) {
+    const IpKey k = parse_ip(r.prefix);
+    old_any[k] = &r;
+    if (r.type == "intra-area") { old_intra[k] = &r; old_keys.emplace(k, r.prefix); } else old_other.push_back(r);
+  }
+  RibOnEngine<V> R(ver, router_id, areas, engine, old_keys);
+  if (!R.rib) return update_global_rib(other_rows, rib_before, ifindex);
+  const uint32_t W = R.W, P = R.P;
   std::map<uint32_t, std::set<std::pair<std::optional<std::string>, std::string>>> slot_sets;      // every slot some vertex uses
-  for (auto &d : devs)
+  for (auto &d : R.devs)
     for (uint32_t v = 0; v < d->res.n_vertices; ++v) {
       if (!(d->res.flags[v] & HSPF_RF_IN_SPT)) continue;
       for (uint32_t w = 0; w < d->W; ++w) {
@@ -736,7 +807,7 @@ inline std::vector<IbusMsg> update_global_rib_device(const std::string &router_i
   RoutesOut old;
   old.best_metric.assign(P, 0xFFFFFFFFu); old.best_entry.assign(P, 0xFFFFFFFFu); old.nexthop_mask.assign((size_t)P * W, 0);
   for (auto &kv : old_intra) {
-    const uint32_t i = where[kv.first];
+    const uint32_t i = R.where[kv.first];
     std::set<std::pair<std::optional<std::string>, std::string>> want(kv.second->nexthops.begin(), kv.second->nexthops.end()), seen;
     for (auto &ss : slot_sets) {
       bool sub = true;
@@ -752,7 +823,7 @@ inline std::vector<IbusMsg> update_global_rib_device(const std::string &router_i
     if (!want.empty() && !anyb) old.nexthop_mask[(size_t)i * W] = 1;
   }
   auto before = engine.routes_upload(old, 1, P, W);
-  const RouteRecords rec = engine.routes_changed(*before, *rib);
+  const RouteRecords rec = engine.routes_changed(*before, *R.rib);
   if (n_records) *n_records = rec.count();
   if (n_prefixes) *n_prefixes = P;
   // ---- the records -> messages
@@ -761,8 +832,8 @@ inline std::vector<IbusMsg> update_global_rib_device(const std::string &router_i
   std::map<IpKey, IbusMsg> walk, gone;
   for (size_t k = 0; k < rec.count(); ++k) {
     const uint32_t *r = rec.rec(k);
-    const IpKey &key = pkeys.at(r[1]);
-    const std::string &prefix = prefixes[r[1]];
+    const IpKey &key = R.pkeys.at(r[1]);
+    const std::string &prefix = R.prefixes[r[1]];
     const RibRow *o = nullptr;
     if (auto it = old_intra.find(key); it != old_intra.end()) o = it->second;
     else if (auto it2 = old_any.find(key); it2 != old_any.end()) o = it2->second;        // held under another type before: the same route to the reference
@@ -771,13 +842,10 @@ inline std::vector<IbusMsg> update_global_rib_device(const std::string &router_i
       continue;
     }
     if (r[2] != HSPF_DIFF_INSTALL && r[2] != HSPF_DIFF_SILENT) continue;
-    Nexthops nhs;
-    for (uint32_t w = 0; w < W; ++w) {
-      uint64_t m = (uint64_t)r[HSPF_ROUTE_REC_WORDS + 2 * w] | ((uint64_t)r[HSPF_ROUTE_REC_WORDS + 2 * w + 1] << 32);
-      while (m) { const int b = __builtin_ctzll(m); m &= m - 1; const auto &nh = slot_nexthops(64 * w + b); if (nh) for (auto &kv : *nh) nhs[kv.first] = kv.second; }
-    }
+    uint64_t mrow[16] = {};
+    for (uint32_t w = 0; w < W && w < 16; ++w) mrow[w] = (uint64_t)r[HSPF_ROUTE_REC_WORDS + 2 * w] | ((uint64_t)r[HSPF_ROUTE_REC_WORDS + 2 * w + 1] << 32);
     RibRow row{prefix, r[3], {}};
-    for (auto &kv : nhs) { if (row.nexthops.size() >= max_paths) break; row.nexthops.push_back({kv.second.addr, kv.second.iface_name}); }
+    for (auto &kv : R.expand(mrow)) { if (row.nexthops.size() >= max_paths) break; row.nexthops.push_back({kv.second.addr, kv.second.iface_name}); }
     if (o && detail::same_route(*o, row)) continue;                        // the reference's "unchanged" (:875-885)
     if (detail::installed(row)) walk[key] = detail::add_msg(row, ifindex);
   }
@@ -787,13 +855,19 @@ inline std::vector<IbusMsg> update_global_rib_device(const std::string &router_i
   for (auto &m : update_global_rib(other_rows, old_for_other, ifindex)) {
     const IpKey k = parse_ip(m.prefix);
     if (m.add) { walk[k] = m; gone.erase(k); }
-    else if (!walk.count(k) && !table_keys.count(k)) gone[k] = m;
+    else if (!walk.count(k) && !R.table_keys.count(k)) gone[k] = m;
   }
   for (auto it = gone.begin(); it != gone.end();) it = (walk.count(it->first) || new_other_keys.count(it->first)) ? gone.erase(it) : std::next(it);
   std::vector<IbusMsg> msgs;
   for (auto &kv : walk) msgs.push_back(kv.second);
   for (auto &kv : gone) msgs.push_back(kv.second);
   return msgs;
+}
+
+inline std::vector<IbusMsg> update_global_rib_device(const std::string &router_id, const std::vector<Area> &areas, uint32_t max_paths, Engine &engine,
+                                                     const std::vector<RibRow> &rib_before, const std::map<std::string, int> &ifindex,
+                                                     const std::vector<RibRow> &other_rows = {}, size_t *n_records = nullptr, size_t *n_prefixes = nullptr) {
+  return update_global_rib_device_t(Ver{}, router_id, areas, max_paths, engine, rib_before, ifindex, other_rows, n_records, n_prefixes);
 }
 
 // ---- OSPFv3 (holo-ospf/src/ospfv3/spf.rs) ----------------------------------------------------------------------------
@@ -1026,6 +1100,87 @@ inline std::vector<RibRow> compute_spf_intra_area(const std::string &router_id, 
     rows.push_back(std::move(r));
   }
   return rows;
+}
+
+// ---- OSPFv3 on the engine: SPT, the ordered prefix fold of every area into one RIB, the wire step ----
+// The ordered table: the stub networks as Ospfv3::intra_area_networks yields them (ospfv3/spf.rs:421-478) — Intra-Area-Prefix-
+// LSAs in LSDB order (adv_rtr, LS-ID), MaxAge skipped, the referenced vertex looked up by (ref type, ref LS-ID, ref adv_rtr),
+// NU-bit prefixes dropped — grouped by prefix, the reference's order kept inside a prefix; the ordered fold then IS
+// update_rib_intra_area (route.rs:343-448).  Entries whose referenced vertex is not in the graph can never be in an SPT and
+// are left out.  Python twin: holo_amd.routes.Ospfv3PrefixTable.
+inline OrderedTable ordered_table(const AreaGraph &g) {
+  struct Row { IpKey key; std::string prefix; uint32_t v, metric, origin; size_t seq; };
+  std::vector<Row> rows;
+  std::vector<const IntraAreaPrefixLsa *> iaps;
+  for (auto &l : g.area->iaps) iaps.push_back(&l);
+  std::stable_sort(iaps.begin(), iaps.end(), [](auto *x, auto *y) { return std::make_pair(ip4(x->adv_rtr), x->lsa_id) < std::make_pair(ip4(y->adv_rtr), y->lsa_id); });
+  for (auto *lsa : iaps) {
+    if (lsa->maxage) continue;
+    auto vi = g.index.end();
+    if (lsa->ref_type == "ospfv3-router-lsa") { if (lsa->ref_lsa_id == 0) vi = g.index.find({RTR, ip4(lsa->ref_adv_rtr), 0}); }
+    else if (lsa->ref_type == "ospfv3-network-lsa") vi = g.index.find({NET, ip4(lsa->ref_adv_rtr), lsa->ref_lsa_id});
+    if (vi == g.index.end()) continue;
+    const uint32_t v = vi->second;
+    const bool is_net = std::get<0>(g.vids[v]) == NET;
+    const uint32_t origin = is_net ? g.networks.at({std::get<1>(g.vids[v]), std::get<2>(g.vids[v])})->lsa_id : g.routers.at(std::get<1>(g.vids[v]))[0]->lsa_id;
+    for (auto &p : lsa->prefixes) {
+      if (has_opt(p.options, "nu-bit")) continue;
+      rows.push_back({parse_ip(p.prefix), p.prefix, v | (is_net ? (uint32_t)HSPF_PFX_ENTRY_NETWORK : 0u), p.metric, origin, rows.size()});
+    }
+  }
+  OrderedTable t;
+  std::map<IpKey, std::string> all;
+  for (auto &r : rows) all.emplace(r.key, r.prefix);
+  std::map<IpKey, uint32_t> pid;
+  for (auto &kv : all) { pid[kv.first] = (uint32_t)t.keys.size(); t.keys.push_back(kv.first); t.prefixes.push_back(kv.second); }
+  std::stable_sort(rows.begin(), rows.end(), [&](const Row &a, const Row &b) { return std::make_pair(pid[a.key], a.seq) < std::make_pair(pid[b.key], b.seq); });
+  t.ptr.assign(t.keys.size() + 1, 0);
+  for (auto &r : rows) t.ptr[pid[r.key] + 1]++;
+  for (size_t i = 0; i < t.keys.size(); ++i) t.ptr[i + 1] += t.ptr[i];
+  for (auto &r : rows) { t.vertex.push_back(r.v); t.metric.push_back(r.metric); t.origin.push_back(r.origin); }
+  return t;
+}
+
+struct Ver {                                     // the version-specific parts of RibOnEngine / update_global_rib_device_t
+  using Area = v3::Area;
+  using AreaGraph = v3::AreaGraph;
+  using Vertex = v3::Vertex;
+  using Nexthops = v3::Nexthops;
+  std::string af = "ipv6";
+  std::unique_ptr<AreaGraph> graph(const Area &a) const { return std::make_unique<AreaGraph>(a, af); }
+  static uint32_t area_key(const Area &a) { return ip4(a.area_id); }
+  static bool find_root(const AreaGraph &g, const std::string &router_id, uint32_t &root) {
+    auto ri = g.index.find({RTR, ip4(router_id), 0});
+    if (ri == g.index.end()) return false;
+    root = ri->second;
+    return true;
+  }
+  static OrderedTable table(const AreaGraph &g) { return ordered_table(g); }
+  static Vertex vertex(const AreaGraph &g, uint32_t v) {
+    Vertex vx;
+    vx.id = g.vids[v];
+    if (std::get<0>(vx.id) == RTR) vx.rlsa = g.routers.at(std::get<1>(vx.id)); else vx.nlsa = g.networks.at({std::get<1>(vx.id), std::get<2>(vx.id)});
+    return vx;
+  }
+  static std::optional<Nexthops> slot_nexthops(const AreaGraph &g, const Vertex &parent, uint32_t k) {
+    const VertexId tv = g.vids[g.col[k]];
+    return calc_nexthops(g, parent, k, tv, std::get<0>(tv) == RTR ? &g.routers.at(std::get<1>(tv)) : nullptr);
+  }
+};
+
+// compute_spf_intra_area with the SPTs and the ordered fold of every area on the engine; same rows.
+// Python twin: holo_amd.routes.ospfv3_intra_area_device_routes.
+inline std::vector<RibRow> intra_area_device_routes(const std::string &router_id, const std::vector<Area> &areas, uint32_t max_paths, Engine &engine,
+                                                    const std::string &af = "ipv6") {
+  return intra_area_rib_device_t(Ver{af}, router_id, areas, max_paths, engine);
+}
+
+// ... + update_global_rib (holo-ospf/src/route.rs:856-916): the RouteIpAdd / RouteIpDel sequence from the engine's records.
+inline std::vector<IbusMsg> update_global_rib_device(const std::string &router_id, const std::vector<Area> &areas, uint32_t max_paths, Engine &engine,
+                                                     const std::vector<RibRow> &rib_before, const std::map<std::string, int> &ifindex,
+                                                     const std::string &af = "ipv6", const std::vector<RibRow> &other_rows = {},
+                                                     size_t *n_records = nullptr, size_t *n_prefixes = nullptr) {
+  return update_global_rib_device_t(Ver{af}, router_id, areas, max_paths, engine, rib_before, ifindex, other_rows, n_records, n_prefixes);
 }
 
 }  // namespace v3

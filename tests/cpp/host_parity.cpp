@@ -413,6 +413,36 @@ static int replay_ospf_step(const J &step, const std::string &golden_dir, Engine
   return 1;
 }
 
+// OSPFv3 from the engine (round 5): the recorded RIB from the ordered fold of every area on the engine, and a wire step — the
+// LSDB as recorded against a perturbed copy of it (remote Intra-Area-Prefix and Router-LSA metrics changed) as the RIB held
+// before; no ibus recording exists for OSPFv3 (the conformance module is commented out upstream), so the expected sequence is
+// the host rule's (pinned by the OSPFv2 recordings: it does not look at the version).
+static int check_ospfv3_device(const J &vec, Engine &eng, size_t &records, size_t &prefixes, int &with_msgs) {
+  const auto areas = areas3_from_vector(vec);
+  const std::string rid = vec["router_id"].s, af = vec["af"].s;
+  const uint32_t mp = (uint32_t)vec["max_paths"].i();
+  const auto rows = O::v3::compute_spf_intra_area(rid, areas, mp, eng, af);
+  if (!(O::v3::intra_area_device_routes(rid, areas, mp, eng, af) == rows)) { std::fprintf(stderr, "  ospfv3: rows from the engine's fold differ\n"); return 0; }
+  auto before_areas = areas;
+  for (auto &a : before_areas) {
+    size_t i = 0;
+    for (auto &l : a.iaps) if (l.adv_rtr != rid && i++ % 3 == 0) for (auto &p : l.prefixes) p.metric += 3;
+    i = 0;
+    for (auto &l : a.routers) if (l.adv_rtr != rid && i++ % 4 == 1) for (auto &k : l.links) k.metric = k.metric % 7 + 1;
+  }
+  std::map<std::string, int> ifindex;
+  for (auto &a : areas) for (auto &f : a.interfaces) ifindex[f.name] = (int)f.index;
+  const auto before = O::v3::compute_spf_intra_area(rid, before_areas, mp, eng, af);
+  for (const auto *old : {&before, &rows}) {                       // a changed LSDB, and an unchanged one (nothing to send)
+    const auto want = O::update_global_rib(rows, *old, ifindex);
+    size_t nr = 0, np = 0;
+    if (!(O::v3::update_global_rib_device(rid, areas, mp, eng, *old, ifindex, af, {}, &nr, &np) == want)) { std::fprintf(stderr, "  ospfv3 wire: device form differs\n"); return 0; }
+    records += nr; prefixes += np;
+    if (!want.empty()) ++with_msgs;
+  }
+  return 1;
+}
+
 int main(int argc, char **argv) {
   std::string engine = "hip", oracle_so = "oracle/liboracle_spf.so", golden_dir;
   std::vector<std::string> files;
@@ -431,7 +461,8 @@ int main(int argc, char **argv) {
   } catch (const std::exception &e) { std::fprintf(stderr, "engine: %s\n", e.what()); return 1; }
   int ok = 0, bad = 0, skipped = 0, manet_cases = 0, manet_bad = 0, steps_ok = 0, steps_bad = 0, steps_patched = 0, dev_ok = 0, dev_bad = 0;
   int wire_ok = 0, wire_bad = 0, wire_pipelines = 0, owire_ok = 0, owire_bad = 0, owire_multi = 0;
-  size_t owire_records = 0, owire_prefixes = 0;
+  size_t owire_records = 0, owire_prefixes = 0, v3_records = 0, v3_prefixes = 0;
+  int v3_ok = 0, v3_bad = 0, v3_msgs = 0;
   size_t wire_records = 0, wire_prefixes = 0;
   if (!check_hash_kat()) { std::fprintf(stderr, "flood_reduction_hash: reference vectors not reproduced\n"); return 1; }
   for (auto &path : files) {
@@ -454,6 +485,7 @@ int main(int argc, char **argv) {
         if (vec["has_vlinks"].b) { ++skipped; continue; }
         const auto rows3 = O::v3::compute_spf_intra_area(vec["router_id"].s, areas3_from_vector(vec), (uint32_t)vec["max_paths"].i(), *eng, vec["af"].s);
         if (ospf_rows_equal(rows3, vec["rib"])) ++ok; else { ++bad; std::fprintf(stderr, "MISMATCH %s (ospfv3)\n", path.c_str()); }
+        if (check_ospfv3_device(vec, *eng, v3_records, v3_prefixes, v3_msgs) > 0) ++v3_ok; else { ++v3_bad; std::fprintf(stderr, "OSPFV3 DEVICE ROUTES / WIRE STEP MISMATCH %s\n", path.c_str()); }
         continue;
       }
       if (vec["proto"].s != "isis") continue;
@@ -493,5 +525,6 @@ int main(int argc, char **argv) {
   if (dev_ok + dev_bad) std::printf("host_parity: %d IS-IS RIBs also derived with the prefix attachment on the engine, %d differ\n", dev_ok + dev_bad, dev_bad);
   if (wire_ok + wire_bad) std::printf("host_parity: %d recorded ibus sequences (RouteIpAdd / RouteIpDel) reproduced by the host rule AND from engine tables (%zu records for %zu prefixes), %d differ; %d also through the running-instance pipeline\n", wire_ok, wire_records, wire_prefixes, wire_bad, wire_pipelines);
   if (owire_ok + owire_bad) std::printf("host_parity: %d recorded OSPFv2 ibus sequences reproduced by the host rule AND from engine tables (%zu records for %zu prefixes; %d of them two-area instances folded into one RIB on the engine), %d differ\n", owire_ok, owire_records, owire_prefixes, owire_multi, owire_bad);
-  return (bad || manet_bad || steps_bad || dev_bad || wire_bad || owire_bad) ? 1 : 0;
+  if (v3_ok + v3_bad) std::printf("host_parity: %d OSPFv3 RIBs also from the ordered fold on the engine, each with two wire steps against the host rule (%zu records for %zu prefixes, %d sequences with messages), %d differ\n", v3_ok, v3_records, v3_prefixes, v3_msgs, v3_bad);
+  return (bad || manet_bad || steps_bad || dev_bad || wire_bad || owire_bad || v3_bad) ? 1 : 0;
 }
