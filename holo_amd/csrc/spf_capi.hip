@@ -1911,7 +1911,9 @@ int Run::xcd_run() {
   const uint32_t n_pad = (n + 1u) & ~1u;
   const uint32_t vw = std::max(64u, (((n + XCD_MAX_WG - 1u) / XCD_MAX_WG) + 1u) & ~1u);   // vertices per workgroup: even, one per thread
   const uint32_t n_wg = (n + vw - 1u) / vw;
-  const uint32_t thr = (vw + 63u) / 64u * 64u;
+  // one thread per vertex of the range — and enough threads for the re-read of changed ranges to be ONE batch of eight
+  // 16-byte loads per thread (n / 16 threads; the kernel is built for at most 640)
+  const uint32_t thr = std::min(640u, std::max((vw + 63u) / 64u * 64u, (n / 16u + 63u) / 64u * 64u));
   // every workgroup STORES its last word (status bits of its vertices, sweeps, "gave up") into pinned host memory
   uint32_t *d_hst = nullptr;
   uint32_t *h_st = ctx->h_lane_flags + L;                            // (the 256 words behind the per-root status bits)
