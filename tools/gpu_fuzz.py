@@ -5,6 +5,7 @@ engine against the CPU oracle, bit for bit.  Not part of the pytest suite (minut
 
     python tools/gpu_fuzz.py [first_seed] [n_graphs]
     FUZZ_WIDE=n python tools/gpu_fuzz.py [first_seed]      (n graphs with LANs of 150-900 routers: up to 15 mask words)
+    FUZZ_MID=n python tools/gpu_fuzz.py [first_seed]       (n graphs of 2 000-19 500 vertices, 1-8 roots per run: k_xcd's range)
 """
 import os
 import sys
@@ -21,9 +22,13 @@ from holo_amd import engine as E               # noqa: E402
 from oracle import graph_oracle as go          # noqa: E402
 
 
+PATHS = {"k_xcd": 0, "other": 0}              # which kernel took the runs (fuzz_mid reports it: a k_xcd run that gave up shows here)
+
+
 def compare(ctx, G, g, roots, flags, tag):
     try:
         res = ctx.run(G, roots, flags)
+        PATHS["k_xcd" if res.stats.get("single_wg") == 2 else "other"] += 1
     except E.HspfError as e:
         if e.code == -5:                       # documented limit: more than 1024 first-hop slots (16 mask words)
             return True
@@ -114,6 +119,53 @@ def fuzz(ctx, first, count, verbose=True):
         G.free()
     if verbose:
         print(f"fuzz: {ok}/{runs} runs bit-exact over {count} graphs in {time.time() - t0:.1f} s", flush=True)
+    return ok, runs
+
+
+def fuzz_mid(ctx, first, count, verbose=True):
+    """Mid-size LSDBs (2 000 - 19 500 vertices: beyond the one-workgroup kernel, inside k_xcd's 20 000), one to eight roots per
+    run — what k_xcd and the choice between it and the sweep engine see in production —, the adversarial ingredients of
+    fuzz() and row patches in between."""
+    ok = runs = 0
+    t0 = time.time()
+    for seed in range(first, first + count):
+        rng = np.random.default_rng(170_000 + seed)
+        nr = int(rng.integers(2000, 19000))
+        nn = int(rng.integers(0, 500))
+        hop = rng.random() < 0.2
+        g = synth.random_lsdb(nr, nn, float(rng.uniform(1.5, 4.0)), 180_000 + seed, metric_lo=1, metric_hi=int(rng.integers(1, 60)),
+                              max_path=(4095 if rng.random() < 0.1 else (0xFFFFFFFF if rng.random() < 0.3 else synth.MAX_PATH_METRIC_WIDE)),
+                              p_oneway=float(rng.choice([0.0, 0.03])), p_parallel=float(rng.choice([0.0, 0.05])),
+                              p_overload=float(rng.choice([0.0, 0.03, 0.2])), p_noexpand=float(rng.choice([0.0, 0.02])),
+                              zero_cost_router_links=bool(rng.random() < 0.1), lan_size=int(rng.choice([2, 4, 8, 20, 40])), hopcount=hop)
+        G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        for rep in range(4):
+            k = int(rng.integers(1, 9))
+            roots = rng.choice(g.n, size=k, replace=False).astype(np.uint32)
+            if k > 2 and rng.random() < 0.3:
+                roots[int(rng.integers(0, k))] = E.NO_ROOT
+            flags = int(rng.choice([0, E.RUN_NET_NEXTHOPS, E.RUN_IGNORE_OVERLOAD, E.RUN_NET_NEXTHOPS | E.RUN_IGNORE_OVERLOAD]))
+            if hop:
+                flags |= E.RUN_IGNORE_OVERLOAD
+            for again in range(1 if rep else 7):                       # the first root set seven times: the product context tries both kernels, then chooses
+                runs += 1
+                ok += compare(ctx, G, g, roots, flags, ("mid", seed, rep, flags, k, again))
+            if rep < 3:
+                vs = np.sort(rng.choice(g.n, size=int(rng.integers(1, 5)), replace=False))
+                rows, fl = [], []
+                costs_only = rng.random() < 0.5
+                for v in vs.tolist():
+                    c = g.col[g.row_ptr[v]:g.row_ptr[v + 1]]; m = g.metric[g.row_ptr[v]:g.row_ptr[v + 1]]
+                    keep = rng.random(len(c)) > (-1.0 if costs_only else 0.25)
+                    c, m = c[keep], m[keep].copy()
+                    if len(m) and (v >= nn or costs_only):
+                        m[rng.random(len(m)) < 0.5] = int(rng.integers(0 if costs_only else 1, 9)) if not hop else int(rng.integers(0, 2))
+                    rows.append((c, m)); fl.append(int(g.vflags[v]))
+                G.patch(vs, rows, fl)
+                g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
+        G.free()
+    if verbose:
+        print(f"fuzz_mid: {ok}/{runs} runs bit-exact over {count} graphs in {time.time() - t0:.1f} s (k_xcd took {PATHS['k_xcd']} of them)", flush=True)
     return ok, runs
 
 
@@ -277,6 +329,9 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     ctx = E.SpfContext(0)
+    if os.environ.get("FUZZ_MID"):                                  # only the mid-size graphs (k_xcd's range)
+        ok, runs = fuzz_mid(ctx, first, int(os.environ["FUZZ_MID"]))
+        sys.exit(0 if ok == runs else 1)
     if os.environ.get("FUZZ_WIDE"):                                 # only the wide-mask graphs
         ok, runs = fuzz_wide(ctx, first, int(os.environ["FUZZ_WIDE"]))
         sys.exit(0 if ok == runs else 1)
