@@ -127,3 +127,33 @@ def test_a_barrier_that_gives_up_sends_the_run_to_the_sweep_engine():
     assert np.array_equal(pr.dist, ref.dist) and np.array_equal(pr.first_hop_mask[..., 0], ref.mask[..., 0])
     G.free()
     ctx.close()
+
+
+def test_two_instances_at_once_stay_correct():
+    """Two contexts on two host threads (two protocol instances), each sending one-root runs through k_xcd back to back: the
+    kernels of the two may land on the same XCD (a workgroup per CU each: they queue behind each other), every result is
+    right, and a run that gave up on a barrier — none is expected — would have been redone by the sweep engine."""
+    import threading
+    g = synth.ospf_10k()
+    ref = {r: go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, np.asarray([r], np.uint32), 1, go.MAP, mask_words_=1) for r in (0, 5000)}
+    out = {}
+
+    def instance(i, root):
+        ctx = _ctx(HSPF_XCD_ALWAYS=1)
+        G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        good = taken = 0
+        for it in range(150):
+            res = ctx.run(G, np.asarray([root], np.uint32), 1)
+            good += _same(res, ref[root])
+            taken += res.stats["single_wg"] == 2
+        G.free(); ctx.close()
+        out[i] = (good, taken)
+
+    ts = [threading.Thread(target=instance, args=(i, r)) for i, r in enumerate((0, 5000))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert out[0][0] == 150 and out[1][0] == 150, out
+    print("k_xcd runs of the two instances:", out)
+    assert out[0][1] >= 140 and out[1][1] >= 140, out                 # (a context that gave up once stops using the kernel: far fewer)
