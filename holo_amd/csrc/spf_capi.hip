@@ -1506,17 +1506,21 @@ int Run::prepare_outputs() {
   // sweeps against 63-98 launches, slower: profiles/r05_notes.md), so the graph remembers what each took last time for
   // this many roots and the faster one runs (patches change the graph under the measurements: the other one is looked
   // at again now and then).
-  xcd_ok = fused && !single && !lv && !ctx->xcd_off && n_roots >= 1 && n_roots <= ctx->xcd_max_roots && n <= XCD_MAX_N && g->n_giant == 0 &&
+  // (k_single's graphs too: with at most eight roots the one-workgroup kernel leaves 248 CUs idle and walks a root's rows
+  // with one CU; k_xcd measured 1.1-4.5 x faster from 300 to 4 000 vertices, profiles/r05_notes.md r05p — the choice below
+  // keeps whichever is faster, e.g. k_single_lean on the reference's own 500-router grid if it is)
+  xcd_ok = fused && !lv && !ctx->xcd_off && n_roots >= 1 && n_roots <= ctx->xcd_max_roots && n <= XCD_MAX_N && g->n_giant == 0 &&
            !(run_flags & HSPF_RUN_COUNT_ROWS);
   xcdp = xcd_ok;
   if (xcd_ok && !ctx->xcd_always) {
-    // choices 0-1: k_xcd, 2-4: the sweep engine (its first runs on a context still size their launch plan), then the
+    // choices 0-1: k_xcd, 2-4: the other kernel (the sweep engine's first runs on a context still size their launch plan), then the
     // faster of the two last times; every 256th choice the other one, to look again
     const uint32_t c = g->xcd_choices[n_roots].fetch_add(1u, std::memory_order_relaxed);
     const uint32_t tx = g->xcd_us[n_roots].load(std::memory_order_relaxed), ts = g->sweep_us[n_roots].load(std::memory_order_relaxed);
     xcdp = c < 2u ? true : c < 5u ? false : (tx != 0u && (ts == 0u || tx <= ts));
     if (c >= 5u && (c & 255u) == 255u) xcdp = !xcdp;
   }
+  if (xcdp) single = false;
   // row-major output targets (device): the caller's device buffers, or staging for host output
   od = OutDev{};
   rn = (size_t)total_rows * n;               // rows of the output arrays (== n_roots unless mapped)

@@ -315,7 +315,8 @@ def test_lean_graphs_take_the_register_resident_kernel(spf_ctx, rows, cols, chor
         pytest.skip("a chord made a vertex too wide for the lean kernel")
     for roots in ([0], [n - 1, n // 2], list(range(n))[:96]):
         res, ref = check(spf_ctx, g, roots, expect_exact=False)
-        assert res.stats["single_wg"] == 1
+        # (up to eight roots the graph tries k_xcd, one XCD per root, next to the one-workgroup kernel and keeps the faster)
+        assert res.stats["single_wg"] == 1 or (len(roots) <= 8 and res.stats["single_wg"] == 2)
 
 
 @sweeps_engine
