@@ -34,11 +34,23 @@ class Graph {                         // one uploaded graph (device resident for
   virtual ~Graph() = default;
 };
 // Results of one run left where the engine produced them (HBM for the product engine): input of routes().
+// The same tables as plain pointers into memory the run object keeps (valid while it lives): what a caller needs that
+// reads a handful of entries (the first-hop slot replay) and must not pay for four std::vector copies per step.
+struct TablesView { const uint32_t *dist = nullptr; const uint16_t *hops = nullptr, *flags = nullptr; const uint64_t *mask = nullptr;
+                    uint32_t n_roots = 0, n_vertices = 0, mask_words = 1; };
 class DeviceRun {
  public:
   virtual ~DeviceRun() = default;
   virtual Tables host_tables() = 0;   // the copy the host side still needs for next-hop resolution
+  // distance / hops / flags (and the masks when asked for) on the host, zero-copy for the caller; the default keeps a Tables
+  virtual TablesView host_view(bool with_mask) {
+    (void)with_mask;
+    if (!view_cache_) view_cache_ = std::make_unique<Tables>(host_tables());
+    return TablesView{view_cache_->dist.data(), view_cache_->hops.data(), view_cache_->flags.data(), view_cache_->mask.data(), n_roots, n_vertices, mask_words};
+  }
   uint32_t n_roots = 0, n_vertices = 0, mask_words = 1;
+ private:
+  std::unique_ptr<Tables> view_cache_;
 };
 struct RoutesOut {                    // per (root, prefix), row-major: see hspf_routes in holo_spf_hip.h
   std::vector<uint32_t> best_metric, best_entry;
@@ -189,41 +201,106 @@ class HipGraph : public Graph {
   hspf_ctx *ctx;
   hspf_graph *g;
 };
-class HipDeviceRun : public DeviceRun {             // dist / hops / flags / masks of one run in plain hipMalloc buffers
+// Device and page-locked host blocks of the objects below, kept for reuse: a running instance makes the same few allocations
+// every SPF event (run tables, route tables, staging), and hipMalloc / hipFree cost 10-50 us each and synchronise the device
+// (the LSP-change pipeline of RibPipeline: 0.94 -> ~0.7 ms, profiles/r05_notes.md).  Blocks are handed out by exact size class
+// (rounded up to 64 KB); every engine call that reads or writes them is synchronous, so a returned block is idle.
+class HipPool {
  public:
-  ~HipDeviceRun() override { for (void *p : {(void *)dist, (void *)hops, (void *)flags, (void *)mask}) if (p) (void)hipFree(p); }
+  ~HipPool() {
+    for (auto &kv : dev_) for (void *p : kv.second) (void)hipFree(p);
+    for (auto &kv : pin_) for (void *p : kv.second) (void)hipHostFree(p);
+  }
+  static size_t cls(size_t bytes) { return (std::max<size_t>(bytes, 1) + 65535) & ~size_t(65535); }
+  void *dev(size_t bytes) {
+    auto &fl = dev_[cls(bytes)];
+    if (!fl.empty()) { void *p = fl.back(); fl.pop_back(); return p; }
+    void *p = nullptr;
+    if (hipMalloc(&p, cls(bytes)) != hipSuccess) throw std::runtime_error("hipMalloc failed");
+    return p;
+  }
+  void dev_free(void *p, size_t bytes) { if (p) dev_[cls(bytes)].push_back(p); }
+  void *pinned(size_t bytes) {
+    auto &fl = pin_[cls(bytes)];
+    if (!fl.empty()) { void *p = fl.back(); fl.pop_back(); return p; }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, cls(bytes), hipHostMallocDefault) != hipSuccess) throw std::runtime_error("hipHostMalloc failed");
+    return p;
+  }
+  void pinned_free(void *p, size_t bytes) { if (p) pin_[cls(bytes)].push_back(p); }
+ private:
+  std::map<size_t, std::vector<void *>> dev_, pin_;
+};
+class HipDeviceRun : public DeviceRun {             // dist / hops / flags / masks of one run in device buffers of the engine's pool
+ public:
+  explicit HipDeviceRun(std::shared_ptr<HipPool> pool) : pool_(std::move(pool)) {}
+  ~HipDeviceRun() override {
+    pool_->dev_free(dist, rn() * 4); pool_->dev_free(hops, rn() * 2); pool_->dev_free(flags, rn() * 2); pool_->dev_free(mask, rn() * 8 * mask_words);
+    pool_->pinned_free(stage_, stage_bytes_);
+  }
+  void alloc() {
+    dist = (uint32_t *)pool_->dev(rn() * 4); hops = (uint16_t *)pool_->dev(rn() * 2); flags = (uint16_t *)pool_->dev(rn() * 2);
+    mask = (uint64_t *)pool_->dev(rn() * 8 * mask_words);
+  }
   Tables host_tables() override {
     Tables t;
     t.n_roots = n_roots; t.n_vertices = n_vertices; t.mask_words = mask_words;
-    const size_t rn = (size_t)n_roots * n_vertices;
-    t.dist.resize(rn); t.hops.resize(rn); t.flags.resize(rn); t.mask.resize(rn * mask_words);
-    if (hipMemcpy(t.dist.data(), dist, rn * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(t.hops.data(), hops, rn * 2, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(t.flags.data(), flags, rn * 2, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(t.mask.data(), mask, rn * 8 * mask_words, hipMemcpyDeviceToHost) != hipSuccess)
+    t.dist.resize(rn()); t.hops.resize(rn()); t.flags.resize(rn()); t.mask.resize(rn() * mask_words);
+    if (hipMemcpy(t.dist.data(), dist, rn() * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(t.hops.data(), hops, rn() * 2, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(t.flags.data(), flags, rn() * 2, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(t.mask.data(), mask, rn() * 8 * mask_words, hipMemcpyDeviceToHost) != hipSuccess)
       throw std::runtime_error("hipMemcpy of the run tables failed");
     return t;
   }
+  // into ONE page-locked block of the pool (bus speed, no std::vector to size and fill): [mask (when asked for) | dist | hops | flags]
+  TablesView host_view(bool with_mask) override {
+    const size_t mb = with_mask ? rn() * 8 * mask_words : 0, need = mb + rn() * 8;
+    if (!stage_ || stage_bytes_ < need || (with_mask && !stage_mask_)) {
+      pool_->pinned_free(stage_, stage_bytes_);
+      stage_ = (char *)pool_->pinned(need); stage_bytes_ = need; stage_mask_ = with_mask; staged_ = false;
+    }
+    char *pm = stage_, *pd = stage_ + (stage_mask_ ? rn() * 8 * mask_words : 0), *ph = pd + rn() * 4, *pf = ph + rn() * 2;
+    if (!staged_) {
+      bool ok = hipMemcpy(pd, dist, rn() * 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(ph, hops, rn() * 2, hipMemcpyDeviceToHost) == hipSuccess &&
+                hipMemcpy(pf, flags, rn() * 2, hipMemcpyDeviceToHost) == hipSuccess;
+      if (ok && stage_mask_) ok = hipMemcpy(pm, mask, rn() * 8 * mask_words, hipMemcpyDeviceToHost) == hipSuccess;
+      if (!ok) throw std::runtime_error("hipMemcpy of the run tables failed");
+      staged_ = true;
+    }
+    return TablesView{(const uint32_t *)pd, (const uint16_t *)ph, (const uint16_t *)pf, stage_mask_ ? (const uint64_t *)pm : nullptr, n_roots, n_vertices, mask_words};
+  }
   uint32_t *dist = nullptr; uint16_t *hops = nullptr, *flags = nullptr; uint64_t *mask = nullptr;
+ private:
+  size_t rn() const { return (size_t)n_roots * n_vertices; }
+  std::shared_ptr<HipPool> pool_;
+  char *stage_ = nullptr; size_t stage_bytes_ = 0; bool stage_mask_ = false, staged_ = false;
 };
-class HipDeviceRoutes : public DeviceRoutes {       // best_metric / best_entry / nexthop_mask of one table set in plain hipMalloc buffers
+class HipDeviceRoutes : public DeviceRoutes {       // best_metric / best_entry / nexthop_mask of one table set in device buffers of the engine's pool
  public:
-  ~HipDeviceRoutes() override { for (void *p : {(void *)bm, (void *)be, (void *)nm, (void *)org}) if (p) (void)hipFree(p); }
+  explicit HipDeviceRoutes(std::shared_ptr<HipPool> pool) : pool_(std::move(pool)) {}
+  ~HipDeviceRoutes() override {
+    pool_->dev_free(bm, rp() * 4); pool_->dev_free(be, rp() * 4); pool_->dev_free(nm, rp() * 8 * mask_words); pool_->dev_free(org, std::max<size_t>(n_prefixes, 1) * 4);
+  }
   RoutesOut host() override {
     RoutesOut o;
-    const size_t rp = (size_t)n_roots * n_prefixes;
-    o.best_metric.resize(rp); o.best_entry.resize(rp); o.nexthop_mask.resize(rp * mask_words);
-    if (rp && (hipMemcpy(o.best_metric.data(), bm, rp * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(o.best_entry.data(), be, rp * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-               hipMemcpy(o.nexthop_mask.data(), nm, rp * 8 * mask_words, hipMemcpyDeviceToHost) != hipSuccess))
+    const size_t n = (size_t)n_roots * n_prefixes;
+    o.best_metric.resize(n); o.best_entry.resize(n); o.nexthop_mask.resize(n * mask_words);
+    if (n && (hipMemcpy(o.best_metric.data(), bm, n * 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(o.best_entry.data(), be, n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+              hipMemcpy(o.nexthop_mask.data(), nm, n * 8 * mask_words, hipMemcpyDeviceToHost) != hipSuccess))
       throw std::runtime_error("hipMemcpy of the route tables failed");
     return o;
   }
   bool alloc() {
-    const size_t rp = std::max<size_t>((size_t)n_roots * n_prefixes, 1);
-    return hipMalloc((void **)&bm, rp * 4) == hipSuccess && hipMalloc((void **)&be, rp * 4) == hipSuccess && hipMalloc((void **)&nm, rp * 8 * mask_words) == hipSuccess;
+    bm = (uint32_t *)pool_->dev(rp() * 4); be = (uint32_t *)pool_->dev(rp() * 4); nm = (uint64_t *)pool_->dev(rp() * 8 * mask_words);
+    return true;
   }
+  void alloc_origin() { org = (uint32_t *)pool_->dev(std::max<size_t>(n_prefixes, 1) * 4); }
   hspf_routes raw() const { return hspf_routes{bm, be, nm}; }
   uint32_t *bm = nullptr, *be = nullptr; uint64_t *nm = nullptr;
   uint32_t *org = nullptr;             // rib_new only: the owners' origins (hspf_rib_device.origin)
+ private:
+  size_t rp() const { return std::max<size_t>((size_t)n_roots * n_prefixes, 1); }
+  std::shared_ptr<HipPool> pool_;
 };
 class HipEngine : public Engine {
  public:
@@ -316,14 +393,11 @@ class HipEngine : public Engine {
   }
   std::unique_ptr<DeviceRun> run_device(Graph &gr, const std::vector<uint32_t> &roots, uint32_t run_flags) override {
     hspf_graph *g = static_cast<HipGraph &>(gr).g;
-    auto r = std::make_unique<HipDeviceRun>();
+    auto r = std::make_unique<HipDeviceRun>(pool_);
     r->n_roots = (uint32_t)roots.size(); r->n_vertices = hspf_graph_n_vertices(g);
     int rc = hspf_mask_words(ctx_, g, roots.data(), r->n_roots, &r->mask_words);
     if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_mask_words: ") + hspf_last_error(ctx_));
-    const size_t rn = (size_t)r->n_roots * r->n_vertices;
-    if (hipMalloc((void **)&r->dist, rn * 4) != hipSuccess || hipMalloc((void **)&r->hops, rn * 2) != hipSuccess ||
-        hipMalloc((void **)&r->flags, rn * 2) != hipSuccess || hipMalloc((void **)&r->mask, rn * 8 * r->mask_words) != hipSuccess)
-      throw std::runtime_error("hipMalloc of the run tables failed");
+    r->alloc();
     hspf_result out{r->dist, r->hops, r->flags, r->mask, r->mask_words, nullptr};
     rc = hspf_run_device(ctx_, g, roots.data(), r->n_roots, run_flags, &out);
     if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_run_device: ") + hspf_last_error(ctx_));
@@ -337,9 +411,8 @@ class HipEngine : public Engine {
     const size_t rp = (size_t)r.n_roots * P;
     o.best_metric.assign(rp, 0xFFFFFFFFu); o.best_entry.assign(rp, 0xFFFFFFFFu); o.nexthop_mask.assign(rp * r.mask_words, 0);
     if (P == 0) return o;
-    uint32_t *bm = nullptr, *be = nullptr; uint64_t *nm = nullptr;
-    if (hipMalloc((void **)&bm, rp * 4) != hipSuccess || hipMalloc((void **)&be, rp * 4) != hipSuccess || hipMalloc((void **)&nm, rp * 8 * r.mask_words) != hipSuccess)
-      throw std::runtime_error("hipMalloc of the route tables failed");
+    uint32_t *bm = (uint32_t *)pool_->dev(rp * 4), *be = (uint32_t *)pool_->dev(rp * 4);
+    uint64_t *nm = (uint64_t *)pool_->dev(rp * 8 * r.mask_words);
     static const uint32_t zero = 0;
     hspf_prefix_table tab{P, (uint32_t)pfx_vertex.size(), pfx_ptr.data(), pfx_vertex.empty() ? &zero : pfx_vertex.data(),
                           pfx_metric.empty() ? &zero : pfx_metric.data(), flags};
@@ -348,14 +421,14 @@ class HipEngine : public Engine {
     bool ok = rc == HSPF_OK && hipMemcpy(o.best_metric.data(), bm, rp * 4, hipMemcpyDeviceToHost) == hipSuccess &&
               hipMemcpy(o.best_entry.data(), be, rp * 4, hipMemcpyDeviceToHost) == hipSuccess &&
               hipMemcpy(o.nexthop_mask.data(), nm, rp * 8 * r.mask_words, hipMemcpyDeviceToHost) == hipSuccess;
-    (void)hipFree(bm); (void)hipFree(be); (void)hipFree(nm);
+    pool_->dev_free(bm, rp * 4); pool_->dev_free(be, rp * 4); pool_->dev_free(nm, rp * 8 * r.mask_words);
     if (!ok) throw std::runtime_error(std::string("hspf_routes_device: ") + hspf_last_error(ctx_));
     return o;
   }
   std::unique_ptr<DeviceRoutes> routes_device(DeviceRun &run, const std::vector<uint32_t> &pfx_ptr, const std::vector<uint32_t> &pfx_vertex,
                                               const std::vector<uint32_t> &pfx_metric, uint32_t flags) override {
     auto &r = static_cast<HipDeviceRun &>(run);
-    auto o = std::make_unique<HipDeviceRoutes>();
+    auto o = std::make_unique<HipDeviceRoutes>(pool_);
     o->n_roots = r.n_roots; o->n_prefixes = (uint32_t)pfx_ptr.size() - 1; o->mask_words = r.mask_words;
     if (!o->alloc()) throw std::runtime_error("hipMalloc of the route tables failed");
     if (o->n_prefixes == 0) return o;
@@ -368,7 +441,7 @@ class HipEngine : public Engine {
     return o;
   }
   std::unique_ptr<DeviceRoutes> routes_upload(const RoutesOut &t, uint32_t n_roots, uint32_t n_prefixes, uint32_t mask_words) override {
-    auto o = std::make_unique<HipDeviceRoutes>();
+    auto o = std::make_unique<HipDeviceRoutes>(pool_);
     o->n_roots = n_roots; o->n_prefixes = n_prefixes; o->mask_words = mask_words;
     const size_t rp = (size_t)n_roots * n_prefixes;
     if (t.best_metric.size() != rp || t.best_entry.size() != rp || t.nexthop_mask.size() != rp * mask_words) throw std::runtime_error("routes_upload: table sizes");
@@ -379,9 +452,9 @@ class HipEngine : public Engine {
     return o;
   }
   std::unique_ptr<DeviceRoutes> rib_new(uint32_t n_prefixes, uint32_t mask_words) override {
-    auto o = std::make_unique<HipDeviceRoutes>();
+    auto o = std::make_unique<HipDeviceRoutes>(pool_);
     o->n_roots = 1; o->n_prefixes = n_prefixes; o->mask_words = mask_words;
-    if (!o->alloc() || hipMalloc((void **)&o->org, std::max<size_t>(n_prefixes, 1) * 4) != hipSuccess) throw std::runtime_error("hipMalloc of the RIB state failed");
+    o->alloc(); o->alloc_origin();
     const hspf_rib_device rib{n_prefixes, mask_words, o->bm, o->be, o->nm, o->org};
     const int rc = hspf_rib_clear_device(ctx_, &rib);
     if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_rib_clear_device: ") + hspf_last_error(ctx_));
@@ -453,6 +526,7 @@ class HipEngine : public Engine {
   hspf_ctx *ctx_ = nullptr;
   void *pin_ = nullptr;
   size_t pin_cap_ = 0;
+  std::shared_ptr<HipPool> pool_ = std::make_shared<HipPool>();      // (shared with the run / route objects: they may outlive the engine)
 };
 
 }  // namespace host

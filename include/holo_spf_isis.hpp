@@ -1032,11 +1032,13 @@ class RibPipeline {
     {
       // first-hop slots -> next hops, every step: which relaxations the root makes, and in which order resolve_nexthop hands
       // out adjacencies, depends on distances elsewhere in the graph (spf.rs:680-701), not only on the root's own rows
-      auto res = std::make_shared<Tables>(run->host_tables());
-      detail::RunView r{res->dist.data(), res->hops.data(), res->flags.data(), res->mask.data(), res->mask_words};
+      // (a view into page-locked memory the run keeps: the replay reads the root's two-hop neighbourhood, not 100 000 rows;
+      // the masks are not needed here and stay on the device)
+      const TablesView res = run->host_view(false);
+      detail::RunView r{res.dist, res.hops, res.flags, res.mask, res.mask_words};
       std::function<RankKey(uint32_t)> rank = [r](uint32_t v) { return RankKey{r.dist[v], v, 0, 0}; };
       bool exact = false;
-      for (uint32_t v = 0; v < graph_->n(); ++v) exact |= (res->flags[v] & HSPF_RF_EXACT) != 0;
+      for (uint32_t v = 0; v < graph_->n(); ++v) exact |= (res.flags[v] & HSPF_RF_EXACT) != 0;
       std::shared_ptr<Tables> rr;
       if (exact) { rr = std::make_shared<Tables>(engine_.run(dev, {root}, graph_->run_flags | HSPF_RUN_POP_RANK)); rank = [rr](uint32_t v) { return RankKey{rr->pop_rank[v], 0, 0, 0}; }; }
       auto nh = detail::slot_nexthops(*graph_, engine_.slot_table(dev, root), r, rank, true, level_, inst);
