@@ -504,7 +504,8 @@ pub(crate) fn update_rib(
             let fresh = eng.routes_device(&run, &pipe.table, pipe.resident).map_err(|e| e.log()).ok()?;
             pipe.resident = true;
             // first-hop slots -> next hops, every event (which relaxations the root makes depends on distances elsewhere)
-            let t = run.to_host().map_err(|e| e.log()).ok()?;
+            // (distance / hops / flags only: the replay reads the root's two-hop neighbourhood, the masks stay on the device)
+            let t = run.to_host_without_masks().map_err(|e| e.log()).ok()?;
             let exact = if (0..t.n_vertices).any(|v| t.exact(0, v)) { Some(eng.pop_ranks(graph, &[root], 0).map_err(|e| e.log()).ok()?) } else { None };
             let key = |v: u32| rank_key(csr, &t, 0, v, false, exact.as_deref());
             let slot_table = graph.slot_table(root).map_err(|e| e.log()).ok()?;
