@@ -1,5 +1,6 @@
 """profiles/traffic.json (the PMC traffic bench.py quotes in its roofline block) must come from the binary that is
-committed: it records the git revision it was measured at, and nothing under holo_amd/csrc or include/ may have
+committed: it records the git revision it was measured at, and nothing the library is built from — holo_amd/csrc and the C ABI
+header include/holo_spf_hip.h (the C++ host twins under include/ are header-only callers, not part of the binary) — may have
 changed since."""
 import json
 import os
@@ -21,7 +22,7 @@ def test_traffic_json_was_measured_on_the_committed_kernels():
     assert rev and rev != "unknown", "profiles/traffic.json has no git_rev: regenerate with GIT_REV=$(git rev-parse --short HEAD) bash tools/gpu_profile.sh <tag>"
     assert _git("cat-file", "-e", rev + "^{commit}").returncode == 0, rev
     assert _git("merge-base", "--is-ancestor", rev, "HEAD").returncode == 0, rev
-    changed = _git("diff", "--name-only", rev, "HEAD", "--", "holo_amd/csrc", "include").stdout.split()
+    changed = _git("diff", "--name-only", rev, "HEAD", "--", "holo_amd/csrc", "include/holo_spf_hip.h").stdout.split()
     assert not changed, f"kernel sources changed since profiles/traffic.json was measured at {rev}: {changed}"
     ps = t["per_step"]
     assert ps["hbm_bytes"] > 0 and "k_fused_lean" in ps["kernels"] and "k_emit_fused" in ps["kernels"]
