@@ -1880,7 +1880,9 @@ int Run::lv_run() {
       if (er != hipSuccess) { ctx->last_error = std::string("lv init: ") + hipGetErrorString(er); return HSPF_E_HIP; }
       hipLaunchKernelGGL(k_init_lv, dim3((n_roots + 63) / 64), dim3(64), 0, s, gd, d_st, a_stamp, d_roots, n_roots);
       LvArgs la{d_changed, 0, n, a_stamp, d_st, d_roots, gd.in_ptr, gd.rowflags, gd.vflags,
-                gd, tabs, d_kcnt, fp_wide, net_nh, ignore_ovl, n_roots, count_rows ? 1u : 0u, d_lf};
+                gd, tabs, d_kcnt, fp_wide, net_nh, ignore_ovl, n_roots, count_rows ? 1u : 0u, d_lf,
+                (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (const uint32_t *)g->d_ell_od,
+                (ctx->variant & (1u << 26)) ? 0u : (ctx->variant & (1u << 25)) ? 1u : 2u};
       const bool mi = g->max_path_metric == HSPF_DIST_INF;
       const dim3 lgrid((n + 255) / 256, n_roots);
       uint32_t n_f = 0;

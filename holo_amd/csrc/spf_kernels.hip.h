@@ -1745,6 +1745,8 @@ struct LvArgs {
   FusedParams P;               // the 8-byte state's parameters (sh = 0)
   uint32_t net_nexthops, ignore_ovl, n_roots, count_rows;
   uint32_t *lane_flags;
+  const uint32_t *ell_so, *ell_w, *ell_od;   // the fixed-stride copy of the rows with at most 16 in-links / out-links (kb_ell)
+  uint32_t ell_mode;                  // 2: records and wake-up offsets from it, 1: records only, 0: not used (HSPF_VARIANT bits 25 / 26: A/B)
   __device__ __forceinline__ const SlotTabs &slot_tabs() const { return tabs; }
 };
 
@@ -1754,29 +1756,87 @@ struct LvArgs {
 // source row is only fetched for links out of a hops-0 parent (the root's neighbours).
 constexpr uint32_t LV_PF = 16;
 
+// Round 5: the link records of the rows with at most 16 in-links come from the fixed-stride (ELL) copy the lean sweep
+// uses, fetched by the WAVE — 64 rows x 64 bytes per array as four 16-byte-per-lane loads, handed to their threads through
+// LDS — instead of 32 loads per thread that each touch 64 different cache lines (a thread's records are consecutive, a
+// wave's are 64 rows apart): a mid-run sweep on isis-100k made ~2 M cache-line requests, 1.4 M of them for records, and
+// took 14 us for it; the gathers of the sources' words stay as they are.  The row's out-neighbours (their stamp offsets,
+// `ell_od`) come the same way: a changed vertex wakes them up without the two dependent round trips through out_ptr / out_dst.  Rows that need the rare-case routine (an
+// overloaded source, a zero-cost link from a higher-numbered source, hop-count graphs) or have more than 16 in-links keep
+// the walk over in_src / in_w.
+constexpr uint32_t LV_ROW_WORDS = 20;             // LDS stride of a staged 16-word record row: 80 bytes (16-byte aligned, off the bank period)
+
 template <bool MAXINF>
 __global__ __launch_bounds__(256) void k_lv(LvArgs a) {
   if (a.sweep > 0 && a.changed[a.sweep - 1] == 0) return;
+  __shared__ uint32_t s_rec[4][3][64 * LV_ROW_WORDS];
   const GraphDev &g = a.g;
   const uint32_t n = a.n;
   const uint32_t root_slot = blockIdx.y;
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
-  if (v >= n) return;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t cur = (uint32_t)a.sweep + 2u;
   uint32_t *A = a.act + (size_t)root_slot * n;
   uint64_t *S = a.st + (size_t)root_slot * n;
   const uint32_t my_root = a.roots[root_slot];
-  const uint32_t av = A[v];
-  const uint32_t e0 = a.in_ptr[v], e1 = a.in_ptr[v + 1];
-  const uint32_t rf = a.rowflags[v], vf = a.vflags[v];
-  const uint64_t old = S[v];
-  if (my_root == INF || av < cur || v == my_root) return;          // nothing changed around this vertex
+  const uint32_t vc = min(v, n - 1u);              // (lanes past the last vertex ride along for the wave's loads)
+  const uint32_t av = A[vc];
+  const uint32_t e0 = a.in_ptr[vc], e1 = a.in_ptr[vc + 1];
+  const uint32_t rf = a.rowflags[vc], vf = a.vflags[vc];
+  const uint64_t old = S[vc];
+  const bool due = v < n && my_root != INF && av >= cur && v != my_root;   // else: nothing changed around this vertex
+  if (!__any(due ? 1 : 0)) return;
   const FusedParams P = a.P;
   const uint32_t mmask = (1u << P.mbits) - 1u;
   const bool rare = P.hc != 0u || (!a.ignore_ovl && (rf & RF_NT)) || (rf & RF_ZERO);
+  const bool ell = due && !rare && !(rf & RF_MANY) && a.ell_mode != 0u;
+  if (__any(ell ? 1 : 0)) {                        // the wave's 64 record rows, 1 KB per load instruction
+    const uint32_t v_w = blockIdx.x * 256u + wave * 64u;
+    const uint4 *eso = (const uint4 *)a.ell_so, *ew = (const uint4 *)a.ell_w, *eod = (const uint4 *)a.ell_od;
+    uint4 qa[4], qb[4], qc[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      const uint32_t row = min(v_w + (lane >> 2) + 16u * i, n);               // row n of the copy is all pad
+      qa[i] = eso[(size_t)row * 4u + (lane & 3u)];
+      qb[i] = ew[(size_t)row * 4u + (lane & 3u)];
+      qc[i] = eod[(size_t)row * 4u + (lane & 3u)];                             // the out-neighbours' stamp offsets: the wake-up below
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+      const uint32_t o = ((lane >> 2) + 16u * i) * LV_ROW_WORDS + (lane & 3u) * 4u;
+      *(uint4 *)&s_rec[wave][0][o] = qa[i];
+      *(uint4 *)&s_rec[wave][1][o] = qb[i];
+      *(uint4 *)&s_rec[wave][2][o] = qc[i];
+    }
+  }
+  if (!due) return;
   const uint32_t v_router = (vf & 1u) ? 0u : 1u;
   RowAcc r{INF, 0u, INF, 0u, false};
   uint32_t bd_all = INF, zb = INF, zm = 0u, zh = 0u;
+  bool od_row = false;                             // the row's out-links are all in its staged record (at most 16 of them)
+  if (ell) {
+    uint32_t rs[LV_PF], rw[LV_PF];
+    uint64_t qs[LV_PF];
+    static_assert(LV_PF == 16, "one ELL row");
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint4 x = *(const uint4 *)&s_rec[wave][0][lane * LV_ROW_WORDS + 4u * k];
+      const uint4 y = *(const uint4 *)&s_rec[wave][1][lane * LV_ROW_WORDS + 4u * k];
+      rs[4 * k] = x.x; rs[4 * k + 1] = x.y; rs[4 * k + 2] = x.z; rs[4 * k + 3] = x.w;
+      rw[4 * k] = y.x; rw[4 * k + 1] = y.y; rw[4 * k + 2] = y.z; rw[4 * k + 3] = y.w;
+    }
+    const uint32_t deg = e1 - e0;                                             // (<= 16: not RF_MANY)
+    od_row = !(rs[0] & 0x20u) && a.ell_mode == 2u;                                                // entry 0's low byte: in-degree | (more than 16 out-links) << 5 | network << 7
+#pragma unroll
+    for (uint32_t k = 0; k < LV_PF; ++k) { rs[k] = k < deg ? rs[k] >> 8 : v; qs[k] = S[rs[k]]; }   // entry = source << 8 (| row info in entry 0)
+#pragma unroll
+    for (uint32_t k = 0; k < LV_PF; ++k) {
+      if (k < deg) {
+        const uint32_t *fp = g.in_fpos + (e0 + k);
+        single_link<MAXINF, false>(r, bd_all, zb, zm, zh, rs[k], rw[k], [fp]() { return *fp; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
+      }
+    }
+  } else
   for (uint32_t eb = e0; eb < e1; eb += LV_PF) {
     uint32_t rs[LV_PF], rw[LV_PF];
     uint64_t qs[LV_PF];
@@ -1803,7 +1863,17 @@ __global__ __launch_bounds__(256) void k_lv(LvArgs a) {
   if (o.nw != old) {
     S[v] = o.nw;
     a.changed[a.sweep] = 1;
-    for (uint32_t k = g.out_ptr[v], k1 = g.out_ptr[v + 1]; k < k1; ++k) A[g.out_dst[k]] = cur + 1u;   // wake the out-neighbours up
+    if (od_row) {                                  // wake the out-neighbours up: their stamp offsets came with the record row
+#pragma unroll
+      for (uint32_t k = 0; k < 4; ++k) {
+        const uint4 x = *(const uint4 *)&s_rec[wave][2][lane * LV_ROW_WORDS + 4u * k];
+        if (x.x != 0xFFFFFFFFu) A[x.x >> 2] = cur + 1u;
+        if (x.y != 0xFFFFFFFFu) A[x.y >> 2] = cur + 1u;
+        if (x.z != 0xFFFFFFFFu) A[x.z >> 2] = cur + 1u;
+        if (x.w != 0xFFFFFFFFu) A[x.w >> 2] = cur + 1u;
+      }
+    } else
+    for (uint32_t k = g.out_ptr[v], k1 = g.out_ptr[v + 1]; k < k1; ++k) A[g.out_dst[k]] = cur + 1u;
   }
   if (a.count_rows) atomicAdd(&a.rows_done[(blockIdx.x + threadIdx.x) & 127u], 1u);
   uint32_t lf = 0;
