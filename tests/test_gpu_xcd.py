@@ -157,3 +157,33 @@ def test_two_instances_at_once_stay_correct():
     assert out[0][0] == 150 and out[1][0] == 150, out
     print("k_xcd runs of the two instances:", out)
     assert out[0][1] >= 140 and out[1][1] >= 140, out                 # (a context that gave up once stops using the kernel: far fewer)
+
+
+def test_tickets_in_flight_through_k_xcd():
+    """Several one- to eight-root runs of one instance in flight (hspf_run_device_async: the lanes are private contexts on
+    their own streams and host threads): every lane's k_xcd launch takes its own XCDs' worth of workgroups next to the
+    others', every table is right; then the same tickets again (the graph has tried both kernels by then and chosen)."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = synth.ospf_10k()
+    ctx = _ctx(HSPF_ASYNC_LANES=3)
+    G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    sets = [np.asarray([17 * k + 3], np.uint32) if k % 2 else (np.arange(1 + k, dtype=np.uint32) * 997 + k) for k in range(6)]
+    refs = [go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, r, 1, go.MAP, mask_words_=1) for r in sets]
+    tabs = [dict(dist=torch.zeros((len(r), g.n), dtype=torch.int32, device=dev), hops=torch.zeros((len(r), g.n), dtype=torch.int16, device=dev),
+                 flags=torch.zeros((len(r), g.n), dtype=torch.int16, device=dev), mask=torch.zeros((len(r), g.n, 1), dtype=torch.int64, device=dev)) for r in sets]
+    for rnd in range(4):
+        for t in tabs:
+            for x in t.values():
+                x.zero_()
+        tickets = [ctx.run_device_async(G, r, 1, dist_ptr=t["dist"].data_ptr(), hops_ptr=t["hops"].data_ptr(), flags_ptr=t["flags"].data_ptr(),
+                                        mask_ptr=t["mask"].data_ptr(), mask_words=1) for r, t in zip(sets, tabs)]
+        for tk in tickets:
+            ctx.wait(tk)
+        for t, ref in zip(tabs, refs):
+            assert np.array_equal(t["dist"].cpu().numpy().view(np.uint32), ref.dist), rnd
+            assert np.array_equal(t["hops"].cpu().numpy().view(np.uint16), ref.hops), rnd
+            assert np.array_equal(t["flags"].cpu().numpy().view(np.uint16) & 1, ref.flags), rnd
+            assert np.array_equal(t["mask"].cpu().numpy().view(np.uint64), ref.mask), rnd
+    G.free()
+    ctx.close()
