@@ -736,10 +736,13 @@ def other_configs(ctx, dev) -> dict:
         d = torch.empty((R, n), dtype=torch.int32, device=dev); h = torch.empty((R, n), dtype=torch.int16, device=dev)
         f = torch.empty((R, n), dtype=torch.int16, device=dev); m = torch.empty((R, n, W), dtype=torch.int64, device=dev)
         ms = []
-        for _ in range(7):
+        # (up to eight roots the graph first tries both kernels — k_xcd twice, the other one three times — and then runs the
+        # faster one: the median is taken over runs after that)
+        for _ in range(14 if len(roots) <= 8 else 7):
             st = ctx.run_device(G, roots, fl, dist_ptr=d.data_ptr(), hops_ptr=h.data_ptr(), flags_ptr=f.data_ptr(),
                                 mask_ptr=m.data_ptr(), mask_words=W)
             ms.append(st["ms_total"])
+        ms = ms[-7:]
         ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, fl, go.HEAP, mask_words_=W, threads=thr)
         ok = bool(np.array_equal(d.cpu().numpy().view(np.uint32), ref.dist) and np.array_equal(h.cpu().numpy().view(np.uint16), ref.hops)
                   and np.array_equal(f.cpu().numpy().view(np.uint16) & 1, ref.flags) and np.array_equal(m.cpu().numpy().view(np.uint64), ref.mask))
@@ -749,7 +752,7 @@ def other_configs(ctx, dev) -> dict:
 
     out = {}
     g10 = synth.ospf_10k()
-    for R in (64, 1024):
+    for R in (8, 64, 1024):
         roots = ((np.arange(R, dtype=np.int64) * g10.n) // R).astype(np.uint32)
         ms, st, W, ok = one(g10, roots, E.RUN_NET_NEXTHOPS)
         rps = R / (ms * 1e-3)
