@@ -1919,11 +1919,13 @@ __global__ __launch_bounds__(256) void k_emit_lv(uint32_t n, const uint64_t *__r
 //     placement, MI355X_MICROARCH.md — which XCD that is depends on where the previous dispatch stopped; never relied on
 //     for correctness: see "bounded" below; every workgroup reports its HW_REG_XCC_ID and the host notes a root whose
 //     workgroups did not share one); root r of the run takes the class (xcd0 + r) % 8, one workgroup per CU, each
-//     owning a contiguous range of `vw` vertices, one vertex per thread;
+//     owning a contiguous range of `vw` vertices, one vertex per thread (and n / 16 threads at least: the re-read below
+//     is one batch of loads per thread then);
 //   * every workgroup keeps ALL n words of its root ([dist32 | hops | mask], the k_single / k_lv word) in LDS: a
-//     neighbour's word is an LDS read, never a round trip to the L2.  A plain vertex (k_single's definition) keeps its
-//     link records in registers for the whole run; the others walk their records in global memory with the general
-//     row routine (single_link / finish_row: same fixed point, same exactness flags as every other kernel);
+//     neighbour's word is an LDS read, never a round trip to the L2.  A vertex of at most XCD_RL links keeps its link
+//     records in registers for the whole run — a plain one (k_single's definition) for the two-pass routine, the others
+//     raw for the general row routine (single_link / finish_row: same fixed point, same exactness flags as every other
+//     kernel); longer rows walk their records in global memory;
 //   * a sweep = evaluate the own vertices from the replica, store what changed to the replica AND to the root's array in
 //     global memory (plain stores: the lines stay in this XCD's L2), then a barrier among the workgroups of the XCD made
 //     of plain flag stores and sc1 polling loads (L1 bypassed, L2 served: 0.55 us for up to 64 workgroups,
