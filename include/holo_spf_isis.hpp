@@ -60,6 +60,20 @@ struct VertexId {                     // holo-isis/src/spf.rs:96-100: derive(Ord
 inline VertexId vertex_id(const LanId &l) { return VertexId{l.pseudonode == 0, l}; }
 
 // ---- the fields of Lsp / LspTlvs / Interface / Adjacency the path reads -----------------------------------------
+// Segment routing (compute_routes' Prefix-SID step, holo-isis/src/spf.rs:931-946 -> sr.rs:34-94, 165-300): the SR-Capabilities
+// and SR-Algorithm sub-TLVs of a router, the Prefix-SID sub-TLV of a reachability entry.
+struct PrefixSid {
+  std::vector<std::string> flags;          // "P", "E", "V", "L", ...
+  std::optional<uint32_t> index, label;    // one of them (the V / L flags say which the LSP carried)
+  bool has(const char *f) const { return std::find(flags.begin(), flags.end(), f) != flags.end(); }
+  bool operator==(const PrefixSid &o) const { return flags == o.flags && index == o.index && label == o.label; }
+};
+struct SrCap {
+  std::vector<std::string> flags;          // "I" (MPLS IPv4), "V" (MPLS IPv6)
+  std::vector<std::pair<uint32_t, uint32_t>> srgb;   // (first label, range)
+  bool has(const char *f) const { return std::find(flags.begin(), flags.end(), f) != flags.end(); }
+  bool operator==(const SrCap &o) const { return flags == o.flags && srgb == o.srgb; }
+};
 struct Lsp {
   SystemId system_id{};
   uint8_t pseudonode = 0, fragment = 0;
@@ -73,6 +87,15 @@ struct Lsp {
   std::vector<std::pair<std::string, uint32_t>> ipv4_internal, ipv4_external;  // TLV 128, 130
   std::vector<std::tuple<std::string, uint32_t, bool>> ext_ipv4, ipv6;         // TLV 135 (+X), 236
   std::vector<std::tuple<int, std::string, uint32_t, bool>> mt_ipv6;           // TLV 237
+  std::optional<SrCap> sr_cap;
+  std::vector<int> sr_algos;                                                   // 0 = SPF
+  std::map<std::string, std::map<int, PrefixSid>> prefix_sids;                 // "ext_ipv4" | "ipv6" | "mt_ipv6" -> entry index -> SID
+  const PrefixSid *prefix_sid(const char *kind, int i) const {
+    auto k = prefix_sids.find(kind);
+    if (k == prefix_sids.end()) return nullptr;
+    auto it = k->second.find(i);
+    return it == k->second.end() ? nullptr : &it->second;
+  }
   LanId lan_id() const { return LanId{system_id, pseudonode}; }
   bool live() const { return seqno != 0 && rem_lifetime != 0; }               // spf.rs:1024-1025
   bool overload_bit(int mt) const { auto it = mt_flags.find(mt); return mt == MT_STANDARD ? overload : (it != mt_flags.end() && it->second.first); }
@@ -81,7 +104,8 @@ struct Lsp {
     return system_id == o.system_id && pseudonode == o.pseudonode && fragment == o.fragment && seqno == o.seqno &&
            rem_lifetime == o.rem_lifetime && overload == o.overload && att == o.att && protocols_supported == o.protocols_supported &&
            mt_flags == o.mt_flags && is_reach == o.is_reach && ext_is_reach == o.ext_is_reach && mt_is_reach == o.mt_is_reach &&
-           ipv4_internal == o.ipv4_internal && ipv4_external == o.ipv4_external && ext_ipv4 == o.ext_ipv4 && ipv6 == o.ipv6 && mt_ipv6 == o.mt_ipv6;
+           ipv4_internal == o.ipv4_internal && ipv4_external == o.ipv4_external && ext_ipv4 == o.ext_ipv4 && ipv6 == o.ipv6 && mt_ipv6 == o.mt_ipv6 &&
+           sr_cap == o.sr_cap && sr_algos == o.sr_algos && prefix_sids == o.prefix_sids;
   }
 };
 struct Adjacency {
@@ -104,6 +128,7 @@ struct InstanceCfg {
   std::string level_type = "level-all";
   std::map<int, std::string> metric_type{{1, "wide"}, {2, "wide"}};
   bool ipv4_enabled = true, ipv6_enabled = true, mt_ipv6_unicast = false, att_ignore = false;
+  bool sr_enabled = false;
   uint32_t max_paths = 16;
   std::vector<std::string> area_addrs;
   bool is_af_enabled(bool v6) const { return v6 ? ipv6_enabled : ipv4_enabled; }
@@ -125,6 +150,11 @@ class Lsdb {                           // LSPs of one level ordered by LSP id (h
       if (!(std::get<0>(it->first) == lan.system_id) || std::get<1>(it->first) != lan.pseudonode) break;
       out.push_back(&it->second);
     }
+    return out;
+  }
+  std::vector<const Lsp *> iter_for_system_id(const SystemId &sid) const {      // every LSP of a system, pseudonodes included, in LSP-id order
+    std::vector<const Lsp *> out;
+    for (auto it = by_id_.lower_bound(Key{sid, 0, 0}); it != by_id_.end() && std::get<0>(it->first) == sid; ++it) out.push_back(&it->second);
     return out;
   }
   const Lsp *zeroth_lsp(const LanId &lan) const {                              // spf.rs:1299-1309
@@ -572,15 +602,17 @@ inline Spt compute_spt(int level, const SystemId &root, bool local, std::optiona
 }
 
 // ---- routes --------------------------------------------------------------------------------------------------------
-struct Nexthop { std::string addr, iface_name; SystemId system_id{}; };
+struct Nexthop { std::string addr, iface_name; SystemId system_id{}; std::optional<uint32_t> label; };   // label: SR output label
 struct Route {                         // holo-isis/src/route.rs:27-37
   std::string prefix;
   uint32_t metric = 0;
   int level = 0;
   bool external = false, connected = false;
   std::map<IpKey, Nexthop> nexthops;   // BTreeMap<IpAddr, Nexthop>: ECMP order = ascending address
+  std::optional<PrefixSid> prefix_sid; // of the network the route was CREATED from (route.rs:78-103)
+  std::optional<uint32_t> sr_label;    // SR input label
 };
-struct Network { std::string prefix; uint32_t metric; bool external; };
+struct Network { std::string prefix; uint32_t metric; bool external; std::optional<PrefixSid> sid; };
 
 // holo-isis/src/spf.rs:1149-1296
 inline std::vector<Network> vertex_networks(const Instance &inst, int level, int mt_id, const LanId &lan, bool att_bit,
@@ -602,17 +634,31 @@ inline std::vector<Network> vertex_networks(const Instance &inst, int level, int
         for (auto &p : lsp->ipv4_internal) out.push_back({p.first, p.second, false});
         for (auto &p : lsp->ipv4_external) out.push_back({p.first, p.second, true});
       }
+      auto sid_of = [&](const char *kind, size_t i) -> std::optional<PrefixSid> {
+        const PrefixSid *q = lsp->prefix_sid(kind, (int)i);
+        return q ? std::optional<PrefixSid>(*q) : std::nullopt;
+      };
       if (wide_on)
-        for (auto &p : lsp->ext_ipv4)
-          if (std::get<1>(p) <= MAX_PATH_METRIC_WIDE) out.push_back({std::get<0>(p), std::get<1>(p), std::get<2>(p)});
+        for (size_t i = 0; i < lsp->ext_ipv4.size(); ++i) {
+          auto &p = lsp->ext_ipv4[i];
+          if (std::get<1>(p) <= MAX_PATH_METRIC_WIDE) out.push_back({std::get<0>(p), std::get<1>(p), std::get<2>(p), sid_of("ext_ipv4", i)});
+        }
     }
     if (ipv6_enabled) {
+      auto sid_of = [&](const char *kind, size_t i) -> std::optional<PrefixSid> {
+        const PrefixSid *q = lsp->prefix_sid(kind, (int)i);
+        return q ? std::optional<PrefixSid>(*q) : std::nullopt;
+      };
       if (mt_id == MT_IPV6_UNICAST) {
-        for (auto &p : lsp->mt_ipv6)
-          if (std::get<0>(p) == MT_IPV6_UNICAST && std::get<2>(p) <= MAX_PATH_METRIC_WIDE) out.push_back({std::get<1>(p), std::get<2>(p), std::get<3>(p)});
+        for (size_t i = 0; i < lsp->mt_ipv6.size(); ++i) {
+          auto &p = lsp->mt_ipv6[i];
+          if (std::get<0>(p) == MT_IPV6_UNICAST && std::get<2>(p) <= MAX_PATH_METRIC_WIDE) out.push_back({std::get<1>(p), std::get<2>(p), std::get<3>(p), sid_of("mt_ipv6", i)});
+        }
       } else {
-        for (auto &p : lsp->ipv6)
-          if (std::get<1>(p) <= MAX_PATH_METRIC_WIDE) out.push_back({std::get<0>(p), std::get<1>(p), std::get<2>(p)});
+        for (size_t i = 0; i < lsp->ipv6.size(); ++i) {
+          auto &p = lsp->ipv6[i];
+          if (std::get<1>(p) <= MAX_PATH_METRIC_WIDE) out.push_back({std::get<0>(p), std::get<1>(p), std::get<2>(p), sid_of("ipv6", i)});
+        }
       }
     }
   }
@@ -627,6 +673,60 @@ inline std::map<IpKey, Nexthop> build_nexthops(const Vertex &v, const std::strin
     if (addr) out[parse_ip(*addr)] = Nexthop{*addr, nh->iface_name.value_or(""), nh->system_id};
   }
   return out;
+}
+
+// ---- SR Prefix-SID bookkeeping of compute_routes (holo-isis/src/spf.rs:931-946, sr.rs:34-94, 165-300) ------------------
+// The SPT feeds it two bits per route update: local = (vertex.hops == 0), last_hop = (vertex.hops == 1); the rest is label
+// arithmetic over the LSDB's SR-Capabilities.  No conformance fixture of the reference has `sr.enabled`: this step is
+// checked against the literal restatement (oracle/isis_ref.py) on random instances, as the Python twin is (parity unpinned).
+constexpr uint32_t LABEL_EXPLICIT_NULL_V4 = 0, LABEL_EXPLICIT_NULL_V6 = 2, LABEL_IMPLICIT_NULL = 3;
+inline const SrCap *sr_cap_of(const Lsdb &lsdb, const SystemId &system_id) {
+  for (const Lsp *lsp : lsdb.iter_for_system_id(system_id))
+    if (lsp->live() && lsp->sr_cap) return &*lsp->sr_cap;
+  return nullptr;
+}
+inline std::optional<uint32_t> sr_index_to_label(uint32_t index, const std::vector<std::pair<uint32_t, uint32_t>> &srgbs) {   // sr.rs:270-300
+  for (auto &r : srgbs) {
+    if (index >= r.second) { index -= r.second; continue; }
+    return r.first + index;
+  }
+  return std::nullopt;
+}
+inline void prefix_sid_update(const Instance &inst, int level, const LanId &adv_rtr, const std::string &prefix, Route &route, bool local, bool last_hop) {
+  if (!route.prefix_sid) return;
+  const PrefixSid &sid = *route.prefix_sid;
+  auto li = inst.lsdb.find(level);
+  if (li == inst.lsdb.end()) return;
+  const Lsdb &lsdb = li->second;
+  bool spf_algo = false;
+  for (const Lsp *lsp : lsdb.iter_for_lan_id(adv_rtr))
+    spf_algo = spf_algo || (lsp->live() && std::find(lsp->sr_algos.begin(), lsp->sr_algos.end(), 0) != lsp->sr_algos.end());
+  if (!spf_algo) return;
+  const bool v6 = prefix.find(':') != std::string::npos;
+  // input label (sr.rs:165-205)
+  if (local && (!sid.has("P") || sid.has("E"))) route.sr_label.reset();
+  else if (sid.index) {
+    const SrCap *cap = sr_cap_of(lsdb, inst.config.system_id);
+    const auto label = cap ? sr_index_to_label(*sid.index, cap->srgb) : std::nullopt;
+    if (label) route.sr_label = *label;
+  } else route.sr_label = sid.label;
+  // output labels (sr.rs:208-267)
+  for (auto &kv : route.nexthops) {
+    Nexthop &nh = kv.second;
+    uint32_t label;
+    if (last_hop && !sid.has("P")) label = LABEL_IMPLICIT_NULL;
+    else {
+      const SrCap *cap = sr_cap_of(lsdb, nh.system_id);
+      if (!cap || !cap->has(v6 ? "V" : "I")) continue;
+      if (last_hop && sid.has("E")) label = v6 ? LABEL_EXPLICIT_NULL_V6 : LABEL_EXPLICIT_NULL_V4;
+      else if (sid.index) {
+        const auto l = sr_index_to_label(*sid.index, cap->srgb);
+        if (!l) continue;
+        label = *l;
+      } else label = last_hop ? *sid.label : LABEL_IMPLICIT_NULL;
+    }
+    nh.label = label;
+  }
 }
 
 // holo-isis/src/spf.rs:840-949
@@ -648,18 +748,23 @@ inline void compute_routes(int level, int mt_id, const Instance &inst, const Spt
       auto it = rib.find(key);
       Route *cur;
       if (it == rib.end() || route_metric < it->second.metric) {
-        rib[key] = Route{net.prefix, route_metric, level, net.external, vertex.hops == 0, build_nexthops(vertex, net.prefix)};
+        rib[key] = Route{net.prefix, route_metric, level, net.external, vertex.hops == 0, build_nexthops(vertex, net.prefix), net.sid, std::nullopt};
         cur = &rib[key];
       } else if (route_metric == it->second.metric) {
         cur = &it->second;
         for (auto &n : build_nexthops(vertex, net.prefix)) cur->nexthops[n.first] = n.second;
       } else continue;
       while (cur->nexthops.size() > cfg.max_paths) cur->nexthops.erase(std::prev(cur->nexthops.end()));   // first k by key
+      if (cfg.sr_enabled && cur->prefix_sid) prefix_sid_update(inst, level, vertex.id.lan_id, net.prefix, *cur, vertex.hops == 0, vertex.hops == 1);   // spf.rs:931-946
     }
   }
 }
 
-struct RibRow { std::string prefix; uint32_t metric; int level; std::vector<std::pair<std::string, std::string>> nexthops; };
+struct RibRow {
+  std::string prefix; uint32_t metric; int level; std::vector<std::pair<std::string, std::string>> nexthops;
+  bool sr = false;                                             // the SR columns only where SR is on
+  std::optional<uint32_t> sr_label; std::vector<std::optional<uint32_t>> nexthop_labels;
+};
 
 // LAN ids with an LSP fragment that differs between two LSDB snapshots (what the reference accumulates in `trigger_lsps`)
 inline std::vector<LanId> changed_lan_ids(const Lsdb &old_db, const Lsdb &new_db) {
@@ -713,6 +818,10 @@ inline std::vector<RibRow> compute_spf(const Instance &inst, Engine &engine, Gra
   for (auto &kv : merged) {
     RibRow r{kv.second.prefix, kv.second.metric, kv.second.level, {}};
     for (auto &n : kv.second.nexthops) r.nexthops.push_back({n.second.addr, n.second.iface_name});
+    if (cfg.sr_enabled) {
+      r.sr = true; r.sr_label = kv.second.sr_label;
+      for (auto &n : kv.second.nexthops) r.nexthop_labels.push_back(n.second.label);
+    }
     rows.push_back(std::move(r));
   }
   return rows;

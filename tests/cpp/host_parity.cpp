@@ -44,6 +44,7 @@ static I::Instance instance_from_vector(const J &vec) {
   inst.config.mt_ipv6_unicast = c["mt_ipv6_unicast"].b;
   inst.config.max_paths = (uint32_t)c["max_paths"].i();
   inst.config.att_ignore = c["att_ignore"].b;
+  inst.config.sr_enabled = c.has("sr_enabled") && c["sr_enabled"].b;
   for (auto &a : c["area_addrs"].arr) inst.config.area_addrs.push_back(a.s);
   for (auto &i : vec["interfaces"].arr) {
     I::Interface f;
@@ -83,6 +84,22 @@ static I::Instance instance_from_vector(const J &vec) {
       for (auto &x : l["ext_ipv4"].arr) p.ext_ipv4.push_back({x[0].s, (uint32_t)x[1].i(), x[2].b});
       for (auto &x : l["ipv6"].arr) p.ipv6.push_back({x[0].s, (uint32_t)x[1].i(), x[2].b});
       for (auto &x : l["mt_ipv6"].arr) p.mt_ipv6.push_back({(int)x[0].i(), x[1].s, (uint32_t)x[2].i(), x[3].b});
+      if (l.has("sr_cap") && !l["sr_cap"].is_null()) {               // segment routing (tests/_random_isis.py add_sr)
+        I::SrCap cap;
+        for (auto &f : l["sr_cap"]["flags"].arr) cap.flags.push_back(f.s);
+        for (auto &r : l["sr_cap"]["srgb"].arr) cap.srgb.push_back({(uint32_t)r[0].i(), (uint32_t)r[1].i()});
+        p.sr_cap = std::move(cap);
+      }
+      if (l.has("sr_algos")) for (auto &x : l["sr_algos"].arr) p.sr_algos.push_back((int)x.i());
+      if (l.has("prefix_sids"))
+        for (auto &kind : l["prefix_sids"].obj)
+          for (auto &e : kind.second.obj) {
+            I::PrefixSid sid;
+            for (auto &f : e.second["flags"].arr) sid.flags.push_back(f.s);
+            if (e.second.has("index")) sid.index = (uint32_t)e.second["index"].i();
+            if (e.second.has("label")) sid.label = (uint32_t)e.second["label"].i();
+            p.prefix_sids[kind.first][std::stoi(e.first)] = std::move(sid);
+          }
       db.insert(std::move(p));
     }
     inst.lsdb[std::stoi(lv.first)] = std::move(db);
@@ -193,6 +210,12 @@ static bool rows_equal(const std::vector<I::RibRow> &rows, const J &rib) {
         w["nexthops"].arr.size() != rows[i].nexthops.size()) return false;
     for (size_t k = 0; k < rows[i].nexthops.size(); ++k)
       if (w["nexthops"][k][0].s != rows[i].nexthops[k].first || w["nexthops"][k][1].s != rows[i].nexthops[k].second) return false;
+    if (w.has("sr_label") != rows[i].sr) return false;                // the SR columns (instances with sr_enabled)
+    if (rows[i].sr) {
+      auto same = [](const J &j, const std::optional<uint32_t> &v) { return j.is_null() ? !v : (v && (uint32_t)j.i() == *v); };
+      if (!same(w["sr_label"], rows[i].sr_label) || w["nexthop_labels"].arr.size() != rows[i].nexthop_labels.size()) return false;
+      for (size_t k = 0; k < rows[i].nexthop_labels.size(); ++k) if (!same(w["nexthop_labels"][k], rows[i].nexthop_labels[k])) return false;
+    }
   }
   return true;
 }
@@ -501,7 +524,8 @@ int main(int argc, char **argv) {
       if (vec.has("manet")) { const int mb = check_manet(vec, inst, *eng, path); manet_cases += (int)vec["manet"].size(); manet_bad += mb; }
       const auto rows = I::compute_spf(inst, *eng);
       // the same RIB with the prefix attachment done by the engine (hspf_run_device + hspf_routes_device)
-      if (rows_equal(I::compute_spf_device_routes(inst, *eng), vec["rib"])) ++dev_ok; else { ++dev_bad; std::fprintf(stderr, "DEVICE ROUTES MISMATCH %s\n", path.c_str()); }
+      // (instances with segment routing keep the host path: the Prefix-SID step needs the Route objects)
+      if (!inst.config.sr_enabled) { if (rows_equal(I::compute_spf_device_routes(inst, *eng), vec["rib"])) ++dev_ok; else { ++dev_bad; std::fprintf(stderr, "DEVICE ROUTES MISMATCH %s\n", path.c_str()); } }
       // recorded rows in BTreeMap<IpNetwork, _> order
       std::vector<const J *> want;
       for (auto &r : vec["rib"].arr) want.push_back(&r);
@@ -516,6 +540,7 @@ int main(int argc, char **argv) {
         if (!same) std::fprintf(stderr, "MISMATCH %s row %zu: %s metric %u level %d (%zu next hops)\n", path.c_str(), i, rows[i].prefix.c_str(),
                                 rows[i].metric, rows[i].level, rows[i].nexthops.size());
       }
+      if (same && !rows_equal(rows, vec["rib"])) { same = false; std::fprintf(stderr, "MISMATCH %s: SR labels\n", path.c_str()); }
       if (same) ++ok; else { ++bad; if (want.size() != rows.size()) std::fprintf(stderr, "MISMATCH %s: %zu rows, recorded %zu\n", path.c_str(), rows.size(), want.size()); }
     } catch (const std::exception &e) { ++bad; std::fprintf(stderr, "ERROR %s: %s\n", path.c_str(), e.what()); }
   }

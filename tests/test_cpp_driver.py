@@ -107,26 +107,40 @@ def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_
     rows = the literal restatements' RIBs (oracle/isis_ref.py, oracle/ospf_ref.py), engine = the CPU oracle."""
     import json
     from oracle import graph_oracle, isis_ref, ospf_ref, ospfv3_ref
-    from _random_isis import make as make_isis
+    from _random_isis import add_sr, make as make_isis
     from _random_ospf import make as make_ospf
     from _random_ospfv3 import make as make_ospfv3
     graph_oracle.build()
     _build_host()
-    files = []
+    files, labelled = [], 0
     for seed in range(3000, 3150):
         v = make_isis(seed)
         v["rib"] = isis_ref.local_rib(v)
         p = tmp_path / f"isis_{seed}.json"; p.write_text(json.dumps(v)); files.append(str(p))
+        if seed % 3 == 0:                                      # ... and with segment routing on: input and output labels (sr.rs)
+            s = add_sr(make_isis(seed), seed)
+            s["rib"] = isis_ref.local_rib(s)
+            labelled += sum(1 for r in s["rib"] if r.get("sr_label") is not None or any(x is not None for x in r.get("nexthop_labels", [])))
+            p = tmp_path / f"isis_sr_{seed}.json"; p.write_text(json.dumps(s)); files.append(str(p))
         w = make_ospf(seed)
         w["rib"] = ospf_ref.intra_area_rib(w)
         p = tmp_path / f"ospf_{seed}.json"; p.write_text(json.dumps(w)); files.append(str(p))
         x = make_ospfv3(seed)
         x["rib"] = ospfv3_ref.intra_area_rib(x)
         p = tmp_path / f"ospfv3_{seed}.json"; p.write_text(json.dumps(x)); files.append(str(p))
+    # the three-router chains of tests/test_host_isis_sr.py whose labels are worked out by hand there (P / E flags, an index
+    # beyond the SRGB, an absolute label, a neighbour without the I flag, an advertiser without the SPF algorithm)
+    from test_host_isis_sr import chain
+    for k, kw in enumerate(({}, {"flags2": ("P",)}, {"flags2": ("P", "E")}, {"flags3": ("P", "E")}, {"srgb2": ((17000, 20),)},
+                            {"sid3": {"flags": ["V", "L"], "label": 5555}}, {"cap2_flags": ("V",)}, {"algos3": (1,)})):
+        c = chain(**kw)
+        c["rib"] = isis_ref.local_rib(c)
+        p = tmp_path / f"isis_sr_chain_{k}.json"; p.write_text(json.dumps(c)); files.append(str(p))
     r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so")] + files,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr[-3000:]
-    assert "450 vectors reproduce" in r.stdout
+    assert "508 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
+    assert labelled > 100                                      # (the SR vectors do carry labels: 186 rows)
 
 
 def _manet_case_files(tmp_path):
