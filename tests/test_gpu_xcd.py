@@ -187,3 +187,18 @@ def test_tickets_in_flight_through_k_xcd():
             assert np.array_equal(t["mask"].cpu().numpy().view(np.uint64), ref.mask), rnd
     G.free()
     ctx.close()
+
+
+@pytest.mark.parametrize("n_routers,expect_xcd", [(19999 - 300, True), (20000 - 300, True), (20001 - 300, False)])
+def test_the_largest_graph_the_kernel_takes(xcd_ctx, n_routers, expect_xcd):
+    """20 000 vertices x 8 bytes = the 160 000 bytes of LDS a workgroup's replica may take: the graph at the limit, one below
+    and one above (which the launch-per-sweep engine runs), one and eight roots, against the oracle."""
+    g = synth.random_lsdb(n_routers, 300, 2.6, 1234 + n_routers, metric_hi=30, lan_size=5)
+    assert g.n == n_routers + 300
+    G = xcd_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    for roots in (np.asarray([g.n - 1], np.uint32), np.asarray([300, 5000, 9999, 12345, 15000, 17000, 19000, g.n - 2], np.uint32)):
+        res = xcd_ctx.run(G, roots, 1)
+        ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 1, go.MAP, mask_words_=res.first_hop_mask.shape[2])
+        assert _same(res, ref), (g.n, len(roots), res.stats)
+        assert (res.stats["single_wg"] == 2) == expect_xcd, res.stats
+    G.free()
