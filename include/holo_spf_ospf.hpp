@@ -870,6 +870,36 @@ inline std::vector<IbusMsg> update_global_rib_device(const std::string &router_i
   return update_global_rib_device_t(Ver{}, router_id, areas, max_paths, engine, rib_before, ifindex, other_rows, n_records, n_prefixes);
 }
 
+// ---- SpfComputation::{Full, Partial} (holo-ospf/src/spf.rs:489-584; `V::spf_computation_type`, ospfv2/spf.rs:99-170,
+// ospfv3/spf.rs:100-163) -------------------------------------------------------------------------------------------------------
+// A changed LSA whose function is on the version's list needs the SPTs again (Full: every area through the engine); anything
+// else is a Partial computation, which does NOT touch the SPTs — the engine is not called.  Its intra-area part re-attaches the
+// prefixes of the changed Intra-Area-Prefix-LSAs (old and new version) to the STORED SPTs (route::update_rib_partial,
+// route.rs:200-237); in OSPFv2 the intra-area information lives in Router- / Network-LSAs, so that part is empty there
+// (ospfv2/spf.rs:121-126).  The inter-area / external members of SpfPartialComputation belong to calculations outside this path.
+// Python twins: holo_amd.ospfv3.spf_computation_type / SpfState, holo_amd.ospf.SpfState.
+struct TriggerLsa { std::string function; std::vector<std::string> new_prefixes, old_prefixes; };   // prefixes: Intra-Area-Prefix-LSAs only
+inline bool spf_is_full(const std::vector<TriggerLsa> &trig, int version) {
+  static const std::set<std::string> v3{"router", "network", "link", "router-info"};
+  static const std::set<std::string> v2{"router", "network", "opaque-area-router-info", "opaque-area-ext-prefix", "opaque-area-ext-link", "opaque-as-ext-prefix"};
+  for (auto &t : trig) if ((version == 3 ? v3 : v2).count(t.function)) return true;
+  return false;
+}
+// OSPFv2: a Full run goes through the engine; a Partial one leaves SPTs, router tables and the intra-area RIB as they are.
+class SpfState {
+ public:
+  SpfState(std::string router_id, uint32_t max_paths, Engine &engine) : router_id_(std::move(router_id)), max_paths_(max_paths), engine_(engine) {}
+  int engine_runs = 0;
+  const std::vector<RibRow> &run(const std::vector<Area> &areas, const std::vector<TriggerLsa> *trigger = nullptr) {
+    if (trigger && !spf_is_full(*trigger, 2)) return rows_;
+    for (auto &a : areas) { AreaGraph g(a); if (g.index.count({RTR, ip4(router_id_)})) ++engine_runs; }
+    rows_ = compute_spf_intra_area(router_id_, areas, max_paths_, engine_, &cache_);
+    return rows_;
+  }
+ private:
+  std::string router_id_; uint32_t max_paths_; Engine &engine_; GraphCache cache_; std::vector<RibRow> rows_;
+};
+
 // ---- OSPFv3 (holo-ospf/src/ospfv3/spf.rs) ----------------------------------------------------------------------------
 // Version-specific parts: VertexId { Network{router_id, iface_id}, Router{router_id} } (:38-42), vertex_lsa_find /
 // vertex_lsa_links over Router-LSA fragments with the R bit (and V6 bit for the IPv6 address family) (:286-419),
@@ -1050,7 +1080,8 @@ inline std::optional<SptMap> run_area(const std::string &router_id, AreaGraph &g
 struct RouteNet { std::string prefix; uint32_t metric = 0, origin = 0; Nexthops nexthops; };
 
 // intra_area_networks (ospfv3/spf.rs:421-478) + update_rib_intra_area (route.rs:343-448)
-inline void update_rib_intra_area(std::map<IpKey, RouteNet> &rib, const Area &area, const SptMap &spt, uint32_t max_paths) {
+inline void update_rib_intra_area(std::map<IpKey, RouteNet> &rib, const Area &area, const SptMap &spt, uint32_t max_paths,
+                                  const std::set<IpKey> *filter = nullptr) {              // filter: the prefix keys of a partial run (route.rs:356-362)
   std::vector<const IntraAreaPrefixLsa *> iaps;
   for (auto &l : area.iaps) iaps.push_back(&l);
   std::stable_sort(iaps.begin(), iaps.end(), [](auto *x, auto *y) { return std::make_pair(ip4(x->adv_rtr), x->lsa_id) < std::make_pair(ip4(y->adv_rtr), y->lsa_id); });
@@ -1066,6 +1097,7 @@ inline void update_rib_intra_area(std::map<IpKey, RouteNet> &rib, const Area &ar
     for (auto &p : lsa->prefixes) {
       if (has_opt(p.options, "nu-bit")) continue;
       const IpKey key = parse_ip(p.prefix);
+      if (filter && !filter->count(key)) continue;
       const uint64_t sum = (uint64_t)v.distance + p.metric;
       const uint32_t metric = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum;
       auto it = rib.find(key);
@@ -1101,6 +1133,58 @@ inline std::vector<RibRow> compute_spf_intra_area(const std::string &router_id, 
   }
   return rows;
 }
+
+// What compute_spf keeps between runs (holo-ospf/src/spf.rs:489-584): the per-area SPTs of the last FULL run (`area.state.spt`) and
+// the intra-area RIB.  A Full computation runs every area on the engine and rebuilds the RIB; a Partial one removes the
+// affected prefixes, re-attaches them from the STORED SPTs over all areas and never calls the engine.
+class SpfState {
+ public:
+  SpfState(std::string router_id, uint32_t max_paths, Engine &engine, std::string af = "ipv6")
+      : router_id_(std::move(router_id)), max_paths_(max_paths), engine_(engine), af_(std::move(af)) {}
+  int engine_runs = 0;
+  std::vector<RibRow> run(const std::vector<Area> &areas, const std::vector<TriggerLsa> *trigger = nullptr) {
+    std::vector<const Area *> order;
+    for (auto &a : areas) order.push_back(&a);
+    std::stable_sort(order.begin(), order.end(), [](const Area *a, const Area *b) { return ip4(a->area_id) < ip4(b->area_id); });
+    if (!trigger || spf_is_full(*trigger, 3)) {
+      rib_.clear();
+      for (const Area *a : order) {
+        AreaGraph g(*a, af_);
+        auto spt = run_area(router_id_, g, engine_);
+        ++engine_runs;
+        if (spt) update_rib_intra_area(rib_, *a, *spt, max_paths_);
+        spts_[a->area_id] = std::move(spt);
+      }
+    } else {
+      std::set<IpKey> intra;
+      for (auto &t : *trigger)
+        if (t.function == "intra-area-prefix") {
+          for (auto &p : t.new_prefixes) intra.insert(parse_ip(p));
+          for (auto &p : t.old_prefixes) intra.insert(parse_ip(p));
+        }
+      if (!intra.empty()) {
+        for (auto &k : intra) rib_.erase(k);
+        std::map<IpKey, RouteNet> part;
+        for (const Area *a : order) {
+          auto it = spts_.find(a->area_id);
+          if (it != spts_.end() && it->second) update_rib_intra_area(part, *a, *it->second, max_paths_, &intra);
+        }
+        for (auto &kv : part) rib_[kv.first] = kv.second;
+      }
+    }
+    std::vector<RibRow> rows;
+    for (auto &kv : rib_) {
+      RibRow r{kv.second.prefix, kv.second.metric, {}};
+      for (auto &n : kv.second.nexthops) r.nexthops.push_back({n.second.addr, n.second.iface_name});
+      rows.push_back(std::move(r));
+    }
+    return rows;
+  }
+ private:
+  std::string router_id_; uint32_t max_paths_; Engine &engine_; std::string af_;
+  std::map<std::string, std::optional<SptMap>> spts_;
+  std::map<IpKey, RouteNet> rib_;
+};
 
 // ---- OSPFv3 on the engine: SPT, the ordered prefix fold of every area into one RIB, the wire step ----
 // The ordered table: the stub networks as Ospfv3::intra_area_networks yields them (ospfv3/spf.rs:421-478) — Intra-Area-Prefix-

@@ -453,6 +453,32 @@ static int check_ospfv3_device(const J &vec, Engine &eng, size_t &records, size_
     i = 0;
     for (auto &l : a.routers) if (l.adv_rtr != rid && i++ % 4 == 1) for (auto &k : l.links) k.metric = k.metric % 7 + 1;
   }
+  {
+    // SpfComputation::{Full, Partial}: the perturbed LSDB first (Full), then the recorded one reached by a change of Intra-Area-
+    // Prefix-LSAs only (their router metrics put back by a Full run in between) — the Partial run re-attaches those prefixes
+    // from the STORED SPTs, gives the rows of a Full run on the same LSDB and does not call the engine
+    auto mid = areas;                                            // recorded router LSAs, perturbed Intra-Area-Prefix-LSAs
+    for (size_t ai = 0; ai < mid.size(); ++ai) mid[ai].iaps = before_areas[ai].iaps;
+    O::v3::SpfState st(rid, mp, eng, af);
+    st.run(before_areas);
+    if (!(st.run(mid) == O::v3::compute_spf_intra_area(rid, mid, mp, eng, af))) { std::fprintf(stderr, "  ospfv3 SpfState: full run differs\n"); return 0; }
+    std::vector<O::TriggerLsa> trig;
+    for (size_t ai = 0; ai < mid.size(); ++ai)
+      for (size_t li = 0; li < mid[ai].iaps.size(); ++li) {
+        const auto &o = mid[ai].iaps[li], &nw = areas[ai].iaps[li];
+        bool differs = o.prefixes.size() != nw.prefixes.size();
+        for (size_t k = 0; !differs && k < o.prefixes.size(); ++k) differs = o.prefixes[k].metric != nw.prefixes[k].metric;
+        if (!differs) continue;
+        O::TriggerLsa t{"intra-area-prefix", {}, {}};
+        for (auto &p : nw.prefixes) t.new_prefixes.push_back(p.prefix);
+        for (auto &p : o.prefixes) t.old_prefixes.push_back(p.prefix);
+        trig.push_back(std::move(t));
+      }
+    const int runs = st.engine_runs;
+    if (!(st.run(areas, &trig) == rows) || st.engine_runs != runs) { std::fprintf(stderr, "  ospfv3 SpfState: partial run differs (or called the engine)\n"); return 0; }
+    trig.push_back(O::TriggerLsa{"router", {}, {}});             // ... and a Router-LSA among the triggers makes it Full
+    if (!(st.run(areas, &trig) == rows) || st.engine_runs == runs) { std::fprintf(stderr, "  ospfv3 SpfState: full dispatch differs\n"); return 0; }
+  }
   std::map<std::string, int> ifindex;
   for (auto &a : areas) for (auto &f : a.interfaces) ifindex[f.name] = (int)f.index;
   const auto before = O::v3::compute_spf_intra_area(rid, before_areas, mp, eng, af);
@@ -502,6 +528,17 @@ int main(int argc, char **argv) {
         }
         const int r = check_ospf(vec, *eng, path);
         if (r > 0) ++ok; else if (r == 0) ++bad; else ++skipped;
+        if (r > 0) {                                              // SpfComputation dispatch, OSPFv2: Type-3 / 4 / 5 changes leave the intra-area part alone
+          const auto areas = areas_from_vector(vec);
+          O::SpfState st(vec["router_id"].s, (uint32_t)vec["max_paths"].i(), *eng);
+          const auto r0 = st.run(areas);
+          const int runs = st.engine_runs;
+          std::vector<O::TriggerLsa> t{O::TriggerLsa{"summary-network", {}, {}}, O::TriggerLsa{"as-external", {}, {}}};
+          const bool same = st.run(areas, &t) == r0 && st.engine_runs == runs;
+          t.push_back(O::TriggerLsa{"network", {}, {}});
+          const bool full = st.run(areas, &t) == r0 && st.engine_runs > runs;
+          if (!same || !full) { ++bad; std::fprintf(stderr, "SPF COMPUTATION DISPATCH MISMATCH %s\n", path.c_str()); }
+        }
         continue;
       }
       if (vec["proto"].s == "ospfv3") {
@@ -550,6 +587,6 @@ int main(int argc, char **argv) {
   if (dev_ok + dev_bad) std::printf("host_parity: %d IS-IS RIBs also derived with the prefix attachment on the engine, %d differ\n", dev_ok + dev_bad, dev_bad);
   if (wire_ok + wire_bad) std::printf("host_parity: %d recorded ibus sequences (RouteIpAdd / RouteIpDel) reproduced by the host rule AND from engine tables (%zu records for %zu prefixes), %d differ; %d also through the running-instance pipeline\n", wire_ok, wire_records, wire_prefixes, wire_bad, wire_pipelines);
   if (owire_ok + owire_bad) std::printf("host_parity: %d recorded OSPFv2 ibus sequences reproduced by the host rule AND from engine tables (%zu records for %zu prefixes; %d of them two-area instances folded into one RIB on the engine), %d differ\n", owire_ok, owire_records, owire_prefixes, owire_multi, owire_bad);
-  if (v3_ok + v3_bad) std::printf("host_parity: %d OSPFv3 RIBs also from the ordered fold on the engine, each with two wire steps against the host rule (%zu records for %zu prefixes, %d sequences with messages), %d differ\n", v3_ok, v3_records, v3_prefixes, v3_msgs, v3_bad);
+  if (v3_ok + v3_bad) std::printf("host_parity: %d OSPFv3 RIBs also from the ordered fold on the engine, each with two wire steps against the host rule (%zu records for %zu prefixes, %d sequences with messages) and a Full / Partial / Full sequence of SpfState, %d differ\n", v3_ok, v3_records, v3_prefixes, v3_msgs, v3_bad);
   return (bad || manet_bad || steps_bad || dev_bad || wire_bad || owire_bad || v3_bad) ? 1 : 0;
 }

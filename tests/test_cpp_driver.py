@@ -77,7 +77,7 @@ def test_cpp_host_side_reproduces_recorded_ribs_with_the_oracle_as_engine():
     # tables (comparison, compaction, packing on the engine) and, where the step kept the interfaces, the running pipeline
     assert "17 recorded ibus sequences" in r.stdout and ", 0 differ; 3 also through the running-instance pipeline" in r.stdout
     assert "11 recorded OSPFv2 ibus sequences" in r.stdout and "2 of them two-area instances folded into one RIB on the engine), 0 differ" in r.stdout
-    assert "38 OSPFv3 RIBs also from the ordered fold on the engine, each with two wire steps" in r.stdout and "sequences with messages), 0 differ" in r.stdout
+    assert "38 OSPFv3 RIBs also from the ordered fold on the engine, each with two wire steps" in r.stdout and "sequences with messages) and a Full / Partial / Full sequence of SpfState, 0 differ" in r.stdout
 
 
 def test_cpp_host_side_without_a_device_reports_it():
@@ -99,7 +99,7 @@ def test_cpp_host_side_reproduces_recorded_ribs_on_gpu():
     assert "57 IS-IS RIBs also derived with the prefix attachment on the engine, 0 differ" in r.stdout     # hspf_routes_device
     assert "17 recorded ibus sequences" in r.stdout and ", 0 differ; 3 also through the running-instance pipeline" in r.stdout   # hspf_routes_diff_device + hspf_routes_pack
     assert "11 recorded OSPFv2 ibus sequences" in r.stdout and "2 of them two-area instances folded into one RIB on the engine), 0 differ" in r.stdout   # hspf_rib_fold_device
-    assert "38 OSPFv3 RIBs also from the ordered fold on the engine, each with two wire steps" in r.stdout and "sequences with messages), 0 differ" in r.stdout
+    assert "38 OSPFv3 RIBs also from the ordered fold on the engine, each with two wire steps" in r.stdout and "sequences with messages) and a Full / Partial / Full sequence of SpfState, 0 differ" in r.stdout
 
 
 def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_path):
