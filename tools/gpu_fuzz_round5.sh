@@ -25,6 +25,8 @@ wait
 wait
 (echo "xcd:            $(env HSPF_SINGLE_MAX_N=0 HSPF_LV_MAX_ROOTS=0 HSPF_XCD_ALWAYS=1 FUZZ_MAX_ROOTS=8 python tools/gpu_fuzz.py $((280000 + O)) $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
 (echo "wide LANs:      $(FUZZ_WIDE=$((N / 8)) python tools/gpu_fuzz.py 3000 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
+(echo "lanevertex:     $(env HSPF_SINGLE_MAX_N=0 HSPF_LV_MAX_ROOTS=64 HSPF_LV_MIN_N=0 HSPF_XCD_MAX_ROOTS=0 python tools/gpu_fuzz.py $((340000 + O)) $N 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
+wait
 (echo "mid, product:   $(FUZZ_MID=$((N / 10)) python tools/gpu_fuzz.py $((300000 + O)) 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
 (echo "mid, k_xcd:     $(HSPF_XCD_ALWAYS=1 FUZZ_MID=$((N / 10)) python tools/gpu_fuzz.py $((320000 + O)) 2>&1 | grep -v amdgpu.ids | tr '\n' ' ')" >> $OUT) &
 wait
