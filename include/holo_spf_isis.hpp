@@ -320,8 +320,11 @@ class LevelGraph {
     Row r;
     for (const Lsp *lsp : frags[lan])
       for (auto &e : vertex_edges(*lsp, mt_id, hopcount, metric_type)) {
-        auto it = index.find(vertex_id(e.first));
-        if (it != index.end()) { r.col.push_back(it->second); r.metric.push_back(e.second); }
+        // (binary search in the sorted vertex list: a million lookups per 100 000-router LSDB, contiguous memory instead
+        // of the tree's nodes)
+        const VertexId vid = vertex_id(e.first);
+        auto it = std::lower_bound(vids.begin(), vids.end(), vid);
+        if (it != vids.end() && *it == vid) { r.col.push_back((uint32_t)(it - vids.begin())); r.metric.push_back(e.second); }
       }
     const bool is_pn = lan.pseudonode != 0;
     uint8_t f = is_pn ? HSPF_VF_NETWORK : 0;
