@@ -4,8 +4,9 @@
 # thresholds, dense stretch from the first sweep on, stretches that stop after their second pass, multi-pass launches on
 # graphs so small that all passes run side by side — next to the older paths (k_fused everywhere, fused path off, LANs of
 # 150-900 routers).        usage: bash tools/gpu_fuzz_round5.sh [graphs per configuration [seed offset]]
-# Two processes at a time, and a gpurun call of this kept to a couple of minutes (a few hundred graphs per
-# configuration): round 4 lost two boxes under longer ones (tools/attic/README.md).
+# Two processes at a time, and a gpurun call of this kept WELL under two minutes (300 graphs per configuration since the
+# lanevertex and mid-size lines joined: ~70 s): round 4 lost two boxes under longer calls, round 5 one more (600 graphs,
+# box gone after 120 s: profiles/r05_notes.md) — whatever it is on the box's side, it is a function of the call's length.
 set -u
 N=${1:-400}
 O=${2:-0}          # added to every configuration's first seed: another slice of the seed space per call
