@@ -204,7 +204,8 @@ class HipGraph : public Graph {
 // Device and page-locked host blocks of the objects below, kept for reuse: a running instance makes the same few allocations
 // every SPF event (run tables, route tables, staging), and hipMalloc / hipFree cost 10-50 us each and synchronise the device
 // (the LSP-change pipeline of RibPipeline: 0.94 -> ~0.7 ms, profiles/r05_notes.md).  Blocks are handed out by exact size class
-// (rounded up to 64 KB); every engine call that reads or writes them is synchronous, so a returned block is idle.
+// (rounded up to 64 KB); every engine call that reads or writes them is synchronous, so a returned block is idle.  Like the
+// engine and its context the pool belongs to ONE thread (the protocol instance's): no locking.
 class HipPool {
  public:
   ~HipPool() {
