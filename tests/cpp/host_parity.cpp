@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <set>
 
 #include "holo_spf_isis.hpp"
 #include "holo_spf_ospf.hpp"
@@ -438,8 +439,9 @@ static int replay_ospf_step(const J &step, const std::string &golden_dir, Engine
 
 // OSPFv3 from the engine (round 5): the recorded RIB from the ordered fold of every area on the engine, and a wire step — the
 // LSDB as recorded against a perturbed copy of it (remote Intra-Area-Prefix and Router-LSA metrics changed) as the RIB held
-// before; no ibus recording exists for OSPFv3 (the conformance module is commented out upstream), so the expected sequence is
-// the host rule's (pinned by the OSPFv2 recordings: it does not look at the version).
+// before; no OSPFv3 STEP recording exists (the conformance module is commented out upstream; the 44 topology recordings are
+// checked by check_cold_start below), so the expected sequence of this perturbed step is the host rule's (pinned by the OSPFv2
+// step recordings and the 132 cold-start states: it does not look at the version).
 static int check_ospfv3_device(const J &vec, Engine &eng, size_t &records, size_t &prefixes, int &with_msgs) {
   const auto areas = areas3_from_vector(vec);
   const std::string rid = vec["router_id"].s, af = vec["af"].s;
@@ -492,6 +494,82 @@ static int check_ospfv3_device(const J &vec, Engine &eng, size_t &records, size_
   return 1;
 }
 
+// The recorded COLD-START wire output (tests/golden/wire/<proto>/<topo>_<rt>.json, tools/make_golden_wire.py: the final per-prefix
+// state of the topology's `output/ibus.jsonl` — IS-IS 38, OSPFv2 50, OSPFv3 44 with fe80:: next hops): update_global_rib from
+// an EMPTY RIB by the host rule and from ENGINE tables must install exactly those routes, in RIB key order.
+// 1 equal, 0 a difference, -1 no recording for this vector.
+typedef std::map<std::string, std::pair<uint32_t, std::vector<std::pair<int, std::string>>>> WireState;
+static bool wire_state_of(const std::vector<IbusMsg> &msgs, WireState &out) {
+  for (size_t i = 0; i < msgs.size(); ++i) {
+    if (!msgs[i].add || out.count(msgs[i].prefix)) return false;
+    if (i && !(parse_ip(msgs[i - 1].prefix) < parse_ip(msgs[i].prefix))) return false;         // BTreeMap<IpNetwork, _> order
+    auto nh = msgs[i].nexthops; std::sort(nh.begin(), nh.end());
+    out[msgs[i].prefix] = {msgs[i].metric, nh};
+  }
+  return true;
+}
+static int check_cold_start(const J &vec, const std::string &path, const std::string &golden_dir, Engine &eng, size_t &records, int &device_forms) {
+  if (golden_dir.empty() || vec["source"].s.find("snapshot ") != std::string::npos) return -1;
+  const std::string proto = vec["proto"].s, wp = golden_dir + "/wire/" + proto + "/" + path.substr(path.find_last_of('/') + 1);
+  { FILE *f = std::fopen(wp.c_str(), "r"); if (!f) return -1; std::fclose(f); }
+  const J w = load_json(wp);
+  std::map<std::string, int> ifindex;
+  for (auto &kv : w["ifindex"].obj) ifindex[kv.first] = (int)kv.second.i();
+  WireState want;
+  for (auto &r : w["final"].arr) {
+    std::vector<std::pair<int, std::string>> nh;
+    for (auto &n : r["nexthops"].arr) { if (n[2].arr.size()) return 0; nh.push_back({(int)n[0].i(), n[1].s}); }
+    std::sort(nh.begin(), nh.end());
+    want[r["prefix"].s] = {(uint32_t)r["metric"].i(), nh};
+  }
+  if (proto == "isis") {
+    const I::Instance inst = instance_from_vector(vec);
+    WireState host;
+    if (!wire_state_of(I::update_global_rib(I::compute_spf(inst, eng), {}, ifindex), host) || host != want) { std::fprintf(stderr, "  cold start: host rule differs\n"); return 0; }
+    if (inst.config.sr_enabled) return 1;
+    WireState dev;
+    if (!wire_state_of(I::update_global_rib(I::compute_spf_device_routes(inst, eng), {}, ifindex), dev) || dev != want) { std::fprintf(stderr, "  cold start: rows attached on the engine differ\n"); return 0; }
+    std::vector<std::pair<int, int>> tabs;
+    for (int lv : inst.config.levels()) for (int mt : {I::MT_STANDARD, I::MT_IPV6_UNICAST}) if (inst.config.is_topology_enabled(mt)) tabs.push_back({lv, mt});
+    if (tabs.size() != 1) return 1;
+    size_t nr = 0, np = 0;
+    WireState pk;
+    if (!wire_state_of(I::update_global_rib_device(inst, eng, {}, ifindex, &nr, &np), pk) || pk != want || nr > np) { std::fprintf(stderr, "  cold start: device form differs\n"); return 0; }
+    records += nr; ++device_forms;
+    return 1;
+  }
+  // OSPFv2 / OSPFv3: the intra-area part is this path's, the other route types come from the recording; at a virtual-link endpoint
+  // the intra-area routes THROUGH the link get their next hops from the transit-area step (outside the path): left out
+  const bool v3 = proto == "ospfv3";
+  const std::string rid = vec["router_id"].s;
+  const uint32_t mp = (uint32_t)vec["max_paths"].i();
+  std::vector<O::RibRow> rows, other;
+  std::vector<IbusMsg> devmsgs;
+  size_t nr = 0, np = 0;
+  for (auto &r : ospf_rib_rows(vec["rib"])) if (r.type != "intra-area") other.push_back(r);
+  if (v3) {
+    const auto areas = areas3_from_vector(vec);
+    rows = O::v3::compute_spf_intra_area(rid, areas, mp, eng, vec["af"].s);
+    devmsgs = O::v3::update_global_rib_device(rid, areas, mp, eng, {}, ifindex, vec["af"].s, other, &nr, &np);
+  } else {
+    const auto areas = areas_from_vector(vec);
+    rows = O::compute_spf_intra_area(rid, areas, mp, eng);
+    devmsgs = O::update_global_rib_device(rid, areas, mp, eng, {}, ifindex, other, &nr, &np);
+  }
+  std::set<std::string> undecided;
+  if (vec["has_vlinks"].b) for (auto &r : rows) if (r.nexthops.empty()) undecided.insert(r.prefix);
+  for (auto &u : undecided) want.erase(u);
+  rows.insert(rows.end(), other.begin(), other.end());
+  WireState host, dev;
+  if (!wire_state_of(O::update_global_rib(rows, {}, ifindex), host)) return 0;
+  if (!wire_state_of(devmsgs, dev)) return 0;
+  for (auto &u : undecided) { host.erase(u); dev.erase(u); }
+  if (host != want) { std::fprintf(stderr, "  cold start: host rule differs\n"); return 0; }
+  if (dev != want) { std::fprintf(stderr, "  cold start: device form differs\n"); return 0; }
+  records += nr; ++device_forms;
+  return 1;
+}
+
 int main(int argc, char **argv) {
   std::string engine = "hip", oracle_so = "oracle/liboracle_spf.so", golden_dir;
   std::vector<std::string> files;
@@ -512,11 +590,16 @@ int main(int argc, char **argv) {
   int wire_ok = 0, wire_bad = 0, wire_pipelines = 0, owire_ok = 0, owire_bad = 0, owire_multi = 0;
   size_t owire_records = 0, owire_prefixes = 0, v3_records = 0, v3_prefixes = 0;
   int v3_ok = 0, v3_bad = 0, v3_msgs = 0;
-  size_t wire_records = 0, wire_prefixes = 0;
+  size_t wire_records = 0, wire_prefixes = 0, cold_records = 0;
+  int cold_ok = 0, cold_bad = 0, cold_dev = 0;
   if (!check_hash_kat()) { std::fprintf(stderr, "flood_reduction_hash: reference vectors not reproduced\n"); return 1; }
   for (auto &path : files) {
     try {
       const J vec = load_json(path);
+      {
+        const int c = check_cold_start(vec, path, golden_dir, *eng, cold_records, cold_dev);
+        if (c > 0) ++cold_ok; else if (c == 0) { ++cold_bad; std::fprintf(stderr, "COLD START WIRE STATE MISMATCH %s\n", path.c_str()); }
+      }
       if (vec["proto"].s == "ospfv2") {
         if (!golden_dir.empty() && vec["source"].s.find("snapshot ") != std::string::npos) {
           const int sr = replay_ospf_step(vec, golden_dir, *eng, steps_patched);
@@ -588,5 +671,6 @@ int main(int argc, char **argv) {
   if (wire_ok + wire_bad) std::printf("host_parity: %d recorded ibus sequences (RouteIpAdd / RouteIpDel) reproduced by the host rule AND from engine tables (%zu records for %zu prefixes), %d differ; %d also through the running-instance pipeline\n", wire_ok, wire_records, wire_prefixes, wire_bad, wire_pipelines);
   if (owire_ok + owire_bad) std::printf("host_parity: %d recorded OSPFv2 ibus sequences reproduced by the host rule AND from engine tables (%zu records for %zu prefixes; %d of them two-area instances folded into one RIB on the engine), %d differ\n", owire_ok, owire_records, owire_prefixes, owire_multi, owire_bad);
   if (v3_ok + v3_bad) std::printf("host_parity: %d OSPFv3 RIBs also from the ordered fold on the engine, each with two wire steps against the host rule (%zu records for %zu prefixes, %d sequences with messages) and a Full / Partial / Full sequence of SpfState, %d differ\n", v3_ok, v3_records, v3_prefixes, v3_msgs, v3_bad);
-  return (bad || manet_bad || steps_bad || dev_bad || wire_bad || owire_bad || v3_bad) ? 1 : 0;
+  if (cold_ok + cold_bad) std::printf("host_parity: %d recorded cold-start ibus states (topology output/ibus.jsonl; OSPFv3 included) reproduced by the host rule AND from engine tables (%d through the device comparison and packing, %zu records), %d differ\n", cold_ok, cold_dev, cold_records, cold_bad);
+  return (bad || manet_bad || steps_bad || dev_bad || wire_bad || owire_bad || v3_bad || cold_bad) ? 1 : 0;
 }

@@ -78,6 +78,7 @@ def test_cpp_host_side_reproduces_recorded_ribs_with_the_oracle_as_engine():
     assert "17 recorded ibus sequences" in r.stdout and ", 0 differ; 3 also through the running-instance pipeline" in r.stdout
     assert "11 recorded OSPFv2 ibus sequences" in r.stdout and "2 of them two-area instances folded into one RIB on the engine), 0 differ" in r.stdout
     assert "38 OSPFv3 RIBs also from the ordered fold on the engine, each with two wire steps" in r.stdout and "sequences with messages) and a Full / Partial / Full sequence of SpfState, 0 differ" in r.stdout
+    assert "132 recorded cold-start ibus states" in r.stdout and "(116 through the device comparison and packing" in r.stdout and "records), 0 differ" in r.stdout   # topology output/ibus.jsonl, OSPFv3 included
 
 
 def test_cpp_host_side_without_a_device_reports_it():
@@ -98,6 +99,7 @@ def test_cpp_host_side_reproduces_recorded_ribs_on_gpu():
     assert "30 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout      # hspf_graph_patch
     assert "57 IS-IS RIBs also derived with the prefix attachment on the engine, 0 differ" in r.stdout     # hspf_routes_device
     assert "17 recorded ibus sequences" in r.stdout and ", 0 differ; 3 also through the running-instance pipeline" in r.stdout   # hspf_routes_diff_device + hspf_routes_pack
+    assert "132 recorded cold-start ibus states" in r.stdout and "(116 through the device comparison and packing" in r.stdout and "records), 0 differ" in r.stdout   # topology output/ibus.jsonl, OSPFv3 included
     assert "11 recorded OSPFv2 ibus sequences" in r.stdout and "2 of them two-area instances folded into one RIB on the engine), 0 differ" in r.stdout   # hspf_rib_fold_device
     assert "38 OSPFv3 RIBs also from the ordered fold on the engine, each with two wire steps" in r.stdout and "sequences with messages) and a Full / Partial / Full sequence of SpfState, 0 differ" in r.stdout
 
@@ -225,4 +227,5 @@ def test_cpp_host_side_under_asan_ubsan():
                         "--replay-steps", os.path.join(ROOT, "tests", "golden")] + VECTORS, capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "163 vectors reproduce" in r.stdout and " 0 do not" in r.stdout and ", 0 differ" in r.stdout
+    assert "132 recorded cold-start ibus states" in r.stdout and "(116 through the device comparison and packing" in r.stdout and "records), 0 differ" in r.stdout   # topology output/ibus.jsonl, OSPFv3 included
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr

@@ -243,7 +243,9 @@ def test_ospf_multi_area_fold_on_device_random_instances_equal_the_host_rule(spf
 def test_ospfv3_wire_step_and_multi_area_fold_on_device_equal_the_host_rule(spf_ctx):
     """The same for OSPFv3 (Intra-Area-Prefix-LSAs in LSDB order, per-entry origins, link-local next hops): one- and two-area
     random instances before / after remote routers change their Intra-Area-Prefix / Router-LSAs; messages = the host rule on
-    the twin's RIBs (no ibus recording exists for OSPFv3: the conformance module is commented out upstream)."""
+    the twin's RIBs.  (The reference holds no OSPFv3 STEP tests — the conformance module is commented out upstream — but it
+    does hold the 44 topology recordings `output/ibus.jsonl`: those pin the OSPFv3 wire step in
+    test_ospf_cold_start_from_device_tables_reproduces_recorded_ibus_state below.)"""
     import copy
     import random
     from _random_ospfv3 import make
@@ -568,3 +570,27 @@ def test_resident_prefix_table_skips_the_upload_and_gives_the_same_routes(spf_ct
     for x, y in zip(a, e):
         assert np.array_equal(x, y)
     assert not np.array_equal(a[0], c[0])
+
+
+# ---- the reference's recorded COLD-START wire output, every topology router ----------------------------
+# tests/golden/wire/ (tools/make_golden_wire.py): the final per-prefix state of `output/ibus.jsonl` — IS-IS 38, OSPFv2 50,
+# OSPFv3 44 (fe80:: link-local next hops).  From DEVICE tables: SPT, prefix attachment / ordered fold, the comparison with an
+# empty RIB, compaction and ONE packed record stream (hspf_routes_diff_device, hspf_routes_pack), expanded on the host.
+import _wire as W        # noqa: E402
+
+_WI = W.wire_paths("isis")
+_WO = W.wire_paths("ospfv2") + W.wire_paths("ospfv3")
+
+
+def test_cold_start_wire_vectors_present():
+    assert (len(_WI), len(W.wire_paths("ospfv2")), len(W.wire_paths("ospfv3"))) == (38, 50, 44)
+
+
+@pytest.mark.parametrize("path", _WI, ids=[os.path.basename(p)[:-5] for p in _WI])
+def test_isis_cold_start_from_device_tables_reproduces_recorded_ibus_state(spf_ctx, path):
+    W.check_isis_cold_start(path, spf_ctx, device=True)
+
+
+@pytest.mark.parametrize("path", _WO, ids=[("v3-" if "ospfv3" in p else "v2-") + os.path.basename(p)[:-5] for p in _WO])
+def test_ospf_cold_start_from_device_tables_reproduces_recorded_ibus_state(spf_ctx, path):
+    W.check_ospf_cold_start(path, spf_ctx, device=True)

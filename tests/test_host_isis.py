@@ -108,3 +108,12 @@ def test_manet_init_cache_is_one_batched_run():
     for sid, c in cache.items():
         ref, order = R.compute_spt(vec, level, sid, False, None, True)
         assert list(c.remote_nbr_list) == sorted(v[1] for v in order if v[0] and ref[v].hops == 1)
+
+
+# ---- the recorded cold-start wire output of every topology router (tests/golden/wire/isis, tools/make_golden_wire.py) -------
+import _wire as W        # noqa: E402
+
+
+@pytest.mark.parametrize("path", W.wire_paths("isis"), ids=[os.path.basename(p)[:-5] for p in W.wire_paths("isis")])
+def test_cold_start_messages_reproduce_recorded_ibus_state(path):
+    W.check_isis_cold_start(path, OracleEngine())

@@ -128,3 +128,16 @@ def check_ospfv3_vector(vec, engine):
 @pytest.mark.parametrize("path", OSPF3, ids=[os.path.basename(p)[:-5] for p in OSPF3])
 def test_ospfv3_run_area_and_intra_area_rib(path):
     check_ospfv3_vector(json.load(open(path)), OracleEngine())
+
+
+# ---- the recorded cold-start wire output of every topology router (tests/golden/wire/ospfv{2,3}) ----------------------------
+import _wire as W        # noqa: E402
+
+WIRE = W.wire_paths("ospfv2") + W.wire_paths("ospfv3")
+
+
+@pytest.mark.parametrize("path", WIRE, ids=[("v3-" if "ospfv3" in p else "v2-") + os.path.basename(p)[:-5] for p in WIRE])
+def test_cold_start_messages_reproduce_recorded_ibus_state(path):
+    """OSPFv3 included: the 44 recordings carry the fe80:: link-local next hops of Ospfv3::calc_nexthop_lladdr
+    (holo-ospf/src/ospfv3/spf.rs:593-612)."""
+    W.check_ospf_cold_start(path, OracleEngine())

@@ -221,3 +221,41 @@ def test_ospfv3_ref_reproduces_reference_intra_area_rib(path):
         _assert_vlink_endpoint(R3.intra_area_rib(vec), want)
         return
     assert R3.intra_area_rib(vec) == want
+
+
+# ---- the recorded COLD-START wire output: every topology router's `output/ibus.jsonl` ------------------
+# tests/golden/wire/<proto>/*.json (tools/make_golden_wire.py) = the final per-prefix state of the RouteIpAdd / RouteIpDel
+# messages the reference put on the ibus while the recorded topology converged: IS-IS 38, OSPFv2 50 (topo1-3 / topo2-4 hold
+# no recording), OSPFv3 44 — the OSPFv3 ones carry the fe80:: link-local next hops of ospfv3/spf.rs:593-612.
+import _wire as W                       # noqa: E402
+
+WIRE_ISIS, WIRE_V2, WIRE_V3 = W.wire_paths("isis"), W.wire_paths("ospfv2"), W.wire_paths("ospfv3")
+
+
+def test_cold_start_wire_vectors_present():
+    assert (len(WIRE_ISIS), len(WIRE_V2), len(WIRE_V3)) == (38, 50, 44)
+    assert sum(len(_load(p)["final"]) for p in WIRE_V3) > 300      # not empty shells
+
+
+@pytest.mark.parametrize("path", WIRE_ISIS, ids=[os.path.basename(p)[:-5] for p in WIRE_ISIS])
+def test_isis_ref_cold_start_reproduces_recorded_ibus_state(path):
+    """update_global_rib (holo-isis/src/route.rs:254-312) from an EMPTY RIB: on the recorded local RIB, and on the RIB the
+    restatement computes from the recorded LSDB — both give exactly the routes (metric, next-hop set with ifindex and
+    address) the reference had installed when its recording ended."""
+    w, vec = W.load_pair(path)
+    want = W.recorded_state(w)
+    assert W.message_state(R.update_global_rib(vec["rib"], [], w["ifindex"]), R._net_key) == want
+    assert W.message_state(R.update_global_rib(R.local_rib(vec), [], w["ifindex"]), R._net_key) == want
+
+
+@pytest.mark.parametrize("path", WIRE_V2 + WIRE_V3, ids=[("v3-" if "ospfv3" in p else "v2-") + os.path.basename(p)[:-5] for p in WIRE_V2 + WIRE_V3])
+def test_ospf_ref_cold_start_reproduces_recorded_ibus_state(path):
+    """update_global_rib (holo-ospf/src/route.rs:856-916, version-generic) from an EMPTY RIB: (1) on the whole recorded
+    local RIB (all route types) = the recorded final state; (2) the chain run_area -> intra-area RIB of the restatement
+    (OSPFv2 / OSPFv3) -> messages = the recorded state of the intra-area prefixes."""
+    w, vec = W.load_pair(path)
+    assert W.message_state(RO.update_global_rib(vec["rib"], [], w["ifindex"]), RO._net_key) == W.recorded_state(w)
+    rows = (R3 if vec["proto"] == "ospfv3" else RO).intra_area_rib(vec)
+    only = W.ospf_decided_prefixes(vec, rows)
+    got = W.message_state(RO.update_global_rib([r for r in rows if r["prefix"] in only], [], w["ifindex"]), RO._net_key)
+    assert got == W.recorded_state(w, only)
