@@ -37,7 +37,9 @@ class HspfStats(ctypes.Structure):
                 ("ms_finish", ctypes.c_float), ("ms_d2h", ctypes.c_float),
                 ("state_bytes", ctypes.c_uint32), ("narrow_overflow", ctypes.c_uint32),
                 ("rows_recomputed", ctypes.c_uint64), ("single_wg", ctypes.c_uint32), ("lane_vertex", ctypes.c_uint32),
-                ("dbg", ctypes.c_uint32 * 4)]
+                ("dbg", ctypes.c_uint32 * 4),
+                ("n_repaired_roots", ctypes.c_uint32), ("repair_sweeps", ctypes.c_uint32), ("repair_evals", ctypes.c_uint32),
+                ("repair_groups", ctypes.c_uint32), ("ms_repair", ctypes.c_float)]
 
 
 class HspfPackedLayout(ctypes.Structure):

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libholo_spf_hip.so")
 SOURCES = ["spf_capi.hip", "hub_sort.hip"]
-DEPS = ["spf_capi.hip", "spf_kernels.hip.h", "graph_build.hip.h", "spf_multi.hip.h", "hub_sort.hip", "hub_sort.h", os.path.join("..", "..", "include", "holo_spf_hip.h")]
+DEPS = ["spf_capi.hip", "spf_kernels.hip.h", "spf_repair.hip.h", "graph_build.hip.h", "spf_multi.hip.h", "hub_sort.hip", "hub_sort.h", os.path.join("..", "..", "include", "holo_spf_hip.h")]
 
 
 def hipcc_path() -> str:

@@ -596,6 +596,35 @@ kb_leaf_links(uint32_t e, const BuildInfo *__restrict__ info, uint32_t *__restri
   if (leaf[s & SRC_MASK]) in_src[i] = s | SRC_LEAF;
 }
 
+// GraphDev::zcyc — which vertices may lie on a CYCLE of zero-cost kept links.  Trimming: a vertex stays alive while it has a
+// zero-cost in-link from an alive vertex AND a zero-cost out-link to an alive vertex; vertices on a cycle never die, whatever
+// survives GB_ZC_ROUNDS rounds is a superset of them (long zero-cost chains end up in it too: conservative).  Used by the sweep
+// kernels to decide which zero-cost links from higher-numbered sources may feed hops / masks (spf_kernels.hip.h finish_row_z).
+constexpr int GB_ZC_ROUNDS = 8;
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_zc_init(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ in_w, const uint32_t *__restrict__ out_ptr,
+           const uint32_t *__restrict__ out_w, uint8_t *__restrict__ alive) {
+  const uint32_t v = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (v >= n) return;
+  bool zi = false, zo = false;
+  for (uint32_t e = in_ptr[v], e1 = in_ptr[v + 1]; e < e1 && !zi; ++e) zi = in_w[e] == 0u;
+  if (zi) for (uint32_t k = out_ptr[v], k1 = out_ptr[v + 1]; k < k1 && !zo; ++k) zo = out_w[k] == 0u;
+  alive[v] = (zi && zo) ? 1 : 0;
+}
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_zc_round(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ in_src, const uint32_t *__restrict__ in_w,
+            const uint32_t *__restrict__ out_ptr, const uint32_t *__restrict__ out_dst, const uint32_t *__restrict__ out_w,
+            const uint8_t *__restrict__ a, uint8_t *__restrict__ b) {
+  const uint32_t v = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (v >= n) return;
+  bool zi = false, zo = false;
+  if (a[v]) {
+    for (uint32_t e = in_ptr[v], e1 = in_ptr[v + 1]; e < e1 && !zi; ++e) zi = in_w[e] == 0u && a[in_src[e] & SRC_MASK];
+    if (zi) for (uint32_t k = out_ptr[v], k1 = out_ptr[v + 1]; k < k1 && !zo; ++k) zo = out_w[k] == 0u && a[out_dst[k]];
+  }
+  b[v] = (zi && zo) ? 1 : 0;
+}
+
 // Fixed-stride (ELL) copy of the link records for k_fused_lean: 16 entries per vertex, rows 0 .. n (row n = all pad).
 //   ell_so[16 v + j] = byte offset of the source's state row (source << 8); j >= in-degree: the pad row n (never reached);
 //                      the low byte of entry 0 carries  in-degree (0 .. 16; more: 0x1F) | (more than 16 out-links) << 5 |

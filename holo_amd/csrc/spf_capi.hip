@@ -8,6 +8,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared spf_capi.hip -o libholo_spf_hip.so
 #include "../../include/holo_spf_hip.h"
 #include "spf_kernels.hip.h"
+#include "spf_repair.hip.h"
 #include "graph_build.hip.h"
 #include "hub_sort.h"
 
@@ -70,6 +71,8 @@ struct hspf_graph {
   uint32_t *d_in_ptr = nullptr, *d_in_src = nullptr, *d_in_w = nullptr, *d_in_fpos = nullptr;
   uint32_t *d_out_ptr = nullptr, *d_out_dst = nullptr, *d_out_w = nullptr, *d_out_fpos = nullptr;
   uint8_t *d_vflags = nullptr, *d_rowflags = nullptr, *d_leaf = nullptr;   // d_leaf: GraphDev::leaf
+  uint8_t *d_zcyc = nullptr, *d_zcyc_tmp = nullptr;                // GraphDev::zcyc (+ the other buffer of the trimming rounds)
+  bool zcyc_valid = false;                                        // d_zcyc describes the current links (zcyc_update)
   uint32_t n_leaf = 0;
   uint32_t *d_unit_first = nullptr;                               // work units (GraphDev::unit_first), n / 4 + 4 entries
   uint32_t *d_giant = nullptr;                                    // giant rows: vertex list [n_giant] | first slices [n_giant + 1]
@@ -114,6 +117,7 @@ struct hspf_graph {
     d_unit_first = (uint32_t *)carve((size_t(nv) / 4 + 8) * 4);
     d_giant = (uint32_t *)carve((size_t(cap) / (GIANT_DEG / 2) + 8) * 4);
     d_ell_so = (uint32_t *)carve((size_t(nv) + 1) * 64); d_ell_w = (uint32_t *)carve((size_t(nv) + 1) * 64); d_ell_od = (uint32_t *)carve((size_t(nv) + 1) * 64);
+    d_zcyc = (uint8_t *)carve(nv); d_zcyc_tmp = (uint8_t *)carve(nv);
     return off;
   }
   GraphDev dev() const {
@@ -121,6 +125,7 @@ struct hspf_graph {
     g.n = n; g.e_in = e_kept;
     g.in_ptr = d_in_ptr; g.in_src = d_in_src; g.in_w = d_in_w; g.in_fpos = d_in_fpos;
     g.vflags = d_vflags; g.rowflags = d_rowflags; g.leaf = d_leaf;
+    g.zcyc = (zcyc_valid && n_zero_rows) ? d_zcyc : nullptr;
     g.out_ptr = d_out_ptr; g.out_dst = d_out_dst; g.out_w = d_out_w; g.out_fpos = d_out_fpos;
     for (int x = 0; x < 9; ++x) g.xcd_start[x] = xcd_start[x];
     g.unit_first = n_heavy_chunks ? d_unit_first : nullptr;
@@ -154,6 +159,9 @@ struct hspf_ctx {
   size_t h_stage_cap = 0;                            // bytes (both blocks)
   hipEvent_t ev_stage[2] = {};
   DevBuf ex_list, ex_heap, ex_pos;
+  DevBuf dyn_part;                                   // FusedGraph::dyn_part: DYN_PARTS partial LF_DYN arrays of the lane = root sweeps
+  DevBuf rp_z, rp_ord, rp_work, rp_status;          // k_repair (spf_repair.hip.h): zero-cost marks + list, (R, pos), stamps + worklists, status
+  uint32_t *h_rp = nullptr; size_t h_rp_cap = 0;    // pinned: the roots' repair status words
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
   bool pf_shadow_ok = false;                        // the device holds a plain table; what it was uploaded from (HSPF_PFX_RESIDENT):
   uint32_t pf_shadow_nv = 0, pf_res_np = 0, pf_res_ne = 0;
@@ -398,6 +406,30 @@ void finish_summary(hspf_graph *g) {
   g->lean_bad = false;
 }
 
+// GraphDev::zcyc after a build or a patch: only graphs with a zero-cost link from a higher- or equal-numbered source need it
+// (n_zero_rows), hop-count graphs have their own rule.  A handful of small launches, then the stream is drained: runs on other
+// streams (lanes, other contexts) must see the array.
+int zcyc_update(hspf_ctx *ctx, hspf_graph *g) {
+  g->zcyc_valid = false;
+  if (g->n_zero_rows == 0 || g->n == 0) return HSPF_OK;
+  hipStream_t s = ctx->stream;
+  const uint32_t n = g->n;
+  const dim3 gn((n + GB_BLOCK - 1) / GB_BLOCK);
+  static_assert(GB_ZC_ROUNDS % 2 == 0, "the last round writes d_zcyc");
+  hipLaunchKernelGGL(kb_zc_init, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_w, (const uint32_t *)g->d_out_ptr,
+                     (const uint32_t *)g->d_out_w, g->d_zcyc);
+  for (int r = 0; r < GB_ZC_ROUNDS; ++r) {
+    const uint8_t *a = (r & 1) ? g->d_zcyc_tmp : g->d_zcyc;
+    uint8_t *b = (r & 1) ? g->d_zcyc : g->d_zcyc_tmp;
+    hipLaunchKernelGGL(kb_zc_round, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src, (const uint32_t *)g->d_in_w,
+                       (const uint32_t *)g->d_out_ptr, (const uint32_t *)g->d_out_dst, (const uint32_t *)g->d_out_w, a, b);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  g->zcyc_valid = true;
+  return HSPF_OK;
+}
+
 // build_launch enqueues the whole build (and the read-back of its counts) on the ctx stream and returns; build_finish
 // waits for it and derives the host-side summary.  hspf_graph_patch does its host work (mirrors, two-way flags) between
 // the two, behind the kernels.
@@ -569,6 +601,8 @@ int build_finish(hspf_ctx *ctx, hspf_graph *g, bool hub, const BuildScratch &bs,
   g->any_net = g->n_net != 0;
   finish_summary(g);
   lap("host summary");
+  { const int zr = zcyc_update(ctx, g); if (zr != HSPF_OK) return zr; }
+  lap("zero-cost cycles");
   return HSPF_OK;
 }
 
@@ -700,12 +734,13 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag, &ctx->xcd_ctl})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->dyn_part, &ctx->rp_z, &ctx->rp_ord, &ctx->rp_work, &ctx->rp_status, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag, &ctx->xcd_ctl})
     release(*b);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (auto &e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
   if (ctx->h_changed) (void)hipHostFree(ctx->h_changed);
   if (ctx->h_lane_flags) (void)hipHostFree(ctx->h_lane_flags);
+  if (ctx->h_rp) (void)hipHostFree(ctx->h_rp);
   if (ctx->h_patch) (void)hipHostFree(ctx->h_patch);
   if (ctx->h_up) (void)hipHostFree(ctx->h_up);
   release(ctx->up);
@@ -885,6 +920,7 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
         g->n_bad_rows = (uint32_t)((int64_t)g->n_bad_rows + pi.d_bad);
         g->any_rowflags = (g->any_rowflags & ~RF_ZERO) | (g->n_zero_rows ? RF_ZERO : 0u);
         finish_summary(g);
+        { const int zr = zcyc_update(ctx, g); if (zr != HSPF_OK) return zr; }     // (a no-op unless the graph has zero-cost links from higher-numbered sources)
         g->costs_only = true;
         ctx->prefill.valid = false;
         return HSPF_OK;
@@ -1144,6 +1180,7 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
     case HSPF_GX_ELL_OUT: src = g->d_ell_od; bytes = ((size_t)g->n + 1) * 64; break;
     case HSPF_GX_SUMMARY: bytes = 48; break;                         // host values
     case HSPF_GX_LEAF: src = g->d_leaf; bytes = g->n; break;
+    case HSPF_GX_ZCYC: src = g->d_zcyc; bytes = (g->zcyc_valid && g->n_zero_rows) ? g->n : 0; break;
     case HSPF_GX_UNITS: src = g->d_unit_first; bytes = g->n_heavy_chunks ? ((size_t)g->n_heavy_chunks * 3 + (g->n + 15u) / 16u) * 4 : 0; break;
     default: ctx->last_error = "hspf_graph_export: unknown array"; return HSPF_E_INVAL;
   }
@@ -1298,6 +1335,8 @@ struct Run {
   uint32_t last_esz = 0, last_ns = 0, last_fillw = 0xFFFFFFFFu, spec_nz = 0;
   bool spec_done = false, emit_reset = false;
   std::vector<uint32_t> ex;            // roots of the sequential kernel
+  std::vector<uint32_t> dy;            // roots with a dynamic pop order whose rows k_repair put right (spf_repair.hip.h)
+  std::vector<uint32_t> oob;           // dy ++ ex: the rows that did not come out of the emit as they are (device copy: ctx->ex_list)
   // packed results
   bool pk_full = false;
   int pk_mode = -1;                    // which fused_run produced the words: 2 lean, 1 narrow, 0 wide; -1: k_pack_full (wide layout)
@@ -1326,6 +1365,7 @@ struct Run {
   int single_run();
   int path_fused();
   int path_wide();
+  int repair_roots();
   int exact_roots();
   int packed_finish();
   int deliver();
@@ -1457,6 +1497,7 @@ int Run::prepare_scratch() {
     if ((rc = ensure(ctx, ctx->stamp, (size_t)B * n * 4))) return rc;
   }
   if ((rc = ensure(ctx, ctx->lane_flags, (size_t)L * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->dyn_part, (size_t)DYN_PARTS * L * 4))) return rc;
   if ((rc = ensure(ctx, ctx->changed, (size_t)CHANGED_CAP * 4))) return rc;
   // upload block (u32 words): roots[L] | tab_ptr[L+1] | tab_vtx[nv] | tab_base[nv] | row_map[L] | pad to 16 B | FusedGraph
   const size_t nv = tab_vtx.size();
@@ -1582,7 +1623,8 @@ int Run::upload_block() {
     std::copy(tab_vtx.begin(), tab_vtx.end(), h + w_vtx);
     std::copy(tab_base.begin(), tab_base.end(), h + w_base);
     for (uint32_t r = 0; r < L; ++r) h[w_map + r] = (row_map && r < n_roots) ? row_map[r] : r;
-    const FusedGraph fg{gd, tabs, d_kcnt, giant ? (uint32_t *)ctx->giant_part.p : (uint32_t *)nullptr};
+    const FusedGraph fg{gd, tabs, d_kcnt, giant ? (uint32_t *)ctx->giant_part.p : (uint32_t *)nullptr,
+                        (g->n_zero_rows && !g->hopcount_like) ? (uint32_t *)ctx->dyn_part.p : (uint32_t *)nullptr, L};
     memcpy(h + w_fg, &fg, sizeof(FusedGraph));
     // An SPF instance repeats its runs (same graph, same roots): when the block is byte for byte the one the device
     // already holds — same allocation, nothing in it is ever written by a kernel — the copy is skipped (HSPF_VARIANT bit
@@ -1743,6 +1785,8 @@ int Run::fused_run(int mode) {
       on_retry = nullptr;
       if (use_lean) on_retry = [&]() { hipLaunchKernelGGL(k_clear_lane_flag, dim3((L + 255) / 256), dim3(256), 0, s, d_lf, L, (uint32_t)LF_OVERFLOW); };
       if (giant && hipMemsetAsync(ctx->giant_part.p, 0, giant_tags * 4, s) != hipSuccess) { ctx->last_error = "giant tags"; return HSPF_E_HIP; }
+      const bool dyn_parts = g->n_zero_rows && !g->hopcount_like;      // FusedGraph::dyn_part is in use
+      if (dyn_parts && hipMemsetAsync(ctx->dyn_part.p, 0, (size_t)DYN_PARTS * L * 4, s) != hipSuccess) { ctx->last_error = "dyn partials"; return HSPF_E_HIP; }
       if (nar) hipLaunchKernelGGL((k_init_fused<uint32_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, (uint32_t *)d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L, ns);
       else     hipLaunchKernelGGL((k_init_fused<uint64_t>), dim3((L + 3) / 4), dim3(256), 0, s, gd, d_st, d_stamp, (uint8_t *)ctx->hnb.p, d_roots, tabs, L, ns);
       uint32_t n_f = 0;
@@ -1833,6 +1877,7 @@ int Run::fused_run(int mode) {
         // results out of the packed state (speculative: valid when this chunk reached the fixed point and, for the
         // 4-byte state, no lane overflowed; otherwise redone behind the next chunk / the wide run)
         (void)hipEventRecord(ctx->ev[2], s);
+        if (dyn_parts) hipLaunchKernelGGL(k_lf_reduce, dim3((L + 255) / 256), dim3(256), 0, s, d_lf, (const uint32_t *)ctx->dyn_part.p, L);
         // (with the speculative fill on, the emit resets the tiles it has read: first half of the next run's scratch fill)
         const int rg = spec_fill ? (int)chunk_last : -1;
         emit_reset = rg >= 0;
@@ -1956,7 +2001,7 @@ int Run::xcd_run() {
     for (uint32_t w = 0; w < n_wg; ++w) {
       const uint32_t x = h_st[r * XCD_MAX_WG + w];
       if (!(x & XCD_ST_DONE) || (x & XCD_ST_ABORT)) gave_up = true;
-      ctx->h_lane_flags[r] |= x & (LF_NEED_EXACT | LF_OVERFLOW);
+      ctx->h_lane_flags[r] |= x & (LF_NEED_EXACT | LF_OVERFLOW | LF_DYN);
       sweeps = std::max(sweeps, (x >> 8) & 0xFFFFu);
       if (((x ^ h_st[r * XCD_MAX_WG]) >> 24) & 15u) st.dbg[1] |= 0x80000000u;   // the root's workgroups did not share an XCD (a run that finished is right all the same)
     }
@@ -2203,15 +2248,98 @@ int Run::path_wide() {
   return HSPF_OK;
 }
 
-// Roots whose pop order is dynamic (or forced): the sequential exact kernel (status bits: last run_phase).
-int Run::exact_roots() {
-  // ---- roots whose pop order is dynamic (or forced): sequential exact kernel (status bits: last run_phase)
-  ex.clear();
-  for (uint32_t r = 0; r < n_roots; ++r) {
-    const bool forced = (run_flags & (HSPF_RUN_FORCE_EXACT | HSPF_RUN_POP_RANK)) != 0;
-    if (roots[r] != HSPF_NO_ROOT && (forced || (ctx->h_lane_flags[r] & LF_NEED_EXACT))) ex.push_back(r);
+// Roots whose pop order is dynamic (LF_DYN: a vertex whose only way in is a zero-cost link from a higher-numbered source): their
+// distances are final; hops and first-hop masks are recomputed in the true pop order on the row-major tables, one workgroup per
+// root (spf_repair.hip.h).  Roots it cannot take (a group larger than the walk's list, tables the caller left out) join `ex`.
+int Run::repair_roots() {
+  if (dy.empty()) return HSPF_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  const uint32_t nd = (uint32_t)dy.size();
+  if ((rc = ensure(ctx, ctx->ex_list, (size_t)n_roots * 4, false))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ex_list.p, dy.data(), (size_t)nd * 4, hipMemcpyHostToDevice, s));
+  if (pk && !pk_full) {                                            // packed words straight out of the fused emit: the rows of these roots back into tables
+    if ((rc = pk_staging())) return rc;
+    od.dist = (uint32_t *)ctx->o_dist.p; od.hops = (uint16_t *)ctx->o_hops.p; od.flags = (uint16_t *)ctx->o_flags.p; od.mask = (uint64_t *)ctx->o_mask.p;
+    const FusedParams PP = pk_mode == 2 ? fp_lean : pk_mode == 1 ? fp_narrow : fp_wide;
+    const dim3 ug((n + 255u) / 256u, nd);
+    if (pk_mode == 2 || pk_mode == 1) hipLaunchKernelGGL((kr_unpack_rows<4>), ug, dim3(256), 0, s, n, nd, (const uint32_t *)ctx->ex_list.p, (const void *)pk_dev(4), PP, od.dist, od.hops, od.flags, od.mask);
+    else                              hipLaunchKernelGGL((kr_unpack_rows<8>), ug, dim3(256), 0, s, n, nd, (const uint32_t *)ctx->ex_list.p, (const void *)pk_dev(8), PP, od.dist, od.hops, od.flags, od.mask);
   }
+  const size_t zl_off = ((size_t)n + 255u) & ~(size_t)255u;        // [zflag: n bytes | zl: n words | nz]
+  if ((rc = ensure(ctx, ctx->rp_z, zl_off + ((size_t)n + 1u) * 4, false))) return rc;
+  if ((rc = ensure(ctx, ctx->rp_ord, (size_t)nd * n * 8, false))) return rc;
+  if ((rc = ensure(ctx, ctx->rp_work, (size_t)nd * n * 12, false))) return rc;
+  if ((rc = ensure(ctx, ctx->rp_status, (size_t)nd * 44, false))) return rc;
+  if (ctx->h_rp_cap < (size_t)nd * 11) {
+    if (ctx->h_rp) (void)hipHostFree(ctx->h_rp);
+    ctx->h_rp = nullptr; ctx->h_rp_cap = 0;
+    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_rp, ((size_t)nd * 11 + 704) * 4, hipHostMallocDefault));
+    ctx->h_rp_cap = (size_t)nd * 11 + 704;
+  }
+  uint8_t *zflag = (uint8_t *)ctx->rp_z.p;
+  uint32_t *zl = (uint32_t *)((char *)ctx->rp_z.p + zl_off), *nz = zl + n;
+  HIPCHK(ctx, hipMemsetAsync(zflag, 0, n, s));
+  HIPCHK(ctx, hipMemsetAsync(nz, 0, 4, s));
+  HIPCHK(ctx, hipMemsetAsync(ctx->rp_work.p, 0, (size_t)nd * n * 4, s));                      // the stamps
+  if (gd.e_in) hipLaunchKernelGGL(kr_zmark, dim3((gd.e_in + 255u) / 256u), dim3(256), 0, s, gd.e_in, gd.out_dst, gd.out_w, zflag);
+  hipLaunchKernelGGL(kr_zcompact, dim3((n + 255u) / 256u), dim3(256), 0, s, n, (const uint8_t *)zflag, zl, nz);
+  RepairArgs a{};
+  a.g = gd; a.root_list = (const uint32_t *)ctx->ex_list.p; a.roots = d_roots; a.n_dyn = nd; a.net_nexthops = net_nh; a.ignore_ovl = ignore_ovl;
+  a.tabs = tabs; a.dist = od.dist; a.hops = od.hops; a.flags = od.flags; a.mask = od.mask; a.words = out_words; a.row_map = od.row_map;
+  a.zflag = zflag; a.zl = zl; a.nz = nz;
+  a.R = (uint32_t *)ctx->rp_ord.p; a.pos = a.R + (size_t)nd * n;
+  a.stamp = (uint32_t *)ctx->rp_work.p; a.wl = a.stamp + (size_t)nd * n;
+  a.status = (uint32_t *)ctx->rp_status.p; a.pop_rank = nullptr;
+  if (out_words <= 1)      hipLaunchKernelGGL((k_repair<1>), dim3(nd), dim3(RP_THREADS), 0, s, a);
+  else if (out_words <= 2) hipLaunchKernelGGL((k_repair<2>), dim3(nd), dim3(RP_THREADS), 0, s, a);
+  else if (out_words <= 4) hipLaunchKernelGGL((k_repair<4>), dim3(nd), dim3(RP_THREADS), 0, s, a);
+  else                     hipLaunchKernelGGL((k_repair<16>), dim3(nd), dim3(RP_THREADS), 0, s, a);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_rp, ctx->rp_status.p, (size_t)nd * 44, hipMemcpyDeviceToHost, s));
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  if (getenv("HSPF_REPAIR_PROF")) {
+    const uint32_t *t = ctx->h_rp + 3 * nd;                         // the first root's workgroup
+    fprintf(stderr, "[hspf k_repair] %u roots, n %u, zero-cost rows %u: seeds %.1f us, R %.1f, walks %.1f, first worklist %.1f, sweeps %.1f (%u sweeps, %u evaluations, %u groups); host %.1f us\n", nd, n, t[5],
+            t[0] / 100.0, t[1] / 100.0, t[2] / 100.0, t[3] / 100.0, t[4] / 100.0, ctx->h_rp[0] >> 8, ctx->h_rp[nd], ctx->h_rp[2 * nd] & 0xFFFFu,
+            std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
+  std::vector<uint32_t> ok;
+  for (uint32_t j = 0; j < nd; ++j) {
+    const uint32_t x = ctx->h_rp[j];
+    if (x & RP_ST_FAIL) { ex.push_back(dy[j]); continue; }
+    ok.push_back(dy[j]);
+    st.repair_sweeps = std::max(st.repair_sweeps, x >> 8);
+    st.repair_evals += ctx->h_rp[nd + j];
+    st.repair_groups += ctx->h_rp[2 * nd + j] & 0xFFFFu;
+  }
+  dy.swap(ok);
+  std::sort(ex.begin(), ex.end());
+  st.n_repaired_roots = (uint32_t)dy.size();
+  st.ms_repair = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return HSPF_OK;
+}
+
+// Roots that need the literal sequential loop (u32 saturation, HSPF_RUN_FORCE_EXACT / HSPF_RUN_POP_RANK, what k_repair handed
+// back): k_exact (status bits: last run_phase).
+int Run::exact_roots() {
+  ex.clear(); dy.clear(); oob.clear();
+  const bool forced = (run_flags & (HSPF_RUN_FORCE_EXACT | HSPF_RUN_POP_RANK)) != 0;
+  const bool tables = pk || (od.hops && od.flags && od.mask);      // everything k_repair reads and writes is there
+  for (uint32_t r = 0; r < n_roots; ++r) {
+    if (roots[r] == HSPF_NO_ROOT) continue;
+    const uint32_t lf = ctx->h_lane_flags[r];
+    if (forced || (lf & LF_NEED_EXACT)) ex.push_back(r);
+    else if (lf & LF_DYN) {
+      if (!pk && !od.hops && !od.mask) continue;                     // distances only: they are final as they are
+      if (tables && !(ctx->variant & (1u << 27))) dy.push_back(r); else ex.push_back(r);      // (HSPF_VARIANT bit 27: k_exact as before round 6 — tests, A/B)
+    }
+  }
+  if ((rc = repair_roots())) return rc;
+  oob = dy; oob.insert(oob.end(), ex.begin(), ex.end());
   st.n_exact_roots = (uint32_t)ex.size();
+  if (!oob.empty()) {
+    if ((rc = ensure(ctx, ctx->ex_list, (size_t)n_roots * 4, false))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ex_list.p, oob.data(), oob.size() * 4, hipMemcpyHostToDevice, s));
+  }
   if (!ex.empty()) {
     // k_exact needs all four result arrays; use staging for the ones the caller skipped.
     ExactArgs a{};
@@ -2226,11 +2354,9 @@ int Run::exact_roots() {
     if (!a.hops) { if ((rc = ensure(ctx, ctx->o_hops, rn * 2))) return rc; a.hops = (uint16_t *)ctx->o_hops.p; }
     if (!a.flags) { if ((rc = ensure(ctx, ctx->o_flags, rn * 2))) return rc; a.flags = (uint16_t *)ctx->o_flags.p; }
     if (!a.mask) { if ((rc = ensure(ctx, ctx->o_mask, rn * 8 * out_words))) return rc; a.mask = (uint64_t *)ctx->o_mask.p; }
-    if ((rc = ensure(ctx, ctx->ex_list, ex.size() * 4))) return rc;
     if ((rc = ensure(ctx, ctx->ex_heap, ex.size() * (size_t)n * 4))) return rc;
     if ((rc = ensure(ctx, ctx->ex_pos, ex.size() * (size_t)n * 4))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->ex_list.p, ex.data(), ex.size() * 4, hipMemcpyHostToDevice, s));
-    a.root_list = (const uint32_t *)ctx->ex_list.p;
+    a.root_list = (const uint32_t *)ctx->ex_list.p + dy.size();
     a.heap = (uint32_t *)ctx->ex_heap.p; a.pos = (uint32_t *)ctx->ex_pos.p;
     hipLaunchKernelGGL(k_exact, dim3((a.n_exact + 63) / 64), dim3(64), 0, s, a);
   }
@@ -2251,8 +2377,8 @@ int Run::packed_finish() {
   if (pk) {
     const FusedParams PP = pk_mode == 2 ? fp_lean : pk_mode == 1 ? fp_narrow : fp_wide;
     pk_esz = (pk_mode == 2 || pk_mode == 1) ? 4 : 8;
-    if (pk_full || !ex.empty()) {
-      const uint32_t nrows = pk_full ? n_roots : (uint32_t)ex.size();
+    if (pk_full || !oob.empty()) {
+      const uint32_t nrows = pk_full ? n_roots : (uint32_t)oob.size();
       const uint32_t *rows_list = pk_full ? (const uint32_t *)nullptr : (const uint32_t *)ctx->ex_list.p;
       const dim3 pg((n + 255u) / 256u, nrows);
       if (pk_esz == 4) hipLaunchKernelGGL((k_pack_full<4>), pg, dim3(256), 0, s, n, nrows, rows_list, (const uint32_t *)od.dist, (const uint16_t *)od.hops, (const uint16_t *)od.flags, (const uint64_t *)od.mask, 1u, PP, (void *)pk_dev(4), d_misfit);
@@ -2266,10 +2392,10 @@ int Run::packed_finish() {
     ly.not_reached = pk_esz == 4 ? (uint64_t)PP.inf_t : ~0ull;
     if (pk->root_status) {
       for (uint32_t r = 0; r < n_roots; ++r) pk->root_status[pk->row_off + r] = 0;
-      for (uint32_t r : ex) pk->root_status[pk->row_off + r] = HSPF_ROOT_EXACT;
+      for (uint32_t r : oob) pk->root_status[pk->row_off + r] = HSPF_ROOT_EXACT;
     }
   }
-  finished = tail_done && ex.empty() && !host_out && !pk_full && !((run_flags & HSPF_RUN_POP_RANK) && d_rank);
+  finished = tail_done && oob.empty() && !host_out && !pk_full && !((run_flags & HSPF_RUN_POP_RANK) && d_rank);
   if (!finished) HIPCHK(ctx, hipEventRecord(ctx->ev[4], s));
   return HSPF_OK;
 }
@@ -2295,7 +2421,7 @@ int Run::deliver() {
   }
   if (host_out) HIPCHK(ctx, hipEventRecord(ctx->ev[5], s));
   if (!finished) HIPCHK(ctx, hipStreamSynchronize(s));
-  if (pk && (pk_full || !ex.empty()) && ctx->h_lane_flags[L + 256 + LEAN_CTL_WORDS] != 0u) {
+  if (pk && (pk_full || !oob.empty()) && ctx->h_lane_flags[L + 256 + LEAN_CTL_WORDS] != 0u) {
     ctx->last_error = "packed results: a value of a row from the one-workgroup / lane = vertex / sequential kernel does not fit the run's fields";
     return HSPF_E_NO_PACKED;
   }
@@ -2371,7 +2497,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
           else if (memcmp(&first, &part.layout, sizeof(first)) != 0) { again = true; break; }
           const hspf_stats &p = ctx->stats;
           acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
-          acc.n_exact_roots += p.n_exact_roots; acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
+          acc.n_exact_roots += p.n_exact_roots; acc.n_repaired_roots += p.n_repaired_roots; acc.repair_sweeps = std::max(acc.repair_sweeps, p.repair_sweeps); acc.repair_evals += p.repair_evals; acc.repair_groups += p.repair_groups; acc.ms_repair += p.ms_repair; acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
           acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_finish += p.ms_finish; acc.ms_d2h += p.ms_d2h;
           acc.state_bytes = std::max(acc.state_bytes, p.state_bytes); acc.narrow_overflow += p.narrow_overflow; acc.rows_recomputed += p.rows_recomputed;
         }
@@ -2396,7 +2522,7 @@ static int run_impl(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots, u
         if (rc) return rc;
         const hspf_stats &p = ctx->stats;
         acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
-        acc.n_dag_launches += p.n_dag_launches; acc.n_exact_roots += p.n_exact_roots;
+        acc.n_dag_launches += p.n_dag_launches; acc.n_exact_roots += p.n_exact_roots; acc.n_repaired_roots += p.n_repaired_roots; acc.repair_sweeps = std::max(acc.repair_sweeps, p.repair_sweeps); acc.repair_evals += p.repair_evals; acc.repair_groups += p.repair_groups; acc.ms_repair += p.ms_repair;
         acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
         acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
         acc.ms_d2h += p.ms_d2h; acc.state_bytes = std::max(acc.state_bytes, p.state_bytes);
@@ -2549,7 +2675,7 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     if (rc) { if (!rc_first) rc_first = rc; continue; }          // (every submitted class is collected before the call returns)
     const hspf_stats &p = cls_ticket[c] ? lane_st : ctx->stats;
     acc.n_roots += p.n_roots; acc.n_batches += p.n_batches; acc.n_relax_launches += p.n_relax_launches;
-    acc.n_dag_launches += p.n_dag_launches; acc.n_exact_roots += p.n_exact_roots;
+    acc.n_dag_launches += p.n_dag_launches; acc.n_exact_roots += p.n_exact_roots; acc.n_repaired_roots += p.n_repaired_roots; acc.repair_sweeps = std::max(acc.repair_sweeps, p.repair_sweeps); acc.repair_evals += p.repair_evals; acc.repair_groups += p.repair_groups; acc.ms_repair += p.ms_repair;
     acc.n_mask_words = std::max(acc.n_mask_words, p.n_mask_words);
     acc.ms_total += p.ms_total; acc.ms_relax += p.ms_relax; acc.ms_dag += p.ms_dag; acc.ms_finish += p.ms_finish;
     acc.state_bytes = std::max(acc.state_bytes, p.state_bytes); acc.narrow_overflow += p.narrow_overflow;

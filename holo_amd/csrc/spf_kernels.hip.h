@@ -43,6 +43,8 @@ constexpr uint32_t HV_EPOCH_MAX = 0xFFFFu;
 // per-root (lane) status bits
 constexpr uint32_t LF_NEED_EXACT = 1u;   // static pop order not provable / saturation: use k_exact
 constexpr uint32_t LF_OVERFLOW = 2u;     // narrow fused state could not hold a value: redo the run wide
+constexpr uint32_t LF_DYN = 4u;          // the pop order of this root is dynamic (a vertex whose only way in is a zero-cost link from a
+                                         // higher-numbered source): distances are final, hops / masks are repaired by k_repair (spf_repair.hip.h)
 
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int VPW = 4;                    // vertices per wave per block
@@ -62,6 +64,11 @@ struct GraphDev {
   // point: its row is evaluated once, from its neighbour's final state, inside the emit (k_emit<W, true>), and a link
   // FROM a leaf only counts in the lane whose root the leaf is (k_fw<.., LEAF>).  The definition does not depend on costs.
   const uint8_t *leaf;      // [n] 1 = leaf
+  // zcyc[v] = 1: v may lie on a CYCLE of zero-cost kept links (it survives the rounds of kb_zc_round, graph_build.hip.h);
+  // null: the graph has no zero-cost link from a higher- or equal-numbered source.  A zero-cost link u -> v, u >= v, is SAFE
+  // unless zcyc[u] && zcyc[v]: a safe one may feed v's hops / mask when it is v's only way in (finish_row_z) without ever
+  // closing a cycle of dependencies among the rows of a sweep.
+  const uint8_t *zcyc;
   // forward CSR (kept links only) for k_exact
   const uint32_t *out_ptr;  // [n+1]
   const uint32_t *out_dst;  // [e_in]
@@ -433,8 +440,8 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
       }
       if (need && !anyp) {
         // In the SPT but no parent precedes it in static order: the reference's pop order is
-        // dynamic here (zero-cost plateau).  Hand the whole root to k_exact.
-        atomicOr(&lane_flags[root_slot], LF_NEED_EXACT);
+        // dynamic here (zero-cost plateau).  Placeholder; k_repair recomputes hops / masks of the root in the true order.
+        atomicOr(&lane_flags[root_slot], LF_DYN);
         out_hv = 0; done = true;
 #pragma unroll
         for (int k = 0; k < W; ++k) m[k] = 0;
@@ -498,7 +505,25 @@ __global__ __launch_bounds__(256) void k_dag(GraphDev g, const uint32_t *__restr
 // (profiles/r02_notes.md: 0.93 vs 0.85 ms per batch).
 // giant_part: [tags: batches x n_giant, padded to 64 words | accumulators: batches x slices x GIANT_WORDS x 64 lanes]; a tag
 // holds sweep + 1 of the sweep whose k_giant_part filled the row's slices for that batch (0: never)
-struct FusedGraph { GraphDev g; SlotTabs tabs; uint32_t *rows_done; uint32_t *giant_part; };   // device-resident descriptor of one run
+// dyn_part (round 6): LF_DYN of the lane = root sweeps goes to one of DYN_PARTS partial status arrays [DYN_PARTS][dyn_L] (null: straight
+// to lane_flags): on a graph with 1 % zero-cost links 5 000 waves per pass each raised the SAME 64 words — atomics on one address
+// retire at ~10 ns apiece, whoever issues them, and a 20 us dense pass took 80.  k_lf_reduce folds them into lane_flags.
+constexpr uint32_t DYN_PARTS = 64u;
+struct FusedGraph { GraphDev g; SlotTabs tabs; uint32_t *rows_done; uint32_t *giant_part; uint32_t *dyn_part; uint32_t dyn_L; };   // device-resident descriptor of one run
+__device__ __forceinline__ void raise_dyn(const FusedGraph *gp, uint32_t *lane_flags, uint32_t root_slot, uint32_t wave_id) {
+  uint32_t *dp = gp->dyn_part;
+  if (dp) {
+    uint32_t *w = dp + (size_t)(wave_id & (DYN_PARTS - 1u)) * gp->dyn_L + root_slot;
+    if (!(*(volatile uint32_t *)w & LF_DYN)) atomicOr(w, LF_DYN);
+  } else atomicOr(&lane_flags[root_slot], LF_DYN);
+}
+__global__ void k_lf_reduce(uint32_t *__restrict__ lane_flags, const uint32_t *__restrict__ part, uint32_t L) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L) return;
+  uint32_t x = 0;
+  for (uint32_t k = 0; k < DYN_PARTS; ++k) x |= part[(size_t)k * L + i];
+  if (x) lane_flags[i] |= x;
+}
 
 struct FusedParams {
   uint32_t sh;        // bit position of the dist field (narrow) / 0 (wide: dist is the high word)
@@ -555,7 +580,7 @@ template <> struct StIO<uint32_t> {
 };
 
 struct RowAcc { uint32_t bd, bm, bpd, bh; bool sat; };
-template <typename ST> struct RowOut { ST nw; bool sat, need_exact, ovf; };
+template <typename ST> struct RowOut { ST nw; bool sat, dyn, ovf; };
 
 template <typename ST, bool MAXINF>
 __device__ __forceinline__ void acc_link(RowAcc &a, const typename StIO<ST>::Raw &q, uint32_t wkey, const FusedParams &P) {
@@ -588,9 +613,33 @@ __device__ __forceinline__ RowOut<ST> finish_row(const RowAcc &a, uint32_t v, ui
     o.ovf = o.ovf || a.bd >= P.ovf_t;
     o.nw = StIO<ST>::join(a.bd, hops, a.bm & ((1u << P.mbits) - 1u), P);
   }
-  // a shorter (or the only) way in through a zero-cost link from a higher-numbered source: the
-  // reference's pop order is dynamic there -> whole root goes to k_exact
-  o.need_exact = v != my_root && bd_all < P.inf_t && bd_all <= P.maxkey && bd_all < a.bd;
+  // a shorter (or the only) way in through a zero-cost link from a higher-numbered source: the reference's pop order is
+  // dynamic there.  The DISTANCE is order-independent and is stored (so that everything downstream converges to its final
+  // distance too); hops and mask of this vertex and of whatever hangs below it are placeholders — the root is flagged
+  // LF_DYN and k_repair (spf_repair.hip.h) recomputes them in the true pop order on the emitted tables.
+  o.dyn = v != my_root && bd_all < P.inf_t && bd_all <= P.maxkey && bd_all < a.bd;
+  if (o.dyn) {
+    o.ovf = o.ovf || bd_all >= P.ovf_t;
+    o.nw = StIO<ST>::join(bd_all, 0u, 0u, P);
+  }
+  return o;
+}
+
+// A zero-cost link from a higher- or equal-numbered source (u >= v, cost 0) is never a parent in the STATIC order — unless it
+// is the row's only way in: then v enters the candidate list when the first such source is popped and, its index being the
+// lower one, is popped right after it: ONE parent, the lowest-numbered one (rows list equal costs by ascending source), no
+// union — the rule hop-count graphs have always used (fused_row_any).  Round 6 applies it to every graph, for the links that
+// are SAFE (GraphDev::zcyc: not inside a possible cycle of zero-cost links, so the dependencies of a sweep stay acyclic and the
+// fixed point unique); an unsafe one still only feeds the distance (bd_all).  Either way the root is flagged LF_DYN: the rule
+// is exact only while every vertex involved is released in index order, and k_repair checks that in the true order.
+__device__ __forceinline__ bool zlink_unsafe(const uint8_t *zcyc, uint32_t u, uint32_t v) { return !zcyc || (zcyc[u] && zcyc[v]); }
+template <typename ST>
+__device__ __forceinline__ RowOut<ST> finish_row_z(RowAcc &a, uint32_t v, uint32_t my_root, uint32_t v_router, uint32_t bd_all,
+                                                   uint32_t zb, uint32_t zm, uint32_t zh, bool hc, const FusedParams &P) {
+  const bool late = zb < a.bd;                                      // strictly better through the zero-cost links
+  a.bm = late ? zm : a.bm; a.bh = late ? zh : a.bh; a.bd = late ? zb : a.bd;
+  RowOut<ST> o = finish_row<ST>(a, v, my_root, v_router, bd_all, P);
+  o.dyn = o.dyn || (!hc && late && v != my_root && a.bd < P.inf_t && a.bd <= P.maxkey);
   return o;
 }
 
@@ -753,8 +802,8 @@ __device__ __forceinline__ void row_any_chunk(AnyAcc &x, const GraphDev &g, __am
       const uint32_t c = add_sat(d, w);
       if (MAXINF && sizeof(ST) == 8 && c == INF && d != INF && w != INF) a.sat = true;
       const bool zlink = has_z && rdlane(zv, j) != 0u;            // uniform
-      if (zlink && !HC) { x.bd_all = min(x.bd_all, c); continue; }
-      const bool lt = (HC && zlink) ? (c < x.zb) : (c < a.bd), eq = !(HC && zlink) && c == a.bd;
+      if (zlink && !HC && zlink_unsafe(g.zcyc, sw & SRC_MASK, v)) { x.bd_all = min(x.bd_all, c); continue; }
+      const bool lt = zlink ? (c < x.zb) : (c < a.bd), eq = !zlink && c == a.bd;
       const uint32_t hh = pay >> P.mbits;
       uint32_t contrib = pay & ((1u << P.mbits) - 1u);
       const bool direct = (lt || eq) && hh == 0u && c < P.inf_t;  // parent: root or hops-0 network
@@ -767,8 +816,8 @@ __device__ __forceinline__ void row_any_chunk(AnyAcc &x, const GraphDev &g, __am
           contrib = ((v_router || net_nexthops) && sidx < P.mbits) ? (1u << sidx) : 0u;
         }
       }
-      if (HC && zlink) {
-        // Hop-count-like graph (holo-isis MetricMode::HopCount, spf.rs:1138-1145): a network whose
+      if (zlink) {
+        // (every graph since round 6, for SAFE links: finish_row_z)  Hop-count-like graph (holo-isis MetricMode::HopCount, spf.rs:1138-1145): a network whose
         // only way in is a zero-cost link from routers of the same distance is put on the candidate
         // list by the FIRST of them to be popped — the lowest-numbered one, rows list equal-cost links
         // by ascending source — and, its own index being lower than any router's, is popped next:
@@ -789,14 +838,7 @@ __device__ __forceinline__ void row_any_chunk(AnyAcc &x, const GraphDev &g, __am
 template <typename ST, bool HC>
 __device__ __forceinline__ RowOut<ST> any_finish(AnyAcc &x, uint32_t v, uint32_t my_root, uint32_t v_router,
                                                  const FusedParams &P) {
-  RowAcc &a = x.a;
-  if (HC) {                                 // late vertex: strictly better through the zero-cost links
-    const bool late = x.zb < a.bd;
-    a.bm = late ? x.zm : a.bm;
-    a.bh = late ? x.zh : a.bh;
-    a.bd = late ? x.zb : a.bd;
-  }
-  return finish_row<ST>(a, v, my_root, v_router, x.bd_all, P);
+  return finish_row_z<ST>(x.a, v, my_root, v_router, x.bd_all, x.zb, x.zm, x.zh, HC, P);
 }
 
 template <typename ST, bool MAXINF, bool HC, int PFN>
@@ -994,7 +1036,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   const __amdgpu_buffer_rsrc_t rsrc_od = st_rsrc(a_out_dst, ebytes);
   const uint32_t lvo = lane * (uint32_t)sizeof(ST);
   const uint32_t lane4 = lane * 4u;
-  bool any = false, sat = false, need_exact = false, ovf = false;
+  bool any = false, sat = false, dyn = false, ovf = false;
   uint32_t n_done = 0;                                            // COUNT only: rows this wave evaluated
 #pragma unroll 1
   for (uint32_t q = 0; q < (uint32_t)FQ; ++q) {
@@ -1044,7 +1086,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
       else
         r = fused_row_any<ST, MAXINF, false, 4>(gp->g, rs, v, e0, e1, svv[i], wvv[i], lane, lvo, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
       sat = sat || r.sat;
-      need_exact = need_exact || r.need_exact;
+      dyn = dyn || r.dyn;
       ovf = ovf || r.ovf;
       const bool ch = r.nw != StIO<ST>::bits(oldq[i]);
       if (ch) { S[(size_t)v * 64 + lane] = r.nw; any = true; }
@@ -1063,9 +1105,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(96))) void k_fu
   if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
   if (COUNT && lane == 0) atomicAdd(&gp->rows_done[(blockIdx.x + wave) & 255u], n_done);
   uint32_t lf = 0;
-  if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
+  if (MAXINF && sat) lf |= LF_NEED_EXACT;
   if (ovf) lf |= LF_OVERFLOW;
   if (lf) atomicOr(&lane_flags[root_slot], lf);
+  if (dyn) raise_dyn(gp, lane_flags, root_slot, blockIdx.x * 4u + wave);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1170,9 +1213,9 @@ template <bool COUNT, int MODE>
 __device__ __forceinline__ void lean_group(const FusedGraph *__restrict__ gp, const __amdgpu_buffer_rsrc_t rs, const __amdgpu_buffer_rsrc_t ra,
                                            const uint32_t lane, const uint32_t lane4, const uint32_t wbeg, const uint32_t cur, const FusedParams &P,
                                            const uint32_t *__restrict__ roots, const uint32_t root_slot, const uint32_t net_nexthops,
-                                           const uint32_t ignore_ovl, const uint32_t due4, const uint32_t fast4, const uint32_t fasth4,
+                                           const uint32_t ignore_ovl, const uint32_t due4, const uint32_t fast4, const uint32_t fasth4, const uint32_t fastz4,
                                            uint32_t (&sov)[VPW], uint32_t (&wk)[VPW], uint32_t (&od)[VPW], uint32_t (&oldq)[VPW], uint32_t (&info)[VPW],
-                                           uint64_t &any, bool &need_exact, uint32_t &n_done, uint32_t &n_chg) {
+                                           uint64_t &any, bool &dyn, uint32_t &n_done, uint32_t &n_chg) {
   typedef uint32_t ST;
   const uint32_t paym = (1u << P.sh) - 1u;
   const uint32_t hopm = P.hmax << P.mbits, maskm = (1u << P.mbits) - 1u;
@@ -1260,9 +1303,60 @@ __device__ __forceinline__ void lean_group(const FusedGraph *__restrict__ gp, co
       for (uint32_t ob = o0 + lane; ob < o1; ob += 64) __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, g.out_dst[ob] * 4u, 0, 0);
     }
   }
+  // ---- rows whose only flag is RF_ZERO (a zero-cost link from a higher- or equal-numbered source; round 6): with 1 % of the
+  // links at cost 0 that is 5 % of the rows, and through the general routine below a dense pass took 3.5 x as long (a wave
+  // with one such row lives three times as long and a pass ends with its last wave).  The rule of finish_row_z on the
+  // candidate words: the zero-cost links from sources >= v are taken OUT of the row's minimum (an all-ones candidate never
+  // wins and is never tight); the first SAFE one with the smallest distance (whole-word minimum: distance, then row order) is
+  // the row's one parent when it beats the rest — its hops and ITS mask, no union —, an UNSAFE one that beats everything
+  // leaves the distance alone (hops 0, mask 0: the placeholder k_repair fills in).  Either way the lane's root is LF_DYN.
+  if (fastz4 != 0u) {
+    const uint8_t *__restrict__ zc = gp->g.zcyc;
+#pragma unroll 1
+    for (uint32_t hm = fastz4; hm != 0u; hm &= hm - 1u) {
+      const uint32_t i = (uint32_t)__builtin_ctz(hm);
+      const uint32_t v = wbeg + i;
+      const uint32_t sov_i = i == 0 ? sov[0] : i == 1 ? sov[1] : i == 2 ? sov[2] : sov[3];
+      const uint32_t wk_i = i == 0 ? wk[0] : i == 1 ? wk[1] : i == 2 ? wk[2] : wk[3];
+      const uint32_t od_i = i == 0 ? od[0] : i == 1 ? od[1] : i == 2 ? od[2] : od[3];
+      const uint32_t old_i = i == 0 ? oldq[0] : i == 1 ? oldq[1] : i == 2 ? oldq[2] : oldq[3];
+      const uint32_t inf_i = i == 0 ? info[0] : i == 1 ? info[1] : i == 2 ? info[2] : info[3];
+      const uint32_t deg = inf_i & 0x1Fu;                                 // <= 16 (a longer row carries RF_MANY)
+      const uint32_t src_l = sov_i >> 8;                                  // lane 16 r + j: source of link j
+      const bool zl = (lane & 15u) < deg && (wk_i >> P.sh) == 0u && src_l >= v;
+      const bool ul = zl && (zc == nullptr || (zc[src_l] != 0 && zc[v] != 0));
+      const uint32_t zmask = (uint32_t)__ballot(zl) & 0xFFFFu, umask = (uint32_t)__ballot(ul) & 0xFFFFu;
+      uint32_t c[16];
+      LeanLinks<16>::load(c, rs, lane4, sov_i);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      LeanLinks<16>::add(c, wk_i);
+      uint32_t cz = INF, du = INF;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (!((zmask >> j) & 1u)) continue;                               // uniform
+        if ((umask >> j) & 1u) du = min(du, c[j] & ~paym); else cz = min(cz, c[j]);
+        c[j] = INF;
+      }
+      const LeanOut r = lean_minor<16>(c, paym);
+      const uint32_t d_reg = r.m & ~paym, d_zs = cz & ~paym;
+      const bool unsafe_wins = du < min(d_reg, d_zs), late = !unsafe_wins && d_zs < d_reg;
+      const uint32_t nw = unsafe_wins ? min(du, P.infw) : finish(late ? LeanOut{cz, cz, cz} : r, inf_i);
+      dyn = dyn || (unsafe_wins && du < P.inf_t) || (late && d_zs < P.inf_t);
+      if (COUNT) ++n_done;
+      const uint64_t ch = __ballot(nw != old_i);
+      if (ch == 0ull) continue;
+      __builtin_amdgcn_raw_buffer_store_b32(nw, rs, lane4, v << 8, 0);
+      any |= ch;
+      if (MODE == 1) { ++n_chg; continue; }
+      if (!(inf_i & 0x20u)) { __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, od_i, 0, 0); continue; }
+      const GraphDev &g = gp->g;
+      const uint32_t o0 = g.out_ptr[v], o1 = g.out_ptr[v + 1];
+      for (uint32_t ob = o0 + lane; ob < o1; ob += 64) __builtin_amdgcn_raw_buffer_store_b32(cur + 1u, ra, g.out_dst[ob] * 4u, 0, 0);
+    }
+  }
   // ---- the due rows that carry a flag: k_fused's general routine on the CSR arrays (rare: one code instance, run-time row)
 #pragma unroll 1
-  for (uint32_t gm = due4 & ~fast4 & ~fasth4; gm != 0u; gm &= gm - 1u) {
+  for (uint32_t gm = due4 & ~fast4 & ~fasth4 & ~fastz4; gm != 0u; gm &= gm - 1u) {
     const uint32_t v = wbeg + (uint32_t)__builtin_ctz(gm);
     const GraphDev &g = gp->g;
     const uint32_t e0 = g.in_ptr[v], e1 = g.in_ptr[v + 1];
@@ -1274,7 +1368,7 @@ __device__ __forceinline__ void lean_group(const FusedGraph *__restrict__ gp, co
     RowOut<ST> r;
     if (P.hc) r = fused_row_any<ST, false, true, 4>(g, rs, v, e0, e1, sv, wv, lane, lane4, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
     else r = fused_row_any<ST, false, false, 4>(g, rs, v, e0, e1, sv, wv, lane, lane4, my_root, root_slot, gp->tabs, net_nexthops, ignore_ovl, P);
-    need_exact = need_exact || r.need_exact;       // (r.ovf is a per-evaluation test of TRANSIENT values: the lean state's fields are tested on the final words, k_emit_fused)
+    dyn = dyn || r.dyn;       // (r.ovf is a per-evaluation test of TRANSIENT values: the lean state's fields are tested on the final words, k_emit_fused)
     if (COUNT) ++n_done;
     const uint64_t ch = __ballot(r.nw != old);
     if (ch == 0ull) continue;
@@ -1393,6 +1487,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
   }
   const uint32_t fast4 = (uint32_t)__ballot(lane < (uint32_t)VPW && hb == 0u) & due4;
   const uint32_t fasth4 = (uint32_t)__ballot(lane < (uint32_t)VPW && (hb & ~RF_ROOT) == RF_HNB) & due4;   // next to a root of the batch (or the row of one), nothing else
+  const uint32_t fastz4 = P.hc ? 0u : ((uint32_t)__ballot(lane < (uint32_t)VPW && hb == RF_ZERO) & due4);  // a zero-cost link from a higher-numbered source, nothing else
   const uint32_t root_slot = batch * 64 + lane;
   const __amdgpu_buffer_rsrc_t ra = st_rsrc(A, n * 4u);
   uint32_t info[VPW];                                             // low byte of ELL entry 0: in-degree | (> 16 out-links) << 5 | network << 7
@@ -1404,10 +1499,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
     od[i] = lane < 16u ? od[i] : 0xFFFFFFFFu;                     // byte offsets into A; pad / upper lanes: out of range = dropped
   }
   uint64_t any = 0ull;
-  bool need_exact = false;
+  bool dyn = false;
   uint32_t n_done = 0, n_chg = 0;
-  lean_group<COUNT, MODE>(gp, rs, ra, lane, lane4, wbeg, cur, P, roots, root_slot, net_nexthops, ignore_ovl, due4, fast4, fasth4,
-                          sov, wk, od, oldq, info, any, need_exact, n_done, n_chg);
+  lean_group<COUNT, MODE>(gp, rs, ra, lane, lane4, wbeg, cur, P, roots, root_slot, net_nexthops, ignore_ovl, due4, fast4, fasth4, fastz4,
+                          sov, wk, od, oldq, info, any, dyn, n_done, n_chg);
   // (Round 5, r05c: INNER iterations — the wave evaluating its rows again with the records it holds, no set-up and no record
   // round trip — were measured and rejected: an iteration that sees only its own rows' and some neighbouring waves' stores
   // converges worse than a pass behind a pass; 2 / 3 iterations per pass: 22.2 / 25.8 x N rows evaluated instead of 17.9,
@@ -1415,9 +1510,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
   if (any != 0ull && lane == 0) changed[sweep] = 1;
   if (COUNT && lane == 0) atomicAdd(&gp->rows_done[(blockIdx.x + wave) & 255u], n_done);
   if (MODE == 1 && sampler && lane == 0 && n_chg != 0u && pg < 64u) atomicAdd(&ctl[LEAN_CTL_PCH + pg * LEAN_CTL_STRIDE], n_chg);
-  uint32_t lf = 0;
-  if (need_exact) lf |= LF_NEED_EXACT;
-  if (lf) atomicOr(&lane_flags[root_slot], lf);
+  if (dyn) raise_dyn(gp, lane_flags, root_slot, blockIdx.x * 4u + wave);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1461,6 +1554,7 @@ struct SingleArgs {
   uint32_t *lane_flags;
   OutDev o;
   __device__ __forceinline__ const SlotTabs &slot_tabs() const { return gp->tabs; }
+  __device__ __forceinline__ const uint8_t *zcyc() const { return gp->g.zcyc; }
 };
 
 // LDS layout (dynamic): state words [n] | when the links are staged, per link: source|NT, cost, position in the source's
@@ -1489,8 +1583,8 @@ __device__ __forceinline__ void single_link(RowAcc &r, uint32_t &bd_all, uint32_
   const uint32_t c = add_sat(d, w);
   if (MAXINF && c == INF && d != INF) r.sat = true;
   const bool zlink = RARE && w == 0u && u >= v;
-  if (RARE && zlink && !P.hc) { bd_all = min(bd_all, c); return; }
-  const bool hz = RARE && P.hc && zlink;
+  if (RARE && zlink && !P.hc && zlink_unsafe(a.zcyc(), u, v)) { bd_all = min(bd_all, c); return; }
+  const bool hz = RARE && zlink;
   const bool lt = hz ? (c < zb) : (c < r.bd), eq = !hz && c == r.bd;
   const uint32_t hh = pay >> P.mbits;
   uint32_t contrib = pay & mmask;
@@ -1593,7 +1687,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
     }
   }
   __syncthreads();
-  bool sat = false, need_exact = false, ovf = false;
+  bool sat = false, need_exact = false, dyn = false, ovf = false;
   const uint32_t max_sweeps = 4u * n + 64u;        // far beyond any run; a run that gets there is handed to k_exact
   uint32_t sweep = 0;
   const uint64_t t_loop0 = clock64();
@@ -1667,12 +1761,8 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
           else      single_link<MAXINF, false>(r, bd_all, zb, zm, zh, rs[k], rw[k], [fk]() { return fk; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
         }
       }
-      if (rare && P.hc) {
-        const bool late = zb < r.bd;
-        r.bm = late ? zm : r.bm; r.bh = late ? zh : r.bh; r.bd = late ? zb : r.bd;
-      }
-      const RowOut<uint64_t> o = finish_row<uint64_t>(r, v, my_root, v_router, bd_all, P);
-      sat = sat || o.sat; need_exact = need_exact || o.need_exact; ovf = ovf || o.ovf;
+      const RowOut<uint64_t> o = finish_row_z<uint64_t>(r, v, my_root, v_router, bd_all, rare ? zb : INF, zm, zh, P.hc != 0u, P);
+      sat = sat || o.sat; dyn = dyn || o.dyn; ovf = ovf || o.ovf;
       if (o.nw != cur[i]) { cur[i] = o.nw; s_st[v] = o.nw; any = true; }
     }
     if (!checked) continue;
@@ -1700,6 +1790,7 @@ __global__ __launch_bounds__(SINGLE_THREADS) void k_single(SingleArgs a) {
   }
   uint32_t lf = 0;
   if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
+  if (dyn) lf |= LF_DYN;
   if (ovf) lf |= LF_OVERFLOW;
   single_store_flags(a.lane_flags, root_slot, lf, &s_changed[0]);
   if (a.count_rows && tid == 0) {                  // HSPF_RUN_COUNT_ROWS: rows evaluated; workgroup 0 also leaves its sweep
@@ -1748,6 +1839,7 @@ struct LvArgs {
   const uint32_t *ell_so, *ell_w, *ell_od;   // the fixed-stride copy of the rows with at most 16 in-links / out-links (kb_ell)
   uint32_t ell_mode;                  // 2: records and wake-up offsets from it, 1: records only, 0: not used (HSPF_VARIANT bits 25 / 26: A/B)
   __device__ __forceinline__ const SlotTabs &slot_tabs() const { return tabs; }
+  __device__ __forceinline__ const uint8_t *zcyc() const { return g.zcyc; }
 };
 
 // A launch is a chain of dependent round trips, not a stream of bytes (one root on isis-100k: ~43 k due vertices per
@@ -1855,11 +1947,7 @@ __global__ __launch_bounds__(256) void k_lv(LvArgs a) {
       else      single_link<MAXINF, false>(r, bd_all, zb, zm, zh, rs[k], rw[k], [fp]() { return *fp; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
     }
   }
-  if (rare && P.hc) {
-    const bool late = zb < r.bd;
-    r.bm = late ? zm : r.bm; r.bh = late ? zh : r.bh; r.bd = late ? zb : r.bd;
-  }
-  const RowOut<uint64_t> o = finish_row<uint64_t>(r, v, my_root, v_router, bd_all, P);
+  const RowOut<uint64_t> o = finish_row_z<uint64_t>(r, v, my_root, v_router, bd_all, rare ? zb : INF, zm, zh, P.hc != 0u, P);
   if (o.nw != old) {
     S[v] = o.nw;
     a.changed[a.sweep] = 1;
@@ -1877,7 +1965,8 @@ __global__ __launch_bounds__(256) void k_lv(LvArgs a) {
   }
   if (a.count_rows) atomicAdd(&a.rows_done[(blockIdx.x + threadIdx.x) & 127u], 1u);
   uint32_t lf = 0;
-  if ((MAXINF && o.sat) || o.need_exact) lf |= LF_NEED_EXACT;
+  if (MAXINF && o.sat) lf |= LF_NEED_EXACT;
+  if (o.dyn) lf |= LF_DYN;
   if (o.ovf) lf |= LF_OVERFLOW;
   if (lf) atomicOr(&a.lane_flags[root_slot], lf);
 }
@@ -1960,6 +2049,7 @@ struct XcdArgs {
   uint64_t timeout_ticks;        // 100 MHz ticks
   OutDev o;
   __device__ __forceinline__ const SlotTabs &slot_tabs() const { return gp->tabs; }
+  __device__ __forceinline__ const uint8_t *zcyc() const { return gp->g.zcyc; }
 };
 
 template <bool MAXINF, bool PROF>
@@ -2032,7 +2122,7 @@ __global__ __launch_bounds__(640) void k_xcd(XcdArgs a) {     // (XCD_MAX_N / XC
         else { ls[k] = min(v, n - 1u); lw[k] = INF; lb[k] = 0u; }
     }
   }
-  bool sat = false, need_exact = false, ovf = false, aborted = false;
+  bool sat = false, need_exact = false, dyn = false, ovf = false, aborted = false;
   const uint32_t max_sweeps = min(4u * n + 64u, XCD_MAX_SWEEPS);
   uint32_t sweep = 0;
   // PROF (HSPF_XCD_PROF, tuning only): 100 MHz ticks workgroup 0 of the first root spends evaluating / publishing / waiting
@@ -2082,11 +2172,7 @@ __global__ __launch_bounds__(640) void k_xcd(XcdArgs a) {     // (XCD_MAX_N / XC
             else      single_link<MAXINF, false>(r, bd_all, zb, zm, zh, ls[k], lw[k], [fk]() { return fk; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
           }
         }
-        if (rare && P.hc) {
-          const bool late = zb < r.bd;
-          r.bm = late ? zm : r.bm; r.bh = late ? zh : r.bh; r.bd = late ? zb : r.bd;
-        }
-        o = finish_row<uint64_t>(r, v, my_root, v_router, bd_all, P);
+        o = finish_row_z<uint64_t>(r, v, my_root, v_router, bd_all, rare ? zb : INF, zm, zh, P.hc != 0u, P);
       } else {
         RowAcc r{INF, 0u, INF, 0u, false};
         uint32_t bd_all = INF, zb = INF, zm = 0u, zh = 0u;
@@ -2109,13 +2195,9 @@ __global__ __launch_bounds__(640) void k_xcd(XcdArgs a) {     // (XCD_MAX_N / XC
             else      single_link<MAXINF, false>(r, bd_all, zb, zm, zh, rs[k], rw[k], [fk]() { return fk; }, qs[k], v, v_router, my_root, root_slot, a, P, mmask);
           }
         }
-        if (rare && P.hc) {
-          const bool late = zb < r.bd;
-          r.bm = late ? zm : r.bm; r.bh = late ? zh : r.bh; r.bd = late ? zb : r.bd;
-        }
-        o = finish_row<uint64_t>(r, v, my_root, v_router, bd_all, P);
+        o = finish_row_z<uint64_t>(r, v, my_root, v_router, bd_all, rare ? zb : INF, zm, zh, P.hc != 0u, P);
       }
-      sat = sat || o.sat; need_exact = need_exact || o.need_exact; ovf = ovf || o.ovf;
+      sat = sat || o.sat; dyn = dyn || o.dyn; ovf = ovf || o.ovf;
       if (o.nw != cur) { cur = o.nw; s_st[v] = o.nw; S[v] = o.nw; any = true; }
     }
     // ---- barrier among the workgroups of this root's XCD, carrying "my range changed"
@@ -2195,6 +2277,7 @@ __global__ __launch_bounds__(640) void k_xcd(XcdArgs a) {     // (XCD_MAX_N / XC
   }
   uint32_t lf = 0;
   if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
+  if (dyn) lf |= LF_DYN;
   if (ovf) lf |= LF_OVERFLOW;
   if (lf) atomicOr(&s_lf, lf);
   __syncthreads();
@@ -2948,7 +3031,7 @@ __global__ __launch_bounds__(256) void k_fw(const FusedGraph *__restrict__ gp, u
   const uint32_t lane4 = lane * 4u, lane8 = lane * 8u;
   const uint32_t pv = g.in_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
   const uint32_t po = g.out_ptr[min(vbeg + min(lane, (uint32_t)VPW), n)];
-  bool any = false, sat = false, need_exact = false;
+  bool any = false, sat = false, dyn = false;
 #pragma unroll 1
   for (int i = 0; i < VPW; ++i) {
     const uint32_t v = vbeg + i;
@@ -3001,8 +3084,12 @@ __global__ __launch_bounds__(256) void k_fw(const FusedGraph *__restrict__ gp, u
     if (v == my_root) { nd = 0u; nh = 0u; }
     else if (bd == INF || bd > maxpath) { nd = INF; nh = 0u; }
     else { nd = bd; nh = min(bh + v_router, 0xFFFFu); }                 // u16 saturating_add
-    const bool live = v != my_root && nd != INF;
-    need_exact = need_exact || (v != my_root && bd_all != INF && bd_all <= maxpath && bd_all < bd);
+    // the only (or a shorter) way in is a zero-cost link from a higher-numbered source: dynamic pop order (finish_row) —
+    // the distance is stored, hops / mask are placeholders that k_repair recomputes
+    const bool dynv = v != my_root && bd_all != INF && bd_all <= maxpath && bd_all < bd;
+    if (dynv) { nd = bd_all; nh = 0u; }
+    dyn = dyn || dynv;
+    const bool live = v != my_root && nd != INF && !dynv;
     bool ch = nd != od || nh != (oh & 0xFFFFu);
 #pragma unroll
     for (int q = 0; q < W; ++q) { am[q] = live ? am[q] : 0ull; ch = ch || am[q] != om[q]; }
@@ -3020,7 +3107,8 @@ __global__ __launch_bounds__(256) void k_fw(const FusedGraph *__restrict__ gp, u
   }
   if (__ballot(any) != 0ull && lane == 0) changed[sweep] = 1;
   uint32_t lf = 0;
-  if ((MAXINF && sat) || need_exact) lf |= LF_NEED_EXACT;
+  if (MAXINF && sat) lf |= LF_NEED_EXACT;
+  if (dyn) lf |= LF_DYN;
   if (lf) atomicOr(&lane_flags[root_slot], lf);
 }
 

@@ -221,7 +221,7 @@ class SpfGraph:
           "out_pos": (11, np.uint32), "rowflags": (12, np.uint8), "twoway": (13, np.uint8), "units": (14, np.uint32),
           "build_mode": (15, np.uint32), "ell_src": (16, np.uint32), "ell_cost": (17, np.uint32),
           "ell_out": (18, np.uint32), "summary": (19, np.uint32), "leaf": (20, np.uint8),
-          "host_row_ptr": (21, np.uint32), "host_col": (22, np.uint32)}
+          "host_row_ptr": (21, np.uint32), "host_col": (22, np.uint32), "zcyc": (23, np.uint8)}
 
     def export(self, name: str) -> np.ndarray:
         """One array of the graph as it sits on the device (hspf_graph_export)."""

@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define HSPF_ABI_VERSION 7u   /* 7: + packed results (hspf_run_packed / _device / _async, hspf_wait_packed, hspf_packed_layout + decode helpers),
+#define HSPF_ABI_VERSION 8u   /* 8: hspf_stats + n_repaired_roots / repair_* (dynamic pop order resolved in parallel); HSPF_RF_EXACT = "the pop order is dynamic";
+                                 7: + packed results (hspf_run_packed / _device / _async, hspf_wait_packed, hspf_packed_layout + decode helpers),
                                     hspf_host_alloc / hspf_host_free, hspf_device_alloc / _free / _to_host / hspf_host_to_device, hspf_rib_clear_device / hspf_rib_fold_device (several areas, one RIB, on the device), HSPF_E_NO_PACKED (additions only); the library no longer sets
                                     GPU_MAX_HW_QUEUES at load time;
                                  6: + hspf_run_device_async / hspf_wait / hspf_wait_all / hspf_async_lanes, hspf_multi_run_async / hspf_multi_run_wait, hspf_recommend_cpu (additions only);
@@ -86,7 +87,8 @@ extern "C" {
 
 /* ---- per-(root,vertex) result flags (hspf_result.vflags_out) --------------------------- */
 #define HSPF_RF_IN_SPT   0x0001u    /* vertex was popped into the SPT                         */
-#define HSPF_RF_EXACT    0x0002u    /* produced by the sequential exact kernel (diagnostic)   */
+#define HSPF_RF_EXACT    0x0002u    /* the root's pop order is NOT the static (distance, index) order (zero-cost links, saturation):
+                                       rows from k_repair or the sequential kernel; ask for pop_rank when the order matters */
 
 #define HSPF_DIST_INF    0xFFFFFFFFu /* dist of a vertex that is not in the SPT               */
 #define HSPF_NO_ROOT     0xFFFFFFFFu /* padding entry in a roots[] array: produces an empty SPT */
@@ -174,6 +176,13 @@ typedef struct {
                                   [2], [3]: host microseconds from the entry of the (last) run to its first enqueue /
                                   to its return.  HSPF_RUN_COUNT_ROWS on the one-workgroup path instead: sweeps,
                                   shader cycles, 100 MHz wall ticks and set-up cycles of the first root's workgroup  */
+  /* ABI 8: roots whose pop order is dynamic (zero-cost router links) — distances from the sweep kernels, hops and first-hop
+     masks recomputed in the true pop order by k_repair, one workgroup per root (holo_amd/csrc/spf_repair.hip.h) */
+  uint32_t n_repaired_roots;   /* roots k_repair put right (n_exact_roots counts only what still needed the sequential kernel) */
+  uint32_t repair_sweeps;      /* worklist sweeps of the slowest of them                               */
+  uint32_t repair_evals;       /* (root, vertex) evaluations in the true order, all of them together    */
+  uint32_t repair_groups;      /* groups of vertices released by a higher-numbered one that were walked  */
+  float    ms_repair;          /* host time of the repair step (enqueue to completion)                   */
 } hspf_stats;
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
@@ -269,6 +278,9 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows);
 #define HSPF_GX_HOST_ROW_PTR 21u /* u32 [n+1]  the HOST mirror of the caller's row bounds (slot tables are made from it; a
                                   structural patch splices it in place): equals ROW_PTR                              */
 #define HSPF_GX_HOST_COL 22u   /* u32 [e]      ... and of the caller's targets: equals COL                           */
+#define HSPF_GX_ZCYC     23u   /* u8  [n]      (ABI 8) 1 = the vertex may lie on a cycle of zero-cost kept links: what survives 8
+                                  rounds of "keeps a zero-cost in-link from and a zero-cost out-link to a survivor".  0 bytes
+                                  when no row has a zero-cost link from a higher- or equal-numbered source (array unused)  */
 int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *dst, size_t cap_bytes,
                       size_t *out_bytes);
 

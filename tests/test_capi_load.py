@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in sorted(decl):
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     assert {n for n, _, _ in _lib.SYMBOLS} == decl, "ctypes binding table out of sync with the header"
-    assert lib.hspf_abi_version() == 7
+    assert lib.hspf_abi_version() == 8
     assert lib.hspf_strerror(-7).decode().startswith("results do not fit")
     assert lib.hspf_strerror(-5).decode().startswith("too many")
 
