@@ -625,6 +625,55 @@ def dropin_e2e() -> dict:
     return out
 
 
+def exact_path(ctx, dev) -> dict:
+    """Roots with a DYNAMIC pop order: ospf-10k and isis-100k with 0.1 % / 1 % of their link entries at
+    metric 0 (holo-isis/src/spf.rs:629-704 treats 0 like any metric), 1 and 64 roots, results in HBM.  Until round 6 every such
+    root was re-run by the sequential kernel (one GPU thread per root: seconds per batch at 100 k vertices); now the sweep
+    kernels deliver the distances and k_repair (holo_amd/csrc/spf_repair.hip.h) recomputes hops / masks in the true order.
+    Beside it: the same graph without zero-cost links, and the CPU heap restatement (1 thread) on the same roots; one root of
+    every case is verified against the oracle's literal loop."""
+    import torch
+    from oracle import graph_oracle as go
+    out = {}
+    for name, g0 in (("ospf-10k", synth.ospf_10k()), ("isis-100k", synth.isis_100k())):
+        for share in (0.0, 0.001, 0.01):
+            g = g0
+            if share:
+                rng = np.random.default_rng(11)
+                m = g0.metric.copy()
+                m[rng.random(len(m)) < share] = 0
+                g = synth.CsrGraph(g0.row_ptr, g0.col, m, g0.vflags, g0.max_path_metric, g0.name)
+            G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+            for rn in (1, 64):
+                roots = (np.arange(rn, dtype=np.uint64) * g.n // rn).astype(np.uint32)
+                W = G.mask_words(roots)
+                b = _bufs(torch, dev, rn, g.n, W)
+                kw = _kw(b, W)
+                for _ in range(3):
+                    st = ctx.run_device(G, roots, 0, **kw)
+                torch.cuda.synchronize()
+                reps = 10
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    st = ctx.run_device(G, roots, 0, **kw)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) * 1e3 / reps
+                rec = {"ms_per_call": round(ms, 4), "runs_per_s": round(rn / ms * 1e3, 1), "n_exact_roots": st["n_exact_roots"],
+                       "n_repaired_roots": st["n_repaired_roots"], "ms_repair": round(st["ms_repair"], 4), "repair_sweeps": st["repair_sweeps"],
+                       "repair_evals": st["repair_evals"]}
+                if share:
+                    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots[:1], 0, go.MAP, mask_words_=W)
+                    t0 = time.perf_counter()
+                    go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots[:1], 0, go.HEAP, mask_words_=W)
+                    rec["cpu_heap_ms_per_run"] = round((time.perf_counter() - t0) * 1e3, 2)
+                    rec["first_root_identical_to_the_literal_loop"] = bool(
+                        np.array_equal(b["dist"][0].cpu().numpy().view(np.uint32), ref.dist[0]) and np.array_equal(b["hops"][0].cpu().numpy().view(np.uint16), ref.hops[0])
+                        and np.array_equal(b["mask"][0].cpu().numpy().view(np.uint64), ref.mask[0]))
+                out[f"{name}, {share * 100:g} % zero-cost entries, {rn} root(s)"] = rec
+            G.free()
+    return out
+
+
 def path_of(st) -> str:
     """Which engine path a run took, from its hspf_stats."""
     if st.get("single_wg") == 2:
@@ -1149,6 +1198,7 @@ def main():
             out["two_instances"] = two_instances(g, dev)
             out["configs"] = other_configs(ctx1, dev)
             out["dropin_e2e"] = dropin_e2e()
+            out["exact_path"] = exact_path(ctx1, dev)
         print(json.dumps(out), flush=True)
 
     m.free_graph(mg)

@@ -159,9 +159,12 @@ struct hspf_ctx {
   size_t h_stage_cap = 0;                            // bytes (both blocks)
   hipEvent_t ev_stage[2] = {};
   DevBuf ex_list, ex_heap, ex_pos;
+  DevBuf rp_rank;                                    // pop_rank of repaired roots: keys / items of the two sorts, rocPRIM's temporary storage
   DevBuf dyn_part;                                   // FusedGraph::dyn_part: DYN_PARTS partial LF_DYN arrays of the lane = root sweeps
   DevBuf rp_z, rp_ord, rp_work, rp_status;          // k_repair (spf_repair.hip.h): zero-cost marks + list, (R, pos), stamps + worklists, status
-  uint32_t *h_rp = nullptr; size_t h_rp_cap = 0;    // pinned: the roots' repair status words
+  uint32_t *h_rp = nullptr; size_t h_rp_cap = 0;    // pinned: the repair's control block (RpCtl)
+  uint32_t est_rp_rounds = 6;                        // relaxation rounds launched ahead
+  uint32_t est_rp = 10;                              // worklist sweeps launched ahead (the last repair's count + 2)
   DevBuf pf_ptr, pf_vtx, pf_met, pf_org;            // prefix table of hspf_routes_device
   bool pf_shadow_ok = false;                        // the device holds a plain table; what it was uploaded from (HSPF_PFX_RESIDENT):
   uint32_t pf_shadow_nv = 0, pf_res_np = 0, pf_res_ne = 0;
@@ -734,7 +737,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->dyn_part, &ctx->rp_z, &ctx->rp_ord, &ctx->rp_work, &ctx->rp_status, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag, &ctx->xcd_ctl})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->rp_rank, &ctx->dyn_part, &ctx->rp_z, &ctx->rp_ord, &ctx->rp_work, &ctx->rp_status, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag, &ctx->xcd_ctl})
     release(*b);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (auto &e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
@@ -2254,63 +2257,116 @@ int Run::path_wide() {
 int Run::repair_roots() {
   if (dy.empty()) return HSPF_OK;
   const auto t0 = std::chrono::steady_clock::now();
-  const uint32_t nd = (uint32_t)dy.size();
   if ((rc = ensure(ctx, ctx->ex_list, (size_t)n_roots * 4, false))) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->ex_list.p, dy.data(), (size_t)nd * 4, hipMemcpyHostToDevice, s));
-  if (pk && !pk_full) {                                            // packed words straight out of the fused emit: the rows of these roots back into tables
-    if ((rc = pk_staging())) return rc;
-    od.dist = (uint32_t *)ctx->o_dist.p; od.hops = (uint16_t *)ctx->o_hops.p; od.flags = (uint16_t *)ctx->o_flags.p; od.mask = (uint64_t *)ctx->o_mask.p;
-    const FusedParams PP = pk_mode == 2 ? fp_lean : pk_mode == 1 ? fp_narrow : fp_wide;
-    const dim3 ug((n + 255u) / 256u, nd);
-    if (pk_mode == 2 || pk_mode == 1) hipLaunchKernelGGL((kr_unpack_rows<4>), ug, dim3(256), 0, s, n, nd, (const uint32_t *)ctx->ex_list.p, (const void *)pk_dev(4), PP, od.dist, od.hops, od.flags, od.mask);
-    else                              hipLaunchKernelGGL((kr_unpack_rows<8>), ug, dim3(256), 0, s, n, nd, (const uint32_t *)ctx->ex_list.p, (const void *)pk_dev(8), PP, od.dist, od.hops, od.flags, od.mask);
+  bool unpacked = false;
+  std::vector<uint32_t> todo = dy, ok;
+  // R settles in a few rounds (the longest chain of zero-cost links a root's order hangs on); a root that needs more is tried
+  // again with more rounds — nothing of a failed attempt has touched its rows — before the sequential kernel gets it
+  for (uint32_t rounds : {std::max(RP_RELAX, ctx->est_rp_rounds), 8u * std::max(RP_RELAX, ctx->est_rp_rounds), 2048u}) {
+    if (todo.empty()) break;
+    const uint32_t nd = (uint32_t)todo.size();
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ex_list.p, todo.data(), (size_t)nd * 4, hipMemcpyHostToDevice, s));
+    if (pk && !pk_full && !unpacked) {                               // packed words straight out of the fused emit: the rows of these roots back into tables
+      if ((rc = pk_staging())) return rc;
+      od.dist = (uint32_t *)ctx->o_dist.p; od.hops = (uint16_t *)ctx->o_hops.p; od.flags = (uint16_t *)ctx->o_flags.p; od.mask = (uint64_t *)ctx->o_mask.p;
+      const FusedParams PP = pk_mode == 2 ? fp_lean : pk_mode == 1 ? fp_narrow : fp_wide;
+      const dim3 ug((n + 255u) / 256u, nd);
+      if (pk_mode == 2 || pk_mode == 1) hipLaunchKernelGGL((kr_unpack_rows<4>), ug, dim3(256), 0, s, n, nd, (const uint32_t *)ctx->ex_list.p, (const void *)pk_dev(4), PP, od.dist, od.hops, od.flags, od.mask);
+      else                              hipLaunchKernelGGL((kr_unpack_rows<8>), ug, dim3(256), 0, s, n, nd, (const uint32_t *)ctx->ex_list.p, (const void *)pk_dev(8), PP, od.dist, od.hops, od.flags, od.mask);
+      unpacked = true;
+    }
+    const size_t zl_off = ((size_t)n + 255u) & ~(size_t)255u;        // [zflag: n bytes | zl: n words | nz]
+    const size_t ctl_words = RpCtl::words(nd);
+    if ((rc = ensure(ctx, ctx->rp_z, zl_off + ((size_t)n + 1u) * 4, false))) return rc;
+    if ((rc = ensure(ctx, ctx->rp_ord, (size_t)nd * n * 8, false))) return rc;
+    if ((rc = ensure(ctx, ctx->rp_work, (size_t)nd * n * 12, false))) return rc;
+    if ((rc = ensure(ctx, ctx->rp_status, ctl_words * 4, false))) return rc;
+    if (ctx->h_rp_cap < ctl_words) {
+      if (ctx->h_rp) (void)hipHostFree(ctx->h_rp);
+      ctx->h_rp = nullptr; ctx->h_rp_cap = 0;
+      HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_rp, (ctl_words + 1024) * 4, hipHostMallocDefault));
+      ctx->h_rp_cap = ctl_words + 1024;
+    }
+    uint8_t *zflag = (uint8_t *)ctx->rp_z.p;
+    uint32_t *zl = (uint32_t *)((char *)ctx->rp_z.p + zl_off), *nz = zl + n;
+    HIPCHK(ctx, hipMemsetAsync(zflag, 0, n, s));
+    HIPCHK(ctx, hipMemsetAsync(nz, 0, 4, s));
+    HIPCHK(ctx, hipMemsetAsync(ctx->rp_work.p, 0, (size_t)nd * n * 4, s));                      // the stamps
+    HIPCHK(ctx, hipMemsetAsync(ctx->rp_status.p, 0, ctl_words * 4, s));
+    if (gd.e_in) hipLaunchKernelGGL(kr_zmark, dim3((gd.e_in + 255u) / 256u), dim3(256), 0, s, gd.e_in, gd.out_dst, gd.out_w, zflag);
+    hipLaunchKernelGGL(kr_zcompact, dim3((n + 255u) / 256u), dim3(256), 0, s, n, (const uint8_t *)zflag, zl, nz);
+    RepairArgs a{};
+    a.g = gd; a.root_list = (const uint32_t *)ctx->ex_list.p; a.roots = d_roots; a.n_dyn = nd; a.net_nexthops = net_nh; a.ignore_ovl = ignore_ovl;
+    a.tabs = tabs; a.dist = od.dist; a.hops = od.hops; a.flags = od.flags; a.mask = od.mask; a.words = out_words; a.row_map = od.row_map;
+    a.zflag = zflag; a.zl = zl; a.nz = nz;
+    a.R = (uint32_t *)ctx->rp_ord.p; a.pos = a.R + (size_t)nd * n;
+    a.stamp = (uint32_t *)ctx->rp_work.p; a.wl = a.stamp + (size_t)nd * n;
+    a.ctl = RpCtl{(uint32_t *)ctx->rp_status.p, nd};
+    // a root's share of the chip: all of it for one root, RP_GX blocks of 16 groups each at most
+    const uint32_t gx = std::max(1u, std::min(RP_GX, 4096u / nd));
+    const dim3 pg(gx, nd), tb(256);
+    hipLaunchKernelGGL(kr_seed, pg, tb, 0, s, a);
+    for (uint32_t r = 0; r < rounds; ++r) hipLaunchKernelGGL(kr_relax, pg, tb, 0, s, a, r);
+    hipLaunchKernelGGL(kr_walks, pg, tb, 0, s, a, rounds);
+    hipLaunchKernelGGL(kr_walks_deep, pg, tb, 0, s, a);
+    hipLaunchKernelGGL(kr_due, pg, tb, 0, s, a);
+    const RpCtl hc{ctx->h_rp, nd};
+    uint32_t s_next = 1u, chunk = std::max(2u, ctx->est_rp);
+    bool overrun = false;
+    for (;;) {
+      for (uint32_t i = 0; i < chunk; ++i) {
+        const uint32_t sw = s_next + i;
+        if (out_words <= 1)      hipLaunchKernelGGL((kr_sweep<1>), pg, tb, 0, s, a, sw);
+        else if (out_words <= 2) hipLaunchKernelGGL((kr_sweep<2>), pg, tb, 0, s, a, sw);
+        else if (out_words <= 4) hipLaunchKernelGGL((kr_sweep<4>), pg, tb, 0, s, a, sw);
+        else                     hipLaunchKernelGGL((kr_sweep<16>), pg, tb, 0, s, a, sw);
+      }
+      s_next += chunk;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->h_rp, ctx->rp_status.p, ctl_words * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(ctx, hipStreamSynchronize(s));
+      if (hc.pend()[s_next] == 0u) break;                             // the last sweep launched woke nobody
+      if (s_next + 8u > RP_MAX_SWEEPS) { overrun = true; break; }
+      chunk = 8u;
+    }
+    if ((run_flags & HSPF_RUN_POP_RANK) && d_rank && !overrun) {
+      // pop ranks of the attempt's roots (a root that failed gets them from a later attempt or from k_exact)
+      const size_t total = (size_t)nd * n;
+      unsigned jb = 1; while ((1ull << jb) < nd) ++jb;
+      size_t t1 = 0, t2 = 0;
+      HIPCHK(ctx, (hipError_t)hub_sort_pairs(nullptr, &t1, nullptr, nullptr, nullptr, nullptr, total, 32, s));
+      HIPCHK(ctx, (hipError_t)hub_sort_pairs(nullptr, &t2, nullptr, nullptr, nullptr, nullptr, total, 32 + jb, s));
+      const size_t tb = (std::max(t1, t2) + 255) & ~(size_t)255;
+      if ((rc = ensure(ctx, ctx->rp_rank, total * 24 + tb + 1024, false))) return rc;
+      uint64_t *k_a = (uint64_t *)ctx->rp_rank.p, *k_b = k_a + total;
+      uint32_t *v_a = (uint32_t *)(k_b + total), *v_b = v_a + total;
+      void *tmp = (void *)(((uintptr_t)(v_b + total) + 255) & ~(uintptr_t)255);
+      size_t tbb = tb;
+      hipLaunchKernelGGL(kr_rank_keys1, dim3((n + 255u) / 256u, nd), dim3(256), 0, s, a, k_a, v_a);
+      HIPCHK(ctx, (hipError_t)hub_sort_pairs(tmp, &tbb, k_a, k_b, v_a, v_b, total, 32, s));
+      hipLaunchKernelGGL(kr_rank_keys2, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, a, (const uint32_t *)v_b, k_a, total);
+      tbb = tb;
+      HIPCHK(ctx, (hipError_t)hub_sort_pairs(tmp, &tbb, k_a, k_b, v_b, v_a, total, 32 + jb, s));
+      hipLaunchKernelGGL(kr_rank_write, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, a, (const uint32_t *)v_a, d_rank, total);
+    }
+    uint32_t used = 0;
+    while (used + 1u <= RP_MAX_SWEEPS && hc.pend()[used + 1u]) ++used;
+    ctx->est_rp = std::min(used + 2u, 64u);
+    { uint32_t need = 0; for (uint32_t j = 0; j < nd; ++j) if (hc.fail()[j] != 1u) need = std::max(need, hc.rlast()[j] + 2u);
+      if (rounds <= 64u) ctx->est_rp_rounds = std::min(std::max(need, RP_RELAX), 64u); }       // rounds the next repair launches (the last one's + a spare)
+    if (getenv("HSPF_REPAIR_PROF"))
+      fprintf(stderr, "[hspf repair] %u roots, n %u, %u rounds: %u sweeps, %u evaluations, %u groups (largest %u); host %.1f us\n", nd, n, rounds, used, hc.tot()[0], hc.tot()[1],
+              hc.tot()[2], std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    std::vector<uint32_t> again;
+    for (uint32_t j = 0; j < nd; ++j) {
+      if (overrun || hc.fail()[j] >= 2u) ex.push_back(todo[j]);
+      else if (hc.fail()[j] == 1u) again.push_back(todo[j]);           // R did not settle: more rounds
+      else ok.push_back(todo[j]);
+    }
+    st.repair_sweeps = std::max(st.repair_sweeps, used); st.repair_evals += hc.tot()[0]; st.repair_groups += hc.tot()[1];
+    todo.swap(again);
   }
-  const size_t zl_off = ((size_t)n + 255u) & ~(size_t)255u;        // [zflag: n bytes | zl: n words | nz]
-  if ((rc = ensure(ctx, ctx->rp_z, zl_off + ((size_t)n + 1u) * 4, false))) return rc;
-  if ((rc = ensure(ctx, ctx->rp_ord, (size_t)nd * n * 8, false))) return rc;
-  if ((rc = ensure(ctx, ctx->rp_work, (size_t)nd * n * 12, false))) return rc;
-  if ((rc = ensure(ctx, ctx->rp_status, (size_t)nd * 44, false))) return rc;
-  if (ctx->h_rp_cap < (size_t)nd * 11) {
-    if (ctx->h_rp) (void)hipHostFree(ctx->h_rp);
-    ctx->h_rp = nullptr; ctx->h_rp_cap = 0;
-    HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_rp, ((size_t)nd * 11 + 704) * 4, hipHostMallocDefault));
-    ctx->h_rp_cap = (size_t)nd * 11 + 704;
-  }
-  uint8_t *zflag = (uint8_t *)ctx->rp_z.p;
-  uint32_t *zl = (uint32_t *)((char *)ctx->rp_z.p + zl_off), *nz = zl + n;
-  HIPCHK(ctx, hipMemsetAsync(zflag, 0, n, s));
-  HIPCHK(ctx, hipMemsetAsync(nz, 0, 4, s));
-  HIPCHK(ctx, hipMemsetAsync(ctx->rp_work.p, 0, (size_t)nd * n * 4, s));                      // the stamps
-  if (gd.e_in) hipLaunchKernelGGL(kr_zmark, dim3((gd.e_in + 255u) / 256u), dim3(256), 0, s, gd.e_in, gd.out_dst, gd.out_w, zflag);
-  hipLaunchKernelGGL(kr_zcompact, dim3((n + 255u) / 256u), dim3(256), 0, s, n, (const uint8_t *)zflag, zl, nz);
-  RepairArgs a{};
-  a.g = gd; a.root_list = (const uint32_t *)ctx->ex_list.p; a.roots = d_roots; a.n_dyn = nd; a.net_nexthops = net_nh; a.ignore_ovl = ignore_ovl;
-  a.tabs = tabs; a.dist = od.dist; a.hops = od.hops; a.flags = od.flags; a.mask = od.mask; a.words = out_words; a.row_map = od.row_map;
-  a.zflag = zflag; a.zl = zl; a.nz = nz;
-  a.R = (uint32_t *)ctx->rp_ord.p; a.pos = a.R + (size_t)nd * n;
-  a.stamp = (uint32_t *)ctx->rp_work.p; a.wl = a.stamp + (size_t)nd * n;
-  a.status = (uint32_t *)ctx->rp_status.p; a.pop_rank = nullptr;
-  if (out_words <= 1)      hipLaunchKernelGGL((k_repair<1>), dim3(nd), dim3(RP_THREADS), 0, s, a);
-  else if (out_words <= 2) hipLaunchKernelGGL((k_repair<2>), dim3(nd), dim3(RP_THREADS), 0, s, a);
-  else if (out_words <= 4) hipLaunchKernelGGL((k_repair<4>), dim3(nd), dim3(RP_THREADS), 0, s, a);
-  else                     hipLaunchKernelGGL((k_repair<16>), dim3(nd), dim3(RP_THREADS), 0, s, a);
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_rp, ctx->rp_status.p, (size_t)nd * 44, hipMemcpyDeviceToHost, s));
-  HIPCHK(ctx, hipStreamSynchronize(s));
-  if (getenv("HSPF_REPAIR_PROF")) {
-    const uint32_t *t = ctx->h_rp + 3 * nd;                         // the first root's workgroup
-    fprintf(stderr, "[hspf k_repair] %u roots, n %u, zero-cost rows %u: seeds %.1f us, R %.1f, walks %.1f, first worklist %.1f, sweeps %.1f (%u sweeps, %u evaluations, %u groups); host %.1f us\n", nd, n, t[5],
-            t[0] / 100.0, t[1] / 100.0, t[2] / 100.0, t[3] / 100.0, t[4] / 100.0, ctx->h_rp[0] >> 8, ctx->h_rp[nd], ctx->h_rp[2 * nd] & 0xFFFFu,
-            std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count());
-  }
-  std::vector<uint32_t> ok;
-  for (uint32_t j = 0; j < nd; ++j) {
-    const uint32_t x = ctx->h_rp[j];
-    if (x & RP_ST_FAIL) { ex.push_back(dy[j]); continue; }
-    ok.push_back(dy[j]);
-    st.repair_sweeps = std::max(st.repair_sweeps, x >> 8);
-    st.repair_evals += ctx->h_rp[nd + j];
-    st.repair_groups += ctx->h_rp[2 * nd + j] & 0xFFFFu;
-  }
+  ex.insert(ex.end(), todo.begin(), todo.end());
+  std::sort(ok.begin(), ok.end());
   dy.swap(ok);
   std::sort(ex.begin(), ex.end());
   st.n_repaired_roots = (uint32_t)dy.size();
@@ -2322,12 +2378,16 @@ int Run::repair_roots() {
 // back): k_exact (status bits: last run_phase).
 int Run::exact_roots() {
   ex.clear(); dy.clear(); oob.clear();
-  const bool forced = (run_flags & (HSPF_RUN_FORCE_EXACT | HSPF_RUN_POP_RANK)) != 0;
+  const bool forced = (run_flags & HSPF_RUN_FORCE_EXACT) != 0;
   const bool tables = pk || (od.hops && od.flags && od.mask);      // everything k_repair reads and writes is there
+  // HSPF_RUN_POP_RANK: every root goes through the repair (a root with a static order has nothing to put right there: its
+  // ranks are the order of (distance, index)) and the ranks come out of two sorts; until round 6 the flag forced k_exact
+  const bool want_rank = (run_flags & HSPF_RUN_POP_RANK) && d_rank && tables && !(ctx->variant & (1u << 27));
   for (uint32_t r = 0; r < n_roots; ++r) {
     if (roots[r] == HSPF_NO_ROOT) continue;
     const uint32_t lf = ctx->h_lane_flags[r];
-    if (forced || (lf & LF_NEED_EXACT)) ex.push_back(r);
+    if (forced || (lf & LF_NEED_EXACT) || ((run_flags & HSPF_RUN_POP_RANK) && !want_rank)) ex.push_back(r);
+    else if (want_rank) dy.push_back(r);
     else if (lf & LF_DYN) {
       if (!pk && !od.hops && !od.mask) continue;                     // distances only: they are final as they are
       if (tables && !(ctx->variant & (1u << 27))) dy.push_back(r); else ex.push_back(r);      // (HSPF_VARIANT bit 27: k_exact as before round 6 — tests, A/B)

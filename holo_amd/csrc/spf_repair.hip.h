@@ -24,10 +24,18 @@
 //        hops(v)    = hops(first parent in that order) + is_router(v),      mask(v) = OR over parents (slot bit | mask(parent)).
 // For natural vertices whose parents are natural this IS the static rule — the emitted rows are right already; k_repair
 // re-evaluates the vertices with a zero-cost tight link from a higher-numbered source and the tight children of non-natural
-// vertices, and from there whatever changes (worklist sweeps, one workgroup per root: the roots are independent).
+// vertices, and from there whatever changes (worklist sweeps).
 //
 // Cost follows the number of zero-cost links and the size of the changed cones, not the size of the graph.  A root whose
-// group does not fit the walk's fixed-size heap, or that has no hops / mask arrays to repair, still goes to k_exact.
+// group does not fit the walk's fixed-size heap, whose R needs more than RP_RELAX rounds, or that has no hops / mask arrays to
+// repair, still goes to k_exact.
+//
+// Shape (round 6, second form).  The first form was ONE launch, one workgroup of 1 024 threads per root: correct, and bound by
+// the latency of its serial per-link loops on ONE compute unit per root — isis-100k with 1 % zero-cost links, 64 roots: 2.2 ms
+// (6 700 evaluations per root, ~30 us each), a single root 1.6 ms with 255 CUs idle (profiles/r06_notes.md).  Now every phase
+// is a chip-wide launch over (roots x items) and an item is worked on by a GROUP OF 16 LANES, one in-link per lane: the
+// dependent loads of a row (record -> source's distance -> source's order / hops / mask) are three round trips per item instead
+// of three per link.  Sweeps are launched ahead in chunks; a sweep whose predecessor woke nobody returns at once.
 #pragma once
 #include "spf_kernels.hip.h"
 
@@ -83,6 +91,27 @@ __global__ __launch_bounds__(256) void kr_unpack_rows(uint32_t n, uint32_t n_row
   }
 }
 
+constexpr uint32_t RP_RELAX = 4u;                // rounds of the R relaxation that are launched (a root still changing in the last one: k_exact)
+constexpr uint32_t RP_MAX_SWEEPS = 4096u;        // worklist sweeps a repair may take
+constexpr uint32_t RP_GX = 64u;                  // blocks per root of a phase launch (256 threads = 16 groups of 16 lanes)
+
+// control block (u32 words, zero on entry).  Per-root counters sit RP_PAD words apart: atomics on one cache LINE retire one after
+// the other whoever issues them (64 roots' counters side by side made the first-worklist launch 1 ms: profiles/r06_notes.md).
+//   cnt[3][n_dyn] worklist lengths (sweep s reads s % 3, fills (s + 1) % 3, clears (s + 2) % 3) | nsc[n_dyn] vertices that wait for a
+//   release path | fail[n_dyn] (1: R did not settle in the rounds launched, 2: anything else) | rlast[n_dyn] last relaxation round that
+//   changed the root | pend[RP_MAX_SWEEPS + 2] "sweep s has work" | evals | groups | gmax
+constexpr uint32_t RP_PAD = 32u;
+struct RpCtl {
+  uint32_t *base; uint32_t nd;
+  __device__ __host__ uint32_t *cnt(uint32_t which, uint32_t j) const { return base + ((size_t)which * nd + j) * RP_PAD; }
+  __device__ __host__ uint32_t *nsc(uint32_t j) const { return base + ((size_t)3u * nd + j) * RP_PAD; }
+  __device__ __host__ uint32_t *fail() const { return base + (size_t)4u * nd * RP_PAD; }
+  __device__ __host__ uint32_t *rlast() const { return fail() + nd; }
+  __device__ __host__ uint32_t *pend() const { return fail() + 2u * (size_t)nd; }
+  __device__ __host__ uint32_t *tot() const { return pend() + RP_MAX_SWEEPS + 2u; }
+  static size_t words(uint32_t nd) { return (size_t)4u * nd * RP_PAD + 2u * (size_t)nd + RP_MAX_SWEEPS + 2u + 4u; }
+};
+
 struct RepairArgs {
   GraphDev g;
   const uint32_t *root_list;   // [n_dyn] indices into roots[] (= the root's slot in the run's slot tables)
@@ -97,9 +126,7 @@ struct RepairArgs {
   uint32_t *R, *pos;           // [n_dyn][n]; only entries of zl vertices are ever written or read
   uint32_t *stamp;             // [n_dyn][n], zero on entry: id of the last sweep a vertex was put on a worklist for
   uint32_t *wl;                // [n_dyn][2][n] worklists
-  uint32_t *status;            // [n_dyn] RP_ST_FAIL | sweeps << 8;  [n_dyn + j]: vertices evaluated;  [2 n_dyn + j]: groups walked | largest << 16;
-                               // [3 n_dyn + 8 j ..]: 100 MHz ticks of the phases (seeds, R, walks, first worklist, sweeps), nz
-  uint32_t *pop_rank;          // may be null (HSPF_RUN_POP_RANK: written by kr_rank_fix)
+  RpCtl ctl;
 };
 
 struct RpCtx {
@@ -124,221 +151,335 @@ __device__ __forceinline__ bool rp_tight(uint32_t du, uint32_t w, uint32_t dv) {
 __device__ __forceinline__ uint64_t rp_ord(const RpCtx &c, uint32_t u) {     // (R, pos) of u; natural vertices: (u, 0)
   return c.zflag[u] ? (((uint64_t)c.R[u] << 32) | c.P[u]) : ((uint64_t)u << 32);
 }
-
-// hops and mask word q..: one vertex in the true order.  Returns false when v has no parent (cannot happen for a vertex of the SPT).
-template <int WMAX>
-__device__ __forceinline__ bool rp_eval(const RpCtx &c, const RepairArgs &a, uint32_t ri, uint32_t v, uint32_t W, uint32_t &nh, uint64_t (&nm)[WMAX]) {
-  const GraphDev &g = c.g;
-  const uint32_t dv = c.D[v];
-  const uint64_t ov = rp_ord(c, v);
-  const bool v_router = !(g.vflags[v] & 1u);
-  uint32_t bd = INF, bhops = 0; uint64_t bo = ~0ull; bool have = false;
-#pragma unroll
-  for (int q = 0; q < WMAX; ++q) nm[q] = 0ull;
-  for (uint32_t e = g.in_ptr[v], e1 = g.in_ptr[v + 1]; e < e1; ++e) {
-    const uint32_t raw = g.in_src[e], w = g.in_w[e], u = raw & SRC_MASK;
-    if (!rp_src_ok(c, raw)) continue;
-    const uint32_t du = c.D[u];
-    if (!rp_tight(du, w, dv)) continue;
-    uint64_t ou = 0;
-    if (w == 0u) { ou = rp_ord(c, u); if (ou >= ov) continue; }     // same level: a parent only if it is popped before v
-    else if (c.zflag[u]) ou = rp_ord(c, u);
-    else ou = (uint64_t)u << 32;
-    const uint32_t hu = c.H[u];
-    if (!have || du < bd || (du == bd && ou < bo)) { have = true; bd = du; bo = ou; bhops = hu; }
-    if (hu == 0u) {                                                 // parent: the root or a hops-0 network -> the link's own slot
-      if (v_router || a.net_nexthops) {
-        const uint32_t base_s = (u == c.root) ? 0u : slot_base_of(a.tabs, ri, u);
-        if (base_s != 0xFFFFFFFFu) {
-          const uint32_t sidx = base_s + g.in_fpos[e];
-          if ((sidx >> 6) < W && (sidx >> 6) < (uint32_t)WMAX) nm[sidx >> 6] |= 1ull << (sidx & 63u);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < WMAX; ++q) if ((uint32_t)q < W) nm[q] |= c.M[(size_t)u * W + q];
-    }
-  }
-  nh = min(bhops + (v_router ? 1u : 0u), 0xFFFFu);                  // u16 saturating_add
-  return have;
+__device__ __forceinline__ bool rp_any16(bool p) {                 // over the 16 lanes of the group
+  return ((__ballot(p) >> (threadIdx.x & 48u)) & 0xFFFFull) != 0ull;
 }
 
-// One workgroup per dynamic root.  WMAX >= mask words of the run (1, 2, 4, 16).
-template <int WMAX>
-__global__ __launch_bounds__(RP_THREADS) void k_repair(RepairArgs a) {
-  __shared__ uint32_t s_cnt[2], s_flag, s_fail, s_evals, s_groups, s_gmax;
-  const uint32_t j = blockIdx.x, tid = threadIdx.x;
-  const uint32_t ri = a.root_list[j];
-  const uint32_t root = a.roots[ri];
+// The per-root view of a phase kernel: block (x, j) works on root j's items x, x + gridDim.x, ... in groups of 16 lanes.
+struct RpRoot {
+  uint32_t j, ri, root, n, W, sub, grp, ngrp;
+  uint32_t *D; uint16_t *H, *F; uint64_t *M; uint32_t *R, *P, *ST, *WL0, *WL1;
+  __device__ __forceinline__ RpRoot(const RepairArgs &a) {
+    j = blockIdx.y; ri = a.root_list[j]; root = a.roots[ri]; n = a.g.n; W = a.words;
+    sub = threadIdx.x & 15u; grp = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); ngrp = gridDim.x * (blockDim.x >> 4);
+    const size_t orow = a.row_map ? a.row_map[ri] : ri;
+    D = a.dist + orow * n; H = a.hops + orow * n; F = a.flags + orow * n; M = a.mask + orow * (size_t)n * W;
+    R = a.R + (size_t)j * n; P = a.pos + (size_t)j * n; ST = a.stamp + (size_t)j * n;
+    WL0 = a.wl + (size_t)j * 2u * n; WL1 = WL0 + n;
+  }
+  __device__ __forceinline__ RpCtx ctx(const RepairArgs &a) const { return RpCtx{a.g, D, H, M, a.zflag, R, P, root, a.ignore_ovl}; }
+};
+
+// Append x to a list of the block's root — every lane of the wave calls it (want = false: nothing to append): ONE atomic per wave.
+__device__ __forceinline__ void rp_append(uint32_t *cnt, uint32_t *list, uint32_t x, bool want) {
+  const uint64_t b = __ballot(want);
+  if (b == 0ull) return;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t base = 0;
+  if (lane == (uint32_t)__builtin_ctzll(b)) base = atomicAdd(cnt, (uint32_t)__popcll(b));
+  base = (uint32_t)__shfl((int)base, __builtin_ctzll(b), 64);
+  if (want) list[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = x;
+}
+// ... onto the worklist of `sweep`, once per sweep and vertex (the stamp decides who appends)
+__device__ __forceinline__ bool rp_wake(const RpRoot &r, uint32_t *cnt, uint32_t *list, uint32_t x, uint32_t sweep, bool want) {
+  want = want && x != r.root && atomicExch(&r.ST[x], sweep) != sweep;
+  rp_append(cnt, list, x, want);
+  return want;
+}
+
+// ---- 1. seeds: R = own index; every other vertex of the list waits for a release path.  Also: HSPF_RF_EXACT on the root's rows.
+__global__ __launch_bounds__(256) void kr_seed(RepairArgs a) {
+  const RpRoot r(a);
   const GraphDev &g = a.g;
-  const uint32_t n = g.n, W = a.words;
-  const size_t orow = a.row_map ? a.row_map[ri] : ri;
-  uint32_t *D = a.dist + orow * n;
-  uint16_t *H = a.hops + orow * n;
-  uint16_t *F = a.flags + orow * n;
-  uint64_t *M = a.mask + orow * (size_t)n * W;
-  uint32_t *R = a.R + (size_t)j * n, *P = a.pos + (size_t)j * n, *ST = a.stamp + (size_t)j * n;
-  uint32_t *WL0 = a.wl + (size_t)j * 2u * n, *WL1 = WL0 + n;
+  const RpCtx c = r.ctx(a);
+  // (the rows are those of a root with a dynamic order: "ask for pop_rank if the order matters")
+  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < r.n; v += gridDim.x * blockDim.x) if (r.F[v] & 1u) r.F[v] = (uint16_t)(r.F[v] | 2u);
   const uint32_t nz = *a.nz;
-  const RpCtx c{g, D, H, M, a.zflag, R, P, root, a.ignore_ovl};
-  if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_flag = 0; s_fail = 0; s_evals = 0; s_groups = 0; s_gmax = 0; }
-  uint32_t *prof = a.status + 3u * a.n_dyn + 8u * j;
-  uint64_t t_mark = wall_clock64();
-  auto lap = [&](uint32_t k) { if (tid == 0) { const uint64_t t = wall_clock64(); prof[k] = (uint32_t)(t - t_mark); t_mark = t; } };
-  if (tid == 0) prof[5] = nz;
-  // ---- 1. seeds: R = own index; every other vertex of the list waits for a release path
-  for (uint32_t i = tid; i < nz; i += RP_THREADS) {
-    const uint32_t v = a.zl[i], dv = D[v];
-    bool seed = dv == INF || v == root;
-    if (!seed)
-      for (uint32_t e = g.in_ptr[v], e1 = g.in_ptr[v + 1]; e < e1 && !seed; ++e) {
-        const uint32_t raw = g.in_src[e], w = g.in_w[e];
-        seed = w != 0u && rp_src_ok(c, raw) && rp_tight(D[raw & SRC_MASK], w, dv);
+  for (uint32_t i = r.grp; i < nz; i += r.ngrp) {
+    const uint32_t v = a.zl[i], dv = r.D[v];
+    bool seed = false;
+    if (dv != INF && v != r.root)
+      for (uint32_t e = g.in_ptr[v] + r.sub, e1 = g.in_ptr[v + 1]; rp_any16(e < e1); e += 16u) {
+        if (e < e1) {
+          const uint32_t raw = g.in_src[e], w = g.in_w[e];
+          seed = seed || (w != 0u && rp_src_ok(c, raw) && rp_tight(r.D[raw & SRC_MASK], w, dv));
+        }
       }
-    R[v] = seed ? v : RP_UNRES;
-    P[v] = 0u;
+    seed = rp_any16(seed) || dv == INF || v == r.root;
+    if (r.sub == 0u) { r.R[v] = seed ? v : RP_UNRES; r.P[v] = 0u; }
+    rp_append(a.ctl.nsc(r.j), r.WL0, v, r.sub == 0u && !seed);       // the only vertices the next two phases look at (WL0 is free until sweep 1)
   }
-  __syncthreads();
-  lap(0);
-  // ---- 2. R = min over zero-cost tight parents of max(R(parent), own index): monotone, to the fixed point
-  for (uint32_t it = 0;; ++it) {
-    bool ch = false;
-    for (uint32_t i = tid; i < nz; i += RP_THREADS) {
-      const uint32_t v = a.zl[i], rv = R[v];
-      if (rv == v) continue;                                         // a seed, or as low as it can get
-      const uint32_t dv = D[v];
-      uint32_t cand = rv;
-      for (uint32_t e = g.in_ptr[v], e1 = g.in_ptr[v + 1]; e < e1; ++e) {
+}
+
+// ---- 2. R = min over zero-cost tight parents of max(R(parent), own index): monotone, to the fixed point (one round per launch)
+__global__ __launch_bounds__(256) void kr_relax(RepairArgs a, uint32_t round) {
+  const RpRoot r(a);
+  uint32_t *rlast = a.ctl.rlast();
+  if (round > 0u && rlast[r.j] + 1u < round) return;               // this root stopped changing (uniform per block)
+  const GraphDev &g = a.g;
+  const RpCtx c = r.ctx(a);
+  const uint32_t ns = *a.ctl.nsc(r.j);
+  bool ch = false;
+  for (uint32_t i = r.grp; i < ns; i += r.ngrp) {
+    const uint32_t v = r.WL0[i], rv = r.R[v];
+    if (rv == v) continue;                                           // as low as it can get (uniform in the group)
+    const uint32_t dv = r.D[v];
+    uint32_t cand = rv;
+    for (uint32_t e = g.in_ptr[v] + r.sub, e1 = g.in_ptr[v + 1]; rp_any16(e < e1); e += 16u) {
+      if (e < e1) {
         const uint32_t raw = g.in_src[e], u = raw & SRC_MASK;
-        if (g.in_w[e] != 0u || !rp_src_ok(c, raw) || D[u] != dv || u == v) continue;
-        const uint32_t ru = a.zflag[u] ? R[u] : u;
-        if (ru != RP_UNRES) cand = min(cand, max(ru, v));
+        if (g.in_w[e] == 0u && rp_src_ok(c, raw) && u != v && r.D[u] == dv) {
+          const uint32_t ru = a.zflag[u] ? r.R[u] : u;
+          if (ru != RP_UNRES) cand = min(cand, max(ru, v));
+        }
       }
-      if (cand < rv) { R[v] = cand; ch = true; }
     }
-    if (ch) s_flag = 1;
-    __syncthreads();
-    const bool again = s_flag != 0;
-    __syncthreads();
-    if (tid == 0) s_flag = 0;
-    __syncthreads();
-    if (!again) break;
-    if (it > 4u * n + 64u) { if (tid == 0) s_fail = 1; break; }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) cand = min(cand, (uint32_t)__shfl_xor((int)cand, off, 16));
+    if (cand < rv) { if (r.sub == 0u) r.R[v] = cand; ch = true; }
   }
-  lap(1);
-  // ---- 3. the groups: members of group y (R == y, other than y) in the order of a lowest-index-first walk from y
-  for (uint32_t i = tid; i < nz; i += RP_THREADS) {
-    const uint32_t v = a.zl[i], y = R[v], dv = D[v];
-    if (y == v || dv == INF) continue;
-    if (y == RP_UNRES) { s_fail = 1; continue; }                     // (in the SPT without a release path: cannot happen)
-    if (!rp_expands(c, y)) continue;
-    // the walk is done by the thread of y's lowest-numbered direct child in the group
-    uint32_t minc = INF; bool direct = false;
-    for (uint32_t k = g.out_ptr[y], k1 = g.out_ptr[y + 1]; k < k1; ++k) {
+  if (ch) rlast[r.j] = round;                                         // (benign race: everybody writes the same value)
+}
+
+// ---- 3. the groups: members of group y (R == y, other than y) in the order of a lowest-index-first walk from y.
+// Nearly every group is FLAT — y's direct zero-cost children, none of which releases a member of its own —, and then the walk is
+// just the children in index order: pos = 1 + the number of links from y to lower-numbered direct children, which every member counts for itself
+// in y's out-row (16 lanes, one out-link each; kr_walks).  A member that is NOT a direct child of y marks the group (stamp of y:
+// free until the first worklist is made) and kr_walks_deep redoes such a group with the real walk, one thread per group.
+constexpr uint32_t RP_DEEP = 0xFFFFFFFEu;
+__global__ __launch_bounds__(256) void kr_walks(RepairArgs a, uint32_t rounds) {
+  const RpRoot r(a);
+  const GraphDev &g = a.g;
+  const RpCtx c = r.ctx(a);
+  if (a.ctl.rlast()[r.j] + 1u >= rounds) { if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl.fail()[r.j] = 1u; return; }   // R did not settle in the rounds launched
+  const uint32_t ns = *a.ctl.nsc(r.j);
+  uint32_t groups = 0;
+  for (uint32_t i = r.grp; i < ns; i += r.ngrp) {
+    const uint32_t v = r.WL0[i], y = r.R[v], dv = r.D[v];
+    if (y == v) continue;                                            // released in index order: natural
+    if (y == RP_UNRES) { if (r.sub == 0u) a.ctl.fail()[r.j] = 2u; continue; }   // (in the SPT without a release path: cannot happen)
+    uint32_t below = 0; bool direct = false;
+    if (rp_expands(c, y))
+      for (uint32_t k = g.out_ptr[y] + r.sub, k1 = g.out_ptr[y + 1]; rp_any16(k < k1); k += 16u) {
+        if (k < k1) {
+          const uint32_t x = g.out_dst[k];
+          if (g.out_w[k] == 0u && x != y && r.D[x] == dv && a.zflag[x] && r.R[x] == y) {
+            direct = direct || x == v;
+            below += x < v ? 1u : 0u;                                // (parallel links count twice: pos only has to ORDER the members)
+          }
+        }
+      }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) below += (uint32_t)__shfl_xor((int)below, off, 16);
+    direct = rp_any16(direct);
+    if (r.sub != 0u) continue;
+    if (direct) { r.P[v] = below + 1u; if (below == 0u) ++groups; }
+    else r.ST[y] = RP_DEEP;                                           // released by another member: the group needs the real walk
+  }
+  if (groups) atomicAdd(a.ctl.tot() + 1, groups);
+}
+__global__ __launch_bounds__(256) void kr_walks_deep(RepairArgs a) {
+  const RpRoot r(a);
+  const GraphDev &g = a.g;
+  const RpCtx c = r.ctx(a);
+  if (a.ctl.fail()[r.j]) return;
+  const uint32_t ns = *a.ctl.nsc(r.j);
+  uint32_t gmax = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+    const uint32_t v = r.WL0[i], y = r.R[v], dv = r.D[v];
+    if (y == v || y == RP_UNRES || r.P[v] != 1u || r.ST[y] != RP_DEEP) continue;     // the walk: the thread of y's lowest direct child
+    const uint32_t k0 = g.out_ptr[y], k1 = g.out_ptr[y + 1];
+    for (uint32_t k = k0; k < k1; ++k) {                               // the flat positions are void
       const uint32_t x = g.out_dst[k];
-      if (g.out_w[k] != 0u || x == y || D[x] != dv || !a.zflag[x] || R[x] != y) continue;
-      minc = min(minc, x); direct = direct || x == v;
+      if (g.out_w[k] == 0u && x != y && r.D[x] == dv && a.zflag[x] && r.R[x] == y) r.P[x] = 0u;
     }
-    if (!direct || minc != v) continue;
     uint32_t heap[RP_HEAP]; uint32_t hn = 0, p = 0; bool fail = false;
     auto push = [&](uint32_t x) {
-      if (P[x] != 0u) return;                                        // on the list or popped already (parallel links, several releasers)
+      if (r.P[x] != 0u) return;                                      // on the list or popped already (parallel links, several releasers)
       if (hn == RP_HEAP) { fail = true; return; }
-      P[x] = RP_INHEAP;
+      r.P[x] = RP_INHEAP;
       uint32_t q = hn++;
       while (q > 0 && heap[q - 1] < x) { heap[q] = heap[q - 1]; --q; }     // kept sorted, largest first: the pop is heap[--hn]
       heap[q] = x;
     };
-    for (uint32_t k = g.out_ptr[y], k1 = g.out_ptr[y + 1]; k < k1; ++k) {
+    for (uint32_t k = k0; k < k1; ++k) {
       const uint32_t x = g.out_dst[k];
-      if (g.out_w[k] == 0u && x != y && D[x] == dv && a.zflag[x] && R[x] == y) push(x);
+      if (g.out_w[k] == 0u && x != y && r.D[x] == dv && a.zflag[x] && r.R[x] == y) push(x);
     }
     while (hn && !fail) {
       const uint32_t m = heap[--hn];
-      P[m] = ++p;
+      r.P[m] = ++p;
       if (!rp_expands(c, m)) continue;
-      for (uint32_t k = g.out_ptr[m], k1 = g.out_ptr[m + 1]; k < k1; ++k) {
+      for (uint32_t k = g.out_ptr[m], ke = g.out_ptr[m + 1]; k < ke; ++k) {
         const uint32_t x = g.out_dst[k];
-        if (g.out_w[k] == 0u && x != y && x != m && D[x] == dv && a.zflag[x] && R[x] == y) push(x);
+        if (g.out_w[k] == 0u && x != y && x != m && r.D[x] == dv && a.zflag[x] && r.R[x] == y) push(x);
       }
     }
-    if (fail) s_fail = 1;
-    atomicAdd(&s_groups, 1u); atomicMax(&s_gmax, p);
+    if (fail) a.ctl.fail()[r.j] = 2u;
+    gmax = max(gmax, p);
   }
-  __syncthreads();
-  lap(2);
-  if (s_fail) {                                                       // nothing was written to the result rows: k_exact redoes the root
-    if (tid == 0) { a.status[j] = RP_ST_FAIL; a.status[a.n_dyn + j] = 0; a.status[2u * a.n_dyn + j] = s_groups | (min(s_gmax, 0xFFFFu) << 16); }
-    return;
-  }
-  // a member that no walk reached (its releaser does not expand, ...) cannot exist: every member has a release path from y
-  // ---- 4. the rows are those of a root with a dynamic order (HSPF_RF_EXACT: "ask for pop_rank if the order matters");
-  //         first worklist: zero-cost tight link from a higher-numbered source; tight children of non-natural vertices
-  for (uint32_t v = tid; v < n; v += RP_THREADS) if (F[v] & 1u) F[v] = (uint16_t)(F[v] | 2u);
-  auto wake = [&](uint32_t x, uint32_t sweep, uint32_t *list, uint32_t which) {
-    if (x == root) return;
-    if (atomicExch(&ST[x], sweep) == sweep) return;
-    list[atomicAdd(&s_cnt[which], 1u)] = x;
-  };
-  for (uint32_t i = tid; i < nz; i += RP_THREADS) {
-    const uint32_t v = a.zl[i], dv = D[v];
-    if (dv == INF || v == root) continue;
-    if (P[v] == RP_INHEAP) { s_fail = 1; continue; }
+  if (gmax) atomicMax(a.ctl.tot() + 2, gmax);
+}
+
+// ---- 4. first worklist: a zero-cost tight link from a higher-numbered source; the tight children of non-natural vertices
+__global__ __launch_bounds__(256) void kr_due(RepairArgs a) {
+  const RpRoot r(a);
+  const GraphDev &g = a.g;
+  const RpCtx c = r.ctx(a);
+  if (a.ctl.fail()[r.j]) return;
+  const uint32_t nz = *a.nz;
+  uint32_t *cnt = a.ctl.cnt(1u, r.j);                                // sweep 1 reads counter 1, list 1
+  bool any = false;
+  for (uint32_t i = r.grp; i < nz; i += r.ngrp) {
+    const uint32_t v = a.zl[i], dv = r.D[v];
+    if (dv == INF || v == r.root) continue;
+    const uint32_t rv = r.R[v];
+    if (rv != v && (r.P[v] == 0u || r.P[v] == RP_INHEAP)) { if (r.sub == 0u) a.ctl.fail()[r.j] = 2u; continue; }   // a member no walk reached: cannot happen
     bool due = false;
-    for (uint32_t e = g.in_ptr[v], e1 = g.in_ptr[v + 1]; e < e1 && !due; ++e) {
-      const uint32_t raw = g.in_src[e], u = raw & SRC_MASK;
-      due = g.in_w[e] == 0u && u >= v && rp_src_ok(c, raw) && D[u] == dv;
-    }
-    if (due) wake(v, 1u, WL0, 0u);
-    if (R[v] != v && rp_expands(c, v))
-      for (uint32_t k = g.out_ptr[v], k1 = g.out_ptr[v + 1]; k < k1; ++k) {
-        const uint32_t x = g.out_dst[k];
-        if (rp_tight(dv, g.out_w[k], D[x]) && D[x] != INF) wake(x, 1u, WL0, 0u);
-      }
-  }
-  __syncthreads();
-  lap(3);
-  // ---- 5. sweeps: evaluate the worklist in the true order; whatever changes wakes its tight children
-  uint32_t sweep = 1u, cur = 0u, evals = 0u;
-  for (;;) {
-    const uint32_t cnt = s_cnt[cur];
-    if (cnt == 0u || s_fail) break;
-    const uint32_t *list = cur ? WL1 : WL0;
-    uint32_t *next = cur ? WL0 : WL1;
-    for (uint32_t i = tid; i < cnt; i += RP_THREADS) {
-      const uint32_t v = list[i];
-      uint32_t nh; uint64_t nm[WMAX];
-      if (!rp_eval<WMAX>(c, a, ri, v, W, nh, nm)) { s_fail = 1; continue; }
-      ++evals;
-      bool ch = nh != H[v];
-#pragma unroll
-      for (int q = 0; q < WMAX; ++q) if ((uint32_t)q < W) ch = ch || nm[q] != M[(size_t)v * W + q];
-      if (!ch) continue;
-      H[v] = (uint16_t)nh;
-#pragma unroll
-      for (int q = 0; q < WMAX; ++q) if ((uint32_t)q < W) M[(size_t)v * W + q] = nm[q];
-      if (!rp_expands(c, v)) continue;
-      const uint32_t dv = D[v];
-      for (uint32_t k = g.out_ptr[v], k1 = g.out_ptr[v + 1]; k < k1; ++k) {
-        const uint32_t x = g.out_dst[k];
-        if (D[x] != INF && rp_tight(dv, g.out_w[k], D[x])) wake(x, sweep + 1u, next, cur ^ 1u);
+    for (uint32_t e = g.in_ptr[v] + r.sub, e1 = g.in_ptr[v + 1]; rp_any16(e < e1); e += 16u) {
+      if (e < e1) {
+        const uint32_t raw = g.in_src[e], u = raw & SRC_MASK;
+        due = due || (g.in_w[e] == 0u && u >= v && rp_src_ok(c, raw) && r.D[u] == dv);
       }
     }
-    __threadfence_block();
-    __syncthreads();
-    if (tid == 0) s_cnt[cur] = 0;
-    cur ^= 1u; ++sweep;
-    __syncthreads();
-    if (sweep > 4u * n + 64u) { if (tid == 0) s_fail = 1; __syncthreads(); break; }
+    any = rp_wake(r, cnt, r.WL1, v, 1u, rp_any16(due) && r.sub == 0u) || any;
+    if (rv != v && rp_expands(c, v))
+      for (uint32_t k = g.out_ptr[v] + r.sub, k1 = g.out_ptr[v + 1]; rp_any16(k < k1); k += 16u) {
+        const uint32_t x = k < k1 ? g.out_dst[k] : v;
+        const bool t = k < k1 && r.D[x] != INF && rp_tight(dv, g.out_w[k], r.D[x]);
+        any = rp_wake(r, cnt, r.WL1, x, 1u, t) || any;
+      }
   }
-  atomicAdd(&s_evals, evals);
-  __syncthreads();
-  lap(4);
-  if (tid == 0) {
-    a.status[j] = (s_fail ? RP_ST_FAIL : 0u) | (min(sweep - 1u, 0xFFFFFFu) << 8);
-    a.status[a.n_dyn + j] = s_evals;
-    a.status[2u * a.n_dyn + j] = s_groups | (min(s_gmax, 0xFFFFu) << 16);
+  if (any) a.ctl.pend()[1] = 1u;
+}
+
+// ---- 5. one sweep: evaluate the worklist in the true order; whatever changes wakes its tight children
+// hops and mask of v: 16 lanes, one in-link each.  `have` false: v has no parent (cannot happen for a vertex of the SPT).
+template <int WMAX>
+__global__ __launch_bounds__(256) void kr_sweep(RepairArgs a, uint32_t sweep) {
+  uint32_t *pend = a.ctl.pend();
+  if (pend[sweep] == 0u) return;                                     // the sweep before woke nobody: the repair is over
+  const RpRoot r(a);
+  const GraphDev &g = a.g;
+  const RpCtx c = r.ctx(a);
+  const uint32_t W = r.W;
+  uint32_t *cnt_cur = a.ctl.cnt(sweep % 3u, r.j), *cnt_next = a.ctl.cnt((sweep + 1u) % 3u, r.j);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *a.ctl.cnt((sweep + 2u) % 3u, r.j) = 0u;   // read by the sweep before, filled by the next one
+  if (a.ctl.fail()[r.j]) return;
+  const uint32_t cnt = *cnt_cur;
+  const uint32_t *list = (sweep & 1u) ? r.WL1 : r.WL0;
+  uint32_t *next = (sweep & 1u) ? r.WL0 : r.WL1;
+  bool any = false; uint32_t evals = 0;
+  for (uint32_t i = r.grp; i < cnt; i += r.ngrp) {
+    const uint32_t v = list[i];
+    const uint32_t dv = r.D[v];
+    const uint64_t ov = rp_ord(c, v);
+    const bool v_router = !(g.vflags[v] & 1u);
+    uint32_t bd = INF, bh = 0; uint64_t bo = ~0ull; bool have = false;
+    uint64_t nm[WMAX];
+#pragma unroll
+    for (int q = 0; q < WMAX; ++q) nm[q] = 0ull;
+    for (uint32_t e = g.in_ptr[v] + r.sub, e1 = g.in_ptr[v + 1]; rp_any16(e < e1); e += 16u) {
+      if (e >= e1) continue;
+      const uint32_t raw = g.in_src[e], w = g.in_w[e], u = raw & SRC_MASK;
+      if (!rp_src_ok(c, raw)) continue;
+      const uint32_t du = r.D[u];
+      if (!rp_tight(du, w, dv)) continue;
+      const uint64_t ou = rp_ord(c, u);
+      if (w == 0u && ou >= ov) continue;                              // same level: a parent only if it is popped before v
+      const uint32_t hu = r.H[u];
+      if (!have || du < bd || (du == bd && ou < bo)) { have = true; bd = du; bo = ou; bh = hu; }
+      if (hu == 0u) {                                                 // parent: the root or a hops-0 network -> the link's own slot
+        if (v_router || a.net_nexthops) {
+          const uint32_t base_s = (u == r.root) ? 0u : slot_base_of(a.tabs, r.ri, u);
+          if (base_s != 0xFFFFFFFFu) {
+            const uint32_t sidx = base_s + g.in_fpos[e];
+            if ((sidx >> 6) < W && (sidx >> 6) < (uint32_t)WMAX) nm[sidx >> 6] |= 1ull << (sidx & 63u);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < WMAX; ++q) if ((uint32_t)q < W) nm[q] |= r.M[(size_t)u * W + q];
+      }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) {                          // the first parent in the order (dist, R, pos); the union of the masks
+      const uint32_t obd = (uint32_t)__shfl_xor((int)bd, off, 16), obh = (uint32_t)__shfl_xor((int)bh, off, 16);
+      const uint64_t obo = (uint64_t)__shfl_xor((long long)bo, off, 16);
+      const bool ohv = __shfl_xor(have ? 1 : 0, off, 16) != 0;
+      if (ohv && (!have || obd < bd || (obd == bd && obo < bo))) { have = true; bd = obd; bo = obo; bh = obh; }
+#pragma unroll
+      for (int q = 0; q < WMAX; ++q) nm[q] |= (uint64_t)__shfl_xor((long long)nm[q], off, 16);
+    }
+    if (!have) { if (r.sub == 0u) a.ctl.fail()[r.j] = 1u; continue; }
+    if (r.sub == 0u) ++evals;
+    const uint32_t nh = min(bh + (v_router ? 1u : 0u), 0xFFFFu);     // u16 saturating_add
+    bool ch = nh != r.H[v];
+#pragma unroll
+    for (int q = 0; q < WMAX; ++q) if ((uint32_t)q < W) ch = ch || nm[q] != r.M[(size_t)v * W + q];
+    if (!ch) continue;                                                // (uniform in the group: every lane compared the same values)
+    // every lane has read the old values: lane 0 stores, the group wakes the tight children up
+    if (r.sub == 0u) {
+      r.H[v] = (uint16_t)nh;
+#pragma unroll
+      for (int q = 0; q < WMAX; ++q) if ((uint32_t)q < W) r.M[(size_t)v * W + q] = nm[q];
+    }
+    if (!rp_expands(c, v)) continue;
+    for (uint32_t k = g.out_ptr[v] + r.sub, k1 = g.out_ptr[v + 1]; rp_any16(k < k1); k += 16u) {
+      const uint32_t x = k < k1 ? g.out_dst[k] : v;
+      const bool t = k < k1 && r.D[x] != INF && rp_tight(dv, g.out_w[k], r.D[x]);
+      any = rp_wake(r, cnt_next, next, x, sweep + 1u, t) || any;
+    }
   }
+  if (any) pend[sweep + 1u] = 1u;
+  if (evals) atomicAdd(a.ctl.tot(), evals);
+}
+
+
+// ---- pop_rank (HSPF_RUN_POP_RANK) of the repaired roots: the position of every vertex in the order of the keys (dist, R, pos).
+// Two stable device-wide radix sorts (hub_sort.h): by R, then by (root, dist); the few runs of equal (dist, R) — a group and the
+// vertex that released it — are put in pos order by their own members.  Vertices off the SPT: 0xFFFFFFFF.
+__global__ __launch_bounds__(256) void kr_rank_keys1(RepairArgs a, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const uint32_t j = blockIdx.y, n = a.g.n;
+  const uint32_t v = blockIdx.x * 256u + threadIdx.x;
+  if (v >= n) return;
+  const size_t item = (size_t)j * n + v;
+  keys[item] = a.zflag[v] ? a.R[item] : v;
+  vals[item] = (uint32_t)item;
+}
+__global__ __launch_bounds__(256) void kr_rank_keys2(RepairArgs a, const uint32_t *__restrict__ items, uint64_t *__restrict__ keys, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t item = items[i], n = a.g.n, j = item / n, v = item - j * n;
+  const uint32_t ri = a.root_list[j];
+  const size_t orow = a.row_map ? a.row_map[ri] : ri;
+  keys[i] = ((uint64_t)j << 32) | a.dist[orow * n + v];
+}
+__global__ __launch_bounds__(256) void kr_rank_write(RepairArgs a, const uint32_t *__restrict__ items, uint32_t *__restrict__ pop_rank, size_t total) {
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t n = a.g.n, item = items[i], j = item / n, v = item - j * n;
+  const uint32_t ri = a.root_list[j];
+  const size_t orow = a.row_map ? a.row_map[ri] : ri;
+  const uint32_t *D = a.dist + orow * n, *R = a.R + (size_t)j * n, *P = a.pos + (size_t)j * n;
+  uint32_t *out = pop_rank + orow * n;
+  const uint32_t dv = D[v];
+  if (dv == INF) { out[v] = INF; return; }
+  const uint32_t rv = a.zflag[v] ? R[v] : v, pv = a.zflag[v] ? P[v] : 0u;
+  // the run of equal (dist, R) around i: the members before me in the run, and those of them with a smaller pos
+  uint32_t before = 0, smaller = 0;
+  const size_t row0 = (size_t)j * n;
+  for (size_t k = i; k > row0; --k) {
+    const uint32_t x = items[k - 1] - j * n;
+    if (D[x] != dv || (a.zflag[x] ? R[x] : x) != rv) break;
+    ++before; smaller += (a.zflag[x] ? P[x] : 0u) < pv ? 1u : 0u;
+  }
+  for (size_t k = i + 1; k < row0 + n; ++k) {
+    const uint32_t x = items[k] - j * n;
+    if (D[x] != dv || (a.zflag[x] ? R[x] : x) != rv) break;
+    smaller += (a.zflag[x] ? P[x] : 0u) < pv ? 1u : 0u;
+  }
+  out[v] = (uint32_t)(i - row0) - before + smaller;
 }
 
 }  // namespace hspf

@@ -10,7 +10,10 @@ EXE = os.path.join(ROOT, "tests", "cpp", "capi_parity")
 
 
 def _build():
-    if not os.path.exists(EXE) or os.path.getmtime(EXE) < os.path.getmtime(EXE + ".cpp"):
+    import glob as _glob
+    # (the headers too: a driver built against an older include/holo_spf_hip.h passes a smaller hspf_stats to the library)
+    deps = [EXE + ".cpp"] + _glob.glob(os.path.join(ROOT, "include", "*.h*"))
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(d) for d in deps):
         from holo_amd import build as hb
         hb.build_lib()
         subprocess.check_call([hb.hipcc_path(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"),

@@ -17,6 +17,14 @@ pytestmark = pytest.mark.gpu
 THREADS = min(64, os.cpu_count() or 1)
 
 
+def _with_zero_links(g, share, seed):
+    """`share` of the links (both directions of a link independently) set to cost 0."""
+    rng = np.random.default_rng(seed)
+    m = g.metric.copy()
+    m[rng.random(len(m)) < share] = 0
+    return synth.CsrGraph(g.row_ptr, g.col, m, g.vflags, g.max_path_metric, g.name + f"-zero{share}")
+
+
 def check_dynamic(ctx, g, roots, run_flags=0, threads=1, want_repaired=True):
     roots = np.asarray(roots, np.uint32)
     G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
@@ -33,6 +41,9 @@ def check_dynamic(ctx, g, roots, run_flags=0, threads=1, want_repaired=True):
     bad = [(int(r), int(np.nonzero((res.first_hop_mask[i] != ref.mask[i]).any(axis=1))[0][0])) for i, r in enumerate(roots)
            if not np.array_equal(res.first_hop_mask[i], ref.mask[i])]
     assert not bad, ("first-hop mask", bad[:4], res.stats)
+    if res.pop_rank is not None:
+        bad = [int(r) for i, r in enumerate(roots) if not np.array_equal(res.pop_rank[i], ref.pop_rank[i])]
+        assert not bad, ("pop rank", bad[:4], res.stats)
     st = res.stats
     assert st["n_exact_roots"] == 0, st
     if want_repaired:
@@ -56,6 +67,24 @@ def test_zero_cost_router_links_without_the_sequential_kernel(spf_ctx, seed, run
     if spf_ctx.mode == "xcd":
         roots = roots[:8]
     check_dynamic(spf_ctx, g, roots, run_flags)
+
+
+@all_engines
+@pytest.mark.parametrize("seed", range(6))
+def test_pop_rank_of_a_dynamic_order_without_the_sequential_kernel(spf_ctx, seed):
+    """HSPF_RUN_POP_RANK: the position of every vertex in the reference's pop order — the order of the keys (dist, R, pos) —
+    equals the oracle's literal loop, nested groups and zero-cost cycles included."""
+    g = synth.random_lsdb(80, 6 if seed % 2 else 0, 2.8, 7400 + seed, metric_hi=1 + seed % 3, zero_cost_router_links=True)
+    roots = np.arange(g.n, dtype=np.uint32)[:50]
+    if spf_ctx.mode == "xcd":
+        roots = roots[:8]
+    check_dynamic(spf_ctx, g, roots, E.RUN_POP_RANK | (E.RUN_NET_NEXTHOPS if seed % 2 else 0))
+
+
+def test_pop_rank_isis_100k_with_zero_cost_links(spf_ctx):
+    g = _with_zero_links(synth.isis_100k(), 0.01, 13)
+    roots = (np.arange(8, dtype=np.uint64) * g.n // 8).astype(np.uint32)
+    check_dynamic(spf_ctx, g, roots, E.RUN_POP_RANK, threads=8)
 
 
 @both_engines
@@ -106,14 +135,6 @@ def test_distances_only_need_no_repair(spf_ctx):
     ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 0, go.MAP)
     assert np.array_equal(d.cpu().numpy().view(np.uint32), ref.dist)
     assert st["n_exact_roots"] == 0 and st["n_repaired_roots"] == 0
-
-
-def _with_zero_links(g, share, seed):
-    """`share` of the links (both directions of a link independently) set to cost 0."""
-    rng = np.random.default_rng(seed)
-    m = g.metric.copy()
-    m[rng.random(len(m)) < share] = 0
-    return synth.CsrGraph(g.row_ptr, g.col, m, g.vflags, g.max_path_metric, g.name + f"-zero{share}")
 
 
 @pytest.mark.parametrize("share", [0.001, 0.01, 0.05])

@@ -85,6 +85,8 @@ def test_forced_exact_and_pop_rank(spf_ctx, seed):
     g = synth.random_lsdb(40, 5, 3.0, 400 + seed, metric_hi=5)
     roots = np.arange(5, 5 + 10, dtype=np.uint32)
     res, ref = check(spf_ctx, g, roots, E.RUN_POP_RANK)
+    assert res.stats["n_exact_roots"] == 0 and res.stats["n_repaired_roots"] == 10      # round 6: the ranks come out of the parallel path
+    res, ref = check(spf_ctx, g, roots, E.RUN_FORCE_EXACT | E.RUN_POP_RANK)
     assert res.stats["n_exact_roots"] == 10
 
 
