@@ -213,7 +213,8 @@ struct hspf_ctx {
   bool xcd_off = false;
   uint32_t xcd_epoch = 0;                  // numbers the barrier flags of a run: nothing is cleared between runs
   uint32_t xcd_attr = 0;
-  uint32_t xcd_timeout_ms = 20;            // HSPF_XCD_TIMEOUT_MS env
+  uint32_t xcd_timeout_ms = 2;             // HSPF_XCD_TIMEOUT_MS env (a barrier normally completes in ~1 us, a sweep in ~4: 2 ms is 500 sweeps; was 20)
+  bool xcd_skew = false;                   // HSPF_XCD_SKEW env (tests): put a root's workgroups on DIFFERENT XCDs — the run must be redone
   DevBuf xcd_ctl;
   // A fused run's scratch, filled for the NEXT run behind this one's results (k_init_fill costs 14 us at the head of a
   // run, and the GPU idles for longer than that while the host turns a run around): valid for exactly these parameters
@@ -713,6 +714,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   if (const char *v = getenv("HSPF_LV_MIN_N")) ctx->lv_min_n = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_XCD_MAX_ROOTS")) ctx->xcd_max_roots = std::min<uint32_t>((uint32_t)strtoul(v, nullptr, 0), XCD_MAX_ROOTS);
   if (const char *v = getenv("HSPF_XCD_ALWAYS")) ctx->xcd_always = strtoul(v, nullptr, 0) != 0;
+  if (const char *v = getenv("HSPF_XCD_SKEW")) ctx->xcd_skew = atoi(v) != 0;
   if (const char *v = getenv("HSPF_XCD_TIMEOUT_MS")) ctx->xcd_timeout_ms = (uint32_t)strtoul(v, nullptr, 0);   // (0: every barrier gives up at once — the test of the fallback)
   if (const char *v = getenv("HSPF_XCD_ROW_COST")) ctx->xcd_row_cost = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_UNIT_HEAVY_DEG")) ctx->unit_heavy_deg = (uint32_t)strtoul(v, nullptr, 0);
@@ -1754,7 +1756,15 @@ int Run::fused_run(int mode) {
       const FusedParams P = use_lean ? fp_lean : (nar ? fp_narrow : fp_wide);
       const size_t esz = nar ? 4 : 8;
       OutDev ode = od;                                           // packed results: the emit writes the state words of THIS width
-      if (pk) { ode.packed = pk_dev(esz); pk_mode = mode; }
+      if (pk) {
+        // a DEVICE destination is written in place by the emit: its size is checked BEFORE anything is launched (ADVICE r05:
+        // the check used to sit in deliver(), behind the kernels that had already overrun a short buffer)
+        if (!pk->host && !pk->dev_stage && (pk->row_off + (size_t)n_roots) * n * esz > pk->cap) {
+          ctx->last_error = "packed results: buffer too small, need " + std::to_string((pk->row_off + (size_t)n_roots) * n * esz) + " bytes";
+          return HSPF_E_INVAL;
+        }
+        ode.packed = pk_dev(esz); pk_mode = mode;
+      }
       const uint32_t ns = use_lean ? n + 1u : n;                 // rows per batch slab (the lean sweep's pad row)
       const size_t rows = (size_t)B * ns * 64;                   // (state rows of THIS width: shadows the member on purpose)
       const uint32_t fillw = use_lean ? P.infw : 0xFFFFFFFFu;
@@ -1985,7 +1995,7 @@ int Run::xcd_run() {
   }
   XcdArgs xa{d_fg, d_roots, fp_wide, net_nh, ignore_ovl, n_roots, ++ctx->xcd_epoch, n_wg, vw,
              g_xcd_next.fetch_add(n_roots, std::memory_order_relaxed) & 7u, n_pad, (uint32_t)(((1ull << 32) + vw - 1u) / vw), d_st, (uint32_t *)ctx->xcd_ctl.p, d_hst,
-             (uint64_t)ctx->xcd_timeout_ms * 100000ull, od};
+             (uint64_t)ctx->xcd_timeout_ms * 100000ull, ctx->xcd_skew ? 1u : 0u, od};
   hipLaunchKernelGGL(kern, dim3(8u * n_wg), dim3(thr), (size_t)n * 8, s, xa);
   (void)hipEventRecord(ctx->ev[2], s);
   (void)hipEventRecord(ctx->ev[4], s);            // the kernel wrote the results in place (as k_single)
@@ -2006,7 +2016,10 @@ int Run::xcd_run() {
       if (!(x & XCD_ST_DONE) || (x & XCD_ST_ABORT)) gave_up = true;
       ctx->h_lane_flags[r] |= x & (LF_NEED_EXACT | LF_OVERFLOW | LF_DYN);
       sweeps = std::max(sweeps, (x >> 8) & 0xFFFFu);
-      if (((x ^ h_st[r * XCD_MAX_WG]) >> 24) & 15u) st.dbg[1] |= 0x80000000u;   // the root's workgroups did not share an XCD (a run that finished is right all the same)
+      // The root's workgroups did not share an XCD: payload and flags are PLAIN stores, coherent only inside one XCD's L2 —
+      // across L2s a flag line can become visible before the state lines it covers, and a run that finished is not proven
+      // right.  Redo it on the launch-per-sweep path, like a barrier that gave up.
+      if (((x ^ h_st[r * XCD_MAX_WG]) >> 24) & 15u) { st.dbg[1] |= 0x80000000u; gave_up = true; }
     }
   if (gave_up) {
     // a workgroup was not resident, or not where its partners' stores are visible: the launch-per-sweep path redoes the
@@ -2437,6 +2450,10 @@ int Run::packed_finish() {
   if (pk) {
     const FusedParams PP = pk_mode == 2 ? fp_lean : pk_mode == 1 ? fp_narrow : fp_wide;
     pk_esz = (pk_mode == 2 || pk_mode == 1) ? 4 : 8;
+    if ((pk_full || !oob.empty()) && !pk->host && !pk->dev_stage && (pk->row_off + (size_t)n_roots) * n * pk_esz > pk->cap) {
+      ctx->last_error = "packed results: buffer too small, need " + std::to_string((pk->row_off + (size_t)n_roots) * n * pk_esz) + " bytes";
+      return HSPF_E_INVAL;
+    }
     if (pk_full || !oob.empty()) {
       const uint32_t nrows = pk_full ? n_roots : (uint32_t)oob.size();
       const uint32_t *rows_list = pk_full ? (const uint32_t *)nullptr : (const uint32_t *)ctx->ex_list.p;
@@ -2879,7 +2896,7 @@ static int lanes_ensure(hspf_ctx *ctx) {
       hspf_ctx *c = ln->sub;
       c->parent = ctx;
       // the caller's context decides the tunables (a lane's own hspf_init read the environment of a later moment)
-      c->variant = ctx->variant; c->single_max_n = ctx->single_max_n; c->lv_max_roots = ctx->lv_max_roots; c->lv_min_n = ctx->lv_min_n; c->xcd_max_roots = ctx->xcd_max_roots; c->xcd_timeout_ms = ctx->xcd_timeout_ms; c->xcd_always = ctx->xcd_always;
+      c->variant = ctx->variant; c->single_max_n = ctx->single_max_n; c->lv_max_roots = ctx->lv_max_roots; c->lv_min_n = ctx->lv_min_n; c->xcd_max_roots = ctx->xcd_max_roots; c->xcd_timeout_ms = ctx->xcd_timeout_ms; c->xcd_skew = ctx->xcd_skew; c->xcd_always = ctx->xcd_always;
       c->lean_dense_pct = ctx->lean_dense_pct; c->lean_stay_pct = ctx->lean_stay_pct; c->lean_dense_passes = ctx->lean_dense_passes;
       c->lean_head = ctx->lean_head; c->lean_passes = ctx->lean_passes; c->hub_deg = ctx->hub_deg; c->lean_multi_min_wgs = ctx->lean_multi_min_wgs;
       c->unit_heavy_deg = ctx->unit_heavy_deg; c->xcd_row_cost = ctx->xcd_row_cost;

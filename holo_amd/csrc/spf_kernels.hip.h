@@ -2047,6 +2047,7 @@ struct XcdArgs {
   uint32_t *ctl;                 // [n_roots][XCD_CTL_WORDS] barrier flags: (epoch << 12 | sweep + 1) << 1 | changed
   uint32_t *status;              // [n_roots][XCD_MAX_WG], pinned host memory
   uint64_t timeout_ticks;        // 100 MHz ticks
+  uint32_t skew;                 // tests (HSPF_XCD_SKEW): a root's workgroups are CONSECUTIVE blocks, i.e. sit on different XCDs
   OutDev o;
   __device__ __forceinline__ const SlotTabs &slot_tabs() const { return gp->tabs; }
   __device__ __forceinline__ const uint8_t *zcyc() const { return gp->g.zcyc; }
@@ -2056,8 +2057,8 @@ template <bool MAXINF, bool PROF>
 __global__ __launch_bounds__(640) void k_xcd(XcdArgs a) {     // (XCD_MAX_N / XCD_MAX_WG vertices, one per thread)
   extern __shared__ uint64_t s_st[];
   __shared__ uint32_t s_wany[16], s_mask, s_go, s_lf;
-  const uint32_t p = blockIdx.x >> 3;
-  const uint32_t root_slot = ((blockIdx.x & 7u) + 8u - a.xcd0) & 7u;
+  const uint32_t p = a.skew ? blockIdx.x % a.n_wg : blockIdx.x >> 3;
+  const uint32_t root_slot = a.skew ? blockIdx.x / a.n_wg : ((blockIdx.x & 7u) + 8u - a.xcd0) & 7u;
   if (root_slot >= a.n_roots) return;
   const GraphDev &g = a.gp->g;
   const uint32_t n = g.n, tid = threadIdx.x, nthr = blockDim.x;

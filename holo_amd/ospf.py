@@ -460,6 +460,10 @@ class SpfState:
                 self.transit_capability[area.area_id] = False
                 self.spts.setdefault(area.area_id, None)
                 self.routers.setdefault(area.area_id, {})
+                # update_rib_full folds EVERY area (holo-ospf/src/route.rs:157-160), this one from the SPT it still holds
+                # (Ospfv2::intra_area_networks walks area.state.spt, ospfv2/spf.rs:462-469): its routes stay
+                if self.spts[area.area_id] is not None:
+                    update_rib_intra_area(rib, self.spts[area.area_id], self.max_paths)
                 continue
             self.spts[area.area_id] = spt
             self.routers[area.area_id], self.transit_capability[area.area_id] = routers_table(area.area_id, spt)

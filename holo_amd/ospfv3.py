@@ -287,6 +287,10 @@ class SpfState:
             for area in ordered:
                 spt = run_area(self.router_id, area, self.engine, self.af)
                 self.engine_runs += 1
+                if spt is None:
+                    # root LSA missing: run_area returns before it touches area.state.spt (holo-ospf/src/spf.rs:596-620) and
+                    # update_rib_full still folds the area from that SPT (route.rs:157-160)
+                    spt = self.spts.get(area.area_id)
                 self.spts[area.area_id] = spt
                 if spt is not None:
                     update_rib_intra_area(self.rib, area, spt, self.max_paths)

@@ -373,8 +373,13 @@ class GraphCache {
 
 // The SPT + intra-area part of compute_spf (holo-ospf/src/spf.rs:489-584, route.rs:146-160): areas in area-id order,
 // one run_area each; rows like the YANG `local-rib` list (type intra-area).
+// `kept` (SpfState): the SPT every area held after its last successful run — `area.state.spt`.  An area whose root LSA is missing
+// keeps it (run_area returns before touching it, holo-ospf/src/spf.rs:596-620) and update_rib_full still folds the area from it
+// (route.rs:157-160): its intra-area routes stay.  The vertices point into the LSAs of the `areas` they were computed from:
+// those must outlive the state, as the reference's Arc<Lsa> handles do.
 inline std::vector<RibRow> compute_spf_intra_area(const std::string &router_id, const std::vector<Area> &areas, uint32_t max_paths, Engine &engine,
-                                                  GraphCache *cache = nullptr, const std::map<std::string, std::vector<VertexId>> *trigger = nullptr) {
+                                                  GraphCache *cache = nullptr, const std::map<std::string, std::vector<VertexId>> *trigger = nullptr,
+                                                  std::map<std::string, SptMap> *kept = nullptr) {
   std::vector<const Area *> order;
   for (auto &a : areas) order.push_back(&a);
   std::stable_sort(order.begin(), order.end(), [](const Area *a, const Area *b) { return ip4(a->area_id) < ip4(b->area_id); });
@@ -390,7 +395,8 @@ inline std::vector<RibRow> compute_spf_intra_area(const std::string &router_id, 
     } else { own = std::make_unique<AreaGraph>(*a); gp = own.get(); }
     AreaGraph &g = *gp;
     auto spt = run_area(router_id, g, engine);
-    if (spt) update_rib_intra_area(rib, *spt, max_paths);
+    if (spt) { update_rib_intra_area(rib, *spt, max_paths); if (kept) (*kept)[a->area_id] = std::move(*spt); }
+    else if (kept) { auto ki = kept->find(a->area_id); if (ki != kept->end()) update_rib_intra_area(rib, ki->second, max_paths); }
   }
   std::vector<RibRow> rows;
   for (auto &kv : rib) {
@@ -893,11 +899,12 @@ class SpfState {
   const std::vector<RibRow> &run(const std::vector<Area> &areas, const std::vector<TriggerLsa> *trigger = nullptr) {
     if (trigger && !spf_is_full(*trigger, 2)) return rows_;
     for (auto &a : areas) { AreaGraph g(a); if (g.index.count({RTR, ip4(router_id_)})) ++engine_runs; }
-    rows_ = compute_spf_intra_area(router_id_, areas, max_paths_, engine_, &cache_);
+    rows_ = compute_spf_intra_area(router_id_, areas, max_paths_, engine_, &cache_, nullptr, &spts_);
     return rows_;
   }
  private:
   std::string router_id_; uint32_t max_paths_; Engine &engine_; GraphCache cache_; std::vector<RibRow> rows_;
+  std::map<std::string, SptMap> spts_;                            // area.state.spt of every area (kept when the root LSA goes missing)
 };
 
 // ---- OSPFv3 (holo-ospf/src/ospfv3/spf.rs) ----------------------------------------------------------------------------
@@ -1152,8 +1159,10 @@ class SpfState {
         AreaGraph g(*a, af_);
         auto spt = run_area(router_id_, g, engine_);
         ++engine_runs;
-        if (spt) update_rib_intra_area(rib_, *a, *spt, max_paths_);
-        spts_[a->area_id] = std::move(spt);
+        // root LSA missing: the area keeps the SPT it had (run_area returns before touching area.state.spt) and is folded from it
+        if (spt) spts_[a->area_id] = std::move(spt);
+        auto it = spts_.find(a->area_id);
+        if (it != spts_.end() && it->second) update_rib_intra_area(rib_, *a, *it->second, max_paths_);
       }
     } else {
       std::set<IpKey> intra;

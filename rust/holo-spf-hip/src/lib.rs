@@ -106,7 +106,11 @@ impl DeviceBuf<'_> {
     pub fn to_host<T: Copy + Default>(&self, count: usize) -> Result<Vec<T>, Error> {
         let mut v = vec![T::default(); count];
         let bytes = count * std::mem::size_of::<T>();
-        debug_assert!(bytes <= self.bytes);
+        // a real check: the pool hands out blocks by size class, a count beyond what was asked for would read a
+        // neighbour's block — or past the allocation — in a release build
+        if bytes > self.bytes {
+            return Err(self.eng.err(sys::HSPF_E_INVAL));
+        }
         let rc = unsafe { sys::hspf_device_to_host(self.eng.ctx, v.as_mut_ptr() as *mut c_void, self.p, bytes) };
         if rc != sys::HSPF_OK {
             return Err(self.eng.err(rc));
@@ -333,11 +337,23 @@ impl RouteRecord {
 
 /// A `run_packed_async` in flight: buffer and status array stay here until `wait_packed` turns them into `Tables`.
 pub struct PackedTicket<'e> {
+    eng: &'e Engine,
     ticket: u64,
-    buf: PinnedBuf<'e>,
-    root_status: Box<[u8]>,
+    buf: Option<PinnedBuf<'e>>,
+    root_status: Option<Box<[u8]>>,
     n_roots: u32,
     n_vertices: u32,
+}
+
+/// A ticket that is dropped without `wait_packed` (an early `?`, an unwinding panic) must not free its page-locked buffer
+/// and status array under the lane thread and the copy stream that still write them (a use-after-free reachable
+/// from safe code): the drop waits for the run first; the fields go afterwards.
+impl Drop for PackedTicket<'_> {
+    fn drop(&mut self) {
+        if self.buf.is_some() {
+            unsafe { sys::hspf_wait(self.eng.ctx, self.ticket, ptr::null_mut()) };
+        }
+    }
 }
 
 /// Level-L ancestor bit sets of every (root, vertex) of a hop-count run (`hspf_ancestors_device`).
@@ -518,19 +534,21 @@ impl Engine {
         if rc != sys::HSPF_OK {
             return Err(self.err(rc));
         }
-        Ok(PackedTicket { ticket, buf, root_status, n_roots: roots.len() as u32, n_vertices: g.n })
+        Ok(PackedTicket { eng: self, ticket, buf: Some(buf), root_status: Some(root_status), n_roots: roots.len() as u32, n_vertices: g.n })
     }
 
-    pub fn wait_packed<'e>(&'e self, t: PackedTicket<'e>) -> Result<Tables<'e>, Error> {
+    pub fn wait_packed<'e>(&'e self, mut t: PackedTicket<'e>) -> Result<Tables<'e>, Error> {
         let mut layout = std::mem::MaybeUninit::<sys::hspf_packed_layout>::zeroed();
         let rc = unsafe { sys::hspf_wait_packed(self.ctx, t.ticket, layout.as_mut_ptr(), ptr::null_mut()) };
+        // (the run is over either way: the ticket's drop has nothing left to wait for)
+        let (buf, root_status) = (t.buf.take().expect("a ticket is waited for once"), t.root_status.take().expect("a ticket is waited for once"));
         if rc != sys::HSPF_OK {
             return Err(self.err(rc));
         }
         Ok(Tables {
             n_roots: t.n_roots,
             n_vertices: t.n_vertices,
-            repr: Repr::Packed { buf: t.buf, layout: unsafe { layout.assume_init() }, root_status: t.root_status.into_vec() },
+            repr: Repr::Packed { buf, layout: unsafe { layout.assume_init() }, root_status: root_status.into_vec() },
         })
     }
 

@@ -621,6 +621,10 @@ int main(int argc, char **argv) {
           t.push_back(O::TriggerLsa{"network", {}, {}});
           const bool full = st.run(areas, &t) == r0 && st.engine_runs > runs;
           if (!same || !full) { ++bad; std::fprintf(stderr, "SPF COMPUTATION DISPATCH MISMATCH %s\n", path.c_str()); }
+          // the root's Router-LSA goes missing: every area keeps the SPT it had and update_rib_full still folds it (route.rs:157-160)
+          auto gone = areas;
+          for (auto &a : gone) a.routers.erase(std::remove_if(a.routers.begin(), a.routers.end(), [&](const O::RouterLsa &l) { return l.adv_rtr == vec["router_id"].s; }), a.routers.end());
+          if (!(st.run(gone) == r0)) { ++bad; std::fprintf(stderr, "ROOT LSA MISSING: THE STORED SPT'S ROUTES DID NOT STAY %s\n", path.c_str()); }
         }
         continue;
       }

@@ -189,6 +189,23 @@ def test_buffer_too_small_is_invalid(spf_ctx):
     G.free()
 
 
+@both_engines
+def test_device_buffer_too_small_is_refused_before_anything_is_written(spf_ctx):
+    """a short DEVICE destination used to be overrun by the emit and refused afterwards.  A canary behind the short
+    buffer must survive the refused call."""
+    import torch
+    g = synth.random_lsdb(2000, 0, 3.0, 78, metric_hi=20)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    roots = np.arange(10, 10 + (8 if spf_ctx.mode == "xcd" else 70), dtype=np.uint32)
+    short = 2 * len(roots) * g.n                                   # half of what 4-byte words need
+    t = torch.full((8 * len(roots) * g.n,), 0xA5, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(E.HspfError) as ei:
+        spf_ctx.run_packed_device(G, roots, 0, words_ptr=t.data_ptr(), cap_bytes=short)
+    assert ei.value.code == -1
+    assert bool((t[short:] == 0xA5).all()), "bytes behind the caller's buffer were written"
+    G.free()
+
+
 def test_large_costs_take_eight_byte_words(spf_ctx):
     """Costs up to 2^20: the 4-byte fields cannot hold the distances — the run is redone wide and says so in the layout."""
     g = synth.random_lsdb(300, 0, 3.0, 80, metric_hi=1 << 20)

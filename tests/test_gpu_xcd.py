@@ -129,6 +129,24 @@ def test_a_barrier_that_gives_up_sends_the_run_to_the_sweep_engine():
     ctx.close()
 
 
+def test_workgroups_on_different_xcds_send_the_run_to_the_sweep_engine():
+    """the barrier's plain stores and sc1 loads are coherent inside ONE XCD's L2 only.  HSPF_XCD_SKEW (tests)
+    makes a root's workgroups consecutive blocks, i.e. spreads them over the eight XCDs: whether that launch times out on a
+    barrier or runs through, its workgroups report different XCC ids and the host must NOT accept what it wrote — the run is
+    redone by the launch-per-sweep engine, results equal the oracle's, and the context stops trying the kernel."""
+    ctx = _ctx(HSPF_XCD_ALWAYS=1, HSPF_XCD_SKEW=1)
+    g = synth.random_lsdb(5000, 300, 3.0, 77, metric_hi=60, lan_size=6)
+    G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    roots = np.asarray([400, 900, 4000], np.uint32)
+    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 1, go.MAP, mask_words_=1)
+    for it in range(3):
+        res = ctx.run(G, roots, 1)
+        assert _same(res, ref), (it, res.stats)
+        assert res.stats["single_wg"] != 2, res.stats                     # never the skewed kernel's own output
+    G.free()
+    ctx.close()
+
+
 def test_two_instances_at_once_stay_correct():
     """Two contexts on two host threads (two protocol instances), each sending one-root runs through k_xcd back to back: the
     kernels of the two may land on the same XCD (a workgroup per CU each: they queue behind each other), every result is

@@ -127,7 +127,7 @@ def test_root_lsa_missing_keeps_the_router_table_and_spt_of_the_area():
     gold = os.path.join(os.path.dirname(__file__), "golden", "ospfv2")
     vec = json.load(open(sorted(glob.glob(os.path.join(gold, "topo2-1_rt1.json")))[0]))
     st = HO.SpfState(vec["router_id"], vec["max_paths"], eng)
-    st.run([HO.Area.from_vector(a) for a in vec["areas"]])
+    before = list(st.run([HO.Area.from_vector(a) for a in vec["areas"]]))
     aid = vec["areas"][0]["area_id"]
     routers, spt = dict(st.routers[aid]), st.spts[aid]
     assert routers and spt is not None
@@ -136,5 +136,26 @@ def test_root_lsa_missing_keeps_the_router_table_and_spt_of_the_area():
     rows = st.run([HO.Area.from_vector(a) for a in gone["areas"]])
     assert st.transit_capability[aid] is False
     assert st.routers[aid] == routers and st.spts[aid] is spt, "the previous run's router table and SPT stay"
+    # ... and update_rib_full still folds the area from that SPT (holo-ospf/src/route.rs:157-160; Ospfv2::intra_area_networks
+    # walks area.state.spt): the routes of the previous run stay in the RIB (the twin used to drop them)
+    assert rows == before and rows
+    # a router that never had an SPT for the area contributes nothing
+    fresh = HO.SpfState(vec["router_id"], vec["max_paths"], eng)
     if len(vec["areas"]) == 1:
-        assert rows == []                           # no intra-area route comes out of an area without a root
+        assert fresh.run([HO.Area.from_vector(a) for a in gone["areas"]]) == []
+
+
+def test_ospfv3_root_lsa_missing_keeps_the_routes_of_the_stored_spt():
+    import copy
+    import glob
+    import json
+    import os
+    from holo_amd import ospfv3 as H3
+    eng = OracleEngine()
+    gold = os.path.join(os.path.dirname(__file__), "golden", "ospfv3")
+    vec = json.load(open(sorted(glob.glob(os.path.join(gold, "topo1-1_rt1.json")))[0]))
+    st = H3.SpfState(vec["router_id"], vec["max_paths"], eng, vec["af"])
+    before = st.run([H3.Area3.from_vector(a) for a in vec["areas"]])
+    gone = copy.deepcopy(vec)
+    gone["areas"][0]["routers"] = [r for r in gone["areas"][0]["routers"] if r["adv_rtr"] != vec["router_id"]]
+    assert before and st.run([H3.Area3.from_vector(a) for a in gone["areas"]]) == before
