@@ -1257,8 +1257,14 @@ __device__ __forceinline__ void lean_group(const FusedGraph *__restrict__ gp, co
     commit(I, finish(r, info[i]));
   };
   static_assert(VPW == 4, "row() is instantiated four times");
+  // (Round 6, VERDICT r05 item 4: the gathers of ALL FOUR rows issued back to back, one wait per row in issue order, was built
+  // and measured — HSPF_LEAN_ALLROWS, profiles/r06_notes.md r06n: 126.4 k against 144.3 k runs/s in flight on the same box, 92.4 k
+  // against 114.0 k one at a time; 18 dense passes instead of 15 and 20.4 x N rows instead of 17.4-18.1, the time per row
+  // unchanged.  The wave's four dependent row trips are what keeps a row behind the row before it in the SAME pass; removed.)
+  {
   row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{});
   row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
+  }
   // ---- rows next to a root (64 roots x ~14 neighbours = 1 % of the rows, and through the general routine 14 % of the
   // run: each kept its wave ~10 us behind the others).  A root's word is all zero in its own lane, so the candidate
   // through the link from the root is [cost | tag | hops 0 | mask 0] there, and what fused_row_any does for a hops-0

@@ -19,7 +19,7 @@
 use std::cell::RefCell;
 use std::collections::{BTreeMap, VecDeque};
 
-use holo_spf_hip::{Csr, CsrCache, Engine, sys};
+use holo_spf_hip::{Csr, CsrCache, DeviceTables, Engine, OrderedPrefixTable, RibDevice, sys};
 
 use super::*;
 
@@ -111,9 +111,20 @@ where
         Some((t, slot_table))
     })?;
 
-    // vertices in (distance, id) order = pop order: a hops == 0 network is materialised before the routers behind it
+    // vertices in pop order: (distance, id) — a hops == 0 network is materialised before the routers behind it — unless the
+    // engine says the root's order is dynamic (zero-cost links: HSPF_RF_EXACT), then by the ranks it computed in that order
     let mut members: Vec<u32> = (0..t.n_vertices).filter(|&v| t.in_spt(0, v)).collect();
-    members.sort_by_key(|&v| (t.dist(0, v), v));
+    if members.iter().any(|&v| t.exact(0, v)) {
+        let rank = GRAPHS.with(|graphs| {
+            let graphs = graphs.borrow();
+            let resident = graphs.get(&area.area_id)?;
+            let graph = Option::as_ref(&resident.graph)?;
+            eng.pop_ranks(graph, &[root], sys::HSPF_RUN_NET_NEXTHOPS).map_err(|e| e.log()).ok()
+        })?;
+        members.sort_by_key(|&v| rank[v as usize]);
+    } else {
+        members.sort_by_key(|&v| (t.dist(0, v), v));
+    }
     let mut lsas: Vec<Option<V::VertexLsa>> = lsas.into_iter().map(Some).collect();
     let mut spt: BTreeMap<V::VertexId, Vertex<V>> = BTreeMap::new();
     let mut slot_cache: BTreeMap<u32, Option<Nexthops<V::IpAddr>>> = BTreeMap::new();
@@ -173,4 +184,84 @@ where
     area.state.spt = spt;
     area.state.spf_run_count += 1;
     area.state.discontinuity_time = Utc::now();
+}
+
+// ---- update_rib_intra_area of every area on the device (route.rs:343-448; the per-area loop of update_rib_full, :157-160) -----
+//
+// `area_tables[a]` = the area's ordered prefix table (one entry per item of `V::intra_area_networks(area, ..)` in the order it
+// yields them: vertex rank, metric, LS-ID of the vertex LSA; `HSPF_PFX_ENTRY_NETWORK` on Network-LSA vertices) and the map from
+// the area's prefixes to the instance-wide prefix list `prefixes` (ascending: BTreeMap<IpNetwork, _> order).  Every area runs
+// its root on the engine (`run_device`), its table is folded into ONE instance-wide RIB state on the device
+// (`Engine::rib_fold` = hspf_rib_fold_device: better replaces, equal merges, the transit-network rule on the larger LS-ID) and
+// only (metric, owner, first-hop mask) of every prefix come back.  `resolve(a, slot)` = the next hops of first-hop slot `slot`
+// of area `a` (the slot replay of `run_area`: V::calc_nexthops once per slot).  Returns the intra-area RIB the unchanged
+// inter-area / external steps and `update_global_rib` (route.rs:856-916) continue with; None: engine error (logged), the
+// caller folds the areas on the host as before.  C++ twin, tested against the recorded RIBs and ibus sequences:
+// include/holo_spf_ospf.hpp RibOnEngine / update_global_rib_device_t; Python: holo_amd/routes.py ospf_update_global_rib_device.
+pub(crate) struct AreaTable {
+    pub graph_root: u32,
+    pub table: OrderedPrefixTable,
+    pub prefix_map: Vec<u32>,
+}
+
+pub(crate) fn update_rib_intra_area_device<V, F>(
+    areas: &[(Ipv4Addr, AreaTable)],
+    prefixes: &[V::IpNetwork],
+    max_paths: u16,
+    mut resolve: F,
+) -> Option<BTreeMap<V::IpNetwork, (u32, u32, Nexthops<V::IpAddr>)>>
+where
+    V: Version,
+    F: FnMut(usize, u32) -> Option<Nexthops<V::IpAddr>>,
+{
+    let eng = ENGINE.with(|e| *e)?;
+    // one run per area, results left in HBM; the areas' first-hop slots get word-aligned places in one instance-wide numbering
+    let mut runs: Vec<DeviceTables<'static>> = Vec::with_capacity(areas.len());
+    let mut offsets = Vec::with_capacity(areas.len());
+    let mut words = 0u32;
+    GRAPHS.with(|graphs| {
+        let graphs = graphs.borrow();
+        for (area_id, at) in areas {
+            let resident = graphs.get(area_id)?;
+            let graph = Option::as_ref(&resident.graph)?;
+            let run = eng.run_device(graph, &[at.graph_root], sys::HSPF_RUN_NET_NEXTHOPS).map_err(|e| e.log()).ok()?;
+            offsets.push(words);
+            words += run.words;
+            runs.push(run);
+        }
+        Some(())
+    })?;
+    let rib: RibDevice<'static> = eng.rib_new(prefixes.len() as u32, words.max(1)).map_err(|e| e.log()).ok()?;
+    for (a, ((_, at), run)) in areas.iter().zip(&runs).enumerate() {
+        eng.rib_fold(&rib, run, &at.table, &at.prefix_map, a as u32, offsets[a]).map_err(|e| e.log()).ok()?;
+    }
+    let (metric, owner, mask) = rib.to_host().map_err(|e| e.log()).ok()?;
+    let w = words.max(1) as usize;
+    let mut out = BTreeMap::new();
+    for (i, prefix) in prefixes.iter().enumerate() {
+        if owner[i] == u32::MAX {
+            continue; // no area reaches the prefix
+        }
+        let mut nexthops = Nexthops::<V::IpAddr>::new();
+        for (a, &off) in offsets.iter().enumerate() {
+            let aw = runs[a].words as usize;
+            for k in 0..aw {
+                let mut m = mask[i * w + off as usize + k];
+                while m != 0 {
+                    let b = m.trailing_zeros();
+                    m &= m - 1;
+                    if let Some(nh) = resolve(a, k as u32 * 64 + b) {
+                        nexthops.extend(nh);
+                    }
+                }
+            }
+        }
+        // route_update's max_paths truncation: the first k by key (route.rs:918-965)
+        while nexthops.len() > max_paths as usize {
+            let last = nexthops.keys().next_back().cloned()?;
+            nexthops.remove(&last);
+        }
+        out.insert(*prefix, (metric[i], owner[i], nexthops));
+    }
+    Some(out)
 }

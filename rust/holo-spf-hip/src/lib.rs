@@ -788,6 +788,98 @@ impl Engine {
         }
         Ok(unsafe { st.assume_init() })
     }
+
+    // ---- several areas, ONE RIB, on the device (ABI 7: hspf_rib_clear_device / hspf_rib_fold_device) ---------------------
+
+    /// The empty instance-wide RIB state in front of the first area (`hspf_rib_clear_device`).
+    pub fn rib_new(&self, n_prefixes: u32, words: u32) -> Result<RibDevice<'_>, Error> {
+        let (p, w) = (n_prefixes as usize, words as usize);
+        let rib = RibDevice {
+            n_prefixes,
+            words,
+            best_metric: self.device_alloc(p.max(1) * 4)?,
+            best_entry: self.device_alloc(p.max(1) * 4)?,
+            nexthop_mask: self.device_alloc((p * w).max(1) * 8)?,
+            origin: self.device_alloc(p.max(1) * 4)?,
+        };
+        let rc = unsafe { sys::hspf_rib_clear_device(self.ctx, &rib.raw()) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(rib)
+    }
+
+    /// `hspf_rib_fold_device`: the literal ordered fold of ONE area's table (`HSPF_PFX_ORDERED`: entries in
+    /// `V::intra_area_networks` order with their owners' LS-IDs) into the state the earlier areas left — `update_rib_intra_area`
+    /// (holo-ospf/src/route.rs:343-448) for the whole area in one call.  `run` = the area's one-root `run_device`;
+    /// `prefix_map[i]` = instance-wide index of the area's prefix i; `word_offset` = where the area's first-hop slots start
+    /// in the instance-wide numbering.
+    #[allow(clippy::too_many_arguments)]
+    pub fn rib_fold(&self, rib: &RibDevice<'_>, run: &DeviceTables<'_>, table: &OrderedPrefixTable, prefix_map: &[u32], area_index: u32, word_offset: u32) -> Result<(), Error> {
+        if run.n_roots != 1 || prefix_map.len() != table.n_prefixes() as usize || word_offset + run.words > rib.words {
+            return Err(Error { code: sys::HSPF_E_INVAL, detail: "rib_fold: one root per area; one map entry per prefix; the area's mask words must fit".into() });
+        }
+        let t = sys::hspf_prefix_table {
+            n_prefixes: table.n_prefixes(),
+            n_entries: table.pfx_vertex.len() as u32,
+            pfx_ptr: table.pfx_ptr.as_ptr(),
+            pfx_vertex: table.pfx_vertex.as_ptr(),
+            pfx_metric: table.pfx_metric.as_ptr(),
+            flags: table.flags | sys::HSPF_PFX_ORDERED,
+            pfx_origin: table.pfx_origin.as_ptr(),
+            init_exists: ptr::null(),
+            init_metric: ptr::null(),
+            init_origin: ptr::null(),
+        };
+        let rc = unsafe {
+            sys::hspf_rib_fold_device(
+                self.ctx, run.n_vertices, run.words, run.dist.p as *const u32, run.flags.p as *const u16, run.mask.p as *const u64, &t, prefix_map.as_ptr(), area_index, word_offset, &rib.raw(),
+            )
+        };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(())
+    }
+
+    /// `hspf_run_packed_device`: the packed words of every (root, vertex) left in HBM (a quarter of `run_device`'s bytes, for
+    /// consumers that stay on the GPU or send the rows on with `Multi::allgather_rows`); returns the buffer, the layout of the
+    /// words and the per-root status (`sys::HSPF_ROOT_EXACT`: the root's pop order is dynamic).
+    pub fn run_packed_device(&self, g: &Graph<'_>, roots: &[u32], run_flags: u32) -> Result<(DeviceBuf<'_>, sys::hspf_packed_layout, Vec<u8>), Error> {
+        let cap = roots.len() * g.n as usize * 8;
+        let buf = self.device_alloc(cap.max(8))?;
+        let mut layout = std::mem::MaybeUninit::<sys::hspf_packed_layout>::zeroed();
+        let mut status = vec![0u8; roots.len()];
+        let rc = unsafe { sys::hspf_run_packed_device(self.ctx, g.g, roots.as_ptr(), roots.len() as u32, run_flags, buf.p, cap, layout.as_mut_ptr(), status.as_mut_ptr()) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok((buf, unsafe { layout.assume_init() }, status))
+    }
+
+    /// Statistics of the last run on this engine (`hspf_get_stats`): which kernels ran, `n_exact_roots`, `n_repaired_roots`.
+    pub fn stats(&self) -> sys::hspf_stats {
+        let mut st = std::mem::MaybeUninit::<sys::hspf_stats>::zeroed();
+        unsafe {
+            sys::hspf_get_stats(self.ctx, st.as_mut_ptr());
+            st.assume_init()
+        }
+    }
+
+    /// Every run handed to a lane is over (`hspf_wait_all`); the number of lanes (`hspf_async_lanes`).
+    pub fn wait_all(&self) -> Result<(), Error> {
+        let rc = unsafe { sys::hspf_wait_all(self.ctx) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(())
+    }
+    pub fn async_lanes(&self) -> u32 {
+        unsafe { sys::hspf_async_lanes(self.ctx) }
+    }
+    pub fn device_count() -> i32 {
+        unsafe { sys::hspf_device_count() }
+    }
 }
 
 impl Drop for Engine {
@@ -905,5 +997,265 @@ impl<'e, K: Ord + Clone> CsrCache<'e, K> {
             self.csr = fresh;
         }
         Ok(self.graph.as_ref().unwrap())
+    }
+}
+
+/// `hspf_prefix_table` of one OSPF area with `HSPF_PFX_ORDERED`: the entries of a prefix in the order
+/// `V::intra_area_networks` yields them, `pfx_origin` = Link State ID of the entry's vertex LSA (the transit-network rule of
+/// holo-ospf/src/route.rs:388-400 compares it); network-LSA entries carry `HSPF_PFX_ENTRY_NETWORK` in `pfx_vertex`.
+#[derive(Debug, Default, Clone)]
+pub struct OrderedPrefixTable {
+    pub pfx_ptr: Vec<u32>,
+    pub pfx_vertex: Vec<u32>,
+    pub pfx_metric: Vec<u32>,
+    pub pfx_origin: Vec<u32>,
+    pub flags: u32, // HSPF_PFX_SATURATING for OSPF (u32 saturating add, spf.rs:672)
+}
+
+impl OrderedPrefixTable {
+    pub fn n_prefixes(&self) -> u32 {
+        self.pfx_ptr.len().saturating_sub(1) as u32
+    }
+}
+
+/// The instance-wide RIB state of one OSPF Full computation on the device (`hspf_rib_device`): after the last area's fold
+/// `(best_metric, best_entry, nexthop_mask)` IS an `hspf_routes` of one root — `into_routes` hands it to `routes_changed`.
+pub struct RibDevice<'e> {
+    pub n_prefixes: u32,
+    pub words: u32,
+    best_metric: DeviceBuf<'e>,
+    best_entry: DeviceBuf<'e>,
+    nexthop_mask: DeviceBuf<'e>,
+    origin: DeviceBuf<'e>,
+}
+
+impl<'e> RibDevice<'e> {
+    fn raw(&self) -> sys::hspf_rib_device {
+        sys::hspf_rib_device {
+            n_prefixes: self.n_prefixes,
+            n_mask_words: self.words,
+            best_metric: self.best_metric.p as *mut u32,
+            best_entry: self.best_entry.p as *mut u32,
+            nexthop_mask: self.nexthop_mask.p as *mut u64,
+            origin: self.origin.p as *mut u32,
+        }
+    }
+    /// Metric, owner (`area_index << 24 | entry`; all ones: no route) and next-hop mask of every prefix, on the host.
+    pub fn to_host(&self) -> Result<(Vec<u32>, Vec<u32>, Vec<u64>), Error> {
+        let (p, w) = (self.n_prefixes as usize, self.words as usize);
+        Ok((self.best_metric.to_host(p)?, self.best_entry.to_host(p)?, self.nexthop_mask.to_host(p * w)?))
+    }
+    pub fn into_routes(self) -> DeviceRoutes<'e> {
+        DeviceRoutes { n_roots: 1, n_prefixes: self.n_prefixes, words: self.words, best_metric: self.best_metric, best_entry: self.best_entry, nexthop_mask: self.nexthop_mask }
+    }
+}
+
+// ---- several GPUs (include/holo_spf_hip.h "several GPUs") -----------------------------------------------------
+// Roots are independent units over a replicated graph: a `Multi` drives the devices of this process (one engine context
+// each) or is ONE rank of a job of processes (RCCL: `unique_id` from rank 0, carried by the host's own transport — holo's
+// ibus).  Tables are DEVICE buffers the caller owns, one `hspf_result` per local device, sized for ALL roots.
+
+pub struct Multi {
+    m: *mut sys::hspf_multi,
+}
+
+pub struct MultiGraph<'m> {
+    multi: &'m Multi,
+    g: *mut sys::hspf_multi_graph,
+    pub n: u32,
+}
+
+impl Multi {
+    fn err(&self, code: i32) -> Error {
+        let detail = unsafe { CStr::from_ptr(sys::hspf_multi_last_error(self.m)) }.to_string_lossy().into_owned();
+        Error { code, detail }
+    }
+
+    /// Rank 0 of a job of processes: the communicator id every rank passes to `new` (`hspf_multi_unique_id`; needs librccl.so).
+    pub fn unique_id() -> Result<[u8; sys::HSPF_COMM_ID_BYTES as usize], Error> {
+        let mut id = [0u8; sys::HSPF_COMM_ID_BYTES as usize];
+        let rc = unsafe { sys::hspf_multi_unique_id(id.as_mut_ptr()) };
+        if rc != sys::HSPF_OK {
+            return Err(Error { code: rc, detail: "hspf_multi_unique_id (librccl.so)".into() });
+        }
+        Ok(id)
+    }
+
+    /// `unique_id == None`: one process drives every device (`world == device_ordinals.len()`, peer copies over xGMI);
+    /// `Some(id)`: this process is the ranks `first_rank ..` of a job of `world` ranks (RCCL).
+    pub fn new(device_ordinals: &[i32], world: u32, first_rank: u32, unique_id: Option<&[u8; sys::HSPF_COMM_ID_BYTES as usize]>) -> Result<Self, Error> {
+        let cfg = sys::hspf_multi_config {
+            n_local: device_ordinals.len() as u32,
+            device_ordinals: device_ordinals.as_ptr(),
+            world,
+            first_rank,
+            unique_id: unique_id.map_or(ptr::null(), |id| id.as_ptr()),
+        };
+        let mut m = ptr::null_mut();
+        let rc = unsafe { sys::hspf_multi_init(&cfg, &mut m) };
+        if rc != sys::HSPF_OK {
+            let detail = unsafe { CStr::from_ptr(sys::hspf_multi_init_error()) }.to_string_lossy().into_owned();
+            return Err(Error { code: rc, detail });
+        }
+        Ok(Multi { m })
+    }
+
+    pub fn n_local(&self) -> u32 {
+        unsafe { sys::hspf_multi_n_local(self.m) }
+    }
+
+    /// A replica of the graph on every local device.
+    pub fn upload(&self, csr: &Csr) -> Result<MultiGraph<'_>, Error> {
+        let c = sys::hspf_csr {
+            n_vertices: csr.n_vertices(),
+            n_edges: csr.col.len() as u32,
+            row_ptr: csr.row_ptr.as_ptr(),
+            col: csr.col.as_ptr(),
+            metric: csr.metric.as_ptr(),
+            vflags: csr.vflags.as_ptr(),
+            max_path_metric: csr.max_path_metric,
+        };
+        let mut g = ptr::null_mut();
+        let rc = unsafe { sys::hspf_multi_graph_upload(self.m, &c, &mut g) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(MultiGraph { multi: self, g, n: csr.n_vertices() })
+    }
+
+    /// `[begin, end)` of `rank` in a list of `n_roots` roots: whole 64-root batches (`hspf_shard_bounds`).
+    pub fn shard_bounds(n_roots: u32, world: u32, rank: u32) -> (u32, u32) {
+        let (mut b, mut e) = (0u32, 0u32);
+        unsafe { sys::hspf_shard_bounds(n_roots, world, rank, &mut b, &mut e) };
+        (b, e)
+    }
+
+    /// Areas first, then roots (multi-area OSPF, BASELINE configs[3]): the (rank, area, root range) slices of `hspf_plan_areas`.
+    pub fn plan_areas(roots_per_area: &[u32], world: u32) -> Vec<sys::hspf_area_slice> {
+        let cap = roots_per_area.len() as u32 + world;
+        let mut out = vec![sys::hspf_area_slice { rank: 0, area: 0, root_begin: 0, root_end: 0 }; cap as usize];
+        let k = unsafe { sys::hspf_plan_areas(roots_per_area.len() as u32, roots_per_area.as_ptr(), world, out.as_mut_ptr(), cap) };
+        out.truncate(k.min(cap) as usize);
+        out
+    }
+
+    pub fn mask_words(&self, g: &MultiGraph<'_>, roots: &[u32]) -> Result<u32, Error> {
+        let mut w = 0u32;
+        let rc = unsafe { sys::hspf_multi_mask_words(self.m, g.g, roots.as_ptr(), roots.len() as u32, &mut w) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(w)
+    }
+
+    /// Sharded run + the all-gather of the tables selected in `gather` (the `HSPF_GATHER_*` bits of `sys`).
+    ///
+    /// # Safety
+    /// `all[i]` holds DEVICE pointers on local device i sized for ALL `roots.len()` rows; valid until the call (or, with
+    /// `HSPF_GATHER_ASYNC`, `wait`) has returned.
+    pub unsafe fn run(&self, g: &MultiGraph<'_>, roots: &[u32], run_flags: u32, all: &mut [sys::hspf_result], gather: u32) -> Result<(), Error> {
+        if all.len() != self.n_local() as usize {
+            return Err(Error { code: sys::HSPF_E_INVAL, detail: "Multi::run: one hspf_result per local device".into() });
+        }
+        let rc = sys::hspf_multi_run(self.m, g.g, roots.as_ptr(), roots.len() as u32, run_flags, all.as_mut_ptr(), gather);
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(())
+    }
+
+    /// The two halves of `run` (several steps in flight, into DIFFERENT tables; wait in ticket order on every rank).
+    ///
+    /// # Safety
+    /// As `run`; the tables of a ticket must not be shared with another ticket in flight.
+    pub unsafe fn run_async(&self, g: &MultiGraph<'_>, roots: &[u32], run_flags: u32, all: &[sys::hspf_result]) -> Result<u64, Error> {
+        let mut ticket = 0u64;
+        let rc = sys::hspf_multi_run_async(self.m, g.g, roots.as_ptr(), roots.len() as u32, run_flags, all.as_ptr(), &mut ticket);
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(ticket)
+    }
+    /// # Safety
+    /// `all` = the tables the ticket was started with.
+    pub unsafe fn run_wait(&self, ticket: u64, all: &mut [sys::hspf_result], gather: u32) -> Result<(), Error> {
+        let rc = sys::hspf_multi_run_wait(self.m, ticket, all.as_mut_ptr(), gather);
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(())
+    }
+
+    /// Pending asynchronous gathers are over (`hspf_multi_wait`).
+    pub fn wait(&self) -> Result<(), Error> {
+        let rc = unsafe { sys::hspf_multi_wait(self.m) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(())
+    }
+
+    /// The collective on its own, for any per-root table (route tables after `routes_device`: "a single all-gather of
+    /// per-root route tables").
+    ///
+    /// # Safety
+    /// `tables[i]`: a device buffer on local device i of `n_roots` rows of `row_bytes` bytes whose own rows are filled.
+    pub unsafe fn allgather_rows(&self, tables: &[*mut c_void], row_bytes: usize, n_roots: u32) -> Result<(), Error> {
+        let rc = sys::hspf_multi_allgather_rows(self.m, tables.as_ptr(), row_bytes, n_roots);
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(())
+    }
+
+    pub fn stats(&self, local_index: u32) -> Result<sys::hspf_stats, Error> {
+        let mut st = std::mem::MaybeUninit::<sys::hspf_stats>::zeroed();
+        let rc = unsafe { sys::hspf_multi_get_stats(self.m, local_index, st.as_mut_ptr()) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok(unsafe { st.assume_init() })
+    }
+
+    /// The context of local device `i`, for the one-device calls (`hspf_device_alloc`, `hspf_routes_device` ...) on that rank.
+    pub fn ctx_raw(&self, local_index: u32) -> *mut sys::hspf_ctx {
+        unsafe { sys::hspf_multi_ctx(self.m, local_index) }
+    }
+}
+
+impl Drop for Multi {
+    fn drop(&mut self) {
+        unsafe { sys::hspf_multi_shutdown(self.m) }
+    }
+}
+
+impl MultiGraph<'_> {
+    /// Whole rows replaced on every replica (`hspf_multi_graph_patch`).
+    pub fn patch(&mut self, rows: &[RowPatch]) -> Result<(), Error> {
+        let vertex: Vec<u32> = rows.iter().map(|r| r.vertex).collect();
+        let vflags: Vec<u8> = rows.iter().map(|r| r.vflags).collect();
+        let mut row_ptr = vec![0u32];
+        let (mut col, mut metric) = (Vec::new(), Vec::new());
+        for r in rows {
+            col.extend_from_slice(&r.col);
+            metric.extend_from_slice(&r.metric);
+            row_ptr.push(col.len() as u32);
+        }
+        let p = sys::hspf_rows { n_changed: rows.len() as u32, vertex: vertex.as_ptr(), row_ptr: row_ptr.as_ptr(), col: col.as_ptr(), metric: metric.as_ptr(), vflags: vflags.as_ptr() };
+        let rc = unsafe { sys::hspf_multi_graph_patch(self.multi.m, self.g, &p) };
+        if rc != sys::HSPF_OK {
+            return Err(self.multi.err(rc));
+        }
+        Ok(())
+    }
+    /// The replica on local device `i` (`hspf_multi_graph_local`), for the one-device calls on that rank's context.
+    pub fn local_raw(&self, local_index: u32) -> *mut sys::hspf_graph {
+        unsafe { sys::hspf_multi_graph_local(self.g, local_index) }
+    }
+}
+
+impl Drop for MultiGraph<'_> {
+    fn drop(&mut self) {
+        unsafe { sys::hspf_multi_graph_free(self.multi.m, self.g) }
     }
 }

@@ -81,6 +81,17 @@ def test_glue_uses_only_wrapper_items_that_exist():
             assert meth in pub, (rel, meth)
 
 
+def test_every_function_of_the_header_has_a_safe_wrapper_or_is_on_the_inspection_list():
+    """33 of the 62 ABI functions (every hspf_multi_*, hspf_rib_fold_device) had no Rust wrapper.  Now every
+    function of include/holo_spf_hip.h is called by the wrapper crate or the glue — or is one of the inspection / plumbing
+    functions below, which a holo build has no use for."""
+    consts, structs, opaques, funcs = _hdr()
+    text = "".join(open(os.path.join(RUST, rel)).read() for rel in ("holo-spf-hip/src/lib.rs", "holo-isis/src/spf/hip.rs", "holo-ospf/src/spf/hip.rs"))
+    used = set(re.findall(r"\bsys::(hspf_[a-z0-9_]+)", text))
+    unbound = sorted(name for _, name, _ in funcs if name not in used)
+    assert unbound == ["hspf_get_stream", "hspf_graph_export", "hspf_graph_n_edges", "hspf_graph_n_edges_kept", "hspf_graph_n_vertices", "hspf_set_stream"], unbound
+
+
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "holo-isis")), reason="reference tree not mounted")
 def test_patches_are_current_and_apply_to_the_reference_tree(tmp_path):
     import make_rust_patches
