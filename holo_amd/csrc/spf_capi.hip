@@ -47,9 +47,6 @@ struct hspf_graph {
   mutable std::atomic<bool> narrow_bad{false};   // a run overflowed the 4-byte fused state: use the 8-byte one
   mutable std::atomic<bool> wide24_bad{false};   // a run overflowed the hop field of the 8-byte state with > 16 mask bits
   mutable std::atomic<bool> lean_bad{false};     // a run overflowed the fields of the lean 4-byte state (k_fused_lean): k_fused from now on
-  // runs of 1-8 roots on a mid-size graph: device microseconds (+1; 0 = not measured yet) of the last such run by k_xcd / by
-  // the launch-per-sweep engine, per root count — the faster one takes the next run (Run::prepare_outputs)
-  mutable std::atomic<uint32_t> xcd_us[9] = {}, sweep_us[9] = {}, xcd_choices[9] = {};
   bool hopcount_like = false;        // every kept link into a network costs 0 (from a router), into a router 1
   bool heavy_rows = false;           // a quarter or more of the links sit in rows of more than 32 (fat-tree switches, big LANs)
   uint32_t xcd_start[9] = {};        // work-balanced chunk ranges of the 8 XCDs (GraphDev::xcd_start)
@@ -862,7 +859,7 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
   // ---- fast path: every replaced row lists the same targets in the same order with the same flags — only costs differ
   // (kb_pc_apply / kb_pc_resort, graph_build.hip.h): nothing is rebuilt, no per-link array crosses the bus, the host
   // mirrors stay as they are.  HSPF_VARIANT bit 16 switches it off (A/B, tests of the rebuild path).
-  if (!(ctx->variant & 65536u) && g->max_in_deg <= 256u && g->n_giant == 0) {
+  if (g->max_in_deg <= 256u && g->n_giant == 0) {
     bool same = true;
     for (uint32_t j = 0; j < m && same; ++j) {
       const uint32_t v = rows->vertex[j], a = g->row_ptr[v], len = g->row_ptr[v + 1] - a;
@@ -1525,7 +1522,7 @@ int Run::prepare_scratch() {
     ctx->h_lane_cap = L;
   }
   // slices of the giant rows (FusedGraph::giant_part): tags, then GIANT_WORDS x 64 words per (batch, slice)
-  giant = g->n_giant != 0 && g->n_heavy_chunks != 0 && !(ctx->variant & 8192u);   // HSPF_VARIANT bit13: rows walked whole
+  giant = g->n_giant != 0 && g->n_heavy_chunks != 0;
   giant_tags = ((size_t)B * g->n_giant + 63) & ~size_t(63);
   if (giant) {                                           // packed path: one accumulator per slice; k_fw: one per 64 links, W-word masks
     const size_t packed = (size_t)B * g->n_giant_slices * GIANT_WORDS * 64 * 4;
@@ -1547,25 +1544,18 @@ int Run::prepare_outputs() {
   single = fused && n <= smax && g->e_kept <= SINGLE_MAX_E;
   lv = fused && !single && n_roots <= ctx->lv_max_roots && n >= ctx->lv_min_n && !giant;
   // One to eight roots on a graph of at most XCD_MAX_N vertices: k_xcd (one launch, a barrier inside one XCD per sweep) or
-  // the launch-per-sweep engine.  Neither wins everywhere: k_xcd's sweeps are Jacobi across workgroups (ospf-10k 37 sweeps
-  // of ~4.5 us against ~36 launches of ~5.3 us; hop-count graphs and several roots 25-40 % faster; a 50 x 50 grid, 111
-  // sweeps against 63-98 launches, slower: profiles/r05_notes.md), so the graph remembers what each took last time for
-  // this many roots and the faster one runs (patches change the graph under the measurements: the other one is looked
-  // at again now and then).
-  // (k_single's graphs too: with at most eight roots the one-workgroup kernel leaves 248 CUs idle and walks a root's rows
-  // with one CU; k_xcd measured 1.1-4.5 x faster from 300 to 4 000 vertices, profiles/r05_notes.md r05p — the choice below
-  // keeps whichever is faster, e.g. k_single_lean on the reference's own 500-router grid if it is)
+  // the launch-per-sweep engine.  k_xcd's sweeps are Jacobi across workgroups (ospf-10k 37 sweeps of ~4.5 us against ~36
+  // launches of ~5.3 us; hop-count graphs and several roots 25-40 % faster; 18 000 vertices one root a tie; a 50 x 50 grid,
+  // 111 sweeps against 63-98 launches, 13 % slower with two roots: profiles/r05_notes.md), and on k_single's graphs it is
+  // 1.1-4.5 x faster from 300 to 4 000 vertices (with at most eight roots the one-workgroup kernel leaves 248 CUs idle,
+  // r05p) — except where k_single_lean applies with ONE root: the reference's own 500-router case, 0.034 against 0.07 ms.
+  // Round 5 let the graph remember which of the two was faster last time; the choice is a pure function of the run's shape
+  // now (latency that depends on a graph's history is hard to reason about in a daemon).
   xcd_ok = fused && !lv && !ctx->xcd_off && n_roots >= 1 && n_roots <= ctx->xcd_max_roots && n <= XCD_MAX_N && g->n_giant == 0 &&
            !(run_flags & HSPF_RUN_COUNT_ROWS);
   xcdp = xcd_ok;
-  if (xcd_ok && !ctx->xcd_always) {
-    // choices 0-1: k_xcd, 2-4: the other kernel (the sweep engine's first runs on a context still size their launch plan), then the
-    // faster of the two last times; every 256th choice the other one, to look again
-    const uint32_t c = g->xcd_choices[n_roots].fetch_add(1u, std::memory_order_relaxed);
-    const uint32_t tx = g->xcd_us[n_roots].load(std::memory_order_relaxed), ts = g->sweep_us[n_roots].load(std::memory_order_relaxed);
-    xcdp = c < 2u ? true : c < 5u ? false : (tx != 0u && (ts == 0u || tx <= ts));
-    if (c >= 5u && (c & 255u) == 255u) xcdp = !xcdp;
-  }
+  if (xcd_ok && !ctx->xcd_always)
+    xcdp = !(single && g->lean && n <= (uint32_t)SINGLE_THREADS && !(ctx->variant & 4096u) && n_roots == 1);
   if (xcdp) single = false;
   // row-major output targets (device): the caller's device buffers, or staging for host output
   od = OutDev{};
@@ -1635,7 +1625,7 @@ int Run::upload_block() {
     // already holds — same allocation, nothing in it is ever written by a kernel — the copy is skipped (HSPF_VARIANT bit
     // 14 keeps it).  Otherwise the halves swap: the block just built becomes the reference.
     st.dbg[2] = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_entry).count();
-    const bool same = ctx->up_valid && ctx->up_len == up_bytes && !(ctx->variant & 16384u) && memcmp(h, prev, up_bytes) == 0;
+    const bool same = ctx->up_valid && ctx->up_len == up_bytes && memcmp(h, prev, up_bytes) == 0;
     if (!same) {
       HIPCHK(ctx, hipMemcpyAsync(d_up, h, up_bytes, hipMemcpyHostToDevice, s));
       ctx->up_valid = true; ctx->up_len = up_bytes; ctx->h_up_sel ^= 1;
@@ -1653,7 +1643,7 @@ int Run::init_state() {
   // when there are any and neither the saturating-distance nor the hop-count instantiation is needed (HSPF_VARIANT
   // bit17: leaves take part like any row).
   use_fw = !fused && !(ctx->variant & 64u) && (!g->hopcount_like || W <= 4);
-  defer = use_fw && g->n_leaf != 0 && g->max_path_metric != HSPF_DIST_INF && !g->hopcount_like && !(ctx->variant & 131072u);
+  defer = use_fw && g->n_leaf != 0 && g->max_path_metric != HSPF_DIST_INF && !g->hopcount_like;
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
   if (fused) {
     // state / stamps / status bits are initialised by fused_run (it may run twice: narrow, then wide), lv_run or the
@@ -1783,8 +1773,7 @@ int Run::fused_run(int mode) {
       ctx->prefill.valid = false;                                // (a speculative fill of an earlier fused_run of this call is gone now)
       spec_done = false;
       spec_fill = nullptr;
-      if (!(ctx->variant & (2048u | 2097152u)))                  // HSPF_VARIANT bit11: no prefill at all; bit21: only after the run, as before
-        spec_fill = [&, esz, fillw, rows](uint32_t last_sweep) {
+      spec_fill = [&, esz, fillw, rows](uint32_t last_sweep) {
           const uint32_t nz = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
           // (the emit in front of this launch has reset the state slab under the same guard: stamps, flags and counters are left)
           hipLaunchKernelGGL(k_init_fill, dim3(emit_reset ? 256 : 2048), dim3(256), 0, s, (uint4 *)d_st, emit_reset ? (size_t)0 : rows * esz / 16, fillw, d_stamp, (size_t)B * n,
@@ -1848,7 +1837,7 @@ int Run::fused_run(int mode) {
 #define HSPF_LAUNCH_LEAN_B(MD_, HD_, grid_, pb_, base_, thr_) do { if (count_rows) HSPF_LAUNCH_LEAN_BM(true, MD_, HD_, grid_, pb_, base_, thr_); else HSPF_LAUNCH_LEAN_BM(false, MD_, HD_, grid_, pb_, base_, thr_); } while (0)
           // at least 8 batches: each XCD takes whole batches (their state stays in its L2 across the passes); HSPF_VARIANT bit 24: off (A/B)
           const uint32_t bm_blocks = (n + (uint32_t)FVPB - 1u) / (uint32_t)FVPB;
-          const bool bmaj = B >= 8u && !(ctx->variant & 16777216u) && 8ull * ((B + 7u) / 8u) * bm_blocks * per_launch < (1ull << 31);
+          const bool bmaj = B >= 8u && 8ull * ((B + 7u) / 8u) * bm_blocks * per_launch < (1ull << 31);
           const dim3 bgrid(8u * ((B + 7u) / 8u) * bm_blocks);        // one pass over all batches, batch-major
           // (the stamped sweeps keep the row-major placement: in batch-major form they were slower — 4.48 against 4.33 ms for the
           // ten areas of configs[3], profiles/r04_notes.md r04y)
@@ -1940,7 +1929,7 @@ int Run::lv_run() {
       LvArgs la{d_changed, 0, n, a_stamp, d_st, d_roots, gd.in_ptr, gd.rowflags, gd.vflags,
                 gd, tabs, d_kcnt, fp_wide, net_nh, ignore_ovl, n_roots, count_rows ? 1u : 0u, d_lf,
                 (const uint32_t *)g->d_ell_so, (const uint32_t *)g->d_ell_w, (const uint32_t *)g->d_ell_od,
-                (ctx->variant & (1u << 26)) ? 0u : (ctx->variant & (1u << 25)) ? 1u : 2u};
+                2u};
       const bool mi = g->max_path_metric == HSPF_DIST_INF;
       const dim3 lgrid((n + 255) / 256, n_roots);
       uint32_t n_f = 0;
@@ -2067,7 +2056,7 @@ int Run::single_run() {
       }
       // the plainest graphs (routers only, no row flag, in-degrees <= 8) with one vertex per thread: the lean kernel
       const bool lean = g->lean && n <= (uint32_t)SINGLE_THREADS && !(ctx->variant & 4096u);
-      if (lean && g->max_in_deg <= 4u && !(ctx->variant & 262144u)) {   // HSPF_VARIANT bit18: eight link records per thread whatever the rows hold
+      if (lean && g->max_in_deg <= 4u) {
         if (mi) hipLaunchKernelGGL((k_single_lean<true, 4>), dim3(n_roots), dim3(thr), (size_t)n * 8, s, sa);
         else    hipLaunchKernelGGL((k_single_lean<false, 4>), dim3(n_roots), dim3(thr), (size_t)n * 8, s, sa);
       } else if (lean) {
@@ -2154,7 +2143,7 @@ int Run::path_fused() {
       }
     }
     st.state_bytes = narrow ? 4 : 8;
-    if (last_esz && !(ctx->variant & 2048u) && !ctx->prefill.valid) {
+    if (last_esz && !ctx->prefill.valid) {
       // the next run's scratch, behind this one's emit (same shape assumed: an SPF instance repeats its root set) — unless
       // the speculative fill behind the last chunk's read-back has done it already
       const uint32_t nz = std::min<uint32_t>(CHANGED_CAP, ctx->est_fused + 4096);
@@ -2518,8 +2507,6 @@ int Run::deliver() {
   }
   if (!(count_rows && st.single_wg))
     st.dbg[3] = (uint32_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_entry).count();
-  if (xcd_ok && st.ms_total > 0.f)                                 // what this path took for this many roots (see prepare_outputs)
-    (xcdp ? g->xcd_us : g->sweep_us)[n_roots].store((uint32_t)(st.ms_total * 1000.f) + 1u, std::memory_order_relaxed);
   return HSPF_OK;
 }
 }  // namespace

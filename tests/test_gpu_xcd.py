@@ -93,23 +93,21 @@ def test_patches_between_runs(xcd_ctx):
     G.free()
 
 
-def test_the_product_context_tries_both_and_keeps_the_faster():
+def test_the_product_context_chooses_by_the_shape_of_the_run_alone():
+    """Round 6: no per-graph history — one to eight roots on a graph of at most 20 000 vertices take
+    k_xcd, run after run; the reference's own case (a lean 500-router area, one root) stays on the one-workgroup kernel; more
+    than eight roots take the batched sweeps."""
     ctx = E.SpfContext(0)
-    g = synth.ospf_10k()
-    G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
-    roots = np.asarray([0], np.uint32)
-    ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 1, go.MAP, mask_words_=1)
-    paths, ms = [], {1: [], 2: []}
-    for it in range(12):
-        res = ctx.run(G, roots, 1)
-        assert _same(res, ref), (it, res.stats)
-        kind = 2 if res.stats["single_wg"] == 2 else 1
-        paths.append(kind); ms[kind].append(res.stats["ms_total"])
-    assert paths[:5] == [2, 2, 1, 1, 1], paths                            # k_xcd twice, the sweep engine three times, then the choice
-    assert len(set(paths[5:])) == 1, (paths, ms)
-    if abs(ms[2][1] - ms[1][2]) > 0.002:                                  # (the library compares whole microseconds)
-        assert paths[5] == (2 if ms[2][1] < ms[1][2] else 1), (paths, ms)
-    G.free()
+    for g, roots, want in ((synth.ospf_10k(), [0], 2), (synth.ospf_10k(), [0, 5, 9000], 2), (synth.ospf_500(), [0], 1), (synth.ospf_500(), [0, 7], 2),
+                           (synth.ospf_10k(), list(range(9)), 0)):
+        G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+        roots = np.asarray(roots, np.uint32)
+        ref = go.run(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric, roots, 1, go.MAP, mask_words_=1)
+        for it in range(4):
+            res = ctx.run(G, roots, 1)
+            assert _same(res, ref), (it, res.stats)
+            assert res.stats["single_wg"] == want, (g.name, len(roots), it, res.stats)
+        G.free()
     ctx.close()
 
 

@@ -12,7 +12,7 @@ d = torch.empty((R, n), dtype=torch.int32, device=dev); h = torch.empty((R, n), 
 f = torch.empty((R, n), dtype=torch.int16, device=dev); m = torch.empty((R, n, 1), dtype=torch.int64, device=dev)
 settings = [{}] + [{"HSPF_DENSE_PCT": v} for v in (5, 15, 50)] + [{"HSPF_LEAN_HEAD": v} for v in (1, 2, 8)] + \
            [{"HSPF_DENSE_PASSES": v} for v in (4, 8, 32)] + [{"HSPF_DENSE_MIN_WGS": v} for v in (512, 2048, 100000)] + \
-           [{"HSPF_DENSE_STAY_PCT": v} for v in (2, 25)] + [{"HSPF_VARIANT": 1 << 24}, {"HSPF_VARIANT": 1 << 19}]
+           [{"HSPF_DENSE_STAY_PCT": v} for v in (2, 25)] + [{"HSPF_VARIANT": 1 << 19}]
 for env in settings:
     env = {k: str(v) for k, v in env.items()}
     old = {k: os.environ.get(k) for k in env}
