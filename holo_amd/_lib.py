@@ -59,6 +59,11 @@ class HspfRows(ctypes.Structure):
                 ("metric", u32p), ("vflags", u8p)]
 
 
+class HspfKeyedLsdb(ctypes.Structure):
+    _fields_ = [("n_vertices", ctypes.c_uint32), ("n_links", ctypes.c_uint32), ("vertex_key", u64p), ("row_ptr", u32p),
+                ("target_key", u64p), ("metric", u32p), ("vflags", u8p), ("max_path_metric", ctypes.c_uint32)]
+
+
 class HspfRoutes(ctypes.Structure):
     _fields_ = [("best_metric", ctypes.c_void_p), ("best_entry", ctypes.c_void_p), ("nexthop_mask", ctypes.c_void_p)]
 
@@ -90,6 +95,7 @@ SYMBOLS = [
     ("hspf_set_stream", ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     ("hspf_get_stream", ctypes.c_void_p, [ctypes.c_void_p]),
     ("hspf_graph_upload", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(HspfCsr), ctypes.POINTER(ctypes.c_void_p)]),
+    ("hspf_graph_upload_keyed", ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(HspfKeyedLsdb), ctypes.POINTER(ctypes.c_void_p), u32p]),
     ("hspf_graph_free", None, [ctypes.c_void_p, ctypes.c_void_p]),
     ("hspf_graph_n_vertices", ctypes.c_uint32, [ctypes.c_void_p]),
     ("hspf_graph_n_edges", ctypes.c_uint32, [ctypes.c_void_p]),

@@ -596,6 +596,58 @@ kb_leaf_links(uint32_t e, const BuildInfo *__restrict__ info, uint32_t *__restri
   if (leaf[s & SRC_MASK]) in_src[i] = s | SRC_LEAF;
 }
 
+// ---- hspf_graph_upload_keyed: LSDB records -> CSR on the device ---------------------------------------------
+// The caller hands over what sits in its LSDB: per vertex a 64-bit KEY (ascending key order = the reference's VertexId order)
+// and its links as (target key, cost) in LSA / LSP link order — vertices in ANY order, targets unresolved.  What the host twins
+// did per link on one core (a binary search among 100 000 vertex ids, a million times: 148 ms) happens here: the keys are
+// ranked by a stable radix sort (hub_sort.h), every link's target is looked up in the sorted keys, links to vertices that are
+// not in the LSDB are dropped (vertex_lsa_links / vertex_edges do not yield them), rows are laid out in rank order.
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_kx_iota(uint32_t n, uint32_t *__restrict__ v) {
+  const uint32_t i = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_kx_rank(uint32_t n, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ skey, const uint8_t *__restrict__ vfl_in,
+           uint32_t *__restrict__ rank, uint8_t *__restrict__ vflags, uint32_t *__restrict__ err) {
+  const uint32_t r = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  const uint32_t i = perm[r];
+  rank[i] = r;
+  vflags[r] = vfl_in[i];
+  if (r && skey[r] == skey[r - 1]) atomicOr(err, 1u);               // the same vertex twice
+}
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_kx_resolve(uint32_t m, const uint64_t *__restrict__ tkey, const uint64_t *__restrict__ skey, uint32_t n, uint32_t *__restrict__ keep,
+              uint32_t *__restrict__ tidx) {
+  const uint32_t j = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (j >= m) return;
+  const uint64_t k = tkey[j];
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (skey[mid] < k) lo = mid + 1; else hi = mid; }
+  const bool found = lo < n && skey[lo] == k;
+  keep[j] = found ? 1u : 0u;
+  tidx[j] = lo;
+}
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_kx_deg(uint32_t n, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ vrow, const uint32_t *__restrict__ kpre, uint32_t *__restrict__ deg) {
+  const uint32_t r = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (r >= n) return;
+  const uint32_t i = perm[r];
+  deg[r] = kpre[vrow[i + 1]] - kpre[vrow[i]];
+}
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_kx_scatter(uint32_t n, const uint32_t *__restrict__ rank, const uint32_t *__restrict__ vrow, const uint32_t *__restrict__ keep,
+              const uint32_t *__restrict__ kpre, const uint32_t *__restrict__ tidx, const uint32_t *__restrict__ tmet,
+              const uint32_t *__restrict__ row_ptr, uint32_t *__restrict__ col, uint32_t *__restrict__ metric) {
+  // 16 lanes per input vertex: its links in their order, the kept ones at row_ptr[rank] + (kept links before them in the row)
+  const uint32_t t = blockIdx.x * GB_BLOCK + threadIdx.x, i = t >> 4, sub = t & 15u;
+  if (i >= n) return;
+  const uint32_t a = vrow[i], b = vrow[i + 1], base = row_ptr[rank[i]], k0 = kpre[a];
+  for (uint32_t j = a + sub; j < b; j += 16u)
+    if (keep[j]) { const uint32_t d = base + (kpre[j] - k0); col[d] = tidx[j]; metric[d] = tmet[j]; }
+}
+
 // GraphDev::zcyc — which vertices may lie on a CYCLE of zero-cost kept links.  Trimming: a vertex stays alive while it has a
 // zero-cost in-link from an alive vertex AND a zero-cost out-link to an alive vertex; vertices on a cycle never die, whatever
 // survives GB_ZC_ROUNDS rounds is a superset of them (long zero-cost chains end up in it too: conservative).  Used by the sweep

@@ -168,6 +168,7 @@ struct hspf_ctx {
   const void *pf_res_ptr = nullptr, *pf_res_vtx = nullptr, *pf_res_met = nullptr;
   DevBuf pack;                                      // record stream of hspf_routes_pack
   uint32_t last_diff_count = 0;                     // changed pairs of the last hspf_routes_diff_device (hspf_routes_diff_count)
+  DevBuf gb_kx;                                                 // hspf_graph_upload_keyed: keys, ranks, resolved targets
   DevBuf gb, gb_delta, gb_hub, giant_part;                      // graph build scratch, patch delta, hub-mode sort buffers
   DevBuf leaf_jobs;                                             // run_classes: the rows derived for leaf roots (LeafRootJob)
   uint32_t hub_deg = HUB_DEG;                       // HSPF_HUB_DEG env: rows with more links than this -> graph build from sorted keys
@@ -736,7 +737,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->rp_rank, &ctx->dyn_part, &ctx->rp_z, &ctx->rp_ord, &ctx->rp_work, &ctx->rp_status, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag, &ctx->xcd_ctl})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->rp_rank, &ctx->dyn_part, &ctx->rp_z, &ctx->rp_ord, &ctx->rp_work, &ctx->rp_status, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb_kx, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag, &ctx->xcd_ctl})
     release(*b);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (auto &e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
@@ -819,6 +820,83 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
   if (rc != HSPF_OK) return fail(rc);
   *out = g;
   return HSPF_OK;
+}
+
+// LSDB records -> CSR on the device -> the usual build (include/holo_spf_hip.h; kernels: graph_build.hip.h kb_kx_*).
+int hspf_graph_upload_keyed(hspf_ctx *ctx, const hspf_keyed_lsdb *k, hspf_graph **out, uint32_t *rank_out) {
+  if (!ctx || !k || !out) return HSPF_E_INVAL;
+  *out = nullptr;
+  const uint32_t n = k->n_vertices, m = k->n_links;
+  if (n == 0 || n > (1u << 24) || m > HSPF_MAX_LINKS || !k->vertex_key || !k->row_ptr || !k->vflags || (m && (!k->target_key || !k->metric))) {
+    ctx->last_error = "hspf_graph_upload_keyed: malformed hspf_keyed_lsdb";
+    return HSPF_E_INVAL;
+  }
+  if (k->row_ptr[0] != 0 || k->row_ptr[n] != m) { ctx->last_error = "row_ptr[0]!=0 or row_ptr[n]!=n_links"; return HSPF_E_INVAL; }
+  for (uint32_t u = 0; u < n; ++u)
+    if (k->row_ptr[u + 1] < k->row_ptr[u]) { ctx->last_error = "row_ptr not monotone"; return HSPF_E_INVAL; }
+  (void)hipSetDevice(ctx->device);
+  return guarded(ctx, [&]() -> int {
+    hspf_graph *g = new (std::nothrow) hspf_graph();
+    if (!g) return HSPF_E_NOMEM;
+    g->n = n; g->e = m; g->max_path_metric = k->max_path_metric;
+    int rc = alloc_arena(ctx, g, n, m + std::max(m / 8, 1024u));
+    if (rc != HSPF_OK) { delete g; return rc; }
+    auto fail = [&](int code) { hspf_graph_free(ctx, g); return code; };
+    hipStream_t s = ctx->stream;
+    // scratch: keys in / sorted, identity / permutation, rank, input rows, target keys, costs, flags, keep, prefix sums, targets,
+    // degrees, scan sums, the sort's temporary storage
+    size_t tsort = 0;
+    if (hub_sort_pairs(nullptr, &tsort, nullptr, nullptr, nullptr, nullptr, n, 64, s) != 0) { ctx->last_error = "hspf_graph_upload_keyed: sort size query"; return fail(HSPF_E_HIP); }
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_kin = carve((size_t)n * 8), o_ks = carve((size_t)n * 8), o_id = carve((size_t)n * 4), o_perm = carve((size_t)n * 4), o_rank = carve((size_t)n * 4),
+                 o_vrow = carve(((size_t)n + 1) * 4), o_tk = carve((size_t)m * 8 + 8), o_tm = carve((size_t)m * 4 + 4), o_vf = carve(n), o_keep = carve((size_t)m * 4 + 4),
+                 o_kpre = carve(((size_t)m + 2) * 4), o_tidx = carve((size_t)m * 4 + 4), o_deg = carve(((size_t)n + 1) * 4),
+                 o_sums = carve((((size_t)std::max(m, n) + 2) / GB_TILE + 4) * 4), o_err = carve(256), o_tmp = carve(tsort + 256);
+    if ((rc = ensure(ctx, ctx->gb_kx, off, false))) return fail(rc);
+    char *b = (char *)ctx->gb_kx.p;
+    uint64_t *kin = (uint64_t *)(b + o_kin), *ks = (uint64_t *)(b + o_ks), *tk = (uint64_t *)(b + o_tk);
+    uint32_t *idn = (uint32_t *)(b + o_id), *perm = (uint32_t *)(b + o_perm), *rank = (uint32_t *)(b + o_rank), *vrow = (uint32_t *)(b + o_vrow), *tm = (uint32_t *)(b + o_tm),
+             *keep = (uint32_t *)(b + o_keep), *kpre = (uint32_t *)(b + o_kpre), *tidx = (uint32_t *)(b + o_tidx), *deg = (uint32_t *)(b + o_deg), *sums = (uint32_t *)(b + o_sums),
+             *err = (uint32_t *)(b + o_err);
+    uint8_t *vf = (uint8_t *)(b + o_vf);
+    HIPCHK(ctx, hipMemcpyAsync(kin, k->vertex_key, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(vrow, k->row_ptr, ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(vf, k->vflags, n, hipMemcpyHostToDevice, s));
+    if (m) {
+      HIPCHK(ctx, hipMemcpyAsync(tk, k->target_key, (size_t)m * 8, hipMemcpyHostToDevice, s));
+      HIPCHK(ctx, hipMemcpyAsync(tm, k->metric, (size_t)m * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(ctx, hipMemsetAsync(err, 0, 4, s));
+    const dim3 gn((n + GB_BLOCK - 1) / GB_BLOCK), gm((std::max(m, 1u) + GB_BLOCK - 1) / GB_BLOCK);
+    hipLaunchKernelGGL(kb_kx_iota, gn, dim3(GB_BLOCK), 0, s, n, idn);
+    size_t tb = tsort;
+    HIPCHK(ctx, (hipError_t)hub_sort_pairs(b + o_tmp, &tb, kin, ks, idn, perm, n, 64, s));
+    hipLaunchKernelGGL(kb_kx_rank, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)perm, (const uint64_t *)ks, (const uint8_t *)vf, rank, g->d_vflags, err);
+    if (m) hipLaunchKernelGGL(kb_kx_resolve, gm, dim3(GB_BLOCK), 0, s, m, (const uint64_t *)tk, (const uint64_t *)ks, n, keep, tidx);
+    gb_scan<uint32_t>(s, keep, m, kpre, sums);
+    hipLaunchKernelGGL(kb_kx_deg, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)perm, (const uint32_t *)vrow, (const uint32_t *)kpre, deg);
+    gb_scan<uint32_t>(s, deg, n, g->d_row_ptr[0], sums);
+    hipLaunchKernelGGL(kb_kx_scatter, dim3((uint32_t)(((size_t)n * 16 + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)rank, (const uint32_t *)vrow,
+                       (const uint32_t *)keep, (const uint32_t *)kpre, (const uint32_t *)tidx, (const uint32_t *)tm, (const uint32_t *)g->d_row_ptr[0], g->d_col[0], g->d_metric[0]);
+    // the host mirrors (slot tables walk the root's neighbourhood on the host): row bounds, targets, flags come back
+    g->row_ptr.resize((size_t)n + 1); g->col.resize(m); g->vflags.resize(n);
+    uint32_t h_err = 0;
+    HIPCHK(ctx, hipMemcpyAsync(g->row_ptr.data(), g->d_row_ptr[0], ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, s));
+    if (m) HIPCHK(ctx, hipMemcpyAsync(g->col.data(), g->d_col[0], (size_t)m * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(g->vflags.data(), g->d_vflags, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));
+    if (rank_out) HIPCHK(ctx, hipMemcpyAsync(rank_out, rank, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+    if (h_err) { ctx->last_error = "hspf_graph_upload_keyed: a vertex key occurs twice"; return fail(HSPF_E_INVAL); }
+    g->e = g->row_ptr[n];
+    g->col.resize(g->e);
+    g->twoway.resize(g->e);
+    rc = build_on_device(ctx, g);
+    if (rc != HSPF_OK) return fail(rc);
+    *out = g;
+    return HSPF_OK;
+  });
 }
 
 static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows, bool &committed);

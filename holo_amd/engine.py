@@ -169,6 +169,29 @@ class SpfGraph:
             raise HspfError(rc, "hspf_graph_upload", ctx.last_error())
         self.handle = h
 
+    @classmethod
+    def from_keys(cls, ctx: "SpfContext", vertex_key, row_ptr, target_key, metric, vflags, max_path_metric: int):
+        """hspf_graph_upload_keyed(): vertices by 64-bit key in any order, links as (target key, cost), targets unresolved — the
+        device ranks the keys, resolves the targets, drops links to absent vertices and builds the graph.  Returns
+        (graph, rank): rank[i] = index of input vertex i.  The numpy mirrors are what the device built (read back)."""
+        vk = np.ascontiguousarray(vertex_key, dtype=np.uint64)
+        rp = np.ascontiguousarray(row_ptr, dtype=np.uint32)
+        tk = np.ascontiguousarray(target_key, dtype=np.uint64)
+        mt = np.ascontiguousarray(metric, dtype=np.uint32)
+        vf = np.ascontiguousarray(vflags, dtype=np.uint8)
+        rank = np.empty(len(vk), np.uint32)
+        k = L.HspfKeyedLsdb(len(vk), len(tk), vk.ctypes.data_as(L.u64p), _u32(rp), tk.ctypes.data_as(L.u64p), _u32(mt),
+                            vf.ctypes.data_as(L.u8p), ctypes.c_uint32(max_path_metric))
+        h = ctypes.c_void_p()
+        rc = ctx.lib.hspf_graph_upload_keyed(ctx.handle, ctypes.byref(k), ctypes.byref(h), _u32(rank))
+        if rc != 0:
+            raise HspfError(rc, "hspf_graph_upload_keyed", ctx.last_error())
+        self = cls.__new__(cls)
+        self.ctx, self.handle, self.n = ctx, h, len(vk)
+        self._pending, self._own_mirrors = [], True
+        self._rp, self._col, self._met, self._vf = (self.export(x) for x in ("row_ptr", "col", "metric", "vflags"))
+        return self, rank
+
     def _flush(self) -> None:
         for vs, cols, mets, nf in self._pending:
             lens = self._rp[vs.astype(np.int64) + 1] - self._rp[vs]

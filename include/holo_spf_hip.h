@@ -209,6 +209,24 @@ void       *hspf_get_stream(const hspf_ctx *ctx);
 
 /* ---- graph ------------------------------------------------------------------------------ */
 int      hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out);
+
+/* The same from LSDB records (ABI 8; SURVEY.md §8f-1: "LSDB -> CSR extraction"): vertices by 64-bit KEY in any order, links as
+ * (target key, cost) in LSA / LSP link order, targets unresolved.  Ascending key order must be the reference's VertexId order
+ * (IS-IS: !pseudonode << 56 | the 7 LAN-id bytes, big-endian — holo-isis/src/spf.rs:96-100; OSPFv2: router << 32 | id —
+ * holo-ospf/src/ospfv2/spf.rs:41-45).  The device ranks the keys, resolves every link's target, drops links whose target is
+ * not a vertex of the LSDB (vertex_lsa_links / vertex_edges do not yield them) and builds the graph; what it built can be
+ * read back with hspf_graph_export (ROW_PTR / COL / METRIC / VFLAGS: the caller's CSR as hspf_graph_upload would have got it).
+ * rank_out (may be NULL): [n_vertices] index of input vertex i in the graph.  Duplicate keys: HSPF_E_INVAL. */
+typedef struct {
+  uint32_t n_vertices, n_links;
+  const uint64_t *vertex_key;   /* [n_vertices]                                                   */
+  const uint32_t *row_ptr;      /* [n_vertices+1] rows of the vertices in the order of vertex_key  */
+  const uint64_t *target_key;   /* [n_links]                                                      */
+  const uint32_t *metric;       /* [n_links]                                                      */
+  const uint8_t  *vflags;       /* [n_vertices] HSPF_VF_*                                         */
+  uint32_t max_path_metric;
+} hspf_keyed_lsdb;
+int      hspf_graph_upload_keyed(hspf_ctx *ctx, const hspf_keyed_lsdb *lsdb, hspf_graph **out, uint32_t *rank_out);
 void     hspf_graph_free(hspf_ctx *ctx, hspf_graph *g);
 uint32_t hspf_graph_n_vertices(const hspf_graph *g);
 uint32_t hspf_graph_n_edges(const hspf_graph *g);          /* links of the caller's CSR (after patches) */

@@ -10,6 +10,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    # A test that asks for an absurd amount of host memory must fail with MemoryError, not take the machine down with it
+    # (round 6: an `np.arange(1 << 40)` in a test helper cost two GPU boxes).  Private writable memory of the test process
+    # is capped at 48 GiB (HIP's address-space reservations are not counted: they are not writable private mappings).
+    try:
+        import resource
+        soft, hard = resource.getrlimit(resource.RLIMIT_DATA)
+        cap = 48 << 30
+        if soft == resource.RLIM_INFINITY or soft > cap:
+            resource.setrlimit(resource.RLIMIT_DATA, (cap, hard))
+    except Exception:      # noqa: BLE001  (platforms without the limit)
+        pass
 
 
 @pytest.fixture(scope="session")
