@@ -80,6 +80,13 @@ class Engine {
   virtual std::unique_ptr<Graph> upload(const std::vector<uint32_t> &row_ptr, const std::vector<uint32_t> &col,
                                         const std::vector<uint32_t> &metric, const std::vector<uint8_t> &vflags,
                                         uint32_t max_path_metric) = 0;
+  // LSDB records -> CSR on the engine (hspf_graph_upload_keyed): vertices by 64-bit key in any order, links as
+  // (target key, cost), targets unresolved.  nullptr: the engine has no such path (the caller derives the CSR itself and calls
+  // upload).  On success csr_* hold the CSR the engine built (vertex index = rank of the key; links to absent keys dropped) and
+  // rank[i] the index of input vertex i.
+  virtual std::unique_ptr<Graph> upload_keyed(const std::vector<uint64_t> &, const std::vector<uint32_t> &, const std::vector<uint64_t> &,
+                                              const std::vector<uint32_t> &, const std::vector<uint8_t> &, uint32_t, std::vector<uint32_t> &,
+                                              std::vector<uint32_t> &, std::vector<uint32_t> &, std::vector<uint32_t> &, std::vector<uint8_t> &) { return nullptr; }
   virtual Tables run(Graph &g, const std::vector<uint32_t> &roots, uint32_t run_flags) = 0;
   virtual SlotTable slot_table(Graph &g, uint32_t root) = 0;
   // whole rows replaced (hspf_graph_patch): vertices strictly ascending, rows[i] = (col, metric) of vertices[i]
@@ -319,6 +326,28 @@ class HipEngine : public Engine {
     const int rc = hspf_graph_upload(ctx_, &csr, &g);
     if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_graph_upload: ") + hspf_last_error(ctx_));
     return std::make_unique<HipGraph>(ctx_, g);
+  }
+  std::unique_ptr<Graph> upload_keyed(const std::vector<uint64_t> &vkey, const std::vector<uint32_t> &vrow, const std::vector<uint64_t> &tkey,
+                                      const std::vector<uint32_t> &tmet, const std::vector<uint8_t> &vfl, uint32_t max_path_metric, std::vector<uint32_t> &rank,
+                                      std::vector<uint32_t> &row_ptr, std::vector<uint32_t> &col, std::vector<uint32_t> &metric, std::vector<uint8_t> &vflags) override {
+    const uint32_t n = (uint32_t)vkey.size();
+    hspf_keyed_lsdb k{n, (uint32_t)tkey.size(), vkey.data(), vrow.data(), tkey.data(), tmet.data(), vfl.data(), max_path_metric};
+    hspf_graph *g = nullptr;
+    rank.resize(n);
+    const int rc = hspf_graph_upload_keyed(ctx_, &k, &g, rank.data());
+    if (rc != HSPF_OK) throw std::runtime_error(std::string("hspf_graph_upload_keyed: ") + hspf_last_error(ctx_));
+    auto out = std::make_unique<HipGraph>(ctx_, g);
+    // the CSR as the engine built it: the twins' slot replay, refresh and Spt queries walk it on the host
+    auto fetch = [&](uint32_t which, void *dst, size_t bytes) {
+      size_t got = 0;
+      if (hspf_graph_export(ctx_, g, which, dst, bytes, &got) != HSPF_OK || got != bytes) throw std::runtime_error(std::string("hspf_graph_export: ") + hspf_last_error(ctx_));
+    };
+    const uint32_t e = hspf_graph_n_edges(g);
+    row_ptr.resize((size_t)n + 1); col.resize(e); metric.resize(e); vflags.resize(n);
+    fetch(HSPF_GX_ROW_PTR, row_ptr.data(), ((size_t)n + 1) * 4);
+    if (e) { fetch(HSPF_GX_COL, col.data(), (size_t)e * 4); fetch(HSPF_GX_METRIC, metric.data(), (size_t)e * 4); }
+    fetch(HSPF_GX_VFLAGS, vflags.data(), n);
+    return out;
   }
   // One run, tables on the host.  Since ABI 7 through the PACKED hand-off (hspf_run_packed: one word per (root, vertex) into a
   // page-locked buffer the engine keeps, a quarter of hspf_run's bytes over the bus) and decoded into the twins' tables

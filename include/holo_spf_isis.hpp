@@ -190,52 +190,84 @@ struct Instance {                      // the slice of InstanceUpView the path r
 // ---- LSDB -> CSR -------------------------------------------------------------------------------------------------
 // Edges one live fragment contributes, in the reference's order (spf.rs:1026-1127); HopCount mode: cost 0 to a
 // pseudonode, 1 to a router (:1131-1146).
-inline std::vector<std::pair<LanId, uint32_t>> vertex_edges(const Lsp &lsp, std::optional<int> mt_id, bool hopcount,
-                                                            const std::string &metric_type) {
-  const bool std_on = metric_type == "standard" || metric_type == "both";
-  const bool wide_on = metric_type == "wide" || metric_type == "both";
-  std::vector<std::pair<LanId, uint32_t>> out;
+template <class F>
+inline void for_each_vertex_edge(const Lsp &lsp, std::optional<int> mt_id, bool hopcount, bool std_on, bool wide_on, F &&emit) {
   auto cost = [&](const LanId &nbr, uint32_t m) { return !hopcount ? m : (nbr.pseudonode != 0 ? 0u : 1u); };
   const bool none_or_std = !mt_id || *mt_id == MT_STANDARD;
   if (none_or_std && std_on)
-    for (auto &e : lsp.is_reach) out.push_back({e.first, cost(e.first, e.second)});
+    for (auto &e : lsp.is_reach) emit(e.first, cost(e.first, e.second));
   if ((none_or_std || lsp.pseudonode != 0) && wide_on)
     for (auto &e : lsp.ext_is_reach)
-      if (e.second < MAX_LINK_METRIC_WIDE) out.push_back({e.first, cost(e.first, e.second)});
+      if (e.second < MAX_LINK_METRIC_WIDE) emit(e.first, cost(e.first, e.second));
   if (mt_id && *mt_id != MT_STANDARD)
     for (auto &e : lsp.mt_is_reach)
-      if (std::get<0>(e) == *mt_id && std::get<2>(e) < MAX_LINK_METRIC_WIDE) out.push_back({std::get<1>(e), cost(std::get<1>(e), std::get<2>(e))});
+      if (std::get<0>(e) == *mt_id && std::get<2>(e) < MAX_LINK_METRIC_WIDE) emit(std::get<1>(e), cost(std::get<1>(e), std::get<2>(e)));
   if (!mt_id)
     for (auto &e : lsp.mt_is_reach)
-      if (std::get<2>(e) < MAX_LINK_METRIC_WIDE) out.push_back({std::get<1>(e), cost(std::get<1>(e), std::get<2>(e))});
+      if (std::get<2>(e) < MAX_LINK_METRIC_WIDE) emit(std::get<1>(e), cost(std::get<1>(e), std::get<2>(e)));
+}
+inline std::vector<std::pair<LanId, uint32_t>> vertex_edges(const Lsp &lsp, std::optional<int> mt_id, bool hopcount,
+                                                            const std::string &metric_type) {
+  std::vector<std::pair<LanId, uint32_t>> out;
+  for_each_vertex_edge(lsp, mt_id, hopcount, metric_type == "standard" || metric_type == "both", metric_type == "wide" || metric_type == "both",
+                       [&](const LanId &nbr, uint32_t c) { out.push_back({nbr, c}); });
   return out;
 }
 
 // CSR form (include/holo_spf_hip.h) of one level's LSDB for one (mt_id, metric mode).  Vertex index = rank in VertexId
 // order over the LAN ids that own at least one live fragment; links to LAN ids without any LSP are not listed (they
 // can never pass the two-way check).
+// VertexId -> vertex index: a binary search in the graph's sorted vertex list with the slice of std::map's interface the callers
+// use (find / end / ->second).  (Round 6: the std::map it replaces cost 100 000 node allocations per first extraction.)
+class VidIndex {
+ public:
+  struct It {
+    uint32_t second = 0; bool ok = false;
+    const It *operator->() const { return this; }
+    bool operator==(const It &o) const { return ok == o.ok && (!ok || second == o.second); }
+    bool operator!=(const It &o) const { return !(*this == o); }
+  };
+  explicit VidIndex(const std::vector<VertexId> &v) : v_(&v) {}
+  It find(const VertexId &x) const {
+    auto it = std::lower_bound(v_->begin(), v_->end(), x);
+    return (it != v_->end() && *it == x) ? It{(uint32_t)(it - v_->begin()), true} : It{};
+  }
+  It end() const { return It{}; }
+  size_t count(const VertexId &x) const { return find(x).ok ? 1 : 0; }
+ private:
+  const std::vector<VertexId> *v_;
+};
+
 class LevelGraph {
  public:
+  LevelGraph(const LevelGraph &) = delete;
+  LevelGraph &operator=(const LevelGraph &) = delete;
   int level;
   std::optional<int> mt_id;
   bool hopcount;
   std::string metric_type;
   std::vector<VertexId> vids;
-  std::map<VertexId, uint32_t> index;
+  VidIndex index{vids};
   std::vector<uint32_t> row_ptr, col, metric;
   std::vector<uint8_t> vflags;
   uint32_t max_path_metric, run_flags;
 
-  LevelGraph(const Instance &inst, int level_, std::optional<int> mt, bool hop = false)
+  // `keyed`: an engine that turns LSDB records into the CSR itself (Engine::upload_keyed = hspf_graph_upload_keyed).  The walk
+  // below then only STREAMS the records — per vertex its key (!pseudonode << 56 | LAN id: ascending = VertexId order,
+  // holo-isis/src/spf.rs:96-100) and its links as (target key, cost) — and the million target look-ups, the ranking of the
+  // vertices and the dropping of links to absent LSPs happen on the device (round 6; 148 ms -> see profiles/r06_notes.md).
+  LevelGraph(const Instance &inst, int level_, std::optional<int> mt, bool hop = false, Engine *keyed = nullptr)
       : level(level_), mt_id(mt), hopcount(hop) {
     const InstanceCfg &cfg = inst.config;
     const Lsdb &lsdb = lsdb_of(inst);
     metric_type = cfg.metric_type.at(level);
     cfg_key_ = cfg_key(cfg);
+    max_path_metric = metric_type == "standard" ? MAX_PATH_METRIC_STANDARD : MAX_PATH_METRIC_WIDE;   // spf.rs:637-641
+    run_flags = mt_id ? 0u : (uint32_t)HSPF_RUN_IGNORE_OVERLOAD;                                     // spf.rs:566-574
+    if (keyed && build_keyed(lsdb, cfg, *keyed)) return;
     auto frags = live_fragments(lsdb);
     for (auto &kv : frags) vids.push_back(vertex_id(kv.first));
     std::sort(vids.begin(), vids.end());
-    for (uint32_t i = 0; i < vids.size(); ++i) index[vids[i]] = i;
     row_ptr.assign(vids.size() + 1, 0);
     vflags.assign(vids.size(), 0);
     for (uint32_t i = 0; i < vids.size(); ++i) {
@@ -245,8 +277,6 @@ class LevelGraph {
       vflags[i] = r.flags;
       row_ptr[i + 1] = (uint32_t)col.size();
     }
-    max_path_metric = metric_type == "standard" ? MAX_PATH_METRIC_STANDARD : MAX_PATH_METRIC_WIDE;   // spf.rs:637-641
-    run_flags = mt_id ? 0u : (uint32_t)HSPF_RUN_IGNORE_OVERLOAD;                                     // spf.rs:566-574
   }
   // Incremental re-derivation after the LSPs of `changed` LAN ids were re-originated, purged or aged out (the reference's
   // `trigger_lsps`, holo-isis/src/spf.rs:144,735): only their rows are rebuilt and — when the graph is on the device —
@@ -301,6 +331,66 @@ class LevelGraph {
     return false;
   }
  private:
+  static uint64_t key_of(const LanId &lan) {
+    uint64_t k = lan.pseudonode == 0 ? 1ull << 56 : 0ull;
+    for (int i = 0; i < 6; ++i) k |= (uint64_t)lan.system_id[i] << (48 - 8 * i);
+    return k | lan.pseudonode;
+  }
+  // One pass over the LSDB in ITS order (LspId: fragments of a LAN id are adjacent): records out, CSR back.
+  bool build_keyed(const Lsdb &lsdb, const InstanceCfg &cfg, Engine &engine) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<uint64_t> vkey, tkey;
+    std::vector<uint32_t> vrow{0}, tmet;
+    std::vector<uint8_t> vfl;
+    std::vector<LanId> lans;
+    const Lsp *zeroth = nullptr;
+    const bool std_on = metric_type == "standard" || metric_type == "both", wide_on = metric_type == "wide" || metric_type == "both";
+    { size_t links = 0; for (auto &kv : lsdb.all()) links += kv.second.is_reach.size() + kv.second.ext_is_reach.size() + kv.second.mt_is_reach.size();
+      tkey.reserve(links); tmet.reserve(links); const size_t nl = lsdb.all().size(); vkey.reserve(nl); vrow.reserve(nl + 1); vfl.reserve(nl); lans.reserve(nl); }
+    auto close = [&]() {                                       // flags of the vertex whose fragments just ended (spf.rs:557-604)
+      if (lans.empty() || vfl.size() == lans.size()) return;
+      const LanId &lan = lans.back();
+      const bool is_pn = lan.pseudonode != 0;
+      uint8_t f = is_pn ? HSPF_VF_NETWORK : 0;
+      const Lsp *z = zeroth;
+      if (!z) f |= HSPF_VF_NO_EXPAND;
+      else {
+        if (!is_pn && mt_id && z->overload_bit(*mt_id)) f |= HSPF_VF_NO_TRANSIT;
+        if (mt_id && *mt_id == MT_STANDARD && !is_pn) {
+          auto has = [&](int p) { return z->protocols_supported && std::find(z->protocols_supported->begin(), z->protocols_supported->end(), p) != z->protocols_supported->end(); };
+          if (!z->protocols_supported || (cfg.ipv4_enabled && !has(NLPID_IPV4)) || (cfg.ipv6_enabled && !has(NLPID_IPV6))) f |= HSPF_VF_NO_EXPAND;
+        }
+      }
+      vfl.push_back(f);
+      vrow.push_back((uint32_t)tkey.size());
+    };
+    // fragments of a LAN id are adjacent, fragment 0 — the zeroth LSP of spf.rs:1299-1309 when it is live — first
+    bool have_lan = false, started = false;
+    LanId cur{};
+    for (auto &kv : lsdb.all()) {
+      const Lsp &l = kv.second;
+      const LanId lan = l.lan_id();
+      if (!have_lan || !(cur == lan)) { if (started) close(); have_lan = true; cur = lan; started = false; zeroth = nullptr; }
+      if (!l.live()) continue;
+      if (l.fragment == 0) zeroth = &l;
+      if (!started) { started = true; lans.push_back(lan); vkey.push_back(key_of(lan)); }
+      for_each_vertex_edge(l, mt_id, hopcount, std_on, wide_on, [&](const LanId &nbr, uint32_t c) { tkey.push_back(key_of(nbr)); tmet.push_back(c); });
+    }
+    if (started) close();
+    if (lans.empty()) return false;
+    const auto t_stream = std::chrono::steady_clock::now();
+    std::vector<uint32_t> rank;
+    dev_ = engine.upload_keyed(vkey, vrow, tkey, tmet, vfl, max_path_metric, rank, row_ptr, col, metric, vflags);
+    if (!dev_) return false;
+    const auto t_engine = std::chrono::steady_clock::now();
+    dev_engine_ = &engine;
+    vids.resize(lans.size());
+    for (size_t i = 0; i < lans.size(); ++i) vids[rank[i]] = vertex_id(lans[i]);
+    if (getenv("HSPF_KEYED_TIMING"))
+      fprintf(stderr, "[LevelGraph keyed] stream %.2f ms, engine %.2f ms, vertex ids %.2f ms\n", std::chrono::duration<double, std::milli>(t_stream - t_begin).count(),
+              std::chrono::duration<double, std::milli>(t_engine - t_stream).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_engine).count());
+    return true;
+  }
   struct Row { std::vector<uint32_t> col, metric; uint8_t flags; };
   using CfgKey = std::tuple<std::string, bool, bool>;       // everything outside the LSDB a row depends on
   CfgKey cfg_key(const InstanceCfg &cfg) const { return {cfg.metric_type.at(level), cfg.ipv4_enabled, cfg.ipv6_enabled}; }
@@ -781,12 +871,13 @@ inline std::vector<LanId> changed_lan_ids(const Lsdb &old_db, const Lsdb &new_db
 class GraphCache {
  public:
   int rebuilt = 0, patched = 0;
+  Engine *keyed = nullptr;         // set: a (re)build streams the LSDB's records to this engine, which derives the CSR (LevelGraph)
   std::map<std::tuple<int, int, bool>, std::unique_ptr<LevelGraph>> graphs;       // (level, mt_id or -1, hop count)
   LevelGraph &get(const Instance &inst, int level, std::optional<int> mt_id, bool hopcount, const std::vector<LanId> *trigger_lsps) {
     auto key = std::make_tuple(level, mt_id ? *mt_id : -1, hopcount);
     auto it = graphs.find(key);
     if (it != graphs.end() && trigger_lsps && it->second->refresh(inst, *trigger_lsps)) { ++patched; return *it->second; }
-    graphs[key] = std::make_unique<LevelGraph>(inst, level, mt_id, hopcount);
+    graphs[key] = std::make_unique<LevelGraph>(inst, level, mt_id, hopcount, keyed);
     ++rebuilt;
     return *graphs[key];
   }

@@ -187,6 +187,11 @@ class TimedEngine : public Engine {
   std::unique_ptr<Graph> upload(const std::vector<uint32_t> &a, const std::vector<uint32_t> &b, const std::vector<uint32_t> &c, const std::vector<uint8_t> &d, uint32_t m) override {
     const auto t = Clock::now(); auto r = e_.upload(a, b, c, d, m); upload_ms += ms_since(t); return r;
   }
+  std::unique_ptr<Graph> upload_keyed(const std::vector<uint64_t> &vk, const std::vector<uint32_t> &vr, const std::vector<uint64_t> &tk, const std::vector<uint32_t> &tm,
+                                      const std::vector<uint8_t> &vf, uint32_t mp, std::vector<uint32_t> &rank, std::vector<uint32_t> &rp, std::vector<uint32_t> &col,
+                                      std::vector<uint32_t> &met, std::vector<uint8_t> &fl) override {
+    const auto t = Clock::now(); auto r = e_.upload_keyed(vk, vr, tk, tm, vf, mp, rank, rp, col, met, fl); upload_ms += ms_since(t); return r;
+  }
   Tables run(Graph &g, const std::vector<uint32_t> &roots, uint32_t fl) override { const auto t = Clock::now(); auto r = e_.run(g, roots, fl); run_ms += ms_since(t); return r; }
   SlotTable slot_table(Graph &g, uint32_t root) override { const auto t = Clock::now(); auto r = e_.slot_table(g, root); slot_ms += ms_since(t); return r; }
   void patch(Graph &g, const std::vector<uint32_t> &v, const std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> &rows, const std::vector<uint8_t> &f) override {
@@ -254,11 +259,29 @@ int main(int argc, char **argv) {
     if (!json_path.empty()) dump_json(S, json_path);
     const I::Instance &inst = S.inst;
 
-    // ---- stage 1: LSDB -> CSR (first time), upload
+    // ---- stage 1: LSDB -> CSR (first time), upload.  The host walk (every link's target looked up among the vertices on one
+    // core) for the record; then what the drop-in does since round 6: the LSDB's records streamed to the engine, which ranks
+    // the vertices, resolves the targets and builds the graph (Engine::upload_keyed = hspf_graph_upload_keyed) — the CSR it
+    // built must be the host walk's, array by array.
+    t0 = Clock::now();
+    double csr_host_ms = 0, csr_keyed_engine_ms = 0;
+    bool keyed_same = true;
+    {
+      I::LevelGraph H(inst, 2, I::MT_STANDARD, false);
+      csr_host_ms = ms_since(t0);
+      if (hip) {
+        te.reset();
+        I::LevelGraph K(inst, 2, I::MT_STANDARD, false, &te);
+        keyed_same = K.vids == H.vids && K.row_ptr == H.row_ptr && K.col == H.col && K.metric == H.metric && K.vflags == H.vflags;
+      }
+    }
+    te.reset();
     t0 = Clock::now();
     I::GraphCache cache;
+    if (hip) cache.keyed = &te;
     I::LevelGraph &G = cache.get(inst, 2, I::MT_STANDARD, false, nullptr);
     const double csr_first_ms = ms_since(t0);
+    csr_keyed_engine_ms = te.upload_ms;
     t0 = Clock::now();
     G.device(te);
     const double upload_ms = ms_since(t0);
@@ -415,7 +438,8 @@ int main(int argc, char **argv) {
     const St *slow = &stages[0];
     for (auto &s : stages) if (s.ms > slow->ms) slow = &s;
     printf("{\"engine\": \"%s\", \"packed_handoff\": %s, \"n_routers\": %u, \"adjacency_entries\": %zu, \"prefix_entries\": %zu, \"root_neighbours\": %zu, "
-           "\"generate_ms\": %.2f, \"lsdb_to_csr_first_ms\": %.2f, \"graph_upload_ms\": %.3f, "
+           "\"generate_ms\": %.2f, \"lsdb_to_csr_first_ms\": %.2f, \"lsdb_to_csr_first_is\": \"%s\", \"lsdb_to_csr_engine_part_ms\": %.2f, \"lsdb_to_csr_host_walk_ms\": %.2f, "
+           "\"keyed_csr_identical_to_host_walk\": %s, \"graph_upload_ms\": %.3f, "
            "\"lsdb_to_csr_incremental\": {\"cost_only_ms\": %.3f, \"cost_only_engine_patch_ms\": %.3f, \"structural_ms\": %.3f, \"structural_engine_patch_ms\": %.3f, \"patched_graph_identical\": %s}, "
            "\"one_root\": {\"run_and_handoff_ms\": %.3f, \"engine_call_ms\": %.3f, \"table_alloc_ms\": %.3f, \"handoff_decode_ms\": %.3f, \"spt_rebuild_ms\": %.2f, \"compute_routes_ms\": %.2f, \"spt_plus_routes_ms\": %.2f, "
            "\"compute_spf_call_ms\": %.2f, \"spt_vertices\": %zu, \"rib_routes\": %zu, \"slowest_stage\": \"%s\"}, "
@@ -423,13 +447,14 @@ int main(int argc, char **argv) {
            "\"running_instance_pipeline\": {\"first_step_ms\": %.2f, \"first_step_messages\": %zu, \"lsp_change_step_ms\": %.3f, \"stages_ms\": {\"refresh_patch\": %.3f, \"run_device\": %.3f, "
            "\"routes_device\": %.3f, \"slot_nexthops\": %.3f, \"diff_pack\": %.3f, \"expand\": %.3f}, \"records_to_host\": %zu, \"messages\": %zu, \"identical_to_host_rule\": %s}",
            engine.c_str(), (hip && packed) ? "true" : "false", n, S.entries, S.prefixes + (n + 4) / 5, inst.interfaces.size(),
-           gen_ms, csr_first_ms, upload_ms, inc_cost_ms, inc_cost_patch_ms, inc_struct_ms, inc_struct_patch_ms, patched_ok ? "true" : "false",
+           gen_ms, csr_first_ms, hip ? "records streamed to the engine (hspf_graph_upload_keyed): graph resident when it returns" : "host walk", csr_keyed_engine_ms, csr_host_ms,
+           keyed_same ? "true" : "false", upload_ms, inc_cost_ms, inc_cost_patch_ms, inc_struct_ms, inc_struct_patch_ms, patched_ok ? "true" : "false",
            run, median(call_v), median(alloc_v), median(decode_v), rebuild, routes, total, compute_spf_ms, spt_size, rib_size, slow->name,
            dev_routes_ms, dev_routes_engine_ms, dev_routes_same ? "true" : "false",
            pipe_first_ms, pipe_first_msgs, pipe_step_ms, pt.refresh_ms, pt.run_ms, pt.routes_ms, pt.slots_ms, pt.diff_pack_ms, pt.expand_ms, pipe_records, pipe_msgs, pipe_ok ? "true" : "false");
     if (batch) printf(", \"batch\": {\"roots\": %u, \"run_and_handoff_ms\": %.3f, \"handoff_decode_ms\": %.3f, \"spt_rebuild_ms\": %.2f}", batch, batch_run_ms, batch_decode_ms, batch_rebuild_ms);
     printf("}\n");
-    return (patched_ok && dev_routes_same && pipe_ok) ? 0 : 1;
+    return (patched_ok && dev_routes_same && pipe_ok && keyed_same) ? 0 : 1;
   } catch (const std::exception &e) {
     fprintf(stderr, "dropin_e2e: %s\n", e.what());
     return 1;

@@ -226,8 +226,14 @@ def test_cpp_host_side_under_asan_ubsan():
             pytest.skip("libasan / libubsan not installed")
         assert r.returncode == 0, r.stderr[-2000:]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+
+    def _no_data_cap():                     # ASan reserves terabytes of shadow address space: the suite's memory cap (conftest.py) off
+        import resource
+        hard = resource.getrlimit(resource.RLIMIT_DATA)[1]
+        resource.setrlimit(resource.RLIMIT_DATA, (hard, hard))
     r = subprocess.run([exe, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so"),
-                        "--replay-steps", os.path.join(ROOT, "tests", "golden")] + VECTORS, capture_output=True, text=True, timeout=1200, env=env)
+                        "--replay-steps", os.path.join(ROOT, "tests", "golden")] + VECTORS, capture_output=True, text=True, timeout=1200, env=env,
+                       preexec_fn=_no_data_cap)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "163 vectors reproduce" in r.stdout and " 0 do not" in r.stdout and ", 0 differ" in r.stdout
     assert "132 recorded cold-start ibus states" in r.stdout and "(116 through the device comparison and packing" in r.stdout and "records), 0 differ" in r.stdout   # topology output/ibus.jsonl, OSPFv3 included
