@@ -345,8 +345,7 @@ class LevelGraph {
     std::vector<LanId> lans;
     const Lsp *zeroth = nullptr;
     const bool std_on = metric_type == "standard" || metric_type == "both", wide_on = metric_type == "wide" || metric_type == "both";
-    { size_t links = 0; for (auto &kv : lsdb.all()) links += kv.second.is_reach.size() + kv.second.ext_is_reach.size() + kv.second.mt_is_reach.size();
-      tkey.reserve(links); tmet.reserve(links); const size_t nl = lsdb.all().size(); vkey.reserve(nl); vrow.reserve(nl + 1); vfl.reserve(nl); lans.reserve(nl); }
+    { const size_t nl = lsdb.all().size(); vkey.reserve(nl); vrow.reserve(nl + 1); vfl.reserve(nl); lans.reserve(nl); tkey.reserve(nl * 8); tmet.reserve(nl * 8); }   // (ONE pass over the LSDB)
     auto close = [&]() {                                       // flags of the vertex whose fragments just ended (spf.rs:557-604)
       if (lans.empty() || vfl.size() == lans.size()) return;
       const LanId &lan = lans.back();
