@@ -2433,16 +2433,18 @@ int Run::repair_roots() {
     ctx->est_rp = std::min(used + 2u, 64u);
     { uint32_t need = 0; for (uint32_t j = 0; j < nd; ++j) if (hc.fail()[j] != 1u) need = std::max(need, hc.rlast()[j] + 2u);
       if (rounds <= 64u) ctx->est_rp_rounds = std::min(std::max(need, RP_RELAX), 64u); }       // rounds the next repair launches (the last one's + a spare)
+    uint32_t t_evals = 0, t_groups = 0, t_gmax = 0;
+    for (uint32_t j = 0; j < nd; ++j) { t_evals += hc.tot(j)[0]; t_groups += hc.tot(j)[1]; t_gmax = std::max(t_gmax, hc.tot(j)[2]); }
     if (getenv("HSPF_REPAIR_PROF"))
-      fprintf(stderr, "[hspf repair] %u roots, n %u, %u rounds: %u sweeps, %u evaluations, %u groups (largest %u); host %.1f us\n", nd, n, rounds, used, hc.tot()[0], hc.tot()[1],
-              hc.tot()[2], std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count());
+      fprintf(stderr, "[hspf repair] %u roots, n %u, %u rounds: %u sweeps, %u evaluations, %u groups (largest deep one %u); host %.1f us\n", nd, n, rounds, used, t_evals, t_groups,
+              t_gmax, std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count());
     std::vector<uint32_t> again;
     for (uint32_t j = 0; j < nd; ++j) {
       if (overrun || hc.fail()[j] >= 2u) ex.push_back(todo[j]);
       else if (hc.fail()[j] == 1u) again.push_back(todo[j]);           // R did not settle: more rounds
       else ok.push_back(todo[j]);
     }
-    st.repair_sweeps = std::max(st.repair_sweeps, used); st.repair_evals += hc.tot()[0]; st.repair_groups += hc.tot()[1];
+    st.repair_sweeps = std::max(st.repair_sweeps, used); st.repair_evals += t_evals; st.repair_groups += t_groups;
     todo.swap(again);
   }
   ex.insert(ex.end(), todo.begin(), todo.end());

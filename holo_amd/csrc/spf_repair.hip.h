@@ -99,7 +99,8 @@ constexpr uint32_t RP_GX = 64u;                  // blocks per root of a phase l
 // the other whoever issues them (64 roots' counters side by side made the first-worklist launch 1 ms: profiles/r06_notes.md).
 //   cnt[3][n_dyn] worklist lengths (sweep s reads s % 3, fills (s + 1) % 3, clears (s + 2) % 3) | nsc[n_dyn] vertices that wait for a
 //   release path | fail[n_dyn] (1: R did not settle in the rounds launched, 2: anything else) | rlast[n_dyn] last relaxation round that
-//   changed the root | pend[RP_MAX_SWEEPS + 2] "sweep s has work" | evals | groups | gmax
+//   changed the root | pend[RP_MAX_SWEEPS + 2] "sweep s has work" | per root, RP_PAD apart: evaluations, groups, largest deep group
+//   (one atomic per BLOCK on the root's own line: a per-thread atomic on one word made the first sweep 240 us instead of 80)
 constexpr uint32_t RP_PAD = 32u;
 struct RpCtl {
   uint32_t *base; uint32_t nd;
@@ -108,8 +109,8 @@ struct RpCtl {
   __device__ __host__ uint32_t *fail() const { return base + (size_t)4u * nd * RP_PAD; }
   __device__ __host__ uint32_t *rlast() const { return fail() + nd; }
   __device__ __host__ uint32_t *pend() const { return fail() + 2u * (size_t)nd; }
-  __device__ __host__ uint32_t *tot() const { return pend() + RP_MAX_SWEEPS + 2u; }
-  static size_t words(uint32_t nd) { return (size_t)4u * nd * RP_PAD + 2u * (size_t)nd + RP_MAX_SWEEPS + 2u + 4u; }
+  __device__ __host__ uint32_t *tot(uint32_t j) const { return pend() + RP_MAX_SWEEPS + 2u + (size_t)j * RP_PAD; }
+  static size_t words(uint32_t nd) { return (size_t)5u * nd * RP_PAD + 2u * (size_t)nd + RP_MAX_SWEEPS + 2u + 4u; }
 };
 
 struct RepairArgs {
@@ -170,6 +171,23 @@ struct RpRoot {
   __device__ __forceinline__ RpCtx ctx(const RepairArgs &a) const { return RpCtx{a.g, D, H, M, a.zflag, R, P, root, a.ignore_ovl}; }
 };
 
+// "This root has failed" read ONCE per block: other blocks of the root may raise the flag while this kernel runs, and the blocks
+// end on block-wide barriers (rp_stat, __syncthreads_or) — a block whose threads disagreed on the early return would hang there.
+__device__ __forceinline__ bool rp_failed(const RepairArgs &a, uint32_t j) {
+  __shared__ uint32_t s_failed;
+  if (threadIdx.x == 0) s_failed = a.ctl.fail()[j];
+  __syncthreads();
+  return s_failed != 0u;
+}
+// One statistics counter of the block's root: the threads' values summed (or maxed) in LDS, ONE global atomic per block.
+__device__ __forceinline__ void rp_stat(uint32_t *word, uint32_t mine, bool is_max) {
+  __shared__ uint32_t s_acc;
+  if (threadIdx.x == 0) s_acc = 0u;
+  __syncthreads();
+  if (mine) { if (is_max) atomicMax(&s_acc, mine); else atomicAdd(&s_acc, mine); }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_acc) { if (is_max) atomicMax(word, s_acc); else atomicAdd(word, s_acc); }
+}
 // Append x to a list of the block's root — every lane of the wave calls it (want = false: nothing to append): ONE atomic per wave.
 __device__ __forceinline__ void rp_append(uint32_t *cnt, uint32_t *list, uint32_t x, bool want) {
   const uint64_t b = __ballot(want);
@@ -238,7 +256,7 @@ __global__ __launch_bounds__(256) void kr_relax(RepairArgs a, uint32_t round) {
     for (int off = 8; off >= 1; off >>= 1) cand = min(cand, (uint32_t)__shfl_xor((int)cand, off, 16));
     if (cand < rv) { if (r.sub == 0u) r.R[v] = cand; ch = true; }
   }
-  if (ch) rlast[r.j] = round;                                         // (benign race: everybody writes the same value)
+  if (__syncthreads_or(ch ? 1 : 0) && threadIdx.x == 0) rlast[r.j] = round;     // (one store per block)
 }
 
 // ---- 3. the groups: members of group y (R == y, other than y) in the order of a lowest-index-first walk from y.
@@ -276,13 +294,13 @@ __global__ __launch_bounds__(256) void kr_walks(RepairArgs a, uint32_t rounds) {
     if (direct) { r.P[v] = below + 1u; if (below == 0u) ++groups; }
     else r.ST[y] = RP_DEEP;                                           // released by another member: the group needs the real walk
   }
-  if (groups) atomicAdd(a.ctl.tot() + 1, groups);
+  rp_stat(a.ctl.tot(r.j) + 1, groups, false);
 }
 __global__ __launch_bounds__(256) void kr_walks_deep(RepairArgs a) {
   const RpRoot r(a);
   const GraphDev &g = a.g;
   const RpCtx c = r.ctx(a);
-  if (a.ctl.fail()[r.j]) return;
+  if (rp_failed(a, r.j)) return;
   const uint32_t ns = *a.ctl.nsc(r.j);
   uint32_t gmax = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
@@ -318,7 +336,7 @@ __global__ __launch_bounds__(256) void kr_walks_deep(RepairArgs a) {
     if (fail) a.ctl.fail()[r.j] = 2u;
     gmax = max(gmax, p);
   }
-  if (gmax) atomicMax(a.ctl.tot() + 2, gmax);
+  rp_stat(a.ctl.tot(r.j) + 2, gmax, true);
 }
 
 // ---- 4. first worklist: a zero-cost tight link from a higher-numbered source; the tight children of non-natural vertices
@@ -326,7 +344,7 @@ __global__ __launch_bounds__(256) void kr_due(RepairArgs a) {
   const RpRoot r(a);
   const GraphDev &g = a.g;
   const RpCtx c = r.ctx(a);
-  if (a.ctl.fail()[r.j]) return;
+  if (rp_failed(a, r.j)) return;
   const uint32_t nz = *a.nz;
   uint32_t *cnt = a.ctl.cnt(1u, r.j);                                // sweep 1 reads counter 1, list 1
   bool any = false;
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(256) void kr_due(RepairArgs a) {
         any = rp_wake(r, cnt, r.WL1, x, 1u, t) || any;
       }
   }
-  if (any) a.ctl.pend()[1] = 1u;
+  if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) a.ctl.pend()[1] = 1u;
 }
 
 // ---- 5. one sweep: evaluate the worklist in the true order; whatever changes wakes its tight children
@@ -365,7 +383,7 @@ __global__ __launch_bounds__(256) void kr_sweep(RepairArgs a, uint32_t sweep) {
   const uint32_t W = r.W;
   uint32_t *cnt_cur = a.ctl.cnt(sweep % 3u, r.j), *cnt_next = a.ctl.cnt((sweep + 1u) % 3u, r.j);
   if (blockIdx.x == 0 && threadIdx.x == 0) *a.ctl.cnt((sweep + 2u) % 3u, r.j) = 0u;   // read by the sweep before, filled by the next one
-  if (a.ctl.fail()[r.j]) return;
+  if (rp_failed(a, r.j)) return;
   const uint32_t cnt = *cnt_cur;
   const uint32_t *list = (sweep & 1u) ? r.WL1 : r.WL0;
   uint32_t *next = (sweep & 1u) ? r.WL0 : r.WL1;
@@ -431,8 +449,8 @@ __global__ __launch_bounds__(256) void kr_sweep(RepairArgs a, uint32_t sweep) {
       any = rp_wake(r, cnt_next, next, x, sweep + 1u, t) || any;
     }
   }
-  if (any) pend[sweep + 1u] = 1u;
-  if (evals) atomicAdd(a.ctl.tot(), evals);
+  if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) pend[sweep + 1u] = 1u;
+  rp_stat(a.ctl.tot(r.j), evals, false);
 }
 
 

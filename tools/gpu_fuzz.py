@@ -22,13 +22,15 @@ from holo_amd import engine as E               # noqa: E402
 from oracle import graph_oracle as go          # noqa: E402
 
 
-PATHS = {"k_xcd": 0, "other": 0}              # which kernel took the runs (fuzz_mid reports it: a k_xcd run that gave up shows here)
+PATHS = {"k_xcd": 0, "other": 0, "repaired": 0, "exact": 0}   # which kernel took the runs (fuzz_mid reports it: a k_xcd run that gave up shows here);
+                                                                # roots put right by k_repair / re-run by the sequential kernel
 
 
 def compare(ctx, G, g, roots, flags, tag):
     try:
         res = ctx.run(G, roots, flags)
         PATHS["k_xcd" if res.stats.get("single_wg") == 2 else "other"] += 1
+        PATHS["repaired"] += res.stats.get("n_repaired_roots", 0); PATHS["exact"] += res.stats.get("n_exact_roots", 0)
     except E.HspfError as e:
         if e.code == -5:                       # documented limit: more than 1024 first-hop slots (16 mask words)
             return True
@@ -71,12 +73,13 @@ def fuzz(ctx, first, count, verbose=True):
         nr = int(rng.integers(5, 260)) if rng.random() > 0.04 else int(rng.integers(800, 3000))
         nn = int(rng.integers(0, 14))
         hop = rng.random() < 0.2
+        zero = os.environ.get("FUZZ_ZERO") is not None              # round 6: every graph with zero-cost router links and tie-heavy costs (dynamic pop orders)
         g = synth.random_lsdb(nr, nn, float(rng.uniform(1.2, 4.5)), 50_000 + seed,
-                              metric_lo=1, metric_hi=int(rng.integers(1, 40)),
+                              metric_lo=1, metric_hi=int(rng.integers(1, 5 if zero else 40)),
                               max_path=(1023 if rng.random() < 0.15 else (0xFFFFFFFF if rng.random() < 0.3 else synth.MAX_PATH_METRIC_WIDE)),
                               p_oneway=float(rng.choice([0.0, 0.03, 0.3])), p_parallel=float(rng.choice([0.0, 0.05, 0.4])),
                               p_overload=float(rng.choice([0.0, 0.03, 0.3])), p_noexpand=float(rng.choice([0.0, 0.02, 0.2])),
-                              zero_cost_router_links=bool(rng.random() < 0.15), lan_size=int(rng.choice([2, 3, 5, 8, 14, 20, 30, 45, 70, 140])), hopcount=hop)
+                              zero_cost_router_links=bool(rng.random() < 0.15) or zero, lan_size=int(rng.choice([2, 3, 5, 8, 14, 20, 30, 45, 70, 140])), hopcount=hop)
         if rng.random() < 0.15 and not hop:                       # large costs: 8-byte state, max-path pruning, u32 saturation
             g.metric = (g.metric.astype(np.uint64) << int(rng.integers(8, 25))).clip(0, 0xFFFFFFFE).astype(np.uint32)
         G = ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
@@ -90,7 +93,7 @@ def fuzz(ctx, first, count, verbose=True):
             flags = int(rng.choice([0, E.RUN_NET_NEXTHOPS, E.RUN_IGNORE_OVERLOAD, E.RUN_NET_NEXTHOPS | E.RUN_IGNORE_OVERLOAD]))
             if hop:
                 flags |= E.RUN_IGNORE_OVERLOAD
-            if rng.random() < 0.08:
+            if rng.random() < (0.3 if zero else 0.08):
                 flags |= E.RUN_POP_RANK
             runs += 1
             t_run = time.time()
@@ -118,7 +121,7 @@ def fuzz(ctx, first, count, verbose=True):
                 g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
         G.free()
     if verbose:
-        print(f"fuzz: {ok}/{runs} runs bit-exact over {count} graphs in {time.time() - t0:.1f} s", flush=True)
+        print(f"fuzz: {ok}/{runs} runs bit-exact over {count} graphs in {time.time() - t0:.1f} s (roots put right by k_repair: {PATHS['repaired']}, by the sequential kernel: {PATHS['exact']})", flush=True)
     return ok, runs
 
 
