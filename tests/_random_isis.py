@@ -13,8 +13,15 @@ def sid(i):
     return f"0000.0000.{i:04x}"
 
 
-def make(seed: int) -> dict:
+def make(seed: int, zero: bool = False) -> dict:
+    """zero=True: about a third of the link metrics are 0 (holo-isis/src/spf.rs:629-704 treats 0 like any metric; YANG allows it): the
+    pop order of many roots is then dynamic — the engine's k_repair / pop ranks and the twins' slot replay in that order."""
     rng = np.random.default_rng(seed)
+    _rand_metric = rng.integers
+
+    def draw(lo, hi):
+        m = int(_rand_metric(lo, hi))
+        return 0 if (zero and rng.random() < 0.35) else m
     n = int(rng.integers(3, 13))
     mtype = str(rng.choice(["standard", "wide", "both"]))
     maxm = 60 if mtype != "wide" else 5000
@@ -25,21 +32,21 @@ def make(seed: int) -> dict:
         for b in range(a + 1, n + 1):
             if rng.random() < min(1.0, 2.2 / n):
                 reps = 2 if rng.random() < 0.25 else 1
-                m = int(rng.integers(1, maxm))
+                m = draw(1, maxm)
                 for _ in range(reps):
                     same = rng.random() < 0.6
-                    p2p.append((a, b, m, m if rng.random() < 0.7 else int(rng.integers(1, maxm))))
+                    p2p.append((a, b, m, m if rng.random() < 0.7 else draw(1, maxm)))
                     if not same:
-                        m = int(rng.integers(1, maxm))
+                        m = draw(1, maxm)
     for a in range(1, n):                        # keep it mostly connected
         if not any(x[:2] in ((a, a + 1),) for x in p2p) and rng.random() < 0.8:
-            m = int(rng.integers(1, maxm)); p2p.append((a, a + 1, m, m))
+            m = draw(1, maxm); p2p.append((a, a + 1, m, m))
     lans = []                                    # (dis, pn id, members, metric per member)
     for k in range(int(rng.integers(0, 3))):
         size = int(rng.integers(2, min(n, 6) + 1))
         members = sorted(rng.choice(np.arange(1, n + 1), size=size, replace=False).tolist())
         dis = int(rng.choice(members))
-        lans.append((dis, k + 1, members, {m: int(rng.integers(1, maxm)) for m in members}))
+        lans.append((dis, k + 1, members, {m: draw(1, maxm) for m in members}))
     # LSPs
     lsps = []
     std_on, wide_on = mtype in ("standard", "both"), mtype in ("wide", "both")

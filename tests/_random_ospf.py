@@ -13,7 +13,8 @@ def rid(i):
     return f"{i}.{i}.{i}.{i}"
 
 
-def make(seed: int) -> dict:
+def make(seed: int, zero: bool = False) -> dict:
+    """zero=True: about a third of the p2p link metrics are 0 (a u16 like any other to holo-ospf/src/spf.rs:666-719)."""
     rng = np.random.default_rng(seed)
     n = int(rng.integers(3, 12))
     local = int(rng.integers(1, n + 1))
@@ -29,6 +30,8 @@ def make(seed: int) -> dict:
                     subnet += 1
                     aa, ab = f"10.{subnet // 250}.{subnet % 250}.1", f"10.{subnet // 250}.{subnet % 250}.2"
                     ma, mb = int(rng.integers(1, hi + 1)), int(rng.integers(1, hi + 1))
+                    if zero:
+                        ma, mb = (0 if rng.random() < 0.35 else ma), (0 if rng.random() < 0.35 else mb)
                     if rng.random() < 0.7: mb = ma
                     la = {"type": "point-to-point-link", "id": rid(b), "data": aa, "metric": ma}
                     lb = {"type": "point-to-point-link", "id": rid(a), "data": ab, "metric": mb}

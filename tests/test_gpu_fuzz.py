@@ -55,3 +55,25 @@ def test_random_isis_instances_and_ospf_areas_through_the_engine(spf_ctx):
             check_spts_against_ref(vec, H.Instance.from_vector(vec), spf_ctx)
     for seed in range(1000, 1060):
         check_ospf(make_ospf(seed), spf_ctx)
+
+
+def test_random_isis_instances_with_zero_metrics_through_the_engine(spf_ctx):
+    """Round 6: a third of the link metrics at 0 — the engine resolves the dynamic pop orders in parallel (k_repair, pop ranks from
+    two sorts) and the twin's slot replay / first-hop lists follow those ranks: RIBs and whole SPTs against the literal loop."""
+    from holo_amd import isis as H
+    from oracle import isis_ref as R
+    from _random_isis import make as make_isis
+    from test_host_isis import check_spts_against_ref
+    exact = 0
+    for seed in range(5000, 5080):
+        vec = make_isis(seed, zero=True)
+        assert H.compute_spf(H.Instance.from_vector(vec), spf_ctx) == R.local_rib(vec), seed
+        if seed % 3 == 0:
+            check_spts_against_ref(vec, H.Instance.from_vector(vec), spf_ctx)
+        st = spf_ctx.stats()
+        exact += st["n_exact_roots"]
+    assert exact == 0, "the sequential kernel ran"
+    from _random_ospf import make as make_ospf
+    from test_host_ospf_random import check as check_ospf
+    for seed in range(7000, 7080):
+        check_ospf(make_ospf(seed, zero=True), spf_ctx)

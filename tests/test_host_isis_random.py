@@ -22,6 +22,19 @@ def test_random_instances_local_rib_and_all_roots(block):
             check_spts_against_ref(vec, H.Instance.from_vector(vec), eng)
 
 
+@pytest.mark.parametrize("block", range(4))
+def test_random_instances_with_zero_metrics_local_rib_and_all_roots(block):
+    """A third of the link metrics at 0 (legal: holo-isis/src/spf.rs:629-704 adds them like any metric): pop orders are dynamic,
+    `first_hops` / `second_hops` lists and the slot replay follow the engine's pop ranks (HSPF_RF_EXACT -> HSPF_RUN_POP_RANK)."""
+    eng = OracleEngine()
+    for seed in range(5000 + block * 25, 5000 + block * 25 + 25):
+        vec = make(seed, zero=True)
+        inst = H.Instance.from_vector(vec)
+        assert H.compute_spf(inst, eng) == R.local_rib(vec), seed
+        if seed % 3 == 0:
+            check_spts_against_ref(vec, H.Instance.from_vector(vec), eng)
+
+
 def mutate(vec, rng):
     """A few LSP-level changes of the kind the protocol produces: overload bit flips, metric changes, a neighbour
     dropped, a fragment purged (lifetime 0)."""

@@ -28,3 +28,11 @@ def test_random_areas_rib_and_spt(block):
     eng = OracleEngine()
     for seed in range(block * 40, block * 40 + 40):
         check(make(seed), eng)
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_areas_with_zero_cost_links_rib_and_spt(block):
+    """A third of the p2p metrics at 0: dynamic pop orders (the twin orders the SPT by the engine's pop ranks)."""
+    eng = OracleEngine()
+    for seed in range(7000 + block * 40, 7000 + block * 40 + 40):
+        check(make(seed, zero=True), eng)
