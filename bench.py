@@ -633,6 +633,7 @@ def exact_path(ctx, dev) -> dict:
     Beside it: the same graph without zero-cost links, and the CPU heap restatement (1 thread) on the same roots; one root of
     every case is verified against the oracle's literal loop."""
     import torch
+    from holo_amd import synth
     from oracle import graph_oracle as go
     out = {}
     for name, g0 in (("ospf-10k", synth.ospf_10k()), ("isis-100k", synth.isis_100k())):
@@ -1191,14 +1192,24 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, roots)
             ctx1 = E.SpfContext(local_rank)
-            out["latency_1root"] = latency_1root(ctx1, dev)
-            out["pipeline_1root"] = pipeline_1root(ctx1, dev)
-            out["cold"] = cold_block(g, dev, roots)
-            out.update(consumer_64root(dev))
-            out["two_instances"] = two_instances(g, dev)
-            out["configs"] = other_configs(ctx1, dev)
-            out["dropin_e2e"] = dropin_e2e()
-            out["exact_path"] = exact_path(ctx1, dev)
+            # the blocks beside the headline: a failure in one of them is recorded in its place, the line is printed all the same
+            def block(key, fn, *a):
+                try:
+                    r = fn(*a)
+                except Exception as ex:  # noqa: BLE001
+                    r = {"error": repr(ex)}
+                if key is None:
+                    out.update(r if "error" not in r else {"consumer_64root": r})
+                else:
+                    out[key] = r
+            block("latency_1root", latency_1root, ctx1, dev)
+            block("pipeline_1root", pipeline_1root, ctx1, dev)
+            block("cold", cold_block, g, dev, roots)
+            block(None, consumer_64root, dev)
+            block("two_instances", two_instances, g, dev)
+            block("configs", other_configs, ctx1, dev)
+            block("dropin_e2e", dropin_e2e)
+            block("exact_path", exact_path, ctx1, dev)
         print(json.dumps(out), flush=True)
 
     m.free_graph(mg)

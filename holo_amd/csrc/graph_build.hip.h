@@ -81,6 +81,11 @@ __device__ __forceinline__ void gb_counts_finish(BuildInfo *info, uint32_t lane)
   }
 }
 
+// rowaux bits (hspf_graph::d_rowaux): the per-row facts behind BuildInfo's hop-count summary, kept so that a structural
+// patch can re-derive the summary from per-row arrays after rewriting only the affected rows (graph_patch.hip.h)
+constexpr uint32_t RA_BAD = 1u;          // some kept in-link of the row is off the hop-count shape
+constexpr uint32_t RA_NET_IN = 2u;       // a network row with a kept in-link
+
 constexpr uint32_t HUB_DEG = 512;        // rows with more links than this: hub mode (HSPF_HUB_DEG)
 
 constexpr int GB_BLOCK = 256;
@@ -408,7 +413,7 @@ kb_hub_gather(uint32_t e, const BuildInfo *__restrict__ info, const uint64_t *__
 __global__ void __launch_bounds__(GB_BLOCK)
 kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__restrict__ in_src,
             const uint32_t *__restrict__ in_w, const uint8_t *__restrict__ vflags, uint8_t *__restrict__ rowflags,
-            BuildInfo *__restrict__ info, uint32_t giant_deg) {
+            uint8_t *__restrict__ rowaux, BuildInfo *__restrict__ info, uint32_t giant_deg) {
   // sixteen lanes per row (a wave = four rows): a row's links arrive in one coalesced load per array and sixteen links,
   // all rows of the wave in flight together (one thread per row walked its links one dependent load after the other:
   // 50-130 us for 100 000 rows of ten links); a row of more than 256 in-links is walked by its whole wave afterwards (a
@@ -450,7 +455,10 @@ kb_rowflags(uint32_t n, const uint32_t *__restrict__ in_ptr, const uint32_t *__r
   }
   f |= (b - a > 16u ? RF_MANY : 0u) | (b - a > giant_deg ? RF_GIANT : 0u);
   const bool head = valid && j == 0u;
-  if (head) rowflags[t] = (uint8_t)f;
+  if (head) {
+    rowflags[t] = (uint8_t)f;
+    rowaux[t] = (uint8_t)((bad ? RA_BAD : 0u) | ((net && b > a) ? RA_NET_IN : 0u));   // what the summary counts, per row (graph_patch.hip.h)
+  }
   // the summary: reduced over the wave, then over the block; maximum and OR only touch BuildInfo when they would change
   // it, the two counts go to the spread counters (gb_spread)
   __shared__ uint32_t red[4][5];

@@ -10,6 +10,7 @@
 #include "spf_kernels.hip.h"
 #include "spf_repair.hip.h"
 #include "graph_build.hip.h"
+#include "graph_patch.hip.h"
 #include "hub_sort.h"
 
 #include <algorithm>
@@ -68,6 +69,8 @@ struct hspf_graph {
   uint32_t *d_in_ptr = nullptr, *d_in_src = nullptr, *d_in_w = nullptr, *d_in_fpos = nullptr;
   uint32_t *d_out_ptr = nullptr, *d_out_dst = nullptr, *d_out_w = nullptr, *d_out_fpos = nullptr;
   uint8_t *d_vflags = nullptr, *d_rowflags = nullptr, *d_leaf = nullptr;   // d_leaf: GraphDev::leaf
+  uint8_t *d_rowaux = nullptr;                                     // RA_* per row (graph_build.hip.h)
+  uint32_t *d_in_src2 = nullptr, *d_in_w2 = nullptr, *d_in_fpos2 = nullptr, *d_out_dst2 = nullptr, *d_out_w2 = nullptr, *d_out_fpos2 = nullptr;
   uint8_t *d_zcyc = nullptr, *d_zcyc_tmp = nullptr;                // GraphDev::zcyc (+ the other buffer of the trimming rounds)
   bool zcyc_valid = false;                                        // d_zcyc describes the current links (zcyc_update)
   uint32_t n_leaf = 0;
@@ -94,6 +97,7 @@ struct hspf_graph {
   }
   bool hub_built = false;                                         // the last build ran in hub mode (sorted keys)
   bool costs_only = false;                                        // the last patch changed costs only: nothing was rebuilt
+  bool patched_in_place = false;                                  // the last patch was structural and took the incremental path (graph_patch.hip.h)
   bool lean = false;                                              // no network vertex, no static row flag, in-degrees <= 8: k_single_lean
   // A patch that failed after it had started to rewrite the device arrays or the host mirrors (HIP error, allocation failure)
   // leaves the two out of step: the graph is marked and every later call on it returns HSPF_E_INVAL — the caller frees it
@@ -110,13 +114,23 @@ struct hspf_graph {
     d_in_ptr = (uint32_t *)carve(vb); d_out_ptr = (uint32_t *)carve(vb);
     d_in_src = (uint32_t *)carve(lb); d_in_w = (uint32_t *)carve(lb); d_in_fpos = (uint32_t *)carve(lb);
     d_out_dst = (uint32_t *)carve(lb); d_out_w = (uint32_t *)carve(lb); d_out_fpos = (uint32_t *)carve(lb);
-    d_vflags = (uint8_t *)carve(nv); d_rowflags = (uint8_t *)carve(nv); d_leaf = (uint8_t *)carve(nv);
+    d_vflags = (uint8_t *)carve(nv); d_rowflags = (uint8_t *)carve(nv); d_leaf = (uint8_t *)carve(nv); d_rowaux = (uint8_t *)carve(nv);
+    // the other set of the six link arrays: a structural patch writes the shifted arrays there and the sets swap (graph_patch.hip.h)
+    d_in_src2 = (uint32_t *)carve(lb); d_in_w2 = (uint32_t *)carve(lb); d_in_fpos2 = (uint32_t *)carve(lb);
+    d_out_dst2 = (uint32_t *)carve(lb); d_out_w2 = (uint32_t *)carve(lb); d_out_fpos2 = (uint32_t *)carve(lb);
     d_unit_first = (uint32_t *)carve((size_t(nv) / 4 + 8) * 4);
     d_giant = (uint32_t *)carve((size_t(cap) / (GIANT_DEG / 2) + 8) * 4);
     d_ell_so = (uint32_t *)carve((size_t(nv) + 1) * 64); d_ell_w = (uint32_t *)carve((size_t(nv) + 1) * 64); d_ell_od = (uint32_t *)carve((size_t(nv) + 1) * 64);
     d_zcyc = (uint8_t *)carve(nv); d_zcyc_tmp = (uint8_t *)carve(nv);
+    if (links_alt) swap_link_sets_ptrs();
     return off;
   }
+  bool links_alt = false;            // the live link arrays are the second set (an odd number of incremental structural patches)
+  void swap_link_sets_ptrs() {
+    std::swap(d_in_src, d_in_src2); std::swap(d_in_w, d_in_w2); std::swap(d_in_fpos, d_in_fpos2);
+    std::swap(d_out_dst, d_out_dst2); std::swap(d_out_w, d_out_w2); std::swap(d_out_fpos, d_out_fpos2);
+  }
+  void swap_link_sets() { swap_link_sets_ptrs(); links_alt = !links_alt; }
   GraphDev dev() const {
     GraphDev g;
     g.n = n; g.e_in = e_kept;
@@ -191,6 +205,9 @@ struct hspf_ctx {
   uint32_t mark_epoch = 0;
   uint32_t *h_patch = nullptr;      // pinned staging block of the cost-only patch
   std::vector<uint32_t> patch_targets;
+  std::vector<uint32_t> patch_aff;  // affected rows of an incremental structural patch (graph_patch.hip.h)
+  DevBuf gb_pa;                     // ... its BuildInfo, chunk flags, row metadata and staging area
+  bool patch_full = false;          // HSPF_PATCH_FULL env (tests, A/B): every structural patch rebuilds the layout, as before round 6
   size_t h_patch_cap = 0;           // words
   uint32_t *h_lane_flags = nullptr; // pinned: per-root status bits, then the 256 rows_done words of the fused kernel
   size_t h_lane_cap = 0;
@@ -516,7 +533,7 @@ int build_launch(hspf_ctx *ctx, hspf_graph *g, bool hub, BuildScratch &bs) {
                        (const uint4 *)tmp, g->d_in_src, g->d_in_w, g->d_in_fpos, ctx->hub_deg);
   }
   hipLaunchKernelGGL(kb_rowflags, dim3((uint32_t)(((size_t)n * 16 + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
-                     (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, info, GIANT_DEG);
+                     (const uint32_t *)g->d_in_w, (const uint8_t *)g->d_vflags, g->d_rowflags, g->d_rowaux, info, GIANT_DEG);
   hipLaunchKernelGGL(kb_leaf_mark, gn, dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)g->d_in_src,
                      (const uint32_t *)g->d_out_ptr, (const uint32_t *)g->d_out_dst, g->d_leaf, info);
   if (e) hipLaunchKernelGGL(kb_leaf_links, ge, dim3(GB_BLOCK), 0, s, e, (const BuildInfo *)info, g->d_in_src, (const uint8_t *)g->d_leaf);
@@ -580,6 +597,7 @@ int build_finish(hspf_ctx *ctx, hspf_graph *g, bool hub, const BuildScratch &bs,
   if (!hub && bi.max_in_deg > ctx->hub_deg) return HSPF_RETRY_HUB;     // kb_rank left those rows unsorted
   g->hub_built = hub;
   g->costs_only = false;
+  g->patched_in_place = false;
   for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
   g->n_heavy_chunks = bi.n_heavy;
   g->max_in_deg = bi.max_in_deg;
@@ -624,6 +642,66 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
   int rc = build_pass(ctx, g, hub, true);
   if (rc == HSPF_RETRY_HUB) rc = build_pass(ctx, g, true, true);
   return rc;
+}
+
+// ---- incremental structural patch (graph_patch.hip.h).  The raw CSR of g (g->cur) and the vertex flags are already the new
+// ones (kb_patch_row_ptr / kb_splice are enqueued); d_aff = the affected rows, ascending, on the device.
+constexpr int HSPF_RETRY_REBUILD = 1001;    // patch_finish -> graph_patch_impl only
+
+int patch_launch(hspf_ctx *ctx, hspf_graph *g, uint32_t na, const uint32_t *d_aff) {
+  const uint32_t n = g->n, nb = (n + 15u) / 16u;
+  hipStream_t s = ctx->stream;
+  const size_t n_info = 32u + GB_SC_WORDS;
+  const size_t words = n_info + ((size_t)nb + 16) + (size_t)PA_META * (na + 1u) + (size_t)na * 3u * (PA_IN_STRIDE + PA_OUT_STRIDE) + 64;
+  int rc = ensure(ctx, ctx->gb_pa, words * 4, false);
+  if (rc != HSPF_OK) return rc;
+  uint32_t *w = (uint32_t *)ctx->gb_pa.p;
+  BuildInfo *info = (BuildInfo *)w; w += n_info;
+  uint32_t *hf = w; w += (size_t)nb + 16;
+  uint32_t *meta = w; w += (size_t)PA_META * (na + 1u);
+  uint32_t *st_in = w; w += (size_t)na * 3u * PA_IN_STRIDE;
+  uint32_t *st_out = w;
+  const uint32_t *row_ptr = g->d_row_ptr[g->cur], *col = g->d_col[g->cur], *metric = g->d_metric[g->cur];
+  hipLaunchKernelGGL(kb_clear, dim3((uint32_t)((n_info + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, hf, 0u, (uint32_t *)info, (uint32_t)n_info);
+  hipLaunchKernelGGL(kb_pa_rows, dim3(na), dim3(256), 0, s, n, na, d_aff, row_ptr, col, metric, (const uint8_t *)g->d_vflags, (const uint32_t *)g->d_in_ptr,
+                     (const uint32_t *)g->d_out_ptr, meta, st_in, st_out, g->d_rowflags, g->d_rowaux, g->d_leaf, g->d_ell_so, g->d_ell_w, g->d_ell_od, GIANT_DEG, info);
+  hipLaunchKernelGGL(kb_pa_scan, dim3(1), dim3(GB_BLOCK), 0, s, na, meta, g->e_kept, info);
+  // the new number of kept links is the device's to know; the grid covers the most it can be
+  const uint64_t bound = std::max<uint64_t>((uint64_t)n + 1u, std::min<uint64_t>((uint64_t)g->e_kept + (uint64_t)na * PA_IN_STRIDE, (uint64_t)g->e));
+  hipLaunchKernelGGL(kb_pa_shift, dim3((uint32_t)((bound + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, n, na, d_aff, (const uint32_t *)meta, (const uint32_t *)st_in,
+                     (const uint32_t *)st_out, (const uint32_t *)g->d_in_src, (const uint32_t *)g->d_in_w, (const uint32_t *)g->d_in_fpos, (const uint32_t *)g->d_out_dst,
+                     (const uint32_t *)g->d_out_w, (const uint32_t *)g->d_out_fpos, g->d_in_src2, g->d_in_w2, g->d_in_fpos2, g->d_out_dst2, g->d_out_w2, g->d_out_fpos2,
+                     g->d_in_ptr, g->d_out_ptr, (const uint8_t *)g->d_leaf, info);
+  g->swap_link_sets();                                           // (host pointers only: the launches above hold the old ones)
+  hipLaunchKernelGGL(kb_pa_summary, dim3((n + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint8_t *)g->d_rowflags,
+                     (const uint8_t *)g->d_rowaux, (const uint8_t *)g->d_leaf, hf, ctx->unit_heavy_deg, info);
+  hipLaunchKernelGGL(kb_units_small, dim3(1), dim3(GB_UNITS_THREADS), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)hf, g->d_unit_first, info,
+                     ctx->xcd_row_cost, g->d_in_ptr, g->d_out_ptr, g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_info, info, sizeof(BuildInfo), hipMemcpyDeviceToHost, s));
+  return HSPF_OK;
+}
+
+int patch_finish(hspf_ctx *ctx, hspf_graph *g) {
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const BuildInfo bi = *ctx->h_info;
+  if (bi.err & GB_ERR_PATCH) return HSPF_RETRY_REBUILD;
+  if (bi.err) { ctx->last_error = "hspf_graph_patch: internal: link error on the incremental path"; return HSPF_E_INTERNAL; }
+  g->e_kept = bi.kept;
+  g->wmax = bi.wmax;
+  g->hc_net = bi.hc_net != 0; g->n_bad_rows = bi.n_bad_rows; g->n_zero_rows = bi.n_zero_rows; g->any_rowflags = bi.any_rowflags;
+  g->heavy_rows = g->heavy_links * 4u >= (uint64_t)std::max<uint32_t>(g->e, 1u);
+  g->hub_built = false;
+  g->costs_only = false;
+  g->patched_in_place = true;
+  for (int x = 0; x < 9; ++x) g->xcd_start[x] = bi.xcd_start[x];
+  g->n_heavy_chunks = bi.n_heavy;
+  g->max_in_deg = bi.max_in_deg;
+  g->n_leaf = bi.n_leaf;
+  g->n_giant = 0; g->n_giant_slices = 0;
+  g->any_net = g->n_net != 0;
+  finish_summary(g);
+  return zcyc_update(ctx, g);
 }
 
 int alloc_arena(hspf_ctx *ctx, hspf_graph *g, uint32_t n, uint32_t cap) {
@@ -718,6 +796,7 @@ int hspf_init(int device_ordinal, hspf_ctx **out) {
   if (const char *v = getenv("HSPF_UNIT_HEAVY_DEG")) ctx->unit_heavy_deg = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_HUB_DEG")) ctx->hub_deg = (uint32_t)strtoul(v, nullptr, 0);
   if (const char *v = getenv("HSPF_TW_HOST_MAX")) ctx->tw_host_max = strtoull(v, nullptr, 0);
+  if (const char *v = getenv("HSPF_PATCH_FULL")) ctx->patch_full = atoi(v) != 0;
   if (const char *v = getenv("HSPF_ASYNC_LANES")) ctx->lanes_cfg = std::min<uint32_t>(std::max<uint32_t>((uint32_t)strtoul(v, nullptr, 0), 1u), 8u);
   if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return HSPF_E_NODEV; }
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HSPF_E_HIP; }
@@ -737,7 +816,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->rp_rank, &ctx->dyn_part, &ctx->rp_z, &ctx->rp_ord, &ctx->rp_work, &ctx->rp_status, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb_kx, &ctx->gb, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag, &ctx->xcd_ctl})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->rp_rank, &ctx->dyn_part, &ctx->rp_z, &ctx->rp_ord, &ctx->rp_work, &ctx->rp_status, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb_kx, &ctx->gb, &ctx->gb_pa, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag, &ctx->xcd_ctl})
     release(*b);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (auto &e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
@@ -1002,6 +1081,7 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
         finish_summary(g);
         { const int zr = zcyc_update(ctx, g); if (zr != HSPF_OK) return zr; }     // (a no-op unless the graph has zero-cost links from higher-numbered sources)
         g->costs_only = true;
+        g->patched_in_place = false;
         ctx->prefill.valid = false;
         return HSPF_OK;
       }();
@@ -1034,7 +1114,9 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
   if (e_new64 > HSPF_MAX_LINKS) { ctx->last_error = "hspf_graph_patch: too many links"; return HSPF_E_INVAL; }
   const uint32_t e_new = (uint32_t)e_new64;
   // grow the arena when the patched graph does not fit (raw CSR and flags move device-to-device)
+  bool grown = false;
   if (e_new > g->cap_e) {
+    grown = true;
     char *old_arena = g->arena;
     const size_t old_bytes = g->arena_bytes;
     const uint32_t old_cap = g->cap_e;
@@ -1056,8 +1138,38 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
     (void)hipFree(old_arena);
     if (er != hipSuccess) { ctx->last_error = std::string("hspf_graph_patch: grow: ") + hipGetErrorString(er); return HSPF_E_HIP; }
   }
-  // the delta, one pinned staging block, one copy: changed[m] | delta_ptr[m+1] | shift[m+1] | delta_col[de] | delta_metric[de] | flags[m] (bytes)
-  const size_t dwords = (size_t)m + 2 * ((size_t)m + 1) + 2 * (size_t)de + ((size_t)m + 3) / 4;
+  // work of keeping the mirror's two-way flags on the host (see "behind the kernels" below); decided here because the
+  // incremental path needs the flags kept by the host (it has no per-link flags to fetch)
+  uint64_t tw_work = 0;
+  for (uint32_t j = 0; j < m; ++j) {
+    const uint32_t v = rows->vertex[j];
+    for (uint32_t k = rows->row_ptr[j]; k < rows->row_ptr[j + 1]; ++k) { const uint32_t t = rows->col[k]; tw_work += g->row_ptr[t + 1] - g->row_ptr[t] + 1u; }
+    for (uint32_t k = g->row_ptr[v]; k < g->row_ptr[v + 1]; ++k) { const uint32_t t = g->col[k]; tw_work += g->row_ptr[t + 1] - g->row_ptr[t] + 1u; }
+  }
+  tw_work += 2ull * de;                                       // rows of replaced targets are read at their new length
+  // (a scanned entry costs ~5 ns, a byte of flags over the bus ~0.1 ns + a fixed ~20 us: the patch keeps the flags itself
+  // while that is the cheaper side — every ordinary LSP; a replaced hub row of 100 000 links is not)
+  const uint64_t tw_bound = ctx->tw_host_max == UINT64_MAX ? std::max<uint64_t>(4096u, e_new / 32u) : ctx->tw_host_max;
+  const bool tw_host = tw_work <= tw_bound && g->twoway.size() == g->e;
+  // ---- the incremental path (graph_patch.hip.h): affected rows = replaced rows + their old and new targets
+  std::vector<uint32_t> &aff = ctx->patch_aff;
+  aff.clear();
+  bool incremental = !ctx->patch_full && tw_host && e_new <= g->cap_e && !grown && g->max_in_deg <= PA_IN_STRIDE && g->n_giant == 0 && !g->hub_built &&
+                     std::max(g->max_out, new_max_len) <= std::min(ctx->hub_deg, PA_OUT_STRIDE) && (n + 15u) / 16u <= GB_UNITS_MAX_CHUNKS && g->e_kept != 0;
+  if (incremental) {
+    aff.assign(rows->vertex, rows->vertex + m);
+    aff.insert(aff.end(), rows->col, rows->col + de);
+    for (uint32_t j = 0; j < m && aff.size() <= 8u * PA_MAX_ROWS; ++j) {
+      const uint32_t v = rows->vertex[j];
+      aff.insert(aff.end(), g->col.begin() + g->row_ptr[v], g->col.begin() + g->row_ptr[v + 1]);
+    }
+    std::sort(aff.begin(), aff.end());
+    aff.erase(std::unique(aff.begin(), aff.end()), aff.end());
+    incremental = aff.size() <= PA_MAX_ROWS;
+  }
+  const uint32_t na = incremental ? (uint32_t)aff.size() : 0u;
+  // the delta, one pinned staging block, one copy: changed[m] | delta_ptr[m+1] | shift[m+1] | delta_col[de] | delta_metric[de] | flags[m] (bytes) | affected[na]
+  const size_t dwords = (size_t)m + 2 * ((size_t)m + 1) + 2 * (size_t)de + ((size_t)m + 3) / 4 + na;
   int rc = ensure(ctx, ctx->gb_delta, dwords * 4 + 64, false);
   if (rc != HSPF_OK) return rc;
   if (ctx->h_patch_cap < dwords) {
@@ -1084,10 +1196,12 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
       memcpy(sh + m + 1 + de, rows->metric, (size_t)de * 4);
     }
     memcpy(sh + m + 1 + 2 * (size_t)de, rows->vflags, m);
+    if (na) memcpy(sh + m + 1 + 2 * (size_t)de + ((size_t)m + 3) / 4, aff.data(), (size_t)na * 4);
   }
   uint32_t *d_changed = (uint32_t *)ctx->gb_delta.p;
   uint32_t *d_dptr = d_changed + m, *d_shift = d_dptr + m + 1, *d_dcol = d_shift + m + 1, *d_dmet = d_dcol + de;
   uint8_t *d_nf = (uint8_t *)(d_dmet + de);
+  const uint32_t *d_aff = d_dmet + de + ((size_t)m + 3) / 4;
   const int nxt = g->cur ^ 1;
   committed = true;                                            // kb_patch_row_ptr rewrites the vertex flags in place; the mirrors follow
   HIPCHK(ctx, hipMemcpyAsync(d_changed, ctx->h_patch, dwords * 4, hipMemcpyHostToDevice, s));
@@ -1114,7 +1228,7 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
   g->e = e_new;
   const bool hub = max_out_new > ctx->hub_deg;
   BuildScratch bs;
-  rc = build_launch(ctx, g, hub, bs);
+  rc = incremental ? patch_launch(ctx, g, na, d_aff) : build_launch(ctx, g, hub, bs);
   if (rc != HSPF_OK) {                                       // nothing of the host side was touched: the graph is unusable only if the device failed
     (void)hipStreamSynchronize(s);
     g->cur = nxt ^ 1; g->e = e_old;
@@ -1126,17 +1240,6 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
   // Two-way flags of the mirror: a link u -> t is two-way when row t lists u.  Replacing row u changes the flags of u's
   // own links and of the links t -> u in the rows of its old and new targets, nothing else.  Long rows would make the
   // membership scans quadratic, so beyond a work bound the flags come back from the device as after an upload.
-  uint64_t tw_work = 0;
-  for (uint32_t j = 0; j < m; ++j) {
-    const uint32_t v = rows->vertex[j];
-    for (uint32_t k = rows->row_ptr[j]; k < rows->row_ptr[j + 1]; ++k) { const uint32_t t = rows->col[k]; tw_work += g->row_ptr[t + 1] - g->row_ptr[t] + 1u; }
-    for (uint32_t k = g->row_ptr[v]; k < g->row_ptr[v + 1]; ++k) { const uint32_t t = g->col[k]; tw_work += g->row_ptr[t + 1] - g->row_ptr[t] + 1u; }
-  }
-  tw_work += 2ull * de;                                       // rows of replaced targets are read at their new length
-  // (a scanned entry costs ~5 ns, a byte of flags over the bus ~0.1 ns + a fixed ~20 us: the patch keeps the flags itself
-  // while that is the cheaper side — every ordinary LSP; a replaced hub row of 100 000 links is not)
-  const uint64_t tw_bound = ctx->tw_host_max == UINT64_MAX ? std::max<uint64_t>(4096u, e_new / 32u) : ctx->tw_host_max;
-  const bool tw_host = tw_work <= tw_bound && g->twoway.size() == e_old;
   // In place: the runs of unchanged rows between two replaced ones move by the length changes in front of them — the runs
   // that move towards the front first, front to back, then those that move towards the back, back to front (a run's new
   // place never reaches into a run that has not moved yet: the order of the runs is the same before and after) — then the
@@ -1225,7 +1328,12 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
   for (uint32_t j = 0; j < m; ++j) g->vflags[rows->vertex[j]] = rows->vflags[j];
   g->max_out = max_out_new; g->heavy_links = heavy_new; g->n_net = n_net_new;
   lap("host mirrors");
-  rc = build_finish(ctx, g, hub, bs, !tw_host);
+  if (incremental) {
+    rc = patch_finish(ctx, g);
+    if (rc == HSPF_RETRY_REBUILD) rc = build_pass(ctx, g, hub, false);      // an affected row outgrew the staging area: the raw CSR is complete, rebuild from it
+  } else {
+    rc = build_finish(ctx, g, hub, bs, !tw_host);
+  }
   if (rc == HSPF_RETRY_HUB) rc = build_pass(ctx, g, true, !tw_host);
   if (rc != HSPF_OK) (void)hipStreamSynchronize(s);
   lap("wait + summary");
@@ -1270,7 +1378,7 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
   if (which == HSPF_GX_TWOWAY) { if (bytes) memcpy(dst, g->twoway.data(), bytes); return HSPF_OK; }
   if (which == HSPF_GX_HOST_ROW_PTR) { memcpy(dst, g->row_ptr.data(), bytes); return HSPF_OK; }
   if (which == HSPF_GX_HOST_COL) { if (bytes) memcpy(dst, g->col.data(), bytes); return HSPF_OK; }
-  if (which == HSPF_GX_BUILD_MODE) { const uint32_t m = g->costs_only ? 2u : g->hub_built ? 1u : 0u; memcpy(dst, &m, 4); return HSPF_OK; }
+  if (which == HSPF_GX_BUILD_MODE) { const uint32_t m = g->costs_only ? 2u : g->patched_in_place ? 3u : g->hub_built ? 1u : 0u; memcpy(dst, &m, 4); return HSPF_OK; }
   if (which == HSPF_GX_SUMMARY) {
     const uint32_t v[12] = {g->wmax, g->hopcount_like ? 1u : 0u, g->lean ? 1u : 0u, g->any_rowflags, g->n_zero_rows, g->n_bad_rows, g->max_in_deg, g->e_kept,
                             g->max_out, g->n_net, (uint32_t)g->heavy_links, g->heavy_rows ? 1u : 0u};
@@ -1718,10 +1826,13 @@ int Run::init_state() {
   d_stamp = (uint32_t *)ctx->stamp.p;
   // Wide masks: k_fw unless the graph is hop-count-like with more than 4 mask words or HSPF_VARIANT bit6 asks for the
   // two-phase path (see below).  Leaves (GraphDev::leaf) stay out of k_fw's fixed point and are derived in the emit,
-  // when there are any and neither the saturating-distance nor the hop-count instantiation is needed (HSPF_VARIANT
-  // bit17: leaves take part like any row).
+  // when there are any and neither the saturating-distance nor the hop-count instantiation is needed — and the graph has no
+  // zero-cost link from a higher-numbered source (n_zero_rows): a leaf behind such a link makes its root's pop order dynamic
+  // (the leaf is popped AFTER its parent, against the static (distance, index) order), the emit's derivation gives the right
+  // triple but cannot raise LF_DYN any more (the status bits were read before it), and the caller would be told the order
+  // is static (round 6: tests/test_gpu_fuzz.py, zero-metric instances, seed 5058).
   use_fw = !fused && !(ctx->variant & 64u) && (!g->hopcount_like || W <= 4);
-  defer = use_fw && g->n_leaf != 0 && g->max_path_metric != HSPF_DIST_INF && !g->hopcount_like;
+  defer = use_fw && g->n_leaf != 0 && g->max_path_metric != HSPF_DIST_INF && !g->hopcount_like && g->n_zero_rows == 0;
   HIPCHK(ctx, hipEventRecord(ctx->ev[0], s));
   if (fused) {
     // state / stamps / status bits are initialised by fused_run (it may run twice: narrow, then wide), lv_run or the

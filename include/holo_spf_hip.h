@@ -278,7 +278,9 @@ int hspf_graph_patch(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows);
 #define HSPF_GX_BUILD_MODE 15u /* u32 [1]      how the last upload / patch derived the layout: 0 = per-link row scans,
                                   1 = hub mode (a row of more than 512 links: two device-wide sorts, O(log degree) per
                                   link), 2 = the last patch changed costs only (same targets, order and flags in every
-                                  replaced row): the affected rows were re-ranked in place, nothing was rebuilt.  The
+                                  replaced row): the affected rows were re-ranked in place, nothing was rebuilt;
+                                  3 = the last patch was structural and only the affected rows (the replaced ones, their
+                                  old and new targets) were re-derived, the compact arrays behind them shifted.  The
                                   layout itself does not depend on the mode                                          */
 #define HSPF_GX_ELL_SRC  16u   /* u32 [16(n+1)] fixed-stride copy of the in-rows of at most 16 links: source << 8, the low
                                   byte of a row's first entry = in-degree (0x1F: more than 16) | more than 16 out-links

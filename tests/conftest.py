@@ -49,7 +49,9 @@ def spf_ctx(request, _ctx_pool):
     whichever was faster last time; the four sweep configurations switch it off: HSPF_XCD_MAX_ROOTS=0);
     "hubsort" is the default engine with every graph built in hub mode (HSPF_HUB_DEG=0: two-way check and
     in-row order from device-wide sorts instead of per-link row scans; HSPF_TW_HOST_MAX=0: a structural patch fetches the
-    two-way flags of its host mirror from the device, as it does for rows too long to scan, instead of keeping them itself).
+    two-way flags of its host mirror from the device, as it does for rows too long to scan, instead of keeping them itself);
+    "patchfull" (round 6) is the default engine with every structural patch rebuilding the layout from the spliced rows
+    (HSPF_PATCH_FULL=1: the path every such patch took before the incremental one, holo_amd/csrc/graph_patch.hip.h).
     Tests choose with tests/_engines.py (indirect parametrisation); unmarked tests get "default"."""
     mode = getattr(request, "param", "default")
     if mode not in _ctx_pool:
@@ -60,7 +62,8 @@ def spf_ctx(request, _ctx_pool):
                "widemask": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_XCD_MAX_ROOTS": "0", "HSPF_VARIANT": "1"},
                "lanevertex": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "64", "HSPF_LV_MIN_N": "0"},
                "xcd": {"HSPF_SINGLE_MAX_N": "0", "HSPF_LV_MAX_ROOTS": "0", "HSPF_XCD_ALWAYS": "1"},
-               "hubsort": {"HSPF_HUB_DEG": "0", "HSPF_TW_HOST_MAX": "0"}}.get(mode, {})
+               "hubsort": {"HSPF_HUB_DEG": "0", "HSPF_TW_HOST_MAX": "0"},
+               "patchfull": {"HSPF_PATCH_FULL": "1"}}.get(mode, {})
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         try:

@@ -251,6 +251,58 @@ def test_patch_equals_fresh_upload(spf_ctx, seed):
         G.free()
 
 
+def patch_graphs():
+    yield synth.random_lsdb(60, 8, 3.0, 21, metric_hi=6)
+    yield synth.random_lsdb(90, 10, 2.5, 22, metric_hi=3, p_oneway=0.3, p_parallel=0.4, p_noexpand=0.2, p_overload=0.3)
+    yield synth.random_lsdb(50, 8, 2.5, 23, hopcount=True)
+    yield synth.random_lsdb(120, 6, 3.0, 24, metric_hi=2, zero_cost_router_links=True)
+    yield synth.random_lsdb(700, 9, 3.0, 25, lan_size=90)                # heavy chunks (work units), rows of 90 links
+    yield synth.random_lsdb(300, 40, 1.2, 26, lan_size=2, metric_hi=4)   # sparse: leaves, stub LANs, isolated vertices
+    yield synth.random_lsdb(3000, 100, 4.0, 27, metric_hi=2, zero_cost_router_links=True)
+
+
+@pytest.mark.parametrize("i", range(7))
+def test_incremental_structural_patches_equal_fresh_uploads(spf_ctx, i):
+    """Round 6 ("structural patch in O(changed rows)"): a patch that changes a row's targets re-derives only
+    the AFFECTED rows (the replaced ones, their old and new targets) and shifts the compact arrays behind them
+    (holo_amd/csrc/graph_patch.hip.h) instead of rebuilding the layout — a chain of such patches, one to three rows each
+    (links withdrawn, announced, re-costed, re-ordered, one-way links, flags flipped, rows emptied and refilled), every
+    exported array and the summary equal to a fresh upload's after every step, and the SPTs of the patched graph equal
+    to the oracle's."""
+    g = list(patch_graphs())[i]
+    rng = np.random.default_rng(900 + i)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    nn = g.meta.get("n_networks", 0)
+    roots = np.arange(nn, min(nn + 24, g.n), dtype=np.uint32)
+    modes = []
+    try:
+        for rnd in range(14):
+            if rnd == 5:                                               # a row emptied ...
+                v = int(rng.integers(nn, g.n))
+                saved = (v, g.col[g.row_ptr[v]:g.row_ptr[v + 1]].copy(), g.metric[g.row_ptr[v]:g.row_ptr[v + 1]].copy(), int(g.vflags[v]))
+                vs, rows, flags = np.array([v]), [(np.zeros(0, np.uint32), np.zeros(0, np.uint32))], np.array([g.vflags[v]], np.uint8)
+            elif rnd == 7:                                             # ... and back two patches later
+                vs, rows, flags = np.array([saved[0]]), [(saved[1], saved[2])], np.array([saved[3]], np.uint8)
+            else:
+                vs, rows, flags = random_rows(g, rng, int(rng.integers(1, 4)))
+            G.patch(vs, rows, flags)
+            modes.append(int(G.export("build_mode")[0]))
+            g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
+            F = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+            try:
+                for name in BUILT + RAW + DERIVED + ("zcyc",):
+                    assert np.array_equal(G.export(name), F.export(name)), (rnd, name, modes)
+                assert G.n_edges_kept == F.n_edges_kept
+            finally:
+                F.free()
+            if rnd % 4 == 3:
+                assert_layout(G, g)
+                check_spf(spf_ctx, G, g, roots, E.RUN_NET_NEXTHOPS)
+        assert modes.count(3) >= 8, modes                             # (2: a draw that changed costs only)
+    finally:
+        G.free()
+
+
 @hub_engines
 def test_structural_patch_keeps_the_host_side_current(spf_ctx):
     """A structural patch enqueues the device build and brings the host side up to date behind it: the mirror of the rows,
@@ -487,13 +539,17 @@ def test_patch_full_size_router_purge_and_return(spf_ctx):
     roots = (np.arange(64, dtype=np.uint64) * g.n // 64).astype(np.uint32)
     try:
         base = spf_ctx.run(G, roots)
+        Gexp0 = {name: G.export(name) for name in BUILT + RAW + DERIVED}
         u = 5000
         a, b = int(g.row_ptr[u]), int(g.row_ptr[u + 1])
         row_u = (g.col[a:b].copy(), g.metric[a:b].copy())
         kept0 = G.n_edges_kept
         G.patch([u], [(np.zeros(0, np.uint32), np.zeros(0, np.uint32))], [g.vflags[u]])
         assert G.n_edges_kept == kept0 - 2 * (b - a)
+        assert int(G.export("build_mode")[0]) == (3 if getattr(spf_ctx, "mode", "default") == "default" else 0)
         F = spf_ctx.upload(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric)
+        for name in BUILT + RAW + DERIVED:
+            assert np.array_equal(G.export(name), F.export(name)), name
         r1, r2 = spf_ctx.run(G, roots), spf_ctx.run(F, roots)
         F.free()
         for f in ("dist", "hops", "flags", "first_hop_mask"):
@@ -501,6 +557,8 @@ def test_patch_full_size_router_purge_and_return(spf_ctx):
         assert (r1.dist[:, u] == E.DIST_INF).all() and (base.dist[:, u] != E.DIST_INF).all()
         G.patch([u], [row_u], [g.vflags[u]])
         assert G.n_edges_kept == kept0
+        for name in BUILT + RAW + DERIVED:
+            assert np.array_equal(G.export(name), Gexp0[name]), name
         r3 = spf_ctx.run(G, roots)
         for f in ("dist", "hops", "flags", "first_hop_mask"):
             assert np.array_equal(getattr(r3, f), getattr(base, f)), f
