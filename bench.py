@@ -305,14 +305,14 @@ def pipeline_1root(ctx, dev) -> dict:
                   "stages_ms": {k: round(float(v), 4) for k, v in zip(("graph_patch", "run_device", "routes_device", "routes_diff_device", "routes_pack"), st2)},
                   "graph_patch_c_call_ms": round(float(np.median(calls2[3:])), 4),
                   "graph_patch_is": "stages_ms.graph_patch = the Python twin's G.patch (C call + splice of its numpy mirrors of 1 M links); graph_patch_c_call_ms = hspf_graph_patch alone",
-                  "patch_mode": {0: "rebuild", 1: "rebuild (hub)", 2: "costs in place"}[mode2], "records_to_host": int(len(rec2)),
+                  "patch_mode": {0: "rebuild", 1: "rebuild (hub)", 2: "costs in place", 3: "affected rows re-derived, arrays shifted"}[mode2], "records_to_host": int(len(rec2)),
                   "spt_identical_to_oracle": ok_spt2, "routes_identical_to_fold": ok_routes2, "records_identical_to_fold": ok_rec2}
     G.free()
     st = np.median(np.array(stages[3:]), axis=0)
     return {"graph": "isis-100k", "roots": 1, "prefixes": int(P), "prefix_entries": int(len(vtx)), "changed_row": int(u), "structural": structural,
             "wall_ms": round(float(np.median(np.array(stages[3:]).sum(axis=1))), 4),
             "stages_ms": {k: round(float(v), 4) for k, v in zip(("graph_patch", "run_device", "routes_device", "routes_diff_device", "routes_pack"), st)},
-            "patch_mode": {0: "rebuild", 1: "rebuild (hub)", 2: "costs in place"}[mode], "records_to_host": int(len(rec)),
+            "patch_mode": {0: "rebuild", 1: "rebuild (hub)", 2: "costs in place", 3: "affected rows re-derived, arrays shifted"}[mode], "records_to_host": int(len(rec)),
             "record_bytes": int(rec.nbytes), "spt_identical_to_oracle": ok_spt, "routes_identical_to_fold": ok_routes,
             "records_identical_to_fold": ok_rec}
 

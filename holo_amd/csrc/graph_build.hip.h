@@ -512,10 +512,12 @@ constexpr int GB_UNITS_THREADS = 1024;
 constexpr uint32_t GB_UNITS_MAX_CHUNKS = 65536;
 __device__ __forceinline__ void kb_xcd_body(uint32_t x, uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *__restrict__ info,
                                             uint32_t row_cost, uint32_t n_heavy);
+__device__ __forceinline__ void kb_xcd_wave(uint32_t x, uint32_t lane, uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *info,
+                                            uint32_t row_cost, uint32_t n_heavy);
 __global__ void __launch_bounds__(GB_UNITS_THREADS)
 kb_units_small(uint32_t n, const uint32_t *__restrict__ in_ptr_c, const uint32_t *__restrict__ hf, uint32_t *__restrict__ unit_first,
-               BuildInfo *__restrict__ info, uint32_t row_cost, uint32_t *in_ptr, uint32_t *out_ptr,
-               uint32_t *a0, uint32_t *a1, uint32_t *a2, uint32_t *a3, uint32_t *a4, uint32_t *a5) {
+               BuildInfo *info, uint32_t row_cost, uint32_t *in_ptr, uint32_t *out_ptr,
+               uint32_t *a0, uint32_t *a1, uint32_t *a2, uint32_t *a3, uint32_t *a4, uint32_t *a5, BuildInfo *host_info) {
   __shared__ uint32_t sh[GB_UNITS_THREADS];
   const uint32_t t = threadIdx.x;
   const uint32_t nb = (n + 15u) / 16u;
@@ -544,12 +546,17 @@ kb_units_small(uint32_t n, const uint32_t *__restrict__ in_ptr_c, const uint32_t
     }
   }
   if (t == 0u) info->n_heavy = nh;
-  if (t < 9u) kb_xcd_body(t, n, in_ptr_c, info, row_cost, nh);
-  if (t >= 128u && t < 192u) gb_counts_finish(info, t - 128u);
-  if (t >= 64u && t < 80u) {                                     // kb_pads (info->kept was written by kb_out_ptr, launches ago)
-    const uint32_t i = t - 64u, kept = info->kept;
+  if (t < 576u) kb_xcd_wave(t >> 6, t & 63u, n, in_ptr_c, info, row_cost, nh);      // waves 0 .. 8: one XCD bound each
+  if (t >= 640u && t < 704u) gb_counts_finish(info, t - 640u);
+  if (t >= 576u && t < 592u) {                                   // kb_pads (info->kept was written by kb_out_ptr, launches ago)
+    const uint32_t i = t - 576u, kept = info->kept;
     in_ptr[n + 1 + i] = 0; out_ptr[n + 1 + i] = 0;
     a0[kept + i] = 0; a1[kept + i] = 0; a2[kept + i] = 0; a3[kept + i] = 0; a4[kept + i] = 0; a5[kept + i] = 0;
+  }
+  if (host_info) {                                               // the summary straight into the caller's page-locked block (a copy packet less on a patch's chain)
+    __syncthreads();
+    __threadfence();
+    if (t < sizeof(BuildInfo) / 4u) ((volatile uint32_t *)host_info)[t] = ((volatile uint32_t *)info)[t];
   }
 }
 
@@ -573,6 +580,32 @@ __device__ __forceinline__ void kb_xcd_body(uint32_t x, uint32_t n, const uint32
     if (cost(mid) >= want) hi = mid; else lo = mid + 1;
   }
   info->xcd_start[x] = x == 8u ? nb : lo;
+}
+// The same bound found by a whole wave: 64 probes per round instead of one (a binary search over 6 250 chunks is 13 dependent
+// trips to the L2, ~8 us of a structural patch's chain; three rounds of 64 probes are ~2).  Smallest k in [0, nb] with
+// cost(k) >= want; cost(nb) = total >= want.
+__device__ __forceinline__ void kb_xcd_wave(uint32_t x, uint32_t lane, uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *info,
+                                            uint32_t row_cost, uint32_t n_heavy) {
+  const uint32_t nb = (n + 15u) / 16u;
+  if (n_heavy) {
+    if (lane == 0u) info->xcd_start[x] = (uint32_t)((uint64_t)(nb - n_heavy) * x / 8ull);
+    return;
+  }
+  auto cost = [&](uint32_t k) -> uint64_t { const uint32_t v = min(k * 16u, n); return (uint64_t)in_ptr[v] + (uint64_t)row_cost * v; };
+  const uint64_t total = cost(nb), want = total * x / 8ull;
+  uint32_t lo = 0, hi = nb;                        // the answer is in [lo, hi]; cost(hi) >= want
+  while (lo < hi) {
+    const uint32_t step = max((hi - lo + 62u) / 63u, 1u);                 // lanes probe lo, lo + step, ..: lane 63 reaches hi
+    const uint32_t k = min(lo + lane * step, hi);
+    const uint64_t m = __ballot(cost(k) >= want);                         // monotone: a run of lanes from the first true one (lane 63 probes hi: never empty)
+    const int f = __ffsll((unsigned long long)m) - 1;
+    const uint32_t kf = min(lo + (uint32_t)f * step, hi);
+    const uint32_t kprev = f ? min(lo + (uint32_t)(f - 1) * step, hi) : lo;
+    hi = kf;
+    lo = f ? kprev + 1u : lo;
+    if (f == 0) break;                                                      // cost(lo) >= want: lo is the answer (hi = lo)
+  }
+  if (lane == 0u) info->xcd_start[x] = x == 8u ? nb : hi;
 }
 __global__ void kb_xcd(uint32_t n, const uint32_t *__restrict__ in_ptr, BuildInfo *__restrict__ info, uint32_t row_cost) {
   if (threadIdx.x <= 8u) kb_xcd_body(threadIdx.x, n, in_ptr, info, row_cost, info->n_heavy);
@@ -800,7 +833,7 @@ __global__ void __launch_bounds__(256)
 kb_pc_resort(uint32_t n_changed, const uint32_t *__restrict__ changed, const uint32_t *__restrict__ dptr,
              const uint32_t *__restrict__ dmet, const uint32_t *__restrict__ targets, const uint32_t *__restrict__ in_ptr,
              uint32_t *__restrict__ in_src, uint32_t *__restrict__ in_w, uint32_t *__restrict__ in_fpos,
-             const uint8_t *__restrict__ vflags, uint8_t *__restrict__ rowflags, uint32_t *__restrict__ ell_so,
+             const uint8_t *__restrict__ vflags, uint8_t *__restrict__ rowflags, uint8_t *__restrict__ rowaux, uint32_t *__restrict__ ell_so,
              uint32_t *__restrict__ ell_w, uint32_t giant_deg, uint32_t wmax_old, PatchInfo *__restrict__ pinfo) {
   __shared__ uint32_t s_src[256], s_w[256], s_pos[256];
   const uint32_t t = targets[blockIdx.x], a = in_ptr[t], d = in_ptr[t + 1] - a, i = threadIdx.x;
@@ -840,6 +873,7 @@ kb_pc_resort(uint32_t n_changed, const uint32_t *__restrict__ changed, const uin
     const uint32_t was = rowflags[t];
     const uint32_t fl = (d > 16u ? RF_MANY : 0u) | (d > giant_deg ? RF_GIANT : 0u) | (any_nt ? RF_NT : 0u) | (any_zero ? RF_ZERO : 0u);
     rowflags[t] = (uint8_t)fl;
+    rowaux[t] = (uint8_t)((any_bad_new ? RA_BAD : 0u) | ((row_net && d > 0u) ? RA_NET_IN : 0u));   // (kb_rowflags; read by the next structural patch's summary)
     const int dz = (int)((fl & RF_ZERO) != 0u) - (int)((was & RF_ZERO) != 0u), db = (any_bad_new != 0) - (any_bad_old != 0);
     if (dz) atomicAdd(&pinfo->d_zero, dz);
     if (db) atomicAdd(&pinfo->d_bad, db);

@@ -36,16 +36,59 @@ constexpr uint32_t GB_ERR_PATCH = 4u;       // kb_pa_*: an affected row does not
 constexpr uint32_t PA_IN_STRIDE = 256u;     // staged kept in-links per affected row
 constexpr uint32_t PA_OUT_STRIDE = 512u;    // staged kept out-links per affected row = longest raw row this path takes
 constexpr uint32_t PA_MAX_ROWS = 2048u;     // affected rows per patch
+constexpr uint32_t PA_LDS_ROWS = 255u;      // kb_pa_shift keeps the rows' metadata in LDS up to this many affected rows
 constexpr uint32_t PA_META = 8u;            // per affected row j (arrays of na + 1 words): old in-start, old in-length, old out-start,
                                             // old out-length, new in-length, new out-length, in-shift, out-shift
+
+// The new raw CSR of a structural patch in ONE launch: kb_patch_row_ptr (row bounds, the replaced rows' flags) + kb_splice
+// (targets, costs) of graph_build.hip.h, and the zeroing of the incremental path's BuildInfo block (kb_clear) — three
+// dependent launches of a few microseconds each were a sixth of the patch's chain.  The three parts touch disjoint arrays.
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_patch_raw(uint32_t n, uint32_t e_new, const uint32_t *__restrict__ old_row_ptr, const uint32_t *__restrict__ old_col,
+             const uint32_t *__restrict__ old_metric, uint32_t n_changed, const uint32_t *__restrict__ changed, const uint32_t *__restrict__ shift,
+             const uint32_t *__restrict__ delta_ptr, const uint32_t *__restrict__ delta_col, const uint32_t *__restrict__ delta_metric,
+             uint32_t *__restrict__ new_row_ptr, uint32_t *__restrict__ new_col, uint32_t *__restrict__ new_metric, const uint8_t *__restrict__ nf,
+             uint8_t *__restrict__ vflags, uint32_t *__restrict__ clear_words, uint32_t n_clear) {
+  const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
+  if (k < n_clear) clear_words[k] = 0u;
+  for (uint32_t i = k; i < n_changed; i += gridDim.x * GB_BLOCK) vflags[changed[i]] = nf[i];
+  if (k <= n) {
+    uint32_t lo = 0, hi = n_changed;                       // replaced rows in front of row k
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (changed[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    new_row_ptr[k] = old_row_ptr[k] + shift[lo];           // modulo 2^32
+  }
+  if (k >= e_new) return;
+  uint32_t lo = 0, hi = n_changed;                         // first replaced row whose new start is behind k
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (old_row_ptr[changed[mid]] + shift[mid] <= k) lo = mid + 1; else hi = mid;
+  }
+  if (lo != 0u) {
+    const uint32_t j = lo - 1u;
+    const uint32_t off = k - (old_row_ptr[changed[j]] + shift[j]);
+    if (off < delta_ptr[j + 1] - delta_ptr[j]) {
+      new_col[k] = delta_col[delta_ptr[j] + off];
+      new_metric[k] = delta_metric[delta_ptr[j] + off];
+      return;
+    }
+  }
+  const uint32_t ko = k - shift[lo];
+  new_col[k] = old_col[ko];
+  new_metric[k] = old_metric[ko];
+}
+
+__device__ __forceinline__ void pa_scan_body(uint32_t na, uint32_t *meta, uint32_t kept_old, BuildInfo *info, uint32_t *sh);
 
 // one workgroup per affected row
 __global__ void __launch_bounds__(256)
 kb_pa_rows(uint32_t n, uint32_t na, const uint32_t *__restrict__ A, const uint32_t *__restrict__ row_ptr, const uint32_t *__restrict__ col,
            const uint32_t *__restrict__ metric, const uint8_t *__restrict__ vflags, const uint32_t *__restrict__ in_ptr,
-           const uint32_t *__restrict__ out_ptr, uint32_t *__restrict__ meta, uint32_t *__restrict__ st_in, uint32_t *__restrict__ st_out,
+           const uint32_t *__restrict__ out_ptr, uint32_t *meta, uint32_t *__restrict__ st_in, uint32_t *__restrict__ st_out,
            uint8_t *__restrict__ rowflags, uint8_t *__restrict__ rowaux, uint8_t *__restrict__ leaf, uint32_t *__restrict__ ell_so,
-           uint32_t *__restrict__ ell_w, uint32_t *__restrict__ ell_od, uint32_t giant_deg, BuildInfo *__restrict__ info) {
+           uint32_t *__restrict__ ell_w, uint32_t *__restrict__ ell_od, uint32_t giant_deg, uint32_t kept_old, uint32_t *done, BuildInfo *info) {
   __shared__ uint32_t s_col[PA_OUT_STRIDE], s_met[PA_OUT_STRIDE];            // the row's raw links; later: the ranked in-row (source, cost)
   __shared__ uint32_t s_isrc[PA_IN_STRIDE], s_iw[PA_IN_STRIDE], s_ipos[PA_IN_STRIDE];
   __shared__ uint32_t s_scan[GB_BLOCK];
@@ -84,12 +127,16 @@ kb_pa_rows(uint32_t n, uint32_t na, const uint32_t *__restrict__ A, const uint32
     const uint32_t tsrc = t | (((tf & HSPF_VF_NO_TRANSIT) && !(tf & HSPF_VF_NETWORK)) ? SRC_NO_TRANSIT : 0u);   // (kb_scatter)
     const uint32_t tb0 = row_ptr[t], tb1 = row_ptr[t + 1];
     bool two = false;
-    for (uint32_t k2 = tb0; k2 < tb1; ++k2) {
-      if (col[k2] != a) continue;
-      two = true;
-      if (!collect) break;
-      const uint32_t slot = atomicAdd(&s_cnt, 1u);
-      if (slot < PA_IN_STRIDE) { s_isrc[slot] = tsrc; s_iw[slot] = metric[k2]; s_ipos[slot] = k2 - tb0; }
+    for (uint32_t k2 = tb0; k2 < tb1 && !(two && !collect); k2 += 4u) {       // four entries per step: one wait per four loads (kb_links)
+      const uint32_t c[4] = {col[k2], k2 + 1u < tb1 ? col[k2 + 1u] : INF, k2 + 2u < tb1 ? col[k2 + 2u] : INF, k2 + 3u < tb1 ? col[k2 + 3u] : INF};
+#pragma unroll
+      for (uint32_t x = 0; x < 4u; ++x) {                                        // (a < n <= 2^24: INF never matches)
+        if (c[x] != a) continue;
+        two = true;
+        if (!collect) continue;
+        const uint32_t slot = atomicAdd(&s_cnt, 1u);
+        if (slot < PA_IN_STRIDE) { s_isrc[slot] = tsrc; s_iw[slot] = metric[k2 + x]; s_ipos[slot] = k2 + x - tb0; }
+      }
     }
     kp[q] = two && expand_a;
   }
@@ -136,7 +183,9 @@ kb_pa_rows(uint32_t n, uint32_t na, const uint32_t *__restrict__ A, const uint32
   if (tid == 0) {
     rowflags[a] = (uint8_t)((d > 16u ? RF_MANY : 0u) | (d > giant_deg ? RF_GIANT : 0u) | (any_nt ? RF_NT : 0u) | (any_zero ? RF_ZERO : 0u));
     rowaux[a] = (uint8_t)((any_bad ? RA_BAD : 0u) | ((row_net && d > 0u) ? RA_NET_IN : 0u));
-    leaf[a] = (d == 1u && (total_out == 0u || (total_out == 1u && s_odst[0] == (s_col[0] & SRC_MASK)))) ? 1u : 0u;   // (kb_leaf_mark)
+    const uint8_t lf = (d == 1u && (total_out == 0u || (total_out == 1u && s_odst[0] == (s_col[0] & SRC_MASK)))) ? 1u : 0u;   // (kb_leaf_mark)
+    if (leaf[a] != lf) atomicAdd(&info->n_leaf, 1u);             // a flipped mark: kb_pa_shift refreshes SRC_LEAF on every in-link
+    leaf[a] = lf;
     meta[4u * na1 + j] = d; meta[5u * na1 + j] = total_out;
   }
   // ---- the ELL record (kb_ell)
@@ -147,18 +196,29 @@ kb_pa_rows(uint32_t n, uint32_t na, const uint32_t *__restrict__ A, const uint32
     if (tid == 0u) eso |= (d <= 16u ? d : 0x1Fu) | (total_out > 16u ? 0x20u : 0u) | (row_net ? 0x80u : 0u);
     ell_so[(size_t)a * 16u + tid] = eso; ell_w[(size_t)a * 16u + tid] = ew; ell_od[(size_t)a * 16u + tid] = eod;
   }
+  // ---- the workgroup that finishes last turns the rows' length changes into shifts (no wait: the canonical "last block"
+  // hand-over — every workgroup publishes its metadata, fences at agent scope and counts itself; whoever counts na - 1 others
+  // fences again and reads them all)
+  __shared__ uint32_t s_last;
+  __syncthreads();                                             // thread 0's metadata stores are issued
+  if (tid == 0) {
+    __threadfence();
+    s_last = (atomicAdd(done, 1u) == na - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  pa_scan_body(na, meta, kept_old, info, s_scan);
 }
 
 // one workgroup: the rows' length changes -> shifts (exclusive prefix sums, modulo 2^32), the new number of kept links
-__global__ void __launch_bounds__(GB_BLOCK)
-kb_pa_scan(uint32_t na, uint32_t *__restrict__ meta, uint32_t kept_old, BuildInfo *__restrict__ info) {
-  __shared__ uint32_t sh[GB_BLOCK];
+__device__ __forceinline__ void pa_scan_body(uint32_t na, uint32_t *meta, uint32_t kept_old, BuildInfo *info, uint32_t *sh) {
   const uint32_t na1 = na + 1u, tid = threadIdx.x;
   const uint32_t ipt = (na + GB_BLOCK - 1u) / GB_BLOCK;                       // <= PA_MAX_ROWS / 256
   const uint32_t j0 = min(tid * ipt, na), j1 = min(j0 + ipt, na);
   uint32_t tot[2];
   for (uint32_t which = 0; which < 2u; ++which) {
-    const uint32_t *oldl = meta + (1u + 2u * which) * na1, *newl = meta + (4u + which) * na1;
+    const volatile uint32_t *oldl = meta + (1u + 2u * which) * na1, *newl = meta + (4u + which) * na1;
     uint32_t *shift = meta + (6u + which) * na1;
     uint32_t s = 0u;
     for (uint32_t j = j0; j < j1; ++j) s += newl[j] - oldl[j];
@@ -173,6 +233,11 @@ kb_pa_scan(uint32_t na, uint32_t *__restrict__ meta, uint32_t kept_old, BuildInf
     info->kept = kept_old + tot[0];
     if (tot[0] != tot[1]) atomicOr(&info->err, GB_ERR_PATCH);              // every kept link is in one in-row and one out-row
   }
+}
+__global__ void __launch_bounds__(GB_BLOCK)
+kb_pa_scan(uint32_t na, uint32_t *meta, uint32_t kept_old, BuildInfo *info) {
+  __shared__ uint32_t sh[GB_BLOCK];
+  pa_scan_body(na, meta, kept_old, info, sh);
 }
 
 // Entry k of a shifted array: from the staging area when it lies in an affected row, else the old entry k - (length changes
@@ -194,7 +259,7 @@ __device__ __forceinline__ PaWhere pa_locate(uint32_t k, uint32_t na, const uint
 }
 
 __global__ void __launch_bounds__(GB_BLOCK)
-kb_pa_shift(uint32_t n, uint32_t na, const uint32_t *__restrict__ A, const uint32_t *__restrict__ meta, const uint32_t *__restrict__ st_in,
+kb_pa_shift(uint32_t n, uint32_t na, const uint32_t *__restrict__ A, const uint32_t *meta, const uint32_t *__restrict__ st_in,
             const uint32_t *__restrict__ st_out, const uint32_t *__restrict__ o_in_src, const uint32_t *__restrict__ o_in_w,
             const uint32_t *__restrict__ o_in_fpos, const uint32_t *__restrict__ o_out_dst, const uint32_t *__restrict__ o_out_w,
             const uint32_t *__restrict__ o_out_fpos, uint32_t *__restrict__ n_in_src, uint32_t *__restrict__ n_in_w,
@@ -203,7 +268,16 @@ kb_pa_shift(uint32_t n, uint32_t na, const uint32_t *__restrict__ A, const uint3
   if (*(volatile uint32_t *)&info->err & GB_ERR_PATCH) return;            // (block-uniform: written by earlier launches)
   const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
   const uint32_t na1 = na + 1u, kept = info->kept;
+  // the tables of the searches in LDS when they fit (a patch of a few rows has a few dozen affected rows): a search is then
+  // ~5 LDS reads instead of ~5 dependent trips to the L2, twice per thread
+  __shared__ uint32_t s_meta[PA_META * (PA_LDS_ROWS + 1u)];
+  if (na <= PA_LDS_ROWS) {
+    for (uint32_t i = threadIdx.x; i < PA_META * na1; i += GB_BLOCK) s_meta[i] = meta[i];
+    __syncthreads();
+    meta = s_meta;
+  }
   uint32_t wmax = 0u;
+  const bool leaf_flips = info->n_leaf != 0u;                    // (kb_pa_rows counts the flipped marks there; kb_pa_summary sets the real count later)
   if (k < kept) {
     {
       const PaWhere p = pa_locate(k, na, meta, meta + 4u * na1, meta + 6u * na1);
@@ -214,7 +288,9 @@ kb_pa_shift(uint32_t n, uint32_t na, const uint32_t *__restrict__ A, const uint3
       } else {
         s = o_in_src[p.old_k]; w = o_in_w[p.old_k]; f = o_in_fpos[p.old_k];
       }
-      s = (s & ~SRC_LEAF) | (leaf[s & SRC_MASK] ? SRC_LEAF : 0u);                  // (kb_leaf_links, from the marks kb_pa_rows left)
+      // SRC_LEAF (kb_leaf_links) from the marks kb_pa_rows left: staged entries carry none yet; the others keep theirs unless
+      // some affected row's mark flipped (then every in-link looks its source up: a random byte per link, rarely needed)
+      if (p.staged || leaf_flips) s = (s & ~SRC_LEAF) | (leaf[s & SRC_MASK] ? SRC_LEAF : 0u);
       n_in_src[k] = s; n_in_w[k] = w; n_in_fpos[k] = f;
     }
     {

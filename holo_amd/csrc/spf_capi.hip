@@ -57,10 +57,41 @@ struct hspf_graph {
     for (int x = 0; x < 8; ++x) m = std::max(m, xcd_start[x + 1] - xcd_start[x] + xcd_heavy(x + 1) - xcd_heavy(x));
     return 8u * std::max(m, 1u);
   }
-  // host mirrors: slot tables walk the root's neighbourhood on the host
-  std::vector<uint32_t> row_ptr, col;
-  std::vector<uint8_t> twoway;     // per original link (computed on device, copied back)
+  // host mirrors: slot tables walk the root's neighbourhood on the host.  Row v of the caller's CSR = the pool entries
+  // [rstart[v], rstart[v] + rlen[v]) of `col` / `twoway`.  An upload lays the rows out back to back; a structural patch
+  // rewrites a replaced row where it is when it does not grow and appends it to the pool otherwise — O(row), where the
+  // compact mirror of rounds 3-5 moved on average half of its 5 MB per one-row patch (0.02-0.17 ms at a million links: more
+  // than the device side of the patch takes since round 6).  The pool is compacted when half of it is dead.
+  std::vector<uint32_t> rstart, rlen, col;
+  std::vector<uint8_t> twoway;     // per pool entry: 1 = the target's row lists the source (computed on device, copied back; kept by patches)
   std::vector<uint8_t> vflags;
+  size_t pool_dead = 0;            // pool entries that belong to no row
+  bool pool_packed = true;         // the rows lie back to back in vertex order (as after an upload)
+  uint32_t rb(uint32_t v) const { return rstart[v]; }
+  uint32_t re(uint32_t v) const { return rstart[v] + rlen[v]; }
+  bool pool_compact() const { return pool_packed; }
+  void mirror_bounds(const uint32_t *row_ptr) {                  // rows back to back, as the caller's CSR has them
+    rstart.assign(row_ptr, row_ptr + n); rlen.resize(n);
+    for (uint32_t v = 0; v < n; ++v) rlen[v] = row_ptr[v + 1] - row_ptr[v];
+    pool_dead = 0; pool_packed = true;
+  }
+  void mirror_compact() {                                       // O(links): rows back to back again, in vertex order
+    if (pool_compact()) return;
+    std::vector<uint32_t> c2((size_t)e);
+    std::vector<uint8_t> t2(twoway.size() == col.size() ? (size_t)e : 0);
+    size_t o = 0;
+    for (uint32_t v = 0; v < n; ++v) {
+      if (rlen[v]) {
+        memcpy(c2.data() + o, col.data() + rstart[v], (size_t)rlen[v] * 4);
+        if (!t2.empty()) memcpy(t2.data() + o, twoway.data() + rstart[v], rlen[v]);
+      }
+      rstart[v] = (uint32_t)o; o += rlen[v];
+    }
+    const bool had_tw = twoway.size() == col.size();
+    col.swap(c2);
+    if (had_tw) twoway.swap(t2); else twoway.clear();
+    pool_dead = 0; pool_packed = true;
+  }
   // device: one allocation, carved by layout()
   char *arena = nullptr;
   size_t arena_bytes = 0;
@@ -89,7 +120,7 @@ struct hspf_graph {
   void host_summary_full() {
     max_out = 0; n_net = 0; heavy_links = 0;
     for (uint32_t v = 0; v < n; ++v) {
-      const uint32_t d = row_ptr[v + 1] - row_ptr[v];
+      const uint32_t d = rlen[v];
       max_out = std::max(max_out, d);
       if (d > 32u) heavy_links += d;
       if (vflags[v] & HSPF_VF_NETWORK) ++n_net;
@@ -358,16 +389,16 @@ void build_slot_table(const hspf_graph *g, uint32_t root, std::vector<uint32_t> 
                       uint32_t stamp) {
   hv.clear(); hb.clear();
   hv.push_back(root); hb.push_back(0);
-  total = g->row_ptr[root + 1] - g->row_ptr[root];
+  total = g->rlen[root];
   mark[root] = stamp;
   for (size_t qi = 0; qi < hv.size(); ++qi) {
     const uint32_t p = hv[qi];
-    for (uint32_t k = g->row_ptr[p]; k < g->row_ptr[p + 1]; ++k) {
+    for (uint32_t k = g->rb(p); k < g->re(p); ++k) {
       const uint32_t t = g->col[k];
       if (!g->twoway[k] || !(g->vflags[t] & HSPF_VF_NETWORK) || mark[t] == stamp) continue;
       mark[t] = stamp;
       hv.push_back(t); hb.push_back(total);
-      total += g->row_ptr[t + 1] - g->row_ptr[t];
+      total += g->rlen[t];
     }
   }
 }
@@ -545,7 +576,7 @@ int build_launch(hspf_ctx *ctx, hspf_graph *g, bool hub, BuildScratch &bs) {
     const uint32_t nb = (n + 15u) / 16u;
     hipLaunchKernelGGL(kb_unit_count, dim3((nb + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, in_cnt, ctx->unit_heavy_deg);
     hipLaunchKernelGGL(kb_units_small, dim3(1), dim3(GB_UNITS_THREADS), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)in_cnt, g->d_unit_first, info,
-                       ctx->xcd_row_cost, g->d_in_ptr, g->d_out_ptr, g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos);
+                       ctx->xcd_row_cost, g->d_in_ptr, g->d_out_ptr, g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos, (BuildInfo *)nullptr);
   } else {
     // work units: heavy flag per chunk -> heavy chunks before each chunk -> unit_first (scratch: in_cnt, n + 17 words, is
     // free again and holds both: nb flags, then nb + 1 positions)
@@ -579,6 +610,7 @@ int build_finish(hspf_ctx *ctx, hspf_graph *g, bool hub, const BuildScratch &bs,
     t_prev = t;
   };
   if (fetch_twoway) {
+    g->mirror_compact();             // the device's flags are in row order: the pool must be too (an upload's is; a patch beyond the host's own flag keeping)
     g->twoway.resize(e);
     if (e) HIPCHK(ctx, hipMemcpyAsync(g->twoway.data(), bs.twoway, e, hipMemcpyDeviceToHost, s));
   }
@@ -648,24 +680,27 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
 // ones (kb_patch_row_ptr / kb_splice are enqueued); d_aff = the affected rows, ascending, on the device.
 constexpr int HSPF_RETRY_REBUILD = 1001;    // patch_finish -> graph_patch_impl only
 
+size_t patch_scratch_words(const hspf_graph *g, uint32_t na) {
+  const size_t nb = (g->n + 15u) / 16u;
+  return (32u + GB_SC_WORDS) + (nb + 16) + (size_t)PA_META * (na + 1u) + (size_t)na * 3u * (PA_IN_STRIDE + PA_OUT_STRIDE) + 64;
+}
+int patch_prepare(hspf_ctx *ctx, hspf_graph *g, uint32_t na) { return ensure(ctx, ctx->gb_pa, patch_scratch_words(g, na) * 4, false); }
+
 int patch_launch(hspf_ctx *ctx, hspf_graph *g, uint32_t na, const uint32_t *d_aff) {
   const uint32_t n = g->n, nb = (n + 15u) / 16u;
   hipStream_t s = ctx->stream;
   const size_t n_info = 32u + GB_SC_WORDS;
-  const size_t words = n_info + ((size_t)nb + 16) + (size_t)PA_META * (na + 1u) + (size_t)na * 3u * (PA_IN_STRIDE + PA_OUT_STRIDE) + 64;
-  int rc = ensure(ctx, ctx->gb_pa, words * 4, false);
-  if (rc != HSPF_OK) return rc;
-  uint32_t *w = (uint32_t *)ctx->gb_pa.p;
+  uint32_t *w = (uint32_t *)ctx->gb_pa.p;                        // (patch_prepare; BuildInfo + spread counters zeroed by kb_patch_raw)
   BuildInfo *info = (BuildInfo *)w; w += n_info;
+  uint32_t *done = (uint32_t *)info + 24;                        // a free word of BuildInfo's 32-word slot: kb_pa_rows' count of finished workgroups
+  static_assert(sizeof(BuildInfo) <= 24 * 4, "BuildInfo reaches the patch's counter");
   uint32_t *hf = w; w += (size_t)nb + 16;
   uint32_t *meta = w; w += (size_t)PA_META * (na + 1u);
   uint32_t *st_in = w; w += (size_t)na * 3u * PA_IN_STRIDE;
   uint32_t *st_out = w;
   const uint32_t *row_ptr = g->d_row_ptr[g->cur], *col = g->d_col[g->cur], *metric = g->d_metric[g->cur];
-  hipLaunchKernelGGL(kb_clear, dim3((uint32_t)((n_info + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, hf, 0u, (uint32_t *)info, (uint32_t)n_info);
   hipLaunchKernelGGL(kb_pa_rows, dim3(na), dim3(256), 0, s, n, na, d_aff, row_ptr, col, metric, (const uint8_t *)g->d_vflags, (const uint32_t *)g->d_in_ptr,
-                     (const uint32_t *)g->d_out_ptr, meta, st_in, st_out, g->d_rowflags, g->d_rowaux, g->d_leaf, g->d_ell_so, g->d_ell_w, g->d_ell_od, GIANT_DEG, info);
-  hipLaunchKernelGGL(kb_pa_scan, dim3(1), dim3(GB_BLOCK), 0, s, na, meta, g->e_kept, info);
+                     (const uint32_t *)g->d_out_ptr, meta, st_in, st_out, g->d_rowflags, g->d_rowaux, g->d_leaf, g->d_ell_so, g->d_ell_w, g->d_ell_od, GIANT_DEG, g->e_kept, done, info);
   // the new number of kept links is the device's to know; the grid covers the most it can be
   const uint64_t bound = std::max<uint64_t>((uint64_t)n + 1u, std::min<uint64_t>((uint64_t)g->e_kept + (uint64_t)na * PA_IN_STRIDE, (uint64_t)g->e));
   hipLaunchKernelGGL(kb_pa_shift, dim3((uint32_t)((bound + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, n, na, d_aff, (const uint32_t *)meta, (const uint32_t *)st_in,
@@ -676,9 +711,8 @@ int patch_launch(hspf_ctx *ctx, hspf_graph *g, uint32_t na, const uint32_t *d_af
   hipLaunchKernelGGL(kb_pa_summary, dim3((n + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint8_t *)g->d_rowflags,
                      (const uint8_t *)g->d_rowaux, (const uint8_t *)g->d_leaf, hf, ctx->unit_heavy_deg, info);
   hipLaunchKernelGGL(kb_units_small, dim3(1), dim3(GB_UNITS_THREADS), 0, s, n, (const uint32_t *)g->d_in_ptr, (const uint32_t *)hf, g->d_unit_first, info,
-                     ctx->xcd_row_cost, g->d_in_ptr, g->d_out_ptr, g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos);
+                     ctx->xcd_row_cost, g->d_in_ptr, g->d_out_ptr, g->d_in_src, g->d_in_w, g->d_in_fpos, g->d_out_dst, g->d_out_w, g->d_out_fpos, ctx->h_info);
   HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_info, info, sizeof(BuildInfo), hipMemcpyDeviceToHost, s));
   return HSPF_OK;
 }
 
@@ -885,7 +919,7 @@ int hspf_graph_upload(hspf_ctx *ctx, const hspf_csr *csr, hspf_graph **out) {
   lap("H2D");
   try {
     // host mirrors for the slot tables (hspf_slot_table walks the root's neighbourhood on the host)
-    g->row_ptr.assign(csr->row_ptr, csr->row_ptr + n + 1);
+    g->mirror_bounds(csr->row_ptr);
     g->col.assign(csr->col, csr->col + e);
     g->vflags.assign(csr->vflags, csr->vflags + n);
     g->twoway.resize(e);
@@ -959,16 +993,18 @@ int hspf_graph_upload_keyed(hspf_ctx *ctx, const hspf_keyed_lsdb *k, hspf_graph 
     hipLaunchKernelGGL(kb_kx_scatter, dim3((uint32_t)(((size_t)n * 16 + GB_BLOCK - 1) / GB_BLOCK)), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)rank, (const uint32_t *)vrow,
                        (const uint32_t *)keep, (const uint32_t *)kpre, (const uint32_t *)tidx, (const uint32_t *)tm, (const uint32_t *)g->d_row_ptr[0], g->d_col[0], g->d_metric[0]);
     // the host mirrors (slot tables walk the root's neighbourhood on the host): row bounds, targets, flags come back
-    g->row_ptr.resize((size_t)n + 1); g->col.resize(m); g->vflags.resize(n);
+    std::vector<uint32_t> h_rp((size_t)n + 1);
+    g->col.resize(m); g->vflags.resize(n);
     uint32_t h_err = 0;
-    HIPCHK(ctx, hipMemcpyAsync(g->row_ptr.data(), g->d_row_ptr[0], ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(h_rp.data(), g->d_row_ptr[0], ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, s));
     if (m) HIPCHK(ctx, hipMemcpyAsync(g->col.data(), g->d_col[0], (size_t)m * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(g->vflags.data(), g->d_vflags, n, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipMemcpyAsync(&h_err, err, 4, hipMemcpyDeviceToHost, s));
     if (rank_out) HIPCHK(ctx, hipMemcpyAsync(rank_out, rank, (size_t)n * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
     if (h_err) { ctx->last_error = "hspf_graph_upload_keyed: a vertex key occurs twice"; return fail(HSPF_E_INVAL); }
-    g->e = g->row_ptr[n];
+    g->e = h_rp[n];
+    g->mirror_bounds(h_rp.data());
     g->col.resize(g->e);
     g->twoway.resize(g->e);
     rc = build_on_device(ctx, g);
@@ -1019,7 +1055,7 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
   if (g->max_in_deg <= 256u && g->n_giant == 0) {
     bool same = true;
     for (uint32_t j = 0; j < m && same; ++j) {
-      const uint32_t v = rows->vertex[j], a = g->row_ptr[v], len = g->row_ptr[v + 1] - a;
+      const uint32_t v = rows->vertex[j], a = g->rb(v), len = g->rlen[v];
       same = rows->row_ptr[j + 1] - rows->row_ptr[j] == len && rows->vflags[j] == g->vflags[v] &&
              (len == 0 || memcmp(rows->col + rows->row_ptr[j], &g->col[a], (size_t)len * 4) == 0);
     }
@@ -1058,7 +1094,7 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
                            g->d_metric[g->cur], (const uint32_t *)g->d_out_ptr, g->d_out_w, (const uint32_t *)g->d_out_fpos);
         if (nt)
           hipLaunchKernelGGL(kb_pc_resort, dim3(nt), dim3(256), 0, s, m, d_changed, d_dptr, d_dmet, d_tg, (const uint32_t *)g->d_in_ptr,
-                             g->d_in_src, g->d_in_w, g->d_in_fpos, (const uint8_t *)g->d_vflags, g->d_rowflags, g->d_ell_so, g->d_ell_w,
+                             g->d_in_src, g->d_in_w, g->d_in_fpos, (const uint8_t *)g->d_vflags, g->d_rowflags, g->d_rowaux, g->d_ell_so, g->d_ell_w,
                              GIANT_DEG, g->wmax, d_pi);
         HIPCHK(ctx, hipMemcpyAsync(h, d_pi, sizeof(PatchInfo), hipMemcpyDeviceToHost, s));
         HIPCHK(ctx, hipStreamSynchronize(s));
@@ -1105,7 +1141,7 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
   bool max_row_shrinks = false;
   for (uint32_t j = 0; j < m; ++j) {
     const uint32_t v = rows->vertex[j];
-    const uint32_t nl = rows->row_ptr[j + 1] - rows->row_ptr[j], ol = g->row_ptr[v + 1] - g->row_ptr[v];
+    const uint32_t nl = rows->row_ptr[j + 1] - rows->row_ptr[j], ol = g->rlen[v];
     e_new64 += (uint64_t)nl;
     e_new64 -= (uint64_t)ol;
     new_max_len = std::max(new_max_len, nl);
@@ -1143,14 +1179,14 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
   uint64_t tw_work = 0;
   for (uint32_t j = 0; j < m; ++j) {
     const uint32_t v = rows->vertex[j];
-    for (uint32_t k = rows->row_ptr[j]; k < rows->row_ptr[j + 1]; ++k) { const uint32_t t = rows->col[k]; tw_work += g->row_ptr[t + 1] - g->row_ptr[t] + 1u; }
-    for (uint32_t k = g->row_ptr[v]; k < g->row_ptr[v + 1]; ++k) { const uint32_t t = g->col[k]; tw_work += g->row_ptr[t + 1] - g->row_ptr[t] + 1u; }
+    for (uint32_t k = rows->row_ptr[j]; k < rows->row_ptr[j + 1]; ++k) { const uint32_t t = rows->col[k]; tw_work += g->rlen[t] + 1u; }
+    for (uint32_t k = g->rb(v); k < g->re(v); ++k) { const uint32_t t = g->col[k]; tw_work += g->rlen[t] + 1u; }
   }
   tw_work += 2ull * de;                                       // rows of replaced targets are read at their new length
   // (a scanned entry costs ~5 ns, a byte of flags over the bus ~0.1 ns + a fixed ~20 us: the patch keeps the flags itself
   // while that is the cheaper side — every ordinary LSP; a replaced hub row of 100 000 links is not)
   const uint64_t tw_bound = ctx->tw_host_max == UINT64_MAX ? std::max<uint64_t>(4096u, e_new / 32u) : ctx->tw_host_max;
-  const bool tw_host = tw_work <= tw_bound && g->twoway.size() == g->e;
+  const bool tw_host = tw_work <= tw_bound && g->twoway.size() == g->col.size();
   // ---- the incremental path (graph_patch.hip.h): affected rows = replaced rows + their old and new targets
   std::vector<uint32_t> &aff = ctx->patch_aff;
   aff.clear();
@@ -1161,11 +1197,11 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
     aff.insert(aff.end(), rows->col, rows->col + de);
     for (uint32_t j = 0; j < m && aff.size() <= 8u * PA_MAX_ROWS; ++j) {
       const uint32_t v = rows->vertex[j];
-      aff.insert(aff.end(), g->col.begin() + g->row_ptr[v], g->col.begin() + g->row_ptr[v + 1]);
+      aff.insert(aff.end(), g->col.begin() + g->rb(v), g->col.begin() + g->re(v));
     }
     std::sort(aff.begin(), aff.end());
     aff.erase(std::unique(aff.begin(), aff.end()), aff.end());
-    incremental = aff.size() <= PA_MAX_ROWS;
+    incremental = aff.size() <= PA_MAX_ROWS && patch_prepare(ctx, g, (uint32_t)aff.size()) == HSPF_OK;   // (no room for the scratch: the rebuild)
   }
   const uint32_t na = incremental ? (uint32_t)aff.size() : 0u;
   // the delta, one pinned staging block, one copy: changed[m] | delta_ptr[m+1] | shift[m+1] | delta_col[de] | delta_metric[de] | flags[m] (bytes) | affected[na]
@@ -1188,7 +1224,7 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
     for (uint32_t j = 0; j < m; ++j) {
       sh[j] = acc;
       const uint32_t v = rows->vertex[j];
-      acc += (rows->row_ptr[j + 1] - rows->row_ptr[j]) - (g->row_ptr[v + 1] - g->row_ptr[v]);
+      acc += (rows->row_ptr[j + 1] - rows->row_ptr[j]) - g->rlen[v];
     }
     sh[m] = acc;
     if (de) {
@@ -1205,13 +1241,16 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
   const int nxt = g->cur ^ 1;
   committed = true;                                            // kb_patch_row_ptr rewrites the vertex flags in place; the mirrors follow
   HIPCHK(ctx, hipMemcpyAsync(d_changed, ctx->h_patch, dwords * 4, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(kb_patch_row_ptr, dim3((n + 1 + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, (const uint32_t *)g->d_row_ptr[g->cur], m,
-                     (const uint32_t *)d_changed, (const uint32_t *)d_shift, g->d_row_ptr[nxt], (const uint8_t *)d_nf, g->d_vflags);
-  if (e_new)
-    hipLaunchKernelGGL(kb_splice, dim3((e_new + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, e_new,
-                       (const uint32_t *)g->d_row_ptr[g->cur], (const uint32_t *)g->d_col[g->cur], (const uint32_t *)g->d_metric[g->cur], m,
-                       (const uint32_t *)d_changed, (const uint32_t *)d_shift, (const uint32_t *)d_dptr, (const uint32_t *)d_dcol,
-                       (const uint32_t *)d_dmet, g->d_col[nxt], g->d_metric[nxt]);
+  {
+    // the incremental path's BuildInfo block is zeroed by the same launch (patch_prepare made room for it)
+    uint32_t *clr = nullptr; uint32_t n_clr = 0;
+    if (incremental) { clr = (uint32_t *)ctx->gb_pa.p; n_clr = 32u + GB_SC_WORDS; }
+    const uint32_t span = std::max(std::max(n + 1u, e_new), n_clr);
+    hipLaunchKernelGGL(kb_patch_raw, dim3((span + GB_BLOCK - 1) / GB_BLOCK), dim3(GB_BLOCK), 0, s, n, e_new, (const uint32_t *)g->d_row_ptr[g->cur],
+                       (const uint32_t *)g->d_col[g->cur], (const uint32_t *)g->d_metric[g->cur], m, (const uint32_t *)d_changed, (const uint32_t *)d_shift,
+                       (const uint32_t *)d_dptr, (const uint32_t *)d_dcol, (const uint32_t *)d_dmet, g->d_row_ptr[nxt], g->d_col[nxt], g->d_metric[nxt],
+                       (const uint8_t *)d_nf, g->d_vflags, clr, n_clr);
+  }
   // the summary of the caller's rows, from the replaced rows alone (the longest row is looked for again only when it
   // was one of them and got shorter)
   const uint32_t e_old = g->e;
@@ -1221,7 +1260,7 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
     uint32_t j = 0;
     for (uint32_t v = 0; v < n; ++v) {
       if (j < m && rows->vertex[j] == v) { ++j; continue; }
-      max_out_new = std::max(max_out_new, g->row_ptr[v + 1] - g->row_ptr[v]);
+      max_out_new = std::max(max_out_new, g->rlen[v]);
     }
   }
   g->cur = nxt;
@@ -1235,87 +1274,75 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
     return rc;
   }
   lap("staging + launches");
-  // ---- behind the kernels: the host mirrors.  Rows between two replaced ones keep their contents and stay contiguous,
-  // so each such run is one memcpy.
+  // ---- behind the kernels: the host mirrors.  A replaced row is rewritten where it is when it does not grow, else appended
+  // to the pool (hspf_graph::rstart / rlen): O(replaced rows), no block move.
   // Two-way flags of the mirror: a link u -> t is two-way when row t lists u.  Replacing row u changes the flags of u's
   // own links and of the links t -> u in the rows of its old and new targets, nothing else.  Long rows would make the
   // membership scans quadratic, so beyond a work bound the flags come back from the device as after an upload.
-  // In place: the runs of unchanged rows between two replaced ones move by the length changes in front of them — the runs
-  // that move towards the front first, front to back, then those that move towards the back, back to front (a run's new
-  // place never reaches into a run that has not moved yet: the order of the runs is the same before and after) — then the
-  // new rows are written into the gaps and the row bounds shifted.  Nothing is allocated or copied that does not move: a
-  // one-row patch moves on average half of the mirror once (a fresh copy of all of it was 0.19 ms at a million links).
-  std::vector<uint32_t> old_targets;
-  std::vector<int64_t> sh;                                    // sh[j]: length change of the first j replaced rows
+  std::vector<uint32_t> old_targets, old_len;
   uint64_t heavy_new = g->heavy_links;
   uint32_t n_net_new = g->n_net;
   try {
-    sh.resize((size_t)m + 1);
-    sh[0] = 0;
+    size_t grow = 0;
+    old_len.resize(m);
     for (uint32_t j = 0; j < m; ++j) {
       const uint32_t u = rows->vertex[j];
-      const uint32_t len = rows->row_ptr[j + 1] - rows->row_ptr[j], ol = g->row_ptr[u + 1] - g->row_ptr[u];
-      sh[j + 1] = sh[j] + (int64_t)len - (int64_t)ol;
+      const uint32_t len = rows->row_ptr[j + 1] - rows->row_ptr[j], ol = g->rlen[u];
+      old_len[j] = ol;
+      if (len > ol) grow += len;
       if (ol > 32u) heavy_new -= ol;
       if (len > 32u) heavy_new += len;
       if (g->vflags[u] & HSPF_VF_NETWORK) --n_net_new;
       if (rows->vflags[j] & HSPF_VF_NETWORK) ++n_net_new;
-      if (tw_host) old_targets.insert(old_targets.end(), g->col.begin() + g->row_ptr[u], g->col.begin() + g->row_ptr[u + 1]);
+      if (tw_host) old_targets.insert(old_targets.end(), g->col.begin() + g->rb(u), g->col.begin() + g->re(u));
     }
-    const uint32_t e_max = std::max(e_old, e_new);
-    g->col.resize(e_max);
-    if (tw_host) g->twoway.resize(e_max);
+    const bool had_tw = g->twoway.size() == g->col.size();
+    if (g->col.size() + grow > g->col.capacity()) g->col.reserve(g->col.size() + grow + g->col.size() / 8);
+    if (had_tw && g->col.size() + grow > g->twoway.capacity()) g->twoway.reserve(g->col.size() + grow + g->col.size() / 8);
+    if (g->col.size() + grow >= (1ull << 32)) throw std::bad_alloc();
   } catch (const std::bad_alloc &) {
     (void)hipStreamSynchronize(s);
-    g->col.resize(e_old);                                     // (shrinking does not allocate)
-    if (g->twoway.size() > e_old) g->twoway.resize(e_old);
     g->cur = nxt ^ 1; g->e = e_old;
+    if (incremental) g->swap_link_sets();                     // (patch_launch had swapped the sets; the kernels' output is dropped)
     return HSPF_E_NOMEM;
   }
   {
-    uint32_t *col = g->col.data();
-    uint8_t *tw = tw_host ? g->twoway.data() : nullptr;
-    const uint32_t *orp = g->row_ptr.data();                  // old bounds (shifted at the end)
-    auto run_begin = [&](uint32_t i) { return i == 0 ? 0u : orp[rows->vertex[i - 1] + 1]; };   // run i: the unchanged rows in front of replaced row i
-    auto run_end = [&](uint32_t i) { return i == m ? e_old : orp[rows->vertex[i]]; };
-    auto move_run = [&](uint32_t i) {
-      const uint32_t a0 = run_begin(i), b0 = run_end(i);
-      if (b0 == a0) return;
-      memmove(col + ((int64_t)a0 + sh[i]), col + a0, (size_t)(b0 - a0) * 4);
-      if (tw) memmove(tw + ((int64_t)a0 + sh[i]), tw + a0, (size_t)(b0 - a0));
-    };
-    for (uint32_t i = 0; i <= m; ++i) if (sh[i] < 0) move_run(i);
-    for (uint32_t i = m + 1; i-- > 0;) if (sh[i] > 0) move_run(i);
-    for (uint32_t j = 0; j < m; ++j) {                         // the new rows, into the gaps
-      const uint32_t len = rows->row_ptr[j + 1] - rows->row_ptr[j];
-      if (len) memcpy(col + ((int64_t)orp[rows->vertex[j]] + sh[j]), rows->col + rows->row_ptr[j], (size_t)len * 4);
+    // (nothing below allocates: the pool's growth was reserved above)
+    const bool keep_tw = g->twoway.size() == g->col.size();
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint32_t u = rows->vertex[j];
+      const uint32_t len = rows->row_ptr[j + 1] - rows->row_ptr[j], ol = g->rlen[u];
+      if (len != ol) g->pool_packed = false;
+      if (len > ol) {
+        g->pool_dead += ol;
+        g->rstart[u] = (uint32_t)g->col.size();
+        g->col.insert(g->col.end(), rows->col + rows->row_ptr[j], rows->col + rows->row_ptr[j] + len);
+        if (keep_tw) g->twoway.resize(g->col.size());
+      } else {
+        g->pool_dead += ol - len;
+        if (len) memcpy(g->col.data() + g->rstart[u], rows->col + rows->row_ptr[j], (size_t)len * 4);
+      }
+      g->rlen[u] = len;
     }
-    uint32_t j = 0;                                            // the bounds: row v moves by the changes of the replaced rows in front of it
-    for (uint32_t v = rows->vertex[0] + 1; v <= n; ++v) {
-      while (j < m && rows->vertex[j] < v) ++j;
-      g->row_ptr[v] = (uint32_t)((int64_t)g->row_ptr[v] + sh[j]);
-    }
-    g->col.resize(e_new);
-    if (tw_host) g->twoway.resize(e_new);
+    if (!keep_tw) g->twoway.clear();
     if (tw_host) {
       // per replaced row u: its own links, then the links t -> u of its old and new targets (old_targets holds the old
       // rows back to back, in the order of rows->vertex)
-      const uint32_t *nrp = g->row_ptr.data();
       const uint32_t *ncol = g->col.data();
       uint8_t *ntw = g->twoway.data();
       size_t ot = 0;
       std::vector<uint32_t> &mine = ctx->patch_targets;         // (scratch of the context: no allocation in the steady state)
       for (uint32_t j2 = 0; j2 < m; ++j2) {
         const uint32_t u = rows->vertex[j2];
-        const uint32_t ua = nrp[u], ub = nrp[u + 1];
-        const size_t ol = (size_t)((int64_t)(ub - ua) - (sh[j2 + 1] - sh[j2]));
+        const uint32_t ua = g->rb(u), ub = g->re(u);
+        const size_t ol = old_len[j2];
         mine.assign(ncol + ua, ncol + ub);
         std::sort(mine.begin(), mine.end());
         auto lists = [&](uint32_t t) { return std::binary_search(mine.begin(), mine.end(), t); };
         auto back_links = [&](uint32_t t) {                              // links t -> u in the (new) row of t
           const bool two = lists(t);
           bool t_lists_u = false;
-          for (uint32_t k = nrp[t]; k < nrp[t + 1]; ++k)
+          for (uint32_t k = g->rb(t); k < g->re(t); ++k)
             if (ncol[k] == u) { ntw[k] = two ? 1 : 0; t_lists_u = true; }
           return t_lists_u;
         };
@@ -1324,6 +1351,8 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
         ot += ol;
       }
     }
+    // half of the pool dead: rows back to back again (O(links), amortised over the patches that made the holes)
+    if (g->pool_dead > (size_t)e_new / 2 + 65536 || !tw_host) g->mirror_compact();
   }
   for (uint32_t j = 0; j < m; ++j) g->vflags[rows->vertex[j]] = rows->vflags[j];
   g->max_out = max_out_new; g->heavy_links = heavy_new; g->n_net = n_net_new;
@@ -1375,9 +1404,18 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
   if (out_bytes) *out_bytes = bytes;
   if (!dst) return HSPF_OK;
   if (cap_bytes < bytes) { ctx->last_error = "hspf_graph_export: buffer too small"; return HSPF_E_INVAL; }
-  if (which == HSPF_GX_TWOWAY) { if (bytes) memcpy(dst, g->twoway.data(), bytes); return HSPF_OK; }
-  if (which == HSPF_GX_HOST_ROW_PTR) { memcpy(dst, g->row_ptr.data(), bytes); return HSPF_OK; }
-  if (which == HSPF_GX_HOST_COL) { if (bytes) memcpy(dst, g->col.data(), bytes); return HSPF_OK; }
+  if (which == HSPF_GX_TWOWAY || which == HSPF_GX_HOST_ROW_PTR || which == HSPF_GX_HOST_COL) {
+    // the host mirror in the caller's (compact) form: rows back to back in vertex order (the pool holds them wherever patches put them)
+    size_t o = 0;
+    for (uint32_t v = 0; v < g->n; ++v) {
+      if (which == HSPF_GX_HOST_ROW_PTR) ((uint32_t *)dst)[v] = (uint32_t)o;
+      else if (which == HSPF_GX_HOST_COL) { if (g->rlen[v]) memcpy((uint32_t *)dst + o, g->col.data() + g->rstart[v], (size_t)g->rlen[v] * 4); }
+      else if (g->rlen[v]) memcpy((uint8_t *)dst + o, g->twoway.data() + g->rstart[v], g->rlen[v]);
+      o += g->rlen[v];
+    }
+    if (which == HSPF_GX_HOST_ROW_PTR) ((uint32_t *)dst)[g->n] = (uint32_t)o;
+    return HSPF_OK;
+  }
   if (which == HSPF_GX_BUILD_MODE) { const uint32_t m = g->costs_only ? 2u : g->patched_in_place ? 3u : g->hub_built ? 1u : 0u; memcpy(dst, &m, 4); return HSPF_OK; }
   if (which == HSPF_GX_SUMMARY) {
     const uint32_t v[12] = {g->wmax, g->hopcount_like ? 1u : 0u, g->lean ? 1u : 0u, g->any_rowflags, g->n_zero_rows, g->n_bad_rows, g->max_in_deg, g->e_kept,
@@ -2831,7 +2869,7 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
   // 0xFFFFFFFF: the sweep kernels send such roots to the sequential kernel), not behind an overloaded or non-expandable
   // neighbour (its tree as a root is not its tree as a transit hop).  HSPF_VARIANT bit 23: off (A/B).
   std::vector<LeafRootJob> leaf_jobs;
-  if (!(ctx->variant & 8388608u) && !g->hopcount_like && g->max_path_metric != HSPF_DIST_INF && g->twoway.size() == g->e) {
+  if (!(ctx->variant & 8388608u) && !g->hopcount_like && g->max_path_metric != HSPF_DIST_INF && g->twoway.size() == g->col.size()) {
     std::vector<std::pair<uint32_t, uint32_t>> where;          // (vertex, first index among the roots)
     where.reserve(n_roots);
     for (uint32_t i = 0; i < n_roots; ++i) if (roots[i] != HSPF_NO_ROOT) where.emplace_back(roots[i], i);
@@ -2846,13 +2884,13 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
       const uint32_t h = roots[i];
       if (h == HSPF_NO_ROOT || (g->vflags[h] & (HSPF_VF_NETWORK | HSPF_VF_NO_EXPAND))) continue;
       uint32_t kept = 0, link = 0;
-      for (uint32_t k = g->row_ptr[h]; k < g->row_ptr[h + 1] && kept < 2u; ++k) if (g->twoway[k]) { ++kept; link = k; }
+      for (uint32_t k = g->rb(h); k < g->re(h) && kept < 2u; ++k) if (g->twoway[k]) { ++kept; link = k; }
       if (kept != 1u) continue;
       const uint32_t pv = g->col[link];
       if (pv == h || (g->vflags[pv] & (HSPF_VF_NETWORK | HSPF_VF_NO_TRANSIT | HSPF_VF_NO_EXPAND))) continue;
-      if (g->row_ptr[pv + 1] - g->row_ptr[pv] > 65536u) continue;   // (the scan below; such a neighbour's leaves take the ordinary path)
+      if (g->rlen[pv] > 65536u) continue;   // (the scan below; such a neighbour's leaves take the ordinary path)
       uint32_t back = 0;                                             // p's links to h: exactly one (two would be two kept in-links)
-      for (uint32_t k = g->row_ptr[pv]; k < g->row_ptr[pv + 1]; ++k) back += g->col[k] == h ? 1u : 0u;
+      for (uint32_t k = g->rb(pv); k < g->re(pv); ++k) back += g->col[k] == h ? 1u : 0u;
       if (back != 1u) continue;
       const int64_t pr = row_of(pv);
       if (pr < 0) continue;
@@ -2860,7 +2898,7 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     }
     for (uint32_t i = 0; i < n_roots; ++i) {
       if (parent_row[i] < 0 || parent_row[(size_t)parent_row[i]] >= 0) continue;    // (two leaves facing each other: both run)
-      leaf_jobs.push_back(LeafRootJob{roots[i], (uint32_t)parent_row[i], i, link_of[i], link_of[i] - g->row_ptr[roots[i]]});
+      leaf_jobs.push_back(LeafRootJob{roots[i], (uint32_t)parent_row[i], i, link_of[i], link_of[i] - g->rb(roots[i])});
       cnt[cls[i]]--;
       cls[i] = 3;
     }
@@ -2945,7 +2983,7 @@ static int run_classes(hspf_ctx *ctx, const hspf_graph *g, const uint32_t *roots
     if ((rc = ensure(ctx, ctx->leaf_jobs, leaf_jobs.size() * sizeof(LeafRootJob), false))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->leaf_jobs.p, leaf_jobs.data(), leaf_jobs.size() * sizeof(LeafRootJob), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_leaf_root_rows, dim3((n + 255u) / 256u, (uint32_t)leaf_jobs.size()), dim3(256), 0, s, n,
-                       (const LeafRootJob *)ctx->leaf_jobs.p, (const uint32_t *)g->d_metric[g->cur], g->max_path_metric, W, U.dist, U.hops,
+                       (const LeafRootJob *)ctx->leaf_jobs.p, (const uint32_t *)g->d_row_ptr[g->cur], (const uint32_t *)g->d_metric[g->cur], g->max_path_metric, W, U.dist, U.hops,
                        U.vflags_out, U.first_hop_mask);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(s));                         // (the pageable job list; and a run returns when its results are there)

@@ -2485,13 +2485,14 @@ __global__ __launch_bounds__(256) void k_init_fused(GraphDev g, ST *st, uint32_t
 // position in h's row — for every vertex reached, and (0, 0, no next hop) for h itself.  Reads p's finished row of the
 // caller's tables, writes h's: no fixed point.  grid = (ceil(n / 256), jobs).
 struct LeafRootJob { uint32_t h, p_row, h_row, link, fpos; };
-__global__ __launch_bounds__(256) void k_leaf_root_rows(uint32_t n, const LeafRootJob *__restrict__ jobs, const uint32_t *__restrict__ metric_raw,
+__global__ __launch_bounds__(256) void k_leaf_root_rows(uint32_t n, const LeafRootJob *__restrict__ jobs, const uint32_t *__restrict__ row_ptr_raw,
+                                                        const uint32_t *__restrict__ metric_raw,
                                                         uint32_t maxpath, uint32_t W, uint32_t *dist, uint16_t *hops, uint16_t *flags,
                                                         uint64_t *mask) {
   const LeafRootJob j = jobs[blockIdx.y];
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
   if (v >= n) return;
-  const uint32_t w = metric_raw[j.link];
+  const uint32_t w = metric_raw[row_ptr_raw[j.h] + j.fpos];      // (j.link: the link in the HOST's row pool, not an index into the device's raw CSR)
   const size_t pi = (size_t)j.p_row * n + v, hi = (size_t)j.h_row * n + v;
   const uint32_t pd = dist[pi];
   const uint64_t sum = (uint64_t)pd + w;

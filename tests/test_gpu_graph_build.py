@@ -285,6 +285,11 @@ def test_incremental_structural_patches_equal_fresh_uploads(spf_ctx, i):
                 vs, rows, flags = np.array([saved[0]]), [(saved[1], saved[2])], np.array([saved[3]], np.uint8)
             else:
                 vs, rows, flags = random_rows(g, rng, int(rng.integers(1, 4)))
+            if rnd % 3 == 1:                                           # new costs on a few rows first, in place (the per-row facts the next summary reads must follow)
+                vs2 = np.sort(rng.choice(g.n, size=min(g.n, 6), replace=False))
+                rows2 = [(g.col[g.row_ptr[v]:g.row_ptr[v + 1]].copy(), rng.integers(0, 4, int(g.row_ptr[v + 1] - g.row_ptr[v])).astype(np.uint32)) for v in vs2.tolist()]
+                G.patch(vs2, rows2, g.vflags[vs2].copy())
+                g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
             G.patch(vs, rows, flags)
             modes.append(int(G.export("build_mode")[0]))
             g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
@@ -482,6 +487,26 @@ def test_patch_grows_past_the_spare_capacity(spf_ctx):
             g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
             assert_layout(G, g)
         check_spf(spf_ctx, G, g, np.arange(10, 74, dtype=np.uint32))
+    finally:
+        G.free()
+
+
+def test_many_growing_patches_keep_the_host_row_pool_right(spf_ctx):
+    """The host mirror of the caller's rows is a pool since round 6: a replaced row that grows is appended, its old place is
+    dead, and the pool is packed again when half of it is (hspf_graph::mirror_compact).  Sixteen rounds of a hundred rows
+    replaced by longer and shorter ones push it through that several times; the mirrors (host_row_ptr / host_col / twoway)
+    and the layout stay those of a fresh upload, and the slot tables made from the mirror still give the oracle's masks."""
+    rng = np.random.default_rng(12)
+    g = synth.random_lsdb(400, 10, 3.0, 812, metric_hi=5)
+    G = spf_ctx.upload(g.row_ptr, g.col, g.metric, g.vflags, g.max_path_metric)
+    try:
+        for rnd in range(16):
+            vs, rows, flags = random_rows(g, rng, 100, grow=[180, 0, 60, 0][rnd % 4])
+            G.patch(vs, rows, flags)
+            g = synth.CsrGraph(G.row_ptr, G.col, G.metric, G.vflags, g.max_path_metric, g.name, g.meta)
+            if rnd % 3 == 2 or rnd == 15:
+                assert_layout(G, g)
+        check_spf(spf_ctx, G, g, np.arange(10, 74, dtype=np.uint32), E.RUN_NET_NEXTHOPS)
     finally:
         G.free()
 
