@@ -17,7 +17,7 @@
 //                (cost descending, source ascending, position ascending) — a total order, so the final
 //                layout does not depend on the order the atomics happened to resolve in.
 //   kb_rowflags  per-row static flags for the fused sweep; hop-count shape of the graph; pads.
-//   kb_splice    (patch) new raw CSR = old rows, except the replaced ones taken from the delta.
+//   kb_patch_raw (patch, graph_patch.hip.h) new raw CSR = old rows, except the replaced ones taken from the delta.
 //
 // Hub mode (some row lists more than HUB_DEG links — a LAN pseudonode with thousands of members): the per-link row scans
 // of kb_links and kb_rank would be quadratic in such a row, so the same layout is derived from two stable device-wide
@@ -756,55 +756,9 @@ __global__ void kb_pads(uint32_t n, const BuildInfo *__restrict__ info, uint32_t
   a0[kept + i] = 0; a1[kept + i] = 0; a2[kept + i] = 0; a3[kept + i] = 0; a4[kept + i] = 0; a5[kept + i] = 0;
 }
 
-// ---- patch: replace whole rows of the raw CSR ----------------------------------------------------------
-
-// Row bounds after a patch, from the old ones: row v starts later by the length changes of the replaced rows in front of
-// it (shift[j] = sum over the first j replaced rows of new length - old length; the host knows both).  Replaces a
-// 400 KB upload of the bounds per patch at 100 000 rows.
-__global__ void __launch_bounds__(GB_BLOCK)
-kb_patch_row_ptr(uint32_t n, const uint32_t *__restrict__ old_row_ptr, uint32_t n_changed, const uint32_t *__restrict__ changed,
-                 const uint32_t *__restrict__ shift, uint32_t *__restrict__ new_row_ptr, const uint8_t *__restrict__ nf,
-                 uint8_t *__restrict__ vflags) {
-  const uint32_t v = blockIdx.x * GB_BLOCK + threadIdx.x;
-  for (uint32_t i = v; i < n_changed; i += gridDim.x * GB_BLOCK) vflags[changed[i]] = nf[i];   // the replaced rows' new flags ride along
-  if (v > n) return;
-  uint32_t lo = 0, hi = n_changed;                       // replaced rows in front of v
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (changed[mid] < v) lo = mid + 1; else hi = mid;
-  }
-  new_row_ptr[v] = old_row_ptr[v] + shift[lo];           // modulo 2^32: a negative shift wraps back
-}
-
-// New raw CSR = the old one with the replaced rows taken from the delta.  A link's source is found among the REPLACED rows
-// (their new starts old_row_ptr[changed[j]] + shift[j] are ascending), not among all rows: J = replaced rows that start at
-// or before k; k inside the last of them -> the delta, otherwise the old link k - shift[J] (everything behind J replaced
-// rows has moved by their length changes).  (Round 3 searched row_ptr for every link: 17 dependent loads, 19 us at 1 M links.)
-__global__ void __launch_bounds__(GB_BLOCK)
-kb_splice(uint32_t e_new, const uint32_t *__restrict__ old_row_ptr, const uint32_t *__restrict__ old_col,
-          const uint32_t *__restrict__ old_metric, uint32_t n_changed, const uint32_t *__restrict__ changed,
-          const uint32_t *__restrict__ shift, const uint32_t *__restrict__ delta_ptr, const uint32_t *__restrict__ delta_col,
-          const uint32_t *__restrict__ delta_metric, uint32_t *__restrict__ new_col, uint32_t *__restrict__ new_metric) {
-  const uint32_t k = blockIdx.x * GB_BLOCK + threadIdx.x;
-  if (k >= e_new) return;
-  uint32_t lo = 0, hi = n_changed;                        // J = first j whose new start is behind k
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (old_row_ptr[changed[mid]] + shift[mid] <= k) lo = mid + 1; else hi = mid;
-  }
-  if (lo != 0u) {
-    const uint32_t j = lo - 1u;
-    const uint32_t off = k - (old_row_ptr[changed[j]] + shift[j]);
-    if (off < delta_ptr[j + 1] - delta_ptr[j]) {          // inside replaced row j
-      new_col[k] = delta_col[delta_ptr[j] + off];
-      new_metric[k] = delta_metric[delta_ptr[j] + off];
-      return;
-    }
-  }
-  const uint32_t ko = k - shift[lo];                      // modulo 2^32
-  new_col[k] = old_col[ko];
-  new_metric[k] = old_metric[ko];
-}
+// ---- patch: replace whole rows of the raw CSR: kb_patch_raw (graph_patch.hip.h) writes the new row bounds (old ones + the length
+// changes of the replaced rows in front: no 400 KB upload of the bounds per patch), the replaced rows' flags and the spliced
+// targets / costs (a link's source is found among the REPLACED rows, not among all rows) in one launch.
 
 // ---- patch, fast path: the replaced rows list the SAME targets in the same order with the same flags, only costs differ
 // (a metric change: the commonest reason an LSP / LSA is re-originated; holo-isis/src/spf.rs:144, 733-735 `trigger_lsps`).

@@ -16,7 +16,7 @@
 //
 // So: one workgroup per affected row derives its new kept out-row and in-row FROM THE NEW RAW CSR (the same rules as kb_links /
 // kb_rank / kb_rowflags / kb_ell / kb_leaf_mark) into a staging area and rewrites the row's fixed-stride records in place
-// (kb_pa_rows); one workgroup turns the rows' length changes into shifts (kb_pa_scan); one streaming kernel writes the six link
+// (kb_pa_rows; the workgroup that finishes last turns the rows' length changes into shifts); one streaming kernel writes the six link
 // arrays into their second set — unaffected entries from the old arrays at their old place, affected rows from the staging
 // area — sets SRC_LEAF, finds the largest cost, and moves the row bounds in place (kb_pa_shift); one pass over the PER-ROW arrays
 // re-derives the build's summary (kb_pa_summary) and the work units / XCD ranges come from the build's own kb_units_small.
@@ -40,9 +40,10 @@ constexpr uint32_t PA_LDS_ROWS = 255u;      // kb_pa_shift keeps the rows' metad
 constexpr uint32_t PA_META = 8u;            // per affected row j (arrays of na + 1 words): old in-start, old in-length, old out-start,
                                             // old out-length, new in-length, new out-length, in-shift, out-shift
 
-// The new raw CSR of a structural patch in ONE launch: kb_patch_row_ptr (row bounds, the replaced rows' flags) + kb_splice
-// (targets, costs) of graph_build.hip.h, and the zeroing of the incremental path's BuildInfo block (kb_clear) — three
-// dependent launches of a few microseconds each were a sixth of the patch's chain.  The three parts touch disjoint arrays.
+// The new raw CSR of a structural patch in ONE launch: row bounds (old ones + the length changes of the replaced rows in front),
+// the replaced rows' flags, targets and costs (a link's row is looked for among the REPLACED rows only), and the zeroing of the
+// incremental path's BuildInfo block — until round 6 three dependent launches of a few microseconds each.  The parts touch
+// disjoint arrays.
 __global__ void __launch_bounds__(GB_BLOCK)
 kb_patch_raw(uint32_t n, uint32_t e_new, const uint32_t *__restrict__ old_row_ptr, const uint32_t *__restrict__ old_col,
              const uint32_t *__restrict__ old_metric, uint32_t n_changed, const uint32_t *__restrict__ changed, const uint32_t *__restrict__ shift,
@@ -233,11 +234,6 @@ __device__ __forceinline__ void pa_scan_body(uint32_t na, uint32_t *meta, uint32
     info->kept = kept_old + tot[0];
     if (tot[0] != tot[1]) atomicOr(&info->err, GB_ERR_PATCH);              // every kept link is in one in-row and one out-row
   }
-}
-__global__ void __launch_bounds__(GB_BLOCK)
-kb_pa_scan(uint32_t na, uint32_t *meta, uint32_t kept_old, BuildInfo *info) {
-  __shared__ uint32_t sh[GB_BLOCK];
-  pa_scan_body(na, meta, kept_old, info, sh);
 }
 
 // Entry k of a shifted array: from the staging area when it lies in an affected row, else the old entry k - (length changes

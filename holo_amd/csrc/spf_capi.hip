@@ -677,7 +677,7 @@ int build_on_device(hspf_ctx *ctx, hspf_graph *g) {
 }
 
 // ---- incremental structural patch (graph_patch.hip.h).  The raw CSR of g (g->cur) and the vertex flags are already the new
-// ones (kb_patch_row_ptr / kb_splice are enqueued); d_aff = the affected rows, ascending, on the device.
+// ones (kb_patch_raw is enqueued); d_aff = the affected rows, ascending, on the device.
 constexpr int HSPF_RETRY_REBUILD = 1001;    // patch_finish -> graph_patch_impl only
 
 size_t patch_scratch_words(const hspf_graph *g, uint32_t na) {
@@ -1131,8 +1131,8 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
     fprintf(stderr, "[hspf patch] %-28s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
     t_prev = t;
   };
-  // ---- structural patch.  The device derives everything from the old arrays and the delta (new row bounds: kb_patch_row_ptr,
-  // raw CSR: kb_splice, then the build), all enqueued first; the host mirrors (rows, two-way flags, the summary of the
+  // ---- structural patch.  The device derives everything from the old arrays and the delta (new row bounds and
+  // raw CSR: kb_patch_raw, then the build or the incremental path), all enqueued first; the host mirrors (rows, two-way flags, the summary of the
   // caller's rows) are brought up to date BEHIND the kernels, in O(replaced rows x their targets' rows) + one block move of
   // the mirrors.  (Round 3: mirrors first, 400 KB of row bounds up and 1 MB of two-way flags down the bus, three walks over
   // all rows: 0.59-0.68 ms at 100 000 rows / 1 000 000 links, now hidden or gone: profiles/r04_notes.md.)
@@ -1220,7 +1220,7 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
     memcpy(h, rows->vertex, (size_t)m * 4);
     memcpy(h + m, rows->row_ptr, ((size_t)m + 1) * 4);
     uint32_t *sh = h + m + (m + 1);
-    uint32_t acc = 0;                                       // modulo 2^32 (kb_patch_row_ptr)
+    uint32_t acc = 0;                                       // modulo 2^32 (kb_patch_raw)
     for (uint32_t j = 0; j < m; ++j) {
       sh[j] = acc;
       const uint32_t v = rows->vertex[j];
@@ -1239,7 +1239,7 @@ static int graph_patch_impl(hspf_ctx *ctx, hspf_graph *g, const hspf_rows *rows,
   uint8_t *d_nf = (uint8_t *)(d_dmet + de);
   const uint32_t *d_aff = d_dmet + de + ((size_t)m + 3) / 4;
   const int nxt = g->cur ^ 1;
-  committed = true;                                            // kb_patch_row_ptr rewrites the vertex flags in place; the mirrors follow
+  committed = true;                                            // kb_patch_raw rewrites the vertex flags in place; the mirrors follow
   HIPCHK(ctx, hipMemcpyAsync(d_changed, ctx->h_patch, dwords * 4, hipMemcpyHostToDevice, s));
   {
     // the incremental path's BuildInfo block is zeroed by the same launch (patch_prepare made room for it)
