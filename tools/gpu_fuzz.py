@@ -62,7 +62,29 @@ def compare(ctx, G, g, roots, flags, tag):
                 bad.append("packed refused a run whose roots have at most 16 first-hop slots")
     if bad:
         print("MISMATCH", tag, bad, "stats", res.stats, flush=True)
+        if os.environ.get("FUZZ_DUMP"):
+            dump_mismatch(ctx, G, g, roots, flags, res, ref)
     return not bad
+
+
+def dump_mismatch(ctx, G, g, roots, flags, res, ref):
+    """Where the tables differ, and whether the same run differs again (FUZZ_DUMP=1: an intermittent mismatch of round 6)."""
+    for name, got, want in (("dist", res.dist, ref.dist), ("hops", res.hops, ref.hops), ("mask", res.first_hop_mask[..., 0], ref.mask[..., 0])):
+        d = np.argwhere(got != want)
+        if not len(d):
+            continue
+        rr, vv = int(d[0][0]), int(d[0][1])
+        print("  ", name, "differs at", len(d), "places; roots", sorted(set(d[:, 0].tolist()))[:10], "first: slot", rr, "root", int(roots[rr]), "vertex", vv,
+              "got", int(got[rr, vv]), "want", int(want[rr, vv]), "dist", int(ref.dist[rr, vv]), "exact flag", int(res.flags[rr, vv] & 2), flush=True)
+        print("   vertices of that root:", d[d[:, 0] == rr][:12, 1].tolist(), "vflags", int(g.vflags[vv]))
+        ins = [(int(u), int(g.metric[kx])) for u in range(g.n) for kx in range(int(g.row_ptr[u]), int(g.row_ptr[u + 1])) if g.col[kx] == vv]
+        print("   links into it (source, cost, ref dist, ref hops, got hops, ref rank):",
+              [(u, c, int(ref.dist[rr, u]), int(ref.hops[rr, u]), int(res.hops[rr, u]), int(ref.pop_rank[rr, u]) if ref.pop_rank is not None else None) for u, c in ins][:20], flush=True)
+        break
+    for again in range(3):
+        r2 = ctx.run(G, roots, flags)
+        print("   again:", {"dist": int((r2.dist != ref.dist).sum()), "hops": int((r2.hops != ref.hops).sum()), "mask": int((r2.first_hop_mask != ref.mask).sum())},
+              "repaired", r2.stats.get("n_repaired_roots"), "sweeps", r2.stats.get("repair_sweeps"), flush=True)
 
 
 def fuzz(ctx, first, count, verbose=True):
