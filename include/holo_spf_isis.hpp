@@ -28,6 +28,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -337,18 +338,23 @@ class LevelGraph {
     return k | lan.pseudonode;
   }
   // One pass over the LSDB in ITS order (LspId: fragments of a LAN id are adjacent): records out, CSR back.
-  bool build_keyed(const Lsdb &lsdb, const InstanceCfg &cfg, Engine &engine) {
-    const auto t_begin = std::chrono::steady_clock::now();
+  // The pass is bound by the latency of walking the map (a node, its LSP, its TLV vectors: ~3 cache misses per LSP, 23.5 ms for
+  // 100 000 LSPs on one core: profiles/r06_notes.md), not by work — so large LSDBs are cut into ranges of whole system ids
+  // (splitter keys interpolated between the first and the last system id; any split is correct, an uneven one only slower) and
+  // the ranges are streamed by a few threads side by side, each into its own buffers, which are then laid end to end.
+  struct KeyedPart {
     std::vector<uint64_t> vkey, tkey;
-    std::vector<uint32_t> vrow{0}, tmet;
+    std::vector<uint32_t> vrow_len, tmet;        // vrow_len: links per vertex
     std::vector<uint8_t> vfl;
     std::vector<LanId> lans;
+  };
+  template <typename It>
+  void stream_range(It it, It end, const InstanceCfg &cfg, bool std_on, bool wide_on, KeyedPart &o) const {
     const Lsp *zeroth = nullptr;
-    const bool std_on = metric_type == "standard" || metric_type == "both", wide_on = metric_type == "wide" || metric_type == "both";
-    { const size_t nl = lsdb.all().size(); vkey.reserve(nl); vrow.reserve(nl + 1); vfl.reserve(nl); lans.reserve(nl); tkey.reserve(nl * 8); tmet.reserve(nl * 8); }   // (ONE pass over the LSDB)
+    size_t row_start = 0;
     auto close = [&]() {                                       // flags of the vertex whose fragments just ended (spf.rs:557-604)
-      if (lans.empty() || vfl.size() == lans.size()) return;
-      const LanId &lan = lans.back();
+      if (o.lans.empty() || o.vfl.size() == o.lans.size()) return;
+      const LanId &lan = o.lans.back();
       const bool is_pn = lan.pseudonode != 0;
       uint8_t f = is_pn ? HSPF_VF_NETWORK : 0;
       const Lsp *z = zeroth;
@@ -360,22 +366,82 @@ class LevelGraph {
           if (!z->protocols_supported || (cfg.ipv4_enabled && !has(NLPID_IPV4)) || (cfg.ipv6_enabled && !has(NLPID_IPV6))) f |= HSPF_VF_NO_EXPAND;
         }
       }
-      vfl.push_back(f);
-      vrow.push_back((uint32_t)tkey.size());
+      o.vfl.push_back(f);
+      o.vrow_len.push_back((uint32_t)(o.tkey.size() - row_start));
+      row_start = o.tkey.size();
     };
     // fragments of a LAN id are adjacent, fragment 0 — the zeroth LSP of spf.rs:1299-1309 when it is live — first
     bool have_lan = false, started = false;
     LanId cur{};
-    for (auto &kv : lsdb.all()) {
-      const Lsp &l = kv.second;
+    for (; it != end; ++it) {
+      const Lsp &l = it->second;
       const LanId lan = l.lan_id();
       if (!have_lan || !(cur == lan)) { if (started) close(); have_lan = true; cur = lan; started = false; zeroth = nullptr; }
       if (!l.live()) continue;
       if (l.fragment == 0) zeroth = &l;
-      if (!started) { started = true; lans.push_back(lan); vkey.push_back(key_of(lan)); }
-      for_each_vertex_edge(l, mt_id, hopcount, std_on, wide_on, [&](const LanId &nbr, uint32_t c) { tkey.push_back(key_of(nbr)); tmet.push_back(c); });
+      if (!started) { started = true; o.lans.push_back(lan); o.vkey.push_back(key_of(lan)); }
+      for_each_vertex_edge(l, mt_id, hopcount, std_on, wide_on, [&](const LanId &nbr, uint32_t c) { o.tkey.push_back(key_of(nbr)); o.tmet.push_back(c); });
     }
     if (started) close();
+  }
+  static uint64_t sid_num(const SystemId &s) { uint64_t x = 0; for (int i = 0; i < 6; ++i) x = (x << 8) | s[i]; return x; }
+  static SystemId num_sid(uint64_t x) { SystemId s{}; for (int i = 5; i >= 0; --i) { s[i] = (uint8_t)(x & 0xFF); x >>= 8; } return s; }
+  bool build_keyed(const Lsdb &lsdb, const InstanceCfg &cfg, Engine &engine) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    const bool std_on = metric_type == "standard" || metric_type == "both", wide_on = metric_type == "wide" || metric_type == "both";
+    const auto &all = lsdb.all();
+    if (all.empty()) return false;
+    // ranges of whole system ids, one thread each (HSPF_KEYED_THREADS; default: the cores, at most 16; small LSDBs: one)
+    unsigned T = 1;
+    if (all.size() >= 4096) {
+      T = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+      if (const char *e = getenv("HSPF_KEYED_THREADS")) T = std::max(1, atoi(e));
+    }
+    std::vector<decltype(all.begin())> cut;
+    cut.push_back(all.begin());
+    if (T > 1) {
+      const uint64_t lo = sid_num(std::get<0>(all.begin()->first)), hi = sid_num(std::get<0>(all.rbegin()->first));
+      for (unsigned k = 1; k < T; ++k) {
+        const uint64_t at = lo + (uint64_t)((unsigned __int128)(hi - lo) * k / T);
+        auto it = all.lower_bound(Lsdb::Key{num_sid(at), 0, 0});            // the first LSP of a system id: never inside a LAN id's fragments
+        if (it != cut.back() && it != all.end()) cut.push_back(it);
+      }
+    }
+    cut.push_back(all.end());
+    const size_t np = cut.size() - 1;
+    std::vector<KeyedPart> part(np);
+    if (np == 1) stream_range(cut[0], cut[1], cfg, std_on, wide_on, part[0]);
+    else {
+      std::vector<std::thread> th;
+      for (size_t k = 0; k < np; ++k) th.emplace_back([&, k]() { stream_range(cut[k], cut[k + 1], cfg, std_on, wide_on, part[k]); });
+      for (auto &t : th) t.join();
+    }
+    // end to end
+    size_t nv = 0, nl = 0;
+    std::vector<size_t> v0(np + 1, 0), l0(np + 1, 0);
+    for (size_t k = 0; k < np; ++k) { v0[k] = nv; l0[k] = nl; nv += part[k].vkey.size(); nl += part[k].tkey.size(); }
+    v0[np] = nv; l0[np] = nl;
+    std::vector<uint64_t> vkey(nv), tkey(nl);
+    std::vector<uint32_t> vrow(nv + 1), tmet(nl);
+    std::vector<uint8_t> vfl(nv);
+    std::vector<LanId> lans(nv);
+    auto place = [&](size_t k) {
+      const KeyedPart &o = part[k];
+      std::copy(o.vkey.begin(), o.vkey.end(), vkey.begin() + v0[k]);
+      std::copy(o.tkey.begin(), o.tkey.end(), tkey.begin() + l0[k]);
+      std::copy(o.tmet.begin(), o.tmet.end(), tmet.begin() + l0[k]);
+      std::copy(o.vfl.begin(), o.vfl.end(), vfl.begin() + v0[k]);
+      std::copy(o.lans.begin(), o.lans.end(), lans.begin() + v0[k]);
+      uint32_t at = (uint32_t)l0[k];
+      for (size_t i = 0; i < o.vrow_len.size(); ++i) { vrow[v0[k] + i] = at; at += o.vrow_len[i]; }
+    };
+    if (np == 1) place(0);
+    else {
+      std::vector<std::thread> th;
+      for (size_t k = 0; k < np; ++k) th.emplace_back([&, k]() { place(k); });
+      for (auto &t : th) t.join();
+    }
+    vrow[nv] = (uint32_t)nl;
     if (lans.empty()) return false;
     const auto t_stream = std::chrono::steady_clock::now();
     std::vector<uint32_t> rank;
