@@ -203,6 +203,7 @@ struct hspf_ctx {
   DevBuf ex_list, ex_heap, ex_pos;
   DevBuf rp_rank;                                    // pop_rank of repaired roots: keys / items of the two sorts, rocPRIM's temporary storage
   DevBuf dyn_part;                                   // FusedGraph::dyn_part: DYN_PARTS partial LF_DYN arrays of the lane = root sweeps
+  DevBuf rp_trace;                                   // HSPF_REPAIR_TRACE (debugging)
   DevBuf rp_z, rp_ord, rp_work, rp_status;          // k_repair (spf_repair.hip.h): zero-cost marks + list, (R, pos), stamps + worklists, status
   uint32_t *h_rp = nullptr; size_t h_rp_cap = 0;    // pinned: the repair's control block (RpCtl)
   uint32_t est_rp_rounds = 6;                        // relaxation rounds launched ahead
@@ -850,7 +851,7 @@ void hspf_shutdown(hspf_ctx *ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (DevBuf *b : {&ctx->dist, &ctx->hv, &ctx->mask, &ctx->lane_flags, &ctx->changed,
                     &ctx->st64, &ctx->stamp, &ctx->hnb, &ctx->o_dist, &ctx->o_hops, &ctx->o_flags,
-                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->rp_rank, &ctx->dyn_part, &ctx->rp_z, &ctx->rp_ord, &ctx->rp_work, &ctx->rp_status, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb_kx, &ctx->gb, &ctx->gb_pa, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag, &ctx->xcd_ctl})
+                    &ctx->o_mask, &ctx->o_rank, &ctx->ex_list, &ctx->ex_heap, &ctx->ex_pos, &ctx->rp_rank, &ctx->dyn_part, &ctx->rp_trace, &ctx->rp_z, &ctx->rp_ord, &ctx->rp_work, &ctx->rp_status, &ctx->pf_ptr, &ctx->pf_vtx, &ctx->pf_met, &ctx->pf_org, &ctx->gb_kx, &ctx->gb, &ctx->gb_pa, &ctx->gb_delta, &ctx->gb_hub, &ctx->giant_part, &ctx->leaf_jobs, &ctx->kcnt, &ctx->pack, &ctx->swcnt, &ctx->o_pack, &ctx->pk_flag, &ctx->xcd_ctl})
     release(*b);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
   for (auto &e : ctx->ev_stage) if (e) (void)hipEventDestroy(e);
@@ -1410,7 +1411,10 @@ int hspf_graph_export(hspf_ctx *ctx, const hspf_graph *g, uint32_t which, void *
     for (uint32_t v = 0; v < g->n; ++v) {
       if (which == HSPF_GX_HOST_ROW_PTR) ((uint32_t *)dst)[v] = (uint32_t)o;
       else if (which == HSPF_GX_HOST_COL) { if (g->rlen[v]) memcpy((uint32_t *)dst + o, g->col.data() + g->rstart[v], (size_t)g->rlen[v] * 4); }
-      else if (g->rlen[v]) memcpy((uint8_t *)dst + o, g->twoway.data() + g->rstart[v], g->rlen[v]);
+      else if (g->rlen[v]) {
+        if (g->twoway.size() == g->col.size()) memcpy((uint8_t *)dst + o, g->twoway.data() + g->rstart[v], g->rlen[v]);
+        else memset((uint8_t *)dst + o, 0, g->rlen[v]);            // (no flags on the host: only on a graph whose last build failed)
+      }
       o += g->rlen[v];
     }
     if (which == HSPF_GX_HOST_ROW_PTR) ((uint32_t *)dst)[g->n] = (uint32_t)o;
@@ -2531,6 +2535,14 @@ int Run::repair_roots() {
     a.R = (uint32_t *)ctx->rp_ord.p; a.pos = a.R + (size_t)nd * n;
     a.stamp = (uint32_t *)ctx->rp_work.p; a.wl = a.stamp + (size_t)nd * n;
     a.ctl = RpCtl{(uint32_t *)ctx->rp_status.p, nd};
+    a.trace = nullptr;
+    if (const char *tv = getenv("HSPF_REPAIR_TRACE")) {          // debugging: root:v0,v1,v2,v3 (see spf_repair.hip.h)
+      unsigned tr = 0, t0 = ~0u, t1 = ~0u, t2 = ~0u, t3 = ~0u;
+      if (sscanf(tv, "%u:%u,%u,%u,%u", &tr, &t0, &t1, &t2, &t3) >= 2 && ensure(ctx, ctx->rp_trace, (4u + 4u * RP_TRACE_CAP) * 4, false) == HSPF_OK) {
+        a.trace = (uint32_t *)ctx->rp_trace.p; a.trace_root = tr; a.trace_v[0] = t0; a.trace_v[1] = t1; a.trace_v[2] = t2; a.trace_v[3] = t3;
+        HIPCHK(ctx, hipMemsetAsync(a.trace, 0, 16, s));
+      }
+    }
     // a root's share of the chip: all of it for one root, RP_GX blocks of 16 groups each at most
     const uint32_t gx = std::max(1u, std::min(RP_GX, 4096u / nd));
     const dim3 pg(gx, nd), tb(256);
@@ -2584,6 +2596,17 @@ int Run::repair_roots() {
       if (rounds <= 64u) ctx->est_rp_rounds = std::min(std::max(need, RP_RELAX), 64u); }       // rounds the next repair launches (the last one's + a spare)
     uint32_t t_evals = 0, t_groups = 0, t_gmax = 0;
     for (uint32_t j = 0; j < nd; ++j) { t_evals += hc.tot(j)[0]; t_groups += hc.tot(j)[1]; t_gmax = std::max(t_gmax, hc.tot(j)[2]); }
+    if (a.trace) {
+      std::vector<uint32_t> tr(4u + 4u * RP_TRACE_CAP);
+      HIPCHK(ctx, hipMemcpy(tr.data(), a.trace, tr.size() * 4, hipMemcpyDeviceToHost));
+      const uint32_t cntt = std::min(tr[0], RP_TRACE_CAP);
+      fprintf(stderr, "[hspf repair trace] %u records (sweeps %u)\n", tr[0], 0u);
+      for (uint32_t i = 0; i < cntt; ++i) {
+        const uint32_t *t = tr.data() + 4 + 4 * i;
+        if ((t[0] >> 28) == 1u) fprintf(stderr, "  wake   for sweep %u: vertex %u by %u -> %s\n", t[0] & 0xFFFFFFu, t[1], t[2], t[3] ? "appended" : "already stamped");
+        else fprintf(stderr, "  eval   in sweep %u: vertex %u first parent's hops %u -> hops %u (was %u), changed %u, R of first parent %u\n", t[0] & 0xFFFFFFu, t[1], t[2] >> 16, t[2] & 0xFFFFu, t[3] >> 16, t[3] & 1u, (t[3] & 0xFFFEu) >> 1);
+      }
+    }
     if (getenv("HSPF_REPAIR_PROF"))
       fprintf(stderr, "[hspf repair] %u roots, n %u, %u rounds: %u sweeps, %u evaluations, %u groups (largest deep one %u); host %.1f us\n", nd, n, rounds, used, t_evals, t_groups,
               t_gmax, std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - t0).count());

@@ -128,7 +128,17 @@ struct RepairArgs {
   uint32_t *stamp;             // [n_dyn][n], zero on entry: id of the last sweep a vertex was put on a worklist for
   uint32_t *wl;                // [n_dyn][2][n] worklists
   RpCtl ctl;
+  // HSPF_REPAIR_TRACE=root:v0,v1,v2,v3 (debugging): evaluations of and wake-ups for these vertices of that root, recorded in order
+  uint32_t *trace; uint32_t trace_root; uint32_t trace_v[4];
 };
+#define RP_TRACE_CAP 4096u
+__device__ __forceinline__ bool rp_traced(const RepairArgs &a, uint32_t root, uint32_t v) {
+  return a.trace && root == a.trace_root && (v == a.trace_v[0] || v == a.trace_v[1] || v == a.trace_v[2] || v == a.trace_v[3]);
+}
+__device__ __forceinline__ void rp_trace(const RepairArgs &a, uint32_t code, uint32_t x, uint32_t y, uint32_t z) {
+  const uint32_t i = atomicAdd(a.trace, 1u);
+  if (i < RP_TRACE_CAP) { uint32_t *t = a.trace + 4u + 4u * i; t[0] = code; t[1] = x; t[2] = y; t[3] = z; }
+}
 
 struct RpCtx {
   const GraphDev &g;
@@ -199,8 +209,11 @@ __device__ __forceinline__ void rp_append(uint32_t *cnt, uint32_t *list, uint32_
   if (want) list[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = x;
 }
 // ... onto the worklist of `sweep`, once per sweep and vertex (the stamp decides who appends)
-__device__ __forceinline__ bool rp_wake(const RpRoot &r, uint32_t *cnt, uint32_t *list, uint32_t x, uint32_t sweep, bool want) {
+__device__ __forceinline__ bool rp_wake(const RpRoot &r, uint32_t *cnt, uint32_t *list, uint32_t x, uint32_t sweep, bool want,
+                                        const RepairArgs *a = nullptr, uint32_t waker = 0) {
+  const bool asked = want;
   want = want && x != r.root && atomicExch(&r.ST[x], sweep) != sweep;
+  if (a && asked && rp_traced(*a, r.root, x)) rp_trace(*a, 0x10000000u | sweep, x, waker, want ? 1u : 0u);
   rp_append(cnt, list, x, want);
   return want;
 }
@@ -360,12 +373,12 @@ __global__ __launch_bounds__(256) void kr_due(RepairArgs a) {
         due = due || (g.in_w[e] == 0u && u >= v && rp_src_ok(c, raw) && r.D[u] == dv);
       }
     }
-    any = rp_wake(r, cnt, r.WL1, v, 1u, rp_any16(due) && r.sub == 0u) || any;
+    any = rp_wake(r, cnt, r.WL1, v, 1u, rp_any16(due) && r.sub == 0u, &a, 0xFFFFFFFFu) || any;
     if (rv != v && rp_expands(c, v))
       for (uint32_t k = g.out_ptr[v] + r.sub, k1 = g.out_ptr[v + 1]; rp_any16(k < k1); k += 16u) {
         const uint32_t x = k < k1 ? g.out_dst[k] : v;
         const bool t = k < k1 && r.D[x] != INF && rp_tight(dv, g.out_w[k], r.D[x]);
-        any = rp_wake(r, cnt, r.WL1, x, 1u, t) || any;
+        any = rp_wake(r, cnt, r.WL1, x, 1u, t, &a, v) || any;
       }
   }
   if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) a.ctl.pend()[1] = 1u;
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(256) void kr_sweep(RepairArgs a, uint32_t sweep) {
       const uint64_t ou = rp_ord(c, u);
       if (w == 0u && ou >= ov) continue;                              // same level: a parent only if it is popped before v
       const uint32_t hu = r.H[u];
-      if (!have || du < bd || (du == bd && ou < bo)) { have = true; bd = du; bo = ou; bh = hu; }
+      if (!have || du < bd || (du == bd && (ou < bo || (ou == bo && hu < bh)))) { have = true; bd = du; bo = ou; bh = hu; }
       if (hu == 0u) {                                                 // parent: the root or a hops-0 network -> the link's own slot
         if (v_router || a.net_nexthops) {
           const uint32_t base_s = (u == r.root) ? 0u : slot_base_of(a.tabs, r.ri, u);
@@ -425,16 +438,23 @@ __global__ __launch_bounds__(256) void kr_sweep(RepairArgs a, uint32_t sweep) {
       const uint32_t obd = (uint32_t)__shfl_xor((int)bd, off, 16), obh = (uint32_t)__shfl_xor((int)bh, off, 16);
       const uint64_t obo = (uint64_t)__shfl_xor((long long)bo, off, 16);
       const bool ohv = __shfl_xor(have ? 1 : 0, off, 16) != 0;
-      if (ohv && (!have || obd < bd || (obd == bd && obo < bo))) { have = true; bd = obd; bo = obo; bh = obh; }
+      // (dist, order, hops) as ONE total order: two lanes can hold the same parent with different hop counts — parallel links
+      // from a parent that another group is re-evaluating in this very sweep, read in different trips of the loop above — and
+      // with the hops left out of the comparison each of them kept its own: the group then disagreed on `ch` below, only the
+      // lanes that saw a change went on to wake the children, and a child behind one of the other lanes' links was never
+      // woken (round 6, tools/debug/dyn_fuzz_seed.py 487107: one wrong hop count in ~40 runs with three processes on the GPU).
+      if (ohv && (!have || obd < bd || (obd == bd && (obo < bo || (obo == bo && obh < bh))))) { have = true; bd = obd; bo = obo; bh = obh; }
 #pragma unroll
       for (int q = 0; q < WMAX; ++q) nm[q] |= (uint64_t)__shfl_xor((long long)nm[q], off, 16);
     }
+    bh = (uint32_t)__shfl((int)bh, 0, 16);                          // (the group's lane 0 decides: `ch` and what is stored must be one value)
     if (!have) { if (r.sub == 0u) a.ctl.fail()[r.j] = 1u; continue; }
     if (r.sub == 0u) ++evals;
     const uint32_t nh = min(bh + (v_router ? 1u : 0u), 0xFFFFu);     // u16 saturating_add
     bool ch = nh != r.H[v];
 #pragma unroll
     for (int q = 0; q < WMAX; ++q) if ((uint32_t)q < W) ch = ch || nm[q] != r.M[(size_t)v * W + q];
+    if (r.sub == 0u && rp_traced(a, r.root, v)) rp_trace(a, 0x20000000u | sweep, v, (bh << 16) | (nh & 0xFFFFu), ((uint32_t)r.H[v] << 16) | (ch ? 1u : 0u) | ((uint32_t)(bo >> 32) << 1 & 0xFFFEu));
     if (!ch) continue;                                                // (uniform in the group: every lane compared the same values)
     // every lane has read the old values: lane 0 stores, the group wakes the tight children up
     if (r.sub == 0u) {
@@ -446,7 +466,7 @@ __global__ __launch_bounds__(256) void kr_sweep(RepairArgs a, uint32_t sweep) {
     for (uint32_t k = g.out_ptr[v] + r.sub, k1 = g.out_ptr[v + 1]; rp_any16(k < k1); k += 16u) {
       const uint32_t x = k < k1 ? g.out_dst[k] : v;
       const bool t = k < k1 && r.D[x] != INF && rp_tight(dv, g.out_w[k], r.D[x]);
-      any = rp_wake(r, cnt_next, next, x, sweep + 1u, t) || any;
+      any = rp_wake(r, cnt_next, next, x, sweep + 1u, t, &a, v) || any;
     }
   }
   if (__syncthreads_or(any ? 1 : 0) && threadIdx.x == 0) pend[sweep + 1u] = 1u;

@@ -46,3 +46,5 @@ for it in range(reps):
             ins = [(int(u), int(g.metric[kx])) for u in range(g.n) for kx in range(int(g.row_ptr[u]), int(g.row_ptr[u + 1])) if g.col[kx] == vv]
             print("   links into it (source, cost, dist of source, hops of source, ref):", [(u, c, int(ref.dist[rr, u]), int(ref.hops[rr, u]), int(res.hops[rr, u])) for u, c in ins][:24])
             break
+    if any(v.any() for v in bad.values()) and os.environ.get("STOP_AT_MISMATCH"):
+        sys.exit(3)
