@@ -62,8 +62,11 @@ struct BuildInfo {       // device-resident summary of one build, copied back on
 // atomic on ONE address costs ~10 ns whoever issues it (15 600 of them made kb_scatter 180 us, 100 000 made kb_rowflags
 // 40-130 us), so each count has 64 counters in 64 different 128-byte lines behind BuildInfo, a block adds to counter
 // blockIdx & 63, and the single-workgroup kernel at the end of the build (kb_units_small / kb_xcd) sums them into BuildInfo.
-constexpr uint32_t GB_SC_BAD = 0, GB_SC_ZERO = 1, GB_SC_LEAF = 2, GB_SC_COUNTS = 3;
-constexpr uint32_t GB_SC_WORDS = GB_SC_COUNTS * 64u * 32u;
+// The largest kept cost is spread the same way (GB_SC_WMAX: 64 maxima, folded into BuildInfo::wmax at the end): a streaming kernel
+// starts with ~8 000 waves that all read "0 so far" and all raise ONE word — kb_pa_shift took 60-100 us in a patch's chain and
+// 14.5 us on a layout of zero costs, where no wave had anything to raise (profiles/r06_notes.md r06zb).
+constexpr uint32_t GB_SC_BAD = 0, GB_SC_ZERO = 1, GB_SC_LEAF = 2, GB_SC_COUNTS = 3, GB_SC_WMAX = 3, GB_SC_CLASSES = 4;
+constexpr uint32_t GB_SC_WORDS = GB_SC_CLASSES * 64u * 32u;
 __device__ __forceinline__ uint32_t *gb_spread(BuildInfo *info, uint32_t which) {
   return (uint32_t *)info + 32u + (which * 64u + (blockIdx.x & 63u)) * 32u;
 }
@@ -74,11 +77,19 @@ __device__ __forceinline__ void gb_counts_finish(BuildInfo *info, uint32_t lane)
     v[c] = ((const uint32_t *)info)[32u + (c * 64u + lane) * 32u];
     for (int o = 32; o; o >>= 1) v[c] += (uint32_t)__shfl_xor((int)v[c], o);
   }
+  uint32_t wm = ((const uint32_t *)info)[32u + (GB_SC_WMAX * 64u + lane) * 32u];
+  for (int o = 32; o; o >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, o));
   if (lane == 0u) {
     info->n_bad_rows = v[GB_SC_BAD]; info->hc_bad = v[GB_SC_BAD] ? 1u : 0u;
     info->n_zero_rows = v[GB_SC_ZERO];
     info->n_leaf = v[GB_SC_LEAF];
+    info->wmax = max(info->wmax, wm);                       // (hub mode: kb_hub_scatter raises BuildInfo::wmax itself, once per block)
   }
+}
+// a wave's largest cost into the spread maxima (lane 0 of the wave; a stale read costs one atomic too many, never a wrong maximum)
+__device__ __forceinline__ void gb_raise_wmax(BuildInfo *info, uint32_t wmax) {
+  uint32_t *slot = gb_spread(info, GB_SC_WMAX);
+  if (wmax > *(volatile uint32_t *)slot) atomicMax(slot, wmax);
 }
 
 // rowaux bits (hspf_graph::d_rowaux): the per-row facts behind BuildInfo's hop-count summary, kept so that a structural
@@ -271,8 +282,7 @@ kb_scatter(uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t *__r
     wmax = w;
   }
   for (int o = 32; o; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
-  // only a wave that would raise the maximum touches it (a stale read costs one atomic too many, never a wrong maximum)
-  if ((threadIdx.x & 63u) == 0u && wmax > *(volatile uint32_t *)&info->wmax) atomicMax(&info->wmax, wmax);
+  if ((threadIdx.x & 63u) == 0u) gb_raise_wmax(info, wmax);
 }
 
 // In-links of a row by (cost descending, source ascending, position ascending): among tight links, i.e. equal
@@ -392,7 +402,7 @@ kb_hub_scatter(uint32_t e, const uint32_t *__restrict__ row_ptr, const uint32_t 
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0 && bmax) atomicMax(&info->wmax, bmax);
+  if (threadIdx.x == 0 && bmax) gb_raise_wmax(info, bmax);
 }
 
 __global__ void __launch_bounds__(GB_BLOCK)

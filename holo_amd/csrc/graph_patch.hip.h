@@ -303,7 +303,7 @@ kb_pa_shift(uint32_t n, uint32_t na, const uint32_t *__restrict__ A, const uint3
     }
   }
   for (int o = 32; o; o >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, o));
-  if ((threadIdx.x & 63u) == 0u && wmax > *(volatile uint32_t *)&info->wmax) atomicMax(&info->wmax, wmax);   // (kb_scatter)
+  if ((threadIdx.x & 63u) == 0u) gb_raise_wmax((BuildInfo *)info, wmax);   // (kb_scatter)
   if (k <= n) {                                                  // row bounds, in place: affected rows in front of row k
     uint32_t lo = 0, hi = na;
     while (lo < hi) {

@@ -63,6 +63,17 @@ impl Csr {
     }
 }
 
+/// The LSDB records of `Engine::upload_keyed` (include/holo_spf_hip.h `hspf_keyed_lsdb`).
+#[derive(Debug, Default, Clone, PartialEq, Eq)]
+pub struct KeyedLsdb {
+    pub vertex_key: Vec<u64>,
+    pub row_ptr: Vec<u32>,
+    pub target_key: Vec<u64>,
+    pub metric: Vec<u32>,
+    pub vflags: Vec<u8>,
+    pub max_path_metric: u32,
+}
+
 /// One replaced row of `Graph::patch`.
 #[derive(Debug, Clone)]
 pub struct RowPatch {
@@ -451,6 +462,37 @@ impl Engine {
             return Err(self.err(rc));
         }
         Ok(Graph { eng: self, g, n: csr.n_vertices(), _not_sync: PhantomData })
+    }
+
+    /// `hspf_graph_upload_keyed` (ABI 8): the LSDB's records as they sit there — vertices by 64-bit key in any order, links
+    /// by target key in LSP / LSA order, targets unresolved.  The device ranks the keys (ascending key order = the reference's
+    /// `VertexId` order, holo-isis/src/spf.rs:96-100), resolves the targets and drops links to vertices the LSDB does not
+    /// hold (`vertex_edges` does not yield them, holo-isis/src/spf.rs:1013-1128).  Returns the graph and, per input
+    /// vertex, its index in it; `Graph::export_csr` reads the CSR it built back for the host mirrors.
+    pub fn upload_keyed(&self, lsdb: &KeyedLsdb) -> Result<(Graph<'_>, Vec<u32>), Error> {
+        let n = lsdb.vertex_key.len();
+        if lsdb.row_ptr.len() != n + 1 || lsdb.vflags.len() != n || lsdb.metric.len() != lsdb.target_key.len()
+            || lsdb.row_ptr.last().copied().unwrap_or(0) as usize != lsdb.target_key.len()
+        {
+            return Err(Error { code: sys::HSPF_E_INVAL, detail: "upload_keyed: array lengths disagree".into() });
+        }
+        let c = sys::hspf_keyed_lsdb {
+            n_vertices: n as u32,
+            n_links: lsdb.target_key.len() as u32,
+            vertex_key: lsdb.vertex_key.as_ptr(),
+            row_ptr: lsdb.row_ptr.as_ptr(),
+            target_key: lsdb.target_key.as_ptr(),
+            metric: lsdb.metric.as_ptr(),
+            vflags: lsdb.vflags.as_ptr(),
+            max_path_metric: lsdb.max_path_metric,
+        };
+        let mut g = ptr::null_mut();
+        let mut rank = vec![0u32; n];
+        let rc = unsafe { sys::hspf_graph_upload_keyed(self.ctx, &c, &mut g, rank.as_mut_ptr()) };
+        if rc != sys::HSPF_OK {
+            return Err(self.err(rc));
+        }
+        Ok((Graph { eng: self, g, n: n as u32, _not_sync: PhantomData }, rank))
     }
 
     pub fn host_alloc(&self, bytes: usize) -> Result<PinnedBuf<'_>, Error> {
@@ -894,6 +936,31 @@ impl Drop for Engine {
 }
 
 impl Graph<'_> {
+    /// The caller's CSR as it is resident on the device (`hspf_graph_export`: ROW_PTR / COL / METRIC / VFLAGS) — what
+    /// `Engine::upload_keyed` built from the LSDB records, for `CsrCache`'s host mirror.
+    pub fn export_csr(&self, max_path_metric: u32) -> Result<Csr, Error> {
+        fn fetch<T: Clone + Default>(g: &Graph<'_>, which: u32) -> Result<Vec<T>, Error> {
+            let mut bytes = 0usize;
+            let rc = unsafe { sys::hspf_graph_export(g.eng.ctx, g.g, which, ptr::null_mut(), 0, &mut bytes) };
+            if rc != sys::HSPF_OK && bytes == 0 {
+                return Err(g.eng.err(rc));
+            }
+            let mut v = vec![T::default(); bytes / std::mem::size_of::<T>()];
+            let rc = unsafe { sys::hspf_graph_export(g.eng.ctx, g.g, which, v.as_mut_ptr() as *mut _, bytes, &mut bytes) };
+            if rc != sys::HSPF_OK {
+                return Err(g.eng.err(rc));
+            }
+            Ok(v)
+        }
+        Ok(Csr {
+            row_ptr: fetch::<u32>(self, sys::HSPF_GX_ROW_PTR)?,
+            col: fetch::<u32>(self, sys::HSPF_GX_COL)?,
+            metric: fetch::<u32>(self, sys::HSPF_GX_METRIC)?,
+            vflags: fetch::<u8>(self, sys::HSPF_GX_VFLAGS)?,
+            max_path_metric,
+        })
+    }
+
     /// Whole rows replaced (the rows of the LSPs / LSAs that triggered the run: `trigger_lsps`, `SpfTriggerLsa`).
     pub fn patch(&mut self, rows: &[RowPatch]) -> Result<(), Error> {
         let vertex: Vec<u32> = rows.iter().map(|r| r.vertex).collect();
