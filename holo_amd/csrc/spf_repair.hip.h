@@ -54,14 +54,22 @@ __global__ __launch_bounds__(256) void kr_zmark(uint32_t e, const uint32_t *__re
   if (k < e && out_w[k] == 0u) zflag[out_dst[k]] = 1;
 }
 __global__ __launch_bounds__(256) void kr_zcompact(uint32_t n, const uint8_t *__restrict__ zflag, uint32_t *__restrict__ zl, uint32_t *__restrict__ nz) {
+  // one atomic per BLOCK on the list's counter (one per wave: 1 600 of them on one word were 13 of this kernel's 19 us at 100 000
+  // vertices); the order of the list does not matter to anyone
+  __shared__ uint32_t s_wave[4], s_base;
   const uint32_t v = blockIdx.x * 256u + threadIdx.x;
   const bool z = v < n && zflag[v] != 0;
   const uint64_t b = __ballot(z);
-  if (b == 0ull) return;
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(nz, (uint32_t)__popcll(b));
-  base = __builtin_amdgcn_readfirstlane(base);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0) s_wave[wave] = (uint32_t)__popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    s_base = t ? atomicAdd(nz, t) : 0u;
+  }
+  __syncthreads();
+  uint32_t base = s_base;
+  for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
   if (z) zl[base + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = v;
 }
 

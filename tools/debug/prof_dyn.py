@@ -1,5 +1,5 @@
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, 'tools')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from holo_amd import engine as E, synth
 import gpu_dynamic_probe as P
 os.environ["HSPF_REPAIR_PROF"]="1"
