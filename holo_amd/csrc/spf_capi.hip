@@ -2543,9 +2543,13 @@ int Run::repair_roots() {
         HIPCHK(ctx, hipMemsetAsync(a.trace, 0, 16, s));
       }
     }
-    // a root's share of the chip: all of it for one root, RP_GX blocks of 16 groups each at most
-    const uint32_t gx = std::max(1u, std::min(RP_GX, 4096u / nd));
-    const dim3 pg(gx, nd), tb(256);
+    // a root's share of the chip.  Eight roots and more: RP_GX blocks each, a root's blocks all on ONE XCD (RpRoot: its tables meet
+    // one L2; repair of 64 roots on isis-100k 1.00 -> 0.92 ms at 1 % zero-cost links, 7.3 -> 5.5 at 5 %, ospf-10k 0.49 -> 0.41 and
+    // 1.13 -> 0.86; with 256 blocks per root — one root at a time per XCD — the launches' own cost ate the gain: 1.56).  Fewer roots:
+    // spread over the whole chip, 256 blocks each (one root: 0.36 -> 0.29 ms at 1 %, 1.59 -> 1.05 at 5 %).  profiles/r06_notes.md r06zd
+    a.xcd_map = nd >= 8u ? 1u : 0u;
+    const uint32_t gx = a.xcd_map ? RP_GX : 256u;
+    const dim3 pg(gx, a.xcd_map ? ((nd + 7u) & ~7u) : nd), tb(256);
     hipLaunchKernelGGL(kr_seed, pg, tb, 0, s, a);
     for (uint32_t r = 0; r < rounds; ++r) hipLaunchKernelGGL(kr_relax, pg, tb, 0, s, a, r);
     hipLaunchKernelGGL(kr_walks, pg, tb, 0, s, a, rounds);

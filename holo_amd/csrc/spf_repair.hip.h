@@ -125,7 +125,7 @@ struct RepairArgs {
   GraphDev g;
   const uint32_t *root_list;   // [n_dyn] indices into roots[] (= the root's slot in the run's slot tables)
   const uint32_t *roots;
-  uint32_t n_dyn, net_nexthops, ignore_ovl;
+  uint32_t n_dyn, net_nexthops, ignore_ovl, xcd_map;
   SlotTabs tabs;
   uint32_t *dist; uint16_t *hops; uint16_t *flags; uint64_t *mask; uint32_t words;
   const uint32_t *row_map;
@@ -174,13 +174,25 @@ __device__ __forceinline__ bool rp_any16(bool p) {                 // over the 1
   return ((__ballot(p) >> (threadIdx.x & 48u)) & 0xFFFFull) != 0ull;
 }
 
-// The per-root view of a phase kernel: block (x, j) works on root j's items x, x + gridDim.x, ... in groups of 16 lanes.
+// The per-root view of a phase kernel: block bx of root j works on the root's items bx, bx + gx, ... in groups of 16 lanes.
+// Placement (a.xcd_map): consecutive workgroups go round-robin to the 8 XCDs, so with the plain (x, j) grid every root's blocks sat on
+// every XCD and each of the eight L2s saw all roots' tables (64 x ~2.5 MB of random 4-byte reads: nothing stayed).  Mapped, workgroup
+// L = x + gridDim.x * y belongs to XCD L % 8 and that XCD works through the roots j = L % 8, L % 8 + 8, ... one after the other,
+// gridDim.x blocks each: a root's distances, hops, masks, order and stamps meet ONE L2, phase after phase (a kernel boundary does
+// not empty it).  Speed only: any placement gives the same result.  The grid is (blocks per root, roots rounded up to 8).
 struct RpRoot {
-  uint32_t j, ri, root, n, W, sub, grp, ngrp;
+  uint32_t j, ri, root, n, W, sub, grp, ngrp, bx, gx; bool live;
   uint32_t *D; uint16_t *H, *F; uint64_t *M; uint32_t *R, *P, *ST, *WL0, *WL1;
   __device__ __forceinline__ RpRoot(const RepairArgs &a) {
-    j = blockIdx.y; ri = a.root_list[j]; root = a.roots[ri]; n = a.g.n; W = a.words;
-    sub = threadIdx.x & 15u; grp = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); ngrp = gridDim.x * (blockDim.x >> 4);
+    gx = gridDim.x;
+    if (a.xcd_map) {
+      const uint32_t L = blockIdx.x + gridDim.x * blockIdx.y, slot = L >> 3;
+      j = (L & 7u) + 8u * (slot / gx); bx = slot % gx;
+    } else { j = blockIdx.y; bx = blockIdx.x; }
+    live = j < a.n_dyn;
+    if (!live) j = 0u;
+    ri = a.root_list[j]; root = a.roots[ri]; n = a.g.n; W = a.words;
+    sub = threadIdx.x & 15u; grp = bx * (blockDim.x >> 4) + (threadIdx.x >> 4); ngrp = gx * (blockDim.x >> 4);
     const size_t orow = a.row_map ? a.row_map[ri] : ri;
     D = a.dist + orow * n; H = a.hops + orow * n; F = a.flags + orow * n; M = a.mask + orow * (size_t)n * W;
     R = a.R + (size_t)j * n; P = a.pos + (size_t)j * n; ST = a.stamp + (size_t)j * n;
@@ -229,10 +241,11 @@ __device__ __forceinline__ bool rp_wake(const RpRoot &r, uint32_t *cnt, uint32_t
 // ---- 1. seeds: R = own index; every other vertex of the list waits for a release path.  Also: HSPF_RF_EXACT on the root's rows.
 __global__ __launch_bounds__(256) void kr_seed(RepairArgs a) {
   const RpRoot r(a);
+  if (!r.live) return;
   const GraphDev &g = a.g;
   const RpCtx c = r.ctx(a);
   // (the rows are those of a root with a dynamic order: "ask for pop_rank if the order matters")
-  for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < r.n; v += gridDim.x * blockDim.x) if (r.F[v] & 1u) r.F[v] = (uint16_t)(r.F[v] | 2u);
+  for (uint32_t v = r.bx * blockDim.x + threadIdx.x; v < r.n; v += r.gx * blockDim.x) if (r.F[v] & 1u) r.F[v] = (uint16_t)(r.F[v] | 2u);
   const uint32_t nz = *a.nz;
   for (uint32_t i = r.grp; i < nz; i += r.ngrp) {
     const uint32_t v = a.zl[i], dv = r.D[v];
@@ -253,6 +266,7 @@ __global__ __launch_bounds__(256) void kr_seed(RepairArgs a) {
 // ---- 2. R = min over zero-cost tight parents of max(R(parent), own index): monotone, to the fixed point (one round per launch)
 __global__ __launch_bounds__(256) void kr_relax(RepairArgs a, uint32_t round) {
   const RpRoot r(a);
+  if (!r.live) return;
   uint32_t *rlast = a.ctl.rlast();
   if (round > 0u && rlast[r.j] + 1u < round) return;               // this root stopped changing (uniform per block)
   const GraphDev &g = a.g;
@@ -288,9 +302,10 @@ __global__ __launch_bounds__(256) void kr_relax(RepairArgs a, uint32_t round) {
 constexpr uint32_t RP_DEEP = 0xFFFFFFFEu;
 __global__ __launch_bounds__(256) void kr_walks(RepairArgs a, uint32_t rounds) {
   const RpRoot r(a);
+  if (!r.live) return;
   const GraphDev &g = a.g;
   const RpCtx c = r.ctx(a);
-  if (a.ctl.rlast()[r.j] + 1u >= rounds) { if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl.fail()[r.j] = 1u; return; }   // R did not settle in the rounds launched
+  if (a.ctl.rlast()[r.j] + 1u >= rounds) { if (r.bx == 0 && threadIdx.x == 0) a.ctl.fail()[r.j] = 1u; return; }   // R did not settle in the rounds launched
   const uint32_t ns = *a.ctl.nsc(r.j);
   uint32_t groups = 0;
   for (uint32_t i = r.grp; i < ns; i += r.ngrp) {
@@ -319,12 +334,13 @@ __global__ __launch_bounds__(256) void kr_walks(RepairArgs a, uint32_t rounds) {
 }
 __global__ __launch_bounds__(256) void kr_walks_deep(RepairArgs a) {
   const RpRoot r(a);
+  if (!r.live) return;
   const GraphDev &g = a.g;
   const RpCtx c = r.ctx(a);
   if (rp_failed(a, r.j)) return;
   const uint32_t ns = *a.ctl.nsc(r.j);
   uint32_t gmax = 0;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += gridDim.x * blockDim.x) {
+  for (uint32_t i = r.bx * blockDim.x + threadIdx.x; i < ns; i += r.gx * blockDim.x) {
     const uint32_t v = r.WL0[i], y = r.R[v], dv = r.D[v];
     if (y == v || y == RP_UNRES || r.P[v] != 1u || r.ST[y] != RP_DEEP) continue;     // the walk: the thread of y's lowest direct child
     const uint32_t k0 = g.out_ptr[y], k1 = g.out_ptr[y + 1];
@@ -363,6 +379,7 @@ __global__ __launch_bounds__(256) void kr_walks_deep(RepairArgs a) {
 // ---- 4. first worklist: a zero-cost tight link from a higher-numbered source; the tight children of non-natural vertices
 __global__ __launch_bounds__(256) void kr_due(RepairArgs a) {
   const RpRoot r(a);
+  if (!r.live) return;
   const GraphDev &g = a.g;
   const RpCtx c = r.ctx(a);
   if (rp_failed(a, r.j)) return;
@@ -399,11 +416,12 @@ __global__ __launch_bounds__(256) void kr_sweep(RepairArgs a, uint32_t sweep) {
   uint32_t *pend = a.ctl.pend();
   if (pend[sweep] == 0u) return;                                     // the sweep before woke nobody: the repair is over
   const RpRoot r(a);
+  if (!r.live) return;
   const GraphDev &g = a.g;
   const RpCtx c = r.ctx(a);
   const uint32_t W = r.W;
   uint32_t *cnt_cur = a.ctl.cnt(sweep % 3u, r.j), *cnt_next = a.ctl.cnt((sweep + 1u) % 3u, r.j);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *a.ctl.cnt((sweep + 2u) % 3u, r.j) = 0u;   // read by the sweep before, filled by the next one
+  if (r.bx == 0 && threadIdx.x == 0) *a.ctl.cnt((sweep + 2u) % 3u, r.j) = 0u;   // read by the sweep before, filled by the next one
   if (rp_failed(a, r.j)) return;
   const uint32_t cnt = *cnt_cur;
   const uint32_t *list = (sweep & 1u) ? r.WL1 : r.WL0;
