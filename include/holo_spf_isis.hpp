@@ -971,9 +971,12 @@ inline std::vector<RibRow> compute_spf(const Instance &inst, Engine &engine, Gra
     per_level[level] = std::move(rib);
   }
   std::map<IpKey, Route> merged;
-  for (int level : {2, 1})
-    for (auto &kv : per_level[level]) merged[kv.first] = kv.second;
+  if (per_level.size() == 1) merged = std::move(per_level.begin()->second);        // (one level: nothing to merge, nothing to copy)
+  else
+    for (int level : {2, 1})
+      for (auto &kv : per_level[level]) merged[kv.first] = kv.second;
   std::vector<RibRow> rows;
+  rows.reserve(merged.size());
   for (auto &kv : merged) {
     RibRow r{kv.second.prefix, kv.second.metric, kv.second.level, {}};
     for (auto &n : kv.second.nexthops) r.nexthops.push_back({n.second.addr, n.second.iface_name});
@@ -991,6 +994,7 @@ inline std::vector<RibRow> compute_spf(const Instance &inst, Engine &engine, Gra
 // table (root independent, built once per LSDB generation); hspf_routes_device reduces it for every root of a run.
 struct PrefixTable {
   std::vector<std::string> prefixes;           // BTreeMap<IpNetwork, _> order
+  std::vector<IpKey> keys;                     // ... and their parsed form
   std::vector<uint32_t> pfx_ptr, pfx_vertex, pfx_metric;
   std::vector<uint8_t> external;
   static PrefixTable build(const Instance &inst, int level, int mt_id, const LevelGraph &g) {
@@ -998,7 +1002,7 @@ struct PrefixTable {
     const bool l2_attached = inst.is_l2_attached_to_backbone(mt_id);
     const bool v4 = cfg.ipv4_enabled && mt_id == MT_STANDARD;
     const bool v6 = cfg.ipv6_enabled && (mt_id == MT_STANDARD ? !cfg.is_topology_enabled(MT_IPV6_UNICAST) : true);
-    struct Row { IpKey key; std::string prefix; uint32_t v, metric; bool ext; size_t seq; };
+    struct Row { IpKey key; std::string prefix; uint32_t v, metric; bool ext; };
     std::vector<Row> rows;
     auto li = inst.lsdb.find(level);
     if (li != inst.lsdb.end())
@@ -1007,15 +1011,24 @@ struct PrefixTable {
         const Lsp *z = li->second.zeroth_lsp(lan);
         if (!z) continue;                                                        // spf.rs:866-869
         const bool att = !cfg.att_ignore && z->att_bit(mt_id) && !z->overload_bit(mt_id);
-        for (auto &net : vertex_networks(inst, level, mt_id, lan, att, l2_attached, v4, v6))
-          rows.push_back({parse_ip(net.prefix), net.prefix, v, net.metric, net.external, rows.size()});
+        auto nets = vertex_networks(inst, level, mt_id, lan, att, l2_attached, v4, v6);
+        for (auto &net : nets) {
+          IpKey key = parse_ip(net.prefix);
+          rows.push_back({key, std::move(net.prefix), v, net.metric, net.external});
+        }
       }
-    std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) { return std::tie(a.key, a.v, a.seq) < std::tie(b.key, b.v, b.seq); });
+    // by (prefix, vertex, order of appearance): the rows were made in (vertex, appearance) order, so a STABLE sort by prefix of
+    // their indices is that order (the rows themselves — a string each — stay where they are)
+    std::vector<uint32_t> order(rows.size());
+    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rows[a].key < rows[b].key; });
     PrefixTable t;
+    t.pfx_vertex.reserve(rows.size()); t.pfx_metric.reserve(rows.size()); t.external.reserve(rows.size());
     t.pfx_ptr.push_back(0);
-    for (size_t i = 0; i < rows.size(); ++i) {
-      if (i == 0 || !(rows[i].key == rows[i - 1].key)) { if (i) t.pfx_ptr.push_back((uint32_t)i); t.prefixes.push_back(rows[i].prefix); }
-      t.pfx_vertex.push_back(rows[i].v); t.pfx_metric.push_back(rows[i].metric); t.external.push_back(rows[i].ext);
+    for (size_t i = 0; i < order.size(); ++i) {
+      Row &r = rows[order[i]];
+      if (i == 0 || !(r.key == rows[order[i - 1]].key)) { if (i) t.pfx_ptr.push_back((uint32_t)i); t.keys.push_back(r.key); t.prefixes.push_back(std::move(r.prefix)); }
+      t.pfx_vertex.push_back(r.v); t.pfx_metric.push_back(r.metric); t.external.push_back(r.ext);
     }
     if (!rows.empty()) t.pfx_ptr.push_back((uint32_t)rows.size());
     return t;
@@ -1023,17 +1036,42 @@ struct PrefixTable {
 };
 
 // compute_spf (spf.rs:719-836) with BOTH the SPT and the prefix attachment on the device; same rows as compute_spf.
-inline std::vector<RibRow> compute_spf_device_routes(const Instance &inst, Engine &engine) {
+// The graph comes from the cache when there is one (as in compute_spf), else straight from the LSDB records through the engine's
+// keyed upload (LevelGraph: 141 ms of host walk -> 9 ms at 100 000 LSPs).  Host work per prefix is a handful of pointer-sized
+// moves: the next hop of every first-hop slot is parsed ONCE (not once per prefix that uses it), the routes arrive in prefix
+// order and are appended to the RIB's end, and a single-level RIB is moved, not copied, into the rows.
+inline std::vector<RibRow> compute_spf_device_routes(const Instance &inst, Engine &engine, GraphCache *cache = nullptr,
+                                                     const std::map<int, std::vector<LanId>> *trigger_lsps = nullptr) {
   const InstanceCfg &cfg = inst.config;
+  const bool tdbg = getenv("HSPF_TWIN_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!tdbg) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[twin device routes] %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   std::map<int, std::map<IpKey, Route>> per_level;
   for (int level : cfg.levels()) {
     std::map<IpKey, Route> rib;
     for (int mt_id : {MT_STANDARD, MT_IPV6_UNICAST}) {
       if (!cfg.is_topology_enabled(mt_id)) continue;
-      auto g = std::make_shared<LevelGraph>(inst, level, mt_id, false);
+      std::unique_ptr<LevelGraph> own;
+      LevelGraph *g = nullptr;
+      if (cache) {
+        static const std::vector<LanId> none;
+        const std::vector<LanId> *trig = nullptr;
+        if (trigger_lsps) { auto ti = trigger_lsps->find(level); trig = ti == trigger_lsps->end() ? &none : &ti->second; }
+        g = &cache->get(inst, level, mt_id, false, trig);
+      } else {
+        own = std::make_unique<LevelGraph>(inst, level, mt_id, false, &engine);
+        g = own.get();
+      }
       auto ri = g->index.find(vertex_id(LanId{cfg.system_id, 0}));
       if (ri == g->index.end()) continue;          // root without LSP: SPT = {root}, zeroth LSP missing -> no routes
+      lap("level graph");
       const PrefixTable table = PrefixTable::build(inst, level, mt_id, *g);
+      lap("prefix table");
       if (table.prefixes.empty()) continue;
       Graph &dev = g->device(engine);
       const uint32_t root = ri->second, n = g->n();
@@ -1050,46 +1088,74 @@ inline std::vector<RibRow> compute_spf_device_routes(const Instance &inst, Engin
         rr = std::make_shared<Tables>(engine.run(dev, {root}, g->run_flags | HSPF_RUN_POP_RANK));
         rank = [rr](uint32_t v) { return RankKey{rr->pop_rank[v], 0, 0, 0}; };
       } else rank = [r](uint32_t v) { return RankKey{r.dist[v], v, 0, 0}; };
+      lap("engine + tables");
       const auto slot_nh = detail::slot_nexthops(*g, engine.slot_table(dev, root), r, rank, true, level, inst);
+      // every slot's next hop, parsed once: [family][slot]
+      struct SlotNh { bool has = false; IpKey key; Nexthop nh; };
+      std::vector<SlotNh> snh[2];
+      snh[0].resize((size_t)W * 64); snh[1].resize((size_t)W * 64);
+      for (auto &kv : slot_nh) {
+        if (kv.first >= (size_t)W * 64) continue;
+        for (int f = 0; f < 2; ++f) {
+          const auto &addr = f ? kv.second->ipv6 : kv.second->ipv4;
+          if (addr) snh[f][kv.first] = SlotNh{true, parse_ip(*addr), Nexthop{*addr, kv.second->iface_name.value_or(""), kv.second->system_id}};
+        }
+      }
+      lap("slot next hops");
+      std::vector<const SlotNh *> pick;
       for (size_t p = 0; p < table.prefixes.size(); ++p) {
         if (ro.best_entry[p] == 0xFFFFFFFFu) continue;
         const std::string &prefix = table.prefixes[p];
         const uint32_t metric = ro.best_metric[p];
-        const bool is6 = prefix.find(':') != std::string::npos;
-        std::map<IpKey, Nexthop> nhs;
+        const IpKey &key = table.keys[p];
+        const std::vector<SlotNh> &fam = snh[key.version == 6 ? 1 : 0];
+        pick.clear();
         for (uint32_t w = 0; w < W; ++w) {
           uint64_t m = ro.nexthop_mask[p * W + w];
           while (m) {
             const int b = __builtin_ctzll(m);
             m &= m - 1;
-            auto it = slot_nh.find(w * 64 + b);
-            if (it == slot_nh.end()) continue;
-            const auto &addr = is6 ? it->second->ipv6 : it->second->ipv4;
-            if (addr) nhs[parse_ip(*addr)] = Nexthop{*addr, it->second->iface_name.value_or(""), it->second->system_id};
+            const SlotNh &sn = fam[w * 64 + b];
+            if (sn.has) pick.push_back(&sn);
           }
         }
-        const IpKey key = parse_ip(prefix);
-        auto it = rib.find(key);
+        // BTreeMap<IpAddr, Nexthop>: ascending address, a later slot with the same address replaces the earlier one
+        std::stable_sort(pick.begin(), pick.end(), [](const SlotNh *a, const SlotNh *b) { return a->key < b->key; });
+        std::map<IpKey, Nexthop> nhs;
+        for (size_t i = 0; i < pick.size(); ++i) {
+          if (i + 1 < pick.size() && pick[i + 1]->key == pick[i]->key) continue;
+          nhs.emplace_hint(nhs.end(), pick[i]->key, pick[i]->nh);
+        }
         Route *cur;
+        const bool at_end = rib.empty() || rib.rbegin()->first < key;           // (the table is in prefix order)
+        auto it = at_end ? rib.end() : rib.find(key);
         if (it == rib.end() || metric < it->second.metric) {
           const uint32_t v = table.pfx_vertex[ro.best_entry[p]];
-          cur = &(rib[key] = Route{prefix, metric, level, (bool)table.external[ro.best_entry[p]], r.hops[v] == 0, nhs});
+          Route fresh{prefix, metric, level, (bool)table.external[ro.best_entry[p]], r.hops[v] == 0, std::move(nhs)};
+          if (at_end) cur = &rib.emplace_hint(rib.end(), key, std::move(fresh))->second;
+          else cur = &(rib[key] = std::move(fresh));
         } else if (metric == it->second.metric) { cur = &it->second; for (auto &kv : nhs) cur->nexthops[kv.first] = kv.second; }
         else continue;
         while (cur->nexthops.size() > cfg.max_paths) cur->nexthops.erase(std::prev(cur->nexthops.end()));
       }
     }
+    lap("rib of the level");
     per_level[level] = std::move(rib);
   }
   std::map<IpKey, Route> merged;
-  for (int level : {2, 1})
-    for (auto &kv : per_level[level]) merged[kv.first] = kv.second;
+  if (per_level.size() == 1) merged = std::move(per_level.begin()->second);
+  else
+    for (int level : {2, 1})
+      for (auto &kv : per_level[level]) merged[kv.first] = kv.second;
   std::vector<RibRow> rows;
+  rows.reserve(merged.size());
   for (auto &kv : merged) {
-    RibRow row{kv.second.prefix, kv.second.metric, kv.second.level, {}};
-    for (auto &nh : kv.second.nexthops) row.nexthops.push_back({nh.second.addr, nh.second.iface_name});
+    RibRow row{std::move(kv.second.prefix), kv.second.metric, kv.second.level, {}};
+    row.nexthops.reserve(kv.second.nexthops.size());
+    for (auto &nh : kv.second.nexthops) row.nexthops.push_back({std::move(nh.second.addr), std::move(nh.second.iface_name)});
     rows.push_back(std::move(row));
   }
+  lap("merge + rows");
   return rows;
 }
 
@@ -1266,7 +1332,7 @@ inline std::vector<IbusMsg> update_global_rib_device(const Instance &inst, Engin
 class RibPipeline {
  public:
   RibPipeline(const Instance &inst, Engine &engine, int level, int mt_id, const std::map<std::string, int> &ifindex)
-      : engine_(engine), level_(level), mt_(mt_id), ifindex_(ifindex), graph_(std::make_unique<LevelGraph>(inst, level, mt_id, false)) {
+      : engine_(engine), level_(level), mt_(mt_id), ifindex_(ifindex), graph_(std::make_unique<LevelGraph>(inst, level, mt_id, false, &engine)) {
     rebuild_tables(inst);
   }
   struct Timing { double refresh_ms = 0, run_ms = 0, routes_ms = 0, slots_ms = 0, diff_pack_ms = 0, expand_ms = 0; size_t records = 0; bool full = false; };
@@ -1278,7 +1344,7 @@ class RibPipeline {
     last = Timing{};
     auto t = C::now();
     if (!changed.empty()) {
-      if (!graph_->refresh(inst, changed)) { graph_ = std::make_unique<LevelGraph>(inst, level_, mt_, false); rebuild_tables(inst); prev_.reset(); last.full = true; }
+      if (!graph_->refresh(inst, changed)) { graph_ = std::make_unique<LevelGraph>(inst, level_, mt_, false, &engine_); rebuild_tables(inst); prev_.reset(); last.full = true; }
       else {
         bool pfx = false;
         for (auto &lan : changed) pfx = pfx || prefixes_of(inst, lan) != pfx_sig_[lan];

@@ -310,6 +310,17 @@ int main(int argc, char **argv) {
     rows = I::compute_spf(inst, te, &cache, &no_triggers);
     const double compute_spf_ms = ms_since(t0);
     if (!rib_path.empty()) dump_rib(rows, rib_path);
+    // the same call with SPT and prefix attachment on the device (graph from the cache as well; checked against `rows`)
+    double dev_routes_cached_ms = 0;
+    bool dev_routes_cached_same = true;
+    {
+      t0 = Clock::now();
+      auto rows3 = I::compute_spf_device_routes(inst, te, &cache, &no_triggers);
+      dev_routes_cached_ms = ms_since(t0);
+      dev_routes_cached_same = rows3.size() == rows.size();
+      for (size_t i = 0; dev_routes_cached_same && i < rows.size(); ++i)
+        dev_routes_cached_same = rows3[i].prefix == rows[i].prefix && rows3[i].metric == rows[i].metric && rows3[i].nexthops == rows[i].nexthops;
+    }
 
     // ---- stage 1b: incremental LSDB -> CSR.  (i) one LSP re-originated with another metric on its first adjacency (cost
     // only), (ii) an adjacency withdrawn by both ends and announced again (structural: two rows change length)
@@ -368,14 +379,14 @@ int main(int argc, char **argv) {
     {
       te.reset();
       t0 = Clock::now();
-      auto rows2 = I::compute_spf_device_routes(inst, te);
+      auto rows2 = I::compute_spf_device_routes(inst, te);           // nothing cached: the graph straight from the LSDB records
       dev_routes_ms = ms_since(t0);
       dev_routes_same = rows2.size() == rows.size();
       for (size_t i = 0; dev_routes_same && i < rows.size(); ++i)
         dev_routes_same = rows2[i].prefix == rows[i].prefix && rows2[i].metric == rows[i].metric && rows2[i].nexthops == rows[i].nexthops;
+      dev_routes_same = dev_routes_same && dev_routes_cached_same;
     }
     const double dev_routes_engine_ms = te.upload_ms + te.run_device_ms + te.routes_ms + te.slot_ms;
-
     // ---- the RUNNING instance: graph, prefix table and the previous route tables resident on the device; per LSP change only
     // the changed records come back (RibPipeline = LevelGraph::refresh + hspf_run_device + hspf_routes_device +
     // hspf_routes_diff_device + hspf_routes_pack x 2 + expansion into RouteIpAdd / RouteIpDel).  Checked against the host
@@ -443,14 +454,14 @@ int main(int argc, char **argv) {
            "\"lsdb_to_csr_incremental\": {\"cost_only_ms\": %.3f, \"cost_only_engine_patch_ms\": %.3f, \"structural_ms\": %.3f, \"structural_engine_patch_ms\": %.3f, \"patched_graph_identical\": %s}, "
            "\"one_root\": {\"run_and_handoff_ms\": %.3f, \"engine_call_ms\": %.3f, \"table_alloc_ms\": %.3f, \"handoff_decode_ms\": %.3f, \"spt_rebuild_ms\": %.2f, \"compute_routes_ms\": %.2f, \"spt_plus_routes_ms\": %.2f, "
            "\"compute_spf_call_ms\": %.2f, \"spt_vertices\": %zu, \"rib_routes\": %zu, \"slowest_stage\": \"%s\"}, "
-           "\"device_routes_path\": {\"compute_spf_device_routes_ms\": %.2f, \"engine_calls_ms\": %.3f, \"same_rib\": %s}, "
+           "\"device_routes_path\": {\"compute_spf_device_routes_ms\": %.2f, \"graph_from_cache_ms\": %.2f, \"engine_calls_ms\": %.3f, \"same_rib\": %s}, "
            "\"running_instance_pipeline\": {\"first_step_ms\": %.2f, \"first_step_messages\": %zu, \"lsp_change_step_ms\": %.3f, \"stages_ms\": {\"refresh_patch\": %.3f, \"run_device\": %.3f, "
            "\"routes_device\": %.3f, \"slot_nexthops\": %.3f, \"diff_pack\": %.3f, \"expand\": %.3f}, \"records_to_host\": %zu, \"messages\": %zu, \"identical_to_host_rule\": %s}",
            engine.c_str(), (hip && packed) ? "true" : "false", n, S.entries, S.prefixes + (n + 4) / 5, inst.interfaces.size(),
            gen_ms, csr_first_ms, hip ? "records streamed to the engine (hspf_graph_upload_keyed): graph resident when it returns" : "host walk", csr_keyed_engine_ms, csr_host_ms,
            keyed_same ? "true" : "false", upload_ms, inc_cost_ms, inc_cost_patch_ms, inc_struct_ms, inc_struct_patch_ms, patched_ok ? "true" : "false",
            run, median(call_v), median(alloc_v), median(decode_v), rebuild, routes, total, compute_spf_ms, spt_size, rib_size, slow->name,
-           dev_routes_ms, dev_routes_engine_ms, dev_routes_same ? "true" : "false",
+           dev_routes_ms, dev_routes_cached_ms, dev_routes_engine_ms, dev_routes_same ? "true" : "false",
            pipe_first_ms, pipe_first_msgs, pipe_step_ms, pt.refresh_ms, pt.run_ms, pt.routes_ms, pt.slots_ms, pt.diff_pack_ms, pt.expand_ms, pipe_records, pipe_msgs, pipe_ok ? "true" : "false");
     if (batch) printf(", \"batch\": {\"roots\": %u, \"run_and_handoff_ms\": %.3f, \"handoff_decode_ms\": %.3f, \"spt_rebuild_ms\": %.2f}", batch, batch_run_ms, batch_decode_ms, batch_rebuild_ms);
     printf("}\n");
