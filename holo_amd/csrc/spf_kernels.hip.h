@@ -1513,7 +1513,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fu
   // round trip — were measured and rejected: an iteration that sees only its own rows' and some neighbouring waves' stores
   // converges worse than a pass behind a pass; 2 / 3 iterations per pass: 22.2 / 25.8 x N rows evaluated instead of 17.9,
   // 0.584 / 0.631 ms per run instead of 0.535.  profiles/r05_notes.md.)
-  if (any != 0ull && lane == 0) changed[sweep] = 1;
+  // A dense launch says "changed" ONCE per pass, whatever it did: the stretch is followed by the all-due sweep in any case (a dense
+  // pass cannot end a run), and 25 000 waves per pass storing the same 1 to the same word were worth 2.4 % of the runs in flight
+  // (three lanes' dense launches side by side: 143.4 / 144.0 -> 146.9 / 147.4 k runs/s on one box; profiles/r06_notes.md r06ze).
+  if (MODE == 1) { if (bx == 0u && batch == 0u && threadIdx.x == 0) changed[sweep] = 1; }
+  else if (any != 0ull && lane == 0) changed[sweep] = 1;
   if (COUNT && lane == 0) atomicAdd(&gp->rows_done[(blockIdx.x + wave) & 255u], n_done);
   if (MODE == 1 && sampler && lane == 0 && n_chg != 0u && pg < 64u) atomicAdd(&ctl[LEAN_CTL_PCH + pg * LEAN_CTL_STRIDE], n_chg);
   if (dyn) raise_dyn(gp, lane_flags, root_slot, blockIdx.x * 4u + wave);
