@@ -1415,6 +1415,10 @@ constexpr uint32_t LEAN_CTL_DUE = 0u, LEAN_CTL_PCH = 64u * LEAN_CTL_STRIDE, LEAN
 constexpr uint32_t LEAN_SAMPLE = 32u;                                             // wave 0 of every 8th block of an XCD's range counts
 constexpr uint32_t LEAN_SENTINEL = 0xFFFFFFFFu;
 template <bool COUNT, int MODE, bool HEAD, bool BMAJ = false>
+// (amdgpu_num_sgpr: 80 leaves 28 scalar spills in the prologue and ~10 reloads per row — v_readlane from a spill VGPR —, 96 keeps the same
+// 8 waves per SIMD with 40 % fewer of them and 104 has none at 7 waves: 148.3 / 148.2 / 146.6 k runs/s in flight, 117.3 / 115.1 / 112.5 k
+// one at a time; and TWENTY extra vector instructions per row cost 4 %, ten 1.5 %: a dense pass is not bound by VALU issue, although the
+// counters show the vector ALUs ~85 % "busy" — profiles/r06_notes.md r06zf.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_fused_lean(
     const FusedGraph *__restrict__ gp, int *changed, int sweep, uint32_t *__restrict__ act,
     const uint8_t *__restrict__ hnb, uint32_t n_arg, const uint32_t *__restrict__ ell_so, const uint32_t *__restrict__ ell_w,
