@@ -162,6 +162,31 @@ class Lsdb {                           // LSPs of one level ordered by LSP id (h
     auto it = by_id_.find(Key{lan.system_id, lan.pseudonode, 0});
     return (it != by_id_.end() && it->second.live()) ? &it->second : nullptr;
   }
+  // The fragments of `lan` for a caller that visits LAN ids in ASCENDING order (a walk over the vertices of a level graph, per
+  // class of vertex): a few steps forward from where the previous visit stood instead of a descent of the tree (two descents
+  // per vertex were 40 of the 48 ms a prefix table of 100 000 vertices took).  Any order is answered correctly — a visit that
+  // does not lie a few LSPs ahead of the cursor descends.  `out`: every fragment, in LSP-id order, live or not (as
+  // iter_for_lan_id); returns the zeroth LSP if it is live (as zeroth_lsp).
+  struct Cursor { std::map<Key, Lsp>::const_iterator at; bool set = false; };
+  const Lsp *fragments_from(Cursor &c, const LanId &lan, std::vector<const Lsp *> &out) const {
+    const Key k{lan.system_id, lan.pseudonode, 0};
+    auto it = by_id_.end();
+    bool found = false;
+    if (c.set && c.at != by_id_.end() && c.at->first < k) {
+      it = c.at;
+      for (int s = 0; s < 8 && !found; ++s) { ++it; found = it == by_id_.end() || !(it->first < k); }
+    }
+    if (!found) it = by_id_.lower_bound(k);
+    c.at = it; c.set = true;
+    out.clear();
+    const Lsp *zeroth = nullptr;
+    for (; it != by_id_.end(); ++it) {
+      if (!(std::get<0>(it->first) == lan.system_id) || std::get<1>(it->first) != lan.pseudonode) break;
+      if (std::get<2>(it->first) == 0 && it->second.live()) zeroth = &it->second;
+      out.push_back(&it->second);
+    }
+    return zeroth;
+  }
  private:
   std::map<Key, Lsp> by_id_;
 };
@@ -773,15 +798,14 @@ struct Route {                         // holo-isis/src/route.rs:27-37
 struct Network { std::string prefix; uint32_t metric; bool external; std::optional<PrefixSid> sid; };
 
 // holo-isis/src/spf.rs:1149-1296
-inline std::vector<Network> vertex_networks(const Instance &inst, int level, int mt_id, const LanId &lan, bool att_bit,
+// (the fragments of the vertex's LAN id handed in: Lsdb::iter_for_lan_id / fragments_from)
+inline std::vector<Network> vertex_networks(const Instance &inst, int level, int mt_id, const std::vector<const Lsp *> &fragments, bool att_bit,
                                             bool l2_attached, bool ipv4_enabled, bool ipv6_enabled) {
   const InstanceCfg &cfg = inst.config;
   const std::string &mt = cfg.metric_type.at(level);
   const bool std_on = mt == "standard" || mt == "both", wide_on = mt == "wide" || mt == "both";
   std::vector<Network> out;
-  auto li = inst.lsdb.find(level);
-  if (li == inst.lsdb.end()) return out;
-  for (const Lsp *lsp : li->second.iter_for_lan_id(lan)) {
+  for (const Lsp *lsp : fragments) {
     if (!lsp->live()) continue;
     if (att_bit && level == 1 && (cfg.level_type == "level-1" || !l2_attached)) {
       if (ipv4_enabled) out.push_back({"0.0.0.0/0", 0, false});
@@ -821,6 +845,12 @@ inline std::vector<Network> vertex_networks(const Instance &inst, int level, int
     }
   }
   return out;
+}
+inline std::vector<Network> vertex_networks(const Instance &inst, int level, int mt_id, const LanId &lan, bool att_bit,
+                                            bool l2_attached, bool ipv4_enabled, bool ipv6_enabled) {
+  auto li = inst.lsdb.find(level);
+  if (li == inst.lsdb.end()) return {};
+  return vertex_networks(inst, level, mt_id, li->second.iter_for_lan_id(lan), att_bit, l2_attached, ipv4_enabled, ipv6_enabled);
 }
 
 inline std::map<IpKey, Nexthop> build_nexthops(const Vertex &v, const std::string &prefix) {     // route.rs:118-142
@@ -895,19 +925,21 @@ inline void compute_routes(int level, int mt_id, const Instance &inst, const Spt
   const bool ipv6_enabled = cfg.ipv6_enabled && (mt_id == MT_STANDARD ? !cfg.is_topology_enabled(MT_IPV6_UNICAST) : true);
   auto li = inst.lsdb.find(level);
   if (li == inst.lsdb.end()) return;
+  Lsdb::Cursor cursor[2];                                               // (VertexId order = ascending LAN ids per class: pseudonodes, routers)
+  std::vector<const Lsp *> fragments;
   for (auto &kv : spt.vertices) {                                       // Spt::iter: VertexId order
     const Vertex &vertex = kv.second;
-    const Lsp *z = li->second.zeroth_lsp(vertex.id.lan_id);
+    const Lsp *z = li->second.fragments_from(cursor[vertex.id.lan_id.pseudonode == 0], vertex.id.lan_id, fragments);
     if (!z) continue;
     const bool att = !cfg.att_ignore && z->att_bit(mt_id) && !z->overload_bit(mt_id);
-    for (auto &net : vertex_networks(inst, level, mt_id, vertex.id.lan_id, att, l2_attached, ipv4_enabled, ipv6_enabled)) {
+    for (auto &net : vertex_networks(inst, level, mt_id, fragments, att, l2_attached, ipv4_enabled, ipv6_enabled)) {
       const IpKey key = parse_ip(net.prefix);
       const uint32_t route_metric = vertex.distance + net.metric;      // route.rs:97, plain `+`
-      auto it = rib.find(key);
+      auto [it, is_new] = rib.try_emplace(key);                        // (one descent of the RIB per network, not three)
       Route *cur;
-      if (it == rib.end() || route_metric < it->second.metric) {
-        rib[key] = Route{net.prefix, route_metric, level, net.external, vertex.hops == 0, build_nexthops(vertex, net.prefix), net.sid, std::nullopt};
-        cur = &rib[key];
+      if (is_new || route_metric < it->second.metric) {
+        it->second = Route{net.prefix, route_metric, level, net.external, vertex.hops == 0, build_nexthops(vertex, net.prefix), net.sid, std::nullopt};
+        cur = &it->second;
       } else if (route_metric == it->second.metric) {
         cur = &it->second;
         for (auto &n : build_nexthops(vertex, net.prefix)) cur->nexthops[n.first] = n.second;
@@ -997,40 +1029,93 @@ struct PrefixTable {
   std::vector<IpKey> keys;                     // ... and their parsed form
   std::vector<uint32_t> pfx_ptr, pfx_vertex, pfx_metric;
   std::vector<uint8_t> external;
-  static PrefixTable build(const Instance &inst, int level, int mt_id, const LevelGraph &g) {
+  using PfxSig = std::vector<std::tuple<std::string, uint32_t, bool>>;     // what one vertex attaches: (prefix, metric, external) in order of appearance
+  // position of a prefix in the table (the keys are in ascending order), or -1
+  long find(const IpKey &k) const {
+    auto it = std::lower_bound(keys.begin(), keys.end(), k);
+    return it != keys.end() && *it == k ? (long)(it - keys.begin()) : -1;
+  }
+  // `sigs` (by vertex index): what every vertex contributed, for the running instance's "did an LSP's prefixes change" check —
+  // from the same pass (a second walk of 100 000 vertices cost 55 ms).  Graphs of 4 096 vertices and more: ranges of vertices on
+  // up to 16 threads (HSPF_KEYED_THREADS, as the keyed LSDB extraction), rows laid end to end in vertex order afterwards.
+  static PrefixTable build(const Instance &inst, int level, int mt_id, const LevelGraph &g, std::vector<PfxSig> *sigs = nullptr) {
     const InstanceCfg &cfg = inst.config;
     const bool l2_attached = inst.is_l2_attached_to_backbone(mt_id);
     const bool v4 = cfg.ipv4_enabled && mt_id == MT_STANDARD;
     const bool v6 = cfg.ipv6_enabled && (mt_id == MT_STANDARD ? !cfg.is_topology_enabled(MT_IPV6_UNICAST) : true);
     struct Row { IpKey key; std::string prefix; uint32_t v, metric; bool ext; };
-    std::vector<Row> rows;
+    const uint32_t n = g.n();
+    if (sigs) { sigs->clear(); sigs->resize(n); }
     auto li = inst.lsdb.find(level);
-    if (li != inst.lsdb.end())
-      for (uint32_t v = 0; v < g.n(); ++v) {
+    unsigned T = 1;
+    if (n >= 4096) {
+      T = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+      if (const char *e = getenv("HSPF_KEYED_THREADS")) T = std::max(1, atoi(e));
+    }
+    std::vector<std::vector<Row>> part(T);
+    auto walk = [&](unsigned k) {
+      std::vector<Row> &rows = part[k];
+      const uint32_t v0 = (uint32_t)((uint64_t)n * k / T), v1 = (uint32_t)((uint64_t)n * (k + 1) / T);
+      Lsdb::Cursor cur[2];                                                       // vertices come in VertexId order: ascending LAN ids per class (pseudonode / router)
+      std::vector<const Lsp *> frags;
+      for (uint32_t v = v0; v < v1; ++v) {
         const LanId lan = g.vids[v].lan_id;
-        const Lsp *z = li->second.zeroth_lsp(lan);
+        const Lsp *z = li->second.fragments_from(cur[lan.pseudonode == 0], lan, frags);
         if (!z) continue;                                                        // spf.rs:866-869
         const bool att = !cfg.att_ignore && z->att_bit(mt_id) && !z->overload_bit(mt_id);
-        auto nets = vertex_networks(inst, level, mt_id, lan, att, l2_attached, v4, v6);
+        auto nets = vertex_networks(inst, level, mt_id, frags, att, l2_attached, v4, v6);
+        if (sigs) { PfxSig &sg = (*sigs)[v]; sg.reserve(nets.size()); for (auto &net : nets) sg.emplace_back(net.prefix, net.metric, net.external); }
         for (auto &net : nets) {
           IpKey key = parse_ip(net.prefix);
           rows.push_back({key, std::move(net.prefix), v, net.metric, net.external});
         }
       }
+    };
+    const bool tdbg = getenv("HSPF_TWIN_TIMING") != nullptr;           // (stage times on stderr, as compute_spf_device_routes)
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!tdbg) return;
+      auto t = std::chrono::steady_clock::now();
+      fprintf(stderr, "[twin prefix table]  %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+      t_prev = t;
+    };
+    if (li != inst.lsdb.end()) {
+      if (T == 1) walk(0);
+      else {
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < T; ++k) th.emplace_back(walk, k);
+        for (auto &t : th) t.join();
+      }
+    }
     // by (prefix, vertex, order of appearance): the rows were made in (vertex, appearance) order, so a STABLE sort by prefix of
-    // their indices is that order (the rows themselves — a string each — stay where they are)
-    std::vector<uint32_t> order(rows.size());
-    for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return rows[a].key < rows[b].key; });
+    // their addresses is that order (the rows themselves — a string each — stay where they are)
+    lap("walk of the vertices");
+    size_t total = 0;
+    for (auto &r : part) total += r.size();
+    // (sorted by VALUE: the key packed into three integers whose order is IpKey's — version, the 16 address bytes, length —
+    // beside the row's address; comparing through 120 000 pointers cost twice as much)
+    struct Ord { uint64_t a, b; uint32_t c; Row *row; };
+    std::vector<Ord> order;
+    order.reserve(total);
+    for (auto &r : part)
+      for (auto &x : r) {
+        uint64_t a = (uint64_t)(uint8_t)x.key.version, b = 0;
+        for (int i = 0; i < 7; ++i) a = (a << 8) | x.key.addr[i];
+        for (int i = 7; i < 15; ++i) b = (b << 8) | x.key.addr[i];
+        order.push_back({a, b, ((uint32_t)x.key.addr[15] << 16) | (uint32_t)(uint16_t)x.key.len, &x});
+      }
+    std::stable_sort(order.begin(), order.end(), [](const Ord &x, const Ord &y) { return std::tie(x.a, x.b, x.c) < std::tie(y.a, y.b, y.c); });
+    lap("sort");
     PrefixTable t;
-    t.pfx_vertex.reserve(rows.size()); t.pfx_metric.reserve(rows.size()); t.external.reserve(rows.size());
+    t.pfx_vertex.reserve(total); t.pfx_metric.reserve(total); t.external.reserve(total);
     t.pfx_ptr.push_back(0);
     for (size_t i = 0; i < order.size(); ++i) {
-      Row &r = rows[order[i]];
-      if (i == 0 || !(r.key == rows[order[i - 1]].key)) { if (i) t.pfx_ptr.push_back((uint32_t)i); t.keys.push_back(r.key); t.prefixes.push_back(std::move(r.prefix)); }
+      Row &r = *order[i].row;
+      if (i == 0 || !(r.key == order[i - 1].row->key)) { if (i) t.pfx_ptr.push_back((uint32_t)i); t.keys.push_back(r.key); t.prefixes.push_back(std::move(r.prefix)); }
       t.pfx_vertex.push_back(r.v); t.pfx_metric.push_back(r.metric); t.external.push_back(r.ext);
     }
-    if (!rows.empty()) t.pfx_ptr.push_back((uint32_t)rows.size());
+    if (total) t.pfx_ptr.push_back((uint32_t)total);
+    lap("lay out");
     return t;
   }
 };
@@ -1052,6 +1137,13 @@ inline std::vector<RibRow> compute_spf_device_routes(const Instance &inst, Engin
     t_prev = t;
   };
   std::map<int, std::map<IpKey, Route>> per_level;
+  // ONE (level, topology) table — the common shape — has nothing to merge: its prefixes come in RIB order, each once, and
+  // go straight into the rows (no intermediate BTreeMap<IpNetwork, Route> with a BTreeMap of next hops per route: two heap
+  // nodes per route made and freed again were a third of the host's share of a 120 000-route cold start)
+  size_t n_tables = 0;
+  for (int mt_id : {MT_STANDARD, MT_IPV6_UNICAST}) n_tables += cfg.is_topology_enabled(mt_id) ? cfg.levels().size() : 0;
+  const bool single = n_tables == 1;
+  std::vector<RibRow> rows;
   for (int level : cfg.levels()) {
     std::map<IpKey, Route> rib;
     for (int mt_id : {MT_STANDARD, MT_IPV6_UNICAST}) {
@@ -1103,6 +1195,7 @@ inline std::vector<RibRow> compute_spf_device_routes(const Instance &inst, Engin
       }
       lap("slot next hops");
       std::vector<const SlotNh *> pick;
+      if (single) rows.reserve(table.prefixes.size());
       for (size_t p = 0; p < table.prefixes.size(); ++p) {
         if (ro.best_entry[p] == 0xFFFFFFFFu) continue;
         const std::string &prefix = table.prefixes[p];
@@ -1121,6 +1214,16 @@ inline std::vector<RibRow> compute_spf_device_routes(const Instance &inst, Engin
         }
         // BTreeMap<IpAddr, Nexthop>: ascending address, a later slot with the same address replaces the earlier one
         std::stable_sort(pick.begin(), pick.end(), [](const SlotNh *a, const SlotNh *b) { return a->key < b->key; });
+        if (single) {
+          RibRow row{prefix, metric, level, {}};
+          row.nexthops.reserve(std::min<size_t>(pick.size(), cfg.max_paths));
+          for (size_t i = 0; i < pick.size() && row.nexthops.size() < cfg.max_paths; ++i) {
+            if (i + 1 < pick.size() && pick[i + 1]->key == pick[i]->key) continue;
+            row.nexthops.push_back({pick[i]->nh.addr, pick[i]->nh.iface_name});
+          }
+          rows.push_back(std::move(row));
+          continue;
+        }
         std::map<IpKey, Nexthop> nhs;
         for (size_t i = 0; i < pick.size(); ++i) {
           if (i + 1 < pick.size() && pick[i + 1]->key == pick[i]->key) continue;
@@ -1142,12 +1245,12 @@ inline std::vector<RibRow> compute_spf_device_routes(const Instance &inst, Engin
     lap("rib of the level");
     per_level[level] = std::move(rib);
   }
+  if (single) return rows;
   std::map<IpKey, Route> merged;
   if (per_level.size() == 1) merged = std::move(per_level.begin()->second);
   else
     for (int level : {2, 1})
       for (auto &kv : per_level[level]) merged[kv.first] = kv.second;
-  std::vector<RibRow> rows;
   rows.reserve(merged.size());
   for (auto &kv : merged) {
     RibRow row{std::move(kv.second.prefix), kv.second.metric, kv.second.level, {}};
@@ -1206,37 +1309,74 @@ inline std::vector<IbusMsg> update_global_rib(const std::vector<RibRow> &new_row
 inline std::vector<IbusMsg> expand_route_records(const RouteRecords &rec, const std::vector<std::string> &prefixes,
                                                  const std::map<uint32_t, std::shared_ptr<VertexNexthop>> &slot_nh,
                                                  const std::map<IpKey, const RibRow *> &old_rows, const std::map<std::string, int> &ifindex, uint32_t max_paths,
-                                                 bool dels_need_old = false) {
+                                                 bool dels_need_old = false, const std::vector<IpKey> *keys = nullptr) {
   std::vector<IbusMsg> adds, dels;
   const uint32_t W = rec.mask_words;
+  // every slot's next hop per address family, resolved ONCE (parsed address, interface index): a cold start expands 120 000
+  // records over a handful of slots.  `keys`: the parsed prefixes when the caller holds them (PrefixTable::keys).
+  struct SlotRes { bool has = false; IpKey key; std::string addr, ifname; int ifx = -1; };
+  std::vector<SlotRes> res[2];
+  res[0].resize((size_t)W * 64); res[1].resize((size_t)W * 64);
+  for (auto &kv : slot_nh) {
+    if (kv.first >= (size_t)W * 64) continue;
+    for (int f = 0; f < 2; ++f) {
+      const auto &addr = f ? kv.second->ipv6 : kv.second->ipv4;
+      if (!addr) continue;
+      SlotRes &sr = res[f][kv.first];
+      sr.has = true; sr.key = parse_ip(*addr); sr.addr = *addr; sr.ifname = kv.second->iface_name.value_or("");
+      auto xi = ifindex.find(sr.ifname);
+      if (xi != ifindex.end()) sr.ifx = xi->second;
+    }
+  }
+  std::vector<const SlotRes *> pick;
+  std::vector<std::pair<std::string, std::string>> keep;
+  adds.reserve(rec.count());
   for (size_t k = 0; k < rec.count(); ++k) {
     const uint32_t *r = rec.rec(k);
     const std::string &prefix = prefixes.at(r[1]);
+    auto key_of = [&]() { return keys ? (*keys)[r[1]] : parse_ip(prefix); };
     if (r[2] == HSPF_DIFF_WITHDRAW) {
       if (r[4] != 0xFFFFFFFFu) continue;
-      if (dels_need_old) { auto oi = old_rows.find(parse_ip(prefix)); if (oi == old_rows.end() || oi->second->nexthops.empty()) continue; }   // (was never installed)
+      if (dels_need_old) { auto oi = old_rows.find(key_of()); if (oi == old_rows.end() || oi->second->nexthops.empty()) continue; }   // (was never installed)
       dels.push_back(IbusMsg{false, prefix, 0, {}});
       continue;
     }
     if (r[2] != HSPF_DIFF_INSTALL) continue;
-    const bool v6 = prefix.find(':') != std::string::npos;
-    std::map<IpKey, std::pair<std::string, std::string>> nhs;
+    const bool v6 = keys ? (*keys)[r[1]].version == 6 : prefix.find(':') != std::string::npos;
+    pick.clear();
     for (uint32_t w = 0; w < W; ++w) {
       uint64_t m = (uint64_t)r[HSPF_ROUTE_REC_WORDS + 2 * w] | ((uint64_t)r[HSPF_ROUTE_REC_WORDS + 2 * w + 1] << 32);
       while (m) {
         const int b = __builtin_ctzll(m);
         m &= m - 1;
-        auto it = slot_nh.find(w * 64 + b);
-        if (it == slot_nh.end()) continue;
-        const auto &addr = v6 ? it->second->ipv6 : it->second->ipv4;
-        if (addr) nhs[parse_ip(*addr)] = {*addr, it->second->iface_name.value_or("")};
+        const SlotRes &sr = res[v6][w * 64 + b];
+        if (sr.has) pick.push_back(&sr);
       }
     }
-    std::vector<std::pair<std::string, std::string>> keep;
-    for (auto &kv : nhs) { if (keep.size() >= max_paths) break; keep.push_back(kv.second); }
-    auto oi = old_rows.find(parse_ip(prefix));
-    if (oi != old_rows.end() && oi->second->metric == r[3] && detail::same_nexthops(oi->second->nexthops, keep)) continue;   // the reference's "unchanged" (:268-277)
-    if (!keep.empty()) adds.push_back(IbusMsg{true, prefix, r[3], detail::wire_nexthops(keep, ifindex)});
+    // BTreeMap<IpAddr, _>: ascending address, a later slot with the same address replaces the earlier one; the first max-paths stay
+    std::stable_sort(pick.begin(), pick.end(), [](const SlotRes *a, const SlotRes *b) { return a->key < b->key; });
+    size_t np = 0;
+    for (size_t i = 0; i < pick.size(); ++i) {
+      if (i + 1 < pick.size() && pick[i + 1]->key == pick[i]->key) continue;
+      pick[np++] = pick[i];
+    }
+    pick.resize(std::min<size_t>(np, max_paths));
+    if (!old_rows.empty()) {
+      auto oi = old_rows.find(key_of());
+      if (oi != old_rows.end() && oi->second->metric == r[3]) {
+        keep.clear();
+        for (const SlotRes *q : pick) keep.push_back({q->addr, q->ifname});
+        if (detail::same_nexthops(oi->second->nexthops, keep)) continue;       // the reference's "unchanged" (:268-277)
+      }
+    }
+    if (pick.empty()) continue;
+    // BTreeSet<Nexthop> order of the message: (ifindex, address)
+    for (const SlotRes *q : pick) if (q->ifx < 0) throw std::out_of_range("expand_route_records: no ifindex for interface '" + q->ifname + "'");
+    std::sort(pick.begin(), pick.end(), [](const SlotRes *a, const SlotRes *b) { return std::tie(a->ifx, a->key) < std::tie(b->ifx, b->key); });
+    IbusMsg msg{true, prefix, r[3], {}};
+    msg.nexthops.reserve(pick.size());
+    for (const SlotRes *q : pick) msg.nexthops.push_back({q->ifx, q->addr});
+    adds.push_back(std::move(msg));
   }
   adds.insert(adds.end(), dels.begin(), dels.end());
   return adds;
@@ -1333,6 +1473,7 @@ class RibPipeline {
  public:
   RibPipeline(const Instance &inst, Engine &engine, int level, int mt_id, const std::map<std::string, int> &ifindex)
       : engine_(engine), level_(level), mt_(mt_id), ifindex_(ifindex), graph_(std::make_unique<LevelGraph>(inst, level, mt_id, false, &engine)) {
+    for (auto &kv : ifindex_) ifname_[kv.second] = kv.first;           // (the last name of an index, as a scan of the map would find it)
     rebuild_tables(inst);
   }
   struct Timing { double refresh_ms = 0, run_ms = 0, routes_ms = 0, slots_ms = 0, diff_pack_ms = 0, expand_ms = 0; size_t records = 0; bool full = false; };
@@ -1347,7 +1488,7 @@ class RibPipeline {
       if (!graph_->refresh(inst, changed)) { graph_ = std::make_unique<LevelGraph>(inst, level_, mt_, false, &engine_); rebuild_tables(inst); prev_.reset(); last.full = true; }
       else {
         bool pfx = false;
-        for (auto &lan : changed) pfx = pfx || prefixes_of(inst, lan) != pfx_sig_[lan];
+        for (auto &lan : changed) pfx = pfx || prefixes_of(inst, lan) != sig_of(lan);
         if (pfx) { rebuild_tables(inst); prev_.reset(); last.full = true; }
       }
     }
@@ -1386,10 +1527,10 @@ class RibPipeline {
       RoutesOut old;
       old.best_metric.assign(P, 0xFFFFFFFFu); old.best_entry.assign(P, 0xFFFFFFFFu); old.nexthop_mask.assign((size_t)P * W, 0);
       for (auto &kv : rib_) {
-        auto wi = where_.find(kv.first);
-        if (wi == where_.end()) continue;
-        old.best_metric[wi->second] = 0xFFFFFFFEu; old.best_entry[wi->second] = 0;         // poisoned: every such pair comes back and the host decides
-        if (!kv.second.nexthops.empty()) old.nexthop_mask[(size_t)wi->second * W] = 1;
+        const long wi = table_.find(kv.first);
+        if (wi < 0) continue;
+        old.best_metric[wi] = 0xFFFFFFFEu; old.best_entry[wi] = 0;                         // poisoned: every such pair comes back and the host decides
+        if (!kv.second.nexthops.empty()) old.nexthop_mask[(size_t)wi * W] = 1;
       }
       prev_ = engine_.routes_upload(old, 1, P, W);
       last.full = true;
@@ -1404,7 +1545,7 @@ class RibPipeline {
     std::map<IpKey, const RibRow *> old_rows;
     for (size_t k = 0; k < rec.count(); ++k) {
       const std::string &prefix = table_.prefixes.at(rec.rec(k)[1]);
-      const IpKey key = parse_ip(prefix);
+      const IpKey &key = table_.keys[rec.rec(k)[1]];
       if (host_old) { auto it = rib_.find(key); if (it != rib_.end()) old_rows[key] = &it->second; continue; }
       const uint32_t *o = rec.old_rec(k);
       if (o[4] == 0xFFFFFFFFu) continue;                               // no route before
@@ -1426,13 +1567,14 @@ class RibPipeline {
       old_store.push_back(std::move(row));
       old_rows[key] = &old_store.back();
     }
-    std::vector<IbusMsg> msgs = expand_route_records(rec, table_.prefixes, slot_nh_, old_rows, ifindex_, cfg.max_paths, true);
+    std::vector<IbusMsg> msgs = expand_route_records(rec, table_.prefixes, slot_nh_, old_rows, ifindex_, cfg.max_paths, true, &table_.keys);
     // prefixes the host knows installed and the (rebuilt) table does not list any more
     if (host_old)
-      for (auto &kv : rib_) if (!where_.count(kv.first) && !kv.second.nexthops.empty()) msgs.push_back(IbusMsg{false, kv.second.prefix, 0, {}});
+      for (auto &kv : rib_) if (table_.find(kv.first) < 0 && !kv.second.nexthops.empty()) msgs.push_back(IbusMsg{false, kv.second.prefix, 0, {}});
     apply(msgs);
     prev_ = std::move(fresh);
     last.expand_ms = ms(t);
+    if (getenv("HSPF_TWIN_TIMING")) fprintf(stderr, "[twin pipeline step]  refresh %.2f run %.2f routes %.2f slots %.2f diff_pack %.2f expand %.2f ms (%zu records)\n", last.refresh_ms, last.run_ms, last.routes_ms, last.slots_ms, last.diff_pack_ms, last.expand_ms, last.records);
     return msgs;
   }
   const std::map<IpKey, RibRow> &rib() const { return rib_; }         // the routes that were put on the wire (installed routes)
@@ -1446,7 +1588,12 @@ class RibPipeline {
           ia->second->ipv4 != ib->second->ipv4 || ia->second->ipv6 != ib->second->ipv6) return false;
     return true;
   }
-  using PfxSig = std::vector<std::tuple<std::string, uint32_t, bool>>;
+  using PfxSig = PrefixTable::PfxSig;
+  const PfxSig &sig_of(const LanId &lan) const {                      // what the vertex attached when the tables were built (nothing: not a vertex then)
+    static const PfxSig none;
+    auto vi = graph_->index.find(vertex_id(lan));
+    return vi == graph_->index.end() || vi->second >= pfx_sig_.size() ? none : pfx_sig_[vi->second];
+  }
   PfxSig prefixes_of(const Instance &inst, const LanId &lan) const {
     PfxSig out;
     auto li = inst.lsdb.find(level_);
@@ -1461,29 +1608,29 @@ class RibPipeline {
     return out;
   }
   void rebuild_tables(const Instance &inst) {
-    table_ = PrefixTable::build(inst, level_, mt_, *graph_);
-    where_.clear();
-    for (size_t i = 0; i < table_.prefixes.size(); ++i) where_[parse_ip(table_.prefixes[i])] = (uint32_t)i;
-    pfx_sig_.clear();
-    for (auto &vid : graph_->vids) pfx_sig_[vid.lan_id] = prefixes_of(inst, vid.lan_id);
+    table_ = PrefixTable::build(inst, level_, mt_, *graph_, &pfx_sig_);
     resident_ = false;
   }
   void apply(const std::vector<IbusMsg> &msgs) {
+    static const std::string no_name;
     for (auto &m : msgs) {
       const IpKey k = parse_ip(m.prefix);
       if (!m.add) { rib_.erase(k); continue; }
       RibRow row{m.prefix, m.metric, level_, {}};
-      for (auto &nh : m.nexthops) { std::string ifn; for (auto &kv : ifindex_) if (kv.second == nh.first) ifn = kv.first; row.nexthops.push_back({nh.second, ifn}); }
-      rib_[k] = std::move(row);
+      row.nexthops.reserve(m.nexthops.size());
+      for (auto &nh : m.nexthops) { auto ni = ifname_.find(nh.first); row.nexthops.push_back({nh.second, ni == ifname_.end() ? no_name : ni->second}); }
+      // (the adds of a step come in prefix order: a cold start appends 120 000 rows to the end of the map)
+      if (rib_.empty() || rib_.rbegin()->first < k) rib_.emplace_hint(rib_.end(), k, std::move(row));
+      else rib_[k] = std::move(row);
     }
   }
   Engine &engine_;
   int level_, mt_;
   std::map<std::string, int> ifindex_;
+  std::map<int, std::string> ifname_;
   std::unique_ptr<LevelGraph> graph_;
   PrefixTable table_;
-  std::map<IpKey, uint32_t> where_;
-  std::map<LanId, PfxSig> pfx_sig_;
+  std::vector<PfxSig> pfx_sig_;                                       // by vertex index of graph_
   std::map<uint32_t, std::shared_ptr<VertexNexthop>> slot_nh_;
   std::unique_ptr<DeviceRoutes> prev_;
   std::map<IpKey, RibRow> rib_;

@@ -51,6 +51,21 @@ def test_cpu_engine_rib_of_the_downsized_twin_matches_the_literal_restatement(n,
     _run_and_check(["--engine", "oracle"], n, tmp_path)
 
 
+@pytest.mark.parametrize("threads", ["1", "7"])
+def test_cpu_engine_prefix_table_on_threads_gives_the_same_rows(threads):
+    """PrefixTable::build walks graphs of 4 096 vertices and more in ranges of vertices on threads (HSPF_KEYED_THREADS) and
+    reads the LSDB through a forward cursor: the rows attached from that table (compute_spf_device_routes, RibPipeline's
+    first step and its LSP-change steps) equal what the host rule makes of compute_spf's SPT on the same instance."""
+    p = subprocess.run([_built(), "--engine", "oracle", "--n", "6000", "--reps", "1", "--batch", "0"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSPF_KEYED_THREADS=threads))
+    assert p.returncode == 0, p.stderr
+    rep = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rep["device_routes_path"]["same_rib"] is True
+    assert rep["running_instance_pipeline"]["identical_to_host_rule"] is True
+    assert rep["running_instance_pipeline"]["first_step_messages"] == rep["one_root"]["rib_routes"] - 2
+    assert rep["one_root"]["rib_routes"] == 7200
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [[], ["--no-packed"]])
 @pytest.mark.parametrize("n", [700, 3000])
