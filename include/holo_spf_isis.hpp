@@ -756,9 +756,16 @@ inline std::vector<Spt> compute_spts(int level, const std::vector<SystemId> &roo
           if (it != slot_nh.end()) vx.nexthops.push_back(it->second);
         }
       }
-      s.vertices[vx.id] = std::move(vx);
+      s.vertices.insert_or_assign(s.vertices.end(), vx.id, std::move(vx));       // (vertex indices are VertexId ranks: appended at the end)
     }
-    std::stable_sort(members.begin(), members.end(), [&](uint32_t a, uint32_t b) { return rank(a) < rank(b); });
+    {                                                                            // pop order: every member's rank ONCE, then the sort
+      std::vector<std::pair<RankKey, uint32_t>> ranked;
+      ranked.reserve(members.size());
+      for (uint32_t v : members) ranked.push_back({rank(v), v});
+      std::stable_sort(ranked.begin(), ranked.end(), [](const std::pair<RankKey, uint32_t> &a, const std::pair<RankKey, uint32_t> &b) { return a.first < b.first; });
+      for (size_t i = 0; i < members.size(); ++i) members[i] = ranked[i].second;
+    }
+    s.pop_order.reserve(members.size());
     for (uint32_t v : members) s.pop_order.push_back(G.vids[v]);
     s.rebuild_ = [keep, res, r, rank, members](std::map<VertexId, std::vector<VertexId>> &out) {
       const LevelGraph &g = *keep;
