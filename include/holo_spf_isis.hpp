@@ -21,6 +21,7 @@
 #include <array>
 #include <chrono>
 #include <cstdint>
+#include <exception>
 #include <functional>
 #include <map>
 #include <memory>
@@ -706,11 +707,19 @@ inline std::vector<Spt> compute_spts(int level, const std::vector<SystemId> &roo
     for (uint32_t j : exact_j) { exact_row[j] = (uint32_t)er.size(); er.push_back(roots[j]); }
     rr = std::make_shared<Tables>(engine.run(dev, er, G.run_flags | HSPF_RUN_POP_RANK));
   }
-  for (uint32_t j = 0; j < roots.size(); ++j) {
+  // One root's Spt is a function of its own rows of the tables: several roots (flooding::manet::init_cache hands in every
+  // neighbour) are rebuilt side by side — the engine calls (one slot table per root) first, on this thread, then the roots on
+  // up to 16 threads (graphs of 4 096 vertices and more; HSPF_KEYED_THREADS as for the LSDB walks; 16 roots at 100 000
+  // vertices were 16 x 15.6 ms one after the other).
+  std::vector<SlotTable> slot_tables;
+  slot_tables.reserve(roots.size());
+  for (uint32_t j = 0; j < roots.size(); ++j) slot_tables.push_back(engine.slot_table(dev, roots[j]));
+  auto rebuild_root = [&](uint32_t j) {
     detail::RunView r{&res->dist[(size_t)j * n], &res->hops[(size_t)j * n], &res->flags[(size_t)j * n], &res->mask[(size_t)j * n * W], W};
     std::function<RankKey(uint32_t)> rank;
-    if (exact_row.count(j)) {
-      const uint32_t *pr = &rr->pop_rank[(size_t)exact_row[j] * n];
+    auto xr = exact_row.find(j);
+    if (xr != exact_row.end()) {
+      const uint32_t *pr = &rr->pop_rank[(size_t)xr->second * n];
       auto hold = rr;
       rank = [pr, hold](uint32_t v) { return RankKey{pr[v], 0, 0, 0}; };
     } else if (G.hopcount) {
@@ -739,7 +748,7 @@ inline std::vector<Spt> compute_spts(int level, const std::vector<SystemId> &roo
       auto hold = res;
       rank = [r, hold](uint32_t v) { return RankKey{r.dist[v], v, 0, 0}; };   // static order
     }
-    const SlotTable st = engine.slot_table(dev, roots[j]);
+    const SlotTable &st = slot_tables[j];
     auto slot_nh = detail::slot_nexthops(G, st, r, rank, local, level, inst);
     Spt &s = spts[where[j]];
     std::vector<uint32_t> members;
@@ -781,6 +790,23 @@ inline std::vector<Spt> compute_spts(int level, const std::vector<SystemId> &roo
         }
       }
     };
+  };
+  unsigned T = 1;
+  if (roots.size() > 1 && n >= 4096) {
+    T = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("HSPF_KEYED_THREADS")) T = std::max(1, atoi(e));
+    T = std::min<unsigned>(T, (unsigned)roots.size());
+  }
+  if (T == 1) for (uint32_t j = 0; j < roots.size(); ++j) rebuild_root(j);
+  else {
+    std::vector<std::exception_ptr> failed(T);
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < T; ++k)
+      th.emplace_back([&, k]() {
+        try { for (uint32_t j = k; j < roots.size(); j += T) rebuild_root(j); } catch (...) { failed[k] = std::current_exception(); }
+      });
+    for (auto &t : th) t.join();
+    for (auto &f : failed) if (f) std::rethrow_exception(f);
   }
   return spts;
 }

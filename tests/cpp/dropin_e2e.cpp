@@ -431,6 +431,7 @@ int main(int argc, char **argv) {
 
     // ---- R roots in one run (flooding::manet::init_cache shape): hand-off and rebuild
     double batch_run_ms = 0, batch_rebuild_ms = 0, batch_decode_ms = 0;
+    bool batch_same = true;
     if (batch) {
       std::vector<I::SystemId> rs;
       for (uint32_t i = 0; i < batch; ++i) rs.push_back(sysid_of((uint32_t)((uint64_t)i * n / batch)));
@@ -441,6 +442,19 @@ int main(int argc, char **argv) {
         const double all = ms_since(t0);
         batch_run_ms = te.run_ms; batch_rebuild_ms = all - te.run_ms;
         if (hip) batch_decode_ms = hip->last_handoff.decode_ms;
+        if (k) continue;
+        // the roots rebuilt side by side (threads) against one root at a time: vertices, distances, hops, next hops, pop order
+        for (size_t i = 0; i < rs.size() && batch_same; ++i) {
+          I::Spt one = I::compute_spt(2, rs[i], false, I::MT_STANDARD, false, inst, te, &G);
+          batch_same = one.vertices.size() == spts[i].vertices.size() && one.pop_order == spts[i].pop_order;
+          auto a = one.vertices.begin();
+          auto b = spts[i].vertices.begin();
+          for (; batch_same && a != one.vertices.end(); ++a, ++b) {
+            batch_same = a->first == b->first && a->second.distance == b->second.distance && a->second.hops == b->second.hops &&
+                         a->second.nexthops.size() == b->second.nexthops.size();
+            for (size_t h = 0; batch_same && h < a->second.nexthops.size(); ++h) batch_same = a->second.nexthops[h]->system_id == b->second.nexthops[h]->system_id;
+          }
+        }
       }
     }
 
@@ -463,7 +477,7 @@ int main(int argc, char **argv) {
            run, median(call_v), median(alloc_v), median(decode_v), rebuild, routes, total, compute_spf_ms, spt_size, rib_size, slow->name,
            dev_routes_ms, dev_routes_cached_ms, dev_routes_engine_ms, dev_routes_same ? "true" : "false",
            pipe_first_ms, pipe_first_msgs, pipe_step_ms, pt.refresh_ms, pt.run_ms, pt.routes_ms, pt.slots_ms, pt.diff_pack_ms, pt.expand_ms, pipe_records, pipe_msgs, pipe_ok ? "true" : "false");
-    if (batch) printf(", \"batch\": {\"roots\": %u, \"run_and_handoff_ms\": %.3f, \"handoff_decode_ms\": %.3f, \"spt_rebuild_ms\": %.2f}", batch, batch_run_ms, batch_decode_ms, batch_rebuild_ms);
+    if (batch) printf(", \"batch\": {\"roots\": %u, \"run_and_handoff_ms\": %.3f, \"handoff_decode_ms\": %.3f, \"spt_rebuild_ms\": %.2f, \"same_as_one_root_at_a_time\": %s}", batch, batch_run_ms, batch_decode_ms, batch_rebuild_ms, batch_same ? "true" : "false");
     printf("}\n");
     return (patched_ok && dev_routes_same && pipe_ok && keyed_same) ? 0 : 1;
   } catch (const std::exception &e) {
