@@ -1402,6 +1402,8 @@ inline std::vector<IbusMsg> expand_route_records(const RouteRecords &rec, const 
         if (detail::same_nexthops(oi->second->nexthops, keep)) continue;       // the reference's "unchanged" (:268-277)
       }
     }
+    // (a route whose next hops did not resolve replaces the old row WITHOUT a message, route.rs:283-301: the fresh route carries
+    // no INSTALLED flag, so nothing is uninstalled either)
     if (pick.empty()) continue;
     // BTreeSet<Nexthop> order of the message: (ifindex, address)
     for (const SlotRes *q : pick) if (q->ifx < 0) throw std::out_of_range("expand_route_records: no ifindex for interface '" + q->ifname + "'");
@@ -1499,14 +1501,16 @@ inline std::vector<IbusMsg> update_global_rib_device(const Instance &inst, Engin
 // resident: nothing is uploaded, nothing but the changed records comes back — packed once from the new set and once from the
 // old one, so that the host sees what each changed route WAS).  The first-hop slots are resolved again every step (which
 // relaxations the root makes depends on distances elsewhere); when a slot comes to mean another next hop, or the prefix list
-// changed, the old tables are void and the step compares against the routes the host knows installed (`rib()`), record by
-// record.  step() = trigger_lsps -> messages.  One (level, topology), local root; interfaces / adjacencies as at
+// changed, the old tables are void and the step compares against the installed routes, record by record.  Which routes ARE
+// installed is read off the previous tables at that moment (settle_installed: rows with resolved next hops), not kept from
+// the messages: a route that loses its next hops changes the RIB without a message (route.rs:283-301; HSPF_DIFF_SILENT, no
+// record) and a set kept from messages would go stale — the random chains of tests/test_cpp_driver.py found exactly that.
+// step() = trigger_lsps -> messages.  One (level, topology), local root; interfaces / adjacencies as at
 // construction (an adjacency change is a new pipeline).
 class RibPipeline {
  public:
   RibPipeline(const Instance &inst, Engine &engine, int level, int mt_id, const std::map<std::string, int> &ifindex)
       : engine_(engine), level_(level), mt_(mt_id), ifindex_(ifindex), graph_(std::make_unique<LevelGraph>(inst, level, mt_id, false, &engine)) {
-    for (auto &kv : ifindex_) ifname_[kv.second] = kv.first;           // (the last name of an index, as a scan of the map would find it)
     rebuild_tables(inst);
   }
   struct Timing { double refresh_ms = 0, run_ms = 0, routes_ms = 0, slots_ms = 0, diff_pack_ms = 0, expand_ms = 0; size_t records = 0; bool full = false; };
@@ -1518,17 +1522,26 @@ class RibPipeline {
     last = Timing{};
     auto t = C::now();
     if (!changed.empty()) {
-      if (!graph_->refresh(inst, changed)) { graph_ = std::make_unique<LevelGraph>(inst, level_, mt_, false, &engine_); rebuild_tables(inst); prev_.reset(); last.full = true; }
+      if (!graph_->refresh(inst, changed)) { settle_installed(); graph_ = std::make_unique<LevelGraph>(inst, level_, mt_, false, &engine_); rebuild_tables(inst); last.full = true; }
       else {
         bool pfx = false;
         for (auto &lan : changed) pfx = pfx || prefixes_of(inst, lan) != sig_of(lan);
-        if (pfx) { rebuild_tables(inst); prev_.reset(); last.full = true; }
+        if (pfx) { settle_installed(); rebuild_tables(inst); last.full = true; }
       }
     }
     last.refresh_ms = ms(t);
     const InstanceCfg &cfg = inst.config;
     auto ri = graph_->index.find(vertex_id(LanId{cfg.system_id, 0}));
-    if (ri == graph_->index.end() || table_.prefixes.empty()) { prev_.reset(); return {}; }
+    if (ri == graph_->index.end() || table_.prefixes.empty()) {
+      // no root LSP (SPT = {root}, no routes: spf.rs:552-561, 866-869) or nothing advertised any more: the new RIB is empty — every
+      // installed route is withdrawn, in RIB order (route.rs:303-310).  (Found by the random LSP changes of tests/test_cpp_driver.py:
+      // until round 6 this returned no message and the routes stayed installed.)
+      settle_installed();
+      std::vector<IbusMsg> msgs;
+      for (auto &kv : rib_) if (!kv.second.nexthops.empty()) msgs.push_back(IbusMsg{false, kv.second.prefix, 0, {}});
+      rib_.clear();
+      return msgs;
+    }
     t = C::now();
     Graph &dev = graph_->device(engine_);
     const uint32_t root = ri->second;
@@ -1550,7 +1563,7 @@ class RibPipeline {
       std::shared_ptr<Tables> rr;
       if (exact) { rr = std::make_shared<Tables>(engine_.run(dev, {root}, graph_->run_flags | HSPF_RUN_POP_RANK)); rank = [rr](uint32_t v) { return RankKey{rr->pop_rank[v], 0, 0, 0}; }; }
       auto nh = detail::slot_nexthops(*graph_, engine_.slot_table(dev, root), r, rank, true, level_, inst);
-      if (prev_ && !same_slots(nh, slot_nh_)) prev_.reset();           // a slot means another next hop now: the old masks are void
+      if (prev_ && !same_slots(nh, slot_nh_)) settle_installed();      // a slot means another next hop now: the old masks are void
       slot_nh_ = std::move(nh);
     }
     last.slots_ms = ms(t); t = C::now();
@@ -1604,13 +1617,27 @@ class RibPipeline {
     // prefixes the host knows installed and the (rebuilt) table does not list any more
     if (host_old)
       for (auto &kv : rib_) if (table_.find(kv.first) < 0 && !kv.second.nexthops.empty()) msgs.push_back(IbusMsg{false, kv.second.prefix, 0, {}});
-    apply(msgs);
+    // the withdrawals go out in the order of the OLD RIB (one pass over a BTreeMap, route.rs:303-310), whichever of the two sources
+    // above a withdrawal came from
+    {
+      auto first_del = std::stable_partition(msgs.begin(), msgs.end(), [](const IbusMsg &m) { return m.add; });
+      if (msgs.end() - first_del > 1) {
+        std::vector<std::pair<IpKey, IbusMsg>> dels;
+        for (auto it = first_del; it != msgs.end(); ++it) dels.push_back({parse_ip(it->prefix), std::move(*it)});
+        std::stable_sort(dels.begin(), dels.end(), [](const std::pair<IpKey, IbusMsg> &a, const std::pair<IpKey, IbusMsg> &b) { return a.first < b.first; });
+        for (size_t i = 0; i < dels.size(); ++i) *(first_del + i) = std::move(dels[i].second);
+      }
+    }
+    rib_.clear();                                                     // (void from here on: settle_installed() reads it off `prev_` when it is needed)
+    max_paths_ = cfg.max_paths;
     prev_ = std::move(fresh);
     last.expand_ms = ms(t);
     if (getenv("HSPF_TWIN_TIMING")) fprintf(stderr, "[twin pipeline step]  refresh %.2f run %.2f routes %.2f slots %.2f diff_pack %.2f expand %.2f ms (%zu records)\n", last.refresh_ms, last.run_ms, last.routes_ms, last.slots_ms, last.diff_pack_ms, last.expand_ms, last.records);
     return msgs;
   }
-  const std::map<IpKey, RibRow> &rib() const { return rib_; }         // the routes that were put on the wire (installed routes)
+  // The installed routes (rows of the RIB that have next hops), read off the tables of the last step (one copy of the tables
+  // to the host: for inspection and tests, not for the per-event path).
+  std::map<IpKey, RibRow> rib() const { return read_installed(); }
   LevelGraph &graph() { return *graph_; }
 
  private:
@@ -1644,29 +1671,65 @@ class RibPipeline {
     table_ = PrefixTable::build(inst, level_, mt_, *graph_, &pfx_sig_);
     resident_ = false;
   }
-  void apply(const std::vector<IbusMsg> &msgs) {
-    static const std::string no_name;
-    for (auto &m : msgs) {
-      const IpKey k = parse_ip(m.prefix);
-      if (!m.add) { rib_.erase(k); continue; }
-      RibRow row{m.prefix, m.metric, level_, {}};
-      row.nexthops.reserve(m.nexthops.size());
-      for (auto &nh : m.nexthops) { auto ni = ifname_.find(nh.first); row.nexthops.push_back({nh.second, ni == ifname_.end() ? no_name : ni->second}); }
-      // (the adds of a step come in prefix order: a cold start appends 120 000 rows to the end of the map)
-      if (rib_.empty() || rib_.rbegin()->first < k) rib_.emplace_hint(rib_.end(), k, std::move(row));
-      else rib_[k] = std::move(row);
+  // The tables of the last step -> `rib_` = the rows that resolve to next hops (prefix, metric, next hops as the route held them:
+  // ascending address, a later slot with the same address replaces the earlier one, the first max-paths), then the tables are
+  // dropped.  One copy of the tables to the host (16 bytes per prefix and mask word) at the few events that void them.
+  void settle_installed() {
+    if (!prev_) return;                                               // (nothing since the last settle: rib_ stands)
+    rib_ = read_installed();
+    prev_.reset();
+  }
+  std::map<IpKey, RibRow> read_installed() const {
+    if (!prev_) return rib_;
+    std::map<IpKey, RibRow> rows;
+    const RoutesOut o = prev_->host();
+    const uint32_t W = prev_->mask_words;
+    struct SlotRes { bool has = false; IpKey key; std::string addr, ifname; };
+    std::vector<SlotRes> res[2];
+    res[0].resize((size_t)W * 64); res[1].resize((size_t)W * 64);
+    for (auto &kv : slot_nh_) {
+      if (kv.first >= (size_t)W * 64) continue;
+      for (int f = 0; f < 2; ++f) {
+        const auto &addr = f ? kv.second->ipv6 : kv.second->ipv4;
+        if (addr) res[f][kv.first] = SlotRes{true, parse_ip(*addr), *addr, kv.second->iface_name.value_or("")};
+      }
     }
+    std::vector<const SlotRes *> pick;
+    const size_t P = std::min<size_t>(table_.prefixes.size(), o.best_entry.size());
+    for (size_t p = 0; p < P; ++p) {
+      if (o.best_entry[p] == 0xFFFFFFFFu) continue;
+      const IpKey &key = table_.keys[p];
+      pick.clear();
+      for (uint32_t w = 0; w < W; ++w) {
+        uint64_t m = o.nexthop_mask[p * W + w];
+        while (m) {
+          const int b = __builtin_ctzll(m);
+          m &= m - 1;
+          const SlotRes &sr = res[key.version == 6 ? 1 : 0][w * 64 + b];
+          if (sr.has) pick.push_back(&sr);
+        }
+      }
+      if (pick.empty()) continue;
+      std::stable_sort(pick.begin(), pick.end(), [](const SlotRes *a, const SlotRes *b) { return a->key < b->key; });
+      RibRow row{table_.prefixes[p], o.best_metric[p], level_, {}};
+      for (size_t i = 0; i < pick.size() && row.nexthops.size() < max_paths_; ++i) {
+        if (i + 1 < pick.size() && pick[i + 1]->key == pick[i]->key) continue;
+        row.nexthops.push_back({pick[i]->addr, pick[i]->ifname});
+      }
+      rows.emplace_hint(rows.end(), key, std::move(row));             // (the table is in RIB order)
+    }
+    return rows;
   }
   Engine &engine_;
   int level_, mt_;
   std::map<std::string, int> ifindex_;
-  std::map<int, std::string> ifname_;
   std::unique_ptr<LevelGraph> graph_;
   PrefixTable table_;
   std::vector<PfxSig> pfx_sig_;                                       // by vertex index of graph_
   std::map<uint32_t, std::shared_ptr<VertexNexthop>> slot_nh_;
   std::unique_ptr<DeviceRoutes> prev_;
-  std::map<IpKey, RibRow> rib_;
+  std::map<IpKey, RibRow> rib_;                                       // installed routes as of the last settle_installed(); void while `prev_` holds tables
+  uint32_t max_paths_ = 16;
   bool resident_ = false;
 };
 

@@ -455,6 +455,34 @@ impl RibPipeline {
             .take(max_paths as usize)
             .collect()
     }
+
+    // The instance's RIB brought in line with the tables of the last event, which are dropped: a change that puts nothing on
+    // the wire leaves no record (HSPF_DIFF_SILENT) — a route that lost its next hops (route.rs:283-301 replaces it by a fresh
+    // route without INSTALLED and sends nothing), a route without next hops whose prefix went away — so a RIB kept from records
+    // alone goes stale, and the next event, which compares against the RIB, would withdraw routes that are not installed
+    // and skip installs that are due.  (Found in the C++ form by random chains of LSP changes, tests/test_cpp_driver.py of the
+    // engine repository; include/holo_spf_isis.hpp `RibPipeline::settle_installed`.)  The metric of a route that lost its next
+    // hops is taken from the tables; its CONNECTED flag is not re-derived (the vertex's hop count left with the run).
+    fn settle(&mut self, rib: &mut BTreeMap<IpNetwork, Route>, max_paths: u16) {
+        let Some(prev) = self.prev.take() else { return };
+        let Ok((metric, entry, mask)) = prev.to_host().map_err(|e| e.log()) else { return };
+        let w = prev.words as usize;
+        for (i, prefix) in self.prefixes.iter().enumerate() {
+            if entry[i] == u32::MAX {
+                if rib.get(prefix).is_some_and(|r| !r.flags.contains(RouteFlags::INSTALLED)) {
+                    rib.remove(prefix);
+                }
+                continue;
+            }
+            if self.nexthops_of(&mask[i * w..(i + 1) * w], prefix.address_family(), max_paths).is_empty()
+                && let Some(route) = rib.get_mut(prefix)
+            {
+                route.metric = metric[i];
+                route.nexthops.clear();
+                route.flags.remove(RouteFlags::INSTALLED);
+            }
+        }
+    }
 }
 
 // compute_routes + route::update_rib for `level` from device tables.  `Some(())`: the instance's RIB and the global RIB are
@@ -483,7 +511,13 @@ pub(crate) fn update_rib(
             let same_vertices = cache.keys == vids;
             let graph = cache.get_or_patch(eng, vids, csr).map_err(|e| e.log()).ok()?;
             let (vids, csr) = (&cache.keys, &cache.csr);
-            let root = vids.binary_search(&VertexId::from(root_system_id)).ok()? as u32;
+            // (no LSP of the root: the caller's compute_routes + route::update_rib handle the event, and the tables kept here
+            // no longer describe the RIB afterwards)
+            let Ok(root) = vids.binary_search(&VertexId::from(root_system_id)) else {
+                ribs.remove(&(level, mt_id));
+                return None;
+            };
+            let root = root as u32;
             // the prefix table: as long as the vertex set stands and no changed LSP advertises other prefixes than before
             let stale = !same_vertices
                 || ribs.get(&(level, mt_id)).is_none_or(|p| {
@@ -496,6 +530,9 @@ pub(crate) fn update_rib(
                     })
                 });
             if stale {
+                if let Some(old) = ribs.get_mut(&(level, mt_id)) {
+                    old.settle(instance.state.rib_mut(instance.config.level_type), instance.config.max_paths);
+                }
                 ribs.insert((level, mt_id), RibPipeline::build(level, mt_id, vids, instance, interfaces, adjacencies, lsp_entries));
             }
             let pipe = ribs.get_mut(&(level, mt_id))?;
@@ -514,12 +551,12 @@ pub(crate) fn update_rib(
                 && slot_nh.iter().zip(&pipe.slot_nh).all(|((sa, a), (sb, b))| {
                     sa == sb && a.system_id == b.system_id && a.iface_idx == b.iface_idx && a.ipv4 == b.ipv4 && a.ipv6 == b.ipv6
                 });
-            if pipe.prev.is_some() && !same_slots {
-                pipe.prev = None; // a slot means another next hop now: the old masks are void
-            }
-            pipe.slot_nh = slot_nh;
             let max_paths = instance.config.max_paths;
             let rib = instance.state.rib_mut(instance.config.level_type);
+            if pipe.prev.is_some() && !same_slots {
+                pipe.settle(rib, max_paths); // a slot means another next hop now: the old masks are void (read with the OLD slots)
+            }
+            pipe.slot_nh = slot_nh;
             // nothing comparable on the device: the stored RIB as "held before" (poisoned metric: every such pair comes back
             // and is decided below, record by record)
             let host_old = pipe.prev.is_none();
@@ -585,6 +622,18 @@ pub(crate) fn update_rib(
                     route.flags.insert(RouteFlags::INSTALLED);
                 }
                 rib.insert(prefix, route);
+            }
+            if host_old {
+                // routes of the RIB whose prefix the (rebuilt) table does not list any more
+                let gone: Vec<IpNetwork> = rib.keys().filter(|p| pipe.prefixes.binary_search(p).is_err()).copied().collect();
+                for prefix in gone {
+                    if let Some(old) = rib.remove(&prefix)
+                        && old.flags.contains(RouteFlags::INSTALLED)
+                    {
+                        withdrawn.push((prefix, old));
+                    }
+                }
+                withdrawn.sort_by(|a, b| a.0.cmp(&b.0)); // one pass over the old RIB in its order (route.rs:303-310)
             }
             for (prefix, route) in withdrawn {
                 ibus::tx::route_uninstall(&instance.tx.ibus, &prefix, &route);

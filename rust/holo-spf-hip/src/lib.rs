@@ -307,6 +307,12 @@ pub struct DeviceRoutes<'e> {
 }
 
 impl DeviceRoutes<'_> {
+    /// Metric, owner entry (all ones: no route) and next-hop mask words of every (root, prefix), on the host: what a caller
+    /// that keeps its own RIB needs when it has to drop these tables (changes that put nothing on the wire leave no record).
+    pub fn to_host(&self) -> Result<(Vec<u32>, Vec<u32>, Vec<u64>), Error> {
+        let rp = self.n_roots as usize * self.n_prefixes as usize;
+        Ok((self.best_metric.to_host(rp)?, self.best_entry.to_host(rp)?, self.nexthop_mask.to_host(rp * self.words as usize)?))
+    }
     fn raw(&self) -> sys::hspf_routes {
         sys::hspf_routes {
             best_metric: self.best_metric.p as *mut u32,

@@ -268,6 +268,9 @@ static std::vector<I::RibRow> rib_rows(const J &rib) {
   }
   return out;
 }
+static void dump(const char *what, const std::vector<I::IbusMsg> &v) {
+  for (auto &m : v) { std::fprintf(stderr, "    %s %s %s metric %u:", what, m.add ? "add" : "del", m.prefix.c_str(), m.metric); for (auto &n : m.nexthops) std::fprintf(stderr, " (%d, %s)", n.first, n.second.c_str()); std::fprintf(stderr, "\n"); }
+}
 static int check_isis_wire(const J &vec, const std::string &golden_dir, Engine &eng, size_t &records, size_t &prefixes, int &pipelines) {
   if (!vec.has("ibus_routes") || !vec.has("rib_before")) return -1;
   if (vec["source"].s.find("nb-config-summary") != std::string::npos) return -1;   // summary routes are configuration, not SPF output (as in tests/test_host_isis.py)
@@ -287,7 +290,9 @@ static int check_isis_wire(const J &vec, const std::string &golden_dir, Engine &
   if (tabs.size() != 1) return 1;                                    // (two tables: the L1 / L2 merge is host logic)
   size_t nr = 0, np = 0;
   if (!(I::update_global_rib_device(inst, eng, before, ifindex, &nr, &np) == want)) { std::fprintf(stderr, "  wire: device form differs\n"); return 0; }
-  if (nr > np || (np && nr > want.size() + 4)) { std::fprintf(stderr, "  wire: %zu records for %zu messages\n", nr, want.size()); return 0; }
+  // (records are CANDIDATES; on the recorded fixtures they stay within four of the messages — random instances with parallel links
+  // and re-ordered slots, marked "random", may hand more pairs to the host's compare)
+  if (nr > np || (np && !vec.has("random") && nr > want.size() + 4)) { std::fprintf(stderr, "  wire: %zu records for %zu messages\n", nr, want.size()); return 0; }
   records += nr; prefixes += np;
   // the running instance: snapshot first, then the step as changed LSPs — when the step kept interfaces and configuration
   const std::string src = vec["source"].s;
@@ -319,7 +324,53 @@ static int check_isis_wire(const J &vec, const std::string &golden_dir, Engine &
   const auto trig = I::changed_lan_ids(i0 == inst0.lsdb.end() ? empty : i0->second, i1 == inst.lsdb.end() ? empty : i1->second);
   const auto msgs = pipe.step(inst, trig);
   // (the recorded sequence starts from `rib_before`, which is the snapshot's RIB whenever the step kept everything else)
-  if (!(msgs == I::update_global_rib(rib_rows(vec["rib"]), rib_rows(base["rib"]), ifindex))) { std::fprintf(stderr, "  wire: pipeline step differs (%zu messages)\n", msgs.size()); return 0; }
+  if (!(msgs == I::update_global_rib(rib_rows(vec["rib"]), rib_rows(base["rib"]), ifindex))) {
+    std::fprintf(stderr, "  wire: pipeline step differs (%zu messages)\n", msgs.size());
+    if (getenv("HSPF_PARITY_DUMP")) {
+      dump("got ", msgs);
+      dump("want", I::update_global_rib(rib_rows(vec["rib"]), rib_rows(base["rib"]), ifindex));
+      std::fprintf(stderr, "    changed LAN ids: %zu, pipeline full %d, records %zu\n", trig.size(), (int)pipe.last.full, pipe.last.records);
+    }
+    return 0;
+  }
+  // further steps on the SAME pipeline (random chains, tests/test_cpp_driver.py): the previous route tables stay on the engine
+  // and the comparison runs there — "next" holds whole vectors (LSDB + the restatement's RIB), interfaces and configuration kept
+  if (vec.has("next")) {
+    I::Instance prev_inst = instance_from_vector(vec);
+    std::vector<I::RibRow> prev_rib = rib_rows(vec["rib"]);
+    for (auto &nx : vec["next"].arr) {
+      I::Instance cur = instance_from_vector(nx);
+      auto p0 = prev_inst.lsdb.find(level), p1 = cur.lsdb.find(level);
+      const auto tr = I::changed_lan_ids(p0 == prev_inst.lsdb.end() ? empty : p0->second, p1 == cur.lsdb.end() ? empty : p1->second);
+      const auto got = pipe.step(cur, tr);
+      const std::vector<I::RibRow> cur_rib = rib_rows(nx["rib"]);
+      if (!(got == I::update_global_rib(cur_rib, prev_rib, ifindex))) {
+        std::fprintf(stderr, "  wire: pipeline differs at a later step of the chain (%zu messages)\n", got.size());
+        if (getenv("HSPF_PARITY_DUMP")) {
+          dump("got ", got); dump("want", I::update_global_rib(cur_rib, prev_rib, ifindex));
+          std::fprintf(stderr, "    changed LAN ids: %zu, pipeline full %d, records %zu\n", tr.size(), (int)pipe.last.full, pipe.last.records);
+        }
+        return 0;
+      }
+      // ... and what the pipeline holds as installed is exactly the RIB's rows with next hops (prefix, metric, next hops)
+      {
+        std::map<IpKey, const I::RibRow *> inst_rows;
+        for (auto &r : cur_rib) if (!r.nexthops.empty()) inst_rows[parse_ip(r.prefix)] = &r;
+        const auto held = pipe.rib();
+        bool same = inst_rows.size() == held.size();
+        for (auto &kv : held) {
+          auto it = inst_rows.find(kv.first);
+          if (it == inst_rows.end() || it->second->metric != kv.second.metric || !I::detail::same_nexthops(it->second->nexthops, kv.second.nexthops)) {
+            same = false;
+            if (getenv("HSPF_PARITY_DUMP")) std::fprintf(stderr, "    installed set: %s metric %u (%zu next hops) is not a row of the RIB with these next hops\n", kv.second.prefix.c_str(), kv.second.metric, kv.second.nexthops.size());
+          }
+        }
+        if (!same) { std::fprintf(stderr, "  wire: the pipeline's installed set differs from the RIB after step %zu of the chain (%zu / %zu rows)\n", (size_t)(&nx - &vec["next"].arr[0]) + 1, held.size(), inst_rows.size()); return 0; }
+      }
+      prev_inst = std::move(cur);
+      prev_rib = cur_rib;
+    }
+  }
   ++pipelines;
   return 1;
 }

@@ -203,6 +203,99 @@ def test_cpp_flooding_manet_reflood_lists_on_gpu(tmp_path):
     assert f"{n_cases} reflood lists checked, 0 differ" in r.stdout
 
 
+def _random_step_files(tmp_path, seeds):
+    """Random (snapshot, step) pairs in the layout of tests/golden (isis/<topo>_<rt>.json + a step vector whose `source` names the
+    snapshot): a random instance (tests/_random_isis.py), then LSP-level changes incl. prefixes gained, lost and re-priced and
+    fragments purged; `rib`, `rib_before` and `ibus_routes` from the literal restatement (oracle/isis_ref.py)."""
+    import copy
+    import json
+    import numpy as np
+    from oracle import isis_ref
+    from _random_isis import make as make_isis
+    from test_host_isis_random import mutate
+    gdir = tmp_path / "golden"
+    (gdir / "isis").mkdir(parents=True)
+    files = []
+    def change(vec, rng):
+        step = mutate(vec, rng) if rng.random() < 0.6 else copy.deepcopy(vec)
+        for _ in range(int(rng.integers(1, 4))):                           # prefix changes: the pipeline's "did an LSP's prefixes change" path
+            zeroth = [l for l in step["lsdb"]["2"] if l["id"].endswith("-00") and (l["ipv4_int"] or l["ext_ipv4"] or l["ipv6"])]
+            if not zeroth:
+                break
+            l = zeroth[int(rng.integers(0, len(zeroth)))]
+            what = int(rng.integers(0, 4))
+            for key in ("ipv4_int", "ext_ipv4", "ipv6"):
+                if not l[key]:
+                    continue
+                if what == 0:
+                    i = int(rng.integers(0, len(l[key])))
+                    l[key][i] = [l[key][i][0], int(rng.integers(0, 30))] + l[key][i][2:]
+                elif what == 1 and len(l[key]) > 1:
+                    l[key].pop(int(rng.integers(0, len(l[key]))))
+                elif what == 2:
+                    new = f"10.9.{int(rng.integers(0, 3))}.0/24" if key != "ipv6" else f"fc09:{int(rng.integers(0, 3))}::/64"
+                    l[key].append([new, int(rng.integers(0, 30))] + ([False] if key != "ipv4_int" else []))
+        for l in step["lsdb"]["2"]:                                        # an LSP that was purged comes back now and then
+            if l.get("lifetime") == 0 and rng.random() < 0.3:
+                del l["lifetime"]
+        step["rib"] = isis_ref.local_rib(step)
+        return step
+
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        base = make_isis(seed, zero=(seed % 4 == 3))
+        base["rib"] = isis_ref.local_rib(base)
+        (gdir / "isis" / f"rnd{seed}_rt0.json").write_text(json.dumps(base))
+        step = change(base, rng)
+        ifindex = {f["name"]: i + 1 for i, f in enumerate(sorted(step["interfaces"], key=lambda f: f["name"]))}
+        step["rib_before"] = base["rib"]
+        step["ifindex"] = ifindex
+        step["ibus_routes"] = isis_ref.update_global_rib(step["rib"], base["rib"], ifindex)
+        step["source"] = f"random step (snapshot rnd{seed}/rt0, seed {seed})"
+        step["random"] = True
+        chain, cur = [], step
+        for _ in range(3):                                                 # three more events on the same running instance
+            cur = change(cur, rng)
+            chain.append({k: cur[k] for k in ("proto", "source", "config", "interfaces", "lsdb", "rib")})
+        step["next"] = chain
+        p = tmp_path / f"step{seed}.json"
+        p.write_text(json.dumps(step))
+        files.append(str(p))
+    return str(gdir), files
+
+
+def test_cpp_running_instance_pipeline_on_random_lsp_changes(tmp_path):
+    """RibPipeline (resident graph, prefix table with per-vertex signatures, record expansion) beyond the 17 recorded step
+    fixtures: 600 random instances, each changed at LSP level four times in a row (metrics, overload bits, neighbours dropped,
+    fragments purged and back, prefixes gained / lost / re-priced) — the messages of every step of the pipeline, of the one-shot
+    device form and of the host rule equal the literal restatement's update_global_rib; the graph patched from the changed
+    LSPs equals a fresh one.  (Its first run found two defects of the pipeline's reset paths: no withdrawals when the root's
+    LSP or the last prefix went away, and withdrawals out of RIB order after a rebuild of the prefix table.)"""
+    from oracle import graph_oracle
+    graph_oracle.build()
+    _build_host()
+    gdir, files = _random_step_files(tmp_path, range(7000, 7600))
+    r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so"), "--replay-steps", gdir] + files,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    import re
+    m = re.search(r"(\d+) recorded ibus sequences .* (\d+) differ; (\d+) also through the running-instance pipeline", r.stdout)
+    assert m and int(m.group(1)) == 600 and int(m.group(2)) == 0 and int(m.group(3)) == 600, r.stdout
+    assert "600 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("HSPF_RANDOM_CHAINS_GPU") != "1",
+                    reason="opt-in (HSPF_RANDOM_CHAINS_GPU=1): written in a session without a GPU, never run on hardware yet")
+def test_cpp_running_instance_pipeline_on_random_lsp_changes_on_gpu(tmp_path):
+    """The same chains with the product engine behind the pipeline (hspf_routes_device / _diff_device / _pack / graph patch)."""
+    _build_host()
+    gdir, files = _random_step_files(tmp_path, range(7000, 7200))
+    r = subprocess.run([HOST, "--engine", "hip", "--replay-steps", gdir] + files, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    assert "200 recorded ibus sequences" in r.stdout and ", 0 differ; 200 also through the running-instance pipeline" in r.stdout
+
+
 def test_cpp_host_side_under_asan_ubsan():
     """the compiled host side (include/holo_spf_{host,isis,ospf}.hpp through tests/cpp/host_parity.cpp) built
     with g++ -fsanitize=address,undefined (-fno-sanitize-recover: any report aborts) and run over every recorded fixture
