@@ -284,6 +284,69 @@ def test_cpp_running_instance_pipeline_on_random_lsp_changes(tmp_path):
     assert "600 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout
 
 
+def _random_ospf_wire_files(tmp_path, seeds):
+    """Random OSPFv2 wire steps in the schema of tests/golden/ospfv2_steps: a random instance (tests/_random_ospf.py) before and
+    after LSA-level changes of the OTHER routers (link costs, links withdrawn, Router- and Network-LSAs aged out and back);
+    `rib_before` / `rib` / `ibus_routes` from the literal restatement (oracle/ospf_ref.py).  Instances whose RIB holds a route
+    with addressed AND unaddressed next hops at once are left out (the restatement's message rule does not model them)."""
+    import copy
+    import json
+    import random
+    from oracle import ospf_ref
+    from _random_ospf import make
+    files = []
+    for seed in seeds:
+        rng = random.Random(seed)
+        v0 = make(seed, zero=(seed % 5 == 4))
+        before = ospf_ref.intra_area_rib(v0)
+        v1 = copy.deepcopy(v0)
+        for area in v1["areas"]:
+            for r in area["routers"]:
+                if r["adv_rtr"] == v1["router_id"]:
+                    continue
+                what = rng.random()
+                if what < 0.3:
+                    for l in r["links"]:
+                        if rng.random() < 0.5:
+                            l["metric"] = rng.randint(0 if seed % 5 == 4 else 1, 12)
+                elif what < 0.38:
+                    r["maxage"] = not r.get("maxage", False)
+                elif what < 0.5 and r["links"]:
+                    r["links"].pop(rng.randrange(len(r["links"])))
+            for nl in area["networks"]:
+                if rng.random() < 0.15:
+                    nl["maxage"] = not nl["maxage"]
+        v1["rib"] = ospf_ref.intra_area_rib(v1)
+        if any(len({a is None for a, _ in r["nexthops"]}) > 1 for r in before + v1["rib"]):
+            continue
+        v1["rib_before"] = before
+        v1["ifindex"] = {nm: k + 2 for k, nm in enumerate(sorted({i["name"] for a in v1["areas"] for i in a["interfaces"]}))}
+        v1["ibus_routes"] = ospf_ref.update_global_rib(v1["rib"], before, v1["ifindex"])
+        v1["source"] = f"random ospf wire step {seed}"
+        p = tmp_path / f"ospf_wire_{seed}.json"
+        p.write_text(json.dumps(v1))
+        files.append(str(p))
+    return files
+
+
+def test_cpp_ospf_wire_step_on_random_lsa_changes(tmp_path):
+    """The OSPFv2 wire step of the compiled host side beyond the 11 recorded sequences: ~390 random instances before / after
+    LSA changes — the host rule and the one-shot device form (areas folded, compared with `rib_before`, packed on the engine)
+    give the literal restatement's RouteIpAdd / RouteIpDel sequence; engine = the CPU oracle."""
+    import re
+    from oracle import graph_oracle
+    graph_oracle.build()
+    _build_host()
+    files = _random_ospf_wire_files(tmp_path, range(9000, 9400))
+    assert len(files) > 350
+    r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so")] + files,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    m = re.search(r"(\d+) recorded OSPFv2 ibus sequences reproduced .*\), (\d+) differ", r.stdout)
+    assert m and int(m.group(1)) == len(files) and int(m.group(2)) == 0, r.stdout
+    assert f"{len(files)} vectors reproduce" in r.stdout and " 0 do not" in r.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(os.environ.get("HSPF_RANDOM_CHAINS_GPU") != "1",
                     reason="opt-in (HSPF_RANDOM_CHAINS_GPU=1): written in a session without a GPU, never run on hardware yet")
