@@ -146,3 +146,38 @@ def add_sr(vec: dict, seed: int) -> dict:
         if sids:
             l["prefix_sids"] = sids
     return v
+
+
+def make_two_level(seed: int) -> dict:
+    """A level-all instance: the level-2 LSDB of make(seed) and a level-1 LSDB derived from it (a sub-area: some routers left
+    out, LSP-level changes, other prefix metrics, ATT bits on some zeroth LSPs), adjacencies usable on one or both levels,
+    foreign area addresses on some (is_l2_attached_to_backbone) — for the L1 / L2 merge of holo-isis/src/route.rs:185-249 and
+    the default route of attached L2 routers (spf.rs:1175-1190)."""
+    import copy
+    from test_host_isis_random import mutate
+    rng = np.random.default_rng(seed + 777)
+    v = make(seed)
+    l1 = copy.deepcopy(v["lsdb"]["2"])
+    drop = {l["id"][:14] for l in l1 if rng.random() < 0.15 and l["id"][:14] != v["config"]["system_id"]}
+    tmp = dict(v)
+    tmp["lsdb"] = {"2": [l for l in l1 if l["id"][:14] not in drop]}
+    for _ in range(3):
+        tmp = mutate(tmp, rng)
+    l1 = tmp["lsdb"]["2"]
+    for l in l1:
+        if l["id"].endswith(".00-00"):
+            if rng.random() < 0.3 and "att" not in l["flags"]:
+                l["flags"] = l["flags"] + ["att"]
+            for key in ("ipv4_int", "ext_ipv4", "ipv6"):
+                for e in l[key]:
+                    if rng.random() < 0.4:
+                        e[1] = int(rng.integers(0, 25))
+    v["lsdb"] = {"1": l1, "2": v["lsdb"]["2"]}
+    v["config"]["level_type"] = "level-all"
+    for f in v["interfaces"]:
+        for a in f["adjacencies"]:
+            a["usage"] = str(rng.choice(["level-all", "level-all", "level-1", "level-2"]))
+            if rng.random() < 0.25:
+                a["area_addrs"] = ["49.0002"]
+    v["source"] = f"random two-level instance {seed}"
+    return v

@@ -35,6 +35,21 @@ def test_random_instances_with_zero_metrics_local_rib_and_all_roots(block):
             check_spts_against_ref(vec, H.Instance.from_vector(vec), eng)
 
 
+@pytest.mark.parametrize("block", range(4))
+def test_random_two_level_instances_local_rib(block):
+    """level-all instances (tests/_random_isis.py make_two_level): one SPT and route set per level, L1 over L2 in the merge
+    (holo-isis/src/route.rs:185-249), the default route of L1 routers towards attached L2 routers."""
+    from _random_isis import make_two_level
+    eng = OracleEngine()
+    both = 0
+    for seed in range(block * 50, block * 50 + 50):
+        vec = make_two_level(seed)
+        want = R.local_rib(vec)
+        assert H.compute_spf(H.Instance.from_vector(vec), eng) == want, seed
+        both += len({r["level"] for r in want}) > 1
+    assert both >= 20
+
+
 def mutate(vec, rng):
     """A few LSP-level changes of the kind the protocol produces: overload bit flips, metric changes, a neighbour
     dropped, a fragment purged (lifetime 0)."""
