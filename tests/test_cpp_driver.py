@@ -206,7 +206,7 @@ def test_cpp_flooding_manet_reflood_lists_on_gpu(tmp_path):
     assert f"{n_cases} reflood lists checked, 0 differ" in r.stdout
 
 
-def _random_step_files(tmp_path, seeds):
+def _random_step_files(tmp_path, seeds, two_level=False):
     """Random (snapshot, step) pairs in the layout of tests/golden (isis/<topo>_<rt>.json + a step vector whose `source` names the
     snapshot): a random instance (tests/_random_isis.py), then LSP-level changes incl. prefixes gained, lost and re-priced and
     fragments purged; `rib`, `rib_before` and `ibus_routes` from the literal restatement (oracle/isis_ref.py)."""
@@ -214,12 +214,21 @@ def _random_step_files(tmp_path, seeds):
     import json
     import numpy as np
     from oracle import isis_ref
-    from _random_isis import make as make_isis
+    from _random_isis import make as make_isis, make_two_level
     from test_host_isis_random import mutate
     gdir = tmp_path / "golden"
     (gdir / "isis").mkdir(parents=True)
     files = []
     def change(vec, rng):
+        if "1" in vec["lsdb"]:                                             # two levels: the same kinds of change on one of them
+            lv = "1" if rng.random() < 0.5 else "2"
+            one = dict(vec)
+            one["lsdb"] = {"2": vec["lsdb"][lv]}
+            one = change(one, rng)
+            step = copy.deepcopy(vec)
+            step["lsdb"][lv] = one["lsdb"]["2"]
+            step["rib"] = isis_ref.local_rib(step)
+            return step
         step = mutate(vec, rng) if rng.random() < 0.6 else copy.deepcopy(vec)
         for _ in range(int(rng.integers(1, 4))):                           # prefix changes: the pipeline's "did an LSP's prefixes change" path
             zeroth = [l for l in step["lsdb"]["2"] if l["id"].endswith("-00") and (l["ipv4_int"] or l["ext_ipv4"] or l["ipv6"])]
@@ -246,7 +255,7 @@ def _random_step_files(tmp_path, seeds):
 
     for seed in seeds:
         rng = np.random.default_rng(seed)
-        base = make_isis(seed, zero=(seed % 4 == 3))
+        base = make_two_level(seed) if two_level else make_isis(seed, zero=(seed % 4 == 3))
         base["rib"] = isis_ref.local_rib(base)
         (gdir / "isis" / f"rnd{seed}_rt0.json").write_text(json.dumps(base))
         step = change(base, rng)
@@ -348,6 +357,22 @@ def test_cpp_ospf_wire_step_on_random_lsa_changes(tmp_path):
     m = re.search(r"(\d+) recorded OSPFv2 ibus sequences reproduced .*\), (\d+) differ", r.stdout)
     assert m and int(m.group(1)) == len(files) and int(m.group(2)) == 0, r.stdout
     assert f"{len(files)} vectors reproduce" in r.stdout and " 0 do not" in r.stdout
+
+
+def test_cpp_wire_step_and_graph_cache_on_random_two_level_lsp_changes(tmp_path):
+    """level-all instances (two tables: the device forms do not apply): the host rule's messages on compute_spf's merged RIB
+    against the restatement's, and both levels' graphs patched from the changed LSPs against fresh ones."""
+    import re
+    from oracle import graph_oracle
+    graph_oracle.build()
+    _build_host()
+    gdir, files = _random_step_files(tmp_path, range(8000, 8200), two_level=True)
+    r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so"), "--replay-steps", gdir] + files,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    m = re.search(r"(\d+) recorded ibus sequences .* (\d+) differ; (\d+) also through the running-instance pipeline", r.stdout)
+    assert m and int(m.group(1)) == 200 and int(m.group(2)) == 0, r.stdout
+    assert "200 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout
 
 
 @pytest.mark.gpu
