@@ -181,3 +181,29 @@ def make_two_level(seed: int) -> dict:
                 a["area_addrs"] = ["49.0002"]
     v["source"] = f"random two-level instance {seed}"
     return v
+
+
+def make_mt(seed: int) -> dict:
+    """MT IPv6-unicast on: a second topology (MT id 2) with its own adjacency entries (a subset of the links, other metrics), its
+    own prefixes (TLV 237) and per-topology overload / attached bits, an entry of a topology that is not enabled (ignored), the
+    local router's adjacencies in one or both topologies (spf.rs:1013-1128, 1149-1296 with mt_id = Ipv6Unicast)."""
+    rng = np.random.default_rng(seed + 4242)
+    v = make(seed)
+    v["config"]["mt_ipv6_unicast"] = True
+    v["config"]["afs"]["ipv6"] = True
+    for l in v["lsdb"]["2"]:
+        src = l["ext_is_reach"] or l["is_reach"]
+        l["mt_is_reach"] = [[2, nbr, int(rng.integers(1, 60)) if rng.random() < 0.5 else m] for nbr, m in src if rng.random() > 0.15]
+        if l["id"].endswith("-00"):
+            fl = (["ol"] if rng.random() < 0.1 else []) + (["att"] if rng.random() < 0.1 else [])
+            l["mt"] = [{"id": 0, "flags": []}, {"id": 2, "flags": fl}] if rng.random() > 0.1 else [{"id": 0, "flags": []}]
+            l["mt_ipv6"] = [[2, p, int(rng.integers(0, 20)), bool(x)] for p, m, x in l["ipv6"]]
+            if rng.random() < 0.3:
+                l["mt_ipv6"].append([2, f"fc07:{int(rng.integers(0, 3))}::/64", int(rng.integers(0, 20)), False])
+            if rng.random() < 0.2:
+                l["mt_ipv6"].append([3, "fc08::/64", 1, False])
+    for f in v["interfaces"]:
+        for a in f["adjacencies"]:
+            a["topologies"] = [0, 2] if rng.random() > 0.2 else ([0] if rng.random() < 0.7 else [2])
+    v["source"] = f"random MT instance {seed}"
+    return v

@@ -50,6 +50,21 @@ def test_random_two_level_instances_local_rib(block):
     assert both >= 20
 
 
+@pytest.mark.parametrize("block", range(3))
+def test_random_multi_topology_instances_local_rib(block):
+    """MT IPv6-unicast instances (tests/_random_isis.py make_mt): the standard topology carries IPv4 only, topology 2 its own
+    links, metrics, prefixes and overload / attached bits; one SPT per topology, one RIB."""
+    from _random_isis import make_mt
+    eng = OracleEngine()
+    v6 = 0
+    for seed in range(block * 50, block * 50 + 50):
+        vec = make_mt(seed)
+        want = R.local_rib(vec)
+        assert H.compute_spf(H.Instance.from_vector(vec), eng) == want, seed
+        v6 += any(":" in r["prefix"] and r["nexthops"] for r in want)
+    assert v6 >= 20
+
+
 def mutate(vec, rng):
     """A few LSP-level changes of the kind the protocol produces: overload bit flips, metric changes, a neighbour
     dropped, a fragment purged (lifetime 0)."""
