@@ -57,6 +57,18 @@ def test_random_isis_instances_and_ospf_areas_through_the_engine(spf_ctx):
         check_ospf(make_ospf(seed), spf_ctx)
 
 
+def test_random_two_level_and_multi_topology_isis_instances_through_the_engine(spf_ctx):
+    """level-all instances (one graph and SPT per level, L1 over L2 in the merge) and MT IPv6-unicast instances (a second topology
+    with its own links, metrics and per-topology overload bits) from tests/_random_isis.py, HIP engine behind the twin, RIBs
+    against the literal restatement.  (Written in a session without a GPU; the same instances pass with the oracle engine.)"""
+    from holo_amd import isis as H
+    from oracle import isis_ref as R
+    from _random_isis import make_mt, make_two_level
+    for seed in range(2000, 2040):
+        for vec in (make_two_level(seed), make_mt(seed)):
+            assert H.compute_spf(H.Instance.from_vector(vec), spf_ctx) == R.local_rib(vec), (seed, vec["source"])
+
+
 def test_random_isis_instances_with_zero_metrics_through_the_engine(spf_ctx):
     """Round 6: a third of the link metrics at 0 — the engine resolves the dynamic pop orders in parallel (k_repair, pop ranks from
     two sorts) and the twin's slot replay / first-hop lists follow those ranks: RIBs and whole SPTs against the literal loop."""
