@@ -313,6 +313,10 @@ def _random_ospf_wire_files(tmp_path, seeds):
     for seed in seeds:
         rng = random.Random(seed)
         v0 = make(seed, zero=(seed % 5 == 4))
+        if seed % 3 == 0:                                      # two or three areas sharing the local router: overlapping prefixes across areas
+            from test_gpu_routes import _multi_area_instance
+            rid, mp, areas = _multi_area_instance(make, seed, rng, 2 + seed % 2)
+            v0 = dict(v0, router_id=rid, max_paths=mp, areas=areas, source=f"random multi-area instance {seed}")
         before = ospf_ref.intra_area_rib(v0)
         v1 = copy.deepcopy(v0)
         for area in v1["areas"]:
@@ -345,9 +349,10 @@ def _random_ospf_wire_files(tmp_path, seeds):
 
 
 def test_cpp_ospf_wire_step_on_random_lsa_changes(tmp_path):
-    """The OSPFv2 wire step of the compiled host side beyond the 11 recorded sequences: ~390 random instances before / after
-    LSA changes — the host rule and the one-shot device form (areas folded, compared with `rib_before`, packed on the engine)
-    give the literal restatement's RouteIpAdd / RouteIpDel sequence; engine = the CPU oracle."""
+    """The OSPFv2 wire step of the compiled host side beyond the 11 recorded sequences: ~390 random instances, a third of them
+    with two or three areas, before / after LSA changes — the host rule and the one-shot device form (areas folded into one RIB,
+    compared with `rib_before`, packed on the engine) give the literal restatement's RouteIpAdd / RouteIpDel sequence; engine =
+    the CPU oracle."""
     import re
     from oracle import graph_oracle
     graph_oracle.build()
@@ -360,6 +365,8 @@ def test_cpp_ospf_wire_step_on_random_lsa_changes(tmp_path):
     m = re.search(r"(\d+) recorded OSPFv2 ibus sequences reproduced .*\), (\d+) differ", r.stdout)
     assert m and int(m.group(1)) == len(files) and int(m.group(2)) == 0, r.stdout
     assert f"{len(files)} vectors reproduce" in r.stdout and " 0 do not" in r.stdout
+    multi = int(re.search(r"(\d+) of them two-area instances", r.stdout).group(1))
+    assert multi > 100, r.stdout
 
 
 def test_cpp_wire_step_and_graph_cache_on_random_two_level_lsp_changes(tmp_path):
