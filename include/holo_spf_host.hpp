@@ -119,9 +119,35 @@ inline void splice_rows(std::vector<uint32_t> &row_ptr, std::vector<uint32_t> &c
                         std::vector<uint8_t> &vflags, const std::vector<uint32_t> &vertices,
                         const std::vector<std::pair<std::vector<uint32_t>, std::vector<uint32_t>>> &rows,
                         const std::vector<uint8_t> &new_flags) {
-  // the stretches BETWEEN the replaced rows move as blocks (one changed row of a million links: two copies per array, not a
-  // million appends: 4 ms -> ~1 ms in the twin's structural refresh)
   const uint32_t n = (uint32_t)row_ptr.size() - 1;
+  if (!vertices.empty() && vertices.size() <= 16) {
+    // a handful of rows (the everyday LSP change): IN PLACE, last row first so that the offsets in front stay valid — the tail
+    // behind a row moves once by its change in length, nothing is allocated; then one pass over the row starts behind the first
+    std::vector<long> d(vertices.size());
+    for (size_t j = vertices.size(); j-- > 0;) {
+      const uint32_t u = vertices[j];
+      const size_t a = row_ptr[u], old_len = row_ptr[u + 1] - a, new_len = rows[j].first.size();
+      d[j] = (long)new_len - (long)old_len;
+      if (new_len > old_len) {
+        col.insert(col.begin() + a + old_len, new_len - old_len, 0u);
+        metric.insert(metric.begin() + a + old_len, new_len - old_len, 0u);
+      } else if (new_len < old_len) {
+        col.erase(col.begin() + a + new_len, col.begin() + a + old_len);
+        metric.erase(metric.begin() + a + new_len, metric.begin() + a + old_len);
+      }
+      std::copy(rows[j].first.begin(), rows[j].first.end(), col.begin() + a);
+      std::copy(rows[j].second.begin(), rows[j].second.end(), metric.begin() + a);
+      vflags[u] = new_flags[j];
+    }
+    long shift = 0;
+    size_t j = 0;
+    for (uint32_t u = vertices[0]; u <= n; ++u) {                        // row u starts behind every replaced row with a lower index
+      while (j < vertices.size() && vertices[j] < u) shift += d[j++];
+      row_ptr[u] = (uint32_t)((long)row_ptr[u] + shift);
+    }
+    return;
+  }
+  // many rows: the stretches BETWEEN the replaced rows move as blocks into exactly sized arrays (not a million appends)
   long delta = 0;
   for (size_t j = 0; j < vertices.size(); ++j) delta += (long)rows[j].first.size() - (long)(row_ptr[vertices[j] + 1] - row_ptr[vertices[j]]);
   const size_t new_len = (size_t)((long)col.size() + delta);
