@@ -251,6 +251,31 @@ static int replay_isis_step(const J &step, const std::string &golden_dir, Engine
     const I::LevelGraph &g = *kv.second;
     if (!(g.vids == fresh.vids) || g.row_ptr != fresh.row_ptr || g.col != fresh.col || g.metric != fresh.metric || g.vflags != fresh.vflags) return 0;
   }
+  // further events on the SAME cache (random chains: "next" holds whole vectors): patch upon patch, rows spliced in place
+  if (step.has("next")) {
+    I::Instance prev = instance_from_vector(step);
+    for (auto &nx : step["next"].arr) {
+      const I::Instance cur = instance_from_vector(nx);
+      std::map<int, std::vector<I::LanId>> tr;
+      for (int level : {1, 2}) {
+        const I::Instance &was = prev;
+        auto i0 = was.lsdb.find(level), i1 = cur.lsdb.find(level);
+        tr[level] = I::changed_lan_ids(i0 == prev.lsdb.end() ? empty : i0->second, i1 == cur.lsdb.end() ? empty : i1->second);
+      }
+      const int b4 = cache.patched;
+      if (!rows_equal(I::compute_spf(cur, eng, &cache, &tr), nx["rib"])) { std::fprintf(stderr, "  replay: RIB differs at a later step of the chain\n"); return 0; }
+      patched += cache.patched - b4;
+      for (auto &kv : cache.graphs) {
+        const int level = std::get<0>(kv.first), mt = std::get<1>(kv.first);
+        const auto levels = cur.config.levels();
+        if (std::find(levels.begin(), levels.end(), level) == levels.end() || !cur.config.is_topology_enabled(mt)) continue;
+        I::LevelGraph fresh(cur, level, mt < 0 ? std::optional<int>() : std::optional<int>(mt), std::get<2>(kv.first));
+        const I::LevelGraph &g = *kv.second;
+        if (!(g.vids == fresh.vids) || g.row_ptr != fresh.row_ptr || g.col != fresh.col || g.metric != fresh.metric || g.vflags != fresh.vflags) { std::fprintf(stderr, "  replay: a graph patched several times differs from a fresh one\n"); return 0; }
+      }
+      prev = cur;
+    }
+  }
   return 1;
 }
 
