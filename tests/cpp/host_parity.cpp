@@ -510,6 +510,24 @@ static int replay_ospf_step(const J &step, const std::string &golden_dir, Engine
     const O::AreaGraph &g = *cache.graphs.at(n.area_id);
     if (g.vids != fresh.vids || g.row_ptr != fresh.row_ptr || g.col != fresh.col || g.metric != fresh.metric || g.link_pos != fresh.link_pos) return 0;
   }
+  // further events on the SAME cache (random chains: "next" holds whole vectors): patch upon patch
+  if (step.has("next")) {
+    auto prev = areas1;
+    for (auto &nx : step["next"].arr) {
+      const auto cur = areas_from_vector(nx);
+      std::map<std::string, std::vector<O::VertexId>> tr;
+      for (auto &n : cur) for (auto &o : prev) if (o.area_id == n.area_id) tr[n.area_id] = O::changed_vertex_ids(o, n);
+      const int b4 = cache.patched;
+      if (!ospf_rows_equal(O::compute_spf_intra_area(nx["router_id"].s, cur, (uint32_t)nx["max_paths"].i(), eng, &cache, &tr), nx["rib"])) { std::fprintf(stderr, "  replay: OSPF RIB differs at a later step of the chain\n"); return 0; }
+      patched += cache.patched - b4;
+      for (auto &n : cur) {
+        O::AreaGraph fresh(n);
+        const O::AreaGraph &g = *cache.graphs.at(n.area_id);
+        if (g.vids != fresh.vids || g.row_ptr != fresh.row_ptr || g.col != fresh.col || g.metric != fresh.metric || g.link_pos != fresh.link_pos) { std::fprintf(stderr, "  replay: an area graph patched several times differs from a fresh one\n"); return 0; }
+      }
+      prev = cur;
+    }
+  }
   return 1;
 }
 

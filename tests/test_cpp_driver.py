@@ -299,7 +299,7 @@ def test_cpp_running_instance_pipeline_on_random_lsp_changes(tmp_path):
     assert "600 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout
 
 
-def _random_ospf_wire_files(tmp_path, seeds):
+def _random_ospf_wire_files(tmp_path, seeds, chains=False):
     """Random OSPFv2 wire steps in the schema of tests/golden/ospfv2_steps: a random instance (tests/_random_ospf.py) before and
     after LSA-level changes of the OTHER routers (link costs, links withdrawn, Router- and Network-LSAs aged out and back);
     `rib_before` / `rib` / `ibus_routes` from the literal restatement (oracle/ospf_ref.py).  Instances whose RIB holds a route
@@ -310,14 +310,8 @@ def _random_ospf_wire_files(tmp_path, seeds):
     from oracle import ospf_ref
     from _random_ospf import make
     files = []
-    for seed in seeds:
-        rng = random.Random(seed)
-        v0 = make(seed, zero=(seed % 5 == 4))
-        if seed % 3 == 0:                                      # two or three areas sharing the local router: overlapping prefixes across areas
-            from test_gpu_routes import _multi_area_instance
-            rid, mp, areas = _multi_area_instance(make, seed, rng, 2 + seed % 2)
-            v0 = dict(v0, router_id=rid, max_paths=mp, areas=areas, source=f"random multi-area instance {seed}")
-        before = ospf_ref.intra_area_rib(v0)
+
+    def change(v0, rng, zero):
         v1 = copy.deepcopy(v0)
         for area in v1["areas"]:
             for r in area["routers"]:
@@ -327,7 +321,7 @@ def _random_ospf_wire_files(tmp_path, seeds):
                 if what < 0.3:
                     for l in r["links"]:
                         if rng.random() < 0.5:
-                            l["metric"] = rng.randint(0 if seed % 5 == 4 else 1, 12)
+                            l["metric"] = rng.randint(0 if zero else 1, 12)
                 elif what < 0.38:
                     r["maxage"] = not r.get("maxage", False)
                 elif what < 0.5 and r["links"]:
@@ -336,12 +330,34 @@ def _random_ospf_wire_files(tmp_path, seeds):
                 if rng.random() < 0.15:
                     nl["maxage"] = not nl["maxage"]
         v1["rib"] = ospf_ref.intra_area_rib(v1)
+        return v1
+
+    if chains:
+        (tmp_path / "golden" / "ospfv2").mkdir(parents=True)
+    for seed in seeds:
+        rng = random.Random(seed)
+        v0 = make(seed, zero=(seed % 5 == 4))
+        if seed % 3 == 0:                                      # two or three areas sharing the local router: overlapping prefixes across areas
+            from test_gpu_routes import _multi_area_instance
+            rid, mp, areas = _multi_area_instance(make, seed, rng, 2 + seed % 2)
+            v0 = dict(v0, router_id=rid, max_paths=mp, areas=areas, source=f"random multi-area instance {seed}")
+        before = ospf_ref.intra_area_rib(v0)
+        v1 = change(v0, rng, seed % 5 == 4)
         if any(len({a is None for a, _ in r["nexthops"]}) > 1 for r in before + v1["rib"]):
             continue
         v1["rib_before"] = before
         v1["ifindex"] = {nm: k + 2 for k, nm in enumerate(sorted({i["name"] for a in v1["areas"] for i in a["interfaces"]}))}
         v1["ibus_routes"] = ospf_ref.update_global_rib(v1["rib"], before, v1["ifindex"])
         v1["source"] = f"random ospf wire step {seed}"
+        if chains:                                             # snapshot + three more events on the same graph cache (replay_ospf_step)
+            v0["rib"] = before
+            (tmp_path / "golden" / "ospfv2" / f"rnd{seed}_rt0.json").write_text(json.dumps(v0))
+            v1["source"] = f"random ospf step (snapshot rnd{seed}/rt0, seed {seed})"
+            cur, nxt = v1, []
+            for _ in range(3):
+                cur = change(cur, rng, seed % 5 == 4)
+                nxt.append({k: cur[k] for k in ("proto", "source", "router_id", "max_paths", "has_vlinks", "areas", "rib")})
+            v1["next"] = nxt
         p = tmp_path / f"ospf_wire_{seed}.json"
         p.write_text(json.dumps(v1))
         files.append(str(p))
@@ -383,6 +399,21 @@ def test_cpp_wire_step_and_graph_cache_on_random_two_level_lsp_changes(tmp_path)
     m = re.search(r"(\d+) recorded ibus sequences .* (\d+) differ; (\d+) also through the running-instance pipeline", r.stdout)
     assert m and int(m.group(1)) == 200 and int(m.group(2)) == 0, r.stdout
     assert "200 step tests replayed through patched graphs" in r.stdout and ", 0 differ" in r.stdout
+
+
+def test_cpp_ospf_graph_cache_on_random_chains_of_lsa_changes(tmp_path):
+    """OSPFv2 area graphs kept current from the changed LSAs (GraphCache: rows patched, spliced in place) over chains of four
+    events on the same cache: the RIB of every event equals the restatement's, every patched graph a fresh one."""
+    import re
+    from oracle import graph_oracle
+    graph_oracle.build()
+    _build_host()
+    files = _random_ospf_wire_files(tmp_path, range(12000, 12300), chains=True)
+    r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so"), "--replay-steps", str(tmp_path / "golden")] + files,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    m = re.search(r"(\d+) step tests replayed through patched graphs \((\d+) row-patch refreshes\), (\d+) differ", r.stdout)
+    assert m and int(m.group(1)) == len(files) and int(m.group(3)) == 0 and int(m.group(2)) > len(files), r.stdout
 
 
 @pytest.mark.gpu
