@@ -207,3 +207,46 @@ def make_mt(seed: int) -> dict:
             a["topologies"] = [0, 2] if rng.random() > 0.2 else ([0] if rng.random() < 0.7 else [2])
     v["source"] = f"random MT instance {seed}"
     return v
+
+
+def make_long(seed: int) -> dict:
+    """A long chain of routers with narrow metrics near their maximum (63): path metrics cross MAX_PATH_METRIC_STANDARD = 1023
+    (spf.rs:637-641) a dozen and a half hops out — vertices beyond it must stay off the SPT; a few chords, some with a cheap way back."""
+    rng = np.random.default_rng(seed + 99)
+    n = int(rng.integers(22, 31))
+    mtype = "standard"      # ("both" lists every adjacency twice: the reference's next-hop list then doubles per hop, 2^29 entries at the far end)
+    local = int(rng.integers(1, 4))
+    links = []
+    for a in range(1, n):
+        m = int(rng.integers(45, 64)); links.append((a, a + 1, m, m if rng.random() < 0.8 else int(rng.integers(45, 64))))
+    for _ in range(int(rng.integers(0, 4))):
+        a = int(rng.integers(1, n - 3)); b = int(rng.integers(a + 2, min(n, a + 6) + 1))
+        m = int(rng.integers(30, 64)); links.append((a, b, m, m))
+    std_on, wide_on = True, mtype == "both"
+    lsps = []
+    for r in range(1, n + 1):
+        nbrs = []
+        for a, b, mab, mba in links:
+            if a == r: nbrs.append((f"{sid(b)}.00", mab))
+            if b == r: nbrs.append((f"{sid(a)}.00", mba))
+        pf4 = [[f"{r}.{r}.{r}.{r}/32", int(rng.integers(0, 20))]]
+        if rng.random() < 0.5: pf4.append([f"10.{int(rng.integers(0, 3))}.0.0/24", int(rng.integers(0, 40))])
+        pf6 = [[f"2001:db8::{r:x}/128", int(rng.integers(0, 20)), False]]
+        lsps.append({"id": f"{sid(r)}.00-00", "flags": [], "protocols": [204, 142],
+                     "is_reach": [[x, m] for x, m in nbrs] if std_on else [], "ext_is_reach": [[x, m] for x, m in nbrs] if wide_on else [],
+                     "mt": [], "mt_is_reach": [], "mt_ipv6": [], "ipv4_int": pf4, "ipv4_ext": [],
+                     "ext_ipv4": [[p, m, False] for p, m in pf4] if wide_on else [], "ipv6": pf6})
+    ifaces, k = [], 0
+    for a, b, mab, mba in links:
+        if local in (a, b):
+            other, m = (b, mab) if a == local else (a, mba)
+            k += 1
+            ifaces.append({"name": f"eth{k:02d}", "type": "point-to-point", "metric": {"1": m, "2": m},
+                           "adjacencies": [{"system_id": sid(other), "usage": "level-2", "state": "up", "ipv4": [f"10.{local}.{k}.{other}"],
+                                            "ipv6": [f"fe80::{local:x}:{k:x}:{other:x}"], "topologies": [0], "area_addrs": ["49.0000"]}]})
+    ifaces.append({"name": "lo", "type": "broadcast", "metric": {"1": 10, "2": 10}, "adjacencies": []})
+    return {"proto": "isis", "source": f"random long chain {seed}",
+            "config": {"system_id": sid(local), "level_type": "level-2", "metric_type": {"1": mtype, "2": mtype},
+                       "afs": {"ipv4": True, "ipv6": True}, "mt_ipv6_unicast": False, "max_paths": int(rng.choice([1, 2, 16])),
+                       "att_ignore": False, "area_addrs": ["49.0000"]},
+            "interfaces": ifaces, "lsdb": {"2": lsps}, "rib": []}

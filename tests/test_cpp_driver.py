@@ -112,7 +112,7 @@ def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_
     rows = the literal restatements' RIBs (oracle/isis_ref.py, oracle/ospf_ref.py), engine = the CPU oracle."""
     import json
     from oracle import graph_oracle, isis_ref, ospf_ref, ospfv3_ref
-    from _random_isis import add_sr, make as make_isis, make_mt, make_two_level
+    from _random_isis import add_sr, make as make_isis, make_long, make_mt, make_two_level
     from _random_ospf import make as make_ospf
     from _random_ospfv3 import make as make_ospfv3
     graph_oracle.build()
@@ -133,6 +133,9 @@ def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_
         t = make_mt(seed)                                      # MT IPv6-unicast: a second topology with its own links and prefixes
         t["rib"] = isis_ref.local_rib(t)
         p = tmp_path / f"isis_mt_{seed}.json"; p.write_text(json.dumps(t)); files.append(str(p))
+        t = make_long(seed)                                    # a long chain: path metrics beyond MAX_PATH_METRIC_STANDARD
+        t["rib"] = isis_ref.local_rib(t)
+        p = tmp_path / f"isis_long_{seed}.json"; p.write_text(json.dumps(t)); files.append(str(p))
         w = make_ospf(seed)
         w["rib"] = ospf_ref.intra_area_rib(w)
         p = tmp_path / f"ospf_{seed}.json"; p.write_text(json.dumps(w)); files.append(str(p))
@@ -150,7 +153,7 @@ def test_cpp_host_side_on_random_instances_against_the_literal_restatements(tmp_
     r = subprocess.run([HOST, "--engine", "oracle", "--oracle-so", os.path.join(ROOT, "oracle", "liboracle_spf.so")] + files,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr[-3000:]
-    assert "808 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
+    assert "958 vectors reproduce" in r.stdout and " 0 do not" in r.stdout
     assert labelled > 100                                      # (the SR vectors do carry labels: 186 rows)
 
 

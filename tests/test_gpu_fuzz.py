@@ -63,9 +63,9 @@ def test_random_two_level_and_multi_topology_isis_instances_through_the_engine(s
     against the literal restatement.  (Written in a session without a GPU; the same instances pass with the oracle engine.)"""
     from holo_amd import isis as H
     from oracle import isis_ref as R
-    from _random_isis import make_mt, make_two_level
+    from _random_isis import make_long, make_mt, make_two_level
     for seed in range(2000, 2040):
-        for vec in (make_two_level(seed), make_mt(seed)):
+        for vec in (make_two_level(seed), make_mt(seed), make_long(seed)):     # make_long: path metrics beyond the maximum (spf.rs:637-641)
             assert H.compute_spf(H.Instance.from_vector(vec), spf_ctx) == R.local_rib(vec), (seed, vec["source"])
 
 

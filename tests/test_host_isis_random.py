@@ -50,6 +50,20 @@ def test_random_two_level_instances_local_rib(block):
     assert both >= 20
 
 
+def test_random_long_chains_beyond_the_maximum_path_metric():
+    """22-30 routers in a line with narrow metrics near 63 (tests/_random_isis.py make_long): path metrics cross
+    MAX_PATH_METRIC_STANDARD = 1023 (holo-isis/src/spf.rs:637-641) and the routers beyond stay off the SPT."""
+    from _random_isis import make_long
+    eng = OracleEngine()
+    cut = 0
+    for seed in range(100):
+        vec = make_long(seed)
+        want = R.local_rib(vec)
+        assert H.compute_spf(H.Instance.from_vector(vec), eng) == want, seed
+        cut += sum(1 for r in want if r["prefix"].endswith("/32")) < len(vec["lsdb"]["2"])
+    assert cut >= 40
+
+
 @pytest.mark.parametrize("block", range(3))
 def test_random_multi_topology_instances_local_rib(block):
     """MT IPv6-unicast instances (tests/_random_isis.py make_mt): the standard topology carries IPv4 only, topology 2 its own
