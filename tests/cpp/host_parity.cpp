@@ -178,6 +178,40 @@ static bool check_hash_kat() {
   }
   return true;
 }
+// Lsdb::fragments_from (the forward cursor of the vertex walks) against iter_for_lan_id + zeroth_lsp: ascending visits (the
+// stepping path), visits that skip far ahead, repeated and DESCENDING visits (the descent fallback), LAN ids without any LSP.
+static bool check_lsdb_cursor() {
+  uint64_t x = 88172645463325252ull;
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  I::Lsdb db;
+  std::vector<I::LanId> lans;
+  for (int i = 0; i < 400; ++i) {
+    I::LanId lan{};
+    lan.system_id[4] = (uint8_t)(rnd() % 40); lan.system_id[5] = (uint8_t)(rnd() % 6);
+    lan.pseudonode = rnd() % 3 ? 0 : (uint8_t)(rnd() % 4);
+    lans.push_back(lan);
+    if (rnd() % 5 == 0) continue;                                       // a LAN id nobody originated
+    const int nf = 1 + (int)(rnd() % 12);
+    for (int f = 0; f < nf; ++f) {
+      if (f == 0 && rnd() % 6 == 0) continue;                          // no zeroth fragment
+      I::Lsp l; l.system_id = lan.system_id; l.pseudonode = lan.pseudonode; l.fragment = (uint8_t)f;
+      l.seqno = rnd() % 7 ? 1 : 0; l.rem_lifetime = rnd() % 7 ? 100 : 0;
+      db.insert(l);
+    }
+  }
+  auto same = [&](I::Lsdb::Cursor &c, const I::LanId &lan) {
+    std::vector<const I::Lsp *> got;
+    const I::Lsp *z = db.fragments_from(c, lan, got);
+    return got == db.iter_for_lan_id(lan) && z == db.zeroth_lsp(lan);
+  };
+  std::vector<I::LanId> asc = lans;
+  std::sort(asc.begin(), asc.end());
+  { I::Lsdb::Cursor c; for (auto &lan : asc) if (!same(c, lan)) return false; }                          // ascending, duplicates included
+  { I::Lsdb::Cursor c; for (size_t i = 0; i < asc.size(); i += 1 + rnd() % 9) if (!same(c, asc[i])) return false; }   // skipping ahead
+  { I::Lsdb::Cursor c; for (size_t i = asc.size(); i-- > 0;) if (!same(c, asc[i])) return false; }       // descending
+  { I::Lsdb::Cursor c; for (int i = 0; i < 3000; ++i) if (!same(c, lans[rnd() % lans.size()])) return false; }   // any order
+  return true;
+}
 static int check_manet(const J &vec, const I::Instance &inst, Engine &eng, const std::string &path) {
   int bad = 0;
   std::map<std::pair<int, std::string>, std::map<I::SystemId, I::flooding::NeighborCache>> caches;
@@ -687,6 +721,7 @@ int main(int argc, char **argv) {
   size_t wire_records = 0, wire_prefixes = 0, cold_records = 0;
   int cold_ok = 0, cold_bad = 0, cold_dev = 0;
   if (!check_hash_kat()) { std::fprintf(stderr, "flood_reduction_hash: reference vectors not reproduced\n"); return 1; }
+  if (!check_lsdb_cursor()) { std::fprintf(stderr, "Lsdb::fragments_from differs from iter_for_lan_id / zeroth_lsp\n"); return 1; }
   for (auto &path : files) {
     try {
       const J vec = load_json(path);
