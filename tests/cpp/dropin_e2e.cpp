@@ -456,6 +456,21 @@ int main(int argc, char **argv) {
           }
         }
       }
+      // the same for HOP-COUNT SPTs (flooding::manet::init_cache: mt_id none, every link cost 1 / 0; the rank of a pseudonode is
+      // looked up through a per-root cache) — small LSDBs only: the graph is walked out of the LSDB on the host.  With the CPU stand-in
+      // only: it checks the twin's threaded rebuild (written in a session without a GPU; the engine's hop-count runs have their own
+      // GPU tests: test_cpp_flooding_manet_reflood_lists_on_gpu, tests/test_gpu_golden.py)
+      if (n <= 20000 && !hip) {
+        auto hc = I::compute_spts(2, rs, false, std::nullopt, true, inst, te);
+        for (size_t i = 0; i < rs.size() && batch_same; ++i) {
+          I::Spt one = I::compute_spt(2, rs[i], false, std::nullopt, true, inst, te);
+          batch_same = one.vertices.size() == hc[i].vertices.size() && one.pop_order == hc[i].pop_order;
+          auto a = one.vertices.begin();
+          auto b = hc[i].vertices.begin();
+          for (; batch_same && a != one.vertices.end(); ++a, ++b)
+            batch_same = a->first == b->first && a->second.distance == b->second.distance && a->second.hops == b->second.hops && a->second.nexthops.size() == b->second.nexthops.size();
+        }
+      }
     }
 
     const double run = median(run_v), rebuild = median(rebuild_v), routes = median(routes_v), total = median(total_v);
